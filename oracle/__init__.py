@@ -1,0 +1,2 @@
+"""CPU oracle = test infrastructure.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this package; the product path (ivln-ce_amd/) never does."""
