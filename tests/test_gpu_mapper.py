@@ -1,0 +1,125 @@
+"""GPU parity of the HIP mapper (through the C ABI / obs-transform boundary) against
+(a) the goldens produced by the reference's own MappingModule and (b) the C oracle on
+full-size 256x256 synthetic rollouts.  Bit-exact: maps, world cloud contents and order."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CASES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "mapper_*.npz")))
+
+
+def _mk(H, W, b_max=8):
+    from ivln_ce_amd.mapping import CameraParameters, MapDimensions, create_gt_semantics_iterative_mapper
+
+    cam = CameraParameters(float(np.deg2rad(90.0 * H / W)), (H, W), 0.1)
+    dims = MapDimensions(6.4, 6.4, 0.1)
+    return create_gt_semantics_iterative_mapper(torch.device("cuda:0"), cam, dims, b_max=b_max)
+
+
+def _obs(g, t, dev):
+    return {
+        "depth": torch.from_numpy(g[f"depth_{t}"]).to(dev),
+        "semantic12": torch.from_numpy(g[f"semantic12_{t}"]).to(dev),
+        "world_robot_pose": torch.from_numpy(g[f"pose_{t}"]).to(dev),
+        "world_robot_orientation": torch.from_numpy(g[f"orientation_{t}"]).to(dev),
+        "not_done_masks": torch.from_numpy(g[f"not_done_{t}"]).to(dev),
+        "env_name": ["s"] * int(g["B"]),
+    }
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[7:-4] for p in CASES])
+@pytest.mark.parametrize("device_frames", [False, True])
+def test_hip_mapper_matches_reference_golden(path, device_frames):
+    g = np.load(path)
+    dev = torch.device("cuda:0")
+    H, W, steps = int(g["H"]), int(g["W"]), int(g["steps"])
+    m = _mk(H, W)
+    for t in range(steps):
+        kw = {}
+        if not device_frames:
+            kw = dict(T=torch.from_numpy(g[f"T_{t}"]).to(dev), rot=torch.from_numpy(g[f"rot_{t}"]).to(dev))
+        mem = m(_obs(g, t, dev), **kw)
+        n = m.check_status()
+        assert n == int(g[f"world_n_{t}"]), f"world size step {t}"
+        assert np.array_equal(mem.occupancy.cpu().numpy(), g[f"occ_{t}"]), f"occupancy step {t}"
+        assert np.array_equal(mem.semantic.cpu().numpy(), g[f"sem_{t}"]), f"semantic step {t}"
+        if f"world_xyz_{t}" in g:
+            xyz, b, s = m.world_cloud()
+            assert np.array_equal(xyz.view(np.uint32), g[f"world_xyz_{t}"].view(np.uint32))
+            assert np.array_equal(b, g[f"world_b_{t}"])
+            assert np.array_equal(s, g[f"world_sem_{t}"])
+
+
+def test_device_frames_match_reference():
+    from ivln_ce_amd.mapping import MapDimensions, MappingModule
+
+    g = np.load(CASES[0])
+    dev = torch.device("cuda:0")
+    m = MappingModule(dev, None, MapDimensions(6.4, 6.4, 0.1))
+    for t in range(int(g["steps"])):
+        T, rot, _ = m.frames(torch.from_numpy(g[f"pose_{t}"]), torch.from_numpy(g[f"orientation_{t}"]))
+        assert np.array_equal(T.cpu().numpy().view(np.uint32), g[f"T_{t}"].view(np.uint32))
+        assert np.array_equal(rot.cpu().numpy().view(np.uint32), g[f"rot_{t}"].view(np.uint32))
+
+
+@pytest.mark.parametrize("B,steps,reset_every", [(4, 12, 0), (8, 8, 3)])
+def test_hip_mapper_matches_oracle_fullsize(B, steps, reset_every):
+    """BASELINE configs[1]/[2] sizes: 256x256 depth, B = 4 / 8 envs, random-walk poses."""
+    from ivln_ce_amd.synthetic import SyntheticRollout
+    from oracle.mapper_ref import MapperRef
+
+    dev = torch.device("cuda:0")
+    roll = SyntheticRollout(B=B, seed=77 + B, reset_every=reset_every)
+    m = _mk(256, 256, b_max=B)
+    ref = MapperRef(256, 256)
+    for t in range(steps):
+        obs = roll.step()
+        T, rot = MapperRef.frames(obs["world_robot_pose"].numpy(), obs["world_robot_orientation"].numpy())
+        occ_r, sem_r = ref.step(
+            obs["depth"].numpy(), obs["semantic12"].numpy(), obs["world_robot_pose"].numpy(),
+            obs["world_robot_orientation"].numpy(), obs["not_done_masks"].numpy(), T=T, rot=rot,
+        )
+        dobs = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in obs.items()}
+        mem = m(dobs, T=torch.from_numpy(T).to(dev), rot=torch.from_numpy(rot).to(dev))
+        n = m.check_status()
+        xr, br, sr = ref.world()
+        assert n == xr.shape[0], f"world size step {t}: {n} vs {xr.shape[0]}"
+        assert np.array_equal(mem.occupancy.cpu().numpy(), occ_r), f"occupancy step {t}"
+        assert np.array_equal(mem.semantic.cpu().numpy(), sem_r), f"semantic step {t}"
+        if t == steps - 1:
+            xyz, b, s = m.world_cloud()
+            assert np.array_equal(xyz.view(np.uint32), xr.view(np.uint32))
+            assert np.array_equal(b, br) and np.array_equal(s, sr)
+
+
+def test_obs_transform_boundary_deletes_keys_and_aliases_buffers():
+    from ivln_ce_amd.config import get_config
+    from ivln_ce_amd.obs_transforms import GTSemanticsIterativeMapper
+    from ivln_ce_amd.synthetic import SyntheticRollout
+
+    cfg = get_config()
+    tr = GTSemanticsIterativeMapper.from_config(cfg)
+    dev = torch.device("cuda:0")
+    roll = SyntheticRollout(B=2, seed=5)
+    out = None
+    for _ in range(2):
+        obs = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in roll.step().items()}
+        out = tr(obs)
+    for k in ["world_robot_orientation", "world_robot_pose", "semantic12", "env_name"]:
+        assert k not in out
+    assert out["occupancy_map"].shape == (2, 64, 64) and out["occupancy_map"].dtype == torch.uint8
+    assert out["semantic_map"].data_ptr() == tr.mapping_module.map_memory._sem.data_ptr()
+    assert int(out["occupancy_map"].sum()) > 0
+
+
+def test_mapper_raises_without_gpu_tensor():
+    from ivln_ce_amd._lib import IvlnError
+    from ivln_ce_amd.mapping import MapDimensions, MappingModule
+
+    with pytest.raises(IvlnError):
+        MappingModule(torch.device("cpu"), None, MapDimensions(6.4, 6.4, 0.1))
