@@ -72,6 +72,119 @@ int ivln_mapper_status(ivln_mapper* m, int64_t* world_n, void* stream);
 int ivln_mapper_world_export(ivln_mapper* m, float* xyz, uint32_t* meta, int64_t* rank,
                              int64_t max_n, int64_t* n_out, void* stream);
 
+
+/* ------------------------------------------------------------------------------------------
+ * fp32 MFMA implicit GEMM:  D[m][n] = sum_k A[m][k] * B[k][n]  (csrc/gemm_conv.hip).
+ * One descriptor covers every GEMM-shaped op of the path.  Replaces the ATen/cuDNN kernels behind
+ * nn.Conv2d (models/encoders/map_encoder.py:13-20, rednet.py:20-65, habitat-lab ResNetEncoder via
+ * models/encoders/resnet_encoders.py:31-43), nn.ConvTranspose2d (rednet.py:117-150,330-340),
+ * nn.Conv1d k=1 and nn.Linear (models/map_cma_policy.py:156-231) and their autograd backward.
+ * ------------------------------------------------------------------------------------------ */
+enum { IVLN_A_MK = 0,      /* A[m*lda + k]  (OIHW weights, Linear.weight)            */
+       IVLN_A_KM = 1,      /* A[k*lda + m]                                            */
+       IVLN_A_NCHW_P = 2   /* A[m = channel][k = pixel] of an NCHW tensor (wgrad dy)  */ };
+enum { IVLN_B_CONV = 0,    /* im2col gather from NCHW via koff/kpos tables            */
+       IVLN_B_CONV1X1 = 1, /* 1x1 conv, pad 0                                         */
+       IVLN_B_KN = 2,      /* B[k*ldb + n]                                            */
+       IVLN_B_NK = 3,      /* B[n*ldb + k]  (activations [rows][features])            */
+       IVLN_B_IM2COL_T = 4,/* B[k = out pixel][n = (ci,kh,kw)] (conv weight gradient) */
+       IVLN_B_CONVT = 5    /* transposed-conv gather (koff = ci*Hin*Win)              */ };
+enum { IVLN_D_NCHW = 0,    /* D[(img*Ctot + m)*HoWo + pp], n = img*HoWo + pp          */
+       IVLN_D_DENSE = 1    /* D[m*sDm + n*sDn]                                        */ };
+
+typedef struct ivln_gemm_desc {
+    const float* A;
+    const float* B;
+    float* D;
+    int M, N, K;
+    int amode, bmode, dmode;
+    int64_t lda, ldb;
+    /* conv geometry (B_CONV / B_CONV1X1 / B_CONVT / B_IM2COL_T, A_NCHW_P, D_NCHW) */
+    int Cin, Hin, Win, Hout, Wout, stride, pad, dil;
+    const int32_t* koff; /* [K or N]: ci*Hin*Win + kh*dil*Win + kw*dil (B_CONVT: ci*Hin*Win) */
+    const int32_t* kpos; /* [K or N]: kh << 16 | kw                                         */
+    int HoWo;            /* Hout*Wout (1 for plain GEMMs)                                   */
+    int Ctot;            /* channels of the NCHW destination (0 -> M); D may point at a slice */
+    int64_t in_img_stride; /* floats between images of the NCHW input (0 -> Cin*Hin*Win)        */
+    int64_t sDm, sDn;
+    /* fused epilogue: v = acc*scale[m] + shift[m] (or + shift[m]); + residual[addr]; + D[addr]
+     * when accumulate; ReLU.  residual is addressed like D. */
+    const float* scale;
+    const float* shift;
+    const float* residual;
+    int relu, accumulate;
+    /* split-K: splits = 0 -> heuristic (needs ws), >= 1 forced.  ws holds splits*M*N floats. */
+    int splits;
+    float* ws;
+    int64_t ws_floats;
+} ivln_gemm_desc;
+
+int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Non-GEMM forward kernels (csrc/nn_ops.hip).  All tensors fp32 NCHW unless noted.
+ * ------------------------------------------------------------------------------------------ */
+/* nn.GroupNorm (+ residual add) (+ ReLU): habitat-lab ddppo resnet Bottleneck / ResNetEncoder
+ * compression (reference call site models/encoders/resnet_encoders.py:31-43,95).  *_img_stride = 0
+ * -> C*HW.  save_mean/save_rstd (N*groups) optional. */
+int ivln_groupnorm_f32(const float* x, const float* gamma, const float* beta, const float* residual,
+                       float* y, int N, int C, int HW, int groups, float eps, int relu,
+                       int64_t x_img_stride, int64_t y_img_stride, int64_t r_img_stride,
+                       float* save_mean, float* save_rstd, void* stream);
+/* nn.BatchNorm2d eval folding / train-mode batch statistics (models/encoders/map_encoder.py:13-20;
+ * quirk Q6: train mode also during rollouts).  Both produce per-channel scale/shift. */
+int ivln_bn_fold_f32(const float* gamma, const float* beta, const float* running_mean,
+                     const float* running_var, float eps, int C, float* scale, float* shift, void* stream);
+int ivln_bn_train_stats_f32(const float* x, int N, int C, int HW, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, float momentum, float eps,
+                            float* scale, float* shift, float* save_mean, float* save_rstd, void* stream);
+/* CBRA tail: relu(x*scale+shift) then AvgPool2d(2) (map_encoder.py:16-19). */
+int ivln_scale_shift_relu_avgpool2_f32(const float* x, const float* scale, const float* shift, float* y,
+                                       int N, int C, int H, int W, void* stream);
+/* F.avg_pool2d / nn.MaxPool2d over (NC,H,W); mode 0 = max, 1 = avg. */
+int ivln_pool2d_f32(const float* x, float* y, int NC, int H, int W, int k, int s, int p, int mode,
+                    void* stream);
+/* SemanticMapEncoder.generate_map_features (map_encoder.py:85-90): u8 maps -> f32 (B,1+classes,cells) */
+int ivln_map_features_f32(const uint8_t* occ, const uint8_t* sem, float* y, int B, int cells, int classes,
+                          void* stream);
+/* InstructionEncoder front end (instruction_encoder.py:70-82): tokens i64 (B,L) -> emb (B*L,E),
+ * lengths i32 (B). */
+int ivln_embed_lengths(const int64_t* tokens, const float* table, int B, int L, int E, int V, float* emb,
+                       int* lengths, void* stream);
+/* nn.LSTM(bidirectional) over packed sequences (instruction_encoder.py:84-94): gx_* = W_ih x + b_ih
+ * for all (b,t) as (B*L, 4H); out (B, 2H, L), zero for t >= lengths[b].  H must be 128. */
+int ivln_lstm_bidir_fwd_f32(const float* gx_f, const float* gx_r, const float* whh_f, const float* whh_r,
+                            const float* bhh_f, const float* bhh_r, const int* lengths, int B, int L, int H,
+                            float* out, float* save_gates, float* save_c, void* stream);
+/* nn.Linear for few rows (rollout batch): y[r][o] = act(W[o].x[r] + b[o]). */
+int ivln_linear_skinny_f32(const float* x, int64_t ldx, const float* W, const float* bias, float* y,
+                           int64_t ldy, int rows, int K, int O, int relu, void* stream);
+/* One masked GRU step (habitat-lab RNNStateEncoder over nn.GRU; map_cma_policy.py:314-318,346-353).
+ * x (rows,I) or gi_pre (rows,3H) = W_ih x + b_ih precomputed; h_in rows with stride ldh; mask u8. */
+int ivln_gru_step_f32(const float* x, int64_t ldx, int I, const float* gi_pre, int64_t ldgi,
+                      const float* h_in, int64_t ldh, const uint8_t* mask, const float* w_ih,
+                      const float* w_hh, const float* b_ih, const float* b_hh, float* h_out, int64_t ldo,
+                      float* h_out2, int64_t ldo2, int rows, int H, float* save_r, float* save_z,
+                      float* save_n, float* save_ghn, void* stream);
+/* MapCMANet._attn (map_cma_policy.py:266-274); k (rows,Ck,I), v (rows,Cv,I) channel-major. */
+int ivln_attn_fwd_f32(const float* q, int64_t ldq, const float* k, int64_t k_img_stride, const float* v,
+                      int64_t v_img_stride, const int* valid_len, float scale, int rows, int Ck, int Cv,
+                      int I, float* out, int64_t ldo, float* save_attn, void* stream);
+/* prev_action_embedding(((a+1)*mask).long()) (map_cma_policy.py:297-299), written to two slices. */
+int ivln_prev_action_embed_f32(const int64_t* prev_actions, const uint8_t* mask, const float* table,
+                               int rows, int E, int n_emb, float* out1, int64_t ld1, float* out2,
+                               int64_t ld2, void* stream);
+/* distribution.mode() (common/utils.py:168-169) and predicted_scores.argmax(1) (mapper.py:796-798). */
+int ivln_argmax_rows(const float* x, int rows, int C, int64_t* out, void* stream);
+int ivln_argmax_channels_u8(const float* x, int N, int C, int HW, uint8_t* out, void* stream);
+/* PredictSemantics input prep (mapper.py:715-736,788-793). */
+int ivln_rgb_resize_normalize_f32(const uint8_t* rgb, int B, int Hi, int Wi, int Ho, int Wo, float* out,
+                                  void* stream);
+int ivln_affine_f32(const float* x, float* y, int64_t n, float sub, float div, void* stream);
+int ivln_add_f32(const float* a, const float* b, float* y, int64_t n, int relu, void* stream);
+int ivln_copy2d_f32(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int rows, int cols,
+                    int broadcast_rows, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,6 +12,8 @@ OUT = os.path.join(HERE, "libivln_hip.so")
 # per-file extra flags; the mapper must round every op exactly where written
 SOURCES = {
     "mapper.hip": ["-ffp-contract=off"],
+    "gemm_conv.hip": [],
+    "nn_ops.hip": [],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

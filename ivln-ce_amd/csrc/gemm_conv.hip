@@ -1,0 +1,333 @@
+// fp32 MFMA implicit-GEMM for gfx950: every GEMM-shaped op of the MapCMA hot path runs through
+// this one kernel family - conv2d forward (7x7/3x3/1x1, any stride/pad), transposed conv (RedNet
+// decoder), conv weight-gradient, linear forward / input-gradient / weight-gradient and Conv1d k=1.
+//
+//   D[m][n] = sum_k A[m][k] * B[k][n]        m = output channel, n = output pixel (or row)
+//
+// * v_mfma_f32_32x32x2_f32 (exact fp32, bit-equal to an fmaf chain over k; 157 TFLOP/s peak): the
+//   reference runs fp32 and parity is stated against fp32, so no reduced-precision path.
+// * NCHW activations and OIHW weights are consumed in place: K is ordered (ci,kh,kw) exactly like the
+//   OIHW flattening, and the im2col operand is gathered straight from NCHW through two small
+//   per-layer tables (koff = ci*Hin*Win + kh*Win + kw, kpos = kh<<16|kw) - no layout conversion pass.
+// * Block = 256 threads = 4 waves, one 32x32 accumulator tile per wave; wave grid WMxWN in
+//   {2x2, 1x4, 4x1} -> block tile 64x64 / 32x128 / 128x32 picked per shape; BK = 16 staged through LDS
+//   (k-major, +1 padded rows -> conflict-free ds_read_b32 operand fetches, <=2-way on stores) with
+//   register prefetch of the next K tile while the MFMAs of the current one run.
+// * split-K over blockIdx.z for the K-heavy / pixel-starved tail layers (4x4 spatial, K up to 9216):
+//   partial slabs are reduced in a fixed order (deterministic) by k_splitk_epilogue.
+// * Epilogue fused: per-channel scale/shift (folded BatchNorm or bias), residual add, ReLU.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ivln_hip.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { AMODE_MK = 0, AMODE_KM = 1, AMODE_NCHW_P = 2 };
+enum { BMODE_CONV = 0, BMODE_CONV1X1 = 1, BMODE_KN = 2, BMODE_NK = 3, BMODE_IM2COL_T = 4, BMODE_CONVT = 5 };
+enum { DMODE_NCHW = 0, DMODE_DENSE = 1 };
+
+constexpr int BK = 16;
+
+__device__ __forceinline__ void epilogue_store(const ivln_gemm_desc& p, int m, int n, float v) {
+    int64_t addr;
+    if (p.dmode == DMODE_NCHW) {
+        int img = n / p.HoWo;
+        int pp = n - img * p.HoWo;
+        addr = ((int64_t)img * p.Ctot + m) * p.HoWo + pp;
+    } else {
+        addr = (int64_t)m * p.sDm + (int64_t)n * p.sDn;
+    }
+    if (p.scale) v = fmaf(v, p.scale[m], p.shift[m]);
+    else if (p.shift) v += p.shift[m];
+    if (p.residual) v += p.residual[addr];
+    if (p.accumulate) v += p.D[addr];
+    if (p.relu) v = fmaxf(v, 0.f);
+    p.D[addr] = v;
+}
+
+template <int WM, int WN, int AMODE, int BMODE>
+__global__ __launch_bounds__(256) void k_gemm(const ivln_gemm_desc p) {
+    constexpr int BM = 32 * WM, BN = 32 * WN;
+    constexpr int LDA_S = BM + 1, LDB_S = BN + 1;
+    constexpr int EA = BM * BK / 256, EB = BN * BK / 256;
+    __shared__ float smem[BK * LDA_S + BK * LDB_S];
+    float* As = smem;
+    float* Bs = smem + BK * LDA_S;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+    // K range of this split
+    const int nk = (p.K + BK - 1) / BK;
+    const int tps = (nk + p.splits - 1) / p.splits;
+    const int kbeg = blockIdx.z * tps * BK;
+    const int kend = min(p.K, kbeg + tps * BK);
+
+    // ---- per-thread load coordinates ----
+    constexpr bool A_KFAST = (AMODE != AMODE_KM);
+    constexpr bool B_KFAST = (BMODE == BMODE_NK || BMODE == BMODE_IM2COL_T);
+    const int a_k = A_KFAST ? (t & 15) : (t / BM);
+    const int a_m = A_KFAST ? (t >> 4) : (t % BM);
+    const int b_k = B_KFAST ? (t & 15) : (t / BN);
+    const int b_n = B_KFAST ? (t >> 4) : (t % BN);
+    constexpr int A_STEP = A_KFAST ? 16 : 256 / BM;  // step of m (k-fast) or of k (m-fast) per element
+    constexpr int B_STEP = B_KFAST ? 16 : 256 / BN;
+
+    // conv-style B operand: this thread's output pixel is fixed (n-fast modes)
+    int64_t pix_base = 0;
+    int hi0 = 0, wi0 = 0;
+    bool n_ok = false;
+    if constexpr (BMODE == BMODE_CONV || BMODE == BMODE_CONV1X1 || BMODE == BMODE_CONVT) {
+        int n = n0 + b_n;
+        n_ok = n < p.N;
+        int nn = n_ok ? n : 0;
+        int img = nn / p.HoWo;
+        int pp = nn - img * p.HoWo;
+        int ho = pp / p.Wout, wo = pp - ho * p.Wout;
+        pix_base = (int64_t)img * p.in_img_stride;
+        if constexpr (BMODE == BMODE_CONVT) {
+            hi0 = ho + p.pad;
+            wi0 = wo + p.pad;
+        } else {
+            hi0 = ho * p.stride - p.pad;
+            wi0 = wo * p.stride - p.pad;
+        }
+    }
+    // wgrad B operand: this thread's (ci,kh,kw) columns are fixed
+    int w_koff[EB], w_kpos[EB];
+    if constexpr (BMODE == BMODE_IM2COL_T) {
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            int n = n0 + b_n + e * B_STEP;
+            bool ok = n < p.N;
+            w_koff[e] = ok ? p.koff[n] : 0;
+            w_kpos[e] = ok ? p.kpos[n] : -1;
+        }
+    }
+
+    float ra[EA], rb[EB];
+
+    auto load_tile = [&](int k0) {
+        // ---------------- A ----------------
+        if constexpr (AMODE == AMODE_MK) {
+            int k = k0 + a_k;
+#pragma unroll
+            for (int e = 0; e < EA; ++e) {
+                int m = m0 + a_m + e * A_STEP;
+                ra[e] = (m < p.M && k < kend) ? p.A[(int64_t)m * p.lda + k] : 0.f;
+            }
+        } else if constexpr (AMODE == AMODE_KM) {
+            int m = m0 + a_m;
+#pragma unroll
+            for (int e = 0; e < EA; ++e) {
+                int k = k0 + a_k + e * A_STEP;
+                ra[e] = (m < p.M && k < kend) ? p.A[(int64_t)k * p.lda + m] : 0.f;
+            }
+        } else {  // AMODE_NCHW_P: A[m = channel][k = pixel] of an NCHW gradient tensor
+            int k = k0 + a_k;
+            bool ok = k < kend;
+            int kk = ok ? k : 0;
+            int img = kk / p.HoWo;
+            int pp = kk - img * p.HoWo;
+#pragma unroll
+            for (int e = 0; e < EA; ++e) {
+                int m = m0 + a_m + e * A_STEP;
+                ra[e] = (ok && m < p.M) ? p.A[((int64_t)img * p.M + m) * p.HoWo + pp] : 0.f;
+            }
+        }
+        // ---------------- B ----------------
+        if constexpr (BMODE == BMODE_CONV) {
+#pragma unroll
+            for (int e = 0; e < EB; ++e) {
+                int k = k0 + b_k + e * B_STEP;
+                float v = 0.f;
+                if (n_ok && k < kend) {
+                    int kp = p.kpos[k];
+                    int hi = hi0 + (kp >> 16) * p.dil, wi = wi0 + (kp & 0xFFFF) * p.dil;
+                    if ((unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win)
+                        v = p.B[pix_base + p.koff[k] + (int64_t)hi0 * p.Win + wi0];
+                }
+                rb[e] = v;
+            }
+        } else if constexpr (BMODE == BMODE_CONV1X1) {
+#pragma unroll
+            for (int e = 0; e < EB; ++e) {
+                int k = k0 + b_k + e * B_STEP;
+                rb[e] = (n_ok && k < kend)
+                            ? p.B[pix_base + (int64_t)k * p.Hin * p.Win + (int64_t)hi0 * p.Win + wi0]
+                            : 0.f;
+            }
+        } else if constexpr (BMODE == BMODE_CONVT) {
+            // y[oh] += x[(oh + pad - kh)/stride] * w[kh] when divisible (nn.ConvTranspose2d)
+#pragma unroll
+            for (int e = 0; e < EB; ++e) {
+                int k = k0 + b_k + e * B_STEP;
+                float v = 0.f;
+                if (n_ok && k < kend) {
+                    int kp = p.kpos[k];
+                    int th = hi0 - (kp >> 16), tw = wi0 - (kp & 0xFFFF);
+                    if (th >= 0 && tw >= 0 && (th % p.stride) == 0 && (tw % p.stride) == 0) {
+                        int hi = th / p.stride, wi = tw / p.stride;
+                        if (hi < p.Hin && wi < p.Win)
+                            v = p.B[pix_base + p.koff[k] + (int64_t)hi * p.Win + wi];
+                    }
+                }
+                rb[e] = v;
+            }
+        } else if constexpr (BMODE == BMODE_KN) {
+            int n = n0 + b_n;
+#pragma unroll
+            for (int e = 0; e < EB; ++e) {
+                int k = k0 + b_k + e * B_STEP;
+                rb[e] = (n < p.N && k < kend) ? p.B[(int64_t)k * p.ldb + n] : 0.f;
+            }
+        } else if constexpr (BMODE == BMODE_NK) {
+            int k = k0 + b_k;
+#pragma unroll
+            for (int e = 0; e < EB; ++e) {
+                int n = n0 + b_n + e * B_STEP;
+                rb[e] = (n < p.N && k < kend) ? p.B[(int64_t)n * p.ldb + k] : 0.f;
+            }
+        } else {  // BMODE_IM2COL_T: B[k = output pixel][n = (ci,kh,kw)] gathered from the NCHW input
+            int k = k0 + b_k;
+            bool ok = k < kend;
+            int kk = ok ? k : 0;
+            int img = kk / p.HoWo;
+            int pp = kk - img * p.HoWo;
+            int ho = pp / p.Wout, wo = pp - ho * p.Wout;
+            int h0 = ho * p.stride - p.pad, w0 = wo * p.stride - p.pad;
+            int64_t base = (int64_t)img * p.in_img_stride + (int64_t)h0 * p.Win + w0;
+#pragma unroll
+            for (int e = 0; e < EB; ++e) {
+                float v = 0.f;
+                if (ok && w_kpos[e] >= 0) {
+                    int hi = h0 + (w_kpos[e] >> 16), wi = w0 + (w_kpos[e] & 0xFFFF);
+                    if ((unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win) v = p.B[base + w_koff[e]];
+                }
+                rb[e] = v;
+            }
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    if (kbeg < kend) {
+        load_tile(kbeg);
+        for (int k0 = kbeg; k0 < kend; k0 += BK) {
+#pragma unroll
+            for (int e = 0; e < EA; ++e) {
+                if constexpr (A_KFAST) As[a_k * LDA_S + a_m + e * A_STEP] = ra[e];
+                else As[(a_k + e * A_STEP) * LDA_S + a_m] = ra[e];
+            }
+#pragma unroll
+            for (int e = 0; e < EB; ++e) {
+                if constexpr (B_KFAST) Bs[b_k * LDB_S + b_n + e * B_STEP] = rb[e];
+                else Bs[(b_k + e * B_STEP) * LDB_S + b_n] = rb[e];
+            }
+            __syncthreads();
+            if (k0 + BK < kend) load_tile(k0 + BK);
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; ++kk) {
+                float a = As[(2 * kk + (lane >> 5)) * LDA_S + wm * 32 + (lane & 31)];
+                float b = Bs[(2 * kk + (lane >> 5)) * LDB_S + wn * 32 + (lane & 31)];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: acc[r] -> row (r&3) + 8*(r>>2) + 4*(lane>>5), col lane&31 ----
+    const int n = n0 + wn * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < p.M && n < p.N) {
+            if (p.splits > 1) p.ws[((int64_t)blockIdx.z * p.M + m) * p.N + n] = acc[r];
+            else epilogue_store(p, m, n, acc[r]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_splitk_epilogue(const ivln_gemm_desc p) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)p.M * p.N) return;
+    int m = (int)(idx / p.N), n = (int)(idx - (int64_t)m * p.N);
+    float v = 0.f;
+    for (int z = 0; z < p.splits; ++z) v += p.ws[((int64_t)z * p.M + m) * p.N + n];
+    epilogue_store(p, m, n, v);
+}
+
+template <int WM, int WN>
+int launch_tile(const ivln_gemm_desc& d, hipStream_t s) {
+    constexpr int BM = 32 * WM, BN = 32 * WN;
+    dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM, d.splits);
+    dim3 block(256);
+#define IVLN_CASE(AM, BMD)                                                              \
+    if (d.amode == AM && d.bmode == BMD) {                                              \
+        hipLaunchKernelGGL((k_gemm<WM, WN, AM, BMD>), grid, block, 0, s, d);            \
+        return IVLN_OK;                                                                 \
+    }
+    IVLN_CASE(AMODE_MK, BMODE_CONV)
+    IVLN_CASE(AMODE_MK, BMODE_CONV1X1)
+    IVLN_CASE(AMODE_MK, BMODE_CONVT)
+    IVLN_CASE(AMODE_MK, BMODE_NK)
+    IVLN_CASE(AMODE_MK, BMODE_KN)
+    IVLN_CASE(AMODE_KM, BMODE_NK)
+    IVLN_CASE(AMODE_KM, BMODE_KN)
+    IVLN_CASE(AMODE_NCHW_P, BMODE_IM2COL_T)
+#undef IVLN_CASE
+    return IVLN_E_UNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream) {
+    if (!desc || !desc->A || !desc->B || !desc->D || desc->M <= 0 || desc->N <= 0 || desc->K <= 0)
+        return IVLN_E_INVALID;
+    ivln_gemm_desc d = *desc;
+    hipStream_t s = (hipStream_t)stream;
+    if (d.HoWo <= 0) d.HoWo = 1;
+    if (d.dil <= 0) d.dil = 1;
+    if (d.Ctot <= 0) d.Ctot = d.M;
+    if (d.in_img_stride <= 0) d.in_img_stride = (int64_t)d.Cin * d.Hin * d.Win;
+    // tile shape: channel-starved -> 32x128, pixel-starved -> 128x32, else 64x64
+    int tile = 0;
+    if (d.M <= 32) tile = 1;
+    else if (d.N <= 32) tile = 2;
+    const int BM = tile == 1 ? 32 : (tile == 2 ? 128 : 64);
+    const int BN = tile == 1 ? 128 : (tile == 2 ? 32 : 64);
+    // split-K when the output grid cannot fill the chip and K is deep
+    int64_t blocks = (int64_t)((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
+    int nk = (d.K + BK - 1) / BK;
+    int splits = 1;
+    if (d.splits == 0) {
+        if (d.ws && blocks < 128 && nk >= 8) {
+            splits = (int)((256 + blocks - 1) / blocks);
+            if (splits > nk / 4) splits = nk / 4;
+            if (splits > 64) splits = 64;
+            int64_t cap = d.ws_floats / ((int64_t)d.M * d.N);
+            if (splits > cap) splits = (int)cap;
+            if (splits < 1) splits = 1;
+        }
+    } else {
+        splits = d.splits;
+        if (splits > 1 && (!d.ws || d.ws_floats < (int64_t)splits * d.M * d.N)) return IVLN_E_INVALID;
+    }
+    // drop empty trailing splits
+    int tps = (nk + splits - 1) / splits;
+    splits = (nk + tps - 1) / tps;
+    d.splits = splits;
+    int rc = tile == 1 ? launch_tile<1, 4>(d, s) : (tile == 2 ? launch_tile<4, 1>(d, s) : launch_tile<2, 2>(d, s));
+    if (rc != IVLN_OK) return rc;
+    if (splits > 1) {
+        int64_t total = (int64_t)d.M * d.N;
+        hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d);
+    }
+    return hipGetLastError() == hipSuccess ? IVLN_OK : IVLN_E_HIP;
+}

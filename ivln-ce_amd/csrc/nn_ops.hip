@@ -1,0 +1,771 @@
+// Non-GEMM forward kernels of the MapCMA hot path for gfx950 (all fp32, NCHW):
+// GroupNorm(+residual,+ReLU), BatchNorm statistics / folding, pooling, one-hot map features,
+// embedding + lengths, bidirectional LSTM recurrence, masked GRU step, skinny (B<=8 rows)
+// linear, cross-modal attention, arg-max heads.  Each entry point cites the reference op it
+// replaces.  These are HBM/L2-bound or latency-bound element/reduction kernels: 64-wide wave
+// reductions via DPP shuffles, LDS for per-block staging, coalesced NCHW row accesses.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include "../../include/ivln_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+// block-wide sum for blockDim.x <= 1024 (red: >= 16 floats of LDS)
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int i = 0; i < nw; ++i) s += red[i];
+    return s;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float s = -INFINITY;
+    for (int i = 0; i < nw; ++i) s = fmaxf(s, red[i]);
+    return s;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// ------------------------------------------------------------------------------------------
+// GroupNorm: one block per (image, group); the group's cpg*HW values are contiguous in NCHW.
+// Two-pass mean / biased variance (values cached in LDS when they fit), then
+// y = (x-mean)*rstd*gamma[c] + beta[c] (+ residual) (ReLU).
+// ------------------------------------------------------------------------------------------
+constexpr int GN_CACHE = 8192;
+
+__global__ __launch_bounds__(256) void k_groupnorm(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta,
+                                                   const float* __restrict__ residual, float* __restrict__ y,
+                                                   int C, int HW, int groups, float eps, int relu,
+                                                   int64_t x_img_stride, int64_t y_img_stride,
+                                                   int64_t r_img_stride, float* __restrict__ save_mean,
+                                                   float* __restrict__ save_rstd) {
+    __shared__ float cache[GN_CACHE];
+    __shared__ float red[16];
+    const int img = blockIdx.x / groups, g = blockIdx.x % groups;
+    const int cpg = C / groups;
+    const int n = cpg * HW;
+    const float* xp = x + (int64_t)img * x_img_stride + (int64_t)g * n;
+    const bool cached = n <= GN_CACHE;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        float v = xp[i];
+        if (cached) cache[i] = v;
+        s += v;
+    }
+    const float mean = block_sum(s, red) / (float)n;
+    float q = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        float d = (cached ? cache[i] : xp[i]) - mean;
+        q += d * d;
+    }
+    const float var = block_sum(q, red) / (float)n;
+    const float rstd = rsqrtf(var + eps);
+    if (threadIdx.x == 0 && save_mean) {
+        save_mean[blockIdx.x] = mean;
+        save_rstd[blockIdx.x] = rstd;
+    }
+    float* yp = y + (int64_t)img * y_img_stride + (int64_t)g * n;
+    const float* rp = residual ? residual + (int64_t)img * r_img_stride + (int64_t)g * n : nullptr;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        int c = g * cpg + i / HW;
+        float v = ((cached ? cache[i] : xp[i]) - mean) * rstd * gamma[c] + beta[c];
+        if (rp) v += rp[i];
+        if (relu) v = fmaxf(v, 0.f);
+        yp[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// BatchNorm2d.  Eval: scale = g/sqrt(rv+eps), shift = b - rm*scale.  Train: batch statistics per
+// channel over (N,H,W) (two-pass), running stats updated with momentum / unbiased variance exactly
+// like torch.nn.BatchNorm2d, scale/shift from the batch statistics.
+// ------------------------------------------------------------------------------------------
+__global__ void k_bn_fold(const float* __restrict__ gamma, const float* __restrict__ beta,
+                          const float* __restrict__ rmean, const float* __restrict__ rvar, float eps, int C,
+                          float* __restrict__ scale, float* __restrict__ shift) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float sc = gamma[c] / sqrtf(rvar[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - rmean[c] * sc;
+}
+
+__global__ __launch_bounds__(256) void k_bn_train_stats(const float* __restrict__ x, int N, int C, int HW,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ rmean,
+                                                        float* __restrict__ rvar, float momentum, float eps,
+                                                        float* __restrict__ scale, float* __restrict__ shift,
+                                                        float* __restrict__ save_mean,
+                                                        float* __restrict__ save_rstd) {
+    __shared__ float red[16];
+    const int c = blockIdx.x;
+    const int64_t cnt = (int64_t)N * HW;
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < cnt; i += blockDim.x) {
+        int img = (int)(i / HW);
+        int pp = (int)(i - (int64_t)img * HW);
+        s += x[((int64_t)img * C + c) * HW + pp];
+    }
+    const float mean = block_sum(s, red) / (float)cnt;
+    float q = 0.f;
+    for (int64_t i = threadIdx.x; i < cnt; i += blockDim.x) {
+        int img = (int)(i / HW);
+        int pp = (int)(i - (int64_t)img * HW);
+        float d = x[((int64_t)img * C + c) * HW + pp] - mean;
+        q += d * d;
+    }
+    const float var = block_sum(q, red) / (float)cnt;
+    if (threadIdx.x == 0) {
+        float rstd = 1.f / sqrtf(var + eps);
+        float sc = gamma[c] * rstd;
+        scale[c] = sc;
+        shift[c] = beta[c] - mean * sc;
+        if (save_mean) {
+            save_mean[c] = mean;
+            save_rstd[c] = rstd;
+        }
+        if (rmean) {
+            float unbiased = cnt > 1 ? var * (float)cnt / (float)(cnt - 1) : var;
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * unbiased;
+        }
+    }
+}
+
+// y[n,c,ho,wo] = mean over the 2x2 window of relu(x*scale[c] + shift[c])   (CBRA tail:
+// BatchNorm2d -> ReLU -> AvgPool2d(2), models/encoders/map_encoder.py:13-20)
+__global__ __launch_bounds__(256) void k_scale_shift_relu_avgpool2(const float* __restrict__ x,
+                                                                   const float* __restrict__ scale,
+                                                                   const float* __restrict__ shift,
+                                                                   float* __restrict__ y, int NC, int C, int H,
+                                                                   int W) {
+    const int Ho = H / 2, Wo = W / 2;
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)NC * Ho * Wo) return;
+    int wo = (int)(idx % Wo);
+    int ho = (int)((idx / Wo) % Ho);
+    int nc = (int)(idx / ((int64_t)Wo * Ho));
+    int c = nc % C;
+    const float sc = scale[c], sh = shift[c];
+    const float* xp = x + ((int64_t)nc * H + 2 * ho) * W + 2 * wo;
+    float a = fmaxf(fmaf(xp[0], sc, sh), 0.f);
+    float b = fmaxf(fmaf(xp[1], sc, sh), 0.f);
+    float c2 = fmaxf(fmaf(xp[W], sc, sh), 0.f);
+    float d = fmaxf(fmaf(xp[W + 1], sc, sh), 0.f);
+    y[idx] = (((a + b) + c2) + d) * 0.25f;
+}
+
+// generic 2-D pooling over (NC,H,W): mode 0 = max (pad value -inf), 1 = avg (count_include_pad)
+__global__ __launch_bounds__(256) void k_pool2d(const float* __restrict__ x, float* __restrict__ y, int NC, int H,
+                                                int W, int Ho, int Wo, int k, int s, int p, int mode) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)NC * Ho * Wo) return;
+    int wo = (int)(idx % Wo);
+    int ho = (int)((idx / Wo) % Ho);
+    int nc = (int)(idx / ((int64_t)Wo * Ho));
+    const float* xp = x + (int64_t)nc * H * W;
+    float acc = mode == 0 ? -INFINITY : 0.f;
+    for (int i = 0; i < k; ++i) {
+        int h = ho * s - p + i;
+        if ((unsigned)h >= (unsigned)H) continue;
+        for (int j = 0; j < k; ++j) {
+            int w = wo * s - p + j;
+            if ((unsigned)w >= (unsigned)W) continue;
+            float v = xp[(int64_t)h * W + w];
+            acc = mode == 0 ? fmaxf(acc, v) : acc + v;
+        }
+    }
+    if (mode == 1) acc = acc / (float)(k * k);
+    y[idx] = acc;
+}
+
+// occupancy (1 ch) ++ one_hot(semantic, classes) -> f32 (B, 1+classes, cells)
+// (models/encoders/map_encoder.py:85-90)
+__global__ __launch_bounds__(256) void k_map_features(const uint8_t* __restrict__ occ,
+                                                      const uint8_t* __restrict__ sem, float* __restrict__ y,
+                                                      int B, int cells, int classes) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t total = (int64_t)B * (1 + classes) * cells;
+    if (idx >= total) return;
+    int p = (int)(idx % cells);
+    int c = (int)((idx / cells) % (1 + classes));
+    int b = (int)(idx / ((int64_t)cells * (1 + classes)));
+    float v;
+    if (c == 0) v = (float)occ[(int64_t)b * cells + p];
+    else v = sem[(int64_t)b * cells + p] == (uint8_t)(c - 1) ? 1.f : 0.f;
+    y[idx] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// Instruction encoder front end (models/encoders/instruction_encoder.py:70-82): embedding gather
+// and lengths = number of tokens whose embedding row has any non-zero entry.
+// out: emb (B*L, E) row-major; lengths (B) int32.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_embed_lengths(const int64_t* __restrict__ tokens,
+                                                       const float* __restrict__ table, int L, int E, int V,
+                                                       float* __restrict__ emb, int* __restrict__ lengths) {
+    __shared__ int cnt;
+    const int b = blockIdx.x;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    int local = 0;
+    for (int t = threadIdx.x; t < L; t += blockDim.x) {
+        int64_t tok = tokens[(int64_t)b * L + t];
+        if (tok < 0 || tok >= V) tok = 0;
+        const float* row = table + tok * E;
+        float* o = emb + ((int64_t)b * L + t) * E;
+        bool nz = false;
+        for (int e = 0; e < E; ++e) {
+            float v = row[e];
+            o[e] = v;
+            nz |= (v != 0.0f);
+        }
+        local += nz ? 1 : 0;
+    }
+    atomicAdd(&cnt, local);
+    __syncthreads();
+    if (threadIdx.x == 0) lengths[b] = cnt;
+}
+
+// ------------------------------------------------------------------------------------------
+// Bidirectional LSTM recurrence (nn.LSTM over a packed sequence, instruction_encoder.py:84-94).
+// grid (B, 2): one block per (sequence, direction); 4H = 512 threads, thread g owns gate row g of
+// W_hh (H=128 weights in registers); h and c live in LDS.  gx = W_ih x + b_ih precomputed by the
+// GEMM for all (b,t).  Gate order i,f,g,o.  out: (B, 2H, L) channel-major, zero for t >= len.
+// Optional saves for BPTT: gates (B,2,L,4H) post-activation, cs (B,2,L,H).
+// ------------------------------------------------------------------------------------------
+template <int H>
+__global__ __launch_bounds__(4 * H) void k_lstm_bidir(const float* __restrict__ gx_f,
+                                                      const float* __restrict__ gx_r,
+                                                      const float* __restrict__ whh_f,
+                                                      const float* __restrict__ whh_r,
+                                                      const float* __restrict__ bhh_f,
+                                                      const float* __restrict__ bhh_r,
+                                                      const int* __restrict__ lengths, int L,
+                                                      float* __restrict__ out, float* __restrict__ save_gates,
+                                                      float* __restrict__ save_c) {
+    constexpr int G = 4 * H;
+    __shared__ __attribute__((aligned(16))) float hs[H];
+    __shared__ float cs[H];
+    __shared__ float gs[G];
+    const int b = blockIdx.x, dir = blockIdx.y, g = threadIdx.x;
+    const float* gx = (dir == 0 ? gx_f : gx_r) + (int64_t)b * L * G;
+    const float* whh = (dir == 0 ? whh_f : whh_r) + (int64_t)g * H;
+    const float bias = (dir == 0 ? bhh_f : bhh_r)[g];
+    float w[H];
+#pragma unroll
+    for (int k = 0; k < H; ++k) w[k] = whh[k];
+    if (g < H) {
+        hs[g] = 0.f;
+        cs[g] = 0.f;
+    }
+    __syncthreads();
+    int len = lengths[b];
+    if (len > L) len = L;
+    for (int s = 0; s < len; ++s) {
+        const int t = dir == 0 ? s : len - 1 - s;
+        float acc = gx[(int64_t)t * G + g] + bias;
+#pragma unroll
+        for (int k = 0; k < H; k += 4) {
+            float4 hv = *reinterpret_cast<const float4*>(&hs[k]);
+            acc = fmaf(w[k], hv.x, acc);
+            acc = fmaf(w[k + 1], hv.y, acc);
+            acc = fmaf(w[k + 2], hv.z, acc);
+            acc = fmaf(w[k + 3], hv.w, acc);
+        }
+        const int gate = g / H;
+        float a = gate == 2 ? tanhf(acc) : sigmoidf_(acc);
+        gs[g] = a;
+        if (save_gates) save_gates[(((int64_t)b * 2 + dir) * L + t) * G + g] = a;
+        __syncthreads();
+        if (g < H) {
+            float c = gs[H + g] * cs[g] + gs[g] * gs[2 * H + g];
+            float h = gs[3 * H + g] * tanhf(c);
+            cs[g] = c;
+            hs[g] = h;
+            out[((int64_t)b * 2 * H + dir * H + g) * L + t] = h;
+            if (save_c) save_c[(((int64_t)b * 2 + dir) * L + t) * H + g] = c;
+        }
+        __syncthreads();
+    }
+    if (g < H)
+        for (int t = len; t < L; ++t) out[((int64_t)b * 2 * H + dir * H + g) * L + t] = 0.f;
+}
+
+// ------------------------------------------------------------------------------------------
+// Skinny linear: y[n][o] = act(W[o].x[n] + b[o]) for few rows n (rollout batch).  One wave per
+// output row, lanes stride K with float4 loads, rows processed 8 at a time.
+// (nn.Linear at models/map_cma_policy.py:156-171,218-224, common/utils.py:176-185)
+// ------------------------------------------------------------------------------------------
+constexpr int SK_ROWS = 8;
+
+__global__ __launch_bounds__(256) void k_linear_skinny(const float* __restrict__ x, int64_t ldx,
+                                                       const float* __restrict__ W, const float* __restrict__ bias,
+                                                       float* __restrict__ y, int64_t ldy, int rows, int K, int O,
+                                                       int relu) {
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (o >= O) return;
+    const float* wr = W + (int64_t)o * K;
+    for (int r0 = 0; r0 < rows; r0 += SK_ROWS) {
+        float acc[SK_ROWS];
+#pragma unroll
+        for (int r = 0; r < SK_ROWS; ++r) acc[r] = 0.f;
+        if ((K & 3) == 0) {
+            for (int k = lane * 4; k < K; k += 256) {
+                float4 wv = *reinterpret_cast<const float4*>(wr + k);
+#pragma unroll
+                for (int r = 0; r < SK_ROWS; ++r) {
+                    if (r0 + r < rows) {
+                        float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)(r0 + r) * ldx + k);
+                        acc[r] = fmaf(wv.x, xv.x, acc[r]);
+                        acc[r] = fmaf(wv.y, xv.y, acc[r]);
+                        acc[r] = fmaf(wv.z, xv.z, acc[r]);
+                        acc[r] = fmaf(wv.w, xv.w, acc[r]);
+                    }
+                }
+            }
+        } else {
+            for (int k = lane; k < K; k += 64) {
+                float wv = wr[k];
+#pragma unroll
+                for (int r = 0; r < SK_ROWS; ++r)
+                    if (r0 + r < rows) acc[r] = fmaf(wv, x[(int64_t)(r0 + r) * ldx + k], acc[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < SK_ROWS; ++r) {
+            float v = wave_sum(acc[r]);
+            if (lane == 0 && r0 + r < rows) {
+                if (bias) v += bias[o];
+                if (relu) v = fmaxf(v, 0.f);
+                y[(int64_t)(r0 + r) * ldy + o] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Masked GRU step (habitat-lab RNNStateEncoder single_forward / one step of seq_forward wrapping
+// nn.GRU; call sites models/map_cma_policy.py:314-318,346-353).  One wave per hidden unit j:
+//   gi = W_ih[{r,z,n}][j].x + b_ih  (or precomputed gi when x == nullptr)
+//   gh = W_hh[{r,z,n}][j].(h*mask) + b_hh
+//   r = s(gi_r+gh_r)  z = s(gi_z+gh_z)  n = tanh(gi_n + r*gh_n)  h' = (1-z)*n + z*h
+// rows processed 8 at a time.  Optional saves for BPTT: (rows, H) each of r, z, n, gh_n.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gru_step(const float* __restrict__ x, int64_t ldx, int I,
+                                                  const float* __restrict__ gi_pre, int64_t ldgi,
+                                                  const float* __restrict__ h_in, int64_t ldh,
+                                                  const uint8_t* __restrict__ mask,
+                                                  const float* __restrict__ w_ih, const float* __restrict__ w_hh,
+                                                  const float* __restrict__ b_ih, const float* __restrict__ b_hh,
+                                                  float* __restrict__ h_out, int64_t ldo,
+                                                  float* __restrict__ h_out2, int64_t ldo2, int rows, int H,
+                                                  float* __restrict__ save_r, float* __restrict__ save_z,
+                                                  float* __restrict__ save_n, float* __restrict__ save_ghn) {
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (j >= H) return;
+    for (int r0 = 0; r0 < rows; r0 += SK_ROWS) {
+        float ai[3][SK_ROWS], ah[3][SK_ROWS];
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int r = 0; r < SK_ROWS; ++r) ai[g][r] = ah[g][r] = 0.f;
+        if (x) {
+            for (int k = lane * 4; k < I; k += 256) {
+                float4 wv[3];
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+                    wv[g] = *reinterpret_cast<const float4*>(w_ih + ((int64_t)g * H + j) * I + k);
+#pragma unroll
+                for (int r = 0; r < SK_ROWS; ++r) {
+                    if (r0 + r < rows) {
+                        float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)(r0 + r) * ldx + k);
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) {
+                            ai[g][r] = fmaf(wv[g].x, xv.x, ai[g][r]);
+                            ai[g][r] = fmaf(wv[g].y, xv.y, ai[g][r]);
+                            ai[g][r] = fmaf(wv[g].z, xv.z, ai[g][r]);
+                            ai[g][r] = fmaf(wv[g].w, xv.w, ai[g][r]);
+                        }
+                    }
+                }
+            }
+        }
+        for (int k = lane * 4; k < H; k += 256) {
+            float4 wv[3];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) wv[g] = *reinterpret_cast<const float4*>(w_hh + ((int64_t)g * H + j) * H + k);
+#pragma unroll
+            for (int r = 0; r < SK_ROWS; ++r) {
+                if (r0 + r < rows) {
+                    float mk = mask ? (mask[r0 + r] ? 1.f : 0.f) : 1.f;
+                    float4 hv = *reinterpret_cast<const float4*>(h_in + (int64_t)(r0 + r) * ldh + k);
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) {
+                        ah[g][r] = fmaf(wv[g].x, hv.x * mk, ah[g][r]);
+                        ah[g][r] = fmaf(wv[g].y, hv.y * mk, ah[g][r]);
+                        ah[g][r] = fmaf(wv[g].z, hv.z * mk, ah[g][r]);
+                        ah[g][r] = fmaf(wv[g].w, hv.w * mk, ah[g][r]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < SK_ROWS; ++r) {
+            float gi[3], gh[3];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                gi[g] = wave_sum(ai[g][r]);
+                gh[g] = wave_sum(ah[g][r]);
+            }
+            if (lane == 0 && r0 + r < rows) {
+                const int row = r0 + r;
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    if (x) gi[g] += b_ih[g * H + j];
+                    else gi[g] = gi_pre[(int64_t)row * ldgi + g * H + j];
+                    gh[g] += b_hh[g * H + j];
+                }
+                float mk = mask ? (mask[row] ? 1.f : 0.f) : 1.f;
+                float hp = h_in[(int64_t)row * ldh + j] * mk;
+                float rg = sigmoidf_(gi[0] + gh[0]);
+                float zg = sigmoidf_(gi[1] + gh[1]);
+                float ng = tanhf(gi[2] + rg * gh[2]);
+                float hn = (1.f - zg) * ng + zg * hp;
+                h_out[(int64_t)row * ldo + j] = hn;
+                if (h_out2) h_out2[(int64_t)row * ldo2 + j] = hn;
+                if (save_r) {
+                    save_r[(int64_t)row * H + j] = rg;
+                    save_z[(int64_t)row * H + j] = zg;
+                    save_n[(int64_t)row * H + j] = ng;
+                    save_ghn[(int64_t)row * H + j] = gh[2];
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Cross-modal attention (MapCMANet._attn, models/map_cma_policy.py:266-274): per row n
+//   logits[i] = sum_c q[n][c] k[n][c][i];  masked i: logits - 1e8;  attn = softmax(logits*scale)
+//   out[n][c'] = sum_i attn[i] v[n][c'][i]
+// k: (N, Ck, I) and v: (N, Cv, I) channel-major with image strides; valid_len[n] (or null):
+// positions >= valid_len are the masked (all-zero) text positions.  One block per row.
+// ------------------------------------------------------------------------------------------
+constexpr int ATT_MAX_I = 512;
+
+__global__ __launch_bounds__(256) void k_attn(const float* __restrict__ q, int64_t ldq,
+                                              const float* __restrict__ k, int64_t k_img_stride,
+                                              const float* __restrict__ v, int64_t v_img_stride,
+                                              const int* __restrict__ valid_len, float scale, int Ck, int Cv,
+                                              int I, float* __restrict__ out, int64_t ldo,
+                                              float* __restrict__ save_attn) {
+    __shared__ float qs[1024];
+    __shared__ float ps[ATT_MAX_I];
+    __shared__ float red[16];
+    const int n = blockIdx.x;
+    for (int c = threadIdx.x; c < Ck; c += blockDim.x) qs[c] = q[(int64_t)n * ldq + c];
+    __syncthreads();
+    const float* kp = k + (int64_t)n * k_img_stride;
+    const int vl = valid_len ? valid_len[n] : I;
+    float lmax = -INFINITY;
+    for (int i = threadIdx.x; i < I; i += blockDim.x) {
+        float acc = 0.f;
+        for (int c = 0; c < Ck; ++c) acc = fmaf(qs[c], kp[(int64_t)c * I + i], acc);
+        if (i >= vl) acc = acc - 1e8f;
+        acc *= scale;
+        ps[i] = acc;
+        lmax = fmaxf(lmax, acc);
+    }
+    lmax = block_max(lmax, red);
+    float sum = 0.f;
+    for (int i = threadIdx.x; i < I; i += blockDim.x) {
+        float e = expf(ps[i] - lmax);
+        ps[i] = e;
+        sum += e;
+    }
+    sum = block_sum(sum, red);
+    const float inv = 1.f / sum;
+    for (int i = threadIdx.x; i < I; i += blockDim.x) {
+        float a = ps[i] * inv;
+        ps[i] = a;
+        if (save_attn) save_attn[(int64_t)n * I + i] = a;
+    }
+    __syncthreads();
+    const float* vp = v + (int64_t)n * v_img_stride;
+    for (int c = threadIdx.x; c < Cv; c += blockDim.x) {
+        float acc = 0.f;
+        for (int i = 0; i < I; ++i) acc = fmaf(ps[i], vp[(int64_t)c * I + i], acc);
+        out[(int64_t)n * ldo + c] = acc;
+    }
+}
+
+// prev-action embedding: idx = (long)((float(a)+1) * mask) (map_cma_policy.py:297-299)
+__global__ void k_prev_action_embed(const int64_t* __restrict__ prev_actions, const uint8_t* __restrict__ mask,
+                                    const float* __restrict__ table, int rows, int E, int n_emb,
+                                    float* __restrict__ out1, int64_t ld1, float* __restrict__ out2,
+                                    int64_t ld2) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * E) return;
+    int r = idx / E, e = idx % E;
+    int64_t a = (int64_t)(((float)prev_actions[r] + 1.f) * (float)(mask[r] ? 1 : 0));
+    if (a < 0) a = 0;
+    if (a >= n_emb) a = n_emb - 1;
+    float v = table[a * E + e];
+    out1[(int64_t)r * ld1 + e] = v;
+    if (out2) out2[(int64_t)r * ld2 + e] = v;
+}
+
+// row-wise argmax of logits (CustomFixedCategorical.mode: probs.argmax(-1), utils.py:168-169)
+__global__ void k_argmax_rows(const float* __restrict__ x, int rows, int C, int64_t* __restrict__ out) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    int best = 0;
+    float bv = x[(int64_t)r * C];
+    for (int c = 1; c < C; ++c) {
+        float v = x[(int64_t)r * C + c];
+        if (v > bv) {
+            bv = v;
+            best = c;
+        }
+    }
+    out[r] = best;
+}
+
+// channel argmax over NCHW logits -> u8 labels (predicted_scores.argmax(1), mapper.py:796-798)
+__global__ __launch_bounds__(256) void k_argmax_channels_u8(const float* __restrict__ x, int N, int C, int HW,
+                                                            uint8_t* __restrict__ out) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)N * HW) return;
+    int img = (int)(idx / HW), pp = (int)(idx % HW);
+    const float* xp = x + (int64_t)img * C * HW + pp;
+    int best = 0;
+    float bv = xp[0];
+    for (int c = 1; c < C; ++c) {
+        float v = xp[(int64_t)c * HW];
+        if (v > bv) {
+            bv = v;
+            best = c;
+        }
+    }
+    out[idx] = (uint8_t)best;
+}
+
+// RedNet input prep (mapper.py:715-736, 788-793): rgb u8 NHWC -> /255 -> bilinear resize
+// (align_corners=False) to (Ho,Wo) -> (x-mean)/std, NCHW f32; depth -> (d-0.213)/0.285.
+__global__ __launch_bounds__(256) void k_rgb_resize_normalize(const uint8_t* __restrict__ rgb, int B, int Hi,
+                                                              int Wi, int Ho, int Wo, float* __restrict__ out) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)B * 3 * Ho * Wo) return;
+    int wo = (int)(idx % Wo);
+    int ho = (int)((idx / Wo) % Ho);
+    int c = (int)((idx / ((int64_t)Wo * Ho)) % 3);
+    int b = (int)(idx / ((int64_t)Wo * Ho * 3));
+    const float mean[3] = {0.485f, 0.456f, 0.406f};
+    const float stdv[3] = {0.229f, 0.224f, 0.225f};
+    // torch upsample_bilinear2d, align_corners=False: src = (dst+0.5)*scale - 0.5, clamped at 0
+    float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
+    float fh = fmaxf(((float)ho + 0.5f) * sh - 0.5f, 0.f);
+    float fw = fmaxf(((float)wo + 0.5f) * sw - 0.5f, 0.f);
+    int h0 = (int)fh, w0 = (int)fw;
+    int h1 = h0 + (h0 < Hi - 1 ? 1 : 0), w1 = w0 + (w0 < Wi - 1 ? 1 : 0);
+    float lh = fh - (float)h0, lw = fw - (float)w0;
+    auto px = [&](int h, int w) { return (float)rgb[(((int64_t)b * Hi + h) * Wi + w) * 3 + c] / 255.0f; };
+    float v = (1.f - lh) * ((1.f - lw) * px(h0, w0) + lw * px(h0, w1)) + lh * ((1.f - lw) * px(h1, w0) + lw * px(h1, w1));
+    out[idx] = (v - mean[c]) / stdv[c];
+}
+
+__global__ __launch_bounds__(256) void k_affine(const float* __restrict__ x, float* __restrict__ y, int64_t n,
+                                                float sub, float div) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx < n) y[idx] = (x[idx] - sub) / div;
+}
+
+// y = relu?(a + b) elementwise (RedNet fuse adds, rednet.py:190-222)
+__global__ __launch_bounds__(256) void k_add(const float* __restrict__ a, const float* __restrict__ b,
+                                             float* __restrict__ y, int64_t n, int relu) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx < n) {
+        float v = a[idx] + b[idx];
+        y[idx] = relu ? fmaxf(v, 0.f) : v;
+    }
+}
+
+// copy a (rows x cols) f32 block between strided buffers (concat plumbing without torch launches)
+__global__ __launch_bounds__(256) void k_copy2d(const float* __restrict__ src, int64_t lds_, float* __restrict__ dst,
+                                                int64_t ldd, int rows, int cols, int bcast_rows) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)rows * cols) return;
+    int r = (int)(idx / cols), c = (int)(idx % cols);
+    dst[(int64_t)r * ldd + c] = src[(bcast_rows ? 0 : (int64_t)r * lds_) + c];
+}
+
+inline unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+#define LAUNCH_OK() (hipGetLastError() == hipSuccess ? IVLN_OK : IVLN_E_HIP)
+
+extern "C" {
+
+int ivln_groupnorm_f32(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
+                       int N, int C, int HW, int groups, float eps, int relu, int64_t x_img_stride,
+                       int64_t y_img_stride, int64_t r_img_stride, float* save_mean, float* save_rstd,
+                       void* stream) {
+    if (N <= 0 || C <= 0 || groups <= 0 || C % groups) return IVLN_E_INVALID;
+    if (x_img_stride <= 0) x_img_stride = (int64_t)C * HW;
+    if (y_img_stride <= 0) y_img_stride = (int64_t)C * HW;
+    if (r_img_stride <= 0) r_img_stride = (int64_t)C * HW;
+    hipLaunchKernelGGL(k_groupnorm, dim3(N * groups), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, residual, y,
+                       C, HW, groups, eps, relu, x_img_stride, y_img_stride, r_img_stride, save_mean, save_rstd);
+    return LAUNCH_OK();
+}
+
+int ivln_bn_fold_f32(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                     float eps, int C, float* scale, float* shift, void* stream) {
+    hipLaunchKernelGGL(k_bn_fold, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, gamma, beta, running_mean,
+                       running_var, eps, C, scale, shift);
+    return LAUNCH_OK();
+}
+
+int ivln_bn_train_stats_f32(const float* x, int N, int C, int HW, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, float momentum, float eps, float* scale,
+                            float* shift, float* save_mean, float* save_rstd, void* stream) {
+    hipLaunchKernelGGL(k_bn_train_stats, dim3(C), dim3(256), 0, (hipStream_t)stream, x, N, C, HW, gamma, beta,
+                       running_mean, running_var, momentum, eps, scale, shift, save_mean, save_rstd);
+    return LAUNCH_OK();
+}
+
+int ivln_scale_shift_relu_avgpool2_f32(const float* x, const float* scale, const float* shift, float* y, int N,
+                                       int C, int H, int W, void* stream) {
+    int64_t total = (int64_t)N * C * (H / 2) * (W / 2);
+    hipLaunchKernelGGL(k_scale_shift_relu_avgpool2, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, x, scale,
+                       shift, y, N * C, C, H, W);
+    return LAUNCH_OK();
+}
+
+int ivln_pool2d_f32(const float* x, float* y, int NC, int H, int W, int k, int s, int p, int mode, void* stream) {
+    int Ho = (H + 2 * p - k) / s + 1, Wo = (W + 2 * p - k) / s + 1;
+    int64_t total = (int64_t)NC * Ho * Wo;
+    hipLaunchKernelGGL(k_pool2d, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, x, y, NC, H, W, Ho, Wo, k, s,
+                       p, mode);
+    return LAUNCH_OK();
+}
+
+int ivln_map_features_f32(const uint8_t* occ, const uint8_t* sem, float* y, int B, int cells, int classes,
+                          void* stream) {
+    int64_t total = (int64_t)B * (1 + classes) * cells;
+    hipLaunchKernelGGL(k_map_features, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, occ, sem, y, B, cells,
+                       classes);
+    return LAUNCH_OK();
+}
+
+int ivln_embed_lengths(const int64_t* tokens, const float* table, int B, int L, int E, int V, float* emb,
+                       int* lengths, void* stream) {
+    hipLaunchKernelGGL(k_embed_lengths, dim3(B), dim3(256), 0, (hipStream_t)stream, tokens, table, L, E, V, emb,
+                       lengths);
+    return LAUNCH_OK();
+}
+
+int ivln_lstm_bidir_fwd_f32(const float* gx_f, const float* gx_r, const float* whh_f, const float* whh_r,
+                            const float* bhh_f, const float* bhh_r, const int* lengths, int B, int L, int H,
+                            float* out, float* save_gates, float* save_c, void* stream) {
+    if (H != 128) return IVLN_E_UNSUPPORTED;
+    hipLaunchKernelGGL((k_lstm_bidir<128>), dim3(B, 2), dim3(512), 0, (hipStream_t)stream, gx_f, gx_r, whh_f, whh_r,
+                       bhh_f, bhh_r, lengths, L, out, save_gates, save_c);
+    return LAUNCH_OK();
+}
+
+int ivln_linear_skinny_f32(const float* x, int64_t ldx, const float* W, const float* bias, float* y, int64_t ldy,
+                           int rows, int K, int O, int relu, void* stream) {
+    if (rows <= 0 || K <= 0 || O <= 0) return IVLN_E_INVALID;
+    if ((K & 3) == 0 && (ldx & 3)) return IVLN_E_INVALID;
+    hipLaunchKernelGGL(k_linear_skinny, dim3((O + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, W, bias, y, ldy,
+                       rows, K, O, relu);
+    return LAUNCH_OK();
+}
+
+int ivln_gru_step_f32(const float* x, int64_t ldx, int I, const float* gi_pre, int64_t ldgi, const float* h_in,
+                      int64_t ldh, const uint8_t* mask, const float* w_ih, const float* w_hh, const float* b_ih,
+                      const float* b_hh, float* h_out, int64_t ldo, float* h_out2, int64_t ldo2, int rows, int H,
+                      float* save_r, float* save_z, float* save_n, float* save_ghn, void* stream) {
+    if (rows <= 0 || (H & 3) || (x && (I & 3)) || (ldh & 3) || (x && (ldx & 3))) return IVLN_E_INVALID;
+    hipLaunchKernelGGL(k_gru_step, dim3((H + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, I, gi_pre, ldgi,
+                       h_in, ldh, mask, w_ih, w_hh, b_ih, b_hh, h_out, ldo, h_out2, ldo2, rows, H, save_r, save_z,
+                       save_n, save_ghn);
+    return LAUNCH_OK();
+}
+
+int ivln_attn_fwd_f32(const float* q, int64_t ldq, const float* k, int64_t k_img_stride, const float* v,
+                      int64_t v_img_stride, const int* valid_len, float scale, int rows, int Ck, int Cv, int I,
+                      float* out, int64_t ldo, float* save_attn, void* stream) {
+    if (I > ATT_MAX_I || Ck > 1024) return IVLN_E_UNSUPPORTED;
+    hipLaunchKernelGGL(k_attn, dim3(rows), dim3(256), 0, (hipStream_t)stream, q, ldq, k, k_img_stride, v,
+                       v_img_stride, valid_len, scale, Ck, Cv, I, out, ldo, save_attn);
+    return LAUNCH_OK();
+}
+
+int ivln_prev_action_embed_f32(const int64_t* prev_actions, const uint8_t* mask, const float* table, int rows, int E,
+                               int n_emb, float* out1, int64_t ld1, float* out2, int64_t ld2, void* stream) {
+    hipLaunchKernelGGL(k_prev_action_embed, dim3((rows * E + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       prev_actions, mask, table, rows, E, n_emb, out1, ld1, out2, ld2);
+    return LAUNCH_OK();
+}
+
+int ivln_argmax_rows(const float* x, int rows, int C, int64_t* out, void* stream) {
+    hipLaunchKernelGGL(k_argmax_rows, dim3((rows + 63) / 64), dim3(64), 0, (hipStream_t)stream, x, rows, C, out);
+    return LAUNCH_OK();
+}
+
+int ivln_argmax_channels_u8(const float* x, int N, int C, int HW, uint8_t* out, void* stream) {
+    hipLaunchKernelGGL(k_argmax_channels_u8, dim3(nblk((int64_t)N * HW)), dim3(256), 0, (hipStream_t)stream, x, N, C,
+                       HW, out);
+    return LAUNCH_OK();
+}
+
+int ivln_rgb_resize_normalize_f32(const uint8_t* rgb, int B, int Hi, int Wi, int Ho, int Wo, float* out,
+                                  void* stream) {
+    hipLaunchKernelGGL(k_rgb_resize_normalize, dim3(nblk((int64_t)B * 3 * Ho * Wo)), dim3(256), 0,
+                       (hipStream_t)stream, rgb, B, Hi, Wi, Ho, Wo, out);
+    return LAUNCH_OK();
+}
+
+int ivln_affine_f32(const float* x, float* y, int64_t n, float sub, float div, void* stream) {
+    hipLaunchKernelGGL(k_affine, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, sub, div);
+    return LAUNCH_OK();
+}
+
+int ivln_add_f32(const float* a, const float* b, float* y, int64_t n, int relu, void* stream) {
+    hipLaunchKernelGGL(k_add, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, a, b, y, n, relu);
+    return LAUNCH_OK();
+}
+
+int ivln_copy2d_f32(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int rows, int cols,
+                    int broadcast_rows, void* stream) {
+    hipLaunchKernelGGL(k_copy2d, dim3(nblk((int64_t)rows * cols)), dim3(256), 0, (hipStream_t)stream, src, ld_src,
+                       dst, ld_dst, rows, cols, broadcast_rows);
+    return LAUNCH_OK();
+}
+
+}  // extern "C"
