@@ -1,0 +1,363 @@
+"""Encoders of the MapCMA policy with the reference's module / parameter names, forward on HIP.
+
+torch.nn modules are used ONLY as parameter containers (identical `state_dict()` keys, init,
+`.to()/.train()/.eval()` semantics); every forward below calls the HIP kernels through ops.py.
+
+  SemanticMapEncoder / CBRA   ivlnce_baselines/models/encoders/map_encoder.py:8-97
+  InstructionEncoder          ivlnce_baselines/models/encoders/instruction_encoder.py:11-94
+  VlnResnetDepthEncoder       ivlnce_baselines/models/encoders/resnet_encoders.py:17-115
+  ResNetEncoder / resnet50    habitat-lab v0.1.7 ddppo policy (un-vendored)
+  RNNStateEncoder             habitat-lab v0.1.7 rnn_state_encoder (Appendix A.2)
+"""
+import gzip
+import json
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+# ------------------------------------------------------------------------------------------------
+# Semantic map encoder
+# ------------------------------------------------------------------------------------------------
+class CBRA(nn.Module):
+    """Conv(7x7 same) -> BatchNorm -> ReLU -> AvgPool(2)."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.conv = nn.Sequential(
+            nn.Conv2d(in_channels, out_channels, kernel_size=7, padding=3),
+            nn.BatchNorm2d(out_channels),
+            nn.ReLU(inplace=True),
+            nn.AvgPool2d(2),
+        )
+
+    def forward_hip(self, x, save=None):
+        conv, bn = self.conv[0], self.conv[1]
+        y = ops.conv2d(x, conv.weight, stride=1, pad=3, shift=conv.bias)
+        C = bn.num_features
+        scale = torch.empty(C, dtype=torch.float32, device=x.device)
+        shift = torch.empty(C, dtype=torch.float32, device=x.device)
+        if bn.training:
+            sm = sr = None
+            if save is not None:
+                sm = torch.empty(C, dtype=torch.float32, device=x.device)
+                sr = torch.empty(C, dtype=torch.float32, device=x.device)
+            ops.bn_train_stats(y, bn, scale, shift, sm, sr)
+            if bn.num_batches_tracked is not None:
+                bn.num_batches_tracked += 1
+            if save is not None:
+                save.append(dict(x=x, y=y, scale=scale, shift=shift, mean=sm, rstd=sr, train=True))
+        else:
+            ops.bn_fold(bn, scale, shift)
+            if save is not None:
+                save.append(dict(x=x, y=y, scale=scale, shift=shift, train=False))
+        return ops.scale_shift_relu_avgpool2(y, scale, shift)
+
+
+class SemanticMapEncoder(nn.Module):
+    def __init__(self, observation_space, num_semantic_classes: int = 13, ch: int = 32, last_ch_mult: int = 8,
+                 trainable: bool = True, from_pretrained: bool = False, checkpoint: Optional[str] = None):
+        super().__init__()
+        for k in ["occupancy_map", "semantic_map"]:
+            if k not in observation_space.spaces:
+                raise ValueError(f"key `{k}` expected in observation space.")
+        self._map_dimensions = observation_space.spaces["occupancy_map"].shape
+        self._num_semantic_classes = num_semantic_classes
+        self.last_ch_mult = last_ch_mult
+        self._ch = ch
+        self.cnn = nn.Sequential(CBRA(14, ch), CBRA(ch, ch * 2), CBRA(ch * 2, ch * 4), CBRA(ch * 4, ch * last_ch_mult))
+        if from_pretrained:
+            ckpt = torch.load(checkpoint, map_location="cpu")["state_dict"]
+            prefix = "encoder.cnn."
+            self.cnn.load_state_dict({k[len(prefix):]: v for k, v in ckpt.items() if k.startswith(prefix)})
+        for param in self.cnn.parameters():
+            param.requires_grad_(trainable)
+        if not trainable:
+            self.eval()
+
+    @property
+    def output_shape(self):
+        return (self._ch * self.last_ch_mult, self._map_dimensions[0] // 16, self._map_dimensions[1] // 16)
+
+    def generate_map_features(self, observations):
+        occ = observations["occupancy_map"].to(torch.uint8).contiguous()
+        sem = observations["semantic_map"].to(torch.uint8).contiguous()
+        return ops.map_features(occ, sem, self._num_semantic_classes)
+
+    def forward(self, observations, save=None):
+        for k in ["occupancy_map", "semantic_map"]:
+            if k not in observations:
+                raise ValueError(f"Observation `{k}` is missing.")
+        x = self.generate_map_features(observations)
+        for blk in self.cnn:
+            x = blk.forward_hip(x, save)
+        return x
+
+
+# ------------------------------------------------------------------------------------------------
+# Instruction encoder
+# ------------------------------------------------------------------------------------------------
+class InstructionEncoder(nn.Module):
+    def __init__(self, config) -> None:
+        super().__init__()
+        self.config = config
+        assert config.rnn_type == "LSTM" and config.bidirectional, "MapCMA uses a bidirectional LSTM"
+        self.encoder_rnn = nn.LSTM(input_size=config.embedding_size, hidden_size=config.hidden_size, bidirectional=True)
+        if config.sensor_uuid == "instruction":
+            if config.use_pretrained_embeddings:
+                self.embedding_layer = nn.Embedding.from_pretrained(
+                    embeddings=self._load_embeddings(), freeze=not config.fine_tune_embeddings
+                )
+            else:
+                self.embedding_layer = nn.Embedding(
+                    num_embeddings=config.vocab_size, embedding_dim=config.embedding_size, padding_idx=0
+                )
+
+    @property
+    def output_size(self):
+        return self.config.hidden_size * 2
+
+    def _load_embeddings(self):
+        with gzip.open(self.config.embedding_file, "rt") as f:
+            return torch.tensor(json.load(f))
+
+    def forward(self, observations, save=None):
+        """(B, L) tokens -> (B, 2H, L) channel-major outputs, zero for t >= length; also returns
+        lengths (device int32).  The reference returns (B, 2H, Lmax); the extra columns here are
+        exactly the masked (zero-weight) attention positions."""
+        tokens = observations["instruction"].long().contiguous()
+        B, L = tokens.shape
+        rnn = self.encoder_rnn
+        H = rnn.hidden_size
+        emb, lengths = ops.embed_lengths(tokens, self.embedding_layer.weight)
+        gx_f = ops.linear_gemm(emb, rnn.weight_ih_l0, rnn.bias_ih_l0)
+        gx_r = ops.linear_gemm(emb, rnn.weight_ih_l0_reverse, rnn.bias_ih_l0_reverse)
+        out, gates, cs = ops.lstm_bidir(
+            gx_f, gx_r, rnn.weight_hh_l0, rnn.weight_hh_l0_reverse, rnn.bias_hh_l0, rnn.bias_hh_l0_reverse, lengths,
+            B, L, H, save=save is not None,
+        )
+        if save is not None:
+            save.update(emb=emb, lengths=lengths, gates=gates, cs=cs, out=out, tokens=tokens)
+        return out, lengths
+
+
+# ------------------------------------------------------------------------------------------------
+# DD-PPO depth ResNet50 (GroupNorm), parameter tree named like habitat-lab's
+# ------------------------------------------------------------------------------------------------
+def _conv(cin, cout, k, stride=1, pad=0):
+    return nn.Conv2d(cin, cout, kernel_size=k, stride=stride, padding=pad, bias=False)
+
+
+class _Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, ngroups, stride=1, downsample=None):
+        super().__init__()
+        self.convs = nn.Sequential(
+            _conv(inplanes, planes, 1), nn.GroupNorm(ngroups, planes), nn.ReLU(True),
+            _conv(planes, planes, 3, stride, 1), nn.GroupNorm(ngroups, planes), nn.ReLU(True),
+            _conv(planes, planes * 4, 1), nn.GroupNorm(ngroups, planes * 4),
+        )
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward_hip(self, x):
+        c = self.convs
+        identity = x
+        if self.downsample is not None:
+            d = ops.conv2d(x, self.downsample[0].weight, stride=self.stride)
+            gn = self.downsample[1]
+            identity = ops.groupnorm(d, gn.weight, gn.bias, gn.num_groups, gn.eps, out=d)
+        y = ops.conv2d(x, c[0].weight)
+        ops.groupnorm(y, c[1].weight, c[1].bias, c[1].num_groups, c[1].eps, relu=True, out=y)
+        y2 = ops.conv2d(y, c[3].weight, stride=self.stride, pad=1)
+        ops.groupnorm(y2, c[4].weight, c[4].bias, c[4].num_groups, c[4].eps, relu=True, out=y2)
+        y3 = ops.conv2d(y2, c[6].weight)
+        return ops.groupnorm(y3, c[7].weight, c[7].bias, c[7].num_groups, c[7].eps, relu=True, residual=identity, out=y3)
+
+
+class _ResNet50GN(nn.Module):
+    def __init__(self, in_channels, base_planes, ngroups):
+        super().__init__()
+        self.conv1 = nn.Sequential(
+            nn.Conv2d(in_channels, base_planes, kernel_size=7, stride=2, padding=3, bias=False),
+            nn.GroupNorm(ngroups, base_planes), nn.ReLU(True),
+        )
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.inplanes = base_planes
+        self.layer1 = self._make_layer(ngroups, base_planes, 3)
+        self.layer2 = self._make_layer(ngroups, base_planes * 2, 4, stride=2)
+        self.layer3 = self._make_layer(ngroups, base_planes * 4, 6, stride=2)
+        self.layer4 = self._make_layer(ngroups, base_planes * 8, 3, stride=2)
+        self.final_channels = self.inplanes
+        self.final_spatial_compress = 1.0 / (2 ** 5)
+
+    def _make_layer(self, ngroups, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * 4:
+            downsample = nn.Sequential(_conv(self.inplanes, planes * 4, 1, stride), nn.GroupNorm(ngroups, planes * 4))
+        layers = [_Bottleneck(self.inplanes, planes, ngroups, stride, downsample)]
+        self.inplanes = planes * 4
+        for _ in range(1, blocks):
+            layers.append(_Bottleneck(self.inplanes, planes, ngroups))
+        return nn.Sequential(*layers)
+
+    def forward_hip(self, x):
+        c, gn = self.conv1[0], self.conv1[1]
+        y = ops.conv2d(x, c.weight, stride=2, pad=3)
+        ops.groupnorm(y, gn.weight, gn.bias, gn.num_groups, gn.eps, relu=True, out=y)
+        y = ops.pool2d(y, 3, 2, 1, "max")
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for blk in layer:
+                y = blk.forward_hip(y)
+        return y
+
+
+class ResNetEncoder(nn.Module):
+    """habitat-lab ResNetEncoder for a depth-only observation space: avg_pool2d(2) -> GN-ResNet50 ->
+    3x3 compression conv + GroupNorm(1) + ReLU -> (B,128,4,4)."""
+
+    def __init__(self, depth_shape, baseplanes=32, ngroups=16):
+        super().__init__()
+        spatial_size = depth_shape[0] // 2
+        self._n_input_depth = depth_shape[2]
+        self.running_mean_and_var = nn.Sequential()
+        self.backbone = _ResNet50GN(self._n_input_depth, baseplanes, ngroups)
+        final_spatial = int(spatial_size * self.backbone.final_spatial_compress)
+        num_compression_channels = int(round(2048 / (final_spatial ** 2)))
+        self.compression = nn.Sequential(
+            nn.Conv2d(self.backbone.final_channels, num_compression_channels, kernel_size=3, padding=1, bias=False),
+            nn.GroupNorm(1, num_compression_channels), nn.ReLU(True),
+        )
+        self.output_shape = (num_compression_channels, final_spatial, final_spatial)
+        for layer in self.modules():
+            if isinstance(layer, (nn.Conv2d, nn.Linear)):
+                nn.init.kaiming_normal_(layer.weight, nn.init.calculate_gain("relu"))
+                if layer.bias is not None:
+                    nn.init.constant_(layer.bias, val=0)
+
+    @property
+    def is_blind(self):
+        return self._n_input_depth == 0
+
+    def forward(self, observations, out=None, out_ctot=0):
+        """observations["depth"]: (B,H,W,1) f32.  `out`: optional (B,128,4,4) channel slice of a wider
+        NCHW buffer with `out_ctot` channels (the policy passes its depth+spatial-embedding buffer)."""
+        depth = observations["depth"].to(torch.float32).contiguous()
+        B, H, W, Cd = depth.shape
+        assert Cd == 1, "depth-only encoder"
+        x = ops.pool2d(depth.view(B, 1, H, W), 2, 2, 0, "avg")  # F.avg_pool2d(x, 2)
+        x = self.backbone.forward_hip(x)
+        c, gn = self.compression[0], self.compression[1]
+        y = ops.conv2d(x, c.weight, pad=1)
+        Co, hw = self.output_shape[0], self.output_shape[1] * self.output_shape[2]
+        if out is None:
+            return ops.groupnorm(y, gn.weight, gn.bias, gn.num_groups, gn.eps, relu=True, out=y)
+        ops.groupnorm(y, gn.weight, gn.bias, gn.num_groups, gn.eps, relu=True, out=out,
+                      y_img_stride=out_ctot * hw, N=B, C=Co, HW=hw)
+        return out
+
+
+class VlnResnetDepthEncoder(nn.Module):
+    def __init__(self, observation_space, output_size: int = 128, checkpoint: str = "NONE", backbone: str = "resnet50",
+                 resnet_baseplanes: int = 32, normalize_visual_inputs: bool = False, trainable: bool = False,
+                 spatial_output: bool = False) -> None:
+        super().__init__()
+        assert backbone == "resnet50" and not normalize_visual_inputs and spatial_output
+        depth_shape = observation_space.spaces["depth"].shape
+        if len(depth_shape) == 4:  # single_frame_box_shape (common/utils.py:38-48)
+            depth_shape = depth_shape[1:]
+        self.visual_encoder = ResNetEncoder(depth_shape, baseplanes=resnet_baseplanes, ngroups=resnet_baseplanes // 2)
+        for param in self.visual_encoder.parameters():
+            param.requires_grad_(trainable)
+        if checkpoint != "NONE":
+            ddppo_weights = torch.load(checkpoint, map_location="cpu")
+            weights_dict = {}
+            for k, v in ddppo_weights["state_dict"].items():  # resnet_encoders.py:48-61
+                split_layer_name = k.split(".")[2:]
+                if split_layer_name[0] != "visual_encoder":
+                    continue
+                weights_dict[".".join(split_layer_name[1:])] = v
+            del ddppo_weights
+            self.visual_encoder.load_state_dict(weights_dict, strict=True)
+        self.spatial_output = spatial_output
+        c, h, w = self.visual_encoder.output_shape
+        self.spatial_embeddings = nn.Embedding(h * w, 64)
+        self.output_shape = (c + self.spatial_embeddings.embedding_dim, h, w)
+
+    @property
+    def is_blind(self):
+        return self.visual_encoder.is_blind
+
+    def forward(self, observations):
+        """-> (B, 192, 4, 4): visual features ++ the learned spatial embedding (a raw `.view` of the
+        (16,64) table as (64,4,4), resnet_encoders.py:97-113)."""
+        c, h, w = self.visual_encoder.output_shape
+        E = self.spatial_embeddings.embedding_dim
+        if "depth_features" in observations:
+            feats = observations["depth_features"].to(torch.float32).contiguous()
+            B = feats.shape[0]
+            out = torch.empty((B, c + E, h, w), dtype=torch.float32, device=feats.device)
+            ops.copy2d(feats.view(B, -1), out.view(B, -1), B, c * h * w)
+        else:
+            B = observations["depth"].shape[0]
+            out = torch.empty((B, c + E, h, w), dtype=torch.float32, device=observations["depth"].device)
+            self.visual_encoder(observations, out=out[:, :c], out_ctot=c + E)
+        ops.copy2d(self.spatial_embeddings.weight.view(1, -1), out.view(B, -1)[:, c * h * w:], B, E * h * w,
+                   broadcast_rows=True)
+        return out
+
+
+# ------------------------------------------------------------------------------------------------
+# RNN state encoder (masked GRU)
+# ------------------------------------------------------------------------------------------------
+class RNNStateEncoder(nn.Module):
+    def __init__(self, input_size: int, hidden_size: int, num_layers: int = 1):
+        super().__init__()
+        assert num_layers == 1
+        self.num_recurrent_layers = num_layers
+        self.rnn = nn.GRU(input_size=input_size, hidden_size=hidden_size, num_layers=num_layers)
+        for name, param in self.rnn.named_parameters():
+            if "weight" in name:
+                nn.init.orthogonal_(param)
+            elif "bias" in name:
+                nn.init.constant_(param, 0)
+
+    def forward(self, x, h0, masks_u8, out, state_out, save=None):
+        """x (rows,I); h0 (N,H) view (row-strided) of the incoming state; masks u8 (rows); `out`
+        (rows,H) row-strided destination of the per-step outputs; state_out (N,H) view for the final
+        hidden state.  rows == N -> single step, else time-major sequence of T = rows/N steps."""
+        rnn = self.rnn
+        rows, N = x.shape[0], h0.shape[0]
+        H = rnn.hidden_size
+        if rows == N:
+            saves = None
+            if save is not None:
+                saves = tuple(torch.empty((rows, H), dtype=torch.float32, device=x.device) for _ in range(4))
+                save.update(r=saves[0], z=saves[1], n=saves[2], ghn=saves[3], T=1, N=N, x=x, h0=h0, masks=masks_u8)
+            ops.gru_step(x, None, h0, masks_u8, rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0,
+                         out, state_out, saves)
+            return out
+        T = rows // N
+        gi = ops.linear_gemm(x, rnn.weight_ih_l0, rnn.bias_ih_l0)
+        saves = None
+        if save is not None:
+            saves = tuple(torch.empty((rows, H), dtype=torch.float32, device=x.device) for _ in range(4))
+            save.update(r=saves[0], z=saves[1], n=saves[2], ghn=saves[3], T=T, N=N, x=x, h0=h0, masks=masks_u8)
+        for t in range(T):
+            sl = slice(t * N, (t + 1) * N)
+            h_in = h0 if t == 0 else out[(t - 1) * N: t * N]
+            st = tuple(s[sl] for s in saves) if saves is not None else None
+            ops.gru_step(None, gi[sl], h_in, masks_u8[sl], rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0,
+                         rnn.bias_hh_l0, out[sl], state_out if t == T - 1 else None, st)
+        return out
+
+
+def build_rnn_state_encoder(input_size: int, hidden_size: int, rnn_type: str = "GRU", num_layers: int = 1):
+    assert rnn_type.lower() == "gru", "MapCMA configs use STATE_ENCODER.rnn_type GRU"
+    return RNNStateEncoder(input_size, hidden_size, num_layers)

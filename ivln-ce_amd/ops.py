@@ -1,0 +1,383 @@
+"""Thin Python bindings of the HIP kernels (ctypes over the C ABI of include/ivln_hip.h).
+
+Every function takes/returns torch GPU tensors, launches on torch's current stream and performs
+no arithmetic itself; tensor allocation and views are the only torch operations used.
+"""
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import check, dptr, f32, i32, i64, lib, stream_ptr, vp
+
+
+class GemmDesc(C.Structure):
+    """Mirror of `ivln_gemm_desc` (include/ivln_hip.h) - field order must match."""
+
+    _fields_ = [
+        ("A", vp), ("B", vp), ("D", vp),
+        ("M", i32), ("N", i32), ("K", i32),
+        ("amode", i32), ("bmode", i32), ("dmode", i32),
+        ("lda", i64), ("ldb", i64),
+        ("Cin", i32), ("Hin", i32), ("Win", i32), ("Hout", i32), ("Wout", i32),
+        ("stride", i32), ("pad", i32), ("dil", i32),
+        ("koff", vp), ("kpos", vp),
+        ("HoWo", i32), ("Ctot", i32),
+        ("in_img_stride", i64),
+        ("sDm", i64), ("sDn", i64),
+        ("scale", vp), ("shift", vp), ("residual", vp),
+        ("relu", i32), ("accumulate", i32),
+        ("splits", i32),
+        ("ws", vp), ("ws_floats", i64),
+    ]
+
+
+A_MK, A_KM, A_NCHW_P = 0, 1, 2
+B_CONV, B_CONV1X1, B_KN, B_NK, B_IM2COL_T, B_CONVT = 0, 1, 2, 3, 4, 5
+D_NCHW, D_DENSE = 0, 1
+
+_sigs_done = False
+
+
+def _L():
+    global _sigs_done
+    L = lib()
+    if not _sigs_done:
+        L.ivln_gemm_f32.argtypes = [C.POINTER(GemmDesc), vp]
+        L.ivln_groupnorm_f32.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, i64, i64, i64, vp, vp, vp]
+        L.ivln_bn_fold_f32.argtypes = [vp, vp, vp, vp, f32, i32, vp, vp, vp]
+        L.ivln_bn_train_stats_f32.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp]
+        L.ivln_scale_shift_relu_avgpool2_f32.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
+        L.ivln_pool2d_f32.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+        L.ivln_map_features_f32.argtypes = [vp, vp, vp, i32, i32, i32, vp]
+        L.ivln_embed_lengths.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp]
+        L.ivln_lstm_bidir_fwd_f32.argtypes = [vp] * 7 + [i32, i32, i32, vp, vp, vp, vp]
+        L.ivln_linear_skinny_f32.argtypes = [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp]
+        L.ivln_gru_step_f32.argtypes = [vp, i64, i32, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp, i64, i32, i32,
+                                        vp, vp, vp, vp, vp]
+        L.ivln_attn_fwd_f32.argtypes = [vp, i64, vp, i64, vp, i64, vp, f32, i32, i32, i32, i32, vp, i64, vp, vp]
+        L.ivln_prev_action_embed_f32.argtypes = [vp, vp, vp, i32, i32, i32, vp, i64, vp, i64, vp]
+        L.ivln_argmax_rows.argtypes = [vp, i32, i32, vp, vp]
+        L.ivln_argmax_channels_u8.argtypes = [vp, i32, i32, i32, vp, vp]
+        L.ivln_rgb_resize_normalize_f32.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
+        L.ivln_affine_f32.argtypes = [vp, vp, i64, f32, f32, vp]
+        L.ivln_add_f32.argtypes = [vp, vp, vp, i64, i32, vp]
+        L.ivln_copy2d_f32.argtypes = [vp, i64, vp, i64, i32, i32, i32, vp]
+        _sigs_done = True
+    return L
+
+
+def _p(t: Optional[torch.Tensor]):
+    """Device pointer; unlike dptr() allows strided views (caller passes the strides)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.IvlnError("HIP hot path needs GPU tensors (no CPU fallback); got " + str(t.device))
+    return t.data_ptr()
+
+
+# ---- per-device caches (index tables, split-K workspace) -----------------------------------------
+_tables = {}
+_ws = {}
+
+
+def conv_tables(cin, kh, kw, hin, win, dil, device, transposed=False):
+    key = (cin, kh, kw, hin, win, dil, str(device), transposed)
+    t = _tables.get(key)
+    if t is None:
+        ci = torch.arange(cin, dtype=torch.int64).view(-1, 1, 1)
+        a = torch.arange(kh, dtype=torch.int64).view(1, -1, 1)
+        b = torch.arange(kw, dtype=torch.int64).view(1, 1, -1)
+        if transposed:
+            koff = (ci * hin * win + 0 * a + 0 * b).reshape(-1)
+        else:
+            koff = (ci * hin * win + a * dil * win + b * dil).reshape(-1)
+        kpos = (0 * ci + (a << 16) + b).reshape(-1)
+        t = (koff.to(torch.int32).to(device), kpos.to(torch.int32).to(device))
+        _tables[key] = t
+    return t
+
+
+def splitk_ws(device, floats=8 << 20):
+    key = str(device)
+    w = _ws.get(key)
+    if w is None or w.numel() < floats:
+        w = torch.empty(floats, dtype=torch.float32, device=device)
+        _ws[key] = w
+    return w
+
+
+def gemm(desc: GemmDesc):
+    check(_L().ivln_gemm_f32(C.byref(desc), stream_ptr()), "ivln_gemm_f32")
+
+
+def _epilogue(d: GemmDesc, scale, shift, residual, relu, accumulate=False):
+    d.scale, d.shift, d.residual = _p(scale), _p(shift), _p(residual)
+    d.relu, d.accumulate = int(bool(relu)), int(bool(accumulate))
+
+
+def conv2d(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, relu=False, out=None, out_ctot=0,
+           in_img_stride=0, splitk=True):
+    """NCHW conv: x (N,Cin,H,W) [contiguous per image, image stride `in_img_stride`], w OIHW.
+    out: optional destination (a channel slice of an (N,out_ctot,Ho,Wo) buffer)."""
+    N, Cin, H, W = x.shape
+    Cout, _, KH, KW = w.shape
+    Ho = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
+    if out is None:
+        out = torch.empty((N, Cout, Ho, Wo), dtype=torch.float32, device=x.device)
+    d = GemmDesc()
+    d.A, d.B, d.D = dptr(w), _p(x), _p(out)
+    d.M, d.N, d.K = Cout, N * Ho * Wo, Cin * KH * KW
+    d.amode, d.dmode = A_MK, D_NCHW
+    d.lda = d.K
+    d.Cin, d.Hin, d.Win, d.Hout, d.Wout = Cin, H, W, Ho, Wo
+    d.stride, d.pad, d.dil = stride, pad, dil
+    d.HoWo, d.Ctot = Ho * Wo, out_ctot
+    d.in_img_stride = in_img_stride
+    if KH == 1 and KW == 1 and pad == 0:
+        d.bmode = B_CONV1X1
+    else:
+        d.bmode = B_CONV
+        koff, kpos = conv_tables(Cin, KH, KW, H, W, dil, x.device)
+        d.koff, d.kpos = dptr(koff), dptr(kpos)
+    _epilogue(d, scale, shift, residual, relu)
+    if splitk:
+        ws = splitk_ws(x.device)
+        d.ws, d.ws_floats, d.splits = dptr(ws), ws.numel(), 0
+    else:
+        d.splits = 1
+    gemm(d)
+    return out
+
+
+def conv_transpose2d(x, w_oihw, stride, pad, out_pad, scale=None, shift=None, residual=None, relu=False, out=None):
+    """nn.ConvTranspose2d with weights pre-arranged as (Cout,Cin,KH,KW)."""
+    N, Cin, H, W = x.shape
+    Cout, _, KH, KW = w_oihw.shape
+    Ho = (H - 1) * stride - 2 * pad + KH + out_pad
+    Wo = (W - 1) * stride - 2 * pad + KW + out_pad
+    if out is None:
+        out = torch.empty((N, Cout, Ho, Wo), dtype=torch.float32, device=x.device)
+    d = GemmDesc()
+    d.A, d.B, d.D = dptr(w_oihw), dptr(x), dptr(out)
+    d.M, d.N, d.K = Cout, N * Ho * Wo, Cin * KH * KW
+    d.amode, d.bmode, d.dmode = A_MK, B_CONVT, D_NCHW
+    d.lda = d.K
+    d.Cin, d.Hin, d.Win, d.Hout, d.Wout = Cin, H, W, Ho, Wo
+    d.stride, d.pad, d.dil = stride, pad, 1
+    d.HoWo = Ho * Wo
+    koff, kpos = conv_tables(Cin, KH, KW, H, W, 1, x.device, transposed=True)
+    d.koff, d.kpos = dptr(koff), dptr(kpos)
+    _epilogue(d, scale, shift, residual, relu)
+    ws = splitk_ws(x.device)
+    d.ws, d.ws_floats, d.splits = dptr(ws), ws.numel(), 0
+    gemm(d)
+    return out
+
+
+def linear_gemm(x, w, bias=None, relu=False, out=None):
+    """y[r][o] = act(x[r] . w[o] + b[o]) through the MFMA GEMM (many rows)."""
+    rows, K = x.shape
+    O = w.shape[0]
+    if out is None:
+        out = torch.empty((rows, O), dtype=torch.float32, device=x.device)
+    d = GemmDesc()
+    d.A, d.B, d.D = dptr(w), _p(x), _p(out)
+    d.M, d.N, d.K = O, rows, K
+    d.amode, d.bmode, d.dmode = A_MK, B_NK, D_DENSE
+    d.lda, d.ldb = K, x.stride(0)
+    d.sDm, d.sDn = 1, out.stride(0)
+    d.HoWo = 1
+    _epilogue(d, None, bias, None, relu)
+    ws = splitk_ws(x.device)
+    d.ws, d.ws_floats, d.splits = dptr(ws), ws.numel(), 0
+    gemm(d)
+    return out
+
+
+def linear(x, w, bias=None, relu=False, out=None):
+    """nn.Linear forward; rows <= 16 use the wave-per-output-row kernel, else the MFMA GEMM."""
+    rows, K = x.shape
+    O = w.shape[0]
+    if rows > 16:
+        return linear_gemm(x, w, bias, relu, out)
+    if out is None:
+        out = torch.empty((rows, O), dtype=torch.float32, device=x.device)
+    check(
+        _L().ivln_linear_skinny_f32(_p(x), x.stride(0), dptr(w), _p(bias), _p(out), out.stride(0), rows, K, O,
+                                    int(bool(relu)), stream_ptr()),
+        "ivln_linear_skinny_f32",
+    )
+    return out
+
+
+def groupnorm(x, gamma, beta, groups, eps=1e-5, relu=False, residual=None, out=None, x_img_stride=0,
+              y_img_stride=0, r_img_stride=0, N=None, C=None, HW=None):
+    if N is None:
+        N, C = x.shape[0], x.shape[1]
+        HW = x.shape[2] * x.shape[3]
+    if out is None:
+        out = torch.empty_like(x)
+    check(
+        _L().ivln_groupnorm_f32(_p(x), dptr(gamma), dptr(beta), _p(residual), _p(out), N, C, HW, groups, eps,
+                                int(bool(relu)), x_img_stride, y_img_stride, r_img_stride, None, None, stream_ptr()),
+        "ivln_groupnorm_f32",
+    )
+    return out
+
+
+def bn_fold(bn, scale, shift):
+    check(
+        _L().ivln_bn_fold_f32(dptr(bn.weight), dptr(bn.bias), dptr(bn.running_mean), dptr(bn.running_var), bn.eps,
+                              bn.num_features, dptr(scale), dptr(shift), stream_ptr()),
+        "ivln_bn_fold_f32",
+    )
+
+
+def bn_train_stats(x, bn, scale, shift, save_mean=None, save_rstd=None, update_running=True):
+    N, Cc, H, W = x.shape
+    mom = bn.momentum if bn.momentum is not None else 0.1
+    check(
+        _L().ivln_bn_train_stats_f32(dptr(x), N, Cc, H * W, dptr(bn.weight), dptr(bn.bias),
+                                     dptr(bn.running_mean) if update_running else None,
+                                     dptr(bn.running_var) if update_running else None, mom, bn.eps, dptr(scale),
+                                     dptr(shift), _p(save_mean), _p(save_rstd), stream_ptr()),
+        "ivln_bn_train_stats_f32",
+    )
+
+
+def scale_shift_relu_avgpool2(x, scale, shift, out=None):
+    N, Cc, H, W = x.shape
+    if out is None:
+        out = torch.empty((N, Cc, H // 2, W // 2), dtype=torch.float32, device=x.device)
+    check(_L().ivln_scale_shift_relu_avgpool2_f32(dptr(x), dptr(scale), dptr(shift), dptr(out), N, Cc, H, W,
+                                                   stream_ptr()), "ivln_scale_shift_relu_avgpool2_f32")
+    return out
+
+
+def pool2d(x, k, s, p, mode, out=None):
+    N, Cc, H, W = x.shape
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    if out is None:
+        out = torch.empty((N, Cc, Ho, Wo), dtype=torch.float32, device=x.device)
+    check(_L().ivln_pool2d_f32(dptr(x), dptr(out), N * Cc, H, W, k, s, p, 0 if mode == "max" else 1, stream_ptr()),
+          "ivln_pool2d_f32")
+    return out
+
+
+def map_features(occ_u8, sem_u8, classes=13, out=None):
+    B, R, Cc = occ_u8.shape
+    if out is None:
+        out = torch.empty((B, classes + 1, R, Cc), dtype=torch.float32, device=occ_u8.device)
+    check(_L().ivln_map_features_f32(dptr(occ_u8), dptr(sem_u8), dptr(out), B, R * Cc, classes, stream_ptr()),
+          "ivln_map_features_f32")
+    return out
+
+
+def embed_lengths(tokens_i64, table):
+    B, L = tokens_i64.shape
+    V, E = table.shape
+    emb = torch.empty((B * L, E), dtype=torch.float32, device=table.device)
+    lengths = torch.empty((B,), dtype=torch.int32, device=table.device)
+    check(_L().ivln_embed_lengths(dptr(tokens_i64), dptr(table), B, L, E, V, dptr(emb), dptr(lengths), stream_ptr()),
+          "ivln_embed_lengths")
+    return emb, lengths
+
+
+def lstm_bidir(gx_f, gx_r, whh_f, whh_r, bhh_f, bhh_r, lengths, B, L, H, save=False):
+    out = torch.empty((B, 2 * H, L), dtype=torch.float32, device=gx_f.device)
+    gates = cs = None
+    if save:
+        gates = torch.zeros((B, 2, L, 4 * H), dtype=torch.float32, device=gx_f.device)
+        cs = torch.zeros((B, 2, L, H), dtype=torch.float32, device=gx_f.device)
+    check(
+        _L().ivln_lstm_bidir_fwd_f32(dptr(gx_f), dptr(gx_r), dptr(whh_f), dptr(whh_r), dptr(bhh_f), dptr(bhh_r),
+                                     dptr(lengths), B, L, H, dptr(out), _p(gates), _p(cs), stream_ptr()),
+        "ivln_lstm_bidir_fwd_f32",
+    )
+    return out, gates, cs
+
+
+def gru_step(x, gi_pre, h_in, mask_u8, w_ih, w_hh, b_ih, b_hh, h_out, h_out2=None, saves=None):
+    """One masked GRU step over `rows` rows; x (rows,I) or gi_pre (rows,3H); h_in/h_out strided."""
+    rows = h_in.shape[0]
+    H = w_hh.shape[1]
+    s = saves or (None, None, None, None)
+    check(
+        _L().ivln_gru_step_f32(
+            _p(x), x.stride(0) if x is not None else 0, w_ih.shape[1], _p(gi_pre),
+            gi_pre.stride(0) if gi_pre is not None else 0, _p(h_in), h_in.stride(0), _p(mask_u8), dptr(w_ih),
+            dptr(w_hh), dptr(b_ih), dptr(b_hh), _p(h_out), h_out.stride(0), _p(h_out2),
+            h_out2.stride(0) if h_out2 is not None else 0, rows, H, _p(s[0]), _p(s[1]), _p(s[2]), _p(s[3]),
+            stream_ptr(),
+        ),
+        "ivln_gru_step_f32",
+    )
+
+
+def attn(q, k, v, valid_len, scale, out, save_attn=None):
+    """q (rows,Ck) strided rows; k (rows,Ck,I), v (rows,Cv,I) with image strides; out (rows,Cv) strided."""
+    rows, Ck = q.shape
+    Cv, I = v.shape[1], v.shape[2]
+    check(
+        _L().ivln_attn_fwd_f32(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(valid_len), scale, rows,
+                               Ck, Cv, I, _p(out), out.stride(0), _p(save_attn), stream_ptr()),
+        "ivln_attn_fwd_f32",
+    )
+    return out
+
+
+def prev_action_embed(prev_actions_i64, mask_u8, table, out1, out2=None):
+    rows = prev_actions_i64.numel()
+    n_emb, E = table.shape
+    check(
+        _L().ivln_prev_action_embed_f32(dptr(prev_actions_i64), dptr(mask_u8), dptr(table), rows, E, n_emb, _p(out1),
+                                        out1.stride(0), _p(out2), out2.stride(0) if out2 is not None else 0,
+                                        stream_ptr()),
+        "ivln_prev_action_embed_f32",
+    )
+
+
+def argmax_rows(x):
+    rows, Cc = x.shape
+    out = torch.empty((rows, 1), dtype=torch.int64, device=x.device)
+    check(_L().ivln_argmax_rows(dptr(x), rows, Cc, dptr(out), stream_ptr()), "ivln_argmax_rows")
+    return out
+
+
+def argmax_channels_u8(x):
+    N, Cc, H, W = x.shape
+    out = torch.empty((N, 1, H, W), dtype=torch.uint8, device=x.device)
+    check(_L().ivln_argmax_channels_u8(dptr(x), N, Cc, H * W, dptr(out), stream_ptr()), "ivln_argmax_channels_u8")
+    return out
+
+
+def rgb_resize_normalize(rgb_u8_nhwc, Ho, Wo):
+    B, Hi, Wi, _ = rgb_u8_nhwc.shape
+    out = torch.empty((B, 3, Ho, Wo), dtype=torch.float32, device=rgb_u8_nhwc.device)
+    check(_L().ivln_rgb_resize_normalize_f32(dptr(rgb_u8_nhwc), B, Hi, Wi, Ho, Wo, dptr(out), stream_ptr()),
+          "ivln_rgb_resize_normalize_f32")
+    return out
+
+
+def affine(x, sub, div):
+    out = torch.empty_like(x)
+    check(_L().ivln_affine_f32(dptr(x), dptr(out), x.numel(), sub, div, stream_ptr()), "ivln_affine_f32")
+    return out
+
+
+def add(a, b, relu=False, out=None):
+    if out is None:
+        out = torch.empty_like(a)
+    check(_L().ivln_add_f32(dptr(a), dptr(b), dptr(out), a.numel(), int(bool(relu)), stream_ptr()), "ivln_add_f32")
+    return out
+
+
+def copy2d(src, dst, rows, cols, broadcast_rows=False):
+    check(
+        _L().ivln_copy2d_f32(_p(src), src.stride(0) if src.dim() > 1 else cols, _p(dst), dst.stride(0), rows, cols,
+                             int(bool(broadcast_rows)), stream_ptr()),
+        "ivln_copy2d_f32",
+    )

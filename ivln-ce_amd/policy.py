@@ -1,0 +1,331 @@
+"""MapCMA policy plugin: same registry name, constructor, `act` / `act_iterative` /
+`build_distribution` surface and `state_dict()` keys as the reference
+(ivlnce_baselines/models/map_cma_policy.py:28-368, models/policy.py:12-83,
+common/utils.py:149-185), forward AND backward on HIP kernels.
+
+torch.nn modules hold parameters only.  The whole net forward is one torch.autograd.Function whose
+backward runs the hand-written HIP backward kernels (train.py), so `loss.backward()` in a trainer
+(base_il_trainer.py:211) works unchanged.
+"""
+from typing import Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from . import ops
+from .aux_losses import AuxLosses
+from .encoders import InstructionEncoder, SemanticMapEncoder, VlnResnetDepthEncoder, build_rnn_state_encoder
+from .registry import baseline_registry
+
+try:  # pragma: no cover
+    from habitat_baselines.rl.ppo.policy import Net, Policy  # type: ignore
+except Exception:  # noqa: BLE001
+
+    class Net(nn.Module):
+        pass
+
+    class Policy(nn.Module):
+        pass
+
+
+class CustomFixedCategorical(torch.distributions.Categorical):
+    """common/utils.py:149-169."""
+
+    def sample(self, sample_shape=torch.Size()):  # noqa: B008
+        return super().sample(sample_shape).unsqueeze(-1)
+
+    def log_prob(self, actions: Tensor) -> Tensor:
+        return super().log_prob(actions.squeeze(-1)).view(actions.size(0), -1).sum(-1).unsqueeze(-1)
+
+    def mode(self):
+        return self.probs.argmax(dim=-1, keepdim=True)
+
+
+class CategoricalNet(nn.Module):
+    """common/utils.py:172-185; the 512->4 linear runs on the HIP skinny/MFMA linear."""
+
+    def __init__(self, num_inputs: int, num_outputs: int) -> None:
+        super().__init__()
+        self.linear = nn.Linear(num_inputs, num_outputs)
+        self.num_outputs = num_outputs
+        nn.init.orthogonal_(self.linear.weight, gain=0.01)
+        nn.init.constant_(self.linear.bias, 0)
+
+    def raw_logits(self, x: Tensor) -> Tensor:
+        if x.shape[-1] != self.num_outputs:
+            if x.requires_grad or (torch.is_grad_enabled() and self.linear.weight.requires_grad):
+                from .train import LinearFn
+
+                x = LinearFn.apply(x, self.linear.weight, self.linear.bias)
+            else:
+                x = ops.linear(x.contiguous(), self.linear.weight, self.linear.bias)
+        return x
+
+    def forward(self, x: Tensor) -> CustomFixedCategorical:
+        return CustomFixedCategorical(logits=self.raw_logits(x))
+
+
+class MapCMANet(Net):
+    """Cross-modal attention network: instruction bi-LSTM, DD-PPO depth ResNet, semantic-map CNN,
+    two GRU state encoders and three attentions (map_cma_policy.py:103-368)."""
+
+    def __init__(self, observation_space, config, num_actions):
+        super().__init__()
+        model_config = config.MODEL
+        self.model_config = model_config
+        model_config.defrost()
+        model_config.INSTRUCTION_ENCODER.final_state_only = False
+        model_config.freeze()
+
+        assert model_config.SEMANTIC_MAP_ENCODER.classname in [
+            "SemanticMapEncoder"
+        ], "SEMANTIC_MAP_ENCODER.classname must be SemanticMapEncoder"
+        sm = model_config.SEMANTIC_MAP_ENCODER
+        self.map_encoder = SemanticMapEncoder(
+            observation_space, sm.num_semantic_classes, sm.channels, sm.last_ch_mult, sm.trainable, sm.from_pretrained,
+            sm.checkpoint,
+        )
+        self.instruction_encoder = InstructionEncoder(model_config.INSTRUCTION_ENCODER)
+        assert model_config.DEPTH_ENCODER.cnn_type in [
+            "VlnResnetDepthEncoder"
+        ], "DEPTH_ENCODER.cnn_type must be VlnResnetDepthEncoder"
+        self.depth_encoder = VlnResnetDepthEncoder(
+            observation_space,
+            output_size=model_config.DEPTH_ENCODER.output_size,
+            checkpoint=model_config.DEPTH_ENCODER.ddppo_checkpoint,
+            backbone=model_config.DEPTH_ENCODER.backbone,
+            spatial_output=True,
+        )
+        self.prev_action_embedding = nn.Embedding(num_actions + 1, 32)
+        hidden_size = model_config.STATE_ENCODER.hidden_size
+        self._hidden_size = hidden_size
+        self.depth_linear = nn.Sequential(
+            nn.Flatten(),
+            nn.Linear(int(np.prod(self.depth_encoder.output_shape)), model_config.DEPTH_ENCODER.output_size),
+            nn.ReLU(True),
+        )
+        self.map_linear = nn.Sequential(
+            nn.Flatten(),
+            nn.Linear(int(np.prod(self.map_encoder.output_shape)), model_config.SEMANTIC_MAP_ENCODER.output_size),
+            nn.ReLU(True),
+        )
+        rnn_input_size = (
+            model_config.DEPTH_ENCODER.output_size
+            + model_config.SEMANTIC_MAP_ENCODER.output_size
+            + self.prev_action_embedding.embedding_dim
+        )
+        self.state_encoder = build_rnn_state_encoder(
+            input_size=rnn_input_size, hidden_size=hidden_size, rnn_type=model_config.STATE_ENCODER.rnn_type, num_layers=1
+        )
+        self._output_size = (
+            hidden_size
+            + model_config.DEPTH_ENCODER.output_size
+            + self.instruction_encoder.output_size
+            + model_config.SEMANTIC_MAP_ENCODER.output_size
+        )
+        self.dep_kv = nn.Conv1d(
+            self.depth_encoder.output_shape[0], hidden_size // 2 + model_config.DEPTH_ENCODER.output_size, 1
+        )
+        self.map_kv = nn.Conv1d(
+            self.map_encoder.output_shape[0], hidden_size // 2 + model_config.SEMANTIC_MAP_ENCODER.output_size, 1
+        )
+        self.state_q = nn.Linear(hidden_size, hidden_size // 2)
+        self.text_k = nn.Conv1d(self.instruction_encoder.output_size, hidden_size // 2, 1)
+        self.text_q = nn.Linear(self.instruction_encoder.output_size, hidden_size // 2)
+        self.register_buffer("_scale", torch.tensor(1.0 / ((hidden_size // 2) ** 0.5)))
+        self.second_state_compress = nn.Sequential(
+            nn.Linear(self._output_size + self.prev_action_embedding.embedding_dim, self._hidden_size), nn.ReLU(True)
+        )
+        self.second_state_encoder = build_rnn_state_encoder(
+            input_size=self._hidden_size, hidden_size=self._hidden_size,
+            rnn_type=model_config.STATE_ENCODER.rnn_type, num_layers=1,
+        )
+        self._output_size = model_config.STATE_ENCODER.hidden_size
+        self.progress_monitor = nn.Linear(self.output_size, 1)
+        self._init_layers()
+        self.train()
+        if not model_config.SEMANTIC_MAP_ENCODER.trainable:
+            self.map_encoder.eval()
+        self._scale_f = float(1.0 / ((hidden_size // 2) ** 0.5))
+
+    @property
+    def output_size(self):
+        return self._output_size
+
+    @property
+    def is_blind(self):
+        return self.depth_encoder.is_blind
+
+    @property
+    def num_recurrent_layers(self):
+        return self.state_encoder.num_recurrent_layers + self.second_state_encoder.num_recurrent_layers
+
+    def _init_layers(self):
+        if self.model_config.PROGRESS_MONITOR.use:
+            nn.init.kaiming_normal_(self.progress_monitor.weight, nonlinearity="tanh")
+            nn.init.constant_(self.progress_monitor.bias, 0)
+
+    # ------------------------------------------------------------------------------------------
+    def forward_hip(self, observations, rnn_states, prev_actions, action_masks, save=None):
+        """HIP forward of map_cma_policy.py:276-353.  Returns (features (rows,512), rnn_states_out
+        (N,2,512)).  `save` (dict) collects what the HIP backward needs."""
+        mc = self.model_config
+        dev = rnn_states.device
+        H = self._hidden_size
+        h2 = H // 2
+        N = rnn_states.shape[0]
+        rnn_states = rnn_states.to(torch.float32).contiguous()
+        masks_u8 = action_masks.reshape(-1).to(torch.uint8).contiguous()
+        rows = masks_u8.shape[0]
+        prev_actions = prev_actions.reshape(-1).long().contiguous()
+
+        s_txt = {} if save is not None else None
+        s_map = [] if save is not None else None
+        txt, lengths = self.instruction_encoder(observations, s_txt)  # (rows,256,L)
+        dep = self.depth_encoder(observations)  # (rows,192,4,4)
+        mp = self.map_encoder(observations, s_map)  # (rows,128,4,4)
+        if mc.ablate_instruction:
+            txt = torch.zeros_like(txt)
+        if mc.ablate_depth:
+            dep = torch.zeros_like(dep)
+        if mc.ablate_map:
+            mp = torch.zeros_like(mp)
+        L = txt.shape[2]
+        Cd, Cm = dep.shape[1], mp.shape[1]
+        P = dep.shape[2] * dep.shape[3]
+        d_out = self.depth_linear[1].out_features
+        m_out = self.map_linear[1].out_features
+        E = self.prev_action_embedding.embedding_dim
+
+        # state_in = [dep_in | map_in | prev]; x2 = [state | text | dep' | map' | prev]
+        state_in = torch.empty((rows, d_out + m_out + E), dtype=torch.float32, device=dev)
+        x2w = H + self.instruction_encoder.output_size + d_out + m_out + E
+        x2 = torch.empty((rows, x2w), dtype=torch.float32, device=dev)
+        o_txt, o_dep, o_map, o_prev = H, H + 256, H + 256 + d_out, H + 256 + d_out + m_out
+        ops.prev_action_embed(prev_actions, masks_u8, self.prev_action_embedding.weight, state_in[:, d_out + m_out:],
+                              x2[:, o_prev:])
+        dl, ml = self.depth_linear[1], self.map_linear[1]
+        dep_flat, mp_flat = dep.view(rows, -1), mp.view(rows, -1)
+        ops.linear(dep_flat, dl.weight, dl.bias, relu=True, out=state_in[:, :d_out])
+        ops.linear(mp_flat, ml.weight, ml.bias, relu=True, out=state_in[:, d_out:d_out + m_out])
+
+        rnn_out = torch.empty_like(rnn_states)
+        s_g1 = {} if save is not None else None
+        s_g2 = {} if save is not None else None
+        state = x2[:, :H]
+        self.state_encoder(state_in, rnn_states[:, 0], masks_u8, state, rnn_out[:, 0], s_g1)
+
+        q1 = ops.linear(state, self.state_q.weight, self.state_q.bias)
+        tk = ops.conv2d(txt.view(rows, -1, 1, L), self.text_k.weight.view(h2, -1, 1, 1), shift=self.text_k.bias)
+        a_txt = torch.empty((rows, L), dtype=torch.float32, device=dev) if save is not None else None
+        text = x2[:, o_txt:o_txt + 256]
+        ops.attn(q1, tk.view(rows, h2, L), txt, lengths, self._scale_f, text, a_txt)
+
+        dkv = ops.conv2d(dep.view(rows, Cd, 1, P), self.dep_kv.weight.view(-1, Cd, 1, 1), shift=self.dep_kv.bias)
+        mkv = ops.conv2d(mp.view(rows, Cm, 1, P), self.map_kv.weight.view(-1, Cm, 1, 1), shift=self.map_kv.bias)
+        dkv, mkv = dkv.view(rows, -1, P), mkv.view(rows, -1, P)
+        q2 = ops.linear(text, self.text_q.weight, self.text_q.bias)
+        a_dep = torch.empty((rows, P), dtype=torch.float32, device=dev) if save is not None else None
+        a_map = torch.empty((rows, P), dtype=torch.float32, device=dev) if save is not None else None
+        ops.attn(q2, dkv[:, :h2], dkv[:, h2:], None, self._scale_f, x2[:, o_dep:o_dep + d_out], a_dep)
+        ops.attn(q2, mkv[:, :h2], mkv[:, h2:], None, self._scale_f, x2[:, o_map:o_map + m_out], a_map)
+
+        sc = self.second_state_compress[0]
+        c2 = ops.linear(x2, sc.weight, sc.bias, relu=True)
+        feats = torch.empty((rows, H), dtype=torch.float32, device=dev)
+        self.second_state_encoder(c2, rnn_states[:, 1], masks_u8, feats, rnn_out[:, 1], s_g2)
+
+        if save is not None:
+            save.update(
+                txt=s_txt, map=s_map, g1=s_g1, g2=s_g2, dep=dep, mp=mp, txt_out=txt, lengths=lengths,
+                state_in=state_in, x2=x2, q1=q1, tk=tk, a_txt=a_txt, dkv=dkv, mkv=mkv, q2=q2, a_dep=a_dep,
+                a_map=a_map, c2=c2, feats=feats, rows=rows, N=N, L=L, P=P, offs=(o_txt, o_dep, o_map, o_prev),
+                masks=masks_u8, prev_actions=prev_actions, depth_from_features="depth_features" in observations,
+            )
+        return feats, rnn_out
+
+    def forward(self, observations, rnn_states, prev_actions, action_masks, episode_masks=None, tour_masks=None):
+        """Same signature/return as the reference forward (map_cma_policy.py:276-368); the MapCMA net
+        only consumes `action_masks` (episode/tour masks default to it, :284-287)."""
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if needs_grad:
+            from .train import MapCMAForwardFn
+
+            feats, rnn_out = MapCMAForwardFn.run(self, observations, rnn_states, prev_actions, action_masks)
+        else:
+            feats, rnn_out = self.forward_hip(observations, rnn_states, prev_actions, action_masks)
+        if self.model_config.PROGRESS_MONITOR.use and AuxLosses.is_active():
+            from .train import progress_monitor_loss
+
+            loss = progress_monitor_loss(self, feats, observations["progress"])
+            AuxLosses.register_loss("progress_monitor", loss, self.model_config.PROGRESS_MONITOR.alpha)
+        return feats, rnn_out
+
+
+class ILPolicy(Policy):
+    """models/policy.py:12-83."""
+
+    def __init__(self, net, dim_actions):
+        nn.Module.__init__(self)
+        self.net = net
+        self.dim_actions = dim_actions
+        self.action_distribution = CategoricalNet(self.net.output_size, self.dim_actions)
+
+    def forward(self, *x):
+        raise NotImplementedError
+
+    def _act(self, features, deterministic):
+        logits = self.action_distribution.raw_logits(features)
+        if deterministic:  # distribution.mode() == argmax of probs == argmax of logits
+            return ops.argmax_rows(logits.contiguous())
+        return CustomFixedCategorical(logits=logits).sample()
+
+    def act(self, observations, rnn_states, prev_actions, masks, deterministic=False):
+        features, rnn_states = self.net(observations, rnn_states, prev_actions, masks)
+        return self._act(features, deterministic), rnn_states
+
+    def act_iterative(self, observations, rnn_hidden_states, prev_actions, agent_episode_not_done_masks,
+                      sim_episode_not_done_masks, tour_not_done_masks, action_masks, deterministic=False):
+        return self.act(observations, rnn_hidden_states, prev_actions, agent_episode_not_done_masks,
+                        deterministic=deterministic)
+
+    def get_value(self, *args, **kwargs):
+        raise NotImplementedError
+
+    def evaluate_actions(self, *args, **kwargs):
+        raise NotImplementedError
+
+    def build_distribution(self, observations, rnn_states, prev_actions, masks) -> CustomFixedCategorical:
+        features, rnn_states = self.net(observations, rnn_states, prev_actions, masks)
+        return self.action_distribution(features)
+
+
+@baseline_registry.register_policy
+class MapCMAPolicy(ILPolicy):
+    def __init__(self, observation_space, action_space, config):
+        super().__init__(
+            MapCMANet(observation_space=observation_space, config=config, num_actions=action_space.n),
+            action_space.n,
+        )
+
+    def act_iterative(self, observations, rnn_hidden_states, prev_actions, agent_episode_not_done_masks,
+                      sim_episode_not_done_masks, tour_not_done_masks, action_masks, deterministic=False):
+        # quirk Q11: only the agent-episode mask reaches the net (map_cma_policy.py:56-63)
+        features, rnn_hidden_states = self.net(
+            observations, rnn_hidden_states, prev_actions, action_masks=agent_episode_not_done_masks,
+            episode_masks=None, tour_masks=None,
+        )
+        return self._act(features, deterministic), rnn_hidden_states
+
+    def build_distribution(self, observations, rnn_hidden_states, prev_actions, agent_episode_not_done_masks,
+                           tour_not_done_masks=None) -> Tuple[CustomFixedCategorical, Tensor]:
+        features, rnn_hidden_states = self.net(
+            observations, rnn_hidden_states, prev_actions, action_masks=agent_episode_not_done_masks
+        )
+        return self.action_distribution(features), rnn_hidden_states
+
+    @classmethod
+    def from_config(cls, config, observation_space, action_space):
+        return cls(observation_space=observation_space, action_space=action_space, config=config)

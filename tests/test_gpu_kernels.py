@@ -1,0 +1,215 @@
+"""Per-kernel GPU parity against plain torch fp32 on CPU (floating-point kernels: tolerance stated
+per test; fp32 MFMA is an exact fmaf chain so only the summation order differs)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _close(got, ref, atol, rtol=1e-4):
+    got, ref = got.detach().cpu(), ref.detach().cpu()
+    err = (got - ref).abs().max().item()
+    assert torch.allclose(got, ref, atol=atol, rtol=rtol), f"max err {err:.3e}, ref max {ref.abs().max().item():.3e}"
+
+
+@pytest.mark.parametrize(
+    "N,Cin,H,W,Cout,k,s,p",
+    [
+        (2, 1, 128, 128, 32, 7, 2, 3),    # DD-PPO stem
+        (4, 32, 32, 32, 32, 3, 1, 1),     # layer1 3x3 (M<=32 -> 32x128 tile)
+        (3, 128, 32, 32, 64, 1, 1, 0),    # 1x1
+        (2, 128, 32, 32, 256, 1, 2, 0),   # strided 1x1 downsample
+        (2, 64, 32, 32, 64, 3, 2, 1),     # strided 3x3
+        (1, 256, 4, 4, 1024, 1, 1, 0),    # pixel-starved (N<=32 -> 128x32 tile)
+        (4, 1024, 4, 4, 128, 3, 1, 1),    # compression conv: split-K
+        (2, 14, 64, 64, 32, 7, 1, 3),     # map CNN layer 1
+        (3, 128, 8, 8, 128, 7, 1, 3),     # map CNN layer 4
+        (1, 3, 37, 53, 5, 3, 1, 1),       # ragged sizes
+    ],
+)
+def test_conv2d(N, Cin, H, W, Cout, k, s, p):
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(N * 1000 + Cin + k)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x, w, b, stride=s, padding=p)
+    got = ops.conv2d(x.to(DEV), w.to(DEV), stride=s, pad=p, shift=b.to(DEV))
+    _close(got, ref, 2e-5)
+    # fused epilogue: scale/shift + residual + relu
+    sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    res = torch.randn_like(ref)
+    ref2 = F.relu(F.conv2d(x, w, None, stride=s, padding=p) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) + res)
+    got2 = ops.conv2d(x.to(DEV), w.to(DEV), stride=s, pad=p, scale=sc.to(DEV), shift=sh.to(DEV),
+                      residual=res.to(DEV), relu=True)
+    _close(got2, ref2, 3e-5)
+
+
+@pytest.mark.parametrize("N,Cin,H,W,Cout,k,s,p,op", [(2, 64, 8, 8, 32, 3, 2, 1, 1), (1, 32, 16, 16, 13, 2, 2, 0, 0),
+                                                      (2, 16, 5, 7, 8, 3, 2, 1, 1)])
+def test_conv_transpose2d(N, Cin, H, W, Cout, k, s, p, op):
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cin, Cout, k, k, generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv_transpose2d(x, w, b, stride=s, padding=p, output_padding=op)
+    got = ops.conv_transpose2d(x.to(DEV), w.permute(1, 0, 2, 3).contiguous().to(DEV), s, p, op, shift=b.to(DEV))
+    _close(got, ref, 2e-5)
+
+
+@pytest.mark.parametrize("rows,K,O", [(1, 512, 4), (4, 3072, 128), (8, 1184, 512), (5, 50, 512), (64, 416, 1536),
+                                      (600, 50, 512), (30, 2048, 256)])
+def test_linear(rows, K, O):
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(rows + K)
+    x = torch.randn(rows, K, generator=g)
+    w = torch.randn(O, K, generator=g) / K ** 0.5
+    b = torch.randn(O, generator=g)
+    _close(ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), relu=True), F.relu(F.linear(x, w, b)), 2e-5)
+    # strided destination (concat-free writes)
+    buf = torch.zeros(rows, O + 7, device=DEV)
+    ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), out=buf[:, 3:3 + O]) if (rows > 16) else None
+    if rows > 16:
+        _close(buf[:, 3:3 + O], F.linear(x, w, b), 2e-5)
+        assert float(buf[:, :3].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("N,C,H,W,G,res", [(2, 32, 64, 64, 16, False), (3, 128, 32, 32, 16, True), (4, 128, 4, 4, 1, False),
+                                           (2, 1024, 4, 4, 16, True)])
+def test_groupnorm(N, C, H, W, G, res):
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(N, C, H, W, generator=g) * 2 + 0.3
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    r = torch.randn(N, C, H, W, generator=g) if res else None
+    ref = F.group_norm(x, G, gamma, beta, 1e-5)
+    if res:
+        ref = ref + r
+    ref = F.relu(ref)
+    got = ops.groupnorm(x.to(DEV), gamma.to(DEV), beta.to(DEV), G, 1e-5, relu=True,
+                        residual=r.to(DEV) if res else None)
+    _close(got, ref, 2e-5)
+
+
+def test_pools_and_map_features():
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 5, 33, 40, generator=g)
+    _close(ops.pool2d(x.to(DEV), 3, 2, 1, "max"), F.max_pool2d(x, 3, 2, 1), 0)
+    x2 = torch.randn(2, 1, 64, 64, generator=g)
+    _close(ops.pool2d(x2.to(DEV), 2, 2, 0, "avg"), F.avg_pool2d(x2, 2), 1e-6)
+    occ = (torch.rand(3, 64, 64, generator=g) < 0.5).to(torch.uint8)
+    sem = torch.randint(0, 13, (3, 64, 64), generator=g).to(torch.uint8)
+    ref = torch.cat((occ.unsqueeze(1), F.one_hot(sem.long(), 13).permute(0, 3, 1, 2)), 1).float()
+    _close(ops.map_features(occ.to(DEV), sem.to(DEV)), ref, 0)
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_cbra_block(train):
+    import torch.nn as nn
+
+    from ivln_ce_amd.encoders import CBRA
+
+    torch.manual_seed(3)
+    blk = CBRA(14, 32)
+    blk.conv[1].running_mean.normal_(0, 0.1)
+    blk.conv[1].running_var.uniform_(0.5, 1.5)
+    blk.train(train)
+    import copy
+
+    ref_blk = copy.deepcopy(blk)
+    x = torch.randn(4, 14, 64, 64)
+    ref = ref_blk.conv(x)
+    blk = blk.to(DEV)
+    with torch.no_grad():
+        got = blk.forward_hip(x.to(DEV))
+    _close(got, ref, 3e-5)
+    if train:
+        _close(blk.conv[1].running_mean, ref_blk.conv[1].running_mean, 1e-6)
+        _close(blk.conv[1].running_var, ref_blk.conv[1].running_var, 1e-6)
+
+
+def test_lstm_bidir_matches_packed_torch_lstm():
+    import torch.nn as nn
+
+    from ivln_ce_amd import ops
+
+    torch.manual_seed(5)
+    B, L, E, H = 4, 37, 50, 128
+    lens = [37, 5, 20, 1]
+    rnn = nn.LSTM(E, H, bidirectional=True)
+    emb_table = torch.randn(100, E)
+    emb_table[0] = 0
+    tokens = torch.zeros(B, L, dtype=torch.long)
+    for b, n in enumerate(lens):
+        tokens[b, :n] = torch.randint(1, 100, (n,))
+    x = emb_table[tokens]
+    packed = nn.utils.rnn.pack_padded_sequence(x, torch.tensor(lens), batch_first=True, enforce_sorted=False)
+    ref = nn.utils.rnn.pad_packed_sequence(rnn(packed)[0], batch_first=True)[0].permute(0, 2, 1)
+    emb, lengths = ops.embed_lengths(tokens.to(DEV), emb_table.to(DEV))
+    assert lengths.cpu().tolist() == lens
+    p = {k: v.detach().to(DEV) for k, v in rnn.named_parameters()}
+    gx_f = ops.linear_gemm(emb, p["weight_ih_l0"], p["bias_ih_l0"])
+    gx_r = ops.linear_gemm(emb, p["weight_ih_l0_reverse"], p["bias_ih_l0_reverse"])
+    out, _, _ = ops.lstm_bidir(gx_f, gx_r, p["weight_hh_l0"], p["weight_hh_l0_reverse"], p["bias_hh_l0"],
+                               p["bias_hh_l0_reverse"], lengths, B, L, H)
+    _close(out, ref, 2e-5)
+
+
+@pytest.mark.parametrize("rows,I", [(3, 416), (8, 512), (11, 416)])
+def test_gru_step(rows, I):
+    import torch.nn as nn
+
+    from ivln_ce_amd import ops
+
+    torch.manual_seed(rows)
+    H = 512
+    rnn = nn.GRU(I, H)
+    x = torch.randn(rows, I)
+    h = torch.randn(rows, 2, H)
+    mask = (torch.rand(rows) < 0.6).to(torch.uint8)
+    ref, _ = rnn(x.unsqueeze(0), (h[:, 1] * mask.view(-1, 1).float()).unsqueeze(0))
+    p = {k: v.detach().to(DEV) for k, v in rnn.named_parameters()}
+    hd = h.to(DEV)
+    out = torch.zeros(rows, H + 8, device=DEV)
+    out2 = torch.zeros(rows, 2, H, device=DEV)
+    ops.gru_step(x.to(DEV), None, hd[:, 1], mask.to(DEV), p["weight_ih_l0"], p["weight_hh_l0"], p["bias_ih_l0"],
+                 p["bias_hh_l0"], out[:, 4:4 + H], out2[:, 1])
+    _close(out[:, 4:4 + H], ref[0], 2e-5)
+    _close(out2[:, 1], ref[0], 2e-5)
+    # precomputed-gi path (sequence mode)
+    gi = F.linear(x, rnn.weight_ih_l0, rnn.bias_ih_l0)
+    out3 = torch.zeros(rows, H, device=DEV)
+    ops.gru_step(None, gi.detach().to(DEV), hd[:, 1], mask.to(DEV), p["weight_ih_l0"], p["weight_hh_l0"],
+                 p["bias_ih_l0"], p["bias_hh_l0"], out3)
+    _close(out3, ref[0], 2e-5)
+
+
+def test_attention():
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(9)
+    rows, Ck, Cv, I = 5, 256, 128, 200
+    q = torch.randn(rows, Ck, generator=g)
+    k = torch.randn(rows, Ck, I, generator=g)
+    v = torch.randn(rows, Cv, I, generator=g)
+    lens = torch.tensor([200, 3, 77, 1, 150], dtype=torch.int32)
+    mask = torch.arange(I).view(1, -1) >= lens.view(-1, 1)
+    logits = torch.einsum("nc,nci->ni", q, k) - mask.float() * 1e8
+    ref = torch.einsum("ni,nci->nc", F.softmax(logits * 0.0625, 1), v)
+    out = torch.zeros(rows, Cv + 3, device=DEV)
+    ops.attn(q.to(DEV), k.to(DEV), v.to(DEV), lens.to(DEV), 0.0625, out[:, :Cv])
+    _close(out[:, :Cv], ref, 2e-5)
+    ref2 = torch.einsum("ni,nci->nc", F.softmax(torch.einsum("nc,nci->ni", q, k[:, :, :16]) * 0.0625, 1), v[:, :, :16])
+    out2 = torch.zeros(rows, Cv, device=DEV)
+    ops.attn(q.to(DEV), k[:, :, :16].contiguous().to(DEV), v[:, :, :16].contiguous().to(DEV), None, 0.0625, out2)
+    _close(out2, ref2, 2e-5)

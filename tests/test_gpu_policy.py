@@ -1,0 +1,123 @@
+"""GPU parity of the HIP MapCMA policy forward (through the registry plugin) against the goldens
+produced by the reference's own MapCMAPolicy, and against the torch-CPU oracle on other shapes.
+fp32 MFMA == fmaf chain, so differences are summation-order only: tolerance 2e-4 abs on
+features/states (values O(1)), 1e-4 on log-probs."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+G = os.path.join(os.path.dirname(__file__), "golden")
+ATOL = 2e-4
+
+
+def make_policy(use_pm=False, train=False):
+    from det_init import det_fill
+
+    from ivln_ce_amd.config import get_config
+    from ivln_ce_amd.policy import MapCMAPolicy
+    from ivln_ce_amd.spaces import Box, Dict, Discrete
+
+    cfg = get_config(opts=[
+        "MODEL.policy_name", "MapCMAPolicy", "MODEL.INSTRUCTION_ENCODER.use_pretrained_embeddings", False,
+        "MODEL.DEPTH_ENCODER.ddppo_checkpoint", "NONE", "MODEL.PROGRESS_MONITOR.use", use_pm,
+    ])
+    space = Dict({
+        "depth": Box(0.0, 1.0, (256, 256, 1), np.float32), "occupancy_map": Box(0, 255, (64, 64), np.uint8),
+        "semantic_map": Box(0, 255, (64, 64), np.uint8), "instruction": Box(0, 2504, (200,), np.int64),
+    })
+    pol = MapCMAPolicy.from_config(cfg, space, Discrete(4))
+    det_fill(pol, seed=0)
+    pol = pol.to("cuda:0")
+    pol.train() if train else pol.eval()
+    return pol
+
+
+def _err(name, got, ref, log):
+    e = float(np.abs(got - ref).max())
+    log.append(f"{name}: max|err|={e:.3e} (ref max {float(np.abs(ref).max()):.3e})")
+    return e
+
+
+def test_state_dict_keys_identical_to_oracle():
+    from oracle.policy_ref import MapCMAPolicyRef
+
+    pol = make_policy()
+    ref = MapCMAPolicyRef()
+    a = {k: tuple(v.shape) for k, v in pol.state_dict().items()}
+    b = {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+    assert a == b
+
+
+def test_act_matches_reference_golden():
+    g = np.load(os.path.join(G, "policy_act.npz"))
+    pol = make_policy()
+    dev = torch.device("cuda:0")
+    log = []
+    feats = {}
+    pol.net.depth_encoder.visual_encoder.register_forward_hook(lambda m, i, o: feats.__setitem__("depth", o.detach().clone()))
+    instr = torch.from_numpy(g["instruction"]).to(dev)
+    worst = 0.0
+    for t in range(2):
+        obs = {
+            "depth": torch.from_numpy(g[f"depth_{t}"]).to(dev), "occupancy_map": torch.from_numpy(g[f"occ_{t}"]).to(dev),
+            "semantic_map": torch.from_numpy(g[f"sem_{t}"]).to(dev), "instruction": instr,
+        }
+        with torch.no_grad():
+            txt, lengths = pol.net.instruction_encoder(obs)
+            mp = pol.net.map_encoder(obs)
+            f, rnn = pol.net(obs, torch.from_numpy(g[f"rnn_in_{t}"]).to(dev), torch.from_numpy(g[f"prev_{t}"]).to(dev),
+                             torch.from_numpy(g[f"masks_{t}"]).to(dev))
+            logits = pol.action_distribution.raw_logits(f)
+            act = pol._act(f, True)
+        if t == 0:
+            Lmax = g["txt_feat"].shape[2]
+            worst = max(worst, _err("txt", txt.cpu().numpy()[:, :, :Lmax], g["txt_feat"], log))
+            assert float(txt[:, :, Lmax:].abs().max()) == 0.0 if Lmax < txt.shape[2] else True
+            assert lengths.cpu().tolist() == [80, 23, 200]
+        worst = max(worst, _err(f"depth_feat_{t}", feats["depth"].cpu().numpy(), g[f"depth_feat_{t}"], log))
+        worst = max(worst, _err(f"map_feat_{t}", mp.cpu().numpy(), g[f"map_feat_{t}"], log))
+        worst = max(worst, _err(f"features_{t}", f.cpu().numpy(), g[f"features_{t}"], log))
+        worst = max(worst, _err(f"rnn_out_{t}", rnn.cpu().numpy(), g[f"rnn_out_{t}"], log))
+        lp = torch.log_softmax(logits, -1).cpu().numpy()
+        e = _err(f"logprobs_{t}", lp, g[f"logits_{t}"], log)
+        assert act.shape == (3, 1) and act.dtype == torch.int64
+        assert np.array_equal(act.cpu().numpy()[:, 0], g[f"logits_{t}"].argmax(-1))
+        assert e < 1e-4, "\n".join(log)
+    print("\n".join(log))
+    os.makedirs("gpurun_out", exist_ok=True)
+    open("gpurun_out/policy_parity.log", "w").write("\n".join(log) + "\n")
+    assert worst < ATOL, "\n".join(log)
+
+
+@pytest.mark.parametrize("B", [1, 4, 8])
+def test_act_matches_oracle_other_batches(B):
+    from det_init import det_fill
+
+    from ivln_ce_amd.synthetic import SyntheticRollout
+    from oracle.policy_ref import MapCMAPolicyRef
+
+    torch.set_num_threads(8)
+    pol = make_policy()
+    ref = det_fill(MapCMAPolicyRef(), seed=0).eval()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B)
+    roll = SyntheticRollout(B=B, seed=100 + B, n_tokens=40 + 10 * B)
+    obs = roll.step()
+    obs["occupancy_map"] = (torch.rand(B, 64, 64, generator=g) < 0.4).to(torch.uint8)
+    obs["semantic_map"] = (torch.randint(0, 13, (B, 64, 64), generator=g) * obs["occupancy_map"]).to(torch.uint8)
+    rnn = 0.1 * torch.randn(B, 2, 512, generator=g)
+    prev = torch.randint(0, 4, (B, 1), generator=g)
+    masks = (torch.rand(B, 1, generator=g) < 0.7).to(torch.uint8)
+    with torch.no_grad():
+        lr, sr, fr = ref.logits(obs, rnn, prev, masks)
+        dobs = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in obs.items()}
+        f, s = pol.net(dobs, rnn.to(dev), prev.to(dev), masks.to(dev))
+        lg = pol.action_distribution.raw_logits(f)
+    assert float((f.cpu() - fr).abs().max()) < ATOL
+    assert float((s.cpu() - sr).abs().max()) < ATOL
+    assert float((lg.cpu() - lr).abs().max()) < 1e-4
