@@ -1,0 +1,240 @@
+"""bench.py - throughput of the MapCMA hot path on MI355X (driver contract: see DESIGN.md section 6).
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+A "step" = one pass of the hot path over one batch of synthetic observations already resident in
+HBM: egocentric mapper (gt semantics) + MapCMAPolicy.act for `--envs` (default 4) parallel envs per
+GPU = BASELINE.json configs[1].  `value` = env-steps/s over all ranks (weak scaling: envs per GPU
+fixed).  The JSON line also carries
+  roofline     - fp32-MFMA implicit-GEMM kernel family (all conv / linear FLOPs of the step):
+                 algorithmic FLOPs per step / summed kernel time per step (HIP events on the launch
+                 stream) against the 157.3 TFLOP/s fp32-matrix peak
+  cpu_baseline - the CPU oracle (torch-CPU policy port + C mapper) timed on this box's host cores
+                 on a bounded sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+METRIC = "env-steps/sec (batched MapCMA fwd+bwd) at 1/2/4/8 MI355X; t-nDTW parity"
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+
+
+def make_policy(device, seed=0):
+    from ivln_ce_amd.config import get_config
+    from ivln_ce_amd.policy import MapCMAPolicy
+    from ivln_ce_amd.spaces import Box, Dict, Discrete
+
+    cfg = get_config(opts=[
+        "MODEL.policy_name", "MapCMAPolicy", "MODEL.INSTRUCTION_ENCODER.use_pretrained_embeddings", False,
+        "MODEL.DEPTH_ENCODER.ddppo_checkpoint", "NONE",
+    ])
+    space = Dict({
+        "depth": Box(0.0, 1.0, (256, 256, 1), np.float32), "occupancy_map": Box(0, 255, (64, 64), np.uint8),
+        "semantic_map": Box(0, 255, (64, 64), np.uint8), "instruction": Box(0, 2504, (200,), np.int64),
+    })
+    torch.manual_seed(seed)
+    pol = MapCMAPolicy.from_config(cfg, space, Discrete(4))
+    return cfg, pol.to(device).eval()
+
+
+def gen_observations(B, n_steps, seed):
+    from ivln_ce_amd.synthetic import SyntheticRollout
+
+    roll = SyntheticRollout(B=B, seed=seed)
+    return [roll.step() for _ in range(n_steps)]
+
+
+class GemmTimer:
+    """Wraps ops.gemm with event pairs on the launch stream; also accumulates algorithmic FLOPs."""
+
+    def __init__(self):
+        self.events = []
+        self.flops = 0
+
+    def __enter__(self):
+        from ivln_ce_amd import ops
+
+        self.ops = ops
+        self.orig = ops.gemm
+
+        def timed(desc):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            self.orig(desc)
+            b.record()
+            self.events.append((a, b))
+            self.flops += 2 * desc.M * desc.N * desc.K
+
+        ops.gemm = timed
+        return self
+
+    def __exit__(self, *a):
+        self.ops.gemm = self.orig
+
+    def total_ms(self):
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in self.events)
+
+
+def rollout_step(mapper_tr, policy, obs, state):
+    """mapper (obs-transform plugin) + policy.act: the per-step body of the reference eval loop
+    (base_il_trainer.py:688-703, 841)."""
+    batch = dict(obs)
+    batch = mapper_tr(batch)
+    with torch.no_grad():
+        actions, state["rnn"] = policy.act(batch, state["rnn"], state["prev"], batch["not_done_masks"],
+                                           deterministic=True)
+    state["prev"] = actions
+    return actions
+
+
+def cpu_baseline(obs_cpu, B, budget_s=12.0):
+    """Torch-CPU policy port + C mapper oracle on the host cores (kind = "port")."""
+    from oracle.mapper_ref import MapperRef
+    from oracle.policy_ref import MapCMAPolicyRef
+
+    torch.manual_seed(0)
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    pol = MapCMAPolicyRef().eval()
+    mapper = MapperRef(256, 256)
+    rnn = torch.zeros(B, 2, 512)
+    prev = torch.zeros(B, 1, dtype=torch.long)
+
+    def step(o):
+        nonlocal rnn, prev
+        occ, sem = mapper.step(o["depth"].numpy(), o["semantic12"].numpy(), o["world_robot_pose"].numpy(),
+                               o["world_robot_orientation"].numpy(), o["not_done_masks"].numpy())
+        ob = {"depth": o["depth"], "instruction": o["instruction"], "occupancy_map": torch.from_numpy(occ),
+              "semantic_map": torch.from_numpy(sem)}
+        with torch.no_grad():
+            a, rnn, _ = pol.act(ob, rnn, prev, o["not_done_masks"])
+        prev = a
+
+    for o in obs_cpu[:3]:
+        step(o)
+    n, t0 = 0, time.perf_counter()
+    i = 3
+    while True:
+        step(obs_cpu[i % len(obs_cpu)])
+        i += 1
+        n += 1
+        el = time.perf_counter() - t0
+        if (n >= 20 and el > budget_s) or n >= 400:
+            break
+    return {
+        "value": round(B * n / el, 2), "unit": "env-steps/s", "cores": ncores, "kind": "port",
+        "sample": f"{n} steps of {B} envs (256x256 depth, gt semantics, 80-token instruction): C mapper oracle + "
+                  f"torch-CPU MapCMA port, {ncores} threads, after 3 warm-up steps",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--envs", type=int, default=4, help="parallel envs per GPU (configs[1]: 4)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import __graft_entry__ as ge
+
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+
+    from ivln_ce_amd.obs_transforms import GTSemanticsIterativeMapper
+
+    B, K, W = args.envs, args.steps, args.warmup
+    cfg, policy = make_policy(dev)
+    mapper_tr = GTSemanticsIterativeMapper.from_config(cfg)
+    n_pool = min(W + K, 240)
+    obs_cpu = gen_observations(B, n_pool, seed=1234 + rank)
+    obs_dev = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in o.items()} for o in obs_cpu]
+    state = {"rnn": torch.zeros(B, 2, 512, device=dev), "prev": torch.zeros(B, 1, dtype=torch.long, device=dev)}
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(W):
+        rollout_step(mapper_tr, policy, obs_dev[i % n_pool], state)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(K):
+        rollout_step(mapper_tr, policy, obs_dev[(W + i) % n_pool], state)
+    barrier()
+    el = time.perf_counter() - t0
+    mapper_tr.mapping_module.check_status()
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    # ---- roofline of the MFMA implicit-GEMM family: instrumented pass (not part of `value`) ----
+    roofline = None
+    if rank == 0:
+        n_inst = min(20, K)
+        with GemmTimer() as gt:
+            for i in range(n_inst):
+                rollout_step(mapper_tr, policy, obs_dev[i % n_pool], state)
+            ms = gt.total_ms()
+        flops_per_step = gt.flops / n_inst
+        launches = len(gt.events) / n_inst
+        ach = (gt.flops / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
+        roofline = {
+            "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 5), "traffic": None,
+            "kernel": "k_gemm<WM,WN,AMODE,BMODE> (fp32 MFMA implicit GEMM: all conv/linear of one step)",
+            "flops_per_step": int(flops_per_step), "launches_per_step": round(launches, 1),
+            "kernel_ms_per_step": round(ms / n_inst, 4),
+        }
+
+    out = {
+        "metric": METRIC, "value": round(world * B * K / el, 2), "unit": "env-steps/s", "n_gpus": world,
+        "steps": K, "warmup": W, "ms_per_step": round(1e3 * el / K, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": "BASELINE configs[1]: MapCMA gt-semantics eval step = egocentric mapper + MapCMAPolicy.act, "
+                        f"{B} parallel envs per GPU, 256x256 depth + semantic12, 80-token instruction, random-init "
+                        "weights of the reference architecture",
+            "envs_per_gpu": B, "parallelism": f"dp{world} (envs sharded, no data-path collective)",
+        },
+        "roofline": roofline,
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(obs_cpu, B)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
