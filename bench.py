@@ -97,13 +97,30 @@ def rollout_step(mapper_tr, policy, obs, state):
     return actions
 
 
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota
+    (the GPU box reports 256 logical CPUs but grants a 16-CPU quota; oversubscribing OpenMP there
+    makes the CPU leg ~1000x slower)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:  # noqa: BLE001
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(obs_cpu, B, budget_s=12.0):
     """Torch-CPU policy port + C mapper oracle on the host cores (kind = "port")."""
     from oracle.mapper_ref import MapperRef
     from oracle.policy_ref import MapCMAPolicyRef
 
     torch.manual_seed(0)
-    ncores = os.cpu_count() or 1
+    ncores = usable_cores()
     torch.set_num_threads(ncores)
     pol = MapCMAPolicyRef().eval()
     mapper = MapperRef(256, 256)
@@ -129,13 +146,17 @@ def cpu_baseline(obs_cpu, B, budget_s=12.0):
         i += 1
         n += 1
         el = time.perf_counter() - t0
-        if (n >= 20 and el > budget_s) or n >= 400:
+        if (n >= 20 and el > budget_s) or n >= 400 or el > 4 * budget_s:
             break
     return {
         "value": round(B * n / el, 2), "unit": "env-steps/s", "cores": ncores, "kind": "port",
         "sample": f"{n} steps of {B} envs (256x256 depth, gt semantics, 80-token instruction): C mapper oracle + "
                   f"torch-CPU MapCMA port, {ncores} threads, after 3 warm-up steps",
     }
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
 
 
 def main():
@@ -182,9 +203,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    log(f"rank {rank}: inputs resident, warm-up {W} steps")
     for i in range(W):
         rollout_step(mapper_tr, policy, obs_dev[i % n_pool], state)
     barrier()
+    log(f"rank {rank}: timing {K} steps")
     t0 = time.perf_counter()
     for i in range(K):
         rollout_step(mapper_tr, policy, obs_dev[(W + i) % n_pool], state)
@@ -196,6 +219,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
+    log(f"rank {rank}: timed region {el:.3f}s")
     # ---- roofline of the MFMA implicit-GEMM family: instrumented pass (not part of `value`) ----
     roofline = None
     if rank == 0:
@@ -229,6 +253,7 @@ def main():
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
+            log("cpu baseline ...")
             out["cpu_baseline"] = cpu_baseline(obs_cpu, B)
         print(json.dumps(out), flush=True)
     if world > 1:
