@@ -1,0 +1,267 @@
+"""RedNet RGB-D semantic segmentation (pred-semantics mapper) on HIP.
+
+Same module / parameter names as the reference (ivlnce_baselines/common/mapping_module/rednet.py:7-358)
+so `rednet_mp3d_best_model.pkl["model_state"]` loads unchanged; `PredictSemantics` mirrors
+mapper.py:703-800.  Inference only (the reference freezes it and runs it under no_grad in eval
+mode): every BatchNorm is folded into the producing conv's fused scale/shift epilogue, residual
+adds and ReLU run in the same GEMM epilogue, transposed convs use the transposed-gather operand
+mode of the MFMA implicit-GEMM kernel.
+"""
+import os
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def _conv3x3(cin, cout, stride=1):
+    return nn.Conv2d(cin, cout, kernel_size=3, stride=stride, padding=1, bias=False)
+
+
+class _Folded:
+    """Cache of folded-BN scale/shift and re-laid-out transposed-conv weights (frozen network)."""
+
+    def __init__(self):
+        self.c = {}
+
+    def bn(self, bn: nn.BatchNorm2d):
+        k = id(bn)
+        if k not in self.c:
+            C = bn.num_features
+            scale = torch.empty(C, dtype=torch.float32, device=bn.weight.device)
+            shift = torch.empty(C, dtype=torch.float32, device=bn.weight.device)
+            ops.bn_fold(bn, scale, shift)
+            self.c[k] = (scale, shift)
+        return self.c[k]
+
+    def wt(self, convt: nn.ConvTranspose2d):
+        k = id(convt)
+        if k not in self.c:
+            self.c[k] = convt.weight.detach().permute(1, 0, 2, 3).contiguous()  # (Cin,Cout,k,k) -> (Cout,Cin,k,k)
+        return self.c[k]
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, kernel_size=1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward_hip(self, x, f: _Folded):
+        residual = x
+        if self.downsample is not None:
+            s, b = f.bn(self.downsample[1])
+            residual = ops.conv2d(x, self.downsample[0].weight, stride=self.stride, scale=s, shift=b)
+        s, b = f.bn(self.bn1)
+        y = ops.conv2d(x, self.conv1.weight, scale=s, shift=b, relu=True)
+        s, b = f.bn(self.bn2)
+        y = ops.conv2d(y, self.conv2.weight, stride=self.stride, pad=1, scale=s, shift=b, relu=True)
+        s, b = f.bn(self.bn3)
+        return ops.conv2d(y, self.conv3.weight, scale=s, shift=b, residual=residual, relu=True)
+
+
+class TransBasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, upsample=None, **kwargs):
+        super().__init__()
+        self.conv1 = _conv3x3(inplanes, inplanes)
+        self.bn1 = nn.BatchNorm2d(inplanes)
+        self.relu = nn.ReLU(inplace=True)
+        if upsample is not None and stride != 1:
+            self.conv2 = nn.ConvTranspose2d(inplanes, planes, kernel_size=3, stride=stride, padding=1,
+                                            output_padding=1, bias=False)
+        else:
+            self.conv2 = _conv3x3(inplanes, planes, stride)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.upsample = upsample
+        self.stride = stride
+
+    def forward_hip(self, x, f: _Folded):
+        residual = x
+        if self.upsample is not None:
+            s, b = f.bn(self.upsample[1])
+            up = self.upsample[0]
+            if isinstance(up, nn.ConvTranspose2d):
+                residual = ops.conv_transpose2d(x, f.wt(up), up.stride[0], 0, 0, scale=s, shift=b)
+            else:
+                residual = ops.conv2d(x, up.weight, scale=s, shift=b)
+        s, b = f.bn(self.bn1)
+        y = ops.conv2d(x, self.conv1.weight, pad=1, scale=s, shift=b, relu=True)
+        s, b = f.bn(self.bn2)
+        if isinstance(self.conv2, nn.ConvTranspose2d):
+            return ops.conv_transpose2d(y, f.wt(self.conv2), self.stride, 1, 1, scale=s, shift=b, residual=residual,
+                                        relu=True)
+        return ops.conv2d(y, self.conv2.weight, stride=self.stride, pad=1, scale=s, shift=b, residual=residual,
+                          relu=True)
+
+
+class RedNet(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        num_classes = cfg["n_classes"]
+        block, transblock, layers = Bottleneck, TransBasicBlock, [3, 4, 6, 3]
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
+        self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
+        self.inplanes = 64
+        self.conv1_d = nn.Conv2d(1, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1_d = nn.BatchNorm2d(64)
+        self.layer1_d = self._make_layer(block, 64, layers[0])
+        self.layer2_d = self._make_layer(block, 128, layers[1], stride=2)
+        self.layer3_d = self._make_layer(block, 256, layers[2], stride=2)
+        self.layer4_d = self._make_layer(block, 512, layers[3], stride=2)
+        self.inplanes = 512
+        self.deconv1 = self._make_transpose(transblock, 256, 6, stride=2)
+        self.deconv2 = self._make_transpose(transblock, 128, 4, stride=2)
+        self.deconv3 = self._make_transpose(transblock, 64, 3, stride=2)
+        self.deconv4 = self._make_transpose(transblock, 64, 3, stride=2)
+        self.agant0 = self._make_agant_layer(64, 64)
+        self.agant1 = self._make_agant_layer(64 * 4, 64)
+        self.agant2 = self._make_agant_layer(128 * 4, 128)
+        self.agant3 = self._make_agant_layer(256 * 4, 256)
+        self.agant4 = self._make_agant_layer(512 * 4, 512)
+        self.inplanes = 64
+        self.final_conv = self._make_transpose(transblock, 64, 3)
+        self.final_deconv_custom = nn.ConvTranspose2d(self.inplanes, num_classes, kernel_size=2, stride=2, padding=0,
+                                                      bias=True)
+        # training-only auxiliary heads (kept so the released state_dict loads strictly)
+        self.out5_conv_custom = nn.Conv2d(256, num_classes, kernel_size=1, stride=1, bias=True)
+        self.out4_conv_custom = nn.Conv2d(128, num_classes, kernel_size=1, stride=1, bias=True)
+        self.out3_conv_custom = nn.Conv2d(64, num_classes, kernel_size=1, stride=1, bias=True)
+        self.out2_conv_custom = nn.Conv2d(64, num_classes, kernel_size=1, stride=1, bias=True)
+        self._folded = _Folded()
+
+    def _make_layer(self, block, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(
+                nn.Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
+                nn.BatchNorm2d(planes * block.expansion),
+            )
+        layers = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            layers.append(block(self.inplanes, planes))
+        return nn.Sequential(*layers)
+
+    def _make_transpose(self, block, planes, blocks, stride=1):
+        upsample = None
+        if stride != 1:
+            upsample = nn.Sequential(
+                nn.ConvTranspose2d(self.inplanes, planes, kernel_size=2, stride=stride, padding=0, bias=False),
+                nn.BatchNorm2d(planes),
+            )
+        elif self.inplanes != planes:
+            upsample = nn.Sequential(
+                nn.Conv2d(self.inplanes, planes, kernel_size=1, stride=stride, bias=False), nn.BatchNorm2d(planes)
+            )
+        layers = [block(self.inplanes, self.inplanes) for _ in range(1, blocks)]
+        layers.append(block(self.inplanes, planes, stride, upsample))
+        self.inplanes = planes
+        return nn.Sequential(*layers)
+
+    def _make_agant_layer(self, inplanes, planes):
+        return nn.Sequential(
+            nn.Conv2d(inplanes, planes, kernel_size=1, stride=1, padding=0, bias=False),
+            nn.BatchNorm2d(planes), nn.ReLU(inplace=True),
+        )
+
+    def invalidate_folded(self):
+        """Call after changing weights (load_state_dict / .to()) so BN folds are recomputed."""
+        self._folded = _Folded()
+
+    def _seq(self, seq, x):
+        for blk in seq:
+            x = blk.forward_hip(x, self._folded)
+        return x
+
+    def _agant(self, layer, x):
+        s, b = self._folded.bn(layer[1])
+        return ops.conv2d(x, layer[0].weight, scale=s, shift=b, relu=True)
+
+    def forward(self, rgb, depth):
+        """rgb (B,3,H,W) normalised, depth (B,1,H,W) normalised -> scores (B,classes,H,W)
+        (rednet.py:190-269, eval path)."""
+        assert not self.training, "HIP RedNet is inference-only (the reference freezes it, mapper.py:751-752)"
+        f = self._folded
+        s, b = f.bn(self.bn1)
+        x = ops.conv2d(rgb, self.conv1.weight, stride=2, pad=3, scale=s, shift=b, relu=True)
+        s, b = f.bn(self.bn1_d)
+        d = ops.conv2d(depth, self.conv1_d.weight, stride=2, pad=3, scale=s, shift=b, relu=True)
+        fuse0 = ops.add(x, d)
+        x = ops.pool2d(fuse0, 3, 2, 1, "max")
+        d = ops.pool2d(d, 3, 2, 1, "max")
+        x, d = self._seq(self.layer1, x), self._seq(self.layer1_d, d)
+        fuse1 = ops.add(x, d)
+        x, d = self._seq(self.layer2, fuse1), self._seq(self.layer2_d, d)
+        fuse2 = ops.add(x, d)
+        x, d = self._seq(self.layer3, fuse2), self._seq(self.layer3_d, d)
+        fuse3 = ops.add(x, d)
+        x, d = self._seq(self.layer4, fuse3), self._seq(self.layer4_d, d)
+        fuse4 = ops.add(x, d)
+        x = self._agant(self.agant4, fuse4)
+        x = ops.add(self._seq(self.deconv1, x), self._agant(self.agant3, fuse3))
+        x = ops.add(self._seq(self.deconv2, x), self._agant(self.agant2, fuse2))
+        x = ops.add(self._seq(self.deconv3, x), self._agant(self.agant1, fuse1))
+        x = ops.add(self._seq(self.deconv4, x), self._agant(self.agant0, fuse0))
+        x = self._seq(self.final_conv, x)
+        fd = self.final_deconv_custom
+        return ops.conv_transpose2d(x, f.wt(fd), 2, 0, 0, shift=fd.bias)
+
+
+class PredictSemantics:
+    """mapper.py:703-800: labels = argmax_c RedNet(normalised rgb, normalised depth) as u8."""
+
+    CFG = {
+        "arch": "rednet", "resnet_pretrained": False, "finetune": True, "SUNRGBD_pretrained_weights": "",
+        "n_classes": 13, "upsample_prediction": True, "load_model": "data/rednet_mp3d_best_model.pkl",
+    }
+
+    def __init__(self, device, model: RedNet = None, load_weights: bool = True):
+        self.device = device
+        self.model = model
+        self.load_weights = load_weights
+
+    def setup(self):
+        if self.model is None:
+            self.model = RedNet(self.CFG)
+            path = self.CFG["load_model"]
+            if self.load_weights and os.path.exists(path):
+                state = torch.load(path, map_location="cpu")["model_state"]
+                if next(iter(state)).split(".")[0] == "module":  # convert_weights_cuda_cpu, mapper.py:767-779
+                    state = {".".join(k.split(".")[1:]): v for k, v in state.items()}
+                self.model.load_state_dict(state)
+            self.model = self.model.to(self.device).eval()
+            for p in self.model.parameters():
+                p.requires_grad = False
+
+    @torch.no_grad()
+    def scores(self, observations):
+        if observations.get("rgb", None) is None:
+            raise Exception("RGB Sensor not in use")  # mapper.py:783-784
+        self.setup()
+        depth = observations["depth"].to(torch.float32).contiguous()  # (B,H,W,1)
+        B, H, W, _ = depth.shape
+        rgb = ops.rgb_resize_normalize(observations["rgb"].to(torch.uint8).contiguous(), H, W)
+        dn = ops.affine(depth.view(B, 1, H, W), 0.213, 0.285)
+        return self.model(rgb, dn)
+
+    def __call__(self, observations):
+        return ops.argmax_channels_u8(self.scores(observations))

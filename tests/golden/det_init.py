@@ -8,7 +8,7 @@ import zlib
 import torch
 
 
-def det_fill(module: torch.nn.Module, seed: int = 0, prefix: str = ""):
+def det_fill(module: torch.nn.Module, seed: int = 0, prefix: str = "", conv_gain: float = 2.0 ** 0.5):
     sd = module.state_dict()
     new = {}
     for k, v in sd.items():
@@ -29,7 +29,7 @@ def det_fill(module: torch.nn.Module, seed: int = 0, prefix: str = ""):
             new[k] = 0.05 * torch.randn(v.shape, generator=g)
         else:
             fan_in = v[0].numel()
-            std = (2.0 / fan_in) ** 0.5 if v.dim() == 4 else (1.0 / fan_in) ** 0.5
+            std = conv_gain * (1.0 / fan_in) ** 0.5 if v.dim() == 4 else (1.0 / fan_in) ** 0.5
             if "embedding" in k:
                 std = 0.5
             new[k] = std * torch.randn(v.shape, generator=g)
