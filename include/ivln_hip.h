@@ -185,6 +185,68 @@ int ivln_add_f32(const float* a, const float* b, float* y, int64_t n, int relu, 
 int ivln_copy2d_f32(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int rows, int cols,
                     int broadcast_rows, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Backward / loss / optimizer kernels of the DAgger update (csrc/train_ops.hip): replace the
+ * autograd backward of the modules above plus F.cross_entropy / AuxLosses / torch.optim.Adam in
+ * BaseVLNCETrainer._update_agent (ivlnce_baselines/common/base_il_trainer.py:173-219).
+ * ------------------------------------------------------------------------------------------ */
+int ivln_relu_bwd_f32(const float* dy, const float* y, float* dx, int rows, int cols, int64_t ld_dy,
+                      int64_t ld_y, int64_t ld_dx, void* stream);
+int ivln_add2d_f32(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy, int rows,
+                   int cols, void* stream);
+/* deterministic column sums (bias gradients); ws: scratch of >= 128*cols floats */
+int ivln_colsum_f32(const float* x, int64_t ld, int rows, int cols, float* out, int accumulate, float* ws,
+                    int64_t ws_floats, void* stream);
+int ivln_nchw_chansum_f32(const float* x, int N, int C, int HW, float* out, void* stream);
+int ivln_transpose_f32(const float* x, float* y, int R, int C, void* stream);
+/* W (O,I,k,k) -> (I,O,k,k) spatially flipped: conv dgrad = conv(dy, W', pad = k-1-pad) */
+int ivln_weight_flip_transpose_f32(const float* w, float* wt, int O, int I, int KH, int KW, void* stream);
+/* backward of ivln_attn_fwd_f32 (MapCMANet._attn, map_cma_policy.py:266-274) */
+int ivln_attn_bwd_f32(const float* dout, int64_t ld_dout, const float* attn, const float* q, int64_t ldq,
+                      const float* k, int64_t k_img_stride, const float* v, int64_t v_img_stride, float scale,
+                      int rows, int Ck, int Cv, int I, float* dq, int64_t ld_dq, float* dk,
+                      int64_t dk_img_stride, float* dv, int64_t dv_img_stride, void* stream);
+/* one BPTT step of the masked GRU: gate gradients (element part) */
+int ivln_gru_bwd_elem_f32(const float* dout, int64_t ld_dout, const float* dh_carry, const float* r,
+                          const float* z, const float* n, const float* ghn, const float* h_prev, int64_t ldh,
+                          const uint8_t* mask, int rows, int H, float* dgi, float* dgh, float* dhz,
+                          float* hp_out, void* stream);
+/* y[r][o] = (W[o].x[r] + add[r][o]) * (rowmask[r] != 0)  (dh_prev of the GRU BPTT) */
+int ivln_linear_skinny_ex_f32(const float* x, int64_t ldx, const float* W, const float* add, int64_t ld_add,
+                              const uint8_t* rowmask, float* y, int64_t ldy, int rows, int K, int O,
+                              void* stream);
+/* BPTT of ivln_lstm_bidir_fwd_f32: dout (B,2H,L) -> dgx_* (B*L,4H), hprev_* (B*L,H) */
+int ivln_lstm_bidir_bwd_f32(const float* dout, const float* out, const float* gates, const float* cs,
+                            const float* whh_f, const float* whh_r, const int* lengths, int B, int L, int H,
+                            float* dgx_f, float* dgx_r, float* hprev_f, float* hprev_r, void* stream);
+/* backward of BatchNorm2d(train|eval) -> ReLU -> AvgPool2d(2) (CBRA, map_encoder.py:13-20) */
+int ivln_cbra_bwd_f32(const float* dout, const float* y, const float* scale, const float* shift,
+                      const float* mean, const float* rstd, int N, int C, int H, int W, int train,
+                      float* dgamma, float* dbeta, float* dy, void* stream);
+int ivln_embedding_scatter_add_f32(const int64_t* tokens, const float* d, int rows, int E, int V,
+                                   int padding_idx, float* grad, void* stream);
+int ivln_prev_action_embed_bwd_f32(const int64_t* prev_actions, const uint8_t* mask, const float* d1,
+                                   int64_t ld1, const float* d2, int64_t ld2, int rows, int E, int n_emb,
+                                   float* grad, void* stream);
+/* inflection-weighted cross entropy + its gradient (base_il_trainer.py:201-204); logits (T,N,A) */
+int ivln_ce_iw_loss_f32(const float* logits, const int64_t* targets, const float* weights, int T, int N, int A,
+                        float loss_scale, float* loss_out, float* dlogits, void* stream);
+/* progress-monitor loss with the reference's (TN,)x(TN,1) broadcast (map_cma_policy.py:355-361) */
+int ivln_pm_loss_fwd_f32(const float* pre, const float* progress, int n, float* hat, float* loss_matrix,
+                         void* stream);
+int ivln_pm_loss_bwd_f32(const float* dL, const float* hat, const float* progress, int n, float* dpre,
+                         void* stream);
+/* torch.optim.Adam step on a flat fp32 bucket (base_il_trainer.py:78-94, 213-215); seg_of/seg_lr give
+ * per-segment learning rates (SEMANTIC_MAP_ENCODER.custom_lr) or NULL; zero_grad clears the grads. */
+int ivln_adam_step_f32(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                       const int* seg_of, const float* seg_lr, float beta1, float beta2, float eps, int step,
+                       float grad_scale, int zero_grad, void* stream);
+
+/* Host-side (CPU) windowed DTW, step pattern symmetric1 (dtw-python 1.3.0 semantics; call site
+ * habitat_extensions/tour_ndtw.py:118-124).  a (n,dim), b (m,dim) HOST doubles; window (n,m) u8 or NULL. */
+int ivln_dtw_symmetric1(const double* a, int n, const double* b, int m, int dim, const uint8_t* window,
+                        double* distance_out);
+
 #ifdef __cplusplus
 }
 #endif

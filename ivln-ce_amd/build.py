@@ -14,6 +14,8 @@ SOURCES = {
     "mapper.hip": ["-ffp-contract=off"],
     "gemm_conv.hip": [],
     "nn_ops.hip": [],
+    "train_ops.hip": [],
+    "dtw.cpp": [],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

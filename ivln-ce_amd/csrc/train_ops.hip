@@ -1,0 +1,655 @@
+// Backward / loss / optimizer kernels of the DAgger update (base_il_trainer.py:173-219) for gfx950.
+// GEMM-shaped gradients (dX, dW of every conv / linear) run through gemm_conv.hip; this file holds the
+// element / reduction / recurrence kernels around them: ReLU mask, deterministic column and channel
+// sums (bias grads), attention backward, GRU BPTT step, bidirectional LSTM BPTT, BatchNorm(train)
+// +ReLU+AvgPool backward, conv weight flip for dgrad, embedding scatter, inflection-weighted
+// cross-entropy (+ gradient), progress-monitor loss, fused flat-bucket Adam.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include "../../include/ivln_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int i = 0; i < nw; ++i) s += red[i];
+    return s;
+}
+inline unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+// dx = dy * (y > 0)
+__global__ __launch_bounds__(256) void k_relu_bwd(const float* __restrict__ dy, const float* __restrict__ y,
+                                                  float* __restrict__ dx, int rows, int cols, int64_t ld_dy,
+                                                  int64_t ld_y, int64_t ld_dx) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)rows * cols) return;
+    int r = (int)(idx / cols), c = (int)(idx % cols);
+    dx[(int64_t)r * ld_dx + c] = y[(int64_t)r * ld_y + c] > 0.f ? dy[(int64_t)r * ld_dy + c] : 0.f;
+}
+
+// out = a + b (strided rows)
+__global__ __launch_bounds__(256) void k_add2d(const float* __restrict__ a, int64_t lda, const float* __restrict__ b,
+                                               int64_t ldb, float* __restrict__ y, int64_t ldy, int rows,
+                                               int cols) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)rows * cols) return;
+    int r = (int)(idx / cols), c = (int)(idx % cols);
+    y[(int64_t)r * ldy + c] = a[(int64_t)r * lda + c] + b[(int64_t)r * ldb + c];
+}
+
+// Deterministic column sums of a (rows, cols) matrix: stage 1 partial[split][c], stage 2 fixed-order sum.
+__global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict__ x, int64_t ld, int rows, int cols,
+                                                        int rows_per_split, float* __restrict__ partial) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int sub = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * rows_per_split;
+    const int r1 = min(rows, r0 + rows_per_split);
+    float s = 0.f;
+    if (c < cols)
+        for (int r = r0 + sub; r < r1; r += 4) s += x[(int64_t)r * ld + c];
+    red[sub][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (sub == 0 && c < cols)
+        partial[(int64_t)blockIdx.y * cols + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ void k_colsum_final(const float* __restrict__ partial, int splits, int cols, float* __restrict__ out,
+                               int accumulate) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += partial[(int64_t)z * cols + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+// per-channel sum over (N, HW) of an NCHW tensor (conv bias grad); one block per channel
+__global__ __launch_bounds__(256) void k_nchw_chansum(const float* __restrict__ x, int N, int C, int HW,
+                                                      float* __restrict__ out) {
+    __shared__ float red[16];
+    const int c = blockIdx.x;
+    float s = 0.f;
+    for (int img = 0; img < N; ++img) {
+        const float* xp = x + ((int64_t)img * C + c) * HW;
+        for (int i = threadIdx.x; i < HW; i += 256) s += xp[i];
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[c] = s;
+}
+
+// (R, C) -> (C, R)
+__global__ __launch_bounds__(256) void k_transpose(const float* __restrict__ x, float* __restrict__ y, int R, int C) {
+    __shared__ float tile[16][17];
+    int bx = blockIdx.x * 16, by = blockIdx.y * 16;
+    int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    if (by + ty < R && bx + tx < C) tile[ty][tx] = x[(int64_t)(by + ty) * C + bx + tx];
+    __syncthreads();
+    if (bx + ty < C && by + tx < R) y[(int64_t)(bx + ty) * R + by + tx] = tile[tx][ty];
+}
+
+// W (O,I,k,k) -> W' (I,O,k,k) with both spatial axes flipped: dgrad of a stride-1 conv is
+// conv(dy, W', pad = k-1-pad)
+__global__ __launch_bounds__(256) void k_weight_flip_transpose(const float* __restrict__ w, float* __restrict__ wt,
+                                                               int O, int I, int KH, int KW) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t total = (int64_t)O * I * KH * KW;
+    if (idx >= total) return;
+    int kw = (int)(idx % KW);
+    int kh = (int)((idx / KW) % KH);
+    int o = (int)((idx / ((int64_t)KW * KH)) % O);
+    int i = (int)(idx / ((int64_t)KW * KH * O));
+    wt[idx] = w[(((int64_t)o * I + i) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)];
+}
+
+// ------------------------------------------------------------------------------------------
+// Attention backward (forward: k_attn in nn_ops.hip).  One block per row.
+//   dv[c][i] = a[i]*dout[c];  da[i] = sum_c dout[c] v[c][i];  dl[i] = a[i]*(da[i] - sum_j a[j]da[j])*scale
+//   dq[c] = sum_i dl[i] k[c][i];  dk[c][i] = dl[i] q[c]
+// dk / dv are written (not accumulated) with image strides; masked positions have a == 0.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_attn_bwd(const float* __restrict__ dout, int64_t ld_dout,
+                                                  const float* __restrict__ attn, const float* __restrict__ q,
+                                                  int64_t ldq, const float* __restrict__ k, int64_t k_img_stride,
+                                                  const float* __restrict__ v, int64_t v_img_stride, float scale,
+                                                  int Ck, int Cv, int I, float* __restrict__ dq, int64_t ld_dq,
+                                                  float* __restrict__ dk, int64_t dk_img_stride,
+                                                  float* __restrict__ dv, int64_t dv_img_stride) {
+    __shared__ float ds[1024];   // dout row, later q row
+    __shared__ float as[512];    // attn
+    __shared__ float dl[512];    // dlogits
+    __shared__ float red[16];
+    const int n = blockIdx.x;
+    for (int c = threadIdx.x; c < Cv; c += 256) ds[c] = dout[(int64_t)n * ld_dout + c];
+    for (int i = threadIdx.x; i < I; i += 256) as[i] = attn[(int64_t)n * I + i];
+    __syncthreads();
+    const float* vp = v + (int64_t)n * v_img_stride;
+    float* dvp = dv + (int64_t)n * dv_img_stride;
+    float dot = 0.f;
+    for (int i = threadIdx.x; i < I; i += 256) {
+        float da = 0.f;
+        for (int c = 0; c < Cv; ++c) da = fmaf(ds[c], vp[(int64_t)c * I + i], da);
+        dl[i] = da;
+        dot += as[i] * da;
+    }
+    // dv (coalesced over i)
+    for (int64_t e = threadIdx.x; e < (int64_t)Cv * I; e += 256) {
+        int c = (int)(e / I), i = (int)(e % I);
+        dvp[e] = as[i] * ds[c];
+    }
+    dot = block_sum(dot, red);
+    for (int i = threadIdx.x; i < I; i += 256) dl[i] = as[i] * (dl[i] - dot) * scale;
+    __syncthreads();
+    for (int c = threadIdx.x; c < Ck; c += 256) ds[c] = q[(int64_t)n * ldq + c];
+    __syncthreads();
+    const float* kp = k + (int64_t)n * k_img_stride;
+    float* dkp = dk + (int64_t)n * dk_img_stride;
+    for (int c = threadIdx.x; c < Ck; c += 256) {
+        float acc = 0.f;
+        for (int i = 0; i < I; ++i) acc = fmaf(dl[i], kp[(int64_t)c * I + i], acc);
+        dq[(int64_t)n * ld_dq + c] = acc;
+    }
+    for (int64_t e = threadIdx.x; e < (int64_t)Ck * I; e += 256) {
+        int c = (int)(e / I), i = (int)(e % I);
+        dkp[e] = dl[i] * ds[c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// GRU BPTT, element part of one step (rows = N sequences of step t):
+//   dh = dout + dh_carry;  dn = dh(1-z); dz = dh(hp - n); dhz = dh z
+//   dn_pre = dn(1-n^2); dz_pre = dz z(1-z); dr_pre = dn_pre ghn r(1-r)
+//   dgi = [dr_pre, dz_pre, dn_pre];  dgh = [dr_pre, dz_pre, dn_pre r];  hp = h_prev*mask
+// The matvec dh_prev = dgh . W_hh then runs through k_linear_skinny_ex with (+dhz)*mask epilogue.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gru_bwd_elem(const float* __restrict__ dout, int64_t ld_dout,
+                                                      const float* __restrict__ dh_carry,
+                                                      const float* __restrict__ r, const float* __restrict__ z,
+                                                      const float* __restrict__ n, const float* __restrict__ ghn,
+                                                      const float* __restrict__ h_prev, int64_t ldh,
+                                                      const uint8_t* __restrict__ mask, int rows, int H,
+                                                      float* __restrict__ dgi, float* __restrict__ dgh,
+                                                      float* __restrict__ dhz, float* __restrict__ hp_out) {
+    int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * H) return;
+    int row = idx / H, j = idx % H;
+    float dh = dout[(int64_t)row * ld_dout + j] + (dh_carry ? dh_carry[idx] : 0.f);
+    float mk = mask[row] ? 1.f : 0.f;
+    float hp = h_prev[(int64_t)row * ldh + j] * mk;
+    float rg = r[idx], zg = z[idx], ng = n[idx], gh = ghn[idx];
+    float dn = dh * (1.f - zg);
+    float dz = dh * (hp - ng);
+    float dn_pre = dn * (1.f - ng * ng);
+    float dz_pre = dz * zg * (1.f - zg);
+    float dr_pre = dn_pre * gh * rg * (1.f - rg);
+    int64_t o = (int64_t)row * 3 * H + j;
+    dgi[o] = dr_pre;
+    dgi[o + H] = dz_pre;
+    dgi[o + 2 * H] = dn_pre;
+    dgh[o] = dr_pre;
+    dgh[o + H] = dz_pre;
+    dgh[o + 2 * H] = dn_pre * rg;
+    dhz[idx] = dh * zg;
+    hp_out[idx] = hp;
+}
+
+// y[r][o] = (W[o].x[r] + add[r][o]) * (rowmask[r] ? 1 : 0)   (skinny rows; see k_linear_skinny)
+__global__ __launch_bounds__(256) void k_linear_skinny_ex(const float* __restrict__ x, int64_t ldx,
+                                                          const float* __restrict__ W,
+                                                          const float* __restrict__ add, int64_t ld_add,
+                                                          const uint8_t* __restrict__ rowmask,
+                                                          float* __restrict__ y, int64_t ldy, int rows, int K,
+                                                          int O) {
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (o >= O) return;
+    const float* wr = W + (int64_t)o * K;
+    for (int r0 = 0; r0 < rows; r0 += 8) {
+        float acc[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+        for (int k = lane * 4; k < K; k += 256) {
+            float4 wv = *reinterpret_cast<const float4*>(wr + k);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                if (r0 + r < rows) {
+                    float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)(r0 + r) * ldx + k);
+                    acc[r] = fmaf(wv.x, xv.x, acc[r]);
+                    acc[r] = fmaf(wv.y, xv.y, acc[r]);
+                    acc[r] = fmaf(wv.z, xv.z, acc[r]);
+                    acc[r] = fmaf(wv.w, xv.w, acc[r]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            float v = wave_sum(acc[r]);
+            if (lane == 0 && r0 + r < rows) {
+                if (add) v += add[(int64_t)(r0 + r) * ld_add + o];
+                if (rowmask) v = rowmask[r0 + r] ? v : 0.f;
+                y[(int64_t)(r0 + r) * ldy + o] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Bidirectional LSTM BPTT (forward: k_lstm_bidir).  grid (B, 2); 4H = 512 threads.  Thread
+// (k = tid % H, part = tid / H) keeps W_hh[part*H .. part*H+H-1][k] (a column slice) in registers so
+// dh_prev[k] = sum_g W_hh[g][k] dgate[g] is 4 partial dots of H terms + an LDS reduction.
+// dout: (B, 2H, L) gradient of the channel-major outputs.  Writes dgx (B*L, 4H) per direction
+// (pre-activation gate grads, zero for t >= len) and hprev (B*L, H) per direction (h_{t-1} in
+// processing order) for the dW_hh / dW_ih GEMMs.
+// ------------------------------------------------------------------------------------------
+template <int H>
+__global__ __launch_bounds__(4 * H) void k_lstm_bidir_bwd(const float* __restrict__ dout,
+                                                          const float* __restrict__ out,
+                                                          const float* __restrict__ gates,
+                                                          const float* __restrict__ cs,
+                                                          const float* __restrict__ whh_f,
+                                                          const float* __restrict__ whh_r,
+                                                          const int* __restrict__ lengths, int L,
+                                                          float* __restrict__ dgx_f, float* __restrict__ dgx_r,
+                                                          float* __restrict__ hprev_f,
+                                                          float* __restrict__ hprev_r) {
+    constexpr int G = 4 * H;
+    __shared__ float dg[G];
+    __shared__ float part[4][H];
+    __shared__ float dhc[H], dcc[H];
+    const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
+    const int k = tid % H, pq = tid / H;
+    const float* whh = dir == 0 ? whh_f : whh_r;
+    float* dgx = (dir == 0 ? dgx_f : dgx_r) + (int64_t)b * L * G;
+    float* hprev = (dir == 0 ? hprev_f : hprev_r) + (int64_t)b * L * H;
+    float w[H];
+#pragma unroll
+    for (int g = 0; g < H; ++g) w[g] = whh[(int64_t)(pq * H + g) * H + k];
+    if (tid < H) {
+        dhc[tid] = 0.f;
+        dcc[tid] = 0.f;
+    }
+    int len = lengths[b];
+    if (len > L) len = L;
+    for (int t = len + pq; t < L; t += 4) {  // padded positions carry no gradient
+#pragma unroll 4
+        for (int g = k; g < G; g += H) dgx[(int64_t)t * G + g] = 0.f;
+        hprev[(int64_t)t * H + k] = 0.f;
+    }
+    __syncthreads();
+    const float* gt = gates + ((int64_t)b * 2 + dir) * L * G;
+    const float* ct = cs + ((int64_t)b * 2 + dir) * L * H;
+    for (int s = len - 1; s >= 0; --s) {
+        const int t = dir == 0 ? s : len - 1 - s;            // time index of processing step s
+        const int tp = dir == 0 ? t - 1 : t + 1;              // time index of the previous processing step
+        const bool has_prev = s > 0;
+        if (tid < H) {
+            const int j = tid;
+            float ig = gt[(int64_t)t * G + j], fg = gt[(int64_t)t * G + H + j];
+            float gg = gt[(int64_t)t * G + 2 * H + j], og = gt[(int64_t)t * G + 3 * H + j];
+            float c = ct[(int64_t)t * H + j];
+            float cp = has_prev ? ct[(int64_t)tp * H + j] : 0.f;
+            float hp = has_prev ? out[((int64_t)b * 2 * H + dir * H + j) * L + tp] : 0.f;
+            float tc = tanhf(c);
+            float dh = dout[((int64_t)b * 2 * H + dir * H + j) * L + t] + dhc[j];
+            float d_o = dh * tc;
+            float dc = dh * og * (1.f - tc * tc) + dcc[j];
+            float di = dc * gg, df = dc * cp, dgg = dc * ig;
+            dcc[j] = dc * fg;
+            float a0 = di * ig * (1.f - ig), a1 = df * fg * (1.f - fg), a2 = dgg * (1.f - gg * gg),
+                  a3 = d_o * og * (1.f - og);
+            dg[j] = a0;
+            dg[H + j] = a1;
+            dg[2 * H + j] = a2;
+            dg[3 * H + j] = a3;
+            dgx[(int64_t)t * G + j] = a0;
+            dgx[(int64_t)t * G + H + j] = a1;
+            dgx[(int64_t)t * G + 2 * H + j] = a2;
+            dgx[(int64_t)t * G + 3 * H + j] = a3;
+            hprev[(int64_t)t * H + j] = hp;
+        }
+        __syncthreads();
+        float acc = 0.f;
+#pragma unroll
+        for (int g = 0; g < H; ++g) acc = fmaf(w[g], dg[pq * H + g], acc);
+        part[pq][k] = acc;
+        __syncthreads();
+        if (tid < H) dhc[tid] = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// CBRA backward (map_encoder.py:13-20): out = avgpool2(relu(y*scale + shift)), BatchNorm in train
+// mode (scale = gamma*rstd, shift = beta - mean*scale) or eval mode.
+// stats: per channel S1 = sum dz, S2 = sum dz*xhat with dz = dout/4 * (z>0), xhat = (y-mean)*rstd.
+// apply: train: dy = gamma*rstd*(dz - S1/M - xhat*S2/M); eval: dy = dz*scale.
+// dgamma = S2 (train) / sum dz*(y-rm)*rsqrt(rv+eps) (eval, same formula with mean=rm, rstd=that);
+// dbeta = S1.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cbra_bwd_stats(const float* __restrict__ dout, const float* __restrict__ y,
+                                                        const float* __restrict__ scale,
+                                                        const float* __restrict__ shift,
+                                                        const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, int N, int C, int H, int W,
+                                                        float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float red[16];
+    const int c = blockIdx.x;
+    const int Ho = H / 2, Wo = W / 2, HW = H * W;
+    const float sc = scale[c], sh = shift[c], mu = mean[c], rs = rstd[c];
+    float s1 = 0.f, s2 = 0.f;
+    for (int img = 0; img < N; ++img) {
+        const float* yp = y + ((int64_t)img * C + c) * HW;
+        const float* dp = dout + ((int64_t)img * C + c) * Ho * Wo;
+        for (int i = threadIdx.x; i < HW; i += 256) {
+            int h = i / W, w = i - h * W;
+            float yv = yp[i];
+            float dz = fmaf(yv, sc, sh) > 0.f ? 0.25f * dp[(h >> 1) * Wo + (w >> 1)] : 0.f;
+            s1 += dz;
+            s2 += dz * (yv - mu) * rs;
+        }
+    }
+    s1 = block_sum(s1, red);
+    s2 = block_sum(s2, red);
+    if (threadIdx.x == 0) {
+        dbeta[c] = s1;
+        dgamma[c] = s2;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cbra_bwd_apply(const float* __restrict__ dout, const float* __restrict__ y,
+                                                        const float* __restrict__ scale,
+                                                        const float* __restrict__ shift,
+                                                        const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd,
+                                                        const float* __restrict__ dgamma,
+                                                        const float* __restrict__ dbeta, int N, int C, int H, int W,
+                                                        int train, float* __restrict__ dy) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int HW = H * W, Ho = H / 2, Wo = W / 2;
+    if (idx >= (int64_t)N * C * HW) return;
+    int i = (int)(idx % HW);
+    int nc = (int)(idx / HW);
+    int c = nc % C;
+    int h = i / W, w = i - h * W;
+    float yv = y[idx];
+    float sc = scale[c];
+    float dz = fmaf(yv, sc, shift[c]) > 0.f ? 0.25f * dout[(int64_t)nc * Ho * Wo + (h >> 1) * Wo + (w >> 1)] : 0.f;
+    float v;
+    if (train) {
+        float M = (float)N * (float)HW;
+        float xhat = (yv - mean[c]) * rstd[c];
+        v = sc * (dz - dbeta[c] / M - xhat * dgamma[c] / M);
+    } else {
+        v = dz * sc;
+    }
+    dy[idx] = v;
+}
+
+// embedding gradient: table_grad[token[r]] += d[r] (atomic; padding row skipped)
+__global__ __launch_bounds__(256) void k_embedding_scatter_add(const int64_t* __restrict__ tokens,
+                                                               const float* __restrict__ d, int rows, int E, int V,
+                                                               int padding_idx, float* __restrict__ grad) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)rows * E) return;
+    int r = (int)(idx / E), e = (int)(idx % E);
+    int64_t tok = tokens[r];
+    if (tok < 0 || tok >= V || tok == padding_idx) return;
+    atomicAdd(&grad[tok * E + e], d[idx]);
+}
+
+// prev-action embedding gradient (deterministic: thread per (a,e) loops over rows)
+__global__ void k_prev_action_embed_bwd(const int64_t* __restrict__ prev_actions, const uint8_t* __restrict__ mask,
+                                        const float* __restrict__ d1, int64_t ld1, const float* __restrict__ d2,
+                                        int64_t ld2, int rows, int E, int n_emb, float* __restrict__ grad) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_emb * E) return;
+    int a = idx / E, e = idx % E;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) {
+        int64_t ar = (int64_t)(((float)prev_actions[r] + 1.f) * (float)(mask[r] ? 1 : 0));
+        if (ar < 0) ar = 0;
+        if (ar >= n_emb) ar = n_emb - 1;
+        if (ar == a) s += d1[(int64_t)r * ld1 + e] + (d2 ? d2[(int64_t)r * ld2 + e] : 0.f);
+    }
+    grad[idx] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// Inflection-weighted cross-entropy (base_il_trainer.py:201-204):
+//   ce[t,n] = -log_softmax(logits[t,n])[target];  loss = mean_n( sum_t w ce / sum_t w )
+// One block; also writes dlogits = d loss / d logits * loss_scale.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ce_iw_loss(const float* __restrict__ logits,
+                                                    const int64_t* __restrict__ targets,
+                                                    const float* __restrict__ weights, int T, int N, int A,
+                                                    float loss_scale, float* __restrict__ loss_out,
+                                                    float* __restrict__ dlogits) {
+    __shared__ float red[16];
+    float total = 0.f;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        float wsum = 0.f, acc = 0.f;
+        for (int t = 0; t < T; ++t) wsum += weights[t * N + n];
+        for (int t = 0; t < T; ++t) {
+            const float* l = logits + ((int64_t)t * N + n) * A;
+            float mx = l[0];
+            for (int a = 1; a < A; ++a) mx = fmaxf(mx, l[a]);
+            float se = 0.f;
+            for (int a = 0; a < A; ++a) se += expf(l[a] - mx);
+            float lse = mx + logf(se);
+            int tg = (int)targets[t * N + n];
+            float w = weights[t * N + n];
+            acc += w * (lse - l[tg]);
+            float coef = loss_scale * w / (wsum * (float)N);
+            for (int a = 0; a < A; ++a)
+                dlogits[((int64_t)t * N + n) * A + a] = coef * (expf(l[a] - lse) - (a == tg ? 1.f : 0.f));
+        }
+        total += acc / wsum;
+    }
+    total = block_sum(total, red);
+    if (threadIdx.x == 0) loss_out[0] = total / (float)N;
+}
+
+// ------------------------------------------------------------------------------------------
+// Progress monitor with the reference's (TN,) x (TN,1) broadcast (quirk Q7, map_cma_policy.py:355-361):
+//   hat[i] = tanh(pre[i]);  L[j][i] = (hat[i] - p[j])^2   (TN x TN)
+// fwd writes L; bwd: dpre[i] = (sum_j dL[j][i] * 2 (hat[i] - p[j])) * (1 - hat[i]^2).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pm_loss_fwd(const float* __restrict__ pre, const float* __restrict__ p,
+                                                     int n, float* __restrict__ hat, float* __restrict__ Lm) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)n * n) return;
+    int j = (int)(idx / n), i = (int)(idx % n);
+    float h = tanhf(pre[i]);
+    if (j == 0) hat[i] = h;
+    float d = h - p[j];
+    Lm[idx] = d * d;
+}
+__global__ __launch_bounds__(256) void k_pm_loss_bwd(const float* __restrict__ dL, const float* __restrict__ hat,
+                                                     const float* __restrict__ p, int n, float* __restrict__ dpre) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float h = hat[i], s = 0.f;
+    for (int j = 0; j < n; ++j) s += dL[(int64_t)j * n + i] * 2.f * (h - p[j]);
+    dpre[i] = s * (1.f - h * h);
+}
+
+// ------------------------------------------------------------------------------------------
+// Adam on a flat fp32 bucket (torch.optim.Adam defaults semantics: bias-corrected, eps outside sqrt
+// of the corrected second moment, no weight decay / amsgrad; base_il_trainer.py:78-94, 213-215).
+// lr may differ per segment: lr_per_elem == nullptr -> scalar lr.  grad_scale folds the 1/world of
+// the data-parallel mean.  Grads are zeroed in the same pass (optimizer.zero_grad()).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_adam_flat(float* __restrict__ p, float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                   float lr, const int* __restrict__ seg_of, const float* seg_lr,
+                                                   float b1, float b2, float eps, float bc1, float bc2,
+                                                   float grad_scale, int zero_grad) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float gi = g[i] * grad_scale;
+    float mi = b1 * m[i] + (1.f - b1) * gi;
+    float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    float l = seg_of ? seg_lr[seg_of[i]] : lr;
+    float step = l / bc1;
+    float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+    p[i] = p[i] - step * (mi / denom);
+    if (zero_grad) g[i] = 0.f;
+}
+
+}  // namespace
+
+#define LAUNCH_OK() (hipGetLastError() == hipSuccess ? IVLN_OK : IVLN_E_HIP)
+
+extern "C" {
+
+int ivln_relu_bwd_f32(const float* dy, const float* y, float* dx, int rows, int cols, int64_t ld_dy, int64_t ld_y,
+                      int64_t ld_dx, void* stream) {
+    hipLaunchKernelGGL(k_relu_bwd, dim3(nblk((int64_t)rows * cols)), dim3(256), 0, (hipStream_t)stream, dy, y, dx,
+                       rows, cols, ld_dy, ld_y, ld_dx);
+    return LAUNCH_OK();
+}
+
+int ivln_add2d_f32(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy, int rows, int cols,
+                   void* stream) {
+    hipLaunchKernelGGL(k_add2d, dim3(nblk((int64_t)rows * cols)), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb,
+                       y, ldy, rows, cols);
+    return LAUNCH_OK();
+}
+
+int ivln_colsum_f32(const float* x, int64_t ld, int rows, int cols, float* out, int accumulate, float* ws,
+                    int64_t ws_floats, void* stream) {
+    if (rows <= 0 || cols <= 0) return IVLN_E_INVALID;
+    int splits = (rows + 255) / 256;
+    if (splits > 128) splits = 128;
+    if ((int64_t)splits * cols > ws_floats) splits = (int)(ws_floats / cols);
+    if (splits < 1) return IVLN_E_INVALID;
+    int rps = (rows + splits - 1) / splits;
+    splits = (rows + rps - 1) / rps;
+    hipLaunchKernelGGL(k_colsum_partial, dim3((cols + 63) / 64, splits), dim3(256), 0, (hipStream_t)stream, x, ld, rows,
+                       cols, rps, ws);
+    hipLaunchKernelGGL(k_colsum_final, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, splits, cols,
+                       out, accumulate);
+    return LAUNCH_OK();
+}
+
+int ivln_nchw_chansum_f32(const float* x, int N, int C, int HW, float* out, void* stream) {
+    hipLaunchKernelGGL(k_nchw_chansum, dim3(C), dim3(256), 0, (hipStream_t)stream, x, N, C, HW, out);
+    return LAUNCH_OK();
+}
+
+int ivln_transpose_f32(const float* x, float* y, int R, int C, void* stream) {
+    hipLaunchKernelGGL(k_transpose, dim3((C + 15) / 16, (R + 15) / 16), dim3(256), 0, (hipStream_t)stream, x, y, R, C);
+    return LAUNCH_OK();
+}
+
+int ivln_weight_flip_transpose_f32(const float* w, float* wt, int O, int I, int KH, int KW, void* stream) {
+    hipLaunchKernelGGL(k_weight_flip_transpose, dim3(nblk((int64_t)O * I * KH * KW)), dim3(256), 0,
+                       (hipStream_t)stream, w, wt, O, I, KH, KW);
+    return LAUNCH_OK();
+}
+
+int ivln_attn_bwd_f32(const float* dout, int64_t ld_dout, const float* attn, const float* q, int64_t ldq,
+                      const float* k, int64_t k_img_stride, const float* v, int64_t v_img_stride, float scale,
+                      int rows, int Ck, int Cv, int I, float* dq, int64_t ld_dq, float* dk, int64_t dk_img_stride,
+                      float* dv, int64_t dv_img_stride, void* stream) {
+    if (I > 512 || Ck > 1024 || Cv > 1024) return IVLN_E_UNSUPPORTED;
+    hipLaunchKernelGGL(k_attn_bwd, dim3(rows), dim3(256), 0, (hipStream_t)stream, dout, ld_dout, attn, q, ldq, k,
+                       k_img_stride, v, v_img_stride, scale, Ck, Cv, I, dq, ld_dq, dk, dk_img_stride, dv,
+                       dv_img_stride);
+    return LAUNCH_OK();
+}
+
+int ivln_gru_bwd_elem_f32(const float* dout, int64_t ld_dout, const float* dh_carry, const float* r, const float* z,
+                          const float* n, const float* ghn, const float* h_prev, int64_t ldh, const uint8_t* mask,
+                          int rows, int H, float* dgi, float* dgh, float* dhz, float* hp_out, void* stream) {
+    hipLaunchKernelGGL(k_gru_bwd_elem, dim3(nblk((int64_t)rows * H)), dim3(256), 0, (hipStream_t)stream, dout, ld_dout,
+                       dh_carry, r, z, n, ghn, h_prev, ldh, mask, rows, H, dgi, dgh, dhz, hp_out);
+    return LAUNCH_OK();
+}
+
+int ivln_linear_skinny_ex_f32(const float* x, int64_t ldx, const float* W, const float* add, int64_t ld_add,
+                              const uint8_t* rowmask, float* y, int64_t ldy, int rows, int K, int O, void* stream) {
+    if ((K & 3) || (ldx & 3)) return IVLN_E_INVALID;
+    hipLaunchKernelGGL(k_linear_skinny_ex, dim3((O + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, W, add,
+                       ld_add, rowmask, y, ldy, rows, K, O);
+    return LAUNCH_OK();
+}
+
+int ivln_lstm_bidir_bwd_f32(const float* dout, const float* out, const float* gates, const float* cs,
+                            const float* whh_f, const float* whh_r, const int* lengths, int B, int L, int H,
+                            float* dgx_f, float* dgx_r, float* hprev_f, float* hprev_r, void* stream) {
+    if (H != 128) return IVLN_E_UNSUPPORTED;
+    hipLaunchKernelGGL((k_lstm_bidir_bwd<128>), dim3(B, 2), dim3(512), 0, (hipStream_t)stream, dout, out, gates, cs,
+                       whh_f, whh_r, lengths, L, dgx_f, dgx_r, hprev_f, hprev_r);
+    return LAUNCH_OK();
+}
+
+int ivln_cbra_bwd_f32(const float* dout, const float* y, const float* scale, const float* shift, const float* mean,
+                      const float* rstd, int N, int C, int H, int W, int train, float* dgamma, float* dbeta,
+                      float* dy, void* stream) {
+    hipLaunchKernelGGL(k_cbra_bwd_stats, dim3(C), dim3(256), 0, (hipStream_t)stream, dout, y, scale, shift, mean, rstd,
+                       N, C, H, W, dgamma, dbeta);
+    hipLaunchKernelGGL(k_cbra_bwd_apply, dim3(nblk((int64_t)N * C * H * W)), dim3(256), 0, (hipStream_t)stream, dout,
+                       y, scale, shift, mean, rstd, dgamma, dbeta, N, C, H, W, train, dy);
+    return LAUNCH_OK();
+}
+
+int ivln_embedding_scatter_add_f32(const int64_t* tokens, const float* d, int rows, int E, int V, int padding_idx,
+                                   float* grad, void* stream) {
+    hipLaunchKernelGGL(k_embedding_scatter_add, dim3(nblk((int64_t)rows * E)), dim3(256), 0, (hipStream_t)stream,
+                       tokens, d, rows, E, V, padding_idx, grad);
+    return LAUNCH_OK();
+}
+
+int ivln_prev_action_embed_bwd_f32(const int64_t* prev_actions, const uint8_t* mask, const float* d1, int64_t ld1,
+                                   const float* d2, int64_t ld2, int rows, int E, int n_emb, float* grad,
+                                   void* stream) {
+    hipLaunchKernelGGL(k_prev_action_embed_bwd, dim3((n_emb * E + 63) / 64), dim3(64), 0, (hipStream_t)stream,
+                       prev_actions, mask, d1, ld1, d2, ld2, rows, E, n_emb, grad);
+    return LAUNCH_OK();
+}
+
+int ivln_ce_iw_loss_f32(const float* logits, const int64_t* targets, const float* weights, int T, int N, int A,
+                        float loss_scale, float* loss_out, float* dlogits, void* stream) {
+    hipLaunchKernelGGL(k_ce_iw_loss, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, targets, weights, T, N, A,
+                       loss_scale, loss_out, dlogits);
+    return LAUNCH_OK();
+}
+
+int ivln_pm_loss_fwd_f32(const float* pre, const float* progress, int n, float* hat, float* loss_matrix,
+                         void* stream) {
+    hipLaunchKernelGGL(k_pm_loss_fwd, dim3(nblk((int64_t)n * n)), dim3(256), 0, (hipStream_t)stream, pre, progress, n,
+                       hat, loss_matrix);
+    return LAUNCH_OK();
+}
+
+int ivln_pm_loss_bwd_f32(const float* dL, const float* hat, const float* progress, int n, float* dpre,
+                         void* stream) {
+    hipLaunchKernelGGL(k_pm_loss_bwd, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, dL, hat, progress, n,
+                       dpre);
+    return LAUNCH_OK();
+}
+
+int ivln_adam_step_f32(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                       const int* seg_of, const float* seg_lr, float beta1, float beta2, float eps, int step,
+                       float grad_scale, int zero_grad, void* stream) {
+    if (n <= 0 || step < 1) return IVLN_E_INVALID;
+    float bc1 = 1.f - powf(beta1, (float)step);
+    float bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(k_adam_flat, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
+                       exp_avg_sq, n, lr, seg_of, seg_lr, beta1, beta2, eps, bc1, bc2, grad_scale, zero_grad);
+    return LAUNCH_OK();
+}
+
+}  // extern "C"

@@ -339,7 +339,7 @@ class RNNStateEncoder(nn.Module):
             saves = None
             if save is not None:
                 saves = tuple(torch.empty((rows, H), dtype=torch.float32, device=x.device) for _ in range(4))
-                save.update(r=saves[0], z=saves[1], n=saves[2], ghn=saves[3], T=1, N=N, x=x, h0=h0, masks=masks_u8)
+                save.update(r=saves[0], z=saves[1], n=saves[2], ghn=saves[3], T=1, N=N, x=x, h0=h0, masks=masks_u8, out=out)
             ops.gru_step(x, None, h0, masks_u8, rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0,
                          out, state_out, saves)
             return out
@@ -348,7 +348,7 @@ class RNNStateEncoder(nn.Module):
         saves = None
         if save is not None:
             saves = tuple(torch.empty((rows, H), dtype=torch.float32, device=x.device) for _ in range(4))
-            save.update(r=saves[0], z=saves[1], n=saves[2], ghn=saves[3], T=T, N=N, x=x, h0=h0, masks=masks_u8)
+            save.update(r=saves[0], z=saves[1], n=saves[2], ghn=saves[3], T=T, N=N, x=x, h0=h0, masks=masks_u8, out=out)
         for t in range(T):
             sl = slice(t * N, (t + 1) * N)
             h_in = h0 if t == 0 else out[(t - 1) * N: t * N]

@@ -381,3 +381,274 @@ def copy2d(src, dst, rows, cols, broadcast_rows=False):
                              int(bool(broadcast_rows)), stream_ptr()),
         "ivln_copy2d_f32",
     )
+
+
+# ---- backward / loss / optimizer bindings (csrc/train_ops.hip) -------------------------------------
+_tsigs_done = False
+
+
+def _T():
+    global _tsigs_done
+    L = _L()
+    if not _tsigs_done:
+        L.ivln_relu_bwd_f32.argtypes = [vp, vp, vp, i32, i32, i64, i64, i64, vp]
+        L.ivln_add2d_f32.argtypes = [vp, i64, vp, i64, vp, i64, i32, i32, vp]
+        L.ivln_colsum_f32.argtypes = [vp, i64, i32, i32, vp, i32, vp, i64, vp]
+        L.ivln_nchw_chansum_f32.argtypes = [vp, i32, i32, i32, vp, vp]
+        L.ivln_transpose_f32.argtypes = [vp, vp, i32, i32, vp]
+        L.ivln_weight_flip_transpose_f32.argtypes = [vp, vp, i32, i32, i32, i32, vp]
+        L.ivln_attn_bwd_f32.argtypes = [vp, i64, vp, vp, i64, vp, i64, vp, i64, f32, i32, i32, i32, i32, vp, i64, vp,
+                                        i64, vp, i64, vp]
+        L.ivln_gru_bwd_elem_f32.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, i64, vp, i32, i32, vp, vp, vp, vp, vp]
+        L.ivln_linear_skinny_ex_f32.argtypes = [vp, i64, vp, vp, i64, vp, vp, i64, i32, i32, i32, vp]
+        L.ivln_lstm_bidir_bwd_f32.argtypes = [vp] * 7 + [i32, i32, i32, vp, vp, vp, vp, vp]
+        L.ivln_cbra_bwd_f32.argtypes = [vp] * 6 + [i32, i32, i32, i32, i32, vp, vp, vp, vp]
+        L.ivln_embedding_scatter_add_f32.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
+        L.ivln_prev_action_embed_bwd_f32.argtypes = [vp, vp, vp, i64, vp, i64, i32, i32, i32, vp, vp]
+        L.ivln_ce_iw_loss_f32.argtypes = [vp, vp, vp, i32, i32, i32, f32, vp, vp, vp]
+        L.ivln_pm_loss_fwd_f32.argtypes = [vp, vp, i32, vp, vp, vp]
+        L.ivln_pm_loss_bwd_f32.argtypes = [vp, vp, vp, i32, vp, vp]
+        L.ivln_adam_step_f32.argtypes = [vp, vp, vp, vp, i64, f32, vp, vp, f32, f32, f32, i32, f32, i32, vp]
+        _tsigs_done = True
+    return L
+
+
+def relu_bwd(dy, y, dx=None):
+    """dx = dy * (y > 0); 2-D row-strided views allowed."""
+    rows, cols = y.shape
+    if dx is None:
+        dx = torch.empty((rows, cols), dtype=torch.float32, device=y.device)
+    check(_T().ivln_relu_bwd_f32(_p(dy), _p(y), _p(dx), rows, cols, dy.stride(0), y.stride(0), dx.stride(0),
+                                 stream_ptr()), "ivln_relu_bwd_f32")
+    return dx
+
+
+def add2d(a, b, out=None):
+    rows, cols = a.shape
+    if out is None:
+        out = torch.empty((rows, cols), dtype=torch.float32, device=a.device)
+    check(_T().ivln_add2d_f32(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), rows, cols,
+                              stream_ptr()), "ivln_add2d_f32")
+    return out
+
+
+_colsum_ws = {}
+
+
+def colsum(x, out=None, accumulate=False):
+    """Column sums of a 2-D (row-strided) matrix -> (cols,)."""
+    rows, cols = x.shape
+    if out is None:
+        out = torch.empty((cols,), dtype=torch.float32, device=x.device)
+    key = str(x.device)
+    ws = _colsum_ws.get(key)
+    if ws is None or ws.numel() < 128 * cols:
+        ws = torch.empty(max(128 * cols, 1 << 18), dtype=torch.float32, device=x.device)
+        _colsum_ws[key] = ws
+    check(_T().ivln_colsum_f32(_p(x), x.stride(0), rows, cols, dptr(out), int(accumulate), dptr(ws), ws.numel(),
+                               stream_ptr()), "ivln_colsum_f32")
+    return out
+
+
+def nchw_chansum(x):
+    N, Cc, H, W = x.shape
+    out = torch.empty((Cc,), dtype=torch.float32, device=x.device)
+    check(_T().ivln_nchw_chansum_f32(dptr(x), N, Cc, H * W, dptr(out), stream_ptr()), "ivln_nchw_chansum_f32")
+    return out
+
+
+def transpose(x):
+    R, Cc = x.shape
+    y = torch.empty((Cc, R), dtype=torch.float32, device=x.device)
+    check(_T().ivln_transpose_f32(dptr(x), dptr(y), R, Cc, stream_ptr()), "ivln_transpose_f32")
+    return y
+
+
+def weight_flip_transpose(w):
+    O, I, KH, KW = w.shape
+    wt = torch.empty((I, O, KH, KW), dtype=torch.float32, device=w.device)
+    check(_T().ivln_weight_flip_transpose_f32(dptr(w), dptr(wt), O, I, KH, KW, stream_ptr()),
+          "ivln_weight_flip_transpose_f32")
+    return wt
+
+
+def attn_bwd(dout, attn_p, q, k, v, scale, dq, dk, dv):
+    rows, Ck = q.shape
+    Cv, I = v.shape[1], v.shape[2]
+    check(
+        _T().ivln_attn_bwd_f32(_p(dout), dout.stride(0), dptr(attn_p), _p(q), q.stride(0), _p(k), k.stride(0), _p(v),
+                               v.stride(0), scale, rows, Ck, Cv, I, _p(dq), dq.stride(0), _p(dk), dk.stride(0),
+                               _p(dv), dv.stride(0), stream_ptr()),
+        "ivln_attn_bwd_f32",
+    )
+
+
+def gru_bwd_elem(dout, dh_carry, r, z, n, ghn, h_prev, mask, dgi, dgh, dhz, hp_out):
+    rows, H = r.shape
+    check(
+        _T().ivln_gru_bwd_elem_f32(_p(dout), dout.stride(0), _p(dh_carry), _p(r), _p(z), _p(n), _p(ghn), _p(h_prev),
+                                   h_prev.stride(0), _p(mask), rows, H, _p(dgi), _p(dgh), _p(dhz), _p(hp_out),
+                                   stream_ptr()),
+        "ivln_gru_bwd_elem_f32",
+    )
+
+
+def linear_skinny_ex(x, W, add, rowmask, out):
+    rows, K = x.shape
+    O = W.shape[0]
+    check(
+        _T().ivln_linear_skinny_ex_f32(_p(x), x.stride(0), dptr(W), _p(add), add.stride(0) if add is not None else 0,
+                                       _p(rowmask), _p(out), out.stride(0), rows, K, O, stream_ptr()),
+        "ivln_linear_skinny_ex_f32",
+    )
+    return out
+
+
+def lstm_bidir_bwd(dout, out, gates, cs, whh_f, whh_r, lengths, B, L, H):
+    dev = dout.device
+    dgx_f = torch.empty((B * L, 4 * H), dtype=torch.float32, device=dev)
+    dgx_r = torch.empty((B * L, 4 * H), dtype=torch.float32, device=dev)
+    hp_f = torch.empty((B * L, H), dtype=torch.float32, device=dev)
+    hp_r = torch.empty((B * L, H), dtype=torch.float32, device=dev)
+    check(
+        _T().ivln_lstm_bidir_bwd_f32(dptr(dout), dptr(out), dptr(gates), dptr(cs), dptr(whh_f), dptr(whh_r),
+                                     dptr(lengths), B, L, H, dptr(dgx_f), dptr(dgx_r), dptr(hp_f), dptr(hp_r),
+                                     stream_ptr()),
+        "ivln_lstm_bidir_bwd_f32",
+    )
+    return dgx_f, dgx_r, hp_f, hp_r
+
+
+def cbra_bwd(dout, y, scale, shift, mean, rstd, train):
+    N, Cc, H, W = y.shape
+    dgamma = torch.empty((Cc,), dtype=torch.float32, device=y.device)
+    dbeta = torch.empty((Cc,), dtype=torch.float32, device=y.device)
+    dy = torch.empty_like(y)
+    check(
+        _T().ivln_cbra_bwd_f32(dptr(dout), dptr(y), dptr(scale), dptr(shift), dptr(mean), dptr(rstd), N, Cc, H, W,
+                               int(bool(train)), dptr(dgamma), dptr(dbeta), dptr(dy), stream_ptr()),
+        "ivln_cbra_bwd_f32",
+    )
+    return dy, dgamma, dbeta
+
+
+def embedding_scatter_add(tokens, d, grad, padding_idx):
+    rows, E = d.shape
+    check(_T().ivln_embedding_scatter_add_f32(dptr(tokens), dptr(d), rows, E, grad.shape[0],
+                                              -1 if padding_idx is None else padding_idx, dptr(grad), stream_ptr()),
+          "ivln_embedding_scatter_add_f32")
+
+
+def prev_action_embed_bwd(prev_actions, mask, d1, d2, n_emb):
+    rows = prev_actions.numel()
+    E = d1.shape[1]
+    grad = torch.empty((n_emb, E), dtype=torch.float32, device=d1.device)
+    check(
+        _T().ivln_prev_action_embed_bwd_f32(dptr(prev_actions), dptr(mask), _p(d1), d1.stride(0), _p(d2),
+                                            d2.stride(0) if d2 is not None else 0, rows, E, n_emb, dptr(grad),
+                                            stream_ptr()),
+        "ivln_prev_action_embed_bwd_f32",
+    )
+    return grad
+
+
+def ce_iw_loss(logits, targets, weights, loss_scale=1.0):
+    """logits (T,N,A) f32, targets (T,N) i64, weights (T,N) f32 -> (loss scalar tensor, dlogits)."""
+    T, N, A = logits.shape
+    loss = torch.empty((1,), dtype=torch.float32, device=logits.device)
+    dl = torch.empty_like(logits)
+    check(_T().ivln_ce_iw_loss_f32(dptr(logits), dptr(targets), dptr(weights), T, N, A, loss_scale, dptr(loss),
+                                   dptr(dl), stream_ptr()), "ivln_ce_iw_loss_f32")
+    return loss, dl
+
+
+def pm_loss_fwd(pre, progress):
+    n = pre.numel()
+    hat = torch.empty((n,), dtype=torch.float32, device=pre.device)
+    Lm = torch.empty((n, n), dtype=torch.float32, device=pre.device)
+    check(_T().ivln_pm_loss_fwd_f32(dptr(pre), dptr(progress), n, dptr(hat), dptr(Lm), stream_ptr()),
+          "ivln_pm_loss_fwd_f32")
+    return hat, Lm
+
+
+def pm_loss_bwd(dL, hat, progress):
+    n = hat.numel()
+    dpre = torch.empty((n,), dtype=torch.float32, device=hat.device)
+    check(_T().ivln_pm_loss_bwd_f32(dptr(dL), dptr(hat), dptr(progress), n, dptr(dpre), stream_ptr()),
+          "ivln_pm_loss_bwd_f32")
+    return dpre
+
+
+def adam_step(params, grads, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, seg_of=None,
+              seg_lr=None, grad_scale=1.0, zero_grad=True):
+    check(
+        _T().ivln_adam_step_f32(dptr(params), dptr(grads), dptr(exp_avg), dptr(exp_avg_sq), params.numel(), lr,
+                                _p(seg_of), _p(seg_lr), beta1, beta2, eps, step, grad_scale, int(bool(zero_grad)),
+                                stream_ptr()),
+        "ivln_adam_step_f32",
+    )
+
+
+# ---- GEMM-shaped gradients ----------------------------------------------------------------------------
+def linear_bwd_input(dy, w, out=None, accumulate=False):
+    """dX[r][i] = sum_o dY[r][o] W[o][i]  (dy, out may be row-strided)."""
+    rows, O = dy.shape
+    I = w.shape[1]
+    if out is None:
+        out = torch.empty((rows, I), dtype=torch.float32, device=dy.device)
+    d = GemmDesc()
+    d.A, d.B, d.D = dptr(w), _p(dy), _p(out)
+    d.M, d.N, d.K = I, rows, O
+    d.amode, d.bmode, d.dmode = A_KM, B_NK, D_DENSE
+    d.lda, d.ldb = I, dy.stride(0)
+    d.sDm, d.sDn = 1, out.stride(0)
+    d.HoWo = 1
+    _epilogue(d, None, None, None, False, accumulate)
+    d.splits = 1
+    gemm(d)
+    return out
+
+
+def linear_bwd_weight(dy, x, out=None, accumulate=False):
+    """dW[o][i] = sum_r dY[r][o] X[r][i]  -> (O, I) contiguous."""
+    rows, O = dy.shape
+    I = x.shape[1]
+    if out is None:
+        out = torch.empty((O, I), dtype=torch.float32, device=dy.device)
+    d = GemmDesc()
+    d.A, d.B, d.D = _p(dy), _p(x), dptr(out)
+    d.M, d.N, d.K = O, I, rows
+    d.amode, d.bmode, d.dmode = A_KM, B_KN, D_DENSE
+    d.lda, d.ldb = dy.stride(0), x.stride(0)
+    d.sDm, d.sDn = I, 1
+    d.HoWo = 1
+    _epilogue(d, None, None, None, False, accumulate)
+    if accumulate:
+        d.splits = 1
+    else:
+        ws = splitk_ws(dy.device)
+        d.ws, d.ws_floats, d.splits = dptr(ws), ws.numel(), 0
+    gemm(d)
+    return out
+
+
+def conv2d_bwd_weight(dy, x, KH, KW, stride=1, pad=0):
+    """dW (Cout, Cin, KH, KW) = sum over pixels dy[co][p] * im2col(x)[(ci,kh,kw)][p]."""
+    N, Cout, Ho, Wo = dy.shape
+    _, Cin, H, W = x.shape
+    out = torch.empty((Cout, Cin, KH, KW), dtype=torch.float32, device=dy.device)
+    d = GemmDesc()
+    d.A, d.B, d.D = dptr(dy), dptr(x), dptr(out)
+    d.M, d.N, d.K = Cout, Cin * KH * KW, N * Ho * Wo
+    d.amode, d.bmode, d.dmode = A_NCHW_P, B_IM2COL_T, D_DENSE
+    d.Cin, d.Hin, d.Win, d.Hout, d.Wout = Cin, H, W, Ho, Wo
+    d.stride, d.pad, d.dil = stride, pad, 1
+    d.HoWo = Ho * Wo
+    d.sDm, d.sDn = Cin * KH * KW, 1
+    koff, kpos = conv_tables(Cin, KH, KW, H, W, 1, x.device)
+    d.koff, d.kpos = dptr(koff), dptr(kpos)
+    _epilogue(d, None, None, None, False)
+    ws = splitk_ws(dy.device)
+    d.ws, d.ws_floats, d.splits = dptr(ws), ws.numel(), 0
+    gemm(d)
+    return out

@@ -1,0 +1,251 @@
+"""HIP backward of the MapCMA policy and the DAgger update step.
+
+`MapCMAForwardFn` wraps the whole net forward (policy.MapCMANet.forward_hip) in ONE
+torch.autograd.Function: autograd is only the plumbing that hands us d(features) and accumulates
+the parameter gradients we return; every gradient is computed by hand-written HIP kernels
+(csrc/train_ops.hip for the element/recurrence parts, csrc/gemm_conv.hip for every dX / dW GEMM).
+So the reference's `loss.backward()` (ivlnce_baselines/common/base_il_trainer.py:211) works on
+this policy unchanged, and `update_agent` below is the all-HIP version of `_update_agent`
+(:173-219) with fused inflection-weighted CE, flat-bucket Adam and one RCCL all-reduce.
+"""
+from typing import Dict, List
+
+import torch
+
+from . import ops
+
+
+# ------------------------------------------------------------------------------------------------
+# small autograd wrappers (plumbing only)
+# ------------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    """nn.Linear forward/backward on HIP (action head, progress monitor)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = x.contiguous()
+        ctx.save_for_backward(x, w)
+        return ops.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = ops.linear_bwd_input(dy, w) if ctx.needs_input_grad[0] else None
+        dw = ops.linear_bwd_weight(dy, x) if ctx.needs_input_grad[1] else None
+        db = ops.colsum(dy) if ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+class _PMLossFn(torch.autograd.Function):
+    """L[j][i] = (tanh(pre[i]) - progress[j])^2 (quirk Q7 broadcast, map_cma_policy.py:355-361)."""
+
+    @staticmethod
+    def forward(ctx, pre, progress):
+        pre = pre.contiguous()
+        progress = progress.to(torch.float32).reshape(-1).contiguous()
+        hat, Lm = ops.pm_loss_fwd(pre, progress)
+        ctx.save_for_backward(hat, progress)
+        return Lm
+
+    @staticmethod
+    def backward(ctx, dL):
+        hat, progress = ctx.saved_tensors
+        return ops.pm_loss_bwd(dL.contiguous(), hat, progress), None
+
+
+def progress_monitor_loss(net, feats, progress):
+    pm = net.progress_monitor
+    pre = LinearFn.apply(feats, pm.weight, pm.bias)  # (rows, 1)
+    return _PMLossFn.apply(pre.reshape(-1), progress)
+
+
+# ------------------------------------------------------------------------------------------------
+# whole-net backward
+# ------------------------------------------------------------------------------------------------
+def _gru_backward(enc, s, d_out, G):
+    """BPTT of the masked GRU state encoder; returns d(x) (rows, I)."""
+    rnn = enc.rnn
+    T, N = s["T"], s["N"]
+    H = rnn.hidden_size
+    rows = T * N
+    dev = d_out.device
+    out, h0, masks, x_in = s["out"], s["h0"], s["masks"], s["x"]
+    whh_t = ops.transpose(rnn.weight_hh_l0)  # (H, 3H): dh_prev = dgh . W_hh as a skinny linear
+    dgi = torch.empty((rows, 3 * H), dtype=torch.float32, device=dev)
+    dgh = torch.empty((rows, 3 * H), dtype=torch.float32, device=dev)
+    hp = torch.empty((rows, H), dtype=torch.float32, device=dev)
+    dhz = torch.empty((N, H), dtype=torch.float32, device=dev)
+    carry = [torch.empty((N, H), dtype=torch.float32, device=dev) for _ in range(2)]
+    dh_carry = None
+    for t in range(T - 1, -1, -1):
+        sl = slice(t * N, (t + 1) * N)
+        h_prev = h0 if t == 0 else out[(t - 1) * N: t * N]
+        ops.gru_bwd_elem(d_out[sl], dh_carry, s["r"][sl], s["z"][sl], s["n"][sl], s["ghn"][sl], h_prev, masks[sl],
+                         dgi[sl], dgh[sl], dhz, hp[sl])
+        if t > 0:
+            nxt = carry[t & 1]
+            ops.linear_skinny_ex(dgh[sl], whh_t, dhz, masks[sl], nxt)
+            dh_carry = nxt
+    G[rnn.weight_ih_l0] = ops.linear_bwd_weight(dgi, x_in)
+    G[rnn.bias_ih_l0] = ops.colsum(dgi)
+    G[rnn.weight_hh_l0] = ops.linear_bwd_weight(dgh, hp)
+    G[rnn.bias_hh_l0] = ops.colsum(dgh)
+    return ops.linear_bwd_input(dgi, rnn.weight_ih_l0)
+
+
+def _conv1d_backward(conv, d_out4, x4, d_in_residual4, G):
+    """Conv1d(k=1) viewed as a 1x1 conv over (rows, C, 1, P): returns d(x) (+ residual)."""
+    O, Cc = conv.weight.shape[0], conv.weight.shape[1]
+    w_t = ops.transpose(conv.weight.view(O, Cc))  # (C, O)
+    G[conv.weight] = ops.conv2d_bwd_weight(d_out4, x4, 1, 1).view(O, Cc, 1)
+    G[conv.bias] = ops.nchw_chansum(d_out4)
+    return ops.conv2d(d_out4, w_t.view(Cc, O, 1, 1), residual=d_in_residual4)
+
+
+def net_backward(net, S: Dict, d_feats: torch.Tensor) -> Dict:
+    """Gradients of every parameter of MapCMANet given d(loss)/d(features).  S = saves of forward_hip."""
+    G: Dict = {}
+    rows, L, P = S["rows"], S["L"], S["P"]
+    H = net._hidden_size
+    h2 = H // 2
+    scale = net._scale_f
+    o_txt, o_dep, o_map, o_prev = S["offs"]
+    x2, state_in = S["x2"], S["state_in"]
+    dev = d_feats.device
+    d_out_dep = net.depth_linear[1].out_features
+    m_out = net.map_linear[1].out_features
+
+    # ---- second GRU and its input compression ---------------------------------------------------
+    d_c2 = _gru_backward(net.second_state_encoder, S["g2"], d_feats.contiguous(), G)
+    d_pre = ops.relu_bwd(d_c2, S["c2"])
+    sc = net.second_state_compress[0]
+    G[sc.weight] = ops.linear_bwd_weight(d_pre, x2)
+    G[sc.bias] = ops.colsum(d_pre)
+    dx2 = ops.linear_bwd_input(d_pre, sc.weight)  # (rows, 1184): [state | text | dep' | map' | prev]
+
+    # ---- depth / map attentions keyed by the attended text --------------------------------------
+    dkv, mkv = S["dkv"], S["mkv"]
+    d_dkv = torch.empty_like(dkv)
+    d_mkv = torch.empty_like(mkv)
+    dq2_d = torch.empty((rows, h2), dtype=torch.float32, device=dev)
+    dq2_m = torch.empty((rows, h2), dtype=torch.float32, device=dev)
+    ops.attn_bwd(dx2[:, o_dep:o_dep + d_out_dep], S["a_dep"], S["q2"], dkv[:, :h2], dkv[:, h2:], scale, dq2_d,
+                 d_dkv[:, :h2], d_dkv[:, h2:])
+    ops.attn_bwd(dx2[:, o_map:o_map + m_out], S["a_map"], S["q2"], mkv[:, :h2], mkv[:, h2:], scale, dq2_m,
+                 d_mkv[:, :h2], d_mkv[:, h2:])
+    dq2 = ops.add2d(dq2_d, dq2_m)
+    text = x2[:, o_txt:o_txt + 256]
+    G[net.text_q.weight] = ops.linear_bwd_weight(dq2, text)
+    G[net.text_q.bias] = ops.colsum(dq2)
+    d_text = dx2[:, o_txt:o_txt + 256]
+    ops.linear_bwd_input(dq2, net.text_q.weight, out=d_text, accumulate=True)
+
+    # ---- text attention (v = the LSTM outputs themselves, k = text_k(outputs)) -------------------
+    txt, tk = S["txt_out"], S["tk"]
+    dq1 = torch.empty((rows, h2), dtype=torch.float32, device=dev)
+    d_tk = torch.empty((rows, h2, L), dtype=torch.float32, device=dev)
+    d_txt = torch.empty_like(txt)
+    ops.attn_bwd(d_text, S["a_txt"], S["q1"], tk.view(rows, h2, L), txt, scale, dq1, d_tk, d_txt)
+    d_txt = _conv1d_backward(net.text_k, d_tk.view(rows, h2, 1, L), txt.view(rows, -1, 1, L),
+                             d_txt.view(rows, -1, 1, L), G).view(rows, -1, L)
+    state = x2[:, :H]
+    G[net.state_q.weight] = ops.linear_bwd_weight(dq1, state)
+    G[net.state_q.bias] = ops.colsum(dq1)
+    d_state = dx2[:, :H]
+    ops.linear_bwd_input(dq1, net.state_q.weight, out=d_state, accumulate=True)
+
+    # ---- first GRU ----------------------------------------------------------------------------------
+    d_state_in = _gru_backward(net.state_encoder, S["g1"], d_state, G)  # (rows, 416)
+    emb = net.prev_action_embedding
+    G[emb.weight] = ops.prev_action_embed_bwd(S["prev_actions"], S["masks"], d_state_in[:, d_out_dep + m_out:],
+                                              dx2[:, o_prev:], emb.num_embeddings)
+
+    # ---- depth branch: depth_linear + dep_kv -> spatial embedding (visual encoder is frozen) --------
+    dep, mp = S["dep"], S["mp"]
+    Cd, Cm = dep.shape[1], mp.shape[1]
+    dl, ml = net.depth_linear[1], net.map_linear[1]
+    d_pre_d = ops.relu_bwd(d_state_in[:, :d_out_dep], state_in[:, :d_out_dep])
+    G[dl.weight] = ops.linear_bwd_weight(d_pre_d, dep.view(rows, -1))
+    G[dl.bias] = ops.colsum(d_pre_d)
+    d_dep = ops.linear_bwd_input(d_pre_d, dl.weight)  # (rows, 192*16)
+    d_dep = _conv1d_backward(net.dep_kv, d_dkv.view(rows, -1, 1, P), dep.view(rows, Cd, 1, P),
+                             d_dep.view(rows, Cd, 1, P), G)
+    se = net.depth_encoder.spatial_embeddings
+    c_vis = Cd - se.embedding_dim
+    G[se.weight] = ops.colsum(d_dep.view(rows, -1)[:, c_vis * P:]).view_as(se.weight)
+
+    # ---- map branch: map_linear + map_kv -> map CNN -----------------------------------------------
+    d_pre_m = ops.relu_bwd(d_state_in[:, d_out_dep:d_out_dep + m_out], state_in[:, d_out_dep:d_out_dep + m_out])
+    G[ml.weight] = ops.linear_bwd_weight(d_pre_m, mp.view(rows, -1))
+    G[ml.bias] = ops.colsum(d_pre_m)
+    d_mp = ops.linear_bwd_input(d_pre_m, ml.weight)
+    d_mp = _conv1d_backward(net.map_kv, d_mkv.view(rows, -1, 1, P), mp.view(rows, Cm, 1, P),
+                            d_mp.view(rows, Cm, 1, P), G)
+    if any(p.requires_grad for p in net.map_encoder.parameters()):
+        d = d_mp.view(mp.shape)
+        blocks = list(net.map_encoder.cnn)
+        for i in range(len(blocks) - 1, -1, -1):
+            conv, bn = blocks[i].conv[0], blocks[i].conv[1]
+            s = S["map"][i]
+            if s["train"]:
+                mean, rstd = s["mean"], s["rstd"]
+            else:
+                mean, rstd = bn.running_mean, torch.rsqrt(bn.running_var + bn.eps)
+            dy, dgamma, dbeta = ops.cbra_bwd(d.contiguous(), s["y"], s["scale"], s["shift"], mean, rstd, s["train"])
+            G[bn.weight], G[bn.bias] = dgamma, dbeta
+            G[conv.weight] = ops.conv2d_bwd_weight(dy, s["x"], 7, 7, 1, 3)
+            G[conv.bias] = ops.nchw_chansum(dy)
+            if i > 0:
+                d = ops.conv2d(dy, ops.weight_flip_transpose(conv.weight), pad=3)
+
+    # ---- instruction encoder: bidirectional LSTM BPTT ---------------------------------------------
+    ie = net.instruction_encoder
+    rnn = ie.encoder_rnn
+    st = S["txt"]
+    dgx_f, dgx_r, hp_f, hp_r = ops.lstm_bidir_bwd(d_txt.contiguous(), st["out"], st["gates"], st["cs"],
+                                                  rnn.weight_hh_l0, rnn.weight_hh_l0_reverse, st["lengths"], rows,
+                                                  L, rnn.hidden_size)
+    emb_x = st["emb"]
+    G[rnn.weight_ih_l0] = ops.linear_bwd_weight(dgx_f, emb_x)
+    G[rnn.weight_ih_l0_reverse] = ops.linear_bwd_weight(dgx_r, emb_x)
+    G[rnn.weight_hh_l0] = ops.linear_bwd_weight(dgx_f, hp_f)
+    G[rnn.weight_hh_l0_reverse] = ops.linear_bwd_weight(dgx_r, hp_r)
+    bf, br = ops.colsum(dgx_f), ops.colsum(dgx_r)
+    G[rnn.bias_ih_l0], G[rnn.bias_hh_l0] = bf, bf
+    G[rnn.bias_ih_l0_reverse], G[rnn.bias_hh_l0_reverse] = br, br
+    if ie.embedding_layer.weight.requires_grad:
+        d_emb = ops.linear_bwd_input(dgx_f, rnn.weight_ih_l0)
+        ops.linear_bwd_input(dgx_r, rnn.weight_ih_l0_reverse, out=d_emb, accumulate=True)
+        g = torch.zeros_like(ie.embedding_layer.weight)
+        ops.embedding_scatter_add(st["tokens"].reshape(-1), d_emb, g, ie.embedding_layer.padding_idx)
+        G[ie.embedding_layer.weight] = g
+    return G
+
+
+class MapCMAForwardFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, holder, *params):
+        net, observations, rnn_states, prev_actions, masks = holder
+        save: Dict = {}
+        with torch.no_grad():
+            feats, rnn_out = net.forward_hip(observations, rnn_states, prev_actions, masks, save=save)
+        ctx.net, ctx.saves, ctx.params = net, save, params
+        ctx.mark_non_differentiable(rnn_out)
+        return feats, rnn_out
+
+    @staticmethod
+    def backward(ctx, d_feats, _d_rnn):
+        with torch.no_grad():
+            G = net_backward(ctx.net, ctx.saves, d_feats)
+        grads: List = []
+        for p, need in zip(ctx.params, ctx.needs_input_grad[1:]):
+            g = G.get(p) if need else None
+            grads.append(g.view_as(p) if g is not None else None)
+        ctx.saves = None
+        return (None, *grads)
+
+    @staticmethod
+    def run(net, observations, rnn_states, prev_actions, masks):
+        params = [p for p in net.parameters() if p.requires_grad]
+        return MapCMAForwardFn.apply((net, observations, rnn_states, prev_actions, masks), *params)

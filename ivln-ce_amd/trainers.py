@@ -1,0 +1,571 @@
+"""DAgger trainers with the reference's registry names and surface
+(`dagger`, `iterative_collection_dagger`; `__init__(config)`, `train()`, `eval()`,
+`_eval_checkpoint(checkpoint_path, writer, checkpoint_index)`; checkpoint dict of
+base_il_trainer.py:158-168; result files `stats_ckpt_{i}_{split}.json` / `dtw_data_ckpt_...`).
+
+  rollout + aggregation   ivlnce_baselines/trainers/dagger_trainer.py:251-504,
+                          iterative_collection_dagger_trainer.py:131-397
+  collate / IW dataset    dagger_trainer.py:42-234
+  update                  ivlnce_baselines/common/base_il_trainer.py:173-219 (`update_agent`, all HIP)
+  eval                    base_il_trainer.py:313-583 (episodic) / :585-928 (iterative, t-nDTW)
+
+MI355X-native differences: policy + mapper run on HIP; the optimizer is one fused Adam kernel over
+a flat fp32 parameter bucket; data-parallel training = one process per GPU, envs and trajectory
+batches sharded per rank, ONE RCCL all-reduce of the flat gradient bucket per update (dist.py).
+The lmdb/msgpack trajectory database is replaced by `TrajectoryStore` (same record content).
+"""
+import json
+import os
+import random
+import time
+from collections import defaultdict
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import dist as D
+from . import ops
+from .aux_losses import AuxLosses
+from .envs import construct_envs
+from .obs_transforms import apply_obs_transforms_batch, apply_obs_transforms_obs_space, get_active_obs_transforms
+from .registry import baseline_registry
+from .tour_ndtw import compute_tour_ndtw
+from .utils import add_batched_data_to_observations, batch_obs, batch_to, extract_instruction_tokens
+
+
+# ------------------------------------------------------------------------------------------------
+# optimizer: fused Adam over a flat bucket (params and grads become views of two flat tensors)
+# ------------------------------------------------------------------------------------------------
+class FlatAdam:
+    """torch.optim.Adam(policy.parameters(), lr) semantics (base_il_trainer.py:78-94) on one flat
+    fp32 bucket: p.data / p.grad are views, the step is ONE kernel, the data-parallel gradient
+    exchange is ONE all-reduce.  `sem_lr` gives `net.map_encoder.*` its own learning rate
+    (MODEL.SEMANTIC_MAP_ENCODER.custom_lr)."""
+
+    def __init__(self, policy, lr=2.5e-4, betas=(0.9, 0.999), eps=1e-8, sem_lr: Optional[float] = None):
+        named = [(k, p) for k, p in policy.named_parameters() if p.requires_grad]
+        self.names = [k for k, _ in named]
+        self.params = [p for _, p in named]
+        dev = self.params[0].device
+        self.offsets, n = [], 0
+        for p in self.params:
+            self.offsets.append(n)
+            n += p.numel()
+        self.numel = n
+        self.flat = torch.empty(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        for p, o in zip(self.params, self.offsets):
+            self.flat[o:o + p.numel()].copy_(p.data.reshape(-1))
+            p.data = self.flat[o:o + p.numel()].view_as(p)
+            p.grad = self.grad[o:o + p.numel()].view_as(p)
+        self.lr, self.betas, self.eps, self.step_count = lr, betas, eps, 0
+        self.seg_of = self.seg_lr = None
+        if sem_lr is not None:
+            seg = torch.zeros(n, dtype=torch.int32)
+            for k, p, o in zip(self.names, self.params, self.offsets):
+                if k.startswith("net.map_encoder"):
+                    seg[o:o + p.numel()] = 1
+            self.seg_of = seg.to(dev)
+            self.seg_lr = torch.tensor([lr, sem_lr], dtype=torch.float32, device=dev)
+
+    def step(self, world: int = 1):
+        """all-reduce (sum) the flat grads when world > 1, then Adam with the 1/world mean folded in;
+        the same kernel zeroes the grads (optimizer.zero_grad())."""
+        if world > 1:
+            D.allreduce_sum_(self.grad)
+        self.step_count += 1
+        if self.flat.is_cuda:
+            ops.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.lr, self.step_count,
+                          self.betas[0], self.betas[1], self.eps, self.seg_of, self.seg_lr, 1.0 / world, True)
+        else:  # CPU path exists only for the gloo multi-process tests of the bucket/all-reduce logic
+            raise RuntimeError("FlatAdam.step needs the HIP library (no CPU fallback)")
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def state_dict(self):
+        return {"step": self.step_count, "exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu(),
+                "names": self.names, "offsets": self.offsets, "lr": self.lr}
+
+    def load_state_dict(self, sd):
+        self.step_count = sd["step"]
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+
+
+def update_agent(policy, optimizer: FlatAdam, observations, prev_actions, not_done_masks, corrected_actions, weights,
+                 hidden_size=512, step_grad=True, loss_accumulation_scalar=1, world=1):
+    """BaseVLNCETrainer._update_agent (base_il_trainer.py:173-219): forward over all T*N rows, weighted
+    CE (+ aux), backward, Adam - every arithmetic step on HIP.  Returns python floats like the
+    reference (loss, action_loss, aux_loss)."""
+    T, N = corrected_actions.size()
+    dev = corrected_actions.device
+    h0 = torch.zeros(N, policy.net.num_recurrent_layers, hidden_size, device=dev)
+    AuxLosses.clear()
+    with torch.enable_grad():
+        feats, _ = policy.net(observations, h0, prev_actions, not_done_masks)
+        logits = policy.action_distribution.raw_logits(feats)  # (T*N, A)
+    A = logits.shape[-1]
+    scale = 1.0 / loss_accumulation_scalar
+    action_loss, dlogits = ops.ce_iw_loss(logits.detach().view(T, N, A).contiguous(), corrected_actions.contiguous(),
+                                          weights.to(torch.float32).contiguous(), scale)
+    roots, grads = [logits], [dlogits.view(T * N, A)]
+    aux_loss = 0.0
+    if AuxLosses.is_active() and len(AuxLosses._losses) > 0:
+        with torch.enable_grad():
+            aux_loss = AuxLosses.reduce((weights > 0).view(-1))  # the reference's own reduction
+        roots.append(aux_loss)
+        grads.append(torch.tensor(scale, device=dev))
+    torch.autograd.backward(roots, grads)
+    if step_grad:
+        optimizer.step(world)
+    al = float(action_loss.item())
+    ax = float(aux_loss.item()) if isinstance(aux_loss, torch.Tensor) else float(aux_loss)
+    return (al + ax) * scale, al, ax
+
+
+# ------------------------------------------------------------------------------------------------
+# trajectory store + inflection-weighted dataset + collate
+# ------------------------------------------------------------------------------------------------
+class TrajectoryStore:
+    """Replaces the lmdb/msgpack_numpy database (dagger_trainer.py:349-381): record i =
+    [obs{key: (T,...)}, prev_actions i64 (T,), oracle_actions i64 (T,)] stored as `<dir>/<i>.npz`."""
+
+    def __init__(self, path):
+        self.path = path
+        os.makedirs(path, exist_ok=True)
+
+    def __len__(self):
+        return len([f for f in os.listdir(self.path) if f.endswith(".npz")])
+
+    def clear(self):
+        for f in os.listdir(self.path):
+            if f.endswith(".npz"):
+                os.remove(os.path.join(self.path, f))
+
+    def put(self, idx, traj_obs: Dict[str, np.ndarray], prev_actions, oracle_actions, tour_id=None):
+        d = {"obs/" + k: v for k, v in traj_obs.items()}
+        d["prev_actions"] = np.asarray(prev_actions, np.int64)
+        d["oracle_actions"] = np.asarray(oracle_actions, np.int64)
+        if tour_id is not None:
+            d["tour_id"] = np.asarray(str(tour_id))
+        np.savez(os.path.join(self.path, f"{idx}.npz"), **d)
+
+    def get(self, idx):
+        with np.load(os.path.join(self.path, f"{idx}.npz")) as f:
+            obs = {k[4:]: f[k] for k in f.files if k.startswith("obs/")}
+            return obs, f["prev_actions"], f["oracle_actions"]
+
+
+def collate_fn(batch):
+    """dagger_trainer.py:42-117: pad every trajectory to the longest (obs with 1.0, actions/weights with
+    0), stack on dim 1 and flatten to time-major (T*N, ...); masks zero on the first step."""
+
+    def _pad(t, max_len, fill_val=0):
+        pad_amount = max_len - t.size(0)
+        if pad_amount == 0:
+            return t
+        pad = torch.full_like(t[0:1], fill_val).expand(pad_amount, *t.size()[1:])
+        return torch.cat([t, pad], dim=0)
+
+    obs_b, prev_b, corr_b, w_b = [list(x) for x in zip(*batch)]
+    B = len(prev_b)
+    new_obs = defaultdict(list)
+    for sensor in obs_b[0]:
+        for bid in range(B):
+            new_obs[sensor].append(obs_b[bid][sensor])
+    max_len = max(e.size(0) for e in prev_b)
+    for bid in range(B):
+        for sensor in new_obs:
+            new_obs[sensor][bid] = _pad(new_obs[sensor][bid], max_len, fill_val=1.0)
+        prev_b[bid] = _pad(prev_b[bid], max_len)
+        corr_b[bid] = _pad(corr_b[bid], max_len)
+        w_b[bid] = _pad(w_b[bid], max_len)
+    out_obs = {}
+    for sensor in new_obs:
+        s = torch.stack(new_obs[sensor], dim=1)
+        out_obs[sensor] = s.view(-1, *s.size()[2:])
+    prev = torch.stack(prev_b, dim=1)
+    corr = torch.stack(corr_b, dim=1)
+    w = torch.stack(w_b, dim=1)
+    nd = torch.ones_like(corr, dtype=torch.uint8)
+    nd[0] = 0
+    return out_obs, prev.view(-1, 1), nd.view(-1, 1), corr, w
+
+
+def _block_shuffle(lst, block_size):
+    blocks = [lst[i:i + block_size] for i in range(0, len(lst), block_size)]
+    random.shuffle(blocks)
+    return [e for b in blocks for e in b]
+
+
+class IWTrajectoryDataset(torch.utils.data.IterableDataset):
+    """dagger_trainer.py:127-234 over a TrajectoryStore: length-sorted block shuffle, inflection
+    weights [1, coef][a_t != a_{t-1}] with the first step an inflection.  `rank/world` shard the
+    record indices for data-parallel training."""
+
+    def __init__(self, store: TrajectoryStore, use_iw, inflection_weight_coef=1.0, batch_size=1, rank=0, world=1):
+        super().__init__()
+        self.store = store
+        self.preload_size = batch_size * 100
+        self._preload = []
+        self.batch_size = batch_size
+        self.inflec_weights = torch.tensor([1.0, inflection_weight_coef if use_iw else 1.0])
+        n = len(store)
+        self.indices = [i for i in range(n) if i % world == rank]
+        self.length = len(self.indices)
+
+    def _load_next(self):
+        if len(self._preload) == 0:
+            if len(self.load_ordering) == 0:
+                raise StopIteration
+            new_preload, lengths = [], []
+            for _ in range(self.preload_size):
+                if len(self.load_ordering) == 0:
+                    break
+                new_preload.append(self.store.get(self.load_ordering.pop()))
+                lengths.append(len(new_preload[-1][1]))
+            sort_priority = list(range(len(lengths)))
+            random.shuffle(sort_priority)
+            order = sorted(range(len(lengths)), key=lambda k: (lengths[k], sort_priority[k]))
+            for idx in _block_shuffle(order, self.batch_size):
+                self._preload.append(new_preload[idx])
+        return self._preload.pop()
+
+    def __next__(self):
+        obs, prev_actions, oracle_actions = self._load_next()
+        obs = {k: torch.from_numpy(np.copy(v)) for k, v in obs.items()}
+        prev_actions = torch.from_numpy(np.copy(prev_actions))
+        oracle_actions = torch.from_numpy(np.copy(oracle_actions))
+        inflections = torch.cat([torch.tensor([1], dtype=torch.long), (oracle_actions[1:] != oracle_actions[:-1]).long()])
+        return obs, prev_actions, oracle_actions, self.inflec_weights[inflections]
+
+    def __iter__(self):
+        self.load_ordering = list(reversed(_block_shuffle(list(self.indices), self.preload_size)))
+        return self
+
+
+# ------------------------------------------------------------------------------------------------
+# trainers
+# ------------------------------------------------------------------------------------------------
+class BaseVLNCETrainer:
+    """common/base_il_trainer.py:46-311 + the BaseILTrainer bits of Appendix D."""
+
+    supported_tasks: List[str] = ["VLN-v0"]
+
+    def __init__(self, config=None):
+        self.config = config
+        self.rank, self.local_rank, self.world = D.world_info()
+        self.policy = None
+        self.optimizer = None
+        if not torch.cuda.is_available():
+            raise RuntimeError("the HIP hot path needs a GPU (no CPU fallback)")
+        self.device = torch.device("cuda", self.local_rank if self.world > 1 else config.TORCH_GPU_ID)
+        self.obs_transforms = []
+        self.start_epoch = 0
+        self.step_id = 0
+        self.flush_secs = 30
+
+    # -- setup ---------------------------------------------------------------------------------
+    def _make_ckpt_dir(self):
+        os.makedirs(self.config.CHECKPOINT_FOLDER, exist_ok=True)
+
+    def _make_results_dir(self):
+        os.makedirs(self.config.RESULTS_DIR, exist_ok=True)
+
+    def _get_spaces(self, config, envs=None):
+        observation_space = envs.observation_spaces[0]
+        action_space = envs.action_spaces[0]
+        self.obs_transforms = get_active_obs_transforms(self.config)
+        observation_space = apply_obs_transforms_obs_space(observation_space, self.obs_transforms)
+        return observation_space, action_space
+
+    def _initialize_policy(self, config, load_from_ckpt, observation_space, action_space):
+        from . import policy as _policy  # noqa: F401  (registers MapCMAPolicy)
+
+        policy_cls = baseline_registry.get_policy(self.config.MODEL.policy_name)
+        self.policy = policy_cls.from_config(config=config, observation_space=observation_space,
+                                             action_space=action_space)
+        self.policy.to(self.device)
+        sem = config.MODEL.SEMANTIC_MAP_ENCODER
+        self.optimizer = FlatAdam(self.policy, lr=config.IL.lr, sem_lr=sem.lr if sem.custom_lr else None)
+        if self.world > 1:  # identical initial weights on every rank
+            torch.distributed.broadcast(self.optimizer.flat, src=0)
+        if load_from_ckpt:
+            ckpt = self.load_checkpoint(config.IL.ckpt_to_load, map_location="cpu")
+            self.policy.load_state_dict(ckpt["state_dict"])
+            if config.IL.is_requeue:
+                self.optimizer.load_state_dict(ckpt["optim_state"])
+                self.start_epoch = ckpt["epoch"] + 1
+                self.step_id = ckpt["step_id"]
+
+    def save_checkpoint(self, file_name, dagger_it=0, epoch=0, step_id=0):
+        """base_il_trainer.py:143-168 (same keys)."""
+        if self.rank != 0:
+            return
+        torch.save(
+            {"state_dict": self.policy.state_dict(), "config": self.config, "optim_state": self.optimizer.state_dict(),
+             "dagger_it": dagger_it, "epoch": epoch, "step_id": step_id},
+            os.path.join(self.config.CHECKPOINT_FOLDER, file_name),
+        )
+
+    def load_checkpoint(self, checkpoint_path, *args, **kwargs):
+        kwargs.setdefault("weights_only", False)
+        return torch.load(checkpoint_path, *args, **kwargs)
+
+    def _update_agent(self, observations, prev_actions, not_done_masks, corrected_actions, weights, step_grad=True,
+                      loss_accumulation_scalar=1):
+        return update_agent(self.policy, self.optimizer, observations, prev_actions, not_done_masks, corrected_actions,
+                            weights, self.config.MODEL.STATE_ENCODER.hidden_size, step_grad, loss_accumulation_scalar,
+                            self.world)
+
+    @staticmethod
+    def _pause_envs(envs_to_pause, envs, recurrent_hidden_states, not_done_masks, prev_actions, batch, rgb_frames=None):
+        """base_il_trainer.py:221-256."""
+        if len(envs_to_pause) > 0:
+            state_index = list(range(envs.num_envs))
+            for idx in reversed(envs_to_pause):
+                state_index.pop(idx)
+                envs.pause_at(idx)
+            recurrent_hidden_states = recurrent_hidden_states[state_index]
+            not_done_masks = not_done_masks[state_index]
+            prev_actions = prev_actions[state_index]
+            for k, v in batch.items():
+                batch[k] = v[state_index] if torch.is_tensor(v) else [v[i] for i in state_index]
+        return envs, recurrent_hidden_states, not_done_masks, prev_actions, batch, rgb_frames
+
+    # -- observations -> batch ----------------------------------------------------------------
+    def _batch(self, observations, not_done_masks):
+        observations = extract_instruction_tokens(observations, self.config.TASK_CONFIG.TASK.INSTRUCTION_SENSOR_UUID)
+        observations = add_batched_data_to_observations(observations, not_done_masks, "not_done_masks")
+        batch = batch_obs(observations, self.device)
+        return observations, apply_obs_transforms_batch(batch, self.obs_transforms)
+
+    # -- eval -------------------------------------------------------------------------------------
+    def eval(self):
+        """BaseILTrainer.eval (Appendix D): a checkpoint file, or every ckpt.N.pth of a folder."""
+        path = self.config.EVAL_CKPT_PATH_DIR
+        if os.path.isfile(path):
+            return [self._eval_checkpoint(path, None, 0)]
+        out = []
+        ckpts = sorted((f for f in os.listdir(path) if f.startswith("ckpt.") and f.endswith(".pth")),
+                       key=lambda f: int(f.split(".")[1]))
+        for i, f in enumerate(ckpts):
+            out.append(self._eval_checkpoint(os.path.join(path, f), None, i))
+        return out
+
+    def _eval_checkpoint(self, checkpoint_path, writer=None, checkpoint_index=0):
+        """Episodic / iterative evaluation (base_il_trainer.py:313-583, 585-928): deterministic
+        policy, per-episode stats aggregated over all envs, dtw_data dumped per tour and t-nDTW
+        against the gt paths; map reset follows EVAL.ITERATIVE_MAP_RESET through the masks handed to
+        the mapper.  Scenes/envs are sharded over ranks; rank 0 merges."""
+        config = self.config
+        split = config.EVAL.SPLIT
+        if config.EVAL.SAVE_RESULTS:
+            self._make_results_dir()
+            fname = os.path.join(config.RESULTS_DIR, f"stats_ckpt_{checkpoint_index}_{split}.json")
+            if os.path.exists(fname):
+                return json.load(open(fname))
+        envs = construct_envs(config, None, auto_reset_done=False, rank=self.rank, world=self.world)
+        observation_space, action_space = self._get_spaces(config, envs=envs)
+        self._initialize_policy(config, load_from_ckpt=False, observation_space=observation_space,
+                                action_space=action_space)
+        if checkpoint_path and os.path.exists(checkpoint_path):
+            self.policy.load_state_dict(self.load_checkpoint(checkpoint_path, map_location="cpu")["state_dict"])
+        self.policy.eval()
+        n = envs.num_envs
+        rnn_states = torch.zeros(n, self.policy.net.num_recurrent_layers, config.MODEL.STATE_ENCODER.hidden_size,
+                                 device=self.device)
+        prev_actions = torch.zeros(n, 1, device=self.device, dtype=torch.long)
+        not_done_masks = torch.zeros(n, 1, dtype=torch.uint8, device=self.device)
+        observations = envs.reset()
+        observations, batch = self._batch(observations, not_done_masks)
+        stats_episodes = {}
+        remaining = list(envs.number_of_episodes)
+        t0 = time.time()
+        while envs.num_envs > 0:
+            with torch.no_grad():
+                actions, rnn_states = self.policy.act_iterative(
+                    batch, rnn_states, prev_actions, not_done_masks, not_done_masks, not_done_masks, not_done_masks,
+                    deterministic=not config.EVAL.SAMPLE,
+                )
+                prev_actions.copy_(actions)
+            current_episodes = envs.current_episodes()
+            outputs = envs.step([a[0].item() for a in actions])
+            observations, _, dones, infos = [list(x) for x in zip(*outputs)]
+            not_done_masks = torch.tensor([[0] if d else [1] for d in dones], dtype=torch.uint8, device=self.device)
+            envs_to_pause = []
+            for i in range(envs.num_envs):
+                if dones[i]:
+                    stats_episodes[current_episodes[i].episode_id] = infos[i]
+                    remaining[i] -= 1
+                    if remaining[i] <= 0:
+                        envs_to_pause.append(i)
+            observations, batch = self._batch(observations, not_done_masks)
+            if envs_to_pause:
+                for idx in reversed(envs_to_pause):
+                    remaining.pop(idx)
+                envs, rnn_states, not_done_masks, prev_actions, batch, _ = self._pause_envs(
+                    envs_to_pause, envs, rnn_states, not_done_masks, prev_actions, batch)
+        agent_paths, gt_paths = envs.dtw_data(), envs.gt_paths()
+        gathered = D.gather_objects((stats_episodes, agent_paths, gt_paths))
+        envs.close()
+        if self.rank != 0:
+            return None
+        stats_episodes, agent_paths, gt_paths = {}, {}, {}
+        for s, a, g in gathered:
+            stats_episodes.update(s)
+            agent_paths.update(a)
+            gt_paths.update(g)
+        agg = {}
+        num = max(1, len(stats_episodes))
+        for k in next(iter(stats_episodes.values())).keys():
+            agg[k] = sum(v[k] for v in stats_episodes.values()) / num
+        agg["t_ndtw"] = compute_tour_ndtw(agent_paths, gt_paths)
+        agg["episodes"] = len(stats_episodes)
+        agg["eval_seconds"] = time.time() - t0
+        if config.EVAL.SAVE_RESULTS:
+            json.dump(agg, open(fname, "w"), indent=4)
+            json.dump(agent_paths, open(os.path.join(config.RESULTS_DIR, f"dtw_data_ckpt_{checkpoint_index}_{split}.json"), "w"))
+        return agg
+
+    def inference(self):
+        raise NotImplementedError("quirk Q10: no reference trainer defines inference() either")
+
+
+@baseline_registry.register_trainer(name="dagger")
+class DaggerTrainer(BaseVLNCETrainer):
+    def __init__(self, config=None):
+        self.lmdb_features_dir = config.IL.DAGGER.lmdb_features_dir.format(split=config.TASK_CONFIG.DATASET.SPLIT)
+        super().__init__(config)
+        if self.world > 1:
+            self.lmdb_features_dir = os.path.join(self.lmdb_features_dir, f"rank{self.rank}")
+        self.store = TrajectoryStore(self.lmdb_features_dir)
+
+    def _make_dirs(self):
+        self._make_ckpt_dir()
+        if self.config.EVAL.SAVE_RESULTS:
+            self._make_results_dir()
+
+    tour_masked_maps = False  # IterativeCollectionDaggerTrainer resets maps with the tour mask
+
+    def _update_dataset(self, data_it):
+        """dagger_trainer.py:251-504: roll the policy out with beta-mixed expert actions, cache the
+        depth-encoder features through the forward hook, store finished trajectories."""
+        cfg = self.config
+        envs = construct_envs(cfg, None, rank=self.rank, world=self.world)
+        expert_uuid = cfg.IL.DAGGER.expert_policy_sensor_uuid
+        n = envs.num_envs
+        rnn_states = torch.zeros(n, self.policy.net.num_recurrent_layers, cfg.MODEL.STATE_ENCODER.hidden_size,
+                                 device=self.device)
+        prev_actions = torch.zeros(n, 1, device=self.device, dtype=torch.long)
+        not_done_masks = torch.zeros(n, 1, dtype=torch.uint8, device=self.device)
+        observations = envs.reset()
+        observations, batch = self._batch(observations, not_done_masks)
+        episodes = [[] for _ in range(n)]
+        skips = [False] * n
+        dones = [False] * n
+        p = cfg.IL.DAGGER.p
+        beta = 0.0 if p == 0.0 else p ** data_it
+        feats = {}
+        hook = self.policy.net.depth_encoder.visual_encoder.register_forward_hook(
+            lambda m, i, o: feats.__setitem__("depth", o.detach().cpu()))
+        collected, start_id = 0, len(self.store)
+        target = max(1, cfg.IL.DAGGER.update_size // self.world)
+        with torch.no_grad():
+            while collected < target:
+                for i in range(envs.num_envs):
+                    if dones[i] and not skips[i]:
+                        ep = episodes[i]
+                        traj_obs = batch_obs([s[0] for s in ep], device=torch.device("cpu"))
+                        del traj_obs[expert_uuid]
+                        traj_obs = {k: v.numpy() for k, v in traj_obs.items() if torch.is_tensor(v)}
+                        self.store.put(start_id + collected, traj_obs, [s[1] for s in ep], [s[2] for s in ep])
+                        collected += 1
+                    if dones[i]:
+                        episodes[i] = []
+                actions, rnn_states = self.policy.act(batch, rnn_states, prev_actions, not_done_masks,
+                                                      deterministic=False)
+                expert = batch[expert_uuid].long()
+                actions = torch.where(torch.rand_like(actions, dtype=torch.float) < beta, expert, actions)
+                occ = batch["occupancy_map"].cpu().numpy() if "occupancy_map" in batch else None
+                sem = batch["semantic_map"].cpu().numpy() if "semantic_map" in batch else None
+                prev_cpu = prev_actions.cpu()
+                expert_cpu = expert.cpu()
+                for i in range(envs.num_envs):
+                    o = dict(observations[i])
+                    o["depth_features"] = feats["depth"][i].clone()
+                    o.pop("depth", None)
+                    if occ is not None:
+                        o["occupancy_map"], o["semantic_map"] = occ[i].copy(), sem[i].copy()
+                    for k in ["semantic", "semantic12", "world_robot_pose", "world_robot_orientation", "env_name",
+                              "rgb", "not_done_masks"]:
+                        o.pop(k, None)
+                    episodes[i].append((o, prev_cpu[i].item(), expert_cpu[i].item()))
+                skips_t = expert == -1
+                actions = torch.where(skips_t, torch.zeros_like(actions), actions)
+                skips = skips_t.squeeze(-1).cpu().tolist()
+                prev_actions.copy_(actions)
+                tours_before = [getattr(e, "tour_id", None) for e in envs.current_episodes()]
+                outputs = envs.step([a[0].item() for a in actions])
+                observations, _, dones, _ = [list(x) for x in zip(*outputs)]
+                not_done_masks = torch.tensor([[0] if d else [1] for d in dones], dtype=torch.uint8,
+                                              device=self.device)
+                map_masks = not_done_masks
+                if self.tour_masked_maps:  # maps persist across the episodes of a tour (:166-168, 373-375)
+                    tours_after = [getattr(e, "tour_id", None) for e in envs.current_episodes()]
+                    map_masks = torch.tensor(
+                        [[0] if (d and a != b) else [1] for d, a, b in zip(dones, tours_after, tours_before)],
+                        dtype=torch.uint8, device=self.device)
+                observations, batch = self._batch(observations, map_masks)
+        hook.remove()
+        envs.close()
+        return collected
+
+    def train(self):
+        """dagger_trainer.py:506-649."""
+        cfg = self.config
+        D.init()
+        self._make_dirs()
+        if not cfg.IL.DAGGER.preload_lmdb_features and cfg.IL.DAGGER.drop_existing_lmdb_features:
+            self.store.clear()
+        envs = construct_envs(cfg, None, rank=self.rank, world=self.world)
+        observation_space, action_space = self._get_spaces(cfg, envs=envs)
+        envs.close()
+        self._initialize_policy(cfg, cfg.IL.load_from_ckpt, observation_space, action_space)
+        if cfg.MODEL.PROGRESS_MONITOR.use:
+            AuxLosses.activate()
+        log = []
+        for dagger_it in range(cfg.IL.DAGGER.iterations):
+            step_id = 0
+            if not cfg.IL.DAGGER.preload_lmdb_features:
+                self._update_dataset(dagger_it + (1 if cfg.IL.load_from_ckpt else 0))
+            dataset = IWTrajectoryDataset(self.store, cfg.IL.use_iw, cfg.IL.inflection_weight_coef, cfg.IL.batch_size)
+            loader = torch.utils.data.DataLoader(dataset, batch_size=cfg.IL.batch_size, shuffle=False,
+                                                 collate_fn=collate_fn, pin_memory=False, drop_last=True, num_workers=0)
+            for epoch in range(self.start_epoch, cfg.IL.epochs):
+                for batch in loader:
+                    obs_b, prev_b, nd_b, corr_b, w_b = batch
+                    obs_b, prev_b, nd_b, _, corr_b, w_b = batch_to(
+                        (obs_b, prev_b, nd_b, None, corr_b, w_b), self.device)
+                    loss, action_loss, aux_loss = self._update_agent(obs_b, prev_b, nd_b, corr_b, w_b)
+                    log.append({"dagger_it": dagger_it, "epoch": epoch, "step": step_id, "loss": loss,
+                                "action_loss": action_loss, "aux_loss": aux_loss})
+                    step_id += 1
+                    self.step_id += 1
+                self.save_checkpoint(f"ckpt.{dagger_it * cfg.IL.epochs + epoch}.pth", dagger_it=dagger_it, epoch=epoch,
+                                     step_id=self.step_id)
+        AuxLosses.deactivate()
+        return log
+
+
+@baseline_registry.register_trainer(name="iterative_collection_dagger")
+class IterativeCollectionDaggerTrainer(DaggerTrainer):
+    """iterative_collection_dagger_trainer.py:24-397: same update, but trajectories are collected
+    tour by tour with the maps carried across the episodes of a tour (the env's `not_done_masks`
+    handed to the mapper are the TOUR masks; the policy state still resets per episode)."""
+
+    tour_masked_maps = True
