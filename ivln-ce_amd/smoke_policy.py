@@ -1,0 +1,52 @@
+"""smoke(): one tiny act + one tiny DAgger update of the MapCMA policy on cuda:0, checked against
+the torch-CPU oracle (imported here only because __graft_entry__.smoke() asks for the check)."""
+import numpy as np
+import torch
+
+
+def run():
+    from oracle.policy_ref import MapCMAPolicyRef  # checker only (smoke), never on the product path
+
+    from .config import get_config
+    from .policy import MapCMAPolicy
+    from .spaces import Box, Dict, Discrete
+    from .synthetic import SyntheticRollout
+    from .trainers import FlatAdam, update_agent
+
+    dev = torch.device("cuda:0")
+    cfg = get_config(opts=["MODEL.policy_name", "MapCMAPolicy", "MODEL.INSTRUCTION_ENCODER.use_pretrained_embeddings",
+                           False, "MODEL.DEPTH_ENCODER.ddppo_checkpoint", "NONE"])
+    space = Dict({"depth": Box(0.0, 1.0, (256, 256, 1), np.float32), "occupancy_map": Box(0, 255, (64, 64), np.uint8),
+                  "semantic_map": Box(0, 255, (64, 64), np.uint8), "instruction": Box(0, 2504, (200,), np.int64)})
+    torch.manual_seed(0)
+    pol = MapCMAPolicy.from_config(cfg, space, Discrete(4))
+    ref = MapCMAPolicyRef()
+    ref.load_state_dict(pol.state_dict())
+    pol, ref = pol.to(dev).eval(), ref.eval()
+    B = 2
+    obs = SyntheticRollout(B=B, seed=9, n_tokens=30).step()
+    g = torch.Generator().manual_seed(1)
+    obs["occupancy_map"] = (torch.rand(B, 64, 64, generator=g) < 0.3).to(torch.uint8)
+    obs["semantic_map"] = (torch.randint(0, 13, (B, 64, 64), generator=g) * obs["occupancy_map"]).to(torch.uint8)
+    rnn, prev, masks = torch.zeros(B, 2, 512), torch.zeros(B, 1, dtype=torch.long), torch.zeros(B, 1, dtype=torch.uint8)
+    with torch.no_grad():
+        lr, sr, _ = ref.logits(obs, rnn, prev, masks)
+        dobs = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in obs.items()}
+        f, s = pol.net(dobs, rnn.to(dev), prev.to(dev), masks.to(dev))
+        lg = pol.action_distribution.raw_logits(f)
+    err = float((lg.cpu() - lr).abs().max())
+    assert err < 1e-4, f"policy logits mismatch vs oracle: {err}"
+    # one tiny DAgger update (T=3, N=2) with cached depth features
+    pol.train()
+    T, N = 3, 2
+    tr = {"depth_features": torch.randn(T * N, 128, 4, 4, generator=g).to(dev),
+          "occupancy_map": obs["occupancy_map"].repeat(T, 1, 1).float().to(dev),
+          "semantic_map": obs["semantic_map"].repeat(T, 1, 1).float().to(dev),
+          "instruction": obs["instruction"].repeat(T, 1).float().to(dev)}
+    nd = torch.ones(T, N, dtype=torch.uint8)
+    nd[0] = 0
+    opt = FlatAdam(pol, lr=2.5e-4)
+    loss, _, _ = update_agent(pol, opt, tr, torch.randint(0, 4, (T * N, 1), generator=g).to(dev), nd.view(-1, 1).to(dev),
+                              torch.randint(0, 4, (T, N), generator=g).to(dev), torch.ones(T, N).to(dev))
+    assert np.isfinite(loss)
+    print(f"smoke: HIP policy logits within {err:.1e} of the oracle; one HIP DAgger update, loss {loss:.4f}")

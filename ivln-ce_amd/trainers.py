@@ -536,8 +536,6 @@ class DaggerTrainer(BaseVLNCETrainer):
         observation_space, action_space = self._get_spaces(cfg, envs=envs)
         envs.close()
         self._initialize_policy(cfg, cfg.IL.load_from_ckpt, observation_space, action_space)
-        if cfg.MODEL.PROGRESS_MONITOR.use:
-            AuxLosses.activate()
         log = []
         for dagger_it in range(cfg.IL.DAGGER.iterations):
             step_id = 0
@@ -546,6 +544,7 @@ class DaggerTrainer(BaseVLNCETrainer):
             dataset = IWTrajectoryDataset(self.store, cfg.IL.use_iw, cfg.IL.inflection_weight_coef, cfg.IL.batch_size)
             loader = torch.utils.data.DataLoader(dataset, batch_size=cfg.IL.batch_size, shuffle=False,
                                                  collate_fn=collate_fn, pin_memory=False, drop_last=True, num_workers=0)
+            AuxLosses.activate()  # only around the updates, never during rollouts (dagger_trainer.py:579)
             for epoch in range(self.start_epoch, cfg.IL.epochs):
                 for batch in loader:
                     obs_b, prev_b, nd_b, corr_b, w_b = batch
@@ -558,7 +557,7 @@ class DaggerTrainer(BaseVLNCETrainer):
                     self.step_id += 1
                 self.save_checkpoint(f"ckpt.{dagger_it * cfg.IL.epochs + epoch}.pth", dagger_it=dagger_it, epoch=epoch,
                                      step_id=self.step_id)
-        AuxLosses.deactivate()
+            AuxLosses.deactivate()
         return log
 
 

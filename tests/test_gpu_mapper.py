@@ -123,3 +123,46 @@ def test_mapper_raises_without_gpu_tensor():
 
     with pytest.raises(IvlnError):
         MappingModule(torch.device("cpu"), None, MapDimensions(6.4, 6.4, 0.1))
+
+
+def test_known_map_mode_matches_oracle(tmp_path):
+    """Known-map mode (mapper.py:851-881): the world cloud of an env is loaded from
+    {maps_location}/{env_name}.npz on episode reset; raster is last-writer-wins in file order."""
+    from ivln_ce_amd.mapping import MapDimensions, MappingModule
+    from oracle.mapper_ref import MapperRef, _p, lib
+
+    rng = np.random.RandomState(0)
+    dev = torch.device("cuda:0")
+    clouds = {}
+    for name in ["sceneA", "sceneB"]:
+        n = 5000
+        xyz = np.stack([rng.uniform(-4, 4, n), rng.uniform(0.0, 2.5, n), rng.uniform(-4, 4, n)], 1).astype(np.float32)
+        xyz[:, [0, 2]] = np.round(xyz[:, [0, 2]] / 0.05) * 0.05  # many points per cell, ties on purpose
+        sem = rng.randint(0, 13, n).astype(np.int64)
+        np.savez(tmp_path / f"{name}.npz", xyz=xyz, semantics=sem)
+        clouds[name] = (xyz, sem.astype(np.uint8))
+    m = MappingModule(dev, None, MapDimensions(6.4, 6.4, 0.1), mode="known", maps_location=str(tmp_path), b_max=2)
+    ref = MapperRef(16, 16)
+    L = lib()
+    names = ["sceneA", "sceneB"]
+    for t in range(3):
+        pose = np.array([[0.3 * t, 1.25, -0.2 * t], [-0.5, 1.3, 0.4 * t]], np.float32)
+        orient = np.array([[0.0, 0.4 * t], [0.0, -0.7 * t]], np.float64)
+        nd = np.array([[0 if t == 0 else 1], [0 if t in (0, 2) else 1]], np.uint8)
+        T, rot = MapperRef.frames(pose, orient)
+        L.mapper_ref_clear_done(ref.h, 2, _p(np.ascontiguousarray(nd.reshape(-1))))
+        for b in range(2):
+            if nd[b, 0] == 0:
+                xyz, sem = clouds[names[b]]
+                L.mapper_ref_load_known(ref.h, b, _p(np.ascontiguousarray(xyz)), _p(np.ascontiguousarray(sem)), len(sem))
+        occ_r = np.zeros((2, 64, 64), np.uint8)
+        sem_r = np.zeros((2, 64, 64), np.uint8)
+        L.mapper_ref_raster(ref.h, 2, _p(pose), _p(np.ascontiguousarray(rot)), _p(occ_r), _p(sem_r))
+        obs = {"depth": torch.zeros(2, 16, 16, 1, device=dev), "world_robot_pose": torch.from_numpy(pose).to(dev),
+               "world_robot_orientation": torch.from_numpy(orient).to(dev), "not_done_masks": torch.from_numpy(nd).to(dev),
+               "env_name": names}
+        mem = m(obs, T=torch.from_numpy(T).to(dev), rot=torch.from_numpy(rot).to(dev))
+        m.check_status()
+        assert np.array_equal(mem.occupancy.cpu().numpy(), occ_r), f"occ step {t}"
+        assert np.array_equal(mem.semantic.cpu().numpy(), sem_r), f"sem step {t}"
+        assert occ_r.sum() > 100

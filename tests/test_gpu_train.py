@@ -36,11 +36,15 @@ def _check_grads(pol, g, log):
             got = float(p.grad.norm()) if p.grad is not None else float("nan")
             rel = abs(got - ref) / max(1e-6, abs(ref))
             log.append(f"{k[9:]}: |g|={got:.6e} ref={ref:.6e} rel={rel:.2e}")
-            if not (rel < 5e-4 or abs(got - ref) < 1e-7):
+            # conv biases in front of a train-mode BatchNorm have an analytically ZERO gradient; both the
+            # reference (4.7e-6) and the HIP path (6.6e-8) only hold rounding noise there
+            noise = 2e-5 if (".conv.0.bias" in k and "map_encoder" in k) else 1e-7
+            if not (rel < 5e-4 or abs(got - ref) < noise):
                 bad.append(k)
         elif k.startswith("grad/"):
             got = params[k[5:]].grad.cpu().numpy()
-            if not np.allclose(got, g[k], atol=2e-6, rtol=1e-3):
+            atol = 2e-5 if (".conv.0.bias" in k and "map_encoder" in k) else 2e-6
+            if not np.allclose(got, g[k], atol=atol, rtol=1e-3):
                 bad.append(k + f" maxerr={np.abs(got - g[k]).max():.3e}")
     return bad
 
@@ -129,7 +133,11 @@ def test_hip_update_agent_matches_reference_loss_and_moves_params():
     obs, prev, nd, tgt, w = _batch(g)
     opt = FlatAdam(pol, lr=2.5e-4)
     before = {k: v.detach().clone() for k, v in pol.named_parameters() if v.requires_grad}
+    from ivln_ce_amd.aux_losses import AuxLosses
+
+    AuxLosses.activate()  # the trainer does this when MODEL.PROGRESS_MONITOR.use (dagger_trainer.py:556-557)
     loss, action_loss, aux = update_agent(pol, opt, obs, prev, nd, tgt, w, hidden_size=512)
+    AuxLosses.deactivate()
     assert abs(loss - float(g["loss"])) < 2e-5 and abs(action_loss - float(g["action_loss"])) < 2e-5
     assert abs(aux - float(g["aux_loss"])) < 2e-5
     # first Adam step moves every element by ~lr * sign(grad)
