@@ -203,14 +203,27 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    use_graph = not args.no_graph
+    if use_graph:
+        from ivln_ce_amd.graphed import GraphedRollout
+
+        log(f"rank {rank}: capturing the step graph")
+        runner = GraphedRollout(policy, [mapper_tr], obs_dev[0], deterministic=True, streams=True)
+
+        def do_step(i):
+            runner.step(obs_dev[i % n_pool])
+    else:
+        def do_step(i):
+            rollout_step(mapper_tr, policy, obs_dev[i % n_pool], state)
+
     log(f"rank {rank}: inputs resident, warm-up {W} steps")
     for i in range(W):
-        rollout_step(mapper_tr, policy, obs_dev[i % n_pool], state)
+        do_step(i)
     barrier()
     log(f"rank {rank}: timing {K} steps")
     t0 = time.perf_counter()
     for i in range(K):
-        rollout_step(mapper_tr, policy, obs_dev[(W + i) % n_pool], state)
+        do_step(W + i)
     barrier()
     el = time.perf_counter() - t0
     mapper_tr.mapping_module.check_status()
@@ -248,6 +261,7 @@ def main():
                         f"{B} parallel envs per GPU, 256x256 depth + semantic12, 80-token instruction, random-init "
                         "weights of the reference architecture",
             "envs_per_gpu": B, "parallelism": f"dp{world} (envs sharded, no data-path collective)",
+            "launch": "hipGraph replay, 3 forked streams" if use_graph else "eager",
         },
         "roofline": roofline,
     }

@@ -117,6 +117,11 @@ typedef struct ivln_gemm_desc {
     int splits;
     float* ws;
     int64_t ws_floats;
+    /* defer_epilogue: write the raw accumulators of every split to ws ([split][M][N]) and launch no
+     * reduce/epilogue kernel - the consumer (ivln_groupnorm_f32, ivln_scale_shift_relu_avgpool2_f32)
+     * fuses the slab reduction.  splits_used (host, optional) receives the split count chosen. */
+    int defer_epilogue;
+    int* splits_used;
 } ivln_gemm_desc;
 
 int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream);
@@ -126,21 +131,26 @@ int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream);
  * ------------------------------------------------------------------------------------------ */
 /* nn.GroupNorm (+ residual add) (+ ReLU): habitat-lab ddppo resnet Bottleneck / ResNetEncoder
  * compression (reference call site models/encoders/resnet_encoders.py:31-43,95).  *_img_stride = 0
- * -> C*HW.  save_mean/save_rstd (N*groups) optional. */
+ * -> C*HW.  save_mean/save_rstd (N*groups) optional.  The input may be the split-K workspace of the
+ * producing conv (splits slabs of a [C][N*HW] matrix: x_chan_stride = N*HW, x_img_stride = HW,
+ * slab_stride = C*N*HW): the slab reduction is fused into the normalisation. */
 int ivln_groupnorm_f32(const float* x, const float* gamma, const float* beta, const float* residual,
                        float* y, int N, int C, int HW, int groups, float eps, int relu,
-                       int64_t x_img_stride, int64_t y_img_stride, int64_t r_img_stride,
-                       float* save_mean, float* save_rstd, void* stream);
+                       int64_t x_img_stride, int64_t x_chan_stride, int splits, int64_t slab_stride,
+                       int64_t y_img_stride, int64_t r_img_stride, float* save_mean, float* save_rstd,
+                       void* stream);
 /* nn.BatchNorm2d eval folding / train-mode batch statistics (models/encoders/map_encoder.py:13-20;
  * quirk Q6: train mode also during rollouts).  Both produce per-channel scale/shift. */
 int ivln_bn_fold_f32(const float* gamma, const float* beta, const float* running_mean,
-                     const float* running_var, float eps, int C, float* scale, float* shift, void* stream);
+                     const float* running_var, const float* conv_bias /* optional, folded into shift */,
+                     float eps, int C, float* scale, float* shift, void* stream);
 int ivln_bn_train_stats_f32(const float* x, int N, int C, int HW, const float* gamma, const float* beta,
                             float* running_mean, float* running_var, float momentum, float eps,
                             float* scale, float* shift, float* save_mean, float* save_rstd, void* stream);
 /* CBRA tail: relu(x*scale+shift) then AvgPool2d(2) (map_encoder.py:16-19). */
 int ivln_scale_shift_relu_avgpool2_f32(const float* x, const float* scale, const float* shift, float* y,
-                                       int N, int C, int H, int W, void* stream);
+                                       int N, int C, int H, int W, int64_t img_stride, int64_t chan_stride,
+                                       int splits, int64_t slab_stride, void* stream);
 /* F.avg_pool2d / nn.MaxPool2d over (NC,H,W); mode 0 = max, 1 = avg. */
 int ivln_pool2d_f32(const float* x, float* y, int NC, int H, int W, int k, int s, int p, int mode,
                     void* stream);

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void k_gemm(const ivln_gemm_desc p) {
     for (int r = 0; r < 16; ++r) {
         int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (m < p.M && n < p.N) {
-            if (p.splits > 1) p.ws[((int64_t)blockIdx.z * p.M + m) * p.N + n] = acc[r];
+            if (p.splits > 1 || p.defer_epilogue) p.ws[((int64_t)blockIdx.z * p.M + m) * p.N + n] = acc[r];
             else epilogue_store(p, m, n, acc[r]);
         }
     }
@@ -306,10 +306,12 @@ extern "C" int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream) {
     int64_t blocks = (int64_t)((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
     int nk = (d.K + BK - 1) / BK;
     int splits = 1;
+    if (d.defer_epilogue && (!d.ws || d.ws_floats < (int64_t)d.M * d.N)) return IVLN_E_INVALID;
     if (d.splits == 0) {
-        if (d.ws && blocks < 128 && nk >= 8) {
+        const int min_tiles = d.defer_epilogue ? 2 : 4;  // the consumer reduces for free when deferred
+        if (d.ws && blocks < 128 && nk >= 2 * min_tiles) {
             splits = (int)((256 + blocks - 1) / blocks);
-            if (splits > nk / 4) splits = nk / 4;
+            if (splits > nk / min_tiles) splits = nk / min_tiles;
             if (splits > 64) splits = 64;
             int64_t cap = d.ws_floats / ((int64_t)d.M * d.N);
             if (splits > cap) splits = (int)cap;
@@ -325,7 +327,8 @@ extern "C" int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream) {
     d.splits = splits;
     int rc = tile == 1 ? launch_tile<1, 4>(d, s) : (tile == 2 ? launch_tile<4, 1>(d, s) : launch_tile<2, 2>(d, s));
     if (rc != IVLN_OK) return rc;
-    if (splits > 1) {
+    if (d.splits_used) *d.splits_used = splits;
+    if (splits > 1 && !d.defer_epilogue) {
         int64_t total = (int64_t)d.M * d.N;
         hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d);
     }

@@ -156,7 +156,10 @@ __global__ __launch_bounds__(kThreads) void k_local_unproject(
             }
             wave_minmax_atomic(valid, r, c, sc->mmW);
         }
-        if (blockIdx.x == (unsigned)pix_blocks && threadIdx.x == 0) sc->cnt_old = n;
+        if (blockIdx.x == (unsigned)pix_blocks && threadIdx.x == 0) {
+            sc->cnt_old = n;
+            sc->cnt_dst = 0;
+        }
     }
 }
 
@@ -323,23 +326,30 @@ __global__ __launch_bounds__(kThreads) void k_world_select(
     }
 }
 
-// ---- G: semantic map from the per-cell winners; reset scalars for the next step ----
+// ---- G: semantic map from the per-cell winners; copy the surviving cloud back into the source
+// buffer (fixed pointers -> the whole step can be captured in a hipGraph and replayed); reset scalars ----
 __global__ __launch_bounds__(kThreads) void k_finalize(unsigned long long* __restrict__ cell,
                                                        uint8_t* __restrict__ sem, int map_cells, Scalars* sc,
-                                                       int swap, unsigned capacity) {
+                                                       int swap, unsigned capacity, const Pt* __restrict__ wdst,
+                                                       const int64_t* __restrict__ rdst, Pt* __restrict__ wsrc,
+                                                       int64_t* __restrict__ rsrc) {
     int i = blockIdx.x * kThreads + threadIdx.x;
     if (i < map_cells) {
         unsigned long long v = cell[i];
         sem[i] = (uint8_t)(v & 0xFFull);
         cell[i] = 0ull;
     }
+    if (swap) {
+        unsigned n = min(sc->cnt_dst, capacity);  // cnt_dst is zeroed by the NEXT step's first kernel
+        for (unsigned j = i; j < n; j += gridDim.x * kThreads) {
+            wsrc[j] = wdst[j];
+            rsrc[j] = rdst[j];
+        }
+        if (i == 0) sc->cnt_src = n;
+    }
     if (i == 0) {
         sc->mmL[0] = sc->mmL[1] = sc->mmW[0] = sc->mmW[1] = INT32_MAX;
         sc->mmL[2] = sc->mmL[3] = sc->mmW[2] = sc->mmW[3] = INT32_MIN;
-        if (swap) {
-            sc->cnt_src = min(sc->cnt_dst, capacity);
-            sc->cnt_dst = 0;
-        }
         sc->cnt_old = 0;
     }
 }
@@ -601,9 +611,10 @@ int ivln_mapper_step(ivln_mapper* m, const float* depth, const uint8_t* labels, 
     hipLaunchKernelGGL(k_world_select, dim3(world_blocks), dim3(kThreads), 0, s, wsrc, rsrc, B, not_done, m->half_res,
                        m->sc, m->tab32, m->tab64, m->table_cells, wdst, rdst, (unsigned)m->capacity, pose, rot,
                        m->rows, m->cols, m->res, m->half_h, m->half_w, occ_out, m->cell);
-    hipLaunchKernelGGL(k_finalize, dim3((map_cells + kThreads - 1) / kThreads), dim3(kThreads), 0, s, m->cell,
-                       sem_out, map_cells, m->sc, 1, (unsigned)m->capacity);
-    m->cur ^= 1;
+    int fin_blocks = (map_cells + kThreads - 1) / kThreads;
+    if (fin_blocks < 256) fin_blocks = 256;
+    hipLaunchKernelGGL(k_finalize, dim3(fin_blocks), dim3(kThreads), 0, s, m->cell, sem_out, map_cells, m->sc, 1,
+                       (unsigned)m->capacity, wdst, rdst, wsrc, rsrc);
     return hipGetLastError() == hipSuccess ? IVLN_OK : IVLN_E_HIP;
 }
 
@@ -639,7 +650,7 @@ int ivln_mapper_known_raster(ivln_mapper* m, const float* pose, const float* rot
     hipLaunchKernelGGL(k_known_raster, dim3(256), dim3(kThreads), 0, s, m->wbuf[m->cur], m->rbuf[m->cur], m->sc, pose,
                        rot, B, m->rows, m->cols, m->res, m->half_h, m->half_w, occ_out, m->cell);
     hipLaunchKernelGGL(k_finalize, dim3((map_cells + kThreads - 1) / kThreads), dim3(kThreads), 0, s, m->cell,
-                       sem_out, map_cells, m->sc, 0, (unsigned)m->capacity);
+                       sem_out, map_cells, m->sc, 0, (unsigned)m->capacity, nullptr, nullptr, nullptr, nullptr);
     return hipGetLastError() == hipSuccess ? IVLN_OK : IVLN_E_HIP;
 }
 

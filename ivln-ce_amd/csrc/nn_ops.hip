@@ -45,37 +45,75 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
 // ------------------------------------------------------------------------------------------
-// GroupNorm: one block per (image, group); the group's cpg*HW values are contiguous in NCHW.
-// Two-pass mean / biased variance (values cached in LDS when they fit), then
-// y = (x-mean)*rstd*gamma[c] + beta[c] (+ residual) (ReLU).
+// GroupNorm (+ residual) (+ ReLU): one 512-thread block per (image, group), float4 accesses.
+// The input is either an NCHW tensor (chan_stride = HW) or the split-K workspace of the producing
+// conv, `splits` slabs of a [C][N*HW] matrix (chan_stride = N*HW, img_stride = HW): the deterministic
+// slab reduction is fused here, so the conv's raw output is never materialised and no reduce kernel
+// is launched.  Two-pass mean / biased variance over values cached in LDS (re-read when they do not
+// fit), then y = (x-mean)*rstd*gamma[c] + beta[c] (+ residual) (ReLU).
 // ------------------------------------------------------------------------------------------
 constexpr int GN_CACHE = 8192;
+constexpr int GN_THREADS = 512;
 
-__global__ __launch_bounds__(256) void k_groupnorm(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                   const float* __restrict__ beta,
-                                                   const float* __restrict__ residual, float* __restrict__ y,
-                                                   int C, int HW, int groups, float eps, int relu,
-                                                   int64_t x_img_stride, int64_t y_img_stride,
-                                                   int64_t r_img_stride, float* __restrict__ save_mean,
-                                                   float* __restrict__ save_rstd) {
-    __shared__ float cache[GN_CACHE];
+__device__ __forceinline__ float4 gn_load4(const float* __restrict__ xp, int i, int HW, int64_t chan_stride,
+                                           int splits, int64_t slab_stride) {
+    int cl = i / HW, pp = i - cl * HW;
+    const float* p = xp + (int64_t)cl * chan_stride + pp;
+    float4 v = *reinterpret_cast<const float4*>(p);
+    for (int z = 1; z < splits; ++z) {
+        float4 w = *reinterpret_cast<const float4*>(p + (int64_t)z * slab_stride);
+        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+    return v;
+}
+__device__ __forceinline__ float gn_load1(const float* __restrict__ xp, int i, int HW, int64_t chan_stride,
+                                          int splits, int64_t slab_stride) {
+    int cl = i / HW, pp = i - cl * HW;
+    const float* p = xp + (int64_t)cl * chan_stride + pp;
+    float v = *p;
+    for (int z = 1; z < splits; ++z) v += p[(int64_t)z * slab_stride];
+    return v;
+}
+
+__global__ __launch_bounds__(GN_THREADS) void k_groupnorm(
+    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ residual, float* __restrict__ y, int C, int HW, int groups, float eps, int relu,
+    int64_t x_img_stride, int64_t x_chan_stride, int splits, int64_t slab_stride, int64_t y_img_stride,
+    int64_t r_img_stride, float* __restrict__ save_mean, float* __restrict__ save_rstd) {
+    __shared__ __attribute__((aligned(16))) float cache[GN_CACHE];
     __shared__ float red[16];
     const int img = blockIdx.x / groups, g = blockIdx.x % groups;
     const int cpg = C / groups;
     const int n = cpg * HW;
-    const float* xp = x + (int64_t)img * x_img_stride + (int64_t)g * n;
+    const float* xp = x + (int64_t)img * x_img_stride + (int64_t)g * cpg * x_chan_stride;
     const bool cached = n <= GN_CACHE;
+    const bool vec = (HW & 3) == 0;
     float s = 0.f;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        float v = xp[i];
-        if (cached) cache[i] = v;
-        s += v;
+    if (vec) {
+        for (int i = threadIdx.x * 4; i < n; i += GN_THREADS * 4) {
+            float4 v = gn_load4(xp, i, HW, x_chan_stride, splits, slab_stride);
+            if (cached) *reinterpret_cast<float4*>(&cache[i]) = v;
+            s += (v.x + v.y) + (v.z + v.w);
+        }
+    } else {
+        for (int i = threadIdx.x; i < n; i += GN_THREADS) {
+            float v = gn_load1(xp, i, HW, x_chan_stride, splits, slab_stride);
+            if (cached) cache[i] = v;
+            s += v;
+        }
     }
     const float mean = block_sum(s, red) / (float)n;
     float q = 0.f;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        float d = (cached ? cache[i] : xp[i]) - mean;
-        q += d * d;
+    if (cached) {
+        for (int i = threadIdx.x; i < n; i += GN_THREADS) {
+            float d = cache[i] - mean;
+            q += d * d;
+        }
+    } else {
+        for (int i = threadIdx.x; i < n; i += GN_THREADS) {
+            float d = gn_load1(xp, i, HW, x_chan_stride, splits, slab_stride) - mean;
+            q += d * d;
+        }
     }
     const float var = block_sum(q, red) / (float)n;
     const float rstd = rsqrtf(var + eps);
@@ -85,12 +123,31 @@ __global__ __launch_bounds__(256) void k_groupnorm(const float* __restrict__ x, 
     }
     float* yp = y + (int64_t)img * y_img_stride + (int64_t)g * n;
     const float* rp = residual ? residual + (int64_t)img * r_img_stride + (int64_t)g * n : nullptr;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        int c = g * cpg + i / HW;
-        float v = ((cached ? cache[i] : xp[i]) - mean) * rstd * gamma[c] + beta[c];
-        if (rp) v += rp[i];
-        if (relu) v = fmaxf(v, 0.f);
-        yp[i] = v;
+    if (vec) {
+        for (int i = threadIdx.x * 4; i < n; i += GN_THREADS * 4) {
+            int c = g * cpg + i / HW;
+            float4 v = cached ? *reinterpret_cast<const float4*>(&cache[i])
+                              : gn_load4(xp, i, HW, x_chan_stride, splits, slab_stride);
+            const float ga = gamma[c] * rstd, be = beta[c] - mean * ga;
+            v.x = fmaf(v.x, ga, be); v.y = fmaf(v.y, ga, be); v.z = fmaf(v.z, ga, be); v.w = fmaf(v.w, ga, be);
+            if (rp) {
+                float4 r = *reinterpret_cast<const float4*>(&rp[i]);
+                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+            }
+            if (relu) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            }
+            *reinterpret_cast<float4*>(&yp[i]) = v;
+        }
+    } else {
+        for (int i = threadIdx.x; i < n; i += GN_THREADS) {
+            int c = g * cpg + i / HW;
+            float v = cached ? cache[i] : gn_load1(xp, i, HW, x_chan_stride, splits, slab_stride);
+            v = (v - mean) * rstd * gamma[c] + beta[c];
+            if (rp) v += rp[i];
+            if (relu) v = fmaxf(v, 0.f);
+            yp[i] = v;
+        }
     }
 }
 
@@ -100,13 +157,15 @@ __global__ __launch_bounds__(256) void k_groupnorm(const float* __restrict__ x, 
 // like torch.nn.BatchNorm2d, scale/shift from the batch statistics.
 // ------------------------------------------------------------------------------------------
 __global__ void k_bn_fold(const float* __restrict__ gamma, const float* __restrict__ beta,
-                          const float* __restrict__ rmean, const float* __restrict__ rvar, float eps, int C,
-                          float* __restrict__ scale, float* __restrict__ shift) {
+                          const float* __restrict__ rmean, const float* __restrict__ rvar,
+                          const float* __restrict__ conv_bias, float eps, int C, float* __restrict__ scale,
+                          float* __restrict__ shift) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     float sc = gamma[c] / sqrtf(rvar[c] + eps);
     scale[c] = sc;
-    shift[c] = beta[c] - rmean[c] * sc;
+    float m = rmean[c] - (conv_bias ? conv_bias[c] : 0.f);  // BN(conv + bias) = conv*sc + (beta - (rm - bias)*sc)
+    shift[c] = beta[c] - m * sc;
 }
 
 __global__ __launch_bounds__(256) void k_bn_train_stats(const float* __restrict__ x, int N, int C, int HW,
@@ -152,25 +211,35 @@ __global__ __launch_bounds__(256) void k_bn_train_stats(const float* __restrict_
 }
 
 // y[n,c,ho,wo] = mean over the 2x2 window of relu(x*scale[c] + shift[c])   (CBRA tail:
-// BatchNorm2d -> ReLU -> AvgPool2d(2), models/encoders/map_encoder.py:13-20)
+// BatchNorm2d -> ReLU -> AvgPool2d(2), models/encoders/map_encoder.py:13-20).  x is NCHW
+// (chan_stride = H*W, img_stride = C*H*W) or the producing conv's split-K slabs ([C][N*H*W]:
+// chan_stride = N*H*W, img_stride = H*W) whose reduction is fused here.
 __global__ __launch_bounds__(256) void k_scale_shift_relu_avgpool2(const float* __restrict__ x,
                                                                    const float* __restrict__ scale,
                                                                    const float* __restrict__ shift,
-                                                                   float* __restrict__ y, int NC, int C, int H,
-                                                                   int W) {
+                                                                   float* __restrict__ y, int N, int C, int H,
+                                                                   int W, int64_t img_stride, int64_t chan_stride,
+                                                                   int splits, int64_t slab_stride) {
     const int Ho = H / 2, Wo = W / 2;
     int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (int64_t)NC * Ho * Wo) return;
+    if (idx >= (int64_t)N * C * Ho * Wo) return;
     int wo = (int)(idx % Wo);
     int ho = (int)((idx / Wo) % Ho);
     int nc = (int)(idx / ((int64_t)Wo * Ho));
-    int c = nc % C;
+    int c = nc % C, n = nc / C;
     const float sc = scale[c], sh = shift[c];
-    const float* xp = x + ((int64_t)nc * H + 2 * ho) * W + 2 * wo;
-    float a = fmaxf(fmaf(xp[0], sc, sh), 0.f);
-    float b = fmaxf(fmaf(xp[1], sc, sh), 0.f);
-    float c2 = fmaxf(fmaf(xp[W], sc, sh), 0.f);
-    float d = fmaxf(fmaf(xp[W + 1], sc, sh), 0.f);
+    const float* xp = x + (int64_t)n * img_stride + (int64_t)c * chan_stride + (int64_t)(2 * ho) * W + 2 * wo;
+    float2 t = *reinterpret_cast<const float2*>(xp);
+    float2 u = *reinterpret_cast<const float2*>(xp + W);
+    for (int z = 1; z < splits; ++z) {
+        float2 t2 = *reinterpret_cast<const float2*>(xp + (int64_t)z * slab_stride);
+        float2 u2 = *reinterpret_cast<const float2*>(xp + (int64_t)z * slab_stride + W);
+        t.x += t2.x; t.y += t2.y; u.x += u2.x; u.y += u2.y;
+    }
+    float a = fmaxf(fmaf(t.x, sc, sh), 0.f);
+    float b = fmaxf(fmaf(t.y, sc, sh), 0.f);
+    float c2 = fmaxf(fmaf(u.x, sc, sh), 0.f);
+    float d = fmaxf(fmaf(u.y, sc, sh), 0.f);
     y[idx] = (((a + b) + c2) + d) * 0.25f;
 }
 
@@ -635,21 +704,24 @@ extern "C" {
 
 int ivln_groupnorm_f32(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
                        int N, int C, int HW, int groups, float eps, int relu, int64_t x_img_stride,
-                       int64_t y_img_stride, int64_t r_img_stride, float* save_mean, float* save_rstd,
-                       void* stream) {
+                       int64_t x_chan_stride, int splits, int64_t slab_stride, int64_t y_img_stride,
+                       int64_t r_img_stride, float* save_mean, float* save_rstd, void* stream) {
     if (N <= 0 || C <= 0 || groups <= 0 || C % groups) return IVLN_E_INVALID;
+    if (x_chan_stride <= 0) x_chan_stride = HW;
     if (x_img_stride <= 0) x_img_stride = (int64_t)C * HW;
     if (y_img_stride <= 0) y_img_stride = (int64_t)C * HW;
     if (r_img_stride <= 0) r_img_stride = (int64_t)C * HW;
-    hipLaunchKernelGGL(k_groupnorm, dim3(N * groups), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, residual, y,
-                       C, HW, groups, eps, relu, x_img_stride, y_img_stride, r_img_stride, save_mean, save_rstd);
+    if (splits < 1) splits = 1;
+    hipLaunchKernelGGL(k_groupnorm, dim3(N * groups), dim3(GN_THREADS), 0, (hipStream_t)stream, x, gamma, beta,
+                       residual, y, C, HW, groups, eps, relu, x_img_stride, x_chan_stride, splits, slab_stride,
+                       y_img_stride, r_img_stride, save_mean, save_rstd);
     return LAUNCH_OK();
 }
 
 int ivln_bn_fold_f32(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
-                     float eps, int C, float* scale, float* shift, void* stream) {
+                     const float* conv_bias, float eps, int C, float* scale, float* shift, void* stream) {
     hipLaunchKernelGGL(k_bn_fold, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, gamma, beta, running_mean,
-                       running_var, eps, C, scale, shift);
+                       running_var, conv_bias, eps, C, scale, shift);
     return LAUNCH_OK();
 }
 
@@ -662,10 +734,15 @@ int ivln_bn_train_stats_f32(const float* x, int N, int C, int HW, const float* g
 }
 
 int ivln_scale_shift_relu_avgpool2_f32(const float* x, const float* scale, const float* shift, float* y, int N,
-                                       int C, int H, int W, void* stream) {
+                                       int C, int H, int W, int64_t img_stride, int64_t chan_stride, int splits,
+                                       int64_t slab_stride, void* stream) {
+    if ((W & 1) || (H & 1)) return IVLN_E_INVALID;
+    if (chan_stride <= 0) chan_stride = (int64_t)H * W;
+    if (img_stride <= 0) img_stride = (int64_t)C * H * W;
+    if (splits < 1) splits = 1;
     int64_t total = (int64_t)N * C * (H / 2) * (W / 2);
     hipLaunchKernelGGL(k_scale_shift_relu_avgpool2, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, x, scale,
-                       shift, y, N * C, C, H, W);
+                       shift, y, N, C, H, W, img_stride, chan_stride, splits, slab_stride);
     return LAUNCH_OK();
 }
 

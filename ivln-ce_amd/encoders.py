@@ -57,6 +57,25 @@ class CBRA(nn.Module):
                 save.append(dict(x=x, y=y, scale=scale, shift=shift, train=False))
         return ops.scale_shift_relu_avgpool2(y, scale, shift)
 
+    def _folded(self):
+        """Eval-mode BatchNorm folded with the conv bias, cached until the weights change."""
+        conv, bn = self.conv[0], self.conv[1]
+        key = (ops.WEIGHT_EPOCH, bn.weight._version, bn.bias._version, bn.running_mean._version,
+               bn.running_var._version, conv.bias._version, bn.weight.data_ptr())
+        if getattr(self, "_fold_key", None) != key:
+            C = bn.num_features
+            scale = torch.empty(C, dtype=torch.float32, device=bn.weight.device)
+            shift = torch.empty(C, dtype=torch.float32, device=bn.weight.device)
+            ops.bn_fold(bn, scale, shift, conv.bias)
+            self._fold_key, self._fold = key, (scale, shift)
+        return self._fold
+
+    def forward_infer(self, x):
+        """Rollout path (BatchNorm in eval mode, nothing saved): conv leaves raw split-K slabs, one
+        kernel reduces them + folded BN + ReLU + AvgPool: 2 launches per block."""
+        scale, shift = self._folded()
+        return ops.scale_shift_relu_avgpool2(ops.conv2d(x, self.conv[0].weight, pad=3, defer=True), scale, shift)
+
 
 class SemanticMapEncoder(nn.Module):
     def __init__(self, observation_space, num_semantic_classes: int = 13, ch: int = 32, last_ch_mult: int = 8,
@@ -94,7 +113,10 @@ class SemanticMapEncoder(nn.Module):
                 raise ValueError(f"Observation `{k}` is missing.")
         x = self.generate_map_features(observations)
         for blk in self.cnn:
-            x = blk.forward_hip(x, save)
+            if save is None and not blk.conv[1].training:
+                x = blk.forward_infer(x)
+            else:
+                x = blk.forward_hip(x, save)
         return x
 
 
@@ -167,18 +189,20 @@ class _Bottleneck(nn.Module):
         self.stride = stride
 
     def forward_hip(self, x):
+        """conv -> GroupNorm(+ReLU) pairs: the conv leaves raw (split-K) slabs in the workspace and the
+        GroupNorm kernel reduces + normalises them, 2 launches per pair."""
         c = self.convs
         identity = x
         if self.downsample is not None:
-            d = ops.conv2d(x, self.downsample[0].weight, stride=self.stride)
             gn = self.downsample[1]
-            identity = ops.groupnorm(d, gn.weight, gn.bias, gn.num_groups, gn.eps, out=d)
-        y = ops.conv2d(x, c[0].weight)
-        ops.groupnorm(y, c[1].weight, c[1].bias, c[1].num_groups, c[1].eps, relu=True, out=y)
-        y2 = ops.conv2d(y, c[3].weight, stride=self.stride, pad=1)
-        ops.groupnorm(y2, c[4].weight, c[4].bias, c[4].num_groups, c[4].eps, relu=True, out=y2)
-        y3 = ops.conv2d(y2, c[6].weight)
-        return ops.groupnorm(y3, c[7].weight, c[7].bias, c[7].num_groups, c[7].eps, relu=True, residual=identity, out=y3)
+            d = ops.conv2d(x, self.downsample[0].weight, stride=self.stride, defer=True)
+            identity = ops.groupnorm(d, gn.weight, gn.bias, gn.num_groups, gn.eps)
+        y = ops.conv2d(x, c[0].weight, defer=True)
+        y = ops.groupnorm(y, c[1].weight, c[1].bias, c[1].num_groups, c[1].eps, relu=True)
+        y = ops.conv2d(y, c[3].weight, stride=self.stride, pad=1, defer=True)
+        y = ops.groupnorm(y, c[4].weight, c[4].bias, c[4].num_groups, c[4].eps, relu=True)
+        y = ops.conv2d(y, c[6].weight, defer=True)
+        return ops.groupnorm(y, c[7].weight, c[7].bias, c[7].num_groups, c[7].eps, relu=True, residual=identity)
 
 
 class _ResNet50GN(nn.Module):
@@ -209,8 +233,8 @@ class _ResNet50GN(nn.Module):
 
     def forward_hip(self, x):
         c, gn = self.conv1[0], self.conv1[1]
-        y = ops.conv2d(x, c.weight, stride=2, pad=3)
-        ops.groupnorm(y, gn.weight, gn.bias, gn.num_groups, gn.eps, relu=True, out=y)
+        y = ops.conv2d(x, c.weight, stride=2, pad=3, defer=True)
+        y = ops.groupnorm(y, gn.weight, gn.bias, gn.num_groups, gn.eps, relu=True)
         y = ops.pool2d(y, 3, 2, 1, "max")
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
             for blk in layer:
@@ -254,13 +278,12 @@ class ResNetEncoder(nn.Module):
         x = ops.pool2d(depth.view(B, 1, H, W), 2, 2, 0, "avg")  # F.avg_pool2d(x, 2)
         x = self.backbone.forward_hip(x)
         c, gn = self.compression[0], self.compression[1]
-        y = ops.conv2d(x, c.weight, pad=1)
-        Co, hw = self.output_shape[0], self.output_shape[1] * self.output_shape[2]
+        y = ops.conv2d(x, c.weight, pad=1, defer=True)
+        hw = self.output_shape[1] * self.output_shape[2]
         if out is None:
-            return ops.groupnorm(y, gn.weight, gn.bias, gn.num_groups, gn.eps, relu=True, out=y)
-        ops.groupnorm(y, gn.weight, gn.bias, gn.num_groups, gn.eps, relu=True, out=out,
-                      y_img_stride=out_ctot * hw, N=B, C=Co, HW=hw)
-        return out
+            return ops.groupnorm(y, gn.weight, gn.bias, gn.num_groups, gn.eps, relu=True)
+        return ops.groupnorm(y, gn.weight, gn.bias, gn.num_groups, gn.eps, relu=True, out=out,
+                             y_img_stride=out_ctot * hw)
 
 
 class VlnResnetDepthEncoder(nn.Module):

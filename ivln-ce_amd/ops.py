@@ -30,6 +30,7 @@ class GemmDesc(C.Structure):
         ("relu", i32), ("accumulate", i32),
         ("splits", i32),
         ("ws", vp), ("ws_floats", i64),
+        ("defer_epilogue", i32), ("splits_used", C.POINTER(i32)),
     ]
 
 
@@ -45,10 +46,11 @@ def _L():
     L = lib()
     if not _sigs_done:
         L.ivln_gemm_f32.argtypes = [C.POINTER(GemmDesc), vp]
-        L.ivln_groupnorm_f32.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, i64, i64, i64, vp, vp, vp]
-        L.ivln_bn_fold_f32.argtypes = [vp, vp, vp, vp, f32, i32, vp, vp, vp]
+        L.ivln_groupnorm_f32.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, i64, i64, i32, i64, i64, i64,
+                                         vp, vp, vp]
+        L.ivln_bn_fold_f32.argtypes = [vp, vp, vp, vp, vp, f32, i32, vp, vp, vp]
         L.ivln_bn_train_stats_f32.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp]
-        L.ivln_scale_shift_relu_avgpool2_f32.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
+        L.ivln_scale_shift_relu_avgpool2_f32.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i32, i64, vp]
         L.ivln_pool2d_f32.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
         L.ivln_map_features_f32.argtypes = [vp, vp, vp, i32, i32, i32, vp]
         L.ivln_embed_lengths.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp]
@@ -100,7 +102,9 @@ def conv_tables(cin, kh, kw, hin, win, dil, device, transposed=False):
 
 
 def splitk_ws(device, floats=8 << 20):
-    key = str(device)
+    """Split-K / deferred-epilogue workspace, one per (device, stream): concurrent branches of the
+    captured step graph must not share it."""
+    key = (str(device), torch.cuda.current_stream().cuda_stream)
     w = _ws.get(key)
     if w is None or w.numel() < floats:
         w = torch.empty(floats, dtype=torch.float32, device=device)
@@ -117,15 +121,24 @@ def _epilogue(d: GemmDesc, scale, shift, residual, relu, accumulate=False):
     d.relu, d.accumulate = int(bool(relu)), int(bool(accumulate))
 
 
+class Deferred:
+    """Raw conv output left in the split-K workspace: `splits` slabs of a [C][N*HW] matrix."""
+
+    def __init__(self, ws, splits, N, C, H, W):
+        self.ws, self.splits, self.N, self.C, self.H, self.W = ws, splits, N, C, H, W
+
+
 def conv2d(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, relu=False, out=None, out_ctot=0,
-           in_img_stride=0, splitk=True):
+           in_img_stride=0, splitk=True, defer=False):
     """NCHW conv: x (N,Cin,H,W) [contiguous per image, image stride `in_img_stride`], w OIHW.
     out: optional destination (a channel slice of an (N,out_ctot,Ho,Wo) buffer)."""
     N, Cin, H, W = x.shape
     Cout, _, KH, KW = w.shape
     Ho = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
     Wo = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
-    if out is None:
+    if defer:
+        out = splitk_ws(x.device)  # D is unused by the kernel in deferred mode
+    elif out is None:
         out = torch.empty((N, Cout, Ho, Wo), dtype=torch.float32, device=x.device)
     d = GemmDesc()
     d.A, d.B, d.D = dptr(w), _p(x), _p(out)
@@ -143,6 +156,13 @@ def conv2d(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, 
         koff, kpos = conv_tables(Cin, KH, KW, H, W, dil, x.device)
         d.koff, d.kpos = dptr(koff), dptr(kpos)
     _epilogue(d, scale, shift, residual, relu)
+    if defer:
+        ws = splitk_ws(x.device)
+        used = i32(0)
+        d.ws, d.ws_floats, d.splits, d.defer_epilogue = dptr(ws), ws.numel(), 0, 1
+        d.splits_used = C.pointer(used)
+        gemm(d)
+        return Deferred(ws, used.value, N, Cout, Ho, Wo)
     if splitk:
         ws = splitk_ws(x.device)
         d.ws, d.ws_floats, d.splits = dptr(ws), ws.numel(), 0
@@ -213,25 +233,39 @@ def linear(x, w, bias=None, relu=False, out=None):
     return out
 
 
-def groupnorm(x, gamma, beta, groups, eps=1e-5, relu=False, residual=None, out=None, x_img_stride=0,
-              y_img_stride=0, r_img_stride=0, N=None, C=None, HW=None):
-    if N is None:
-        N, C = x.shape[0], x.shape[1]
-        HW = x.shape[2] * x.shape[3]
+def groupnorm(x, gamma, beta, groups, eps=1e-5, relu=False, residual=None, out=None, y_img_stride=0,
+              r_img_stride=0):
+    """x: NCHW tensor or a `Deferred` conv output (slab reduction fused).  `out` may be a channel slice
+    of a wider NCHW buffer (y_img_stride = its image stride)."""
+    if isinstance(x, Deferred):
+        N, Cc, H, W = x.N, x.C, x.H, x.W
+        HW = H * W
+        xp, x_img, x_chan, splits, slab = dptr(x.ws), HW, N * HW, x.splits, Cc * N * HW
+        dev = x.ws.device
+    else:
+        N, Cc, H, W = x.shape
+        HW = H * W
+        xp, x_img, x_chan, splits, slab = _p(x), 0, 0, 1, 0
+        dev = x.device
     if out is None:
-        out = torch.empty_like(x)
+        out = torch.empty((N, Cc, H, W), dtype=torch.float32, device=dev)
     check(
-        _L().ivln_groupnorm_f32(_p(x), dptr(gamma), dptr(beta), _p(residual), _p(out), N, C, HW, groups, eps,
-                                int(bool(relu)), x_img_stride, y_img_stride, r_img_stride, None, None, stream_ptr()),
+        _L().ivln_groupnorm_f32(xp, dptr(gamma), dptr(beta), _p(residual), _p(out), N, Cc, HW, groups, eps,
+                                int(bool(relu)), x_img, x_chan, splits, slab, y_img_stride, r_img_stride, None, None,
+                                stream_ptr()),
         "ivln_groupnorm_f32",
     )
     return out
 
 
-def bn_fold(bn, scale, shift):
+WEIGHT_EPOCH = 0  # bumped by FlatAdam.step(): kernels update parameters through raw pointers, which
+#                   torch's tensor version counters do not see
+
+
+def bn_fold(bn, scale, shift, conv_bias=None):
     check(
-        _L().ivln_bn_fold_f32(dptr(bn.weight), dptr(bn.bias), dptr(bn.running_mean), dptr(bn.running_var), bn.eps,
-                              bn.num_features, dptr(scale), dptr(shift), stream_ptr()),
+        _L().ivln_bn_fold_f32(dptr(bn.weight), dptr(bn.bias), dptr(bn.running_mean), dptr(bn.running_var),
+                              _p(conv_bias), bn.eps, bn.num_features, dptr(scale), dptr(shift), stream_ptr()),
         "ivln_bn_fold_f32",
     )
 
@@ -249,11 +283,19 @@ def bn_train_stats(x, bn, scale, shift, save_mean=None, save_rstd=None, update_r
 
 
 def scale_shift_relu_avgpool2(x, scale, shift, out=None):
-    N, Cc, H, W = x.shape
+    """x: NCHW tensor or a `Deferred` conv output (slab reduction fused)."""
+    if isinstance(x, Deferred):
+        N, Cc, H, W = x.N, x.C, x.H, x.W
+        xp, img_s, chan_s, splits, slab = dptr(x.ws), H * W, N * H * W, x.splits, Cc * N * H * W
+        dev = x.ws.device
+    else:
+        N, Cc, H, W = x.shape
+        xp, img_s, chan_s, splits, slab = dptr(x), 0, 0, 1, 0
+        dev = x.device
     if out is None:
-        out = torch.empty((N, Cc, H // 2, W // 2), dtype=torch.float32, device=x.device)
-    check(_L().ivln_scale_shift_relu_avgpool2_f32(dptr(x), dptr(scale), dptr(shift), dptr(out), N, Cc, H, W,
-                                                   stream_ptr()), "ivln_scale_shift_relu_avgpool2_f32")
+        out = torch.empty((N, Cc, H // 2, W // 2), dtype=torch.float32, device=dev)
+    check(_L().ivln_scale_shift_relu_avgpool2_f32(xp, dptr(scale), dptr(shift), dptr(out), N, Cc, H, W, img_s, chan_s,
+                                                   splits, slab, stream_ptr()), "ivln_scale_shift_relu_avgpool2_f32")
     return out
 
 

@@ -183,9 +183,25 @@ class MapCMANet(Net):
 
         s_txt = {} if save is not None else None
         s_map = [] if save is not None else None
-        txt, lengths = self.instruction_encoder(observations, s_txt)  # (rows,256,L)
-        dep = self.depth_encoder(observations)  # (rows,192,4,4)
-        mp = self.map_encoder(observations, s_map)  # (rows,128,4,4)
+        side = getattr(self, "_side_streams", None) if save is None else None
+        if side is None:
+            txt, lengths = self.instruction_encoder(observations, s_txt)  # (rows,256,L)
+            dep = self.depth_encoder(observations)  # (rows,192,4,4)
+            mp = self.map_encoder(observations, s_map)  # (rows,128,4,4)
+        else:
+            # three independent, latency-bound branches on forked streams (graphed.py): instruction
+            # bi-LSTM || (mapper ->) map CNN || depth ResNet; joined before the recurrent head
+            cur = torch.cuda.current_stream()
+            st_txt, st_map = side
+            st_txt.wait_stream(cur)
+            st_map.wait_stream(cur)
+            with torch.cuda.stream(st_txt):
+                txt, lengths = self.instruction_encoder(observations, None)
+            with torch.cuda.stream(st_map):
+                mp = self.map_encoder(observations, None)
+            dep = self.depth_encoder(observations)
+            cur.wait_stream(st_txt)
+            cur.wait_stream(st_map)
         if mc.ablate_instruction:
             txt = torch.zeros_like(txt)
         if mc.ablate_depth:

@@ -213,3 +213,35 @@ def test_attention():
     out2 = torch.zeros(rows, Cv, device=DEV)
     ops.attn(q.to(DEV), k[:, :, :16].contiguous().to(DEV), v[:, :, :16].contiguous().to(DEV), None, 0.0625, out2)
     _close(out2, ref2, 2e-5)
+
+
+@pytest.mark.parametrize("N,Cin,H,W,Cout,k,s,p,G", [(4, 256, 8, 8, 128, 3, 1, 1, 16), (4, 1024, 4, 4, 128, 3, 1, 1, 1),
+                                                     (2, 32, 32, 32, 128, 1, 1, 0, 16), (3, 1, 128, 128, 32, 7, 2, 3, 16)])
+def test_deferred_conv_fused_into_groupnorm(N, Cin, H, W, Cout, k, s, p, G):
+    """conv leaves split-K slabs in the workspace; GroupNorm reduces + normalises (+res, +ReLU)."""
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(Cin + k)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    gamma, beta = torch.randn(Cout, generator=g), torch.randn(Cout, generator=g)
+    y = F.conv2d(x, w, None, stride=s, padding=p)
+    res = torch.randn_like(y)
+    ref = F.relu(F.group_norm(y, G, gamma, beta, 1e-5) + res)
+    d = ops.conv2d(x.to(DEV), w.to(DEV), stride=s, pad=p, defer=True)
+    assert isinstance(d, ops.Deferred) and d.splits >= 1
+    got = ops.groupnorm(d, gamma.to(DEV), beta.to(DEV), G, 1e-5, relu=True, residual=res.to(DEV))
+    _close(got, ref, 3e-5)
+
+
+def test_deferred_conv_fused_into_bn_relu_pool():
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(4, 128, 8, 8, generator=g)
+    w = torch.randn(128, 128, 7, 7, generator=g) / (128 * 49) ** 0.5
+    sc, sh = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g)
+    ref = F.avg_pool2d(F.relu(F.conv2d(x, w, None, padding=3) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)), 2)
+    d = ops.conv2d(x.to(DEV), w.to(DEV), pad=3, defer=True)
+    assert d.splits > 1
+    _close(ops.scale_shift_relu_avgpool2(d, sc.to(DEV), sh.to(DEV)), ref, 3e-5)
