@@ -88,7 +88,9 @@ enum { IVLN_B_CONV = 0,    /* im2col gather from NCHW via koff/kpos tables      
        IVLN_B_KN = 2,      /* B[k*ldb + n]                                            */
        IVLN_B_NK = 3,      /* B[n*ldb + k]  (activations [rows][features])            */
        IVLN_B_IM2COL_T = 4,/* B[k = out pixel][n = (ci,kh,kw)] (conv weight gradient) */
-       IVLN_B_CONVT = 5    /* transposed-conv gather (koff = ci*Hin*Win)              */ };
+       IVLN_B_CONVT = 5,   /* transposed-conv gather (koff = ci*Hin*Win)              */
+       IVLN_B_CONV_K3 = 6, /* 3x3, dilation 1: tap indices by constant division, no tables */
+       IVLN_B_CONV_K7 = 7  /* 7x7, dilation 1                                            */ };
 enum { IVLN_D_NCHW = 0,    /* D[(img*Ctot + m)*HoWo + pp], n = img*HoWo + pp          */
        IVLN_D_DENSE = 1    /* D[m*sDm + n*sDn]                                        */ };
 

@@ -25,7 +25,8 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 enum { AMODE_MK = 0, AMODE_KM = 1, AMODE_NCHW_P = 2 };
-enum { BMODE_CONV = 0, BMODE_CONV1X1 = 1, BMODE_KN = 2, BMODE_NK = 3, BMODE_IM2COL_T = 4, BMODE_CONVT = 5 };
+enum { BMODE_CONV = 0, BMODE_CONV1X1 = 1, BMODE_KN = 2, BMODE_NK = 3, BMODE_IM2COL_T = 4, BMODE_CONVT = 5,
+       BMODE_CONV_K3 = 6, BMODE_CONV_K7 = 7 };  // 3x3 / 7x7, dilation 1: (ci,kh,kw) by constant division, no tables
 enum { DMODE_NCHW = 0, DMODE_DENSE = 1 };
 
 constexpr int BK = 16;
@@ -81,7 +82,8 @@ __global__ __launch_bounds__(256) void k_gemm(const ivln_gemm_desc p) {
     int64_t pix_base = 0;
     int hi0 = 0, wi0 = 0;
     bool n_ok = false;
-    if constexpr (BMODE == BMODE_CONV || BMODE == BMODE_CONV1X1 || BMODE == BMODE_CONVT) {
+    if constexpr (BMODE == BMODE_CONV || BMODE == BMODE_CONV1X1 || BMODE == BMODE_CONVT || BMODE == BMODE_CONV_K3 ||
+                  BMODE == BMODE_CONV_K7) {
         int n = n0 + b_n;
         n_ok = n < p.N;
         int nn = n_ok ? n : 0;
@@ -109,9 +111,9 @@ __global__ __launch_bounds__(256) void k_gemm(const ivln_gemm_desc p) {
         }
     }
 
-    float ra[EA], rb[EB];
+    float ra0[EA], rb0[EB], ra1[EA], rb1[EB];
 
-    auto load_tile = [&](int k0) {
+    auto load_tile = [&](int k0, float (&ra)[EA], float (&rb)[EB]) {
         // ---------------- A ----------------
         if constexpr (AMODE == AMODE_MK) {
             int k = k0 + a_k;
@@ -150,6 +152,24 @@ __global__ __launch_bounds__(256) void k_gemm(const ivln_gemm_desc p) {
                     int hi = hi0 + (kp >> 16) * p.dil, wi = wi0 + (kp & 0xFFFF) * p.dil;
                     if ((unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win)
                         v = p.B[pix_base + p.koff[k] + (int64_t)hi0 * p.Win + wi0];
+                }
+                rb[e] = v;
+            }
+        } else if constexpr (BMODE == BMODE_CONV_K3 || BMODE == BMODE_CONV_K7) {
+            // same gather with (ci,kh,kw) from constant divisions: removes the dependent table load from
+            // the per-tile critical path (these launches are latency- not bandwidth-bound)
+            constexpr int KS = BMODE == BMODE_CONV_K3 ? 3 : 7;
+            const int HWin = p.Hin * p.Win;
+#pragma unroll
+            for (int e = 0; e < EB; ++e) {
+                int k = k0 + b_k + e * B_STEP;
+                float v = 0.f;
+                if (n_ok && k < kend) {
+                    int ci = k / (KS * KS), r = k - ci * (KS * KS);
+                    int kh = r / KS, kw = r - kh * KS;
+                    int hi = hi0 + kh, wi = wi0 + kw;
+                    if ((unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win)
+                        v = p.B[pix_base + (int64_t)ci * HWin + (int64_t)hi * p.Win + wi];
                 }
                 rb[e] = v;
             }
@@ -217,21 +237,29 @@ __global__ __launch_bounds__(256) void k_gemm(const ivln_gemm_desc p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
+    // Software pipeline, two K tiles in flight in registers: the global/gather loads issued in
+    // iteration i are consumed in iteration i+2, so their latency overlaps two MFMA phases (with only a
+    // handful of blocks per CU at rollout batch sizes there is little else to hide it behind).
     if (kbeg < kend) {
-        load_tile(kbeg);
+        load_tile(kbeg, ra0, rb0);
+        if (kbeg + BK < kend) load_tile(kbeg + BK, ra1, rb1);
         for (int k0 = kbeg; k0 < kend; k0 += BK) {
 #pragma unroll
             for (int e = 0; e < EA; ++e) {
-                if constexpr (A_KFAST) As[a_k * LDA_S + a_m + e * A_STEP] = ra[e];
-                else As[(a_k + e * A_STEP) * LDA_S + a_m] = ra[e];
+                if constexpr (A_KFAST) As[a_k * LDA_S + a_m + e * A_STEP] = ra0[e];
+                else As[(a_k + e * A_STEP) * LDA_S + a_m] = ra0[e];
             }
 #pragma unroll
             for (int e = 0; e < EB; ++e) {
-                if constexpr (B_KFAST) Bs[b_k * LDB_S + b_n + e * B_STEP] = rb[e];
-                else Bs[(b_k + e * B_STEP) * LDB_S + b_n] = rb[e];
+                if constexpr (B_KFAST) Bs[b_k * LDB_S + b_n + e * B_STEP] = rb0[e];
+                else Bs[(b_k + e * B_STEP) * LDB_S + b_n] = rb0[e];
             }
             __syncthreads();
-            if (k0 + BK < kend) load_tile(k0 + BK);
+#pragma unroll
+            for (int e = 0; e < EA; ++e) ra0[e] = ra1[e];
+#pragma unroll
+            for (int e = 0; e < EB; ++e) rb0[e] = rb1[e];
+            if (k0 + 2 * BK < kend) load_tile(k0 + 2 * BK, ra1, rb1);
 #pragma unroll
             for (int kk = 0; kk < BK / 2; ++kk) {
                 float a = As[(2 * kk + (lane >> 5)) * LDA_S + wm * 32 + (lane & 31)];
@@ -275,6 +303,8 @@ int launch_tile(const ivln_gemm_desc& d, hipStream_t s) {
     }
     IVLN_CASE(AMODE_MK, BMODE_CONV)
     IVLN_CASE(AMODE_MK, BMODE_CONV1X1)
+    IVLN_CASE(AMODE_MK, BMODE_CONV_K3)
+    IVLN_CASE(AMODE_MK, BMODE_CONV_K7)
     IVLN_CASE(AMODE_MK, BMODE_CONVT)
     IVLN_CASE(AMODE_MK, BMODE_NK)
     IVLN_CASE(AMODE_MK, BMODE_KN)
@@ -308,11 +338,14 @@ extern "C" int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream) {
     int splits = 1;
     if (d.defer_epilogue && (!d.ws || d.ws_floats < (int64_t)d.M * d.N)) return IVLN_E_INVALID;
     if (d.splits == 0) {
-        const int min_tiles = d.defer_epilogue ? 2 : 4;  // the consumer reduces for free when deferred
-        if (d.ws && blocks < 128 && nk >= 2 * min_tiles) {
-            splits = (int)((256 + blocks - 1) / blocks);
+        // the consumer reduces for free when deferred: split until ~4 blocks per CU hide the load latency
+        const int min_tiles = d.defer_epilogue ? 2 : 4;
+        const int64_t want = d.defer_epilogue ? 1024 : 256;
+        if (d.ws && blocks < (d.defer_epilogue ? 512 : 128) && nk >= 2 * min_tiles) {
+            splits = (int)((want + blocks - 1) / blocks);
             if (splits > nk / min_tiles) splits = nk / min_tiles;
-            if (splits > 64) splits = 64;
+            const int max_splits = d.defer_epilogue ? (blocks <= 8 ? 64 : (blocks <= 32 ? 32 : 16)) : 64;
+            if (splits > max_splits) splits = max_splits;
             int64_t cap = d.ws_floats / ((int64_t)d.M * d.N);
             if (splits > cap) splits = (int)cap;
             if (splits < 1) splits = 1;

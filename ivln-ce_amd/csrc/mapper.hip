@@ -49,7 +49,12 @@ __device__ __forceinline__ int cell_index(float v, float half_res) {
     return (int)rintf(__fdiv_rn(v, half_res));  // mapper.py:464 (v / (res/2)).round().long()
 }
 
-__device__ __forceinline__ void wave_minmax_atomic(bool valid, int r, int c, int* mm) {
+// Global min/max of the cell indices without atomics: every block writes ONE partial
+// {rmin,cmin,rmax,cmax} (wave shuffles + LDS), and the next kernel's blocks each fold the (few hundred
+// to ~1300) partials at start-up.  (The first version issued 4 same-address atomics per wave:
+// ~16k serialised L2 atomics = 100-146 us for what is a ~5 us kernel.)
+__device__ __forceinline__ void block_minmax_store(bool valid, int r, int c, int* __restrict__ dst4) {
+    __shared__ int sh[4][4];
     int rmin = valid ? r : INT32_MAX, cmin = valid ? c : INT32_MAX;
     int rmax = valid ? r : INT32_MIN, cmax = valid ? c : INT32_MIN;
 #pragma unroll
@@ -59,15 +64,50 @@ __device__ __forceinline__ void wave_minmax_atomic(bool valid, int r, int c, int
         rmax = max(rmax, __shfl_xor(rmax, o));
         cmax = max(cmax, __shfl_xor(cmax, o));
     }
-    // min/max are monotone, so a (possibly stale) relaxed read that already beats this wave's value
-    // makes the atomic unnecessary: after the first few waves almost every wave skips all four
-    // (the un-filtered version serialised ~16k same-address atomics: 146 us -> a few us).
-    if ((threadIdx.x & 63) == 0 && rmin != INT32_MAX) {
-        if (rmin < __hip_atomic_load(&mm[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&mm[0], rmin);
-        if (cmin < __hip_atomic_load(&mm[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&mm[1], cmin);
-        if (rmax > __hip_atomic_load(&mm[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&mm[2], rmax);
-        if (cmax > __hip_atomic_load(&mm[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&mm[3], cmax);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        sh[w][0] = rmin; sh[w][1] = cmin; sh[w][2] = rmax; sh[w][3] = cmax;
     }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        dst4[0] = min(min(sh[0][0], sh[1][0]), min(sh[2][0], sh[3][0]));
+        dst4[1] = min(min(sh[0][1], sh[1][1]), min(sh[2][1], sh[3][1]));
+        dst4[2] = max(max(sh[0][2], sh[1][2]), max(sh[2][2], sh[3][2]));
+        dst4[3] = max(max(sh[0][3], sh[1][3]), max(sh[2][3], sh[3][3]));
+    }
+}
+
+// Fold n partials into mm4 (shared memory of the calling block); block 0 also publishes them.
+__device__ __forceinline__ void block_minmax_fold(const int* __restrict__ partials, int n, int* mm4,
+                                                  int* __restrict__ publish) {
+    __shared__ int sh[4][4];
+    int rmin = INT32_MAX, cmin = INT32_MAX, rmax = INT32_MIN, cmax = INT32_MIN;
+    for (int i = threadIdx.x; i < n; i += kThreads) {
+        const int4 v = *reinterpret_cast<const int4*>(partials + 4 * i);
+        rmin = min(rmin, v.x); cmin = min(cmin, v.y); rmax = max(rmax, v.z); cmax = max(cmax, v.w);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        rmin = min(rmin, __shfl_xor(rmin, o));
+        cmin = min(cmin, __shfl_xor(cmin, o));
+        rmax = max(rmax, __shfl_xor(rmax, o));
+        cmax = max(cmax, __shfl_xor(cmax, o));
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        sh[w][0] = rmin; sh[w][1] = cmin; sh[w][2] = rmax; sh[w][3] = cmax;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mm4[0] = min(min(sh[0][0], sh[1][0]), min(sh[2][0], sh[3][0]));
+        mm4[1] = min(min(sh[0][1], sh[1][1]), min(sh[2][1], sh[3][1]));
+        mm4[2] = max(max(sh[0][2], sh[1][2]), max(sh[2][2], sh[3][2]));
+        mm4[3] = max(max(sh[0][3], sh[1][3]), max(sh[2][3], sh[3][3]));
+        if (publish && blockIdx.x == 0) {
+            publish[0] = mm4[0]; publish[1] = mm4[1]; publish[2] = mm4[2]; publish[3] = mm4[3];
+        }
+    }
+    __syncthreads();
 }
 
 // Wave-aggregated append: returns the slot for lanes with pred, or 0xFFFFFFFF when full.
@@ -98,7 +138,8 @@ __global__ __launch_bounds__(kThreads) void k_local_unproject(
     const float* __restrict__ depth, const float* __restrict__ T, const float* __restrict__ pose,
     const uint8_t* __restrict__ not_done, const float* __restrict__ xs, const float* __restrict__ ys,
     int B, int H, int W, float half_res, float4* __restrict__ rec, const Pt* __restrict__ wsrc,
-    Scalars* sc, uint8_t* __restrict__ occ, int map_cells, int pix_blocks) {
+    Scalars* sc, uint8_t* __restrict__ occ, int map_cells, int pix_blocks, int* __restrict__ bmmL,
+    int* __restrict__ bmmW) {
     if ((int)blockIdx.x < pix_blocks) {
         int64_t pix = (int64_t)blockIdx.x * kThreads + threadIdx.x;
         int64_t total = (int64_t)B * H * W;
@@ -134,27 +175,45 @@ __global__ __launch_bounds__(kThreads) void k_local_unproject(
             }
             rec[pix] = out;
         }
-        wave_minmax_atomic(valid, r, c, sc->mmL);
+        block_minmax_store(valid, r, c, bmmL + 4 * blockIdx.x);
         // zero the occupancy output (DenseMap.update_map fill_(0), mapper.py:570)
         for (int64_t i = pix; i < map_cells; i += (int64_t)pix_blocks * kThreads) occ[i] = 0;
     } else {
         // old world points that survive clear_completed_episode_data (mapper.py:310-326)
         unsigned n = sc->cnt_src;
         int nb = gridDim.x - pix_blocks;
-        for (unsigned base = ((unsigned)blockIdx.x - pix_blocks) * kThreads; base < n; base += nb * kThreads) {
-            unsigned i = base + threadIdx.x;
-            bool valid = false;
-            int r = 0, c = 0;
-            if (i < n) {
-                Pt p = wsrc[i];
-                int b = (int)(p.meta >> 8);
-                if (b < B && not_done[b] != 0) {
-                    valid = true;
-                    r = cell_index(p.z, half_res);
-                    c = cell_index(p.x, half_res);
-                }
+        int rmin = INT32_MAX, cmin = INT32_MAX, rmax = INT32_MIN, cmax = INT32_MIN;
+        for (unsigned i = ((unsigned)blockIdx.x - pix_blocks) * kThreads + threadIdx.x; i < n; i += nb * kThreads) {
+            Pt p = wsrc[i];
+            int b = (int)(p.meta >> 8);
+            if (b < B && not_done[b] != 0) {
+                int r = cell_index(p.z, half_res), c = cell_index(p.x, half_res);
+                rmin = min(rmin, r); cmin = min(cmin, c); rmax = max(rmax, r); cmax = max(cmax, c);
             }
-            wave_minmax_atomic(valid, r, c, sc->mmW);
+        }
+        // encode the per-thread box as two "points" for the block reduction
+        const bool any = rmin != INT32_MAX;
+        __shared__ int shw[4][4];
+        int v0 = rmin, v1 = cmin, v2 = rmax, v3 = cmax;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            v0 = min(v0, __shfl_xor(v0, o));
+            v1 = min(v1, __shfl_xor(v1, o));
+            v2 = max(v2, __shfl_xor(v2, o));
+            v3 = max(v3, __shfl_xor(v3, o));
+        }
+        (void)any;
+        const int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) {
+            shw[w][0] = v0; shw[w][1] = v1; shw[w][2] = v2; shw[w][3] = v3;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int* dst = bmmW + 4 * ((int)blockIdx.x - pix_blocks);
+            dst[0] = min(min(shw[0][0], shw[1][0]), min(shw[2][0], shw[3][0]));
+            dst[1] = min(min(shw[0][1], shw[1][1]), min(shw[2][1], shw[3][1]));
+            dst[2] = max(max(shw[0][2], shw[1][2]), max(shw[2][2], shw[3][2]));
+            dst[3] = max(max(shw[0][3], shw[1][3]), max(shw[2][3], shw[3][3]));
         }
         if (blockIdx.x == (unsigned)pix_blocks && threadIdx.x == 0) {
             sc->cnt_old = n;
@@ -167,13 +226,16 @@ __global__ __launch_bounds__(kThreads) void k_local_unproject(
 __global__ __launch_bounds__(kThreads) void k_local_argmax(const float4* __restrict__ rec, int B, int H, int W,
                                                            float half_res, Scalars* sc,
                                                            unsigned long long* __restrict__ tab64,
-                                                           int64_t table_cells) {
+                                                           int64_t table_cells, const int* __restrict__ bmmL,
+                                                           int n_partials) {
+    __shared__ int mm[4];
+    block_minmax_fold(bmmL, n_partials, mm, sc->mmL);
     int64_t pix = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (pix >= (int64_t)B * H * W) return;
     float4 p = rec[pix];
     if (p.w == 0.f) return;
     int b = (int)(pix / ((int64_t)W * H));
-    int64_t key = make_key(b, cell_index(p.z, half_res), cell_index(p.x, half_res), sc->mmL);
+    int64_t key = make_key(b, cell_index(p.z, half_res), cell_index(p.x, half_res), mm);
     if (key < 0 || key >= table_cells) {
         sc->err = IVLN_E_KEYSPACE;
         return;
@@ -188,7 +250,8 @@ __global__ __launch_bounds__(kThreads) void k_local_select(const float4* __restr
                                                            int W, float half_res, Scalars* sc,
                                                            unsigned long long* __restrict__ tab64,
                                                            int64_t table_cells, Pt* __restrict__ wsrc,
-                                                           int64_t* __restrict__ rsrc, unsigned capacity) {
+                                                           int64_t* __restrict__ rsrc, unsigned capacity,
+                                                           int* __restrict__ bmmW_local) {
     int64_t pix = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     bool win = false;
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -218,7 +281,7 @@ __global__ __launch_bounds__(kThreads) void k_local_select(const float4* __restr
         wsrc[slot] = q;
         rsrc[slot] = (int64_t)(kLocalRankBit | (uint64_t)key);
     }
-    wave_minmax_atomic(stored, r, c, sc->mmW);
+    block_minmax_store(stored, r, c, bmmW_local + 4 * blockIdx.x);
 }
 
 __device__ __forceinline__ bool world_alive(const Pt& p, unsigned i, unsigned cnt_old, int B,
@@ -232,13 +295,16 @@ __device__ __forceinline__ bool world_alive(const Pt& p, unsigned i, unsigned cn
 __global__ __launch_bounds__(kThreads) void k_world_max(const Pt* __restrict__ wsrc, int B,
                                                         const uint8_t* __restrict__ not_done, float half_res,
                                                         Scalars* sc, unsigned* __restrict__ tab32,
-                                                        int64_t table_cells, unsigned capacity) {
+                                                        int64_t table_cells, unsigned capacity,
+                                                        const int* __restrict__ bmmW, int n_partials) {
+    __shared__ int mm[4];
+    block_minmax_fold(bmmW, n_partials, mm, sc->mmW);
     unsigned n = min(sc->cnt_src, capacity);
     unsigned cnt_old = sc->cnt_old;
     for (unsigned i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
         Pt p = wsrc[i];
         if (!world_alive(p, i, cnt_old, B, not_done)) continue;
-        int64_t key = make_key((int)(p.meta >> 8), cell_index(p.z, half_res), cell_index(p.x, half_res), sc->mmW);
+        int64_t key = make_key((int)(p.meta >> 8), cell_index(p.z, half_res), cell_index(p.x, half_res), mm);
         if (key < 0 || key >= table_cells) {
             sc->err = IVLN_E_KEYSPACE;
             continue;
@@ -465,6 +531,8 @@ struct ivln_mapper {
     unsigned* tab32;
     unsigned long long* cell;
     Scalars* sc;
+    int* bmmL;  // per-block min/max partials (local cloud)
+    int* bmmW;  // per-block partials (old world blocks, then local-select blocks)
     int64_t known_rank;
 };
 
@@ -544,7 +612,9 @@ int ivln_mapper_create(int B_max, int H, int W, double vfov_rad, double height_m
               hipMalloc(&m->tab64, sizeof(unsigned long long) * (size_t)m->table_cells) == hipSuccess &&
               hipMalloc(&m->tab32, sizeof(unsigned) * (size_t)m->table_cells) == hipSuccess &&
               hipMalloc(&m->cell, sizeof(unsigned long long) * (size_t)cells) == hipSuccess &&
-              hipMalloc(&m->sc, sizeof(Scalars)) == hipSuccess;
+              hipMalloc(&m->sc, sizeof(Scalars)) == hipSuccess &&
+              hipMalloc(&m->bmmL, sizeof(int) * 4 * (((size_t)B_max * H * W + kThreads - 1) / kThreads + 1)) == hipSuccess &&
+              hipMalloc(&m->bmmW, sizeof(int) * 4 * (256 + ((size_t)B_max * H * W + kThreads - 1) / kThreads + 1)) == hipSuccess;
     if (ok) {
         ok = hipMemcpy(m->xs, hx, sizeof(float) * W, hipMemcpyHostToDevice) == hipSuccess &&
              hipMemcpy(m->ys, hy, sizeof(float) * H, hipMemcpyHostToDevice) == hipSuccess &&
@@ -567,7 +637,7 @@ int ivln_mapper_destroy(ivln_mapper* m) {
     if (!m) return IVLN_OK;
     (void)hipFree(m->xs); (void)hipFree(m->ys); (void)hipFree(m->rec);
     (void)hipFree(m->wbuf[0]); (void)hipFree(m->wbuf[1]); (void)hipFree(m->rbuf[0]); (void)hipFree(m->rbuf[1]);
-    (void)hipFree(m->tab64); (void)hipFree(m->tab32); (void)hipFree(m->cell); (void)hipFree(m->sc);
+    (void)hipFree(m->tab64); (void)hipFree(m->tab32); (void)hipFree(m->cell); (void)hipFree(m->sc); (void)hipFree(m->bmmL); (void)hipFree(m->bmmW);
     delete m;
     return IVLN_OK;
 }
@@ -599,13 +669,14 @@ int ivln_mapper_step(ivln_mapper* m, const float* depth, const uint8_t* labels, 
     int64_t* rdst = m->rbuf[m->cur ^ 1];
     hipLaunchKernelGGL(k_local_unproject, dim3(pix_blocks + world_blocks), dim3(kThreads), 0, s, depth, T, pose,
                        not_done, m->xs, m->ys, B, m->H, m->W, m->half_res, m->rec, wsrc, m->sc, occ_out, map_cells,
-                       pix_blocks);
+                       pix_blocks, m->bmmL, m->bmmW);
     hipLaunchKernelGGL(k_local_argmax, dim3(pix_blocks), dim3(kThreads), 0, s, m->rec, B, m->H, m->W, m->half_res,
-                       m->sc, m->tab64, m->table_cells);
+                       m->sc, m->tab64, m->table_cells, m->bmmL, pix_blocks);
     hipLaunchKernelGGL(k_local_select, dim3(pix_blocks), dim3(kThreads), 0, s, m->rec, labels, B, m->H, m->W,
-                       m->half_res, m->sc, m->tab64, m->table_cells, wsrc, rsrc, (unsigned)m->capacity);
+                       m->half_res, m->sc, m->tab64, m->table_cells, wsrc, rsrc, (unsigned)m->capacity,
+                       m->bmmW + 4 * world_blocks);
     hipLaunchKernelGGL(k_world_max, dim3(world_blocks), dim3(kThreads), 0, s, wsrc, B, not_done, m->half_res, m->sc,
-                       m->tab32, m->table_cells, (unsigned)m->capacity);
+                       m->tab32, m->table_cells, (unsigned)m->capacity, m->bmmW, world_blocks + pix_blocks);
     hipLaunchKernelGGL(k_world_first, dim3(world_blocks), dim3(kThreads), 0, s, wsrc, rsrc, B, not_done, m->half_res,
                        m->sc, m->tab32, m->tab64, m->table_cells, (unsigned)m->capacity);
     hipLaunchKernelGGL(k_world_select, dim3(world_blocks), dim3(kThreads), 0, s, wsrc, rsrc, B, not_done, m->half_res,

@@ -385,8 +385,9 @@ __global__ __launch_bounds__(4 * H) void k_lstm_bidir(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
-// Skinny linear: y[n][o] = act(W[o].x[n] + b[o]) for few rows n (rollout batch).  One wave per
-// output row, lanes stride K with float4 loads, rows processed 8 at a time.
+// Skinny linear: y[n][o] = act(W[o].x[n] + b[o]) for few rows n (rollout batch).  One 256-thread
+// block per output row: the 4 waves split K (float4 loads, every lane busy even at K = 3072),
+// partial sums meet in LDS.  Rows processed 8 at a time.
 // (nn.Linear at models/map_cma_policy.py:156-171,218-224, common/utils.py:176-185)
 // ------------------------------------------------------------------------------------------
 constexpr int SK_ROWS = 8;
@@ -395,16 +396,16 @@ __global__ __launch_bounds__(256) void k_linear_skinny(const float* __restrict__
                                                        const float* __restrict__ W, const float* __restrict__ bias,
                                                        float* __restrict__ y, int64_t ldy, int rows, int K, int O,
                                                        int relu) {
-    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (o >= O) return;
+    __shared__ float part[4][SK_ROWS];
+    const int o = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* wr = W + (int64_t)o * K;
     for (int r0 = 0; r0 < rows; r0 += SK_ROWS) {
         float acc[SK_ROWS];
 #pragma unroll
         for (int r = 0; r < SK_ROWS; ++r) acc[r] = 0.f;
         if ((K & 3) == 0) {
-            for (int k = lane * 4; k < K; k += 256) {
+            for (int k = threadIdx.x * 4; k < K; k += 1024) {
                 float4 wv = *reinterpret_cast<const float4*>(wr + k);
 #pragma unroll
                 for (int r = 0; r < SK_ROWS; ++r) {
@@ -418,7 +419,7 @@ __global__ __launch_bounds__(256) void k_linear_skinny(const float* __restrict__
                 }
             }
         } else {
-            for (int k = lane; k < K; k += 64) {
+            for (int k = threadIdx.x; k < K; k += 256) {
                 float wv = wr[k];
 #pragma unroll
                 for (int r = 0; r < SK_ROWS; ++r)
@@ -428,20 +429,25 @@ __global__ __launch_bounds__(256) void k_linear_skinny(const float* __restrict__
 #pragma unroll
         for (int r = 0; r < SK_ROWS; ++r) {
             float v = wave_sum(acc[r]);
-            if (lane == 0 && r0 + r < rows) {
-                if (bias) v += bias[o];
-                if (relu) v = fmaxf(v, 0.f);
-                y[(int64_t)(r0 + r) * ldy + o] = v;
-            }
+            if (lane == 0) part[wave][r] = v;
         }
+        __syncthreads();
+        if (threadIdx.x < SK_ROWS && r0 + (int)threadIdx.x < rows) {
+            const int r = threadIdx.x;
+            float v = (part[0][r] + part[1][r]) + (part[2][r] + part[3][r]);
+            if (bias) v += bias[o];
+            if (relu) v = fmaxf(v, 0.f);
+            y[(int64_t)(r0 + r) * ldy + o] = v;
+        }
+        __syncthreads();
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // Masked GRU step (habitat-lab RNNStateEncoder single_forward / one step of seq_forward wrapping
-// nn.GRU; call sites models/map_cma_policy.py:314-318,346-353).  One wave per hidden unit j:
-//   gi = W_ih[{r,z,n}][j].x + b_ih  (or precomputed gi when x == nullptr)
-//   gh = W_hh[{r,z,n}][j].(h*mask) + b_hh
+// nn.GRU; call sites models/map_cma_policy.py:314-318,346-353).  One block per hidden unit j, the 4
+// waves split K of the six weight rows W_ih[{r,z,n}][j], W_hh[{r,z,n}][j]:
+//   gi = W_ih x + b_ih  (or precomputed gi when x == nullptr);  gh = W_hh (h*mask) + b_hh
 //   r = s(gi_r+gh_r)  z = s(gi_z+gh_z)  n = tanh(gi_n + r*gh_n)  h' = (1-z)*n + z*h
 // rows processed 8 at a time.  Optional saves for BPTT: (rows, H) each of r, z, n, gh_n.
 // ------------------------------------------------------------------------------------------
@@ -455,9 +461,9 @@ __global__ __launch_bounds__(256) void k_gru_step(const float* __restrict__ x, i
                                                   float* __restrict__ h_out2, int64_t ldo2, int rows, int H,
                                                   float* __restrict__ save_r, float* __restrict__ save_z,
                                                   float* __restrict__ save_n, float* __restrict__ save_ghn) {
-    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (j >= H) return;
+    __shared__ float part[4][6][SK_ROWS];
+    const int j = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int r0 = 0; r0 < rows; r0 += SK_ROWS) {
         float ai[3][SK_ROWS], ah[3][SK_ROWS];
 #pragma unroll
@@ -465,7 +471,7 @@ __global__ __launch_bounds__(256) void k_gru_step(const float* __restrict__ x, i
 #pragma unroll
             for (int r = 0; r < SK_ROWS; ++r) ai[g][r] = ah[g][r] = 0.f;
         if (x) {
-            for (int k = lane * 4; k < I; k += 256) {
+            for (int k = threadIdx.x * 4; k < I; k += 1024) {
                 float4 wv[3];
 #pragma unroll
                 for (int g = 0; g < 3; ++g)
@@ -485,7 +491,7 @@ __global__ __launch_bounds__(256) void k_gru_step(const float* __restrict__ x, i
                 }
             }
         }
-        for (int k = lane * 4; k < H; k += 256) {
+        for (int k = threadIdx.x * 4; k < H; k += 1024) {
             float4 wv[3];
 #pragma unroll
             for (int g = 0; g < 3; ++g) wv[g] = *reinterpret_cast<const float4*>(w_hh + ((int64_t)g * H + j) * H + k);
@@ -505,37 +511,44 @@ __global__ __launch_bounds__(256) void k_gru_step(const float* __restrict__ x, i
             }
         }
 #pragma unroll
-        for (int r = 0; r < SK_ROWS; ++r) {
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int r = 0; r < SK_ROWS; ++r) {
+                float vi = wave_sum(ai[g][r]);
+                float vh = wave_sum(ah[g][r]);
+                if (lane == 0) {
+                    part[wave][g][r] = vi;
+                    part[wave][3 + g][r] = vh;
+                }
+            }
+        __syncthreads();
+        if (threadIdx.x < SK_ROWS && r0 + (int)threadIdx.x < rows) {
+            const int r = threadIdx.x, row = r0 + r;
             float gi[3], gh[3];
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
-                gi[g] = wave_sum(ai[g][r]);
-                gh[g] = wave_sum(ah[g][r]);
+                gi[g] = (part[0][g][r] + part[1][g][r]) + (part[2][g][r] + part[3][g][r]);
+                gh[g] = (part[0][3 + g][r] + part[1][3 + g][r]) + (part[2][3 + g][r] + part[3][3 + g][r]);
+                if (x) gi[g] += b_ih[g * H + j];
+                else gi[g] = gi_pre[(int64_t)row * ldgi + g * H + j];
+                gh[g] += b_hh[g * H + j];
             }
-            if (lane == 0 && r0 + r < rows) {
-                const int row = r0 + r;
-#pragma unroll
-                for (int g = 0; g < 3; ++g) {
-                    if (x) gi[g] += b_ih[g * H + j];
-                    else gi[g] = gi_pre[(int64_t)row * ldgi + g * H + j];
-                    gh[g] += b_hh[g * H + j];
-                }
-                float mk = mask ? (mask[row] ? 1.f : 0.f) : 1.f;
-                float hp = h_in[(int64_t)row * ldh + j] * mk;
-                float rg = sigmoidf_(gi[0] + gh[0]);
-                float zg = sigmoidf_(gi[1] + gh[1]);
-                float ng = tanhf(gi[2] + rg * gh[2]);
-                float hn = (1.f - zg) * ng + zg * hp;
-                h_out[(int64_t)row * ldo + j] = hn;
-                if (h_out2) h_out2[(int64_t)row * ldo2 + j] = hn;
-                if (save_r) {
-                    save_r[(int64_t)row * H + j] = rg;
-                    save_z[(int64_t)row * H + j] = zg;
-                    save_n[(int64_t)row * H + j] = ng;
-                    save_ghn[(int64_t)row * H + j] = gh[2];
-                }
+            float mk = mask ? (mask[row] ? 1.f : 0.f) : 1.f;
+            float hp = h_in[(int64_t)row * ldh + j] * mk;
+            float rg = sigmoidf_(gi[0] + gh[0]);
+            float zg = sigmoidf_(gi[1] + gh[1]);
+            float ng = tanhf(gi[2] + rg * gh[2]);
+            float hn = (1.f - zg) * ng + zg * hp;
+            h_out[(int64_t)row * ldo + j] = hn;
+            if (h_out2) h_out2[(int64_t)row * ldo2 + j] = hn;
+            if (save_r) {
+                save_r[(int64_t)row * H + j] = rg;
+                save_z[(int64_t)row * H + j] = zg;
+                save_n[(int64_t)row * H + j] = ng;
+                save_ghn[(int64_t)row * H + j] = gh[2];
             }
         }
+        __syncthreads();
     }
 }
 
@@ -544,7 +557,9 @@ __global__ __launch_bounds__(256) void k_gru_step(const float* __restrict__ x, i
 //   logits[i] = sum_c q[n][c] k[n][c][i];  masked i: logits - 1e8;  attn = softmax(logits*scale)
 //   out[n][c'] = sum_i attn[i] v[n][c'][i]
 // k: (N, Ck, I) and v: (N, Cv, I) channel-major with image strides; valid_len[n] (or null):
-// positions >= valid_len are the masked (all-zero) text positions.  One block per row.
+// positions >= valid_len are the masked (all-zero) text positions.  One block per row.  Logits:
+// threads are (position i, channel part) so that all 256 lanes work for I = 16 (depth/map) as well as
+// I = 200 (text), loads coalesced along i.  Output: one wave per channel c', lanes along i.
 // ------------------------------------------------------------------------------------------
 constexpr int ATT_MAX_I = 512;
 
@@ -556,41 +571,57 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ q, int64
                                               float* __restrict__ save_attn) {
     __shared__ float qs[1024];
     __shared__ float ps[ATT_MAX_I];
+    __shared__ float pl[256];
     __shared__ float red[16];
     const int n = blockIdx.x;
-    for (int c = threadIdx.x; c < Ck; c += blockDim.x) qs[c] = q[(int64_t)n * ldq + c];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = threadIdx.x; c < Ck; c += 256) qs[c] = q[(int64_t)n * ldq + c];
     __syncthreads();
     const float* kp = k + (int64_t)n * k_img_stride;
     const int vl = valid_len ? valid_len[n] : I;
+    int IP = 1;
+    while (IP < I && IP < 256) IP <<= 1;  // positions per pass (power of two <= 256)
+    const int nparts = 256 / IP;
+    const int ti = threadIdx.x % IP, tp = threadIdx.x / IP;
     float lmax = -INFINITY;
-    for (int i = threadIdx.x; i < I; i += blockDim.x) {
+    for (int i0 = 0; i0 < I; i0 += IP) {
+        const int i = i0 + ti;
         float acc = 0.f;
-        for (int c = 0; c < Ck; ++c) acc = fmaf(qs[c], kp[(int64_t)c * I + i], acc);
-        if (i >= vl) acc = acc - 1e8f;
-        acc *= scale;
-        ps[i] = acc;
-        lmax = fmaxf(lmax, acc);
+        if (i < I)
+            for (int c = tp; c < Ck; c += nparts) acc = fmaf(qs[c], kp[(int64_t)c * I + i], acc);
+        pl[threadIdx.x] = acc;
+        __syncthreads();
+        if (tp == 0 && i < I) {
+            float s = 0.f;
+            for (int pp = 0; pp < nparts; ++pp) s += pl[pp * IP + ti];
+            if (i >= vl) s = s - 1e8f;
+            s *= scale;
+            ps[i] = s;
+            lmax = fmaxf(lmax, s);
+        }
+        __syncthreads();
     }
     lmax = block_max(lmax, red);
     float sum = 0.f;
-    for (int i = threadIdx.x; i < I; i += blockDim.x) {
+    for (int i = threadIdx.x; i < I; i += 256) {
         float e = expf(ps[i] - lmax);
         ps[i] = e;
         sum += e;
     }
     sum = block_sum(sum, red);
     const float inv = 1.f / sum;
-    for (int i = threadIdx.x; i < I; i += blockDim.x) {
+    for (int i = threadIdx.x; i < I; i += 256) {
         float a = ps[i] * inv;
         ps[i] = a;
         if (save_attn) save_attn[(int64_t)n * I + i] = a;
     }
     __syncthreads();
     const float* vp = v + (int64_t)n * v_img_stride;
-    for (int c = threadIdx.x; c < Cv; c += blockDim.x) {
+    for (int c = wave; c < Cv; c += 4) {
         float acc = 0.f;
-        for (int i = 0; i < I; ++i) acc = fmaf(ps[i], vp[(int64_t)c * I + i], acc);
-        out[(int64_t)n * ldo + c] = acc;
+        for (int i = lane; i < I; i += 64) acc = fmaf(ps[i], vp[(int64_t)c * I + i], acc);
+        acc = wave_sum(acc);
+        if (lane == 0) out[(int64_t)n * ldo + c] = acc;
     }
 }
 
@@ -782,7 +813,7 @@ int ivln_linear_skinny_f32(const float* x, int64_t ldx, const float* W, const fl
                            int rows, int K, int O, int relu, void* stream) {
     if (rows <= 0 || K <= 0 || O <= 0) return IVLN_E_INVALID;
     if ((K & 3) == 0 && (ldx & 3)) return IVLN_E_INVALID;
-    hipLaunchKernelGGL(k_linear_skinny, dim3((O + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, W, bias, y, ldy,
+    hipLaunchKernelGGL(k_linear_skinny, dim3(O), dim3(256), 0, (hipStream_t)stream, x, ldx, W, bias, y, ldy,
                        rows, K, O, relu);
     return LAUNCH_OK();
 }
@@ -792,7 +823,7 @@ int ivln_gru_step_f32(const float* x, int64_t ldx, int I, const float* gi_pre, i
                       const float* b_hh, float* h_out, int64_t ldo, float* h_out2, int64_t ldo2, int rows, int H,
                       float* save_r, float* save_z, float* save_n, float* save_ghn, void* stream) {
     if (rows <= 0 || (H & 3) || (x && (I & 3)) || (ldh & 3) || (x && (ldx & 3))) return IVLN_E_INVALID;
-    hipLaunchKernelGGL(k_gru_step, dim3((H + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, I, gi_pre, ldgi,
+    hipLaunchKernelGGL(k_gru_step, dim3(H), dim3(256), 0, (hipStream_t)stream, x, ldx, I, gi_pre, ldgi,
                        h_in, ldh, mask, w_ih, w_hh, b_ih, b_hh, h_out, ldo, h_out2, ldo2, rows, H, save_r, save_z,
                        save_n, save_ghn);
     return LAUNCH_OK();

@@ -1,83 +1,113 @@
-"""hipGraph-replayed rollout step: mapper obs-transform + `policy.act` captured ONCE (through
+"""hipGraph-replayed rollout step: mapper obs-transform + `policy.act` captured (through
 torch.cuda.CUDAGraph - our kernels launch on torch's current stream, so stream capture records
 them) and replayed per env step.  Inside the capture the three independent branches of the step run
 on forked streams: instruction bi-LSTM || mapper -> semantic-map CNN || DD-PPO depth ResNet, joined
 before the recurrent/attention head.  At 4-8 envs the step is ~170 launches of a few microseconds
 each: replay removes the per-launch host cost and the fork overlaps the latency-bound branches.
+
+Two graphs are captured with the recurrent state / previous action ping-ponging between two
+buffer sets (graph 0: A -> B, graph 1: B -> A), so no state copies are needed between steps; the
+only per-step copies are the observation tensors the step actually reads.
 """
 from typing import Dict
 
 import torch
 
+_STEP_KEYS = ("depth", "semantic12", "rgb", "instruction", "world_robot_pose", "world_robot_orientation",
+              "not_done_masks")
+
 
 class GraphedRollout:
     def __init__(self, policy, obs_transforms, example_obs: Dict, deterministic: bool = True, streams: bool = True,
-                 warmup: int = 3):
+                 warmup: int = 2):
         self.policy = policy
         self.transforms = list(obs_transforms)
         self.deterministic = deterministic
         dev = next(policy.parameters()).device
         self.device = dev
-        self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in example_obs.items()}
+        self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in example_obs.items()
+                       if (k in _STEP_KEYS or not torch.is_tensor(v))}
         B = example_obs["depth"].shape[0]
         H = policy.net._hidden_size
-        self.rnn = torch.zeros(B, policy.net.num_recurrent_layers, H, device=dev)
-        self.prev = torch.zeros(B, 1, dtype=torch.long, device=dev)
-        self.actions = torch.zeros(B, 1, dtype=torch.long, device=dev)
+        L = policy.net.num_recurrent_layers
+        self.rnn = [torch.zeros(B, L, H, device=dev) for _ in range(2)]
+        self.prev = [torch.zeros(B, 1, dtype=torch.long, device=dev) for _ in range(2)]
         self.side = (torch.cuda.Stream(dev), torch.cuda.Stream(dev)) if streams else None
-        self.graph = None
+        self.graphs = []
+        self.phase = 0  # which buffer set holds the current state
         self._capture(warmup)
 
-    def _body(self):
+    @property
+    def actions(self):
+        return self.prev[self.phase]
+
+    @property
+    def rnn_states(self):
+        return self.rnn[self.phase]
+
+    def _body(self, src: int):
+        dst = src ^ 1
         cur = torch.cuda.current_stream()
         batch = dict(self.static)
+        net = self.policy.net
         if self.side is not None:
             s_txt, s_map = self.side
             s_map.wait_stream(cur)
             with torch.cuda.stream(s_map):  # the mapper feeds only the map CNN, which stays on s_map
                 for t in self.transforms:
                     batch = t(batch)
-            self.policy.net._side_streams = self.side
+            net._side_streams = self.side
         else:
             for t in self.transforms:
                 batch = t(batch)
+        net._rnn_out_buffer = self.rnn[dst]
+        self.policy._action_out_buffer = self.prev[dst] if self.deterministic else None
         try:
             with torch.no_grad():
-                actions, rnn = self.policy.act(batch, self.rnn, self.prev, batch["not_done_masks"],
+                actions, rnn = self.policy.act(batch, self.rnn[src], self.prev[src], batch["not_done_masks"],
                                                deterministic=self.deterministic)
-                self.rnn.copy_(rnn)
-                self.prev.copy_(actions)
-                self.actions.copy_(actions)
+                if actions.data_ptr() != self.prev[dst].data_ptr():
+                    self.prev[dst].copy_(actions)
+                if rnn.data_ptr() != self.rnn[dst].data_ptr():
+                    self.rnn[dst].copy_(rnn)
         finally:
-            self.policy.net._side_streams = None
+            net._side_streams = None
+            net._rnn_out_buffer = None
+            self.policy._action_out_buffer = None
 
     def _capture(self, warmup):
         s = torch.cuda.Stream(self.device)
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):  # warm-up off the default stream: creates tables, workspaces, handles
-            for _ in range(warmup):
-                self._body()
+            for i in range(warmup):
+                self._body(i & 1)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self._body()
+        for src in (0, 1):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._body(src)
+            self.graphs.append(g)
+        self.phase = 0
 
     def load(self, obs: Dict):
         for k, v in obs.items():
             if torch.is_tensor(v):
-                self.static[k].copy_(v, non_blocking=True)
+                if k in self.static:
+                    self.static[k].copy_(v, non_blocking=True)
             else:
                 self.static[k] = v
 
     def step(self, obs: Dict = None):
-        """Copy the observations into the captured graph's input buffers and replay the step.
-        Returns the (B,1) int64 action tensor (a persistent buffer)."""
+        """Copy the observations the step reads into the captured input buffers and replay.
+        Returns the (B,1) int64 action tensor (one of the two persistent buffers)."""
         if obs is not None:
             self.load(obs)
-        self.graph.replay()
+        self.graphs[self.phase].replay()
+        self.phase ^= 1
         return self.actions
 
     def reset_state(self):
-        self.rnn.zero_()
-        self.prev.zero_()
+        for t in self.rnn + self.prev:
+            t.zero_()
+        self.phase = 0

@@ -35,7 +35,7 @@ class GemmDesc(C.Structure):
 
 
 A_MK, A_KM, A_NCHW_P = 0, 1, 2
-B_CONV, B_CONV1X1, B_KN, B_NK, B_IM2COL_T, B_CONVT = 0, 1, 2, 3, 4, 5
+B_CONV, B_CONV1X1, B_KN, B_NK, B_IM2COL_T, B_CONVT, B_CONV_K3, B_CONV_K7 = 0, 1, 2, 3, 4, 5, 6, 7
 D_NCHW, D_DENSE = 0, 1
 
 _sigs_done = False
@@ -151,6 +151,8 @@ def conv2d(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, 
     d.in_img_stride = in_img_stride
     if KH == 1 and KW == 1 and pad == 0:
         d.bmode = B_CONV1X1
+    elif KH == KW and KH in (3, 7) and dil == 1:
+        d.bmode = B_CONV_K3 if KH == 3 else B_CONV_K7
     else:
         d.bmode = B_CONV
         koff, kpos = conv_tables(Cin, KH, KW, H, W, dil, x.device)
@@ -382,9 +384,10 @@ def prev_action_embed(prev_actions_i64, mask_u8, table, out1, out2=None):
     )
 
 
-def argmax_rows(x):
+def argmax_rows(x, out=None):
     rows, Cc = x.shape
-    out = torch.empty((rows, 1), dtype=torch.int64, device=x.device)
+    if out is None:
+        out = torch.empty((rows, 1), dtype=torch.int64, device=x.device)
     check(_L().ivln_argmax_rows(dptr(x), rows, Cc, dptr(out), stream_ptr()), "ivln_argmax_rows")
     return out
 

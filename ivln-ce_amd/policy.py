@@ -227,7 +227,9 @@ class MapCMANet(Net):
         ops.linear(dep_flat, dl.weight, dl.bias, relu=True, out=state_in[:, :d_out])
         ops.linear(mp_flat, ml.weight, ml.bias, relu=True, out=state_in[:, d_out:d_out + m_out])
 
-        rnn_out = torch.empty_like(rnn_states)
+        rnn_out = getattr(self, "_rnn_out_buffer", None) if save is None else None  # graphed.py: persistent buffer
+        if rnn_out is None:
+            rnn_out = torch.empty_like(rnn_states)
         s_g1 = {} if save is not None else None
         s_g2 = {} if save is not None else None
         state = x2[:, :H]
@@ -295,7 +297,7 @@ class ILPolicy(Policy):
     def _act(self, features, deterministic):
         logits = self.action_distribution.raw_logits(features)
         if deterministic:  # distribution.mode() == argmax of probs == argmax of logits
-            return ops.argmax_rows(logits.contiguous())
+            return ops.argmax_rows(logits.contiguous(), out=getattr(self, "_action_out_buffer", None))
         return CustomFixedCategorical(logits=logits).sample()
 
     def act(self, observations, rnn_states, prev_actions, masks, deterministic=False):

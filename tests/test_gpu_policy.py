@@ -157,6 +157,6 @@ def test_graphed_multistream_rollout_is_bit_identical_to_eager():
         torch.cuda.synchronize()
         mem = tr_g.mapping_module.map_memory
         assert torch.equal(a, eager[t][0]), f"actions step {t}"
-        assert torch.equal(runner.rnn, eager[t][1]), f"rnn step {t}"
+        assert torch.equal(runner.rnn_states, eager[t][1]), f"rnn step {t}"
         assert torch.equal(mem.occupancy, eager[t][2]) and torch.equal(mem.semantic, eager[t][3]), f"maps step {t}"
     tr_g.mapping_module.check_status()
