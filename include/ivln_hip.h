@@ -181,7 +181,8 @@ int ivln_gru_step_f32(const float* x, int64_t ldx, int I, const float* gi_pre, i
 /* MapCMANet._attn (map_cma_policy.py:266-274); k (rows,Ck,I), v (rows,Cv,I) channel-major. */
 int ivln_attn_fwd_f32(const float* q, int64_t ldq, const float* k, int64_t k_img_stride, const float* v,
                       int64_t v_img_stride, const int* valid_len, float scale, int rows, int Ck, int Cv,
-                      int I, float* out, int64_t ldo, float* save_attn, void* stream);
+                      int I, float* out, int64_t ldo, float* save_attn, float* logits_ws /* rows*I */,
+                      void* stream);
 /* prev_action_embedding(((a+1)*mask).long()) (map_cma_policy.py:297-299), written to two slices. */
 int ivln_prev_action_embed_f32(const int64_t* prev_actions, const uint8_t* mask, const float* table,
                                int rows, int E, int n_emb, float* out1, int64_t ld1, float* out2,

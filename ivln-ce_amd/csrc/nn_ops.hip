@@ -60,7 +60,36 @@ __device__ __forceinline__ float4 gn_load4(const float* __restrict__ xp, int i, 
     int cl = i / HW, pp = i - cl * HW;
     const float* p = xp + (int64_t)cl * chan_stride + pp;
     float4 v = *reinterpret_cast<const float4*>(p);
-    for (int z = 1; z < splits; ++z) {
+    int z = 1;
+    for (; z + 3 < splits; z += 4) {  // 4 independent loads in flight
+        float4 w0 = *reinterpret_cast<const float4*>(p + (int64_t)z * slab_stride);
+        float4 w1 = *reinterpret_cast<const float4*>(p + (int64_t)(z + 1) * slab_stride);
+        float4 w2 = *reinterpret_cast<const float4*>(p + (int64_t)(z + 2) * slab_stride);
+        float4 w3 = *reinterpret_cast<const float4*>(p + (int64_t)(z + 3) * slab_stride);
+        v.x += (w0.x + w1.x) + (w2.x + w3.x);
+        v.y += (w0.y + w1.y) + (w2.y + w3.y);
+        v.z += (w0.z + w1.z) + (w2.z + w3.z);
+        v.w += (w0.w + w1.w) + (w2.w + w3.w);
+    }
+    for (; z < splits; ++z) {
+        float4 w = *reinterpret_cast<const float4*>(p + (int64_t)z * slab_stride);
+        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+    return v;
+}
+// slabs z0, z0+zs, z0+2zs, ... of one float4 (cooperative reduction: several threads per element)
+__device__ __forceinline__ float4 gn_load4_strided(const float* __restrict__ xp, int i, int HW, int64_t chan_stride,
+                                                   int splits, int64_t slab_stride, int z0, int zs) {
+    int cl = i / HW, pp = i - cl * HW;
+    const float* p = xp + (int64_t)cl * chan_stride + pp;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    int z = z0;
+    for (; z + zs < splits; z += 2 * zs) {
+        float4 w0 = *reinterpret_cast<const float4*>(p + (int64_t)z * slab_stride);
+        float4 w1 = *reinterpret_cast<const float4*>(p + (int64_t)(z + zs) * slab_stride);
+        v.x += w0.x + w1.x; v.y += w0.y + w1.y; v.z += w0.z + w1.z; v.w += w0.w + w1.w;
+    }
+    if (z < splits) {
         float4 w = *reinterpret_cast<const float4*>(p + (int64_t)z * slab_stride);
         v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
     }
@@ -89,7 +118,32 @@ __global__ __launch_bounds__(GN_THREADS) void k_groupnorm(
     const bool cached = n <= GN_CACHE;
     const bool vec = (HW & 3) == 0;
     float s = 0.f;
-    if (vec) {
+    const int n4 = n >> 2;
+    if (vec && splits > 1 && n4 * 2 <= GN_THREADS && 2 * n <= GN_CACHE) {
+        // small group, many slabs (late ResNet layers: n = 512..2048, up to 64 slabs): several
+        // threads share one float4, each summing a strided subset of the slabs; partials meet in LDS
+        const int max_slots = (GN_CACHE - n) / n;  // staging room behind the final image (>= 1: 2n <= GN_CACHE)
+        const int nz = min(min(GN_THREADS / n4, splits), max_slots + 1);
+        const int e = threadIdx.x % n4, zp = threadIdx.x / n4;
+        float* part = cache + n;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (zp < nz) v = gn_load4_strided(xp, e * 4, HW, x_chan_stride, splits, slab_stride, zp, nz);
+        if (zp < nz) {  // slot 0 -> cache, slots 1.. -> part
+            if (zp == 0) *reinterpret_cast<float4*>(&cache[e * 4]) = v;
+            else *reinterpret_cast<float4*>(&part[(zp - 1) * n + e * 4]) = v;
+        }
+        __syncthreads();
+        if (zp == 0) {
+            float4 t = *reinterpret_cast<float4*>(&cache[e * 4]);
+            for (int q2 = 0; q2 < nz - 1; ++q2) {
+                float4 w = *reinterpret_cast<float4*>(&part[q2 * n + e * 4]);
+                t.x += w.x; t.y += w.y; t.z += w.z; t.w += w.w;
+            }
+            *reinterpret_cast<float4*>(&cache[e * 4]) = t;
+            s = (t.x + t.y) + (t.z + t.w);
+        }
+        __syncthreads();
+    } else if (vec) {
         for (int i = threadIdx.x * 4; i < n; i += GN_THREADS * 4) {
             float4 v = gn_load4(xp, i, HW, x_chan_stride, splits, slab_stride);
             if (cached) *reinterpret_cast<float4*>(&cache[i]) = v;
@@ -557,49 +611,60 @@ __global__ __launch_bounds__(256) void k_gru_step(const float* __restrict__ x, i
 //   logits[i] = sum_c q[n][c] k[n][c][i];  masked i: logits - 1e8;  attn = softmax(logits*scale)
 //   out[n][c'] = sum_i attn[i] v[n][c'][i]
 // k: (N, Ck, I) and v: (N, Cv, I) channel-major with image strides; valid_len[n] (or null):
-// positions >= valid_len are the masked (all-zero) text positions.  One block per row.  Logits:
-// threads are (position i, channel part) so that all 256 lanes work for I = 16 (depth/map) as well as
-// I = 200 (text), loads coalesced along i.  Output: one wave per channel c', lanes along i.
+// positions >= valid_len are the masked (all-zero) text positions.
+// Two launches so that a 4-row rollout batch still spreads over the chip (one block per row was
+// ~80 us of serialised L2 round trips): k_attn_logits grid (rows, I/32) - 32 positions x 8 channel
+// parts per block, 8 loads in flight per thread; k_attn_out grid (rows, Cv/16) - every block
+// redoes the (tiny) softmax over I, then 16 channels x 16 position parts.
 // ------------------------------------------------------------------------------------------
 constexpr int ATT_MAX_I = 512;
 
-__global__ __launch_bounds__(256) void k_attn(const float* __restrict__ q, int64_t ldq,
-                                              const float* __restrict__ k, int64_t k_img_stride,
-                                              const float* __restrict__ v, int64_t v_img_stride,
-                                              const int* __restrict__ valid_len, float scale, int Ck, int Cv,
-                                              int I, float* __restrict__ out, int64_t ldo,
-                                              float* __restrict__ save_attn) {
+__global__ __launch_bounds__(256) void k_attn_logits(const float* __restrict__ q, int64_t ldq,
+                                                     const float* __restrict__ k, int64_t k_img_stride,
+                                                     const int* __restrict__ valid_len, float scale, int Ck, int I,
+                                                     float* __restrict__ logits) {
     __shared__ float qs[1024];
-    __shared__ float ps[ATT_MAX_I];
-    __shared__ float pl[256];
-    __shared__ float red[16];
+    __shared__ float pl[8][33];
     const int n = blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int c = threadIdx.x; c < Ck; c += 256) qs[c] = q[(int64_t)n * ldq + c];
     __syncthreads();
     const float* kp = k + (int64_t)n * k_img_stride;
-    const int vl = valid_len ? valid_len[n] : I;
-    int IP = 1;
-    while (IP < I && IP < 256) IP <<= 1;  // positions per pass (power of two <= 256)
-    const int nparts = 256 / IP;
-    const int ti = threadIdx.x % IP, tp = threadIdx.x / IP;
-    float lmax = -INFINITY;
-    for (int i0 = 0; i0 < I; i0 += IP) {
-        const int i = i0 + ti;
-        float acc = 0.f;
-        if (i < I)
-            for (int c = tp; c < Ck; c += nparts) acc = fmaf(qs[c], kp[(int64_t)c * I + i], acc);
-        pl[threadIdx.x] = acc;
-        __syncthreads();
-        if (tp == 0 && i < I) {
-            float s = 0.f;
-            for (int pp = 0; pp < nparts; ++pp) s += pl[pp * IP + ti];
-            if (i >= vl) s = s - 1e8f;
-            s *= scale;
-            ps[i] = s;
-            lmax = fmaxf(lmax, s);
+    const int ti = threadIdx.x & 31, tp = threadIdx.x >> 5;  // position, channel part (8 parts)
+    const int i = blockIdx.y * 32 + ti;
+    float acc = 0.f;
+    if (i < I) {
+        int c = tp;
+        for (; c + 56 < Ck; c += 64) {
+            float kv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) kv[u] = kp[(int64_t)(c + 8 * u) * I + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = fmaf(qs[c + 8 * u], kv[u], acc);
         }
-        __syncthreads();
+        for (; c < Ck; c += 8) acc = fmaf(qs[c], kp[(int64_t)c * I + i], acc);
+    }
+    pl[tp][ti] = acc;
+    __syncthreads();
+    if (tp == 0 && i < I) {
+        float s = ((pl[0][ti] + pl[1][ti]) + (pl[2][ti] + pl[3][ti])) + ((pl[4][ti] + pl[5][ti]) + (pl[6][ti] + pl[7][ti]));
+        const int vl = valid_len ? valid_len[n] : I;
+        if (i >= vl) s = s - 1e8f;
+        logits[(int64_t)n * I + i] = s * scale;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_attn_out(const float* __restrict__ logits, const float* __restrict__ v,
+                                                  int64_t v_img_stride, int Cv, int I, float* __restrict__ out,
+                                                  int64_t ldo, float* __restrict__ save_attn) {
+    __shared__ float ps[ATT_MAX_I];
+    __shared__ float pl[16][17];
+    __shared__ float red[16];
+    const int n = blockIdx.x;
+    float lmax = -INFINITY;
+    for (int i = threadIdx.x; i < I; i += 256) {
+        float l = logits[(int64_t)n * I + i];
+        ps[i] = l;
+        lmax = fmaxf(lmax, l);
     }
     lmax = block_max(lmax, red);
     float sum = 0.f;
@@ -613,15 +678,31 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ q, int64
     for (int i = threadIdx.x; i < I; i += 256) {
         float a = ps[i] * inv;
         ps[i] = a;
-        if (save_attn) save_attn[(int64_t)n * I + i] = a;
+        if (save_attn && blockIdx.y == 0) save_attn[(int64_t)n * I + i] = a;
     }
     __syncthreads();
-    const float* vp = v + (int64_t)n * v_img_stride;
-    for (int c = wave; c < Cv; c += 4) {
-        float acc = 0.f;
-        for (int i = lane; i < I; i += 64) acc = fmaf(ps[i], vp[(int64_t)c * I + i], acc);
-        acc = wave_sum(acc);
-        if (lane == 0) out[(int64_t)n * ldo + c] = acc;
+    const int tc = threadIdx.x >> 4, tpart = threadIdx.x & 15;  // channel within the chunk, position part
+    const int c = blockIdx.y * 16 + tc;
+    float acc = 0.f;
+    if (c < Cv) {
+        const float* vp = v + (int64_t)n * v_img_stride + (int64_t)c * I;
+        int i = tpart;
+        for (; i + 48 < I; i += 64) {
+            float v0 = vp[i], v1 = vp[i + 16], v2 = vp[i + 32], v3 = vp[i + 48];
+            acc = fmaf(ps[i], v0, acc);
+            acc = fmaf(ps[i + 16], v1, acc);
+            acc = fmaf(ps[i + 32], v2, acc);
+            acc = fmaf(ps[i + 48], v3, acc);
+        }
+        for (; i < I; i += 16) acc = fmaf(ps[i], vp[i], acc);
+    }
+    pl[tc][tpart] = acc;
+    __syncthreads();
+    if (tpart == 0 && c < Cv) {
+        float s = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += pl[tc][u];
+        out[(int64_t)n * ldo + c] = s;
     }
 }
 
@@ -831,10 +912,12 @@ int ivln_gru_step_f32(const float* x, int64_t ldx, int I, const float* gi_pre, i
 
 int ivln_attn_fwd_f32(const float* q, int64_t ldq, const float* k, int64_t k_img_stride, const float* v,
                       int64_t v_img_stride, const int* valid_len, float scale, int rows, int Ck, int Cv, int I,
-                      float* out, int64_t ldo, float* save_attn, void* stream) {
-    if (I > ATT_MAX_I || Ck > 1024) return IVLN_E_UNSUPPORTED;
-    hipLaunchKernelGGL(k_attn, dim3(rows), dim3(256), 0, (hipStream_t)stream, q, ldq, k, k_img_stride, v,
-                       v_img_stride, valid_len, scale, Ck, Cv, I, out, ldo, save_attn);
+                      float* out, int64_t ldo, float* save_attn, float* logits_ws, void* stream) {
+    if (I > ATT_MAX_I || Ck > 1024 || !logits_ws) return IVLN_E_UNSUPPORTED;
+    hipLaunchKernelGGL(k_attn_logits, dim3(rows, (I + 31) / 32), dim3(256), 0, (hipStream_t)stream, q, ldq, k,
+                       k_img_stride, valid_len, scale, Ck, I, logits_ws);
+    hipLaunchKernelGGL(k_attn_out, dim3(rows, (Cv + 15) / 16), dim3(256), 0, (hipStream_t)stream, logits_ws, v,
+                       v_img_stride, Cv, I, out, ldo, save_attn);
     return LAUNCH_OK();
 }
 

@@ -53,6 +53,11 @@ class GraphedRollout:
         if self.side is not None:
             s_txt, s_map = self.side
             s_map.wait_stream(cur)
+            # hipGraph replay submits nodes in capture order (~3 us of host time each), so the critical
+            # path - the 107-kernel depth ResNet chain - is captured FIRST; the policy then takes the
+            # cached `depth_features` path (resnet_encoders.py:92-95)
+            with torch.no_grad():
+                batch["depth_features"] = net.depth_encoder.visual_encoder(batch)
             with torch.cuda.stream(s_map):  # the mapper feeds only the map CNN, which stays on s_map
                 for t in self.transforms:
                     batch = t(batch)

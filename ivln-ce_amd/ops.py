@@ -58,7 +58,7 @@ def _L():
         L.ivln_linear_skinny_f32.argtypes = [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp]
         L.ivln_gru_step_f32.argtypes = [vp, i64, i32, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp, i64, i32, i32,
                                         vp, vp, vp, vp, vp]
-        L.ivln_attn_fwd_f32.argtypes = [vp, i64, vp, i64, vp, i64, vp, f32, i32, i32, i32, i32, vp, i64, vp, vp]
+        L.ivln_attn_fwd_f32.argtypes = [vp, i64, vp, i64, vp, i64, vp, f32, i32, i32, i32, i32, vp, i64, vp, vp, vp]
         L.ivln_prev_action_embed_f32.argtypes = [vp, vp, vp, i32, i32, i32, vp, i64, vp, i64, vp]
         L.ivln_argmax_rows.argtypes = [vp, i32, i32, vp, vp]
         L.ivln_argmax_channels_u8.argtypes = [vp, i32, i32, i32, vp, vp]
@@ -365,9 +365,10 @@ def attn(q, k, v, valid_len, scale, out, save_attn=None):
     """q (rows,Ck) strided rows; k (rows,Ck,I), v (rows,Cv,I) with image strides; out (rows,Cv) strided."""
     rows, Ck = q.shape
     Cv, I = v.shape[1], v.shape[2]
+    logits_ws = torch.empty((rows, I), dtype=torch.float32, device=q.device)
     check(
         _L().ivln_attn_fwd_f32(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(valid_len), scale, rows,
-                               Ck, Cv, I, _p(out), out.stride(0), _p(save_attn), stream_ptr()),
+                               Ck, Cv, I, _p(out), out.stride(0), _p(save_attn), dptr(logits_ws), stream_ptr()),
         "ivln_attn_fwd_f32",
     )
     return out

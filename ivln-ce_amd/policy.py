@@ -183,49 +183,70 @@ class MapCMANet(Net):
 
         s_txt = {} if save is not None else None
         s_map = [] if save is not None else None
-        side = getattr(self, "_side_streams", None) if save is None else None
-        if side is None:
-            txt, lengths = self.instruction_encoder(observations, s_txt)  # (rows,256,L)
-            dep = self.depth_encoder(observations)  # (rows,192,4,4)
-            mp = self.map_encoder(observations, s_map)  # (rows,128,4,4)
-        else:
-            # three independent, latency-bound branches on forked streams (graphed.py): instruction
-            # bi-LSTM || (mapper ->) map CNN || depth ResNet; joined before the recurrent head
-            cur = torch.cuda.current_stream()
-            st_txt, st_map = side
-            st_txt.wait_stream(cur)
-            st_map.wait_stream(cur)
-            with torch.cuda.stream(st_txt):
-                txt, lengths = self.instruction_encoder(observations, None)
-            with torch.cuda.stream(st_map):
-                mp = self.map_encoder(observations, None)
-            dep = self.depth_encoder(observations)
-            cur.wait_stream(st_txt)
-            cur.wait_stream(st_map)
-        if mc.ablate_instruction:
-            txt = torch.zeros_like(txt)
-        if mc.ablate_depth:
-            dep = torch.zeros_like(dep)
-        if mc.ablate_map:
-            mp = torch.zeros_like(mp)
-        L = txt.shape[2]
-        Cd, Cm = dep.shape[1], mp.shape[1]
-        P = dep.shape[2] * dep.shape[3]
         d_out = self.depth_linear[1].out_features
         m_out = self.map_linear[1].out_features
         E = self.prev_action_embedding.embedding_dim
-
         # state_in = [dep_in | map_in | prev]; x2 = [state | text | dep' | map' | prev]
         state_in = torch.empty((rows, d_out + m_out + E), dtype=torch.float32, device=dev)
         x2w = H + self.instruction_encoder.output_size + d_out + m_out + E
         x2 = torch.empty((rows, x2w), dtype=torch.float32, device=dev)
+        dl, ml = self.depth_linear[1], self.map_linear[1]
+
+        def _txt_branch(sv):
+            t, ln = self.instruction_encoder(observations, sv)  # (rows,256,L)
+            if mc.ablate_instruction:
+                t = torch.zeros_like(t)
+            r_, L_ = t.shape[0], t.shape[2]
+            tk_ = ops.conv2d(t.view(r_, -1, 1, L_), self.text_k.weight.view(h2, -1, 1, 1), shift=self.text_k.bias,
+                             splitk=False)
+            return t, ln, tk_
+
+        def _map_branch(sv):
+            m = self.map_encoder(observations, sv)  # (rows,128,4,4)
+            if mc.ablate_map:
+                m = torch.zeros_like(m)
+            r_, Cm_, P_ = m.shape[0], m.shape[1], m.shape[2] * m.shape[3]
+            kv = ops.conv2d(m.view(r_, Cm_, 1, P_), self.map_kv.weight.view(-1, Cm_, 1, 1), shift=self.map_kv.bias,
+                            splitk=False)
+            ops.linear(m.view(r_, -1), ml.weight, ml.bias, relu=True, out=state_in[:, d_out:d_out + m_out])
+            return m, kv
+
+        def _dep_branch():
+            d = self.depth_encoder(observations)  # (rows,192,4,4)
+            if mc.ablate_depth:
+                d = torch.zeros_like(d)
+            r_, Cd_, P_ = d.shape[0], d.shape[1], d.shape[2] * d.shape[3]
+            kv = ops.conv2d(d.view(r_, Cd_, 1, P_), self.dep_kv.weight.view(-1, Cd_, 1, 1), shift=self.dep_kv.bias,
+                            splitk=False)
+            ops.linear(d.view(r_, -1), dl.weight, dl.bias, relu=True, out=state_in[:, :d_out])
+            return d, kv
+
+        # The key/value projections depend only on their own encoder, so they run inside the branches.
+        side = getattr(self, "_side_streams", None) if save is None else None
+        if side is None:
+            txt, lengths, tk = _txt_branch(s_txt)
+            dep, dkv = _dep_branch()
+            mp, mkv = _map_branch(s_map)
+        else:
+            # three independent, latency-bound branches on forked streams (graphed.py): depth ResNet
+            # (critical path, submitted first) || instruction bi-LSTM || (mapper ->) map CNN
+            cur = torch.cuda.current_stream()
+            st_txt, st_map = side
+            st_txt.wait_stream(cur)
+            st_map.wait_stream(cur)
+            dep, dkv = _dep_branch()
+            with torch.cuda.stream(st_txt):
+                txt, lengths, tk = _txt_branch(None)
+            with torch.cuda.stream(st_map):
+                mp, mkv = _map_branch(None)
+            cur.wait_stream(st_txt)
+            cur.wait_stream(st_map)
+        L = txt.shape[2]
+        Cd, Cm = dep.shape[1], mp.shape[1]
+        P = dep.shape[2] * dep.shape[3]
         o_txt, o_dep, o_map, o_prev = H, H + 256, H + 256 + d_out, H + 256 + d_out + m_out
         ops.prev_action_embed(prev_actions, masks_u8, self.prev_action_embedding.weight, state_in[:, d_out + m_out:],
                               x2[:, o_prev:])
-        dl, ml = self.depth_linear[1], self.map_linear[1]
-        dep_flat, mp_flat = dep.view(rows, -1), mp.view(rows, -1)
-        ops.linear(dep_flat, dl.weight, dl.bias, relu=True, out=state_in[:, :d_out])
-        ops.linear(mp_flat, ml.weight, ml.bias, relu=True, out=state_in[:, d_out:d_out + m_out])
 
         rnn_out = getattr(self, "_rnn_out_buffer", None) if save is None else None  # graphed.py: persistent buffer
         if rnn_out is None:
@@ -236,13 +257,10 @@ class MapCMANet(Net):
         self.state_encoder(state_in, rnn_states[:, 0], masks_u8, state, rnn_out[:, 0], s_g1)
 
         q1 = ops.linear(state, self.state_q.weight, self.state_q.bias)
-        tk = ops.conv2d(txt.view(rows, -1, 1, L), self.text_k.weight.view(h2, -1, 1, 1), shift=self.text_k.bias)
         a_txt = torch.empty((rows, L), dtype=torch.float32, device=dev) if save is not None else None
         text = x2[:, o_txt:o_txt + 256]
         ops.attn(q1, tk.view(rows, h2, L), txt, lengths, self._scale_f, text, a_txt)
 
-        dkv = ops.conv2d(dep.view(rows, Cd, 1, P), self.dep_kv.weight.view(-1, Cd, 1, 1), shift=self.dep_kv.bias)
-        mkv = ops.conv2d(mp.view(rows, Cm, 1, P), self.map_kv.weight.view(-1, Cm, 1, 1), shift=self.map_kv.bias)
         dkv, mkv = dkv.view(rows, -1, P), mkv.view(rows, -1, P)
         q2 = ops.linear(text, self.text_q.weight, self.text_q.bias)
         a_dep = torch.empty((rows, P), dtype=torch.float32, device=dev) if save is not None else None
