@@ -167,6 +167,9 @@ def main():
     ap.add_argument("--envs", type=int, default=4, help="parallel envs per GPU (configs[1]: 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--streams", action="store_true",
+                    help="fork the three encoder branches onto side streams inside the graph (measured SLOWER on "
+                         "ROCm 7.2: cross-queue dependencies cost more than the overlap wins)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -208,7 +211,7 @@ def main():
         from ivln_ce_amd.graphed import GraphedRollout
 
         log(f"rank {rank}: capturing the step graph")
-        runner = GraphedRollout(policy, [mapper_tr], obs_dev[0], deterministic=True, streams=True)
+        runner = GraphedRollout(policy, [mapper_tr], obs_dev[0], deterministic=True, streams=args.streams)
 
         def do_step(i):
             runner.step(obs_dev[i % n_pool])
@@ -261,7 +264,7 @@ def main():
                         f"{B} parallel envs per GPU, 256x256 depth + semantic12, 80-token instruction, random-init "
                         "weights of the reference architecture",
             "envs_per_gpu": B, "parallelism": f"dp{world} (envs sharded, no data-path collective)",
-            "launch": "hipGraph replay, 3 forked streams" if use_graph else "eager",
+            "launch": ("hipGraph replay, " + ("3 forked streams" if args.streams else "1 stream")) if use_graph else "eager",
         },
         "roofline": roofline,
     }
