@@ -110,16 +110,26 @@ __device__ __forceinline__ void block_minmax_fold(const int* __restrict__ partia
     __syncthreads();
 }
 
-// Wave-aggregated append: returns the slot for lanes with pred, or 0xFFFFFFFF when full.
+// Block-aggregated append: ONE atomicAdd per block call (wave ballots + a 4-entry LDS prefix);
+// returns the slot for threads with pred, 0xFFFFFFFF otherwise / when full.  Every thread of the block
+// must call it.  (Per-wave atomics on the single counter serialised ~4k same-address atomics in
+// k_world_select: 59 us.)
 __device__ __forceinline__ unsigned wave_append(bool pred, unsigned* counter, unsigned capacity, int* err) {
-    unsigned long long mask = __ballot(pred);
-    if (mask == 0) return 0xFFFFFFFFu;
-    int lane = threadIdx.x & 63;
-    int leader = __ffsll((long long)mask) - 1;
-    unsigned base = 0;
-    if (lane == leader) base = atomicAdd(counter, (unsigned)__popcll(mask));
-    base = __shfl(base, leader);
-    unsigned slot = base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+    __shared__ unsigned wcnt[4];
+    __shared__ unsigned bbase;
+    const unsigned long long mask = __ballot(pred);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) wcnt[w] = (unsigned)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned total = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        bbase = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    unsigned off = bbase;
+    for (int i = 0; i < w; ++i) off += wcnt[i];
+    const unsigned slot = off + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+    __syncthreads();  // wcnt / bbase are reused by the next call
     if (!pred) return 0xFFFFFFFFu;
     if (slot >= capacity) {
         *err = IVLN_E_CAPACITY;
@@ -351,7 +361,10 @@ __device__ __forceinline__ void raster_point(const Pt& p, uint64_t rank, const f
     int o = (b * rows + (int)fr) * cols + (int)fc;
     occ[o] = 1;
     uint32_t label = p.meta & 0xFFu;
-    if (label != 0) atomicMax(&cell[o], ((unsigned long long)(rank + 1) << 8) | label);
+    if (label != 0) {
+        const unsigned long long v = ((unsigned long long)(rank + 1) << 8) | label;
+        if (v > __hip_atomic_load(&cell[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&cell[o], v);
+    }
 }
 
 // ---- F: world survivors -> destination buffer + raster ----

@@ -117,6 +117,14 @@ __global__ __launch_bounds__(GN_THREADS) void k_groupnorm(
     const float* xp = x + (int64_t)img * x_img_stride + (int64_t)g * cpg * x_chan_stride;
     const bool cached = n <= GN_CACHE;
     const bool vec = (HW & 3) == 0;
+    // affine parameters of this thread's first float4 are fetched now, under the data loads, instead
+    // of as a dependent load after the two reductions
+    float g_first = 0.f, b_first = 0.f;
+    if (vec && (int)threadIdx.x * 4 < n) {
+        const int c0 = g * cpg + ((int)threadIdx.x * 4) / HW;
+        g_first = gamma[c0];
+        b_first = beta[c0];
+    }
     float s = 0.f;
     const int n4 = n >> 2;
     if (vec && splits > 1 && n4 * 2 <= GN_THREADS && 2 * n <= GN_CACHE) {
@@ -182,7 +190,8 @@ __global__ __launch_bounds__(GN_THREADS) void k_groupnorm(
             int c = g * cpg + i / HW;
             float4 v = cached ? *reinterpret_cast<const float4*>(&cache[i])
                               : gn_load4(xp, i, HW, x_chan_stride, splits, slab_stride);
-            const float ga = gamma[c] * rstd, be = beta[c] - mean * ga;
+            const bool first = i == (int)threadIdx.x * 4;
+            const float ga = (first ? g_first : gamma[c]) * rstd, be = (first ? b_first : beta[c]) - mean * ga;
             v.x = fmaf(v.x, ga, be); v.y = fmaf(v.y, ga, be); v.z = fmaf(v.z, ga, be); v.w = fmaf(v.w, ga, be);
             if (rp) {
                 float4 r = *reinterpret_cast<const float4*>(&rp[i]);
@@ -409,24 +418,28 @@ __global__ __launch_bounds__(4 * H) void k_lstm_bidir(const float* __restrict__ 
     float gx_next = len > 0 ? gx[(int64_t)(dir == 0 ? 0 : len - 1) * G + g] : 0.f;
     for (int s = 0; s < len; ++s) {
         const int t = dir == 0 ? s : len - 1 - s;
-        float acc = gx_next + bias;
+        // four independent accumulator chains: a single 128-long dependent fmaf chain (4-cycle latency
+        // each) was the critical path of every timestep
+        float a0 = gx_next + bias, a1 = 0.f, a2 = 0.f, a3 = 0.f;
         if (s + 1 < len) gx_next = gx[(int64_t)(dir == 0 ? s + 1 : len - 2 - s) * G + g];
 #pragma unroll
         for (int k = 0; k < H; k += 4) {
             float4 hv = *reinterpret_cast<const float4*>(&hs[k]);
-            acc = fmaf(w[k], hv.x, acc);
-            acc = fmaf(w[k + 1], hv.y, acc);
-            acc = fmaf(w[k + 2], hv.z, acc);
-            acc = fmaf(w[k + 3], hv.w, acc);
+            a0 = fmaf(w[k], hv.x, a0);
+            a1 = fmaf(w[k + 1], hv.y, a1);
+            a2 = fmaf(w[k + 2], hv.z, a2);
+            a3 = fmaf(w[k + 3], hv.w, a3);
         }
+        const float acc = (a0 + a1) + (a2 + a3);
         const int gate = g / H;
-        float a = gate == 2 ? tanhf(acc) : sigmoidf_(acc);
+        // sigmoid / tanh through one fast exp each (|err| ~1e-7): tanh(x) = 2*sigmoid(2x) - 1
+        float a = gate == 2 ? (2.f / (1.f + __expf(-2.f * acc)) - 1.f) : (1.f / (1.f + __expf(-acc)));
         gs[g] = a;
         if (save_gates) save_gates[(((int64_t)b * 2 + dir) * L + t) * G + g] = a;
         __syncthreads();
         if (g < H) {
             float c = gs[H + g] * cs[g] + gs[g] * gs[2 * H + g];
-            float h = gs[3 * H + g] * tanhf(c);
+            float h = gs[3 * H + g] * (2.f / (1.f + __expf(-2.f * c)) - 1.f);
             cs[g] = c;
             hs[g] = h;
             out[((int64_t)b * 2 * H + dir * H + g) * L + t] = h;
