@@ -124,6 +124,8 @@ typedef struct ivln_gemm_desc {
      * fuses the slab reduction.  splits_used (host, optional) receives the split count chosen. */
     int defer_epilogue;
     int* splits_used;
+    /* 0 = heuristic; 1..5 force block tile 64x64 / 32x128 / 128x32 / 128x128 / 64x128 (tuning, tests) */
+    int tile_override;
 } ivln_gemm_desc;
 
 int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream);
@@ -148,7 +150,9 @@ int ivln_bn_fold_f32(const float* gamma, const float* beta, const float* running
                      float eps, int C, float* scale, float* shift, void* stream);
 int ivln_bn_train_stats_f32(const float* x, int N, int C, int HW, const float* gamma, const float* beta,
                             float* running_mean, float* running_var, float momentum, float eps,
-                            float* scale, float* shift, float* save_mean, float* save_rstd, void* stream);
+                            float* scale, float* shift, float* save_mean, float* save_rstd,
+                            float* ws /* scratch, >= 3*C floats (3*C*64 for full parallelism) */,
+                            int64_t ws_floats, void* stream);
 /* CBRA tail: relu(x*scale+shift) then AvgPool2d(2) (map_encoder.py:16-19). */
 int ivln_scale_shift_relu_avgpool2_f32(const float* x, const float* scale, const float* shift, float* y,
                                        int N, int C, int H, int W, int64_t img_stride, int64_t chan_stride,
@@ -210,7 +214,8 @@ int ivln_add2d_f32(const float* a, int64_t lda, const float* b, int64_t ldb, flo
 /* deterministic column sums (bias gradients); ws: scratch of >= 128*cols floats */
 int ivln_colsum_f32(const float* x, int64_t ld, int rows, int cols, float* out, int accumulate, float* ws,
                     int64_t ws_floats, void* stream);
-int ivln_nchw_chansum_f32(const float* x, int N, int C, int HW, float* out, void* stream);
+int ivln_nchw_chansum_f32(const float* x, int N, int C, int HW, float* out, float* ws, int64_t ws_floats,
+                          void* stream);
 int ivln_transpose_f32(const float* x, float* y, int R, int C, void* stream);
 /* W (O,I,k,k) -> (I,O,k,k) spatially flipped: conv dgrad = conv(dy, W', pad = k-1-pad) */
 int ivln_weight_flip_transpose_f32(const float* w, float* wt, int O, int I, int KH, int KW, void* stream);
@@ -235,7 +240,7 @@ int ivln_lstm_bidir_bwd_f32(const float* dout, const float* out, const float* ga
 /* backward of BatchNorm2d(train|eval) -> ReLU -> AvgPool2d(2) (CBRA, map_encoder.py:13-20) */
 int ivln_cbra_bwd_f32(const float* dout, const float* y, const float* scale, const float* shift,
                       const float* mean, const float* rstd, int N, int C, int H, int W, int train,
-                      float* dgamma, float* dbeta, float* dy, void* stream);
+                      float* dgamma, float* dbeta, float* dy, float* ws, int64_t ws_floats, void* stream);
 int ivln_embedding_scatter_add_f32(const int64_t* tokens, const float* d, int rows, int E, int V,
                                    int padding_idx, float* grad, void* stream);
 int ivln_prev_action_embed_bwd_f32(const int64_t* prev_actions, const uint8_t* mask, const float* d1,

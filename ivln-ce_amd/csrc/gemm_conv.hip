@@ -48,9 +48,11 @@ __device__ __forceinline__ void epilogue_store(const ivln_gemm_desc& p, int m, i
     p.D[addr] = v;
 }
 
-template <int WM, int WN, int AMODE, int BMODE>
+template <int WM, int WN, int TM, int TN, int AMODE, int BMODE>
 __global__ __launch_bounds__(256) void k_gemm(const ivln_gemm_desc p) {
-    constexpr int BM = 32 * WM, BN = 32 * WN;
+    // each wave owns TM x TN accumulator tiles of 32x32 (register tiling: TM+TN LDS operand reads feed
+    // TM*TN MFMAs per k-pair, and the per-tile staging cost is amortised over 4x the MFMA work at 2x2)
+    constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
     constexpr int LDA_S = BM + 1, LDB_S = BN + 1;
     constexpr int EA = BM * BK / 256, EB = BN * BK / 256;
     __shared__ float smem[BK * LDA_S + BK * LDB_S];
@@ -113,173 +115,209 @@ __global__ __launch_bounds__(256) void k_gemm(const ivln_gemm_desc p) {
 
     float ra0[EA], rb0[EB], ra1[EA], rb1[EB];
 
+    // Branch-free tile loads: every lane ALWAYS issues its load from a clamped (valid) address and the
+    // out-of-range / padding case is a select afterwards.  With the loads unconditional hipcc can count
+    // them and emits partial s_waitcnt vmcnt(N) for the older register set instead of vmcnt(0).
     auto load_tile = [&](int k0, float (&ra)[EA], float (&rb)[EB]) {
         // ---------------- A ----------------
         if constexpr (AMODE == AMODE_MK) {
-            int k = k0 + a_k;
+            const int k = k0 + a_k;
+            const bool kok = k < kend;
 #pragma unroll
             for (int e = 0; e < EA; ++e) {
-                int m = m0 + a_m + e * A_STEP;
-                ra[e] = (m < p.M && k < kend) ? p.A[(int64_t)m * p.lda + k] : 0.f;
+                const int m = m0 + a_m + e * A_STEP;
+                const bool ok = kok && m < p.M;
+                const float v = p.A[ok ? (int64_t)m * p.lda + k : 0];
+                ra[e] = ok ? v : 0.f;
             }
         } else if constexpr (AMODE == AMODE_KM) {
-            int m = m0 + a_m;
+            const int m = m0 + a_m;
 #pragma unroll
             for (int e = 0; e < EA; ++e) {
-                int k = k0 + a_k + e * A_STEP;
-                ra[e] = (m < p.M && k < kend) ? p.A[(int64_t)k * p.lda + m] : 0.f;
+                const int k = k0 + a_k + e * A_STEP;
+                const bool ok = m < p.M && k < kend;
+                const float v = p.A[ok ? (int64_t)k * p.lda + m : 0];
+                ra[e] = ok ? v : 0.f;
             }
         } else {  // AMODE_NCHW_P: A[m = channel][k = pixel] of an NCHW gradient tensor
-            int k = k0 + a_k;
-            bool ok = k < kend;
-            int kk = ok ? k : 0;
-            int img = kk / p.HoWo;
-            int pp = kk - img * p.HoWo;
+            const int k = k0 + a_k;
+            const bool kok = k < kend;
+            const int kk = kok ? k : 0;
+            const int img = kk / p.HoWo;
+            const int pp = kk - img * p.HoWo;
 #pragma unroll
             for (int e = 0; e < EA; ++e) {
-                int m = m0 + a_m + e * A_STEP;
-                ra[e] = (ok && m < p.M) ? p.A[((int64_t)img * p.M + m) * p.HoWo + pp] : 0.f;
+                const int m = m0 + a_m + e * A_STEP;
+                const bool ok = kok && m < p.M;
+                const float v = p.A[ok ? ((int64_t)img * p.M + m) * p.HoWo + pp : 0];
+                ra[e] = ok ? v : 0.f;
             }
         }
         // ---------------- B ----------------
         if constexpr (BMODE == BMODE_CONV) {
 #pragma unroll
             for (int e = 0; e < EB; ++e) {
-                int k = k0 + b_k + e * B_STEP;
-                float v = 0.f;
-                if (n_ok && k < kend) {
-                    int kp = p.kpos[k];
-                    int hi = hi0 + (kp >> 16) * p.dil, wi = wi0 + (kp & 0xFFFF) * p.dil;
-                    if ((unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win)
-                        v = p.B[pix_base + p.koff[k] + (int64_t)hi0 * p.Win + wi0];
-                }
-                rb[e] = v;
+                const int k = k0 + b_k + e * B_STEP;
+                const bool kok = n_ok && k < kend;
+                const int kc = kok ? k : 0;
+                const int kp = p.kpos[kc];
+                const int hi = hi0 + (kp >> 16) * p.dil, wi = wi0 + (kp & 0xFFFF) * p.dil;
+                const bool ok = kok && (unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win;
+                const float v = p.B[ok ? pix_base + p.koff[kc] + (int64_t)hi0 * p.Win + wi0 : 0];
+                rb[e] = ok ? v : 0.f;
             }
         } else if constexpr (BMODE == BMODE_CONV_K3 || BMODE == BMODE_CONV_K7) {
-            // same gather with (ci,kh,kw) from constant divisions: removes the dependent table load from
-            // the per-tile critical path (these launches are latency- not bandwidth-bound)
+            // (ci,kh,kw) from constant divisions: no dependent table load on the per-tile critical path
             constexpr int KS = BMODE == BMODE_CONV_K3 ? 3 : 7;
             const int HWin = p.Hin * p.Win;
 #pragma unroll
             for (int e = 0; e < EB; ++e) {
-                int k = k0 + b_k + e * B_STEP;
-                float v = 0.f;
-                if (n_ok && k < kend) {
-                    int ci = k / (KS * KS), r = k - ci * (KS * KS);
-                    int kh = r / KS, kw = r - kh * KS;
-                    int hi = hi0 + kh, wi = wi0 + kw;
-                    if ((unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win)
-                        v = p.B[pix_base + (int64_t)ci * HWin + (int64_t)hi * p.Win + wi];
-                }
-                rb[e] = v;
+                const int k = k0 + b_k + e * B_STEP;
+                const int ci = k / (KS * KS), r = k - ci * (KS * KS);
+                const int kh = r / KS, kw = r - kh * KS;
+                const int hi = hi0 + kh, wi = wi0 + kw;
+                const bool ok = n_ok && k < kend && (unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win;
+                const float v = p.B[ok ? pix_base + (int64_t)ci * HWin + (int64_t)hi * p.Win + wi : 0];
+                rb[e] = ok ? v : 0.f;
             }
         } else if constexpr (BMODE == BMODE_CONV1X1) {
+            const int64_t HWin = (int64_t)p.Hin * p.Win;
+            const int64_t pbase = pix_base + (int64_t)hi0 * p.Win + wi0;
 #pragma unroll
             for (int e = 0; e < EB; ++e) {
-                int k = k0 + b_k + e * B_STEP;
-                rb[e] = (n_ok && k < kend)
-                            ? p.B[pix_base + (int64_t)k * p.Hin * p.Win + (int64_t)hi0 * p.Win + wi0]
-                            : 0.f;
+                const int k = k0 + b_k + e * B_STEP;
+                const bool ok = n_ok && k < kend;
+                const float v = p.B[ok ? pbase + (int64_t)k * HWin : 0];
+                rb[e] = ok ? v : 0.f;
             }
         } else if constexpr (BMODE == BMODE_CONVT) {
             // y[oh] += x[(oh + pad - kh)/stride] * w[kh] when divisible (nn.ConvTranspose2d)
 #pragma unroll
             for (int e = 0; e < EB; ++e) {
-                int k = k0 + b_k + e * B_STEP;
-                float v = 0.f;
-                if (n_ok && k < kend) {
-                    int kp = p.kpos[k];
-                    int th = hi0 - (kp >> 16), tw = wi0 - (kp & 0xFFFF);
-                    if (th >= 0 && tw >= 0 && (th % p.stride) == 0 && (tw % p.stride) == 0) {
-                        int hi = th / p.stride, wi = tw / p.stride;
-                        if (hi < p.Hin && wi < p.Win)
-                            v = p.B[pix_base + p.koff[k] + (int64_t)hi * p.Win + wi];
-                    }
-                }
-                rb[e] = v;
+                const int k = k0 + b_k + e * B_STEP;
+                const bool kok = n_ok && k < kend;
+                const int kc = kok ? k : 0;
+                const int kp = p.kpos[kc];
+                const int th = hi0 - (kp >> 16), tw = wi0 - (kp & 0xFFFF);
+                const int hi = th / p.stride, wi = tw / p.stride;
+                const bool ok = kok && th >= 0 && tw >= 0 && hi * p.stride == th && wi * p.stride == tw &&
+                                hi < p.Hin && wi < p.Win;
+                const float v = p.B[ok ? pix_base + p.koff[kc] + (int64_t)hi * p.Win + wi : 0];
+                rb[e] = ok ? v : 0.f;
             }
         } else if constexpr (BMODE == BMODE_KN) {
-            int n = n0 + b_n;
+            const int n = n0 + b_n;
 #pragma unroll
             for (int e = 0; e < EB; ++e) {
-                int k = k0 + b_k + e * B_STEP;
-                rb[e] = (n < p.N && k < kend) ? p.B[(int64_t)k * p.ldb + n] : 0.f;
+                const int k = k0 + b_k + e * B_STEP;
+                const bool ok = n < p.N && k < kend;
+                const float v = p.B[ok ? (int64_t)k * p.ldb + n : 0];
+                rb[e] = ok ? v : 0.f;
             }
         } else if constexpr (BMODE == BMODE_NK) {
-            int k = k0 + b_k;
+            const int k = k0 + b_k;
+            const bool kok = k < kend;
 #pragma unroll
             for (int e = 0; e < EB; ++e) {
-                int n = n0 + b_n + e * B_STEP;
-                rb[e] = (n < p.N && k < kend) ? p.B[(int64_t)n * p.ldb + k] : 0.f;
+                const int n = n0 + b_n + e * B_STEP;
+                const bool ok = kok && n < p.N;
+                const float v = p.B[ok ? (int64_t)n * p.ldb + k : 0];
+                rb[e] = ok ? v : 0.f;
             }
         } else {  // BMODE_IM2COL_T: B[k = output pixel][n = (ci,kh,kw)] gathered from the NCHW input
-            int k = k0 + b_k;
-            bool ok = k < kend;
-            int kk = ok ? k : 0;
-            int img = kk / p.HoWo;
-            int pp = kk - img * p.HoWo;
-            int ho = pp / p.Wout, wo = pp - ho * p.Wout;
-            int h0 = ho * p.stride - p.pad, w0 = wo * p.stride - p.pad;
-            int64_t base = (int64_t)img * p.in_img_stride + (int64_t)h0 * p.Win + w0;
+            const int k = k0 + b_k;
+            const bool kok = k < kend;
+            const int kk = kok ? k : 0;
+            const int img = kk / p.HoWo;
+            const int pp = kk - img * p.HoWo;
+            const int ho = pp / p.Wout, wo = pp - ho * p.Wout;
+            const int h0 = ho * p.stride - p.pad, w0 = wo * p.stride - p.pad;
+            const int64_t base = (int64_t)img * p.in_img_stride + (int64_t)h0 * p.Win + w0;
 #pragma unroll
             for (int e = 0; e < EB; ++e) {
-                float v = 0.f;
-                if (ok && w_kpos[e] >= 0) {
-                    int hi = h0 + (w_kpos[e] >> 16), wi = w0 + (w_kpos[e] & 0xFFFF);
-                    if ((unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win) v = p.B[base + w_koff[e]];
-                }
-                rb[e] = v;
+                const int hi = h0 + (w_kpos[e] >> 16), wi = w0 + (w_kpos[e] & 0xFFFF);
+                const bool ok = kok && w_kpos[e] >= 0 && (unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win;
+                const float v = p.B[ok ? base + w_koff[e] : 0];
+                rb[e] = ok ? v : 0.f;
             }
         }
     };
 
-    f32x16 acc;
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[tm][tn][i] = 0.f;
 
-    // Software pipeline, two K tiles in flight in registers: the global/gather loads issued in
-    // iteration i are consumed in iteration i+2, so their latency overlaps two MFMA phases (with only a
-    // handful of blocks per CU at rollout batch sizes there is little else to hide it behind).
+    // Software pipeline with TWO K tiles in flight in two register sets.  The loop is unrolled by two so
+    // that the sets swap roles without register copies: a copy (ra0 = ra1) made hipcc wait vmcnt(0) at
+    // the loop top, i.e. the loads issued one iteration earlier had only ONE MFMA phase (~512 cycles) to
+    // land and every tile stalled on L2/MALL latency (MFMA pipe 47 % busy on a 1024x4096x1024 GEMM).
+    auto stage = [&](float (&ra)[EA], float (&rb)[EB]) {
+#pragma unroll
+        for (int e = 0; e < EA; ++e) {
+            if constexpr (A_KFAST) As[a_k * LDA_S + a_m + e * A_STEP] = ra[e];
+            else As[(a_k + e * A_STEP) * LDA_S + a_m] = ra[e];
+        }
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            if constexpr (B_KFAST) Bs[b_k * LDB_S + b_n + e * B_STEP] = rb[e];
+            else Bs[(b_k + e * B_STEP) * LDB_S + b_n] = rb[e];
+        }
+    };
+    auto compute = [&]() {
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+                a[tm] = As[(2 * kk + (lane >> 5)) * LDA_S + (wm * TM + tm) * 32 + (lane & 31)];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+                b[tn] = Bs[(2 * kk + (lane >> 5)) * LDB_S + (wn * TN + tn) * 32 + (lane & 31)];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+        }
+    };
     if (kbeg < kend) {
         load_tile(kbeg, ra0, rb0);
-        if (kbeg + BK < kend) load_tile(kbeg + BK, ra1, rb1);
-        for (int k0 = kbeg; k0 < kend; k0 += BK) {
-#pragma unroll
-            for (int e = 0; e < EA; ++e) {
-                if constexpr (A_KFAST) As[a_k * LDA_S + a_m + e * A_STEP] = ra0[e];
-                else As[(a_k + e * A_STEP) * LDA_S + a_m] = ra0[e];
-            }
-#pragma unroll
-            for (int e = 0; e < EB; ++e) {
-                if constexpr (B_KFAST) Bs[b_k * LDB_S + b_n + e * B_STEP] = rb0[e];
-                else Bs[(b_k + e * B_STEP) * LDB_S + b_n] = rb0[e];
-            }
+        load_tile(kbeg + BK, ra1, rb1);  // past-the-end tiles load clamped addresses and select zeros
+        for (int k0 = kbeg; k0 < kend; k0 += 2 * BK) {
+            stage(ra0, rb0);
             __syncthreads();
-#pragma unroll
-            for (int e = 0; e < EA; ++e) ra0[e] = ra1[e];
-#pragma unroll
-            for (int e = 0; e < EB; ++e) rb0[e] = rb1[e];
-            if (k0 + 2 * BK < kend) load_tile(k0 + 2 * BK, ra1, rb1);
-#pragma unroll
-            for (int kk = 0; kk < BK / 2; ++kk) {
-                float a = As[(2 * kk + (lane >> 5)) * LDA_S + wm * 32 + (lane & 31)];
-                float b = Bs[(2 * kk + (lane >> 5)) * LDB_S + wn * 32 + (lane & 31)];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-            }
+            load_tile(k0 + 2 * BK, ra0, rb0);
+            compute();
+            __syncthreads();
+            if (k0 + BK >= kend) break;
+            stage(ra1, rb1);
+            __syncthreads();
+            load_tile(k0 + 3 * BK, ra1, rb1);
+            compute();
             __syncthreads();
         }
     }
 
     // ---- epilogue: acc[r] -> row (r&3) + 8*(r>>2) + 4*(lane>>5), col lane&31 ----
-    const int n = n0 + wn * 32 + (lane & 31);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m < p.M && n < p.N) {
-            if (p.splits > 1 || p.defer_epilogue) p.ws[((int64_t)blockIdx.z * p.M + m) * p.N + n] = acc[r];
-            else epilogue_store(p, m, n, acc[r]);
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int n = n0 + (wn * TN + tn) * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < p.M && n < p.N) {
+                    if (p.splits > 1 || p.defer_epilogue)
+                        p.ws[((int64_t)blockIdx.z * p.M + m) * p.N + n] = acc[tm][tn][r];
+                    else epilogue_store(p, m, n, acc[tm][tn][r]);
+                }
+            }
         }
-    }
 }
 
 __global__ __launch_bounds__(256) void k_splitk_epilogue(const ivln_gemm_desc p) {
@@ -291,14 +329,14 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const ivln_gemm_desc p)
     epilogue_store(p, m, n, v);
 }
 
-template <int WM, int WN>
+template <int WM, int WN, int TM, int TN>
 int launch_tile(const ivln_gemm_desc& d, hipStream_t s) {
-    constexpr int BM = 32 * WM, BN = 32 * WN;
+    constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
     dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM, d.splits);
     dim3 block(256);
 #define IVLN_CASE(AM, BMD)                                                              \
     if (d.amode == AM && d.bmode == BMD) {                                              \
-        hipLaunchKernelGGL((k_gemm<WM, WN, AM, BMD>), grid, block, 0, s, d);            \
+        hipLaunchKernelGGL((k_gemm<WM, WN, TM, TN, AM, BMD>), grid, block, 0, s, d);            \
         return IVLN_OK;                                                                 \
     }
     IVLN_CASE(AMODE_MK, BMODE_CONV)
@@ -326,12 +364,19 @@ extern "C" int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream) {
     if (d.dil <= 0) d.dil = 1;
     if (d.Ctot <= 0) d.Ctot = d.M;
     if (d.in_img_stride <= 0) d.in_img_stride = (int64_t)d.Cin * d.Hin * d.Win;
-    // tile shape: channel-starved -> 32x128, pixel-starved -> 128x32, else 64x64
+    // tile shape: channel-starved -> 32x128, pixel-starved -> 128x32; otherwise the largest of
+    // 128x128 / 64x128 / 64x64 that still gives >= 2 blocks per CU (512 blocks)
     int tile = 0;
     if (d.M <= 32) tile = 1;
     else if (d.N <= 32) tile = 2;
-    const int BM = tile == 1 ? 32 : (tile == 2 ? 128 : 64);
-    const int BN = tile == 1 ? 128 : (tile == 2 ? 32 : 64);
+    else {
+        auto nblocks = [&](int bm, int bn) { return (int64_t)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn); };
+        if (d.M > 64 && nblocks(128, 128) >= 512) tile = 3;
+        else if (nblocks(64, 128) >= 512) tile = 4;
+    }
+    if (d.tile_override > 0) tile = d.tile_override - 1;
+    const int BM = tile == 1 ? 32 : (tile == 2 || tile == 3 ? 128 : 64);
+    const int BN = tile == 1 ? 128 : (tile == 2 ? 32 : (tile == 3 || tile == 4 ? 128 : 64));
     // split-K when the output grid cannot fill the chip and K is deep
     int64_t blocks = (int64_t)((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
     int nk = (d.K + BK - 1) / BK;
@@ -340,11 +385,12 @@ extern "C" int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream) {
     if (d.splits == 0) {
         // the consumer reduces for free when deferred: split until ~4 blocks per CU hide the load latency
         const int min_tiles = d.defer_epilogue ? 2 : 4;
-        const int64_t want = d.defer_epilogue ? 1024 : 256;
-        if (d.ws && blocks < (d.defer_epilogue ? 512 : 128) && nk >= 2 * min_tiles) {
+        const int64_t want = d.defer_epilogue ? 1024 : 512;
+        if (d.ws && blocks < (d.defer_epilogue ? 512 : 256) && nk >= 2 * min_tiles) {
             splits = (int)((want + blocks - 1) / blocks);
             if (splits > nk / min_tiles) splits = nk / min_tiles;
-            const int max_splits = d.defer_epilogue ? (blocks <= 8 ? 64 : (blocks <= 32 ? 32 : 16)) : 64;
+            // weight gradients reduce over millions of pixels with a tiny M x N: allow deep splits there
+            const int max_splits = d.defer_epilogue ? (blocks <= 8 ? 64 : (blocks <= 32 ? 32 : 16)) : (nk >= 4096 ? 256 : 16);
             if (splits > max_splits) splits = max_splits;
             int64_t cap = d.ws_floats / ((int64_t)d.M * d.N);
             if (splits > cap) splits = (int)cap;
@@ -358,7 +404,14 @@ extern "C" int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream) {
     int tps = (nk + splits - 1) / splits;
     splits = (nk + tps - 1) / tps;
     d.splits = splits;
-    int rc = tile == 1 ? launch_tile<1, 4>(d, s) : (tile == 2 ? launch_tile<4, 1>(d, s) : launch_tile<2, 2>(d, s));
+    int rc;
+    switch (tile) {
+        case 1: rc = launch_tile<1, 4, 1, 1>(d, s); break;
+        case 2: rc = launch_tile<4, 1, 1, 1>(d, s); break;
+        case 3: rc = launch_tile<2, 2, 2, 2>(d, s); break;
+        case 4: rc = launch_tile<2, 2, 1, 2>(d, s); break;
+        default: rc = launch_tile<2, 2, 1, 1>(d, s); break;
+    }
     if (rc != IVLN_OK) return rc;
     if (d.splits_used) *d.splits_used = splits;
     if (splits > 1 && !d.defer_epilogue) {

@@ -231,45 +231,71 @@ __global__ void k_bn_fold(const float* __restrict__ gamma, const float* __restri
     shift[c] = beta[c] - m * sc;
 }
 
-__global__ __launch_bounds__(256) void k_bn_train_stats(const float* __restrict__ x, int N, int C, int HW,
-                                                        const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, float* __restrict__ rmean,
-                                                        float* __restrict__ rvar, float momentum, float eps,
-                                                        float* __restrict__ scale, float* __restrict__ shift,
-                                                        float* __restrict__ save_mean,
-                                                        float* __restrict__ save_rstd) {
+// Train-mode batch statistics in two launches: grid (C, S) blocks each reduce a slice of the images
+// with a local two-pass (count, mean, M2); one thread per channel then merges the S partials in a
+// fixed order with Chan's parallel-variance formula (deterministic, no cancellation), produces
+// scale/shift and updates the running statistics.  (One block per channel took 7.8 ms on the
+// (512,32,64,64) update batch.)
+__global__ __launch_bounds__(256) void k_bn_stats_partial(const float* __restrict__ x, int N, int C, int HW,
+                                                          int imgs_per_split, float* __restrict__ partial) {
     __shared__ float red[16];
-    const int c = blockIdx.x;
-    const int64_t cnt = (int64_t)N * HW;
+    const int c = blockIdx.x, sp = blockIdx.y, S = gridDim.y;
+    const int i0 = sp * imgs_per_split, i1 = min(N, i0 + imgs_per_split);
+    const int64_t cnt = (int64_t)max(0, i1 - i0) * HW;
     float s = 0.f;
-    for (int64_t i = threadIdx.x; i < cnt; i += blockDim.x) {
-        int img = (int)(i / HW);
-        int pp = (int)(i - (int64_t)img * HW);
-        s += x[((int64_t)img * C + c) * HW + pp];
+    for (int img = i0; img < i1; ++img) {
+        const float* xp = x + ((int64_t)img * C + c) * HW;
+        for (int i = threadIdx.x; i < HW; i += 256) s += xp[i];
     }
-    const float mean = block_sum(s, red) / (float)cnt;
+    const float mean = cnt > 0 ? block_sum(s, red) / (float)cnt : 0.f;
     float q = 0.f;
-    for (int64_t i = threadIdx.x; i < cnt; i += blockDim.x) {
-        int img = (int)(i / HW);
-        int pp = (int)(i - (int64_t)img * HW);
-        float d = x[((int64_t)img * C + c) * HW + pp] - mean;
-        q += d * d;
+    for (int img = i0; img < i1; ++img) {
+        const float* xp = x + ((int64_t)img * C + c) * HW;
+        for (int i = threadIdx.x; i < HW; i += 256) {
+            float d = xp[i] - mean;
+            q += d * d;
+        }
     }
-    const float var = block_sum(q, red) / (float)cnt;
+    q = block_sum(q, red);
     if (threadIdx.x == 0) {
-        float rstd = 1.f / sqrtf(var + eps);
-        float sc = gamma[c] * rstd;
-        scale[c] = sc;
-        shift[c] = beta[c] - mean * sc;
-        if (save_mean) {
-            save_mean[c] = mean;
-            save_rstd[c] = rstd;
-        }
-        if (rmean) {
-            float unbiased = cnt > 1 ? var * (float)cnt / (float)(cnt - 1) : var;
-            rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
-            rvar[c] = (1.f - momentum) * rvar[c] + momentum * unbiased;
-        }
+        float* o = partial + ((int64_t)c * S + sp) * 3;
+        o[0] = (float)cnt;
+        o[1] = mean;
+        o[2] = q;
+    }
+}
+
+__global__ void k_bn_stats_final(const float* __restrict__ partial, int S, int C, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, float* __restrict__ rmean,
+                                 float* __restrict__ rvar, float momentum, float eps, float* __restrict__ scale,
+                                 float* __restrict__ shift, float* __restrict__ save_mean,
+                                 float* __restrict__ save_rstd) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int sp = 0; sp < S; ++sp) {
+        const float* o = partial + ((int64_t)c * S + sp) * 3;
+        const float nb = o[0];
+        if (nb <= 0.f) continue;
+        const float delta = o[1] - mean;
+        const float nn = n + nb;
+        mean += delta * (nb / nn);
+        m2 += o[2] + delta * delta * (n * nb / nn);
+        n = nn;
+    }
+    const float var = m2 / n;
+    const float rstd = 1.f / sqrtf(var + eps);
+    const float sc = gamma[c] * rstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - mean * sc;
+    if (save_mean) {
+        save_mean[c] = mean;
+        save_rstd[c] = rstd;
+    }
+    if (rmean) {
+        const float unbiased = n > 1.f ? m2 / (n - 1.f) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * unbiased;
     }
 }
 
@@ -852,8 +878,18 @@ int ivln_bn_fold_f32(const float* gamma, const float* beta, const float* running
 
 int ivln_bn_train_stats_f32(const float* x, int N, int C, int HW, const float* gamma, const float* beta,
                             float* running_mean, float* running_var, float momentum, float eps, float* scale,
-                            float* shift, float* save_mean, float* save_rstd, void* stream) {
-    hipLaunchKernelGGL(k_bn_train_stats, dim3(C), dim3(256), 0, (hipStream_t)stream, x, N, C, HW, gamma, beta,
+                            float* shift, float* save_mean, float* save_rstd, float* ws, int64_t ws_floats,
+                            void* stream) {
+    if (!ws || ws_floats < (int64_t)3 * C) return IVLN_E_INVALID;
+    int S = (int)(((int64_t)N * HW + 16383) / 16384);  // >= 16k elements per block
+    if (S > N) S = N;
+    if (S > 64) S = 64;
+    if ((int64_t)S * C * 3 > ws_floats) S = (int)(ws_floats / ((int64_t)C * 3));
+    if (S < 1) S = 1;
+    const int ips = (N + S - 1) / S;
+    S = (N + ips - 1) / ips;
+    hipLaunchKernelGGL(k_bn_stats_partial, dim3(C, S), dim3(256), 0, (hipStream_t)stream, x, N, C, HW, ips, ws);
+    hipLaunchKernelGGL(k_bn_stats_final, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, ws, S, C, gamma, beta,
                        running_mean, running_var, momentum, eps, scale, shift, save_mean, save_rstd);
     return LAUNCH_OK();
 }

@@ -73,18 +73,32 @@ __global__ void k_colsum_final(const float* __restrict__ partial, int splits, in
     out[c] = accumulate ? out[c] + s : s;
 }
 
-// per-channel sum over (N, HW) of an NCHW tensor (conv bias grad); one block per channel
-__global__ __launch_bounds__(256) void k_nchw_chansum(const float* __restrict__ x, int N, int C, int HW,
-                                                      float* __restrict__ out) {
+// per-channel sum over (N, HW) of an NCHW tensor (conv bias grad): grid (C, S) partials over image
+// slices, then a fixed-order final sum (deterministic)
+__global__ __launch_bounds__(256) void k_nchw_chansum_partial(const float* __restrict__ x, int N, int C, int HW,
+                                                              int imgs_per_split, float* __restrict__ partial) {
     __shared__ float red[16];
-    const int c = blockIdx.x;
+    const int c = blockIdx.x, sp = blockIdx.y, S = gridDim.y;
+    const int i0 = sp * imgs_per_split, i1 = min(N, i0 + imgs_per_split);
     float s = 0.f;
-    for (int img = 0; img < N; ++img) {
+    for (int img = i0; img < i1; ++img) {
         const float* xp = x + ((int64_t)img * C + c) * HW;
         for (int i = threadIdx.x; i < HW; i += 256) s += xp[i];
     }
     s = block_sum(s, red);
-    if (threadIdx.x == 0) out[c] = s;
+    if (threadIdx.x == 0) partial[(int64_t)c * S + sp] = s;
+}
+__global__ void k_chan_final(const float* __restrict__ partial, int S, int C, int K, float* __restrict__ out0,
+                             float* __restrict__ out1) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f, b2 = 0.f;
+    for (int sp = 0; sp < S; ++sp) {
+        a += partial[((int64_t)c * S + sp) * K];
+        if (K > 1) b2 += partial[((int64_t)c * S + sp) * K + 1];
+    }
+    out0[c] = a;
+    if (K > 1) out1[c] = b2;
 }
 
 // (R, C) -> (C, R)
@@ -340,13 +354,14 @@ __global__ __launch_bounds__(256) void k_cbra_bwd_stats(const float* __restrict_
                                                         const float* __restrict__ shift,
                                                         const float* __restrict__ mean,
                                                         const float* __restrict__ rstd, int N, int C, int H, int W,
-                                                        float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                        int imgs_per_split, float* __restrict__ partial) {
     __shared__ float red[16];
-    const int c = blockIdx.x;
+    const int c = blockIdx.x, sp = blockIdx.y, S = gridDim.y;
+    const int i0 = sp * imgs_per_split, i1 = min(N, i0 + imgs_per_split);
     const int Ho = H / 2, Wo = W / 2, HW = H * W;
     const float sc = scale[c], sh = shift[c], mu = mean[c], rs = rstd[c];
     float s1 = 0.f, s2 = 0.f;
-    for (int img = 0; img < N; ++img) {
+    for (int img = i0; img < i1; ++img) {
         const float* yp = y + ((int64_t)img * C + c) * HW;
         const float* dp = dout + ((int64_t)img * C + c) * Ho * Wo;
         for (int i = threadIdx.x; i < HW; i += 256) {
@@ -360,8 +375,8 @@ __global__ __launch_bounds__(256) void k_cbra_bwd_stats(const float* __restrict_
     s1 = block_sum(s1, red);
     s2 = block_sum(s2, red);
     if (threadIdx.x == 0) {
-        dbeta[c] = s1;
-        dgamma[c] = s2;
+        partial[((int64_t)c * S + sp) * 2] = s1;      // -> dbeta
+        partial[((int64_t)c * S + sp) * 2 + 1] = s2;  // -> dgamma
     }
 }
 
@@ -543,8 +558,23 @@ int ivln_colsum_f32(const float* x, int64_t ld, int rows, int cols, float* out, 
     return LAUNCH_OK();
 }
 
-int ivln_nchw_chansum_f32(const float* x, int N, int C, int HW, float* out, void* stream) {
-    hipLaunchKernelGGL(k_nchw_chansum, dim3(C), dim3(256), 0, (hipStream_t)stream, x, N, C, HW, out);
+static int chan_splits(int N, int HW, int C, int K, int64_t ws_floats) {
+    int S = (int)(((int64_t)N * HW + 16383) / 16384);
+    if (S > N) S = N;
+    if (S > 64) S = 64;
+    if ((int64_t)S * C * K > ws_floats) S = (int)(ws_floats / ((int64_t)C * K));
+    return S < 1 ? 1 : S;
+}
+
+int ivln_nchw_chansum_f32(const float* x, int N, int C, int HW, float* out, float* ws, int64_t ws_floats,
+                          void* stream) {
+    if (!ws || ws_floats < C) return IVLN_E_INVALID;
+    int S = chan_splits(N, HW, C, 1, ws_floats);
+    const int ips = (N + S - 1) / S;
+    S = (N + ips - 1) / ips;
+    hipLaunchKernelGGL(k_nchw_chansum_partial, dim3(C, S), dim3(256), 0, (hipStream_t)stream, x, N, C, HW, ips, ws);
+    hipLaunchKernelGGL(k_chan_final, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, ws, S, C, 1, out,
+                       (float*)nullptr);
     return LAUNCH_OK();
 }
 
@@ -597,9 +627,14 @@ int ivln_lstm_bidir_bwd_f32(const float* dout, const float* out, const float* ga
 
 int ivln_cbra_bwd_f32(const float* dout, const float* y, const float* scale, const float* shift, const float* mean,
                       const float* rstd, int N, int C, int H, int W, int train, float* dgamma, float* dbeta,
-                      float* dy, void* stream) {
-    hipLaunchKernelGGL(k_cbra_bwd_stats, dim3(C), dim3(256), 0, (hipStream_t)stream, dout, y, scale, shift, mean, rstd,
-                       N, C, H, W, dgamma, dbeta);
+                      float* dy, float* ws, int64_t ws_floats, void* stream) {
+    if (!ws || ws_floats < (int64_t)2 * C) return IVLN_E_INVALID;
+    int S = chan_splits(N, H * W, C, 2, ws_floats);
+    const int ips = (N + S - 1) / S;
+    S = (N + ips - 1) / ips;
+    hipLaunchKernelGGL(k_cbra_bwd_stats, dim3(C, S), dim3(256), 0, (hipStream_t)stream, dout, y, scale, shift, mean,
+                       rstd, N, C, H, W, ips, ws);
+    hipLaunchKernelGGL(k_chan_final, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, ws, S, C, 2, dbeta, dgamma);
     hipLaunchKernelGGL(k_cbra_bwd_apply, dim3(nblk((int64_t)N * C * H * W)), dim3(256), 0, (hipStream_t)stream, dout,
                        y, scale, shift, mean, rstd, dgamma, dbeta, N, C, H, W, train, dy);
     return LAUNCH_OK();

@@ -31,6 +31,7 @@ class GemmDesc(C.Structure):
         ("splits", i32),
         ("ws", vp), ("ws_floats", i64),
         ("defer_epilogue", i32), ("splits_used", C.POINTER(i32)),
+        ("tile_override", i32),
     ]
 
 
@@ -49,7 +50,7 @@ def _L():
         L.ivln_groupnorm_f32.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, i64, i64, i32, i64, i64, i64,
                                          vp, vp, vp]
         L.ivln_bn_fold_f32.argtypes = [vp, vp, vp, vp, vp, f32, i32, vp, vp, vp]
-        L.ivln_bn_train_stats_f32.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp]
+        L.ivln_bn_train_stats_f32.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, i64, vp]
         L.ivln_scale_shift_relu_avgpool2_f32.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i32, i64, vp]
         L.ivln_pool2d_f32.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
         L.ivln_map_features_f32.argtypes = [vp, vp, vp, i32, i32, i32, vp]
@@ -112,7 +113,12 @@ def splitk_ws(device, floats=8 << 20):
     return w
 
 
+TILE_OVERRIDE = 0  # tuning/tests: force a block tile (1..5), see ivln_gemm_desc.tile_override
+
+
 def gemm(desc: GemmDesc):
+    if TILE_OVERRIDE:
+        desc.tile_override = TILE_OVERRIDE
     check(_L().ivln_gemm_f32(C.byref(desc), stream_ptr()), "ivln_gemm_f32")
 
 
@@ -272,6 +278,19 @@ def bn_fold(bn, scale, shift, conv_bias=None):
     )
 
 
+_red_ws = {}
+
+
+def _reduce_ws(device):
+    """Scratch for the two-stage per-channel reductions (C * 64 splits * 3 values, per stream)."""
+    key = (str(device), torch.cuda.current_stream().cuda_stream)
+    w = _red_ws.get(key)
+    if w is None:
+        w = torch.empty(1 << 20, dtype=torch.float32, device=device)
+        _red_ws[key] = w
+    return w
+
+
 def bn_train_stats(x, bn, scale, shift, save_mean=None, save_rstd=None, update_running=True):
     N, Cc, H, W = x.shape
     mom = bn.momentum if bn.momentum is not None else 0.1
@@ -279,7 +298,8 @@ def bn_train_stats(x, bn, scale, shift, save_mean=None, save_rstd=None, update_r
         _L().ivln_bn_train_stats_f32(dptr(x), N, Cc, H * W, dptr(bn.weight), dptr(bn.bias),
                                      dptr(bn.running_mean) if update_running else None,
                                      dptr(bn.running_var) if update_running else None, mom, bn.eps, dptr(scale),
-                                     dptr(shift), _p(save_mean), _p(save_rstd), stream_ptr()),
+                                     dptr(shift), _p(save_mean), _p(save_rstd), dptr(_reduce_ws(x.device)),
+                                     _reduce_ws(x.device).numel(), stream_ptr()),
         "ivln_bn_train_stats_f32",
     )
 
@@ -440,7 +460,7 @@ def _T():
         L.ivln_relu_bwd_f32.argtypes = [vp, vp, vp, i32, i32, i64, i64, i64, vp]
         L.ivln_add2d_f32.argtypes = [vp, i64, vp, i64, vp, i64, i32, i32, vp]
         L.ivln_colsum_f32.argtypes = [vp, i64, i32, i32, vp, i32, vp, i64, vp]
-        L.ivln_nchw_chansum_f32.argtypes = [vp, i32, i32, i32, vp, vp]
+        L.ivln_nchw_chansum_f32.argtypes = [vp, i32, i32, i32, vp, vp, i64, vp]
         L.ivln_transpose_f32.argtypes = [vp, vp, i32, i32, vp]
         L.ivln_weight_flip_transpose_f32.argtypes = [vp, vp, i32, i32, i32, i32, vp]
         L.ivln_attn_bwd_f32.argtypes = [vp, i64, vp, vp, i64, vp, i64, vp, i64, f32, i32, i32, i32, i32, vp, i64, vp,
@@ -448,7 +468,7 @@ def _T():
         L.ivln_gru_bwd_elem_f32.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, i64, vp, i32, i32, vp, vp, vp, vp, vp]
         L.ivln_linear_skinny_ex_f32.argtypes = [vp, i64, vp, vp, i64, vp, vp, i64, i32, i32, i32, vp]
         L.ivln_lstm_bidir_bwd_f32.argtypes = [vp] * 7 + [i32, i32, i32, vp, vp, vp, vp, vp]
-        L.ivln_cbra_bwd_f32.argtypes = [vp] * 6 + [i32, i32, i32, i32, i32, vp, vp, vp, vp]
+        L.ivln_cbra_bwd_f32.argtypes = [vp] * 6 + [i32, i32, i32, i32, i32, vp, vp, vp, vp, i64, vp]
         L.ivln_embedding_scatter_add_f32.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
         L.ivln_prev_action_embed_bwd_f32.argtypes = [vp, vp, vp, i64, vp, i64, i32, i32, i32, vp, vp]
         L.ivln_ce_iw_loss_f32.argtypes = [vp, vp, vp, i32, i32, i32, f32, vp, vp, vp]
@@ -499,7 +519,9 @@ def colsum(x, out=None, accumulate=False):
 def nchw_chansum(x):
     N, Cc, H, W = x.shape
     out = torch.empty((Cc,), dtype=torch.float32, device=x.device)
-    check(_T().ivln_nchw_chansum_f32(dptr(x), N, Cc, H * W, dptr(out), stream_ptr()), "ivln_nchw_chansum_f32")
+    ws = _reduce_ws(x.device)
+    check(_T().ivln_nchw_chansum_f32(dptr(x), N, Cc, H * W, dptr(out), dptr(ws), ws.numel(), stream_ptr()),
+          "ivln_nchw_chansum_f32")
     return out
 
 
@@ -572,7 +594,8 @@ def cbra_bwd(dout, y, scale, shift, mean, rstd, train):
     dy = torch.empty_like(y)
     check(
         _T().ivln_cbra_bwd_f32(dptr(dout), dptr(y), dptr(scale), dptr(shift), dptr(mean), dptr(rstd), N, Cc, H, W,
-                               int(bool(train)), dptr(dgamma), dptr(dbeta), dptr(dy), stream_ptr()),
+                               int(bool(train)), dptr(dgamma), dptr(dbeta), dptr(dy), dptr(_reduce_ws(y.device)),
+                               _reduce_ws(y.device).numel(), stream_ptr()),
         "ivln_cbra_bwd_f32",
     )
     return dy, dgamma, dbeta

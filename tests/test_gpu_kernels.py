@@ -245,3 +245,23 @@ def test_deferred_conv_fused_into_bn_relu_pool():
     d = ops.conv2d(x.to(DEV), w.to(DEV), pad=3, defer=True)
     assert d.splits > 1
     _close(ops.scale_shift_relu_avgpool2(d, sc.to(DEV), sh.to(DEV)), ref, 3e-5)
+
+
+@pytest.mark.parametrize("override", [1, 4, 5])
+@pytest.mark.parametrize("N,Cin,H,W,Cout,k,s,p", [(2, 64, 32, 32, 192, 3, 1, 1), (1, 96, 40, 24, 130, 1, 1, 0),
+                                                   (2, 24, 33, 31, 70, 7, 2, 3)])
+def test_conv2d_every_block_tile(override, N, Cin, H, W, Cout, k, s, p):
+    """The register-tiled 128x128 / 64x128 variants must agree with the 64x64 tile (ragged edges too)."""
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(override * 7 + k)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = F.relu(F.conv2d(x, w, b, stride=s, padding=p))
+    ops.TILE_OVERRIDE = override
+    try:
+        got = ops.conv2d(x.to(DEV), w.to(DEV), stride=s, pad=p, shift=b.to(DEV), relu=True)
+    finally:
+        ops.TILE_OVERRIDE = 0
+    _close(got, ref, 3e-5)

@@ -49,10 +49,15 @@ def bench_convs():
         w = torch.randn(Cout, Cin, k, k, device=DEV)
         Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
         y = torch.empty(N, Cout, Ho, Wo, device=DEV)
-        t = timeit(lambda: ops.conv2d(x, w, stride=s, pad=p, out=y, relu=True), 3, 20)
         fl = 2.0 * N * Ho * Wo * Cout * Cin * k * k
-        out.append((name, round(t * 1e6, 1), round(fl / t / 1e12, 2)))
-        print(f"{name:42s} {t*1e6:9.1f} us  {fl/t/1e12:7.2f} TFLOP/s", flush=True)
+        row = []
+        for ov in (0, 1, 4, 5):
+            ops.TILE_OVERRIDE = ov
+            t = timeit(lambda: ops.conv2d(x, w, stride=s, pad=p, out=y, relu=True), 3, 20)
+            row.append(round(fl / t / 1e12, 1))
+        ops.TILE_OVERRIDE = 0
+        out.append((name, row))
+        print(f"{name:42s} TFLOP/s auto {row[0]:6.1f} | 64x64 {row[1]:6.1f} | 128x128 {row[2]:6.1f} | 64x128 {row[3]:6.1f}", flush=True)
     return out
 
 
