@@ -159,6 +159,40 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+def bench_update(policy, dev, world, barrier, T=64, N=8, iters=5, warm=2):
+    """DAgger update step (base_il_trainer.py:173-219): forward over T*N rows with BPTT, weighted CE +
+    progress-monitor loss, hand-written HIP backward, one flat-bucket RCCL all-reduce (world > 1), Adam.
+    Same barrier / max-over-ranks clock as the rollout leg; rows/s is the whole-job aggregate."""
+    from ivln_ce_amd.trainers import FlatAdam, update_agent
+
+    policy.train()
+    opt = FlatAdam(policy, lr=2.5e-4)
+    g = torch.Generator().manual_seed(7)
+    TN = T * N
+    instr = torch.zeros(N, 200)
+    instr[:, :80] = torch.randint(2, 2504, (N, 80), generator=g).float()
+    obs = {"depth_features": torch.randn(TN, 128, 4, 4, generator=g).to(dev),
+           "occupancy_map": (torch.rand(TN, 64, 64, generator=g) < 0.3).float().to(dev),
+           "semantic_map": torch.randint(0, 13, (TN, 64, 64), generator=g).float().to(dev),
+           "instruction": instr.repeat(T, 1).to(dev)}
+    prev = torch.randint(0, 4, (TN, 1), generator=g).to(dev)
+    nd = torch.ones(T, N, dtype=torch.uint8)
+    nd[0] = 0
+    nd = nd.view(-1, 1).to(dev)
+    tgt = torch.randint(0, 4, (T, N), generator=g).to(dev)
+    w = torch.ones(T, N).to(dev)
+    for _ in range(warm):
+        update_agent(policy, opt, obs, prev, nd, tgt, w, world=world)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        update_agent(policy, opt, obs, prev, nd, tgt, w, world=world)
+    barrier()
+    el = time.perf_counter() - t0
+    policy.eval()
+    return el, {"rows_per_step_per_gpu": TN, "T": T, "N": N, "iters": iters}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -166,6 +200,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs", type=int, default=4, help="parallel envs per GPU (configs[1]: 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-update", action="store_true", help="skip the DAgger update-step leg (extra JSON object)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--streams", action="store_true",
                     help="fork the three encoder branches onto side streams inside the graph (measured SLOWER on "
@@ -236,6 +271,22 @@ def main():
         el = float(t.item())
 
     log(f"rank {rank}: timed region {el:.3f}s")
+    # ---- DAgger update step (fwd + bwd + all-reduce + Adam): reported beside the headline ----
+    update = None
+    if not args.no_update:
+        if use_graph:
+            del runner  # graphs hold the activation pools
+        log(f"rank {rank}: update-step leg")
+        uel, uinfo = bench_update(policy, dev, world, barrier)
+        if world > 1:
+            t = torch.tensor([uel], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            uel = float(t.item())
+        update = {"value": round(world * uinfo["rows_per_step_per_gpu"] * uinfo["iters"] / uel, 1), "unit": "rows/s",
+                  "ms_per_update": round(1e3 * uel / uinfo["iters"], 3), "rows_per_update_per_gpu": uinfo["rows_per_step_per_gpu"],
+                  "what": f"DAgger update T={uinfo['T']} x N={uinfo['N']} per GPU from cached depth features: MapCMA forward "
+                          "with BPTT, inflection-weighted CE + progress monitor, HIP backward, "
+                          + ("one flat RCCL all-reduce, " if world > 1 else "") + "Adam"}
     # ---- roofline of the MFMA implicit-GEMM family: instrumented pass (not part of `value`) ----
     roofline = None
     if rank == 0:
@@ -268,6 +319,8 @@ def main():
         },
         "roofline": roofline,
     }
+    if update is not None:
+        out["update_step"] = update
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline ...")
