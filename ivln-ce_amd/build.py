@@ -13,6 +13,7 @@ OUT = os.path.join(HERE, "libivln_hip.so")
 SOURCES = {
     "mapper.hip": ["-ffp-contract=off"],
     "gemm_conv.hip": [],
+    "conv_direct.hip": [],
     "nn_ops.hip": [],
     "train_ops.hip": [],
     "dtw.cpp": [],

@@ -1,0 +1,216 @@
+// Direct stride-1 3x3 / 7x7 convolution on the fp32 MFMA pipe (gfx950): the map CNN of the MapCMA policy
+// (4 x 7x7, forward and input-gradient), the 3x3 convs of the DD-PPO ResNet and of RedNet.
+//
+// The implicit GEMM in gemm_conv.hip gathers every B element (one input pixel per (ci,kh,kw)) with its own
+// address computation and bounds test; on 7x7 that VALU work competes with the MFMA issue slots.  Here a
+// block owns 128 output pixels (IMGS images x PTH x PTW) x BM output channels and walks the input
+// channels in chunks of CI:
+//   * the (PTH+KS-1) x (PTW+KS-1) input patch of the chunk is staged ONCE in LDS (zero padded) and every
+//     (kh,kw) tap re-reads it from there: KS*KS-fold reuse of each global load;
+//   * the weight slice [BM][CI*KS*KS] is staged k-major next to it;
+//   * the two k slots of v_mfma_f32_32x32x2_f32 (lane halves) take the two input channels of a pair, so
+//     both operand fetches are `ds_read_b32 v, base offset:imm` with a per-lane base that never changes
+//     and an immediate that encodes (channel pair, kh, kw): the MFMA loop carries no VALU work at all.
+// K is therefore accumulated in (channel pair, kh, kw, channel parity) order instead of OIHW order; fp32
+// sums differ from the implicit GEMM in the last bits (tests state the tolerance).
+// Epilogue, split over channel chunks (blockIdx.z) and deferred raw slabs are the ones of ivln_gemm_f32.
+#include <stdlib.h>
+
+#include "gemm_common.h"
+
+namespace {
+
+template <int KS, int PTW, int PTH, int IMGS, int WM>
+__global__ __launch_bounds__(256) void k_conv_direct(const ivln_gemm_desc p, int tiles_w, int tiles_h, int nimg,
+                                                     int chunks_per_split) {
+    constexpr int CI = KS == 7 ? 2 : 8;  // input channels per chunk (even: channel pairs fill the k slots)
+    constexpr int KK = KS * KS;
+    constexpr int KC = CI * KK;   // k extent of a chunk
+    constexpr int NQ = KC / 2;    // MFMA steps per chunk
+    constexpr int WN = 4 / WM, TN = WM == 2 ? 2 : 1;
+    constexpr int BM = 32 * WM, BN = 32 * WN * TN;
+    static_assert(IMGS * PTH * PTW == BN, "pixel tile must hold 128 outputs");
+    constexpr int PH = PTH + KS - 1, PW = PTW + KS - 1, PLANE = PH * PW;
+    constexpr int PATCH = IMGS * CI * PLANE;
+    constexpr int LDA = BM + 1;
+    constexpr int NA = (BM * KC + 255) / 256, NP = (PATCH + 255) / 256;
+    __shared__ float As[KC * LDA];
+    __shared__ float Ps[PATCH];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wm = wave / WN, wn = wave % WN;
+    const int bx = blockIdx.x;
+    const int tw = bx % tiles_w, th = (bx / tiles_w) % tiles_h, ig = bx / (tiles_w * tiles_h);
+    const int img0 = ig * IMGS, ho0 = th * PTH, wo0 = tw * PTW;
+    const int m0 = blockIdx.y * BM;
+    const int nch = p.Cin / CI;
+    const int c_beg = blockIdx.z * chunks_per_split;
+    const int c_end = min(nch, c_beg + chunks_per_split);
+    const int HW = p.Hin * p.Win;
+
+    // patch elements of this thread: chunk-invariant source offsets (-1 = zero padding / no such image)
+    int poff[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int idx = t + i * 256;
+        const int il = idx / (CI * PLANE), rem = idx - il * (CI * PLANE);
+        const int ci = rem / PLANE, rem2 = rem - ci * PLANE;
+        const int y = rem2 / PW, x = rem2 - y * PW;
+        const int hi = ho0 - p.pad + y, wi = wo0 - p.pad + x, img = img0 + il;
+        const bool ok = idx < PATCH && img < nimg && (unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win;
+        poff[i] = ok ? (int)((int64_t)img * p.in_img_stride + (int64_t)ci * HW + hi * p.Win + wi) : -1;
+    }
+
+    float ra[NA], rp[NP];
+    auto load_chunk = [&](int c) {
+        const int kbase = c * KC;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int idx = t + i * 256;
+            const int co = idx / KC, kk = idx - co * KC;
+            const bool ok = idx < BM * KC && m0 + co < p.M;
+            const float v = p.A[ok ? (int64_t)(m0 + co) * p.lda + kbase + kk : 0];
+            ra[i] = ok ? v : 0.f;
+        }
+        const int cbase = c * CI * HW;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const bool ok = poff[i] >= 0;
+            const float v = p.B[ok ? poff[i] + cbase : 0];
+            rp[i] = ok ? v : 0.f;
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int idx = t + i * 256;
+            const int co = idx / KC, kk = idx - co * KC;
+            const int ci = kk / KK, r = kk - ci * KK;
+            if (idx < BM * KC) As[((((ci >> 1) * KK + r) << 1) + (ci & 1)) * LDA + co] = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int idx = t + i * 256;
+            if (idx < PATCH) Ps[idx] = rp[i];
+        }
+    };
+
+    // per-lane operand bases: k slot (lane half) = channel parity inside the pair
+    const int abase = half * LDA + wm * 32 + l31;
+    int bbase[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int nl = (wn * TN + tn) * 32 + l31;
+        const int il = nl / (PTH * PTW), ph = (nl / PTW) % PTH, pw = nl % PTW;
+        bbase[tn] = il * CI * PLANE + half * PLANE + ph * PW + pw;
+    }
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[tn][i] = 0.f;
+
+    if (c_beg < c_end) {
+        load_chunk(c_beg);
+        for (int c = c_beg; c < c_end; ++c) {
+            stage();
+            __syncthreads();
+            if (c + 1 < c_end) load_chunk(c + 1);  // in flight under the MFMA phase
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int cp = q / KK, r = q - cp * KK, kh = r / KS, kw = r - kh * KS;
+                const float a = As[abase + q * 2 * LDA];
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const float b = Ps[bbase[tn] + cp * 2 * PLANE + kh * PW + kw];
+                    acc[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[tn], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: acc[r] -> channel (r&3) + 8*(r>>2) + 4*half, pixel l31 of the sub-tile ----
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int nl = (wn * TN + tn) * 32 + l31;
+        const int il = nl / (PTH * PTW), ph = (nl / PTW) % PTH, pw = nl % PTW;
+        const int img = img0 + il, ho = ho0 + ph, wo = wo0 + pw;
+        const bool pix_ok = img < nimg && ho < p.Hout && wo < p.Wout;
+        const int n = img * p.HoWo + ho * p.Wout + wo;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (pix_ok && m < p.M) {
+                if (p.splits > 1 || p.defer_epilogue) p.ws[((int64_t)blockIdx.z * p.M + m) * p.N + n] = acc[tn][r];
+                else epilogue_store(p, m, n, acc[tn][r]);
+            }
+        }
+    }
+}
+
+template <int KS, int PTW, int PTH, int IMGS>
+void launch_wm(const ivln_gemm_desc& d, hipStream_t s, int nimg, int cps) {
+    const int tiles_w = (d.Wout + PTW - 1) / PTW, tiles_h = (d.Hout + PTH - 1) / PTH;
+    const int groups = (nimg + IMGS - 1) / IMGS;
+    if (d.M <= 32) {
+        dim3 grid(tiles_w * tiles_h * groups, (d.M + 31) / 32, d.splits);
+        hipLaunchKernelGGL((k_conv_direct<KS, PTW, PTH, IMGS, 1>), grid, dim3(256), 0, s, d, tiles_w, tiles_h, nimg, cps);
+    } else {
+        dim3 grid(tiles_w * tiles_h * groups, (d.M + 63) / 64, d.splits);
+        hipLaunchKernelGGL((k_conv_direct<KS, PTW, PTH, IMGS, 2>), grid, dim3(256), 0, s, d, tiles_w, tiles_h, nimg, cps);
+    }
+}
+
+template <int KS>
+void launch_ks(const ivln_gemm_desc& d, hipStream_t s, int nimg, int cps) {
+    if (d.Wout > 16) launch_wm<KS, 32, 4, 1>(d, s, nimg, cps);
+    else if (d.Wout > 8) launch_wm<KS, 16, 8, 1>(d, s, nimg, cps);
+    else if (d.Wout > 4) launch_wm<KS, 8, 8, 2>(d, s, nimg, cps);
+    else launch_wm<KS, 4, 4, 8>(d, s, nimg, cps);
+}
+
+}  // namespace
+
+int ivln_conv_direct_launch(ivln_gemm_desc& d, hipStream_t s) {
+    static const bool disabled = getenv("IVLN_NO_DIRECT_CONV") != nullptr;
+    const int KS = d.bmode == BMODE_CONV_K7 ? 7 : (d.bmode == BMODE_CONV_K3 ? 3 : 0);
+    if (disabled || KS == 0 || d.amode != AMODE_MK || d.stride != 1 || d.dil != 1) return IVLN_E_UNSUPPORTED;
+    const int CI = KS == 7 ? 2 : 8;
+    if (d.Cin % CI != 0 || d.K != d.Cin * KS * KS || d.HoWo != d.Hout * d.Wout || d.N % d.HoWo != 0)
+        return IVLN_E_UNSUPPORTED;
+    const int nimg = d.N / d.HoWo;
+    if ((int64_t)nimg * d.in_img_stride >= (int64_t)1 << 31) return IVLN_E_UNSUPPORTED;  // 32-bit patch offsets
+    const int PTW = d.Wout > 16 ? 32 : (d.Wout > 8 ? 16 : (d.Wout > 4 ? 8 : 4));
+    const int PTH = PTW == 32 ? 4 : (PTW == 4 ? 4 : 8);
+    const int IMGS = 128 / (PTW * PTH);
+    const int64_t tiles = (int64_t)((d.Wout + PTW - 1) / PTW) * ((d.Hout + PTH - 1) / PTH) * ((nimg + IMGS - 1) / IMGS);
+    const int BM = d.M <= 32 ? 32 : 64;
+    const int64_t blocks = tiles * ((d.M + BM - 1) / BM);
+    const int nch = d.Cin / CI;
+    int splits = 1;
+    if (d.defer_epilogue && (!d.ws || d.ws_floats < (int64_t)d.M * d.N)) return IVLN_E_INVALID;
+    if (d.splits == 0) {
+        // split the channel chunks over blockIdx.z until the grid covers the chip
+        const int64_t want = d.defer_epilogue ? 1024 : 512;
+        if (d.ws && blocks < (d.defer_epilogue ? 512 : 256) && nch >= 2) {
+            splits = (int)((want + blocks - 1) / blocks);
+            if (splits > nch) splits = nch;
+            if (splits > 16) splits = 16;
+            const int64_t cap = d.ws_floats / ((int64_t)d.M * d.N);
+            if (splits > cap) splits = (int)cap;
+            if (splits < 1) splits = 1;
+        }
+    } else {
+        splits = d.splits > nch ? nch : d.splits;
+        if (splits > 1 && (!d.ws || d.ws_floats < (int64_t)splits * d.M * d.N)) return IVLN_E_INVALID;
+    }
+    const int cps = (nch + splits - 1) / splits;
+    splits = (nch + cps - 1) / cps;
+    d.splits = splits;
+    if (KS == 7) launch_ks<7>(d, s, nimg, cps);
+    else launch_ks<3>(d, s, nimg, cps);
+    return IVLN_OK;
+}

@@ -16,37 +16,9 @@
 // * split-K over blockIdx.z for the K-heavy / pixel-starved tail layers (4x4 spatial, K up to 9216):
 //   partial slabs are reduced in a fixed order (deterministic) by k_splitk_epilogue.
 // * Epilogue fused: per-channel scale/shift (folded BatchNorm or bias), residual add, ReLU.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include "../../include/ivln_hip.h"
+#include "gemm_common.h"
 
 namespace {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-enum { AMODE_MK = 0, AMODE_KM = 1, AMODE_NCHW_P = 2 };
-enum { BMODE_CONV = 0, BMODE_CONV1X1 = 1, BMODE_KN = 2, BMODE_NK = 3, BMODE_IM2COL_T = 4, BMODE_CONVT = 5,
-       BMODE_CONV_K3 = 6, BMODE_CONV_K7 = 7 };  // 3x3 / 7x7, dilation 1: (ci,kh,kw) by constant division, no tables
-enum { DMODE_NCHW = 0, DMODE_DENSE = 1 };
-
-constexpr int BK = 16;
-
-__device__ __forceinline__ void epilogue_store(const ivln_gemm_desc& p, int m, int n, float v) {
-    int64_t addr;
-    if (p.dmode == DMODE_NCHW) {
-        int img = n / p.HoWo;
-        int pp = n - img * p.HoWo;
-        addr = ((int64_t)img * p.Ctot + m) * p.HoWo + pp;
-    } else {
-        addr = (int64_t)m * p.sDm + (int64_t)n * p.sDn;
-    }
-    if (p.scale) v = fmaf(v, p.scale[m], p.shift[m]);
-    else if (p.shift) v += p.shift[m];
-    if (p.residual) v += p.residual[addr];
-    if (p.accumulate) v += p.D[addr];
-    if (p.relu) v = fmaxf(v, 0.f);
-    p.D[addr] = v;
-}
 
 template <int WM, int WN, int TM, int TN, int AMODE, int BMODE>
 __global__ __launch_bounds__(256) void k_gemm(const ivln_gemm_desc p) {
@@ -364,15 +336,30 @@ extern "C" int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream) {
     if (d.dil <= 0) d.dil = 1;
     if (d.Ctot <= 0) d.Ctot = d.M;
     if (d.in_img_stride <= 0) d.in_img_stride = (int64_t)d.Cin * d.Hin * d.Win;
-    // tile shape: channel-starved -> 32x128, pixel-starved -> 128x32; otherwise the largest of
-    // 128x128 / 64x128 / 64x64 that still gives >= 2 blocks per CU (512 blocks)
+    // stride-1 3x3 / 7x7: LDS-staged direct convolution (conv_direct.hip); tile_override 1..5 pins the
+    // implicit GEMM tiles, 6 insists on the direct kernel
+    if (d.tile_override == 0 || d.tile_override == 6) {
+        int rc = ivln_conv_direct_launch(d, s);
+        if (rc == IVLN_OK) {
+            if (d.splits_used) *d.splits_used = d.splits;
+            if (d.splits > 1 && !d.defer_epilogue) {
+                int64_t total = (int64_t)d.M * d.N;
+                hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d);
+            }
+            return hipGetLastError() == hipSuccess ? IVLN_OK : IVLN_E_HIP;
+        }
+        if (rc != IVLN_E_UNSUPPORTED || d.tile_override == 6) return rc;
+    }
+    // tile shape: channel-starved -> 32x128, pixel-starved -> 128x32; otherwise 64x128 when that still
+    // gives >= 2 blocks per CU (512 blocks), else 64x64
     int tile = 0;
     if (d.M <= 32) tile = 1;
     else if (d.N <= 32) tile = 2;
     else {
         auto nblocks = [&](int bm, int bn) { return (int64_t)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn); };
-        if (d.M > 64 && nblocks(128, 128) >= 512) tile = 3;
-        else if (nblocks(64, 128) >= 512) tile = 4;
+        // (the 128x128 register-tiled variant measured slower than 64x128 on every conv / GEMM shape of
+        //  the path - it runs at one block per CU - and is only reachable through tile_override)
+        if (nblocks(64, 128) >= 512) tile = 4;
     }
     if (d.tile_override > 0) tile = d.tile_override - 1;
     const int BM = tile == 1 ? 32 : (tile == 2 || tile == 3 ? 128 : 64);

@@ -265,3 +265,69 @@ def test_conv2d_every_block_tile(override, N, Cin, H, W, Cout, k, s, p):
     finally:
         ops.TILE_OVERRIDE = 0
     _close(got, ref, 3e-5)
+
+
+@pytest.mark.parametrize(
+    "N,Cin,H,W,Cout,k,p",
+    [
+        (3, 14, 64, 64, 32, 7, 3),     # 32x4 pixel tile, 32-channel blocks (map CNN layer 1)
+        (2, 32, 32, 32, 64, 7, 3),     # 32x4 tile, 64-channel blocks
+        (5, 64, 16, 16, 128, 7, 3),    # 16x8 tile
+        (5, 128, 8, 8, 128, 7, 3),     # 8x8 tile, two images per block (odd image count -> masked image)
+        (9, 16, 4, 4, 48, 7, 3),       # 4x4 tile, eight images per block
+        (2, 64, 40, 24, 70, 3, 1),     # ragged: tile overhang in both directions, 70 channels
+        (3, 256, 8, 8, 256, 3, 1),
+        (11, 512, 4, 4, 40, 3, 1),
+        (2, 8, 21, 19, 24, 3, 0),      # no padding: output smaller than input
+        (1, 16, 12, 12, 8, 7, 6),      # pad = KS-1 (the input-gradient form of a pad-0 conv)
+    ],
+)
+def test_conv2d_direct_lds_patch_kernel(N, Cin, H, W, Cout, k, p):
+    """conv_direct.hip forced (tile_override 6) against torch CPU fp32 and against the implicit GEMM;
+    tolerance 3e-5 abs on O(1) outputs (only the fp32 summation order differs)."""
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(N * 100 + Cin + k)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    ref0 = F.conv2d(x, w, None, stride=1, padding=p)
+    res = torch.randn_like(ref0)
+    ref = F.relu(ref0 * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) + res)
+    xd, wd = x.to(DEV), w.to(DEV)
+    try:
+        ops.TILE_OVERRIDE = 6
+        got = ops.conv2d(xd, wd, pad=p, scale=sc.to(DEV), shift=sh.to(DEV), residual=res.to(DEV), relu=True)
+        got_nosplit = ops.conv2d(xd, wd, pad=p, splitk=False)
+        # channel slice of a wider destination (concat-free skip connections)
+        wide = torch.zeros(N, Cout + 5, *ref0.shape[2:], device=DEV)
+        ops.conv2d(xd, wd, pad=p, out=wide[:, 3:], out_ctot=Cout + 5)
+        # deferred raw slabs, reduced by the consumer
+        dfr = ops.conv2d(xd, wd, pad=p, defer=True)
+        slabs = dfr.ws[: dfr.splits * Cout * N * ref0.shape[2] * ref0.shape[3]].view(dfr.splits, Cout, N, *ref0.shape[2:]).sum(0)
+        ops.TILE_OVERRIDE = 1
+        gemm = ops.conv2d(xd, wd, pad=p, splitk=False)
+    finally:
+        ops.TILE_OVERRIDE = 0
+    _close(got, ref, 3e-5)
+    _close(got_nosplit, ref0, 3e-5)
+    _close(got_nosplit, gemm, 3e-5)
+    _close(wide[:, 3:3 + Cout], ref0, 3e-5)
+    assert float(wide[:, :3].abs().max()) == 0.0 and float(wide[:, 3 + Cout:].abs().max()) == 0.0
+    _close(slabs.permute(1, 0, 2, 3), ref0, 3e-5)
+
+
+def test_conv2d_direct_refuses_ineligible_shapes():
+    from ivln_ce_amd import ops
+    from ivln_ce_amd._lib import IvlnError
+
+    x = torch.randn(1, 3, 16, 16, device=DEV)   # 3 input channels: not a multiple of the channel chunk
+    w = torch.randn(8, 3, 3, 3, device=DEV)
+    ref = F.conv2d(x.cpu(), w.cpu(), padding=1)
+    _close(ops.conv2d(x, w, pad=1), ref, 2e-5)  # auto: falls through to the implicit GEMM
+    try:
+        ops.TILE_OVERRIDE = 6
+        with pytest.raises(IvlnError):
+            ops.conv2d(x, w, pad=1)
+    finally:
+        ops.TILE_OVERRIDE = 0
