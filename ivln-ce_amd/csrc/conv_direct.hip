@@ -190,6 +190,9 @@ int ivln_conv_direct_launch(ivln_gemm_desc& d, hipStream_t s) {
     const int BM = d.M <= 32 ? 32 : 64;
     const int64_t blocks = tiles * ((d.M + BM - 1) / BM);
     const int nch = d.Cin / CI;
+    // pixel-starved shapes (rollout batch, 4x4 / 8x8 tails): the implicit GEMM splits K far deeper than the
+    // 16 channel-chunk splits available here and measured faster below these grid sizes
+    if (d.tile_override == 0 && blocks < (KS == 7 ? 16 : 96)) return IVLN_E_UNSUPPORTED;
     int splits = 1;
     if (d.defer_epilogue && (!d.ws || d.ws_floats < (int64_t)d.M * d.N)) return IVLN_E_INVALID;
     if (d.splits == 0) {

@@ -411,6 +411,8 @@ __global__ __launch_bounds__(256) void k_embed_lengths(const int64_t* __restrict
 // GEMM for all (b,t).  Gate order i,f,g,o.  out: (B, 2H, L) channel-major, zero for t >= len.
 // Optional saves for BPTT: gates (B,2,L,4H) post-activation, cs (B,2,L,H).
 // ------------------------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 template <int H>
 __global__ __launch_bounds__(4 * H) void k_lstm_bidir(const float* __restrict__ gx_f,
                                                       const float* __restrict__ gx_r,
@@ -429,9 +431,10 @@ __global__ __launch_bounds__(4 * H) void k_lstm_bidir(const float* __restrict__ 
     const float* gx = (dir == 0 ? gx_f : gx_r) + (int64_t)b * L * G;
     const float* whh = (dir == 0 ? whh_f : whh_r) + (int64_t)g * H;
     const float bias = (dir == 0 ? bhh_f : bhh_r)[g];
-    float w[H];
+    // weights as float2 pairs: the matvec issues v_pk_fma_f32 (two fp32 FMAs per lane per instruction)
+    v2f w[H / 2];
 #pragma unroll
-    for (int k = 0; k < H; ++k) w[k] = whh[k];
+    for (int k = 0; k < H / 2; ++k) w[k] = v2f{whh[2 * k], whh[2 * k + 1]};
     if (g < H) {
         hs[g] = 0.f;
         cs[g] = 0.f;
@@ -446,17 +449,19 @@ __global__ __launch_bounds__(4 * H) void k_lstm_bidir(const float* __restrict__ 
         const int t = dir == 0 ? s : len - 1 - s;
         // four independent accumulator chains: a single 128-long dependent fmaf chain (4-cycle latency
         // each) was the critical path of every timestep
-        float a0 = gx_next + bias, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        v2f a0 = v2f{gx_next + bias, 0.f}, a1 = v2f{0.f, 0.f}, a2 = a1, a3 = a1;
         if (s + 1 < len) gx_next = gx[(int64_t)(dir == 0 ? s + 1 : len - 2 - s) * G + g];
 #pragma unroll
-        for (int k = 0; k < H; k += 4) {
-            float4 hv = *reinterpret_cast<const float4*>(&hs[k]);
-            a0 = fmaf(w[k], hv.x, a0);
-            a1 = fmaf(w[k + 1], hv.y, a1);
-            a2 = fmaf(w[k + 2], hv.z, a2);
-            a3 = fmaf(w[k + 3], hv.w, a3);
+        for (int k = 0; k < H; k += 8) {
+            const float4 h0 = *reinterpret_cast<const float4*>(&hs[k]);
+            const float4 h1 = *reinterpret_cast<const float4*>(&hs[k + 4]);
+            a0 = __builtin_elementwise_fma(w[k / 2], v2f{h0.x, h0.y}, a0);
+            a1 = __builtin_elementwise_fma(w[k / 2 + 1], v2f{h0.z, h0.w}, a1);
+            a2 = __builtin_elementwise_fma(w[k / 2 + 2], v2f{h1.x, h1.y}, a2);
+            a3 = __builtin_elementwise_fma(w[k / 2 + 3], v2f{h1.z, h1.w}, a3);
         }
-        const float acc = (a0 + a1) + (a2 + a3);
+        const v2f asum = (a0 + a1) + (a2 + a3);
+        const float acc = asum.x + asum.y;
         const int gate = g / H;
         // sigmoid / tanh through one fast exp each (|err| ~1e-7): tanh(x) = 2*sigmoid(2x) - 1
         float a = gate == 2 ? (2.f / (1.f + __expf(-2.f * acc)) - 1.f) : (1.f / (1.f + __expf(-acc)));
