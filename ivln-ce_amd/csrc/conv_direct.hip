@@ -172,6 +172,160 @@ void launch_ks(const ivln_gemm_desc& d, hipStream_t s, int nimg, int cps) {
     else launch_wm<KS, 4, 4, 8>(d, s, nimg, cps);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Direct weight gradient of the same convolutions:
+//   dW[co][ci][kh][kw] = sum over (img,ho,wo) dy[img][co][ho][wo] * x[img][ci][ho+kh-pad][wo+kw-pad]
+// GEMM view: M = co, N = (ci,kh,kw), K = output pixels.  A block owns BM channels x 128 columns n and walks
+// pixel tiles (IMGS x PTH x PTW = 128 pixels, the K extent of one iteration):
+//   * dy tile staged pixel-major in LDS, x patch of the <= NCI input channels its 128 columns touch staged
+//     once per pixel tile (each x element feeds up to KS*KS columns);
+//   * the two k slots of the MFMA take two horizontally adjacent pixels, so again both operand fetches are
+//     ds_read with a loop-invariant per-lane base ((ci,kh,kw) of the lane's column) + immediate (pixel).
+// Pixel tiles are split over blockIdx.z (hundreds of splits: M x N is tiny, K is millions of pixels);
+// slabs are reduced in fixed order by k_splitk_epilogue.
+// ------------------------------------------------------------------------------------------------
+template <int KS, int PTW, int PTH, int IMGS, int WM>
+__global__ __launch_bounds__(256) void k_wgrad_direct(const ivln_gemm_desc p, int tiles_w, int tiles_h, int nimg,
+                                                      int ntiles, int tiles_per_split) {
+    constexpr int KK = KS * KS;
+    constexpr int WN = 4 / WM, TN = WM == 2 ? 2 : 1;
+    constexpr int BM = 32 * WM, BN = 32 * WN * TN;
+    constexpr int NPX = IMGS * PTH * PTW;
+    static_assert(NPX == 128 && BN == 128, "128 pixels per tile, 128 columns per block");
+    constexpr int NCI = (BN + KK - 2) / KK + 1;  // input channels a 128-column tile can touch
+    constexpr int PH = PTH + KS - 1, PW = PTW + KS - 1, PLANE = PH * PW;
+    constexpr int PATCH = IMGS * NCI * PLANE;
+    constexpr int LDA = BM + 1;
+    constexpr int NA = BM * NPX / 256, NP = (PATCH + 255) / 256;
+    constexpr int NQ = NPX / 2;
+    __shared__ float Ds[NPX * LDA];
+    __shared__ float Ps[PATCH];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wm = wave / WN, wn = wave % WN;
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    const int c_lo = n0 / KK;
+    const int HW = p.Hin * p.Win;
+    const int t_beg = blockIdx.z * tiles_per_split;
+    const int t_end = min(ntiles, t_beg + tiles_per_split);
+
+    float ra[NA], rp[NP];
+    auto load_tile = [&](int tile) {
+        const int tw = tile % tiles_w, th = (tile / tiles_w) % tiles_h, ig = tile / (tiles_w * tiles_h);
+        const int img0 = ig * IMGS, ho0 = th * PTH, wo0 = tw * PTW;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int idx = t + i * 256;  // (co, pixel): pixel fastest -> coalesced rows of dy
+            const int co = idx / NPX, px = idx - co * NPX;
+            const int il = px / (PTH * PTW), ph = (px / PTW) % PTH, pw = px % PTW;
+            const int img = img0 + il, ho = ho0 + ph, wo = wo0 + pw;
+            const bool ok = m0 + co < p.M && img < nimg && ho < p.Hout && wo < p.Wout;
+            const float v = p.A[ok ? ((int64_t)img * p.M + m0 + co) * p.HoWo + ho * p.Wout + wo : 0];
+            ra[i] = ok ? v : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int idx = t + i * 256;
+            const int il = idx / (NCI * PLANE), rem = idx - il * (NCI * PLANE);
+            const int cl = rem / PLANE, rem2 = rem - cl * PLANE;
+            const int y = rem2 / PW, x = rem2 - y * PW;
+            const int img = img0 + il, ci = c_lo + cl, hi = ho0 - p.pad + y, wi = wo0 - p.pad + x;
+            const bool ok = idx < PATCH && img < nimg && ci < p.Cin && (unsigned)hi < (unsigned)p.Hin &&
+                            (unsigned)wi < (unsigned)p.Win;
+            const float v = p.B[ok ? (int64_t)img * p.in_img_stride + (int64_t)ci * HW + hi * p.Win + wi : 0];
+            rp[i] = ok ? v : 0.f;
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int idx = t + i * 256;
+            const int co = idx / NPX, px = idx - co * NPX;
+            Ds[px * LDA + co] = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int idx = t + i * 256;
+            if (idx < PATCH) Ps[idx] = rp[i];
+        }
+    };
+
+    // per-lane operand bases: k slot (lane half) = the odd pixel of a horizontal pair
+    const int abase = half * LDA + wm * 32 + l31;
+    int bbase[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        int n = n0 + (wn * TN + tn) * 32 + l31;
+        if (n >= p.N) n = p.N - 1;  // masked at the store; keeps the LDS address in range
+        const int ci = n / KK, r = n - ci * KK, kh = r / KS, kw = r - kh * KS;
+        bbase[tn] = (ci - c_lo) * PLANE + kh * PW + kw + half;
+    }
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[tn][i] = 0.f;
+
+    if (t_beg < t_end) {
+        load_tile(t_beg);
+        for (int tile = t_beg; tile < t_end; ++tile) {
+            stage();
+            __syncthreads();
+            if (tile + 1 < t_end) load_tile(tile + 1);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int px = 2 * q;  // even pixel of the pair; the odd one is +1 in the same row
+                const int il = px / (PTH * PTW), ph = (px / PTW) % PTH, pw = px % PTW;
+                const float a = Ds[abase + px * LDA];
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const float b = Ps[bbase[tn] + il * NCI * PLANE + ph * PW + pw];
+                    acc[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[tn], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int n = n0 + (wn * TN + tn) * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (m < p.M && n < p.N) {
+                if (p.splits > 1) p.ws[((int64_t)blockIdx.z * p.M + m) * p.N + n] = acc[tn][r];
+                else epilogue_store(p, m, n, acc[tn][r]);
+            }
+        }
+    }
+}
+
+template <int KS, int PTW, int PTH, int IMGS>
+void launch_wgrad_wm(const ivln_gemm_desc& d, hipStream_t s, int nimg, int ntiles, int tps) {
+    const int tiles_w = (d.Wout + PTW - 1) / PTW, tiles_h = (d.Hout + PTH - 1) / PTH;
+    if (d.M <= 32) {
+        dim3 grid((d.N + 127) / 128, (d.M + 31) / 32, d.splits);
+        hipLaunchKernelGGL((k_wgrad_direct<KS, PTW, PTH, IMGS, 1>), grid, dim3(256), 0, s, d, tiles_w, tiles_h, nimg,
+                           ntiles, tps);
+    } else {
+        dim3 grid((d.N + 127) / 128, (d.M + 63) / 64, d.splits);
+        hipLaunchKernelGGL((k_wgrad_direct<KS, PTW, PTH, IMGS, 2>), grid, dim3(256), 0, s, d, tiles_w, tiles_h, nimg,
+                           ntiles, tps);
+    }
+}
+
+template <int KS>
+void launch_wgrad_ks(const ivln_gemm_desc& d, hipStream_t s, int nimg, int ntiles, int tps) {
+    if (d.Wout > 16) launch_wgrad_wm<KS, 32, 4, 1>(d, s, nimg, ntiles, tps);
+    else if (d.Wout > 8) launch_wgrad_wm<KS, 16, 8, 1>(d, s, nimg, ntiles, tps);
+    else if (d.Wout > 4) launch_wgrad_wm<KS, 8, 8, 2>(d, s, nimg, ntiles, tps);
+    else launch_wgrad_wm<KS, 4, 4, 8>(d, s, nimg, ntiles, tps);
+}
+
 }  // namespace
 
 int ivln_conv_direct_launch(ivln_gemm_desc& d, hipStream_t s) {
@@ -215,5 +369,44 @@ int ivln_conv_direct_launch(ivln_gemm_desc& d, hipStream_t s) {
     d.splits = splits;
     if (KS == 7) launch_ks<7>(d, s, nimg, cps);
     else launch_ks<3>(d, s, nimg, cps);
+    return IVLN_OK;
+}
+
+int ivln_wgrad_direct_launch(ivln_gemm_desc& d, hipStream_t s) {
+    static const bool disabled = getenv("IVLN_NO_DIRECT_CONV") != nullptr;
+    if (disabled || d.amode != AMODE_NCHW_P || d.bmode != BMODE_IM2COL_T || d.stride != 1 || d.dil != 1 ||
+        d.Cin <= 0 || d.N % d.Cin != 0 || d.defer_epilogue)
+        return IVLN_E_UNSUPPORTED;
+    const int KK = d.N / d.Cin;
+    const int KS = KK == 49 ? 7 : (KK == 9 ? 3 : 0);
+    if (KS == 0 || d.HoWo != d.Hout * d.Wout || d.K % d.HoWo != 0) return IVLN_E_UNSUPPORTED;
+    // the kernel reads x[ho + kh - pad]: only the same-geometry case the forward conv produced
+    if (d.Hout != d.Hin + 2 * d.pad - KS + 1 || d.Wout != d.Win + 2 * d.pad - KS + 1) return IVLN_E_UNSUPPORTED;
+    const int nimg = d.K / d.HoWo;
+    const int PTW = d.Wout > 16 ? 32 : (d.Wout > 8 ? 16 : (d.Wout > 4 ? 8 : 4));
+    const int PTH = PTW == 32 ? 4 : (PTW == 4 ? 4 : 8);
+    const int IMGS = 128 / (PTW * PTH);
+    const int ntiles = ((d.Wout + PTW - 1) / PTW) * ((d.Hout + PTH - 1) / PTH) * ((nimg + IMGS - 1) / IMGS);
+    const int BM = d.M <= 32 ? 32 : 64;
+    const int64_t blocks = (int64_t)((d.N + 127) / 128) * ((d.M + BM - 1) / BM);
+    int splits = 1;
+    if (d.splits == 0) {
+        if (d.ws && ntiles >= 2) {
+            splits = (int)((1024 + blocks - 1) / blocks);  // ~4 blocks per CU
+            if (splits > ntiles) splits = ntiles;
+            if (splits > 512) splits = 512;
+            const int64_t cap = d.ws_floats / ((int64_t)d.M * d.N);
+            if (splits > cap) splits = (int)cap;
+            if (splits < 1) splits = 1;
+        }
+    } else {
+        splits = d.splits > ntiles ? ntiles : d.splits;
+        if (splits > 1 && (!d.ws || d.ws_floats < (int64_t)splits * d.M * d.N)) return IVLN_E_INVALID;
+    }
+    const int tps = (ntiles + splits - 1) / splits;
+    splits = (ntiles + tps - 1) / tps;
+    d.splits = splits;
+    if (KS == 7) launch_wgrad_ks<7>(d, s, nimg, ntiles, tps);
+    else launch_wgrad_ks<3>(d, s, nimg, ntiles, tps);
     return IVLN_OK;
 }

@@ -37,3 +37,5 @@ __device__ __forceinline__ void epilogue_store(const ivln_gemm_desc& p, int m, i
 // conv_direct.hip: stride-1 3x3 / 7x7 convolution with the input patch and a weight slice staged in LDS.
 // Returns IVLN_E_UNSUPPORTED when the shape is not eligible (the caller then uses the implicit GEMM).
 int ivln_conv_direct_launch(ivln_gemm_desc& d, hipStream_t s);
+// same file: direct weight gradient (A = dy NCHW, B = x gathered) of those convolutions
+int ivln_wgrad_direct_launch(ivln_gemm_desc& d, hipStream_t s);

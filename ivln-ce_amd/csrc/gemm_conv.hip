@@ -340,6 +340,7 @@ extern "C" int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream) {
     // implicit GEMM tiles, 6 insists on the direct kernel
     if (d.tile_override == 0 || d.tile_override == 6) {
         int rc = ivln_conv_direct_launch(d, s);
+        if (rc == IVLN_E_UNSUPPORTED) rc = ivln_wgrad_direct_launch(d, s);
         if (rc == IVLN_OK) {
             if (d.splits_used) *d.splits_used = d.splits;
             if (d.splits > 1 && !d.defer_epilogue) {

@@ -331,3 +331,40 @@ def test_conv2d_direct_refuses_ineligible_shapes():
             ops.conv2d(x, w, pad=1)
     finally:
         ops.TILE_OVERRIDE = 0
+
+
+@pytest.mark.parametrize(
+    "N,Cin,H,W,Cout,k,p",
+    [
+        (5, 14, 64, 64, 32, 7, 3),     # map CNN layer 1 (686 columns: ragged last column tile)
+        (4, 32, 32, 32, 64, 7, 3),
+        (6, 64, 16, 16, 128, 7, 3),
+        (7, 128, 8, 8, 128, 7, 3),     # two images per pixel tile, odd image count
+        (9, 16, 4, 4, 48, 7, 3),
+        (3, 64, 40, 24, 70, 3, 1),     # ragged spatial tile, 70 channels
+        (10, 256, 4, 4, 40, 3, 1),
+        (2, 8, 21, 19, 24, 3, 0),      # no padding
+        (2, 6, 12, 12, 8, 7, 6),       # pad = KS-1
+    ],
+)
+def test_conv2d_weight_gradient_direct_kernel(N, Cin, H, W, Cout, k, p):
+    """k_wgrad_direct (forced, tile_override 6) against torch CPU autograd and the implicit GEMM path;
+    sums run over N*Ho*Wo pixels: tolerance 2e-4 relative to the gradient's max magnitude."""
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(N * 10 + Cin + k)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g, requires_grad=True)
+    y = F.conv2d(x, w, None, stride=1, padding=p)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    try:
+        ops.TILE_OVERRIDE = 6
+        got = ops.conv2d_bwd_weight(dy.to(DEV), x.to(DEV), k, k, stride=1, pad=p)
+        ops.TILE_OVERRIDE = 1
+        gemm = ops.conv2d_bwd_weight(dy.to(DEV), x.to(DEV), k, k, stride=1, pad=p)
+    finally:
+        ops.TILE_OVERRIDE = 0
+    scale = w.grad.abs().max().item()
+    _close(got / scale, w.grad / scale, 2e-5, rtol=2e-4)
+    _close(got / scale, gemm / scale, 2e-5, rtol=2e-4)
