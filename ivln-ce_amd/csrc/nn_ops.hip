@@ -543,12 +543,13 @@ __global__ __launch_bounds__(256) void k_linear_skinny(const float* __restrict__
 
 // ------------------------------------------------------------------------------------------
 // Masked GRU step (habitat-lab RNNStateEncoder single_forward / one step of seq_forward wrapping
-// nn.GRU; call sites models/map_cma_policy.py:314-318,346-353).  One block per hidden unit j, the 4
-// waves split K of the six weight rows W_ih[{r,z,n}][j], W_hh[{r,z,n}][j]:
+// nn.GRU; call sites models/map_cma_policy.py:314-318,346-353).  One block per hidden unit j; the six
+// weight rows W_ih[{r,z,n}][j], W_hh[{r,z,n}][j] are dotted with 8 (or 4) rows at a time:
 //   gi = W_ih x + b_ih  (or precomputed gi when x == nullptr);  gh = W_hh (h*mask) + b_hh
 //   r = s(gi_r+gh_r)  z = s(gi_z+gh_z)  n = tanh(gi_n + r*gh_n)  h' = (1-z)*n + z*h
-// rows processed 8 at a time.  Optional saves for BPTT: (rows, H) each of r, z, n, gh_n.
+// Optional saves for BPTT: (rows, H) each of r, z, n, gh_n.
 // ------------------------------------------------------------------------------------------
+template <int LPR>
 __global__ __launch_bounds__(256) void k_gru_step(const float* __restrict__ x, int64_t ldx, int I,
                                                   const float* __restrict__ gi_pre, int64_t ldgi,
                                                   const float* __restrict__ h_in, int64_t ldh,
@@ -559,79 +560,60 @@ __global__ __launch_bounds__(256) void k_gru_step(const float* __restrict__ x, i
                                                   float* __restrict__ h_out2, int64_t ldo2, int rows, int H,
                                                   float* __restrict__ save_r, float* __restrict__ save_z,
                                                   float* __restrict__ save_n, float* __restrict__ save_ghn) {
-    __shared__ float part[4][6][SK_ROWS];
+    // LPR lanes share one row: each lane owns every LPR-th float4 of K, so a (row, unit) needs one
+    // log2(LPR)-step shuffle reduction of 6 values and no LDS / barrier (the previous wave-splits-K form
+    // spent most of its 13 us in 48 full-wave reductions per block)
+    constexpr int RPB = 256 / LPR;  // rows per pass
     const int j = blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int r0 = 0; r0 < rows; r0 += SK_ROWS) {
-        float ai[3][SK_ROWS], ah[3][SK_ROWS];
-#pragma unroll
-        for (int g = 0; g < 3; ++g)
-#pragma unroll
-            for (int r = 0; r < SK_ROWS; ++r) ai[g][r] = ah[g][r] = 0.f;
+    const int l = threadIdx.x % LPR, rr = threadIdx.x / LPR;
+    for (int r0 = 0; r0 < rows; r0 += RPB) {
+        const int row = r0 + rr;
+        const bool row_ok = row < rows;
+        const int rowc = row_ok ? row : 0;
+        float ai[3] = {0.f, 0.f, 0.f}, ah[3] = {0.f, 0.f, 0.f};
         if (x) {
-            for (int k = threadIdx.x * 4; k < I; k += 1024) {
-                float4 wv[3];
+            const float* xr = x + (int64_t)rowc * ldx;
+            for (int k = l * 4; k < I; k += LPR * 4) {
+                const float4 xv = *reinterpret_cast<const float4*>(xr + k);
 #pragma unroll
-                for (int g = 0; g < 3; ++g)
-                    wv[g] = *reinterpret_cast<const float4*>(w_ih + ((int64_t)g * H + j) * I + k);
-#pragma unroll
-                for (int r = 0; r < SK_ROWS; ++r) {
-                    if (r0 + r < rows) {
-                        float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)(r0 + r) * ldx + k);
-#pragma unroll
-                        for (int g = 0; g < 3; ++g) {
-                            ai[g][r] = fmaf(wv[g].x, xv.x, ai[g][r]);
-                            ai[g][r] = fmaf(wv[g].y, xv.y, ai[g][r]);
-                            ai[g][r] = fmaf(wv[g].z, xv.z, ai[g][r]);
-                            ai[g][r] = fmaf(wv[g].w, xv.w, ai[g][r]);
-                        }
-                    }
+                for (int g = 0; g < 3; ++g) {
+                    const float4 wv = *reinterpret_cast<const float4*>(w_ih + ((int64_t)g * H + j) * I + k);
+                    ai[g] = fmaf(wv.x, xv.x, ai[g]);
+                    ai[g] = fmaf(wv.y, xv.y, ai[g]);
+                    ai[g] = fmaf(wv.z, xv.z, ai[g]);
+                    ai[g] = fmaf(wv.w, xv.w, ai[g]);
                 }
             }
         }
-        for (int k = threadIdx.x * 4; k < H; k += 1024) {
-            float4 wv[3];
+        const float mk = mask ? (mask[rowc] ? 1.f : 0.f) : 1.f;
+        const float* hr = h_in + (int64_t)rowc * ldh;
+        for (int k = l * 4; k < H; k += LPR * 4) {
+            float4 hv = *reinterpret_cast<const float4*>(hr + k);
+            hv.x *= mk, hv.y *= mk, hv.z *= mk, hv.w *= mk;
 #pragma unroll
-            for (int g = 0; g < 3; ++g) wv[g] = *reinterpret_cast<const float4*>(w_hh + ((int64_t)g * H + j) * H + k);
-#pragma unroll
-            for (int r = 0; r < SK_ROWS; ++r) {
-                if (r0 + r < rows) {
-                    float mk = mask ? (mask[r0 + r] ? 1.f : 0.f) : 1.f;
-                    float4 hv = *reinterpret_cast<const float4*>(h_in + (int64_t)(r0 + r) * ldh + k);
-#pragma unroll
-                    for (int g = 0; g < 3; ++g) {
-                        ah[g][r] = fmaf(wv[g].x, hv.x * mk, ah[g][r]);
-                        ah[g][r] = fmaf(wv[g].y, hv.y * mk, ah[g][r]);
-                        ah[g][r] = fmaf(wv[g].z, hv.z * mk, ah[g][r]);
-                        ah[g][r] = fmaf(wv[g].w, hv.w * mk, ah[g][r]);
-                    }
-                }
+            for (int g = 0; g < 3; ++g) {
+                const float4 wv = *reinterpret_cast<const float4*>(w_hh + ((int64_t)g * H + j) * H + k);
+                ah[g] = fmaf(wv.x, hv.x, ah[g]);
+                ah[g] = fmaf(wv.y, hv.y, ah[g]);
+                ah[g] = fmaf(wv.z, hv.z, ah[g]);
+                ah[g] = fmaf(wv.w, hv.w, ah[g]);
             }
         }
 #pragma unroll
-        for (int g = 0; g < 3; ++g)
+        for (int off = LPR / 2; off > 0; off >>= 1) {
 #pragma unroll
-            for (int r = 0; r < SK_ROWS; ++r) {
-                float vi = wave_sum(ai[g][r]);
-                float vh = wave_sum(ah[g][r]);
-                if (lane == 0) {
-                    part[wave][g][r] = vi;
-                    part[wave][3 + g][r] = vh;
-                }
+            for (int g = 0; g < 3; ++g) {
+                if (x) ai[g] += __shfl_xor(ai[g], off, 64);
+                ah[g] += __shfl_xor(ah[g], off, 64);
             }
-        __syncthreads();
-        if (threadIdx.x < SK_ROWS && r0 + (int)threadIdx.x < rows) {
-            const int r = threadIdx.x, row = r0 + r;
+        }
+        if (l == 0 && row_ok) {
             float gi[3], gh[3];
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
-                gi[g] = (part[0][g][r] + part[1][g][r]) + (part[2][g][r] + part[3][g][r]);
-                gh[g] = (part[0][3 + g][r] + part[1][3 + g][r]) + (part[2][3 + g][r] + part[3][3 + g][r]);
-                if (x) gi[g] += b_ih[g * H + j];
-                else gi[g] = gi_pre[(int64_t)row * ldgi + g * H + j];
-                gh[g] += b_hh[g * H + j];
+                gi[g] = x ? ai[g] + b_ih[g * H + j] : gi_pre[(int64_t)row * ldgi + g * H + j];
+                gh[g] = ah[g] + b_hh[g * H + j];
             }
-            float mk = mask ? (mask[row] ? 1.f : 0.f) : 1.f;
             float hp = h_in[(int64_t)row * ldh + j] * mk;
             float rg = sigmoidf_(gi[0] + gh[0]);
             float zg = sigmoidf_(gi[1] + gh[1]);
@@ -646,7 +628,6 @@ __global__ __launch_bounds__(256) void k_gru_step(const float* __restrict__ x, i
                 save_ghn[(int64_t)row * H + j] = gh[2];
             }
         }
-        __syncthreads();
     }
 }
 
@@ -958,9 +939,14 @@ int ivln_gru_step_f32(const float* x, int64_t ldx, int I, const float* gi_pre, i
                       const float* b_hh, float* h_out, int64_t ldo, float* h_out2, int64_t ldo2, int rows, int H,
                       float* save_r, float* save_z, float* save_n, float* save_ghn, void* stream) {
     if (rows <= 0 || (H & 3) || (x && (I & 3)) || (ldh & 3) || (x && (ldx & 3))) return IVLN_E_INVALID;
-    hipLaunchKernelGGL(k_gru_step, dim3(H), dim3(256), 0, (hipStream_t)stream, x, ldx, I, gi_pre, ldgi,
-                       h_in, ldh, mask, w_ih, w_hh, b_ih, b_hh, h_out, ldo, h_out2, ldo2, rows, H, save_r, save_z,
-                       save_n, save_ghn);
+    if (rows <= 4)
+        hipLaunchKernelGGL(k_gru_step<64>, dim3(H), dim3(256), 0, (hipStream_t)stream, x, ldx, I, gi_pre, ldgi,
+                           h_in, ldh, mask, w_ih, w_hh, b_ih, b_hh, h_out, ldo, h_out2, ldo2, rows, H, save_r, save_z,
+                           save_n, save_ghn);
+    else
+        hipLaunchKernelGGL(k_gru_step<32>, dim3(H), dim3(256), 0, (hipStream_t)stream, x, ldx, I, gi_pre, ldgi,
+                           h_in, ldh, mask, w_ih, w_hh, b_ih, b_hh, h_out, ldo, h_out2, ldo2, rows, H, save_r, save_z,
+                           save_n, save_ghn);
     return LAUNCH_OK();
 }
 

@@ -217,41 +217,37 @@ __global__ __launch_bounds__(256) void k_gru_bwd_elem(const float* __restrict__ 
 }
 
 // y[r][o] = (W[o].x[r] + add[r][o]) * (rowmask[r] ? 1 : 0)   (skinny rows; see k_linear_skinny)
+// One block per output o, 32 lanes per row (8 rows per pass): each lane owns every 32nd float4 of K and a
+// (row, o) costs one 5-step shuffle reduction - no LDS, no barrier.
 __global__ __launch_bounds__(256) void k_linear_skinny_ex(const float* __restrict__ x, int64_t ldx,
                                                           const float* __restrict__ W,
                                                           const float* __restrict__ add, int64_t ld_add,
                                                           const uint8_t* __restrict__ rowmask,
                                                           float* __restrict__ y, int64_t ldy, int rows, int K,
                                                           int O) {
-    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (o >= O) return;
+    const int o = blockIdx.x;
+    const int l = threadIdx.x & 31, rr = threadIdx.x >> 5;
     const float* wr = W + (int64_t)o * K;
     for (int r0 = 0; r0 < rows; r0 += 8) {
-        float acc[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) acc[r] = 0.f;
-        for (int k = lane * 4; k < K; k += 256) {
-            float4 wv = *reinterpret_cast<const float4*>(wr + k);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                if (r0 + r < rows) {
-                    float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)(r0 + r) * ldx + k);
-                    acc[r] = fmaf(wv.x, xv.x, acc[r]);
-                    acc[r] = fmaf(wv.y, xv.y, acc[r]);
-                    acc[r] = fmaf(wv.z, xv.z, acc[r]);
-                    acc[r] = fmaf(wv.w, xv.w, acc[r]);
-                }
-            }
+        const int row = r0 + rr;
+        const bool row_ok = row < rows;
+        const float* xr = x + (int64_t)(row_ok ? row : 0) * ldx;
+        float a0 = 0.f, a1 = 0.f;
+        for (int k = l * 4; k < K; k += 128) {
+            const float4 wv = *reinterpret_cast<const float4*>(wr + k);
+            const float4 xv = *reinterpret_cast<const float4*>(xr + k);
+            a0 = fmaf(wv.x, xv.x, a0);
+            a1 = fmaf(wv.y, xv.y, a1);
+            a0 = fmaf(wv.z, xv.z, a0);
+            a1 = fmaf(wv.w, xv.w, a1);
         }
+        float v = a0 + a1;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            float v = wave_sum(acc[r]);
-            if (lane == 0 && r0 + r < rows) {
-                if (add) v += add[(int64_t)(r0 + r) * ld_add + o];
-                if (rowmask) v = rowmask[r0 + r] ? v : 0.f;
-                y[(int64_t)(r0 + r) * ldy + o] = v;
-            }
+        for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (l == 0 && row_ok) {
+            if (add) v += add[(int64_t)row * ld_add + o];
+            if (rowmask) v = rowmask[row] ? v : 0.f;
+            y[(int64_t)row * ldy + o] = v;
         }
     }
 }
@@ -611,7 +607,7 @@ int ivln_gru_bwd_elem_f32(const float* dout, int64_t ld_dout, const float* dh_ca
 int ivln_linear_skinny_ex_f32(const float* x, int64_t ldx, const float* W, const float* add, int64_t ld_add,
                               const uint8_t* rowmask, float* y, int64_t ldy, int rows, int K, int O, void* stream) {
     if ((K & 3) || (ldx & 3)) return IVLN_E_INVALID;
-    hipLaunchKernelGGL(k_linear_skinny_ex, dim3((O + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, W, add,
+    hipLaunchKernelGGL(k_linear_skinny_ex, dim3(O), dim3(256), 0, (hipStream_t)stream, x, ldx, W, add,
                        ld_add, rowmask, y, ldy, rows, K, O);
     return LAUNCH_OK();
 }
