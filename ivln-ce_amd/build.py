@@ -14,6 +14,7 @@ SOURCES = {
     "mapper.hip": ["-ffp-contract=off"],
     "gemm_conv.hip": [],
     "conv_direct.hip": [],
+    "gemm_vec.hip": [],
     "nn_ops.hip": [],
     "train_ops.hip": [],
     "dtw.cpp": [],

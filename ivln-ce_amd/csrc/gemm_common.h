@@ -39,3 +39,6 @@ __device__ __forceinline__ void epilogue_store(const ivln_gemm_desc& p, int m, i
 int ivln_conv_direct_launch(ivln_gemm_desc& d, hipStream_t s);
 // same file: direct weight gradient (A = dy NCHW, B = x gathered) of those convolutions
 int ivln_wgrad_direct_launch(ivln_gemm_desc& d, hipStream_t s);
+// gemm_vec.hip: float4-staged GEMM for contiguous operand modes (1x1 conv, linear); K tile of 32
+bool ivln_gemm_vec_eligible(const ivln_gemm_desc& d);
+int ivln_gemm_vec_launch(const ivln_gemm_desc& d, hipStream_t s, int tile);

@@ -362,12 +362,17 @@ extern "C" int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream) {
         //  the path - it runs at one block per CU - and is only reachable through tile_override)
         if (nblocks(64, 128) >= 512) tile = 4;
     }
-    if (d.tile_override > 0) tile = d.tile_override - 1;
+    if (d.tile_override > 0 && d.tile_override <= 5) tile = d.tile_override - 1;
+    // contiguous operand modes (1x1 conv, linear): float4-staged kernel with 32-deep K tiles
+    // (gemm_vec.hip); tile_override 7 insists on it, 1..5 pin the scalar-gather kernel
+    const bool vec = (d.tile_override == 0 || d.tile_override == 7) && ivln_gemm_vec_eligible(d);
+    if (d.tile_override == 7 && !vec) return IVLN_E_UNSUPPORTED;
+    const int bk = vec ? 32 : BK;
     const int BM = tile == 1 ? 32 : (tile == 2 || tile == 3 ? 128 : 64);
     const int BN = tile == 1 ? 128 : (tile == 2 ? 32 : (tile == 3 || tile == 4 ? 128 : 64));
     // split-K when the output grid cannot fill the chip and K is deep
     int64_t blocks = (int64_t)((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
-    int nk = (d.K + BK - 1) / BK;
+    int nk = (d.K + bk - 1) / bk;
     int splits = 1;
     if (d.defer_epilogue && (!d.ws || d.ws_floats < (int64_t)d.M * d.N)) return IVLN_E_INVALID;
     if (d.splits == 0) {
@@ -393,7 +398,8 @@ extern "C" int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream) {
     splits = (nk + tps - 1) / tps;
     d.splits = splits;
     int rc;
-    switch (tile) {
+    if (vec) rc = ivln_gemm_vec_launch(d, s, tile);
+    else switch (tile) {
         case 1: rc = launch_tile<1, 4, 1, 1>(d, s); break;
         case 2: rc = launch_tile<4, 1, 1, 1>(d, s); break;
         case 3: rc = launch_tile<2, 2, 2, 2>(d, s); break;

@@ -1,0 +1,262 @@
+// Vector-load fp32 MFMA GEMM for the operand modes whose global layout is contiguous along one GEMM index
+// (1x1 convolutions over NCHW, nn.Linear forward / input-gradient / weight-gradient, Conv1d k=1):
+//
+//   D[m][n] = sum_k A[m][k] B[k][n]     A: [m][k] (k contiguous) or [k][m];  B: [k][n] (n contiguous) or [n][k]
+//
+// against k_gemm (gemm_conv.hip), which stages 16-deep K tiles with one scalar load + address computation
+// per element:
+//   * every global load is a float4 along the operand's contiguous index and goes to LDS as one
+//     ds_write_b128; K tiles are 32 deep (half the barriers, twice the MFMA work per staged tile);
+//   * an operand that is k-contiguous keeps its [row][k] order in LDS (row stride 36 words: conflict-free
+//     b128) and feeds the MFMA with ds_read_b128 - the two k slots of v_mfma_f32_32x32x2_f32 take
+//     k = j and k = 16 + j, so one lane's 16 operand values of a tile are 4 consecutive float4;
+//   * an operand that is row-contiguous is stored [k][row] and read with ds_read_b32 base + immediate.
+//   Either way the MFMA loop has no address arithmetic.
+// Tiles, split-K slabs, the deferred mode and the fused epilogue are those of ivln_gemm_f32.
+#include <stdlib.h>
+
+#include "gemm_common.h"
+
+namespace {
+
+constexpr int BKV = 32;
+enum { LAY_K = 0, LAY_R = 1 };
+
+template <int WM, int WN, int TM, int TN, int ALAY, int BLAY>
+__global__ __launch_bounds__(256) void k_gemm_vec(const ivln_gemm_desc p) {
+    constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
+    constexpr int LDK = BKV + 4;  // [row][k] layout row stride (words)
+    constexpr int A_WORDS = ALAY == LAY_K ? BM * LDK : BKV * BM;
+    constexpr int B_WORDS = BLAY == LAY_K ? BN * LDK : BKV * BN;
+    constexpr int EA = BM * BKV / 1024, EB = BN * BKV / 1024;  // float4 per thread per tile
+    __shared__ __attribute__((aligned(16))) float As[A_WORDS];
+    __shared__ __attribute__((aligned(16))) float Bs[B_WORDS];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int nk = (p.K + BKV - 1) / BKV;
+    const int tps = (nk + p.splits - 1) / p.splits;
+    const int kbeg = blockIdx.z * tps * BKV;
+    const int kend = min(p.K, kbeg + tps * BKV);
+
+    // ---- per-thread staging coordinates (tile-invariant) ----
+    // [row][k] operands: 8 float4 per row, thread -> (row = t/8 + 32 e, kq = t%8)
+    // [k][row] operands: R4 = rows/4 float4 per k, thread -> (k = t/R4 + (256/R4) e, rq = t%R4)
+    constexpr int AR4 = BM / 4, BR4 = BN / 4;
+    int64_t a_off[EA], b_off[EB];
+    bool a_ok[EA], b_ok[EB];
+    int a_k[EA], b_k[EB];  // k offset of the element inside the tile
+#pragma unroll
+    for (int e = 0; e < EA; ++e) {
+        if constexpr (ALAY == LAY_K) {
+            const int m = m0 + (t >> 3) + 32 * e;
+            a_k[e] = (t & 7) * 4;
+            a_ok[e] = m < p.M;
+            a_off[e] = a_ok[e] ? (int64_t)m * p.lda + a_k[e] : 0;
+        } else {
+            const int m = m0 + (t % AR4) * 4;
+            a_k[e] = t / AR4 + (256 / AR4) * e;
+            a_ok[e] = m < p.M;
+            a_off[e] = a_ok[e] ? (int64_t)a_k[e] * p.lda + m : 0;
+        }
+    }
+    const bool bconv = p.bmode == BMODE_CONV1X1;
+    const int64_t brow = bconv ? (int64_t)p.HoWo : p.ldb;  // stride of k for [k][n] operands
+#pragma unroll
+    for (int e = 0; e < EB; ++e) {
+        if constexpr (BLAY == LAY_K) {
+            const int n = n0 + (t >> 3) + 32 * e;
+            b_k[e] = (t & 7) * 4;
+            b_ok[e] = n < p.N;
+            b_off[e] = b_ok[e] ? (int64_t)n * p.ldb + b_k[e] : 0;
+        } else {
+            const int n = n0 + (t % BR4) * 4;
+            b_k[e] = t / BR4 + (256 / BR4) * e;
+            b_ok[e] = n < p.N;
+            int64_t base = 0;
+            if (b_ok[e]) {
+                if (bconv) {
+                    const int img = n / p.HoWo;
+                    base = (int64_t)img * p.in_img_stride + (n - img * p.HoWo);
+                } else {
+                    base = n;
+                }
+            }
+            b_off[e] = base + (int64_t)b_k[e] * brow;
+        }
+    }
+    const int64_t a_kstep = ALAY == LAY_K ? 1 : p.lda;
+    const int64_t b_kstep = BLAY == LAY_K ? 1 : brow;
+
+    float4 ra0[EA], rb0[EB], ra1[EA], rb1[EB];
+    // (component-wise selects: `ok ? v : zero4` on float4 lvalues became a pointer select through scratch)
+    auto load_tile = [&](int k0, float4 (&ra)[EA], float4 (&rb)[EB]) {
+#pragma unroll
+        for (int e = 0; e < EA; ++e) {
+            const bool ok = a_ok[e] && k0 + a_k[e] < kend;
+            const float4 v = *reinterpret_cast<const float4*>(p.A + (ok ? a_off[e] + (int64_t)k0 * a_kstep : 0));
+            ra[e] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+        }
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            const bool ok = b_ok[e] && k0 + b_k[e] < kend;
+            const float4 v = *reinterpret_cast<const float4*>(p.B + (ok ? b_off[e] + (int64_t)k0 * b_kstep : 0));
+            rb[e] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+        }
+    };
+    auto stage = [&](float4 (&ra)[EA], float4 (&rb)[EB]) {
+#pragma unroll
+        for (int e = 0; e < EA; ++e) {
+            if constexpr (ALAY == LAY_K) *reinterpret_cast<float4*>(&As[((t >> 3) + 32 * e) * LDK + (t & 7) * 4]) = ra[e];
+            else *reinterpret_cast<float4*>(&As[(t / AR4 + (256 / AR4) * e) * BM + (t % AR4) * 4]) = ra[e];
+        }
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            if constexpr (BLAY == LAY_K) *reinterpret_cast<float4*>(&Bs[((t >> 3) + 32 * e) * LDK + (t & 7) * 4]) = rb[e];
+            else *reinterpret_cast<float4*>(&Bs[(t / BR4 + (256 / BR4) * e) * BN + (t % BR4) * 4]) = rb[e];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[tm][tn][i] = 0.f;
+
+    // k slot `half` of MFMA step j holds k = 16*half + j
+    auto compute = [&]() {
+        float a[TM][BKV / 2], b[TN][BKV / 2];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int ml = (wm * TM + tm) * 32 + l31;
+            if constexpr (ALAY == LAY_K) {
+#pragma unroll
+                for (int i = 0; i < BKV / 8; ++i) {
+                    const float4 v = *reinterpret_cast<const float4*>(&As[ml * LDK + half * (BKV / 2) + 4 * i]);
+                    a[tm][4 * i] = v.x, a[tm][4 * i + 1] = v.y, a[tm][4 * i + 2] = v.z, a[tm][4 * i + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < BKV / 2; ++j) a[tm][j] = As[(half * (BKV / 2) + j) * BM + ml];
+            }
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int nl = (wn * TN + tn) * 32 + l31;
+            if constexpr (BLAY == LAY_K) {
+#pragma unroll
+                for (int i = 0; i < BKV / 8; ++i) {
+                    const float4 v = *reinterpret_cast<const float4*>(&Bs[nl * LDK + half * (BKV / 2) + 4 * i]);
+                    b[tn][4 * i] = v.x, b[tn][4 * i + 1] = v.y, b[tn][4 * i + 2] = v.z, b[tn][4 * i + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < BKV / 2; ++j) b[tn][j] = Bs[(half * (BKV / 2) + j) * BN + nl];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < BKV / 2; ++j)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][j], b[tn][j], acc[tm][tn], 0, 0, 0);
+    };
+
+    if (kbeg < kend) {
+        load_tile(kbeg, ra0, rb0);
+        load_tile(kbeg + BKV, ra1, rb1);
+        for (int k0 = kbeg; k0 < kend; k0 += 2 * BKV) {
+            stage(ra0, rb0);
+            __syncthreads();
+            load_tile(k0 + 2 * BKV, ra0, rb0);
+            compute();
+            __syncthreads();
+            if (k0 + BKV >= kend) break;
+            stage(ra1, rb1);
+            __syncthreads();
+            load_tile(k0 + 3 * BKV, ra1, rb1);
+            compute();
+            __syncthreads();
+        }
+    }
+
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int n = n0 + (wn * TN + tn) * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m < p.M && n < p.N) {
+                    if (p.splits > 1 || p.defer_epilogue)
+                        p.ws[((int64_t)blockIdx.z * p.M + m) * p.N + n] = acc[tm][tn][r];
+                    else epilogue_store(p, m, n, acc[tm][tn][r]);
+                }
+            }
+        }
+}
+
+template <int WM, int WN, int TM, int TN>
+void launch_vec(const ivln_gemm_desc& d, hipStream_t s, int alay, int blay) {
+    constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
+    dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM, d.splits);
+#define IVLN_VCASE(AL, BL)                                                                          \
+    if (alay == AL && blay == BL) {                                                                 \
+        hipLaunchKernelGGL((k_gemm_vec<WM, WN, TM, TN, AL, BL>), grid, dim3(256), 0, s, d);          \
+        return;                                                                                     \
+    }
+    IVLN_VCASE(LAY_K, LAY_R)
+    IVLN_VCASE(LAY_K, LAY_K)
+    IVLN_VCASE(LAY_R, LAY_R)
+    IVLN_VCASE(LAY_R, LAY_K)
+#undef IVLN_VCASE
+}
+
+inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace
+
+int ivln_gemm_vec_tile_k() { return BKV; }
+
+// Eligible: every float4 the kernel forms must be 16-byte aligned and must not straddle a row / image.
+bool ivln_gemm_vec_eligible(const ivln_gemm_desc& d) {
+    static const bool disabled = getenv("IVLN_NO_VEC_GEMM") != nullptr;
+    if (disabled || !al16(d.A) || !al16(d.B)) return false;
+    if (d.amode == AMODE_MK) {
+        if ((d.K & 3) || (d.lda & 3)) return false;
+    } else if (d.amode == AMODE_KM) {
+        if ((d.M & 3) || (d.lda & 3)) return false;
+    } else {
+        return false;
+    }
+    if (d.bmode == BMODE_CONV1X1) {
+        if (d.stride != 1 || d.pad != 0 || d.Hin * d.Win != d.HoWo || (d.HoWo & 3) || (d.in_img_stride & 3)) return false;
+    } else if (d.bmode == BMODE_KN) {
+        if ((d.N & 3) || (d.ldb & 3)) return false;
+    } else if (d.bmode == BMODE_NK) {
+        if ((d.K & 3) || (d.ldb & 3)) return false;
+    } else {
+        return false;
+    }
+    return true;
+}
+
+// tile: 0 = 64x64, 1 = 32x128, 2 = 128x32, 4 = 64x128 (numbering of ivln_gemm_f32)
+int ivln_gemm_vec_launch(const ivln_gemm_desc& d, hipStream_t s, int tile) {
+    const int alay = d.amode == AMODE_MK ? LAY_K : LAY_R;
+    const int blay = d.bmode == BMODE_NK ? LAY_K : LAY_R;
+    switch (tile) {
+        case 1: launch_vec<1, 4, 1, 1>(d, s, alay, blay); break;
+        case 2: launch_vec<4, 1, 1, 1>(d, s, alay, blay); break;
+        case 4: launch_vec<2, 2, 1, 2>(d, s, alay, blay); break;
+        case 0: launch_vec<2, 2, 1, 1>(d, s, alay, blay); break;
+        default: return IVLN_E_UNSUPPORTED;
+    }
+    return IVLN_OK;
+}

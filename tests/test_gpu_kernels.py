@@ -368,3 +368,72 @@ def test_conv2d_weight_gradient_direct_kernel(N, Cin, H, W, Cout, k, p):
     scale = w.grad.abs().max().item()
     _close(got / scale, w.grad / scale, 2e-5, rtol=2e-4)
     _close(got / scale, gemm / scale, 2e-5, rtol=2e-4)
+
+
+@pytest.mark.parametrize(
+    "rows,K,O",
+    [
+        (640, 256, 512),     # 64x128 tiles
+        (100, 64, 96),       # 64x64 tiles, ragged rows / outputs
+        (4096, 1184, 24),    # O <= 32: 32x128 tiles
+        (24, 3072, 512),     # rows <= 32: 128x32 tiles, deep K (split-K)
+        (333, 36, 260),      # K barely more than one 32-deep tile
+    ],
+)
+def test_vector_load_gemm_all_operand_layouts(rows, K, O):
+    """gemm_vec.hip forced (tile_override 7) on its four operand-layout combinations - linear forward
+    ([m][k] x [n][k]), input gradient ([k][m] x [n][k]), weight gradient ([k][m] x [k][n]) and the 1x1
+    convolution ([m][k] x [k][n]) - against torch CPU fp32; tolerance 3e-5 on O(1) results."""
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(rows + K + O)
+    x = torch.randn(rows, K, generator=g)
+    w = torch.randn(O, K, generator=g) / K ** 0.5
+    b = torch.randn(O, generator=g)
+    dy = torch.randn(rows, O, generator=g) / O ** 0.5
+    try:
+        ops.TILE_OVERRIDE = 7
+        y = ops.linear_gemm(x.to(DEV), w.to(DEV), b.to(DEV), relu=True)
+        dx = ops.linear_bwd_input(dy.to(DEV), w.to(DEV))
+        dw = ops.linear_bwd_weight((dy / rows ** 0.5).to(DEV), x.to(DEV))
+    finally:
+        ops.TILE_OVERRIDE = 0
+    _close(y, F.relu(x @ w.t() + b), 3e-5)
+    _close(dx, dy @ w, 3e-5)
+    _close(dw, (dy / rows ** 0.5).t() @ x, 3e-5)
+
+
+@pytest.mark.parametrize("N,Cin,H,W,Cout", [(3, 128, 32, 32, 64), (8, 64, 64, 64, 256), (2, 256, 4, 4, 1024),
+                                            (4, 1024, 4, 4, 128), (5, 48, 6, 10, 20)])
+def test_vector_load_gemm_conv1x1(N, Cin, H, W, Cout):
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(N + Cin + Cout)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    ref0 = F.conv2d(x, w)
+    res = torch.randn_like(ref0)
+    try:
+        ops.TILE_OVERRIDE = 7
+        got = ops.conv2d(x.to(DEV), w.to(DEV), scale=sc.to(DEV), shift=sh.to(DEV), residual=res.to(DEV), relu=True)
+        dfr = ops.conv2d(x.to(DEV), w.to(DEV), defer=True)
+    finally:
+        ops.TILE_OVERRIDE = 0
+    _close(got, F.relu(ref0 * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) + res), 3e-5)
+    slabs = dfr.ws[: dfr.splits * Cout * N * H * W].view(dfr.splits, Cout, N, H, W).sum(0)
+    _close(slabs.permute(1, 0, 2, 3), ref0, 3e-5)
+
+
+def test_vector_load_gemm_refuses_unaligned_shapes():
+    from ivln_ce_amd import ops
+    from ivln_ce_amd._lib import IvlnError
+
+    x, w = torch.randn(40, 50, device=DEV), torch.randn(12, 50, device=DEV)  # K = 50: rows not 16-byte multiples
+    _close(ops.linear_gemm(x, w), x.cpu() @ w.cpu().t(), 3e-5)  # auto: scalar-gather kernel
+    try:
+        ops.TILE_OVERRIDE = 7
+        with pytest.raises(IvlnError):
+            ops.linear_gemm(x, w)
+    finally:
+        ops.TILE_OVERRIDE = 0
