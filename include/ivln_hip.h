@@ -92,7 +92,10 @@ enum { IVLN_B_CONV = 0,    /* im2col gather from NCHW via koff/kpos tables      
        IVLN_B_CONV_K3 = 6, /* 3x3, dilation 1: tap indices by constant division, no tables */
        IVLN_B_CONV_K7 = 7  /* 7x7, dilation 1                                            */ };
 enum { IVLN_D_NCHW = 0,    /* D[(img*Ctot + m)*HoWo + pp], n = img*HoWo + pp          */
-       IVLN_D_DENSE = 1    /* D[m*sDm + n*sDn]                                        */ };
+       IVLN_D_DENSE = 1,   /* D[m*sDm + n*sDn]                                        */
+       IVLN_D_NCHW_UP2 = 2 /* one output-parity class of a stride-2 transposed conv: pixel (ho,wo) of the
+                              (Hout x Wout) class grid lands at (2*ho + sDm, 2*wo + sDn) of a
+                              (2*Hout x 2*Wout) NCHW destination (sDm, sDn in {0,1} = row/col parity) */ };
 
 typedef struct ivln_gemm_desc {
     const float* A;

@@ -346,7 +346,7 @@ int ivln_conv_direct_launch(ivln_gemm_desc& d, hipStream_t s) {
     const int nch = d.Cin / CI;
     // pixel-starved shapes (rollout batch, 4x4 / 8x8 tails): the implicit GEMM splits K far deeper than the
     // 16 channel-chunk splits available here and measured faster below these grid sizes
-    if (d.tile_override == 0 && blocks < (KS == 7 ? 16 : 96)) return IVLN_E_UNSUPPORTED;
+    if (d.tile_override == 0 && (KS == 7 ? blocks < 16 : blocks * (nch < 16 ? nch : 16) < 128)) return IVLN_E_UNSUPPORTED;
     int splits = 1;
     if (d.defer_epilogue && (!d.ws || d.ws_floats < (int64_t)d.M * d.N)) return IVLN_E_INVALID;
     if (d.splits == 0) {

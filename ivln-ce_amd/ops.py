@@ -37,7 +37,7 @@ class GemmDesc(C.Structure):
 
 A_MK, A_KM, A_NCHW_P = 0, 1, 2
 B_CONV, B_CONV1X1, B_KN, B_NK, B_IM2COL_T, B_CONVT, B_CONV_K3, B_CONV_K7 = 0, 1, 2, 3, 4, 5, 6, 7
-D_NCHW, D_DENSE = 0, 1
+D_NCHW, D_DENSE, D_NCHW_UP2 = 0, 1, 2
 
 _sigs_done = False
 
@@ -202,6 +202,60 @@ def conv_transpose2d(x, w_oihw, stride, pad, out_pad, scale=None, shift=None, re
     ws = splitk_ws(x.device)
     d.ws, d.ws_floats, d.splits = dptr(ws), ws.numel(), 0
     gemm(d)
+    return out
+
+
+def convt_s2_classes(w_t, pad):
+    """Split a stride-2 ConvTranspose2d weight (Cin,Cout,k,k) into its four output-parity classes.
+    Output row oh = 2i + a only receives taps kh = a + pad - 2*dh (dh = input row offset, ih = i + dh), so
+    each class is an ordinary correlation with a (1|2)x(1|2) kernel over the un-dilated input: 4x fewer
+    MACs than gathering all k*k taps per output pixel (3 of 4 are structurally zero).
+    Returns [(a, b, w_sub (Cout,Cin,ta,tb))] or None when a class would need a negative offset."""
+    Cin, Cout, KH, KW = w_t.shape
+    out = []
+    for a in (0, 1):
+        khs = [(dh, a + pad - 2 * dh) for dh in range(0, KH) if 0 <= a + pad - 2 * dh < KH]
+        neg = [dh for dh in range(-KH, 0) if 0 <= a + pad - 2 * dh < KH]
+        for b in (0, 1):
+            kws = [(dw, b + pad - 2 * dw) for dw in range(0, KW) if 0 <= b + pad - 2 * dw < KW]
+            negw = [dw for dw in range(-KW, 0) if 0 <= b + pad - 2 * dw < KW]
+            if neg or negw or not khs or not kws or [d for d, _ in khs] != list(range(len(khs))) or \
+                    [d for d, _ in kws] != list(range(len(kws))):
+                return None
+            sub = w_t[:, :, [k for _, k in khs]][:, :, :, [k for _, k in kws]]  # (Cin,Cout,ta,tb)
+            out.append((a, b, sub.permute(1, 0, 2, 3).contiguous()))
+    return out
+
+
+def conv_transpose2d_s2(x, classes, scale=None, shift=None, residual=None, relu=False, out=None):
+    """nn.ConvTranspose2d(stride=2) whose output is exactly (2H, 2W) (k=3,p=1,op=1 / k=2,p=0): one implicit
+    GEMM per output-parity class from convt_s2_classes, each writing its interleaved quarter of the
+    NCHW destination with the fused epilogue (rednet.py:210-216,262-279 upsampling blocks)."""
+    N, Cin, H, W = x.shape
+    Cout = classes[0][2].shape[0]
+    if out is None:
+        out = torch.empty((N, Cout, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+    ws = splitk_ws(x.device)
+    for a, b, w in classes:
+        ta, tb = w.shape[2], w.shape[3]
+        d = GemmDesc()
+        d.A, d.B, d.D = dptr(w), dptr(x), dptr(out)
+        d.M, d.N, d.K = Cout, N * H * W, Cin * ta * tb
+        d.amode, d.dmode = A_MK, D_NCHW_UP2
+        d.lda = d.K
+        d.Cin, d.Hin, d.Win, d.Hout, d.Wout = Cin, H, W, H, W
+        d.stride, d.pad, d.dil = 1, 0, 1
+        d.HoWo = H * W
+        d.sDm, d.sDn = a, b
+        if ta == 1 and tb == 1:
+            d.bmode = B_CONV1X1
+        else:  # taps at input offsets (0..ta-1, 0..tb-1); rows/cols past the edge read as zero
+            d.bmode = B_CONV
+            koff, kpos = conv_tables(Cin, ta, tb, H, W, 1, x.device)
+            d.koff, d.kpos = dptr(koff), dptr(kpos)
+        _epilogue(d, scale, shift, residual, relu)
+        d.ws, d.ws_floats, d.splits = dptr(ws), ws.numel(), 0
+        gemm(d)
     return out
 
 

@@ -35,11 +35,29 @@ class _Folded:
             self.c[k] = (scale, shift)
         return self.c[k]
 
+    def classes(self, convt: nn.ConvTranspose2d):
+        """Output-parity decomposition of a stride-2 transposed conv (None when not applicable)."""
+        k = ("cls", id(convt))
+        if k not in self.c:
+            ok = convt.stride == (2, 2) and convt.kernel_size[0] == convt.kernel_size[1] and \
+                2 - 2 * convt.padding[0] + convt.kernel_size[0] - 2 + convt.output_padding[0] == 2
+            self.c[k] = ops.convt_s2_classes(convt.weight.detach(), convt.padding[0]) if ok else None
+        return self.c[k]
+
     def wt(self, convt: nn.ConvTranspose2d):
         k = id(convt)
         if k not in self.c:
             self.c[k] = convt.weight.detach().permute(1, 0, 2, 3).contiguous()  # (Cin,Cout,k,k) -> (Cout,Cin,k,k)
         return self.c[k]
+
+
+def _convt(x, convt: nn.ConvTranspose2d, f: _Folded, **epi):
+    """Stride-2 upsampling convs run as four output-parity sub-convolutions; anything else through the
+    transposed-gather operand mode."""
+    cls = f.classes(convt)
+    if cls is not None:
+        return ops.conv_transpose2d_s2(x, cls, **epi)
+    return ops.conv_transpose2d(x, f.wt(convt), convt.stride[0], convt.padding[0], convt.output_padding[0], **epi)
 
 
 class Bottleneck(nn.Module):
@@ -93,15 +111,14 @@ class TransBasicBlock(nn.Module):
             s, b = f.bn(self.upsample[1])
             up = self.upsample[0]
             if isinstance(up, nn.ConvTranspose2d):
-                residual = ops.conv_transpose2d(x, f.wt(up), up.stride[0], 0, 0, scale=s, shift=b)
+                residual = _convt(x, up, f, scale=s, shift=b)
             else:
                 residual = ops.conv2d(x, up.weight, scale=s, shift=b)
         s, b = f.bn(self.bn1)
         y = ops.conv2d(x, self.conv1.weight, pad=1, scale=s, shift=b, relu=True)
         s, b = f.bn(self.bn2)
         if isinstance(self.conv2, nn.ConvTranspose2d):
-            return ops.conv_transpose2d(y, f.wt(self.conv2), self.stride, 1, 1, scale=s, shift=b, residual=residual,
-                                        relu=True)
+            return _convt(y, self.conv2, f, scale=s, shift=b, residual=residual, relu=True)
         return ops.conv2d(y, self.conv2.weight, stride=self.stride, pad=1, scale=s, shift=b, residual=residual,
                           relu=True)
 
@@ -223,7 +240,7 @@ class RedNet(nn.Module):
         x = ops.add(self._seq(self.deconv4, x), self._agant(self.agant0, fuse0))
         x = self._seq(self.final_conv, x)
         fd = self.final_deconv_custom
-        return ops.conv_transpose2d(x, f.wt(fd), 2, 0, 0, shift=fd.bias)
+        return _convt(x, fd, f, shift=fd.bias)
 
 
 class PredictSemantics:

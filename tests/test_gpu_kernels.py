@@ -437,3 +437,25 @@ def test_vector_load_gemm_refuses_unaligned_shapes():
             ops.linear_gemm(x, w)
     finally:
         ops.TILE_OVERRIDE = 0
+
+
+@pytest.mark.parametrize("N,Cin,H,W,Cout,k,p,op", [(2, 64, 8, 8, 32, 3, 1, 1), (3, 32, 16, 12, 13, 2, 0, 0),
+                                                   (2, 16, 5, 7, 8, 3, 1, 1), (1, 128, 32, 32, 64, 3, 1, 1)])
+def test_conv_transpose2d_stride2_parity_classes(N, Cin, H, W, Cout, k, p, op):
+    """Stride-2 transposed conv as four output-parity sub-convolutions (RedNet upsampling blocks) against
+    torch CPU, with the fused scale/shift + residual + ReLU epilogue; tolerance 3e-5."""
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(N + Cin + k)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cin, Cout, k, k, generator=g) / (Cin * k * k / 4) ** 0.5
+    sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    ref0 = F.conv_transpose2d(x, w, None, stride=2, padding=p, output_padding=op)
+    assert ref0.shape[2:] == (2 * H, 2 * W)
+    res = torch.randn_like(ref0)
+    cls = ops.convt_s2_classes(w.to(DEV), p)
+    assert cls is not None and len(cls) == 4
+    got = ops.conv_transpose2d_s2(x.to(DEV), cls, scale=sc.to(DEV), shift=sh.to(DEV), residual=res.to(DEV), relu=True)
+    _close(got, F.relu(ref0 * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) + res), 3e-5)
+    # k=3, p=0 needs a negative input offset for the even rows: not decomposed this way
+    assert ops.convt_s2_classes(torch.randn(4, 4, 3, 3, device=DEV), 0) is None
