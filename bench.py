@@ -189,8 +189,17 @@ def bench_update(policy, dev, world, barrier, T=64, N=8, iters=5, warm=2):
         update_agent(policy, opt, obs, prev, nd, tgt, w, world=world)
     barrier()
     el = time.perf_counter() - t0
+    # MFMA kernel family of one update (instrumented pass, outside the timed region)
+    with GemmTimer() as gt:
+        update_agent(policy, opt, obs, prev, nd, tgt, w, world=world)
+        ms = gt.total_ms()
+    ach = (gt.flops / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
+    roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "flops_per_update": int(gt.flops),
+            "launches_per_update": len(gt.events), "kernel_ms_per_update": round(ms, 3),
+            "kernel": "fp32 MFMA family: k_conv_direct / k_wgrad_direct / k_gemm_vec / k_gemm"}
     policy.eval()
-    return el, {"rows_per_step_per_gpu": TN, "T": T, "N": N, "iters": iters}
+    return el, {"rows_per_step_per_gpu": TN, "T": T, "N": N, "iters": iters, "roofline": roof}
 
 
 def main():
@@ -286,7 +295,8 @@ def main():
                   "ms_per_update": round(1e3 * uel / uinfo["iters"], 3), "rows_per_update_per_gpu": uinfo["rows_per_step_per_gpu"],
                   "what": f"DAgger update T={uinfo['T']} x N={uinfo['N']} per GPU from cached depth features: MapCMA forward "
                           "with BPTT, inflection-weighted CE + progress monitor, HIP backward, "
-                          + ("one flat RCCL all-reduce, " if world > 1 else "") + "Adam"}
+                          + ("one flat RCCL all-reduce, " if world > 1 else "") + "Adam",
+                  "roofline": uinfo["roofline"]}
     # ---- roofline of the MFMA implicit-GEMM family: instrumented pass (not part of `value`) ----
     roofline = None
     if rank == 0:
@@ -301,7 +311,7 @@ def main():
         roofline = {
             "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 5), "traffic": None,
-            "kernel": "k_gemm<WM,WN,AMODE,BMODE> (fp32 MFMA implicit GEMM: all conv/linear of one step)",
+            "kernel": "fp32 MFMA family (k_gemm / k_gemm_vec / k_conv_direct): all conv/linear launches of one step",
             "flops_per_step": int(flops_per_step), "launches_per_step": round(launches, 1),
             "kernel_ms_per_step": round(ms / n_inst, 4),
         }

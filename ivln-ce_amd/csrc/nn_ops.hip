@@ -411,6 +411,22 @@ __global__ __launch_bounds__(256) void k_embed_lengths(const int64_t* __restrict
 // GEMM for all (b,t).  Gate order i,f,g,o.  out: (B, 2H, L) channel-major, zero for t >= len.
 // Optional saves for BPTT: gates (B,2,L,4H) post-activation, cs (B,2,L,H).
 // ------------------------------------------------------------------------------------------
+// DPP quad permutation of a float (ctrl = p0 | p1<<2 | p2<<4 | p3<<6: lane i of each quad reads lane p_i)
+template <int CTRL>
+__device__ __forceinline__ float quad_perm(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
+// Barrier that orders LDS traffic only.  __syncthreads() also releases GLOBAL stores, i.e. the compiler
+// puts s_waitcnt vmcnt(0) in front of it: in a per-timestep loop that also writes its outputs to HBM
+// every step then waits for the store acknowledgement.  Nothing in those loops reads global data written
+// by the block, so the recurrent kernels order only their LDS traffic.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 template <int H>
@@ -424,62 +440,94 @@ __global__ __launch_bounds__(4 * H) void k_lstm_bidir(const float* __restrict__ 
                                                       float* __restrict__ out, float* __restrict__ save_gates,
                                                       float* __restrict__ save_c) {
     constexpr int G = 4 * H;
-    __shared__ __attribute__((aligned(16))) float hs[H];
-    __shared__ float cs[H];
-    __shared__ float gs[G];
-    const int b = blockIdx.x, dir = blockIdx.y, g = threadIdx.x;
+    // Quad j (threads 4j..4j+3) owns hidden unit j: lane q multiplies the 4 gate rows {i,f,g,o} of unit j
+    // with ITS quarter of h (a 4 x H/4 block of W_hh = H weights in registers), the quad adds the partial
+    // sums by DPP, lane q activates gate q, the quad exchanges the four activations by DPP and every lane
+    // updates c/h redundantly (c lives in a register).  Per timestep: H/16 ds_read_b128 per thread (every
+    // thread reading all of h saturated the LDS port), no LDS round trip for gates or cell state and ONE
+    // barrier (h for the next step).
+    constexpr int HQ = H / 4, HQP = HQ + 4;  // +4 words per quarter: the 4 quarters hit different banks
+    __shared__ __attribute__((aligned(16))) float hs[2][4 * HQP];  // double-buffered: one barrier per step
+    const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
+    const int q = tid & 3, j = tid >> 2;
+    const int g = q * H + j;  // this lane's gate row (PyTorch order i,f,g,o)
     const float* gx = (dir == 0 ? gx_f : gx_r) + (int64_t)b * L * G;
-    const float* whh = (dir == 0 ? whh_f : whh_r) + (int64_t)g * H;
+    const float* whh = (dir == 0 ? whh_f : whh_r);
     const float bias = (dir == 0 ? bhh_f : bhh_r)[g];
-    // weights as float2 pairs: the matvec issues v_pk_fma_f32 (two fp32 FMAs per lane per instruction)
-    v2f w[H / 2];
+    v2f w[4][HQ / 2];
 #pragma unroll
-    for (int k = 0; k < H / 2; ++k) w[k] = v2f{whh[2 * k], whh[2 * k + 1]};
-    if (g < H) {
-        hs[g] = 0.f;
-        cs[g] = 0.f;
-    }
-    __syncthreads();
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int k = 0; k < HQ / 2; ++k) {
+            const float* wp = whh + (int64_t)(r * H + j) * H + q * HQ + 2 * k;
+            w[r][k] = v2f{wp[0], wp[1]};
+        }
+    const int hslot = (j / HQ) * HQP + j % HQ;
+    if (q == 0) hs[0][hslot] = 0.f;
+    float c = 0.f;
+    lds_barrier();
     int len = lengths[b];
     if (len > L) len = L;
-    // gx for step s+1 is fetched while step s computes: the dependent global load (~0.5-1 us of
-    // L2/HBM latency per timestep) was 80% of this kernel before the prefetch.
-    float gx_next = len > 0 ? gx[(int64_t)(dir == 0 ? 0 : len - 1) * G + g] : 0.f;
-    for (int s = 0; s < len; ++s) {
+    // gx (this lane's gate input, one float per timestep) is prefetched FOUR steps ahead in a rotating
+    // register queue: a timestep is ~0.4 us of work but a fresh HBM row costs ~2 us, so a one-step
+    // prefetch left every step waiting on memory.
+    auto gx_at = [&](int s) -> float {
+        return s < len ? gx[(int64_t)(dir == 0 ? s : len - 1 - s) * G + g] : 0.f;
+    };
+    auto step = [&](int s, float gxv) {
         const int t = dir == 0 ? s : len - 1 - s;
-        // four independent accumulator chains: a single 128-long dependent fmaf chain (4-cycle latency
-        // each) was the critical path of every timestep
-        v2f a0 = v2f{gx_next + bias, 0.f}, a1 = v2f{0.f, 0.f}, a2 = a1, a3 = a1;
-        if (s + 1 < len) gx_next = gx[(int64_t)(dir == 0 ? s + 1 : len - 2 - s) * G + g];
+        const float* hcur = hs[s & 1];
+        v2f p[4] = {v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}};
 #pragma unroll
-        for (int k = 0; k < H; k += 8) {
-            const float4 h0 = *reinterpret_cast<const float4*>(&hs[k]);
-            const float4 h1 = *reinterpret_cast<const float4*>(&hs[k + 4]);
-            a0 = __builtin_elementwise_fma(w[k / 2], v2f{h0.x, h0.y}, a0);
-            a1 = __builtin_elementwise_fma(w[k / 2 + 1], v2f{h0.z, h0.w}, a1);
-            a2 = __builtin_elementwise_fma(w[k / 2 + 2], v2f{h1.x, h1.y}, a2);
-            a3 = __builtin_elementwise_fma(w[k / 2 + 3], v2f{h1.z, h1.w}, a3);
+        for (int k = 0; k < HQ; k += 4) {
+            const float4 hv = *reinterpret_cast<const float4*>(&hcur[q * HQP + k]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                p[r] = __builtin_elementwise_fma(w[r][k / 2], v2f{hv.x, hv.y}, p[r]);
+                p[r] = __builtin_elementwise_fma(w[r][k / 2 + 1], v2f{hv.z, hv.w}, p[r]);
+            }
         }
-        const v2f asum = (a0 + a1) + (a2 + a3);
-        const float acc = asum.x + asum.y;
-        const int gate = g / H;
+        float ps[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = p[r].x + p[r].y;
+            v += quad_perm<0xB1>(v);  // lanes 1,0,3,2
+            v += quad_perm<0x4E>(v);  // lanes 2,3,0,1
+            ps[r] = v;
+        }
+        const float acc = gxv + bias + (q == 0 ? ps[0] : (q == 1 ? ps[1] : (q == 2 ? ps[2] : ps[3])));
         // sigmoid / tanh through one fast exp each (|err| ~1e-7): tanh(x) = 2*sigmoid(2x) - 1
-        float a = gate == 2 ? (2.f / (1.f + __expf(-2.f * acc)) - 1.f) : (1.f / (1.f + __expf(-acc)));
-        gs[g] = a;
+        // (v_rcp_f32 is 1 ulp; an IEEE division is a ~10-instruction sequence on the per-step critical path)
+        const float e = __expf(q == 2 ? -2.f * acc : -acc);
+        const float rc = __builtin_amdgcn_rcpf(1.f + e);
+        const float a = q == 2 ? 2.f * rc - 1.f : rc;
         if (save_gates) save_gates[(((int64_t)b * 2 + dir) * L + t) * G + g] = a;
-        __syncthreads();
-        if (g < H) {
-            float c = gs[H + g] * cs[g] + gs[g] * gs[2 * H + g];
-            float h = gs[3 * H + g] * (2.f / (1.f + __expf(-2.f * c)) - 1.f);
-            cs[g] = c;
-            hs[g] = h;
-            out[((int64_t)b * 2 * H + dir * H + g) * L + t] = h;
-            if (save_c) save_c[(((int64_t)b * 2 + dir) * L + t) * H + g] = c;
+        const float ai = quad_perm<0x00>(a), af = quad_perm<0x55>(a), ag = quad_perm<0xAA>(a), ao = quad_perm<0xFF>(a);
+        c = af * c + ai * ag;
+        const float h = ao * (2.f * __builtin_amdgcn_rcpf(1.f + __expf(-2.f * c)) - 1.f);
+        if (q == 0) {
+            hs[(s + 1) & 1][hslot] = h;
+            out[((int64_t)b * 2 * H + dir * H + j) * L + t] = h;
+            if (save_c) save_c[(((int64_t)b * 2 + dir) * L + t) * H + j] = c;
         }
-        __syncthreads();
+        lds_barrier();
+    };
+    float g0 = gx_at(0), g1 = gx_at(1), g2 = gx_at(2), g3 = gx_at(3);
+    for (int s = 0; s < len; s += 4) {
+        step(s, g0);
+        g0 = gx_at(s + 4);
+        if (s + 1 >= len) break;
+        step(s + 1, g1);
+        g1 = gx_at(s + 5);
+        if (s + 2 >= len) break;
+        step(s + 2, g2);
+        g2 = gx_at(s + 6);
+        if (s + 3 >= len) break;
+        step(s + 3, g3);
+        g3 = gx_at(s + 7);
     }
-    if (g < H)
-        for (int t = len; t < L; ++t) out[((int64_t)b * 2 * H + dir * H + g) * L + t] = 0.f;
+    if (q == 0)
+        for (int t = len; t < L; ++t) out[((int64_t)b * 2 * H + dir * H + j) * L + t] = 0.f;
 }
 
 // ------------------------------------------------------------------------------------------

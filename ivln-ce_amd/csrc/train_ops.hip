@@ -260,6 +260,13 @@ __global__ __launch_bounds__(256) void k_linear_skinny_ex(const float* __restric
 // (pre-activation gate grads, zero for t >= len) and hprev (B*L, H) per direction (h_{t-1} in
 // processing order) for the dW_hh / dW_ih GEMMs.
 // ------------------------------------------------------------------------------------------
+// LDS-only barrier (see nn_ops.hip): __syncthreads() would wait for the per-step global stores.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 template <int H>
 __global__ __launch_bounds__(4 * H) void k_lstm_bidir_bwd(const float* __restrict__ dout,
                                                           const float* __restrict__ out,
@@ -294,7 +301,7 @@ __global__ __launch_bounds__(4 * H) void k_lstm_bidir_bwd(const float* __restric
         for (int g = k; g < G; g += H) dgx[(int64_t)t * G + g] = 0.f;
         hprev[(int64_t)t * H + k] = 0.f;
     }
-    __syncthreads();
+    lds_barrier();
     const float* gt = gates + ((int64_t)b * 2 + dir) * L * G;
     const float* ct = cs + ((int64_t)b * 2 + dir) * L * H;
     for (int s = len - 1; s >= 0; --s) {
@@ -326,14 +333,14 @@ __global__ __launch_bounds__(4 * H) void k_lstm_bidir_bwd(const float* __restric
             dgx[(int64_t)t * G + 3 * H + j] = a3;
             hprev[(int64_t)t * H + j] = hp;
         }
-        __syncthreads();
+        lds_barrier();
         float acc = 0.f;
 #pragma unroll
         for (int g = 0; g < H; ++g) acc = fmaf(w[g], dg[pq * H + g], acc);
         part[pq][k] = acc;
-        __syncthreads();
+        lds_barrier();
         if (tid < H) dhc[tid] = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
-        __syncthreads();
+        lds_barrier();
     }
 }
 
