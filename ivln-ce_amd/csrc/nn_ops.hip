@@ -303,28 +303,39 @@ __global__ void k_bn_stats_final(const float* __restrict__ partial, int S, int C
 // BatchNorm2d -> ReLU -> AvgPool2d(2), models/encoders/map_encoder.py:13-20).  x is NCHW
 // (chan_stride = H*W, img_stride = C*H*W) or the producing conv's split-K slabs ([C][N*H*W]:
 // chan_stride = N*H*W, img_stride = H*W) whose reduction is fused here.
+// lpo (1,2,4,8,16) lanes share one output and split the slabs between them: the tail layers at rollout
+// batch have few outputs (8192) but 16-64 slabs each - one thread per output was a 224-load serial chain.
 __global__ __launch_bounds__(256) void k_scale_shift_relu_avgpool2(const float* __restrict__ x,
                                                                    const float* __restrict__ scale,
                                                                    const float* __restrict__ shift,
                                                                    float* __restrict__ y, int N, int C, int H,
                                                                    int W, int64_t img_stride, int64_t chan_stride,
-                                                                   int splits, int64_t slab_stride) {
+                                                                   int splits, int64_t slab_stride, int lpo) {
     const int Ho = H / 2, Wo = W / 2;
-    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (int64_t)N * C * Ho * Wo) return;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int sub = (int)(gid % lpo);
+    int64_t idx = gid / lpo;
+    const bool live = idx < (int64_t)N * C * Ho * Wo;
+    if (!live) idx = 0;  // keep the whole wave in the shuffles
     int wo = (int)(idx % Wo);
     int ho = (int)((idx / Wo) % Ho);
     int nc = (int)(idx / ((int64_t)Wo * Ho));
     int c = nc % C, n = nc / C;
-    const float sc = scale[c], sh = shift[c];
     const float* xp = x + (int64_t)n * img_stride + (int64_t)c * chan_stride + (int64_t)(2 * ho) * W + 2 * wo;
-    float2 t = *reinterpret_cast<const float2*>(xp);
-    float2 u = *reinterpret_cast<const float2*>(xp + W);
-    for (int z = 1; z < splits; ++z) {
+    float2 t = make_float2(0.f, 0.f), u = make_float2(0.f, 0.f);
+    for (int z = sub; z < splits; z += lpo) {
         float2 t2 = *reinterpret_cast<const float2*>(xp + (int64_t)z * slab_stride);
         float2 u2 = *reinterpret_cast<const float2*>(xp + (int64_t)z * slab_stride + W);
         t.x += t2.x; t.y += t2.y; u.x += u2.x; u.y += u2.y;
     }
+    for (int off = lpo >> 1; off > 0; off >>= 1) {
+        t.x += __shfl_xor(t.x, off, 64);
+        t.y += __shfl_xor(t.y, off, 64);
+        u.x += __shfl_xor(u.x, off, 64);
+        u.y += __shfl_xor(u.y, off, 64);
+    }
+    if (!live || sub != 0) return;
+    const float sc = scale[c], sh = shift[c];
     float a = fmaxf(fmaf(t.x, sc, sh), 0.f);
     float b = fmaxf(fmaf(t.y, sc, sh), 0.f);
     float c2 = fmaxf(fmaf(u.x, sc, sh), 0.f);
@@ -378,28 +389,31 @@ __global__ __launch_bounds__(256) void k_map_features(const uint8_t* __restrict_
 // and lengths = number of tokens whose embedding row has any non-zero entry.
 // out: emb (B*L, E) row-major; lengths (B) int32.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_embed_lengths(const int64_t* __restrict__ tokens,
-                                                       const float* __restrict__ table, int L, int E, int V,
-                                                       float* __restrict__ emb, int* __restrict__ lengths) {
+// One block per sequence, 16 waves, a wave per token: lanes run along the embedding row (coalesced 200-byte
+// rows; one thread per token walked its row serially - 50 dependent strided loads).
+__global__ __launch_bounds__(1024) void k_embed_lengths(const int64_t* __restrict__ tokens,
+                                                        const float* __restrict__ table, int L, int E, int V,
+                                                        float* __restrict__ emb, int* __restrict__ lengths) {
     __shared__ int cnt;
     const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     if (threadIdx.x == 0) cnt = 0;
     __syncthreads();
     int local = 0;
-    for (int t = threadIdx.x; t < L; t += blockDim.x) {
+    for (int t = wave; t < L; t += nw) {
         int64_t tok = tokens[(int64_t)b * L + t];
         if (tok < 0 || tok >= V) tok = 0;
         const float* row = table + tok * E;
         float* o = emb + ((int64_t)b * L + t) * E;
         bool nz = false;
-        for (int e = 0; e < E; ++e) {
-            float v = row[e];
+        for (int e = lane; e < E; e += 64) {
+            const float v = row[e];
             o[e] = v;
             nz |= (v != 0.0f);
         }
-        local += nz ? 1 : 0;
+        local += __any(nz) ? 1 : 0;
     }
-    atomicAdd(&cnt, local);
+    if (lane == 0) atomicAdd(&cnt, local);
     __syncthreads();
     if (threadIdx.x == 0) lengths[b] = cnt;
 }
@@ -936,8 +950,10 @@ int ivln_scale_shift_relu_avgpool2_f32(const float* x, const float* scale, const
     if (img_stride <= 0) img_stride = (int64_t)C * H * W;
     if (splits < 1) splits = 1;
     int64_t total = (int64_t)N * C * (H / 2) * (W / 2);
-    hipLaunchKernelGGL(k_scale_shift_relu_avgpool2, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, x, scale,
-                       shift, y, N, C, H, W, img_stride, chan_stride, splits, slab_stride);
+    int lpo = 1;  // lanes per output: split the slab sum until ~64K threads are in flight
+    while (lpo < 16 && lpo * 2 <= splits && total * lpo < 65536) lpo *= 2;
+    hipLaunchKernelGGL(k_scale_shift_relu_avgpool2, dim3(nblk(total * lpo)), dim3(256), 0, (hipStream_t)stream, x,
+                       scale, shift, y, N, C, H, W, img_stride, chan_stride, splits, slab_stride, lpo);
     return LAUNCH_OK();
 }
 
@@ -959,7 +975,7 @@ int ivln_map_features_f32(const uint8_t* occ, const uint8_t* sem, float* y, int 
 
 int ivln_embed_lengths(const int64_t* tokens, const float* table, int B, int L, int E, int V, float* emb,
                        int* lengths, void* stream) {
-    hipLaunchKernelGGL(k_embed_lengths, dim3(B), dim3(256), 0, (hipStream_t)stream, tokens, table, L, E, V, emb,
+    hipLaunchKernelGGL(k_embed_lengths, dim3(B), dim3(1024), 0, (hipStream_t)stream, tokens, table, L, E, V, emb,
                        lengths);
     return LAUNCH_OK();
 }
