@@ -127,7 +127,11 @@ typedef struct ivln_gemm_desc {
      * fuses the slab reduction.  splits_used (host, optional) receives the split count chosen. */
     int defer_epilogue;
     int* splits_used;
-    /* 0 = heuristic; 1..5 force block tile 64x64 / 32x128 / 128x32 / 128x128 / 64x128 (tuning, tests) */
+    /* 0 = heuristic (direct conv / vector-load GEMM where eligible, else the scalar-gather implicit GEMM);
+     * 1..5 force the scalar-gather kernel with block tile 64x64 / 32x128 / 128x32 / 128x128 / 64x128;
+     * 6 insist on the LDS-patch direct conv / weight-gradient kernels (conv_direct.hip);
+     * 7 insist on the float4-staged GEMM (gemm_vec.hip).  6/7 return IVLN_E_UNSUPPORTED when the shape is
+     * not eligible (tuning, tests). */
     int tile_override;
 } ivln_gemm_desc;
 
