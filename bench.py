@@ -155,6 +155,19 @@ def cpu_baseline(obs_cpu, B, budget_s=12.0):
     }
 
 
+def pmc_traffic(B):
+    """HBM bytes per MFMA-family launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
+    in separate runs, gfx950 FETCH correction applied; profiles/r01_rollout_pmc_traffic.json).  A counter
+    pass cannot run inside the timed bench, so the figure is the committed one and only for its workload."""
+    path = os.path.join(ROOT, "profiles", "r01_rollout_pmc_traffic.json")
+    if B != 4 or not os.path.exists(path):
+        return None
+    try:
+        return json.load(open(path))["mfma_family"]["hbm_bytes_per_launch_corrected"]
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
@@ -310,7 +323,7 @@ def main():
         ach = (gt.flops / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
         roofline = {
             "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 5), "traffic": None,
+            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 5), "traffic": pmc_traffic(B),
             "kernel": "fp32 MFMA family (k_gemm / k_gemm_vec / k_conv_direct): all conv/linear launches of one step",
             "flops_per_step": int(flops_per_step), "launches_per_step": round(launches, 1),
             "kernel_ms_per_step": round(ms / n_inst, 4),

@@ -37,6 +37,55 @@ __device__ __forceinline__ void epilogue_store(const ivln_gemm_desc& p, int m, i
     p.D[addr] = v;
 }
 
+// One 32x32 accumulator tile -> D.  Lane (l31, half) holds column n = n_base + l31 and, in registers
+// 4q..4q+3, the FOUR CONSECUTIVE rows m = m_base + 8q + 4*half + {0..3}.  When D is dense with unit row
+// stride (nn.Linear outputs y[row][feature]: m is the contiguous index) those four go out as one 16-byte
+// store instead of four 4-byte stores to the same 64-byte granule (the scalar form wrote every granule
+// of a (102400 x 512) LSTM input projection 16 times over: 527 MB of WRITE_SIZE for a 210 MB tensor).
+__device__ __forceinline__ void epilogue_tile(const ivln_gemm_desc& p, int m_base, int n, int half, const f32x16& acc,
+                                              int split_z) {
+    const bool to_ws = p.splits > 1 || p.defer_epilogue;
+    const bool vec4 = !to_ws && p.dmode == DMODE_DENSE && p.sDm == 1 && (p.sDn & 3) == 0 && (p.M & 3) == 0 &&
+                      (((uintptr_t)p.D | (uintptr_t)p.residual) & 15) == 0;
+    if (n >= p.N) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int m = m_base + 8 * q + 4 * half;
+        if (vec4) {
+            if (m >= p.M) continue;  // M % 4 == 0: the four rows are in or out together
+            const int64_t addr = (int64_t)m + (int64_t)n * p.sDn;
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i] = acc[4 * q + i];
+                if (p.scale) v[i] = fmaf(v[i], p.scale[m + i], p.shift[m + i]);
+                else if (p.shift) v[i] += p.shift[m + i];
+            }
+            if (p.residual) {
+                const float4 r = *reinterpret_cast<const float4*>(p.residual + addr);
+                v[0] += r.x, v[1] += r.y, v[2] += r.z, v[3] += r.w;
+            }
+            if (p.accumulate) {
+                const float4 r = *reinterpret_cast<const float4*>(p.D + addr);
+                v[0] += r.x, v[1] += r.y, v[2] += r.z, v[3] += r.w;
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+            }
+            *reinterpret_cast<float4*>(p.D + addr) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (m + i < p.M) {
+                    if (to_ws) p.ws[((int64_t)split_z * p.M + m + i) * p.N + n] = acc[4 * q + i];
+                    else epilogue_store(p, m + i, n, acc[4 * q + i]);
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // conv_direct.hip: stride-1 3x3 / 7x7 convolution with the input patch and a weight slice staged in LDS.

@@ -16,6 +16,8 @@
 // * split-K over blockIdx.z for the K-heavy / pixel-starved tail layers (4x4 spatial, K up to 9216):
 //   partial slabs are reduced in a fixed order (deterministic) by k_splitk_epilogue.
 // * Epilogue fused: per-channel scale/shift (folded BatchNorm or bias), residual add, ReLU.
+#include <stdlib.h>
+
 #include "gemm_common.h"
 
 namespace {
@@ -278,18 +280,9 @@ __global__ __launch_bounds__(256) void k_gemm(const ivln_gemm_desc p) {
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int n = n0 + (wn * TN + tn) * 32 + (lane & 31);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int m = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m < p.M && n < p.N) {
-                    if (p.splits > 1 || p.defer_epilogue)
-                        p.ws[((int64_t)blockIdx.z * p.M + m) * p.N + n] = acc[tm][tn][r];
-                    else epilogue_store(p, m, n, acc[tm][tn][r]);
-                }
-            }
-        }
+        for (int tn = 0; tn < TN; ++tn)
+            epilogue_tile(p, m0 + (wm * TM + tm) * 32, n0 + (wn * TN + tn) * 32 + (lane & 31), lane >> 5, acc[tm][tn],
+                          blockIdx.z);
 }
 
 __global__ __launch_bounds__(256) void k_splitk_epilogue(const ivln_gemm_desc p) {
@@ -378,7 +371,8 @@ extern "C" int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream) {
     if (d.splits == 0) {
         // the consumer reduces for free when deferred: split until ~4 blocks per CU hide the load latency
         const int min_tiles = d.defer_epilogue ? 2 : 4;
-        const int64_t want = d.defer_epilogue ? 1024 : 512;
+        static const int want_env = getenv("IVLN_SPLIT_WANT") ? atoi(getenv("IVLN_SPLIT_WANT")) : 0;  // tuning
+        const int64_t want = want_env > 0 ? want_env : (d.defer_epilogue ? 1024 : 512);
         if (d.ws && blocks < (d.defer_epilogue ? 512 : 256) && nk >= 2 * min_tiles) {
             splits = (int)((want + blocks - 1) / blocks);
             if (splits > nk / min_tiles) splits = nk / min_tiles;

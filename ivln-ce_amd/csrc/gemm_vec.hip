@@ -188,18 +188,8 @@ __global__ __launch_bounds__(256) void k_gemm_vec(const ivln_gemm_desc p) {
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int n = n0 + (wn * TN + tn) * 32 + l31;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m < p.M && n < p.N) {
-                    if (p.splits > 1 || p.defer_epilogue)
-                        p.ws[((int64_t)blockIdx.z * p.M + m) * p.N + n] = acc[tm][tn][r];
-                    else epilogue_store(p, m, n, acc[tm][tn][r]);
-                }
-            }
-        }
+        for (int tn = 0; tn < TN; ++tn)
+            epilogue_tile(p, m0 + (wm * TM + tm) * 32, n0 + (wn * TN + tn) * 32 + l31, half, acc[tm][tn], blockIdx.z);
 }
 
 template <int WM, int WN, int TM, int TN>
