@@ -351,8 +351,8 @@ int ivln_conv_direct_launch(ivln_gemm_desc& d, hipStream_t s) {
     if (d.defer_epilogue && (!d.ws || d.ws_floats < (int64_t)d.M * d.N)) return IVLN_E_INVALID;
     if (d.splits == 0) {
         // split the channel chunks over blockIdx.z until the grid covers the chip
-        const int64_t want = d.defer_epilogue ? 1024 : 512;
-        if (d.ws && blocks < (d.defer_epilogue ? 512 : 256) && nch >= 2) {
+        const int64_t want = d.defer_epilogue ? 256 : 512;
+        if (d.ws && blocks < 256 && nch >= 2) {
             splits = (int)((want + blocks - 1) / blocks);
             if (splits > nch) splits = nch;
             if (splits > 16) splits = 16;

@@ -1,5 +1,6 @@
 """smoke(): one tiny act + one tiny DAgger update of the MapCMA policy on cuda:0, checked against
-the torch-CPU oracle (imported here only because __graft_entry__.smoke() asks for the check)."""
+the torch-CPU oracle.  Lives under tests/ (called by __graft_entry__.smoke()): nothing in the product
+package may import the oracle."""
 import numpy as np
 import torch
 
@@ -7,11 +8,11 @@ import torch
 def run():
     from oracle.policy_ref import MapCMAPolicyRef  # checker only (smoke), never on the product path
 
-    from .config import get_config
-    from .policy import MapCMAPolicy
-    from .spaces import Box, Dict, Discrete
-    from .synthetic import SyntheticRollout
-    from .trainers import FlatAdam, update_agent
+    from ivln_ce_amd.config import get_config
+    from ivln_ce_amd.policy import MapCMAPolicy
+    from ivln_ce_amd.spaces import Box, Dict, Discrete
+    from ivln_ce_amd.synthetic import SyntheticRollout
+    from ivln_ce_amd.trainers import FlatAdam, update_agent
 
     dev = torch.device("cuda:0")
     cfg = get_config(opts=["MODEL.policy_name", "MapCMAPolicy", "MODEL.INSTRUCTION_ENCODER.use_pretrained_embeddings",
