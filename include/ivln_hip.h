@@ -206,6 +206,10 @@ int ivln_rgb_resize_normalize_f32(const uint8_t* rgb, int B, int Hi, int Wi, int
                                   void* stream);
 int ivln_affine_f32(const float* x, float* y, int64_t n, float sub, float div, void* stream);
 int ivln_add_f32(const float* a, const float* b, float* y, int64_t n, int relu, void* stream);
+/* n <= 8 contiguous device-to-device copies in one launch (GraphedRollout.load: the observation tensors of
+ * an env step -> the captured input buffers of the step graph; replaces per-tensor Tensor.copy_ at
+ * base_il_trainer.py:688-703's batch_obs hand-over). */
+int ivln_copy_multi(const void* const* srcs, void* const* dsts, const int64_t* bytes, int n, void* stream);
 int ivln_copy2d_f32(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int rows, int cols,
                     int broadcast_rows, void* stream);
 

@@ -96,12 +96,24 @@ class GraphedRollout:
         self.phase = 0
 
     def load(self, obs: Dict):
+        """Observation tensors -> the captured input buffers: one multi-copy launch for everything that is
+        already a matching contiguous device tensor, Tensor.copy_ (H2D / cast / strided) for the rest."""
+        from . import ops
+
+        pairs = []
         for k, v in obs.items():
             if torch.is_tensor(v):
-                if k in self.static:
-                    self.static[k].copy_(v, non_blocking=True)
+                dst = self.static.get(k)
+                if dst is None:
+                    continue
+                if v.is_cuda and v.dtype == dst.dtype and v.shape == dst.shape and v.is_contiguous():
+                    pairs.append((v, dst))
+                else:
+                    dst.copy_(v, non_blocking=True)
             else:
                 self.static[k] = v
+        if pairs:
+            ops.copy_multi(pairs)
 
     def step(self, obs: Dict = None):
         """Copy the observations the step reads into the captured input buffers and replay.

@@ -495,6 +495,22 @@ def add(a, b, relu=False, out=None):
     return out
 
 
+def copy_multi(pairs):
+    """[(src, dst)] contiguous same-shape/dtype device tensors copied by one launch (<= 8 per call)."""
+    L = _L()
+    L.ivln_copy_multi.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int,
+                                  C.c_void_p]
+    for k in range(0, len(pairs), 8):
+        chunk = pairs[k:k + 8]
+        n = len(chunk)
+        srcs, dsts, nb = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_int64 * n)()
+        for i, (s, d) in enumerate(chunk):
+            if s.shape != d.shape or s.dtype != d.dtype or not s.is_contiguous() or not d.is_contiguous():
+                raise _lib.IvlnError("copy_multi needs contiguous tensors of identical shape and dtype")
+            srcs[i], dsts[i], nb[i] = _p(s), _p(d), s.numel() * s.element_size()
+        check(L.ivln_copy_multi(srcs, dsts, nb, n, stream_ptr()), "ivln_copy_multi")
+
+
 def copy2d(src, dst, rows, cols, broadcast_rows=False):
     check(
         _L().ivln_copy2d_f32(_p(src), src.stride(0) if src.dim() > 1 else cols, _p(dst), dst.stride(0), rows, cols,
