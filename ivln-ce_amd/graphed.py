@@ -32,10 +32,14 @@ class GraphedRollout:
         L = policy.net.num_recurrent_layers
         self.rnn = [torch.zeros(B, L, H, device=dev) for _ in range(2)]
         self.prev = [torch.zeros(B, 1, dtype=torch.long, device=dev) for _ in range(2)]
-        self.side = (torch.cuda.Stream(dev), torch.cuda.Stream(dev)) if streams else None
+        self.split = streams == "split"
+        self.side = (torch.cuda.Stream(dev), torch.cuda.Stream(dev)) if (streams and not self.split) else None
         self.graphs = []
         self.phase = 0  # which buffer set holds the current state
-        self._capture(warmup)
+        if self.split:
+            self._capture_split(warmup)
+        else:
+            self._capture(warmup)
 
     @property
     def actions(self):
@@ -80,6 +84,92 @@ class GraphedRollout:
             net._rnn_out_buffer = None
             self.policy._action_out_buffer = None
 
+    # ---- split mode: three graphs per step on two streams ---------------------------------------
+    #   gA  (side stream): depth ResNet -> depth_features            (60 % of the step's kernel time,
+    #                                                                 depends only on the new depth image)
+    #   gB1 (main stream): mapper -> map CNN, instruction encoder, their k/v projections
+    #   gB2 (main stream, after gA): depth k/v + linear, GRUs, attention, action head
+    # Separate graphs on separate streams instead of forked branches inside one capture (which replays
+    # slower than a single stream on ROCm 7.2): the only cross-stream edges are two events per step.
+    def _capture_split(self, warmup):
+        dev = self.device
+        net = self.policy.net
+        self.sA = torch.cuda.Stream(dev)
+        self.ev_in, self.ev_A = torch.cuda.Event(), torch.cuda.Event()
+        main = torch.cuda.current_stream()
+
+        def run_A():
+            with torch.no_grad():
+                return net.depth_encoder.visual_encoder(dict(self.static))
+
+        def run_B1():
+            batch = dict(self.static)
+            for t in self.transforms:
+                batch = t(batch)
+            net._stage = "pre"
+            try:
+                with torch.no_grad():
+                    net.forward_hip(batch, self.rnn[0], self.prev[0], batch["not_done_masks"])
+            finally:
+                net._stage = None
+            return batch
+
+        def run_B2(src, batch, feats):
+            dst = src ^ 1
+            batch = dict(batch)
+            batch["depth_features"] = feats
+            net._stage = "post"
+            net._rnn_out_buffer = self.rnn[dst]
+            self.policy._action_out_buffer = self.prev[dst] if self.deterministic else None
+            try:
+                with torch.no_grad():
+                    actions, rnn = self.policy.act(batch, self.rnn[src], self.prev[src], batch["not_done_masks"],
+                                                   deterministic=self.deterministic)
+                    if actions.data_ptr() != self.prev[dst].data_ptr():
+                        self.prev[dst].copy_(actions)
+                    if rnn.data_ptr() != self.rnn[dst].data_ptr():
+                        self.rnn[dst].copy_(rnn)
+            finally:
+                net._stage = None
+                net._rnn_out_buffer = None
+                self.policy._action_out_buffer = None
+
+        s = torch.cuda.Stream(dev)
+        s.wait_stream(main)
+        with torch.cuda.stream(s):  # warm-up: tables, workspaces (per stream), folded weights
+            for i in range(warmup):
+                f = run_A()
+                b = run_B1()
+                run_B2(i & 1, b, f)
+        with torch.cuda.stream(self.sA):  # the side stream needs its own split-K workspace before capture
+            run_A()
+        main.wait_stream(s)
+        torch.cuda.synchronize()
+        self.gA = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.gA, stream=self.sA):
+            self._feats = run_A()
+        self.gB1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.gB1):
+            self._batch = run_B1()
+        pool = self.gB1.pool()
+        for src in (0, 1):
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, pool=pool):
+                run_B2(src, self._batch, self._feats)
+            self.graphs.append(gr)
+        self.phase = 0
+
+    def _replay_split(self):
+        main = torch.cuda.current_stream()
+        self.ev_in.record(main)
+        self.sA.wait_event(self.ev_in)
+        with torch.cuda.stream(self.sA):
+            self.gA.replay()
+            self.ev_A.record(self.sA)
+        self.gB1.replay()
+        main.wait_event(self.ev_A)
+        self.graphs[self.phase].replay()
+
     def _capture(self, warmup):
         s = torch.cuda.Stream(self.device)
         s.wait_stream(torch.cuda.current_stream())
@@ -120,7 +210,10 @@ class GraphedRollout:
         Returns the (B,1) int64 action tensor (one of the two persistent buffers)."""
         if obs is not None:
             self.load(obs)
-        self.graphs[self.phase].replay()
+        if self.split:
+            self._replay_split()
+        else:
+            self.graphs[self.phase].replay()
         self.phase ^= 1
         return self.actions
 

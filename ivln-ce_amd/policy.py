@@ -223,7 +223,21 @@ class MapCMANet(Net):
 
         # The key/value projections depend only on their own encoder, so they run inside the branches.
         side = getattr(self, "_side_streams", None) if save is None else None
-        if side is None:
+        stage = getattr(self, "_stage", None) if save is None else None
+        if stage == "pre":
+            # graphed.py, split mode: the instruction and map branches are captured as their own graph and
+            # run while the depth ResNet (a third graph, on another stream) is still in flight
+            txt, lengths, tk = _txt_branch(None)
+            mp, mkv = _map_branch(None)
+            self._stash = dict(state_in=state_in, x2=x2, txt=(txt, lengths, tk), map=(mp, mkv))
+            return None, None
+        if stage == "post":
+            st = self._stash
+            state_in, x2 = st["state_in"], st["x2"]
+            txt, lengths, tk = st["txt"]
+            mp, mkv = st["map"]
+            dep, dkv = _dep_branch()
+        elif side is None:
             txt, lengths, tk = _txt_branch(s_txt)
             dep, dkv = _dep_branch()
             mp, mkv = _map_branch(s_map)

@@ -123,8 +123,10 @@ def test_act_matches_oracle_other_batches(B):
     assert float((lg.cpu() - lr).abs().max()) < 1e-4
 
 
-def test_graphed_multistream_rollout_is_bit_identical_to_eager():
-    """hipGraph replay with forked streams must not change a single bit of actions / states / maps."""
+@pytest.mark.parametrize("streams", [True, False, "split"])
+def test_graphed_multistream_rollout_is_bit_identical_to_eager(streams):
+    """hipGraph replay (forked streams / one stream / three graphs on two streams) must not change a single
+    bit of actions / states / maps."""
     from ivln_ce_amd.config import get_config
     from ivln_ce_amd.graphed import GraphedRollout
     from ivln_ce_amd.obs_transforms import GTSemanticsIterativeMapper
@@ -149,7 +151,7 @@ def test_graphed_multistream_rollout_is_bit_identical_to_eager():
         eager.append((a.clone(), rnn.clone(), b["occupancy_map"].clone(), b["semantic_map"].clone()))
     # graphed: the capture warm-up replays obs[0] a few times, so restart mapper + policy state afterwards
     tr_g = GTSemanticsIterativeMapper.from_config(cfg)
-    runner = GraphedRollout(pol, [tr_g], obs[0], deterministic=True, streams=True)
+    runner = GraphedRollout(pol, [tr_g], obs[0], deterministic=True, streams=streams)
     tr_g.mapping_module.reset()
     runner.reset_state()
     for t, o in enumerate(obs):
