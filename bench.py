@@ -224,8 +224,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-update", action="store_true", help="skip the DAgger update-step leg (extra JSON object)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
-    ap.add_argument("--split", action="store_true",
-                    help="three graphs on two streams: depth ResNet || mapper + map CNN + instruction encoder, then the head")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="one graph on one stream instead of the default three graphs on two streams (depth ResNet || "
+                         "mapper + map CNN + instruction encoder, then the head)")
     ap.add_argument("--streams", action="store_true",
                     help="fork the three encoder branches onto side streams inside the graph (measured SLOWER on "
                          "ROCm 7.2: cross-queue dependencies cost more than the overlap wins)")
@@ -271,7 +272,7 @@ def main():
 
         log(f"rank {rank}: capturing the step graph")
         runner = GraphedRollout(policy, [mapper_tr], obs_dev[0], deterministic=True,
-                                streams="split" if args.split else args.streams)
+                                streams=args.streams if (args.streams or args.single_stream) else "split")
 
         def do_step(i):
             runner.step(obs_dev[i % n_pool])
@@ -341,7 +342,7 @@ def main():
                         f"{B} parallel envs per GPU, 256x256 depth + semantic12, 80-token instruction, random-init "
                         "weights of the reference architecture",
             "envs_per_gpu": B, "parallelism": f"dp{world} (envs sharded, no data-path collective)",
-            "launch": ("hipGraph replay, " + ("3 graphs on 2 streams" if args.split else ("3 forked streams" if args.streams else "1 stream"))) if use_graph else "eager",
+            "launch": ("hipGraph replay, " + ("3 forked streams" if args.streams else ("1 stream" if args.single_stream else "3 graphs on 2 streams"))) if use_graph else "eager",
         },
         "roofline": roofline,
     }

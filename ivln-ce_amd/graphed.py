@@ -85,40 +85,53 @@ class GraphedRollout:
             self.policy._action_out_buffer = None
 
     # ---- split mode: three graphs per step on two streams ---------------------------------------
-    #   gA  (side stream): depth ResNet -> depth_features            (60 % of the step's kernel time,
-    #                                                                 depends only on the new depth image)
-    #   gB1 (main stream): mapper -> map CNN, instruction encoder, their k/v projections
-    #   gB2 (main stream, after gA): depth k/v + linear, GRUs, attention, action head
+    #   gA  (side stream): depth ResNet, its k/v projection, depth_linear   (60 % of the step's kernel
+    #                                                      time, depends only on the new depth image)
+    #   gB1 (main stream): mapper -> map CNN, instruction encoder, their k/v projections, prev-action embedding
+    #   gB2 (main stream, after gA): GRUs, attention, action head
     # Separate graphs on separate streams instead of forked branches inside one capture (which replays
     # slower than a single stream on ROCm 7.2): the only cross-stream edges are two events per step.
     def _capture_split(self, warmup):
         dev = self.device
         net = self.policy.net
-        self.sA = torch.cuda.Stream(dev)
+        self.sA = torch.cuda.Stream(dev, priority=-1)  # the critical chain wins dispatch when both queues are ready
         self.ev_in, self.ev_A = torch.cuda.Event(), torch.cuda.Event()
         main = torch.cuda.current_stream()
 
-        def run_A():
-            with torch.no_grad():
-                return net.depth_encoder.visual_encoder(dict(self.static))
+        B = self.rnn[0].shape[0]
+        d_out, m_out = net.depth_linear[1].out_features, net.map_linear[1].out_features
+        E, H = net.prev_action_embedding.embedding_dim, net._hidden_size
+        self._persist = dict(
+            state_in=torch.empty((B, d_out + m_out + E), dtype=torch.float32, device=dev),
+            x2=torch.empty((B, H + net.instruction_encoder.output_size + d_out + m_out + E), dtype=torch.float32,
+                           device=dev),
+        )
 
-        def run_B1():
+        def run_A():
+            net._stage, net._persist = "dep", self._persist
+            try:
+                with torch.no_grad():
+                    batch = dict(self.static)
+                    net.forward_hip(batch, self.rnn[0], self.prev[0], batch["not_done_masks"])
+            finally:
+                net._stage = net._persist = None
+
+        def run_B1(src):
             batch = dict(self.static)
             for t in self.transforms:
                 batch = t(batch)
-            net._stage = "pre"
+            net._stage, net._persist = "pre", self._persist
             try:
                 with torch.no_grad():
-                    net.forward_hip(batch, self.rnn[0], self.prev[0], batch["not_done_masks"])
+                    net.forward_hip(batch, self.rnn[src], self.prev[src], batch["not_done_masks"])
             finally:
-                net._stage = None
+                net._stage = net._persist = None
             return batch
 
-        def run_B2(src, batch, feats):
+        def run_B2(src, batch):
             dst = src ^ 1
             batch = dict(batch)
-            batch["depth_features"] = feats
-            net._stage = "post"
+            net._stage, net._persist = "post", self._persist
             net._rnn_out_buffer = self.rnn[dst]
             self.policy._action_out_buffer = self.prev[dst] if self.deterministic else None
             try:
@@ -130,7 +143,7 @@ class GraphedRollout:
                     if rnn.data_ptr() != self.rnn[dst].data_ptr():
                         self.rnn[dst].copy_(rnn)
             finally:
-                net._stage = None
+                net._stage = net._persist = None
                 net._rnn_out_buffer = None
                 self.policy._action_out_buffer = None
 
@@ -138,25 +151,31 @@ class GraphedRollout:
         s.wait_stream(main)
         with torch.cuda.stream(s):  # warm-up: tables, workspaces (per stream), folded weights
             for i in range(warmup):
-                f = run_A()
-                b = run_B1()
-                run_B2(i & 1, b, f)
+                run_A()
+                run_B2(i & 1, run_B1(i & 1))
         with torch.cuda.stream(self.sA):  # the side stream needs its own split-K workspace before capture
             run_A()
         main.wait_stream(s)
         torch.cuda.synchronize()
         self.gA = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.gA, stream=self.sA):
-            self._feats = run_A()
-        self.gB1 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.gB1):
-            self._batch = run_B1()
-        pool = self.gB1.pool()
+            run_A()
+        self._dep = net._stash_dep  # (depth features, k/v) live in gA's pool
+        # the previous action (read by the embedding in gB1) ping-pongs with the state: one gB1 per phase
+        self.gB1, pool = [], None
         for src in (0, 1):
-            gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr, pool=pool):
-                run_B2(src, self._batch, self._feats)
-            self.graphs.append(gr)
+            g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1, pool=pool):
+                batch = run_B1(src)
+            pool = g1.pool()
+            stash = net._stash
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, pool=pool):
+                net._stash, net._stash_dep = stash, self._dep
+                run_B2(src, batch)
+            self.gB1.append(g1)
+            self.graphs.append(g2)
+        self._keep = (batch, stash)
         self.phase = 0
 
     def _replay_split(self):
@@ -166,7 +185,7 @@ class GraphedRollout:
         with torch.cuda.stream(self.sA):
             self.gA.replay()
             self.ev_A.record(self.sA)
-        self.gB1.replay()
+        self.gB1[self.phase].replay()
         main.wait_event(self.ev_A)
         self.graphs[self.phase].replay()
 

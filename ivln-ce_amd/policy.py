@@ -187,10 +187,15 @@ class MapCMANet(Net):
         m_out = self.map_linear[1].out_features
         E = self.prev_action_embedding.embedding_dim
         # state_in = [dep_in | map_in | prev]; x2 = [state | text | dep' | map' | prev]
-        state_in = torch.empty((rows, d_out + m_out + E), dtype=torch.float32, device=dev)
         x2w = H + self.instruction_encoder.output_size + d_out + m_out + E
-        x2 = torch.empty((rows, x2w), dtype=torch.float32, device=dev)
+        persist = getattr(self, "_persist", None) if save is None else None  # graphed.py split mode
+        if persist is not None and persist["state_in"].shape[0] == rows:
+            state_in, x2 = persist["state_in"], persist["x2"]
+        else:
+            state_in = torch.empty((rows, d_out + m_out + E), dtype=torch.float32, device=dev)
+            x2 = torch.empty((rows, x2w), dtype=torch.float32, device=dev)
         dl, ml = self.depth_linear[1], self.map_linear[1]
+        o_txt, o_dep, o_map, o_prev = H, H + 256, H + 256 + d_out, H + 256 + d_out + m_out
 
         def _txt_branch(sv):
             t, ln = self.instruction_encoder(observations, sv)  # (rows,256,L)
@@ -224,19 +229,25 @@ class MapCMANet(Net):
         # The key/value projections depend only on their own encoder, so they run inside the branches.
         side = getattr(self, "_side_streams", None) if save is None else None
         stage = getattr(self, "_stage", None) if save is None else None
+        if stage == "dep":
+            # graphed.py, split mode: depth ResNet + its k/v projection + depth_linear as one graph on a side
+            # stream (they depend on nothing but the new depth image); results land in the persistent buffers
+            self._stash_dep = _dep_branch()
+            return None, None
         if stage == "pre":
-            # graphed.py, split mode: the instruction and map branches are captured as their own graph and
-            # run while the depth ResNet (a third graph, on another stream) is still in flight
+            # ... while the instruction and map branches (and the previous-action embedding) run as a second
+            # graph on the main stream
             txt, lengths, tk = _txt_branch(None)
             mp, mkv = _map_branch(None)
-            self._stash = dict(state_in=state_in, x2=x2, txt=(txt, lengths, tk), map=(mp, mkv))
+            ops.prev_action_embed(prev_actions, masks_u8, self.prev_action_embedding.weight,
+                                  state_in[:, d_out + m_out:], x2[:, o_prev:])
+            self._stash = dict(txt=(txt, lengths, tk), map=(mp, mkv))
             return None, None
         if stage == "post":
             st = self._stash
-            state_in, x2 = st["state_in"], st["x2"]
             txt, lengths, tk = st["txt"]
             mp, mkv = st["map"]
-            dep, dkv = _dep_branch()
+            dep, dkv = self._stash_dep
         elif side is None:
             txt, lengths, tk = _txt_branch(s_txt)
             dep, dkv = _dep_branch()
@@ -258,9 +269,9 @@ class MapCMANet(Net):
         L = txt.shape[2]
         Cd, Cm = dep.shape[1], mp.shape[1]
         P = dep.shape[2] * dep.shape[3]
-        o_txt, o_dep, o_map, o_prev = H, H + 256, H + 256 + d_out, H + 256 + d_out + m_out
-        ops.prev_action_embed(prev_actions, masks_u8, self.prev_action_embedding.weight, state_in[:, d_out + m_out:],
-                              x2[:, o_prev:])
+        if stage != "post":
+            ops.prev_action_embed(prev_actions, masks_u8, self.prev_action_embedding.weight,
+                                  state_in[:, d_out + m_out:], x2[:, o_prev:])
 
         rnn_out = getattr(self, "_rnn_out_buffer", None) if save is None else None  # graphed.py: persistent buffer
         if rnn_out is None:

@@ -1,0 +1,65 @@
+"""Where the split-graph step spends its time: event timestamps at the end of each of the three graphs."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from bench import gen_observations, make_policy  # noqa: E402
+from ivln_ce_amd.graphed import GraphedRollout  # noqa: E402
+from ivln_ce_amd.obs_transforms import GTSemanticsIterativeMapper  # noqa: E402
+
+B = 4
+dev = torch.device("cuda:0")
+cfg, policy = make_policy(dev)
+tr = GTSemanticsIterativeMapper.from_config(cfg)
+obs = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in o.items()} for o in gen_observations(B, 40, 1)]
+r = GraphedRollout(policy, [tr], obs[0], deterministic=True, streams="split")
+for i in range(20):
+    r.step(obs[i % 40])
+torch.cuda.synchronize()
+E = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
+acc = [0.0, 0.0, 0.0, 0.0]
+n = 100
+for i in range(n):
+    r.load(obs[i % 40])
+    main = torch.cuda.current_stream()
+    e0, eA, eB1, eEnd, eA0 = E(), E(), E(), E(), E()
+    e0.record(main)
+    r.ev_in.record(main)
+    r.sA.wait_event(r.ev_in)
+    with torch.cuda.stream(r.sA):
+        eA0.record(r.sA)
+        r.gA.replay()
+        eA.record(r.sA)
+        r.ev_A.record(r.sA)
+    r.gB1[r.phase].replay()
+    eB1.record(main)
+    main.wait_event(r.ev_A)
+    r.graphs[r.phase].replay()
+    eEnd.record(main)
+    r.phase ^= 1
+    torch.cuda.synchronize()
+    acc[0] += e0.elapsed_time(eA0)
+    acc[1] += e0.elapsed_time(eA)
+    acc[2] += e0.elapsed_time(eB1)
+    acc[3] += e0.elapsed_time(eEnd)
+print("per step (us), one step in flight at a time: gA start %.1f | gA end %.1f | gB1 end %.1f | step end %.1f"
+      % tuple(1e3 * a / n for a in acc))
+
+
+def alone(fn, stream, n=100):
+    torch.cuda.synchronize()
+    a, b = E(), E()
+    with torch.cuda.stream(stream):
+        a.record(stream)
+        for _ in range(n):
+            fn()
+        b.record(stream)
+    torch.cuda.synchronize()
+    return 1e3 * a.elapsed_time(b) / n
+
+
+print("alone (us): gA %.1f | gB1 %.1f | gB2 %.1f" % (alone(r.gA.replay, r.sA), alone(r.gB1[0].replay, torch.cuda.current_stream()),
+                                                   alone(r.graphs[0].replay, torch.cuda.current_stream())))
