@@ -46,10 +46,10 @@ def make_policy(device, seed=0):
     return cfg, pol.to(device).eval()
 
 
-def gen_observations(B, n_steps, seed):
+def gen_observations(B, n_steps, seed, with_rgb=False):
     from ivln_ce_amd.synthetic import SyntheticRollout
 
-    roll = SyntheticRollout(B=B, seed=seed)
+    roll = SyntheticRollout(B=B, seed=seed, with_rgb=with_rgb)
     return [roll.step() for _ in range(n_steps)]
 
 
@@ -221,6 +221,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs", type=int, default=4, help="parallel envs per GPU (configs[1]: 4)")
+    ap.add_argument("--pred-semantics", action="store_true",
+                    help="BASELINE configs[2]: RedNet-predicted semantics feed the mapper (not the headline workload; "
+                         "no CPU baseline / roofline legs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-update", action="store_true", help="skip the DAgger update-step leg (extra JSON object)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
@@ -250,13 +253,14 @@ def main():
     if world > 1:
         dist.barrier()
 
-    from ivln_ce_amd.obs_transforms import GTSemanticsIterativeMapper
+    from ivln_ce_amd.obs_transforms import GTSemanticsIterativeMapper, PredictedSemanticsIterativeMapper
 
     B, K, W = args.envs, args.steps, args.warmup
     cfg, policy = make_policy(dev)
-    mapper_tr = GTSemanticsIterativeMapper.from_config(cfg)
+    pred = args.pred_semantics
+    mapper_tr = (PredictedSemanticsIterativeMapper if pred else GTSemanticsIterativeMapper).from_config(cfg)
     n_pool = min(W + K, 240)
-    obs_cpu = gen_observations(B, n_pool, seed=1234 + rank)
+    obs_cpu = gen_observations(B, n_pool, seed=1234 + rank, with_rgb=pred)
     obs_dev = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in o.items()} for o in obs_cpu]
     state = {"rnn": torch.zeros(B, 2, 512, device=dev), "prev": torch.zeros(B, 1, dtype=torch.long, device=dev)}
 
@@ -299,7 +303,7 @@ def main():
     log(f"rank {rank}: timed region {el:.3f}s")
     # ---- DAgger update step (fwd + bwd + all-reduce + Adam): reported beside the headline ----
     update = None
-    if not args.no_update:
+    if not args.no_update and not pred:
         if use_graph:
             del runner  # graphs hold the activation pools
         log(f"rank {rank}: update-step leg")
@@ -316,7 +320,7 @@ def main():
                   "roofline": uinfo["roofline"]}
     # ---- roofline of the MFMA implicit-GEMM family: instrumented pass (not part of `value`) ----
     roofline = None
-    if rank == 0:
+    if rank == 0 and not pred:
         n_inst = min(20, K)
         with GemmTimer() as gt:
             for i in range(n_inst):
@@ -338,8 +342,10 @@ def main():
         "steps": K, "warmup": W, "ms_per_step": round(1e3 * el / K, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
-            "workload": "BASELINE configs[1]: MapCMA gt-semantics eval step = egocentric mapper + MapCMAPolicy.act, "
-                        f"{B} parallel envs per GPU, 256x256 depth + semantic12, 80-token instruction, random-init "
+            "workload": ("BASELINE configs[2]: MapCMA pred-semantics eval step = RedNet(rgb 224x224, depth) + egocentric "
+                         "mapper + MapCMAPolicy.act, " if pred else
+                         "BASELINE configs[1]: MapCMA gt-semantics eval step = egocentric mapper + MapCMAPolicy.act, ")
+                        + f"{B} parallel envs per GPU, 256x256 depth + semantic12, 80-token instruction, random-init "
                         "weights of the reference architecture",
             "envs_per_gpu": B, "parallelism": f"dp{world} (envs sharded, no data-path collective)",
             "launch": ("hipGraph replay, " + ("3 forked streams" if args.streams else ("1 stream" if args.single_stream else "3 graphs on 2 streams"))) if use_graph else "eager",
@@ -349,7 +355,7 @@ def main():
     if update is not None:
         out["update_step"] = update
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not pred:
             log("cpu baseline ...")
             out["cpu_baseline"] = cpu_baseline(obs_cpu, B)
         print(json.dumps(out), flush=True)
