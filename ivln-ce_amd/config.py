@@ -154,6 +154,9 @@ def _experiment_defaults() -> Config:
     _C.EVAL.USE_CKPT_CONFIG = False
     _C.EVAL.SAVE_RESULTS = True
     _C.EVAL.ITERATIVE_MAP_RESET = "iterative"
+    # (not a reference key) replay the eval step - mapper + policy.act - as captured hipGraphs
+    # (graphed.py); falls back to eager launches for sampled actions and the known-map transformers
+    _C.EVAL.USE_HIP_GRAPH = True
     _C.EVAL.ITERATIVE_GT_PATHS = "data/gt_ndtw.json"
     # --- IL (default.py:42-82) ---
     _C.IL = CN()

@@ -339,11 +339,36 @@ class BaseVLNCETrainer:
         return envs, recurrent_hidden_states, not_done_masks, prev_actions, batch, rgb_frames
 
     # -- observations -> batch ----------------------------------------------------------------
-    def _batch(self, observations, not_done_masks):
+    def _batch(self, observations, not_done_masks, transform=True):
         observations = extract_instruction_tokens(observations, self.config.TASK_CONFIG.TASK.INSTRUCTION_SENSOR_UUID)
         observations = add_batched_data_to_observations(observations, not_done_masks, "not_done_masks")
         batch = batch_obs(observations, self.device)
-        return observations, apply_obs_transforms_batch(batch, self.obs_transforms)
+        return observations, (apply_obs_transforms_batch(batch, self.obs_transforms) if transform else batch)
+
+    def _graph_eligible(self):
+        """The step can be captured when actions are deterministic and every transformer is an iterative
+        mapper (the known-map ones read files on episode reset: host work that cannot live in a graph)."""
+        cfg = self.config
+        return (bool(getattr(cfg.EVAL, "USE_HIP_GRAPH", True)) and not cfg.EVAL.SAMPLE and self.device.type == "cuda"
+                and len(self.obs_transforms) > 0
+                and all(type(t).__name__.endswith("IterativeMapper") for t in self.obs_transforms))
+
+    def _make_runner(self, batch, rnn_states, prev_actions, first):
+        """GraphedRollout for the current number of active envs, seeded with the carried state.  The first
+        capture warms up by running the step (the mapper is reset afterwards: nothing has been mapped yet
+        and the first real step arrives with not_done_masks == 0 anyway); later captures - envs were paused,
+        the batch shrank - must not touch the mapper's world cloud, so they capture without executing."""
+        from .graphed import GraphedRollout
+
+        runner = GraphedRollout(self.policy, self.obs_transforms, batch, deterministic=True, streams="split",
+                                warmup=2 if first else 0)
+        if first:
+            for t in self.obs_transforms:
+                if getattr(t, "mapping_module", None) is not None:
+                    t.mapping_module.reset()
+        runner.rnn[runner.phase].copy_(rnn_states)
+        runner.prev[runner.phase].copy_(prev_actions)
+        return runner
 
     # -- eval -------------------------------------------------------------------------------------
     def eval(self):
@@ -383,17 +408,27 @@ class BaseVLNCETrainer:
         prev_actions = torch.zeros(n, 1, device=self.device, dtype=torch.long)
         not_done_masks = torch.zeros(n, 1, dtype=torch.uint8, device=self.device)
         observations = envs.reset()
-        observations, batch = self._batch(observations, not_done_masks)
+        use_graph = self._graph_eligible()
+        observations, batch = self._batch(observations, not_done_masks, transform=not use_graph)
+        runner, captured = None, False
         stats_episodes = {}
         remaining = list(envs.number_of_episodes)
         t0 = time.time()
         while envs.num_envs > 0:
-            with torch.no_grad():
-                actions, rnn_states = self.policy.act_iterative(
-                    batch, rnn_states, prev_actions, not_done_masks, not_done_masks, not_done_masks, not_done_masks,
-                    deterministic=not config.EVAL.SAMPLE,
-                )
-                prev_actions.copy_(actions)
+            if use_graph:
+                # mapper + policy.act replayed as captured graphs; state lives in the runner's buffers
+                if runner is None:
+                    runner = self._make_runner(batch, rnn_states, prev_actions, first=not captured)
+                    captured = True
+                actions = runner.step(batch)
+                rnn_states, prev_actions = runner.rnn_states, actions
+            else:
+                with torch.no_grad():
+                    actions, rnn_states = self.policy.act_iterative(
+                        batch, rnn_states, prev_actions, not_done_masks, not_done_masks, not_done_masks,
+                        not_done_masks, deterministic=not config.EVAL.SAMPLE,
+                    )
+                    prev_actions.copy_(actions)
             current_episodes = envs.current_episodes()
             outputs = envs.step([a[0].item() for a in actions])
             observations, _, dones, infos = [list(x) for x in zip(*outputs)]
@@ -405,12 +440,13 @@ class BaseVLNCETrainer:
                     remaining[i] -= 1
                     if remaining[i] <= 0:
                         envs_to_pause.append(i)
-            observations, batch = self._batch(observations, not_done_masks)
+            observations, batch = self._batch(observations, not_done_masks, transform=not use_graph)
             if envs_to_pause:
                 for idx in reversed(envs_to_pause):
                     remaining.pop(idx)
                 envs, rnn_states, not_done_masks, prev_actions, batch, _ = self._pause_envs(
                     envs_to_pause, envs, rnn_states, not_done_masks, prev_actions, batch)
+                runner = None  # fewer rows: capture again for the new batch size, seeded with the kept rows
         agent_paths, gt_paths = envs.dtw_data(), envs.gt_paths()
         gathered = D.gather_objects((stats_episodes, agent_paths, gt_paths))
         envs.close()

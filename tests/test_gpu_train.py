@@ -182,3 +182,30 @@ def test_dagger_trainer_end_to_end(tmp_path, trainer):
     res = tr2.eval()[0]
     assert res["episodes"] == 16 and 0.0 < res["t_ndtw"] <= 1.0
     assert os.path.exists(tmp_path / "res" / "stats_ckpt_0_val_seen.json")
+
+
+def test_eval_with_graph_replay_matches_eager_eval(tmp_path):
+    """The trainer's eval loop replays mapper + policy.act as captured graphs by default
+    (EVAL.USE_HIP_GRAPH); per-episode stats and t-nDTW must equal the eager loop's exactly, including across
+    the re-captures when envs run out of episodes and are paused."""
+    import ivln_ce_amd  # noqa: F401
+    from ivln_ce_amd import trainers  # noqa: F401
+    from ivln_ce_amd.config import get_config
+    from ivln_ce_amd.registry import baseline_registry
+
+    out = {}
+    for mode in (True, False):
+        torch.manual_seed(0)
+        cfg = get_config(opts=[
+            "TRAINER_NAME", "dagger", "NUM_ENVIRONMENTS", 3, "MODEL.policy_name", "MapCMAPolicy",
+            "MODEL.INSTRUCTION_ENCODER.use_pretrained_embeddings", False, "MODEL.DEPTH_ENCODER.ddppo_checkpoint", "NONE",
+            "RL.POLICY.OBS_TRANSFORMS.ENABLED_TRANSFORMS", ["GTSemanticsIterativeMapper"],
+            "RESULTS_DIR", str(tmp_path / f"res{int(mode)}"), "EVAL_CKPT_PATH_DIR", str(tmp_path / "none.pth"),
+            "EVAL.USE_HIP_GRAPH", mode, "EVAL.SAVE_RESULTS", False,
+        ])
+        tr = baseline_registry.get_trainer("dagger")(cfg)
+        res = tr._eval_checkpoint(str(tmp_path / "none.pth"))
+        res.pop("eval_seconds")
+        out[mode] = res
+    assert out[True] == out[False], f"graph {out[True]} vs eager {out[False]}"
+    assert out[True]["episodes"] > 0
