@@ -225,6 +225,7 @@ def main():
                     help="BASELINE configs[2]: RedNet-predicted semantics feed the mapper (not the headline workload; "
                          "no CPU baseline / roofline legs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pred-leg", action="store_true", help="skip the pred-semantics leg (extra JSON object)")
     ap.add_argument("--no-update", action="store_true", help="skip the DAgger update-step leg (extra JSON object)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--single-stream", action="store_true",
@@ -337,6 +338,34 @@ def main():
             "kernel_ms_per_step": round(ms / n_inst, 4),
         }
 
+    # ---- configs[2]: RedNet-predicted semantics feeding the mapper (extra object, not the headline) ----
+    pred_leg = None
+    if not pred and not args.no_pred_leg:
+        from ivln_ce_amd.graphed import GraphedRollout
+
+        log(f"rank {rank}: pred-semantics leg")
+        ptr = PredictedSemanticsIterativeMapper.from_config(cfg)
+        pobs = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in o.items()}
+                for o in gen_observations(B, 24, seed=4321 + rank, with_rgb=True)]
+        prun = GraphedRollout(policy, [ptr], pobs[0], deterministic=True, streams="split")
+        for i in range(6):
+            prun.step(pobs[i % 24])
+        barrier()
+        pk = 40
+        t0 = time.perf_counter()
+        for i in range(pk):
+            prun.step(pobs[(6 + i) % 24])
+        barrier()
+        pel = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([pel], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            pel = float(t.item())
+        pred_leg = {"value": round(world * B * pk / pel, 1), "unit": "env-steps/s", "ms_per_step": round(1e3 * pel / pk, 3),
+                    "steps": pk, "what": f"BASELINE configs[2]: RedNet(rgb 224x224 + depth) -> labels -> mapper -> "
+                                         f"MapCMAPolicy.act, {B} envs per GPU, graph replay"}
+        del prun
+
     out = {
         "metric": METRIC, "value": round(world * B * K / el, 2), "unit": "env-steps/s", "n_gpus": world,
         "steps": K, "warmup": W, "ms_per_step": round(1e3 * el / K, 4), "higher_is_better": True, "scaling": "weak",
@@ -354,6 +383,8 @@ def main():
     }
     if update is not None:
         out["update_step"] = update
+    if pred_leg is not None:
+        out["pred_semantics_step"] = pred_leg
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not pred:
             log("cpu baseline ...")
