@@ -356,11 +356,15 @@ extern "C" int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream) {
         if (nblocks(64, 128) >= 512) tile = 4;
     }
     if (d.tile_override > 0 && d.tile_override <= 5) tile = d.tile_override - 1;
+    static const int vec_tile_env = getenv("IVLN_VEC_TILE") ? atoi(getenv("IVLN_VEC_TILE")) : -1;  // tuning
     // contiguous operand modes (1x1 conv, linear): float4-staged kernel with 32-deep K tiles
     // (gemm_vec.hip); tile_override 7 insists on it, 1..5 pin the scalar-gather kernel
     const bool vec = (d.tile_override == 0 || d.tile_override == 7) && ivln_gemm_vec_eligible(d);
     if (d.tile_override == 7 && !vec) return IVLN_E_UNSUPPORTED;
     const int bk = vec ? 32 : BK;
+    // the float4-staged kernel is fastest at 64x64 (~100 VGPRs: four waves per SIMD; 64x128 and 128x128
+    // measured 90 / 79 vs 94 TFLOP/s on 1024x4096x1024 and lose more on the small 1x1 convs)
+    if (vec && tile != 1 && tile != 2) tile = vec_tile_env >= 0 ? vec_tile_env : 0;
     const int BM = tile == 1 ? 32 : (tile == 2 || tile == 3 ? 128 : 64);
     const int BN = tile == 1 ? 128 : (tile == 2 ? 32 : (tile == 3 || tile == 4 ? 128 : 64));
     // split-K when the output grid cannot fill the chip and K is deep

@@ -23,7 +23,7 @@ constexpr int BKV = 32;
 enum { LAY_K = 0, LAY_R = 1 };
 
 template <int WM, int WN, int TM, int TN, int ALAY, int BLAY>
-__global__ __launch_bounds__(256) void k_gemm_vec(const ivln_gemm_desc p) {
+__global__ __launch_bounds__(256, 2) void k_gemm_vec(const ivln_gemm_desc p) {
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
     constexpr int LDK = BKV + 4;  // [row][k] layout row stride (words)
     constexpr int A_WORDS = ALAY == LAY_K ? BM * LDK : BKV * BM;
@@ -127,44 +127,48 @@ __global__ __launch_bounds__(256) void k_gemm_vec(const ivln_gemm_desc p) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[tm][tn][i] = 0.f;
 
-    // k slot `half` of MFMA step j holds k = 16*half + j
+    // k slot `half` of MFMA step j holds k = 16*half + j; operands are fetched 8 steps at a time (two
+    // float4 per k-contiguous operand) to keep the 128x128 tile under 256 VGPRs
     auto compute = [&]() {
-        float a[TM][BKV / 2], b[TN][BKV / 2];
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            const int ml = (wm * TM + tm) * 32 + l31;
-            if constexpr (ALAY == LAY_K) {
+        for (int c = 0; c < 2; ++c) {
+            float a[TM][8], b[TN][8];
 #pragma unroll
-                for (int i = 0; i < BKV / 8; ++i) {
-                    const float4 v = *reinterpret_cast<const float4*>(&As[ml * LDK + half * (BKV / 2) + 4 * i]);
-                    a[tm][4 * i] = v.x, a[tm][4 * i + 1] = v.y, a[tm][4 * i + 2] = v.z, a[tm][4 * i + 3] = v.w;
+            for (int tm = 0; tm < TM; ++tm) {
+                const int ml = (wm * TM + tm) * 32 + l31;
+                if constexpr (ALAY == LAY_K) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const float4 v = *reinterpret_cast<const float4*>(&As[ml * LDK + half * (BKV / 2) + 8 * c + 4 * i]);
+                        a[tm][4 * i] = v.x, a[tm][4 * i + 1] = v.y, a[tm][4 * i + 2] = v.z, a[tm][4 * i + 3] = v.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) a[tm][j] = As[(half * (BKV / 2) + 8 * c + j) * BM + ml];
                 }
-            } else {
-#pragma unroll
-                for (int j = 0; j < BKV / 2; ++j) a[tm][j] = As[(half * (BKV / 2) + j) * BM + ml];
             }
-        }
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int nl = (wn * TN + tn) * 32 + l31;
-            if constexpr (BLAY == LAY_K) {
+            for (int tn = 0; tn < TN; ++tn) {
+                const int nl = (wn * TN + tn) * 32 + l31;
+                if constexpr (BLAY == LAY_K) {
 #pragma unroll
-                for (int i = 0; i < BKV / 8; ++i) {
-                    const float4 v = *reinterpret_cast<const float4*>(&Bs[nl * LDK + half * (BKV / 2) + 4 * i]);
-                    b[tn][4 * i] = v.x, b[tn][4 * i + 1] = v.y, b[tn][4 * i + 2] = v.z, b[tn][4 * i + 3] = v.w;
+                    for (int i = 0; i < 2; ++i) {
+                        const float4 v = *reinterpret_cast<const float4*>(&Bs[nl * LDK + half * (BKV / 2) + 8 * c + 4 * i]);
+                        b[tn][4 * i] = v.x, b[tn][4 * i + 1] = v.y, b[tn][4 * i + 2] = v.z, b[tn][4 * i + 3] = v.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) b[tn][j] = Bs[(half * (BKV / 2) + 8 * c + j) * BN + nl];
                 }
-            } else {
-#pragma unroll
-                for (int j = 0; j < BKV / 2; ++j) b[tn][j] = Bs[(half * (BKV / 2) + j) * BN + nl];
             }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][j], b[tn][j], acc[tm][tn], 0, 0, 0);
         }
-#pragma unroll
-        for (int j = 0; j < BKV / 2; ++j)
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][j], b[tn][j], acc[tm][tn], 0, 0, 0);
     };
 
     if (kbeg < kend) {
@@ -237,13 +241,14 @@ bool ivln_gemm_vec_eligible(const ivln_gemm_desc& d) {
     return true;
 }
 
-// tile: 0 = 64x64, 1 = 32x128, 2 = 128x32, 4 = 64x128 (numbering of ivln_gemm_f32)
+// tile: 0 = 64x64, 1 = 32x128, 2 = 128x32, 3 = 128x128, 4 = 64x128 (numbering of ivln_gemm_f32)
 int ivln_gemm_vec_launch(const ivln_gemm_desc& d, hipStream_t s, int tile) {
     const int alay = d.amode == AMODE_MK ? LAY_K : LAY_R;
     const int blay = d.bmode == BMODE_NK ? LAY_K : LAY_R;
     switch (tile) {
         case 1: launch_vec<1, 4, 1, 1>(d, s, alay, blay); break;
         case 2: launch_vec<4, 1, 1, 1>(d, s, alay, blay); break;
+        case 3: launch_vec<2, 2, 2, 2>(d, s, alay, blay); break;
         case 4: launch_vec<2, 2, 1, 2>(d, s, alay, blay); break;
         case 0: launch_vec<2, 2, 1, 1>(d, s, alay, blay); break;
         default: return IVLN_E_UNSUPPORTED;
