@@ -243,7 +243,13 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if os.environ.get("IVLN_BENCH_ONE_DEVICE"):
+            # control-flow smoke test of the multi-rank path on a 1-GPU box: every rank on cuda:0, gloo
+            # instead of RCCL (which refuses two ranks on one device).  Not a measurement.
+            local_rank = 0
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
