@@ -57,8 +57,18 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict_
     const int r0 = blockIdx.y * rows_per_split;
     const int r1 = min(rows, r0 + rows_per_split);
     float s = 0.f;
-    if (c < cols)
-        for (int r = r0 + sub; r < r1; r += 4) s += x[(int64_t)r * ld + c];
+    if (c < cols) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // four loads in flight per thread
+        int r = r0 + sub;
+        for (; r + 12 < r1; r += 16) {
+            a0 += x[(int64_t)r * ld + c];
+            a1 += x[(int64_t)(r + 4) * ld + c];
+            a2 += x[(int64_t)(r + 8) * ld + c];
+            a3 += x[(int64_t)(r + 12) * ld + c];
+        }
+        for (; r < r1; r += 4) a0 += x[(int64_t)r * ld + c];
+        s = (a0 + a1) + (a2 + a3);
+    }
     red[sub][threadIdx.x & 63] = s;
     __syncthreads();
     if (sub == 0 && c < cols)
@@ -81,9 +91,21 @@ __global__ __launch_bounds__(256) void k_nchw_chansum_partial(const float* __res
     const int c = blockIdx.x, sp = blockIdx.y, S = gridDim.y;
     const int i0 = sp * imgs_per_split, i1 = min(N, i0 + imgs_per_split);
     float s = 0.f;
-    for (int img = i0; img < i1; ++img) {
-        const float* xp = x + ((int64_t)img * C + c) * HW;
-        for (int i = threadIdx.x; i < HW; i += 256) s += xp[i];
+    if ((HW & 3) == 0 && ((uintptr_t)x & 15) == 0) {  // 16-byte loads, four independent partial sums
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int img = i0; img < i1; ++img) {
+            const float* xp = x + ((int64_t)img * C + c) * HW;
+            for (int i = threadIdx.x * 4; i < HW; i += 1024) {
+                const float4 v = *reinterpret_cast<const float4*>(xp + i);
+                a.x += v.x, a.y += v.y, a.z += v.z, a.w += v.w;
+            }
+        }
+        s = (a.x + a.y) + (a.z + a.w);
+    } else {
+        for (int img = i0; img < i1; ++img) {
+            const float* xp = x + ((int64_t)img * C + c) * HW;
+            for (int i = threadIdx.x; i < HW; i += 256) s += xp[i];
+        }
     }
     s = block_sum(s, red);
     if (threadIdx.x == 0) partial[(int64_t)c * S + sp] = s;
@@ -364,15 +386,39 @@ __global__ __launch_bounds__(256) void k_cbra_bwd_stats(const float* __restrict_
     const int Ho = H / 2, Wo = W / 2, HW = H * W;
     const float sc = scale[c], sh = shift[c], mu = mean[c], rs = rstd[c];
     float s1 = 0.f, s2 = 0.f;
-    for (int img = i0; img < i1; ++img) {
-        const float* yp = y + ((int64_t)img * C + c) * HW;
-        const float* dp = dout + ((int64_t)img * C + c) * Ho * Wo;
-        for (int i = threadIdx.x; i < HW; i += 256) {
-            int h = i / W, w = i - h * W;
-            float yv = yp[i];
-            float dz = fmaf(yv, sc, sh) > 0.f ? 0.25f * dp[(h >> 1) * Wo + (w >> 1)] : 0.f;
-            s1 += dz;
-            s2 += dz * (yv - mu) * rs;
+    if ((W & 3) == 0 && (((uintptr_t)y | (uintptr_t)dout) & 15) == 0) {
+        // four consecutive pixels of a row per thread: one float4 of y, one float2 of the pooled gradient
+        float t1 = 0.f, t2 = 0.f;
+        for (int img = i0; img < i1; ++img) {
+            const float* yp = y + ((int64_t)img * C + c) * HW;
+            const float* dp = dout + ((int64_t)img * C + c) * Ho * Wo;
+            for (int i = threadIdx.x * 4; i < HW; i += 1024) {
+                const int h = i / W, w = i - h * W;
+                const float4 yv = *reinterpret_cast<const float4*>(yp + i);
+                const float2 dv = *reinterpret_cast<const float2*>(dp + (h >> 1) * Wo + (w >> 1));
+                const float d0 = fmaf(yv.x, sc, sh) > 0.f ? 0.25f * dv.x : 0.f;
+                const float d1 = fmaf(yv.y, sc, sh) > 0.f ? 0.25f * dv.x : 0.f;
+                const float d2 = fmaf(yv.z, sc, sh) > 0.f ? 0.25f * dv.y : 0.f;
+                const float d3 = fmaf(yv.w, sc, sh) > 0.f ? 0.25f * dv.y : 0.f;
+                s1 += d0 + d1;
+                t1 += d2 + d3;
+                s2 += d0 * (yv.x - mu) * rs + d1 * (yv.y - mu) * rs;
+                t2 += d2 * (yv.z - mu) * rs + d3 * (yv.w - mu) * rs;
+            }
+        }
+        s1 += t1;
+        s2 += t2;
+    } else {
+        for (int img = i0; img < i1; ++img) {
+            const float* yp = y + ((int64_t)img * C + c) * HW;
+            const float* dp = dout + ((int64_t)img * C + c) * Ho * Wo;
+            for (int i = threadIdx.x; i < HW; i += 256) {
+                int h = i / W, w = i - h * W;
+                float yv = yp[i];
+                float dz = fmaf(yv, sc, sh) > 0.f ? 0.25f * dp[(h >> 1) * Wo + (w >> 1)] : 0.f;
+                s1 += dz;
+                s2 += dz * (yv - mu) * rs;
+            }
         }
     }
     s1 = block_sum(s1, red);
@@ -381,6 +427,44 @@ __global__ __launch_bounds__(256) void k_cbra_bwd_stats(const float* __restrict_
         partial[((int64_t)c * S + sp) * 2] = s1;      // -> dbeta
         partial[((int64_t)c * S + sp) * 2 + 1] = s2;  // -> dgamma
     }
+}
+
+// four pixels of a row per thread (W % 4 == 0, 16-byte aligned tensors)
+__global__ __launch_bounds__(256) void k_cbra_bwd_apply4(const float* __restrict__ dout, const float* __restrict__ y,
+                                                         const float* __restrict__ scale,
+                                                         const float* __restrict__ shift,
+                                                         const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd,
+                                                         const float* __restrict__ dgamma,
+                                                         const float* __restrict__ dbeta, int N, int C, int H, int W,
+                                                         int train, float* __restrict__ dy) {
+    const int64_t idx = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const int HW = H * W, Ho = H / 2, Wo = W / 2;
+    if (idx >= (int64_t)N * C * HW) return;
+    const int i = (int)(idx % HW);
+    const int nc = (int)(idx / HW);
+    const int c = nc % C;
+    const int h = i / W, w = i - h * W;
+    const float4 yv = *reinterpret_cast<const float4*>(y + idx);
+    const float2 dv = *reinterpret_cast<const float2*>(dout + (int64_t)nc * Ho * Wo + (h >> 1) * Wo + (w >> 1));
+    const float sc = scale[c], sh = shift[c];
+    float yy[4] = {yv.x, yv.y, yv.z, yv.w};
+    float dd[4] = {dv.x, dv.x, dv.y, dv.y};
+    float o[4];
+    const float M = (float)N * (float)HW;
+    const float mu = train ? mean[c] : 0.f, rs = train ? rstd[c] : 0.f;
+    const float b_m = train ? dbeta[c] / M : 0.f, g_m = train ? dgamma[c] / M : 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float dz = fmaf(yy[k], sc, sh) > 0.f ? 0.25f * dd[k] : 0.f;
+        if (train) {
+            const float xhat = (yy[k] - mu) * rs;
+            o[k] = sc * (dz - b_m - xhat * g_m);
+        } else {
+            o[k] = dz * sc;
+        }
+    }
+    *reinterpret_cast<float4*>(dy + idx) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
 __global__ __launch_bounds__(256) void k_cbra_bwd_apply(const float* __restrict__ dout, const float* __restrict__ y,
@@ -661,8 +745,12 @@ int ivln_cbra_bwd_f32(const float* dout, const float* y, const float* scale, con
     hipLaunchKernelGGL(k_cbra_bwd_stats, dim3(C, S), dim3(256), 0, (hipStream_t)stream, dout, y, scale, shift, mean,
                        rstd, N, C, H, W, ips, ws);
     hipLaunchKernelGGL(k_chan_final, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, ws, S, C, 2, dbeta, dgamma);
-    hipLaunchKernelGGL(k_cbra_bwd_apply, dim3(nblk((int64_t)N * C * H * W)), dim3(256), 0, (hipStream_t)stream, dout,
-                       y, scale, shift, mean, rstd, dgamma, dbeta, N, C, H, W, train, dy);
+    if ((W & 3) == 0 && (((uintptr_t)y | (uintptr_t)dout | (uintptr_t)dy) & 15) == 0)
+        hipLaunchKernelGGL(k_cbra_bwd_apply4, dim3(nblk((int64_t)N * C * H * W / 4)), dim3(256), 0, (hipStream_t)stream,
+                           dout, y, scale, shift, mean, rstd, dgamma, dbeta, N, C, H, W, train, dy);
+    else
+        hipLaunchKernelGGL(k_cbra_bwd_apply, dim3(nblk((int64_t)N * C * H * W)), dim3(256), 0, (hipStream_t)stream,
+                           dout, y, scale, shift, mean, rstd, dgamma, dbeta, N, C, H, W, train, dy);
     return LAUNCH_OK();
 }
 
