@@ -240,6 +240,14 @@ int ivln_gru_bwd_elem_f32(const float* dout, int64_t ld_dout, const float* dh_ca
                           const float* z, const float* n, const float* ghn, const float* h_prev, int64_t ldh,
                           const uint8_t* mask, int rows, int H, float* dgi, float* dgh, float* dhz,
                           float* hp_out, void* stream);
+/* one full BPTT step of the masked GRU in one launch: dh_prev = (dgh_t . W_hh + dhz) * mask_t (whh_t = W_hh^T,
+ * (H, 3H)) followed by the element part of step t-1 (ivln_gru_bwd_elem_f32 with that carry) on the same
+ * hidden unit; dhz (rows, H) is read (step t) and overwritten (step t-1) in place.  r/z/n/ghn, h_prev,
+ * mask_prev, dout_prev and the outputs are the step t-1 slices. */
+int ivln_gru_bwd_step_f32(const float* dgh_t, int64_t ld_dgh, const float* whh_t, const uint8_t* mask_t,
+                          const float* dout_prev, int64_t ld_dout, const float* r, const float* z, const float* n,
+                          const float* ghn, const float* h_prev, int64_t ldh, const uint8_t* mask_prev, int rows, int H,
+                          float* dhz, float* dgi_prev, float* dgh_prev, float* hp_prev, void* stream);
 /* y[r][o] = (W[o].x[r] + add[r][o]) * (rowmask[r] != 0)  (dh_prev of the GRU BPTT) */
 int ivln_linear_skinny_ex_f32(const float* x, int64_t ldx, const float* W, const float* add, int64_t ld_add,
                               const uint8_t* rowmask, float* y, int64_t ldy, int rows, int K, int O,

@@ -274,6 +274,66 @@ __global__ __launch_bounds__(256) void k_linear_skinny_ex(const float* __restric
     }
 }
 
+// One BPTT step of the masked GRU in ONE launch: block j first finishes step t for hidden unit j,
+//   dh_prev[row][j] = (W_hh^T[j] . dgh_t[row] + dhz[row][j]) * mask_t[row]        (k_linear_skinny_ex)
+// and, since the element part of step t-1 for unit j needs nothing but that value, runs it right away
+// (k_gru_bwd_elem on column j).  Halves the launches of the BPTT chain (2 x 126 per GRU per update).
+__global__ __launch_bounds__(256) void k_gru_bwd_step(
+    const float* __restrict__ dgh_t, int64_t ld_dgh, const float* __restrict__ Wt, const uint8_t* __restrict__ mask_t,
+    const float* __restrict__ dout_p, int64_t ld_dout, const float* __restrict__ r, const float* __restrict__ z,
+    const float* __restrict__ n, const float* __restrict__ ghn, const float* __restrict__ h_pp, int64_t ldh,
+    const uint8_t* __restrict__ mask_p, int rows, int H, float* __restrict__ dhz, float* __restrict__ dgi_p,
+    float* __restrict__ dgh_p, float* __restrict__ hp_p) {
+    const int j = blockIdx.x;
+    const int l = threadIdx.x & 31, rr = threadIdx.x >> 5;
+    const int K = 3 * H;
+    const float* wr = Wt + (int64_t)j * K;
+    for (int r0 = 0; r0 < rows; r0 += 8) {
+        const int row = r0 + rr;
+        const bool row_ok = row < rows;
+        const int rowc = row_ok ? row : 0;
+        const float* xr = dgh_t + (int64_t)rowc * ld_dgh;
+        // the element part's inputs do not depend on the matvec: fetch them first, under its loads
+        const int idx = rowc * H + j;
+        const float e_dout = dout_p[(int64_t)rowc * ld_dout + j], e_dhz = dhz[idx];
+        const float e_h = h_pp[(int64_t)rowc * ldh + j];
+        const float rg = r[idx], zg = z[idx], ng = n[idx], gh = ghn[idx];
+        const bool e_mt = mask_t[rowc] != 0, e_mp = mask_p[rowc] != 0;
+        float a0 = 0.f, a1 = 0.f;
+        for (int k = l * 4; k < K; k += 128) {
+            const float4 wv = *reinterpret_cast<const float4*>(wr + k);
+            const float4 xv = *reinterpret_cast<const float4*>(xr + k);
+            a0 = fmaf(wv.x, xv.x, a0);
+            a1 = fmaf(wv.y, xv.y, a1);
+            a0 = fmaf(wv.z, xv.z, a0);
+            a1 = fmaf(wv.w, xv.w, a1);
+        }
+        float v = a0 + a1;
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (l == 0 && row_ok) {
+            v = e_mt ? v + e_dhz : 0.f;  // dh carried into step t-1
+            // ---- element part of step t-1 (k_gru_bwd_elem) ----
+            const float dh = e_dout + v;
+            const float hp = e_mp ? e_h : 0.f;
+            const float dn = dh * (1.f - zg);
+            const float dz = dh * (hp - ng);
+            const float dn_pre = dn * (1.f - ng * ng);
+            const float dz_pre = dz * zg * (1.f - zg);
+            const float dr_pre = dn_pre * gh * rg * (1.f - rg);
+            const int64_t o = (int64_t)row * 3 * H + j;
+            dgi_p[o] = dr_pre;
+            dgi_p[o + H] = dz_pre;
+            dgi_p[o + 2 * H] = dn_pre;
+            dgh_p[o] = dr_pre;
+            dgh_p[o + H] = dz_pre;
+            dgh_p[o + 2 * H] = dn_pre * rg;
+            dhz[idx] = dh * zg;
+            hp_p[idx] = hp;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Bidirectional LSTM BPTT (forward: k_lstm_bidir).  grid (B, 2); 4H = 512 threads.  Thread
 // (k = tid % H, part = tid / H) keeps W_hh[part*H .. part*H+H-1][k] (a column slice) in registers so
@@ -715,6 +775,17 @@ int ivln_gru_bwd_elem_f32(const float* dout, int64_t ld_dout, const float* dh_ca
                           int rows, int H, float* dgi, float* dgh, float* dhz, float* hp_out, void* stream) {
     hipLaunchKernelGGL(k_gru_bwd_elem, dim3(nblk((int64_t)rows * H)), dim3(256), 0, (hipStream_t)stream, dout, ld_dout,
                        dh_carry, r, z, n, ghn, h_prev, ldh, mask, rows, H, dgi, dgh, dhz, hp_out);
+    return LAUNCH_OK();
+}
+
+int ivln_gru_bwd_step_f32(const float* dgh_t, int64_t ld_dgh, const float* whh_t, const uint8_t* mask_t,
+                          const float* dout_prev, int64_t ld_dout, const float* r, const float* z, const float* n,
+                          const float* ghn, const float* h_prev, int64_t ldh, const uint8_t* mask_prev, int rows, int H,
+                          float* dhz, float* dgi_prev, float* dgh_prev, float* hp_prev, void* stream) {
+    if ((H & 3) || (ld_dgh & 3) || rows <= 0) return IVLN_E_INVALID;
+    hipLaunchKernelGGL(k_gru_bwd_step, dim3(H), dim3(256), 0, (hipStream_t)stream, dgh_t, ld_dgh, whh_t, mask_t,
+                       dout_prev, ld_dout, r, z, n, ghn, h_prev, ldh, mask_prev, rows, H, dhz, dgi_prev, dgh_prev,
+                       hp_prev);
     return LAUNCH_OK();
 }
 

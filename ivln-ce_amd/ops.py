@@ -631,6 +631,20 @@ def gru_bwd_elem(dout, dh_carry, r, z, n, ghn, h_prev, mask, dgi, dgh, dhz, hp_o
     )
 
 
+def gru_bwd_step(dgh_t, whh_t, mask_t, dout_prev, r, z, n, ghn, h_prev, mask_prev, dhz, dgi_prev, dgh_prev, hp_prev):
+    """Fused BPTT step: carry of step t (matvec + dhz, masked) -> element part of step t-1."""
+    rows, H = r.shape
+    L = _T()
+    L.ivln_gru_bwd_step_f32.argtypes = [vp, i64, vp, vp, vp, i64, vp, vp, vp, vp, vp, i64, vp, i32, i32, vp, vp, vp, vp,
+                                        vp]
+    check(
+        L.ivln_gru_bwd_step_f32(_p(dgh_t), dgh_t.stride(0), dptr(whh_t), _p(mask_t), _p(dout_prev), dout_prev.stride(0),
+                                _p(r), _p(z), _p(n), _p(ghn), _p(h_prev), h_prev.stride(0), _p(mask_prev), rows, H,
+                                _p(dhz), _p(dgi_prev), _p(dgh_prev), _p(hp_prev), stream_ptr()),
+        "ivln_gru_bwd_step_f32",
+    )
+
+
 def linear_skinny_ex(x, W, add, rowmask, out):
     rows, K = x.shape
     O = W.shape[0]

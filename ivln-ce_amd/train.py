@@ -76,17 +76,15 @@ def _gru_backward(enc, s, d_out, G):
     dgh = torch.empty((rows, 3 * H), dtype=torch.float32, device=dev)
     hp = torch.empty((rows, H), dtype=torch.float32, device=dev)
     dhz = torch.empty((N, H), dtype=torch.float32, device=dev)
-    carry = [torch.empty((N, H), dtype=torch.float32, device=dev) for _ in range(2)]
-    dh_carry = None
-    for t in range(T - 1, -1, -1):
-        sl = slice(t * N, (t + 1) * N)
-        h_prev = h0 if t == 0 else out[(t - 1) * N: t * N]
-        ops.gru_bwd_elem(d_out[sl], dh_carry, s["r"][sl], s["z"][sl], s["n"][sl], s["ghn"][sl], h_prev, masks[sl],
-                         dgi[sl], dgh[sl], dhz, hp[sl])
-        if t > 0:
-            nxt = carry[t & 1]
-            ops.linear_skinny_ex(dgh[sl], whh_t, dhz, masks[sl], nxt)
-            dh_carry = nxt
+    # step T-1: element part alone; every earlier step t-1 rides in the launch that finishes step t
+    sl = slice((T - 1) * N, T * N)
+    ops.gru_bwd_elem(d_out[sl], None, s["r"][sl], s["z"][sl], s["n"][sl], s["ghn"][sl],
+                     h0 if T == 1 else out[(T - 2) * N: (T - 1) * N], masks[sl], dgi[sl], dgh[sl], dhz, hp[sl])
+    for t in range(T - 1, 0, -1):
+        sl, sp = slice(t * N, (t + 1) * N), slice((t - 1) * N, t * N)
+        h_pp = h0 if t == 1 else out[(t - 2) * N: (t - 1) * N]
+        ops.gru_bwd_step(dgh[sl], whh_t, masks[sl], d_out[sp], s["r"][sp], s["z"][sp], s["n"][sp], s["ghn"][sp], h_pp,
+                         masks[sp], dhz, dgi[sp], dgh[sp], hp[sp])
     G[rnn.weight_ih_l0] = ops.linear_bwd_weight(dgi, x_in)
     G[rnn.bias_ih_l0] = ops.colsum(dgi)
     G[rnn.weight_hh_l0] = ops.linear_bwd_weight(dgh, hp)
