@@ -193,7 +193,13 @@ def net_backward(net, S: Dict, d_feats: torch.Tensor) -> Dict:
             dy, dgamma, dbeta = ops.cbra_bwd(d.contiguous(), s["y"], s["scale"], s["shift"], mean, rstd, s["train"])
             G[bn.weight], G[bn.bias] = dgamma, dbeta
             G[conv.weight] = ops.conv2d_bwd_weight(dy, s["x"], 7, 7, 1, 3)
-            G[conv.bias] = ops.nchw_chansum(dy)
+            if s["train"]:
+                # train-mode BatchNorm: sum_{n,h,w} dy = gamma*rstd*(S1 - S1 - S2*sum(xhat)/M) and sum(xhat) = 0,
+                # so the gradient of a conv bias feeding it is identically zero (autograd in the reference
+                # returns ~1e-9 rounding noise there); no pass over the 270 MB dy tensor
+                G[conv.bias] = torch.zeros_like(conv.bias)
+            else:
+                G[conv.bias] = ops.nchw_chansum(dy)
             if i > 0:
                 d = ops.conv2d(dy, ops.weight_flip_transpose(conv.weight), pad=3)
 
