@@ -150,6 +150,16 @@ int ivln_groupnorm_f32(const float* x, const float* gamma, const float* beta, co
                        int64_t x_img_stride, int64_t x_chan_stride, int splits, int64_t slab_stride,
                        int64_t y_img_stride, int64_t r_img_stride, float* save_mean, float* save_rstd,
                        void* stream);
+/* Same, plus a second group-normalised operand added before the ReLU: y = act(GN(x) + GN2(x2) [+ residual]).
+ * x2 (raw tensor or split-K slabs, same C / HW / groups) is the downsample branch of a ResNet bottleneck
+ * (habitat-lab ddppo resnet Bottleneck: `out = relu(convs(x) + downsample(x))`): its GroupNorm needs no launch
+ * of its own. */
+int ivln_groupnorm2_f32(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
+                        int N, int C, int HW, int groups, float eps, int relu, int64_t x_img_stride,
+                        int64_t x_chan_stride, int splits, int64_t slab_stride, int64_t y_img_stride,
+                        int64_t r_img_stride, float* save_mean, float* save_rstd, const float* x2, const float* gamma2,
+                        const float* beta2, int64_t x2_img_stride, int64_t x2_chan_stride, int splits2,
+                        int64_t slab_stride2, void* stream);
 /* nn.BatchNorm2d eval folding / train-mode batch statistics (models/encoders/map_encoder.py:13-20;
  * quirk Q6: train mode also during rollouts).  Both produce per-channel scale/shift. */
 int ivln_bn_fold_f32(const float* gamma, const float* beta, const float* running_mean,

@@ -108,7 +108,11 @@ __global__ __launch_bounds__(GN_THREADS) void k_groupnorm(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ residual, float* __restrict__ y, int C, int HW, int groups, float eps, int relu,
     int64_t x_img_stride, int64_t x_chan_stride, int splits, int64_t slab_stride, int64_t y_img_stride,
-    int64_t r_img_stride, float* __restrict__ save_mean, float* __restrict__ save_rstd) {
+    int64_t r_img_stride, float* __restrict__ save_mean, float* __restrict__ save_rstd,
+    // optional second group-normalised operand added before the ReLU (the bottleneck's downsample branch:
+    // y = relu(GN(conv3) + GN_ds(conv_ds)), same channel/group partition): raw slabs of the downsample conv
+    const float* __restrict__ x2, const float* __restrict__ gamma2, const float* __restrict__ beta2,
+    int64_t x2_img_stride, int64_t x2_chan_stride, int splits2, int64_t slab_stride2) {
     __shared__ __attribute__((aligned(16))) float cache[GN_CACHE];
     __shared__ float red[16];
     const int img = blockIdx.x / groups, g = blockIdx.x % groups;
@@ -183,6 +187,35 @@ __global__ __launch_bounds__(GN_THREADS) void k_groupnorm(
         save_mean[blockIdx.x] = mean;
         save_rstd[blockIdx.x] = rstd;
     }
+    // statistics of the second operand (two passes straight from its slabs: it is small)
+    const float* x2p = x2 ? x2 + (int64_t)img * x2_img_stride + (int64_t)g * cpg * x2_chan_stride : nullptr;
+    float mean2 = 0.f, rstd2 = 0.f;
+    if (x2p) {
+        float s2 = 0.f;
+        if (vec) {
+            for (int i = threadIdx.x * 4; i < n; i += GN_THREADS * 4) {
+                const float4 v = gn_load4(x2p, i, HW, x2_chan_stride, splits2, slab_stride2);
+                s2 += (v.x + v.y) + (v.z + v.w);
+            }
+        } else {
+            for (int i = threadIdx.x; i < n; i += GN_THREADS) s2 += gn_load1(x2p, i, HW, x2_chan_stride, splits2, slab_stride2);
+        }
+        mean2 = block_sum(s2, red) / (float)n;
+        float q2 = 0.f;
+        if (vec) {
+            for (int i = threadIdx.x * 4; i < n; i += GN_THREADS * 4) {
+                const float4 v = gn_load4(x2p, i, HW, x2_chan_stride, splits2, slab_stride2);
+                const float d0 = v.x - mean2, d1 = v.y - mean2, d2 = v.z - mean2, d3 = v.w - mean2;
+                q2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+        } else {
+            for (int i = threadIdx.x; i < n; i += GN_THREADS) {
+                const float d = gn_load1(x2p, i, HW, x2_chan_stride, splits2, slab_stride2) - mean2;
+                q2 += d * d;
+            }
+        }
+        rstd2 = rsqrtf(block_sum(q2, red) / (float)n + eps);
+    }
     float* yp = y + (int64_t)img * y_img_stride + (int64_t)g * n;
     const float* rp = residual ? residual + (int64_t)img * r_img_stride + (int64_t)g * n : nullptr;
     if (vec) {
@@ -197,6 +230,11 @@ __global__ __launch_bounds__(GN_THREADS) void k_groupnorm(
                 float4 r = *reinterpret_cast<const float4*>(&rp[i]);
                 v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
             }
+            if (x2p) {
+                const float4 r = gn_load4(x2p, i, HW, x2_chan_stride, splits2, slab_stride2);
+                const float g2 = gamma2[c] * rstd2, b2 = beta2[c] - mean2 * g2;
+                v.x += fmaf(r.x, g2, b2); v.y += fmaf(r.y, g2, b2); v.z += fmaf(r.z, g2, b2); v.w += fmaf(r.w, g2, b2);
+            }
             if (relu) {
                 v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
             }
@@ -208,6 +246,8 @@ __global__ __launch_bounds__(GN_THREADS) void k_groupnorm(
             float v = cached ? cache[i] : gn_load1(xp, i, HW, x_chan_stride, splits, slab_stride);
             v = (v - mean) * rstd * gamma[c] + beta[c];
             if (rp) v += rp[i];
+            if (x2p)
+                v += (gn_load1(x2p, i, HW, x2_chan_stride, splits2, slab_stride2) - mean2) * rstd2 * gamma2[c] + beta2[c];
             if (relu) v = fmaxf(v, 0.f);
             yp[i] = v;
         }
@@ -955,20 +995,36 @@ __global__ __launch_bounds__(256) void k_copy_multi(const CopyJobs J) {
 
 extern "C" {
 
-int ivln_groupnorm_f32(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
-                       int N, int C, int HW, int groups, float eps, int relu, int64_t x_img_stride,
-                       int64_t x_chan_stride, int splits, int64_t slab_stride, int64_t y_img_stride,
-                       int64_t r_img_stride, float* save_mean, float* save_rstd, void* stream) {
+int ivln_groupnorm2_f32(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
+                        int N, int C, int HW, int groups, float eps, int relu, int64_t x_img_stride,
+                        int64_t x_chan_stride, int splits, int64_t slab_stride, int64_t y_img_stride,
+                        int64_t r_img_stride, float* save_mean, float* save_rstd, const float* x2, const float* gamma2,
+                        const float* beta2, int64_t x2_img_stride, int64_t x2_chan_stride, int splits2,
+                        int64_t slab_stride2, void* stream) {
     if (N <= 0 || C <= 0 || groups <= 0 || C % groups) return IVLN_E_INVALID;
+    if (x2 && (!gamma2 || !beta2)) return IVLN_E_INVALID;
     if (x_chan_stride <= 0) x_chan_stride = HW;
     if (x_img_stride <= 0) x_img_stride = (int64_t)C * HW;
     if (y_img_stride <= 0) y_img_stride = (int64_t)C * HW;
     if (r_img_stride <= 0) r_img_stride = (int64_t)C * HW;
+    if (x2_chan_stride <= 0) x2_chan_stride = HW;
+    if (x2_img_stride <= 0) x2_img_stride = (int64_t)C * HW;
     if (splits < 1) splits = 1;
+    if (splits2 < 1) splits2 = 1;
     hipLaunchKernelGGL(k_groupnorm, dim3(N * groups), dim3(GN_THREADS), 0, (hipStream_t)stream, x, gamma, beta,
                        residual, y, C, HW, groups, eps, relu, x_img_stride, x_chan_stride, splits, slab_stride,
-                       y_img_stride, r_img_stride, save_mean, save_rstd);
+                       y_img_stride, r_img_stride, save_mean, save_rstd, x2, gamma2, beta2, x2_img_stride,
+                       x2_chan_stride, splits2, slab_stride2);
     return LAUNCH_OK();
+}
+
+int ivln_groupnorm_f32(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
+                       int N, int C, int HW, int groups, float eps, int relu, int64_t x_img_stride,
+                       int64_t x_chan_stride, int splits, int64_t slab_stride, int64_t y_img_stride,
+                       int64_t r_img_stride, float* save_mean, float* save_rstd, void* stream) {
+    return ivln_groupnorm2_f32(x, gamma, beta, residual, y, N, C, HW, groups, eps, relu, x_img_stride, x_chan_stride,
+                               splits, slab_stride, y_img_stride, r_img_stride, save_mean, save_rstd, nullptr, nullptr,
+                               nullptr, 0, 0, 1, 0, stream);
 }
 
 int ivln_bn_fold_f32(const float* gamma, const float* beta, const float* running_mean, const float* running_var,

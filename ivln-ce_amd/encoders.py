@@ -192,17 +192,22 @@ class _Bottleneck(nn.Module):
         """conv -> GroupNorm(+ReLU) pairs: the conv leaves raw (split-K) slabs in the workspace and the
         GroupNorm kernel reduces + normalises them, 2 launches per pair."""
         c = self.convs
-        identity = x
+        ds = None
         if self.downsample is not None:
-            gn = self.downsample[1]
-            d = ops.conv2d(x, self.downsample[0].weight, stride=self.stride, defer=True)
-            identity = ops.groupnorm(d, gn.weight, gn.bias, gn.num_groups, gn.eps)
+            # the downsample conv leaves its slabs in the second workspace; its GroupNorm is folded into the
+            # block's last GroupNorm launch (same channels, same groups)
+            ds = ops.conv2d(x, self.downsample[0].weight, stride=self.stride, defer=True, ws_slot=1)
         y = ops.conv2d(x, c[0].weight, defer=True)
         y = ops.groupnorm(y, c[1].weight, c[1].bias, c[1].num_groups, c[1].eps, relu=True)
         y = ops.conv2d(y, c[3].weight, stride=self.stride, pad=1, defer=True)
         y = ops.groupnorm(y, c[4].weight, c[4].bias, c[4].num_groups, c[4].eps, relu=True)
         y = ops.conv2d(y, c[6].weight, defer=True)
-        return ops.groupnorm(y, c[7].weight, c[7].bias, c[7].num_groups, c[7].eps, relu=True, residual=identity)
+        if ds is not None:
+            gn = self.downsample[1]
+            assert gn.num_groups == c[7].num_groups and gn.eps == c[7].eps
+            return ops.groupnorm(y, c[7].weight, c[7].bias, c[7].num_groups, c[7].eps, relu=True, x2=ds,
+                                 gamma2=gn.weight, beta2=gn.bias)
+        return ops.groupnorm(y, c[7].weight, c[7].bias, c[7].num_groups, c[7].eps, relu=True, residual=x)
 
 
 class _ResNet50GN(nn.Module):

@@ -102,10 +102,11 @@ def conv_tables(cin, kh, kw, hin, win, dil, device, transposed=False):
     return t
 
 
-def splitk_ws(device, floats=8 << 20):
+def splitk_ws(device, floats=8 << 20, slot=0):
     """Split-K / deferred-epilogue workspace, one per (device, stream): concurrent branches of the
-    captured step graph must not share it."""
-    key = (str(device), torch.cuda.current_stream().cuda_stream)
+    captured step graph must not share it.  slot 1 is a second workspace for a deferred conv whose slabs
+    must outlive later deferred convs (the bottleneck's downsample branch)."""
+    key = (str(device), torch.cuda.current_stream().cuda_stream, slot)
     w = _ws.get(key)
     if w is None or w.numel() < floats:
         w = torch.empty(floats, dtype=torch.float32, device=device)
@@ -135,7 +136,7 @@ class Deferred:
 
 
 def conv2d(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, relu=False, out=None, out_ctot=0,
-           in_img_stride=0, splitk=True, defer=False):
+           in_img_stride=0, splitk=True, defer=False, ws_slot=0):
     """NCHW conv: x (N,Cin,H,W) [contiguous per image, image stride `in_img_stride`], w OIHW.
     out: optional destination (a channel slice of an (N,out_ctot,Ho,Wo) buffer)."""
     N, Cin, H, W = x.shape
@@ -143,7 +144,7 @@ def conv2d(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, 
     Ho = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
     Wo = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
     if defer:
-        out = splitk_ws(x.device)  # D is unused by the kernel in deferred mode
+        out = splitk_ws(x.device, slot=ws_slot)  # D is unused by the kernel in deferred mode
     elif out is None:
         out = torch.empty((N, Cout, Ho, Wo), dtype=torch.float32, device=x.device)
     d = GemmDesc()
@@ -165,7 +166,7 @@ def conv2d(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, 
         d.koff, d.kpos = dptr(koff), dptr(kpos)
     _epilogue(d, scale, shift, residual, relu)
     if defer:
-        ws = splitk_ws(x.device)
+        ws = splitk_ws(x.device, slot=ws_slot)
         used = i32(0)
         d.ws, d.ws_floats, d.splits, d.defer_epilogue = dptr(ws), ws.numel(), 0, 1
         d.splits_used = C.pointer(used)
@@ -296,9 +297,10 @@ def linear(x, w, bias=None, relu=False, out=None):
 
 
 def groupnorm(x, gamma, beta, groups, eps=1e-5, relu=False, residual=None, out=None, y_img_stride=0,
-              r_img_stride=0):
+              r_img_stride=0, x2=None, gamma2=None, beta2=None):
     """x: NCHW tensor or a `Deferred` conv output (slab reduction fused).  `out` may be a channel slice
-    of a wider NCHW buffer (y_img_stride = its image stride)."""
+    of a wider NCHW buffer (y_img_stride = its image stride).  x2 (+gamma2, beta2): a second operand that is
+    group-normalised (same groups) and added before the ReLU."""
     if isinstance(x, Deferred):
         N, Cc, H, W = x.N, x.C, x.H, x.W
         HW = H * W
@@ -311,11 +313,28 @@ def groupnorm(x, gamma, beta, groups, eps=1e-5, relu=False, residual=None, out=N
         dev = x.device
     if out is None:
         out = torch.empty((N, Cc, H, W), dtype=torch.float32, device=dev)
+    if x2 is None:
+        check(
+            _L().ivln_groupnorm_f32(xp, dptr(gamma), dptr(beta), _p(residual), _p(out), N, Cc, HW, groups, eps,
+                                    int(bool(relu)), x_img, x_chan, splits, slab, y_img_stride, r_img_stride, None,
+                                    None, stream_ptr()),
+            "ivln_groupnorm_f32",
+        )
+        return out
+    if isinstance(x2, Deferred):
+        assert (x2.N, x2.C, x2.H, x2.W) == (N, Cc, H, W)
+        x2p, x2_img, x2_chan, splits2, slab2 = dptr(x2.ws), HW, N * HW, x2.splits, Cc * N * HW
+    else:
+        assert tuple(x2.shape) == (N, Cc, H, W)
+        x2p, x2_img, x2_chan, splits2, slab2 = _p(x2), 0, 0, 1, 0
+    L = _L()
+    L.ivln_groupnorm2_f32.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, i64, i64, i32, i64, i64, i64, vp,
+                                      vp, vp, vp, vp, i64, i64, i32, i64, vp]
     check(
-        _L().ivln_groupnorm_f32(xp, dptr(gamma), dptr(beta), _p(residual), _p(out), N, Cc, HW, groups, eps,
-                                int(bool(relu)), x_img, x_chan, splits, slab, y_img_stride, r_img_stride, None, None,
-                                stream_ptr()),
-        "ivln_groupnorm_f32",
+        L.ivln_groupnorm2_f32(xp, dptr(gamma), dptr(beta), _p(residual), _p(out), N, Cc, HW, groups, eps,
+                              int(bool(relu)), x_img, x_chan, splits, slab, y_img_stride, r_img_stride, None, None,
+                              x2p, dptr(gamma2), dptr(beta2), x2_img, x2_chan, splits2, slab2, stream_ptr()),
+        "ivln_groupnorm2_f32",
     )
     return out
 

@@ -459,3 +459,29 @@ def test_conv_transpose2d_stride2_parity_classes(N, Cin, H, W, Cout, k, p, op):
     _close(got, F.relu(ref0 * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) + res), 3e-5)
     # k=3, p=0 needs a negative input offset for the even rows: not decomposed this way
     assert ops.convt_s2_classes(torch.randn(4, 4, 3, 3, device=DEV), 0) is None
+
+
+@pytest.mark.parametrize("N,C,H,W,G", [(2, 128, 16, 16, 16), (3, 64, 8, 8, 16), (2, 32, 5, 7, 4)])
+def test_groupnorm_with_second_normalised_operand(N, C, H, W, G):
+    """y = relu(GN(x) + GN2(x2)): the bottleneck's downsample GroupNorm folded into the block's last
+    GroupNorm launch, x2 given as deferred conv slabs or as a plain tensor; tolerance 2e-5."""
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(N + C)
+    x, x2 = torch.randn(N, C, H, W, generator=g), 2.0 * torch.randn(N, C, H, W, generator=g) + 0.5
+    g1, b1, g2, b2 = (torch.randn(C, generator=g) for _ in range(4))
+    ref = F.relu(F.group_norm(x, G, g1, b1, 1e-5) + F.group_norm(x2, G, g2, b2, 1e-5))
+    got = ops.groupnorm(x.to(DEV), g1.to(DEV), b1.to(DEV), G, 1e-5, relu=True, x2=x2.to(DEV), gamma2=g2.to(DEV),
+                        beta2=b2.to(DEV))
+    _close(got, ref, 2e-5)
+    if (H * W) % 4 == 0:
+        # x2 as the raw slabs of a deferred 1x1 conv in the second workspace
+        xin = torch.randn(N, 24, H, W, generator=g)
+        w = torch.randn(C, 24, 1, 1, generator=g) / 24 ** 0.5
+        ds = ops.conv2d(xin.to(DEV), w.to(DEV), defer=True, ws_slot=1)
+        junk = ops.conv2d(xin.to(DEV), w.to(DEV), defer=True)  # a later deferred conv must not disturb slot 1
+        ref2 = F.relu(F.group_norm(x, G, g1, b1, 1e-5) + F.group_norm(F.conv2d(xin, w), G, g2, b2, 1e-5))
+        got2 = ops.groupnorm(x.to(DEV), g1.to(DEV), b1.to(DEV), G, 1e-5, relu=True, x2=ds, gamma2=g2.to(DEV),
+                             beta2=b2.to(DEV))
+        _close(got2, ref2, 3e-5)
+        assert junk.splits >= 1
