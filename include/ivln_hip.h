@@ -204,6 +204,13 @@ int ivln_attn_fwd_f32(const float* q, int64_t ldq, const float* k, int64_t k_img
                       int64_t v_img_stride, const int* valid_len, float scale, int rows, int Ck, int Cv,
                       int I, float* out, int64_t ldo, float* save_attn, float* logits_ws /* rows*I */,
                       void* stream);
+/* The same attention for a short key axis (I <= 32: the 4x4 depth / map feature grids of MapCMANet.forward,
+ * map_cma_policy.py:330-343) and up to two key/value sets that share the query, in ONE launch; k1 == NULL ->
+ * one set.  No mask, no saved probabilities (rollout head). */
+int ivln_attn_small2_f32(const float* q, int64_t ldq, float scale, int rows, int I, const float* k0,
+                         int64_t k0_img_stride, const float* v0, int64_t v0_img_stride, int Ck0, int Cv0, float* out0,
+                         int64_t ldo0, const float* k1, int64_t k1_img_stride, const float* v1, int64_t v1_img_stride,
+                         int Ck1, int Cv1, float* out1, int64_t ldo1, void* stream);
 /* prev_action_embedding(((a+1)*mask).long()) (map_cma_policy.py:297-299), written to two slices. */
 int ivln_prev_action_embed_f32(const int64_t* prev_actions, const uint8_t* mask, const float* table,
                                int rows, int E, int n_emb, float* out1, int64_t ld1, float* out2,

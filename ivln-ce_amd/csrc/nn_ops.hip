@@ -859,6 +859,74 @@ __global__ __launch_bounds__(256) void k_attn_out(const float* __restrict__ logi
     }
 }
 
+// Attention over a SHORT key axis (I <= 32: the 4x4 depth / map feature grids) in one launch, for up to two
+// key/value sets sharing the query (blockIdx.z): logits (32 positions x 8 channel parts), softmax over the
+// <= 32 positions by one wave, then 16 output channels x 16 position parts per block - every block redoes the
+// (tiny) logits.  Replaces k_attn_logits + k_attn_out per set: 4 launches -> 1 in the rollout head.
+struct AttnSet {
+    const float* k;
+    const float* v;
+    float* out;
+    int64_t k_img_stride, v_img_stride, ldo;
+    int Ck, Cv;
+};
+__global__ __launch_bounds__(256) void k_attn_small(const float* __restrict__ q, int64_t ldq, float scale, int I,
+                                                    const AttnSet s0, const AttnSet s1) {
+    __shared__ float qs[1024];
+    __shared__ float pl[16][33];
+    __shared__ float ps[32];
+    const AttnSet& S = blockIdx.z == 0 ? s0 : s1;
+    if ((int)blockIdx.y * 16 >= S.Cv) return;  // the two sets may have different output widths
+    const int n = blockIdx.x;
+    for (int c = threadIdx.x; c < S.Ck; c += 256) qs[c] = q[(int64_t)n * ldq + c];
+    __syncthreads();
+    {
+        const float* kp = S.k + (int64_t)n * S.k_img_stride;
+        const int ti = threadIdx.x & 31, tp = threadIdx.x >> 5;
+        float acc = 0.f;
+        if (ti < I) {
+            int c = tp;
+            for (; c + 56 < S.Ck; c += 64) {
+                float kv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) kv[u] = kp[(int64_t)(c + 8 * u) * I + ti];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc = fmaf(qs[c + 8 * u], kv[u], acc);
+            }
+            for (; c < S.Ck; c += 8) acc = fmaf(qs[c], kp[(int64_t)c * I + ti], acc);
+        }
+        pl[tp][ti] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {  // one wave: same summation order as k_attn_logits, softmax over <= 32 values
+        const int ti = threadIdx.x;
+        float l = -INFINITY;
+        if (ti < I)
+            l = (((pl[0][ti] + pl[1][ti]) + (pl[2][ti] + pl[3][ti])) + ((pl[4][ti] + pl[5][ti]) + (pl[6][ti] + pl[7][ti]))) * scale;
+        const float mx = wave_max(l);
+        const float e = ti < I ? expf(l - mx) : 0.f;
+        const float sum = wave_sum(e);
+        if (ti < I) ps[ti] = e * (1.f / sum);
+    }
+    __syncthreads();
+    const int tc = threadIdx.x >> 4, tpart = threadIdx.x & 15;
+    const int c = blockIdx.y * 16 + tc;
+    float acc = 0.f;
+    if (c < S.Cv) {
+        const float* vp = S.v + (int64_t)n * S.v_img_stride + (int64_t)c * I;
+        for (int i = tpart; i < I; i += 16) acc = fmaf(ps[i], vp[i], acc);
+    }
+    __syncthreads();
+    pl[tc][tpart] = acc;
+    __syncthreads();
+    if (tpart == 0 && c < S.Cv) {
+        float t = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t += pl[tc][u];
+        S.out[(int64_t)n * S.ldo + c] = t;
+    }
+}
+
 // prev-action embedding: idx = (long)((float(a)+1) * mask) (map_cma_policy.py:297-299)
 __global__ void k_prev_action_embed(const int64_t* __restrict__ prev_actions, const uint8_t* __restrict__ mask,
                                     const float* __restrict__ table, int rows, int E, int n_emb,
@@ -1132,6 +1200,20 @@ int ivln_attn_fwd_f32(const float* q, int64_t ldq, const float* k, int64_t k_img
                        k_img_stride, valid_len, scale, Ck, I, logits_ws);
     hipLaunchKernelGGL(k_attn_out, dim3(rows, (Cv + 15) / 16), dim3(256), 0, (hipStream_t)stream, logits_ws, v,
                        v_img_stride, Cv, I, out, ldo, save_attn);
+    return LAUNCH_OK();
+}
+
+int ivln_attn_small2_f32(const float* q, int64_t ldq, float scale, int rows, int I, const float* k0,
+                         int64_t k0_img_stride, const float* v0, int64_t v0_img_stride, int Ck0, int Cv0, float* out0,
+                         int64_t ldo0, const float* k1, int64_t k1_img_stride, const float* v1, int64_t v1_img_stride,
+                         int Ck1, int Cv1, float* out1, int64_t ldo1, void* stream) {
+    if (I > 32 || I <= 0 || Ck0 > 1024 || Ck1 > 1024 || rows <= 0) return IVLN_E_UNSUPPORTED;
+    AttnSet a{k0, v0, out0, k0_img_stride, v0_img_stride, ldo0, Ck0, Cv0};
+    AttnSet b{k1, v1, out1, k1_img_stride, v1_img_stride, ldo1, Ck1, Cv1};
+    const int sets = k1 ? 2 : 1;
+    const int cv = sets == 2 && Cv1 > Cv0 ? Cv1 : Cv0;
+    hipLaunchKernelGGL(k_attn_small, dim3(rows, (cv + 15) / 16, sets), dim3(256), 0, (hipStream_t)stream, q, ldq, scale,
+                       I, a, b);
     return LAUNCH_OK();
 }
 

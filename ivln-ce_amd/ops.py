@@ -437,6 +437,21 @@ def lstm_bidir(gx_f, gx_r, whh_f, whh_r, bhh_f, bhh_r, lengths, B, L, H, save=Fa
     return out, gates, cs
 
 
+def attn_small2(q, k0, v0, out0, k1, v1, out1, scale):
+    """Two attentions over a short key axis (<= 32 positions) sharing the query, one launch."""
+    rows = q.shape[0]
+    I = v0.shape[2]
+    L = _L()
+    L.ivln_attn_small2_f32.argtypes = [vp, i64, f32, i32, i32, vp, i64, vp, i64, i32, i32, vp, i64, vp, i64, vp, i64,
+                                       i32, i32, vp, i64, vp]
+    check(
+        L.ivln_attn_small2_f32(_p(q), q.stride(0), scale, rows, I, _p(k0), k0.stride(0), _p(v0), v0.stride(0),
+                               k0.shape[1], v0.shape[1], _p(out0), out0.stride(0), _p(k1), k1.stride(0), _p(v1),
+                               v1.stride(0), k1.shape[1], v1.shape[1], _p(out1), out1.stride(0), stream_ptr()),
+        "ivln_attn_small2_f32",
+    )
+
+
 def gru_step(x, gi_pre, h_in, mask_u8, w_ih, w_hh, b_ih, b_hh, h_out, h_out2=None, saves=None):
     """One masked GRU step over `rows` rows; x (rows,I) or gi_pre (rows,3H); h_in/h_out strided."""
     rows = h_in.shape[0]

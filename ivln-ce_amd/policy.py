@@ -290,8 +290,13 @@ class MapCMANet(Net):
         q2 = ops.linear(text, self.text_q.weight, self.text_q.bias)
         a_dep = torch.empty((rows, P), dtype=torch.float32, device=dev) if save is not None else None
         a_map = torch.empty((rows, P), dtype=torch.float32, device=dev) if save is not None else None
-        ops.attn(q2, dkv[:, :h2], dkv[:, h2:], None, self._scale_f, x2[:, o_dep:o_dep + d_out], a_dep)
-        ops.attn(q2, mkv[:, :h2], mkv[:, h2:], None, self._scale_f, x2[:, o_map:o_map + m_out], a_map)
+        if save is None and P <= 32:
+            # rollout head: both short-axis attentions (they share the query) in one launch
+            ops.attn_small2(q2, dkv[:, :h2], dkv[:, h2:], x2[:, o_dep:o_dep + d_out], mkv[:, :h2], mkv[:, h2:],
+                            x2[:, o_map:o_map + m_out], self._scale_f)
+        else:
+            ops.attn(q2, dkv[:, :h2], dkv[:, h2:], None, self._scale_f, x2[:, o_dep:o_dep + d_out], a_dep)
+            ops.attn(q2, mkv[:, :h2], mkv[:, h2:], None, self._scale_f, x2[:, o_map:o_map + m_out], a_map)
 
         sc = self.second_state_compress[0]
         c2 = ops.linear(x2, sc.weight, sc.bias, relu=True)

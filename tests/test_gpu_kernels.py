@@ -485,3 +485,28 @@ def test_groupnorm_with_second_normalised_operand(N, C, H, W, G):
                              beta2=b2.to(DEV))
         _close(got2, ref2, 3e-5)
         assert junk.splits >= 1
+
+
+def test_attention_short_axis_two_sets_one_launch():
+    """k_attn_small: both 16-position attentions of the rollout head (depth and map features, shared query)
+    in one launch, against torch and against the two-kernel path; tolerance 2e-5."""
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(21)
+    rows, Ck, I = 5, 256, 16
+    q = torch.randn(rows, Ck, generator=g)
+    kv0, kv1 = torch.randn(rows, Ck + 192, I, generator=g), torch.randn(rows, Ck + 128, I, generator=g)
+
+    def ref(kv):
+        k, v = kv[:, :Ck], kv[:, Ck:]
+        return torch.einsum("ni,nci->nc", F.softmax(torch.einsum("nc,nci->ni", q, k) * 0.0625, 1), v)
+
+    d0, d1 = kv0.to(DEV), kv1.to(DEV)
+    x2 = torch.zeros(rows, 400, device=DEV)
+    ops.attn_small2(q.to(DEV), d0[:, :Ck], d0[:, Ck:], x2[:, 10:202], d1[:, :Ck], d1[:, Ck:], x2[:, 250:378], 0.0625)
+    _close(x2[:, 10:202], ref(kv0), 2e-5)
+    _close(x2[:, 250:378], ref(kv1), 2e-5)
+    assert float(x2[:, :10].abs().max()) == 0.0 and float(x2[:, 202:250].abs().max()) == 0.0
+    two = torch.zeros(rows, 192, device=DEV)
+    ops.attn(q.to(DEV), d0[:, :Ck], d0[:, Ck:], None, 0.0625, two)
+    _close(x2[:, 10:202], two, 1e-6)
