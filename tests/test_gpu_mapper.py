@@ -166,3 +166,42 @@ def test_known_map_mode_matches_oracle(tmp_path):
         assert np.array_equal(mem.occupancy.cpu().numpy(), occ_r), f"occ step {t}"
         assert np.array_equal(mem.semantic.cpu().numpy(), sem_r), f"sem step {t}"
         assert occ_r.sum() > 100
+
+
+@pytest.mark.parametrize("case", ["all_invalid", "all_saturated", "single_env", "all_reset_every_step", "one_valid_pixel"])
+def test_hip_mapper_edge_cases_match_oracle(case):
+    """Degenerate inputs against the C oracle, bit-exact: no valid depth at all (empty local cloud, empty
+    world), depth saturated at the 0.99 cut, one env, every env reset on every step (world cleared each
+    time), a single valid pixel."""
+    from ivln_ce_amd.synthetic import SyntheticRollout
+    from oracle.mapper_ref import MapperRef
+
+    dev = torch.device("cuda:0")
+    B = 1 if case == "single_env" else 3
+    H = W = 64
+    roll = SyntheticRollout(B=B, H=H, W=W, seed=5)
+    m = _mk(H, W, b_max=B)
+    ref = MapperRef(H, W)
+    for t in range(4):
+        obs = roll.step()
+        if case == "all_invalid":
+            obs["depth"] = torch.zeros_like(obs["depth"])
+        elif case == "all_saturated":
+            obs["depth"] = torch.full_like(obs["depth"], 0.995)
+        elif case == "one_valid_pixel":
+            d = torch.zeros_like(obs["depth"])
+            d[:, H // 2, W // 3] = 0.37
+            obs["depth"] = d
+        elif case == "all_reset_every_step":
+            obs["not_done_masks"] = torch.zeros_like(obs["not_done_masks"])
+        T, rot = MapperRef.frames(obs["world_robot_pose"].numpy(), obs["world_robot_orientation"].numpy())
+        occ_r, sem_r = ref.step(obs["depth"].numpy(), obs["semantic12"].numpy(), obs["world_robot_pose"].numpy(),
+                                obs["world_robot_orientation"].numpy(), obs["not_done_masks"].numpy(), T=T, rot=rot)
+        dobs = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in obs.items()}
+        mem = m(dobs, T=torch.from_numpy(T).to(dev), rot=torch.from_numpy(rot).to(dev))
+        n = m.check_status()
+        assert n == ref.world()[0].shape[0], f"{case}: world size step {t}"
+        assert np.array_equal(mem.occupancy.cpu().numpy(), occ_r), f"{case}: occupancy step {t}"
+        assert np.array_equal(mem.semantic.cpu().numpy(), sem_r), f"{case}: semantic step {t}"
+    if case in ("all_invalid", "all_saturated"):
+        assert n == 0 and int(mem.occupancy.sum()) == 0

@@ -162,3 +162,38 @@ def test_graphed_multistream_rollout_is_bit_identical_to_eager(streams):
         assert torch.equal(runner.rnn_states, eager[t][1]), f"rnn step {t}"
         assert torch.equal(mem.occupancy, eager[t][2]) and torch.equal(mem.semantic, eager[t][3]), f"maps step {t}"
     tr_g.mapping_module.check_status()
+
+
+@pytest.mark.parametrize("lens", [[1, 200, 37, 200], [200], [1, 1]])
+def test_act_instruction_length_extremes_match_oracle(lens):
+    """Instruction of one token and of the maximum 200 tokens (no padding at all) in the same batch: packed
+    bi-LSTM lengths, the -1e8 text-attention mask and the zero-padded outputs against the oracle."""
+    from det_init import det_fill
+
+    from ivln_ce_amd.synthetic import SyntheticRollout
+    from oracle.policy_ref import MapCMAPolicyRef
+
+    torch.set_num_threads(8)
+    B = len(lens)
+    pol = make_policy()
+    ref = det_fill(MapCMAPolicyRef(), seed=0).eval()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(sum(lens))
+    obs = SyntheticRollout(B=B, seed=9).step()
+    instr = torch.zeros(B, 200, dtype=torch.int64)
+    for b, n in enumerate(lens):
+        instr[b, :n] = torch.randint(2, 2504, (n,), generator=g)
+    obs["instruction"] = instr
+    obs["occupancy_map"] = (torch.rand(B, 64, 64, generator=g) < 0.4).to(torch.uint8)
+    obs["semantic_map"] = (torch.randint(0, 13, (B, 64, 64), generator=g) * obs["occupancy_map"]).to(torch.uint8)
+    rnn = 0.1 * torch.randn(B, 2, 512, generator=g)
+    prev = torch.randint(0, 4, (B, 1), generator=g)
+    masks = torch.ones(B, 1, dtype=torch.uint8)
+    with torch.no_grad():
+        lr, sr, fr = ref.logits(obs, rnn, prev, masks)
+        dobs = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in obs.items()}
+        f, s = pol.net(dobs, rnn.to(dev), prev.to(dev), masks.to(dev))
+        lg = pol.action_distribution.raw_logits(f)
+    assert float((f.cpu() - fr).abs().max()) < ATOL
+    assert float((s.cpu() - sr).abs().max()) < ATOL
+    assert float((lg.cpu() - lr).abs().max()) < 1e-4
