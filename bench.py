@@ -81,9 +81,11 @@ class GemmTimer:
         self.ops.gemm = self.orig
 
     def total_ms(self):
+        """Sum of the event-pair times.  A pair brackets one launch on the launch stream, so it carries the
+        launch's dispatch latency as well (about 2.5 us more per launch than rocprofv3's kernel durations,
+        profiles/r01_rollout_eager_kernel_stats.csv): the reported TFLOP/s is the conservative figure."""
         torch.cuda.synchronize()
         return sum(a.elapsed_time(b) for a, b in self.events)
-
 
 def rollout_step(mapper_tr, policy, obs, state):
     """mapper (obs-transform plugin) + policy.act: the per-step body of the reference eval loop
@@ -331,6 +333,10 @@ def main():
         n_inst = min(20, K)
         with GemmTimer() as gt:
             for i in range(n_inst):
+                # eager launches are host-bound (~8 us each with the event pair): park the GPU on a spin
+                # kernel while the host enqueues the step, so the event pairs time back-to-back kernels
+                # (what rocprofv3's per-kernel durations show) and not the host's launch gaps
+                torch.cuda._sleep(12_000_000)
                 rollout_step(mapper_tr, policy, obs_dev[i % n_pool], state)
             ms = gt.total_ms()
         flops_per_step = gt.flops / n_inst
