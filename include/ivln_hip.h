@@ -216,6 +216,11 @@ int ivln_prev_action_embed_f32(const int64_t* prev_actions, const uint8_t* mask,
                                int rows, int E, int n_emb, float* out1, int64_t ld1, float* out2,
                                int64_t ld2, void* stream);
 /* distribution.mode() (common/utils.py:168-169) and predicted_scores.argmax(1) (mapper.py:796-798). */
+/* CategoricalNet + distribution.mode() of a deterministic step in one launch (models/policy.py:35-48,
+ * common/utils.py:149-185): logits = W x + b (O <= 8 actions), action[r] = first arg-max; logits_out optional
+ * (rows, O). */
+int ivln_linear_argmax_f32(const float* x, int64_t ldx, const float* W, const float* bias, int rows, int K, int O,
+                           int64_t* action, float* logits_out, void* stream);
 int ivln_argmax_rows(const float* x, int rows, int C, int64_t* out, void* stream);
 int ivln_argmax_channels_u8(const float* x, int N, int C, int HW, uint8_t* out, void* stream);
 /* PredictSemantics input prep (mapper.py:715-736,788-793). */

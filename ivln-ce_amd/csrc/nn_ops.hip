@@ -959,6 +959,60 @@ __global__ void k_argmax_rows(const float* __restrict__ x, int rows, int C, int6
     out[r] = best;
 }
 
+// Action head of a deterministic rollout step in one launch: wave w computes the logits of actions w and w+4
+// (lanes split K, one shuffle reduction per row), then the first arg-max per row (distribution.mode(),
+// common/utils.py:149-185).  One block, O <= 8 actions; rows processed 8 at a time.
+__global__ __launch_bounds__(256) void k_linear_argmax(const float* __restrict__ x, int64_t ldx,
+                                                       const float* __restrict__ W, const float* __restrict__ bias,
+                                                       int rows, int K, int O, int64_t* __restrict__ action,
+                                                       float* __restrict__ logits_out) {
+    __shared__ float lg[SK_ROWS][8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r0 = 0; r0 < rows; r0 += SK_ROWS) {
+        for (int o = wave; o < O; o += 4) {
+            const float* wr = W + (int64_t)o * K;
+            float acc[SK_ROWS];
+#pragma unroll
+            for (int r = 0; r < SK_ROWS; ++r) acc[r] = 0.f;
+            for (int k = lane * 4; k < K; k += 256) {
+                const float4 wv = *reinterpret_cast<const float4*>(wr + k);
+#pragma unroll
+                for (int r = 0; r < SK_ROWS; ++r) {
+                    if (r0 + r < rows) {
+                        const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)(r0 + r) * ldx + k);
+                        acc[r] = fmaf(wv.x, xv.x, acc[r]);
+                        acc[r] = fmaf(wv.y, xv.y, acc[r]);
+                        acc[r] = fmaf(wv.z, xv.z, acc[r]);
+                        acc[r] = fmaf(wv.w, xv.w, acc[r]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < SK_ROWS; ++r) {
+                float v = wave_sum(acc[r]);
+                if (lane == 0 && r0 + r < rows) {
+                    if (bias) v += bias[o];
+                    lg[r][o] = v;
+                    if (logits_out) logits_out[(int64_t)(r0 + r) * O + o] = v;
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < SK_ROWS && r0 + (int)threadIdx.x < rows) {
+            const int r = threadIdx.x;
+            int best = 0;
+            float bv = lg[r][0];
+            for (int o = 1; o < O; ++o)
+                if (lg[r][o] > bv) {
+                    bv = lg[r][o];
+                    best = o;
+                }
+            action[r0 + r] = best;
+        }
+        __syncthreads();
+    }
+}
+
 // channel argmax over NCHW logits -> u8 labels (predicted_scores.argmax(1), mapper.py:796-798)
 __global__ __launch_bounds__(256) void k_argmax_channels_u8(const float* __restrict__ x, int N, int C, int HW,
                                                             uint8_t* __restrict__ out) {
@@ -1226,6 +1280,14 @@ int ivln_prev_action_embed_f32(const int64_t* prev_actions, const uint8_t* mask,
 
 int ivln_argmax_rows(const float* x, int rows, int C, int64_t* out, void* stream) {
     hipLaunchKernelGGL(k_argmax_rows, dim3((rows + 63) / 64), dim3(64), 0, (hipStream_t)stream, x, rows, C, out);
+    return LAUNCH_OK();
+}
+
+int ivln_linear_argmax_f32(const float* x, int64_t ldx, const float* W, const float* bias, int rows, int K, int O,
+                           int64_t* action, float* logits_out, void* stream) {
+    if (O > 8 || O <= 0 || (K & 3) || (ldx & 3) || rows <= 0) return IVLN_E_UNSUPPORTED;
+    hipLaunchKernelGGL(k_linear_argmax, dim3(1), dim3(256), 0, (hipStream_t)stream, x, ldx, W, bias, rows, K, O, action,
+                       logits_out);
     return LAUNCH_OK();
 }
 

@@ -493,6 +493,18 @@ def prev_action_embed(prev_actions_i64, mask_u8, table, out1, out2=None):
     )
 
 
+def linear_argmax(x, w, bias, out=None):
+    """argmax_o (x . w[o] + b[o]) per row, one launch (deterministic action head); out (rows,1) int64."""
+    rows, K = x.shape
+    if out is None:
+        out = torch.empty((rows, 1), dtype=torch.int64, device=x.device)
+    L = _L()
+    L.ivln_linear_argmax_f32.argtypes = [vp, i64, vp, vp, i32, i32, i32, vp, vp, vp]
+    check(L.ivln_linear_argmax_f32(_p(x), x.stride(0), dptr(w), _p(bias), rows, K, w.shape[0], dptr(out), None,
+                                   stream_ptr()), "ivln_linear_argmax_f32")
+    return out
+
+
 def argmax_rows(x, out=None):
     rows, Cc = x.shape
     if out is None:

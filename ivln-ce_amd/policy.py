@@ -343,9 +343,13 @@ class ILPolicy(Policy):
         raise NotImplementedError
 
     def _act(self, features, deterministic):
-        logits = self.action_distribution.raw_logits(features)
-        if deterministic:  # distribution.mode() == argmax of probs == argmax of logits
+        if deterministic:  # distribution.mode() == argmax of probs == argmax of logits: head + argmax, one launch
+            lin = self.action_distribution.linear
+            if features.is_cuda and lin.out_features <= 8 and features.stride(-1) == 1:
+                return ops.linear_argmax(features, lin.weight, lin.bias, out=getattr(self, "_action_out_buffer", None))
+            logits = self.action_distribution.raw_logits(features)
             return ops.argmax_rows(logits.contiguous(), out=getattr(self, "_action_out_buffer", None))
+        logits = self.action_distribution.raw_logits(features)
         return CustomFixedCategorical(logits=logits).sample()
 
     def act(self, observations, rnn_states, prev_actions, masks, deterministic=False):

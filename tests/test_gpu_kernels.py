@@ -510,3 +510,24 @@ def test_attention_short_axis_two_sets_one_launch():
     two = torch.zeros(rows, 192, device=DEV)
     ops.attn(q.to(DEV), d0[:, :Ck], d0[:, Ck:], None, 0.0625, two)
     _close(x2[:, 10:202], two, 1e-6)
+
+
+@pytest.mark.parametrize("rows", [1, 4, 8, 11, 40])
+def test_action_head_linear_argmax_one_launch(rows):
+    """k_linear_argmax == torch.argmax of the fp32 logits and == argmax_rows(linear(x)) (random logits: no
+    near-ties), first maximum on exact ties."""
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, 512, generator=g)
+    w, b = torch.randn(4, 512, generator=g) * 0.05, torch.randn(4, generator=g) * 0.01
+    got = ops.linear_argmax(x.to(DEV), w.to(DEV), b.to(DEV))
+    assert got.shape == (rows, 1) and got.dtype == torch.int64
+    ref = torch.argmax(x @ w.t() + b, dim=1, keepdim=True)
+    assert torch.equal(got.cpu(), ref)
+    if rows <= 16:
+        two = ops.argmax_rows(ops.linear(x.to(DEV), w.to(DEV), b.to(DEV)))
+        assert torch.equal(got, two)
+    # first maximum wins on exact ties (torch.argmax / distribution.mode())
+    xt = torch.zeros(2, 512)
+    assert ops.linear_argmax(xt.to(DEV), w.to(DEV), torch.zeros(4).to(DEV)).flatten().tolist() == [0, 0]
