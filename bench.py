@@ -284,9 +284,21 @@ def main():
         from ivln_ce_amd.graphed import GraphedRollout
 
         log(f"rank {rank}: capturing the step graph")
-        runner = GraphedRollout(policy, [mapper_tr], obs_dev[0], deterministic=True,
-                                streams=args.streams if (args.streams or args.single_stream) else "split")
+        mode = args.streams if (args.streams or args.single_stream) else "split"
+        runner, launch_note = None, None
+        for attempt in ([mode, False] if mode else [False]):
+            try:
+                runner = GraphedRollout(policy, [mapper_tr], obs_dev[0], deterministic=True, streams=attempt)
+                launch_note = ("3 forked streams" if attempt is True else
+                               "3 graphs on 2 streams" if attempt == "split" else "1 stream")
+                break
+            except Exception as e:  # noqa: BLE001 - a capture problem must not cost the measurement
+                log(f"rank {rank}: graph capture ({attempt!r}) failed: {type(e).__name__}: {e}")
+                torch.cuda.synchronize()
+        if runner is None:
+            use_graph = False
 
+    if use_graph:
         def do_step(i):
             runner.step(obs_dev[i % n_pool])
     else:
@@ -359,7 +371,12 @@ def main():
         ptr = PredictedSemanticsIterativeMapper.from_config(cfg)
         pobs = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in o.items()}
                 for o in gen_observations(B, 24, seed=4321 + rank, with_rgb=True)]
-        prun = GraphedRollout(policy, [ptr], pobs[0], deterministic=True, streams="split")
+        try:
+            prun = GraphedRollout(policy, [ptr], pobs[0], deterministic=True, streams="split")
+        except Exception as e:  # noqa: BLE001
+            log(f"rank {rank}: split capture failed for the pred-semantics leg ({type(e).__name__}: {e}); one stream")
+            torch.cuda.synchronize()
+            prun = GraphedRollout(policy, [ptr], pobs[0], deterministic=True, streams=False)
         for i in range(6):
             prun.step(pobs[i % 24])
         barrier()
@@ -389,7 +406,7 @@ def main():
                         + f"{B} parallel envs per GPU, 256x256 depth + semantic12, 80-token instruction, random-init "
                         "weights of the reference architecture",
             "envs_per_gpu": B, "parallelism": f"dp{world} (envs sharded, no data-path collective)",
-            "launch": ("hipGraph replay, " + ("3 forked streams" if args.streams else ("1 stream" if args.single_stream else "3 graphs on 2 streams"))) if use_graph else "eager",
+            "launch": ("hipGraph replay, " + launch_note) if use_graph else "eager",
         },
         "roofline": roofline,
     }
