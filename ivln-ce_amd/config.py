@@ -288,6 +288,14 @@ def _task_defaults() -> Config:
     T.TASK.SENSORS = ["INSTRUCTION_SENSOR", "SHORTEST_PATH_SENSOR", "VLN_ORACLE_PROGRESS_SENSOR"]
     T.TASK.POSSIBLE_ACTIONS = ["STOP", "MOVE_FORWARD", "TURN_LEFT", "TURN_RIGHT"]
     T.TASK.MEASUREMENTS = ["DISTANCE_TO_GOAL", "SUCCESS", "SPL", "NDTW", "SDTW", "PATH_LENGTH"]
+    T.TASK.NDTW = CN()  # habitat_extensions/config/default.py:108-115
+    T.TASK.NDTW.TYPE = "NDTW"
+    T.TASK.NDTW.SPLIT = "val_seen"
+    T.TASK.NDTW.FDTW = True  # False: exact DTW
+    T.TASK.NDTW.GT_PATH = "data/datasets/R2R_VLNCE_v1-3_preprocessed/{split}/{split}_gt.json.gz"
+    T.TASK.NDTW.SUCCESS_DISTANCE = 3.0
+    T.TASK.SDTW = CN()
+    T.TASK.SDTW.TYPE = "SDTW"
     T.TASK.INSTRUCTION_SENSOR_UUID = "instruction"
     T.DATASET = CN()
     T.DATASET.TYPE = "VLN-CE-v1"

@@ -14,6 +14,7 @@ from typing import List
 
 import numpy as np
 
+from .measures import SDTW, ndtw
 from .spaces import Box, Dict, Discrete
 
 STOP, FORWARD, LEFT, RIGHT = 0, 1, 2, 3
@@ -30,6 +31,8 @@ class _SynthEnv:
         self.rgb_hw = (r.HEIGHT, r.WIDTH)
         self.with_rgb, self.with_semantic = with_rgb, with_semantic
         self.max_steps = cfg.TASK_CONFIG.ENVIRONMENT.MAX_EPISODE_STEPS
+        nd = cfg.TASK_CONFIG.TASK.NDTW
+        self.ndtw_fdtw, self.ndtw_success_distance = bool(nd.FDTW), float(nd.SUCCESS_DISTANCE)
         self.episodes = []
         for e in range(n_episodes):
             n = self.rng.randint(min_len, max_len + 1)
@@ -90,15 +93,38 @@ class _SynthEnv:
         self.pose = self.current_episode.start.copy()
         self.heading = 0.0
         self.t = 0
+        self._positions = [[float(x) for x in self.pose]]
         self._log()
         return self._obs()
+
+    @staticmethod
+    def _gt_positions(ep):
+        pose, heading = ep.start.copy(), 0.0
+        pts = [[float(x) for x in pose]]
+        for a in ep.script:
+            if a == FORWARD:
+                pose[0] += np.float32(-0.25 * math.sin(heading))
+                pose[2] += np.float32(-0.25 * math.cos(heading))
+                pts.append([float(x) for x in pose])
+            elif a == LEFT:
+                heading += math.radians(15.0)
+            elif a == RIGHT:
+                heading -= math.radians(15.0)
+        return pts
 
     def step(self, action):
         self._apply(int(action))
         self.t += 1
         done = int(action) == STOP or self.t >= min(self.max_steps, 4 * len(self.current_episode.script))
         self._log()
-        info = {"distance_to_goal": 0.0, "success": float(done and int(action) == STOP), "spl": 0.0, "ndtw": 0.0,
+        success = float(done and int(action) == STOP)
+        self._positions.append([float(x) for x in self.pose])
+        ndtw_v = 0.0
+        if done:  # per-episode nDTW / SDTW against the scripted expert's path (measures.py:152-230)
+            agent = [p for i, p in enumerate(self._positions) if i == 0 or p != self._positions[i - 1]]
+            ndtw_v = ndtw(agent, self._gt_positions(self.current_episode), self.ndtw_success_distance, self.ndtw_fdtw)
+        info = {"distance_to_goal": 0.0, "success": success, "spl": 0.0, "ndtw": ndtw_v,
+                "sdtw": SDTW.get_metric(success, ndtw_v),
                 "path_length": 0.25 * self.t, "oracle_success": 0.0, "steps_taken": float(self.t)}
         obs = self.reset() if done else self._obs()
         return obs, 0.0, done, info

@@ -152,6 +152,11 @@ def test_synthetic_env_protocol_and_sharding():
         out = envs.step(expert)
         obs = [o[0] for o in out]
         done_count += sum(o[2] for o in out)
+        for o in out:
+            if o[2]:  # the expert's own path: nDTW == SDTW == 1 (fastdtw of identical paths is exact)
+                assert abs(o[3]["ndtw"] - 1.0) < 1e-12 and abs(o[3]["sdtw"] - 1.0) < 1e-12
+            else:
+                assert o[3]["ndtw"] == 0.0
     assert done_count >= 4
     from ivln_ce_amd.tour_ndtw import compute_tour_ndtw
 
@@ -160,3 +165,42 @@ def test_synthetic_env_protocol_and_sharding():
     assert set(agent) == set(gt) and abs(compute_tour_ndtw(agent, gt) - 1.0) < 1e-9
     a = SyntheticVectorEnv(cfg, num_envs=2, rank=1, world=4)
     assert [e.idx for e in a._envs] == [1, 5]
+
+
+def test_dtw_recurrence_matches_reference_golden():
+    """csrc/dtw.cpp (the DTW under nDTW / SDTW / t-nDTW) against distances produced by the reference's own
+    exact DTW (habitat_extensions/utils.py:155-221), tests/golden/gen_dtw_golden.py; 1e-9 relative."""
+    from ivln_ce_amd.measures import ndtw
+    from ivln_ce_amd.tour_ndtw import dtw_symmetric1
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dtw.npz"))
+    for k in range(int(g["n_cases"])):
+        x, y = g[f"x_{k}"], g[f"y_{k}"]
+        d = dtw_symmetric1(x, y)
+        assert abs(d - float(g[f"d_{k}"])) <= 1e-9 * max(1.0, abs(float(g[f"d_{k}"]))), (k, d, float(g[f"d_{k}"]))
+        assert abs(ndtw(x.tolist(), y.tolist(), 3.0, fdtw=False) - float(g[f"ndtw_{k}"])) < 1e-12
+
+
+def test_fastdtw_restatement_known_answers():
+    """FastDTW (third-party, unpinned): identical paths -> 0; sequences shorter than radius+2 -> exact DTW;
+    never below the exact DTW distance and close to it on smooth trajectories; NDTW/SDTW measure plumbing."""
+    from ivln_ce_amd.measures import NDTW, SDTW, fastdtw, ndtw
+    from ivln_ce_amd.tour_ndtw import dtw_symmetric1
+
+    rng = np.random.RandomState(3)
+    a = np.cumsum(rng.randn(50, 3) * 0.25, axis=0)
+    assert fastdtw(a, a)[0] == 0.0
+    s1, s2 = rng.rand(2, 3), rng.rand(2, 3)
+    assert abs(fastdtw(s1, s2)[0] - dtw_symmetric1(s1, s2)) < 1e-12
+    b = a[::2] + rng.randn(25, 3) * 0.05
+    exact, fast = dtw_symmetric1(a, b), fastdtw(a, b)[0]
+    assert exact - 1e-9 <= fast <= 1.25 * exact
+    path = fastdtw(a, b)[1]
+    assert path[0] == (0, 0) and path[-1] == (49, 24)
+    m = NDTW(3.0, fdtw=False)
+    m.reset_metric(b.tolist(), a[0])
+    for p in a[1:]:
+        m.update_metric(p)
+        m.update_metric(p)  # an unchanged position is not appended (measures.py:196-200)
+    assert len(m.locations) == 50 and abs(m.get_metric() - ndtw(a.tolist(), b.tolist(), 3.0)) < 1e-12
+    assert SDTW.get_metric(1.0, m.get_metric()) == m.get_metric() and SDTW.get_metric(0.0, m.get_metric()) == 0.0
