@@ -473,6 +473,62 @@ class BaseVLNCETrainer:
         raise NotImplementedError("quirk Q10: no reference trainer defines inference() either")
 
 
+class PrefetchLoader:
+    """Keeps the update loop fed ("so updates are not input-bound"): a worker thread reads
+    and collates the next trajectory batches (npz decode, padding), pins them and copies them to the GPU on
+    its own stream while the previous update runs; the consumer only waits on the copy's event.  Order is the
+    wrapped loader's order (one worker), so runs are reproducible.  Replaces the reference's DataLoader
+    workers (dagger_trainer.py:585-596)."""
+
+    def __init__(self, loader, device, depth=2):
+        self.loader, self.device, self.depth = loader, device, depth
+
+    def __iter__(self):
+        import queue
+        import threading
+
+        q = queue.Queue(maxsize=self.depth)
+        cuda = self.device.type == "cuda"
+        stream = torch.cuda.Stream(self.device) if cuda else None
+
+        def pin(x):
+            if isinstance(x, dict):
+                return {k: pin(v) for k, v in x.items()}
+            return x.pin_memory() if (cuda and torch.is_tensor(x)) else x
+
+        def work():
+            try:
+                for batch in self.loader:
+                    obs_b, prev_b, nd_b, corr_b, w_b = (pin(b) for b in batch)
+                    if cuda:
+                        with torch.cuda.stream(stream):
+                            moved = batch_to((obs_b, prev_b, nd_b, None, corr_b, w_b), self.device)
+                            ev = torch.cuda.Event()
+                            ev.record(stream)
+                    else:
+                        moved, ev = batch_to((obs_b, prev_b, nd_b, None, corr_b, w_b), self.device), None
+                    q.put((moved, ev))
+                q.put(None)
+            except BaseException as e:  # noqa: BLE001 - surface loader errors in the training thread
+                q.put(e)
+
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        while True:
+            item = q.get()
+            if item is None:
+                break
+            if isinstance(item, BaseException):
+                raise item
+            moved, ev = item
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
+                for v in list(moved[0].values()) + [m for m in moved[1:] if m is not None]:
+                    v.record_stream(torch.cuda.current_stream())  # allocated on the copy stream, used on this one
+            yield moved
+        th.join()
+
+
 @baseline_registry.register_trainer(name="dagger")
 class DaggerTrainer(BaseVLNCETrainer):
     def __init__(self, config=None):
@@ -583,10 +639,7 @@ class DaggerTrainer(BaseVLNCETrainer):
                                                  collate_fn=collate_fn, pin_memory=False, drop_last=True, num_workers=0)
             AuxLosses.activate()  # only around the updates, never during rollouts (dagger_trainer.py:579)
             for epoch in range(self.start_epoch, cfg.IL.epochs):
-                for batch in loader:
-                    obs_b, prev_b, nd_b, corr_b, w_b = batch
-                    obs_b, prev_b, nd_b, _, corr_b, w_b = batch_to(
-                        (obs_b, prev_b, nd_b, None, corr_b, w_b), self.device)
+                for obs_b, prev_b, nd_b, _, corr_b, w_b in PrefetchLoader(loader, self.device):
                     loss, action_loss, aux_loss = self._update_agent(obs_b, prev_b, nd_b, corr_b, w_b)
                     log.append({"dagger_it": dagger_it, "epoch": epoch, "step": step_id, "loss": loss,
                                 "action_loss": action_loss, "aux_loss": aux_loss})

@@ -204,3 +204,21 @@ def test_fastdtw_restatement_known_answers():
         m.update_metric(p)  # an unchanged position is not appended (measures.py:196-200)
     assert len(m.locations) == 50 and abs(m.get_metric() - ndtw(a.tolist(), b.tolist(), 3.0)) < 1e-12
     assert SDTW.get_metric(1.0, m.get_metric()) == m.get_metric() and SDTW.get_metric(0.0, m.get_metric()) == 0.0
+
+
+def test_prefetch_loader_preserves_order_and_surfaces_errors():
+    from ivln_ce_amd.trainers import PrefetchLoader
+
+    def batches(n, fail_at=None):
+        for i in range(n):
+            if i == fail_at:
+                raise RuntimeError("broken record")
+            yield ({"occupancy_map": torch.full((4, 2), float(i))}, torch.full((4, 1), i), torch.ones(4, 1, dtype=torch.uint8),
+                   torch.zeros(2, 2, dtype=torch.long), torch.ones(2, 2))
+
+    got = [int(b[1][0, 0]) for b in PrefetchLoader(batches(7), torch.device("cpu"))]
+    assert got == list(range(7))
+    out = next(iter(PrefetchLoader(batches(1), torch.device("cpu"))))
+    assert out[0]["occupancy_map"].dtype == torch.float32 and out[3] is None
+    with pytest.raises(RuntimeError, match="broken record"):
+        list(PrefetchLoader(batches(5, fail_at=2), torch.device("cpu")))
