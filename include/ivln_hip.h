@@ -221,6 +221,12 @@ int ivln_prev_action_embed_f32(const int64_t* prev_actions, const uint8_t* mask,
  * (rows, O). */
 int ivln_linear_argmax_f32(const float* x, int64_t ldx, const float* W, const float* bias, int rows, int K, int O,
                            int64_t* action, float* logits_out, void* stream);
+/* u8 NHWC -> f32 NCHW / div (TorchVisionResNet.forward, models/encoders/resnet_encoders.py:171-198: / 255) */
+int ivln_rgb_to_nchw_f32(const uint8_t* rgb, int B, int H, int W, float div, float* out, void* stream);
+/* F.adaptive_avg_pool2d (SpatialAvgPool -> 4x4, resnet_encoders.py:152-158); out_img_stride lets `out` be a
+ * channel slice of a wider NCHW buffer (0 -> C*OH*OW) */
+int ivln_adaptive_avgpool2d_f32(const float* x, int N, int C, int H, int W, int OH, int OW, float* out,
+                                int64_t out_img_stride, void* stream);
 int ivln_argmax_rows(const float* x, int rows, int C, int64_t* out, void* stream);
 int ivln_argmax_channels_u8(const float* x, int N, int C, int HW, uint8_t* out, void* stream);
 /* PredictSemantics input prep (mapper.py:715-736,788-793). */

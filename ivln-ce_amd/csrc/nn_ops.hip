@@ -1013,6 +1013,37 @@ __global__ __launch_bounds__(256) void k_linear_argmax(const float* __restrict__
     }
 }
 
+// u8 NHWC image -> f32 NCHW / div (TorchVisionResNet.forward: permute(0,3,1,2) and an IEEE division by 255,
+// resnet_encoders.py:171-198 with normalize_visual_inputs False)
+__global__ __launch_bounds__(256) void k_rgb_to_nchw(const uint8_t* __restrict__ rgb, int B, int H, int W, float div,
+                                                     float* __restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over B*H*W pixels
+    if (idx >= (int64_t)B * H * W) return;
+    const int64_t b = idx / ((int64_t)H * W), p = idx - b * H * W;
+    const uint8_t* px = rgb + idx * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[(b * 3 + c) * H * W + p] = (float)px[c] / div;
+}
+
+// F.adaptive_avg_pool2d: window [floor(i*H/OH), ceil((i+1)*H/OH)) per output row / column
+// (SpatialAvgPool to 4x4, resnet_encoders.py:152-158); out may be a channel slice of a wider NCHW buffer
+__global__ __launch_bounds__(256) void k_adaptive_avgpool2d(const float* __restrict__ x, int N, int C, int H, int W,
+                                                            int OH, int OW, float* __restrict__ out,
+                                                            int64_t out_img_stride) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)N * C * OH * OW) return;
+    const int ow = (int)(idx % OW), oh = (int)((idx / OW) % OH);
+    const int64_t nc = idx / ((int64_t)OW * OH);
+    const int n = (int)(nc / C), c = (int)(nc % C);
+    const int h0 = (oh * H) / OH, h1 = ((oh + 1) * H + OH - 1) / OH;
+    const int w0 = (ow * W) / OW, w1 = ((ow + 1) * W + OW - 1) / OW;
+    const float* xp = x + nc * H * W;
+    float s = 0.f;
+    for (int h = h0; h < h1; ++h)
+        for (int w = w0; w < w1; ++w) s += xp[h * W + w];
+    out[(int64_t)n * out_img_stride + ((int64_t)c * OH + oh) * OW + ow] = s / (float)((h1 - h0) * (w1 - w0));
+}
+
 // channel argmax over NCHW logits -> u8 labels (predicted_scores.argmax(1), mapper.py:796-798)
 __global__ __launch_bounds__(256) void k_argmax_channels_u8(const float* __restrict__ x, int N, int C, int HW,
                                                             uint8_t* __restrict__ out) {
@@ -1288,6 +1319,22 @@ int ivln_linear_argmax_f32(const float* x, int64_t ldx, const float* W, const fl
     if (O > 8 || O <= 0 || (K & 3) || (ldx & 3) || rows <= 0) return IVLN_E_UNSUPPORTED;
     hipLaunchKernelGGL(k_linear_argmax, dim3(1), dim3(256), 0, (hipStream_t)stream, x, ldx, W, bias, rows, K, O, action,
                        logits_out);
+    return LAUNCH_OK();
+}
+
+int ivln_rgb_to_nchw_f32(const uint8_t* rgb, int B, int H, int W, float div, float* out, void* stream) {
+    if (B <= 0 || div == 0.f) return IVLN_E_INVALID;
+    hipLaunchKernelGGL(k_rgb_to_nchw, dim3(nblk((int64_t)B * H * W)), dim3(256), 0, (hipStream_t)stream, rgb, B, H, W,
+                       div, out);
+    return LAUNCH_OK();
+}
+
+int ivln_adaptive_avgpool2d_f32(const float* x, int N, int C, int H, int W, int OH, int OW, float* out,
+                                int64_t out_img_stride, void* stream) {
+    if (N <= 0 || OH <= 0 || OW <= 0) return IVLN_E_INVALID;
+    if (out_img_stride <= 0) out_img_stride = (int64_t)C * OH * OW;
+    hipLaunchKernelGGL(k_adaptive_avgpool2d, dim3(nblk((int64_t)N * C * OH * OW)), dim3(256), 0, (hipStream_t)stream, x,
+                       N, C, H, W, OH, OW, out, out_img_stride);
     return LAUNCH_OK();
 }
 

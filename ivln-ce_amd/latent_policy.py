@@ -1,0 +1,287 @@
+"""Latent-CMA baseline on HIP: `LatentCMAPolicy` / `LatentCMANet`
+(ivlnce_baselines/models/latent_cma_policy.py:28-497) and the `TorchVisionResNet50` RGB encoder
+(models/encoders/resnet_encoders.py:118-229) under the same registry name and state_dict keys.
+
+Inference path (`act`, `act_iterative`, tour-memory variants) runs on the HIP kernels of this package: the RGB
+ResNet-50 is the BN-folded bottleneck stack already used by RedNet (MFMA convs with fused scale/shift/
+residual/ReLU epilogues), the head reuses the MapCMA kernels (instruction bi-LSTM, DD-PPO depth ResNet,
+GRU steps, attention).  Training of this baseline (unrolled tour memory, `IterativeDaggerTrainer`) is not
+built: `forward` under autograd raises.
+"""
+from typing import Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from . import ops
+from .encoders import InstructionEncoder, VlnResnetDepthEncoder, build_rnn_state_encoder
+from .policy import ILPolicy, Net
+from .rednet import Bottleneck, _Folded
+from .registry import baseline_registry
+
+
+class TorchVisionResNet50(nn.Module):
+    """resnet_encoders.py:118-229 with `spatial_output=True` (the only way LatentCMANet builds it): torchvision
+    ResNet-50 children [conv1, bn1, relu, maxpool, layer1..4] as `cnn` (avgpool -> adaptive 4x4), plus a 64-d
+    learned embedding of the 16 positions.  Output (B, 2048 + 64, 4, 4)."""
+
+    def __init__(self, output_size: int, normalize_visual_inputs: bool = False, trainable: bool = False,
+                 spatial_output: bool = True, single_spatial_filter: bool = True) -> None:
+        super().__init__()
+        assert spatial_output, "LatentCMANet uses the spatial output"
+        assert not normalize_visual_inputs, "the reference never enables ImageNet normalisation here"
+        self.normalize_visual_inputs = normalize_visual_inputs
+        self.spatial_output = spatial_output
+        self.resnet_layer_size = 2048
+        inplanes = [64]
+
+        def make_layer(planes, blocks, stride=1):
+            downsample = None
+            if stride != 1 or inplanes[0] != planes * 4:
+                downsample = nn.Sequential(nn.Conv2d(inplanes[0], planes * 4, 1, stride, bias=False),
+                                           nn.BatchNorm2d(planes * 4))
+            layers = [Bottleneck(inplanes[0], planes, stride, downsample)]
+            inplanes[0] = planes * 4
+            layers += [Bottleneck(inplanes[0], planes) for _ in range(1, blocks)]
+            return nn.Sequential(*layers)
+
+        self.cnn = nn.Sequential(
+            nn.Conv2d(3, 64, 7, 2, 3, bias=False), nn.BatchNorm2d(64), nn.ReLU(inplace=True), nn.MaxPool2d(3, 2, 1),
+            make_layer(64, 3), make_layer(128, 4, 2), make_layer(256, 6, 2), make_layer(512, 3, 2),
+        )
+        for param in self.cnn.parameters():
+            param.requires_grad_(trainable)
+        self.cnn.train(trainable)
+        self.spatial_embeddings = nn.Embedding(4 * 4, 64)
+        self.output_shape = (self.resnet_layer_size + self.spatial_embeddings.embedding_dim, 4, 4)
+        self._folded = _Folded()
+        self._epoch = -1
+
+    @property
+    def is_blind(self):
+        return False
+
+    def forward(self, observations) -> Tensor:
+        c, E = self.resnet_layer_size, self.spatial_embeddings.embedding_dim
+        if self._epoch != ops.WEIGHT_EPOCH:  # folded BatchNorms follow parameter updates / checkpoint loads
+            self._folded, self._epoch = _Folded(), ops.WEIGHT_EPOCH
+        f = self._folded
+        if "rgb_features" in observations:
+            feats = observations["rgb_features"].to(torch.float32).contiguous()
+            B = feats.shape[0]
+            out = torch.empty((B, c + E, 4, 4), dtype=torch.float32, device=feats.device)
+            ops.copy2d(feats.view(B, -1), out.view(B, -1), B, c * 16)
+        else:
+            rgb = observations["rgb"]
+            if not rgb.is_cuda:
+                raise RuntimeError("HIP hot path needs GPU tensors (no CPU fallback)")
+            B = rgb.shape[0]
+            x = ops.rgb_to_nchw(rgb.to(torch.uint8).contiguous(), 255.0)
+            s, b = f.bn(self.cnn[1])
+            x = ops.conv2d(x, self.cnn[0].weight, stride=2, pad=3, scale=s, shift=b, relu=True)
+            x = ops.pool2d(x, 3, 2, 1, "max")
+            for layer in (self.cnn[4], self.cnn[5], self.cnn[6], self.cnn[7]):
+                for blk in layer:
+                    x = blk.forward_hip(x, f)
+            out = torch.empty((B, c + E, 4, 4), dtype=torch.float32, device=x.device)
+            ops.adaptive_avgpool2d(x, 4, 4, out=out, out_ctot=c + E)
+        # the (16, 64) table viewed as (1, 64, 4, 4): a reshape of row-major memory, not a transpose
+        ops.copy2d(self.spatial_embeddings.weight.view(1, -1), out.view(B, -1)[:, c * 16:], B, E * 16, broadcast_rows=True)
+        return out
+
+
+class LatentCMANet(Net):
+    """latent_cma_policy.py:195-497 (inference): instruction bi-LSTM, DD-PPO depth ResNet, torchvision RGB
+    ResNet-50, two GRU state encoders, three attentions, optional cross-episode tour memory."""
+
+    def __init__(self, observation_space, model_config, num_actions):
+        super().__init__()
+        self.model_config = model_config
+        model_config.defrost()
+        model_config.INSTRUCTION_ENCODER.final_state_only = False
+        model_config.freeze()
+        self.instruction_encoder = InstructionEncoder(model_config.INSTRUCTION_ENCODER)
+        assert model_config.DEPTH_ENCODER.cnn_type in ["VlnResnetDepthEncoder"], \
+            "DEPTH_ENCODER.cnn_type must be VlnResnetDepthEncoder"
+        self.depth_encoder = VlnResnetDepthEncoder(
+            observation_space, output_size=model_config.DEPTH_ENCODER.output_size,
+            checkpoint=model_config.DEPTH_ENCODER.ddppo_checkpoint, backbone=model_config.DEPTH_ENCODER.backbone,
+            spatial_output=True,
+        )
+        assert model_config.RGB_ENCODER.cnn_type in ["TorchVisionResNet50"], \
+            "RGB_ENCODER.cnn_type must be TorchVisionResNet50"
+        self.rgb_encoder = TorchVisionResNet50(output_size=model_config.RGB_ENCODER.output_size, spatial_output=True)
+        self.prev_action_embedding = nn.Embedding(num_actions + 1, 32)
+        hidden_size = model_config.STATE_ENCODER.hidden_size
+        self._hidden_size = hidden_size
+        self.rgb_linear = nn.Sequential(
+            nn.AdaptiveAvgPool1d(1), nn.Flatten(),
+            nn.Linear(self.rgb_encoder.output_shape[0], model_config.RGB_ENCODER.output_size), nn.ReLU(True),
+        )
+        self.depth_linear = nn.Sequential(
+            nn.Flatten(), nn.Linear(int(np.prod(self.depth_encoder.output_shape)), model_config.DEPTH_ENCODER.output_size),
+            nn.ReLU(True),
+        )
+        rnn_input_size = (model_config.DEPTH_ENCODER.output_size + model_config.RGB_ENCODER.output_size
+                          + self.prev_action_embedding.embedding_dim)
+        if model_config.tour_memory_variant:
+            rnn_input_size += hidden_size
+        self.state_encoder = build_rnn_state_encoder(input_size=rnn_input_size, hidden_size=hidden_size,
+                                                     rnn_type=model_config.STATE_ENCODER.rnn_type, num_layers=1)
+        self._output_size = (hidden_size + model_config.RGB_ENCODER.output_size + model_config.DEPTH_ENCODER.output_size
+                             + self.instruction_encoder.output_size)
+        self.rgb_kv = nn.Conv1d(self.rgb_encoder.output_shape[0], hidden_size // 2 + model_config.RGB_ENCODER.output_size, 1)
+        self.depth_kv = nn.Conv1d(self.depth_encoder.output_shape[0],
+                                  hidden_size // 2 + model_config.DEPTH_ENCODER.output_size, 1)
+        self.state_q = nn.Linear(hidden_size, hidden_size // 2)
+        self.text_k = nn.Conv1d(self.instruction_encoder.output_size, hidden_size // 2, 1)
+        self.text_q = nn.Linear(self.instruction_encoder.output_size, hidden_size // 2)
+        self.register_buffer("_scale", torch.tensor(1.0 / ((hidden_size // 2) ** 0.5)))
+        self._scale_f = float(1.0 / ((hidden_size // 2) ** 0.5))
+        self.second_state_compress = nn.Sequential(
+            nn.Linear(self._output_size + self.prev_action_embedding.embedding_dim, hidden_size), nn.ReLU(True))
+        self.second_state_encoder = build_rnn_state_encoder(input_size=hidden_size, hidden_size=hidden_size,
+                                                            rnn_type=model_config.STATE_ENCODER.rnn_type, num_layers=1)
+        assert (not model_config.memory_at_end) or model_config.tour_memory_variant, \
+            "`memory_at_end` requires `tour_memory_variant`."
+        if model_config.memory_at_end:
+            self.out_layer = nn.Sequential(nn.Linear(hidden_size * 2, hidden_size), nn.ReLU(True))
+        self._output_size = hidden_size
+        self.progress_monitor = nn.Linear(self.output_size, 1)
+        if model_config.PROGRESS_MONITOR.use:
+            nn.init.kaiming_normal_(self.progress_monitor.weight, nonlinearity="tanh")
+            nn.init.constant_(self.progress_monitor.bias, 0)
+        self.train()
+
+    @property
+    def output_size(self):
+        return self._output_size
+
+    @property
+    def is_blind(self):
+        return self.rgb_encoder.is_blind or self.depth_encoder.is_blind
+
+    @property
+    def num_recurrent_layers(self):
+        return (self.state_encoder.num_recurrent_layers + self.second_state_encoder.num_recurrent_layers
+                + int(self.model_config.tour_memory_variant))
+
+    def forward(self, observations, rnn_states, prev_actions, action_masks, episode_masks=None, tour_masks=None):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("Latent-CMA training is not built on HIP yet: call under torch.no_grad()")
+        mc = self.model_config
+        if mc.disable_tour_memory:
+            tour_masks = None
+        if episode_masks is None:
+            episode_masks = action_masks
+        if tour_masks is None:
+            tour_masks = episode_masks
+        dev = rnn_states.device
+        H, h2 = self._hidden_size, self._hidden_size // 2
+        N = rnn_states.shape[0]
+        variant = bool(mc.tour_memory_variant)
+        rnn_states = rnn_states.to(torch.float32).contiguous()
+        act_u8 = action_masks.reshape(-1).to(torch.uint8).contiguous()
+        ep_u8 = episode_masks.reshape(-1).to(torch.uint8).contiguous()
+        rows = act_u8.shape[0]
+        if rows != N:
+            raise NotImplementedError("Latent-CMA on HIP serves single-step inference (rows == envs)")
+        prev_actions = prev_actions.reshape(-1).long().contiguous()
+        if variant:  # latent_cma_policy.py:381-385: the tour memory is cleared where a new tour starts
+            rnn_states = rnn_states.clone()
+            rnn_states[:, 2:] = tour_masks.view(-1, 1, 1).to(torch.float32) * rnn_states[:, 2:]
+
+        txt, lengths = self.instruction_encoder(observations, None)  # (rows, 256, L), zero beyond each length
+        dep = self.depth_encoder(observations)                        # (rows, 192, 4, 4)
+        rgb = self.rgb_encoder(observations)                          # (rows, 2112, 4, 4)
+        if mc.ablate_instruction:
+            txt = torch.zeros_like(txt)
+        if mc.ablate_depth:
+            dep = torch.zeros_like(dep)
+        if mc.ablate_rgb:
+            rgb = torch.zeros_like(rgb)
+        L = txt.shape[2]
+        P = dep.shape[2] * dep.shape[3]
+        Cr, Cd = rgb.shape[1], dep.shape[1]
+        r_out, d_out = self.rgb_linear[2].out_features, self.depth_linear[1].out_features
+        E = self.prev_action_embedding.embedding_dim
+
+        # state_in = [rgb_in | depth_in | prev (| tour memory)];  x2 = [state | text | rgb' | depth' | prev]
+        s_w = r_out + d_out + E + (H if variant else 0)
+        state_in = torch.empty((rows, s_w), dtype=torch.float32, device=dev)
+        x2 = torch.empty((rows, H + 256 + r_out + d_out + E), dtype=torch.float32, device=dev)
+        o_txt, o_rgb, o_dep, o_prev = H, H + 256, H + 256 + r_out, H + 256 + r_out + d_out
+        ops.prev_action_embed(prev_actions, act_u8, self.prev_action_embedding.weight, state_in[:, r_out + d_out:r_out + d_out + E],
+                              x2[:, o_prev:])
+        rgb_mean = ops.pool2d(rgb, 4, 4, 0, "avg")  # AdaptiveAvgPool1d(1) over the 16 positions
+        ops.linear(rgb_mean.view(rows, Cr), self.rgb_linear[2].weight, self.rgb_linear[2].bias, relu=True,
+                   out=state_in[:, :r_out])
+        ops.linear(dep.view(rows, -1), self.depth_linear[1].weight, self.depth_linear[1].bias, relu=True,
+                   out=state_in[:, r_out:r_out + d_out])
+        if variant:
+            state_in[:, r_out + d_out + E:] = rnn_states[:, 2]
+
+        rnn_out = rnn_states.detach().clone()
+        state = x2[:, :H]
+        self.state_encoder(state_in, rnn_states[:, 0], ep_u8, state, rnn_out[:, 0], None)
+        if variant:  # cross-episode memory = running max of the first GRU's state (latent_cma_policy.py:420-425)
+            rnn_out[:, 2] = torch.max(rnn_out[:, 2], rnn_out[:, 0])
+
+        q1 = ops.linear(state, self.state_q.weight, self.state_q.bias)
+        tk = ops.conv2d(txt.view(rows, -1, 1, L), self.text_k.weight.view(h2, -1, 1, 1), shift=self.text_k.bias, splitk=False)
+        text = x2[:, o_txt:o_txt + 256]
+        ops.attn(q1, tk.view(rows, h2, L), txt, lengths, self._scale_f, text)
+        rkv = ops.conv2d(rgb.view(rows, Cr, 1, P), self.rgb_kv.weight.view(-1, Cr, 1, 1), shift=self.rgb_kv.bias).view(rows, -1, P)
+        dkv = ops.conv2d(dep.view(rows, Cd, 1, P), self.depth_kv.weight.view(-1, Cd, 1, 1), shift=self.depth_kv.bias).view(rows, -1, P)
+        q2 = ops.linear(text, self.text_q.weight, self.text_q.bias)
+        ops.attn_small2(q2, rkv[:, :h2], rkv[:, h2:], x2[:, o_rgb:o_rgb + r_out], dkv[:, :h2], dkv[:, h2:],
+                        x2[:, o_dep:o_dep + d_out], self._scale_f)
+        sc = self.second_state_compress[0]
+        c2 = ops.linear(x2, sc.weight, sc.bias, relu=True)
+        feats = torch.empty((rows, H), dtype=torch.float32, device=dev)
+        self.second_state_encoder(c2, rnn_states[:, 1], ep_u8, feats, rnn_out[:, 1], None)
+        if mc.memory_at_end:
+            ol = self.out_layer[0]
+            feats = ops.linear(torch.cat([feats, rnn_states[:, 2]], dim=1), ol.weight, ol.bias, relu=True)
+        return feats, rnn_out
+
+
+@baseline_registry.register_policy
+class LatentCMAPolicy(ILPolicy):
+    """latent_cma_policy.py:28-193: memory options - `tour_memory`: the RNN states reset with the TOUR, not the
+    episode; `tour_memory_variant`: episodic states plus a third, tour-long memory slot."""
+
+    def __init__(self, observation_space, action_space, model_config):
+        self.tour_memory = model_config.tour_memory
+        self.tour_memory_variant = model_config.tour_memory_variant
+        self.train_unrolled = model_config.train_unrolled
+        super().__init__(
+            LatentCMANet(observation_space=observation_space, model_config=model_config, num_actions=action_space.n),
+            action_space.n,
+        )
+
+    def act_iterative(self, observations, rnn_hidden_states, prev_actions, agent_episode_not_done_masks,
+                      sim_episode_not_done_masks, tour_not_done_masks, action_masks, deterministic=False):
+        if self.tour_memory_variant:
+            episode_masks, tour_masks = agent_episode_not_done_masks, tour_not_done_masks
+        else:
+            episode_masks = tour_not_done_masks if self.tour_memory else None
+            tour_masks = None
+        features, rnn_hidden_states = self.net(
+            observations, rnn_hidden_states, prev_actions, action_masks=agent_episode_not_done_masks,
+            episode_masks=episode_masks, tour_masks=tour_masks,
+        )
+        return self._act(features, deterministic), rnn_hidden_states
+
+    def build_distribution(self, observations, rnn_hidden_states, prev_actions, agent_episode_not_done_masks,
+                           tour_not_done_masks=None) -> Tuple:
+        raise NotImplementedError("Latent-CMA training (unrolled tour memory) is not built on HIP yet")
+
+    @classmethod
+    def from_config(cls, config, observation_space, action_space):
+        config.defrost()
+        config.MODEL.TORCH_GPU_ID = config.TORCH_GPU_ID
+        config.freeze()
+        return cls(observation_space=observation_space, action_space=action_space, model_config=config.MODEL)

@@ -528,6 +528,26 @@ def rgb_resize_normalize(rgb_u8_nhwc, Ho, Wo):
     return out
 
 
+def rgb_to_nchw(rgb_u8_nhwc, div=255.0):
+    B, H, W, _ = rgb_u8_nhwc.shape
+    out = torch.empty((B, 3, H, W), dtype=torch.float32, device=rgb_u8_nhwc.device)
+    L = _L()
+    L.ivln_rgb_to_nchw_f32.argtypes = [vp, i32, i32, i32, f32, vp, vp]
+    check(L.ivln_rgb_to_nchw_f32(dptr(rgb_u8_nhwc), B, H, W, div, dptr(out), stream_ptr()), "ivln_rgb_to_nchw_f32")
+    return out
+
+
+def adaptive_avgpool2d(x, OH, OW, out=None, out_ctot=0):
+    N, Cc, H, W = x.shape
+    if out is None:
+        out = torch.empty((N, Cc, OH, OW), dtype=torch.float32, device=x.device)
+    L = _L()
+    L.ivln_adaptive_avgpool2d_f32.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, i64, vp]
+    check(L.ivln_adaptive_avgpool2d_f32(dptr(x), N, Cc, H, W, OH, OW, _p(out), out_ctot * OH * OW, stream_ptr()),
+          "ivln_adaptive_avgpool2d_f32")
+    return out
+
+
 def affine(x, sub, div):
     out = torch.empty_like(x)
     check(_L().ivln_affine_f32(dptr(x), dptr(out), x.numel(), sub, div, stream_ptr()), "ivln_affine_f32")

@@ -138,8 +138,9 @@ def install():
             return x
 
     tv_t = _mod("torchvision.transforms", Compose=Compose)
+    tv_ref = _load("oracle_torchvision_ref", os.path.join(REPO, "oracle", "torchvision_ref.py"))
     tv_r = _mod("torchvision.models.resnet", model_urls={})
-    tv_m = _mod("torchvision.models", resnet=tv_r)
+    tv_m = _mod("torchvision.models", resnet=tv_r, resnet50=tv_ref.resnet50)
     _mod("torchvision", transforms=tv_t, models=tv_m)
     _mod("torch_scatter", scatter_max=ext.scatter_max)
 

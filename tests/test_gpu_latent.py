@@ -1,0 +1,76 @@
+"""GPU parity of the Latent-CMA baseline against goldens produced by the reference's
+own LatentCMAPolicy / TorchVisionResNet50 wrapper (tests/golden/gen_latent_golden.py).  Floating point:
+features / states / logits within 2e-4 abs (50-layer fp32 conv stack, values O(1)-O(10)), actions equal."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+DEV = torch.device("cuda:0")
+
+
+def _policy(variant):
+    from det_init import det_fill
+
+    import ivln_ce_amd  # noqa: F401
+    from ivln_ce_amd import latent_policy  # noqa: F401
+    from ivln_ce_amd.config import get_config
+    from ivln_ce_amd.registry import baseline_registry
+    from ivln_ce_amd.spaces import Box, Dict, Discrete
+
+    cfg = get_config(opts=["MODEL.policy_name", "LatentCMAPolicy", "MODEL.INSTRUCTION_ENCODER.use_pretrained_embeddings",
+                           False, "MODEL.DEPTH_ENCODER.ddppo_checkpoint", "NONE", "MODEL.tour_memory_variant", variant,
+                           "MODEL.tour_memory", variant])
+    space = Dict({"depth": Box(0.0, 1.0, (256, 256, 1), np.float32), "rgb": Box(0, 255, (224, 224, 3), np.uint8),
+                  "instruction": Box(0, 2504, (200,), np.int64)})
+    pol = baseline_registry.get_policy("LatentCMAPolicy").from_config(cfg, space, Discrete(4))
+    det_fill(pol, seed=0, conv_gain=1.0)
+    return pol.to(DEV).eval()
+
+
+@pytest.mark.parametrize("variant,name", [(False, "latent_act_plain.npz"), (True, "latent_act_tourmem.npz")])
+def test_latent_cma_act_matches_reference_golden(variant, name):
+    g = np.load(os.path.join(HERE, "golden", name))
+    pol = _policy(variant)
+    assert pol.net.num_recurrent_layers == int(g["L"])
+    instr = torch.from_numpy(g["instruction"]).to(DEV)
+    for t in range(3):
+        obs = {"depth": torch.from_numpy(g[f"depth_{t}"]).to(DEV), "rgb": torch.from_numpy(g[f"rgb_{t}"]).to(DEV),
+               "instruction": instr}
+        rnn = torch.from_numpy(g[f"rnn_in_{t}"]).to(DEV)
+        prev = torch.from_numpy(g[f"prev_{t}"]).to(DEV)
+        ep, tour = torch.from_numpy(g[f"ep_{t}"]).to(DEV), torch.from_numpy(g[f"tour_{t}"]).to(DEV)
+        with torch.no_grad():
+            if t == 0:
+                rf = pol.net.rgb_encoder(obs)
+                err = float((rf.cpu() - torch.from_numpy(g["rgb_feats_0"])).abs().max())
+                assert err < 2e-4, f"rgb encoder features: max err {err:.3e}"
+            feats, rnn_out = pol.net(obs, rnn.clone(), prev, action_masks=ep, episode_masks=(ep if variant else None),
+                                     tour_masks=(tour if variant else None))
+            # the golden holds Categorical(logits=...).logits, i.e. normalised log-probabilities
+            logits = torch.log_softmax(pol.action_distribution.raw_logits(feats), dim=-1)
+            act, rnn_out2 = pol.act_iterative(obs, rnn.clone(), prev, ep, ep, tour, ep, deterministic=True)
+        assert float((feats.cpu() - torch.from_numpy(g[f"features_{t}"])).abs().max()) < 2e-4, f"features step {t}"
+        assert float((rnn_out.cpu() - torch.from_numpy(g[f"rnn_out_{t}"])).abs().max()) < 2e-4, f"rnn states step {t}"
+        assert float((logits.cpu() - torch.from_numpy(g[f"logits_{t}"])).abs().max()) < 1e-4, f"logits step {t}"
+        assert torch.equal(act.cpu(), torch.from_numpy(g[f"action_{t}"])), f"actions step {t}"
+        assert torch.equal(rnn_out, rnn_out2)
+
+
+def test_latent_cma_state_dict_keys_and_training_guard():
+    pol = _policy(True)
+    keys = set(pol.state_dict().keys())
+    for k in ["net.rgb_encoder.cnn.0.weight", "net.rgb_encoder.cnn.1.running_mean", "net.rgb_encoder.cnn.4.0.conv1.weight",
+              "net.rgb_encoder.cnn.7.2.bn3.bias", "net.rgb_encoder.cnn.5.0.downsample.1.weight",
+              "net.rgb_encoder.spatial_embeddings.weight", "net.rgb_linear.2.weight", "net.rgb_kv.weight",
+              "net.depth_kv.bias", "net.state_encoder.rnn.weight_ih_l0", "net.second_state_compress.0.weight",
+              "net.progress_monitor.weight", "action_distribution.linear.weight"]:
+        assert k in keys, k
+    assert pol.net.state_encoder.rnn.weight_ih_l0.shape[1] == 256 + 128 + 32 + 512  # tour memory feeds GRU 1
+    with pytest.raises(NotImplementedError):
+        pol.build_distribution({}, None, None, None)

@@ -47,10 +47,11 @@ def test_reference_yaml_files_load_when_present():
 
 
 def test_registry_names_match_reference():
-    from ivln_ce_amd import obs_transforms, policy, trainers  # noqa: F401
+    from ivln_ce_amd import latent_policy, obs_transforms, policy, trainers  # noqa: F401
     from ivln_ce_amd.registry import baseline_registry as reg
 
     assert reg.get_policy("MapCMAPolicy") is policy.MapCMAPolicy
+    assert reg.get_policy("LatentCMAPolicy") is latent_policy.LatentCMAPolicy
     for n in ["GTSemanticsIterativeMapper", "PredictedSemanticsIterativeMapper", "GTSemanticsKnownMapper",
               "PredictedSemanticsKnownMapper"]:
         assert reg.get_obs_transformer(n) is getattr(obs_transforms, n)
