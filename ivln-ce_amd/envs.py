@@ -154,6 +154,11 @@ class SyntheticVectorEnv:
         seed = config.TASK_CONFIG.SEED if seed is None else seed
         # envs sharded round-robin over ranks like construct_envs splits scenes (env_utils.py:77-99)
         ids = [i for i in range(n * world) if i % world == rank]
+        # RGB frames only for policies that read them (RedNet-predicted semantics, Latent-CMA): they are 150 KB
+        # of host RNG per step and env otherwise
+        needs_rgb = (config.MODEL.policy_name == "LatentCMAPolicy"
+                     or any("Predicted" in t for t in config.RL.POLICY.OBS_TRANSFORMS.ENABLED_TRANSFORMS))
+        env_kw.setdefault("with_rgb", needs_rgb)
         self._envs: List[_SynthEnv] = [_SynthEnv(i, seed + 1000 * i, config, **env_kw) for i in ids]
         self._paused: List[_SynthEnv] = []
         d = config.TASK_CONFIG.SIMULATOR.DEPTH_SENSOR
@@ -166,6 +171,9 @@ class SyntheticVectorEnv:
             "progress": Box(0.0, 1.0, (1,), np.float64),
             "shortest_path_sensor": Box(0.0, 100.0, (1,), np.float64),
         }
+        if env_kw["with_rgb"]:
+            r = config.TASK_CONFIG.SIMULATOR.RGB_SENSOR
+            sp["rgb"] = Box(0, 255, (r.HEIGHT, r.WIDTH, 3), np.uint8)
         self.observation_spaces = [Dict(dict(sp)) for _ in self._envs]
         self.action_spaces = [Discrete(4) for _ in self._envs]
 

@@ -74,3 +74,24 @@ def test_latent_cma_state_dict_keys_and_training_guard():
     assert pol.net.state_encoder.rnn.weight_ih_l0.shape[1] == 256 + 128 + 32 + 512  # tour memory feeds GRU 1
     with pytest.raises(NotImplementedError):
         pol.build_distribution({}, None, None, None)
+
+
+def test_latent_cma_eval_loop_plumbing(tmp_path):
+    """BASELINE configs[0] in spirit: the trainer's eval loop drives LatentCMAPolicy (no mapper transforms,
+    RGB + depth + instruction observations) over the synthetic envs and writes the stats / t-nDTW report."""
+    import ivln_ce_amd  # noqa: F401
+    from ivln_ce_amd import trainers  # noqa: F401
+    from ivln_ce_amd.config import get_config
+    from ivln_ce_amd.registry import baseline_registry
+
+    torch.manual_seed(0)
+    cfg = get_config(opts=[
+        "TRAINER_NAME", "dagger", "NUM_ENVIRONMENTS", 2, "MODEL.policy_name", "LatentCMAPolicy",
+        "MODEL.INSTRUCTION_ENCODER.use_pretrained_embeddings", False, "MODEL.DEPTH_ENCODER.ddppo_checkpoint", "NONE",
+        "RL.POLICY.OBS_TRANSFORMS.ENABLED_TRANSFORMS", [], "RESULTS_DIR", str(tmp_path / "res"),
+        "EVAL_CKPT_PATH_DIR", str(tmp_path / "none.pth"),
+    ])
+    tr = baseline_registry.get_trainer("dagger")(cfg)
+    res = tr._eval_checkpoint(str(tmp_path / "none.pth"))
+    assert res["episodes"] == 16 and 0.0 < res["t_ndtw"] <= 1.0 and 0.0 <= res["ndtw"] <= 1.0
+    assert os.path.exists(tmp_path / "res" / "stats_ckpt_0_val_seen.json")
