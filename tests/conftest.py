@@ -15,3 +15,14 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_sessionstart(session):
+    """A fresh checkout has no built artefacts (*.so are git-ignored): build the HIP library and the C oracle
+    once (hipcc cross-compiles gfx950 without a GPU; ~1-2 minutes the first time, a no-op afterwards)."""
+    need = [os.path.join(ROOT, "ivln-ce_amd", "libivln_hip.so"), os.path.join(ROOT, "oracle", "libmapper_ref.so")]
+    if all(os.path.exists(p) for p in need):
+        return
+    import __graft_entry__ as ge
+
+    ge.build()
