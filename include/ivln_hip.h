@@ -133,9 +133,17 @@ typedef struct ivln_gemm_desc {
      * 7 insist on the float4-staged GEMM (gemm_vec.hip).  6/7 return IVLN_E_UNSUPPORTED when the shape is
      * not eligible (tuning, tests). */
     int tile_override;
+    /* optional (stride-1 3x3 / 7x7 convs): the weights pre-arranged by ivln_conv_pack_weights_f32; when set and
+     * the direct kernel is chosen, its weight staging becomes a linear float4 copy.  A must still be given. */
+    const float* A_packed;
 } ivln_gemm_desc;
 
 int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream);
+/* Pre-arrangement of OIHW conv weights (M, Cin, KS, KS), KS in {3, 7}, Cin % (KS == 7 ? 2 : 8) == 0, into the
+ * LDS image of the direct convolution kernel; `out` holds ivln_conv_packed_floats(M, Cin, KS) floats (0 = shape
+ * not eligible).  Re-run whenever the weights change. */
+int64_t ivln_conv_packed_floats(int M, int Cin, int KS);
+int ivln_conv_pack_weights_f32(const float* W, int M, int Cin, int KS, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Non-GEMM forward kernels (csrc/nn_ops.hip).  All tensors fp32 NCHW unless noted.

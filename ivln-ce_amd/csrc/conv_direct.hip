@@ -20,7 +20,10 @@
 
 namespace {
 
-template <int KS, int PTW, int PTH, int IMGS, int WM>
+// PACKED: the weights arrive pre-arranged by ivln_conv_pack_weights_f32 - per (64- or 32-channel block, chunk)
+// the exact LDS image [k slot order][BM + 4] - so staging the weight slice is a linear copy of float4s
+// (7 loads + 7 ds_write_b128 per thread instead of 25 scalar loads with their address arithmetic).
+template <int KS, int PTW, int PTH, int IMGS, int WM, bool PACKED>
 __global__ __launch_bounds__(256) void k_conv_direct(const ivln_gemm_desc p, int tiles_w, int tiles_h, int nimg,
                                                      int chunks_per_split) {
     constexpr int CI = KS == 7 ? 2 : 8;  // input channels per chunk (even: channel pairs fill the k slots)
@@ -32,9 +35,9 @@ __global__ __launch_bounds__(256) void k_conv_direct(const ivln_gemm_desc p, int
     static_assert(IMGS * PTH * PTW == BN, "pixel tile must hold 128 outputs");
     constexpr int PH = PTH + KS - 1, PW = PTW + KS - 1, PLANE = PH * PW;
     constexpr int PATCH = IMGS * CI * PLANE;
-    constexpr int LDA = BM + 1;
-    constexpr int NA = (BM * KC + 255) / 256, NP = (PATCH + 255) / 256;
-    __shared__ float As[KC * LDA];
+    constexpr int LDA = PACKED ? BM + 4 : BM + 1;
+    constexpr int NA = PACKED ? (KC * LDA / 4 + 255) / 256 * 4 : (BM * KC + 255) / 256, NP = (PATCH + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float As[KC * LDA];
     __shared__ float Ps[PATCH];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -64,14 +67,25 @@ __global__ __launch_bounds__(256) void k_conv_direct(const ivln_gemm_desc p, int
 
     float ra[NA], rp[NP];
     auto load_chunk = [&](int c) {
-        const int kbase = c * KC;
+        if constexpr (PACKED) {
+            const float* wp = p.A_packed + ((int64_t)blockIdx.y * nch + c) * (KC * LDA);
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int idx = t + i * 256;
-            const int co = idx / KC, kk = idx - co * KC;
-            const bool ok = idx < BM * KC && m0 + co < p.M;
-            const float v = p.A[ok ? (int64_t)(m0 + co) * p.lda + kbase + kk : 0];
-            ra[i] = ok ? v : 0.f;
+            for (int i = 0; i < NA / 4; ++i) {
+                const int f = t + i * 256;
+                const bool ok = f < KC * LDA / 4;
+                const float4 v = *reinterpret_cast<const float4*>(wp + (ok ? f * 4 : 0));
+                ra[4 * i] = v.x, ra[4 * i + 1] = v.y, ra[4 * i + 2] = v.z, ra[4 * i + 3] = v.w;
+            }
+        } else {
+            const int kbase = c * KC;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int idx = t + i * 256;
+                const int co = idx / KC, kk = idx - co * KC;
+                const bool ok = idx < BM * KC && m0 + co < p.M;
+                const float v = p.A[ok ? (int64_t)(m0 + co) * p.lda + kbase + kk : 0];
+                ra[i] = ok ? v : 0.f;
+            }
         }
         const int cbase = c * CI * HW;
 #pragma unroll
@@ -82,12 +96,21 @@ __global__ __launch_bounds__(256) void k_conv_direct(const ivln_gemm_desc p, int
         }
     };
     auto stage = [&]() {
+        if constexpr (PACKED) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int idx = t + i * 256;
-            const int co = idx / KC, kk = idx - co * KC;
-            const int ci = kk / KK, r = kk - ci * KK;
-            if (idx < BM * KC) As[((((ci >> 1) * KK + r) << 1) + (ci & 1)) * LDA + co] = ra[i];
+            for (int i = 0; i < NA / 4; ++i) {
+                const int f = t + i * 256;
+                if (f < KC * LDA / 4)
+                    *reinterpret_cast<float4*>(&As[f * 4]) = make_float4(ra[4 * i], ra[4 * i + 1], ra[4 * i + 2], ra[4 * i + 3]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int idx = t + i * 256;
+                const int co = idx / KC, kk = idx - co * KC;
+                const int ci = kk / KK, r = kk - ci * KK;
+                if (idx < BM * KC) As[((((ci >> 1) * KK + r) << 1) + (ci & 1)) * LDA + co] = ra[i];
+            }
         }
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
@@ -151,16 +174,43 @@ __global__ __launch_bounds__(256) void k_conv_direct(const ivln_gemm_desc p, int
     }
 }
 
+// OIHW weights -> the direct kernel's LDS image, one [KC][BM + 4] tile per (channel block, chunk):
+// row kp = ((ci>>1)*KS*KS + r)*2 + (ci&1) of chunk c holds W[m0 .. m0+BM-1][(c*CI + ci), r]; pad columns and
+// channels past M are zero.
+__global__ __launch_bounds__(256) void k_conv_pack_weights(const float* __restrict__ W, int M, int Cin, int KS, int BM,
+                                                           float* __restrict__ out) {
+    const int KK = KS * KS, CI = KS == 7 ? 2 : 8, KC = CI * KK, LDA = BM + 4;
+    const int nch = Cin / CI;
+    const int64_t total = (int64_t)((M + BM - 1) / BM) * nch * KC * LDA;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int col = (int)(idx % LDA);
+    const int kp = (int)((idx / LDA) % KC);
+    const int c = (int)((idx / ((int64_t)LDA * KC)) % nch);
+    const int mb = (int)(idx / ((int64_t)LDA * KC * nch));
+    const int q = kp >> 1, par = kp & 1;
+    const int cp = q / KK, r = q - cp * KK;
+    const int ci = c * CI + cp * 2 + par;
+    const int m = mb * BM + col;
+    out[idx] = (col < BM && m < M) ? W[((int64_t)m * Cin + ci) * KK + r] : 0.f;
+}
+
 template <int KS, int PTW, int PTH, int IMGS>
 void launch_wm(const ivln_gemm_desc& d, hipStream_t s, int nimg, int cps) {
     const int tiles_w = (d.Wout + PTW - 1) / PTW, tiles_h = (d.Hout + PTH - 1) / PTH;
     const int groups = (nimg + IMGS - 1) / IMGS;
     if (d.M <= 32) {
         dim3 grid(tiles_w * tiles_h * groups, (d.M + 31) / 32, d.splits);
-        hipLaunchKernelGGL((k_conv_direct<KS, PTW, PTH, IMGS, 1>), grid, dim3(256), 0, s, d, tiles_w, tiles_h, nimg, cps);
+        if (d.A_packed)
+            hipLaunchKernelGGL((k_conv_direct<KS, PTW, PTH, IMGS, 1, true>), grid, dim3(256), 0, s, d, tiles_w, tiles_h, nimg, cps);
+        else
+            hipLaunchKernelGGL((k_conv_direct<KS, PTW, PTH, IMGS, 1, false>), grid, dim3(256), 0, s, d, tiles_w, tiles_h, nimg, cps);
     } else {
         dim3 grid(tiles_w * tiles_h * groups, (d.M + 63) / 64, d.splits);
-        hipLaunchKernelGGL((k_conv_direct<KS, PTW, PTH, IMGS, 2>), grid, dim3(256), 0, s, d, tiles_w, tiles_h, nimg, cps);
+        if (d.A_packed)
+            hipLaunchKernelGGL((k_conv_direct<KS, PTW, PTH, IMGS, 2, true>), grid, dim3(256), 0, s, d, tiles_w, tiles_h, nimg, cps);
+        else
+            hipLaunchKernelGGL((k_conv_direct<KS, PTW, PTH, IMGS, 2, false>), grid, dim3(256), 0, s, d, tiles_w, tiles_h, nimg, cps);
     }
 }
 
@@ -409,4 +459,19 @@ int ivln_wgrad_direct_launch(ivln_gemm_desc& d, hipStream_t s) {
     if (KS == 7) launch_wgrad_ks<7>(d, s, nimg, ntiles, tps);
     else launch_wgrad_ks<3>(d, s, nimg, ntiles, tps);
     return IVLN_OK;
+}
+
+extern "C" int64_t ivln_conv_packed_floats(int M, int Cin, int KS) {
+    if ((KS != 3 && KS != 7) || M <= 0) return 0;
+    const int CI = KS == 7 ? 2 : 8, BM = M <= 32 ? 32 : 64;
+    if (Cin % CI) return 0;
+    return (int64_t)((M + BM - 1) / BM) * (Cin / CI) * (CI * KS * KS) * (BM + 4);
+}
+
+extern "C" int ivln_conv_pack_weights_f32(const float* W, int M, int Cin, int KS, float* out, void* stream) {
+    const int64_t total = ivln_conv_packed_floats(M, Cin, KS);
+    if (!W || !out || total <= 0) return IVLN_E_INVALID;
+    hipLaunchKernelGGL(k_conv_pack_weights, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, M,
+                       Cin, KS, M <= 32 ? 32 : 64, out);
+    return hipGetLastError() == hipSuccess ? IVLN_OK : IVLN_E_HIP;
 }

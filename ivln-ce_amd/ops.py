@@ -32,6 +32,7 @@ class GemmDesc(C.Structure):
         ("ws", vp), ("ws_floats", i64),
         ("defer_epilogue", i32), ("splits_used", C.POINTER(i32)),
         ("tile_override", i32),
+        ("A_packed", vp),
     ]
 
 
@@ -115,6 +116,7 @@ def splitk_ws(device, floats=8 << 20, slot=0):
 
 
 TILE_OVERRIDE = 0  # tuning/tests: force a block tile (1..5), see ivln_gemm_desc.tile_override
+PACK_WEIGHTS = True  # A/B switch: pre-arranged weights for the direct conv kernel
 
 
 def gemm(desc: GemmDesc):
@@ -126,6 +128,33 @@ def gemm(desc: GemmDesc):
 def _epilogue(d: GemmDesc, scale, shift, residual, relu, accumulate=False):
     d.scale, d.shift, d.residual = _p(scale), _p(shift), _p(residual)
     d.relu, d.accumulate = int(bool(relu)), int(bool(accumulate))
+
+
+_packed = {}
+
+
+def packed_conv_weights(w):
+    """Weights of a stride-1 3x3 / 7x7 conv in the direct kernel's LDS order, cached until the tensor or the
+    parameters behind it change (tensor version / WEIGHT_EPOCH)."""
+    Cout, Cin, KH, KW = w.shape
+    L = _L()
+    L.ivln_conv_packed_floats.restype = i64
+    L.ivln_conv_packed_floats.argtypes = [i32, i32, i32]
+    n = L.ivln_conv_packed_floats(Cout, Cin, KH)
+    if n <= 0:
+        return None
+    key = (w.data_ptr(), tuple(w.shape), torch.cuda.current_stream().cuda_stream)
+    stamp = (w._version, WEIGHT_EPOCH)
+    hit = _packed.get(key)
+    if hit is not None and hit[0] == stamp:
+        return hit[1]
+    out = hit[1] if hit is not None else torch.empty(n, dtype=torch.float32, device=w.device)
+    L.ivln_conv_pack_weights_f32.argtypes = [vp, i32, i32, i32, vp, vp]
+    check(L.ivln_conv_pack_weights_f32(dptr(w), Cout, Cin, KH, dptr(out), stream_ptr()), "ivln_conv_pack_weights_f32")
+    if len(_packed) > 4096:
+        _packed.clear()
+    _packed[key] = (stamp, out, w)  # w kept alive: its data_ptr is the key
+    return out
 
 
 class Deferred:
@@ -160,6 +189,10 @@ def conv2d(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, 
         d.bmode = B_CONV1X1
     elif KH == KW and KH in (3, 7) and dil == 1:
         d.bmode = B_CONV_K3 if KH == 3 else B_CONV_K7
+        if stride == 1 and PACK_WEIGHTS and w.is_contiguous():
+            pk = packed_conv_weights(w)
+            if pk is not None:
+                d.A_packed = dptr(pk)
     else:
         d.bmode = B_CONV
         koff, kpos = conv_tables(Cin, KH, KW, H, W, dil, x.device)

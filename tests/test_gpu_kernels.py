@@ -317,6 +317,29 @@ def test_conv2d_direct_lds_patch_kernel(N, Cin, H, W, Cout, k, p):
     _close(slabs.permute(1, 0, 2, 3), ref0, 3e-5)
 
 
+def test_conv2d_direct_packed_and_unpacked_weights_agree():
+    """The pre-arranged-weight variant of the direct kernel (default) against the variant that gathers OIHW
+    weights itself: bit-identical (same MFMA order), and the packed cache follows in-place weight updates."""
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    for (N, Cin, H, W, Cout, k) in [(3, 14, 64, 64, 32, 7), (5, 64, 16, 16, 128, 7), (2, 64, 40, 24, 70, 3)]:
+        x = torch.randn(N, Cin, H, W, generator=g).to(DEV)
+        w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).to(DEV)
+        try:
+            ops.TILE_OVERRIDE = 6
+            a = ops.conv2d(x, w, pad=k // 2)
+            ops.PACK_WEIGHTS = False
+            b = ops.conv2d(x, w, pad=k // 2)
+            ops.PACK_WEIGHTS = True
+            w.mul_(2.0)  # in-place update: the tensor version changes, the cache must re-pack
+            c = ops.conv2d(x, w, pad=k // 2)
+        finally:
+            ops.TILE_OVERRIDE, ops.PACK_WEIGHTS = 0, True
+        assert torch.equal(a, b)
+        _close(c, 2.0 * a, 1e-5)
+
+
 def test_conv2d_direct_refuses_ineligible_shapes():
     from ivln_ce_amd import ops
     from ivln_ce_amd._lib import IvlnError
