@@ -235,7 +235,11 @@ void launch_ks(const ivln_gemm_desc& d, hipStream_t s, int nimg, int cps) {
 // Pixel tiles are split over blockIdx.z (hundreds of splits: M x N is tiny, K is millions of pixels);
 // slabs are reduced in fixed order by k_splitk_epilogue.
 // ------------------------------------------------------------------------------------------------
-template <int KS, int PTW, int PTH, int IMGS, int WM>
+// VEC (Wout % 4 == 0, dy 16-byte aligned): dy is fetched four horizontally adjacent pixels at a time and kept
+// channel-major in LDS ([co][128 px + 1]: the +1 makes both the scalar stores - lanes = 4 channels x 8 pixel
+// quads - and the operand reads - lanes = channels - conflict-free); a quarter of the loads and of the
+// address arithmetic of the scalar path, which stores pixel-major.
+template <int KS, int PTW, int PTH, int IMGS, int WM, bool VEC>
 __global__ __launch_bounds__(256) void k_wgrad_direct(const ivln_gemm_desc p, int tiles_w, int tiles_h, int nimg,
                                                       int ntiles, int tiles_per_split) {
     constexpr int KK = KS * KS;
@@ -246,10 +250,11 @@ __global__ __launch_bounds__(256) void k_wgrad_direct(const ivln_gemm_desc p, in
     constexpr int NCI = (BN + KK - 2) / KK + 1;  // input channels a 128-column tile can touch
     constexpr int PH = PTH + KS - 1, PW = PTW + KS - 1, PLANE = PH * PW;
     constexpr int PATCH = IMGS * NCI * PLANE;
-    constexpr int LDA = BM + 1;
+    constexpr int LDA = BM + 1;    // pixel-major layout: Ds[px][co]
+    constexpr int LDP = NPX + 1;   // channel-major layout (VEC): Ds[co][px]
     constexpr int NA = BM * NPX / 256, NP = (PATCH + 255) / 256;
     constexpr int NQ = NPX / 2;
-    __shared__ float Ds[NPX * LDA];
+    __shared__ float Ds[VEC ? BM * LDP : NPX * LDA];
     __shared__ float Ps[PATCH];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -265,15 +270,30 @@ __global__ __launch_bounds__(256) void k_wgrad_direct(const ivln_gemm_desc p, in
     auto load_tile = [&](int tile) {
         const int tw = tile % tiles_w, th = (tile / tiles_w) % tiles_h, ig = tile / (tiles_w * tiles_h);
         const int img0 = ig * IMGS, ho0 = th * PTH, wo0 = tw * PTW;
+        if constexpr (VEC) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int idx = t + i * 256;  // (co, pixel): pixel fastest -> coalesced rows of dy
-            const int co = idx / NPX, px = idx - co * NPX;
-            const int il = px / (PTH * PTW), ph = (px / PTW) % PTH, pw = px % PTW;
-            const int img = img0 + il, ho = ho0 + ph, wo = wo0 + pw;
-            const bool ok = m0 + co < p.M && img < nimg && ho < p.Hout && wo < p.Wout;
-            const float v = p.A[ok ? ((int64_t)img * p.M + m0 + co) * p.HoWo + ho * p.Wout + wo : 0];
-            ra[i] = ok ? v : 0.f;
+            for (int i = 0; i < NA / 4; ++i) {
+                const int f = t + i * 256;  // (pixel-quad high, channel, pixel-quad low): 8 quads = 128 B per row
+                const int co = (f >> 3) % BM, p4 = (f & 7) + 8 * (f / (8 * BM)), px = p4 * 4;
+                const int il = px / (PTH * PTW), ph = (px / PTW) % PTH, pw = px % PTW;
+                const int img = img0 + il, ho = ho0 + ph, wo = wo0 + pw;
+                const bool ok = m0 + co < p.M && img < nimg && ho < p.Hout && wo < p.Wout;
+                const float4 v = *reinterpret_cast<const float4*>(
+                    p.A + (ok ? ((int64_t)img * p.M + m0 + co) * p.HoWo + ho * p.Wout + wo : 0));
+                ra[4 * i] = ok ? v.x : 0.f, ra[4 * i + 1] = ok ? v.y : 0.f;
+                ra[4 * i + 2] = ok ? v.z : 0.f, ra[4 * i + 3] = ok ? v.w : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int idx = t + i * 256;  // (co, pixel): pixel fastest -> coalesced rows of dy
+                const int co = idx / NPX, px = idx - co * NPX;
+                const int il = px / (PTH * PTW), ph = (px / PTW) % PTH, pw = px % PTW;
+                const int img = img0 + il, ho = ho0 + ph, wo = wo0 + pw;
+                const bool ok = m0 + co < p.M && img < nimg && ho < p.Hout && wo < p.Wout;
+                const float v = p.A[ok ? ((int64_t)img * p.M + m0 + co) * p.HoWo + ho * p.Wout + wo : 0];
+                ra[i] = ok ? v : 0.f;
+            }
         }
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
@@ -289,11 +309,21 @@ __global__ __launch_bounds__(256) void k_wgrad_direct(const ivln_gemm_desc p, in
         }
     };
     auto stage = [&]() {
+        if constexpr (VEC) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int idx = t + i * 256;
-            const int co = idx / NPX, px = idx - co * NPX;
-            Ds[px * LDA + co] = ra[i];
+            for (int i = 0; i < NA / 4; ++i) {
+                const int f = t + i * 256;
+                const int co = (f >> 3) % BM, px = ((f & 7) + 8 * (f / (8 * BM))) * 4;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) Ds[co * LDP + px + k] = ra[4 * i + k];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int idx = t + i * 256;
+                const int co = idx / NPX, px = idx - co * NPX;
+                Ds[px * LDA + co] = ra[i];
+            }
         }
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
@@ -303,7 +333,7 @@ __global__ __launch_bounds__(256) void k_wgrad_direct(const ivln_gemm_desc p, in
     };
 
     // per-lane operand bases: k slot (lane half) = the odd pixel of a horizontal pair
-    const int abase = half * LDA + wm * 32 + l31;
+    const int abase = VEC ? (wm * 32 + l31) * LDP + half : half * LDA + wm * 32 + l31;
     int bbase[TN];
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
@@ -329,7 +359,7 @@ __global__ __launch_bounds__(256) void k_wgrad_direct(const ivln_gemm_desc p, in
             for (int q = 0; q < NQ; ++q) {
                 const int px = 2 * q;  // even pixel of the pair; the odd one is +1 in the same row
                 const int il = px / (PTH * PTW), ph = (px / PTW) % PTH, pw = px % PTW;
-                const float a = Ds[abase + px * LDA];
+                const float a = Ds[abase + (VEC ? px : px * LDA)];
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) {
                     const float b = Ps[bbase[tn] + il * NCI * PLANE + ph * PW + pw];
@@ -357,14 +387,24 @@ __global__ __launch_bounds__(256) void k_wgrad_direct(const ivln_gemm_desc p, in
 template <int KS, int PTW, int PTH, int IMGS>
 void launch_wgrad_wm(const ivln_gemm_desc& d, hipStream_t s, int nimg, int ntiles, int tps) {
     const int tiles_w = (d.Wout + PTW - 1) / PTW, tiles_h = (d.Hout + PTH - 1) / PTH;
+    static const bool novec = getenv("IVLN_WGRAD_SCALAR") != nullptr;  // A/B switch
+    const bool vec = !novec && PTW >= 4 && (d.Wout & 3) == 0 && ((uintptr_t)d.A & 15) == 0 && (d.HoWo & 3) == 0;
     if (d.M <= 32) {
         dim3 grid((d.N + 127) / 128, (d.M + 31) / 32, d.splits);
-        hipLaunchKernelGGL((k_wgrad_direct<KS, PTW, PTH, IMGS, 1>), grid, dim3(256), 0, s, d, tiles_w, tiles_h, nimg,
-                           ntiles, tps);
+        if (vec)
+            hipLaunchKernelGGL((k_wgrad_direct<KS, PTW, PTH, IMGS, 1, true>), grid, dim3(256), 0, s, d, tiles_w, tiles_h,
+                               nimg, ntiles, tps);
+        else
+            hipLaunchKernelGGL((k_wgrad_direct<KS, PTW, PTH, IMGS, 1, false>), grid, dim3(256), 0, s, d, tiles_w, tiles_h,
+                               nimg, ntiles, tps);
     } else {
         dim3 grid((d.N + 127) / 128, (d.M + 63) / 64, d.splits);
-        hipLaunchKernelGGL((k_wgrad_direct<KS, PTW, PTH, IMGS, 2>), grid, dim3(256), 0, s, d, tiles_w, tiles_h, nimg,
-                           ntiles, tps);
+        if (vec)
+            hipLaunchKernelGGL((k_wgrad_direct<KS, PTW, PTH, IMGS, 2, true>), grid, dim3(256), 0, s, d, tiles_w, tiles_h,
+                               nimg, ntiles, tps);
+        else
+            hipLaunchKernelGGL((k_wgrad_direct<KS, PTW, PTH, IMGS, 2, false>), grid, dim3(256), 0, s, d, tiles_w, tiles_h,
+                               nimg, ntiles, tps);
     }
 }
 
