@@ -350,9 +350,12 @@ class BaseVLNCETrainer:
         """The step can be captured when actions are deterministic and every transformer is an iterative
         mapper (the known-map ones read files on episode reset: host work that cannot live in a graph)."""
         cfg = self.config
-        return (bool(getattr(cfg.EVAL, "USE_HIP_GRAPH", True)) and not cfg.EVAL.SAMPLE and self.device.type == "cuda"
-                and len(self.obs_transforms) > 0
-                and all(type(t).__name__.endswith("IterativeMapper") for t in self.obs_transforms))
+        if not (bool(getattr(cfg.EVAL, "USE_HIP_GRAPH", True)) and not cfg.EVAL.SAMPLE and self.device.type == "cuda"):
+            return False
+        if not all(type(t).__name__.endswith("IterativeMapper") for t in self.obs_transforms):
+            return False
+        # MapCMA needs its mapper in the step; the map-free policies (Latent-CMA) are captured as they are
+        return len(self.obs_transforms) > 0 or cfg.MODEL.policy_name != "MapCMAPolicy"
 
     def _make_runner(self, batch, rnn_states, prev_actions, first):
         """GraphedRollout for the current number of active envs, seeded with the carried state.  The first
@@ -361,8 +364,10 @@ class BaseVLNCETrainer:
         the batch shrank - must not touch the mapper's world cloud, so they capture without executing."""
         from .graphed import GraphedRollout
 
-        runner = GraphedRollout(self.policy, self.obs_transforms, batch, deterministic=True, streams="split",
-                                warmup=2 if first else 0)
+        # the three-graph split is MapCMANet's staging; other policies replay one graph on one stream
+        split = type(self.policy).__name__ == "MapCMAPolicy"
+        runner = GraphedRollout(self.policy, self.obs_transforms, batch, deterministic=True,
+                                streams="split" if split else False, warmup=2 if first else 0)
         if first:
             for t in self.obs_transforms:
                 if getattr(t, "mapping_module", None) is not None:

@@ -92,6 +92,18 @@ def test_latent_cma_eval_loop_plumbing(tmp_path):
         "EVAL_CKPT_PATH_DIR", str(tmp_path / "none.pth"),
     ])
     tr = baseline_registry.get_trainer("dagger")(cfg)
-    res = tr._eval_checkpoint(str(tmp_path / "none.pth"))
+    assert tr is not None
+    res = tr._eval_checkpoint(str(tmp_path / "none.pth"))  # graph replay (one graph, one stream) by default
     assert res["episodes"] == 16 and 0.0 < res["t_ndtw"] <= 1.0 and 0.0 <= res["ndtw"] <= 1.0
     assert os.path.exists(tmp_path / "res" / "stats_ckpt_0_val_seen.json")
+    # eager launches give the same report
+    torch.manual_seed(0)
+    cfg2 = get_config(opts=[
+        "TRAINER_NAME", "dagger", "NUM_ENVIRONMENTS", 2, "MODEL.policy_name", "LatentCMAPolicy",
+        "MODEL.INSTRUCTION_ENCODER.use_pretrained_embeddings", False, "MODEL.DEPTH_ENCODER.ddppo_checkpoint", "NONE",
+        "RL.POLICY.OBS_TRANSFORMS.ENABLED_TRANSFORMS", [], "RESULTS_DIR", str(tmp_path / "res2"),
+        "EVAL_CKPT_PATH_DIR", str(tmp_path / "none.pth"), "EVAL.USE_HIP_GRAPH", False,
+    ])
+    res2 = baseline_registry.get_trainer("dagger")(cfg2)._eval_checkpoint(str(tmp_path / "none.pth"))
+    res.pop("eval_seconds"), res2.pop("eval_seconds")
+    assert res == res2
