@@ -13,7 +13,6 @@ import gzip
 import json
 from typing import Optional
 
-import numpy as np
 import torch
 import torch.nn as nn
 

@@ -1,7 +1,7 @@
 """Glue with the reference's names (ivlnce_baselines/common/utils.py:12-135): observation batching
 and host->device moves.  No arithmetic."""
 from collections import defaultdict
-from typing import Any, Dict, List, Optional, Set, Tuple
+from typing import Dict, List, Optional, Set, Tuple
 
 import numpy as np
 import torch

@@ -1,7 +1,6 @@
 """Time k_lstm_bidir for different sequence lengths (fixed part vs per-timestep part)."""
 import os
 import sys
-import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
