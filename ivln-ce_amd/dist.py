@@ -10,7 +10,8 @@ import torch.distributed as dist
 
 
 def world_info():
-    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = 0 if os.environ.get("IVLN_ONE_DEVICE") else int(os.environ.get("LOCAL_RANK", "0"))
+    return int(os.environ.get("RANK", "0")), local, int(os.environ.get("WORLD_SIZE", "1"))
 
 
 def init(backend: str = None):
@@ -19,7 +20,9 @@ def init(backend: str = None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # IVLN_DIST_BACKEND=gloo + IVLN_ONE_DEVICE=1: every rank on one GPU - a control-flow smoke test of the
+            # multi-rank paths on a 1-GPU box (RCCL refuses two ranks per device); never a measurement
+            backend = os.environ.get("IVLN_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
