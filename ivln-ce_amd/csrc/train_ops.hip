@@ -361,54 +361,76 @@ __global__ __launch_bounds__(4 * H) void k_lstm_bidir_bwd(const float* __restric
                                                           float* __restrict__ hprev_f,
                                                           float* __restrict__ hprev_r) {
     constexpr int G = 4 * H;
-    __shared__ float dg[G];
-    __shared__ float part[4][H];
-    __shared__ float dhc[H], dcc[H];
+    // Matvec dh_prev[k] = sum_g W_hh[g][k] * dgate[g] (G = 4H terms): thread (ko = tid/16, ig = tid%16) owns the
+    // 4 outputs k = 4ko..4ko+3 and the 32 gate rows g = 32ig..32ig+31 (H weights in registers), reads ONLY its
+    // 32 gate gradients from LDS (8 ds_read_b128; every thread reading all 4H saturated the LDS port), and the
+    // 16 lanes that share an output add their partial sums by shuffles.  The element part's inputs (saved gates,
+    // cell states, dout) are fetched one timestep ahead.  Two barriers per timestep.
+    constexpr int GS = 36;  // LDS stride of a 32-gate group: +4 words -> the 16 groups spread over the banks
+    __shared__ __attribute__((aligned(16))) float dg[16 * GS];
+    __shared__ float dhc[H];
+    static_assert(H == 128, "mapping below assumes 4H = 512 threads");
     const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
-    const int k = tid % H, pq = tid / H;
+    const int ig = tid & 15, ko = tid >> 4;
     const float* whh = dir == 0 ? whh_f : whh_r;
     float* dgx = (dir == 0 ? dgx_f : dgx_r) + (int64_t)b * L * G;
     float* hprev = (dir == 0 ? hprev_f : hprev_r) + (int64_t)b * L * H;
-    float w[H];
+    float w[4][32];
 #pragma unroll
-    for (int g = 0; g < H; ++g) w[g] = whh[(int64_t)(pq * H + g) * H + k];
-    if (tid < H) {
-        dhc[tid] = 0.f;
-        dcc[tid] = 0.f;
+    for (int g = 0; g < 32; ++g) {
+        const float4 v = *reinterpret_cast<const float4*>(whh + (int64_t)(ig * 32 + g) * H + ko * 4);
+        w[0][g] = v.x, w[1][g] = v.y, w[2][g] = v.z, w[3][g] = v.w;
     }
+    if (tid < H) dhc[tid] = 0.f;
     int len = lengths[b];
     if (len > L) len = L;
-    for (int t = len + pq; t < L; t += 4) {  // padded positions carry no gradient
+    {
+        const int k = tid % H, pq = tid / H;
+        for (int t = len + pq; t < L; t += 4) {  // padded positions carry no gradient
 #pragma unroll 4
-        for (int g = k; g < G; g += H) dgx[(int64_t)t * G + g] = 0.f;
-        hprev[(int64_t)t * H + k] = 0.f;
+            for (int g = k; g < G; g += H) dgx[(int64_t)t * G + g] = 0.f;
+            hprev[(int64_t)t * H + k] = 0.f;
+        }
     }
     lds_barrier();
     const float* gt = gates + ((int64_t)b * 2 + dir) * L * G;
     const float* ct = cs + ((int64_t)b * 2 + dir) * L * H;
+    const int j = tid;  // element part: threads 0..H-1 own hidden unit j
+    const int64_t orow = ((int64_t)b * 2 * H + dir * H + (j < H ? j : 0)) * L;
+    float dcc = 0.f;    // dc carried to the previous timestep (register: only thread j touches it)
+    // inputs of a timestep: gates i,f,g,o, c, c_prev, h_prev, dout
+    float n_i = 0.f, n_f = 0.f, n_g = 0.f, n_o = 0.f, n_c = 0.f, n_cp = 0.f, n_hp = 0.f, n_do = 0.f;
+    auto fetch = [&](int s) {
+        if (j < H && s >= 0) {
+            const int t = dir == 0 ? s : len - 1 - s, tp = dir == 0 ? t - 1 : t + 1;
+            n_i = gt[(int64_t)t * G + j], n_f = gt[(int64_t)t * G + H + j];
+            n_g = gt[(int64_t)t * G + 2 * H + j], n_o = gt[(int64_t)t * G + 3 * H + j];
+            n_c = ct[(int64_t)t * H + j];
+            n_cp = s > 0 ? ct[(int64_t)tp * H + j] : 0.f;
+            n_hp = s > 0 ? out[orow + tp] : 0.f;
+            n_do = dout[orow + t];
+        }
+    };
+    fetch(len - 1);
     for (int s = len - 1; s >= 0; --s) {
-        const int t = dir == 0 ? s : len - 1 - s;            // time index of processing step s
-        const int tp = dir == 0 ? t - 1 : t + 1;              // time index of the previous processing step
-        const bool has_prev = s > 0;
-        if (tid < H) {
-            const int j = tid;
-            float ig = gt[(int64_t)t * G + j], fg = gt[(int64_t)t * G + H + j];
-            float gg = gt[(int64_t)t * G + 2 * H + j], og = gt[(int64_t)t * G + 3 * H + j];
-            float c = ct[(int64_t)t * H + j];
-            float cp = has_prev ? ct[(int64_t)tp * H + j] : 0.f;
-            float hp = has_prev ? out[((int64_t)b * 2 * H + dir * H + j) * L + tp] : 0.f;
-            float tc = tanhf(c);
-            float dh = dout[((int64_t)b * 2 * H + dir * H + j) * L + t] + dhc[j];
-            float d_o = dh * tc;
-            float dc = dh * og * (1.f - tc * tc) + dcc[j];
-            float di = dc * gg, df = dc * cp, dgg = dc * ig;
-            dcc[j] = dc * fg;
-            float a0 = di * ig * (1.f - ig), a1 = df * fg * (1.f - fg), a2 = dgg * (1.f - gg * gg),
-                  a3 = d_o * og * (1.f - og);
-            dg[j] = a0;
-            dg[H + j] = a1;
-            dg[2 * H + j] = a2;
-            dg[3 * H + j] = a3;
+        const int t = dir == 0 ? s : len - 1 - s;  // time index of processing step s
+        const float ig_ = n_i, fg = n_f, gg = n_g, og = n_o, c = n_c, cp = n_cp, hp = n_hp, dov = n_do;
+        fetch(s - 1);  // next timestep's inputs, in flight under this one
+        if (j < H) {
+            const float e2 = __expf(-2.f * c);
+            const float tc = 2.f * __builtin_amdgcn_rcpf(1.f + e2) - 1.f;  // tanh(c)
+            const float dh = dov + dhc[j];
+            const float d_o = dh * tc;
+            const float dc = dh * og * (1.f - tc * tc) + dcc;
+            const float di = dc * gg, df = dc * cp, dgg = dc * ig_;
+            dcc = dc * fg;
+            const float a0 = di * ig_ * (1.f - ig_), a1 = df * fg * (1.f - fg), a2 = dgg * (1.f - gg * gg),
+                        a3 = d_o * og * (1.f - og);
+            // gate row q*H + j lives in group (q*H + j) / 32, slot (q*H + j) % 32
+            dg[((0 * H + j) >> 5) * GS + (j & 31)] = a0;
+            dg[((1 * H + j) >> 5) * GS + (j & 31)] = a1;
+            dg[((2 * H + j) >> 5) * GS + (j & 31)] = a2;
+            dg[((3 * H + j) >> 5) * GS + (j & 31)] = a3;
             dgx[(int64_t)t * G + j] = a0;
             dgx[(int64_t)t * G + H + j] = a1;
             dgx[(int64_t)t * G + 2 * H + j] = a2;
@@ -416,12 +438,31 @@ __global__ __launch_bounds__(4 * H) void k_lstm_bidir_bwd(const float* __restric
             hprev[(int64_t)t * H + j] = hp;
         }
         lds_barrier();
-        float acc = 0.f;
+        float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
 #pragma unroll
-        for (int g = 0; g < H; ++g) acc = fmaf(w[g], dg[pq * H + g], acc);
-        part[pq][k] = acc;
-        lds_barrier();
-        if (tid < H) dhc[tid] = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+        for (int g = 0; g < 32; g += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(&dg[ig * GS + g]);
+            p0 = fmaf(w[0][g], v.x, p0), p1 = fmaf(w[1][g], v.x, p1), p2 = fmaf(w[2][g], v.x, p2), p3 = fmaf(w[3][g], v.x, p3);
+            p0 = fmaf(w[0][g + 1], v.y, p0), p1 = fmaf(w[1][g + 1], v.y, p1), p2 = fmaf(w[2][g + 1], v.y, p2),
+            p3 = fmaf(w[3][g + 1], v.y, p3);
+            p0 = fmaf(w[0][g + 2], v.z, p0), p1 = fmaf(w[1][g + 2], v.z, p1), p2 = fmaf(w[2][g + 2], v.z, p2),
+            p3 = fmaf(w[3][g + 2], v.z, p3);
+            p0 = fmaf(w[0][g + 3], v.w, p0), p1 = fmaf(w[1][g + 3], v.w, p1), p2 = fmaf(w[2][g + 3], v.w, p2),
+            p3 = fmaf(w[3][g + 3], v.w, p3);
+        }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {  // the 16 lanes of an output group are consecutive
+            p0 += __shfl_xor(p0, off, 64);
+            p1 += __shfl_xor(p1, off, 64);
+            p2 += __shfl_xor(p2, off, 64);
+            p3 += __shfl_xor(p3, off, 64);
+        }
+        if (ig == 0) {  // dhc of this step was consumed before the first barrier: safe to overwrite
+            dhc[ko * 4] = p0;
+            dhc[ko * 4 + 1] = p1;
+            dhc[ko * 4 + 2] = p2;
+            dhc[ko * 4 + 3] = p3;
+        }
         lds_barrier();
     }
 }
