@@ -133,27 +133,35 @@ def _epilogue(d: GemmDesc, scale, shift, residual, relu, accumulate=False):
 _packed = {}
 
 
-def packed_conv_weights(w):
-    """Weights of a stride-1 3x3 / 7x7 conv in the direct kernel's LDS order, cached until the tensor or the
-    parameters behind it change (tensor version / WEIGHT_EPOCH)."""
+def packed_conv_weights(w, cache=True):
+    """Weights of a stride-1 3x3 / 7x7 conv in the direct kernel's LDS order.  Long-lived tensors (module
+    parameters) are cached until they change (tensor version / WEIGHT_EPOCH) or die (weak reference: a freed
+    address may be handed to another tensor); temporaries (`cache=False`, e.g. the flipped weights of an input
+    gradient) are packed into a fresh buffer every call so that nothing accumulates."""
+    import weakref
+
     Cout, Cin, KH, KW = w.shape
     L = _L()
     L.ivln_conv_packed_floats.restype = i64
     L.ivln_conv_packed_floats.argtypes = [i32, i32, i32]
+    L.ivln_conv_pack_weights_f32.argtypes = [vp, i32, i32, i32, vp, vp]
     n = L.ivln_conv_packed_floats(Cout, Cin, KH)
     if n <= 0:
         return None
+    if not cache:
+        out = torch.empty(n, dtype=torch.float32, device=w.device)
+        check(L.ivln_conv_pack_weights_f32(dptr(w), Cout, Cin, KH, dptr(out), stream_ptr()), "ivln_conv_pack_weights_f32")
+        return out
     key = (w.data_ptr(), tuple(w.shape), torch.cuda.current_stream().cuda_stream)
     stamp = (w._version, WEIGHT_EPOCH)
     hit = _packed.get(key)
-    if hit is not None and hit[0] == stamp:
+    if hit is not None and hit[2]() is w and hit[0] == stamp:
         return hit[1]
-    out = hit[1] if hit is not None else torch.empty(n, dtype=torch.float32, device=w.device)
-    L.ivln_conv_pack_weights_f32.argtypes = [vp, i32, i32, i32, vp, vp]
+    out = hit[1] if (hit is not None and hit[2]() is w) else torch.empty(n, dtype=torch.float32, device=w.device)
     check(L.ivln_conv_pack_weights_f32(dptr(w), Cout, Cin, KH, dptr(out), stream_ptr()), "ivln_conv_pack_weights_f32")
-    if len(_packed) > 4096:
+    if len(_packed) > 1024:
         _packed.clear()
-    _packed[key] = (stamp, out, w)  # w kept alive: its data_ptr is the key
+    _packed[key] = (stamp, out, weakref.ref(w))
     return out
 
 
@@ -165,7 +173,7 @@ class Deferred:
 
 
 def conv2d(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, relu=False, out=None, out_ctot=0,
-           in_img_stride=0, splitk=True, defer=False, ws_slot=0):
+           in_img_stride=0, splitk=True, defer=False, ws_slot=0, weight_is_temp=False):
     """NCHW conv: x (N,Cin,H,W) [contiguous per image, image stride `in_img_stride`], w OIHW.
     out: optional destination (a channel slice of an (N,out_ctot,Ho,Wo) buffer)."""
     N, Cin, H, W = x.shape
@@ -190,7 +198,7 @@ def conv2d(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, 
     elif KH == KW and KH in (3, 7) and dil == 1:
         d.bmode = B_CONV_K3 if KH == 3 else B_CONV_K7
         if stride == 1 and PACK_WEIGHTS and w.is_contiguous():
-            pk = packed_conv_weights(w)
+            pk = packed_conv_weights(w, cache=not weight_is_temp)
             if pk is not None:
                 d.A_packed = dptr(pk)
     else:

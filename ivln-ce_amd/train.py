@@ -201,7 +201,7 @@ def net_backward(net, S: Dict, d_feats: torch.Tensor) -> Dict:
             else:
                 G[conv.bias] = ops.nchw_chansum(dy)
             if i > 0:
-                d = ops.conv2d(dy, ops.weight_flip_transpose(conv.weight), pad=3)
+                d = ops.conv2d(dy, ops.weight_flip_transpose(conv.weight), pad=3, weight_is_temp=True)
 
     # ---- instruction encoder: bidirectional LSTM BPTT ---------------------------------------------
     ie = net.instruction_encoder
