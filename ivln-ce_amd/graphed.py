@@ -13,6 +13,19 @@ from typing import Dict
 
 import torch
 
+_streams = {}
+
+
+def _stream(device, role, **kw):
+    """One long-lived stream per (device, role): per-stream resources (split-K workspaces, 32 MB each) are keyed
+    by the stream, so a fresh stream per capture - the eval loop re-captures whenever envs pause - would pin a
+    new set every time."""
+    key = (str(device), role)
+    if key not in _streams:
+        _streams[key] = torch.cuda.Stream(device, **kw)
+    return _streams[key]
+
+
 _STEP_KEYS = ("depth", "semantic12", "rgb", "instruction", "world_robot_pose", "world_robot_orientation",
               "not_done_masks")
 
@@ -33,7 +46,7 @@ class GraphedRollout:
         self.rnn = [torch.zeros(B, L, H, device=dev) for _ in range(2)]
         self.prev = [torch.zeros(B, 1, dtype=torch.long, device=dev) for _ in range(2)]
         self.split = streams == "split"
-        self.side = (torch.cuda.Stream(dev), torch.cuda.Stream(dev)) if (streams and not self.split) else None
+        self.side = (_stream(dev, "fork_txt"), _stream(dev, "fork_map")) if (streams and not self.split) else None
         self.graphs = []
         self.phase = 0  # which buffer set holds the current state
         if self.split:
@@ -94,7 +107,7 @@ class GraphedRollout:
     def _capture_split(self, warmup):
         dev = self.device
         net = self.policy.net
-        self.sA = torch.cuda.Stream(dev, priority=-1)  # the critical chain wins dispatch when both queues are ready
+        self.sA = _stream(dev, "depth", priority=-1)  # the critical chain wins dispatch when both queues are ready
         self.ev_in, self.ev_A = torch.cuda.Event(), torch.cuda.Event()
         main = torch.cuda.current_stream()
 
@@ -147,7 +160,7 @@ class GraphedRollout:
                 net._rnn_out_buffer = None
                 self.policy._action_out_buffer = None
 
-        s = torch.cuda.Stream(dev)
+        s = _stream(dev, "warmup")
         s.wait_stream(main)
         with torch.cuda.stream(s):  # warm-up: tables, workspaces (per stream), folded weights
             for i in range(warmup):
@@ -190,7 +203,7 @@ class GraphedRollout:
         self.graphs[self.phase].replay()
 
     def _capture(self, warmup):
-        s = torch.cuda.Stream(self.device)
+        s = _stream(self.device, "warmup")
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):  # warm-up off the default stream: creates tables, workspaces, handles
             for i in range(warmup):
