@@ -2,11 +2,11 @@
 (ivlnce_baselines/models/latent_cma_policy.py:28-497) and the `TorchVisionResNet50` RGB encoder
 (models/encoders/resnet_encoders.py:118-229) under the same registry name and state_dict keys.
 
-Inference path (`act`, `act_iterative`, tour-memory variants) runs on the HIP kernels of this package: the RGB
-ResNet-50 is the BN-folded bottleneck stack already used by RedNet (MFMA convs with fused scale/shift/
+Inference (`act`, `act_iterative`, tour-memory variants) and training (`build_distribution` under autograd:
+sequence mode and the tour-memory variant the reference unrolls) run on the HIP kernels of this package: the
+RGB ResNet-50 is the BN-folded bottleneck stack already used by RedNet (MFMA convs with fused scale/shift/
 residual/ReLU epilogues), the head reuses the MapCMA kernels (instruction bi-LSTM, DD-PPO depth ResNet,
-GRU steps, attention).  Training of this baseline (unrolled tour memory, `IterativeDaggerTrainer`) is not
-built: `forward` under autograd raises.
+GRU steps and BPTT, attention forward/backward); `backward_hip` is the hand-written backward.
 """
 from typing import Tuple
 
@@ -16,6 +16,7 @@ import torch.nn as nn
 from torch import Tensor
 
 from . import ops
+from .aux_losses import AuxLosses
 from .encoders import InstructionEncoder, VlnResnetDepthEncoder, build_rnn_state_encoder
 from .policy import ILPolicy, Net
 from .rednet import Bottleneck, _Folded
@@ -169,8 +170,27 @@ class LatentCMANet(Net):
                 + int(self.model_config.tour_memory_variant))
 
     def forward(self, observations, rnn_states, prev_actions, action_masks, episode_masks=None, tour_masks=None):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("Latent-CMA training is not built on HIP yet: call under torch.no_grad()")
+        """Same signature/return as latent_cma_policy.py:375-497.  rows == envs: one step; rows == T*envs: a
+        time-major trajectory batch (every mode, including the tour-memory variant the reference unrolls in Python).
+        Under autograd the whole net is one Function whose backward is `backward_hip`."""
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if needs_grad:
+            from .train import MapCMAForwardFn
+
+            feats, rnn_out = MapCMAForwardFn.run(self, observations, rnn_states, prev_actions, action_masks,
+                                                 episode_masks, tour_masks)
+        else:
+            feats, rnn_out = self.forward_hip(observations, rnn_states, prev_actions, action_masks, episode_masks,
+                                              tour_masks)
+        if self.model_config.PROGRESS_MONITOR.use and AuxLosses.is_active():
+            from .train import progress_monitor_loss
+
+            loss = progress_monitor_loss(self, feats, observations["progress"])
+            AuxLosses.register_loss("progress_monitor", loss, self.model_config.PROGRESS_MONITOR.alpha)
+        return feats, rnn_out
+
+    def forward_hip(self, observations, rnn_states, prev_actions, action_masks, episode_masks=None, tour_masks=None,
+                    save=None):
         mc = self.model_config
         if mc.disable_tour_memory:
             tour_masks = None
@@ -182,20 +202,19 @@ class LatentCMANet(Net):
         H, h2 = self._hidden_size, self._hidden_size // 2
         N = rnn_states.shape[0]
         variant = bool(mc.tour_memory_variant)
-        rnn_states = rnn_states.to(torch.float32).contiguous()
+        rnn_states = rnn_states.detach().to(torch.float32).contiguous()
         act_u8 = action_masks.reshape(-1).to(torch.uint8).contiguous()
         ep_u8 = episode_masks.reshape(-1).to(torch.uint8).contiguous()
         rows = act_u8.shape[0]
-        if rows != N:
-            raise NotImplementedError("Latent-CMA on HIP serves single-step inference (rows == envs)")
+        T = rows // N
+        if rows != T * N:
+            raise ValueError(f"{rows} rows are not a multiple of {N} recurrent states")
         prev_actions = prev_actions.reshape(-1).long().contiguous()
-        if variant:  # latent_cma_policy.py:381-385: the tour memory is cleared where a new tour starts
-            rnn_states = rnn_states.clone()
-            rnn_states[:, 2:] = tour_masks.view(-1, 1, 1).to(torch.float32) * rnn_states[:, 2:]
 
-        txt, lengths = self.instruction_encoder(observations, None)  # (rows, 256, L), zero beyond each length
-        dep = self.depth_encoder(observations)                        # (rows, 192, 4, 4)
-        rgb = self.rgb_encoder(observations)                          # (rows, 2112, 4, 4)
+        s_txt = {} if save is not None else None
+        txt, lengths = self.instruction_encoder(observations, s_txt)  # (rows, 256, L), zero beyond each length
+        dep = self.depth_encoder(observations)                         # (rows, 192, 4, 4)
+        rgb = self.rgb_encoder(observations)                           # (rows, 2112, 4, 4)
         if mc.ablate_instruction:
             txt = torch.zeros_like(txt)
         if mc.ablate_depth:
@@ -209,43 +228,179 @@ class LatentCMANet(Net):
         E = self.prev_action_embedding.embedding_dim
 
         # state_in = [rgb_in | depth_in | prev (| tour memory)];  x2 = [state | text | rgb' | depth' | prev]
-        s_w = r_out + d_out + E + (H if variant else 0)
-        state_in = torch.empty((rows, s_w), dtype=torch.float32, device=dev)
+        base = r_out + d_out + E
+        state_in = torch.empty((rows, base + (H if variant else 0)), dtype=torch.float32, device=dev)
         x2 = torch.empty((rows, H + 256 + r_out + d_out + E), dtype=torch.float32, device=dev)
         o_txt, o_rgb, o_dep, o_prev = H, H + 256, H + 256 + r_out, H + 256 + r_out + d_out
-        ops.prev_action_embed(prev_actions, act_u8, self.prev_action_embedding.weight, state_in[:, r_out + d_out:r_out + d_out + E],
+        ops.prev_action_embed(prev_actions, act_u8, self.prev_action_embedding.weight, state_in[:, r_out + d_out:base],
                               x2[:, o_prev:])
-        rgb_mean = ops.pool2d(rgb, 4, 4, 0, "avg")  # AdaptiveAvgPool1d(1) over the 16 positions
-        ops.linear(rgb_mean.view(rows, Cr), self.rgb_linear[2].weight, self.rgb_linear[2].bias, relu=True,
-                   out=state_in[:, :r_out])
+        rgb_mean = ops.pool2d(rgb, 4, 4, 0, "avg").view(rows, Cr)  # AdaptiveAvgPool1d(1) over the 16 positions
+        ops.linear(rgb_mean, self.rgb_linear[2].weight, self.rgb_linear[2].bias, relu=True, out=state_in[:, :r_out])
         ops.linear(dep.view(rows, -1), self.depth_linear[1].weight, self.depth_linear[1].bias, relu=True,
                    out=state_in[:, r_out:r_out + d_out])
-        if variant:
-            state_in[:, r_out + d_out + E:] = rnn_states[:, 2]
 
-        rnn_out = rnn_states.detach().clone()
+        rnn_out = rnn_states.clone()
         state = x2[:, :H]
-        self.state_encoder(state_in, rnn_states[:, 0], ep_u8, state, rnn_out[:, 0], None)
-        if variant:  # cross-episode memory = running max of the first GRU's state (latent_cma_policy.py:420-425)
-            rnn_out[:, 2] = torch.max(rnn_out[:, 2], rnn_out[:, 0])
+        s_g1 = {} if save is not None else None
+        s_g2 = {} if save is not None else None
+        mem_in = None
+        if variant:
+            # the tour-long slot: cleared where a tour starts, fed to the first GRU, then max-pooled with that
+            # GRU's new state (latent_cma_policy.py:395-399,422-425,433-439).  It carries no gradient in the
+            # reference (updated under no_grad from a detached clone), so it is a constant input here too; the
+            # first GRU reads its own previous output through it, hence the per-step loop for this one layer.
+            rnn = self.state_encoder.rnn
+            tour_f = tour_masks.reshape(T, N, 1).to(torch.float32)
+            mem = rnn_states[:, 2]
+            mem_in = torch.empty((rows, H), dtype=torch.float32, device=dev)
+            saves = None
+            if save is not None:
+                saves = tuple(torch.empty((rows, H), dtype=torch.float32, device=dev) for _ in range(4))
+                s_g1.update(r=saves[0], z=saves[1], n=saves[2], ghn=saves[3], T=T, N=N, x=state_in,
+                            h0=rnn_states[:, 0], masks=ep_u8, out=state)
+            for t in range(T):
+                sl = slice(t * N, (t + 1) * N)
+                mem = mem * tour_f[t]
+                mem_in[sl] = mem
+                state_in[sl, base:] = mem
+                h_in = rnn_states[:, 0] if t == 0 else state[(t - 1) * N: t * N]
+                ops.gru_step(state_in[sl], None, h_in, ep_u8[sl], rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0,
+                             rnn.bias_hh_l0, state[sl], rnn_out[:, 0] if t == T - 1 else None,
+                             tuple(x[sl] for x in saves) if saves is not None else None)
+                mem = torch.max(mem, state[sl])
+            rnn_out[:, 2] = mem
+        else:
+            self.state_encoder(state_in, rnn_states[:, 0], ep_u8, state, rnn_out[:, 0], s_g1)
 
         q1 = ops.linear(state, self.state_q.weight, self.state_q.bias)
         tk = ops.conv2d(txt.view(rows, -1, 1, L), self.text_k.weight.view(h2, -1, 1, 1), shift=self.text_k.bias, splitk=False)
         text = x2[:, o_txt:o_txt + 256]
-        ops.attn(q1, tk.view(rows, h2, L), txt, lengths, self._scale_f, text)
+        a_txt = torch.empty((rows, L), dtype=torch.float32, device=dev) if save is not None else None
+        ops.attn(q1, tk.view(rows, h2, L), txt, lengths, self._scale_f, text, a_txt)
         rkv = ops.conv2d(rgb.view(rows, Cr, 1, P), self.rgb_kv.weight.view(-1, Cr, 1, 1), shift=self.rgb_kv.bias).view(rows, -1, P)
         dkv = ops.conv2d(dep.view(rows, Cd, 1, P), self.depth_kv.weight.view(-1, Cd, 1, 1), shift=self.depth_kv.bias).view(rows, -1, P)
         q2 = ops.linear(text, self.text_q.weight, self.text_q.bias)
-        ops.attn_small2(q2, rkv[:, :h2], rkv[:, h2:], x2[:, o_rgb:o_rgb + r_out], dkv[:, :h2], dkv[:, h2:],
-                        x2[:, o_dep:o_dep + d_out], self._scale_f)
+        a_rgb = a_dep = None
+        if save is None and P <= 32:
+            ops.attn_small2(q2, rkv[:, :h2], rkv[:, h2:], x2[:, o_rgb:o_rgb + r_out], dkv[:, :h2], dkv[:, h2:],
+                            x2[:, o_dep:o_dep + d_out], self._scale_f)
+        else:
+            a_rgb = torch.empty((rows, P), dtype=torch.float32, device=dev) if save is not None else None
+            a_dep = torch.empty((rows, P), dtype=torch.float32, device=dev) if save is not None else None
+            ops.attn(q2, rkv[:, :h2], rkv[:, h2:], None, self._scale_f, x2[:, o_rgb:o_rgb + r_out], a_rgb)
+            ops.attn(q2, dkv[:, :h2], dkv[:, h2:], None, self._scale_f, x2[:, o_dep:o_dep + d_out], a_dep)
         sc = self.second_state_compress[0]
         c2 = ops.linear(x2, sc.weight, sc.bias, relu=True)
-        feats = torch.empty((rows, H), dtype=torch.float32, device=dev)
-        self.second_state_encoder(c2, rnn_states[:, 1], ep_u8, feats, rnn_out[:, 1], None)
+        g2_out = torch.empty((rows, H), dtype=torch.float32, device=dev)
+        self.second_state_encoder(c2, rnn_states[:, 1], ep_u8, g2_out, rnn_out[:, 1], s_g2)
+        feats, cat = g2_out, None
         if mc.memory_at_end:
             ol = self.out_layer[0]
-            feats = ops.linear(torch.cat([feats, rnn_states[:, 2]], dim=1), ol.weight, ol.bias, relu=True)
+            cat = torch.cat([g2_out, mem_in], dim=1)
+            feats = ops.linear(cat, ol.weight, ol.bias, relu=True)
+        if save is not None:
+            save.update(txt=s_txt, g1=s_g1, g2=s_g2, dep=dep, rgb=rgb, rgb_mean=rgb_mean, txt_out=txt, state_in=state_in,
+                        x2=x2, q1=q1, tk=tk, a_txt=a_txt, rkv=rkv, dkv=dkv, q2=q2, a_rgb=a_rgb, a_dep=a_dep, c2=c2,
+                        cat=cat, feats=feats, rows=rows, N=N, L=L, P=P, offs=(o_txt, o_rgb, o_dep, o_prev),
+                        act_masks=act_u8, prev_actions=prev_actions)
         return feats, rnn_out
+
+    def backward_hip(self, S, d_feats):
+        """Gradients of every trainable parameter given d(loss)/d(features): the hand-written HIP backward of
+        `forward_hip` (the frozen RGB / depth ResNets are not traversed; their learned spatial embeddings are)."""
+        from .train import _conv1d_backward, _gru_backward, instruction_backward
+
+        G = {}
+        mc = self.model_config
+        rows, L, P = S["rows"], S["L"], S["P"]
+        H, h2 = self._hidden_size, self._hidden_size // 2
+        scale = self._scale_f
+        o_txt, o_rgb, o_dep, o_prev = S["offs"]
+        x2, state_in = S["x2"], S["state_in"]
+        dev = d_feats.device
+        r_out, d_out = self.rgb_linear[2].out_features, self.depth_linear[1].out_features
+        E = self.prev_action_embedding.embedding_dim
+        d_feats = d_feats.contiguous()
+
+        if mc.memory_at_end:  # out_layer over [second GRU output | tour memory]; the memory half is a constant
+            ol = self.out_layer[0]
+            d_pre = ops.relu_bwd(d_feats, S["feats"])
+            G[ol.weight] = ops.linear_bwd_weight(d_pre, S["cat"])
+            G[ol.bias] = ops.colsum(d_pre)
+            d_feats = ops.linear_bwd_input(d_pre, ol.weight)[:, :H]
+
+        d_c2 = _gru_backward(self.second_state_encoder, S["g2"], d_feats, G)
+        d_pre = ops.relu_bwd(d_c2, S["c2"])
+        sc = self.second_state_compress[0]
+        G[sc.weight] = ops.linear_bwd_weight(d_pre, x2)
+        G[sc.bias] = ops.colsum(d_pre)
+        dx2 = ops.linear_bwd_input(d_pre, sc.weight)  # [state | text | rgb' | depth' | prev]
+
+        rkv, dkv = S["rkv"], S["dkv"]
+        d_rkv, d_dkv = torch.empty_like(rkv), torch.empty_like(dkv)
+        dq2_r = torch.empty((rows, h2), dtype=torch.float32, device=dev)
+        dq2_d = torch.empty((rows, h2), dtype=torch.float32, device=dev)
+        ops.attn_bwd(dx2[:, o_rgb:o_rgb + r_out], S["a_rgb"], S["q2"], rkv[:, :h2], rkv[:, h2:], scale, dq2_r,
+                     d_rkv[:, :h2], d_rkv[:, h2:])
+        ops.attn_bwd(dx2[:, o_dep:o_dep + d_out], S["a_dep"], S["q2"], dkv[:, :h2], dkv[:, h2:], scale, dq2_d,
+                     d_dkv[:, :h2], d_dkv[:, h2:])
+        dq2 = ops.add2d(dq2_r, dq2_d)
+        text = x2[:, o_txt:o_txt + 256]
+        G[self.text_q.weight] = ops.linear_bwd_weight(dq2, text)
+        G[self.text_q.bias] = ops.colsum(dq2)
+        d_text = dx2[:, o_txt:o_txt + 256]
+        ops.linear_bwd_input(dq2, self.text_q.weight, out=d_text, accumulate=True)
+
+        txt, tk = S["txt_out"], S["tk"]
+        dq1 = torch.empty((rows, h2), dtype=torch.float32, device=dev)
+        d_tk = torch.empty((rows, h2, L), dtype=torch.float32, device=dev)
+        d_txt = torch.empty_like(txt)
+        ops.attn_bwd(d_text, S["a_txt"], S["q1"], tk.view(rows, h2, L), txt, scale, dq1, d_tk, d_txt)
+        d_txt = _conv1d_backward(self.text_k, d_tk.view(rows, h2, 1, L), txt.view(rows, -1, 1, L),
+                                 d_txt.view(rows, -1, 1, L), G).view(rows, -1, L)
+        state = x2[:, :H]
+        G[self.state_q.weight] = ops.linear_bwd_weight(dq1, state)
+        G[self.state_q.bias] = ops.colsum(dq1)
+        d_state = dx2[:, :H]
+        ops.linear_bwd_input(dq1, self.state_q.weight, out=d_state, accumulate=True)
+
+        d_state_in = _gru_backward(self.state_encoder, S["g1"], d_state, G)  # (rows, 288 [+ 512 memory: unused])
+        emb = self.prev_action_embedding
+        G[emb.weight] = ops.prev_action_embed_bwd(S["prev_actions"], S["act_masks"],
+                                                  d_state_in[:, r_out + d_out:r_out + d_out + E], dx2[:, o_prev:],
+                                                  emb.num_embeddings)
+
+        # ---- rgb branch: mean over positions -> rgb_linear; rgb_kv.  Only the 64 learned spatial-embedding
+        # channels of the (frozen) encoder output need an input gradient.
+        rgb, dep = S["rgb"], S["dep"]
+        Cr, Cd = rgb.shape[1], dep.shape[1]
+        rl, dl = self.rgb_linear[2], self.depth_linear[1]
+        se_r, se_d = self.rgb_encoder.spatial_embeddings, self.depth_encoder.spatial_embeddings
+        Er, Ed = se_r.embedding_dim, se_d.embedding_dim
+        d_pre_r = ops.relu_bwd(d_state_in[:, :r_out], state_in[:, :r_out])
+        G[rl.weight] = ops.linear_bwd_weight(d_pre_r, S["rgb_mean"])
+        G[rl.bias] = ops.colsum(d_pre_r)
+        kvw = self.rgb_kv.weight.view(-1, Cr)
+        G[self.rgb_kv.weight] = ops.conv2d_bwd_weight(d_rkv.view(rows, -1, 1, P), rgb.view(rows, Cr, 1, P), 1, 1).view_as(
+            self.rgb_kv.weight)
+        G[self.rgb_kv.bias] = ops.nchw_chansum(d_rkv.view(rows, -1, 1, P))
+        w_se = ops.transpose(kvw[:, Cr - Er:].contiguous())  # (Er, O)
+        d_se = ops.conv2d(d_rkv.view(rows, -1, 1, P), w_se.view(Er, -1, 1, 1), weight_is_temp=True).view(rows, Er, P)
+        g_se = ops.colsum(d_se.view(rows, -1)).view(Er, P)
+        d_mean = ops.colsum(ops.linear_bwd_input(d_pre_r, rl.weight[:, Cr - Er:].contiguous()))  # (Er,)
+        G[se_r.weight] = (g_se + d_mean.view(Er, 1) / P).reshape(se_r.weight.shape)
+
+        # ---- depth branch: depth_linear + depth_kv -> spatial embedding
+        d_pre_d = ops.relu_bwd(d_state_in[:, r_out:r_out + d_out], state_in[:, r_out:r_out + d_out])
+        G[dl.weight] = ops.linear_bwd_weight(d_pre_d, dep.view(rows, -1))
+        G[dl.bias] = ops.colsum(d_pre_d)
+        d_dep = ops.linear_bwd_input(d_pre_d, dl.weight)
+        d_dep = _conv1d_backward(self.depth_kv, d_dkv.view(rows, -1, 1, P), dep.view(rows, Cd, 1, P),
+                                 d_dep.view(rows, Cd, 1, P), G)
+        G[se_d.weight] = ops.colsum(d_dep.view(rows, -1)[:, (Cd - Ed) * P:]).view_as(se_d.weight)
+
+        instruction_backward(self.instruction_encoder, S["txt"], d_txt, rows, L, G)
+        return G
 
 
 @baseline_registry.register_policy
@@ -277,7 +432,21 @@ class LatentCMAPolicy(ILPolicy):
 
     def build_distribution(self, observations, rnn_hidden_states, prev_actions, agent_episode_not_done_masks,
                            tour_not_done_masks=None) -> Tuple:
-        raise NotImplementedError("Latent-CMA training (unrolled tour memory) is not built on HIP yet")
+        """latent_cma_policy.py:124-179.  The reference unrolls the time axis in Python for the tour-memory
+        variant (`_view_sequential_inputs`); the HIP net takes the time-major batch directly in every mode - the
+        masks select which memory resets where."""
+        if tour_not_done_masks is None:
+            tour_not_done_masks = agent_episode_not_done_masks.clone()
+        if self.tour_memory_variant or self.train_unrolled:
+            episode_masks, tour_masks = agent_episode_not_done_masks, tour_not_done_masks
+        else:
+            episode_masks = tour_not_done_masks if self.tour_memory else None
+            tour_masks = None
+        features, rnn_hidden_states = self.net(
+            observations, rnn_hidden_states, prev_actions, action_masks=agent_episode_not_done_masks,
+            episode_masks=episode_masks, tour_masks=tour_masks,
+        )
+        return self.action_distribution(features), rnn_hidden_states
 
     @classmethod
     def from_config(cls, config, observation_space, action_space):

@@ -101,6 +101,28 @@ def _conv1d_backward(conv, d_out4, x4, d_in_residual4, G):
     return ops.conv2d(d_out4, w_t.view(Cc, O, 1, 1), residual=d_in_residual4)
 
 
+def instruction_backward(ie, st, d_txt, rows, L, G):
+    """Bidirectional-LSTM BPTT of the instruction encoder (+ the embedding table when it trains)."""
+    rnn = ie.encoder_rnn
+    dgx_f, dgx_r, hp_f, hp_r = ops.lstm_bidir_bwd(d_txt.contiguous(), st["out"], st["gates"], st["cs"],
+                                                  rnn.weight_hh_l0, rnn.weight_hh_l0_reverse, st["lengths"], rows,
+                                                  L, rnn.hidden_size)
+    emb_x = st["emb"]
+    G[rnn.weight_ih_l0] = ops.linear_bwd_weight(dgx_f, emb_x)
+    G[rnn.weight_ih_l0_reverse] = ops.linear_bwd_weight(dgx_r, emb_x)
+    G[rnn.weight_hh_l0] = ops.linear_bwd_weight(dgx_f, hp_f)
+    G[rnn.weight_hh_l0_reverse] = ops.linear_bwd_weight(dgx_r, hp_r)
+    bf, br = ops.colsum(dgx_f), ops.colsum(dgx_r)
+    G[rnn.bias_ih_l0], G[rnn.bias_hh_l0] = bf, bf
+    G[rnn.bias_ih_l0_reverse], G[rnn.bias_hh_l0_reverse] = br, br
+    if ie.embedding_layer.weight.requires_grad:
+        d_emb = ops.linear_bwd_input(dgx_f, rnn.weight_ih_l0)
+        ops.linear_bwd_input(dgx_r, rnn.weight_ih_l0_reverse, out=d_emb, accumulate=True)
+        g = torch.zeros_like(ie.embedding_layer.weight)
+        ops.embedding_scatter_add(st["tokens"].reshape(-1), d_emb, g, ie.embedding_layer.padding_idx)
+        G[ie.embedding_layer.weight] = g
+
+
 def net_backward(net, S: Dict, d_feats: torch.Tensor) -> Dict:
     """Gradients of every parameter of MapCMANet given d(loss)/d(features).  S = saves of forward_hip."""
     G: Dict = {}
@@ -203,37 +225,20 @@ def net_backward(net, S: Dict, d_feats: torch.Tensor) -> Dict:
             if i > 0:
                 d = ops.conv2d(dy, ops.weight_flip_transpose(conv.weight), pad=3, weight_is_temp=True)
 
-    # ---- instruction encoder: bidirectional LSTM BPTT ---------------------------------------------
-    ie = net.instruction_encoder
-    rnn = ie.encoder_rnn
-    st = S["txt"]
-    dgx_f, dgx_r, hp_f, hp_r = ops.lstm_bidir_bwd(d_txt.contiguous(), st["out"], st["gates"], st["cs"],
-                                                  rnn.weight_hh_l0, rnn.weight_hh_l0_reverse, st["lengths"], rows,
-                                                  L, rnn.hidden_size)
-    emb_x = st["emb"]
-    G[rnn.weight_ih_l0] = ops.linear_bwd_weight(dgx_f, emb_x)
-    G[rnn.weight_ih_l0_reverse] = ops.linear_bwd_weight(dgx_r, emb_x)
-    G[rnn.weight_hh_l0] = ops.linear_bwd_weight(dgx_f, hp_f)
-    G[rnn.weight_hh_l0_reverse] = ops.linear_bwd_weight(dgx_r, hp_r)
-    bf, br = ops.colsum(dgx_f), ops.colsum(dgx_r)
-    G[rnn.bias_ih_l0], G[rnn.bias_hh_l0] = bf, bf
-    G[rnn.bias_ih_l0_reverse], G[rnn.bias_hh_l0_reverse] = br, br
-    if ie.embedding_layer.weight.requires_grad:
-        d_emb = ops.linear_bwd_input(dgx_f, rnn.weight_ih_l0)
-        ops.linear_bwd_input(dgx_r, rnn.weight_ih_l0_reverse, out=d_emb, accumulate=True)
-        g = torch.zeros_like(ie.embedding_layer.weight)
-        ops.embedding_scatter_add(st["tokens"].reshape(-1), d_emb, g, ie.embedding_layer.padding_idx)
-        G[ie.embedding_layer.weight] = g
+    instruction_backward(net.instruction_encoder, S["txt"], d_txt, rows, L, G)
     return G
 
 
 class MapCMAForwardFn(torch.autograd.Function):
+    """`holder` = (net, *forward_hip arguments); the net's `backward_hip` (default: net_backward) turns
+    d(features) into the parameter gradients."""
+
     @staticmethod
     def forward(ctx, holder, *params):
-        net, observations, rnn_states, prev_actions, masks = holder
+        net, args = holder[0], holder[1:]
         save: Dict = {}
         with torch.no_grad():
-            feats, rnn_out = net.forward_hip(observations, rnn_states, prev_actions, masks, save=save)
+            feats, rnn_out = net.forward_hip(*args, save=save)
         ctx.net, ctx.saves, ctx.params = net, save, params
         ctx.mark_non_differentiable(rnn_out)
         return feats, rnn_out
@@ -241,7 +246,8 @@ class MapCMAForwardFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_feats, _d_rnn):
         with torch.no_grad():
-            G = net_backward(ctx.net, ctx.saves, d_feats)
+            G = getattr(ctx.net, "backward_hip", None)
+            G = (G or (lambda S, d: net_backward(ctx.net, S, d)))(ctx.saves, d_feats)
         grads: List = []
         for p, need in zip(ctx.params, ctx.needs_input_grad[1:]):
             g = G.get(p) if need else None
@@ -250,6 +256,6 @@ class MapCMAForwardFn(torch.autograd.Function):
         return (None, *grads)
 
     @staticmethod
-    def run(net, observations, rnn_states, prev_actions, masks):
+    def run(net, *args):
         params = [p for p in net.parameters() if p.requires_grad]
-        return MapCMAForwardFn.apply((net, observations, rnn_states, prev_actions, masks), *params)
+        return MapCMAForwardFn.apply((net, *args), *params)

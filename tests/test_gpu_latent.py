@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.join(HERE, "golden"))
 DEV = torch.device("cuda:0")
 
 
-def _policy(variant):
+def _policy(variant, **kw):
     from det_init import det_fill
 
     import ivln_ce_amd  # noqa: F401
@@ -25,12 +25,17 @@ def _policy(variant):
 
     cfg = get_config(opts=["MODEL.policy_name", "LatentCMAPolicy", "MODEL.INSTRUCTION_ENCODER.use_pretrained_embeddings",
                            False, "MODEL.DEPTH_ENCODER.ddppo_checkpoint", "NONE", "MODEL.tour_memory_variant", variant,
-                           "MODEL.tour_memory", variant])
+                           "MODEL.tour_memory", variant] + [x for k, v in kw.items() for x in (k, v)])
     space = Dict({"depth": Box(0.0, 1.0, (256, 256, 1), np.float32), "rgb": Box(0, 255, (224, 224, 3), np.uint8),
                   "instruction": Box(0, 2504, (200,), np.int64)})
     pol = baseline_registry.get_policy("LatentCMAPolicy").from_config(cfg, space, Discrete(4))
     det_fill(pol, seed=0, conv_gain=1.0)
     return pol.to(DEV).eval()
+
+
+def _update_policy(mode):
+    return _policy(False, **{"MODEL.tour_memory": mode == "tour", "MODEL.tour_memory_variant": mode == "variant",
+                             "MODEL.memory_at_end": mode == "variant", "MODEL.PROGRESS_MONITOR.use": mode == "plain"}).train()
 
 
 @pytest.mark.parametrize("variant,name", [(False, "latent_act_plain.npz"), (True, "latent_act_tourmem.npz")])
@@ -72,8 +77,58 @@ def test_latent_cma_state_dict_keys_and_training_guard():
               "net.progress_monitor.weight", "action_distribution.linear.weight"]:
         assert k in keys, k
     assert pol.net.state_encoder.rnn.weight_ih_l0.shape[1] == 256 + 128 + 32 + 512  # tour memory feeds GRU 1
-    with pytest.raises(NotImplementedError):
-        pol.build_distribution({}, None, None, None)
+
+
+@pytest.mark.parametrize("mode", ["plain", "tour", "variant"])
+def test_latent_cma_update_matches_reference_golden(mode):
+    """`build_distribution` + the loss of IterativeDaggerTrainer._update_agent + backward, against the
+    reference's autograd (gen_latent_update_golden.py): episodic memory with the progress monitor, `tour_memory`
+    with a carried state, and the unrolled `tour_memory_variant` + `memory_at_end`.  Tolerances as for the MapCMA
+    update: logits 1e-5 abs, loss 2e-5 abs, gradient norms 5e-4 relative, full gradients 1e-3 rel + 2e-6 abs."""
+    import torch.nn.functional as F
+    from gen_latent_update_features import features
+
+    from ivln_ce_amd.aux_losses import AuxLosses
+
+    g = np.load(os.path.join(HERE, "golden", f"latent_update_{mode}.npz"))
+    T, N = int(g["T"]), int(g["N"])
+    rgb_np, dep_np = features(int(g["seed"]), T, N)
+    pol = _update_policy(mode)
+    obs = {"rgb_features": torch.from_numpy(rgb_np).to(DEV), "depth_features": torch.from_numpy(dep_np).to(DEV),
+           "instruction": torch.from_numpy(g["instruction"]).to(DEV), "progress": torch.from_numpy(g["progress"]).to(DEV)}
+    prev = torch.from_numpy(g["prev"]).to(DEV)
+    ep, tour = torch.from_numpy(g["ep"]).to(DEV), torch.from_numpy(g["tour"]).to(DEV)
+    tgt, w = torch.from_numpy(g["targets"]).to(DEV), torch.from_numpy(g["weights"]).to(DEV)
+    h0 = torch.from_numpy(g["h0"]).to(DEV)
+    AuxLosses.clear()
+    AuxLosses.activate() if mode == "plain" else AuxLosses.deactivate()
+    try:
+        dist, rnn_out = pol.build_distribution(obs, h0.clone(), prev, ep, tour)
+        logits = dist.logits.view(T, N, -1)
+        ce = F.cross_entropy(logits.permute(0, 2, 1), tgt, reduction="none")
+        action_loss = ((w * ce).sum(0) / w.sum(0)).mean()
+        aux = AuxLosses.reduce((w > 0).view(-1)) if mode == "plain" else 0.0
+        loss = action_loss + aux
+        loss.backward()
+    finally:
+        AuxLosses.deactivate()
+    assert np.allclose(logits.detach().cpu().numpy(), g["logits"], atol=1e-5), "logits"
+    assert np.allclose(rnn_out.cpu().numpy(), g["rnn_out"], atol=1e-5), "rnn states out"
+    assert abs(float(loss.detach()) - float(g["loss"])) < 2e-5 and abs(float(aux.detach() if torch.is_tensor(aux) else aux) - float(g["aux_loss"])) < 2e-5
+    params = dict(pol.named_parameters())
+    bad, seen = [], 0
+    for k in g.files:
+        if k.startswith("gradnorm/"):
+            ref, p = float(g[k]), params[k[9:]]
+            got = float(p.grad.norm()) if p.grad is not None else float("nan")
+            seen += 1
+            if not (abs(got - ref) / max(1e-6, abs(ref)) < 5e-4 or abs(got - ref) < 1e-7):
+                bad.append(f"{k[9:]}: |g|={got:.6e} ref={ref:.6e}")
+        elif k.startswith("grad/"):
+            got = params[k[5:]].grad.cpu().numpy()
+            if not np.allclose(got, g[k], atol=2e-6, rtol=1e-3):
+                bad.append(k + f" maxerr={np.abs(got - g[k]).max():.3e}")
+    assert seen >= 38 and not bad, "\n".join(bad)
 
 
 def test_latent_cma_eval_loop_plumbing(tmp_path):
