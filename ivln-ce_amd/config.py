@@ -258,6 +258,15 @@ def _task_defaults() -> Config:
     T.ENVIRONMENT.ITERATOR_OPTIONS = CN()
     T.ENVIRONMENT.ITERATOR_OPTIONS.SHUFFLE = True
     T.ENVIRONMENT.ITERATOR_OPTIONS.MAX_SCENE_REPEAT_STEPS = -1
+    # iterative (tour-by-tour) evaluation, habitat_extensions/config/default.py:19-44
+    T.ENVIRONMENT.ITERATIVE = CN()
+    T.ENVIRONMENT.ITERATIVE.ENABLED = False
+    T.ENVIRONMENT.ITERATIVE.ENV_NAME = "VLNCEIterativeEnv"
+    T.ENVIRONMENT.ITERATIVE.PRECISE_EPISODE_START = False
+    T.ENVIRONMENT.ITERATIVE.ORACLE_STOP_ON_ERROR = False
+    T.ENVIRONMENT.ITERATIVE.ORACLE_STEP_ERROR_LIMIT = -1
+    T.ENVIRONMENT.ITERATIVE.ORACLE_GOAL_PHASE = True
+    T.ENVIRONMENT.ITERATIVE.ORACLE_PHASES = True
     T.SIMULATOR = CN()
     T.SIMULATOR.FORWARD_STEP_SIZE = 0.25
     T.SIMULATOR.TURN_ANGLE = 15

@@ -26,8 +26,14 @@ def _stream(device, role, **kw):
     return _streams[key]
 
 
+# `not_done_masks` resets the mapper (and the policy, unless `episode_not_done_masks` is given too: iterative
+# evaluation keeps the maps for a whole tour while the policy state still resets per episode)
 _STEP_KEYS = ("depth", "semantic12", "rgb", "instruction", "world_robot_pose", "world_robot_orientation",
-              "not_done_masks")
+              "not_done_masks", "episode_not_done_masks")
+
+
+def _policy_masks(batch):
+    return batch.get("episode_not_done_masks", batch["not_done_masks"])
 
 
 class GraphedRollout:
@@ -86,7 +92,7 @@ class GraphedRollout:
         self.policy._action_out_buffer = self.prev[dst] if self.deterministic else None
         try:
             with torch.no_grad():
-                actions, rnn = self.policy.act(batch, self.rnn[src], self.prev[src], batch["not_done_masks"],
+                actions, rnn = self.policy.act(batch, self.rnn[src], self.prev[src], _policy_masks(batch),
                                                deterministic=self.deterministic)
                 if actions.data_ptr() != self.prev[dst].data_ptr():
                     self.prev[dst].copy_(actions)
@@ -125,7 +131,7 @@ class GraphedRollout:
             try:
                 with torch.no_grad():
                     batch = dict(self.static)
-                    net.forward_hip(batch, self.rnn[0], self.prev[0], batch["not_done_masks"])
+                    net.forward_hip(batch, self.rnn[0], self.prev[0], _policy_masks(batch))
             finally:
                 net._stage = net._persist = None
 
@@ -136,7 +142,7 @@ class GraphedRollout:
             net._stage, net._persist = "pre", self._persist
             try:
                 with torch.no_grad():
-                    net.forward_hip(batch, self.rnn[src], self.prev[src], batch["not_done_masks"])
+                    net.forward_hip(batch, self.rnn[src], self.prev[src], _policy_masks(batch))
             finally:
                 net._stage = net._persist = None
             return batch
@@ -149,7 +155,7 @@ class GraphedRollout:
             self.policy._action_out_buffer = self.prev[dst] if self.deterministic else None
             try:
                 with torch.no_grad():
-                    actions, rnn = self.policy.act(batch, self.rnn[src], self.prev[src], batch["not_done_masks"],
+                    actions, rnn = self.policy.act(batch, self.rnn[src], self.prev[src], _policy_masks(batch),
                                                    deterministic=self.deterministic)
                     if actions.data_ptr() != self.prev[dst].data_ptr():
                         self.prev[dst].copy_(actions)

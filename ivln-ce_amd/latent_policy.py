@@ -48,7 +48,7 @@ class TorchVisionResNet50(nn.Module):
             layers += [Bottleneck(inplanes[0], planes) for _ in range(1, blocks)]
             return nn.Sequential(*layers)
 
-        self.cnn = nn.Sequential(
+        self.cnn = _ResNet50Body(
             nn.Conv2d(3, 64, 7, 2, 3, bias=False), nn.BatchNorm2d(64), nn.ReLU(inplace=True), nn.MaxPool2d(3, 2, 1),
             make_layer(64, 3), make_layer(128, 4, 2), make_layer(256, 6, 2), make_layer(512, 3, 2),
         )
@@ -56,9 +56,8 @@ class TorchVisionResNet50(nn.Module):
             param.requires_grad_(trainable)
         self.cnn.train(trainable)
         self.spatial_embeddings = nn.Embedding(4 * 4, 64)
+        self.cnn.extra_channels = self.spatial_embeddings.embedding_dim
         self.output_shape = (self.resnet_layer_size + self.spatial_embeddings.embedding_dim, 4, 4)
-        self._folded = _Folded()
-        self._epoch = -1
 
     @property
     def is_blind(self):
@@ -66,9 +65,6 @@ class TorchVisionResNet50(nn.Module):
 
     def forward(self, observations) -> Tensor:
         c, E = self.resnet_layer_size, self.spatial_embeddings.embedding_dim
-        if self._epoch != ops.WEIGHT_EPOCH:  # folded BatchNorms follow parameter updates / checkpoint loads
-            self._folded, self._epoch = _Folded(), ops.WEIGHT_EPOCH
-        f = self._folded
         if "rgb_features" in observations:
             feats = observations["rgb_features"].to(torch.float32).contiguous()
             B = feats.shape[0]
@@ -79,18 +75,38 @@ class TorchVisionResNet50(nn.Module):
             if not rgb.is_cuda:
                 raise RuntimeError("HIP hot path needs GPU tensors (no CPU fallback)")
             B = rgb.shape[0]
-            x = ops.rgb_to_nchw(rgb.to(torch.uint8).contiguous(), 255.0)
-            s, b = f.bn(self.cnn[1])
-            x = ops.conv2d(x, self.cnn[0].weight, stride=2, pad=3, scale=s, shift=b, relu=True)
-            x = ops.pool2d(x, 3, 2, 1, "max")
-            for layer in (self.cnn[4], self.cnn[5], self.cnn[6], self.cnn[7]):
-                for blk in layer:
-                    x = blk.forward_hip(x, f)
-            out = torch.empty((B, c + E, 4, 4), dtype=torch.float32, device=x.device)
-            ops.adaptive_avgpool2d(x, 4, 4, out=out, out_ctot=c + E)
+            self.cnn(rgb)  # a module call, so the trainers' forward hook on `.cnn` sees the (B,2048,4,4) features
+            out = self.cnn.full_output
         # the (16, 64) table viewed as (1, 64, 4, 4): a reshape of row-major memory, not a transpose
         ops.copy2d(self.spatial_embeddings.weight.view(1, -1), out.view(B, -1)[:, c * 16:], B, E * 16, broadcast_rows=True)
         return out
+
+
+class _ResNet50Body(nn.Sequential):
+    """torchvision ResNet-50 children [conv1, bn1, relu, maxpool, layer1..4] (+ the 4x4 spatial average pool the
+    reference swaps in for `avgpool`, resnet_encoders.py:153-163) as parameter holders with a HIP forward.  The
+    result is written into the first 2048 channels of a (B, 2048 + extra, 4, 4) buffer - the caller appends the
+    spatial embedding without a concat copy - and returned as that view, which is what the reference's
+    `rgb_encoder.cnn` forward hook caches as `rgb_features` (dagger_trainer.py:306-314)."""
+
+    extra_channels = 0
+
+    def forward(self, rgb: Tensor) -> Tensor:
+        if getattr(self, "_epoch", -1) != ops.WEIGHT_EPOCH:  # folded BatchNorms follow parameter updates / loads
+            self._folded, self._epoch = _Folded(), ops.WEIGHT_EPOCH
+        f = self._folded
+        x = ops.rgb_to_nchw(rgb.to(torch.uint8).contiguous(), 255.0)
+        s, b = f.bn(self[1])
+        x = ops.conv2d(x, self[0].weight, stride=2, pad=3, scale=s, shift=b, relu=True)
+        x = ops.pool2d(x, 3, 2, 1, "max")
+        for layer in (self[4], self[5], self[6], self[7]):
+            for blk in layer:
+                x = blk.forward_hip(x, f)
+        c = x.shape[1]
+        out = torch.empty((x.shape[0], c + self.extra_channels, 4, 4), dtype=torch.float32, device=x.device)
+        ops.adaptive_avgpool2d(x, 4, 4, out=out, out_ctot=c + self.extra_channels)
+        self.full_output = out
+        return out[:, :c]
 
 
 class LatentCMANet(Net):
@@ -432,6 +448,12 @@ class LatentCMAPolicy(ILPolicy):
 
     def build_distribution(self, observations, rnn_hidden_states, prev_actions, agent_episode_not_done_masks,
                            tour_not_done_masks=None) -> Tuple:
+        features, rnn_hidden_states = self.build_features(observations, rnn_hidden_states, prev_actions,
+                                                          agent_episode_not_done_masks, tour_not_done_masks)
+        return self.action_distribution(features), rnn_hidden_states
+
+    def build_features(self, observations, rnn_hidden_states, prev_actions, agent_episode_not_done_masks,
+                       tour_not_done_masks=None) -> Tuple:
         """latent_cma_policy.py:124-179.  The reference unrolls the time axis in Python for the tour-memory
         variant (`_view_sequential_inputs`); the HIP net takes the time-major batch directly in every mode - the
         masks select which memory resets where."""
@@ -442,11 +464,8 @@ class LatentCMAPolicy(ILPolicy):
         else:
             episode_masks = tour_not_done_masks if self.tour_memory else None
             tour_masks = None
-        features, rnn_hidden_states = self.net(
-            observations, rnn_hidden_states, prev_actions, action_masks=agent_episode_not_done_masks,
-            episode_masks=episode_masks, tour_masks=tour_masks,
-        )
-        return self.action_distribution(features), rnn_hidden_states
+        return self.net(observations, rnn_hidden_states, prev_actions, action_masks=agent_episode_not_done_masks,
+                        episode_masks=episode_masks, tour_masks=tour_masks)
 
     @classmethod
     def from_config(cls, config, observation_space, action_space):

@@ -389,11 +389,15 @@ class MapCMAPolicy(ILPolicy):
         )
         return self._act(features, deterministic), rnn_hidden_states
 
+    def build_features(self, observations, rnn_hidden_states, prev_actions, agent_episode_not_done_masks,
+                       tour_not_done_masks=None) -> Tuple[Tensor, Tensor]:
+        """The net half of `build_distribution` (the fused CE kernel of the HIP update takes raw logits)."""
+        return self.net(observations, rnn_hidden_states, prev_actions, action_masks=agent_episode_not_done_masks)
+
     def build_distribution(self, observations, rnn_hidden_states, prev_actions, agent_episode_not_done_masks,
                            tour_not_done_masks=None) -> Tuple[CustomFixedCategorical, Tensor]:
-        features, rnn_hidden_states = self.net(
-            observations, rnn_hidden_states, prev_actions, action_masks=agent_episode_not_done_masks
-        )
+        features, rnn_hidden_states = self.build_features(observations, rnn_hidden_states, prev_actions,
+                                                          agent_episode_not_done_masks, tour_not_done_masks)
         return self.action_distribution(features), rnn_hidden_states
 
     @classmethod

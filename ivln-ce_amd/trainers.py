@@ -98,16 +98,20 @@ class FlatAdam:
 
 
 def update_agent(policy, optimizer: FlatAdam, observations, prev_actions, not_done_masks, corrected_actions, weights,
-                 hidden_size=512, step_grad=True, loss_accumulation_scalar=1, world=1):
+                 hidden_size=512, step_grad=True, loss_accumulation_scalar=1, world=1, tour_not_done_masks=None,
+                 rnn_states=None):
     """BaseVLNCETrainer._update_agent (base_il_trainer.py:173-219): forward over all T*N rows, weighted
     CE (+ aux), backward, Adam - every arithmetic step on HIP.  Returns python floats like the
-    reference (loss, action_loss, aux_loss)."""
+    reference (loss, action_loss, aux_loss).  With `rnn_states` (IterativeDaggerTrainer._update_agent,
+    iterative_dagger_trainer.py:33-94) the recurrent state carried from the previous batch of the same tours
+    seeds the forward (no gradient through it) and the new state is returned as a fourth value."""
     T, N = corrected_actions.size()
     dev = corrected_actions.device
-    h0 = torch.zeros(N, policy.net.num_recurrent_layers, hidden_size, device=dev)
+    carry = rnn_states is not None
+    h0 = rnn_states.detach() if carry else torch.zeros(N, policy.net.num_recurrent_layers, hidden_size, device=dev)
     AuxLosses.clear()
     with torch.enable_grad():
-        feats, _ = policy.net(observations, h0, prev_actions, not_done_masks)
+        feats, rnn_out = policy.build_features(observations, h0, prev_actions, not_done_masks, tour_not_done_masks)
         logits = policy.action_distribution.raw_logits(feats)  # (T*N, A)
     A = logits.shape[-1]
     scale = 1.0 / loss_accumulation_scalar
@@ -125,6 +129,8 @@ def update_agent(policy, optimizer: FlatAdam, observations, prev_actions, not_do
         optimizer.step(world)
     al = float(action_loss.item())
     ax = float(aux_loss.item()) if isinstance(aux_loss, torch.Tensor) else float(aux_loss)
+    if carry:
+        return (al + ax) * scale, al, ax, rnn_out.detach()
     return (al + ax) * scale, al, ax
 
 
@@ -144,7 +150,7 @@ class TrajectoryStore:
 
     def clear(self):
         for f in os.listdir(self.path):
-            if f.endswith(".npz"):
+            if f.endswith(".npz") or f == "0.json":
                 os.remove(os.path.join(self.path, f))
 
     def put(self, idx, traj_obs: Dict[str, np.ndarray], prev_actions, oracle_actions, tour_id=None):
@@ -159,6 +165,19 @@ class TrajectoryStore:
         with np.load(os.path.join(self.path, f"{idx}.npz")) as f:
             obs = {k[4:]: f[k] for k in f.files if k.startswith("obs/")}
             return obs, f["prev_actions"], f["oracle_actions"]
+
+    # the reference keeps {tour_id: [record indices]} as JSON under lmdb key "0" and numbers the trajectories
+    # from 1 (iterative_collection_dagger_trainer.py:228-235, 377-385); here it is `0.json` next to 1.npz, 2.npz ...
+    def put_tour_index(self, tours_to_idxs):
+        with open(os.path.join(self.path, "0.json"), "w") as f:
+            json.dump(tours_to_idxs, f)
+
+    def get_tour_index(self):
+        path = os.path.join(self.path, "0.json")
+        if not os.path.exists(path):
+            return {}
+        with open(path) as f:
+            return json.load(f)
 
 
 def collate_fn(batch):
@@ -396,9 +415,13 @@ class BaseVLNCETrainer:
         the mapper.  Scenes/envs are sharded over ranks; rank 0 merges."""
         config = self.config
         split = config.EVAL.SPLIT
+        iterative = bool(config.TASK_CONFIG.ENVIRONMENT.ITERATIVE.ENABLED)
+        prefix = "iterative_stats" if iterative else "stats"
+        if iterative:
+            assert config.EVAL.ITERATIVE_MAP_RESET in ["episodic", "iterative"], "config.EVAL.ITERATIVE_MAP_RESET not valid"
         if config.EVAL.SAVE_RESULTS:
             self._make_results_dir()
-            fname = os.path.join(config.RESULTS_DIR, f"stats_ckpt_{checkpoint_index}_{split}.json")
+            fname = os.path.join(config.RESULTS_DIR, f"{prefix}_ckpt_{checkpoint_index}_{split}.json")
             if os.path.exists(fname):
                 return json.load(open(fname))
         envs = construct_envs(config, None, auto_reset_done=False, rank=self.rank, world=self.world)
@@ -413,11 +436,24 @@ class BaseVLNCETrainer:
                                  device=self.device)
         prev_actions = torch.zeros(n, 1, device=self.device, dtype=torch.long)
         not_done_masks = torch.zeros(n, 1, dtype=torch.uint8, device=self.device)
+        tour_masks = torch.zeros(n, 1, dtype=torch.uint8, device=self.device)
+        # iterative evaluation (base_il_trainer.py:585-928): the maps live for a whole tour unless
+        # ITERATIVE_MAP_RESET == "episodic"; the policy gets the episode AND the tour masks (act_iterative)
+        maps_by_tour = iterative and config.EVAL.ITERATIVE_MAP_RESET == "iterative"
+        tour_policy = bool(config.MODEL.tour_memory or config.MODEL.tour_memory_variant)
         observations = envs.reset()
-        use_graph = self._graph_eligible()
-        observations, batch = self._batch(observations, not_done_masks, transform=not use_graph)
+        # a captured step has one policy mask (+ one mapper mask): policies with a tour memory run eagerly
+        use_graph = self._graph_eligible() and not (iterative and tour_policy)
+
+        def make_batch(observations):
+            if maps_by_tour:  # the mapper resets on `not_done_masks`; the policy keeps its own episode masks
+                observations = add_batched_data_to_observations(observations, not_done_masks, "episode_not_done_masks")
+            return self._batch(observations, tour_masks if maps_by_tour else not_done_masks, transform=not use_graph)
+
+        observations, batch = make_batch(observations)
         runner, captured = None, False
         stats_episodes = {}
+        stats_tours = defaultdict(dict)
         remaining = list(envs.number_of_episodes)
         t0 = time.time()
         while envs.num_envs > 0:
@@ -431,48 +467,63 @@ class BaseVLNCETrainer:
             else:
                 with torch.no_grad():
                     actions, rnn_states = self.policy.act_iterative(
-                        batch, rnn_states, prev_actions, not_done_masks, not_done_masks, not_done_masks,
-                        not_done_masks, deterministic=not config.EVAL.SAMPLE,
+                        batch, rnn_states, prev_actions, not_done_masks, not_done_masks,
+                        tour_masks if iterative else not_done_masks, torch.ones_like(not_done_masks),
+                        deterministic=not config.EVAL.SAMPLE,
                     )
                     prev_actions.copy_(actions)
             current_episodes = envs.current_episodes()
             outputs = envs.step([a[0].item() for a in actions])
             observations, _, dones, infos = [list(x) for x in zip(*outputs)]
             not_done_masks = torch.tensor([[0] if d else [1] for d in dones], dtype=torch.uint8, device=self.device)
+            next_episodes = envs.current_episodes()
+            tour_masks = torch.tensor(
+                [[0] if (d and getattr(a, "tour_id", None) != getattr(b, "tour_id", None)) else [1]
+                 for d, a, b in zip(dones, next_episodes, current_episodes)], dtype=torch.uint8, device=self.device)
             envs_to_pause = []
             for i in range(envs.num_envs):
                 if dones[i]:
                     stats_episodes[current_episodes[i].episode_id] = infos[i]
+                    stats_tours[str(getattr(current_episodes[i], "tour_id", ""))][current_episodes[i].episode_id] = infos[i]
                     remaining[i] -= 1
                     if remaining[i] <= 0:
                         envs_to_pause.append(i)
-            observations, batch = self._batch(observations, not_done_masks, transform=not use_graph)
+            observations, batch = make_batch(observations)
             if envs_to_pause:
                 for idx in reversed(envs_to_pause):
                     remaining.pop(idx)
+                keep = [i for i in range(envs.num_envs) if i not in envs_to_pause]
+                tour_masks = tour_masks[keep]
                 envs, rnn_states, not_done_masks, prev_actions, batch, _ = self._pause_envs(
                     envs_to_pause, envs, rnn_states, not_done_masks, prev_actions, batch)
                 runner = None  # fewer rows: capture again for the new batch size, seeded with the kept rows
         agent_paths, gt_paths = envs.dtw_data(), envs.gt_paths()
-        gathered = D.gather_objects((stats_episodes, agent_paths, gt_paths))
+        gathered = D.gather_objects((stats_episodes, agent_paths, gt_paths, dict(stats_tours)))
         envs.close()
         if self.rank != 0:
             return None
-        stats_episodes, agent_paths, gt_paths = {}, {}, {}
-        for s, a, g in gathered:
+        stats_episodes, agent_paths, gt_paths, stats_tours = {}, {}, {}, {}
+        for s, a, g, st in gathered:
             stats_episodes.update(s)
             agent_paths.update(a)
             gt_paths.update(g)
+            for tour, eps in st.items():
+                stats_tours.setdefault(tour, {}).update(eps)
         agg = {}
         num = max(1, len(stats_episodes))
         for k in next(iter(stats_episodes.values())).keys():
             agg[k] = sum(v[k] for v in stats_episodes.values()) / num
         agg["t_ndtw"] = compute_tour_ndtw(agent_paths, gt_paths)
+        if iterative:
+            agg["tndtw"] = agg["t_ndtw"]  # the key the reference's iterative report uses (base_il_trainer.py:911)
         agg["episodes"] = len(stats_episodes)
         agg["eval_seconds"] = time.time() - t0
         if config.EVAL.SAVE_RESULTS:
             json.dump(agg, open(fname, "w"), indent=4)
             json.dump(agent_paths, open(os.path.join(config.RESULTS_DIR, f"dtw_data_ckpt_{checkpoint_index}_{split}.json"), "w"))
+            if iterative:  # every episode's stats, grouped by tour (base_il_trainer.py:889-895)
+                json.dump(stats_tours, open(os.path.join(
+                    config.RESULTS_DIR, f"iterative_all_stats_ckpt_{checkpoint_index}_{split}.json"), "w"), indent=2)
         return agg
 
     def inference(self):
@@ -505,14 +556,16 @@ class PrefetchLoader:
         def work():
             try:
                 for batch in self.loader:
-                    obs_b, prev_b, nd_b, corr_b, w_b = (pin(b) for b in batch)
+                    parts = tuple(pin(b) for b in batch)
+                    if len(parts) == 5:  # episodic collate: no tour masks (slot 3 of the 6-tuple the loops unpack)
+                        parts = parts[:3] + (None,) + parts[3:]
                     if cuda:
                         with torch.cuda.stream(stream):
-                            moved = batch_to((obs_b, prev_b, nd_b, None, corr_b, w_b), self.device)
+                            moved = batch_to(parts, self.device)
                             ev = torch.cuda.Event()
                             ev.record(stream)
                     else:
-                        moved, ev = batch_to((obs_b, prev_b, nd_b, None, corr_b, w_b), self.device), None
+                        moved, ev = batch_to(parts, self.device), None
                     q.put((moved, ev))
                 q.put(None)
             except BaseException as e:  # noqa: BLE001 - surface loader errors in the training thread
@@ -551,9 +604,10 @@ class DaggerTrainer(BaseVLNCETrainer):
 
     tour_masked_maps = False  # IterativeCollectionDaggerTrainer resets maps with the tour mask
 
-    def _update_dataset(self, data_it):
-        """dagger_trainer.py:251-504: roll the policy out with beta-mixed expert actions, cache the
-        depth-encoder features through the forward hook, store finished trajectories."""
+    def _update_dataset(self, data_it, save_tour_idx_data=False):
+        """dagger_trainer.py:251-504 / iterative_collection_dagger_trainer.py:131-397: roll the policy out with
+        beta-mixed expert actions, cache the frozen encoders' features through forward hooks, store finished
+        trajectories; with `save_tour_idx_data` also the {tour_id: [record indices]} table, which is returned."""
         cfg = self.config
         envs = construct_envs(cfg, None, rank=self.rank, world=self.world)
         expert_uuid = cfg.IL.DAGGER.expert_policy_sensor_uuid
@@ -570,9 +624,17 @@ class DaggerTrainer(BaseVLNCETrainer):
         p = cfg.IL.DAGGER.p
         beta = 0.0 if p == 0.0 else p ** data_it
         feats = {}
-        hook = self.policy.net.depth_encoder.visual_encoder.register_forward_hook(
-            lambda m, i, o: feats.__setitem__("depth", o.detach().cpu()))
+        hooks = [self.policy.net.depth_encoder.visual_encoder.register_forward_hook(
+            lambda m, i, o: feats.__setitem__("depth", o.detach().cpu()))]
+        if hasattr(self.policy.net, "rgb_encoder") and not cfg.MODEL.RGB_ENCODER.trainable:
+            hooks.append(self.policy.net.rgb_encoder.cnn.register_forward_hook(
+                lambda m, i, o: feats.__setitem__("rgb", o.detach().cpu())))
         collected, start_id = 0, len(self.store)
+        tours_to_idxs = defaultdict(list)
+        if save_tour_idx_data:
+            tours_to_idxs.update(self.store.get_tour_index())
+            start_id += 1  # record 0 is the tour table
+        tour_masks = torch.zeros(n, 1, dtype=torch.uint8, device=self.device)
         target = max(1, cfg.IL.DAGGER.update_size // self.world)
         with torch.no_grad():
             while collected < target:
@@ -582,28 +644,38 @@ class DaggerTrainer(BaseVLNCETrainer):
                         traj_obs = batch_obs([s[0] for s in ep], device=torch.device("cpu"))
                         del traj_obs[expert_uuid]
                         traj_obs = {k: v.numpy() for k, v in traj_obs.items() if torch.is_tensor(v)}
-                        self.store.put(start_id + collected, traj_obs, [s[1] for s in ep], [s[2] for s in ep])
+                        self.store.put(start_id + collected, traj_obs, [s[1] for s in ep], [s[2] for s in ep],
+                                       tour_id=ep[0][3])
+                        tours_to_idxs[str(ep[0][3])].append(start_id + collected)
                         collected += 1
                     if dones[i]:
                         episodes[i] = []
-                actions, rnn_states = self.policy.act(batch, rnn_states, prev_actions, not_done_masks,
-                                                      deterministic=False)
+                if self.tour_masked_maps:  # tour-by-tour collection: the policy sees episode AND tour boundaries
+                    actions, rnn_states = self.policy.act_iterative(
+                        batch, rnn_states, prev_actions, not_done_masks, not_done_masks, tour_masks,
+                        torch.ones_like(not_done_masks), deterministic=False)
+                else:
+                    actions, rnn_states = self.policy.act(batch, rnn_states, prev_actions, not_done_masks,
+                                                          deterministic=False)
                 expert = batch[expert_uuid].long()
                 actions = torch.where(torch.rand_like(actions, dtype=torch.float) < beta, expert, actions)
                 occ = batch["occupancy_map"].cpu().numpy() if "occupancy_map" in batch else None
                 sem = batch["semantic_map"].cpu().numpy() if "semantic_map" in batch else None
                 prev_cpu = prev_actions.cpu()
                 expert_cpu = expert.cpu()
+                tours_now = [getattr(e, "tour_id", None) for e in envs.current_episodes()]
                 for i in range(envs.num_envs):
                     o = dict(observations[i])
                     o["depth_features"] = feats["depth"][i].clone()
                     o.pop("depth", None)
+                    if "rgb" in feats:
+                        o["rgb_features"] = feats["rgb"][i].clone()
                     if occ is not None:
                         o["occupancy_map"], o["semantic_map"] = occ[i].copy(), sem[i].copy()
                     for k in ["semantic", "semantic12", "world_robot_pose", "world_robot_orientation", "env_name",
                               "rgb", "not_done_masks"]:
                         o.pop(k, None)
-                    episodes[i].append((o, prev_cpu[i].item(), expert_cpu[i].item()))
+                    episodes[i].append((o, prev_cpu[i].item(), expert_cpu[i].item(), tours_now[i]))
                 skips_t = expert == -1
                 actions = torch.where(skips_t, torch.zeros_like(actions), actions)
                 skips = skips_t.squeeze(-1).cpu().tolist()
@@ -613,15 +685,18 @@ class DaggerTrainer(BaseVLNCETrainer):
                 observations, _, dones, _ = [list(x) for x in zip(*outputs)]
                 not_done_masks = torch.tensor([[0] if d else [1] for d in dones], dtype=torch.uint8,
                                               device=self.device)
-                map_masks = not_done_masks
-                if self.tour_masked_maps:  # maps persist across the episodes of a tour (:166-168, 373-375)
-                    tours_after = [getattr(e, "tour_id", None) for e in envs.current_episodes()]
-                    map_masks = torch.tensor(
-                        [[0] if (d and a != b) else [1] for d, a, b in zip(dones, tours_after, tours_before)],
-                        dtype=torch.uint8, device=self.device)
-                observations, batch = self._batch(observations, map_masks)
-        hook.remove()
+                tours_after = [getattr(e, "tour_id", None) for e in envs.current_episodes()]
+                tour_masks = torch.tensor(
+                    [[0] if (d and a != b) else [1] for d, a, b in zip(dones, tours_after, tours_before)],
+                    dtype=torch.uint8, device=self.device)
+                # maps persist across the episodes of a tour when collecting tour by tour (:166-168, 373-375)
+                observations, batch = self._batch(observations, tour_masks if self.tour_masked_maps else not_done_masks)
+        for h in hooks:
+            h.remove()
         envs.close()
+        if save_tour_idx_data:
+            self.store.put_tour_index(tours_to_idxs)
+            return dict(tours_to_idxs)
         return collected
 
     def train(self):
@@ -635,6 +710,10 @@ class DaggerTrainer(BaseVLNCETrainer):
         observation_space, action_space = self._get_spaces(cfg, envs=envs)
         envs.close()
         self._initialize_policy(cfg, cfg.IL.load_from_ckpt, observation_space, action_space)
+        return self._train_loop()
+
+    def _train_loop(self):
+        cfg = self.config
         log = []
         for dagger_it in range(cfg.IL.DAGGER.iterations):
             step_id = 0
@@ -664,3 +743,65 @@ class IterativeCollectionDaggerTrainer(DaggerTrainer):
     handed to the mapper are the TOUR masks; the policy state still resets per episode)."""
 
     tour_masked_maps = True
+
+
+@baseline_registry.register_trainer(name="iterative_dagger")
+class IterativeDaggerTrainer(IterativeCollectionDaggerTrainer):
+    """iterative_dagger_trainer.py:31-283: tour-ordered updates.  Batches come from `TourSampler` (row i of every
+    batch continues the tours of bin i), the recurrent state returned by one update seeds the next one
+    (detached), and the policy's memory mode decides what of it survives: nothing (episodic policies), everything
+    (`tour_memory`) or only the tour-long slot (`tour_memory_variant`)."""
+
+    def _update_agent(self, observations, prev_actions, episode_not_done_masks, tour_not_done_masks,
+                      corrected_actions, weights, step_grad=True, loss_accumulation_scalar=1, rnn_states=None):
+        mc = self.config.MODEL
+        T, N = corrected_actions.size()
+        L = self.policy.net.num_recurrent_layers
+        reset_memory = not (mc.tour_memory or mc.tour_memory_variant)
+        if rnn_states is None or reset_memory:
+            rnn_states = torch.zeros(N, L, mc.STATE_ENCODER.hidden_size, device=self.device)
+        if mc.tour_memory_variant:  # only the tour-long slot survives a batch boundary (:58-60)
+            rnn_states = rnn_states.clone()
+            rnn_states[:, : L - 1] = 0
+        return update_agent(self.policy, self.optimizer, observations, prev_actions, episode_not_done_masks,
+                            corrected_actions, weights, mc.STATE_ENCODER.hidden_size, step_grad,
+                            loss_accumulation_scalar, self.world, tour_not_done_masks=tour_not_done_masks,
+                            rnn_states=rnn_states)
+
+    def _train_loop(self):
+        from .tour_batches import TourSampler, TourTrajectoryDataset, tour_collate
+
+        cfg = self.config
+        log = []
+        for dagger_it in range(cfg.IL.DAGGER.iterations):
+            step_id = 0
+            if cfg.IL.DAGGER.preload_lmdb_features:
+                tours_to_idxs = self.store.get_tour_index()
+            else:
+                tours_to_idxs = self._update_dataset(dagger_it + (1 if cfg.IL.load_from_ckpt else 0),
+                                                     save_tour_idx_data=True)
+            AuxLosses.activate()
+            for epoch in range(self.start_epoch, cfg.IL.epochs):
+                dataset = TourTrajectoryDataset(self.store, cfg.IL.use_iw, cfg.IL.inflection_weight_coef)
+                sampler = TourSampler({k: list(v) for k, v in tours_to_idxs.items()}, batch_size=cfg.IL.batch_size,
+                                      shuffle=True, drop_last=True)
+                if self.world > 1:
+                    n = torch.tensor([len(sampler)], device=self.device)
+                    torch.distributed.all_reduce(n, op=torch.distributed.ReduceOp.MIN)
+                    sampler.truncate(int(n.item()))
+                dataset.set_tour_done_idxs(sampler.get_tour_done_idxs())
+                loader = torch.utils.data.DataLoader(dataset, batch_sampler=sampler, collate_fn=tour_collate,
+                                                     pin_memory=False, num_workers=0)
+                rnn_states = torch.zeros(cfg.IL.batch_size, self.policy.net.num_recurrent_layers,
+                                         cfg.MODEL.STATE_ENCODER.hidden_size, device=self.device)
+                for obs_b, prev_b, ep_b, tour_b, corr_b, w_b in PrefetchLoader(loader, self.device):
+                    loss, action_loss, aux_loss, rnn_states = self._update_agent(
+                        obs_b, prev_b, ep_b, tour_b, corr_b, w_b, rnn_states=rnn_states)
+                    log.append({"dagger_it": dagger_it, "epoch": epoch, "step": step_id, "loss": loss,
+                                "action_loss": action_loss, "aux_loss": aux_loss})
+                    step_id += 1
+                    self.step_id += 1
+                self.save_checkpoint(f"ckpt.{dagger_it * cfg.IL.epochs + epoch}.pth", dagger_it=dagger_it, epoch=epoch,
+                                     step_id=self.step_id)
+            AuxLosses.deactivate()
+        return log

@@ -209,3 +209,75 @@ def test_eval_with_graph_replay_matches_eager_eval(tmp_path):
         out[mode] = res
     assert out[True] == out[False], f"graph {out[True]} vs eager {out[False]}"
     assert out[True]["episodes"] > 0
+
+
+@pytest.mark.parametrize("policy", ["MapCMAPolicy", "LatentCMAPolicy"])
+def test_iterative_dagger_trainer_end_to_end(tmp_path, policy):
+    """iterative_dagger: tour-by-tour collection (tour table stored as record 0) -> TourSampler batches -> HIP
+    updates with the recurrent state carried between batches -> checkpoint -> iterative eval report files."""
+    import ivln_ce_amd  # noqa: F401
+    from ivln_ce_amd import trainers  # noqa: F401
+    from ivln_ce_amd.config import get_config
+    from ivln_ce_amd.registry import baseline_registry
+
+    torch.manual_seed(0)
+    np.random.seed(0)
+    latent = policy == "LatentCMAPolicy"
+    opts = [
+        "TRAINER_NAME", "iterative_dagger", "NUM_ENVIRONMENTS", 2, "MODEL.policy_name", policy,
+        "MODEL.INSTRUCTION_ENCODER.use_pretrained_embeddings", False, "MODEL.DEPTH_ENCODER.ddppo_checkpoint", "NONE",
+        "RL.POLICY.OBS_TRANSFORMS.ENABLED_TRANSFORMS", [] if latent else ["GTSemanticsIterativeMapper"],
+        "IL.DAGGER.iterations", 1, "IL.DAGGER.update_size", 12, "IL.DAGGER.p", 1.0, "IL.epochs", 2, "IL.batch_size", 2,
+        "IL.DAGGER.lmdb_features_dir", str(tmp_path / "traj"), "CHECKPOINT_FOLDER", str(tmp_path / "ckpt"),
+        "RESULTS_DIR", str(tmp_path / "res"), "EVAL_CKPT_PATH_DIR", str(tmp_path / "ckpt"),
+        "TASK_CONFIG.ENVIRONMENT.ITERATIVE.ENABLED", True,
+    ]
+    if latent:
+        opts += ["MODEL.tour_memory_variant", True, "MODEL.memory_at_end", True]
+    cfg = get_config(opts=opts)
+    tr = baseline_registry.get_trainer("iterative_dagger")(cfg)
+    before = None
+    log = tr.train()
+    assert len(log) >= 2 and all(np.isfinite(l["loss"]) for l in log), log
+    table = tr.store.get_tour_index()
+    assert sum(len(v) for v in table.values()) == 12 and min(min(v) for v in table.values()) == 1
+    obs, prev, expert = tr.store.get(1)
+    assert "depth_features" in obs and ("rgb_features" in obs) == latent and "rgb" not in obs
+    if latent:
+        assert obs["rgb_features"].shape[1:] == (2048, 4, 4)
+    assert os.path.exists(tmp_path / "ckpt" / "ckpt.1.pth")
+    res = baseline_registry.get_trainer("iterative_dagger")(cfg).eval()[0]
+    assert res["episodes"] == 16 and 0.0 < res["tndtw"] <= 1.0
+    assert os.path.exists(tmp_path / "res" / "iterative_stats_ckpt_0_val_seen.json")
+    import json
+
+    all_stats = json.load(open(tmp_path / "res" / "iterative_all_stats_ckpt_0_val_seen.json"))
+    assert sum(len(v) for v in all_stats.values()) == 16 and len(all_stats) == 6  # 2 envs x 3 tours
+
+
+@pytest.mark.parametrize("reset", ["iterative", "episodic"])
+def test_iterative_eval_graph_replay_matches_eager(tmp_path, reset):
+    """Iterative evaluation keeps the maps for a whole tour (mapper reset by the TOUR mask) while the policy state
+    resets per episode: the captured step carries both masks and must reproduce the eager loop exactly."""
+    import ivln_ce_amd  # noqa: F401
+    from ivln_ce_amd import trainers  # noqa: F401
+    from ivln_ce_amd.config import get_config
+    from ivln_ce_amd.registry import baseline_registry
+
+    out = {}
+    for mode in (True, False):
+        torch.manual_seed(0)
+        cfg = get_config(opts=[
+            "TRAINER_NAME", "dagger", "NUM_ENVIRONMENTS", 3, "MODEL.policy_name", "MapCMAPolicy",
+            "MODEL.INSTRUCTION_ENCODER.use_pretrained_embeddings", False, "MODEL.DEPTH_ENCODER.ddppo_checkpoint", "NONE",
+            "RL.POLICY.OBS_TRANSFORMS.ENABLED_TRANSFORMS", ["GTSemanticsIterativeMapper"],
+            "RESULTS_DIR", str(tmp_path / f"res{int(mode)}"), "EVAL_CKPT_PATH_DIR", str(tmp_path / "none.pth"),
+            "EVAL.USE_HIP_GRAPH", mode, "EVAL.SAVE_RESULTS", False, "EVAL.ITERATIVE_MAP_RESET", reset,
+            "TASK_CONFIG.ENVIRONMENT.ITERATIVE.ENABLED", True,
+        ])
+        tr = baseline_registry.get_trainer("dagger")(cfg)
+        res = tr._eval_checkpoint(str(tmp_path / "none.pth"))
+        res.pop("eval_seconds")
+        out[mode] = res
+    assert out[True] == out[False], f"graph {out[True]} vs eager {out[False]}"
+    assert out[True]["episodes"] > 0 and "tndtw" in out[True]
