@@ -424,5 +424,32 @@ def main():
         dist.destroy_process_group()
 
 
+def _watchdog(seconds, code, what):
+    """A wedged GPU call cannot be interrupted from Python: end the process instead of sitting until the caller's
+    limit (which would take the GPU box with it)."""
+    import threading
+
+    def _fire():
+        sys.stderr.write(f"[bench] watchdog: {what} after {seconds}s, exiting\n")
+        sys.stderr.flush()
+        os._exit(code)
+
+    t = threading.Timer(seconds, _fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
 if __name__ == "__main__":
+    wd = _watchdog(int(os.environ.get("IVLN_BENCH_LIMIT_S", "1500")), 3, "run not finished")
     main()
+    wd.cancel()
+    sys.stdout.flush()
+    sys.stderr.flush()
+    profiled = any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB"))
+    if not profiled:
+        os._exit(0)  # the JSON line is out: skip interpreter / runtime teardown (graphs, streams) altogether
+    import signal
+
+    signal.signal(signal.SIGALRM, signal.SIG_DFL)
+    signal.alarm(120)  # under a profiler its finalizers must run: give teardown two minutes, not forever

@@ -378,8 +378,12 @@ extern "C" int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream) {
         static const int want_env = getenv("IVLN_SPLIT_WANT") ? atoi(getenv("IVLN_SPLIT_WANT")) : 0;  // tuning
         // deferred: one block per CU measured as fast as four (3.50-3.54 K env-steps/s for 192..2048) at a
         // quarter of the slab bytes the consumer has to read back
-        const int64_t want = want_env > 0 ? want_env : (d.defer_epilogue ? 256 : 512);
-        if (d.ws && blocks < 256 && nk >= 2 * min_tiles) {
+        static const int want_nd_env = getenv("IVLN_SPLIT_WANT_ND") ? atoi(getenv("IVLN_SPLIT_WANT_ND")) : 0;
+        const int64_t want = want_env > 0 ? want_env
+                             : (d.defer_epilogue ? 256 : (want_nd_env > 0 ? want_nd_env : 512));
+        static const int below_env = getenv("IVLN_SPLIT_BELOW") ? atoi(getenv("IVLN_SPLIT_BELOW")) : 0;  // tuning
+        const int64_t below = (below_env > 0 && !d.defer_epilogue) ? below_env : 256;
+        if (d.ws && blocks < below && nk >= 2 * min_tiles) {
             splits = (int)((want + blocks - 1) / blocks);
             if (splits > nk / min_tiles) splits = nk / min_tiles;
             // weight gradients reduce over millions of pixels with a tiny M x N: allow deep splits there

@@ -9,9 +9,12 @@ Two graphs are captured with the recurrent state / previous action ping-ponging 
 buffer sets (graph 0: A -> B, graph 1: B -> A), so no state copies are needed between steps; the
 only per-step copies are the observation tensors the step actually reads.
 """
+import os
 from typing import Dict
 
 import torch
+
+from . import ops
 
 _streams = {}
 
@@ -21,6 +24,8 @@ def _stream(device, role, **kw):
     by the stream, so a fresh stream per capture - the eval loop re-captures whenever envs pause - would pin a
     new set every time."""
     key = (str(device), role)
+    if os.environ.get("IVLN_FRESH_STREAMS"):  # experiment switch: a new stream per capture
+        return torch.cuda.Stream(device, **kw)
     if key not in _streams:
         _streams[key] = torch.cuda.Stream(device, **kw)
     return _streams[key]
@@ -176,6 +181,7 @@ class GraphedRollout:
             run_A()
         main.wait_stream(s)
         torch.cuda.synchronize()
+        ops.settle_packed_weights()
         self.gA = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.gA, stream=self.sA):
             run_A()
@@ -216,6 +222,7 @@ class GraphedRollout:
                 self._body(i & 1)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        ops.settle_packed_weights()
         for src in (0, 1):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
@@ -226,8 +233,6 @@ class GraphedRollout:
     def load(self, obs: Dict):
         """Observation tensors -> the captured input buffers: one multi-copy launch for everything that is
         already a matching contiguous device tensor, Tensor.copy_ (H2D / cast / strided) for the rest."""
-        from . import ops
-
         pairs = []
         for k, v in obs.items():
             if torch.is_tensor(v):

@@ -152,17 +152,51 @@ def packed_conv_weights(w, cache=True):
         out = torch.empty(n, dtype=torch.float32, device=w.device)
         check(L.ivln_conv_pack_weights_f32(dptr(w), Cout, Cin, KH, dptr(out), stream_ptr()), "ivln_conv_pack_weights_f32")
         return out
-    key = (w.data_ptr(), tuple(w.shape), torch.cuda.current_stream().cuda_stream)
+    key = (w.data_ptr(), tuple(w.shape))
     stamp = (w._version, WEIGHT_EPOCH)
+    cur = torch.cuda.current_stream()
     hit = _packed.get(key)
-    if hit is not None and hit[2]() is w and hit[0] == stamp:
-        return hit[1]
-    out = hit[1] if (hit is not None and hit[2]() is w) else torch.empty(n, dtype=torch.float32, device=w.device)
+    if hit is not None and hit.ref() is w and hit.stamp == stamp:
+        if hit.settled or hit.stream == cur.cuda_stream:
+            return hit.out
+        if not torch.cuda.is_current_stream_capturing():
+            cur.wait_event(hit.event)  # packed on another stream: order this stream behind it
+            return hit.out
+        # capturing on a stream that never saw the packing and nobody settled the cache: pack again (into a
+        # buffer of the capture's own pool), as a node of this graph
+    capturing = torch.cuda.is_current_stream_capturing()
+    same = hit is not None and hit.ref() is w  # same live tensor, new contents: refresh its buffer in place
+    if same and not capturing:
+        if hit.stream != cur.cuda_stream:
+            cur.wait_event(hit.event)
+        out = hit.out
+    else:
+        out = torch.empty(n, dtype=torch.float32, device=w.device)
     check(L.ivln_conv_pack_weights_f32(dptr(w), Cout, Cin, KH, dptr(out), stream_ptr()), "ivln_conv_pack_weights_f32")
+    if capturing:
+        return out  # lives in this graph's pool, valid inside this graph only: not cached
     if len(_packed) > 1024:
         _packed.clear()
-    _packed[key] = (stamp, out, weakref.ref(w))
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    _packed[key] = _Packed(stamp, out, weakref.ref(w), cur.cuda_stream, ev)
     return out
+
+
+class _Packed:
+    __slots__ = ("stamp", "out", "ref", "stream", "event", "settled")
+
+    def __init__(self, stamp, out, ref, stream, event):
+        self.stamp, self.out, self.ref, self.stream, self.event, self.settled = stamp, out, ref, stream, event, False
+
+
+def settle_packed_weights():
+    """Call right after a device-wide synchronize: every packed buffer is complete, so any stream - and any
+    graph captured from now on - may read it without ordering (graphed.py calls this before capturing; without
+    it a capture on a stream other than the one that packed would record the packing kernels as graph nodes
+    and replay them every step)."""
+    for e in _packed.values():
+        e.settled = True
 
 
 class Deferred:
