@@ -229,6 +229,12 @@ int ivln_prev_action_embed_f32(const int64_t* prev_actions, const uint8_t* mask,
  * (rows, O). */
 int ivln_linear_argmax_f32(const float* x, int64_t ldx, const float* W, const float* bias, int rows, int K, int O,
                            int64_t* action, float* logits_out, void* stream);
+/* Tour-long memory slot of the Latent-CMA `tour_memory_variant` (models/latent_cma_policy.py:395-399, 433-439):
+ * out[n] = mask[n] * (h ? max(mem[n], h[n]) : mem[n]) - the previous step's max-pool with the first GRU's new
+ * state and this step's reset where a tour starts, in one launch; written to out1 and (optionally) out2, all
+ * row-strided (N, H) views. */
+int ivln_tour_memory_f32(const float* mem, int64_t ld_mem, const float* h, int64_t ld_h, const uint8_t* mask, int N,
+                         int H, float* out1, int64_t ld1, float* out2, int64_t ld2, void* stream);
 /* u8 NHWC -> f32 NCHW / div (TorchVisionResNet.forward, models/encoders/resnet_encoders.py:171-198: / 255) */
 int ivln_rgb_to_nchw_f32(const uint8_t* rgb, int B, int H, int W, float div, float* out, void* stream);
 /* F.adaptive_avg_pool2d (SpatialAvgPool -> 4x4, resnet_encoders.py:152-158); out_img_stride lets `out` be a

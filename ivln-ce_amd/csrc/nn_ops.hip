@@ -1309,6 +1309,27 @@ int ivln_prev_action_embed_f32(const int64_t* prev_actions, const uint8_t* mask,
     return LAUNCH_OK();
 }
 
+__global__ void k_tour_memory(const float* __restrict__ mem, int64_t ld_mem, const float* __restrict__ h, int64_t ld_h,
+                              const uint8_t* __restrict__ mask, int N, int H, float* __restrict__ out1, int64_t ld1,
+                              float* __restrict__ out2, int64_t ld2) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * H) return;
+    const int n = i / H, c = i - n * H;
+    float v = mem[(int64_t)n * ld_mem + c];
+    if (h) v = fmaxf(v, h[(int64_t)n * ld_h + c]);
+    v = mask && !mask[n] ? 0.f : v;
+    out1[(int64_t)n * ld1 + c] = v;
+    if (out2) out2[(int64_t)n * ld2 + c] = v;
+}
+
+int ivln_tour_memory_f32(const float* mem, int64_t ld_mem, const float* h, int64_t ld_h, const uint8_t* mask, int N,
+                         int H, float* out1, int64_t ld1, float* out2, int64_t ld2, void* stream) {
+    if (N <= 0 || H <= 0 || !mem || !out1) return IVLN_E_INVALID;
+    hipLaunchKernelGGL(k_tour_memory, dim3((N * H + 255) / 256), dim3(256), 0, (hipStream_t)stream, mem, ld_mem, h, ld_h,
+                       mask, N, H, out1, ld1, out2, ld2);
+    return LAUNCH_OK();
+}
+
 int ivln_argmax_rows(const float* x, int rows, int C, int64_t* out, void* stream) {
     hipLaunchKernelGGL(k_argmax_rows, dim3((rows + 63) / 64), dim3(64), 0, (hipStream_t)stream, x, rows, C, out);
     return LAUNCH_OK();

@@ -266,8 +266,7 @@ class LatentCMANet(Net):
             # reference (updated under no_grad from a detached clone), so it is a constant input here too; the
             # first GRU reads its own previous output through it, hence the per-step loop for this one layer.
             rnn = self.state_encoder.rnn
-            tour_f = tour_masks.reshape(T, N, 1).to(torch.float32)
-            mem = rnn_states[:, 2]
+            tour_u8 = tour_masks.reshape(-1).to(torch.uint8).contiguous()
             mem_in = torch.empty((rows, H), dtype=torch.float32, device=dev)
             saves = None
             if save is not None:
@@ -275,16 +274,15 @@ class LatentCMANet(Net):
                 s_g1.update(r=saves[0], z=saves[1], n=saves[2], ghn=saves[3], T=T, N=N, x=state_in,
                             h0=rnn_states[:, 0], masks=ep_u8, out=state)
             for t in range(T):
-                sl = slice(t * N, (t + 1) * N)
-                mem = mem * tour_f[t]
-                mem_in[sl] = mem
-                state_in[sl, base:] = mem
-                h_in = rnn_states[:, 0] if t == 0 else state[(t - 1) * N: t * N]
+                sl, sp = slice(t * N, (t + 1) * N), slice((t - 1) * N, t * N)
+                # memory entering step t = tour mask * max(memory entering t-1, first GRU's state at t-1)
+                ops.tour_memory(rnn_states[:, 2] if t == 0 else mem_in[sp], None if t == 0 else state[sp], tour_u8[sl],
+                                mem_in[sl], state_in[sl, base:])
+                h_in = rnn_states[:, 0] if t == 0 else state[sp]
                 ops.gru_step(state_in[sl], None, h_in, ep_u8[sl], rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0,
                              rnn.bias_hh_l0, state[sl], rnn_out[:, 0] if t == T - 1 else None,
                              tuple(x[sl] for x in saves) if saves is not None else None)
-                mem = torch.max(mem, state[sl])
-            rnn_out[:, 2] = mem
+            ops.tour_memory(mem_in[(T - 1) * N:], state[(T - 1) * N:], None, rnn_out[:, 2])
         else:
             self.state_encoder(state_in, rnn_states[:, 0], ep_u8, state, rnn_out[:, 0], s_g1)
 

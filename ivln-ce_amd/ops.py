@@ -68,6 +68,7 @@ def _L():
         L.ivln_affine_f32.argtypes = [vp, vp, i64, f32, f32, vp]
         L.ivln_add_f32.argtypes = [vp, vp, vp, i64, i32, vp]
         L.ivln_copy2d_f32.argtypes = [vp, i64, vp, i64, i32, i32, i32, vp]
+        L.ivln_tour_memory_f32.argtypes = [vp, i64, vp, i64, vp, i32, i32, vp, i64, vp, i64, vp]
         _sigs_done = True
     return L
 
@@ -650,6 +651,19 @@ def copy_multi(pairs):
                 raise _lib.IvlnError("copy_multi needs contiguous tensors of identical shape and dtype")
             srcs[i], dsts[i], nb[i] = _p(s), _p(d), s.numel() * s.element_size()
         check(L.ivln_copy_multi(srcs, dsts, nb, n, stream_ptr()), "ivln_copy_multi")
+
+
+def tour_memory(mem, h, mask_u8, out1, out2=None):
+    """out = mask * max(mem, h) (h optional), row-strided (N,H) views; see ivln_tour_memory_f32."""
+    N, H = mem.shape
+    check(
+        _L().ivln_tour_memory_f32(_p(mem), mem.stride(0), _p(h) if h is not None else None, h.stride(0) if h is not None else 0,
+                                  _p(mask_u8) if mask_u8 is not None else None, N, H, _p(out1), out1.stride(0),
+                                  _p(out2) if out2 is not None else None, out2.stride(0) if out2 is not None else 0,
+                                  stream_ptr()),
+        "ivln_tour_memory_f32",
+    )
+    return out1
 
 
 def copy2d(src, dst, rows, cols, broadcast_rows=False):

@@ -49,3 +49,43 @@ for mode in ("eager", "graph"):
     el = time.perf_counter() - t0
     print(f"Latent-CMA B={B} {mode}: {1e3 * el / n:.3f} ms/step  {B * n / el:.0f} env-steps/s "
           f"(RGB ResNet-50 8.2 GFLOP + depth ResNet 0.7 GFLOP per env-step)")
+
+# ---- DAgger update from cached rgb / depth features (IterativeDaggerTrainer._update_agent), per memory mode ----
+if os.environ.get("IVLN_LATENT_UPDATE", "1") != "0":
+    from ivln_ce_amd.trainers import FlatAdam, update_agent
+
+    T, N = 64, 5  # IL.batch_size 5 of the latent_baselines configs, full-length trajectories
+    for mode in ("plain", "tour", "variant"):
+        c = get_config(opts=["MODEL.policy_name", "LatentCMAPolicy", "MODEL.INSTRUCTION_ENCODER.use_pretrained_embeddings",
+                             False, "MODEL.DEPTH_ENCODER.ddppo_checkpoint", "NONE", "MODEL.tour_memory", mode == "tour",
+                             "MODEL.tour_memory_variant", mode == "variant", "MODEL.memory_at_end", mode == "variant"])
+        torch.manual_seed(0)
+        p = baseline_registry.get_policy("LatentCMAPolicy").from_config(c, space, Discrete(4)).to(dev).train()
+        opt = FlatAdam(p, lr=2.5e-4)
+        g = torch.Generator().manual_seed(0)
+        TN = T * N
+        instr = torch.zeros(N, 200)
+        instr[:, :80] = torch.randint(2, 2504, (N, 80), generator=g).float()
+        o = {"rgb_features": torch.rand(TN, 2048, 4, 4, generator=g).to(dev),
+             "depth_features": torch.randn(TN, 128, 4, 4, generator=g).to(dev), "instruction": instr.repeat(T, 1).to(dev)}
+        prev = torch.randint(0, 4, (TN, 1), generator=g).to(dev)
+        ep = torch.ones(T, N, dtype=torch.uint8)
+        ep[0] = 0
+        ep = ep.view(-1, 1).to(dev)
+        tour = torch.ones(TN, 1, dtype=torch.uint8, device=dev)
+        tgt = torch.randint(0, 4, (T, N), generator=g).to(dev)
+        w = torch.ones(T, N, device=dev)
+        rnn = torch.zeros(N, p.net.num_recurrent_layers, 512, device=dev)
+
+        def upd():
+            return update_agent(p, opt, o, prev, ep, tgt, w, tour_not_done_masks=tour, rnn_states=rnn)
+
+        for _ in range(3):
+            upd()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            upd()
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / 10
+        print(f"Latent-CMA update [{mode}] T={T} N={N}: {1e3 * el:.2f} ms  {TN / el:.0f} rows/s")
