@@ -17,25 +17,28 @@ from ivln_ce_amd.config import get_config  # noqa: E402
 from ivln_ce_amd.registry import baseline_registry  # noqa: E402
 
 out = sys.argv[1]
+TRAINER = sys.argv[2] if len(sys.argv) > 2 else "dagger"  # or iterative_dagger: tour batches, MIN-reduced batch count
 rank, _, world = D.init()
 torch.manual_seed(0)
+np.random.seed(rank)
 cfg = get_config(opts=[
-    "TRAINER_NAME", "dagger", "NUM_ENVIRONMENTS", 2, "MODEL.policy_name", "MapCMAPolicy",
+    "TRAINER_NAME", TRAINER, "NUM_ENVIRONMENTS", 2, "MODEL.policy_name", "MapCMAPolicy",
     "MODEL.INSTRUCTION_ENCODER.use_pretrained_embeddings", False, "MODEL.DEPTH_ENCODER.ddppo_checkpoint", "NONE",
     "RL.POLICY.OBS_TRANSFORMS.ENABLED_TRANSFORMS", ["GTSemanticsIterativeMapper"],
-    "IL.DAGGER.iterations", 1, "IL.DAGGER.update_size", 4, "IL.DAGGER.p", 0.5, "IL.epochs", 1, "IL.batch_size", 2,
+    "IL.DAGGER.iterations", 1, "IL.DAGGER.update_size", 4 if TRAINER == "dagger" else 16, "IL.DAGGER.p", 0.5,
+    "IL.epochs", 1, "IL.batch_size", 2,
     "IL.DAGGER.lmdb_features_dir", os.path.join(out, f"traj{rank}"), "CHECKPOINT_FOLDER", os.path.join(out, "ckpt"),
     "RESULTS_DIR", os.path.join(out, "res"), "EVAL_CKPT_PATH_DIR", os.path.join(out, "ckpt"),
 ])
-tr = baseline_registry.get_trainer("dagger")(cfg)
+tr = baseline_registry.get_trainer(TRAINER)(cfg)
 log = tr.train()
 assert len(log) >= 1 and all(np.isfinite(l["loss"]) for l in log)
 # data-parallel replicas must hold identical parameters after the all-reduced update
 flat = tr.optimizer.flat.detach().clone()
 gathered = D.gather_objects(float(flat.double().sum().item()))
 assert max(gathered) - min(gathered) == 0.0, gathered
-res = baseline_registry.get_trainer("dagger")(cfg).eval()
+res = baseline_registry.get_trainer(TRAINER)(cfg).eval()
 if rank == 0:
-    print("dist smoke ok: world", world, "updates", len(log), "eval", {k: round(v, 4) for k, v in res[0].items() if k in ("episodes", "t_ndtw")})
+    print("dist smoke ok:", TRAINER, "world", world, "updates", len(log), "eval", {k: round(v, 4) for k, v in res[0].items() if k in ("episodes", "t_ndtw")})
 torch.distributed.barrier()
 torch.distributed.destroy_process_group()
