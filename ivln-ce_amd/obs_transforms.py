@@ -64,7 +64,17 @@ class Mapper(ObservationTransformer):
     def forward(self, observations: Dict[str, Tensor]) -> Dict[str, Tensor]:
         self.setup_mapping_module(observations)
         observations = self.update_maps_from_observations(observations)
+        observations = self.visualize_maps(observations)
         observations = self.delete_extra_information(observations)
+        return observations
+
+    def visualize_maps(self, observations):
+        """obs_transforms.py:105-113: colour frames of both maps for the video writer (host-side numpy)."""
+        if self.visualize:
+            from .visualize import visualize_ego_occupancy_map, visualize_ego_semantic_map
+
+            observations["occupancy_map_viz"] = visualize_ego_occupancy_map(observations["occupancy_map"])
+            observations["semantic_map_viz"] = visualize_ego_semantic_map(observations["semantic_map"])
         return observations
 
     def setup_mapping_module(self, observations: Dict[str, Tensor]):

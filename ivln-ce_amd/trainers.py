@@ -371,6 +371,8 @@ class BaseVLNCETrainer:
         cfg = self.config
         if not (bool(getattr(cfg.EVAL, "USE_HIP_GRAPH", True)) and not cfg.EVAL.SAMPLE and self.device.type == "cuda"):
             return False
+        if len(cfg.VIDEO_OPTION) > 0:  # the *_viz frames are host-side numpy (a D2H copy per step)
+            return False
         if not all(type(t).__name__.endswith("IterativeMapper") for t in self.obs_transforms):
             return False
         # MapCMA needs its mapper in the step; the map-free policies (Latent-CMA) are captured as they are
