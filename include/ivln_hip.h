@@ -136,6 +136,11 @@ typedef struct ivln_gemm_desc {
     /* optional (stride-1 3x3 / 7x7 convs): the weights pre-arranged by ivln_conv_pack_weights_f32; when set and
      * the direct kernel is chosen, its weight staging becomes a linear float4 copy.  A must still be given. */
     const float* A_packed;
+    /* 0 (default): workgroup ids are remapped so that each XCD (hardware places workgroup b on XCD b % 8, each
+     * with its own 4 MB L2) works on one contiguous range of output tiles - neighbouring tiles share operand rows /
+     * input halos through that L2 instead of re-fetching them from HBM.  1: identity mapping (A/B measurements).
+     * Results are identical either way. */
+    int no_xcd_remap;
 } ivln_gemm_desc;
 
 int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream);

@@ -43,12 +43,13 @@ __global__ __launch_bounds__(256) void k_conv_direct(const ivln_gemm_desc p, int
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int wm = wave / WN, wn = wave % WN;
-    const int bx = blockIdx.x;
+    const BlockId bid = xcd_block_id(p.no_xcd_remap);
+    const int bx = bid.x;
     const int tw = bx % tiles_w, th = (bx / tiles_w) % tiles_h, ig = bx / (tiles_w * tiles_h);
     const int img0 = ig * IMGS, ho0 = th * PTH, wo0 = tw * PTW;
-    const int m0 = blockIdx.y * BM;
+    const int m0 = bid.y * BM;
     const int nch = p.Cin / CI;
-    const int c_beg = blockIdx.z * chunks_per_split;
+    const int c_beg = bid.z * chunks_per_split;
     const int c_end = min(nch, c_beg + chunks_per_split);
     const int HW = p.Hin * p.Win;
 
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256) void k_conv_direct(const ivln_gemm_desc p, int
     float ra[NA], rp[NP];
     auto load_chunk = [&](int c) {
         if constexpr (PACKED) {
-            const float* wp = p.A_packed + ((int64_t)blockIdx.y * nch + c) * (KC * LDA);
+            const float* wp = p.A_packed + ((int64_t)bid.y * nch + c) * (KC * LDA);
 #pragma unroll
             for (int i = 0; i < NA / 4; ++i) {
                 const int f = t + i * 256;
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(256) void k_conv_direct(const ivln_gemm_desc p, int
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             if (pix_ok && m < p.M) {
-                if (p.splits > 1 || p.defer_epilogue) p.ws[((int64_t)blockIdx.z * p.M + m) * p.N + n] = acc[tn][r];
+                if (p.splits > 1 || p.defer_epilogue) p.ws[((int64_t)bid.z * p.M + m) * p.N + n] = acc[tn][r];
                 else epilogue_store(p, m, n, acc[tn][r]);
             }
         }
@@ -260,10 +261,11 @@ __global__ __launch_bounds__(256) void k_wgrad_direct(const ivln_gemm_desc p, in
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int wm = wave / WN, wn = wave % WN;
-    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    const BlockId bid = xcd_block_id(p.no_xcd_remap);
+    const int n0 = bid.x * BN, m0 = bid.y * BM;
     const int c_lo = n0 / KK;
     const int HW = p.Hin * p.Win;
-    const int t_beg = blockIdx.z * tiles_per_split;
+    const int t_beg = bid.z * tiles_per_split;
     const int t_end = min(ntiles, t_beg + tiles_per_split);
 
     float ra[NA], rp[NP];
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(256) void k_wgrad_direct(const ivln_gemm_desc p, in
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             if (m < p.M && n < p.N) {
-                if (p.splits > 1) p.ws[((int64_t)blockIdx.z * p.M + m) * p.N + n] = acc[tn][r];
+                if (p.splits > 1) p.ws[((int64_t)bid.z * p.M + m) * p.N + n] = acc[tn][r];
                 else epilogue_store(p, m, n, acc[tn][r]);
             }
         }

@@ -15,6 +15,28 @@ enum { DMODE_NCHW = 0, DMODE_DENSE = 1, DMODE_NCHW_UP2 = 2 };
 
 constexpr int BK = 16;
 
+// XCD-aware workgroup id (guide technique T1).  The dispatcher places workgroup b on XCD b % 8 and every XCD has
+// a private 4 MB L2, so with the identity mapping neighbouring tiles - which share operand rows, or the halo of a
+// convolution patch - sit on eight different L2s and each re-fetches the shared bytes from HBM.  The remap hands
+// XCD x the x-th contiguous eighth of the tile ids (bijective for any grid size); tile -> result is unchanged.
+struct BlockId {
+    int x, y, z;
+};
+__device__ __forceinline__ BlockId xcd_block_id(int disabled) {
+    BlockId b{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int nwg = gx * gy * (int)gridDim.z;
+    if (disabled || nwg < 16) return b;
+    const int orig = (b.z * gy + b.y) * gx + b.x;
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    const int t = id / gx;
+    b.x = id - t * gx;
+    b.z = t / gy;
+    b.y = t - b.z * gy;
+    return b;
+}
+
 __device__ __forceinline__ void epilogue_store(const ivln_gemm_desc& p, int m, int n, float v) {
     int64_t addr;
     if (p.dmode == DMODE_NCHW) {

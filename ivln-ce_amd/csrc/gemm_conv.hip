@@ -36,12 +36,13 @@ __global__ __launch_bounds__(256) void k_gemm(const ivln_gemm_desc p) {
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const BlockId bid = xcd_block_id(p.no_xcd_remap);
+    const int m0 = bid.y * BM, n0 = bid.x * BN;
 
     // K range of this split
     const int nk = (p.K + BK - 1) / BK;
     const int tps = (nk + p.splits - 1) / p.splits;
-    const int kbeg = blockIdx.z * tps * BK;
+    const int kbeg = bid.z * tps * BK;
     const int kend = min(p.K, kbeg + tps * BK);
 
     // ---- per-thread load coordinates ----
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(256) void k_gemm(const ivln_gemm_desc p) {
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
             epilogue_tile(p, m0 + (wm * TM + tm) * 32, n0 + (wn * TN + tn) * 32 + (lane & 31), lane >> 5, acc[tm][tn],
-                          blockIdx.z);
+                          bid.z);
 }
 
 __global__ __launch_bounds__(256) void k_splitk_epilogue(const ivln_gemm_desc p) {
@@ -325,6 +326,8 @@ extern "C" int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream) {
         return IVLN_E_INVALID;
     ivln_gemm_desc d = *desc;
     hipStream_t s = (hipStream_t)stream;
+    static const bool no_xcd_env = getenv("IVLN_NO_XCD_REMAP") != nullptr;  // A/B switch
+    if (no_xcd_env) d.no_xcd_remap = 1;
     if (d.HoWo <= 0) d.HoWo = 1;
     if (d.dil <= 0) d.dil = 1;
     if (d.Ctot <= 0) d.Ctot = d.M;

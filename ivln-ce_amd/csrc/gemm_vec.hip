@@ -35,10 +35,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_vec(const ivln_gemm_desc p) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const BlockId bid = xcd_block_id(p.no_xcd_remap);
+    const int m0 = bid.y * BM, n0 = bid.x * BN;
     const int nk = (p.K + BKV - 1) / BKV;
     const int tps = (nk + p.splits - 1) / p.splits;
-    const int kbeg = blockIdx.z * tps * BKV;
+    const int kbeg = bid.z * tps * BKV;
     const int kend = min(p.K, kbeg + tps * BKV);
 
     // ---- per-thread staging coordinates (tile-invariant) ----
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_vec(const ivln_gemm_desc p) {
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
-            epilogue_tile(p, m0 + (wm * TM + tm) * 32, n0 + (wn * TN + tn) * 32 + l31, half, acc[tm][tn], blockIdx.z);
+            epilogue_tile(p, m0 + (wm * TM + tm) * 32, n0 + (wn * TN + tn) * 32 + l31, half, acc[tm][tn], bid.z);
 }
 
 template <int WM, int WN, int TM, int TN>

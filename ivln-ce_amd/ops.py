@@ -33,6 +33,7 @@ class GemmDesc(C.Structure):
         ("defer_epilogue", i32), ("splits_used", C.POINTER(i32)),
         ("tile_override", i32),
         ("A_packed", vp),
+        ("no_xcd_remap", i32),
     ]
 
 
@@ -117,12 +118,15 @@ def splitk_ws(device, floats=8 << 20, slot=0):
 
 
 TILE_OVERRIDE = 0  # tuning/tests: force a block tile (1..5), see ivln_gemm_desc.tile_override
+NO_XCD_REMAP = False  # tests / A-B: identity workgroup -> tile mapping (ivln_gemm_desc.no_xcd_remap)
 PACK_WEIGHTS = True  # A/B switch: pre-arranged weights for the direct conv kernel
 
 
 def gemm(desc: GemmDesc):
     if TILE_OVERRIDE:
         desc.tile_override = TILE_OVERRIDE
+    if NO_XCD_REMAP:
+        desc.no_xcd_remap = 1
     check(_L().ivln_gemm_f32(C.byref(desc), stream_ptr()), "ivln_gemm_f32")
 
 

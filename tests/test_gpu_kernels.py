@@ -554,3 +554,37 @@ def test_action_head_linear_argmax_one_launch(rows):
     # first maximum wins on exact ties (torch.argmax / distribution.mode())
     xt = torch.zeros(2, 512)
     assert ops.linear_argmax(xt.to(DEV), w.to(DEV), torch.zeros(4).to(DEV)).flatten().tolist() == [0, 0]
+
+
+@pytest.mark.parametrize("N,Cin,H,W,Cout,k,s,p,override", [
+    (5, 32, 32, 32, 64, 3, 1, 1, 6),     # direct conv, 40 x 1 workgroups
+    (3, 14, 64, 64, 32, 7, 1, 3, 6),     # direct 7x7, grid not a multiple of 8
+    (7, 96, 20, 12, 72, 1, 1, 0, 7),     # vector-load GEMM, ragged grid (27 x 2 tiles)
+    (4, 1024, 4, 4, 128, 3, 1, 1, 1),    # scalar-gather GEMM with split-K (z dimension in the remap)
+    (3, 64, 33, 17, 48, 3, 2, 1, 0),     # strided conv, default dispatch
+])
+def test_xcd_aware_workgroup_remap_is_a_pure_permutation(N, Cin, H, W, Cout, k, s, p, override):
+    """ivln_gemm_desc.no_xcd_remap: handing each XCD a contiguous range of tiles only permutes which workgroup
+    computes which tile - outputs (and split-K slab order) are bit-identical to the identity mapping, for grids
+    whose size is not a multiple of the 8 XCDs too."""
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(N + Cin + Cout + k)
+    x = torch.randn(N, Cin, H, W, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).to(DEV)
+    sh = torch.randn(Cout, generator=g).to(DEV)
+    out = {}
+    try:
+        ops.TILE_OVERRIDE = override
+        for flag in (False, True):
+            ops.NO_XCD_REMAP = flag
+            out[flag] = ops.conv2d(x, w, stride=s, pad=p, shift=sh, relu=True).clone()
+            gw = ops.conv2d_bwd_weight(out[flag], x, k, k, s, p) if (s == 1 and override in (0, 6)) else None
+            out[(flag, "dw")] = gw.clone() if gw is not None else None
+    finally:
+        ops.TILE_OVERRIDE = 0
+        ops.NO_XCD_REMAP = False
+    assert torch.equal(out[False], out[True])
+    if out[(False, "dw")] is not None:
+        assert torch.equal(out[(False, "dw")], out[(True, "dw")])
+    _close(out[False], F.relu(F.conv2d(x.cpu(), w.cpu(), sh.cpu(), stride=s, padding=p)), 3e-5)
