@@ -249,9 +249,22 @@ class MapCMANet(Net):
             mp, mkv = st["map"]
             dep, dkv = self._stash_dep
         elif side is None:
-            txt, lengths, tk = _txt_branch(s_txt)
+            from . import train as _train
+
+            overlap = save is not None and _train.OVERLAP_INSTRUCTION and not torch.cuda.is_current_stream_capturing()
+            if overlap:  # training pass: the instruction bi-LSTM runs beside the map CNN (train.py)
+                cur, st = torch.cuda.current_stream(), _train.side_stream(dev)
+                st.wait_stream(cur)
+                _train.share_with_stream(observations.get("instruction"), st)
+                with torch.cuda.stream(st):
+                    txt, lengths, tk = _txt_branch(s_txt)
+            else:
+                txt, lengths, tk = _txt_branch(s_txt)
             dep, dkv = _dep_branch()
             mp, mkv = _map_branch(s_map)
+            if overlap:
+                cur.wait_stream(st)
+                _train.share_with_stream((txt, lengths, tk, s_txt), cur)
         else:
             # three independent, latency-bound branches on forked streams (graphed.py): depth ResNet
             # (critical path, submitted first) || instruction bi-LSTM || (mapper ->) map CNN

@@ -8,11 +8,39 @@ So the reference's `loss.backward()` (ivlnce_baselines/common/base_il_trainer.py
 this policy unchanged, and `update_agent` below is the all-HIP version of `_update_agent`
 (:173-219) with fused inflection-weighted CE, flat-bucket Adam and one RCCL all-reduce.
 """
+import os
 from typing import Dict, List
 
 import torch
 
 from . import ops
+
+
+# The instruction bi-LSTM (forward 0.3 ms, BPTT 0.6 ms at T*N = 512 rows) is a latency-bound recurrence that
+# leaves the chip idle, and it is independent of the map CNN's convolutions (3.5 / 5.5 ms, MFMA-bound): in a
+# training pass it runs on a side stream next to them.  A/B switch for measurements and tests.
+OVERLAP_INSTRUCTION = not bool(os.environ.get("IVLN_NO_TRAIN_OVERLAP"))
+_side = {}
+
+
+def side_stream(device):
+    key = str(device)
+    if key not in _side:
+        _side[key] = torch.cuda.Stream(device)
+    return _side[key]
+
+
+def share_with_stream(obj, stream):
+    """Tensors allocated on one stream and read on another: tell the caching allocator (record_stream)."""
+    if torch.is_tensor(obj):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            share_with_stream(v, stream)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            share_with_stream(v, stream)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -169,6 +197,14 @@ def net_backward(net, S: Dict, d_feats: torch.Tensor) -> Dict:
     ops.attn_bwd(d_text, S["a_txt"], S["q1"], tk.view(rows, h2, L), txt, scale, dq1, d_tk, d_txt)
     d_txt = _conv1d_backward(net.text_k, d_tk.view(rows, h2, 1, L), txt.view(rows, -1, 1, L),
                              d_txt.view(rows, -1, 1, L), G).view(rows, -1, L)
+    G_txt, side, main = None, None, torch.cuda.current_stream()
+    if OVERLAP_INSTRUCTION and not torch.cuda.is_current_stream_capturing():
+        # d(instruction features) is final here: the bi-LSTM BPTT runs beside the GRU / map-CNN backward below
+        side, G_txt = side_stream(dev), {}
+        side.wait_stream(main)
+        share_with_stream((d_txt, S["txt"]), side)
+        with torch.cuda.stream(side):
+            instruction_backward(net.instruction_encoder, S["txt"], d_txt, rows, L, G_txt)
     state = x2[:, :H]
     G[net.state_q.weight] = ops.linear_bwd_weight(dq1, state)
     G[net.state_q.bias] = ops.colsum(dq1)
@@ -225,7 +261,12 @@ def net_backward(net, S: Dict, d_feats: torch.Tensor) -> Dict:
             if i > 0:
                 d = ops.conv2d(dy, ops.weight_flip_transpose(conv.weight), pad=3, weight_is_temp=True)
 
-    instruction_backward(net.instruction_encoder, S["txt"], d_txt, rows, L, G)
+    if G_txt is None:
+        instruction_backward(net.instruction_encoder, S["txt"], d_txt, rows, L, G)
+    else:
+        main.wait_stream(side)
+        share_with_stream(G_txt, main)
+        G.update(G_txt)
     return G
 
 
