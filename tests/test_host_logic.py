@@ -328,3 +328,41 @@ def test_map_visualization_frames():
     assert (s[0, :25, :25] == LABEL_COLOURS[7]).all() and (s[1, 176:, 176:] == LABEL_COLOURS[12]).all()
     assert (s[1, :90, :90] == 0).all()
     assert tuple(LABEL_COLOURS[1]) == (106, 137, 204) and len(LABEL_COLOURS) == 13
+
+
+def test_greedy_bin_packing_properties():
+    """to_constant_bin_number (restated `binpacking` function): every key lands in exactly one bin, the bin count
+    is constant, and the greedy rule bounds the spread of the bin loads by the largest item."""
+    import numpy as np
+
+    from ivln_ce_amd.tour_batches import TourSampler, to_constant_bin_number
+
+    rs = np.random.RandomState(3)
+    for n_bins in (1, 2, 5, 8):
+        w = {f"t{i}": int(v) for i, v in enumerate(rs.randint(1, 40, size=rs.randint(n_bins, 60)))}
+        bins = to_constant_bin_number(w, n_bins)
+        assert len(bins) == n_bins
+        keys = [k for b in bins for k in b]
+        assert sorted(keys) == sorted(w) and all(b[k] == w[k] for b in bins for k in b)
+        loads = [sum(b.values()) for b in bins]
+        assert max(loads) - min(loads) <= max(w.values())
+    # the sampler never repeats or invents a record, whatever the tour sizes
+    table, nxt = {}, 1
+    for t, n in enumerate(rs.randint(1, 9, size=11)):
+        table[f"tour{t}"] = list(range(nxt, nxt + int(n)))
+        nxt += int(n)
+    np.random.seed(1)
+    s = TourSampler({k: list(v) for k, v in table.items()}, batch_size=4, shuffle=True, drop_last=False)
+    flat = [i for b in s.batched_idxs for i in b]
+    assert sorted(flat) == list(range(1, nxt)) and len(s.get_tour_done_idxs()) == len(table)
+    # row r of consecutive batches walks bin r in order: each tour's episodes stay contiguous within their row
+    rows = [[b[r] for b in s.batched_idxs if len(b) == 4] for r in range(4)]  # full batches: position r = bin r
+    tour_of = {i: t for t, idxs in table.items() for i in idxs}
+    for row in rows:
+        seen, last = set(), None
+        for i in row:
+            t = tour_of[i]
+            if t != last:
+                assert t not in seen, "a tour was split inside its row"
+                seen.add(t)
+                last = t
