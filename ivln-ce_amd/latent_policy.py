@@ -228,7 +228,23 @@ class LatentCMANet(Net):
         prev_actions = prev_actions.reshape(-1).long().contiguous()
 
         s_txt = {} if save is not None else None
-        txt, lengths = self.instruction_encoder(observations, s_txt)  # (rows, 256, L), zero beyond each length
+        from . import train as _train
+
+        # training pass: the instruction bi-LSTM (latency-bound) runs on a side stream beside the encoders' feature
+        # plumbing and the 2112-channel k/v projection below (train.OVERLAP_INSTRUCTION)
+        overlap = (save is not None and _train.OVERLAP_INSTRUCTION and not mc.ablate_instruction
+                   and not torch.cuda.is_current_stream_capturing())
+        if overlap:
+            cur, st = torch.cuda.current_stream(), _train.side_stream(dev)
+            st.wait_stream(cur)
+            _train.share_with_stream(observations.get("instruction"), st)
+            with torch.cuda.stream(st):
+                txt, lengths = self.instruction_encoder(observations, s_txt)
+                tk = ops.conv2d(txt.view(txt.shape[0], -1, 1, txt.shape[2]), self.text_k.weight.view(h2, -1, 1, 1),
+                                shift=self.text_k.bias, splitk=False)
+        else:
+            txt, lengths = self.instruction_encoder(observations, s_txt)  # (rows, 256, L), zero beyond each length
+            tk = None
         dep = self.depth_encoder(observations)                         # (rows, 192, 4, 4)
         rgb = self.rgb_encoder(observations)                           # (rows, 2112, 4, 4)
         if mc.ablate_instruction:
@@ -286,13 +302,19 @@ class LatentCMANet(Net):
         else:
             self.state_encoder(state_in, rnn_states[:, 0], ep_u8, state, rnn_out[:, 0], s_g1)
 
+        # the key/value projections of the visual features do not depend on the recurrent state: issued before
+        # the join with the instruction branch
+        rkv = ops.conv2d(rgb.view(rows, Cr, 1, P), self.rgb_kv.weight.view(-1, Cr, 1, 1), shift=self.rgb_kv.bias).view(rows, -1, P)
+        dkv = ops.conv2d(dep.view(rows, Cd, 1, P), self.depth_kv.weight.view(-1, Cd, 1, 1), shift=self.depth_kv.bias).view(rows, -1, P)
+        if overlap:
+            cur.wait_stream(st)
+            _train.share_with_stream((txt, lengths, tk, s_txt), cur)
         q1 = ops.linear(state, self.state_q.weight, self.state_q.bias)
-        tk = ops.conv2d(txt.view(rows, -1, 1, L), self.text_k.weight.view(h2, -1, 1, 1), shift=self.text_k.bias, splitk=False)
+        if tk is None:
+            tk = ops.conv2d(txt.view(rows, -1, 1, L), self.text_k.weight.view(h2, -1, 1, 1), shift=self.text_k.bias, splitk=False)
         text = x2[:, o_txt:o_txt + 256]
         a_txt = torch.empty((rows, L), dtype=torch.float32, device=dev) if save is not None else None
         ops.attn(q1, tk.view(rows, h2, L), txt, lengths, self._scale_f, text, a_txt)
-        rkv = ops.conv2d(rgb.view(rows, Cr, 1, P), self.rgb_kv.weight.view(-1, Cr, 1, 1), shift=self.rgb_kv.bias).view(rows, -1, P)
-        dkv = ops.conv2d(dep.view(rows, Cd, 1, P), self.depth_kv.weight.view(-1, Cd, 1, 1), shift=self.depth_kv.bias).view(rows, -1, P)
         q2 = ops.linear(text, self.text_q.weight, self.text_q.bias)
         a_rgb = a_dep = None
         if save is None and P <= 32:
@@ -322,6 +344,7 @@ class LatentCMANet(Net):
     def backward_hip(self, S, d_feats):
         """Gradients of every trainable parameter given d(loss)/d(features): the hand-written HIP backward of
         `forward_hip` (the frozen RGB / depth ResNets are not traversed; their learned spatial embeddings are)."""
+        from . import train as _train
         from .train import _conv1d_backward, _gru_backward, instruction_backward
 
         G = {}
@@ -372,6 +395,13 @@ class LatentCMANet(Net):
         ops.attn_bwd(d_text, S["a_txt"], S["q1"], tk.view(rows, h2, L), txt, scale, dq1, d_tk, d_txt)
         d_txt = _conv1d_backward(self.text_k, d_tk.view(rows, h2, 1, L), txt.view(rows, -1, 1, L),
                                  d_txt.view(rows, -1, 1, L), G).view(rows, -1, L)
+        G_txt, side, main = None, None, torch.cuda.current_stream()
+        if _train.OVERLAP_INSTRUCTION and not torch.cuda.is_current_stream_capturing():
+            side, G_txt = _train.side_stream(dev), {}
+            side.wait_stream(main)
+            _train.share_with_stream((d_txt, S["txt"]), side)
+            with torch.cuda.stream(side):
+                instruction_backward(self.instruction_encoder, S["txt"], d_txt, rows, L, G_txt)
         state = x2[:, :H]
         G[self.state_q.weight] = ops.linear_bwd_weight(dq1, state)
         G[self.state_q.bias] = ops.colsum(dq1)
@@ -413,7 +443,12 @@ class LatentCMANet(Net):
                                  d_dep.view(rows, Cd, 1, P), G)
         G[se_d.weight] = ops.colsum(d_dep.view(rows, -1)[:, (Cd - Ed) * P:]).view_as(se_d.weight)
 
-        instruction_backward(self.instruction_encoder, S["txt"], d_txt, rows, L, G)
+        if G_txt is None:
+            instruction_backward(self.instruction_encoder, S["txt"], d_txt, rows, L, G)
+        else:
+            main.wait_stream(side)
+            _train.share_with_stream(G_txt, main)
+            G.update(G_txt)
         return G
 
 
