@@ -304,7 +304,7 @@ class BaseVLNCETrainer:
         return observation_space, action_space
 
     def _initialize_policy(self, config, load_from_ckpt, observation_space, action_space):
-        from . import latent_policy as _latent  # noqa: F401  (registers LatentCMAPolicy, inference only)
+        from . import latent_policy as _latent  # noqa: F401  (registers LatentCMAPolicy)
         from . import policy as _policy  # noqa: F401  (registers MapCMAPolicy)
 
         policy_cls = baseline_registry.get_policy(self.config.MODEL.policy_name)
