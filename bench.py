@@ -186,10 +186,15 @@ def bench_update(policy, dev, world, barrier, T=64, N=8, iters=5, warm=2):
     TN = T * N
     instr = torch.zeros(N, 200)
     instr[:, :80] = torch.randint(2, 2504, (N, 80), generator=g).float()
+    from ivln_ce_amd.utils import trim_instruction_padding
+
+    # the trainer's loader drops the all-padding tail of the token batch on the host (trainers.PrefetchLoader):
+    # like the reference's packed LSTM, the update only ever sees the batch's longest instruction (80 of 200)
+    host = trim_instruction_padding({"instruction": instr.repeat(T, 1)})
     obs = {"depth_features": torch.randn(TN, 128, 4, 4, generator=g).to(dev),
            "occupancy_map": (torch.rand(TN, 64, 64, generator=g) < 0.3).float().to(dev),
            "semantic_map": torch.randint(0, 13, (TN, 64, 64), generator=g).float().to(dev),
-           "instruction": instr.repeat(T, 1).to(dev)}
+           "instruction": host["instruction"].to(dev)}
     prev = torch.randint(0, 4, (TN, 1), generator=g).to(dev)
     nd = torch.ones(T, N, dtype=torch.uint8)
     nd[0] = 0

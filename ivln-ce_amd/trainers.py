@@ -31,7 +31,8 @@ from .envs import construct_envs
 from .obs_transforms import apply_obs_transforms_batch, apply_obs_transforms_obs_space, get_active_obs_transforms
 from .registry import baseline_registry
 from .tour_ndtw import compute_tour_ndtw
-from .utils import add_batched_data_to_observations, batch_obs, batch_to, extract_instruction_tokens
+from .utils import (add_batched_data_to_observations, batch_obs, batch_to, extract_instruction_tokens,
+                    trim_instruction_padding)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -558,6 +559,7 @@ class PrefetchLoader:
         def work():
             try:
                 for batch in self.loader:
+                    batch = (trim_instruction_padding(batch[0]),) + tuple(batch[1:])  # host side, before the H2D copy
                     parts = tuple(pin(b) for b in batch)
                     if len(parts) == 5:  # episodic collate: no tour masks (slot 3 of the 6-tuple the loops unpack)
                         parts = parts[:3] + (None,) + parts[3:]

@@ -60,6 +60,24 @@ def batch_to(batch: Tuple, device: torch.device = None, non_blocking: bool = Tru
     )
 
 
+def trim_instruction_padding(observations: Dict, key: str = "instruction", multiple: int = 8) -> Dict:
+    """Drop the all-padding tail of a HOST-side token batch (rows, 200) before it is copied to the GPU: the
+    reference's packed bi-LSTM / pad_packed_sequence only ever produces the batch's longest instruction
+    (instruction_encoder.py:70-92), so every consumer (W_ih GEMM, text_k, the attention axis) sees Lmax columns,
+    not 200.  Lmax is rounded up to `multiple` (16-byte loads along the token axis); columns beyond a row's own
+    length stay masked exactly as before.  A device tensor is returned unchanged (finding Lmax would be a sync)."""
+    t = observations.get(key)
+    if t is None or not torch.is_tensor(t) or t.is_cuda or t.dim() != 2:
+        return observations
+    L = t.shape[1]
+    longest = int((t != 0).sum(dim=1).max().item()) if t.shape[0] > 0 else L
+    keep = min(L, max(multiple, -(-longest // multiple) * multiple))
+    if keep < L:
+        observations = dict(observations)
+        observations[key] = t[:, :keep].contiguous()
+    return observations
+
+
 def add_batched_data_to_observations(observations: List[Dict], batched_data, batched_data_key: str):
     if batched_data is not None:
         for i in range(len(observations)):

@@ -281,3 +281,40 @@ def test_iterative_eval_graph_replay_matches_eager(tmp_path, reset):
         out[mode] = res
     assert out[True] == out[False], f"graph {out[True]} vs eager {out[False]}"
     assert out[True]["episodes"] > 0 and "tndtw" in out[True]
+
+
+def test_update_with_host_trimmed_instruction_padding_is_the_same_update():
+    """trainers.PrefetchLoader drops the all-padding tail of the token batch on the host
+    (utils.trim_instruction_padding): the update must not notice - same loss, same gradients as with the full
+    200-column batch (the dropped columns are masked attention positions and zero LSTM steps)."""
+    from test_gpu_policy import make_policy
+
+    from ivln_ce_amd.aux_losses import AuxLosses
+    from ivln_ce_amd.trainers import FlatAdam, update_agent
+    from ivln_ce_amd.utils import trim_instruction_padding
+
+    g = np.load(os.path.join(G, "policy_update.npz"))
+    host = {"instruction": torch.from_numpy(g["instruction"])}
+    trimmed = trim_instruction_padding(host)["instruction"]
+    longest = int((host["instruction"] != 0).sum(1).max())
+    assert trimmed.shape[1] == min(200, -(-longest // 8) * 8) and torch.equal(trimmed, host["instruction"][:, :trimmed.shape[1]])
+    short = {"instruction": host["instruction"].clone()}
+    short["instruction"][:, 40:] = 0
+    assert trim_instruction_padding(short)["instruction"].shape[1] == 40
+    assert trim_instruction_padding({"instruction": host["instruction"].to(DEV)})["instruction"].shape[1] == 200  # device: untouched
+    res = {}
+    for name, instr in (("full", short["instruction"]), ("trim", trim_instruction_padding(short)["instruction"])):
+        pol = make_policy(use_pm=True, train=True)
+        obs, prev, nd, tgt, w = _batch(g)
+        obs["instruction"] = instr.to(DEV)
+        opt = FlatAdam(pol, lr=2.5e-4)
+        AuxLosses.activate()
+        try:
+            out = update_agent(pol, opt, obs, prev, nd, tgt, w, hidden_size=512, step_grad=False)
+        finally:
+            AuxLosses.deactivate()
+        res[name] = (out, {k: p.grad.detach().clone() for k, p in pol.named_parameters() if p.grad is not None})
+    assert abs(res["full"][0][0] - res["trim"][0][0]) < 1e-6
+    for k, gfull in res["full"][1].items():
+        gt = res["trim"][1][k]
+        assert torch.allclose(gfull, gt, rtol=1e-4, atol=1e-7), f"{k}: {float((gfull - gt).abs().max()):.3e}"

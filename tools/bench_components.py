@@ -90,7 +90,12 @@ def bench_update(T=64, N=8):
     obs = {"depth_features": torch.randn(TN, 128, 4, 4, generator=g).to(DEV),
            "occupancy_map": (torch.rand(TN, 64, 64, generator=g) < 0.3).float().to(DEV),
            "semantic_map": torch.randint(0, 13, (TN, 64, 64), generator=g).float().to(DEV),
-           "instruction": instr.repeat(T, 1).to(DEV)}
+           "instruction": instr.repeat(T, 1)}
+    if not os.environ.get("IVLN_NO_TRIM"):
+        from ivln_ce_amd.utils import trim_instruction_padding
+
+        obs = trim_instruction_padding(obs)  # what trainers.PrefetchLoader does on the host
+    obs["instruction"] = obs["instruction"].to(DEV)
     prev = torch.randint(0, 4, (TN, 1), generator=g).to(DEV)
     nd = torch.ones(T, N, dtype=torch.uint8)
     nd[0] = 0

@@ -66,8 +66,11 @@ if os.environ.get("IVLN_LATENT_UPDATE", "1") != "0":
         TN = T * N
         instr = torch.zeros(N, 200)
         instr[:, :80] = torch.randint(2, 2504, (N, 80), generator=g).float()
+        from ivln_ce_amd.utils import trim_instruction_padding
+
         o = {"rgb_features": torch.rand(TN, 2048, 4, 4, generator=g).to(dev),
-             "depth_features": torch.randn(TN, 128, 4, 4, generator=g).to(dev), "instruction": instr.repeat(T, 1).to(dev)}
+             "depth_features": torch.randn(TN, 128, 4, 4, generator=g).to(dev),
+             "instruction": trim_instruction_padding({"instruction": instr.repeat(T, 1)})["instruction"].to(dev)}
         prev = torch.randint(0, 4, (TN, 1), generator=g).to(dev)
         ep = torch.ones(T, N, dtype=torch.uint8)
         ep[0] = 0
