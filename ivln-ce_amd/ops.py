@@ -4,6 +4,7 @@ Every function takes/returns torch GPU tensors, launches on torch's current stre
 no arithmetic itself; tensor allocation and views are the only torch operations used.
 """
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -118,6 +119,7 @@ def splitk_ws(device, floats=8 << 20, slot=0):
 
 
 TILE_OVERRIDE = 0  # tuning/tests: force a block tile (1..5), see ivln_gemm_desc.tile_override
+LINEAR_BWD_SPLIT = not bool(os.environ.get("IVLN_LINEAR_BWD_NO_SPLIT"))  # A/B: split-K in Linear dX / accumulating dW
 NO_XCD_REMAP = False  # tests / A-B: identity workgroup -> tile mapping (ivln_gemm_desc.no_xcd_remap)
 PACK_WEIGHTS = True  # A/B switch: pre-arranged weights for the direct conv kernel
 
@@ -916,7 +918,12 @@ def linear_bwd_input(dy, w, out=None, accumulate=False):
     d.sDm, d.sDn = 1, out.stride(0)
     d.HoWo = 1
     _epilogue(d, None, None, None, False, accumulate)
-    d.splits = 1
+    # rows x I is a small output (512 x 416 = 56 tiles) under a deep K (up to 3072 outputs): split-K fills the chip
+    if LINEAR_BWD_SPLIT:
+        ws = splitk_ws(dy.device)
+        d.ws, d.ws_floats, d.splits = dptr(ws), ws.numel(), 0
+    else:
+        d.splits = 1
     gemm(d)
     return out
 
@@ -935,11 +942,11 @@ def linear_bwd_weight(dy, x, out=None, accumulate=False):
     d.sDm, d.sDn = I, 1
     d.HoWo = 1
     _epilogue(d, None, None, None, False, accumulate)
-    if accumulate:
-        d.splits = 1
-    else:
-        ws = splitk_ws(dy.device)
+    if LINEAR_BWD_SPLIT or not accumulate:
+        ws = splitk_ws(dy.device)  # the fixed-order slab epilogue adds into `out` when accumulating
         d.ws, d.ws_floats, d.splits = dptr(ws), ws.numel(), 0
+    else:
+        d.splits = 1
     gemm(d)
     return out
 
