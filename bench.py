@@ -209,10 +209,18 @@ def bench_update(policy, dev, world, barrier, T=64, N=8, iters=5, warm=2):
         update_agent(policy, opt, obs, prev, nd, tgt, w, world=world)
     barrier()
     el = time.perf_counter() - t0
-    # MFMA kernel family of one update (instrumented pass, outside the timed region)
-    with GemmTimer() as gt:
-        update_agent(policy, opt, obs, prev, nd, tgt, w, world=world)
-        ms = gt.total_ms()
+    # MFMA kernel family of one update (instrumented pass, outside the timed region).  The event pairs sum
+    # per-launch elapsed times, so the pass runs everything on one stream: with the instruction branch on its
+    # side stream (the timed configuration) concurrent launches would be counted twice over the same wall time.
+    from ivln_ce_amd import train as _train
+
+    overlap, _train.OVERLAP_INSTRUCTION = _train.OVERLAP_INSTRUCTION, False
+    try:
+        with GemmTimer() as gt:
+            update_agent(policy, opt, obs, prev, nd, tgt, w, world=world)
+            ms = gt.total_ms()
+    finally:
+        _train.OVERLAP_INSTRUCTION = overlap
     ach = (gt.flops / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
     roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "flops_per_update": int(gt.flops),
