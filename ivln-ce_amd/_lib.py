@@ -46,8 +46,6 @@ def lib():
             )
         L = C.CDLL(_SO)
         _sig(L)
-        for name, fn in list(vars(L).items()):
-            pass
         _LIB = L
     return _LIB
 

@@ -1,42 +1,65 @@
-"""`AuxLosses` singleton with the reference's interface (ivlnce_baselines/common/aux_losses.py:4-44)."""
+"""Auxiliary-loss registry of the update step.
+
+Interface contract (what policy.py / latent_policy.py / trainers.py call, same method names as the
+reference's module-level `AuxLosses` object, ivlnce_baselines/common/aux_losses.py:4-44):
+`activate()`, `deactivate()`, `is_active()`, `clear()`, `register_loss(name, loss, alpha)`,
+`get_loss(name)`, `reduce(mask)`.  The only registered term on this hot path is the progress monitor's
+(TN,TN) squared-error matrix (quirk Q7, `train.progress_monitor_loss`), whose masked mean times `alpha`
+joins the action loss in `trainers.update_agent`.
+"""
+from typing import Dict, NamedTuple
+
 import torch
 
 
-class _AuxLosses:
-    def __init__(self) -> None:
-        self._losses = {}
-        self._loss_alphas = {}
-        self._is_active = False
+class _Term(NamedTuple):
+    values: torch.Tensor  # per-element loss, any shape `mask` broadcasts against under masked_select
+    alpha: float
 
-    def clear(self):
-        self._losses.clear()
-        self._loss_alphas.clear()
 
-    def register_loss(self, name, loss, alpha=1.0):
-        assert self.is_active()
-        assert name not in self._losses
-        self._losses[name] = loss
-        self._loss_alphas[name] = alpha
+class AuxLossRegistry:
+    """Process-wide registry: terms are only accepted between `activate()` and `deactivate()` (the trainers
+    switch it on around the updates, never during rollouts) and live until the next `clear()`."""
 
-    def get_loss(self, name):
-        return self._losses[name]
+    def __init__(self):
+        self._terms: Dict[str, _Term] = {}
+        self._enabled = False
 
-    def reduce(self, mask):
-        assert self.is_active()
-        total = 0.0
-        for k in self._losses.keys():
-            k_loss = torch.masked_select(self._losses[k], mask).mean()
-            total = total + self._loss_alphas[k] * k_loss
-        return total
-
-    def is_active(self):
-        return self._is_active
-
-    def activate(self) -> None:
-        self._is_active = True
+    # -- switch ---------------------------------------------------------------------------------
+    def activate(self):
+        self._enabled = True
 
     def deactivate(self):
-        self._is_active = False
+        self._enabled = False
+
+    def is_active(self) -> bool:
+        return self._enabled
+
+    # -- terms ----------------------------------------------------------------------------------
+    def clear(self):
+        self._terms = {}
+
+    def __len__(self):
+        return len(self._terms)
+
+    def register_loss(self, name: str, loss: torch.Tensor, alpha: float = 1.0):
+        if not self._enabled:
+            raise AssertionError("AuxLosses.register_loss while inactive")
+        if name in self._terms:
+            raise AssertionError(f"aux loss `{name}` registered twice before clear()")
+        self._terms[name] = _Term(loss, float(alpha))
+
+    def get_loss(self, name: str) -> torch.Tensor:
+        return self._terms[name].values
+
+    def reduce(self, mask: torch.Tensor):
+        """sum_k alpha_k * mean(values_k[mask]); 0.0 when nothing is registered."""
+        if not self._enabled:
+            raise AssertionError("AuxLosses.reduce while inactive")
+        total = 0.0
+        for term in self._terms.values():
+            total = total + term.alpha * torch.masked_select(term.values, mask).mean()
+        return total
 
 
-AuxLosses = _AuxLosses()
+AuxLosses = AuxLossRegistry()

@@ -140,6 +140,7 @@ def _experiment_defaults() -> Config:
     _C.CMD_TRAILING_OPTS = []
     _C.TRAINER_NAME = "dagger"
     _C.ENV_NAME = "VLNCEDaggerEnv"
+    _C.ENV_BACKEND = "synthetic"  # envs.construct_envs: the only vector env this package's trainers drive
     _C.SIMULATOR_GPU_IDS = [0]
     _C.VIDEO_OPTION = []
     _C.VIDEO_DIR = "data/videos/debug"
@@ -190,6 +191,10 @@ def _experiment_defaults() -> Config:
     _C.RL.POLICY.OBS_TRANSFORMS.EGOCENTRIC_MAPPER.height_clip = 0.1
     _C.RL.POLICY.OBS_TRANSFORMS.EGOCENTRIC_MAPPER.height_meters = 6.4
     _C.RL.POLICY.OBS_TRANSFORMS.EGOCENTRIC_MAPPER.width_meters = 6.4
+    # HIP mapper sizing (not reference keys): dense keep-highest table cells (0 = library default) and world-cloud
+    # capacity in points (0 = 2^20 per env); exceeding either raises through MappingModule.check_status()
+    _C.RL.POLICY.OBS_TRANSFORMS.EGOCENTRIC_MAPPER.table_cells = 0
+    _C.RL.POLICY.OBS_TRANSFORMS.EGOCENTRIC_MAPPER.world_capacity = 0
     # --- MODEL (default.py:98-163) ---
     _C.MODEL = CN()
     _C.MODEL.policy_name = "CMAPolicy"

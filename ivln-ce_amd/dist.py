@@ -31,11 +31,40 @@ def init(backend: str = None):
     return rank, local_rank, world
 
 
+def _require_group(what: str) -> bool:
+    """True when a collective is needed.  A multi-rank launch (WORLD_SIZE > 1 in the environment) without an
+    initialised process group is an error, never a silent single-rank result: a trainer entry point that forgot
+    `init()` would otherwise write its local shard as if it were the whole job."""
+    world = world_info()[2]
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size() > 1
+    if world > 1:
+        raise RuntimeError(f"{what}: WORLD_SIZE={world} but torch.distributed is not initialised (call dist.init())")
+    return False
+
+
 def allreduce_sum_(flat: torch.Tensor):
     """In-place sum all-reduce of the flat gradient bucket (26.3 MB fp32 for MapCMA)."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _require_group("allreduce_sum_"):
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
+
+
+def broadcast_(flat: torch.Tensor, src: int = 0):
+    """Rank `src`'s tensor to every rank (identical initial weights)."""
+    if _require_group("broadcast_"):
+        dist.broadcast(flat, src=src)
+    return flat
+
+
+def allreduce_min_int(value: int, device) -> int:
+    """MIN over ranks of a python int (number of update batches a rank can supply: every rank must run the same
+    number of `update_agent` calls, each of which contains one gradient all-reduce)."""
+    if _require_group("allreduce_min_int"):
+        t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t.item())
+    return int(value)
 
 
 def shard(items, rank: int, world: int):
@@ -44,7 +73,7 @@ def shard(items, rank: int, world: int):
 
 
 def gather_objects(obj):
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _require_group("gather_objects"):
         out = [None] * dist.get_world_size()
         dist.all_gather_object(out, obj)
         return out

@@ -221,10 +221,21 @@ class SyntheticVectorEnv:
 
 
 def construct_envs(config, env_class=None, auto_reset_done=True, rank=0, world=1, **kw):
-    """Reference `construct_envs` when Habitat exists, synthetic otherwise (env_utils.py:25-108)."""
-    try:  # pragma: no cover
-        from ivlnce_baselines.common.env_utils import construct_envs as ref_construct_envs  # type: ignore
+    """The vector env the trainers of this package drive.
 
-        return ref_construct_envs(config, env_class, auto_reset_done=auto_reset_done)
-    except Exception:  # noqa: BLE001
-        return SyntheticVectorEnv(config, rank=rank, world=world, **kw)
+    Only the synthetic env is supported: the rollout / eval loops in trainers.py read trajectories and ground
+    truth through `dtw_data()` / `gt_paths()` and rely on its auto-advancing episodes, while a real Habitat
+    `VectorEnv` (env_utils.py:25-108) reports them through `infos["dtw_data"]` and needs `reset_at` after every
+    done (base_il_trainer.py:495, 805) - that simulator-side protocol is out of scope (SURVEY.md section 2 rows
+    8-9).  The choice is explicit: `config.ENV_BACKEND` ("synthetic", the default of this package's config) or the
+    IVLN_ENV_BACKEND environment variable; anything else fails loudly instead of silently training on synthetic
+    observations.  To run on Habitat, use the reference's own trainers with this package's policy / mapper
+    plugins (INTEGRATION.md)."""
+    import os
+
+    backend = os.environ.get("IVLN_ENV_BACKEND") or str(getattr(config, "ENV_BACKEND", "synthetic"))
+    if backend != "synthetic":
+        raise NotImplementedError(
+            f"ENV_BACKEND={backend!r}: ivln_ce_amd.trainers only drives the synthetic vector env; real Habitat envs "
+            "run through the reference's trainers with the MapCMAPolicy / *Mapper plugins of this package")
+    return SyntheticVectorEnv(config, rank=rank, world=world, **kw)

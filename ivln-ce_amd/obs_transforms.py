@@ -47,6 +47,7 @@ class Mapper(ObservationTransformer):
         self.map_dimensions = map_dimensions
         self.visualize = visualize
         self.mapping_module = None
+        self.sizing = {}  # HIP-mapper sizing from the config (table_cells / world_capacity), see from_config
         # obs_transforms.py:46-52: keys deleted after generating the maps
         self.keys_to_delete = ["world_robot_orientation", "world_robot_pose", "semantic", "semantic12", "env_name"]
 
@@ -69,12 +70,13 @@ class Mapper(ObservationTransformer):
         return observations
 
     def visualize_maps(self, observations):
-        """obs_transforms.py:105-113: colour frames of both maps for the video writer (host-side numpy)."""
+        """The reference adds `occupancy_map_viz` / `semantic_map_viz` colour frames here when VIDEO_OPTION is set
+        (obs_transforms.py:105-113).  Video / visualisation is outside the hot path this package replaces
+        (SURVEY.md section 2 row 11), so a request for it fails loudly instead of returning maps without frames."""
         if self.visualize:
-            from .visualize import visualize_ego_occupancy_map, visualize_ego_semantic_map
-
-            observations["occupancy_map_viz"] = visualize_ego_occupancy_map(observations["occupancy_map"])
-            observations["semantic_map_viz"] = visualize_ego_semantic_map(observations["semantic_map"])
+            raise NotImplementedError(
+                "map visualisation frames (VIDEO_OPTION / visualize=True) are not part of the MI355X hot path; "
+                "render `occupancy_map` / `semantic_map` with the reference's visualize_semantic_map.py")
         return observations
 
     def setup_mapping_module(self, observations: Dict[str, Tensor]):
@@ -99,11 +101,15 @@ class Mapper(ObservationTransformer):
             map_sensor_params=config.RL.POLICY.OBS_TRANSFORMS.EGOCENTRIC_MAPPER,
         )
         dims = extract_egocentric_map_parameters(config.RL.POLICY.OBS_TRANSFORMS.EGOCENTRIC_MAPPER)
-        return cls(
+        tr = cls(
             camera_parameters=camera_parameters,
             map_dimensions=dims,
             visualize=(len(config.VIDEO_OPTION) > 0) or visualize,
         )
+        mp = config.RL.POLICY.OBS_TRANSFORMS.EGOCENTRIC_MAPPER
+        tr.sizing = {k: int(getattr(mp, k)) for k in ("table_cells", "world_capacity") if int(getattr(mp, k, 0) or 0) > 0}
+        tr.sizing["b_max"] = max(64, int(getattr(config, "NUM_ENVIRONMENTS", 0) or 0))
+        return tr
 
 
 @baseline_registry.register_obs_transformer()
@@ -114,6 +120,7 @@ class GTSemanticsIterativeMapper(Mapper):
                 device=observations["depth"].device,
                 camera_parameters=self.camera_parameters,
                 map_dimensions=self.map_dimensions,
+                **self.sizing,
             )
 
 
@@ -125,6 +132,7 @@ class PredictedSemanticsIterativeMapper(Mapper):
                 device=observations["depth"].device,
                 camera_parameters=self.camera_parameters,
                 map_dimensions=self.map_dimensions,
+                **self.sizing,
             )
 
 
@@ -133,7 +141,7 @@ class GTSemanticsKnownMapper(Mapper):
     def setup_mapping_module(self, observations):
         if self.mapping_module is None:
             self.mapping_module = create_gt_semantics_known_mapper(
-                device=observations["depth"].device, map_dimensions=self.map_dimensions
+                device=observations["depth"].device, map_dimensions=self.map_dimensions, **self.sizing
             )
 
 
@@ -142,7 +150,7 @@ class PredictedSemanticsKnownMapper(Mapper):
     def setup_mapping_module(self, observations):
         if self.mapping_module is None:
             self.mapping_module = create_predicted_semantics_known_mapper(
-                device=observations["depth"].device, map_dimensions=self.map_dimensions
+                device=observations["depth"].device, map_dimensions=self.map_dimensions, **self.sizing
             )
 
 

@@ -120,7 +120,7 @@ def update_agent(policy, optimizer: FlatAdam, observations, prev_actions, not_do
                                           weights.to(torch.float32).contiguous(), scale)
     roots, grads = [logits], [dlogits.view(T * N, A)]
     aux_loss = 0.0
-    if AuxLosses.is_active() and len(AuxLosses._losses) > 0:
+    if AuxLosses.is_active() and len(AuxLosses) > 0:
         with torch.enable_grad():
             aux_loss = AuxLosses.reduce((weights > 0).view(-1))  # the reference's own reduction
         roots.append(aux_loss)
@@ -315,7 +315,7 @@ class BaseVLNCETrainer:
         sem = config.MODEL.SEMANTIC_MAP_ENCODER
         self.optimizer = FlatAdam(self.policy, lr=config.IL.lr, sem_lr=sem.lr if sem.custom_lr else None)
         if self.world > 1:  # identical initial weights on every rank
-            torch.distributed.broadcast(self.optimizer.flat, src=0)
+            D.broadcast_(self.optimizer.flat, src=0)
         if load_from_ckpt:
             ckpt = self.load_checkpoint(config.IL.ckpt_to_load, map_location="cpu")
             self.policy.load_state_dict(ckpt["state_dict"])
@@ -359,6 +359,14 @@ class BaseVLNCETrainer:
                 batch[k] = v[state_index] if torch.is_tensor(v) else [v[i] for i in state_index]
         return envs, recurrent_hidden_states, not_done_masks, prev_actions, batch, rgb_frames
 
+    def _check_mappers(self):
+        """Raise if a mapper's device-side error flag is set (IVLN_E_KEYSPACE / IVLN_E_CAPACITY: points were
+        dropped, so the maps of this rollout are wrong).  Called where the loops synchronise anyway."""
+        for t in self.obs_transforms:
+            mm = getattr(t, "mapping_module", None)
+            if mm is not None and getattr(mm, "_h", None) is not None:
+                mm.check_status()
+
     # -- observations -> batch ----------------------------------------------------------------
     def _batch(self, observations, not_done_masks, transform=True):
         observations = extract_instruction_tokens(observations, self.config.TASK_CONFIG.TASK.INSTRUCTION_SENSOR_UUID)
@@ -401,6 +409,7 @@ class BaseVLNCETrainer:
     # -- eval -------------------------------------------------------------------------------------
     def eval(self):
         """BaseILTrainer.eval (Appendix D): a checkpoint file, or every ckpt.N.pth of a folder."""
+        D.init()  # multi-rank eval without a preceding train(): the gather / broadcast below need the group
         path = self.config.EVAL_CKPT_PATH_DIR
         if os.path.isfile(path):
             return [self._eval_checkpoint(path, None, 0)]
@@ -416,6 +425,7 @@ class BaseVLNCETrainer:
         policy, per-episode stats aggregated over all envs, dtw_data dumped per tour and t-nDTW
         against the gt paths; map reset follows EVAL.ITERATIVE_MAP_RESET through the masks handed to
         the mapper.  Scenes/envs are sharded over ranks; rank 0 merges."""
+        D.init()
         config = self.config
         split = config.EVAL.SPLIT
         iterative = bool(config.TASK_CONFIG.ENVIRONMENT.ITERATIVE.ENABLED)
@@ -484,6 +494,8 @@ class BaseVLNCETrainer:
                 [[0] if (d and getattr(a, "tour_id", None) != getattr(b, "tour_id", None)) else [1]
                  for d, a, b in zip(dones, next_episodes, current_episodes)], dtype=torch.uint8, device=self.device)
             envs_to_pause = []
+            if any(dones):
+                self._check_mappers()  # episode boundary; the stream was just synchronised by the actions' .item()
             for i in range(envs.num_envs):
                 if dones[i]:
                     stats_episodes[current_episodes[i].episode_id] = infos[i]
@@ -500,6 +512,7 @@ class BaseVLNCETrainer:
                 envs, rnn_states, not_done_masks, prev_actions, batch, _ = self._pause_envs(
                     envs_to_pause, envs, rnn_states, not_done_masks, prev_actions, batch)
                 runner = None  # fewer rows: capture again for the new batch size, seeded with the kept rows
+        self._check_mappers()
         agent_paths, gt_paths = envs.dtw_data(), envs.gt_paths()
         gathered = D.gather_objects((stats_episodes, agent_paths, gt_paths, dict(stats_tours)))
         envs.close()
@@ -548,6 +561,18 @@ class PrefetchLoader:
         import threading
 
         q = queue.Queue(maxsize=self.depth)
+        stop = threading.Event()  # set when the consumer leaves early (break / exception): the worker must not
+        #                           sit forever on a full queue holding pinned batches
+
+        def put(item):
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.1)
+                    return True
+                except queue.Full:
+                    continue
+            return False
+
         cuda = self.device.type == "cuda"
         stream = torch.cuda.Stream(self.device) if cuda else None
 
@@ -559,7 +584,8 @@ class PrefetchLoader:
         def work():
             try:
                 for batch in self.loader:
-                    batch = (trim_instruction_padding(batch[0]),) + tuple(batch[1:])  # host side, before the H2D copy
+                    # host side, before the H2D copy; batch[-2] = corrected actions (T, N)
+                    batch = (trim_instruction_padding(batch[0], first_rows=batch[-2].shape[1]),) + tuple(batch[1:])
                     parts = tuple(pin(b) for b in batch)
                     if len(parts) == 5:  # episodic collate: no tour masks (slot 3 of the 6-tuple the loops unpack)
                         parts = parts[:3] + (None,) + parts[3:]
@@ -570,26 +596,30 @@ class PrefetchLoader:
                             ev.record(stream)
                     else:
                         moved, ev = batch_to(parts, self.device), None
-                    q.put((moved, ev))
-                q.put(None)
+                    if not put((moved, ev)):
+                        return
+                put(None)
             except BaseException as e:  # noqa: BLE001 - surface loader errors in the training thread
-                q.put(e)
+                put(e)
 
         th = threading.Thread(target=work, daemon=True)
         th.start()
-        while True:
-            item = q.get()
-            if item is None:
-                break
-            if isinstance(item, BaseException):
-                raise item
-            moved, ev = item
-            if ev is not None:
-                torch.cuda.current_stream().wait_event(ev)
-                for v in list(moved[0].values()) + [m for m in moved[1:] if m is not None]:
-                    v.record_stream(torch.cuda.current_stream())  # allocated on the copy stream, used on this one
-            yield moved
-        th.join()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                moved, ev = item
+                if ev is not None:
+                    torch.cuda.current_stream().wait_event(ev)
+                    for v in list(moved[0].values()) + [m for m in moved[1:] if m is not None]:
+                        v.record_stream(torch.cuda.current_stream())  # allocated on the copy stream, used on this one
+                yield moved
+        finally:
+            stop.set()
+            th.join(timeout=5.0)
 
 
 @baseline_registry.register_trainer(name="dagger")
@@ -628,8 +658,11 @@ class DaggerTrainer(BaseVLNCETrainer):
         p = cfg.IL.DAGGER.p
         beta = 0.0 if p == 0.0 else p ** data_it
         feats = {}
-        hooks = [self.policy.net.depth_encoder.visual_encoder.register_forward_hook(
-            lambda m, i, o: feats.__setitem__("depth", o.detach().cpu()))]
+        hooks = []
+        cache_depth = not cfg.MODEL.DEPTH_ENCODER.trainable  # dagger_trainer.py:317-323: frozen encoders only
+        if cache_depth:
+            hooks.append(self.policy.net.depth_encoder.visual_encoder.register_forward_hook(
+                lambda m, i, o: feats.__setitem__("depth", o.detach().cpu())))
         if hasattr(self.policy.net, "rgb_encoder") and not cfg.MODEL.RGB_ENCODER.trainable:
             hooks.append(self.policy.net.rgb_encoder.cnn.register_forward_hook(
                 lambda m, i, o: feats.__setitem__("rgb", o.detach().cpu())))
@@ -643,7 +676,7 @@ class DaggerTrainer(BaseVLNCETrainer):
         with torch.no_grad():
             while collected < target:
                 for i in range(envs.num_envs):
-                    if dones[i] and not skips[i]:
+                    if dones[i] and not skips[i] and collected < target:  # never overshoot: ranks must agree
                         ep = episodes[i]
                         traj_obs = batch_obs([s[0] for s in ep], device=torch.device("cpu"))
                         del traj_obs[expert_uuid]
@@ -654,6 +687,8 @@ class DaggerTrainer(BaseVLNCETrainer):
                         collected += 1
                     if dones[i]:
                         episodes[i] = []
+                if collected >= target:
+                    break
                 if self.tour_masked_maps:  # tour-by-tour collection: the policy sees episode AND tour boundaries
                     actions, rnn_states = self.policy.act_iterative(
                         batch, rnn_states, prev_actions, not_done_masks, not_done_masks, tour_masks,
@@ -670,8 +705,9 @@ class DaggerTrainer(BaseVLNCETrainer):
                 tours_now = [getattr(e, "tour_id", None) for e in envs.current_episodes()]
                 for i in range(envs.num_envs):
                     o = dict(observations[i])
-                    o["depth_features"] = feats["depth"][i].clone()
-                    o.pop("depth", None)
+                    if cache_depth:
+                        o["depth_features"] = feats["depth"][i].clone()
+                        o.pop("depth", None)
                     if "rgb" in feats:
                         o["rgb_features"] = feats["rgb"][i].clone()
                     if occ is not None:
@@ -698,6 +734,7 @@ class DaggerTrainer(BaseVLNCETrainer):
         for h in hooks:
             h.remove()
         envs.close()
+        self._check_mappers()
         if save_tour_idx_data:
             self.store.put_tour_index(tours_to_idxs)
             return dict(tours_to_idxs)
@@ -726,9 +763,16 @@ class DaggerTrainer(BaseVLNCETrainer):
             dataset = IWTrajectoryDataset(self.store, cfg.IL.use_iw, cfg.IL.inflection_weight_coef, cfg.IL.batch_size)
             loader = torch.utils.data.DataLoader(dataset, batch_size=cfg.IL.batch_size, shuffle=False,
                                                  collate_fn=collate_fn, pin_memory=False, drop_last=True, num_workers=0)
+            # every rank owns its own store (preloaded / kept features can leave them unequal): all ranks run the
+            # MIN batch count, so no rank issues a gradient all-reduce the others never join
+            n_batches = D.allreduce_min_int(dataset.length // cfg.IL.batch_size, self.device)
             AuxLosses.activate()  # only around the updates, never during rollouts (dagger_trainer.py:579)
-            for epoch in range(self.start_epoch, cfg.IL.epochs):
-                for obs_b, prev_b, nd_b, _, corr_b, w_b in PrefetchLoader(loader, self.device):
+            # a requeued run resumes its interrupted iteration at start_epoch; later iterations start at 0
+            first_epoch = self.start_epoch if dagger_it == 0 else 0
+            for epoch in range(first_epoch, cfg.IL.epochs):
+                for bi, (obs_b, prev_b, nd_b, _, corr_b, w_b) in enumerate(PrefetchLoader(loader, self.device)):
+                    if bi >= n_batches:
+                        break
                     loss, action_loss, aux_loss = self._update_agent(obs_b, prev_b, nd_b, corr_b, w_b)
                     log.append({"dagger_it": dagger_it, "epoch": epoch, "step": step_id, "loss": loss,
                                 "action_loss": action_loss, "aux_loss": aux_loss})
@@ -785,14 +829,12 @@ class IterativeDaggerTrainer(IterativeCollectionDaggerTrainer):
                 tours_to_idxs = self._update_dataset(dagger_it + (1 if cfg.IL.load_from_ckpt else 0),
                                                      save_tour_idx_data=True)
             AuxLosses.activate()
-            for epoch in range(self.start_epoch, cfg.IL.epochs):
+            for epoch in range(self.start_epoch if dagger_it == 0 else 0, cfg.IL.epochs):
                 dataset = TourTrajectoryDataset(self.store, cfg.IL.use_iw, cfg.IL.inflection_weight_coef)
                 sampler = TourSampler({k: list(v) for k, v in tours_to_idxs.items()}, batch_size=cfg.IL.batch_size,
                                       shuffle=True, drop_last=True)
                 if self.world > 1:
-                    n = torch.tensor([len(sampler)], device=self.device)
-                    torch.distributed.all_reduce(n, op=torch.distributed.ReduceOp.MIN)
-                    sampler.truncate(int(n.item()))
+                    sampler.truncate(D.allreduce_min_int(len(sampler), self.device))
                 dataset.set_tour_done_idxs(sampler.get_tour_done_idxs())
                 loader = torch.utils.data.DataLoader(dataset, batch_sampler=sampler, collate_fn=tour_collate,
                                                      pin_memory=False, num_workers=0)

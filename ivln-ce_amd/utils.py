@@ -60,17 +60,25 @@ def batch_to(batch: Tuple, device: torch.device = None, non_blocking: bool = Tru
     )
 
 
-def trim_instruction_padding(observations: Dict, key: str = "instruction", multiple: int = 8) -> Dict:
+def trim_instruction_padding(observations: Dict, key: str = "instruction", multiple: int = 8,
+                             first_rows: Optional[int] = None) -> Dict:
     """Drop the all-padding tail of a HOST-side token batch (rows, 200) before it is copied to the GPU: the
     reference's packed bi-LSTM / pad_packed_sequence only ever produces the batch's longest instruction
     (instruction_encoder.py:70-92), so every consumer (W_ih GEMM, text_k, the attention axis) sees Lmax columns,
     not 200.  Lmax is rounded up to `multiple` (16-byte loads along the token axis); columns beyond a row's own
-    length stay masked exactly as before.  A device tensor is returned unchanged (finding Lmax would be a sync)."""
+    length stay masked exactly as before.  A device tensor is returned unchanged (finding Lmax would be a sync).
+
+    `first_rows` = N for a collated time-major (T*N, 200) batch: only the t = 0 rows are measured.  `collate_fn`
+    pads the observations of finished trajectories with 1.0 (dagger_trainer.py:66-70), so a padded timestep row
+    counts 200 "tokens" and would disable the trim for every batch of unequal trajectory lengths; the instruction
+    of a trajectory is the same at every timestep and t = 0 is never padding.  Padded rows keep their first Lmax
+    ones - those timesteps carry zero loss weight, so what the encoder makes of them never reaches a gradient."""
     t = observations.get(key)
     if t is None or not torch.is_tensor(t) or t.is_cuda or t.dim() != 2:
         return observations
     L = t.shape[1]
-    longest = int((t != 0).sum(dim=1).max().item()) if t.shape[0] > 0 else L
+    probe = t if first_rows is None else t[:first_rows]
+    longest = int((probe != 0).sum(dim=1).max().item()) if probe.shape[0] > 0 else L
     keep = min(L, max(multiple, -(-longest // multiple) * multiple))
     if keep < L:
         observations = dict(observations)

@@ -116,16 +116,12 @@ def test_obs_transform_boundary_deletes_keys_and_aliases_buffers():
     assert out["semantic_map"].data_ptr() == tr.mapping_module.map_memory._sem.data_ptr()
     assert int(out["occupancy_map"].sum()) > 0
     assert "occupancy_map_viz" not in out
-    # VIDEO_OPTION set (or visualize=True): colour frames of both maps ride along (obs_transforms.py:105-113)
+    # the *_viz colour frames (visualize_semantic_map.py) are out of scope: asking for
+    # them is a loud error, not a silent no-op
     tr_v = GTSemanticsIterativeMapper.from_config(cfg, visualize=True)
     obs = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in roll.step().items()}
-    out_v = tr_v(obs)
-    assert out_v["occupancy_map_viz"].shape == out_v["semantic_map_viz"].shape == (2, 200, 200, 3)
-    occupied = out_v["occupancy_map"][0].cpu().numpy().astype(bool)
-    frame = out_v["occupancy_map_viz"][0]
-    r, c = np.argwhere(occupied)[0]
-    if abs(int(r) - 32) > 4 or abs(int(c) - 32) > 4:  # away from the agent marker
-        assert (frame[int(r * 200 / 64) + 1, int(c * 200 / 64) + 1] == 0).all()
+    with pytest.raises(NotImplementedError):
+        tr_v(obs)
 
 
 def test_mapper_raises_without_gpu_tensor():

@@ -318,3 +318,33 @@ def test_update_with_host_trimmed_instruction_padding_is_the_same_update():
     for k, gfull in res["full"][1].items():
         gt = res["trim"][1][k]
         assert torch.allclose(gfull, gt, rtol=1e-4, atol=1e-7), f"{k}: {float((gfull - gt).abs().max()):.3e}"
+
+
+def _run_two_ranks_one_gpu(tmp_path, port, *args):
+    """Two ranks sharing cuda:0 over gloo (RCCL refuses two ranks per device): control flow of the multi-rank
+    paths - env sharding, FlatAdam's all-reduce, rank-0 gather - on the 1-GPU box.  Never a measurement."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, IVLN_DIST_BACKEND="gloo", IVLN_ONE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "tools", "dist_smoke.py"), str(tmp_path), *args]
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+
+
+@pytest.mark.gpu
+def test_two_rank_eval_without_a_preceding_train(tmp_path):
+    """eval() / _eval_checkpoint() must set up the process group themselves and rank 0 must report
+    BOTH ranks' episodes."""
+    r = _run_two_ranks_one_gpu(tmp_path, 29561, "dagger", "eval_only")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "dist smoke ok: eval_only world 2 episodes 32" in r.stdout
+
+
+@pytest.mark.gpu
+def test_two_rank_dagger_train_keeps_replicas_identical(tmp_path):
+    """FlatAdam.step with world > 1 (all-reduce + Adam with 1/world folded in), MIN-reduced batch count, then eval."""
+    r = _run_two_ranks_one_gpu(tmp_path, 29563, "dagger")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "dist smoke ok: dagger world 2" in r.stdout

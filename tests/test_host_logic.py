@@ -309,27 +309,6 @@ def test_tour_trajectory_dataset_and_store_tour_index(tmp_path):
     assert len(store) == 0 and store.get_tour_index() == {}
 
 
-def test_map_visualization_frames():
-    """`occupancy_map_viz` / `semantic_map_viz` (obs_transforms.py:105-113): palette, free = white, nearest
-    upscale to 200 px, one frame per env."""
-    import numpy as np
-    import torch
-
-    from ivln_ce_amd.visualize import LABEL_COLOURS, visualize_ego_occupancy_map, visualize_ego_semantic_map
-
-    occ = torch.zeros(2, 64, 64, dtype=torch.uint8)
-    sem = torch.zeros(2, 64, 64, dtype=torch.uint8)
-    occ[0, :8, :8] = 1
-    sem[0, :8, :8] = 7
-    sem[1, 56:, 56:] = 12
-    o, s = visualize_ego_occupancy_map(occ), visualize_ego_semantic_map(sem)
-    assert o.shape == s.shape == (2, 200, 200, 3) and o.dtype == s.dtype == np.uint8
-    assert (o[0, :25, :25] == 0).all() and (o[0, 30:60, 30:60] == 255).all() and (o[1, :90, :90] == 255).all()
-    assert (s[0, :25, :25] == LABEL_COLOURS[7]).all() and (s[1, 176:, 176:] == LABEL_COLOURS[12]).all()
-    assert (s[1, :90, :90] == 0).all()
-    assert tuple(LABEL_COLOURS[1]) == (106, 137, 204) and len(LABEL_COLOURS) == 13
-
-
 def test_greedy_bin_packing_properties():
     """to_constant_bin_number (restated `binpacking` function): every key lands in exactly one bin, the bin count
     is constant, and the greedy rule bounds the spread of the bin loads by the largest item."""

@@ -18,7 +18,11 @@ from ivln_ce_amd.registry import baseline_registry  # noqa: E402
 
 out = sys.argv[1]
 TRAINER = sys.argv[2] if len(sys.argv) > 2 else "dagger"  # or iterative_dagger: tour batches, MIN-reduced batch count
-rank, _, world = D.init()
+EVAL_ONLY = len(sys.argv) > 3 and sys.argv[3] == "eval_only"  # eval() must set the process group up by itself
+if EVAL_ONLY:
+    rank, _, world = D.world_info()
+else:
+    rank, _, world = D.init()
 torch.manual_seed(0)
 np.random.seed(rank)
 cfg = get_config(opts=[
@@ -30,6 +34,21 @@ cfg = get_config(opts=[
     "IL.DAGGER.lmdb_features_dir", os.path.join(out, f"traj{rank}"), "CHECKPOINT_FOLDER", os.path.join(out, "ckpt"),
     "RESULTS_DIR", os.path.join(out, "res"), "EVAL_CKPT_PATH_DIR", os.path.join(out, "ckpt"),
 ])
+if EVAL_ONLY:
+    os.makedirs(os.path.join(out, "ckpt"), exist_ok=True)
+    ckpt = os.path.join(out, "ckpt", "none.pth")  # absent file: random-init weights, broadcast from rank 0
+    cfg.defrost()
+    cfg.EVAL_CKPT_PATH_DIR = ckpt
+    cfg.freeze()
+    res = [baseline_registry.get_trainer(TRAINER)(cfg)._eval_checkpoint(ckpt, None, 0)]
+    assert torch.distributed.is_initialized(), "eval must initialise the process group itself"
+    if rank == 0:
+        # both ranks' episodes were gathered: 2 envs per rank x 8 episodes
+        assert res[0]["episodes"] == 2 * world * 8, res[0]["episodes"]
+        print("dist smoke ok: eval_only world", world, "episodes", res[0]["episodes"])
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+    sys.exit(0)
 tr = baseline_registry.get_trainer(TRAINER)(cfg)
 log = tr.train()
 assert len(log) >= 1 and all(np.isfinite(l["loss"]) for l in log)
