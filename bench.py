@@ -1,20 +1,27 @@
 """bench.py - throughput of the MapCMA hot path on MI355X (driver contract: see DESIGN.md section 6).
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
 
-A "step" = one pass of the hot path over one batch of synthetic observations already resident in
-HBM: egocentric mapper (gt semantics) + MapCMAPolicy.act for `--envs` (default 4) parallel envs per
-GPU = BASELINE.json configs[1].  `value` = env-steps/s over all ranks (weak scaling: envs per GPU
-fixed).  The JSON line also carries
-  roofline     - fp32-MFMA implicit-GEMM kernel family (all conv / linear FLOPs of the step):
-                 algorithmic FLOPs per step / summed kernel time per step (HIP events on the launch
-                 stream) against the 157.3 TFLOP/s fp32-matrix peak
-  cpu_baseline - the CPU oracle (torch-CPU policy port + C mapper) timed on this box's host cores
-                 on a bounded sample of the same workload (rank 0, N=1 only)
+With N > 1 and no WORLD_SIZE in the environment the parent spawns N ranks itself (one process per GPU through
+`python -m torch.distributed.run`, started BEFORE the parent touches the GPU) and relays rank 0's JSON line; when
+the driver launches it under torch.distributed.run the ranks are used as they come.
+
+A "step" = one pass of the hot path over one batch of synthetic observations already resident in HBM.
+Headline (`value`): BASELINE.json configs[1] - egocentric mapper (gt semantics) + MapCMAPolicy.act for `--envs`
+(default 4) parallel envs per GPU, env-steps/s over all ranks (weak scaling: envs per GPU fixed).
+The JSON line also carries
+  roofline             fp32-MFMA implicit-GEMM family of the headline step: algorithmic FLOPs / summed kernel time
+                       (HIP events on the launch stream) against the 157.3 TFLOP/s fp32-matrix peak
+  mapper_roofline      the egocentric mapper's kernels: algorithmic bytes per step / kernel time against 8 TB/s
+  cpu_baseline         the CPU oracle (torch-CPU policy port + C mapper) on this box's host cores, bounded sample
+  pred_semantics_step  BASELINE configs[2] at its stated size (8 envs): RedNet + mapper + policy, with its own
+                       `roofline` (RedNet's MFMA launches) and `cpu_baseline` (oracle RedNet + C mapper + port)
+  update_step          DAgger update T=64 x N=8 per GPU (fwd + bwd + all-reduce + Adam) with its MFMA roofline
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -26,6 +33,12 @@ import torch  # noqa: E402
 
 METRIC = "env-steps/sec (batched MapCMA fwd+bwd) at 1/2/4/8 MI355X; t-nDTW parity"
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+PEAK_HBM_GBS = 8000.0  # same guide: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+MFMA_FAMILY = "fp32 MFMA family (k_gemm / k_gemm_vec / k_conv_direct / k_conv_gn)"
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
 
 
 def make_policy(device, seed=0):
@@ -36,6 +49,7 @@ def make_policy(device, seed=0):
     cfg = get_config(opts=[
         "MODEL.policy_name", "MapCMAPolicy", "MODEL.INSTRUCTION_ENCODER.use_pretrained_embeddings", False,
         "MODEL.DEPTH_ENCODER.ddppo_checkpoint", "NONE",
+        "MODEL.PROGRESS_MONITOR.use", True,  # the MapCMA experiment YAMLs switch it on (0_train_tf.yaml:30-34)
     ])
     space = Dict({
         "depth": Box(0.0, 1.0, (256, 256, 1), np.float32), "occupancy_map": Box(0, 255, (64, 64), np.uint8),
@@ -51,6 +65,10 @@ def gen_observations(B, n_steps, seed, with_rgb=False):
 
     roll = SyntheticRollout(B=B, seed=seed, with_rgb=with_rgb)
     return [roll.step() for _ in range(n_steps)]
+
+
+def to_dev(obs_list, dev):
+    return [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in o.items()} for o in obs_list]
 
 
 class GemmTimer:
@@ -82,10 +100,22 @@ class GemmTimer:
 
     def total_ms(self):
         """Sum of the event-pair times.  A pair brackets one launch on the launch stream, so it carries the
-        launch's dispatch latency as well (about 2.5 us more per launch than rocprofv3's kernel durations,
-        profiles/r01_rollout_eager_kernel_stats.csv): the reported TFLOP/s is the conservative figure."""
+        launch's dispatch latency as well (about 2.5 us more per launch than rocprofv3's kernel durations):
+        the reported TFLOP/s is the conservative figure."""
         torch.cuda.synchronize()
         return sum(a.elapsed_time(b) for a, b in self.events)
+
+
+def mfma_roofline(gt, ms, n_steps, traffic, what):
+    ach = (gt.flops / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
+    return {
+        "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 5), "traffic": traffic,
+        "kernel": MFMA_FAMILY + ": " + what,
+        "flops_per_step": int(gt.flops / n_steps), "launches_per_step": round(len(gt.events) / n_steps, 1),
+        "kernel_ms_per_step": round(ms / n_steps, 4),
+    }
+
 
 def rollout_step(mapper_tr, policy, obs, state):
     """mapper (obs-transform plugin) + policy.act: the per-step body of the reference eval loop
@@ -116,8 +146,9 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(obs_cpu, B, budget_s=12.0):
-    """Torch-CPU policy port + C mapper oracle on the host cores (kind = "port")."""
+def cpu_baseline(obs_cpu, B, budget_s=12.0, pred=False):
+    """Torch-CPU policy port + C mapper oracle on the host cores (kind = "port"); with `pred` the labels come
+    from the torch-CPU RedNet port (configs[2])."""
     from oracle.mapper_ref import MapperRef
     from oracle.policy_ref import MapCMAPolicyRef
 
@@ -128,10 +159,19 @@ def cpu_baseline(obs_cpu, B, budget_s=12.0):
     mapper = MapperRef(256, 256)
     rnn = torch.zeros(B, 2, 512)
     prev = torch.zeros(B, 1, dtype=torch.long)
+    rednet = None
+    if pred:
+        from oracle.rednet_ref import RedNetRef, predict_semantics_ref
+
+        rednet = RedNetRef().eval()
 
     def step(o):
         nonlocal rnn, prev
-        occ, sem = mapper.step(o["depth"].numpy(), o["semantic12"].numpy(), o["world_robot_pose"].numpy(),
+        if pred:
+            labels = predict_semantics_ref(rednet, o["rgb"], o["depth"])[1].numpy()
+        else:
+            labels = o["semantic12"].numpy()
+        occ, sem = mapper.step(o["depth"].numpy(), labels, o["world_robot_pose"].numpy(),
                                o["world_robot_orientation"].numpy(), o["not_done_masks"].numpy())
         ob = {"depth": o["depth"], "instruction": o["instruction"], "occupancy_map": torch.from_numpy(occ),
               "semantic_map": torch.from_numpy(sem)}
@@ -139,46 +179,59 @@ def cpu_baseline(obs_cpu, B, budget_s=12.0):
             a, rnn, _ = pol.act(ob, rnn, prev, o["not_done_masks"])
         prev = a
 
-    for o in obs_cpu[:3]:
+    n_warm, n_min, n_max = (1, 6, 40) if pred else (3, 20, 400)
+    for o in obs_cpu[:n_warm]:
         step(o)
     n, t0 = 0, time.perf_counter()
-    i = 3
+    i = n_warm
     while True:
         step(obs_cpu[i % len(obs_cpu)])
         i += 1
         n += 1
         el = time.perf_counter() - t0
-        if (n >= 20 and el > budget_s) or n >= 400 or el > 4 * budget_s:
+        if (n >= n_min and el > budget_s) or n >= n_max or el > 3 * budget_s:
             break
+    what = ("torch-CPU RedNet port + C mapper oracle + torch-CPU MapCMA port" if pred
+            else "C mapper oracle + torch-CPU MapCMA port")
     return {
         "value": round(B * n / el, 2), "unit": "env-steps/s", "cores": ncores, "kind": "port",
-        "sample": f"{n} steps of {B} envs (256x256 depth, gt semantics, 80-token instruction): C mapper oracle + "
-                  f"torch-CPU MapCMA port, {ncores} threads, after 3 warm-up steps",
+        "sample": f"{n} steps of {B} envs (256x256 depth, " + ("224x224 rgb, " if pred else "gt semantics, ")
+                  + f"80-token instruction): {what}, {ncores} threads, after {n_warm} warm-up step(s)",
     }
 
 
-def pmc_traffic(B):
-    """HBM bytes per MFMA-family launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
-    in separate runs, gfx950 FETCH correction applied; profiles/r01_rollout_pmc_traffic.json).  A counter
-    pass cannot run inside the timed bench, so the figure is the committed one and only for its workload."""
-    path = os.path.join(ROOT, "profiles", "r01_rollout_pmc_traffic.json")
-    if B != 4 or not os.path.exists(path):
-        return None
-    try:
-        return json.load(open(path))["mfma_family"]["hbm_bytes_per_launch_corrected"]
-    except Exception:  # noqa: BLE001
-        return None
+def pmc_traffic(name, key):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs,
+    gfx950 FETCH correction applied; profiles/<name>).  A counter pass cannot run inside the timed bench, so the
+    figure is the committed one and only for its workload; None when no such profile is committed."""
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_{name}")
+        if os.path.exists(path):
+            try:
+                d = json.load(open(path))
+                for k in key:
+                    d = d[k]
+                return d
+            except Exception:  # noqa: BLE001
+                return None
+    return None
 
 
-def log(*a):
-    print("[bench]", *a, file=sys.stderr, flush=True)
+def inflection_weights(targets_TN, coef=3.2):
+    """dagger_trainer.py:193-214: weight `coef` where the expert action differs from the previous step's (the first
+    step counts as an inflection), 1 elsewhere."""
+    infl = torch.ones_like(targets_TN, dtype=torch.bool)
+    infl[1:] = targets_TN[1:] != targets_TN[:-1]
+    return torch.where(infl, torch.tensor(coef), torch.tensor(1.0))
 
 
 def bench_update(policy, dev, world, barrier, T=64, N=8, iters=5, warm=2):
-    """DAgger update step (base_il_trainer.py:173-219): forward over T*N rows with BPTT, weighted CE +
-    progress-monitor loss, hand-written HIP backward, one flat-bucket RCCL all-reduce (world > 1), Adam.
-    Same barrier / max-over-ranks clock as the rollout leg; rows/s is the whole-job aggregate."""
+    """DAgger update step (base_il_trainer.py:173-219) on SURVEY section 8d's synthetic batch: forward over T*N rows
+    with BPTT, inflection-weighted CE + progress-monitor aux loss (quirk Q7), hand-written HIP backward, one
+    flat-bucket RCCL all-reduce (world > 1), Adam.  Same barrier / max-over-ranks clock as the rollout leg."""
+    from ivln_ce_amd.aux_losses import AuxLosses
     from ivln_ce_amd.trainers import FlatAdam, update_agent
+    from ivln_ce_amd.utils import trim_instruction_padding
 
     policy.train()
     opt = FlatAdam(policy, lr=2.5e-4)
@@ -186,41 +239,45 @@ def bench_update(policy, dev, world, barrier, T=64, N=8, iters=5, warm=2):
     TN = T * N
     instr = torch.zeros(N, 200)
     instr[:, :80] = torch.randint(2, 2504, (N, 80), generator=g).float()
-    from ivln_ce_amd.utils import trim_instruction_padding
-
     # the trainer's loader drops the all-padding tail of the token batch on the host (trainers.PrefetchLoader):
     # like the reference's packed LSTM, the update only ever sees the batch's longest instruction (80 of 200)
-    host = trim_instruction_padding({"instruction": instr.repeat(T, 1)})
+    host = trim_instruction_padding({"instruction": instr.repeat(T, 1)}, first_rows=N)
     obs = {"depth_features": torch.randn(TN, 128, 4, 4, generator=g).to(dev),
            "occupancy_map": (torch.rand(TN, 64, 64, generator=g) < 0.3).float().to(dev),
            "semantic_map": torch.randint(0, 13, (TN, 64, 64), generator=g).float().to(dev),
-           "instruction": host["instruction"].to(dev)}
+           "instruction": host["instruction"].to(dev),
+           "progress": torch.rand(TN, 1, generator=g).to(dev)}
     prev = torch.randint(0, 4, (TN, 1), generator=g).to(dev)
     nd = torch.ones(T, N, dtype=torch.uint8)
     nd[0] = 0
     nd = nd.view(-1, 1).to(dev)
-    tgt = torch.randint(0, 4, (T, N), generator=g).to(dev)
-    w = torch.ones(T, N).to(dev)
-    for _ in range(warm):
-        update_agent(policy, opt, obs, prev, nd, tgt, w, world=world)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        update_agent(policy, opt, obs, prev, nd, tgt, w, world=world)
-    barrier()
-    el = time.perf_counter() - t0
-    # MFMA kernel family of one update (instrumented pass, outside the timed region).  The event pairs sum
-    # per-launch elapsed times, so the pass runs everything on one stream: with the instruction branch on its
-    # side stream (the timed configuration) concurrent launches would be counted twice over the same wall time.
-    from ivln_ce_amd import train as _train
-
-    overlap, _train.OVERLAP_INSTRUCTION = _train.OVERLAP_INSTRUCTION, False
+    tgt_cpu = torch.randint(0, 4, (T, N), generator=g)
+    tgt = tgt_cpu.to(dev)
+    w = inflection_weights(tgt_cpu).to(dev)
+    AuxLosses.activate()
     try:
-        with GemmTimer() as gt:
+        for _ in range(warm):
             update_agent(policy, opt, obs, prev, nd, tgt, w, world=world)
-            ms = gt.total_ms()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            update_agent(policy, opt, obs, prev, nd, tgt, w, world=world)
+        barrier()
+        el = time.perf_counter() - t0
+        # MFMA kernel family of one update (instrumented pass, outside the timed region).  The event pairs sum
+        # per-launch elapsed times, so the pass runs everything on one stream: with the instruction branch on its
+        # side stream (the timed configuration) concurrent launches would be counted twice over the same wall time.
+        from ivln_ce_amd import train as _train
+
+        overlap, _train.OVERLAP_INSTRUCTION = _train.OVERLAP_INSTRUCTION, False
+        try:
+            with GemmTimer() as gt:
+                update_agent(policy, opt, obs, prev, nd, tgt, w, world=world)
+                ms = gt.total_ms()
+        finally:
+            _train.OVERLAP_INSTRUCTION = overlap
     finally:
-        _train.OVERLAP_INSTRUCTION = overlap
+        AuxLosses.deactivate()
     ach = (gt.flops / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
     roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "flops_per_update": int(gt.flops),
@@ -230,15 +287,105 @@ def bench_update(policy, dev, world, barrier, T=64, N=8, iters=5, warm=2):
     return el, {"rows_per_step_per_gpu": TN, "T": T, "N": N, "iters": iters, "roofline": roof}
 
 
+def mapper_roofline(mapper_tr, obs_dev, B, n_steps=20):
+    """HBM roofline of the egocentric mapper (north_star: "achieved HBM GB/s for the scatter against gfx950
+    peak").  Event pair around the mapper's launches of one step, the GPU parked on a spin kernel while the host
+    enqueues so that the pair times back-to-back kernels.  Algorithmic bytes per env-step as SURVEY section 8d
+    defines them: 65 536 px x (4 B depth + 1 B label) in, the world cloud (x, y, z, batch, label = 17 B per point)
+    read and written once, two 64x64 u8 maps out."""
+    mm = mapper_tr.mapping_module
+    evs = []
+    for i in range(n_steps):
+        o = dict(obs_dev[i % len(obs_dev)])
+        torch.cuda._sleep(4_000_000)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        mapper_tr(o)
+        b.record()
+        evs.append((a, b))
+    torch.cuda.synchronize()
+    world_pts = mm.check_status()
+    us = 1e3 * sum(a.elapsed_time(b) for a, b in evs) / n_steps
+    H, W = mm._hw
+    bytes_step = B * (H * W * 5 + 2 * 64 * 64) + 2 * 17 * world_pts
+    ach = bytes_step / (us * 1e-6) / 1e9 if us > 0 else 0.0
+    traffic = pmc_traffic("rollout_pmc_traffic.json", ("mapper", "hbm_bytes_per_step_corrected")) if B == 4 else None
+    return {
+        "bound": "hbm", "achieved": round(ach, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+        "frac": round(ach / PEAK_HBM_GBS, 5), "traffic": traffic,
+        "kernel": "egocentric mapper (csrc/mapper.hip: unproject, keep-highest scatter-max, world merge, raster), "
+                  "all launches of one step",
+        "bytes_per_step": int(bytes_step), "us_per_step": round(us, 2), "world_points": int(world_pts), "envs": B,
+        "note": "launch-latency class: ~1 MB of algorithmic traffic per env-step (SURVEY section 8d)",
+    }
+
+
+def capture(policy, transforms, example, mode, rank):
+    """GraphedRollout in the wanted mode, falling back to one stream if the split capture fails."""
+    from ivln_ce_amd.graphed import GraphedRollout
+
+    for attempt in ([mode, False] if mode else [False]):
+        try:
+            runner = GraphedRollout(policy, transforms, example, deterministic=True, streams=attempt)
+            note = ("3 forked streams" if attempt is True else
+                    "3 graphs on 2 streams" if attempt == "split" else "1 stream")
+            return runner, note
+        except Exception as e:  # noqa: BLE001 - a capture problem must not cost the measurement
+            log(f"rank {rank}: graph capture ({attempt!r}) failed: {type(e).__name__}: {e}")
+            torch.cuda.synchronize()
+    return None, None
+
+
+def spawn_ranks(n):
+    """--gpus N without a launcher: start N ranks (one per GPU) through torch.distributed.run BEFORE this process
+    initialises HIP, stream their output through and exit with their status."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    if not env.get("IVLN_BENCH_ONE_DEVICE") and "--plumbing-only" not in sys.argv:
+        have = torch.cuda.device_count()  # does not initialise the runtime
+        if have < n:
+            log(f"--gpus {n} but only {have} visible device(s)")
+            return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("spawning", n, "ranks:", " ".join(cmd[1:]))
+    return subprocess.call(cmd, env=env)
+
+
+def plumbing_only(args, rank, world):
+    """Launch-path check without a GPU (tests/test_host_logic.py): rendezvous over gloo, barrier, max-over-ranks of
+    a dummy clock, rank 0 prints a line shaped like the real one but marked as NOT a measurement."""
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert int(t.item()) == world
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": None, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "plumbing_only": True, "data": "none (launch-path check, no GPU work)"}),
+              flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--envs", type=int, default=4, help="parallel envs per GPU (configs[1]: 4)")
+    ap.add_argument("--envs", type=int, default=4, help="parallel envs per GPU of the headline (configs[1]: 4)")
+    ap.add_argument("--pred-envs", type=int, default=8, help="envs per GPU of the pred-semantics leg (configs[2]: 8)")
     ap.add_argument("--pred-semantics", action="store_true",
-                    help="BASELINE configs[2]: RedNet-predicted semantics feed the mapper (not the headline workload; "
-                         "no CPU baseline / roofline legs)")
+                    help="make BASELINE configs[2] (RedNet-predicted semantics, --pred-envs envs) the headline `value`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pred-leg", action="store_true", help="skip the pred-semantics leg (extra JSON object)")
     ap.add_argument("--no-update", action="store_true", help="skip the DAgger update-step leg (extra JSON object)")
@@ -249,11 +396,18 @@ def main():
     ap.add_argument("--streams", action="store_true",
                     help="fork the three encoder branches onto side streams inside the graph (measured SLOWER on "
                          "ROCm 7.2: cross-queue dependencies cost more than the overlap wins)")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="exercise the launch / rendezvous path only (no GPU work, not a measurement)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.plumbing_only:
+        return plumbing_only(args, rank, world)
     if world > 1:
         import torch.distributed as dist
 
@@ -277,160 +431,150 @@ def main():
 
     from ivln_ce_amd.obs_transforms import GTSemanticsIterativeMapper, PredictedSemanticsIterativeMapper
 
-    B, K, W = args.envs, args.steps, args.warmup
-    cfg, policy = make_policy(dev)
-    pred = args.pred_semantics
-    mapper_tr = (PredictedSemanticsIterativeMapper if pred else GTSemanticsIterativeMapper).from_config(cfg)
-    n_pool = min(W + K, 240)
-    obs_cpu = gen_observations(B, n_pool, seed=1234 + rank, with_rgb=pred)
-    obs_dev = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in o.items()} for o in obs_cpu]
-    state = {"rnn": torch.zeros(B, 2, 512, device=dev), "prev": torch.zeros(B, 1, dtype=torch.long, device=dev)}
-
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
 
-    use_graph = not args.no_graph
-    if use_graph:
-        from ivln_ce_amd.graphed import GraphedRollout
-
-        log(f"rank {rank}: capturing the step graph")
-        mode = args.streams if (args.streams or args.single_stream) else "split"
-        runner, launch_note = None, None
-        for attempt in ([mode, False] if mode else [False]):
-            try:
-                runner = GraphedRollout(policy, [mapper_tr], obs_dev[0], deterministic=True, streams=attempt)
-                launch_note = ("3 forked streams" if attempt is True else
-                               "3 graphs on 2 streams" if attempt == "split" else "1 stream")
-                break
-            except Exception as e:  # noqa: BLE001 - a capture problem must not cost the measurement
-                log(f"rank {rank}: graph capture ({attempt!r}) failed: {type(e).__name__}: {e}")
-                torch.cuda.synchronize()
-        if runner is None:
-            use_graph = False
-
-    if use_graph:
-        def do_step(i):
-            runner.step(obs_dev[i % n_pool])
-    else:
-        def do_step(i):
-            rollout_step(mapper_tr, policy, obs_dev[i % n_pool], state)
-
-    log(f"rank {rank}: inputs resident, warm-up {W} steps")
-    for i in range(W):
-        do_step(i)
-    barrier()
-    log(f"rank {rank}: timing {K} steps")
-    t0 = time.perf_counter()
-    for i in range(K):
-        do_step(W + i)
-    barrier()
-    el = time.perf_counter() - t0
-    mapper_tr.mapping_module.check_status()
-    if world > 1:
-        t = torch.tensor([el], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-
-    log(f"rank {rank}: timed region {el:.3f}s")
-    # ---- DAgger update step (fwd + bwd + all-reduce + Adam): reported beside the headline ----
-    update = None
-    if not args.no_update and not pred:
-        if use_graph:
-            del runner  # graphs hold the activation pools
-        log(f"rank {rank}: update-step leg")
-        uel, uinfo = bench_update(policy, dev, world, barrier)
+    def max_over_ranks(seconds):
         if world > 1:
-            t = torch.tensor([uel], device=dev, dtype=torch.float64)
+            t = torch.tensor([seconds], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            uel = float(t.item())
-        update = {"value": round(world * uinfo["rows_per_step_per_gpu"] * uinfo["iters"] / uel, 1), "unit": "rows/s",
-                  "ms_per_update": round(1e3 * uel / uinfo["iters"], 3), "rows_per_update_per_gpu": uinfo["rows_per_step_per_gpu"],
-                  "what": f"DAgger update T={uinfo['T']} x N={uinfo['N']} per GPU from cached depth features: MapCMA forward "
-                          "with BPTT, inflection-weighted CE + progress monitor, HIP backward, "
-                          + ("one flat RCCL all-reduce, " if world > 1 else "") + "Adam",
-                  "roofline": uinfo["roofline"]}
-    # ---- roofline of the MFMA implicit-GEMM family: instrumented pass (not part of `value`) ----
-    roofline = None
-    if rank == 0 and not pred:
-        n_inst = min(20, K)
+            return float(t.item())
+        return seconds
+
+    K, W = args.steps, args.warmup
+    cfg, policy = make_policy(dev)
+    mode = False if args.no_graph else (True if args.streams else (False if args.single_stream else "split"))
+
+    def run_leg(pred, B, K, W, seed):
+        """Time K steps of one workload after W warm-up steps: barrier + synchronize on both sides, max over
+        ranks.  Returns the leg's dict of results and what the instrumented passes need."""
+        cls = PredictedSemanticsIterativeMapper if pred else GTSemanticsIterativeMapper
+        tr = cls.from_config(cfg)
+        n_pool = min(W + K, 240 if not pred else 32)
+        obs_cpu = gen_observations(B, n_pool, seed=seed + rank, with_rgb=pred)
+        obs_dev = to_dev(obs_cpu, dev)
+        state = {"rnn": torch.zeros(B, 2, 512, device=dev), "prev": torch.zeros(B, 1, dtype=torch.long, device=dev)}
+        runner, note = (None, None)
+        if not args.no_graph:
+            log(f"rank {rank}: capturing the {'pred-semantics ' if pred else ''}step graph ({B} envs)")
+            runner, note = capture(policy, [tr], obs_dev[0], mode, rank)
+        if runner is not None:
+            def do_step(i):
+                runner.step(obs_dev[i % n_pool])
+        else:
+            def do_step(i):
+                rollout_step(tr, policy, obs_dev[i % n_pool], state)
+        for i in range(W):
+            do_step(i)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(K):
+            do_step(W + i)
+        barrier()
+        el = max_over_ranks(time.perf_counter() - t0)
+        tr.mapping_module.check_status()
+        del runner  # graphs hold the activation pools
+        return {"el": el, "tr": tr, "obs_cpu": obs_cpu, "obs_dev": obs_dev, "state": state, "n_pool": n_pool,
+                "launch": ("hipGraph replay, " + note) if note else "eager"}
+
+    def instrumented_mfma(leg, n_inst, what, traffic):
+        """MFMA-family roofline of a leg: eager pass with an event pair per GEMM-family launch, the GPU parked on a
+        spin kernel while the host enqueues each step so that pairs time back-to-back kernels (what rocprofv3's
+        per-kernel durations show) and not the host's launch gaps.  Not part of any `value`."""
         with GemmTimer() as gt:
             for i in range(n_inst):
-                # eager launches are host-bound (~8 us each with the event pair): park the GPU on a spin
-                # kernel while the host enqueues the step, so the event pairs time back-to-back kernels
-                # (what rocprofv3's per-kernel durations show) and not the host's launch gaps
                 torch.cuda._sleep(12_000_000)
-                rollout_step(mapper_tr, policy, obs_dev[i % n_pool], state)
+                rollout_step(leg["tr"], policy, leg["obs_dev"][i % leg["n_pool"]], leg["state"])
             ms = gt.total_ms()
-        flops_per_step = gt.flops / n_inst
-        launches = len(gt.events) / n_inst
-        ach = (gt.flops / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
-        roofline = {
-            "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 5), "traffic": pmc_traffic(B),
-            "kernel": "fp32 MFMA family (k_gemm / k_gemm_vec / k_conv_direct): all conv/linear launches of one step",
-            "flops_per_step": int(flops_per_step), "launches_per_step": round(launches, 1),
-            "kernel_ms_per_step": round(ms / n_inst, 4),
-        }
+        return mfma_roofline(gt, ms, n_inst, traffic, what)
 
-    # ---- configs[2]: RedNet-predicted semantics feeding the mapper (extra object, not the headline) ----
+    head_pred = args.pred_semantics
+    B = args.pred_envs if head_pred else args.envs
+    log(f"rank {rank}: headline leg ({'configs[2] pred-semantics' if head_pred else 'configs[1] gt-semantics'}, {B} envs)")
+    head = run_leg(head_pred, B, K, W, seed=1234)
+    log(f"rank {rank}: timed region {head['el']:.3f}s")
+
+    roofline = mapper_roof = None
+    if rank == 0:
+        if head_pred:
+            roofline = instrumented_mfma(head, min(6, K), "RedNet + depth ResNet + map CNN launches of one step",
+                                         pmc_traffic(f"predsem_B{B}_pmc_traffic.json",
+                                                     ("mfma_family", "hbm_bytes_per_launch_corrected")))
+        else:
+            roofline = instrumented_mfma(head, min(20, K), "all conv/linear launches of one step",
+                                         pmc_traffic("rollout_pmc_traffic.json",
+                                                     ("mfma_family", "hbm_bytes_per_launch_corrected")) if B == 4 else None)
+            mapper_roof = mapper_roofline(head["tr"], head["obs_dev"], B)
+
+    # ---- configs[2]: RedNet-predicted semantics feeding the mapper, at its stated 8 envs ----
     pred_leg = None
-    if not pred and not args.no_pred_leg:
-        from ivln_ce_amd.graphed import GraphedRollout
+    if not head_pred and not args.no_pred_leg:
+        Bp, pk, pw = args.pred_envs, 30, 5
+        log(f"rank {rank}: pred-semantics leg ({Bp} envs)")
+        pl = run_leg(True, Bp, pk, pw, seed=4321)
+        pred_leg = {
+            "value": round(world * Bp * pk / pl["el"], 1), "unit": "env-steps/s",
+            "ms_per_step": round(1e3 * pl["el"] / pk, 3), "steps": pk, "warmup": pw, "envs_per_gpu": Bp,
+            "config": {"workload": f"BASELINE configs[2]: RedNet(rgb 224x224 -> 256x256, depth) -> arg-max labels -> "
+                                   f"egocentric mapper -> MapCMAPolicy.act, {Bp} envs per GPU",
+                       "launch": pl["launch"]},
+        }
+        if rank == 0:
+            pred_leg["roofline"] = instrumented_mfma(
+                pl, 4, "RedNet + depth ResNet + map CNN launches of one step",
+                pmc_traffic(f"predsem_B{Bp}_pmc_traffic.json", ("mfma_family", "hbm_bytes_per_launch_corrected")))
+            if world == 1 and not args.no_cpu_baseline:
+                log("cpu baseline (pred-semantics) ...")
+                pred_leg["cpu_baseline"] = cpu_baseline(pl["obs_cpu"], Bp, budget_s=12.0, pred=True)
+        del pl
 
-        log(f"rank {rank}: pred-semantics leg")
-        ptr = PredictedSemanticsIterativeMapper.from_config(cfg)
-        pobs = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in o.items()}
-                for o in gen_observations(B, 24, seed=4321 + rank, with_rgb=True)]
-        try:
-            prun = GraphedRollout(policy, [ptr], pobs[0], deterministic=True, streams="split")
-        except Exception as e:  # noqa: BLE001
-            log(f"rank {rank}: split capture failed for the pred-semantics leg ({type(e).__name__}: {e}); one stream")
-            torch.cuda.synchronize()
-            prun = GraphedRollout(policy, [ptr], pobs[0], deterministic=True, streams=False)
-        for i in range(6):
-            prun.step(pobs[i % 24])
-        barrier()
-        pk = 40
-        t0 = time.perf_counter()
-        for i in range(pk):
-            prun.step(pobs[(6 + i) % 24])
-        barrier()
-        pel = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([pel], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            pel = float(t.item())
-        pred_leg = {"value": round(world * B * pk / pel, 1), "unit": "env-steps/s", "ms_per_step": round(1e3 * pel / pk, 3),
-                    "steps": pk, "what": f"BASELINE configs[2]: RedNet(rgb 224x224 + depth) -> labels -> mapper -> "
-                                         f"MapCMAPolicy.act, {B} envs per GPU, graph replay"}
-        del prun
+    # ---- DAgger update step (fwd + bwd + all-reduce + Adam): reported beside the headline ----
+    update = None
+    if not args.no_update:
+        log(f"rank {rank}: update-step leg")
+        uel, uinfo = bench_update(policy, dev, world, barrier)
+        uel = max_over_ranks(uel)
+        update = {"value": round(world * uinfo["rows_per_step_per_gpu"] * uinfo["iters"] / uel, 1), "unit": "rows/s",
+                  "ms_per_update": round(1e3 * uel / uinfo["iters"], 3),
+                  "rows_per_update_per_gpu": uinfo["rows_per_step_per_gpu"],
+                  "what": f"DAgger update T={uinfo['T']} x N={uinfo['N']} per GPU from cached depth features (SURVEY 8d "
+                          "batch: inflection weights 3.2 from the targets, progress U(0,1)): MapCMA forward with BPTT, "
+                          "inflection-weighted CE + progress-monitor aux loss, HIP backward, "
+                          + ("one flat RCCL all-reduce, " if world > 1 else "") + "Adam",
+                  "roofline": uinfo["roofline"]}
 
+    why = ("headline = configs[2] by request (--pred-semantics)" if head_pred else
+           "headline = configs[1], the single-GPU configuration BASELINE.json's env-steps/s metric is quoted on "
+           "(configs[0] is the CPU plumbing case); configs[2] at its stated 8 envs is `pred_semantics_step` with its "
+           "own roofline and cpu_baseline, the DAgger update of configs[3]'s per-GPU shard is `update_step`")
     out = {
-        "metric": METRIC, "value": round(world * B * K / el, 2), "unit": "env-steps/s", "n_gpus": world,
-        "steps": K, "warmup": W, "ms_per_step": round(1e3 * el / K, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "metric": METRIC, "value": round(world * B * K / head["el"], 2), "unit": "env-steps/s", "n_gpus": world,
+        "steps": K, "warmup": W, "ms_per_step": round(1e3 * head["el"] / K, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
             "workload": ("BASELINE configs[2]: MapCMA pred-semantics eval step = RedNet(rgb 224x224, depth) + egocentric "
-                         "mapper + MapCMAPolicy.act, " if pred else
+                         "mapper + MapCMAPolicy.act, " if head_pred else
                          "BASELINE configs[1]: MapCMA gt-semantics eval step = egocentric mapper + MapCMAPolicy.act, ")
-                        + f"{B} parallel envs per GPU, 256x256 depth + semantic12, 80-token instruction, random-init "
-                        "weights of the reference architecture",
+                        + f"{B} parallel envs per GPU, 256x256 depth" + (" + 224x224 rgb" if head_pred else " + semantic12")
+                        + ", 80-token instruction, random-init weights of the reference architecture; " + why,
             "envs_per_gpu": B, "parallelism": f"dp{world} (envs sharded, no data-path collective)",
-            "launch": ("hipGraph replay, " + launch_note) if use_graph else "eager",
+            "launch": head["launch"],
         },
         "roofline": roofline,
     }
+    if mapper_roof is not None:
+        out["mapper_roofline"] = mapper_roof
     if update is not None:
         out["update_step"] = update
     if pred_leg is not None:
         out["pred_semantics_step"] = pred_leg
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline and not pred:
+        if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline ...")
-            out["cpu_baseline"] = cpu_baseline(obs_cpu, B)
+            out["cpu_baseline"] = cpu_baseline(head["obs_cpu"], B, pred=head_pred)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -248,7 +248,10 @@ class IWTrajectoryDataset(torch.utils.data.IterableDataset):
                 if len(self.load_ordering) == 0:
                     break
                 new_preload.append(self.store.get(self.load_ordering.pop()))
-                lengths.append(len(new_preload[-1][1]))
+                # reference quirk, reproduced (dagger_trainer.py:165): the "length" it sorts a preload by is
+                # len(record[0]) = the number of observation KEYS, identical for every record, so the order within
+                # a preload is the random `sort_priority` alone (pinned by tests/golden/collate_golden.json)
+                lengths.append(len(new_preload[-1][0]))
             sort_priority = list(range(len(lengths)))
             random.shuffle(sort_priority)
             order = sorted(range(len(lengths)), key=lambda k: (lengths[k], sort_priority[k]))
@@ -641,7 +644,15 @@ class DaggerTrainer(BaseVLNCETrainer):
     def _update_dataset(self, data_it, save_tour_idx_data=False):
         """dagger_trainer.py:251-504 / iterative_collection_dagger_trainer.py:131-397: roll the policy out with
         beta-mixed expert actions, cache the frozen encoders' features through forward hooks, store finished
-        trajectories; with `save_tour_idx_data` also the {tour_id: [record indices]} table, which is returned."""
+        trajectories; with `save_tour_idx_data` also the {tour_id: [record indices]} table, which is returned.
+
+        The episodic flow follows the reference statement by statement and is pinned to it by
+        tests/golden/rollout_golden.json (the reference's own `_update_dataset` on a scripted env): beta = p^it
+        with 0^0 = 0 (:295-299), `where(rand < beta, expert, policy)` (:423-427; the draw comes from the host
+        generator so that a seeded run is reproducible whatever the device), expert -1 => step with action 0 and
+        drop the episode (:469-472, 352), at beta == 1 envs whose next episode was already collected are paused and
+        every per-env state row compacted (:312-316, 392-412), a pass over the envs stores EVERY finished episode
+        even past `update_size` (:349-386)."""
         cfg = self.config
         envs = construct_envs(cfg, None, rank=self.rank, world=self.world)
         expert_uuid = cfg.IL.DAGGER.expert_policy_sensor_uuid
@@ -657,6 +668,7 @@ class DaggerTrainer(BaseVLNCETrainer):
         dones = [False] * n
         p = cfg.IL.DAGGER.p
         beta = 0.0 if p == 0.0 else p ** data_it
+        ensure_unique_episodes = beta == 1.0
         feats = {}
         hooks = []
         cache_depth = not cfg.MODEL.DEPTH_ENCODER.trainable  # dagger_trainer.py:317-323: frozen encoders only
@@ -667,6 +679,7 @@ class DaggerTrainer(BaseVLNCETrainer):
             hooks.append(self.policy.net.rgb_encoder.cnn.register_forward_hook(
                 lambda m, i, o: feats.__setitem__("rgb", o.detach().cpu())))
         collected, start_id = 0, len(self.store)
+        ep_ids_collected = {ep.episode_id for ep in envs.current_episodes()} if ensure_unique_episodes else None
         tours_to_idxs = defaultdict(list)
         if save_tour_idx_data:
             tours_to_idxs.update(self.store.get_tour_index())
@@ -675,8 +688,12 @@ class DaggerTrainer(BaseVLNCETrainer):
         target = max(1, cfg.IL.DAGGER.update_size // self.world)
         with torch.no_grad():
             while collected < target:
+                envs_to_pause = []
+                current_episodes = envs.current_episodes() if ensure_unique_episodes else None
                 for i in range(envs.num_envs):
-                    if dones[i] and not skips[i] and collected < target:  # never overshoot: ranks must agree
+                    # data-parallel ranks stop exactly at their share (no reference counterpart; a single process
+                    # stores every episode that finished in this pass, like the reference)
+                    if dones[i] and not skips[i] and (self.world == 1 or collected < target):
                         ep = episodes[i]
                         traj_obs = batch_obs([s[0] for s in ep], device=torch.device("cpu"))
                         del traj_obs[expert_uuid]
@@ -685,9 +702,26 @@ class DaggerTrainer(BaseVLNCETrainer):
                                        tour_id=ep[0][3])
                         tours_to_idxs[str(ep[0][3])].append(start_id + collected)
                         collected += 1
+                        if ensure_unique_episodes:
+                            if current_episodes[i].episode_id in ep_ids_collected:
+                                envs_to_pause.append(i)
+                            else:
+                                ep_ids_collected.add(current_episodes[i].episode_id)
                     if dones[i]:
                         episodes[i] = []
-                if collected >= target:
+                if ensure_unique_episodes and envs_to_pause:
+                    keep = [i for i in range(envs.num_envs) if i not in envs_to_pause]
+                    envs, rnn_states, not_done_masks, prev_actions, batch, _ = self._pause_envs(
+                        envs_to_pause, envs, rnn_states, not_done_masks, prev_actions, batch)
+                    # per-env host state follows the same compaction
+                    observations = [observations[i] for i in keep]
+                    episodes = [episodes[i] for i in keep]
+                    skips = [skips[i] for i in keep]
+                    dones = [dones[i] for i in keep]
+                    tour_masks = tour_masks[keep]
+                    if envs.num_envs == 0:
+                        break
+                if self.world > 1 and collected >= target:
                     break
                 if self.tour_masked_maps:  # tour-by-tour collection: the policy sees episode AND tour boundaries
                     actions, rnn_states = self.policy.act_iterative(
@@ -697,24 +731,28 @@ class DaggerTrainer(BaseVLNCETrainer):
                     actions, rnn_states = self.policy.act(batch, rnn_states, prev_actions, not_done_masks,
                                                           deterministic=False)
                 expert = batch[expert_uuid].long()
-                actions = torch.where(torch.rand_like(actions, dtype=torch.float) < beta, expert, actions)
+                draw = torch.rand(actions.shape, dtype=torch.float).to(actions.device)
+                actions = torch.where(draw < beta, expert, actions)
                 occ = batch["occupancy_map"].cpu().numpy() if "occupancy_map" in batch else None
                 sem = batch["semantic_map"].cpu().numpy() if "semantic_map" in batch else None
+                if (occ is None) != (sem is None):
+                    raise RuntimeError("either both map keys should exist in the batch or neither")
                 prev_cpu = prev_actions.cpu()
-                expert_cpu = expert.cpu()
+                expert_cpu = batch[expert_uuid].cpu()
                 tours_now = [getattr(e, "tour_id", None) for e in envs.current_episodes()]
                 for i in range(envs.num_envs):
                     o = dict(observations[i])
+                    if "rgb" in feats:
+                        o["rgb_features"] = feats["rgb"][i].clone()
+                        o.pop("rgb", None)
                     if cache_depth:
                         o["depth_features"] = feats["depth"][i].clone()
                         o.pop("depth", None)
-                    if "rgb" in feats:
-                        o["rgb_features"] = feats["rgb"][i].clone()
                     if occ is not None:
                         o["occupancy_map"], o["semantic_map"] = occ[i].copy(), sem[i].copy()
-                    for k in ["semantic", "semantic12", "world_robot_pose", "world_robot_orientation", "env_name",
-                              "rgb", "not_done_masks"]:
-                        o.pop(k, None)
+                        for k in ["semantic", "semantic12", "world_robot_pose", "world_robot_orientation", "env_name",
+                                  "rgb"]:
+                            o.pop(k, None)
                     episodes[i].append((o, prev_cpu[i].item(), expert_cpu[i].item(), tours_now[i]))
                 skips_t = expert == -1
                 actions = torch.where(skips_t, torch.zeros_like(actions), actions)

@@ -84,3 +84,24 @@ class MapperRef:
         s = np.zeros((n,), np.uint8)
         lib().mapper_ref_world_get(self.h, _p(xyz), _p(b), _p(s))
         return xyz, b, s
+
+    # -- known-map mode (mapper.py:851-881) --------------------------------------------------------------
+    def known_step(self, clouds, env_names, pose, orientation, not_done):
+        """One step of the known-map mapper: drop the clouds of finished envs, load `clouds[env_name]` =
+        (xyz f32 (n,3), semantics u8 (n,)) for each of them in batch order, raster."""
+        pose = np.ascontiguousarray(pose, np.float32)
+        nd = np.ascontiguousarray(not_done, np.uint8).reshape(-1)
+        B = pose.shape[0]
+        _, rot = self.frames(pose, orientation)
+        L = lib()
+        L.mapper_ref_clear_done(self.h, B, _p(nd))
+        for b in range(B):
+            if nd[b] == 0:
+                xyz, sem = clouds[env_names[b]]
+                xyz = np.ascontiguousarray(xyz, np.float32)
+                sem = np.ascontiguousarray(sem).astype(np.uint8)
+                L.mapper_ref_load_known(self.h, b, _p(xyz), _p(sem), len(sem))
+        occ = np.zeros((B, self.rows, self.cols), np.uint8)
+        sem_o = np.zeros((B, self.rows, self.cols), np.uint8)
+        L.mapper_ref_raster(self.h, B, _p(pose), _p(np.ascontiguousarray(rot)), _p(occ), _p(sem_o))
+        return occ, sem_o

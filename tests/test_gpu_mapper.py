@@ -212,3 +212,37 @@ def test_hip_mapper_edge_cases_match_oracle(case):
         assert np.array_equal(mem.semantic.cpu().numpy(), sem_r), f"{case}: semantic step {t}"
     if case in ("all_invalid", "all_saturated"):
         assert n == 0 and int(mem.occupancy.sum()) == 0
+
+
+@pytest.mark.parametrize("plugin,sub", [("GTSemanticsKnownMapper", "gt_semantics"),
+                                        ("PredictedSemanticsKnownMapper", "predicted_semantics")])
+def test_known_mapper_plugins_match_reference_golden(plugin, sub, tmp_path, monkeypatch):
+    """`*KnownMapper.from_config(cfg)` -> forward(dict), the registry path a trainer takes (obs_transforms.py:159-176),
+    against the reference's own `create_known_mapper` run (tests/golden/known_map.npz): maps bit-exact every step.
+    The factories read `data/known_maps/{gt,predicted}_semantics/{env_name}.npz` relative to the working directory
+    (mapper.py:1011-1028), so the scene files are laid out under a temporary cwd."""
+    from ivln_ce_amd.config import get_config
+    from ivln_ce_amd.registry import baseline_registry
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "known_map.npz"))
+    names = [str(x) for x in g["env_names"]]
+    d = tmp_path / "data" / "known_maps" / sub
+    d.mkdir(parents=True)
+    for n in set(names):
+        np.savez(d / f"{n}.npz", xyz=g[f"scene_{n}_xyz"], semantics=g[f"scene_{n}_semantics"])
+    monkeypatch.chdir(tmp_path)
+    dev = torch.device("cuda:0")
+    tr = baseline_registry.get_obs_transformer(plugin).from_config(get_config())
+    B = int(g["B"])
+    for t in range(int(g["steps"])):
+        obs = {"depth": torch.zeros(B, 256, 256, 1, device=dev),
+               "world_robot_pose": torch.from_numpy(g[f"pose_{t}"]).to(dev),
+               "world_robot_orientation": torch.from_numpy(g[f"orientation_{t}"]).to(dev),
+               "not_done_masks": torch.from_numpy(g[f"not_done_{t}"]).to(dev), "env_name": list(names),
+               "semantic12": torch.zeros(B, 256, 256, 1, dtype=torch.uint8, device=dev)}
+        out = tr(obs)
+        n = tr.mapping_module.check_status()
+        assert "env_name" not in out and "world_robot_pose" not in out and "semantic12" not in out
+        assert np.array_equal(out["occupancy_map"].cpu().numpy(), g[f"occ_{t}"]), f"occupancy step {t}"
+        assert np.array_equal(out["semantic_map"].cpu().numpy(), g[f"sem_{t}"]), f"semantic step {t}"
+        assert n == int(g[f"world_n_{t}"])

@@ -1,0 +1,143 @@
+"""BASELINE configs[2] at its stated size: MapCMA with RedNet-predicted semantics, iterative maps, 8 envs on one
+GPU, through the registry plugin `PredictedSemanticsIterativeMapper` (reference: obs_transforms.py:136-157,
+mapper.py:703-800, rednet.py:190-263).
+
+Contract ("RedNet => labels"): RedNet scores within 3e-4 abs of the fp32 oracle and >= 99.9 %
+label agreement at B = 8, 256x256; the mapper bit-exact GIVEN the label images the HIP RedNet produced; the policy
+within the usual 2e-4 / 1e-4; hipGraph replay bit-identical to eager launches."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+DEV = torch.device("cuda:0")
+B = 8
+
+
+def _cfg():
+    from ivln_ce_amd.config import get_config
+
+    return get_config(opts=[
+        "MODEL.policy_name", "MapCMAPolicy", "MODEL.INSTRUCTION_ENCODER.use_pretrained_embeddings", False,
+        "MODEL.DEPTH_ENCODER.ddppo_checkpoint", "NONE", "NUM_ENVIRONMENTS", B,
+        "RL.POLICY.OBS_TRANSFORMS.ENABLED_TRANSFORMS", ["PredictedSemanticsIterativeMapper"],
+    ])
+
+
+def _plugin(cfg, example):
+    """The obs-transform plugin with deterministic RedNet weights (no checkpoint travels to the GPU box)."""
+    from det_init import det_fill
+
+    from ivln_ce_amd.obs_transforms import get_active_obs_transforms
+
+    (tr,) = get_active_obs_transforms(cfg)
+    assert type(tr).__name__ == "PredictedSemanticsIterativeMapper"
+    tr.setup_mapping_module(example)
+    ps = tr.mapping_module.semantics_module
+    ps.setup()
+    det_fill(ps.model, seed=1, conv_gain=0.6)
+    ps.model.invalidate_folded()
+    return tr
+
+
+def _policy():
+    from test_gpu_policy import make_policy
+
+    return make_policy()
+
+
+def _obs(steps, seed):
+    from ivln_ce_amd.synthetic import SyntheticRollout
+
+    roll = SyntheticRollout(B=B, seed=seed, with_rgb=True)
+    cpu = [roll.step() for _ in range(steps)]
+    dev = [{k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in o.items()} for o in cpu]
+    return cpu, dev
+
+
+def test_predsem_plugin_B8_rednet_mapper_policy_match_oracle():
+    from det_init import det_fill
+
+    from oracle.mapper_ref import MapperRef
+    from oracle.policy_ref import MapCMAPolicyRef
+    from oracle.rednet_ref import RedNetRef, predict_semantics_ref
+
+    torch.set_num_threads(8)
+    cfg = _cfg()
+    cpu, dev = _obs(3, seed=77)
+    tr = _plugin(cfg, dev[0])
+    pol = _policy()
+    ref_net = det_fill(RedNetRef(), seed=1, conv_gain=0.6).eval()
+    ref_pol = det_fill(MapCMAPolicyRef(), seed=0).eval()
+    ref_map = MapperRef(256, 256)
+    ps = tr.mapping_module.semantics_module
+    rnn = torch.zeros(B, 2, 512, device=DEV)
+    prev = torch.zeros(B, 1, dtype=torch.long, device=DEV)
+    rnn_r, prev_r = torch.zeros(B, 2, 512), torch.zeros(B, 1, dtype=torch.long)
+    for t, (o, d) in enumerate(zip(cpu, dev)):
+        labels = ps(d).cpu()  # the label images the mapper inside the plugin will see (deterministic kernels)
+        if t == 0:  # RedNet at B = 8, full size, against the fp32 oracle
+            scores_ref, labels_ref, _ = predict_semantics_ref(ref_net, o["rgb"], o["depth"])
+            scores = ps.scores(d).cpu()
+            err = float((scores - scores_ref).abs().max())
+            agree = float((labels == labels_ref).float().mean())
+            print(f"rednet B=8 256x256: max|err|={err:.3e} labels agree={agree:.5f}")
+            assert err < 3e-4 and agree >= 0.999
+        batch = tr(dict(d))
+        for k in ["world_robot_orientation", "world_robot_pose", "semantic12", "env_name"]:
+            assert k not in batch
+        tr.mapping_module.check_status()
+        occ_r, sem_r = ref_map.step(o["depth"].numpy(), labels.numpy(), o["world_robot_pose"].numpy(),
+                                    o["world_robot_orientation"].numpy(), o["not_done_masks"].numpy())
+        assert np.array_equal(batch["occupancy_map"].cpu().numpy(), occ_r), f"occupancy step {t}"
+        assert np.array_equal(batch["semantic_map"].cpu().numpy(), sem_r), f"semantic map step {t}"
+        with torch.no_grad():
+            feats, rnn_next = pol.net(batch, rnn, prev, batch["not_done_masks"])
+            logits = pol.action_distribution.raw_logits(feats)
+            act, _ = pol.act(batch, rnn, prev, batch["not_done_masks"], deterministic=True)
+            ob_r = {"depth": o["depth"], "instruction": o["instruction"], "occupancy_map": torch.from_numpy(occ_r),
+                    "semantic_map": torch.from_numpy(sem_r)}
+            lr, sr, fr = ref_pol.logits(ob_r, rnn_r, prev_r, o["not_done_masks"])
+        assert float((feats.cpu() - fr).abs().max()) < 2e-4
+        assert float((rnn_next.cpu() - sr).abs().max()) < 2e-4
+        assert float((logits.cpu() - lr).abs().max()) < 1e-4
+        top2 = lr.topk(2, -1).values
+        safe = (top2[:, 0] - top2[:, 1]) > 1e-4  # rows whose arg-max cannot flip within the tolerance
+        assert torch.equal(act.cpu()[safe, 0], lr.argmax(-1)[safe])
+        rnn, prev = rnn_next, act
+        rnn_r, prev_r = sr, act.cpu()
+
+
+@pytest.mark.parametrize("streams", ["split", False])
+def test_predsem_graph_replay_is_bit_identical_to_eager_B8(streams):
+    from ivln_ce_amd.graphed import GraphedRollout
+
+    cfg = _cfg()
+    _, dev = _obs(5, seed=78)
+    pol = _policy()
+    tr_e = _plugin(cfg, dev[0])
+    rnn = torch.zeros(B, 2, 512, device=DEV)
+    prev = torch.zeros(B, 1, dtype=torch.long, device=DEV)
+    eager = []
+    for o in dev:
+        b = tr_e(dict(o))
+        with torch.no_grad():
+            a, rnn = pol.act(b, rnn, prev, b["not_done_masks"], deterministic=True)
+        prev = a
+        eager.append((a.clone(), rnn.clone(), b["occupancy_map"].clone(), b["semantic_map"].clone()))
+    tr_g = _plugin(cfg, dev[0])
+    runner = GraphedRollout(pol, [tr_g], dev[0], deterministic=True, streams=streams)
+    tr_g.mapping_module.reset()
+    runner.reset_state()
+    for t, o in enumerate(dev):
+        a = runner.step(o)
+        torch.cuda.synchronize()
+        mem = tr_g.mapping_module.map_memory
+        assert torch.equal(a, eager[t][0]), f"actions step {t}"
+        assert torch.equal(runner.rnn_states, eager[t][1]), f"rnn step {t}"
+        assert torch.equal(mem.occupancy, eager[t][2]) and torch.equal(mem.semantic, eager[t][3]), f"maps step {t}"
+    tr_g.mapping_module.check_status()

@@ -348,3 +348,82 @@ def test_two_rank_dagger_train_keeps_replicas_identical(tmp_path):
     r = _run_two_ranks_one_gpu(tmp_path, 29563, "dagger")
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "dist smoke ok: dagger world 2" in r.stdout
+
+
+@pytest.mark.gpu
+def test_update_at_bench_shape_T64_N8_matches_oracle():
+    """The benched update shape (T = 64 x N = 8 per GPU, configs[3]'s per-rank shard) against the torch-CPU
+    oracle's autograd: loss, aux loss, logits and every parameter's gradient norm.  Unequal trajectory lengths
+    (zero-weight padded tail rows), inflection weights, 80-token instructions trimmed on the host."""
+    from det_init import det_fill
+    from test_gpu_policy import make_policy
+
+    from ivln_ce_amd.aux_losses import AuxLosses
+    from ivln_ce_amd.utils import trim_instruction_padding
+    from oracle.policy_ref import MapCMAPolicyRef
+
+    torch.set_num_threads(8)
+    T, N = 64, 8
+    TN = T * N
+    g = torch.Generator().manual_seed(64)
+    lens = [64, 64, 51, 40, 64, 33, 64, 57]
+    instr = torch.zeros(N, 200)
+    for n in range(N):
+        L = 80 - 7 * n
+        instr[n, :L] = torch.randint(2, 2504, (L,), generator=g).float()
+    obs = {"depth_features": torch.randn(TN, 128, 4, 4, generator=g),
+           "occupancy_map": (torch.rand(TN, 64, 64, generator=g) < 0.3).float(),
+           "semantic_map": torch.randint(0, 13, (TN, 64, 64), generator=g).float(),
+           "instruction": instr.repeat(T, 1), "progress": torch.rand(TN, 1, generator=g)}
+    prev = torch.randint(0, 4, (TN, 1), generator=g)
+    nd = torch.ones(T, N, dtype=torch.uint8)
+    nd[0] = 0
+    nd = nd.view(-1, 1)
+    tgt = torch.randint(0, 4, (T, N), generator=g)
+    infl = torch.ones(T, N, dtype=torch.bool)
+    infl[1:] = tgt[1:] != tgt[:-1]
+    w = torch.where(infl, torch.tensor(3.2), torch.tensor(1.0))
+    for n, L in enumerate(lens):  # collate_fn pads finished trajectories: obs 1.0, actions / weights 0
+        w[L:, n] = 0
+        tgt[L:, n] = 0
+        for k in obs:
+            v = obs[k].view(T, N, *obs[k].shape[1:])
+            v[L:, n] = 1.0
+        prev.view(T, N)[L:, n] = 0
+    ref = det_fill(MapCMAPolicyRef(use_pm=True), seed=0).train()
+    loss_r, act_r, aux_r, logits_r = ref.update_loss(obs, prev, nd, tgt, w)
+    loss_r.backward()
+    gref = {k: float(p.grad.norm()) for k, p in ref.named_parameters() if p.grad is not None}
+
+    pol = make_policy(use_pm=True, train=True)
+    dobs = {k: v.to(DEV) for k, v in trim_instruction_padding(dict(obs), first_rows=N).items()}
+    assert dobs["instruction"].shape[1] == 80
+    AuxLosses.activate()
+    AuxLosses.clear()
+    try:
+        h0 = torch.zeros(N, 2, 512, device=DEV)
+        dist, _ = pol.build_distribution(dobs, h0, prev.to(DEV), nd.to(DEV))
+        logits = dist.logits.view(T, N, -1)
+        ce = F.cross_entropy(logits.permute(0, 2, 1), tgt.to(DEV), reduction="none")
+        wd = w.to(DEV)
+        action_loss = ((wd * ce).sum(0) / wd.sum(0)).mean()
+        aux = AuxLosses.reduce((wd > 0).view(-1))
+        loss = action_loss + aux
+        loss.backward()
+    finally:
+        AuxLosses.deactivate()
+    live = (w > 0).view(T, N, 1).expand_as(logits_r)
+    err = float((logits.detach().cpu() - logits_r.detach())[live].abs().max())
+    print(f"T64xN8: loss {float(loss):.7f} ref {float(loss_r):.7f} aux {float(aux):.7f} ref {float(aux_r):.7f} "
+          f"logits max|err| {err:.2e}")
+    assert err < 1e-4
+    assert abs(float(loss) - float(loss_r)) < 2e-5 and abs(float(aux) - float(aux_r)) < 2e-5
+    bad = []
+    for k, p in pol.named_parameters():
+        if not p.requires_grad or k not in gref:
+            continue
+        got = float(p.grad.norm())
+        noise = 2e-5 if (".conv.0.bias" in k and "map_encoder" in k) else 1e-7
+        if not (abs(got - gref[k]) / max(1e-6, abs(gref[k])) < 1e-3 or abs(got - gref[k]) < noise):
+            bad.append(f"{k}: {got:.6e} ref {gref[k]:.6e}")
+    assert not bad, "\n".join(bad)

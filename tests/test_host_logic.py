@@ -2,12 +2,15 @@
 collate / inflection weights / block shuffle, trajectory store, t-nDTW known answers, synthetic env."""
 import os
 import random
+import sys
 
 import numpy as np
 import pytest
 import torch
 
 import ivln_ce_amd  # noqa: F401
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from ivln_ce_amd.config import Config, get_config
 
 
@@ -345,3 +348,109 @@ def test_greedy_bin_packing_properties():
                 assert t not in seen, "a tour was split inside its row"
                 seen.add(t)
                 last = t
+
+
+def test_bench_gpus_flag_spawns_that_many_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must start two ranks itself (torch.distributed.run,
+    before the parent touches a GPU) and rank 0's line must say n_gpus 2.  --plumbing-only keeps the ranks off the
+    GPU (there is none here): rendezvous, barrier and the max-over-ranks reduction still run."""
+    import json
+    import subprocess
+    import sys
+
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--plumbing-only"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(line) for line in r.stdout.splitlines() if line.startswith("{")]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["plumbing_only"] is True
+    assert lines[0]["value"] is None  # never mistaken for a measurement
+    # under a launcher (WORLD_SIZE set) the flag does not spawn again
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--plumbing-only"], env=env,
+                        capture_output=True, text=True, timeout=300)
+    assert r1.returncode == 0 and json.loads(r1.stdout.splitlines()[-1])["n_gpus"] == 1
+
+
+def _np(d):
+    import numpy as np
+
+    return np.array(d["data"], dtype=np.dtype(d["dtype"])).reshape(d["shape"])
+
+
+@pytest.mark.parametrize("case", ["teacher_forcing_unique", "beta_quarter", "policy_only"])
+def test_dagger_rollout_logic_matches_reference_run(case, tmp_path, monkeypatch):
+    """A18: `DaggerTrainer._update_dataset` against what the REFERENCE's own `_update_dataset` + `_pause_envs`
+    stored, stepped and fed to `policy.act` on the same scripted env / stand-in policy
+    (tests/golden/gen_rollout_golden.py -> rollout_golden.json): beta-mixing, expert -1 skip, pause compaction at
+    beta == 1, stored-trajectory contents.  Host logic only - runs on the CPU."""
+    import json
+
+    import numpy as np
+    import torch
+
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import rollout_script as RS
+
+    from ivln_ce_amd import trainers
+    from ivln_ce_amd.config import get_config
+
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "rollout_golden.json")))[case]
+    p, data_it, update_size, seed = RS.CASES[case]
+    assert (g["p"], g["data_it"], g["update_size"], g["seed"]) == (p, data_it, update_size, seed)
+    cfg = get_config(opts=["IL.DAGGER.p", p, "IL.DAGGER.update_size", update_size])
+    tr = trainers.DaggerTrainer.__new__(trainers.DaggerTrainer)  # no GPU needed for the host logic
+    tr.config, tr.device, tr.obs_transforms = cfg, torch.device("cpu"), []
+    tr.rank, tr.local_rank, tr.world = 0, 0, 1
+    tr.policy = RS.ScriptedPolicy()
+    tr.store = trainers.TrajectoryStore(str(tmp_path / "traj"))
+    envs = RS.ScriptedEnvs(RS.SCRIPTS)
+    monkeypatch.setattr(trainers, "construct_envs", lambda *a, **k: envs)
+    torch.manual_seed(seed)
+    n = tr._update_dataset(data_it)
+    assert n == len(g["records"]) == len(tr.store)
+    assert envs.action_log == g["env_actions"]          # what the simulator was told to do, step by step
+    assert tr.policy.calls == g["policy_calls"]         # rows / masks / previous actions / compacted state per act()
+    for i, rec in enumerate(g["records"]):
+        obs, prev, oracle = tr.store.get(i)
+        assert sorted(obs) == sorted(rec["obs"]), (sorted(obs), sorted(rec["obs"]))
+        for k, v in rec["obs"].items():
+            ref = _np(v)
+            assert obs[k].dtype == ref.dtype and np.array_equal(obs[k], ref), (i, k)
+        assert np.array_equal(prev, _np(rec["prev_actions"])) and np.array_equal(oracle, _np(rec["oracle_actions"]))
+
+
+def test_collate_block_shuffle_and_iw_dataset_match_reference_run(tmp_path):
+    """A19: `collate_fn`, `_block_shuffle`, `IWTrajectoryDataset` against the reference's own functions
+    (gen_rollout_golden.py -> collate_golden.json): padded time-major batch, inflection weights, and the ORDER a
+    seeded dataset yields trajectories in (incl. the reference's quirk of sorting a preload by len(obs dict))."""
+    import json
+    import random
+
+    import numpy as np
+    import torch
+
+    from ivln_ce_amd import trainers
+
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "collate_golden.json")))
+    t = lambda d: torch.from_numpy(_np(d))  # noqa: E731
+    samples = [({k: t(v) for k, v in s["obs"].items()}, t(s["prev"]), t(s["oracle"]), t(s["weights"]))
+               for s in g["collate"]["samples"]]
+    obs_b, prev_b, nd_b, corr_b, w_b = trainers.collate_fn(samples)
+    out = g["collate"]["out"]
+    for k, v in out["obs"].items():
+        assert torch.equal(obs_b[k], t(v)) and obs_b[k].dtype == t(v).dtype, k
+    for got, key in [(prev_b, "prev"), (nd_b, "not_done"), (corr_b, "oracle"), (w_b, "weights")]:
+        assert torch.equal(got, t(out[key])) and got.dtype == t(out[key]).dtype, key
+    for c in g["block_shuffle"]:
+        random.seed(c["seed"])
+        assert trainers._block_shuffle(list(range(c["n"])), c["block"]) == c["out"]
+    store = trainers.TrajectoryStore(str(tmp_path / "iw"))
+    for i, tj in enumerate(g["trajectories"]):
+        store.put(i, {k: _np(v) for k, v in tj["obs"].items()}, _np(tj["prev"]), _np(tj["oracle"]))
+    for c in g["iw_dataset"]:
+        random.seed(c["seed"])
+        ds = trainers.IWTrajectoryDataset(store, c["use_iw"], c["coef"], batch_size=c["batch_size"])
+        assert ds.length == c["length"]
+        got = [{"id": int(obs["instruction"][0, 0]) - 1, "weights": [float(x) for x in w]} for obs, _, _, w in ds]
+        assert got == c["yielded"]

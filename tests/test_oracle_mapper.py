@@ -39,3 +39,19 @@ def test_frames_match_reference_trig():
         T, rot = MapperRef.frames(g[f"pose_{t}"], g[f"orientation_{t}"])
         assert np.array_equal(T.view(np.uint32), g[f"T_{t}"].view(np.uint32))
         assert np.array_equal(rot.view(np.uint32), g[f"rot_{t}"].view(np.uint32))
+
+
+def test_oracle_known_map_mode_matches_reference_golden():
+    """Known-map mode of the C oracle against the reference's own `create_known_mapper` run
+    (tests/golden/gen_known_map_golden.py): maps bit-exact every step, world-cloud size, two envs sharing a scene,
+    reloads on reset."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "known_map.npz"))
+    names = [str(x) for x in g["env_names"]]
+    clouds = {n: (g[f"scene_{n}_xyz"], g[f"scene_{n}_semantics"]) for n in set(names)}
+    ref = MapperRef(8, 8)
+    for t in range(int(g["steps"])):
+        occ, sem = ref.known_step(clouds, names, g[f"pose_{t}"], g[f"orientation_{t}"], g[f"not_done_{t}"])
+        assert np.array_equal(occ, g[f"occ_{t}"]), f"occupancy step {t}"
+        assert np.array_equal(sem, g[f"sem_{t}"]), f"semantic step {t}"
+        assert ref.world()[0].shape[0] == int(g[f"world_n_{t}"])
+        assert np.array_equal(ref.world()[1], g[f"world_b_{t}"])
