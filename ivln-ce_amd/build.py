@@ -15,6 +15,7 @@ SOURCES = {
     "gemm_conv.hip": [],
     "conv_direct.hip": [],
     "gemm_vec.hip": [],
+    "conv_gn.hip": [],
     "nn_ops.hip": [],
     "train_ops.hip": [],
     "dtw.cpp": [],

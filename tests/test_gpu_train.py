@@ -413,7 +413,8 @@ def test_update_at_bench_shape_T64_N8_matches_oracle():
     finally:
         AuxLosses.deactivate()
     live = (w > 0).view(T, N, 1).expand_as(logits_r)
-    err = float((logits.detach().cpu() - logits_r.detach())[live].abs().max())
+    # Categorical stores normalised logits (log-probs); the oracle returns the raw head output
+    err = float((torch.log_softmax(logits.detach().cpu(), -1) - torch.log_softmax(logits_r.detach(), -1))[live].abs().max())
     print(f"T64xN8: loss {float(loss):.7f} ref {float(loss_r):.7f} aux {float(aux):.7f} ref {float(aux_r):.7f} "
           f"logits max|err| {err:.2e}")
     assert err < 1e-4
@@ -423,7 +424,9 @@ def test_update_at_bench_shape_T64_N8_matches_oracle():
         if not p.requires_grad or k not in gref:
             continue
         got = float(p.grad.norm())
-        noise = 2e-5 if (".conv.0.bias" in k and "map_encoder" in k) else 1e-7
+        # conv biases in front of a train-mode BatchNorm: analytically ZERO gradient (exact 0 here); the oracle's
+        # autograd holds rounding noise there that grows with the batch (2e-4 at 512 rows of 64x64 maps)
+        noise = 1e-3 if (".conv.0.bias" in k and "map_encoder" in k) else 1e-7
         if not (abs(got - gref[k]) / max(1e-6, abs(gref[k])) < 1e-3 or abs(got - gref[k]) < noise):
             bad.append(f"{k}: {got:.6e} ref {gref[k]:.6e}")
     assert not bad, "\n".join(bad)
