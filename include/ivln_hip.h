@@ -292,6 +292,48 @@ int ivln_copy2d_f32(const float* src, int64_t ld_src, float* dst, int64_t ld_dst
                     int broadcast_rows, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Fused recurrent / attention head of one rollout step (csrc/cma_step.hip): everything MapCMANet.forward does
+ * after its encoders (ivlnce_baselines/models/map_cma_policy.py:305-353, `_attn` :266-274; two single-step
+ * habitat-lab RNNStateEncoders):  GRU-1 -> state_q / text attention -> text_q / depth + map attention ->
+ * second_state_compress -> GRU-2, as five dependent phase kernels enqueued by this ONE call (`mode` is reserved, pass 0;
+ * a persistent single-launch form was measured slower and dropped, see csrc/cma_step.hip).  The caller supplies the
+ * instruction-only folds (see the file header):
+ *   Mq  (rows, H+1, L): rows 0..H-1 = W_q^T text_k, row H = b_q . text_k      (image stride Mq_img floats)
+ *   TQb (rows, Hq, L) = W_tq txt + b_tq                                        (image stride TQb_img)
+ * and the per-step operands: state_in (rows, d_out+m_out+E) = [ReLU(depth_linear) | ReLU(map_linear) | prev-action
+ * embedding], h_in (rows, 2, H) with row stride ld_h, mask u8 (rows), txt (rows, Ct, L), lengths i32 (rows),
+ * dkv (rows, Hq+d_out, P) / mkv (rows, Hq+m_out, P) = the dep_kv / map_kv projections (keys first).
+ * Outputs: x2 (rows, x2w) = [state | text | dep' | map' | prev] (the prev slice is the caller's), h_out (rows, 2, H)
+ * row stride ld_ho, feats (rows, H).  ws: ivln_cma_step_ws_floats() floats of scratch (128-byte aligned).
+ * IVLN_E_UNSUPPORTED outside L <= 512, P <= 16, 64-aligned widths. */
+typedef struct ivln_cma_step_desc {
+    int rows, L, P, H, Hq, Ct, d_out, m_out, E, x2w;
+    const float* state_in;
+    const float* h_in;
+    int64_t ld_h;
+    const uint8_t* mask;
+    const float *w_ih1, *w_hh1, *b_ih1, *b_hh1; /* state_encoder.rnn  (3H x (d_out+m_out+E), 3H x H) */
+    const float* Mq;
+    int64_t Mq_img;
+    const int* lengths;
+    const float* txt;
+    const float* TQb;
+    int64_t TQb_img;
+    const float* dkv;
+    const float* mkv;
+    float scale;
+    const float *w_c, *b_c;                     /* second_state_compress.0 (H x x2w) */
+    const float *w_ih2, *w_hh2, *b_ih2, *b_hh2; /* second_state_encoder.rnn (3H x H twice) */
+    float* x2;
+    float* h_out;
+    int64_t ld_ho;
+    float* feats;
+    float* ws;
+} ivln_cma_step_desc;
+int64_t ivln_cma_step_ws_floats(int rows, int L, int P, int H);
+int ivln_cma_step_fwd(const ivln_cma_step_desc* d, int mode, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Backward / loss / optimizer kernels of the DAgger update (csrc/train_ops.hip): replace the
  * autograd backward of the modules above plus F.cross_entropy / AuxLosses / torch.optim.Adam in
  * BaseVLNCETrainer._update_agent (ivlnce_baselines/common/base_il_trainer.py:173-219).

@@ -60,6 +60,8 @@ class GraphedRollout:
         self.side = (_stream(dev, "fork_txt"), _stream(dev, "fork_map")) if (streams and not self.split) else None
         self.graphs = []
         self.phase = 0  # which buffer set holds the current state
+        if hasattr(policy.net, "prepare_capture"):
+            policy.net.prepare_capture(self.static)
         if self.split:
             self._capture_split(warmup)
         else:

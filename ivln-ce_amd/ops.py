@@ -478,6 +478,52 @@ def conv_gn(x, w, gn, stride=1, pad=0, relu=False, residual=None, ds=None, out=N
     return out
 
 
+class CmaStepDesc(C.Structure):
+    """Mirror of `ivln_cma_step_desc` (include/ivln_hip.h) - field order must match."""
+
+    _fields_ = [
+        ("rows", i32), ("L", i32), ("P", i32), ("H", i32), ("Hq", i32), ("Ct", i32), ("d_out", i32), ("m_out", i32),
+        ("E", i32), ("x2w", i32),
+        ("state_in", vp), ("h_in", vp), ("ld_h", i64), ("mask", vp),
+        ("w_ih1", vp), ("w_hh1", vp), ("b_ih1", vp), ("b_hh1", vp),
+        ("Mq", vp), ("Mq_img", i64), ("lengths", vp), ("txt", vp), ("TQb", vp), ("TQb_img", i64),
+        ("dkv", vp), ("mkv", vp), ("scale", f32),
+        ("w_c", vp), ("b_c", vp), ("w_ih2", vp), ("w_hh2", vp), ("b_ih2", vp), ("b_hh2", vp),
+        ("x2", vp), ("h_out", vp), ("ld_ho", i64), ("feats", vp), ("ws", vp),
+    ]
+
+
+# rollout head: 0 = ivln_cma_step_fwd (folded operands, five phase kernels), -1 = the unfused chain of ten separate ops
+# (A/B switch IVLN_CMA_STEP_MODE; measured 0.977 vs 0.988 ms per 4-env step)
+CMA_STEP_MODE = int(os.environ.get("IVLN_CMA_STEP_MODE", "0"))
+_cma_ws = {}
+
+
+def cma_step_ws(rows, L, P, H, device):
+    """Scratch of the fused head, one per (device, shape): a policy's head
+    never runs concurrently with itself.  Not keyed by stream on purpose: the buffer must not be born inside a stream
+    capture (it would belong to that graph's private pool and outlive it in this cache); the warm-up steps that
+    precede every capture create it."""
+    L_ = _L()
+    L_.ivln_cma_step_ws_floats.restype = i64
+    L_.ivln_cma_step_ws_floats.argtypes = [i32, i32, i32, i32]
+    n = L_.ivln_cma_step_ws_floats(rows, L, P, H)
+    key = (str(device), rows, L, P, H)
+    w = _cma_ws.get(key)
+    if w is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.IvlnError("cma_step workspace must exist before stream capture (run one warm-up step first)")
+        w = torch.zeros(n, dtype=torch.float32, device=device)
+        _cma_ws[key] = w
+    return w
+
+
+def cma_step(d: CmaStepDesc, mode=None):
+    L_ = _L()
+    L_.ivln_cma_step_fwd.argtypes = [C.POINTER(CmaStepDesc), i32, vp]
+    check(L_.ivln_cma_step_fwd(C.byref(d), 0, stream_ptr()), "ivln_cma_step_fwd")
+
+
 WEIGHT_EPOCH = 0  # bumped by FlatAdam.step(): kernels update parameters through raw pointers, which
 #                   torch's tensor version counters do not see
 

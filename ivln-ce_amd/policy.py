@@ -162,6 +162,34 @@ class MapCMANet(Net):
     def num_recurrent_layers(self):
         return self.state_encoder.num_recurrent_layers + self.second_state_encoder.num_recurrent_layers
 
+    def _cma_fold_weights(self):
+        """Instruction-side folds of the fused rollout head (csrc/cma_step.hip), cached until the weights change:
+        rows 0..H-1 = W_q^T W_k, row H = b_q^T W_k (shift: the same rows applied to b_k), then W_tq / b_tq - one
+        (H + 1 + h2) x 256 weight for a single 1x1 conv over the instruction encoder's output."""
+        ps = (self.state_q.weight, self.state_q.bias, self.text_k.weight, self.text_k.bias, self.text_q.weight,
+              self.text_q.bias)
+        key = (ops.WEIGHT_EPOCH,) + tuple(p._version for p in ps) + tuple(p.data_ptr() for p in ps)
+        if getattr(self, "_cma_fold_key", None) != key:
+            with torch.no_grad():
+                wq, bq, wk, bk, wtq, btq = [p.detach() for p in ps]
+                a = torch.cat([ops.transpose(wq.contiguous()), bq.view(1, -1)], 0).contiguous()  # (H+1, h2)
+                wk2 = torch.cat([wk.view(wk.shape[0], -1), bk.view(-1, 1)], 1).contiguous()       # (h2, Ct + 1)
+                y = ops.linear_gemm(a, ops.transpose(wk2))                                        # (H+1, Ct + 1)
+                ct = wk.shape[1]
+                wf = torch.cat([y[:, :ct], wtq.view(wtq.shape[0], -1)], 0).contiguous()
+                bf = torch.cat([y[:, ct], btq], 0).contiguous()
+            self._cma_fold_key, self._cma_fold = key, (wf, bf)
+        return self._cma_fold
+
+    def prepare_capture(self, example_obs):
+        """Create everything the rollout step caches lazily BEFORE a stream capture (graphed.py): a buffer born inside
+        a capture lives in that graph's private pool and must not survive in a process-wide cache."""
+        if ops.CMA_STEP_MODE < 0 or "instruction" not in example_obs:
+            return
+        rows, L = example_obs["instruction"].shape[0], example_obs["instruction"].shape[1]
+        self._cma_fold_weights()
+        ops.cma_step_ws(rows, L, 16, self._hidden_size, example_obs["instruction"].device)
+
     def _init_layers(self):
         if self.model_config.PROGRESS_MONITOR.use:
             nn.init.kaiming_normal_(self.progress_monitor.weight, nonlinearity="tanh")
@@ -197,11 +225,20 @@ class MapCMANet(Net):
         dl, ml = self.depth_linear[1], self.map_linear[1]
         o_txt, o_dep, o_map, o_prev = H, H + 256, H + 256 + d_out, H + 256 + d_out + m_out
 
+        fused_head = (save is None and ops.CMA_STEP_MODE >= 0
+                      and not (mc.ablate_instruction or mc.ablate_depth or mc.ablate_map))
+
         def _txt_branch(sv):
             t, ln = self.instruction_encoder(observations, sv)  # (rows,256,L)
             if mc.ablate_instruction:
                 t = torch.zeros_like(t)
             r_, L_ = t.shape[0], t.shape[2]
+            if fused_head:
+                # rollout: text_k, state_q and text_q folded over the instruction (csrc/cma_step.hip): ONE 1x1 conv
+                # yields Mq (H+1 channels) and TQb (h2 channels) for the fused head, no text_k tensor is made
+                wf, bf = self._cma_fold_weights()
+                fold = ops.conv2d(t.view(r_, -1, 1, L_), wf.view(wf.shape[0], -1, 1, 1), shift=bf, splitk=False)
+                return t, ln, fold.view(r_, -1, L_)
             tk_ = ops.conv2d(t.view(r_, -1, 1, L_), self.text_k.weight.view(h2, -1, 1, 1), shift=self.text_k.bias,
                              splitk=False)
             return t, ln, tk_
@@ -289,6 +326,28 @@ class MapCMANet(Net):
         rnn_out = getattr(self, "_rnn_out_buffer", None) if save is None else None  # graphed.py: persistent buffer
         if rnn_out is None:
             rnn_out = torch.empty_like(rnn_states)
+        if fused_head and P <= 16 and L <= 512 and tk.shape[1] == H + 1 + h2:
+            # GRU-1 -> text attention -> depth / map attention -> compress -> GRU-2 as one C-ABI call (five phase kernels,
+            # csrc/cma_step.hip); `tk` holds the folded [Mq | TQb] operand here
+            feats = torch.empty((rows, H), dtype=torch.float32, device=dev)
+            g1, g2, sc = self.state_encoder.rnn, self.second_state_encoder.rnn, self.second_state_compress[0]
+            d = ops.CmaStepDesc()
+            d.rows, d.L, d.P, d.H, d.Hq, d.Ct, d.d_out, d.m_out, d.E, d.x2w = rows, L, P, H, h2, txt.shape[1], d_out, m_out, E, x2w
+            d.state_in, d.h_in, d.ld_h, d.mask = ops.dptr(state_in), ops.dptr(rnn_states), rnn_states.stride(0), ops.dptr(masks_u8)
+            d.w_ih1, d.w_hh1, d.b_ih1, d.b_hh1 = (ops.dptr(g1.weight_ih_l0), ops.dptr(g1.weight_hh_l0),
+                                                  ops.dptr(g1.bias_ih_l0), ops.dptr(g1.bias_hh_l0))
+            d.Mq, d.Mq_img = ops._p(tk), tk.stride(0)
+            d.TQb, d.TQb_img = ops._p(tk[:, H + 1:]), tk.stride(0)
+            d.lengths, d.txt = ops.dptr(lengths), ops.dptr(txt)
+            d.dkv, d.mkv, d.scale = ops.dptr(dkv), ops.dptr(mkv), self._scale_f
+            d.w_c, d.b_c = ops.dptr(sc.weight), ops.dptr(sc.bias)
+            d.w_ih2, d.w_hh2, d.b_ih2, d.b_hh2 = (ops.dptr(g2.weight_ih_l0), ops.dptr(g2.weight_hh_l0),
+                                                  ops.dptr(g2.bias_ih_l0), ops.dptr(g2.bias_hh_l0))
+            d.x2, d.h_out, d.ld_ho, d.feats = ops.dptr(x2), ops.dptr(rnn_out), rnn_out.stride(0), ops.dptr(feats)
+            ws = ops.cma_step_ws(rows, L, P, H, dev)
+            d.ws = ops.dptr(ws)
+            ops.cma_step(d)
+            return feats, rnn_out
         s_g1 = {} if save is not None else None
         s_g2 = {} if save is not None else None
         state = x2[:, :H]

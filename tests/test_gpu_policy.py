@@ -197,3 +197,51 @@ def test_act_instruction_length_extremes_match_oracle(lens):
     assert float((f.cpu() - fr).abs().max()) < ATOL
     assert float((s.cpu() - sr).abs().max()) < ATOL
     assert float((lg.cpu() - lr).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("B,lens", [(3, None), (8, None), (4, [1, 200, 17, 80]), (20, None)])
+def test_fused_head_matches_unfused_chain_and_oracle(B, lens):
+    """ivln_cma_step_fwd (folded operands, five phase kernels) against the unfused op chain and the torch-CPU
+    oracle: features, both recurrent states, logits.  The folds reorder sums (state . (W_q^T text_k) instead of
+    (W_q state) . text_k), so fused vs unfused agree to rounding (1e-5), each within 2e-4 of the oracle."""
+    from det_init import det_fill
+
+    from ivln_ce_amd import ops
+    from ivln_ce_amd.synthetic import SyntheticRollout
+    from oracle.policy_ref import MapCMAPolicyRef
+
+    torch.set_num_threads(8)
+    pol = make_policy()
+    ref = det_fill(MapCMAPolicyRef(), seed=0).eval()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(40 + B)
+    obs = SyntheticRollout(B=B, seed=300 + B, n_tokens=64).step()
+    if lens is not None:
+        for b, n in enumerate(lens):
+            obs["instruction"][b] = 0
+            obs["instruction"][b, :n] = torch.randint(2, 2504, (n,), generator=g)
+    obs["occupancy_map"] = (torch.rand(B, 64, 64, generator=g) < 0.4).to(torch.uint8)
+    obs["semantic_map"] = (torch.randint(0, 13, (B, 64, 64), generator=g) * obs["occupancy_map"]).to(torch.uint8)
+    rnn = 0.2 * torch.randn(B, 2, 512, generator=g)
+    prev = torch.randint(0, 4, (B, 1), generator=g)
+    masks = (torch.rand(B, 1, generator=g) < 0.7).to(torch.uint8)
+    dobs = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in obs.items()}
+    out = {}
+    saved = ops.CMA_STEP_MODE
+    try:
+        for mode in (-1, 0):
+            ops.CMA_STEP_MODE = mode
+            with torch.no_grad():
+                f, s = pol.net(dobs, rnn.to(dev), prev.to(dev), masks.to(dev))
+                lg = pol.action_distribution.raw_logits(f)
+            out[mode] = (f.cpu(), s.cpu(), lg.cpu())
+    finally:
+        ops.CMA_STEP_MODE = saved
+    for k in range(3):
+        assert float((out[0][k] - out[-1][k]).abs().max()) < 2e-5, k
+    with torch.no_grad():
+        lr, sr, fr = ref.logits(obs, rnn, prev, masks)
+    for mode in (-1, 0):
+        assert float((out[mode][0] - fr).abs().max()) < ATOL
+        assert float((out[mode][1] - sr).abs().max()) < ATOL
+        assert float((out[mode][2] - lr).abs().max()) < 1e-4
