@@ -231,7 +231,7 @@ def bench_update(policy, dev, world, barrier, T=64, N=8, iters=5, warm=2):
     flat-bucket RCCL all-reduce (world > 1), Adam.  Same barrier / max-over-ranks clock as the rollout leg."""
     from ivln_ce_amd.aux_losses import AuxLosses
     from ivln_ce_amd.trainers import FlatAdam, update_agent
-    from ivln_ce_amd.utils import trim_instruction_padding
+    from ivln_ce_amd.utils import dedupe_instructions, trim_instruction_padding
 
     policy.train()
     opt = FlatAdam(policy, lr=2.5e-4)
@@ -241,12 +241,13 @@ def bench_update(policy, dev, world, barrier, T=64, N=8, iters=5, warm=2):
     instr[:, :80] = torch.randint(2, 2504, (N, 80), generator=g).float()
     # the trainer's loader drops the all-padding tail of the token batch on the host (trainers.PrefetchLoader):
     # like the reference's packed LSTM, the update only ever sees the batch's longest instruction (80 of 200)
-    host = trim_instruction_padding({"instruction": instr.repeat(T, 1)}, first_rows=N)
+    # ... and hands the policy the batch's UNIQUE token rows + each row's index (one encoding per trajectory)
+    host = dedupe_instructions(trim_instruction_padding({"instruction": instr.repeat(T, 1)}, first_rows=N))
     obs = {"depth_features": torch.randn(TN, 128, 4, 4, generator=g).to(dev),
            "occupancy_map": (torch.rand(TN, 64, 64, generator=g) < 0.3).float().to(dev),
            "semantic_map": torch.randint(0, 13, (TN, 64, 64), generator=g).float().to(dev),
-           "instruction": host["instruction"].to(dev),
            "progress": torch.rand(TN, 1, generator=g).to(dev)}
+    obs.update({k: v.float().to(dev) for k, v in host.items()})  # batch_to casts every observation to float32
     prev = torch.randint(0, 4, (TN, 1), generator=g).to(dev)
     nd = torch.ones(T, N, dtype=torch.uint8)
     nd[0] = 0
@@ -396,6 +397,8 @@ def main():
     ap.add_argument("--streams", action="store_true",
                     help="fork the three encoder branches onto side streams inside the graph (measured SLOWER on "
                          "ROCm 7.2: cross-queue dependencies cost more than the overlap wins)")
+    ap.add_argument("--only-update", action="store_true",
+                    help="profiling aid: run the DAgger update leg alone and print its object (not the driver's line)")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="exercise the launch / rendezvous path only (no GPU work, not a measurement)")
     args = ap.parse_args()
@@ -446,6 +449,12 @@ def main():
 
     K, W = args.steps, args.warmup
     cfg, policy = make_policy(dev)
+    if args.only_update:
+        uel, uinfo = bench_update(policy, dev, world, barrier, iters=max(5, min(K, 20)))
+        if rank == 0:
+            print(json.dumps({"update_step": {"ms_per_update": round(1e3 * max_over_ranks(uel) / uinfo["iters"], 3),
+                                              "roofline": uinfo["roofline"]}}), flush=True)
+        return
     mode = False if args.no_graph else (True if args.streams else (False if args.single_stream else "split"))
 
     def run_leg(pred, B, K, W, seed):

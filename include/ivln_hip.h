@@ -243,11 +243,25 @@ int ivln_gru_step_f32(const float* x, int64_t ldx, int I, const float* gi_pre, i
                       const float* w_hh, const float* b_ih, const float* b_hh, float* h_out, int64_t ldo,
                       float* h_out2, int64_t ldo2, int rows, int H, float* save_r, float* save_z,
                       float* save_n, float* save_ghn, void* stream);
+/* The masked GRU over a whole time-major (T*N rows) sequence batch in ONE call (habitat-lab RNNStateEncoder
+ * seq_forward; BPTT forward of base_il_trainer.py:173-219): gi = W_ih x + b_ih for all rows (caller's GEMM), h0 (N, H)
+ * row stride ld_h0, masks u8 (T*N) -> out (T*N, H) row stride ldo, state_out (N, H) = the last step; optional saves
+ * r / z / n / gh_n (T*N, H) for ivln_cma_seq_bwd_f32.  T dependent launches enqueued from C. */
+int ivln_cma_seq_fwd_f32(const float* gi, const float* h0, int64_t ld_h0, const uint8_t* masks, const float* w_hh,
+                         const float* b_hh, float* out, int64_t ldo, float* state_out, int64_t ld_so, int T, int N,
+                         int H, float* save_r, float* save_z, float* save_n, float* save_ghn, void* stream);
 /* MapCMANet._attn (map_cma_policy.py:266-274); k (rows,Ck,I), v (rows,Cv,I) channel-major. */
 int ivln_attn_fwd_f32(const float* q, int64_t ldq, const float* k, int64_t k_img_stride, const float* v,
                       int64_t v_img_stride, const int* valid_len, float scale, int rows, int Ck, int Cv,
                       int I, float* out, int64_t ldo, float* save_attn, float* logits_ws /* rows*I */,
                       void* stream);
+/* Same, with row_index i32 (rows): row r attends over key/value image row_index[r] (valid_len is per image).  Update
+ * batches are time-major T*N rows whose instruction is the same at every timestep of a trajectory: the instruction
+ * encoder runs once per UNIQUE token row and T rows share its output. */
+int ivln_attn_fwd_idx_f32(const float* q, int64_t ldq, const float* k, int64_t k_img_stride, const float* v,
+                          int64_t v_img_stride, const int* valid_len, float scale, int rows, int Ck, int Cv, int I,
+                          float* out, int64_t ldo, float* save_attn, float* logits_ws, const int* row_index,
+                          void* stream);
 /* The same attention for a short key axis (I <= 32: the 4x4 depth / map feature grids of MapCMANet.forward,
  * map_cma_policy.py:330-343) and up to two key/value sets that share the query, in ONE launch; k1 == NULL ->
  * one set.  No mask, no saved probabilities (rollout head). */
@@ -355,6 +369,14 @@ int ivln_attn_bwd_f32(const float* dout, int64_t ld_dout, const float* attn, con
                       const float* k, int64_t k_img_stride, const float* v, int64_t v_img_stride, float scale,
                       int rows, int Ck, int Cv, int I, float* dq, int64_t ld_dq, float* dk,
                       int64_t dk_img_stride, float* dv, int64_t dv_img_stride, void* stream);
+/* the same with shared key/value images (ivln_attn_fwd_idx_f32): k / v are read through row_index, dk / dv are still
+ * written per ROW; ivln_index_sum_f32 then folds them onto the images:
+ *   dst[u][:] = sum_{r : index[r] == u} src[r][:]   (ascending r; M % 4 == 0, 16-byte aligned) */
+int ivln_attn_bwd_idx_f32(const float* dout, int64_t ld_dout, const float* attn, const float* q, int64_t ldq,
+                          const float* k, int64_t k_img_stride, const float* v, int64_t v_img_stride, float scale,
+                          int rows, int Ck, int Cv, int I, float* dq, int64_t ld_dq, float* dk,
+                          int64_t dk_img_stride, float* dv, int64_t dv_img_stride, const int* row_index, void* stream);
+int ivln_index_sum_f32(const float* src, const int* index, int rows, int64_t M, int U, float* dst, void* stream);
 /* one BPTT step of the masked GRU: gate gradients (element part) */
 int ivln_gru_bwd_elem_f32(const float* dout, int64_t ld_dout, const float* dh_carry, const float* r,
                           const float* z, const float* n, const float* ghn, const float* h_prev, int64_t ldh,
@@ -368,6 +390,12 @@ int ivln_gru_bwd_step_f32(const float* dgh_t, int64_t ld_dgh, const float* whh_t
                           const float* dout_prev, int64_t ld_dout, const float* r, const float* z, const float* n,
                           const float* ghn, const float* h_prev, int64_t ldh, const uint8_t* mask_prev, int rows, int H,
                           float* dhz, float* dgi_prev, float* dgh_prev, float* hp_prev, void* stream);
+/* BPTT of ivln_cma_seq_fwd_f32 in one call (whh_t = W_hh^T (H, 3H)): d_out (T*N, H) row stride ld_dout, the forward's
+ * saves and outputs -> dgi, dgh (T*N, 3H), hp = h_prev * mask (T*N, H); dhz (N, H) scratch. */
+int ivln_cma_seq_bwd_f32(const float* d_out, int64_t ld_dout, const float* r, const float* z, const float* n,
+                         const float* ghn, const float* out, int64_t ld_out, const float* h0, int64_t ld_h0,
+                         const uint8_t* masks, const float* whh_t, int T, int N, int H, float* dgi, float* dgh, float* hp,
+                         float* dhz, void* stream);
 /* y[r][o] = (W[o].x[r] + add[r][o]) * (rowmask[r] != 0)  (dh_prev of the GRU BPTT) */
 int ivln_linear_skinny_ex_f32(const float* x, int64_t ldx, const float* W, const float* add, int64_t ld_add,
                               const uint8_t* rowmask, float* y, int64_t ldy, int rows, int K, int O,

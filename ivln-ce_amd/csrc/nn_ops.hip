@@ -775,13 +775,16 @@ constexpr int ATT_MAX_I = 512;
 __global__ __launch_bounds__(256) void k_attn_logits(const float* __restrict__ q, int64_t ldq,
                                                      const float* __restrict__ k, int64_t k_img_stride,
                                                      const int* __restrict__ valid_len, float scale, int Ck, int I,
-                                                     float* __restrict__ logits) {
+                                                     float* __restrict__ logits, const int* __restrict__ row_index) {
     __shared__ float qs[1024];
     __shared__ float pl[8][33];
     const int n = blockIdx.x;
+    // row_index: several rows attend over the SAME key/value image (update batches: the instruction of a
+    // trajectory is encoded once, not once per timestep); valid_len is per image
+    const int img = row_index ? row_index[n] : n;
     for (int c = threadIdx.x; c < Ck; c += 256) qs[c] = q[(int64_t)n * ldq + c];
     __syncthreads();
-    const float* kp = k + (int64_t)n * k_img_stride;
+    const float* kp = k + (int64_t)img * k_img_stride;
     const int ti = threadIdx.x & 31, tp = threadIdx.x >> 5;  // position, channel part (8 parts)
     const int i = blockIdx.y * 32 + ti;
     float acc = 0.f;
@@ -800,7 +803,7 @@ __global__ __launch_bounds__(256) void k_attn_logits(const float* __restrict__ q
     __syncthreads();
     if (tp == 0 && i < I) {
         float s = ((pl[0][ti] + pl[1][ti]) + (pl[2][ti] + pl[3][ti])) + ((pl[4][ti] + pl[5][ti]) + (pl[6][ti] + pl[7][ti]));
-        const int vl = valid_len ? valid_len[n] : I;
+        const int vl = valid_len ? valid_len[img] : I;
         if (i >= vl) s = s - 1e8f;
         logits[(int64_t)n * I + i] = s * scale;
     }
@@ -808,11 +811,13 @@ __global__ __launch_bounds__(256) void k_attn_logits(const float* __restrict__ q
 
 __global__ __launch_bounds__(256) void k_attn_out(const float* __restrict__ logits, const float* __restrict__ v,
                                                   int64_t v_img_stride, int Cv, int I, float* __restrict__ out,
-                                                  int64_t ldo, float* __restrict__ save_attn) {
+                                                  int64_t ldo, float* __restrict__ save_attn,
+                                                  const int* __restrict__ row_index) {
     __shared__ float ps[ATT_MAX_I];
     __shared__ float pl[16][17];
     __shared__ float red[16];
     const int n = blockIdx.x;
+    const int img = row_index ? row_index[n] : n;
     float lmax = -INFINITY;
     for (int i = threadIdx.x; i < I; i += 256) {
         float l = logits[(int64_t)n * I + i];
@@ -838,7 +843,7 @@ __global__ __launch_bounds__(256) void k_attn_out(const float* __restrict__ logi
     const int c = blockIdx.y * 16 + tc;
     float acc = 0.f;
     if (c < Cv) {
-        const float* vp = v + (int64_t)n * v_img_stride + (int64_t)c * I;
+        const float* vp = v + (int64_t)img * v_img_stride + (int64_t)c * I;
         int i = tpart;
         for (; i + 48 < I; i += 64) {
             float v0 = vp[i], v1 = vp[i + 16], v2 = vp[i + 32], v3 = vp[i + 48];
@@ -1277,15 +1282,53 @@ int ivln_gru_step_f32(const float* x, int64_t ldx, int I, const float* gi_pre, i
     return LAUNCH_OK();
 }
 
+/* GRU over a whole time-major sequence batch in ONE call: T dependent k_gru_step launches enqueued from C.  The
+ * per-timestep Python -> ctypes round trip (~15 us) was longer than the 6.5 us kernel, so the 128 forward steps of
+ * an update left the GPU idle for ~1 ms (profiles/r02_update_kernel_stats.csv); enqueued back to back they are
+ * GPU-bound.  gi = W_ih x + b_ih for all T*N rows (one GEMM, done by the caller). */
+int ivln_cma_seq_fwd_f32(const float* gi, const float* h0, int64_t ld_h0, const uint8_t* masks, const float* w_hh,
+                         const float* b_hh, float* out, int64_t ldo, float* state_out, int64_t ld_so, int T, int N,
+                         int H, float* save_r, float* save_z, float* save_n, float* save_ghn, void* stream) {
+    if (!gi || !h0 || !masks || !w_hh || !b_hh || !out || T <= 0 || N <= 0 || (H & 3) || (ld_h0 & 3) || (ldo & 3))
+        return IVLN_E_INVALID;
+    for (int t = 0; t < T; ++t) {
+        const int64_t r0 = (int64_t)t * N;
+        const float* h_in = t == 0 ? h0 : out + (r0 - N) * ldo;
+        const int64_t ldh = t == 0 ? ld_h0 : ldo;
+        float* so = (t == T - 1) ? state_out : nullptr;
+        float* sr = save_r ? save_r + r0 * H : nullptr;
+        float* sz = save_r ? save_z + r0 * H : nullptr;
+        float* sn = save_r ? save_n + r0 * H : nullptr;
+        float* sg = save_r ? save_ghn + r0 * H : nullptr;
+        if (N <= 4)
+            hipLaunchKernelGGL(k_gru_step<64>, dim3(H), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr, (int64_t)0,
+                               0, gi + r0 * 3 * H, (int64_t)3 * H, h_in, ldh, masks + r0, (const float*)nullptr, w_hh,
+                               (const float*)nullptr, b_hh, out + r0 * ldo, ldo, so, ld_so, N, H, sr, sz, sn, sg);
+        else
+            hipLaunchKernelGGL(k_gru_step<32>, dim3(H), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr, (int64_t)0,
+                               0, gi + r0 * 3 * H, (int64_t)3 * H, h_in, ldh, masks + r0, (const float*)nullptr, w_hh,
+                               (const float*)nullptr, b_hh, out + r0 * ldo, ldo, so, ld_so, N, H, sr, sz, sn, sg);
+    }
+    return LAUNCH_OK();
+}
+
+int ivln_attn_fwd_idx_f32(const float* q, int64_t ldq, const float* k, int64_t k_img_stride, const float* v,
+                          int64_t v_img_stride, const int* valid_len, float scale, int rows, int Ck, int Cv, int I,
+                          float* out, int64_t ldo, float* save_attn, float* logits_ws, const int* row_index,
+                          void* stream) {
+    if (I > ATT_MAX_I || Ck > 1024 || !logits_ws) return IVLN_E_UNSUPPORTED;
+    hipLaunchKernelGGL(k_attn_logits, dim3(rows, (I + 31) / 32), dim3(256), 0, (hipStream_t)stream, q, ldq, k,
+                       k_img_stride, valid_len, scale, Ck, I, logits_ws, row_index);
+    hipLaunchKernelGGL(k_attn_out, dim3(rows, (Cv + 15) / 16), dim3(256), 0, (hipStream_t)stream, logits_ws, v,
+                       v_img_stride, Cv, I, out, ldo, save_attn, row_index);
+    return LAUNCH_OK();
+}
+
 int ivln_attn_fwd_f32(const float* q, int64_t ldq, const float* k, int64_t k_img_stride, const float* v,
                       int64_t v_img_stride, const int* valid_len, float scale, int rows, int Ck, int Cv, int I,
                       float* out, int64_t ldo, float* save_attn, float* logits_ws, void* stream) {
-    if (I > ATT_MAX_I || Ck > 1024 || !logits_ws) return IVLN_E_UNSUPPORTED;
-    hipLaunchKernelGGL(k_attn_logits, dim3(rows, (I + 31) / 32), dim3(256), 0, (hipStream_t)stream, q, ldq, k,
-                       k_img_stride, valid_len, scale, Ck, I, logits_ws);
-    hipLaunchKernelGGL(k_attn_out, dim3(rows, (Cv + 15) / 16), dim3(256), 0, (hipStream_t)stream, logits_ws, v,
-                       v_img_stride, Cv, I, out, ldo, save_attn);
-    return LAUNCH_OK();
+    return ivln_attn_fwd_idx_f32(q, ldq, k, k_img_stride, v, v_img_stride, valid_len, scale, rows, Ck, Cv, I, out, ldo,
+                                 save_attn, logits_ws, nullptr, stream);
 }
 
 int ivln_attn_small2_f32(const float* q, int64_t ldq, float scale, int rows, int I, const float* k0,

@@ -159,16 +159,18 @@ __global__ __launch_bounds__(256) void k_attn_bwd(const float* __restrict__ dout
                                                   const float* __restrict__ v, int64_t v_img_stride, float scale,
                                                   int Ck, int Cv, int I, float* __restrict__ dq, int64_t ld_dq,
                                                   float* __restrict__ dk, int64_t dk_img_stride,
-                                                  float* __restrict__ dv, int64_t dv_img_stride) {
+                                                  float* __restrict__ dv, int64_t dv_img_stride,
+                                                  const int* __restrict__ row_index) {
     __shared__ float ds[1024];   // dout row, later q row
     __shared__ float as[512];    // attn
     __shared__ float dl[512];    // dlogits
     __shared__ float red[16];
     const int n = blockIdx.x;
+    const int img = row_index ? row_index[n] : n;  // rows sharing one key/value image (forward: k_attn_logits)
     for (int c = threadIdx.x; c < Cv; c += 256) ds[c] = dout[(int64_t)n * ld_dout + c];
     for (int i = threadIdx.x; i < I; i += 256) as[i] = attn[(int64_t)n * I + i];
     __syncthreads();
-    const float* vp = v + (int64_t)n * v_img_stride;
+    const float* vp = v + (int64_t)img * v_img_stride;
     float* dvp = dv + (int64_t)n * dv_img_stride;
     float dot = 0.f;
     for (int i = threadIdx.x; i < I; i += 256) {
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd(const float* __restrict__ dout
     __syncthreads();
     for (int c = threadIdx.x; c < Ck; c += 256) ds[c] = q[(int64_t)n * ldq + c];
     __syncthreads();
-    const float* kp = k + (int64_t)n * k_img_stride;
+    const float* kp = k + (int64_t)img * k_img_stride;
     float* dkp = dk + (int64_t)n * dk_img_stride;
     for (int c = threadIdx.x; c < Ck; c += 256) {
         float acc = 0.f;
@@ -733,6 +735,25 @@ __global__ __launch_bounds__(256) void k_adam_flat(float* __restrict__ p, float*
     if (zero_grad) g[i] = 0.f;
 }
 
+// dst[u][m] = sum over rows with index[row] == u of src[row][m], rows in ascending order (deterministic): the
+// per-row gradients of a key/value image shared by several rows (k_attn_bwd with row_index) folded onto the image.
+// One thread per 4 consecutive m; the index vector (<= a few thousand ints) is scanned from L1 / scalar cache.
+__global__ __launch_bounds__(256) void k_index_sum(const float* __restrict__ src, const int* __restrict__ index, int rows,
+                                                   int64_t M4, int U, float* __restrict__ dst) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= M4 * U) return;
+    const int u = (int)(gid / M4);
+    const int64_t m = gid - (int64_t)u * M4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = 0; r < rows; ++r) {
+        if (index[r] == u) {
+            const float4 v = reinterpret_cast<const float4*>(src)[(int64_t)r * M4 + m];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    reinterpret_cast<float4*>(dst)[gid] = acc;
+}
+
 }  // namespace
 
 #define LAUNCH_OK() (hipGetLastError() == hipSuccess ? IVLN_OK : IVLN_E_HIP)
@@ -800,15 +821,23 @@ int ivln_weight_flip_transpose_f32(const float* w, float* wt, int O, int I, int 
     return LAUNCH_OK();
 }
 
+int ivln_attn_bwd_idx_f32(const float* dout, int64_t ld_dout, const float* attn, const float* q, int64_t ldq,
+                      const float* k, int64_t k_img_stride, const float* v, int64_t v_img_stride, float scale,
+                      int rows, int Ck, int Cv, int I, float* dq, int64_t ld_dq, float* dk, int64_t dk_img_stride,
+                      float* dv, int64_t dv_img_stride, const int* row_index, void* stream) {
+    if (I > 512 || Ck > 1024 || Cv > 1024) return IVLN_E_UNSUPPORTED;
+    hipLaunchKernelGGL(k_attn_bwd, dim3(rows), dim3(256), 0, (hipStream_t)stream, dout, ld_dout, attn, q, ldq, k,
+                       k_img_stride, v, v_img_stride, scale, Ck, Cv, I, dq, ld_dq, dk, dk_img_stride, dv,
+                       dv_img_stride, row_index);
+    return LAUNCH_OK();
+}
+
 int ivln_attn_bwd_f32(const float* dout, int64_t ld_dout, const float* attn, const float* q, int64_t ldq,
                       const float* k, int64_t k_img_stride, const float* v, int64_t v_img_stride, float scale,
                       int rows, int Ck, int Cv, int I, float* dq, int64_t ld_dq, float* dk, int64_t dk_img_stride,
                       float* dv, int64_t dv_img_stride, void* stream) {
-    if (I > 512 || Ck > 1024 || Cv > 1024) return IVLN_E_UNSUPPORTED;
-    hipLaunchKernelGGL(k_attn_bwd, dim3(rows), dim3(256), 0, (hipStream_t)stream, dout, ld_dout, attn, q, ldq, k,
-                       k_img_stride, v, v_img_stride, scale, Ck, Cv, I, dq, ld_dq, dk, dk_img_stride, dv,
-                       dv_img_stride);
-    return LAUNCH_OK();
+    return ivln_attn_bwd_idx_f32(dout, ld_dout, attn, q, ldq, k, k_img_stride, v, v_img_stride, scale, rows, Ck, Cv, I, dq, ld_dq,
+                                 dk, dk_img_stride, dv, dv_img_stride, nullptr, stream);
 }
 
 int ivln_gru_bwd_elem_f32(const float* dout, int64_t ld_dout, const float* dh_carry, const float* r, const float* z,
@@ -827,6 +856,39 @@ int ivln_gru_bwd_step_f32(const float* dgh_t, int64_t ld_dgh, const float* whh_t
     hipLaunchKernelGGL(k_gru_bwd_step, dim3(H), dim3(256), 0, (hipStream_t)stream, dgh_t, ld_dgh, whh_t, mask_t,
                        dout_prev, ld_dout, r, z, n, ghn, h_prev, ldh, mask_prev, rows, H, dhz, dgi_prev, dgh_prev,
                        hp_prev);
+    return LAUNCH_OK();
+}
+
+/* BPTT of ivln_cma_seq_fwd_f32 in one call: the element part of step T-1, then T-1 fused (carry of step t + element
+ * part of step t-1) launches, enqueued from C (see the forward).  whh_t = W_hh^T (H, 3H).  Outputs dgi / dgh
+ * (T*N, 3H), hp = h_prev * mask (T*N, H); dhz (N, H) is scratch. */
+int ivln_cma_seq_bwd_f32(const float* d_out, int64_t ld_dout, const float* r, const float* z, const float* n,
+                         const float* ghn, const float* out, int64_t ld_out, const float* h0, int64_t ld_h0,
+                         const uint8_t* masks, const float* whh_t, int T, int N, int H, float* dgi, float* dgh, float* hp,
+                         float* dhz, void* stream) {
+    if (!d_out || !r || !out || !h0 || !masks || !whh_t || !dgi || !dgh || !hp || !dhz || T <= 0 || N <= 0 || (H & 3))
+        return IVLN_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    auto hprev = [&](int t, int64_t& ld) -> const float* {  // hidden state entering step t
+        ld = t == 0 ? ld_h0 : ld_out;
+        return t == 0 ? h0 : out + (int64_t)(t - 1) * N * ld_out;
+    };
+    {
+        const int64_t r0 = (int64_t)(T - 1) * N;
+        int64_t ld;
+        const float* hpv = hprev(T - 1, ld);
+        hipLaunchKernelGGL(k_gru_bwd_elem, dim3(nblk((int64_t)N * H)), dim3(256), 0, s, d_out + r0 * ld_dout, ld_dout,
+                           (const float*)nullptr, r + r0 * H, z + r0 * H, n + r0 * H, ghn + r0 * H, hpv, ld, masks + r0, N,
+                           H, dgi + r0 * 3 * H, dgh + r0 * 3 * H, dhz, hp + r0 * H);
+    }
+    for (int t = T - 1; t > 0; --t) {
+        const int64_t rt = (int64_t)t * N, rp = (int64_t)(t - 1) * N;
+        int64_t ld;
+        const float* hpp = hprev(t - 1, ld);
+        hipLaunchKernelGGL(k_gru_bwd_step, dim3(H), dim3(256), 0, s, dgh + rt * 3 * H, (int64_t)3 * H, whh_t, masks + rt,
+                           d_out + rp * ld_dout, ld_dout, r + rp * H, z + rp * H, n + rp * H, ghn + rp * H, hpp, ld,
+                           masks + rp, N, H, dhz, dgi + rp * 3 * H, dgh + rp * 3 * H, hp + rp * H);
+    }
     return LAUNCH_OK();
 }
 
@@ -912,6 +974,14 @@ int ivln_adam_step_f32(float* params, float* grads, float* exp_avg, float* exp_a
     float bc2 = 1.f - powf(beta2, (float)step);
     hipLaunchKernelGGL(k_adam_flat, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
                        exp_avg_sq, n, lr, seg_of, seg_lr, beta1, beta2, eps, bc1, bc2, grad_scale, zero_grad);
+    return LAUNCH_OK();
+}
+
+int ivln_index_sum_f32(const float* src, const int* index, int rows, int64_t M, int U, float* dst, void* stream) {
+    if (!src || !index || !dst || rows <= 0 || U <= 0 || M <= 0 || (M & 3)) return IVLN_E_INVALID;
+    if ((((uintptr_t)src | (uintptr_t)dst) & 15) != 0) return IVLN_E_INVALID;
+    hipLaunchKernelGGL(k_index_sum, dim3(nblk((M / 4) * U)), dim3(256), 0, (hipStream_t)stream, src, index, rows, M / 4, U,
+                       dst);
     return LAUNCH_OK();
 }
 

@@ -391,12 +391,7 @@ class RNNStateEncoder(nn.Module):
         if save is not None:
             saves = tuple(torch.empty((rows, H), dtype=torch.float32, device=x.device) for _ in range(4))
             save.update(r=saves[0], z=saves[1], n=saves[2], ghn=saves[3], T=T, N=N, x=x, h0=h0, masks=masks_u8, out=out)
-        for t in range(T):
-            sl = slice(t * N, (t + 1) * N)
-            h_in = h0 if t == 0 else out[(t - 1) * N: t * N]
-            st = tuple(s[sl] for s in saves) if saves is not None else None
-            ops.gru_step(None, gi[sl], h_in, masks_u8[sl], rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0,
-                         rnn.bias_hh_l0, out[sl], state_out if t == T - 1 else None, st)
+        ops.gru_seq(gi, h0, masks_u8, rnn.weight_hh_l0, rnn.bias_hh_l0, out, state_out, T, N, saves)
         return out
 
 

@@ -654,15 +654,39 @@ def gru_step(x, gi_pre, h_in, mask_u8, w_ih, w_hh, b_ih, b_hh, h_out, h_out2=Non
     )
 
 
-def attn(q, k, v, valid_len, scale, out, save_attn=None):
-    """q (rows,Ck) strided rows; k (rows,Ck,I), v (rows,Cv,I) with image strides; out (rows,Cv) strided."""
+def gru_seq(gi, h0, masks_u8, w_hh, b_hh, out, state_out, T, N, saves=None):
+    """Masked GRU over T timesteps of N rows in one C-ABI call (T dependent launches enqueued from C)."""
+    H = w_hh.shape[1]
+    sv = saves or (None, None, None, None)
+    L = _L()
+    L.ivln_cma_seq_fwd_f32.argtypes = [vp, vp, i64, vp, vp, vp, vp, i64, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp]
+    check(L.ivln_cma_seq_fwd_f32(dptr(gi), _p(h0), h0.stride(0), dptr(masks_u8), dptr(w_hh), dptr(b_hh), _p(out),
+                                 out.stride(0), _p(state_out), state_out.stride(0) if state_out is not None else 0, T, N,
+                                 H, _p(sv[0]), _p(sv[1]), _p(sv[2]), _p(sv[3]), stream_ptr()), "ivln_cma_seq_fwd_f32")
+
+
+def gru_seq_bwd(d_out, r, z, n, ghn, out, h0, masks_u8, whh_t, T, N, dgi, dgh, hp, dhz):
+    H = r.shape[1]
+    L = _T()
+    L.ivln_cma_seq_bwd_f32.argtypes = [vp, i64, vp, vp, vp, vp, vp, i64, vp, i64, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]
+    check(L.ivln_cma_seq_bwd_f32(_p(d_out), d_out.stride(0), dptr(r), dptr(z), dptr(n), dptr(ghn), _p(out), out.stride(0),
+                                 _p(h0), h0.stride(0), dptr(masks_u8), dptr(whh_t), T, N, H, dptr(dgi), dptr(dgh), dptr(hp),
+                                 dptr(dhz), stream_ptr()), "ivln_cma_seq_bwd_f32")
+
+
+def attn(q, k, v, valid_len, scale, out, save_attn=None, row_index=None):
+    """q (rows,Ck) strided rows; k (imgs,Ck,I), v (imgs,Cv,I) with image strides; out (rows,Cv) strided.
+    row_index (rows,) i32: the key/value image of each row (None: row r uses image r); valid_len is per image."""
     rows, Ck = q.shape
     Cv, I = v.shape[1], v.shape[2]
     logits_ws = torch.empty((rows, I), dtype=torch.float32, device=q.device)
+    L = _L()
+    L.ivln_attn_fwd_idx_f32.argtypes = [vp, i64, vp, i64, vp, i64, vp, f32, i32, i32, i32, i32, vp, i64, vp, vp, vp, vp]
     check(
-        _L().ivln_attn_fwd_f32(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(valid_len), scale, rows,
-                               Ck, Cv, I, _p(out), out.stride(0), _p(save_attn), dptr(logits_ws), stream_ptr()),
-        "ivln_attn_fwd_f32",
+        L.ivln_attn_fwd_idx_f32(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(valid_len), scale, rows,
+                                Ck, Cv, I, _p(out), out.stride(0), _p(save_attn), dptr(logits_ws), _p(row_index),
+                                stream_ptr()),
+        "ivln_attn_fwd_idx_f32",
     )
     return out
 
@@ -874,15 +898,30 @@ def weight_flip_transpose(w):
     return wt
 
 
-def attn_bwd(dout, attn_p, q, k, v, scale, dq, dk, dv):
+def attn_bwd(dout, attn_p, q, k, v, scale, dq, dk, dv, row_index=None):
+    """dk / dv are per ROW (rows, C, I) even when rows share key/value images through row_index (index_sum folds them)."""
     rows, Ck = q.shape
     Cv, I = v.shape[1], v.shape[2]
+    L = _T()
+    L.ivln_attn_bwd_idx_f32.argtypes = [vp, i64, vp, vp, i64, vp, i64, vp, i64, f32, i32, i32, i32, i32, vp, i64, vp,
+                                        i64, vp, i64, vp, vp]
     check(
-        _T().ivln_attn_bwd_f32(_p(dout), dout.stride(0), dptr(attn_p), _p(q), q.stride(0), _p(k), k.stride(0), _p(v),
-                               v.stride(0), scale, rows, Ck, Cv, I, _p(dq), dq.stride(0), _p(dk), dk.stride(0),
-                               _p(dv), dv.stride(0), stream_ptr()),
-        "ivln_attn_bwd_f32",
+        L.ivln_attn_bwd_idx_f32(_p(dout), dout.stride(0), dptr(attn_p), _p(q), q.stride(0), _p(k), k.stride(0), _p(v),
+                                v.stride(0), scale, rows, Ck, Cv, I, _p(dq), dq.stride(0), _p(dk), dk.stride(0),
+                                _p(dv), dv.stride(0), _p(row_index), stream_ptr()),
+        "ivln_attn_bwd_idx_f32",
     )
+
+
+def index_sum(src, index, U):
+    """dst[u] = sum of the rows of `src` (rows, ...) whose index is u, in ascending row order -> (U, ...)."""
+    rows = src.shape[0]
+    M = src[0].numel()
+    dst = torch.empty((U,) + tuple(src.shape[1:]), dtype=torch.float32, device=src.device)
+    L = _T()
+    L.ivln_index_sum_f32.argtypes = [vp, vp, i32, i64, i32, vp, vp]
+    check(L.ivln_index_sum_f32(dptr(src), dptr(index), rows, M, U, dptr(dst), stream_ptr()), "ivln_index_sum_f32")
+    return dst
 
 
 def gru_bwd_elem(dout, dh_carry, r, z, n, ghn, h_prev, mask, dgi, dgh, dhz, hp_out):

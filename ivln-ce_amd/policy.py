@@ -228,8 +228,16 @@ class MapCMANet(Net):
         fused_head = (save is None and ops.CMA_STEP_MODE >= 0
                       and not (mc.ablate_instruction or mc.ablate_depth or mc.ablate_map))
 
+        # update batches: the instruction of a trajectory is the same at every timestep, so the loader hands over the
+        # UNIQUE token rows and each row's index into them (trainers.PrefetchLoader); the encoder, text_k and their
+        # backward then run on U sequences instead of T*N (8-9 instead of 512 at the benched shape)
+        inv = None
+        if save is not None and "instruction_index" in observations and "instruction_unique" in observations:
+            inv = observations["instruction_index"].reshape(-1).to(torch.int32).contiguous()
+
         def _txt_branch(sv):
-            t, ln = self.instruction_encoder(observations, sv)  # (rows,256,L)
+            src = observations if inv is None else {"instruction": observations["instruction_unique"]}
+            t, ln = self.instruction_encoder(src, sv)  # (rows | U, 256, L)
             if mc.ablate_instruction:
                 t = torch.zeros_like(t)
             r_, L_ = t.shape[0], t.shape[2]
@@ -292,7 +300,7 @@ class MapCMANet(Net):
             if overlap:  # training pass: the instruction bi-LSTM runs beside the map CNN (train.py)
                 cur, st = torch.cuda.current_stream(), _train.side_stream(dev)
                 st.wait_stream(cur)
-                _train.share_with_stream(observations.get("instruction"), st)
+                _train.share_with_stream((observations.get("instruction"), observations.get("instruction_unique")), st)
                 with torch.cuda.stream(st):
                     txt, lengths, tk = _txt_branch(s_txt)
             else:
@@ -356,7 +364,7 @@ class MapCMANet(Net):
         q1 = ops.linear(state, self.state_q.weight, self.state_q.bias)
         a_txt = torch.empty((rows, L), dtype=torch.float32, device=dev) if save is not None else None
         text = x2[:, o_txt:o_txt + 256]
-        ops.attn(q1, tk.view(rows, h2, L), txt, lengths, self._scale_f, text, a_txt)
+        ops.attn(q1, tk.view(tk.shape[0], h2, L), txt, lengths, self._scale_f, text, a_txt, row_index=inv)
 
         dkv, mkv = dkv.view(rows, -1, P), mkv.view(rows, -1, P)
         q2 = ops.linear(text, self.text_q.weight, self.text_q.bias)
@@ -381,6 +389,7 @@ class MapCMANet(Net):
                 state_in=state_in, x2=x2, q1=q1, tk=tk, a_txt=a_txt, dkv=dkv, mkv=mkv, q2=q2, a_dep=a_dep,
                 a_map=a_map, c2=c2, feats=feats, rows=rows, N=N, L=L, P=P, offs=(o_txt, o_dep, o_map, o_prev),
                 masks=masks_u8, prev_actions=prev_actions, depth_from_features="depth_features" in observations,
+                inv=inv,
             )
         return feats, rnn_out
 

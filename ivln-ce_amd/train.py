@@ -104,15 +104,9 @@ def _gru_backward(enc, s, d_out, G):
     dgh = torch.empty((rows, 3 * H), dtype=torch.float32, device=dev)
     hp = torch.empty((rows, H), dtype=torch.float32, device=dev)
     dhz = torch.empty((N, H), dtype=torch.float32, device=dev)
-    # step T-1: element part alone; every earlier step t-1 rides in the launch that finishes step t
-    sl = slice((T - 1) * N, T * N)
-    ops.gru_bwd_elem(d_out[sl], None, s["r"][sl], s["z"][sl], s["n"][sl], s["ghn"][sl],
-                     h0 if T == 1 else out[(T - 2) * N: (T - 1) * N], masks[sl], dgi[sl], dgh[sl], dhz, hp[sl])
-    for t in range(T - 1, 0, -1):
-        sl, sp = slice(t * N, (t + 1) * N), slice((t - 1) * N, t * N)
-        h_pp = h0 if t == 1 else out[(t - 2) * N: (t - 1) * N]
-        ops.gru_bwd_step(dgh[sl], whh_t, masks[sl], d_out[sp], s["r"][sp], s["z"][sp], s["n"][sp], s["ghn"][sp], h_pp,
-                         masks[sp], dhz, dgi[sp], dgh[sp], hp[sp])
+    # step T-1: element part alone; every earlier step t-1 rides in the launch that finishes step t - the whole chain
+    # enqueued by one C-ABI call (ivln_cma_seq_bwd_f32)
+    ops.gru_seq_bwd(d_out, s["r"], s["z"], s["n"], s["ghn"], out, h0, masks, whh_t, T, N, dgi, dgh, hp, dhz)
     G[rnn.weight_ih_l0] = ops.linear_bwd_weight(dgi, x_in)
     G[rnn.bias_ih_l0] = ops.colsum(dgi)
     G[rnn.weight_hh_l0] = ops.linear_bwd_weight(dgh, hp)
@@ -190,13 +184,16 @@ def net_backward(net, S: Dict, d_feats: torch.Tensor) -> Dict:
     ops.linear_bwd_input(dq2, net.text_q.weight, out=d_text, accumulate=True)
 
     # ---- text attention (v = the LSTM outputs themselves, k = text_k(outputs)) -------------------
-    txt, tk = S["txt_out"], S["tk"]
+    txt, tk, inv = S["txt_out"], S["tk"], S.get("inv")
+    U = txt.shape[0]  # == rows unless the batch came with its unique instruction rows (policy.forward_hip)
     dq1 = torch.empty((rows, h2), dtype=torch.float32, device=dev)
     d_tk = torch.empty((rows, h2, L), dtype=torch.float32, device=dev)
-    d_txt = torch.empty_like(txt)
-    ops.attn_bwd(d_text, S["a_txt"], S["q1"], tk.view(rows, h2, L), txt, scale, dq1, d_tk, d_txt)
-    d_txt = _conv1d_backward(net.text_k, d_tk.view(rows, h2, 1, L), txt.view(rows, -1, 1, L),
-                             d_txt.view(rows, -1, 1, L), G).view(rows, -1, L)
+    d_txt = torch.empty((rows, txt.shape[1], L), dtype=torch.float32, device=dev)
+    ops.attn_bwd(d_text, S["a_txt"], S["q1"], tk.view(U, h2, L), txt, scale, dq1, d_tk, d_txt, row_index=inv)
+    if inv is not None:  # fold the per-row gradients onto the U shared instruction encodings (fixed row order)
+        d_tk, d_txt = ops.index_sum(d_tk, inv, U), ops.index_sum(d_txt, inv, U)
+    d_txt = _conv1d_backward(net.text_k, d_tk.view(U, h2, 1, L), txt.view(U, -1, 1, L),
+                             d_txt.view(U, -1, 1, L), G).view(U, -1, L)
     G_txt, side, main = None, None, torch.cuda.current_stream()
     if OVERLAP_INSTRUCTION and not torch.cuda.is_current_stream_capturing():
         # d(instruction features) is final here: the bi-LSTM BPTT runs beside the GRU / map-CNN backward below
@@ -204,7 +201,7 @@ def net_backward(net, S: Dict, d_feats: torch.Tensor) -> Dict:
         side.wait_stream(main)
         share_with_stream((d_txt, S["txt"]), side)
         with torch.cuda.stream(side):
-            instruction_backward(net.instruction_encoder, S["txt"], d_txt, rows, L, G_txt)
+            instruction_backward(net.instruction_encoder, S["txt"], d_txt, U, L, G_txt)
     state = x2[:, :H]
     G[net.state_q.weight] = ops.linear_bwd_weight(dq1, state)
     G[net.state_q.bias] = ops.colsum(dq1)
@@ -262,7 +259,7 @@ def net_backward(net, S: Dict, d_feats: torch.Tensor) -> Dict:
                 d = ops.conv2d(dy, ops.weight_flip_transpose(conv.weight), pad=3, weight_is_temp=True)
 
     if G_txt is None:
-        instruction_backward(net.instruction_encoder, S["txt"], d_txt, rows, L, G)
+        instruction_backward(net.instruction_encoder, S["txt"], d_txt, U, L, G)
     else:
         main.wait_stream(side)
         share_with_stream(G_txt, main)

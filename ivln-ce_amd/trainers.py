@@ -31,8 +31,8 @@ from .envs import construct_envs
 from .obs_transforms import apply_obs_transforms_batch, apply_obs_transforms_obs_space, get_active_obs_transforms
 from .registry import baseline_registry
 from .tour_ndtw import compute_tour_ndtw
-from .utils import (add_batched_data_to_observations, batch_obs, batch_to, extract_instruction_tokens,
-                    trim_instruction_padding)
+from .utils import (add_batched_data_to_observations, batch_obs, batch_to, dedupe_instructions,
+                    extract_instruction_tokens, trim_instruction_padding)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -588,7 +588,8 @@ class PrefetchLoader:
             try:
                 for batch in self.loader:
                     # host side, before the H2D copy; batch[-2] = corrected actions (T, N)
-                    batch = (trim_instruction_padding(batch[0], first_rows=batch[-2].shape[1]),) + tuple(batch[1:])
+                    obs_h = dedupe_instructions(trim_instruction_padding(batch[0], first_rows=batch[-2].shape[1]))
+                    batch = (obs_h,) + tuple(batch[1:])
                     parts = tuple(pin(b) for b in batch)
                     if len(parts) == 5:  # episodic collate: no tour masks (slot 3 of the 6-tuple the loops unpack)
                         parts = parts[:3] + (None,) + parts[3:]

@@ -86,6 +86,24 @@ def trim_instruction_padding(observations: Dict, key: str = "instruction", multi
     return observations
 
 
+def dedupe_instructions(observations: Dict, key: str = "instruction") -> Dict:
+    """HOST side, update batches: a collated time-major batch repeats each trajectory's token row at every timestep
+    (T*N rows, N + 1 distinct ones: the trajectories and collate_fn's all-ones padding row).  Adds
+    `instruction_unique` (U, L) and `instruction_index` (T*N,) so that the policy encodes U sequences instead of T*N
+    (policy.MapCMANet.forward_hip); the gradient is identical - the per-row gradients are summed onto the shared
+    encoding in row order.  Left alone when nothing repeats or the tensor is already on the device."""
+    t = observations.get(key)
+    if t is None or not torch.is_tensor(t) or t.is_cuda or t.dim() != 2 or t.shape[0] < 2:
+        return observations
+    uniq, inv = torch.unique(t, dim=0, return_inverse=True)
+    if uniq.shape[0] * 2 > t.shape[0]:
+        return observations
+    observations = dict(observations)
+    observations[key + "_unique"] = uniq.contiguous()
+    observations[key + "_index"] = inv.to(torch.int32).contiguous()
+    return observations
+
+
 def add_batched_data_to_observations(observations: List[Dict], batched_data, batched_data_key: str):
     if batched_data is not None:
         for i in range(len(observations)):

@@ -430,3 +430,59 @@ def test_update_at_bench_shape_T64_N8_matches_oracle():
         if not (abs(got - gref[k]) / max(1e-6, abs(gref[k])) < 1e-3 or abs(got - gref[k]) < noise):
             bad.append(f"{k}: {got:.6e} ref {gref[k]:.6e}")
     assert not bad, "\n".join(bad)
+
+
+@pytest.mark.gpu
+def test_update_with_deduplicated_instruction_rows_is_the_same_update():
+    """Loader-side instruction de-duplication (utils.dedupe_instructions): encoding the U unique token rows once and
+    letting T*N rows share them (indexed attention, per-row gradients folded in row order) must give the loss and the
+    gradients of the plain per-row path - unequal trajectory lengths (collate's all-ones padding rows) included."""
+    from test_gpu_policy import make_policy
+
+    from ivln_ce_amd.aux_losses import AuxLosses
+    from ivln_ce_amd.trainers import FlatAdam, update_agent
+    from ivln_ce_amd.utils import dedupe_instructions, trim_instruction_padding
+
+    T, N = 12, 5
+    TN = T * N
+    g = torch.Generator().manual_seed(12)
+    lens = [12, 9, 12, 4, 7]
+    instr = torch.zeros(N, 200)
+    for n in range(N):
+        L = 30 + 9 * n
+        instr[n, :L] = torch.randint(2, 2504, (L,), generator=g).float()
+    obs_h = {"depth_features": torch.randn(TN, 128, 4, 4, generator=g),
+             "occupancy_map": (torch.rand(TN, 64, 64, generator=g) < 0.3).float(),
+             "semantic_map": torch.randint(0, 13, (TN, 64, 64), generator=g).float(),
+             "instruction": instr.repeat(T, 1), "progress": torch.rand(TN, 1, generator=g)}
+    prev = torch.randint(0, 4, (TN, 1), generator=g)
+    nd = torch.ones(T, N, dtype=torch.uint8)
+    nd[0] = 0
+    tgt = torch.randint(0, 4, (T, N), generator=g)
+    w = torch.where(torch.rand(T, N, generator=g) < 0.4, torch.tensor(3.2), torch.tensor(1.0))
+    for n, Ln in enumerate(lens):
+        w[Ln:, n] = 0
+        tgt[Ln:, n] = 0
+        for k in obs_h:
+            obs_h[k].view(T, N, *obs_h[k].shape[1:])[Ln:, n] = 1.0
+    obs_h = trim_instruction_padding(obs_h, first_rows=N)
+    dd = dedupe_instructions(obs_h)
+    assert dd["instruction_unique"].shape[0] == N + 1 and dd["instruction_index"].shape == (TN,)  # + the padding row
+    assert torch.equal(dd["instruction_unique"][dd["instruction_index"].long()], obs_h["instruction"])
+    res = []
+    for host in (obs_h, dd):
+        pol = make_policy(use_pm=True, train=True)
+        opt = FlatAdam(pol, lr=2.5e-4)
+        obs = {k: v.float().to(DEV) for k, v in host.items()}
+        AuxLosses.activate()
+        try:
+            loss = update_agent(pol, opt, obs, prev.to(DEV), nd.view(-1, 1).to(DEV), tgt.to(DEV), w.to(DEV), step_grad=False)
+        finally:
+            AuxLosses.deactivate()
+        res.append((loss, {k: p.grad.detach().clone() for k, p in pol.named_parameters() if p.requires_grad}))
+    (l0, g0), (l1, g1) = res
+    assert abs(l0[0] - l1[0]) < 1e-6 and abs(l0[2] - l1[2]) < 1e-6, (l0, l1)
+    for k in g0:
+        a, b = g0[k], g1[k]
+        tol = 1e-5 * max(1.0, float(a.abs().max()))
+        assert float((a - b).abs().max()) <= tol, (k, float((a - b).abs().max()), float(a.abs().max()))
