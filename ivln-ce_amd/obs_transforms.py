@@ -108,7 +108,7 @@ class Mapper(ObservationTransformer):
         )
         mp = config.RL.POLICY.OBS_TRANSFORMS.EGOCENTRIC_MAPPER
         tr.sizing = {k: int(getattr(mp, k)) for k in ("table_cells", "world_capacity") if int(getattr(mp, k, 0) or 0) > 0}
-        tr.sizing["b_max"] = max(64, int(getattr(config, "NUM_ENVIRONMENTS", 0) or 0))
+        tr.sizing["b_max"] = 64  # envs per process the mapper is sized for (ivln_mapper_create: <= 64)
         return tr
 
 

@@ -6,14 +6,15 @@ import csv
 import json
 import sys
 
-MFMA = ("k_gemm", "k_conv_direct", "k_wgrad")
+MFMA = ("k_gemm", "k_conv_direct", "k_wgrad", "k_conv_gn")
+MAPPER = ("k_local_", "k_world_", "k_finalize", "k_frames")
 
 
-def load(path):
+def load(path, family=MFMA):
     rows = list(csv.DictReader(open(path)))
     tot = sum(float(r["Total"]) for r in rows) * 1024
-    mf = sum(float(r["Total"]) for r in rows if r["Name"].startswith(MFMA)) * 1024
-    launches = sum(int(r["Launches"]) for r in rows if r["Name"].startswith(MFMA))
+    mf = sum(float(r["Total"]) for r in rows if r["Name"].startswith(family)) * 1024
+    launches = sum(int(r["Launches"]) for r in rows if r["Name"].startswith(family))
     return tot, mf, launches
 
 
@@ -21,6 +22,8 @@ fetch, write, steps, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[
 ft, fm, fl = load(fetch)
 wt, wm, _ = load(write)
 lps = fl / steps
+_, mpf, mpl = load(fetch, MAPPER)
+_, mpw, _ = load(write, MAPPER)
 d = {
     "workload": f"bench.py --envs 4 --no-graph (eager launches; PMC serialises kernels), {steps} steps",
     "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline "
@@ -33,6 +36,12 @@ d = {
         "write_bytes_per_step": int(wm / steps),
         "hbm_bytes_per_step_corrected": int((2 * fm + wm) / steps),
         "hbm_bytes_per_launch_corrected": int((2 * fm + wm) / steps / lps),
+    },
+    "mapper": {
+        "launches_per_step": round(mpl / steps, 2),
+        "fetch_bytes_per_step_raw": int(mpf / steps),
+        "write_bytes_per_step": int(mpw / steps),
+        "hbm_bytes_per_step_corrected": int((2 * mpf + mpw) / steps),
     },
     "all_kernels": {
         "fetch_bytes_per_step_raw": int(ft / steps),
