@@ -141,6 +141,14 @@ typedef struct ivln_gemm_desc {
      * input halos through that L2 instead of re-fetching them from HBM.  1: identity mapping (A/B measurements).
      * Results are identical either way. */
     int no_xcd_remap;
+    /* Image-grouped weights (conv modes with D_NCHW; 0 = off): images [g*grp_imgs, (g+1)*grp_imgs) use weight set g,
+     * A + g*a_grp_stride (and A_packed + g*a_packed_grp_stride), and epilogue parameters scale / shift [g*M + m].
+     * RedNet's RGB and depth encoders are the same ResNet-50 with different weights (rednet.py:190-222): stacked on the
+     * image axis they run as ONE launch per layer with twice the output tiles (fewer split-K epilogues).  Output tiles
+     * must not straddle a group: grp_imgs * HoWo has to be a multiple of the pixel tile (checked, else
+     * IVLN_E_UNSUPPORTED). */
+    int grp_imgs;
+    int64_t a_grp_stride, a_packed_grp_stride;
 } ivln_gemm_desc;
 
 int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream);

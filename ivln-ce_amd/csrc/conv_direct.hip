@@ -52,6 +52,8 @@ __global__ __launch_bounds__(256) void k_conv_direct(const ivln_gemm_desc p, int
     const int c_beg = bid.z * chunks_per_split;
     const int c_end = min(nch, c_beg + chunks_per_split);
     const int HW = p.Hin * p.Win;
+    const int grp = p.grp_imgs > 0 ? img0 / p.grp_imgs : 0;  // weight set of this tile's images (image-grouped convs)
+    const float* __restrict__ Ag = p.A + (int64_t)grp * p.a_grp_stride;
 
     // patch elements of this thread: chunk-invariant source offsets (-1 = zero padding / no such image)
     int poff[NP];
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(256) void k_conv_direct(const ivln_gemm_desc p, int
     float ra[NA], rp[NP];
     auto load_chunk = [&](int c) {
         if constexpr (PACKED) {
-            const float* wp = p.A_packed + ((int64_t)bid.y * nch + c) * (KC * LDA);
+            const float* wp = p.A_packed + (int64_t)grp * p.a_packed_grp_stride + ((int64_t)bid.y * nch + c) * (KC * LDA);
 #pragma unroll
             for (int i = 0; i < NA / 4; ++i) {
                 const int f = t + i * 256;
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(256) void k_conv_direct(const ivln_gemm_desc p, int
                 const int idx = t + i * 256;
                 const int co = idx / KC, kk = idx - co * KC;
                 const bool ok = idx < BM * KC && m0 + co < p.M;
-                const float v = p.A[ok ? (int64_t)(m0 + co) * p.lda + kbase + kk : 0];
+                const float v = Ag[ok ? (int64_t)(m0 + co) * p.lda + kbase + kk : 0];
                 ra[i] = ok ? v : 0.f;
             }
         }
@@ -432,6 +434,7 @@ int ivln_conv_direct_launch(ivln_gemm_desc& d, hipStream_t s) {
     const int PTW = d.Wout > 16 ? 32 : (d.Wout > 8 ? 16 : (d.Wout > 4 ? 8 : 4));
     const int PTH = PTW == 32 ? 4 : (PTW == 4 ? 4 : 8);
     const int IMGS = 128 / (PTW * PTH);
+    if (d.grp_imgs > 0 && (d.grp_imgs % IMGS != 0 || nimg % d.grp_imgs != 0)) return IVLN_E_UNSUPPORTED;  // a tile's images share one weight set
     const int64_t tiles = (int64_t)((d.Wout + PTW - 1) / PTW) * ((d.Hout + PTH - 1) / PTH) * ((nimg + IMGS - 1) / IMGS);
     const int BM = d.M <= 32 ? 32 : 64;
     const int64_t blocks = tiles * ((d.M + BM - 1) / BM);

@@ -37,12 +37,19 @@ __device__ __forceinline__ BlockId xcd_block_id(int disabled) {
     return b;
 }
 
+// weight set of the output tile whose first column is n0 (image-grouped convs, ivln_gemm_desc.grp_imgs)
+__device__ __forceinline__ int tile_group(const ivln_gemm_desc& p, int n0) {
+    return p.grp_imgs > 0 ? (n0 / p.HoWo) / p.grp_imgs : 0;
+}
+
 __device__ __forceinline__ void epilogue_store(const ivln_gemm_desc& p, int m, int n, float v) {
     int64_t addr;
+    int me = m;  // index of the epilogue parameters: weight set g of image-grouped convs keeps them at [g*M + m]
     if (p.dmode == DMODE_NCHW) {
         int img = n / p.HoWo;
         int pp = n - img * p.HoWo;
         addr = ((int64_t)img * p.Ctot + m) * p.HoWo + pp;
+        if (p.grp_imgs > 0) me = (img / p.grp_imgs) * p.M + m;
     } else if (p.dmode == DMODE_NCHW_UP2) {
         int img = n / p.HoWo;
         int pp = n - img * p.HoWo;
@@ -51,8 +58,8 @@ __device__ __forceinline__ void epilogue_store(const ivln_gemm_desc& p, int m, i
     } else {
         addr = (int64_t)m * p.sDm + (int64_t)n * p.sDn;
     }
-    if (p.scale) v = fmaf(v, p.scale[m], p.shift[m]);
-    else if (p.shift) v += p.shift[m];
+    if (p.scale) v = fmaf(v, p.scale[me], p.shift[me]);
+    else if (p.shift) v += p.shift[me];
     if (p.residual) v += p.residual[addr];
     if (p.accumulate) v += p.D[addr];
     if (p.relu) v = fmaxf(v, 0.f);

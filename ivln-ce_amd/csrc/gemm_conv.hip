@@ -89,6 +89,7 @@ __global__ __launch_bounds__(256) void k_gemm(const ivln_gemm_desc p) {
     }
 
     float ra0[EA], rb0[EB], ra1[EA], rb1[EB];
+    const float* __restrict__ Ag = p.A + (int64_t)tile_group(p, n0) * p.a_grp_stride;  // this tile's weight set
 
     // Branch-free tile loads: every lane ALWAYS issues its load from a clamped (valid) address and the
     // out-of-range / padding case is a select afterwards.  With the loads unconditional hipcc can count
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256) void k_gemm(const ivln_gemm_desc p) {
             for (int e = 0; e < EA; ++e) {
                 const int m = m0 + a_m + e * A_STEP;
                 const bool ok = kok && m < p.M;
-                const float v = p.A[ok ? (int64_t)m * p.lda + k : 0];
+                const float v = Ag[ok ? (int64_t)m * p.lda + k : 0];
                 ra[e] = ok ? v : 0.f;
             }
         } else if constexpr (AMODE == AMODE_KM) {
@@ -332,6 +333,10 @@ extern "C" int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream) {
     if (d.dil <= 0) d.dil = 1;
     if (d.Ctot <= 0) d.Ctot = d.M;
     if (d.in_img_stride <= 0) d.in_img_stride = (int64_t)d.Cin * d.Hin * d.Win;
+    if (d.grp_imgs > 0) {  // image-grouped weights: forward convs into an NCHW destination only
+        if (d.amode != AMODE_MK || d.dmode != DMODE_NCHW || d.N % ((int64_t)d.grp_imgs * d.HoWo) != 0) return IVLN_E_INVALID;
+        if (d.a_grp_stride <= 0) d.a_grp_stride = (int64_t)d.M * d.lda;
+    }
     // stride-1 3x3 / 7x7: LDS-staged direct convolution (conv_direct.hip); tile_override 1..5 pins the
     // implicit GEMM tiles, 6 insists on the direct kernel
     if (d.tile_override == 0 || d.tile_override == 6) {
@@ -368,6 +373,15 @@ extern "C" int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream) {
     // the float4-staged kernel is fastest at 64x64 (~100 VGPRs: four waves per SIMD; 64x128 and 128x128
     // measured 90 / 79 vs 94 TFLOP/s on 1024x4096x1024 and lose more on the small 1x1 convs)
     if (vec && tile != 1 && tile != 2) tile = vec_tile_env >= 0 ? vec_tile_env : 0;
+    if (d.grp_imgs > 0) {  // an output tile must lie inside one weight group
+        const int64_t gp = (int64_t)d.grp_imgs * d.HoWo;
+        const int bn = tile == 1 ? 128 : (tile == 2 ? 32 : (tile == 3 || tile == 4 ? 128 : 64));
+        if (gp % bn != 0) {
+            if (gp % 64 == 0) tile = 0;
+            else if (gp % 32 == 0) tile = 2;
+            else return IVLN_E_UNSUPPORTED;
+        }
+    }
     const int BM = tile == 1 ? 32 : (tile == 2 || tile == 3 ? 128 : 64);
     const int BN = tile == 1 ? 128 : (tile == 2 ? 32 : (tile == 3 || tile == 4 ? 128 : 64));
     // split-K when the output grid cannot fill the chip and K is deep

@@ -89,6 +89,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_vec(const ivln_gemm_desc p) {
         }
     }
     const int64_t a_kstep = ALAY == LAY_K ? 1 : p.lda;
+    const float* __restrict__ Ag = p.A + (int64_t)tile_group(p, n0) * p.a_grp_stride;  // this tile's weight set
     const int64_t b_kstep = BLAY == LAY_K ? 1 : brow;
 
     float4 ra0[EA], rb0[EB], ra1[EA], rb1[EB];
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_vec(const ivln_gemm_desc p) {
 #pragma unroll
         for (int e = 0; e < EA; ++e) {
             const bool ok = a_ok[e] && k0 + a_k[e] < kend;
-            const float4 v = *reinterpret_cast<const float4*>(p.A + (ok ? a_off[e] + (int64_t)k0 * a_kstep : 0));
+            const float4 v = *reinterpret_cast<const float4*>(Ag + (ok ? a_off[e] + (int64_t)k0 * a_kstep : 0));
             ra[e] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
         }
 #pragma unroll

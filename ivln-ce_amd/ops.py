@@ -35,6 +35,7 @@ class GemmDesc(C.Structure):
         ("tile_override", i32),
         ("A_packed", vp),
         ("no_xcd_remap", i32),
+        ("grp_imgs", i32), ("a_grp_stride", i64), ("a_packed_grp_stride", i64),
     ]
 
 
@@ -147,17 +148,26 @@ def packed_conv_weights(w, cache=True):
     gradient) are packed into a fresh buffer every call so that nothing accumulates."""
     import weakref
 
-    Cout, Cin, KH, KW = w.shape
+    G = w.shape[0] if w.dim() == 5 else 1  # (G, Cout, Cin, k, k): image-grouped weight sets, packed one after another
+    Cout, Cin, KH, KW = w.shape[-4:]
     L = _L()
     L.ivln_conv_packed_floats.restype = i64
     L.ivln_conv_packed_floats.argtypes = [i32, i32, i32]
     L.ivln_conv_pack_weights_f32.argtypes = [vp, i32, i32, i32, vp, vp]
-    n = L.ivln_conv_packed_floats(Cout, Cin, KH)
-    if n <= 0:
+    n1 = L.ivln_conv_packed_floats(Cout, Cin, KH)
+    if n1 <= 0:
         return None
+    n = n1 * G
+    wsz = Cout * Cin * KH * KW
+
+    def _pack(dst):
+        for g in range(G):
+            check(L.ivln_conv_pack_weights_f32(w.data_ptr() + 4 * g * wsz, Cout, Cin, KH, dst.data_ptr() + 4 * g * n1,
+                                               stream_ptr()), "ivln_conv_pack_weights_f32")
+
     if not cache:
         out = torch.empty(n, dtype=torch.float32, device=w.device)
-        check(L.ivln_conv_pack_weights_f32(dptr(w), Cout, Cin, KH, dptr(out), stream_ptr()), "ivln_conv_pack_weights_f32")
+        _pack(out)
         return out
     key = (w.data_ptr(), tuple(w.shape))
     stamp = (w._version, WEIGHT_EPOCH)
@@ -179,7 +189,7 @@ def packed_conv_weights(w, cache=True):
         out = hit.out
     else:
         out = torch.empty(n, dtype=torch.float32, device=w.device)
-    check(L.ivln_conv_pack_weights_f32(dptr(w), Cout, Cin, KH, dptr(out), stream_ptr()), "ivln_conv_pack_weights_f32")
+    _pack(out)
     if capturing:
         return out  # lives in this graph's pool, valid inside this graph only: not cached
     if len(_packed) > 1024:
@@ -218,7 +228,8 @@ def conv2d(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, 
     """NCHW conv: x (N,Cin,H,W) [contiguous per image, image stride `in_img_stride`], w OIHW.
     out: optional destination (a channel slice of an (N,out_ctot,Ho,Wo) buffer)."""
     N, Cin, H, W = x.shape
-    Cout, _, KH, KW = w.shape
+    G = w.shape[0] if w.dim() == 5 else 0  # (G, Cout, Cin, k, k): weight set g for images [g*N/G, (g+1)*N/G)
+    Cout, _, KH, KW = w.shape[-4:]
     Ho = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
     Wo = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
     if defer:
@@ -234,6 +245,10 @@ def conv2d(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, 
     d.stride, d.pad, d.dil = stride, pad, dil
     d.HoWo, d.Ctot = Ho * Wo, out_ctot
     d.in_img_stride = in_img_stride
+    if G:
+        if N % G or not w.is_contiguous():
+            raise _lib.IvlnError("image-grouped conv: N must be a multiple of the weight sets, weights contiguous")
+        d.grp_imgs, d.a_grp_stride = N // G, Cout * Cin * KH * KW
     if KH == 1 and KW == 1 and pad == 0:
         d.bmode = B_CONV1X1
     elif KH == KW and KH in (3, 7) and dil == 1:
@@ -242,6 +257,7 @@ def conv2d(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, 
             pk = packed_conv_weights(w, cache=not weight_is_temp)
             if pk is not None:
                 d.A_packed = dptr(pk)
+                d.a_packed_grp_stride = pk.numel() // max(G, 1)
     else:
         d.bmode = B_CONV
         koff, kpos = conv_tables(Cin, KH, KW, H, W, dil, x.device)

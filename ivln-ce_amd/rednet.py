@@ -15,6 +15,10 @@ import torch.nn as nn
 from . import ops
 
 
+# RGB + depth encoders as one image-grouped pass (A/B switch: IVLN_REDNET_NO_GROUP=1 runs them as two chains)
+GROUP_ENCODERS = not bool(os.environ.get("IVLN_REDNET_NO_GROUP"))
+
+
 def _conv3x3(cin, cout, stride=1):
     return nn.Conv2d(cin, cout, kernel_size=3, stride=stride, padding=1, bias=False)
 
@@ -33,6 +37,16 @@ class _Folded:
             shift = torch.empty(C, dtype=torch.float32, device=bn.weight.device)
             ops.bn_fold(bn, scale, shift)
             self.c[k] = (scale, shift)
+        return self.c[k]
+
+    def pair(self, conv_a, bn_a, conv_b, bn_b):
+        """Twin layers of the RGB and depth encoders as ONE image-grouped conv: weights stacked (2, Cout, Cin, k, k),
+        folded BatchNorm scale / shift stacked (2*Cout) - set g serves images [g*B, (g+1)*B) (ivln_gemm_desc.grp_imgs)."""
+        k = ("pair", id(conv_a))
+        if k not in self.c:
+            (sa, ba), (sb, bb) = self.bn(bn_a), self.bn(bn_b)
+            w = torch.stack([conv_a.weight.detach(), conv_b.weight.detach()]).contiguous()
+            self.c[k] = (w, torch.cat([sa, sb]).contiguous(), torch.cat([ba, bb]).contiguous())
         return self.c[k]
 
     def classes(self, convt: nn.ConvTranspose2d):
@@ -86,6 +100,38 @@ class Bottleneck(nn.Module):
         y = ops.conv2d(y, self.conv2.weight, stride=self.stride, pad=1, scale=s, shift=b, relu=True)
         s, b = f.bn(self.bn3)
         return ops.conv2d(y, self.conv3.weight, scale=s, shift=b, residual=residual, relu=True)
+
+
+def _conv_pair(x2, w2, s2, b2, stride=1, pad=0, residual=None, relu=False):
+    """Image-grouped conv of the stacked [RGB ; depth] batch; tiny feature maps (fewer than 32 pixels per weight
+    set: an output tile would straddle the sets) run as two plain convs into the halves of one output."""
+    N, _, H, W = x2.shape
+    G, Cout, _, KH, KW = w2.shape
+    B = N // G
+    Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    if (B * Ho * Wo) % 32 == 0:
+        return ops.conv2d(x2, w2, stride=stride, pad=pad, scale=s2, shift=b2, residual=residual, relu=relu)
+    out = torch.empty((N, Cout, Ho, Wo), dtype=torch.float32, device=x2.device)
+    for g in range(G):
+        sl = slice(g * B, (g + 1) * B)
+        ops.conv2d(x2[sl], w2[g], stride=stride, pad=pad, scale=s2[g * Cout:(g + 1) * Cout], shift=b2[g * Cout:(g + 1) * Cout],
+                   residual=residual[sl] if residual is not None else None, relu=relu, out=out[sl])
+    return out
+
+
+def _bottleneck_pair(blk: Bottleneck, blk_d: Bottleneck, x2, f: _Folded):
+    """The same bottleneck of the RGB encoder (first half of the stacked batch) and of the depth encoder (second
+    half) in one pass: 3-4 launches instead of 6-8, every launch with twice the output tiles."""
+    residual = x2
+    if blk.downsample is not None:
+        w, s, b = f.pair(blk.downsample[0], blk.downsample[1], blk_d.downsample[0], blk_d.downsample[1])
+        residual = _conv_pair(x2, w, s, b, stride=blk.stride)
+    w, s, b = f.pair(blk.conv1, blk.bn1, blk_d.conv1, blk_d.bn1)
+    y = _conv_pair(x2, w, s, b, relu=True)
+    w, s, b = f.pair(blk.conv2, blk.bn2, blk_d.conv2, blk_d.bn2)
+    y = _conv_pair(y, w, s, b, stride=blk.stride, pad=1, relu=True)
+    w, s, b = f.pair(blk.conv3, blk.bn3, blk_d.conv3, blk_d.bn3)
+    return _conv_pair(y, w, s, b, residual=residual, relu=True)
 
 
 class TransBasicBlock(nn.Module):
@@ -218,21 +264,42 @@ class RedNet(nn.Module):
         (rednet.py:190-269, eval path)."""
         assert not self.training, "HIP RedNet is inference-only (the reference freezes it, mapper.py:751-752)"
         f = self._folded
-        s, b = f.bn(self.bn1)
-        x = ops.conv2d(rgb, self.conv1.weight, stride=2, pad=3, scale=s, shift=b, relu=True)
-        s, b = f.bn(self.bn1_d)
-        d = ops.conv2d(depth, self.conv1_d.weight, stride=2, pad=3, scale=s, shift=b, relu=True)
-        fuse0 = ops.add(x, d)
-        x = ops.pool2d(fuse0, 3, 2, 1, "max")
-        d = ops.pool2d(d, 3, 2, 1, "max")
-        x, d = self._seq(self.layer1, x), self._seq(self.layer1_d, d)
-        fuse1 = ops.add(x, d)
-        x, d = self._seq(self.layer2, fuse1), self._seq(self.layer2_d, d)
-        fuse2 = ops.add(x, d)
-        x, d = self._seq(self.layer3, fuse2), self._seq(self.layer3_d, d)
-        fuse3 = ops.add(x, d)
-        x, d = self._seq(self.layer4, fuse3), self._seq(self.layer4_d, d)
-        fuse4 = ops.add(x, d)
+        if GROUP_ENCODERS:
+            # The two encoders are the same ResNet-50 with different weights, coupled only by the five fusion adds
+            # (rednet.py:190-222): stacked on the image axis - [RGB branch ; depth branch] - every layer is ONE
+            # image-grouped launch.  A fusion add is done in place on the first half, which then IS the RGB branch's
+            # next input (and the decoder's skip tensor).
+            B = rgb.shape[0]
+            S = torch.empty((2 * B, 64, rgb.shape[2] // 2, rgb.shape[3] // 2), dtype=torch.float32, device=rgb.device)
+            s, b = f.bn(self.bn1)
+            ops.conv2d(rgb, self.conv1.weight, stride=2, pad=3, scale=s, shift=b, relu=True, out=S[:B])
+            s, b = f.bn(self.bn1_d)
+            ops.conv2d(depth, self.conv1_d.weight, stride=2, pad=3, scale=s, shift=b, relu=True, out=S[B:])
+            fuse0 = ops.add(S[:B], S[B:], out=S[:B])
+            P = ops.pool2d(S, 3, 2, 1, "max")
+            fuses = []
+            for la, lb in ((self.layer1, self.layer1_d), (self.layer2, self.layer2_d), (self.layer3, self.layer3_d),
+                           (self.layer4, self.layer4_d)):
+                for blk, blk_d in zip(la, lb):
+                    P = _bottleneck_pair(blk, blk_d, P, f)
+                fuses.append(ops.add(P[:B], P[B:], out=P[:B]))
+            fuse1, fuse2, fuse3, fuse4 = fuses
+        else:
+            s, b = f.bn(self.bn1)
+            x = ops.conv2d(rgb, self.conv1.weight, stride=2, pad=3, scale=s, shift=b, relu=True)
+            s, b = f.bn(self.bn1_d)
+            d = ops.conv2d(depth, self.conv1_d.weight, stride=2, pad=3, scale=s, shift=b, relu=True)
+            fuse0 = ops.add(x, d)
+            x = ops.pool2d(fuse0, 3, 2, 1, "max")
+            d = ops.pool2d(d, 3, 2, 1, "max")
+            x, d = self._seq(self.layer1, x), self._seq(self.layer1_d, d)
+            fuse1 = ops.add(x, d)
+            x, d = self._seq(self.layer2, fuse1), self._seq(self.layer2_d, d)
+            fuse2 = ops.add(x, d)
+            x, d = self._seq(self.layer3, fuse2), self._seq(self.layer3_d, d)
+            fuse3 = ops.add(x, d)
+            x, d = self._seq(self.layer4, fuse3), self._seq(self.layer4_d, d)
+            fuse4 = ops.add(x, d)
         x = self._agant(self.agant4, fuse4)
         x = ops.add(self._seq(self.deconv1, x), self._agant(self.agant3, fuse3))
         x = ops.add(self._seq(self.deconv2, x), self._agant(self.agant2, fuse2))

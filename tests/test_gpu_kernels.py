@@ -684,3 +684,29 @@ def test_conv_groupnorm_refuses_shapes_outside_its_envelope():
     assert ops.conv_gn(torch.randn(2, 256, 4, 4, device=DEV), torch.randn(1024, 256, 1, 1, device=DEV), gn3, relu=True,
                        ds=(torch.randn(2, 512, 8, 8, device=DEV), torch.randn(1024, 512, 1, 1, device=DEV), gnd, 2),
                        force=True) is None
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout,k,s,p", [(4, 64, 16, 16, 64, 3, 1, 1), (2, 256, 8, 8, 64, 1, 1, 0), (3, 64, 8, 8, 256, 1, 1, 0),
+                                                   (2, 128, 16, 16, 128, 3, 2, 1), (2, 256, 16, 16, 512, 1, 2, 0),
+                                                   (8, 512, 8, 8, 512, 3, 1, 1), (1, 64, 32, 32, 64, 3, 1, 1)])
+def test_image_grouped_conv_matches_two_separate_convs(B, Cin, H, W, Cout, k, s, p):
+    """ivln_gemm_desc.grp_imgs: images [0, B) with weight set 0 and [B, 2B) with set 1 in ONE launch (RedNet's RGB and
+    depth encoders stacked) == the two convs run separately, with per-set folded-BN scale / shift, residual, ReLU.
+    Covers the direct 3x3 kernel (packed weights per set), the vector-load 1x1 GEMM and the strided gather GEMM."""
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(B * 100 + Cin + k)
+    x = torch.randn(2 * B, Cin, H, W, generator=g).to(DEV)
+    w = (torch.randn(2, Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).to(DEV)
+    sc, sh = (1 + 0.2 * torch.randn(2 * Cout, generator=g)).to(DEV), torch.randn(2 * Cout, generator=g).to(DEV)
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    res = torch.randn(2 * B, Cout, Ho, Wo, generator=g).to(DEV)
+    got = ops.conv2d(x, w, stride=s, pad=p, scale=sc, shift=sh, residual=res, relu=True)
+    for gi in range(2):
+        sl = slice(gi * B, (gi + 1) * B)
+        ref = ops.conv2d(x[sl], w[gi].contiguous(), stride=s, pad=p, scale=sc[gi * Cout:(gi + 1) * Cout].contiguous(),
+                         shift=sh[gi * Cout:(gi + 1) * Cout].contiguous(), residual=res[sl], relu=True)
+        tref = F.relu(F.conv2d(x[sl].cpu(), w[gi].cpu(), None, s, p) * sc[gi * Cout:(gi + 1) * Cout].cpu().view(1, -1, 1, 1)
+                      + sh[gi * Cout:(gi + 1) * Cout].cpu().view(1, -1, 1, 1) + res[sl].cpu())
+        _close(ref, tref, 2e-5)
+        assert float((got[sl] - ref).abs().max()) < 2e-5, gi
