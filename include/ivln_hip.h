@@ -190,6 +190,46 @@ typedef struct ivln_conv_gn_desc {
 int ivln_conv_gn_f32(const ivln_conv_gn_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * GroupNorm (+ second normalised operand) (+ residual) (+ ReLU) (+ MaxPool2d(3, 2, 1)) fused with the NEXT
+ * bias-free convolution(s) (csrc/gn_conv.hip) - the other way round from ivln_conv_gn_f32.  One workgroup per
+ * (image, group) reduces the `splits` slabs of the incoming [C][N*H*W] matrix (the split-K workspace of a deferred
+ * ivln_gemm_f32, or the slabs a previous ivln_gn_conv_f32 wrote: slab s at x + s*slab_stride), normalises and
+ * activates its C/groups channels, and multiplies them into conv A (k = 1 | 3) and optionally conv B (1x1): the next
+ * convolution is split over K by GroupNorm group, every workgroup writes partial slab `group` of
+ *   ya : [groups][Cout_a][N*Ho*Wo]        yb : [groups][Cout_b][N*Hb*Wb]
+ * which the next ivln_gn_conv_f32 / ivln_groupnorm_f32 (splits = groups, slab_stride = Cout*N*Ho*Wo) reduces.
+ * One launch per conv layer of habitat-lab's DD-PPO ResNetEncoder (models/encoders/resnet_encoders.py:31-43, 95):
+ * conv -> GroupNorm -> ReLU -> conv ..., Bottleneck tails relu(GN(c3) + GN_ds(ds)) / relu(GN(c3) + identity) feeding
+ * the next block's conv1 (A) and downsample conv (B).  act_out (N, C, H', W') receives the activation when a later
+ * block needs it as its identity.  IVLN_E_UNSUPPORTED: (C/groups)*H*W > 8192, C/groups not 2 | 4 | a multiple of 8,
+ * more than 1024 output pixels per image, k not in {1, 3}. */
+typedef struct ivln_gn_conv_desc {
+    const float* x;       /* slabs of [C][N*H*W] */
+    int splits;
+    int64_t slab_stride;
+    const float* gamma;   /* (C) */
+    const float* beta;
+    const float* x2;      /* second operand: slabs of [C][N*H*W], or NULL */
+    int splits2;
+    int64_t slab_stride2;
+    const float* gamma2;
+    const float* beta2;
+    const float* residual; /* (N, C, H, W) or NULL */
+    int N, C, H, W, groups;
+    float eps;
+    int relu;
+    int pool;             /* 1: MaxPool2d(3, stride 2, padding 1) after the activation */
+    float* act_out;       /* (N, C, H', W') (after the pool) or NULL */
+    const float* wa;      /* (Cout_a, C, ka, ka) or NULL */
+    int Cout_a, ka, stride_a, pad_a;
+    float* ya;
+    const float* wb;      /* (Cout_b, C, 1, 1) or NULL */
+    int Cout_b, stride_b;
+    float* yb;
+} ivln_gn_conv_desc;
+int ivln_gn_conv_f32(const ivln_gn_conv_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Non-GEMM forward kernels (csrc/nn_ops.hip).  All tensors fp32 NCHW unless noted.
  * ------------------------------------------------------------------------------------------ */
 /* nn.GroupNorm (+ residual add) (+ ReLU): habitat-lab ddppo resnet Bottleneck / ResNetEncoder

@@ -16,6 +16,7 @@ SOURCES = {
     "conv_direct.hip": [],
     "gemm_vec.hip": [],
     "conv_gn.hip": [],
+    "gn_conv.hip": [],
     "cma_step.hip": [],
     "nn_ops.hip": [],
     "train_ops.hip": [],

@@ -1,0 +1,488 @@
+// GroupNorm (+ second normalised operand / residual) (+ ReLU) (+ MaxPool) fused with the NEXT convolution(s), for the
+// DD-PPO depth ResNet at rollout batch sizes (habitat-lab ResNetEncoder: conv -> GroupNorm(16, C) -> ReLU chains and
+// Bottleneck tails relu(convs(x) + downsample(x)) / relu(convs(x) + x); call site
+// ivlnce_baselines/models/encoders/resnet_encoders.py:31-43, 95; restated in oracle/habitat_ext_ref.py:37-175).
+//
+// The encoder's chain at 4-8 envs is launch-bound: 105 dependent launches of ~6 us (conv with split-K slabs, then a
+// GroupNorm launch that reduces them).  Fusing the conv INTO ITS OWN GroupNorm (csrc/conv_gn.hip: workgroup = (image,
+// group) with the whole K reduction inside) lost - the block then has to stream the image's whole input.  This
+// kernel fuses the other way round: a workgroup still owns one (image, group) of GroupNorm i - it reduces the slabs,
+// normalises, activates - and then multiplies ITS cpg activated channels into the NEXT convolution:
+//     y_{i+1}[co][p] = sum_g  sum_{c in group g, taps} W[co][c][tap] a_i[c][p + tap]
+// i.e. the next conv is split over K by GroupNorm group, each block writes one partial slab (all Cout, all pixels of
+// its image, its cpg*k*k slice of K), and the NEXT GroupNorm kernel reduces the 16 slabs exactly like the split-K
+// slabs it reduces today.  K per block is tiny (cpg*k*k = 8..576), the activated tile sits in LDS, weights are the
+// block's wave-uniform [co][cpg*k*k] slices: one launch per conv layer, 52 instead of 105 for the encoder.
+// The bottleneck's first conv and its downsample conv share the producing kernel (conv A and conv B).
+//
+// Bound: L2 -> CU bandwidth for the slab reduction (16 x the tile) and the slab write (Cout x pixels per block), then
+// fp32 VALU for the partial conv (0.26 - 0.6 MMAC per block).  Not MFMA-shaped: K per block is 8-72 in the layers
+// that matter.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include <stdlib.h>
+#include <mutex>
+#include <set>
+#include "../../include/ivln_hip.h"
+
+namespace {
+
+constexpr int GT = 512;          // threads per block
+constexpr int TILE_MAX = 8192;   // cpg * H * W floats held in LDS
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr size_t kLdsFloats = 38 * 1024;  // 152 KB of the CU's 160 KB
+
+typedef ivln_gn_conv_desc Desc;
+
+#ifdef GN_CONV_TIMING  // tools/gn_conv_phases.py: per-block phase stamps (100 MHz wall clock)
+__device__ unsigned long long g_stamp[4096 * 8];
+#define STAMP(k)                                                                                         \
+    do {                                                                                                 \
+        __syncthreads();                                                                                 \
+        if (threadIdx.x == 0) g_stamp[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (k)] = wall_clock64(); \
+    } while (0)
+#else
+#define STAMP(k)
+#endif
+
+// wave64 sum on the DPP cross-lane path (6 VALU ops; __shfl_xor is an LDS permute per step): total in lane 63
+__device__ __forceinline__ float wave_sum(float v) {
+#define IVLN_DPP_ADD(ctrl, row_mask)                                                                                   \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, row_mask, 0xf, false))
+    IVLN_DPP_ADD(0xB1, 0xf);   // quad_perm [1,0,3,2]
+    IVLN_DPP_ADD(0x4E, 0xf);   // quad_perm [2,3,0,1]
+    IVLN_DPP_ADD(0x141, 0xf);  // row_half_mirror
+    IVLN_DPP_ADD(0x140, 0xf);  // row_mirror: every lane of a row of 16 holds the row's sum
+    IVLN_DPP_ADD(0x142, 0xa);  // row_bcast:15 -> rows 1, 3
+    IVLN_DPP_ADD(0x143, 0xc);  // row_bcast:31 -> rows 2, 3
+#undef IVLN_DPP_ADD
+    return v;
+}
+// block-wide sums of two values at once (red: 32 floats of LDS)
+__device__ __forceinline__ void block_sum2(float& a, float& b, float* red) {
+    a = wave_sum(a);
+    b = wave_sum(b);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 63) {
+        red[w] = a;
+        red[16 + w] = b;
+    }
+    __syncthreads();
+    a = 0.f;
+    b = 0.f;
+#pragma unroll
+    for (int i = 0; i < GT / 64; ++i) {
+        a += red[i];
+        b += red[16 + i];
+    }
+}
+
+// a / b for 0 <= a < 2^20 without the ~40-instruction integer division: (a + 0.5) / b is at least 0.5 / b away from an
+// integer, far more than the float error
+struct fdiv {
+    float r;
+    __device__ __forceinline__ explicit fdiv(int b) : r(__builtin_amdgcn_rcpf((float)b)) {}
+    __device__ __forceinline__ int operator()(int a) const { return (int)(((float)a + 0.5f) * r); }
+};
+
+// launch geometry derived on the host (no divisions by launch constants in the kernel)
+struct Geo {
+    int cpg, Hc, Wc;           // channels per group; the convs' input size (after the pool)
+    int Ho_a, Wo_a, Ho_b, Wo_b;
+    int per_a, per_b;          // output channels per blockIdx.z
+    int wl_floats, wthr, part_floats;
+};
+
+template <int V> struct vecf;
+template <> struct vecf<4> { typedef float4 type; };
+template <> struct vecf<1> { typedef float type; };
+__device__ __forceinline__ void vadd(float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+__device__ __forceinline__ void vadd(float& a, const float& b) { a += b; }
+__device__ __forceinline__ float vsum(const float4& a) { return (a.x + a.y) + (a.z + a.w); }
+__device__ __forceinline__ float vsum(const float& a) { return a; }
+
+// `splits` slabs at p (stride slab_stride) summed in slab order; the 16-slab case (the output of a previous gn_conv)
+// keeps all its loads in flight at once
+template <int V>
+__device__ __forceinline__ typename vecf<V>::type slab_sum(const float* __restrict__ p, int splits, int64_t slab_stride) {
+    typedef typename vecf<V>::type T;
+    T v = *reinterpret_cast<const T*>(p);
+    int z = 1;
+    if (splits == 16) {
+        T w[15];
+#pragma unroll
+        for (int q = 0; q < 15; ++q) w[q] = *reinterpret_cast<const T*>(p + (int64_t)(q + 1) * slab_stride);
+#pragma unroll
+        for (int q = 0; q < 15; ++q) vadd(v, w[q]);
+        return v;
+    }
+    for (; z + 3 < splits; z += 4) {
+        const T w0 = *reinterpret_cast<const T*>(p + (int64_t)z * slab_stride);
+        const T w1 = *reinterpret_cast<const T*>(p + (int64_t)(z + 1) * slab_stride);
+        const T w2 = *reinterpret_cast<const T*>(p + (int64_t)(z + 2) * slab_stride);
+        const T w3 = *reinterpret_cast<const T*>(p + (int64_t)(z + 3) * slab_stride);
+        vadd(v, w0); vadd(v, w1); vadd(v, w2); vadd(v, w3);
+    }
+    for (; z < splits; ++z) vadd(v, *reinterpret_cast<const T*>(p + (int64_t)z * slab_stride));
+    return v;
+}
+
+// One pass over the block's (image, group) tile by threads [0, nthr): the slabs of x (and of the second operand x2)
+// summed into LDS, the residual copied next to them - every global load of the GroupNorm front-end is issued in
+// this one loop, so the tile costs one memory round trip.  s / s2: this thread's partial sums of x / x2.
+template <int V>
+__device__ __forceinline__ void load_tiles(const Desc& D, int n, int c0, int cpg, int HW, int nthr, float* tile, float* tile2,
+                                           float* tres, float& s, float& s2) {
+    typedef typename vecf<V>::type T;
+    const int nel = cpg * HW;
+    const int64_t NHW = (int64_t)D.N * HW;
+    const fdiv by_hw(HW);
+    for (int i = threadIdx.x * V; i < nel; i += nthr * V) {
+        const int cl = by_hw(i), pp = i - cl * HW;
+        const int64_t o = (int64_t)(c0 + cl) * NHW + (int64_t)n * HW + pp;
+        T r;
+        if (D.residual) r = *reinterpret_cast<const T*>(D.residual + ((int64_t)n * D.C + c0) * HW + i);
+        const T v = slab_sum<V>(D.x + o, D.splits, D.slab_stride);
+        *reinterpret_cast<T*>(&tile[i]) = v;
+        s += vsum(v);
+        if (D.x2) {
+            const T v2 = slab_sum<V>(D.x2 + o, D.splits2, D.slab_stride2);
+            *reinterpret_cast<T*>(&tile2[i]) = v2;
+            s2 += vsum(v2);
+        }
+        if (D.residual) *reinterpret_cast<T*>(&tres[i]) = r;
+    }
+}
+
+// This block's weight slice W[co0 .. co0+nrow)[koff .. koff+Kb) (rows of K floats in global) -> wl[nrow][Kbp] (LDS) by
+// threads [t0, t0+nthr), float4 when the rows allow it.
+__device__ __forceinline__ void stage_weights(const float* __restrict__ w, int K, int koff, int Kb, int Kbp, int co0, int nrow,
+                                              float* wl, int t0, int nthr) {
+    const int tid = (int)threadIdx.x - t0;
+    if (tid < 0 || tid >= nthr) return;
+    if (((Kb | K) & 3) == 0) {  // koff = group * Kb is then a multiple of 4 too
+        const int q = Kb >> 2, tot = nrow * q;
+        const fdiv by_q(q);
+#pragma unroll 4
+        for (int e = tid; e < tot; e += nthr) {
+            const int r = by_q(e), c = e - r * q;
+            *reinterpret_cast<float4*>(wl + r * Kbp + 4 * c) =
+                *reinterpret_cast<const float4*>(w + (int64_t)(co0 + r) * K + koff + 4 * c);
+        }
+    } else {
+        const int tot = nrow * Kb;
+        const fdiv by_kb(Kb);
+#pragma unroll 4
+        for (int e = tid; e < tot; e += nthr) {
+            const int r = by_kb(e), c = e - r * Kb;
+            wl[r * Kbp + c] = w[(int64_t)(co0 + r) * K + koff + c];
+        }
+    }
+}
+__device__ __forceinline__ int padded_row(int Kb) { return ((Kb + 3) & ~3) + 4; }  // +4: neighbouring rows on different banks
+
+// Partial convolution of the block's activated tile act[cpg][H*W] (LDS) into slab `g` of y ([groups][Cout][N*HoWo]) on
+// the matrix cores: out[co][px] = sum_k W[co][k] A[k][px] with k = (tap, channel of the group), 32 co x 32 px tiles of
+// v_mfma_f32_32x32x2_f32 (the two k slots = a channel pair), one tile per wave.  A operand: the staged weight slice
+// wl[row][Kbp] (LDS), B operand: the tile gathered through per-lane tap addresses (zero padding and pixels past the
+// map read the block's zero word with channel stride 0 - no conditional load).  When a block has fewer than 8 tiles
+// its waves split the channel pairs of a tile between them and the partial tiles are summed through LDS (`part`).
+template <int KSZ>
+__device__ __forceinline__ void partial_conv(const float* act, int cpg, int H, int W, const float* __restrict__ w, int C,
+                                             int c0, int co_beg, int co_end, int stride, int pad, int Ho, int Wo,
+                                             float* __restrict__ yslab, int64_t NHWo, int n, float* wl, int wl_floats,
+                                             bool prestaged, int zero_off, float* part) {
+    constexpr int KK = KSZ * KSZ;
+    const int HWo = Ho * Wo, HW = H * W;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
+    const int K = C * KK, Kb = cpg * KK, Kbp = padded_row(Kb), hc = cpg >> 1;
+    const int ptl = (HWo + 31) >> 5;  // pixel tiles
+    int rows_max = co_end - co_beg;  // prestaged: the whole slice is resident, one chunk
+    if (!prestaged) {
+        rows_max = fdiv(Kbp)(wl_floats);
+        if (rows_max > 32) rows_max &= ~31;
+    }
+    if (rows_max <= 0) return;  // (block-uniform: this blockIdx.z has no channels of this conv)
+    const fdiv by_ptl(ptl), by_wo(Wo);
+    for (int cb0 = co_beg; cb0 < co_end; cb0 += rows_max) {
+        const int nrow = min(rows_max, co_end - cb0);
+        if (!prestaged) {  // (prestaged: the whole slice was loaded next to the tile, before the block's barriers)
+            __syncthreads();  // the tile is complete / the previous chunk has been consumed
+            stage_weights(w, K, c0 * KK, Kb, Kbp, cb0, nrow, wl, 0, GT);
+            __syncthreads();
+        }
+        const int T = ((nrow + 31) >> 5) * ptl;
+        int ksl = (T >= 8 || !part) ? 0 : (T >= 4 ? 1 : (T >= 2 ? 2 : 3));  // log2 of the waves per tile
+        while ((1 << ksl) > hc) --ksl;
+        const int KS = 1 << ksl;
+        for (int item = wave; item < T * KS; item += 8) {
+            const int tile = item >> ksl, ks = item - (tile << ksl);
+            const int ci = by_ptl(tile), pi = tile - ci * ptl;
+            const int p = pi * 32 + l31;
+            const bool live = p < HWo;
+            const int oh = live ? by_wo(p) : 0, ow = live ? p - oh * Wo : 0;
+            const int cp0 = (ks * hc) >> ksl, cp1 = ((ks + 1) * hc) >> ksl;
+            const float* wrow = wl + min(ci * 32 + l31, nrow - 1) * Kbp + half * KK;  // rows past the slice repeat its last row
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < KK; ++t) {
+                const int ih = oh * stride - pad + t / KSZ, iw = ow * stride - pad + t % KSZ;
+                const bool in = live && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                const float* ap = act + (in ? ih * W + iw + half * HW : zero_off);
+                const int cstr = in ? 2 * HW : 0;
+                for (int cp = cp0; cp < cp1; ++cp)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[2 * cp * KK + t], ap[cp * cstr], acc, 0, 0, 0);
+            }
+            // acc[r] -> row (r & 3) + 8 * (r >> 2) + 4 * half, column l31
+#ifdef GN_CONV_TIMING
+            if (item < 8 && threadIdx.x == (unsigned)wave * 64 && wave == 0) g_stamp[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + 6] = wall_clock64();
+#endif
+            if (KS == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = ci * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (live && row < nrow) yslab[(int64_t)(cb0 + row) * NHWo + (int64_t)n * HWo + p] = acc[r];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) part[item * 1024 + r * 64 + lane] = acc[r];
+            }
+        }
+        if (KS > 1) {  // (block-uniform)
+            __syncthreads();
+            for (int idx = threadIdx.x; idx < T * 1024; idx += GT) {
+                const int tile = idx >> 10, e = idx & 1023, r = e >> 6, ln = e & 63;
+                float v = part[(tile * KS) * 1024 + e];
+                for (int ks = 1; ks < KS; ++ks) v += part[(tile * KS + ks) * 1024 + e];
+                const int ci = by_ptl(tile), pi = tile - ci * ptl;
+                const int row = ci * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), p = pi * 32 + (ln & 31);
+                if (p < HWo && row < nrow) yslab[(int64_t)(cb0 + row) * NHWo + (int64_t)n * HWo + p] = v;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int KSZ>
+__global__ __launch_bounds__(GT) void k_gn_conv(const Desc D, const Geo G) {
+    const int wthr = G.wthr;  // the last `wthr` threads load this block's weight slices beside the tile (0: chunked)
+    const int prestage = wthr > 0;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int HW = D.H * D.W;
+    const int cpg = G.cpg, nel = cpg * HW, nel4 = (nel + 3) & ~3;
+    float* red = smem;        // 32: block reductions; red[31] stays 0 (the convs' padding word)
+    float* gb = smem + 32;    // gamma, beta, gamma2, beta2 of this group's channels
+    float* tile = gb + 4 * ((cpg + 3) & ~3);  // cpg*HW
+    float* p = tile + nel4;
+    float* tile2 = p;         // second operand
+    if (D.x2) p += nel4;
+    float* tres = p;          // residual
+    if (D.residual) p += nel4;
+    const int Hc = G.Hc, Wc = G.Wc;  // the convs' input size
+    float* pooled = p;
+    if (D.pool) p += (cpg * Hc * Wc + 3) & ~3;
+    float* part = G.part_floats ? p : nullptr;  // partial tiles of waves that share a tile
+    p += G.part_floats;
+    float* wl = p;            // staged weights: conv A, then (prestage) conv B behind it
+    // grid (group, image, slice of the output channels): the slices of one (image, group) share an XCD's L2
+    const int g = blockIdx.x, n = blockIdx.y, sy = blockIdx.z;
+    const int c0 = g * cpg;
+    const int a_beg = sy * G.per_a, a_end = min(D.Cout_a, a_beg + G.per_a), b_beg = sy * G.per_b, b_end = min(D.Cout_b, b_beg + G.per_b);
+    const int kbp_a = padded_row(cpg * KSZ * KSZ), kbp_b = padded_row(cpg);
+    float* wl_b = wl + (prestage && D.wa ? max(a_end - a_beg, 0) * kbp_a : 0);
+
+    STAMP(0);
+    // every global load of the kernel up front: most waves pull the tile(s), the others this block's weights
+    float s = 0.f, s2 = 0.f;
+    const int nload = GT - wthr;
+    if ((int)threadIdx.x >= GT - cpg) {  // affine parameters: fetched with everything else, read from LDS after the statistics
+        const int c = (int)threadIdx.x - (GT - cpg), cp = (cpg + 3) & ~3;
+        gb[c] = D.gamma[c0 + c];
+        gb[cp + c] = D.beta[c0 + c];
+        if (D.x2) {
+            gb[2 * cp + c] = D.gamma2[c0 + c];
+            gb[3 * cp + c] = D.beta2[c0 + c];
+        }
+    }
+    if (threadIdx.x == 0) red[31] = 0.f;
+    if ((int)threadIdx.x < nload) {
+        if ((HW & 3) == 0) load_tiles<4>(D, n, c0, cpg, HW, nload, tile, tile2, tres, s, s2);
+        else load_tiles<1>(D, n, c0, cpg, HW, nload, tile, tile2, tres, s, s2);
+    } else {
+        if (D.wa) stage_weights(D.wa, D.C * KSZ * KSZ, c0 * KSZ * KSZ, cpg * KSZ * KSZ, kbp_a, a_beg, a_end - a_beg, wl, nload, GT - nload);
+        if (D.wb) stage_weights(D.wb, D.C, c0, cpg, kbp_b, b_beg, b_end - b_beg, wl_b, nload, GT - nload);
+    }
+    STAMP(1);
+    // statistics of both operands: two block reductions (means, then centred squares)
+    block_sum2(s, s2, red);
+    const float mean = s / (float)nel, mean2 = s2 / (float)nel;
+    float q = 0.f, q2 = 0.f;
+    for (int i = threadIdx.x; i < nel; i += GT) {
+        const float d = tile[i] - mean;
+        q += d * d;
+        if (D.x2) {
+            const float d2 = tile2[i] - mean2;
+            q2 += d2 * d2;
+        }
+    }
+    block_sum2(q, q2, red);
+    const float rstd = rsqrtf(q / (float)nel + D.eps), rstd2 = rsqrtf(q2 / (float)nel + D.eps);
+    // normalise (+ second operand) (+ residual) (+ ReLU), in place
+    const fdiv by_hw(HW);
+    for (int i = threadIdx.x; i < nel; i += GT) {
+        const int c = by_hw(i), cp = (cpg + 3) & ~3;
+        const float ga = gb[c] * rstd, be = gb[cp + c] - mean * ga;
+        float v = fmaf(tile[i], ga, be);
+        if (D.x2) {
+            const float g2 = gb[2 * cp + c] * rstd2, b2 = gb[3 * cp + c] - mean2 * g2;
+            v += fmaf(tile2[i], g2, b2);
+        }
+        if (D.residual) v += tres[i];
+        if (D.relu) v = fmaxf(v, 0.f);
+        tile[i] = v;
+    }
+    __syncthreads();
+    // MaxPool2d(3, stride 2, padding 1) of the activated tile (the stem)
+    const float* act = tile;
+    if (D.pool) {
+        const fdiv by_hwc(Hc * Wc), by_wc(Wc);
+        for (int i = threadIdx.x; i < cpg * Hc * Wc; i += GT) {
+            const int c = by_hwc(i), pp = i - c * Hc * Wc, ho = by_wc(pp), wo = pp - ho * Wc;
+            float m = -INFINITY;
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    const int h = ho * 2 - 1 + a, ww = wo * 2 - 1 + b;
+                    if ((unsigned)h < (unsigned)D.H && (unsigned)ww < (unsigned)D.W) m = fmaxf(m, tile[c * HW + h * D.W + ww]);
+                }
+            pooled[i] = m;
+        }
+        __syncthreads();
+        act = pooled;
+    }
+    STAMP(2);
+    if (D.act_out && sy == 0) {
+        float* ap = D.act_out + ((int64_t)n * D.C + c0) * Hc * Wc;
+        for (int i = threadIdx.x; i < cpg * Hc * Wc; i += GT) ap[i] = act[i];
+    }
+    STAMP(3);
+    // the next convolution(s): this block's slice of K, output channels [beg, end) of this blockIdx.z
+    if (D.wa) {
+        const int64_t NHWo = (int64_t)D.N * G.Ho_a * G.Wo_a;
+        partial_conv<KSZ>(act, cpg, Hc, Wc, D.wa, D.C, c0, a_beg, a_end, D.stride_a, D.pad_a, G.Ho_a, G.Wo_a,
+                          D.ya + (int64_t)g * D.Cout_a * NHWo, NHWo, n, wl, G.wl_floats, prestage != 0, (int)(red + 31 - act), part);
+    }
+    STAMP(4);
+    if (D.wb) {
+        const int64_t NHWo = (int64_t)D.N * G.Ho_b * G.Wo_b;
+        partial_conv<1>(act, cpg, Hc, Wc, D.wb, D.C, c0, b_beg, b_end, D.stride_b, 0, G.Ho_b, G.Wo_b,
+                        D.yb + (int64_t)g * D.Cout_b * NHWo, NHWo, n, wl_b, G.wl_floats, prestage != 0, (int)(red + 31 - act), part);
+    }
+    STAMP(5);
+}
+
+typedef void (*gn_conv_fn)(const Desc, const Geo);
+
+}  // namespace
+
+extern "C" {
+
+int ivln_gn_conv_f32(const ivln_gn_conv_desc* d, void* stream) {
+    if (!d || !d->x || !d->gamma || !d->beta || d->N <= 0 || d->C <= 0 || d->groups <= 0 || d->C % d->groups) return IVLN_E_INVALID;
+    if (d->splits < 1 || (d->x2 && (d->splits2 < 1 || !d->gamma2 || !d->beta2))) return IVLN_E_INVALID;
+    if (!d->wa && !d->wb && !d->act_out) return IVLN_E_INVALID;
+    if (d->wa && (!d->ya || d->Cout_a <= 0 || (d->ka != 1 && d->ka != 3) || d->stride_a < 1)) return IVLN_E_UNSUPPORTED;
+    if (d->wb && (!d->yb || d->Cout_b <= 0 || d->stride_b < 1)) return IVLN_E_INVALID;
+    const int cpg = d->C / d->groups, HW = d->H * d->W, nel = cpg * HW;
+    if (nel > TILE_MAX || cpg > GT / 2) return IVLN_E_UNSUPPORTED;
+    int H = d->H, W = d->W;
+    if (d->pool) {
+        H = (H + 2 - 3) / 2 + 1;
+        W = (W + 2 - 3) / 2 + 1;
+    }
+    Geo G = {};
+    G.cpg = cpg;
+    G.Hc = H;
+    G.Wc = W;
+    int HWo_a = 0, HWo_b = 0;
+    if (d->wa) {
+        G.Ho_a = (H + 2 * d->pad_a - d->ka) / d->stride_a + 1;
+        G.Wo_a = (W + 2 * d->pad_a - d->ka) / d->stride_a + 1;
+        if (G.Ho_a <= 0 || G.Wo_a <= 0) return IVLN_E_INVALID;
+        HWo_a = G.Ho_a * G.Wo_a;
+    }
+    if (d->wb) {
+        G.Ho_b = (H - 1) / d->stride_b + 1;
+        G.Wo_b = (W - 1) / d->stride_b + 1;
+        HWo_b = G.Ho_b * G.Wo_b;
+    }
+    if ((d->wa || d->wb) && (cpg & 1)) return IVLN_E_UNSUPPORTED;  // the MFMA's two k slots take a channel pair
+    gn_conv_fn fn = (d->wa && d->ka == 3) ? k_gn_conv<3> : k_gn_conv<1>;
+    // output channels over blockIdx.y so that ~256 blocks are in flight (every block repeats the cheap GroupNorm)
+    int S = 1;
+    const int blocks = d->N * d->groups;
+    const int cmin = d->wa ? (d->wb && d->Cout_b < d->Cout_a ? d->Cout_b : d->Cout_a) : (d->wb ? d->Cout_b : 1);
+    static const int s_cap = getenv("IVLN_GN_CONV_S") ? atoi(getenv("IVLN_GN_CONV_S")) : 4;
+    while (S < s_cap && blocks * S * 2 <= 256 && cmin / (S * 2) >= 16) S *= 2;
+    // LDS: reduction scratch + tile (+ second operand) (+ residual) (+ pooled tile) + the staged weight slices.  When
+    // both convs' slices fit they are loaded up front beside the tile (prestage); otherwise each conv streams its
+    // slice through the remaining space in chunks of rows.
+    const size_t nel4 = (size_t)((nel + 3) & ~3);
+    // waves of a block with fewer than 8 output tiles (32 channels x 32 pixels) share tiles: 8 partial tiles in LDS
+    const int tiles_a = d->wa ? (((d->Cout_a + S - 1) / S + 31) / 32) * ((HWo_a + 31) / 32) : 8;
+    const int tiles_b = d->wb ? (((d->Cout_b + S - 1) / S + 31) / 32) * ((HWo_b + 31) / 32) : 8;
+    size_t part = (tiles_a < 8 || tiles_b < 8) ? 8 * 1024 : 0;
+    size_t fixed = 32 + 4 * (size_t)((cpg + 3) & ~3) + nel4 * (1 + (d->x2 ? 1 : 0) + (d->residual ? 1 : 0)) +
+                   (d->pool ? (size_t)((cpg * H * W + 3) & ~3) : 0);
+    if (fixed + part + 2048 > kLdsFloats) part = 0;
+    fixed += part;
+    if (fixed + 64 > kLdsFloats) return IVLN_E_UNSUPPORTED;
+    const size_t kbp_a = d->wa ? (size_t)((cpg * d->ka * d->ka + 3) & ~3) + 4 : 0, kbp_b = d->wb ? (size_t)((cpg + 3) & ~3) + 4 : 0;
+    const size_t need_a = d->wa ? (size_t)((d->Cout_a + S - 1) / S) * kbp_a : 0, need_b = d->wb ? (size_t)((d->Cout_b + S - 1) / S) * kbp_b : 0;
+    const size_t cap = kLdsFloats - fixed;
+    const int prestage = need_a + need_b <= cap;
+    const size_t wl = prestage ? need_a + need_b : cap;
+    if (wl < kbp_a || wl < kbp_b) return IVLN_E_UNSUPPORTED;
+    const size_t bytes = sizeof(float) * (fixed + wl);
+    {
+        static std::mutex mu;
+        static std::set<const void*> raised;
+        std::lock_guard<std::mutex> lk(mu);
+        if (!raised.count((const void*)fn)) {
+            if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsFloats * sizeof(float))) !=
+                hipSuccess)
+                return IVLN_E_HIP;
+            raised.insert((const void*)fn);
+        }
+    }
+    // waves that load weights instead of tile slabs, in proportion to the bytes (1..7 of the 8)
+    int wthr = 0;
+    if (prestage) {
+        const double wb = (double)(need_a + need_b), tb = (double)nel * (d->splits + (d->x2 ? d->splits2 : 0) + (d->residual ? 1 : 0));
+        int nw = (int)(8.0 * wb / (wb + tb) + 0.5);
+        nw = nw < 1 ? 1 : (nw > 6 ? 6 : nw);
+        wthr = 64 * nw;
+        if (wthr < cpg) wthr = (cpg + 63) / 64 * 64;
+    }
+    G.per_a = d->wa ? (d->Cout_a + S - 1) / S : 0;
+    G.per_b = d->wb ? (d->Cout_b + S - 1) / S : 0;
+    G.wl_floats = (int)wl;
+    G.wthr = wthr;
+    G.part_floats = (int)part;
+    if (d->N > 65535) return IVLN_E_UNSUPPORTED;
+    hipLaunchKernelGGL(fn, dim3(d->groups, d->N, S), dim3(GT), bytes, (hipStream_t)stream, *d, G);
+    return hipGetLastError() == hipSuccess ? IVLN_OK : IVLN_E_HIP;
+}
+
+#ifdef GN_CONV_TIMING
+int ivln_gn_conv_stamps(unsigned long long* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
+}
+#endif
+
+}  // extern "C"

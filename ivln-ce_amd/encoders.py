@@ -204,22 +204,29 @@ class _Bottleneck(nn.Module):
                     out = ops.conv_gn(y2, c[6].weight, c[7], relu=True, residual=x)
                 if out is not None:
                     return out
+        y, ds = self.body_hip(x)
+        if ds is not None:
+            gn = self.downsample[1]
+            return ops.groupnorm(y, c[7].weight, c[7].bias, c[7].num_groups, c[7].eps, relu=True, x2=ds,
+                                 gamma2=gn.weight, beta2=gn.bias)
+        return ops.groupnorm(y, c[7].weight, c[7].bias, c[7].num_groups, c[7].eps, relu=True, residual=x)
+
+    def body_hip(self, x):
+        """Everything but the block's last GroupNorm: -> (raw conv3 output, raw downsample conv output | None), both
+        left as split-K slabs in the two workspaces."""
+        c = self.convs
         ds = None
         if self.downsample is not None:
             # the downsample conv leaves its slabs in the second workspace; its GroupNorm is folded into the
             # block's last GroupNorm launch (same channels, same groups)
+            gn = self.downsample[1]
+            assert gn.num_groups == c[7].num_groups and gn.eps == c[7].eps
             ds = ops.conv2d(x, self.downsample[0].weight, stride=self.stride, defer=True, ws_slot=1)
         y = ops.conv2d(x, c[0].weight, defer=True)
         y = ops.groupnorm(y, c[1].weight, c[1].bias, c[1].num_groups, c[1].eps, relu=True)
         y = ops.conv2d(y, c[3].weight, stride=self.stride, pad=1, defer=True)
         y = ops.groupnorm(y, c[4].weight, c[4].bias, c[4].num_groups, c[4].eps, relu=True)
-        y = ops.conv2d(y, c[6].weight, defer=True)
-        if ds is not None:
-            gn = self.downsample[1]
-            assert gn.num_groups == c[7].num_groups and gn.eps == c[7].eps
-            return ops.groupnorm(y, c[7].weight, c[7].bias, c[7].num_groups, c[7].eps, relu=True, x2=ds,
-                                 gamma2=gn.weight, beta2=gn.bias)
-        return ops.groupnorm(y, c[7].weight, c[7].bias, c[7].num_groups, c[7].eps, relu=True, residual=x)
+        return ops.conv2d(y, c[6].weight, defer=True), ds
 
 
 class _ResNet50GN(nn.Module):
@@ -247,6 +254,54 @@ class _ResNet50GN(nn.Module):
         for _ in range(1, blocks):
             layers.append(_Bottleneck(self.inplanes, planes, ngroups))
         return nn.Sequential(*layers)
+
+    def forward_chain(self, x, tail):
+        """The whole backbone as a chain of ops.gn_conv launches: every GroupNorm kernel also computes its slice of
+        the NEXT conv (csrc/gn_conv.hip), so a bottleneck is 3 launches and no conv launch remains after the stem.
+        `tail` = (weight, stride, pad) of the conv that follows the backbone (the encoder's compression conv).
+        Returns that conv's raw output (a `Deferred`), or None when a shape is outside the kernel's envelope."""
+        blocks = [b for layer in (self.layer1, self.layer2, self.layer3, self.layer4) for b in layer]
+
+        def feeds(blk):  # what the kernel that produces `blk`'s input has to emit for it
+            ds = None if blk.downsample is None else (blk.downsample[0].weight, blk.stride)
+            return dict(conv_a=(blk.convs[0].weight, 1, 0), conv_b=ds, want_act=ds is None)
+
+        c, gn = self.conv1[0], self.conv1[1]
+        y = ops.conv2d(x, c.weight, stride=2, pad=3, defer=True)
+        first = min(ops.CHAIN_FROM_BLOCK, len(blocks))  # blocks before it run as conv + GroupNorm pairs
+        if first == 0:
+            r = ops.gn_conv(y, gn, relu=True, pool=True, **feeds(blocks[0]))
+        else:
+            act = ops.pool2d(ops.groupnorm(y, gn.weight, gn.bias, gn.num_groups, gn.eps, relu=True), 3, 2, 1, "max")
+            for blk in blocks[:first - 1]:
+                act = blk.forward_hip(act)
+            # the last pairwise block hands over: its final GroupNorm is the chain's first launch
+            blk = blocks[first - 1]
+            y3, ds = blk.body_hip(act)
+            nxt = feeds(blocks[first]) if first < len(blocks) else dict(conv_a=tail)
+            if ds is not None:
+                r = ops.gn_conv(y3, blk.convs[7], x2=ds, gn2=blk.downsample[1], **nxt)
+            else:
+                r = ops.gn_conv(y3, blk.convs[7], residual=act, **nxt)
+        for i, blk in enumerate(blocks):
+            if i < first:
+                continue
+            if r is None:
+                return None
+            act, ya, yb = r
+            c = blk.convs
+            r = ops.gn_conv(ya, c[1], conv_a=(c[3].weight, blk.stride, 1))
+            if r is None:
+                return None
+            r = ops.gn_conv(r[1], c[4], conv_a=(c[6].weight, 1, 0))
+            if r is None:
+                return None
+            nxt = feeds(blocks[i + 1]) if i + 1 < len(blocks) else dict(conv_a=tail)
+            if blk.downsample is not None:
+                r = ops.gn_conv(r[1], c[7], x2=yb, gn2=blk.downsample[1], **nxt)
+            else:
+                r = ops.gn_conv(r[1], c[7], residual=act, **nxt)
+        return None if r is None else r[1]
 
     def forward_hip(self, x):
         c, gn = self.conv1[0], self.conv1[1]
@@ -295,9 +350,11 @@ class ResNetEncoder(nn.Module):
         B, H, W, Cd = depth.shape
         assert Cd == 1, "depth-only encoder"
         x = ops.pool2d(depth.view(B, 1, H, W), 2, 2, 0, "avg")  # F.avg_pool2d(x, 2)
-        x = self.backbone.forward_hip(x)
         c, gn = self.compression[0], self.compression[1]
-        y = ops.conv2d(x, c.weight, pad=1, defer=True)
+        y = self.backbone.forward_chain(x, (c.weight, 1, 1)) if ops.CHAIN_GN_CONV else None
+        if y is None:
+            x = self.backbone.forward_hip(x)
+            y = ops.conv2d(x, c.weight, pad=1, defer=True)
         hw = self.output_shape[1] * self.output_shape[2]
         if out is None:
             return ops.groupnorm(y, gn.weight, gn.bias, gn.num_groups, gn.eps, relu=True)

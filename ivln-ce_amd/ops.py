@@ -494,6 +494,72 @@ def conv_gn(x, w, gn, stride=1, pad=0, relu=False, residual=None, ds=None, out=N
     return out
 
 
+# depth ResNet as a chain of GroupNorm+next-conv launches (csrc/gn_conv.hip); IVLN_GN_CONV=0 selects the deferred
+# conv + GroupNorm pairs
+CHAIN_GN_CONV = os.environ.get("IVLN_GN_CONV", "1") != "0"
+# first bottleneck (0..16) that runs in the chain; earlier ones (large feature maps: 16 partial slabs of a 32x32 map
+# are more traffic than the launches they save) stay conv + GroupNorm pairs.  0 = the whole backbone incl. the stem;
+# 3 = from layer2 on (measured best at 4 envs: 0.790 ms/step vs 0.820 from the stem and 0.996 without the chain).
+CHAIN_FROM_BLOCK = int(os.environ.get("IVLN_GN_CONV_FROM", "3"))
+
+
+class GnConvDesc(C.Structure):
+    """Mirror of `ivln_gn_conv_desc` (include/ivln_hip.h) - field order must match."""
+
+    _fields_ = [
+        ("x", vp), ("splits", i32), ("slab_stride", i64), ("gamma", vp), ("beta", vp),
+        ("x2", vp), ("splits2", i32), ("slab_stride2", i64), ("gamma2", vp), ("beta2", vp),
+        ("residual", vp),
+        ("N", i32), ("C", i32), ("H", i32), ("W", i32), ("groups", i32), ("eps", f32), ("relu", i32), ("pool", i32),
+        ("act_out", vp),
+        ("wa", vp), ("Cout_a", i32), ("ka", i32), ("stride_a", i32), ("pad_a", i32), ("ya", vp),
+        ("wb", vp), ("Cout_b", i32), ("stride_b", i32), ("yb", vp),
+    ]
+
+
+def gn_conv(x, gn, relu=True, pool=False, x2=None, gn2=None, residual=None, want_act=False, conv_a=None, conv_b=None):
+    """act(GroupNorm(x) [+ GroupNorm2(x2)] [+ residual]) [-> MaxPool(3, 2, 1)] and the NEXT convolution(s) of that
+    activation in one launch (csrc/gn_conv.hip).  x, x2: `Deferred` slabs; conv_a = (weight (Co, C, k, k), stride, pad),
+    conv_b = (weight (Co, C, 1, 1), stride).  Returns (act | None, Deferred a | None, Deferred b | None); the conv
+    outputs are `groups` partial slabs for the next gn_conv / groupnorm.  None when the shape is outside the kernel's
+    envelope."""
+    N, Cc, H, W = x.N, x.C, x.H, x.W
+    dev = x.ws.device
+    d = GnConvDesc()
+    d.x, d.splits, d.slab_stride = dptr(x.ws), x.splits, Cc * N * H * W
+    d.gamma, d.beta = dptr(gn.weight), dptr(gn.bias)
+    if x2 is not None:
+        assert (x2.N, x2.C, x2.H, x2.W) == (N, Cc, H, W) and gn2.num_groups == gn.num_groups and gn2.eps == gn.eps
+        d.x2, d.splits2, d.slab_stride2 = dptr(x2.ws), x2.splits, Cc * N * H * W
+        d.gamma2, d.beta2 = dptr(gn2.weight), dptr(gn2.bias)
+    d.residual = _p(residual)
+    d.N, d.C, d.H, d.W, d.groups, d.eps, d.relu, d.pool = N, Cc, H, W, gn.num_groups, gn.eps, int(bool(relu)), int(bool(pool))
+    Hp, Wp = ((H - 1) // 2 + 1, (W - 1) // 2 + 1) if pool else (H, W)
+    act = torch.empty((N, Cc, Hp, Wp), dtype=torch.float32, device=dev) if want_act else None
+    d.act_out = _p(act)
+    G = gn.num_groups
+    ya = yb = None
+    if conv_a is not None:
+        w, s, p = conv_a
+        Co, _, k, _ = w.shape
+        Ho, Wo = (Hp + 2 * p - k) // s + 1, (Wp + 2 * p - k) // s + 1
+        ya = Deferred(torch.empty(G * Co * N * Ho * Wo, dtype=torch.float32, device=dev), G, N, Co, Ho, Wo)
+        d.wa, d.Cout_a, d.ka, d.stride_a, d.pad_a, d.ya = dptr(w), Co, k, s, p, dptr(ya.ws)
+    if conv_b is not None:
+        w, s = conv_b
+        Co = w.shape[0]
+        Ho, Wo = (Hp - 1) // s + 1, (Wp - 1) // s + 1
+        yb = Deferred(torch.empty(G * Co * N * Ho * Wo, dtype=torch.float32, device=dev), G, N, Co, Ho, Wo)
+        d.wb, d.Cout_b, d.stride_b, d.yb = dptr(w), Co, s, dptr(yb.ws)
+    L = _L()
+    L.ivln_gn_conv_f32.argtypes = [C.POINTER(GnConvDesc), vp]
+    code = L.ivln_gn_conv_f32(C.byref(d), stream_ptr())
+    if code == IVLN_E_UNSUPPORTED:
+        return None
+    check(code, "ivln_gn_conv_f32")
+    return act, ya, yb
+
+
 class CmaStepDesc(C.Structure):
     """Mirror of `ivln_cma_step_desc` (include/ivln_hip.h) - field order must match."""
 
