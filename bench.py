@@ -34,7 +34,7 @@ import torch  # noqa: E402
 METRIC = "env-steps/sec (batched MapCMA fwd+bwd) at 1/2/4/8 MI355X; t-nDTW parity"
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
 PEAK_HBM_GBS = 8000.0  # same guide: HBM3E 8 TB/s spec (6.3 TB/s achievable)
-MFMA_FAMILY = "fp32 MFMA family (k_gemm / k_gemm_vec / k_conv_direct / k_conv_gn)"
+MFMA_FAMILY = "fp32 MFMA family (k_gemm / k_gemm_vec / k_conv_direct / k_gn_conv)"
 
 
 def log(*a):
@@ -92,11 +92,29 @@ class GemmTimer:
             self.events.append((a, b))
             self.flops += 2 * desc.M * desc.N * desc.K
 
+        self.orig_gn_conv = ops.gn_conv
+
+        def timed_gn_conv(x, gn, **kw):
+            """GroupNorm + next-conv launch of the depth ResNet chain: its convs run on the same matrix cores"""
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            r = self.orig_gn_conv(x, gn, **kw)
+            b.record()
+            if r is not None:
+                self.events.append((a, b))
+                for y, cw in ((r[1], kw.get("conv_a")), (r[2], kw.get("conv_b"))):
+                    if y is not None:
+                        w = cw[0]
+                        self.flops += 2 * w.shape[0] * (y.N * y.H * y.W) * w.shape[1] * w.shape[2] * w.shape[3]
+            return r
+
         ops.gemm = timed
+        ops.gn_conv = timed_gn_conv
         return self
 
     def __exit__(self, *a):
         self.ops.gemm = self.orig
+        self.ops.gn_conv = self.orig_gn_conv
 
     def total_ms(self):
         """Sum of the event-pair times.  A pair brackets one launch on the launch stream, so it carries the

@@ -6,7 +6,7 @@ import csv
 import json
 import sys
 
-MFMA = ("k_gemm", "k_conv_direct", "k_wgrad", "k_conv_gn")
+MFMA = ("k_gemm", "k_conv_direct", "k_wgrad", "k_conv_gn", "k_gn_conv")
 MAPPER = ("k_local_", "k_world_", "k_finalize", "k_frames")
 
 
@@ -19,14 +19,15 @@ def load(path, family=MFMA):
 
 
 fetch, write, steps, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+flags = sys.argv[5] if len(sys.argv) > 5 else "--envs 4"
 ft, fm, fl = load(fetch)
 wt, wm, _ = load(write)
 lps = fl / steps
 _, mpf, mpl = load(fetch, MAPPER)
 _, mpw, _ = load(write, MAPPER)
 d = {
-    "workload": f"bench.py --envs 4 --no-graph (eager launches; PMC serialises kernels), {steps} steps",
-    "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline "
+    "workload": f"bench.py {flags} --no-graph (eager launches; PMC serialises kernels), {steps} steps",
+    "command": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 bench.py {flags} --no-cpu-baseline "
                "--no-update --no-pred-leg --no-graph (and a second pass with --pmc WRITE_SIZE)",
     "correction": "gfx950: FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM section: wide coalesced reads are tallied at "
                   "half their bytes); WRITE_SIZE as reported (uncalibrated)",
@@ -48,8 +49,9 @@ d = {
         "write_bytes_per_step": int(wt / steps),
         "hbm_bytes_per_step_corrected": int((2 * ft + wt) / steps),
     },
-    "note": "write traffic of the MFMA family is dominated by split-K slabs (deferred mode: up to 64 raw slabs per conv, "
-            "reduced inside the consuming GroupNorm / pool kernel): latency at 4 envs is bought with slab bytes",
+    "note": "write traffic of the MFMA family is dominated by partial slabs (deferred split-K convs; the 16 per-group "
+            "slabs of every k_gn_conv launch, reduced inside the consuming GroupNorm kernel): latency at 4 envs is bought "
+            "with slab bytes",
 }
 json.dump(d, open(out, "w"), indent=1)
 print(json.dumps(d["mfma_family"]))
