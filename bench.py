@@ -102,6 +102,9 @@ class GemmTimer:
             b.record()
             if r is not None:
                 self.events.append((a, b))
+                if kw.get("front") is not None:  # the 1x1 conv of the front stage (full K, per group block)
+                    x0, _, w0 = kw["front"]
+                    self.flops += 2 * w0.shape[0] * w0.shape[1] * x0.N * x0.H * x0.W
                 for y, cw in ((r[1], kw.get("conv_a")), (r[2], kw.get("conv_b"))):
                     if y is not None:
                         w = cw[0]

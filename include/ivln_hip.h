@@ -201,8 +201,8 @@ int ivln_conv_gn_f32(const ivln_conv_gn_desc* d, void* stream);
  * One launch per conv layer of habitat-lab's DD-PPO ResNetEncoder (models/encoders/resnet_encoders.py:31-43, 95):
  * conv -> GroupNorm -> ReLU -> conv ..., Bottleneck tails relu(GN(c3) + GN_ds(ds)) / relu(GN(c3) + identity) feeding
  * the next block's conv1 (A) and downsample conv (B).  act_out (N, C, H', W') receives the activation when a later
- * block needs it as its identity.  IVLN_E_UNSUPPORTED: (C/groups)*H*W > 8192, C/groups not 2 | 4 | a multiple of 8,
- * more than 1024 output pixels per image, k not in {1, 3}. */
+ * block needs it as its identity.  IVLN_E_UNSUPPORTED: (C/groups)*H*W > 8192, odd C/groups, k not in {1, 3}, tiles +
+ * weights that do not fit 152 KB of LDS. */
 typedef struct ivln_gn_conv_desc {
     const float* x;       /* slabs of [C][N*H*W] */
     int splits;
@@ -226,6 +226,18 @@ typedef struct ivln_gn_conv_desc {
     const float* wb;      /* (Cout_b, C, 1, 1) or NULL */
     int Cout_b, stride_b;
     float* yb;
+    /* Optional front stage (x == NULL then): the GroupNorm input is itself computed in the block, two conv layers per
+     * launch.  x0 = slabs of the PREVIOUS layer's raw output [C0][N*H*W]; the block normalises ALL groups0 groups of
+     * its image (gamma0 / beta0, ReLU), and runs the 1x1 conv w0 (C, C0, 1, 1) for its own C/groups output channels
+     * over the full K = C0 - the (image, group) tile of x that the statistics above then see.  The Bottleneck's
+     * GroupNorm -> ReLU -> conv3 -> GroupNorm -> (+ identity | + downsample) -> ReLU -> next conv1 in one launch. */
+    const float* x0;
+    int splits0;
+    int64_t slab_stride0;
+    int C0, groups0;
+    const float* gamma0;
+    const float* beta0;
+    const float* w0;
 } ivln_gn_conv_desc;
 int ivln_gn_conv_f32(const ivln_gn_conv_desc* d, void* stream);
 

@@ -93,6 +93,7 @@ struct Geo {
     int Ho_a, Wo_a, Ho_b, Wo_b;
     int per_a, per_b;          // output channels per blockIdx.z
     int wl_floats, wthr, part_floats;
+    int fthr, w0thr;           // front stage: threads that load its slabs / its weight slice + affine parameters
 };
 
 template <int V> struct vecf;
@@ -144,15 +145,57 @@ __device__ __forceinline__ void load_tiles(const Desc& D, int n, int c0, int cpg
         const int64_t o = (int64_t)(c0 + cl) * NHW + (int64_t)n * HW + pp;
         T r;
         if (D.residual) r = *reinterpret_cast<const T*>(D.residual + ((int64_t)n * D.C + c0) * HW + i);
-        const T v = slab_sum<V>(D.x + o, D.splits, D.slab_stride);
-        *reinterpret_cast<T*>(&tile[i]) = v;
-        s += vsum(v);
+        if (D.x) {  // (absent with a front stage: the tile is then computed in the block)
+            const T v = slab_sum<V>(D.x + o, D.splits, D.slab_stride);
+            *reinterpret_cast<T*>(&tile[i]) = v;
+            s += vsum(v);
+        }
         if (D.x2) {
             const T v2 = slab_sum<V>(D.x2 + o, D.splits2, D.slab_stride2);
             *reinterpret_cast<T*>(&tile2[i]) = v2;
             s2 += vsum(v2);
         }
         if (D.residual) *reinterpret_cast<T*>(&tres[i]) = r;
+    }
+}
+
+// Front stage, part 1: the slabs of ALL C0 channels of image n summed into act0[C0][HW] (LDS) by threads [t0, t0+nthr)
+template <int V>
+__device__ __forceinline__ void load_front(const Desc& D, int n, int HW, int t0, int nthr, float* act0) {
+    typedef typename vecf<V>::type T;
+    const int tid = (int)threadIdx.x - t0;
+    if (tid < 0 || tid >= nthr) return;
+    const int nel = D.C0 * HW;
+    const int64_t NHW = (int64_t)D.N * HW;
+    const fdiv by_hw(HW);
+    for (int i = tid * V; i < nel; i += nthr * V) {
+        const int c = by_hw(i), pp = i - c * HW;
+        *reinterpret_cast<T*>(&act0[i]) = slab_sum<V>(D.x0 + (int64_t)c * NHW + (int64_t)n * HW + pp, D.splits0, D.slab_stride0);
+    }
+}
+// Front stage, part 2: GroupNorm (+ ReLU) of every group of act0 in place, one wave per group at a time (wave-level
+// two-pass statistics, no block barrier inside); gb0 = gamma0 | beta0 staged in LDS.
+__device__ __forceinline__ void norm_front(const Desc& D, int HW, float* act0, const float* gb0) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cpg0 = D.C0 / D.groups0, nel = cpg0 * HW;
+    const fdiv by_hw(HW);
+    for (int g0 = wave; g0 < D.groups0; g0 += GT / 64) {
+        float* t = act0 + g0 * nel;
+        float s = 0.f;
+        for (int i = lane; i < nel; i += 64) s += t[i];
+        const float mean = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_sum(s)), 63)) / (float)nel;
+        float q = 0.f;
+        for (int i = lane; i < nel; i += 64) {
+            const float d = t[i] - mean;
+            q += d * d;
+        }
+        const float var = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_sum(q)), 63)) / (float)nel;
+        const float rstd = rsqrtf(var + D.eps);
+        for (int i = lane; i < nel; i += 64) {
+            const int c = g0 * cpg0 + by_hw(i);
+            const float ga = gb0[c] * rstd, be = gb0[D.C0 + c] - mean * ga;
+            t[i] = fmaxf(fmaf(t[i], ga, be), 0.f);
+        }
     }
 }
 
@@ -287,6 +330,17 @@ __global__ __launch_bounds__(GT) void k_gn_conv(const Desc D, const Geo G) {
     if (D.pool) p += (cpg * Hc * Wc + 3) & ~3;
     float* part = G.part_floats ? p : nullptr;  // partial tiles of waves that share a tile
     p += G.part_floats;
+    // front stage (two conv layers per launch): all channels of the previous layer, its affine parameters, the rows of
+    // its 1x1 conv that produce this block's group
+    float* act0 = p;
+    float* gb0 = p;
+    float* w0l = p;
+    const int kbp0 = D.x0 ? padded_row(D.C0) : 0;
+    if (D.x0) {
+        gb0 = act0 + ((D.C0 * HW + 3) & ~3);
+        w0l = gb0 + ((2 * D.C0 + 3) & ~3);
+        p = w0l + cpg * kbp0;
+    }
     float* wl = p;            // staged weights: conv A, then (prestage) conv B behind it
     // grid (group, image, slice of the output channels): the slices of one (image, group) share an XCD's L2
     const int g = blockIdx.x, n = blockIdx.y, sy = blockIdx.z;
@@ -296,11 +350,13 @@ __global__ __launch_bounds__(GT) void k_gn_conv(const Desc D, const Geo G) {
     float* wl_b = wl + (prestage && D.wa ? max(a_end - a_beg, 0) * kbp_a : 0);
 
     STAMP(0);
-    // every global load of the kernel up front: most waves pull the tile(s), the others this block's weights
+    // every global load of the kernel up front, by role: threads [0, t1) the (image, group) tile(s), [t1, t2) the front
+    // stage's slabs, [t2, t3) its weight rows and affine parameters, [t3, GT) this block's slices of the next conv(s)
     float s = 0.f, s2 = 0.f;
-    const int nload = GT - wthr;
-    if ((int)threadIdx.x >= GT - cpg) {  // affine parameters: fetched with everything else, read from LDS after the statistics
-        const int c = (int)threadIdx.x - (GT - cpg), cp = (cpg + 3) & ~3;
+    const int t3 = GT - wthr, t2 = t3 - G.w0thr, t1 = t2 - G.fthr;
+    const int tid = threadIdx.x;
+    if (tid >= GT - cpg) {  // affine parameters: fetched with everything else, read from LDS after the statistics
+        const int c = tid - (GT - cpg), cp = (cpg + 3) & ~3;
         gb[c] = D.gamma[c0 + c];
         gb[cp + c] = D.beta[c0 + c];
         if (D.x2) {
@@ -308,15 +364,38 @@ __global__ __launch_bounds__(GT) void k_gn_conv(const Desc D, const Geo G) {
             gb[3 * cp + c] = D.beta2[c0 + c];
         }
     }
-    if (threadIdx.x == 0) red[31] = 0.f;
-    if ((int)threadIdx.x < nload) {
-        if ((HW & 3) == 0) load_tiles<4>(D, n, c0, cpg, HW, nload, tile, tile2, tres, s, s2);
-        else load_tiles<1>(D, n, c0, cpg, HW, nload, tile, tile2, tres, s, s2);
+    if (tid == 0) red[31] = 0.f;
+    if (tid < t1) {
+        if ((HW & 3) == 0) load_tiles<4>(D, n, c0, cpg, HW, t1, tile, tile2, tres, s, s2);
+        else load_tiles<1>(D, n, c0, cpg, HW, t1, tile, tile2, tres, s, s2);
+    } else if (tid < t2) {
+        if ((HW & 3) == 0) load_front<4>(D, n, HW, t1, t2 - t1, act0);
+        else load_front<1>(D, n, HW, t1, t2 - t1, act0);
+    } else if (tid < t3) {
+        stage_weights(D.w0, D.C0, 0, D.C0, kbp0, c0, cpg, w0l, t2, t3 - t2);
+        for (int c = tid - t2; c < D.C0; c += t3 - t2) {
+            gb0[c] = D.gamma0[c];
+            gb0[D.C0 + c] = D.beta0[c];
+        }
     } else {
-        if (D.wa) stage_weights(D.wa, D.C * KSZ * KSZ, c0 * KSZ * KSZ, cpg * KSZ * KSZ, kbp_a, a_beg, a_end - a_beg, wl, nload, GT - nload);
-        if (D.wb) stage_weights(D.wb, D.C, c0, cpg, kbp_b, b_beg, b_end - b_beg, wl_b, nload, GT - nload);
+        if (D.wa) stage_weights(D.wa, D.C * KSZ * KSZ, c0 * KSZ * KSZ, cpg * KSZ * KSZ, kbp_a, a_beg, a_end - a_beg, wl, t3, GT - t3);
+        if (D.wb) stage_weights(D.wb, D.C, c0, cpg, kbp_b, b_beg, b_end - b_beg, wl_b, t3, GT - t3);
     }
-    STAMP(1);
+    if (D.x0) {
+        STAMP(1);
+        // GroupNorm + ReLU of the whole previous layer (every block of the image repeats it: 16-64 KB of LDS work), then
+        // this group's rows of the 1x1 conv over the full K = C0 -> the tile the statistics below see
+        __syncthreads();
+        norm_front(D, HW, act0, gb0);
+        __syncthreads();
+        partial_conv<1>(act0, D.C0, D.H, D.W, D.w0, D.C0, 0, c0, c0 + cpg, 1, 0, D.H, D.W, tile - (int64_t)c0 * HW, HW, 0, w0l,
+                        cpg * kbp0, true, (int)(red + 31 - act0), part);
+        __syncthreads();
+        for (int i = tid; i < nel; i += GT) s += tile[i];
+        STAMP(7);
+    } else {
+        STAMP(1);
+    }
     // statistics of both operands: two block reductions (means, then centred squares)
     block_sum2(s, s2, red);
     const float mean = s / (float)nel, mean2 = s2 / (float)nel;
@@ -393,9 +472,12 @@ typedef void (*gn_conv_fn)(const Desc, const Geo);
 extern "C" {
 
 int ivln_gn_conv_f32(const ivln_gn_conv_desc* d, void* stream) {
-    if (!d || !d->x || !d->gamma || !d->beta || d->N <= 0 || d->C <= 0 || d->groups <= 0 || d->C % d->groups) return IVLN_E_INVALID;
-    if (d->splits < 1 || (d->x2 && (d->splits2 < 1 || !d->gamma2 || !d->beta2))) return IVLN_E_INVALID;
+    if (!d || (!d->x && !d->x0) || !d->gamma || !d->beta || d->N <= 0 || d->C <= 0 || d->groups <= 0 || d->C % d->groups) return IVLN_E_INVALID;
+    if ((d->x && d->splits < 1) || (d->x2 && (d->splits2 < 1 || !d->gamma2 || !d->beta2))) return IVLN_E_INVALID;
     if (!d->wa && !d->wb && !d->act_out) return IVLN_E_INVALID;
+    if (d->x0 && (d->x || d->pool || d->splits0 < 1 || d->C0 <= 0 || d->groups0 <= 0 || d->C0 % d->groups0 || (d->C0 & 1) || !d->gamma0 ||
+                  !d->beta0 || !d->w0))
+        return IVLN_E_INVALID;
     if (d->wa && (!d->ya || d->Cout_a <= 0 || (d->ka != 1 && d->ka != 3) || d->stride_a < 1)) return IVLN_E_UNSUPPORTED;
     if (d->wb && (!d->yb || d->Cout_b <= 0 || d->stride_b < 1)) return IVLN_E_INVALID;
     const int cpg = d->C / d->groups, HW = d->H * d->W, nel = cpg * HW;
@@ -439,6 +521,12 @@ int ivln_gn_conv_f32(const ivln_gn_conv_desc* d, void* stream) {
     size_t part = (tiles_a < 8 || tiles_b < 8) ? 8 * 1024 : 0;
     size_t fixed = 32 + 4 * (size_t)((cpg + 3) & ~3) + nel4 * (1 + (d->x2 ? 1 : 0) + (d->residual ? 1 : 0)) +
                    (d->pool ? (size_t)((cpg * H * W + 3) & ~3) : 0);
+    size_t front = 0;
+    if (d->x0) {  // all channels of the previous layer + its affine parameters + this group's rows of its 1x1 conv
+        front = (size_t)((d->C0 * HW + 3) & ~3) + (size_t)((2 * d->C0 + 3) & ~3) + (size_t)cpg * (((d->C0 + 3) & ~3) + 4);
+        if (((cpg + 31) / 32) * ((HW + 31) / 32) < 8) part = 8 * 1024;
+        fixed += front;
+    }
     if (fixed + part + 2048 > kLdsFloats) part = 0;
     fixed += part;
     if (fixed + 64 > kLdsFloats) return IVLN_E_UNSUPPORTED;
@@ -460,19 +548,39 @@ int ivln_gn_conv_f32(const ivln_gn_conv_desc* d, void* stream) {
             raised.insert((const void*)fn);
         }
     }
-    // waves that load weights instead of tile slabs, in proportion to the bytes (1..7 of the 8)
-    int wthr = 0;
-    if (prestage) {
-        const double wb = (double)(need_a + need_b), tb = (double)nel * (d->splits + (d->x2 ? d->splits2 : 0) + (d->residual ? 1 : 0));
-        int nw = (int)(8.0 * wb / (wb + tb) + 0.5);
-        nw = nw < 1 ? 1 : (nw > 6 ? 6 : nw);
-        wthr = 64 * nw;
-        if (wthr < cpg) wthr = (cpg + 63) / 64 * 64;
+    // the block's 8 waves take load roles in proportion to the bytes: tile slabs | front-stage slabs | front-stage weights |
+    // the next convs' weight slices (none when those are streamed in chunks)
+    {
+        const double tb = (double)nel * ((d->x ? d->splits : 0) + (d->x2 ? d->splits2 : 0) + (d->residual ? 1 : 0));
+        const double fb = d->x0 ? (double)d->C0 * HW * d->splits0 : 0.0;
+        const double w0b = d->x0 ? (double)cpg * d->C0 + 2.0 * d->C0 : 0.0;
+        const double wb = prestage ? (double)(need_a + need_b) : 0.0;
+        const double tot = tb + fb + w0b + wb;
+        int nw[4];
+        const double by[4] = {tb, fb, w0b, wb};
+        int used = 0;
+        for (int i = 0; i < 4; ++i) {
+            nw[i] = by[i] > 0 ? (int)(8.0 * by[i] / tot + 0.5) : 0;
+            if (by[i] > 0 && nw[i] < 1) nw[i] = 1;
+            used += nw[i];
+        }
+        while (used > 8) {  // take from the largest
+            int m = 0;
+            for (int i = 1; i < 4; ++i) if (nw[i] > nw[m]) m = i;
+            --nw[m];
+            --used;
+        }
+        int big = tb >= fb ? 0 : 1;  // spare waves go to the larger slab role
+        if (by[big] <= 0) big = 3;
+        nw[big] += 8 - used;
+        G.wthr = 64 * nw[3];
+        G.w0thr = 64 * nw[2];
+        G.fthr = 64 * nw[1];
+        if (by[big] <= 0) return IVLN_E_INVALID;
     }
     G.per_a = d->wa ? (d->Cout_a + S - 1) / S : 0;
     G.per_b = d->wb ? (d->Cout_b + S - 1) / S : 0;
     G.wl_floats = (int)wl;
-    G.wthr = wthr;
     G.part_floats = (int)part;
     if (d->N > 65535) return IVLN_E_UNSUPPORTED;
     hipLaunchKernelGGL(fn, dim3(d->groups, d->N, S), dim3(GT), bytes, (hipStream_t)stream, *d, G);

@@ -293,14 +293,17 @@ class _ResNet50GN(nn.Module):
             r = ops.gn_conv(ya, c[1], conv_a=(c[3].weight, blk.stride, 1))
             if r is None:
                 return None
-            r = ops.gn_conv(r[1], c[4], conv_a=(c[6].weight, 1, 0))
-            if r is None:
-                return None
             nxt = feeds(blocks[i + 1]) if i + 1 < len(blocks) else dict(conv_a=tail)
-            if blk.downsample is not None:
-                r = ops.gn_conv(r[1], c[7], x2=yb, gn2=blk.downsample[1], **nxt)
-            else:
-                r = ops.gn_conv(r[1], c[7], residual=act, **nxt)
+            tail_in = dict(x2=yb, gn2=blk.downsample[1]) if blk.downsample is not None else dict(residual=act)
+            r2 = None
+            if i >= ops.CHAIN_PAIR_FROM_BLOCK:  # GN2 -> conv3 -> GN3 tail -> next conv1 in one launch
+                r2 = ops.gn_conv(None, c[7], front=(r[1], c[4], c[6].weight), **tail_in, **nxt)
+            if r2 is None:
+                r = ops.gn_conv(r[1], c[4], conv_a=(c[6].weight, 1, 0))
+                if r is None:
+                    return None
+                r2 = ops.gn_conv(r[1], c[7], **tail_in, **nxt)
+            r = r2
         return None if r is None else r[1]
 
     def forward_hip(self, x):

@@ -501,6 +501,10 @@ CHAIN_GN_CONV = os.environ.get("IVLN_GN_CONV", "1") != "0"
 # are more traffic than the launches they save) stay conv + GroupNorm pairs.  0 = the whole backbone incl. the stem;
 # 3 = from layer2 on (measured best at 4 envs: 0.790 ms/step vs 0.820 from the stem and 0.996 without the chain).
 CHAIN_FROM_BLOCK = int(os.environ.get("IVLN_GN_CONV_FROM", "3"))
+# first bottleneck whose GN2 -> conv3 -> GN3 tail -> next conv1 run as ONE launch (the block re-normalises the whole
+# 16-64 KB conv2 output of its image): 2 launches per bottleneck instead of 3.  Measured SLOWER (0.835 vs 0.805 ms per
+# step from layer 3 on, profiles/r02_gn_conv_ab.txt: the merged launch takes 20 us against 8.5 + 9.8), so 16 = never.
+CHAIN_PAIR_FROM_BLOCK = int(os.environ.get("IVLN_GN_CONV_PAIR_FROM", "16"))
 
 
 class GnConvDesc(C.Structure):
@@ -514,19 +518,34 @@ class GnConvDesc(C.Structure):
         ("act_out", vp),
         ("wa", vp), ("Cout_a", i32), ("ka", i32), ("stride_a", i32), ("pad_a", i32), ("ya", vp),
         ("wb", vp), ("Cout_b", i32), ("stride_b", i32), ("yb", vp),
+        ("x0", vp), ("splits0", i32), ("slab_stride0", i64), ("C0", i32), ("groups0", i32), ("gamma0", vp), ("beta0", vp),
+        ("w0", vp),
     ]
 
 
-def gn_conv(x, gn, relu=True, pool=False, x2=None, gn2=None, residual=None, want_act=False, conv_a=None, conv_b=None):
+def gn_conv(x, gn, relu=True, pool=False, x2=None, gn2=None, residual=None, want_act=False, conv_a=None, conv_b=None,
+            front=None):
     """act(GroupNorm(x) [+ GroupNorm2(x2)] [+ residual]) [-> MaxPool(3, 2, 1)] and the NEXT convolution(s) of that
     activation in one launch (csrc/gn_conv.hip).  x, x2: `Deferred` slabs; conv_a = (weight (Co, C, k, k), stride, pad),
     conv_b = (weight (Co, C, 1, 1), stride).  Returns (act | None, Deferred a | None, Deferred b | None); the conv
     outputs are `groups` partial slabs for the next gn_conv / groupnorm.  None when the shape is outside the kernel's
-    envelope."""
-    N, Cc, H, W = x.N, x.C, x.H, x.W
-    dev = x.ws.device
+    envelope.
+    front = (x0 Deferred, gn0, w0 (C, C0, 1, 1)) with x None: two conv layers per launch - the block first normalises
+    (+ ReLU) the WHOLE previous layer x0 of its image and runs the 1x1 conv w0 for its own group over the full K; that
+    tile is what `gn` then normalises (Bottleneck: GN2 -> ReLU -> conv3 -> GN3 -> + identity -> ReLU -> next conv1)."""
     d = GnConvDesc()
-    d.x, d.splits, d.slab_stride = dptr(x.ws), x.splits, Cc * N * H * W
+    if front is not None:
+        assert x is None
+        x0, gn0, w0 = front
+        N, Cc, H, W = x0.N, w0.shape[0], x0.H, x0.W
+        dev = x0.ws.device
+        assert w0.shape[1] == x0.C and w0.shape[2] == 1 and gn0.eps == gn.eps
+        d.x0, d.splits0, d.slab_stride0 = dptr(x0.ws), x0.splits, x0.C * N * H * W
+        d.C0, d.groups0, d.gamma0, d.beta0, d.w0 = x0.C, gn0.num_groups, dptr(gn0.weight), dptr(gn0.bias), dptr(w0)
+    else:
+        N, Cc, H, W = x.N, x.C, x.H, x.W
+        dev = x.ws.device
+        d.x, d.splits, d.slab_stride = dptr(x.ws), x.splits, Cc * N * H * W
     d.gamma, d.beta = dptr(gn.weight), dptr(gn.bias)
     if x2 is not None:
         assert (x2.N, x2.C, x2.H, x2.W) == (N, Cc, H, W) and gn2.num_groups == gn.num_groups and gn2.eps == gn.eps

@@ -117,6 +117,53 @@ def test_stem_groupnorm_relu_maxpool_and_both_convs_of_the_first_bottleneck():
     assert float((_sum(yb) - F.conv2d(ref, wb)).abs().max()) < 1e-4
 
 
+@pytest.mark.parametrize("N,C0,H,W,Cc,ca,cb,tail", [
+    (4, 128, 8, 8, 512, (128, 1, 1, 0), None, "residual"),       # layer3 bottleneck tail
+    (2, 128, 8, 8, 512, (256, 1, 1, 0), (1024, 2), "residual"),  # layer3 last -> layer4 conv1 + downsample
+    (4, 256, 4, 4, 1024, (256, 1, 1, 0), None, "second"),        # layer4 first block (downsample operand)
+    (4, 256, 4, 4, 1024, (128, 3, 1, 1), None, "residual"),      # layer4 last -> compression conv
+    (2, 64, 16, 16, 256, (64, 1, 1, 0), None, "residual"),       # layer2
+    (3, 32, 5, 7, 96, (10, 3, 2, 1), (6, 1), "plain"),           # odd sizes
+])
+def test_two_conv_layers_per_launch_front_stage(N, C0, H, W, Cc, ca, cb, tail):
+    """front = (x0 slabs, GroupNorm0, 1x1 conv w0): relu(GN0(x0)) -> conv w0 -> GN -> (+ ...) -> ReLU -> next conv(s),
+    i.e. a Bottleneck's GN2 -> conv3 -> GN3 tail -> the next block's conv1 in ONE launch."""
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(C0 + Cc + H)
+    x0 = torch.randn(N, C0, H, W, generator=g) * 1.5 + 0.2
+    gn0, gn = _gn(C0, 16, g), _gn(Cc, 16, g)
+    w0 = torch.randn(Cc, C0, 1, 1, generator=g) / C0 ** 0.5
+    mid = F.conv2d(F.relu(F.group_norm(x0, 16, gn0.weight, gn0.bias, 1e-5)), w0)
+    ref = F.group_norm(mid, 16, gn.weight, gn.bias, 1e-5)
+    kw = {}
+    if tail == "second":
+        x2, gn2 = torch.randn(N, Cc, H, W, generator=g), _gn(Cc, 16, g)
+        ref = ref + F.group_norm(x2, 16, gn2.weight, gn2.bias, 1e-5)
+        kw = dict(x2=_slabs(x2, 16, g), gn2=gn2.to(DEV))
+    elif tail == "residual":
+        res = torch.randn(N, Cc, H, W, generator=g)
+        ref = ref + res
+        kw = dict(residual=res.to(DEV))
+    ref = F.relu(ref).detach()
+    wa = torch.randn(ca[0], Cc, ca[1], ca[1], generator=g) / (Cc * ca[1] ** 2) ** 0.5
+    ref_a = F.conv2d(ref, wa, None, ca[2], ca[3])
+    conv_b = ref_b = None
+    if cb is not None:
+        wb = torch.randn(cb[0], Cc, 1, 1, generator=g) / Cc ** 0.5
+        ref_b = F.conv2d(ref, wb, None, cb[1])
+        conv_b = (wb.to(DEV), cb[1])
+    r = ops.gn_conv(None, gn.to(DEV), relu=True, want_act=True, conv_a=(wa.to(DEV), ca[2], ca[3]), conv_b=conv_b,
+                    front=(_slabs(x0, 16, g), gn0.to(DEV), w0.to(DEV)), **kw)
+    assert r is not None, "shape must be inside the kernel's envelope"
+    act, ya, yb = r
+    tol = 1e-4 * max(1.0, float(ref.abs().max()))
+    assert float((act.cpu() - ref).abs().max()) < tol
+    assert float((_sum(ya) - ref_a).abs().max()) < 2 * tol
+    if cb is not None:
+        assert float((_sum(yb) - ref_b).abs().max()) < 2 * tol
+
+
 def test_refuses_shapes_outside_its_envelope():
     from ivln_ce_amd import ops
 
@@ -127,8 +174,8 @@ def test_refuses_shapes_outside_its_envelope():
     assert ops.gn_conv(_slabs(torch.randn(1, 32, 96, 96, generator=g), 1, g), _gn(32, 16, g).to(DEV), conv_a=(w, 1, 0)) is None  # tile > LDS budget
 
 
-@pytest.mark.parametrize("B,first", [(1, 0), (4, 0), (8, 0), (4, 3), (4, 7), (2, 16)])
-def test_depth_encoder_chain_matches_pairwise_path_and_oracle(B, first):
+@pytest.mark.parametrize("B,first,pair", [(1, 0, 16), (4, 0, 0), (8, 0, 16), (4, 3, 7), (4, 7, 7), (2, 16, 16), (8, 3, 3), (4, 3, 13)])
+def test_depth_encoder_chain_matches_pairwise_path_and_oracle(B, first, pair):
     """The whole ResNetEncoder through the gn_conv chain == the deferred conv + GroupNorm pairs == the oracle's
     torch restatement (oracle/habitat_ext_ref.py), random-init weights, fp32."""
     import sys
@@ -141,9 +188,10 @@ def test_depth_encoder_chain_matches_pairwise_path_and_oracle(B, first):
     torch.manual_seed(5)
     enc = ResNetEncoder((256, 256, 1)).to(DEV).eval()
     depth = torch.rand(B, 256, 256, 1, generator=torch.Generator().manual_seed(B))
-    old, old_first = ops.CHAIN_GN_CONV, ops.CHAIN_FROM_BLOCK
+    old, old_first, old_pair = ops.CHAIN_GN_CONV, ops.CHAIN_FROM_BLOCK, ops.CHAIN_PAIR_FROM_BLOCK
     try:
-        ops.CHAIN_GN_CONV, ops.CHAIN_FROM_BLOCK = True, first  # `first`: the bottleneck at which the chain takes over
+        # `first`: the bottleneck at which the chain takes over; `pair`: the first one with two conv layers per launch
+        ops.CHAIN_GN_CONV, ops.CHAIN_FROM_BLOCK, ops.CHAIN_PAIR_FROM_BLOCK = True, first, pair
         with torch.no_grad():
             a = enc({"depth": depth.to(DEV)}).cpu()
             a2 = enc({"depth": depth.to(DEV)}).cpu()
@@ -151,7 +199,7 @@ def test_depth_encoder_chain_matches_pairwise_path_and_oracle(B, first):
         with torch.no_grad():
             b = enc({"depth": depth.to(DEV)}).cpu()
     finally:
-        ops.CHAIN_GN_CONV, ops.CHAIN_FROM_BLOCK = old, old_first
+        ops.CHAIN_GN_CONV, ops.CHAIN_FROM_BLOCK, ops.CHAIN_PAIR_FROM_BLOCK = old, old_first, old_pair
     assert torch.equal(a, a2), "the chain is deterministic"
     assert float((a - b).abs().max()) < 2e-4, float((a - b).abs().max())
     import types

@@ -42,16 +42,31 @@ SHAPES = [
     ("l4 gn2", 256, 4, 4, 16, 0, 0, 0, (1024, 1, 1, 0), None),
     ("l4 tail ds", 1024, 4, 4, 16, 1, 0, 0, (256, 1, 1, 0), None),
     ("l4 last", 1024, 4, 4, 16, 0, 1, 0, (128, 3, 1, 1), None),
+    # two conv layers per launch: splits < 0 = channels of the front stage (GN2 -> conv3 -> this GroupNorm)
+    ("l2 pair", 256, 16, 16, -64, 0, 1, 0, (64, 1, 1, 0), None),
+    ("l3 pair", 512, 8, 8, -128, 0, 1, 0, (128, 1, 1, 0), None),
+    ("l4 pair", 1024, 4, 4, -256, 0, 1, 0, (256, 1, 1, 0), None),
+    ("l4 pair last", 1024, 4, 4, -256, 0, 1, 0, (128, 3, 1, 1), None),
 ]
 print(f"N = {N}; us per phase, median over blocks")
-print(f"{'shape':12s} {'grid':>9s} {'load':>6s} {'gn':>6s} {'act':>6s} {'convA':>6s} {'convB':>6s} {'mfma':>6s} {'block':>6s} {'grid span':>9s} {'event':>7s}")
+print(f"{'shape':12s} {'grid':>9s} {'load':>6s} {'gn':>6s} {'act':>6s} {'convA':>6s} {'convB':>6s} {'mfma':>6s} {'front':>6s} {'block':>6s} {'grid span':>9s} {'event':>7s}")
 for name, Cc, H, W, splits, x2, res, pool, ca, cb in SHAPES:
     g = torch.Generator(device="cpu").manual_seed(1)
     d = ops.GnConvDesc()
-    x = torch.randn(splits, Cc, N * H * W, device=dev)
     gam, bet = torch.randn(Cc, device=dev), torch.randn(Cc, device=dev)
-    keep = [x, gam, bet]
-    d.x, d.splits, d.slab_stride, d.gamma, d.beta = x.data_ptr(), splits, Cc * N * H * W, gam.data_ptr(), bet.data_ptr()
+    keep = [gam, bet]
+    d.gamma, d.beta = gam.data_ptr(), bet.data_ptr()
+    if splits > 0:
+        x = torch.randn(splits, Cc, N * H * W, device=dev)
+        d.x, d.splits, d.slab_stride = x.data_ptr(), splits, Cc * N * H * W
+    else:
+        C0 = -splits
+        x = torch.randn(16, C0, N * H * W, device=dev)
+        g0, b0, w0 = torch.randn(C0, device=dev), torch.randn(C0, device=dev), torch.randn(Cc, C0, 1, 1, device=dev) / C0 ** 0.5
+        keep += [g0, b0, w0]
+        d.x0, d.splits0, d.slab_stride0, d.C0, d.groups0 = x.data_ptr(), 16, C0 * N * H * W, C0, 16
+        d.gamma0, d.beta0, d.w0 = g0.data_ptr(), b0.data_ptr(), w0.data_ptr()
+    keep.append(x)
     if x2:
         t = torch.randn(16, Cc, N * H * W, device=dev)
         keep.append(t)
@@ -94,6 +109,12 @@ for name, Cc, H, W, splits, x2, res, pool, ca, cb in SHAPES:
     newest = st[:, 0].max()
     live = used & (st[:, 0] > newest - 100_000)
     t = st[live][:, :6] / 100.0  # 100 MHz -> us
+    front = 0.0
+    if splits < 0:  # stamps: 0 start, 1 loads done, 7 front stage done, 2 GroupNorm done, ...
+        t7 = st[live][:, 7] / 100.0
+        front = float(np.median(t7 - t[:, 1]))
+        t = t.copy()
+        t[:, 2:] -= (t7 - t[:, 1])[:, None]  # report the GroupNorm phase from the end of the front stage
     ph = np.median(np.diff(t, axis=1), axis=0)
-    print(f"{name:12s} {int(live.sum()):9d} {ph[0]:6.2f} {ph[1]:6.2f} {ph[2]:6.2f} {ph[3]:6.2f} {ph[4]:6.2f} {np.median(st[live][:, 6] / 100.0 - t[:, 3]):6.2f} {np.median(t[:, 5] - t[:, 0]):6.2f} "
+    print(f"{name:12s} {int(live.sum()):9d} {ph[0]:6.2f} {ph[1]:6.2f} {ph[2]:6.2f} {ph[3]:6.2f} {ph[4]:6.2f} {np.median(st[live][:, 6] / 100.0 - t[:, 3]):6.2f} {front:6.2f} {np.median(t[:, 5] - t[:, 0]):6.2f} "
           f"{t[:, 5].max() - t[:, 0].min():9.2f} {ev:7.2f}")
