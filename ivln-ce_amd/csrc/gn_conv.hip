@@ -28,7 +28,12 @@
 
 namespace {
 
-constexpr int GT = 512;          // threads per block
+#ifndef GN_CONV_THREADS
+#define GN_CONV_THREADS 512
+#endif
+constexpr int GT = GN_CONV_THREADS;  // threads per block
+constexpr int NW = GT / 64;      // waves per block
+constexpr int ZW = 2 * NW;       // index of the zero word in the reduction scratch
 constexpr int TILE_MAX = 8192;   // cpg * H * W floats held in LDS
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr size_t kLdsFloats = 38 * 1024;  // 152 KB of the CU's 160 KB
@@ -67,7 +72,7 @@ __device__ __forceinline__ void block_sum2(float& a, float& b, float* red) {
     __syncthreads();
     if ((threadIdx.x & 63) == 63) {
         red[w] = a;
-        red[16 + w] = b;
+        red[NW + w] = b;
     }
     __syncthreads();
     a = 0.f;
@@ -75,7 +80,7 @@ __device__ __forceinline__ void block_sum2(float& a, float& b, float* red) {
 #pragma unroll
     for (int i = 0; i < GT / 64; ++i) {
         a += red[i];
-        b += red[16 + i];
+        b += red[NW + i];
     }
 }
 
@@ -133,7 +138,7 @@ __device__ __forceinline__ typename vecf<V>::type slab_sum(const float* __restri
 // One pass over the block's (image, group) tile by threads [0, nthr): the slabs of x (and of the second operand x2)
 // summed into LDS, the residual copied next to them - every global load of the GroupNorm front-end is issued in
 // this one loop, so the tile costs one memory round trip.  s / s2: this thread's partial sums of x / x2.
-template <int V>
+template <int V, bool FRONT>
 __device__ __forceinline__ void load_tiles(const Desc& D, int n, int c0, int cpg, int HW, int nthr, float* tile, float* tile2,
                                            float* tres, float& s, float& s2) {
     typedef typename vecf<V>::type T;
@@ -145,7 +150,7 @@ __device__ __forceinline__ void load_tiles(const Desc& D, int n, int c0, int cpg
         const int64_t o = (int64_t)(c0 + cl) * NHW + (int64_t)n * HW + pp;
         T r;
         if (D.residual) r = *reinterpret_cast<const T*>(D.residual + ((int64_t)n * D.C + c0) * HW + i);
-        if (D.x) {  // (absent with a front stage: the tile is then computed in the block)
+        if (!FRONT) {  // (with a front stage the tile is computed in the block)
             const T v = slab_sum<V>(D.x + o, D.splits, D.slab_stride);
             *reinterpret_cast<T*>(&tile[i]) = v;
             s += vsum(v);
@@ -260,7 +265,7 @@ __device__ __forceinline__ void partial_conv(const float* act, int cpg, int H, i
         int ksl = (T >= 8 || !part) ? 0 : (T >= 4 ? 1 : (T >= 2 ? 2 : 3));  // log2 of the waves per tile
         while ((1 << ksl) > hc) --ksl;
         const int KS = 1 << ksl;
-        for (int item = wave; item < T * KS; item += 8) {
+        for (int item = wave; item < T * KS; item += NW) {
             const int tile = item >> ksl, ks = item - (tile << ksl);
             const int ci = by_ptl(tile), pi = tile - ci * ptl;
             const int p = pi * 32 + l31;
@@ -310,15 +315,15 @@ __device__ __forceinline__ void partial_conv(const float* act, int cpg, int H, i
     }
 }
 
-template <int KSZ>
+template <int KSZ, bool FRONT>
 __global__ __launch_bounds__(GT) void k_gn_conv(const Desc D, const Geo G) {
     const int wthr = G.wthr;  // the last `wthr` threads load this block's weight slices beside the tile (0: chunked)
     const int prestage = wthr > 0;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int HW = D.H * D.W;
     const int cpg = G.cpg, nel = cpg * HW, nel4 = (nel + 3) & ~3;
-    float* red = smem;        // 32: block reductions; red[31] stays 0 (the convs' padding word)
-    float* gb = smem + 32;    // gamma, beta, gamma2, beta2 of this group's channels
+    float* red = smem;        // 64: block reductions; red[ZW] stays 0 (the convs' padding word)
+    float* gb = smem + 64;    // gamma, beta, gamma2, beta2 of this group's channels
     float* tile = gb + 4 * ((cpg + 3) & ~3);  // cpg*HW
     float* p = tile + nel4;
     float* tile2 = p;         // second operand
@@ -335,8 +340,8 @@ __global__ __launch_bounds__(GT) void k_gn_conv(const Desc D, const Geo G) {
     float* act0 = p;
     float* gb0 = p;
     float* w0l = p;
-    const int kbp0 = D.x0 ? padded_row(D.C0) : 0;
-    if (D.x0) {
+    const int kbp0 = FRONT ? padded_row(D.C0) : 0;
+    if (FRONT) {
         gb0 = act0 + ((D.C0 * HW + 3) & ~3);
         w0l = gb0 + ((2 * D.C0 + 3) & ~3);
         p = w0l + cpg * kbp0;
@@ -364,14 +369,14 @@ __global__ __launch_bounds__(GT) void k_gn_conv(const Desc D, const Geo G) {
             gb[3 * cp + c] = D.beta2[c0 + c];
         }
     }
-    if (tid == 0) red[31] = 0.f;
+    if (tid == 0) red[ZW] = 0.f;
     if (tid < t1) {
-        if ((HW & 3) == 0) load_tiles<4>(D, n, c0, cpg, HW, t1, tile, tile2, tres, s, s2);
-        else load_tiles<1>(D, n, c0, cpg, HW, t1, tile, tile2, tres, s, s2);
-    } else if (tid < t2) {
+        if ((HW & 3) == 0) load_tiles<4, FRONT>(D, n, c0, cpg, HW, t1, tile, tile2, tres, s, s2);
+        else load_tiles<1, FRONT>(D, n, c0, cpg, HW, t1, tile, tile2, tres, s, s2);
+    } else if (FRONT && tid < t2) {
         if ((HW & 3) == 0) load_front<4>(D, n, HW, t1, t2 - t1, act0);
         else load_front<1>(D, n, HW, t1, t2 - t1, act0);
-    } else if (tid < t3) {
+    } else if (FRONT && tid < t3) {
         stage_weights(D.w0, D.C0, 0, D.C0, kbp0, c0, cpg, w0l, t2, t3 - t2);
         for (int c = tid - t2; c < D.C0; c += t3 - t2) {
             gb0[c] = D.gamma0[c];
@@ -381,7 +386,7 @@ __global__ __launch_bounds__(GT) void k_gn_conv(const Desc D, const Geo G) {
         if (D.wa) stage_weights(D.wa, D.C * KSZ * KSZ, c0 * KSZ * KSZ, cpg * KSZ * KSZ, kbp_a, a_beg, a_end - a_beg, wl, t3, GT - t3);
         if (D.wb) stage_weights(D.wb, D.C, c0, cpg, kbp_b, b_beg, b_end - b_beg, wl_b, t3, GT - t3);
     }
-    if (D.x0) {
+    if (FRONT) {
         STAMP(1);
         // GroupNorm + ReLU of the whole previous layer (every block of the image repeats it: 16-64 KB of LDS work), then
         // this group's rows of the 1x1 conv over the full K = C0 -> the tile the statistics below see
@@ -389,7 +394,7 @@ __global__ __launch_bounds__(GT) void k_gn_conv(const Desc D, const Geo G) {
         norm_front(D, HW, act0, gb0);
         __syncthreads();
         partial_conv<1>(act0, D.C0, D.H, D.W, D.w0, D.C0, 0, c0, c0 + cpg, 1, 0, D.H, D.W, tile - (int64_t)c0 * HW, HW, 0, w0l,
-                        cpg * kbp0, true, (int)(red + 31 - act0), part);
+                        cpg * kbp0, true, (int)(red + ZW - act0), part);
         __syncthreads();
         for (int i = tid; i < nel; i += GT) s += tile[i];
         STAMP(7);
@@ -454,13 +459,13 @@ __global__ __launch_bounds__(GT) void k_gn_conv(const Desc D, const Geo G) {
     if (D.wa) {
         const int64_t NHWo = (int64_t)D.N * G.Ho_a * G.Wo_a;
         partial_conv<KSZ>(act, cpg, Hc, Wc, D.wa, D.C, c0, a_beg, a_end, D.stride_a, D.pad_a, G.Ho_a, G.Wo_a,
-                          D.ya + (int64_t)g * D.Cout_a * NHWo, NHWo, n, wl, G.wl_floats, prestage != 0, (int)(red + 31 - act), part);
+                          D.ya + (int64_t)g * D.Cout_a * NHWo, NHWo, n, wl, G.wl_floats, prestage != 0, (int)(red + ZW - act), part);
     }
     STAMP(4);
     if (D.wb) {
         const int64_t NHWo = (int64_t)D.N * G.Ho_b * G.Wo_b;
         partial_conv<1>(act, cpg, Hc, Wc, D.wb, D.C, c0, b_beg, b_end, D.stride_b, 0, G.Ho_b, G.Wo_b,
-                        D.yb + (int64_t)g * D.Cout_b * NHWo, NHWo, n, wl_b, G.wl_floats, prestage != 0, (int)(red + 31 - act), part);
+                        D.yb + (int64_t)g * D.Cout_b * NHWo, NHWo, n, wl_b, G.wl_floats, prestage != 0, (int)(red + ZW - act), part);
     }
     STAMP(5);
 }
@@ -504,7 +509,8 @@ int ivln_gn_conv_f32(const ivln_gn_conv_desc* d, void* stream) {
         HWo_b = G.Ho_b * G.Wo_b;
     }
     if ((d->wa || d->wb) && (cpg & 1)) return IVLN_E_UNSUPPORTED;  // the MFMA's two k slots take a channel pair
-    gn_conv_fn fn = (d->wa && d->ka == 3) ? k_gn_conv<3> : k_gn_conv<1>;
+    const bool k3 = d->wa && d->ka == 3;
+    gn_conv_fn fn = d->x0 ? (k3 ? k_gn_conv<3, true> : k_gn_conv<1, true>) : (k3 ? k_gn_conv<3, false> : k_gn_conv<1, false>);
     // output channels over blockIdx.y so that ~256 blocks are in flight (every block repeats the cheap GroupNorm)
     int S = 1;
     const int blocks = d->N * d->groups;
@@ -519,7 +525,7 @@ int ivln_gn_conv_f32(const ivln_gn_conv_desc* d, void* stream) {
     const int tiles_a = d->wa ? (((d->Cout_a + S - 1) / S + 31) / 32) * ((HWo_a + 31) / 32) : 8;
     const int tiles_b = d->wb ? (((d->Cout_b + S - 1) / S + 31) / 32) * ((HWo_b + 31) / 32) : 8;
     size_t part = (tiles_a < 8 || tiles_b < 8) ? 8 * 1024 : 0;
-    size_t fixed = 32 + 4 * (size_t)((cpg + 3) & ~3) + nel4 * (1 + (d->x2 ? 1 : 0) + (d->residual ? 1 : 0)) +
+    size_t fixed = 64 + 4 * (size_t)((cpg + 3) & ~3) + nel4 * (1 + (d->x2 ? 1 : 0) + (d->residual ? 1 : 0)) +
                    (d->pool ? (size_t)((cpg * H * W + 3) & ~3) : 0);
     size_t front = 0;
     if (d->x0) {  // all channels of the previous layer + its affine parameters + this group's rows of its 1x1 conv
@@ -560,11 +566,11 @@ int ivln_gn_conv_f32(const ivln_gn_conv_desc* d, void* stream) {
         const double by[4] = {tb, fb, w0b, wb};
         int used = 0;
         for (int i = 0; i < 4; ++i) {
-            nw[i] = by[i] > 0 ? (int)(8.0 * by[i] / tot + 0.5) : 0;
+            nw[i] = by[i] > 0 ? (int)((double)NW * by[i] / tot + 0.5) : 0;
             if (by[i] > 0 && nw[i] < 1) nw[i] = 1;
             used += nw[i];
         }
-        while (used > 8) {  // take from the largest
+        while (used > NW) {  // take from the largest
             int m = 0;
             for (int i = 1; i < 4; ++i) if (nw[i] > nw[m]) m = i;
             --nw[m];
@@ -572,7 +578,7 @@ int ivln_gn_conv_f32(const ivln_gn_conv_desc* d, void* stream) {
         }
         int big = tb >= fb ? 0 : 1;  // spare waves go to the larger slab role
         if (by[big] <= 0) big = 3;
-        nw[big] += 8 - used;
+        nw[big] += NW - used;
         G.wthr = 64 * nw[3];
         G.w0thr = 64 * nw[2];
         G.fthr = 64 * nw[1];
