@@ -93,9 +93,12 @@ enum { IVLN_B_CONV = 0,    /* im2col gather from NCHW via koff/kpos tables      
        IVLN_B_CONV_K7 = 7  /* 7x7, dilation 1                                            */ };
 enum { IVLN_D_NCHW = 0,    /* D[(img*Ctot + m)*HoWo + pp], n = img*HoWo + pp          */
        IVLN_D_DENSE = 1,   /* D[m*sDm + n*sDn]                                        */
-       IVLN_D_NCHW_UP2 = 2 /* one output-parity class of a stride-2 transposed conv: pixel (ho,wo) of the
+       IVLN_D_NCHW_UP2 = 2,/* one output-parity class of a stride-2 transposed conv: pixel (ho,wo) of the
                               (Hout x Wout) class grid lands at (2*ho + sDm, 2*wo + sDn) of a
-                              (2*Hout x 2*Wout) NCHW destination (sDm, sDn in {0,1} = row/col parity) */ };
+                              (2*Hout x 2*Wout) NCHW destination (sDm, sDn in {0,1} = row/col parity) */
+       IVLN_D_NCHW_UP2X4 = 3 /* all four parity classes in ONE GEMM: rows m = cls*(M/4) + channel, cls = 2*a + b;
+                              pixel (ho,wo) of row m lands at (2*ho + a, 2*wo + b) of channel m % (M/4); the
+                              epilogue parameters are indexed by the channel (rednet.py:210-216, 262-279) */ };
 
 typedef struct ivln_gemm_desc {
     const float* A;

@@ -11,7 +11,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 enum { AMODE_MK = 0, AMODE_KM = 1, AMODE_NCHW_P = 2 };
 enum { BMODE_CONV = 0, BMODE_CONV1X1 = 1, BMODE_KN = 2, BMODE_NK = 3, BMODE_IM2COL_T = 4, BMODE_CONVT = 5,
        BMODE_CONV_K3 = 6, BMODE_CONV_K7 = 7 };  // 3x3 / 7x7, dilation 1: (ci,kh,kw) by constant division, no tables
-enum { DMODE_NCHW = 0, DMODE_DENSE = 1, DMODE_NCHW_UP2 = 2 };
+enum { DMODE_NCHW = 0, DMODE_DENSE = 1, DMODE_NCHW_UP2 = 2, DMODE_NCHW_UP2X4 = 3 };
 
 constexpr int BK = 16;
 
@@ -55,6 +55,13 @@ __device__ __forceinline__ void epilogue_store(const ivln_gemm_desc& p, int m, i
         int pp = n - img * p.HoWo;
         int ho = pp / p.Wout, wo = pp - ho * p.Wout;
         addr = (((int64_t)img * p.Ctot + m) * (2 * p.Hout) + 2 * ho + (int)p.sDm) * (2 * p.Wout) + 2 * wo + (int)p.sDn;
+    } else if (p.dmode == DMODE_NCHW_UP2X4) {  // four output-parity classes stacked along M
+        const int cq = p.M >> 2, cls = m / cq;
+        me = m - cls * cq;
+        int img = n / p.HoWo;
+        int pp = n - img * p.HoWo;
+        int ho = pp / p.Wout, wo = pp - ho * p.Wout;
+        addr = (((int64_t)img * p.Ctot + me) * (2 * p.Hout) + 2 * ho + (cls >> 1)) * (2 * p.Wout) + 2 * wo + (cls & 1);
     } else {
         addr = (int64_t)m * p.sDm + (int64_t)n * p.sDn;
     }

@@ -41,7 +41,7 @@ class GemmDesc(C.Structure):
 
 A_MK, A_KM, A_NCHW_P = 0, 1, 2
 B_CONV, B_CONV1X1, B_KN, B_NK, B_IM2COL_T, B_CONVT, B_CONV_K3, B_CONV_K7 = 0, 1, 2, 3, 4, 5, 6, 7
-D_NCHW, D_DENSE, D_NCHW_UP2 = 0, 1, 2
+D_NCHW, D_DENSE, D_NCHW_UP2, D_NCHW_UP2X4 = 0, 1, 2, 3
 
 _sigs_done = False
 
@@ -326,25 +326,42 @@ def convt_s2_classes(w_t, pad):
     return out
 
 
-def conv_transpose2d_s2(x, classes, scale=None, shift=None, residual=None, relu=False, out=None):
-    """nn.ConvTranspose2d(stride=2) whose output is exactly (2H, 2W) (k=3,p=1,op=1 / k=2,p=0): one implicit
-    GEMM per output-parity class from convt_s2_classes, each writing its interleaved quarter of the
-    NCHW destination with the fused epilogue (rednet.py:210-216,262-279 upsampling blocks)."""
+def convt_s2_stack(classes):
+    """The four parity classes of convt_s2_classes as ONE weight (4*Cout, Cin, t, t), rows cls*Cout + co with
+    cls = 2a + b; classes with fewer taps are zero-padded to the common (t x t) window (k=3: 16 instead of 9 tap
+    products per input pixel, bought back by one launch that reads the input once and writes whole output rows)."""
+    t = max(max(w.shape[2], w.shape[3]) for _, _, w in classes)
+    Cout, Cin = classes[0][2].shape[:2]
+    W = torch.zeros((4, Cout, Cin, t, t), dtype=torch.float32, device=classes[0][2].device)
+    for a, b, w in classes:
+        W[2 * a + b, :, :, :w.shape[2], :w.shape[3]] = w
+    return W.view(4 * Cout, Cin, t, t).contiguous()
+
+
+STACK_CONVT = os.environ.get("IVLN_CONVT_STACK", "1") != "0"
+
+
+def conv_transpose2d_s2(x, classes, scale=None, shift=None, residual=None, relu=False, out=None, stacked=None):
+    """nn.ConvTranspose2d(stride=2) whose output is exactly (2H, 2W) (k=3,p=1,op=1 / k=2,p=0) through its four
+    output-parity classes (convt_s2_classes) with the fused epilogue (rednet.py:210-216,262-279 upsampling blocks):
+    ONE implicit GEMM over the stacked classes (`stacked` = convt_s2_stack(classes), D_NCHW_UP2X4), or one per class."""
     N, Cin, H, W = x.shape
     Cout = classes[0][2].shape[0]
     if out is None:
         out = torch.empty((N, Cout, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
     ws = splitk_ws(x.device)
-    for a, b, w in classes:
+    todo = [(0, 0, stacked)] if (stacked is not None and STACK_CONVT) else classes
+    for a, b, w in todo:
         ta, tb = w.shape[2], w.shape[3]
         d = GemmDesc()
         d.A, d.B, d.D = dptr(w), dptr(x), dptr(out)
-        d.M, d.N, d.K = Cout, N * H * W, Cin * ta * tb
-        d.amode, d.dmode = A_MK, D_NCHW_UP2
+        d.M, d.N, d.K = w.shape[0], N * H * W, Cin * ta * tb
+        d.amode, d.dmode = A_MK, (D_NCHW_UP2X4 if w.shape[0] != Cout else D_NCHW_UP2)
         d.lda = d.K
         d.Cin, d.Hin, d.Win, d.Hout, d.Wout = Cin, H, W, H, W
         d.stride, d.pad, d.dil = 1, 0, 1
         d.HoWo = H * W
+        d.Ctot = Cout
         d.sDm, d.sDn = a, b
         if ta == 1 and tb == 1:
             d.bmode = B_CONV1X1
@@ -497,6 +514,10 @@ def conv_gn(x, w, gn, stride=1, pad=0, relu=False, residual=None, ds=None, out=N
 # depth ResNet as a chain of GroupNorm+next-conv launches (csrc/gn_conv.hip); IVLN_GN_CONV=0 selects the deferred
 # conv + GroupNorm pairs
 CHAIN_GN_CONV = os.environ.get("IVLN_GN_CONV", "1") != "0"
+# The chain trades launches for slab bytes (16 partial slabs per conv), which pays while the step is latency-bound:
+# measured 4 envs 5.1 K vs 4.0 K env-steps/s, 8 envs 7.5 K vs 6.9 K, but 16 envs 9.5 K vs 10.1 K and 32 envs 11.1 K vs
+# 15.2 K - beyond 8 images per GPU the conv + GroupNorm pairs run.
+CHAIN_MAX_IMAGES = int(os.environ.get("IVLN_GN_CONV_MAX_IMAGES", "8"))
 # first bottleneck (0..16) that runs in the chain; earlier ones (large feature maps: 16 partial slabs of a 32x32 map
 # are more traffic than the launches they save) stay conv + GroupNorm pairs.  0 = the whole backbone incl. the stem;
 # 3 = from layer2 on (measured best at 4 envs: 0.790 ms/step vs 0.820 from the stem and 0.996 without the chain).

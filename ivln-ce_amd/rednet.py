@@ -55,7 +55,8 @@ class _Folded:
         if k not in self.c:
             ok = convt.stride == (2, 2) and convt.kernel_size[0] == convt.kernel_size[1] and \
                 2 - 2 * convt.padding[0] + convt.kernel_size[0] - 2 + convt.output_padding[0] == 2
-            self.c[k] = ops.convt_s2_classes(convt.weight.detach(), convt.padding[0]) if ok else None
+            cls = ops.convt_s2_classes(convt.weight.detach(), convt.padding[0]) if ok else None
+            self.c[k] = None if cls is None else (cls, ops.convt_s2_stack(cls))
         return self.c[k]
 
     def wt(self, convt: nn.ConvTranspose2d):
@@ -70,7 +71,7 @@ def _convt(x, convt: nn.ConvTranspose2d, f: _Folded, **epi):
     transposed-gather operand mode."""
     cls = f.classes(convt)
     if cls is not None:
-        return ops.conv_transpose2d_s2(x, cls, **epi)
+        return ops.conv_transpose2d_s2(x, cls[0], stacked=cls[1], **epi)
     return ops.conv_transpose2d(x, f.wt(convt), convt.stride[0], convt.padding[0], convt.output_padding[0], **epi)
 
 

@@ -197,7 +197,7 @@ int ivln_gemm_f32(const ivln_gemm_desc *desc, void *stream) {
     if (d.bmode == IVLN_B_IM2COL_T || d.bmode == IVLN_B_CONVT || d.defer_epilogue) return IVLN_E_UNSUPPORTED;
     if (d.HoWo <= 0) d.HoWo = 1;
     if (d.dil <= 0) d.dil = 1;
-    if (d.Ctot <= 0) d.Ctot = d.M;
+    if (d.Ctot <= 0) d.Ctot = d.dmode == IVLN_D_NCHW_UP2X4 ? d.M / 4 : d.M;
     if (d.in_img_stride <= 0) d.in_img_stride = (int64_t)d.Cin * d.Hin * d.Win;
     if (d.grp_imgs > 0 && d.a_grp_stride <= 0) d.a_grp_stride = (int64_t)d.M * d.lda;
     for (int n = 0; n < d.N; ++n) {
@@ -212,8 +212,11 @@ int ivln_gemm_f32(const ivln_gemm_desc *desc, void *stream) {
             else if (d.dmode == IVLN_D_NCHW_UP2) {
                 int ho = pp / d.Wout, wo = pp - ho * d.Wout;
                 addr = (((int64_t)img * d.Ctot + m) * (2 * d.Hout) + 2 * ho + (int)d.sDm) * (2 * d.Wout) + 2 * wo + (int)d.sDn;
+            } else if (d.dmode == IVLN_D_NCHW_UP2X4) {
+                int cq = d.M / 4, cls = m / cq, ho = pp / d.Wout, wo = pp - ho * d.Wout;
+                addr = (((int64_t)img * d.Ctot + (m - cls * cq)) * (2 * d.Hout) + 2 * ho + (cls >> 1)) * (2 * d.Wout) + 2 * wo + (cls & 1);
             } else addr = (int64_t)m * d.sDm + (int64_t)n * d.sDn;
-            int me = (d.dmode == IVLN_D_NCHW && d.grp_imgs > 0) ? grp * d.M + m : m;
+            int me = (d.dmode == IVLN_D_NCHW && d.grp_imgs > 0) ? grp * d.M + m : (d.dmode == IVLN_D_NCHW_UP2X4 ? m % (d.M / 4) : m);
             float v = acc;
             if (d.scale) v = fmaf(v, d.scale[me], d.shift[me]);
             else if (d.shift) v += d.shift[me];

@@ -480,6 +480,12 @@ def test_conv_transpose2d_stride2_parity_classes(N, Cin, H, W, Cout, k, p, op):
     assert cls is not None and len(cls) == 4
     got = ops.conv_transpose2d_s2(x.to(DEV), cls, scale=sc.to(DEV), shift=sh.to(DEV), residual=res.to(DEV), relu=True)
     _close(got, F.relu(ref0 * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) + res), 3e-5)
+    # the same four classes stacked along M: ONE launch (D_NCHW_UP2X4), zero-padded taps for k=3
+    stacked = ops.convt_s2_stack(cls)
+    assert stacked.shape[0] == 4 * Cout
+    got1 = ops.conv_transpose2d_s2(x.to(DEV), cls, scale=sc.to(DEV), shift=sh.to(DEV), residual=res.to(DEV), relu=True,
+                                   stacked=stacked)
+    _close(got1, F.relu(ref0 * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) + res), 3e-5)
     # k=3, p=0 needs a negative input offset for the even rows: not decomposed this way
     assert ops.convt_s2_classes(torch.randn(4, 4, 3, 3, device=DEV), 0) is None
 
