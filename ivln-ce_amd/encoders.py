@@ -272,7 +272,9 @@ class _ResNet50GN(nn.Module):
         if first == 0:
             r = ops.gn_conv(y, gn, relu=True, pool=True, **feeds(blocks[0]))
         else:
-            act = ops.pool2d(ops.groupnorm(y, gn.weight, gn.bias, gn.num_groups, gn.eps, relu=True), 3, 2, 1, "max")
+            r0 = ops.gn_conv(y, gn, relu=True, pool=True, want_act=True)  # stem GroupNorm + ReLU + MaxPool in one launch
+            act = r0[0] if r0 is not None else \
+                ops.pool2d(ops.groupnorm(y, gn.weight, gn.bias, gn.num_groups, gn.eps, relu=True), 3, 2, 1, "max")
             for blk in blocks[:first - 1]:
                 act = blk.forward_hip(act)
             # the last pairwise block hands over: its final GroupNorm is the chain's first launch
