@@ -28,6 +28,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   run u_$n --kernel-trace --pmc $c -d $O/u_$n -- python3 bench.py --only-update --steps 5;                    pmc u_$n update_pmc_$n.csv
 done
 run mfma --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -d $O/u_mfma -- python3 bench.py --only-update --steps 5; pmc u_mfma update_pmc_mfma_util.csv
+run pmfma --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -d $O/p_mfma -- python3 bench.py --pred-semantics --pred-envs 8 --steps 10 --warmup 2 $COMMON --no-graph; pmc p_mfma predsem_B8_pmc_mfma_util.csv
 find $O -name "*.db" -delete
 # steps traced per rollout pass = warm-up 5 + timed 20 + instrumented roofline passes 20 + 20 (mapper); pred-sem: 2 + 10 + 6
 python tools/pmc_traffic.py $O/rollout_pmc_fetch_size.csv $O/rollout_pmc_write_size.csv 65 $O/rollout_pmc_traffic.json "--envs 4 --steps 20 --warmup 5"
