@@ -296,6 +296,12 @@ int ivln_embed_lengths(const int64_t* tokens, const float* table, int B, int L, 
 int ivln_lstm_bidir_fwd_f32(const float* gx_f, const float* gx_r, const float* whh_f, const float* whh_r,
                             const float* bhh_f, const float* bhh_r, const int* lengths, int B, int L, int H,
                             float* out, float* save_gates, float* save_c, void* stream);
+/* The two consumers of an encoder's feature map in the MapCMA head in ONE launch (models/map_cma_policy.py:156-171,
+ * 180-185, 276-296): feat (rows, C, P) contiguous ->  kv (rows, Ckv, P) = nn.Conv1d(C, Ckv, 1)  and
+ * lin[r*ld_lin + o] = act(nn.Linear(C*P, O) of the flattened row).  rows <= 8 and rows*C*P*4 B <= 150 KB of LDS,
+ * else IVLN_E_UNSUPPORTED (the caller runs ivln_gemm_f32 + ivln_linear_skinny_f32). */
+int ivln_kv_linear_f32(const float* feat, int rows, int C, int P, const float* w_kv, const float* b_kv, int Ckv, float* kv,
+                       const float* w_lin, const float* b_lin, int O, int relu, float* lin, int64_t ld_lin, void* stream);
 /* nn.Linear for few rows (rollout batch): y[r][o] = act(W[o].x[r] + b[o]). */
 int ivln_linear_skinny_f32(const float* x, int64_t ldx, const float* W, const float* bias, float* y,
                            int64_t ldy, int rows, int K, int O, int relu, void* stream);

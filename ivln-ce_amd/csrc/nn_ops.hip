@@ -670,6 +670,82 @@ __global__ __launch_bounds__(256) void k_linear_skinny(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------
+// The two consumers of an encoder's (rows, C, P) feature map in the MapCMA head in ONE launch
+// (models/map_cma_policy.py:276-296): the k/v projection nn.Conv1d(C, Ckv, 1) over the P positions and
+// nn.Flatten -> nn.Linear(C*P, O) -> ReLU.  Every block stages the feature map (<= 8 rows) once in LDS; the first
+// kv_blocks blocks compute 16 k/v channels each (a wave owns 4 channels: lane = (row, position), one LDS read feeds
+// four FMAs, weights are wave-uniform), the rest 4 linear outputs each (a wave per output, K split over the lanes).
+// ------------------------------------------------------------------------------------------
+constexpr int KVL_CO = 4, KVL_ROWS = 8;
+
+__global__ __launch_bounds__(256) void k_kv_linear(const float* __restrict__ feat, int rows, int C, int P,
+                                                   const float* __restrict__ Wkv, const float* __restrict__ bkv, int Ckv,
+                                                   float* __restrict__ kv, const float* __restrict__ Wl,
+                                                   const float* __restrict__ bl, int O, int relu, float* __restrict__ lin,
+                                                   int64_t ldl, int kv_blocks) {
+    extern __shared__ __attribute__((aligned(16))) float kvl_fs[];
+    const int CP = C * P, st = CP + 16;  // +16 words: the rows of a (row, position) wave land on different banks
+    for (int i = threadIdx.x * 4; i < rows * CP; i += 1024) {
+        const int r = i / CP, k = i - r * CP;
+        *reinterpret_cast<float4*>(&kvl_fs[r * st + k]) = *reinterpret_cast<const float4*>(&feat[i]);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if ((int)blockIdx.x < kv_blocks) {
+        const int co0 = (blockIdx.x * 4 + wave) * KVL_CO;
+        if (co0 >= Ckv) return;
+        const int nco = min(KVL_CO, Ckv - co0);
+        for (int q = lane; q < rows * P; q += 64) {
+            const int r = q / P, px = q - r * P;
+            const float* f = kvl_fs + r * st + px;
+            float acc[KVL_CO];
+#pragma unroll
+            for (int j = 0; j < KVL_CO; ++j) acc[j] = (bkv && j < nco) ? bkv[co0 + j] : 0.f;
+#pragma unroll 8
+            for (int c = 0; c < C; ++c) {
+                const float x = f[c * P];
+#pragma unroll
+                for (int j = 0; j < KVL_CO; ++j) acc[j] = fmaf(Wkv[(int64_t)(co0 + min(j, nco - 1)) * C + c], x, acc[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < KVL_CO; ++j)
+                if (j < nco) kv[((int64_t)r * Ckv + co0 + j) * P + px] = acc[j];
+        }
+    } else {
+        const int o = ((int)blockIdx.x - kv_blocks) * 4 + wave;
+        if (o >= O) return;
+        float acc[KVL_ROWS];
+#pragma unroll
+        for (int r = 0; r < KVL_ROWS; ++r) acc[r] = 0.f;
+        const float* wr = Wl + (int64_t)o * CP;
+        for (int k = lane * 4; k < CP; k += 256) {
+            const float4 wv = *reinterpret_cast<const float4*>(wr + k);
+#pragma unroll
+            for (int r = 0; r < KVL_ROWS; ++r) {
+                if (r < rows) {
+                    const float4 xv = *reinterpret_cast<const float4*>(&kvl_fs[r * st + k]);
+                    acc[r] = fmaf(wv.x, xv.x, acc[r]);
+                    acc[r] = fmaf(wv.y, xv.y, acc[r]);
+                    acc[r] = fmaf(wv.z, xv.z, acc[r]);
+                    acc[r] = fmaf(wv.w, xv.w, acc[r]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < KVL_ROWS; ++r) {
+            if (r < rows) {
+                float v = wave_sum(acc[r]);
+                if (lane == 0) {
+                    if (bl) v += bl[o];
+                    if (relu) v = fmaxf(v, 0.f);
+                    lin[(int64_t)r * ldl + o] = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Masked GRU step (habitat-lab RNNStateEncoder single_forward / one step of seq_forward wrapping
 // nn.GRU; call sites models/map_cma_policy.py:314-318,346-353).  One block per hidden unit j; the six
 // weight rows W_ih[{r,z,n}][j], W_hh[{r,z,n}][j] are dotted with 8 (or 4) rows at a time:
@@ -1254,6 +1330,24 @@ int ivln_lstm_bidir_fwd_f32(const float* gx_f, const float* gx_r, const float* w
     if (H != 128) return IVLN_E_UNSUPPORTED;
     hipLaunchKernelGGL((k_lstm_bidir<128>), dim3(B, 2), dim3(512), 0, (hipStream_t)stream, gx_f, gx_r, whh_f, whh_r,
                        bhh_f, bhh_r, lengths, L, out, save_gates, save_c);
+    return LAUNCH_OK();
+}
+
+int ivln_kv_linear_f32(const float* feat, int rows, int C, int P, const float* w_kv, const float* b_kv, int Ckv, float* kv,
+                       const float* w_lin, const float* b_lin, int O, int relu, float* lin, int64_t ld_lin, void* stream) {
+    if (!feat || !w_kv || !kv || !w_lin || !lin || rows <= 0 || C <= 0 || P <= 0 || Ckv <= 0 || O <= 0) return IVLN_E_INVALID;
+    if (rows > KVL_ROWS || ((C * P) & 3)) return IVLN_E_UNSUPPORTED;
+    const size_t bytes = sizeof(float) * (size_t)rows * (C * P + 16);
+    if (bytes > 150 * 1024) return IVLN_E_UNSUPPORTED;
+    static bool raised = false;
+    if (!raised) {
+        if (hipFuncSetAttribute((const void*)k_kv_linear, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+            return IVLN_E_HIP;
+        raised = true;
+    }
+    const int kv_blocks = (Ckv + 4 * KVL_CO - 1) / (4 * KVL_CO), lin_blocks = (O + 3) / 4;
+    hipLaunchKernelGGL(k_kv_linear, dim3(kv_blocks + lin_blocks), dim3(256), bytes, (hipStream_t)stream, feat, rows, C, P, w_kv,
+                       b_kv, Ckv, kv, w_lin, b_lin, O, relu, lin, ld_lin, kv_blocks);
     return LAUNCH_OK();
 }
 

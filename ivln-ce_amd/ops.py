@@ -411,6 +411,31 @@ def linear(x, w, bias=None, relu=False, out=None):
     return out
 
 
+FUSE_KV_LINEAR = os.environ.get("IVLN_KV_LINEAR", "1") != "0"
+
+
+def kv_linear(feat, w_kv, b_kv, w_lin, b_lin, lin_out, relu=True):
+    """kv = Conv1d(C, Ckv, 1)(feat.view(rows, C, P)) and lin_out[:] = act(Linear(C*P, O)(feat.flatten(1))) in ONE launch
+    (csrc/nn_ops.hip k_kv_linear) for rollout batches (rows <= 8).  Returns kv (rows, Ckv, 1, P) or None when the shape is
+    outside the kernel's envelope."""
+    if not FUSE_KV_LINEAR:
+        return None
+    rows, Cc = feat.shape[0], feat.shape[1]
+    P = feat.numel() // (rows * Cc)
+    Ckv, O = w_kv.shape[0], w_lin.shape[0]
+    if rows > 8 or not feat.is_contiguous():
+        return None
+    kv = torch.empty((rows, Ckv, 1, P), dtype=torch.float32, device=feat.device)
+    L = _L()
+    L.ivln_kv_linear_f32.argtypes = [vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, i32, i32, vp, i64, vp]
+    code = L.ivln_kv_linear_f32(_p(feat), rows, Cc, P, dptr(w_kv), _p(b_kv), Ckv, _p(kv), dptr(w_lin), _p(b_lin), O,
+                                int(bool(relu)), _p(lin_out), lin_out.stride(0), stream_ptr())
+    if code == IVLN_E_UNSUPPORTED:
+        return None
+    check(code, "ivln_kv_linear_f32")
+    return kv
+
+
 def groupnorm(x, gamma, beta, groups, eps=1e-5, relu=False, residual=None, out=None, y_img_stride=0,
               r_img_stride=0, x2=None, gamma2=None, beta2=None):
     """x: NCHW tensor or a `Deferred` conv output (slab reduction fused).  `out` may be a channel slice

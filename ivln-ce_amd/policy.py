@@ -256,9 +256,12 @@ class MapCMANet(Net):
             if mc.ablate_map:
                 m = torch.zeros_like(m)
             r_, Cm_, P_ = m.shape[0], m.shape[1], m.shape[2] * m.shape[3]
-            kv = ops.conv2d(m.view(r_, Cm_, 1, P_), self.map_kv.weight.view(-1, Cm_, 1, 1), shift=self.map_kv.bias,
-                            splitk=False)
-            ops.linear(m.view(r_, -1), ml.weight, ml.bias, relu=True, out=state_in[:, d_out:d_out + m_out])
+            # k/v projection + map_linear: one launch for rollout batches, else the MFMA GEMM + the skinny linear
+            kv = ops.kv_linear(m, self.map_kv.weight, self.map_kv.bias, ml.weight, ml.bias, state_in[:, d_out:d_out + m_out])
+            if kv is None:
+                kv = ops.conv2d(m.view(r_, Cm_, 1, P_), self.map_kv.weight.view(-1, Cm_, 1, 1), shift=self.map_kv.bias,
+                                splitk=False)
+                ops.linear(m.view(r_, -1), ml.weight, ml.bias, relu=True, out=state_in[:, d_out:d_out + m_out])
             return m, kv
 
         def _dep_branch():
@@ -266,9 +269,11 @@ class MapCMANet(Net):
             if mc.ablate_depth:
                 d = torch.zeros_like(d)
             r_, Cd_, P_ = d.shape[0], d.shape[1], d.shape[2] * d.shape[3]
-            kv = ops.conv2d(d.view(r_, Cd_, 1, P_), self.dep_kv.weight.view(-1, Cd_, 1, 1), shift=self.dep_kv.bias,
-                            splitk=False)
-            ops.linear(d.view(r_, -1), dl.weight, dl.bias, relu=True, out=state_in[:, :d_out])
+            kv = ops.kv_linear(d, self.dep_kv.weight, self.dep_kv.bias, dl.weight, dl.bias, state_in[:, :d_out])
+            if kv is None:
+                kv = ops.conv2d(d.view(r_, Cd_, 1, P_), self.dep_kv.weight.view(-1, Cd_, 1, 1), shift=self.dep_kv.bias,
+                                splitk=False)
+                ops.linear(d.view(r_, -1), dl.weight, dl.bias, relu=True, out=state_in[:, :d_out])
             return d, kv
 
         # The key/value projections depend only on their own encoder, so they run inside the branches.

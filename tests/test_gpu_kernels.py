@@ -716,3 +716,27 @@ def test_image_grouped_conv_matches_two_separate_convs(B, Cin, H, W, Cout, k, s,
                       + sh[gi * Cout:(gi + 1) * Cout].cpu().view(1, -1, 1, 1) + res[sl].cpu())
         _close(ref, tref, 2e-5)
         assert float((got[sl] - ref).abs().max()) < 2e-5, gi
+
+
+@pytest.mark.parametrize("rows,Cc,H,W,Ckv,O", [(4, 192, 4, 4, 384, 128), (8, 128, 4, 4, 384, 128), (1, 192, 4, 4, 384, 128),
+                                                (3, 20, 3, 4, 10, 7)])
+def test_kv_projection_and_flatten_linear_in_one_launch(rows, Cc, H, W, Ckv, O):
+    """ivln_kv_linear_f32: nn.Conv1d(C, Ckv, 1) over the positions + nn.Flatten -> nn.Linear -> ReLU of the same
+    feature map (the MapCMA head's two consumers of an encoder output) against torch CPU; written into a column
+    slice of a wider state buffer like the policy does."""
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(rows + Cc)
+    feat = torch.randn(rows, Cc, H, W, generator=g)
+    wkv, bkv = torch.randn(Ckv, Cc, 1, generator=g) / Cc ** 0.5, torch.randn(Ckv, generator=g)
+    wl, bl = torch.randn(O, Cc * H * W, generator=g) / (Cc * H * W) ** 0.5, torch.randn(O, generator=g)
+    ref_kv = F.conv1d(feat.view(rows, Cc, H * W), wkv, bkv)
+    ref_l = F.relu(F.linear(feat.flatten(1), wl, bl))
+    wide = torch.full((rows, O + 9), 5.0, device=DEV)
+    kv = ops.kv_linear(feat.to(DEV), wkv.to(DEV), bkv.to(DEV), wl.to(DEV), bl.to(DEV), wide[:, 4:4 + O])
+    assert kv is not None and tuple(kv.shape) == (rows, Ckv, 1, H * W)
+    _close(kv.view(rows, Ckv, H * W), ref_kv, 2e-5)
+    _close(wide[:, 4:4 + O], ref_l, 2e-5)
+    assert float((wide[:, :4] - 5.0).abs().max()) == 0.0 and float((wide[:, 4 + O:] - 5.0).abs().max()) == 0.0
+    assert ops.kv_linear(torch.randn(9, 8, 2, 2, device=DEV), wkv[:4, :8].contiguous().to(DEV), None, torch.randn(3, 32, device=DEV),
+                         None, torch.empty(9, 3, device=DEV)) is None  # more than 8 rows: the caller's GEMM path
