@@ -1011,7 +1011,7 @@ def colsum(x, out=None, accumulate=False):
     rows, cols = x.shape
     if out is None:
         out = torch.empty((cols,), dtype=torch.float32, device=x.device)
-    key = str(x.device)
+    key = (str(x.device), torch.cuda.current_stream().cuda_stream)  # per stream: the training pass runs two at once
     ws = _colsum_ws.get(key)
     if ws is None or ws.numel() < 128 * cols:
         ws = torch.empty(max(128 * cols, 1 << 18), dtype=torch.float32, device=x.device)
