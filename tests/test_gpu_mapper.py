@@ -246,3 +246,54 @@ def test_known_mapper_plugins_match_reference_golden(plugin, sub, tmp_path, monk
         assert np.array_equal(out["occupancy_map"].cpu().numpy(), g[f"occ_{t}"]), f"occupancy step {t}"
         assert np.array_equal(out["semantic_map"].cpu().numpy(), g[f"sem_{t}"]), f"semantic step {t}"
         assert n == int(g[f"world_n_{t}"])
+
+
+def _rand_step(mapper, B, H, W, seed, spread=1.0):
+    g = torch.Generator().manual_seed(seed)
+    dev = torch.device("cuda:0")
+    obs = {
+        "depth": torch.rand(B, H, W, 1, generator=g).to(dev),
+        "semantic12": torch.randint(0, 13, (B, H, W), generator=g, dtype=torch.int64).to(torch.uint8).to(dev),
+        "world_robot_pose": ((torch.rand(B, 3, generator=g) - 0.5) * spread).to(dev),
+        "world_robot_orientation": torch.zeros(B, 2, dtype=torch.float64).to(dev),
+        "not_done_masks": torch.ones(B, 1, dtype=torch.uint8).to(dev),
+        "env_name": ["s"] * B,
+    }
+    return mapper(obs)
+
+
+def test_keyspace_and_capacity_overflows_are_reported_not_silent():
+    """The keep-highest key table and the world cloud have fixed capacities (ivln_mapper_create); exceeding either
+    sets a sticky device flag that `check_status()` turns into IvlnError (IVLN_E_KEYSPACE / IVLN_E_CAPACITY) - the
+    trainers poll it at episode boundaries (`_check_mappers`), so a too-small table can never silently drop points."""
+    from ivln_ce_amd._lib import IvlnError
+
+    H = W = 64
+    ok = _mk(H, W, b_max=2)
+    _rand_step(ok, 2, H, W, 1)
+    assert ok.check_status() > 0  # default sizing: fine, returns the world cloud size
+    small_table = _mk(H, W, b_max=2)
+    small_table._table_cells = 64  # far fewer cells than the bounding box of one frame at 5 cm
+    _rand_step(small_table, 2, H, W, 1, spread=20.0)
+    with pytest.raises(IvlnError, match="key"):
+        small_table.check_status()
+    small_world = _mk(H, W, b_max=2)
+    small_world._world_capacity = 256  # a 64x64 frame keeps more points than that
+    _rand_step(small_world, 2, H, W, 2)
+    _rand_step(small_world, 2, H, W, 3)
+    with pytest.raises(IvlnError, match="capacity|world"):
+        small_world.check_status()
+
+
+def test_create_rejects_sizes_outside_the_abi():
+    import ctypes as C
+
+    from ivln_ce_amd._lib import lib
+
+    h = C.c_void_p()
+    L = lib()
+    L.ivln_mapper_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64,
+                                     C.c_int64, C.POINTER(C.c_void_p)]
+    assert L.ivln_mapper_create(65, 64, 64, 1.57, 6.4, 6.4, 0.1, 0, 0, C.byref(h)) != 0   # more than 64 envs per mapper
+    assert L.ivln_mapper_create(0, 64, 64, 1.57, 6.4, 6.4, 0.1, 0, 0, C.byref(h)) != 0
+    assert L.ivln_mapper_create(2, 64, 64, 1.57, 6.4, 6.4, 0.0, 0, 0, C.byref(h)) != 0    # zero resolution
