@@ -291,6 +291,12 @@ int ivln_map_features_f32(const uint8_t* occ, const uint8_t* sem, float* y, int 
  * lengths i32 (B). */
 int ivln_embed_lengths(const int64_t* tokens, const float* table, int B, int L, int E, int V, float* emb,
                        int* lengths, void* stream);
+/* Inference fold of the same front end with the bi-LSTM's input projections (instruction_encoder.py:70-94):
+ * table (V, 2G) = embedding . [W_ih ; W_ih_reverse]^T + [b_ih ; b_ih_reverse] (built by the caller with
+ * ivln_gemm_f32 whenever the weights change), row_nonzero u8 (V) = the embedding row has a non-zero element.
+ * tokens i64 (B,L) -> gx_f, gx_r (B*L, G) = the two halves of the token's table row, lengths i32 (B). */
+int ivln_embed_gates_f32(const int64_t* tokens, const float* table, const uint8_t* row_nonzero, int B, int L, int G, int V,
+                         float* gx_f, float* gx_r, int* lengths, void* stream);
 /* nn.LSTM(bidirectional) over packed sequences (instruction_encoder.py:84-94): gx_* = W_ih x + b_ih
  * for all (b,t) as (B*L, 4H); out (B, 2H, L), zero for t >= lengths[b].  H must be 128. */
 int ivln_lstm_bidir_fwd_f32(const float* gx_f, const float* gx_r, const float* whh_f, const float* whh_r,

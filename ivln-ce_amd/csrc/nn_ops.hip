@@ -484,6 +484,39 @@ __global__ __launch_bounds__(1024) void k_embed_lengths(const int64_t* __restric
     if (threadIdx.x == 0) lengths[b] = cnt;
 }
 
+// Inference fold of the instruction front end: the embedding lookup followed by the two W_ih projections of the
+// bi-LSTM is a lookup in table[v] = embedding[v] . [W_ih ; W_ih_reverse]^T + [b_ih ; b_ih_reverse] (V x 2G, built
+// once per weight version by the MFMA GEMM).  One block per sequence, a wave per token: the first G floats of the
+// token's row go to gx_f, the next G to gx_r; lengths counts the tokens whose EMBEDDING row has a non-zero element
+// (row_nonzero[v], the reference's `(instruction != 0).sum(2) != 0` quirk, instruction_encoder.py:70-78).
+__global__ __launch_bounds__(1024) void k_embed_gates(const int64_t* __restrict__ tokens, const float* __restrict__ table,
+                                                      const uint8_t* __restrict__ row_nonzero, int L, int G, int V,
+                                                      float* __restrict__ gx_f, float* __restrict__ gx_r,
+                                                      int* __restrict__ lengths) {
+    __shared__ int cnt;
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    int local = 0;
+    for (int t = wave; t < L; t += nw) {
+        int64_t tok = tokens[(int64_t)b * L + t];
+        if (tok < 0 || tok >= V) tok = 0;
+        const float4* row = reinterpret_cast<const float4*>(table + tok * 2 * G);
+        float4* of = reinterpret_cast<float4*>(gx_f + ((int64_t)b * L + t) * G);
+        float4* orv = reinterpret_cast<float4*>(gx_r + ((int64_t)b * L + t) * G);
+        const int q = G >> 2;
+        for (int e = lane; e < q; e += 64) {
+            of[e] = row[e];
+            orv[e] = row[q + e];
+        }
+        local += row_nonzero[tok] ? 1 : 0;
+    }
+    if (lane == 0) atomicAdd(&cnt, local);
+    __syncthreads();
+    if (threadIdx.x == 0) lengths[b] = cnt;
+}
+
 // ------------------------------------------------------------------------------------------
 // Bidirectional LSTM recurrence (nn.LSTM over a packed sequence, instruction_encoder.py:84-94).
 // grid (B, 2): one block per (sequence, direction); 4H = 512 threads, thread g owns gate row g of
@@ -1321,6 +1354,15 @@ int ivln_embed_lengths(const int64_t* tokens, const float* table, int B, int L, 
                        int* lengths, void* stream) {
     hipLaunchKernelGGL(k_embed_lengths, dim3(B), dim3(1024), 0, (hipStream_t)stream, tokens, table, L, E, V, emb,
                        lengths);
+    return LAUNCH_OK();
+}
+
+int ivln_embed_gates_f32(const int64_t* tokens, const float* table, const uint8_t* row_nonzero, int B, int L, int G, int V,
+                         float* gx_f, float* gx_r, int* lengths, void* stream) {
+    if (!tokens || !table || !row_nonzero || !gx_f || !gx_r || !lengths || B <= 0 || L <= 0 || G <= 0 || (G & 3) || V <= 0)
+        return IVLN_E_INVALID;
+    hipLaunchKernelGGL(k_embed_gates, dim3(B), dim3(1024), 0, (hipStream_t)stream, tokens, table, row_nonzero, L, G, V, gx_f,
+                       gx_r, lengths);
     return LAUNCH_OK();
 }
 

@@ -146,6 +146,24 @@ class InstructionEncoder(nn.Module):
         with gzip.open(self.config.embedding_file, "rt") as f:
             return torch.tensor(json.load(f))
 
+    def _gate_table(self):
+        """(table (V, 8H), row_nonzero u8 (V)) of ivln_embed_gates_f32, cached until a weight changes; None while a
+        stream capture is running and no valid table exists (the caller then runs the unfolded launches)."""
+        rnn, E = self.encoder_rnn, self.embedding_layer.weight
+        ps = (E, rnn.weight_ih_l0, rnn.weight_ih_l0_reverse, rnn.bias_ih_l0, rnn.bias_ih_l0_reverse)
+        key = (ops.WEIGHT_EPOCH,) + tuple(p._version for p in ps) + tuple(p.data_ptr() for p in ps)
+        c = self.__dict__.get("_gate_cache")
+        if c is None or c[0] != key:
+            if torch.cuda.is_current_stream_capturing():
+                return None
+            with torch.no_grad():
+                W = torch.cat([rnn.weight_ih_l0, rnn.weight_ih_l0_reverse]).contiguous()
+                b = torch.cat([rnn.bias_ih_l0, rnn.bias_ih_l0_reverse]).contiguous()
+                table = ops.linear_gemm(E.detach().contiguous(), W, b)
+                nz = (E.detach() != 0).any(dim=1).to(torch.uint8).contiguous()
+            c = self.__dict__["_gate_cache"] = (key, (table, nz))
+        return c[1]
+
     def forward(self, observations, save=None):
         """(B, L) tokens -> (B, 2H, L) channel-major outputs, zero for t >= length; also returns
         lengths (device int32).  The reference returns (B, 2H, Lmax); the extra columns here are
@@ -154,9 +172,14 @@ class InstructionEncoder(nn.Module):
         B, L = tokens.shape
         rnn = self.encoder_rnn
         H = rnn.hidden_size
-        emb, lengths = ops.embed_lengths(tokens, self.embedding_layer.weight)
-        gx_f = ops.linear_gemm(emb, rnn.weight_ih_l0, rnn.bias_ih_l0)
-        gx_r = ops.linear_gemm(emb, rnn.weight_ih_l0_reverse, rnn.bias_ih_l0_reverse)
+        fold = self._gate_table() if (save is None and ops.FOLD_INSTRUCTION_GATES) else None
+        if fold is not None:  # inference: embedding lookup + both W_ih projections = one lookup in a folded table
+            emb = None
+            gx_f, gx_r, lengths = ops.embed_gates(tokens, *fold)
+        else:
+            emb, lengths = ops.embed_lengths(tokens, self.embedding_layer.weight)
+            gx_f = ops.linear_gemm(emb, rnn.weight_ih_l0, rnn.bias_ih_l0)
+            gx_r = ops.linear_gemm(emb, rnn.weight_ih_l0_reverse, rnn.bias_ih_l0_reverse)
         out, gates, cs = ops.lstm_bidir(
             gx_f, gx_r, rnn.weight_hh_l0, rnn.weight_hh_l0_reverse, rnn.bias_hh_l0, rnn.bias_hh_l0_reverse, lengths,
             B, L, H, save=save is not None,

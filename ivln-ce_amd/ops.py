@@ -412,6 +412,7 @@ def linear(x, w, bias=None, relu=False, out=None):
 
 
 FUSE_KV_LINEAR = os.environ.get("IVLN_KV_LINEAR", "1") != "0"
+FOLD_INSTRUCTION_GATES = os.environ.get("IVLN_FOLD_GATES", "1") != "0"  # inference: embedding + W_ih as one table lookup
 
 
 def kv_linear(feat, w_kv, b_kv, w_lin, b_lin, lin_out, relu=True):
@@ -753,6 +754,21 @@ def embed_lengths(tokens_i64, table):
     check(_L().ivln_embed_lengths(dptr(tokens_i64), dptr(table), B, L, E, V, dptr(emb), dptr(lengths), stream_ptr()),
           "ivln_embed_lengths")
     return emb, lengths
+
+
+def embed_gates(tokens_i64, table, row_nonzero):
+    """tokens (B, L) -> gx_f, gx_r (B*L, G) looked up in the folded (V, 2G) table, lengths i32 (B) (k_embed_gates)."""
+    B, L = tokens_i64.shape
+    V, G2 = table.shape
+    G = G2 // 2
+    gx_f = torch.empty((B * L, G), dtype=torch.float32, device=table.device)
+    gx_r = torch.empty((B * L, G), dtype=torch.float32, device=table.device)
+    lengths = torch.empty((B,), dtype=torch.int32, device=table.device)
+    Lb = _L()
+    Lb.ivln_embed_gates_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
+    check(Lb.ivln_embed_gates_f32(dptr(tokens_i64), dptr(table), dptr(row_nonzero), B, L, G, V, dptr(gx_f), dptr(gx_r),
+                                  dptr(lengths), stream_ptr()), "ivln_embed_gates_f32")
+    return gx_f, gx_r, lengths
 
 
 def lstm_bidir(gx_f, gx_r, whh_f, whh_r, bhh_f, bhh_r, lengths, B, L, H, save=False):

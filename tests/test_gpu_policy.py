@@ -245,3 +245,43 @@ def test_fused_head_matches_unfused_chain_and_oracle(B, lens):
         assert float((out[mode][0] - fr).abs().max()) < ATOL
         assert float((out[mode][1] - sr).abs().max()) < ATOL
         assert float((out[mode][2] - lr).abs().max()) < 1e-4
+
+
+def test_instruction_front_end_folded_into_a_table_lookup_is_the_same_encoder():
+    """Inference fold: embedding lookup + the two W_ih projections of the bi-LSTM = one lookup in
+    table[v] = E[v] . [W_ih ; W_ih_rev]^T + b (ivln_embed_gates_f32).  Same outputs and the same `lengths` as the
+    unfolded launches, including the reference's quirk that a token counts only if its EMBEDDING row has a non-zero
+    element (instruction_encoder.py:70-78) - rows 0 and 7 of the table are zeroed here - and the table is rebuilt
+    when a weight changes."""
+    from ivln_ce_amd import ops
+
+    pol = make_policy()
+    enc = pol.net.instruction_encoder
+    with torch.no_grad():
+        enc.embedding_layer.weight[0].zero_()
+        enc.embedding_layer.weight[7].zero_()
+    g = torch.Generator().manual_seed(4)
+    tokens = torch.randint(1, 2504, (5, 200), generator=g)
+    tokens[0, 60:] = 0
+    tokens[1, 10:] = 0
+    tokens[2, 3] = 7      # a zero-embedding token inside the sentence: not counted
+    tokens[3, :] = 0      # empty instruction
+    obs = {"instruction": tokens.to("cuda:0")}
+    old = ops.FOLD_INSTRUCTION_GATES
+    try:
+        ops.FOLD_INSTRUCTION_GATES = False
+        with torch.no_grad():
+            ref, ref_len = enc(obs)
+        ops.FOLD_INSTRUCTION_GATES = True
+        with torch.no_grad():
+            got, got_len = enc(obs)
+            assert enc.__dict__.get("_gate_cache") is not None
+            assert torch.equal(got_len, ref_len) and ref_len.tolist()[:4] == [60, 10, 199, 0]
+            assert float((got - ref).abs().max()) < 2e-6
+            enc.encoder_rnn.weight_ih_l0.mul_(1.5)  # a weight update invalidates the table
+            got2, _ = enc(obs)
+            ops.FOLD_INSTRUCTION_GATES = False
+            ref2, _ = enc(obs)
+        assert float((got2 - ref2).abs().max()) < 2e-6 and float((got2 - got).abs().max()) > 1e-3
+    finally:
+        ops.FOLD_INSTRUCTION_GATES = old
