@@ -43,6 +43,12 @@ int ivln_mapper_destroy(ivln_mapper* m);
 /* Forget the world cloud (new process / new eval). */
 int ivln_mapper_reset(ivln_mapper* m, void* stream);
 
+/* Launch width of the step's kernels: the local-cloud kernels on `local_blocks` workgroups and the world-cloud kernels
+ * on `world_blocks` (0 = full width: one chunk of 1024 pixels per workgroup / 1024 workgroups).  Results do not depend
+ * on it.  A mapper that runs BESIDE a latency-bound kernel chain on another stream (the depth ResNet of the rollout
+ * step) should be narrow - e.g. 64 / 32: it then takes ~150 instead of ~60 us but leaves the chip to the chain. */
+int ivln_mapper_set_launch_width(ivln_mapper* m, int local_blocks, int world_blocks);
+
 /* core.py:6-37 (_transform3D with elevation + pi, mapper.py:132-138) and mapper.py:38-48
  * (rotate_around_y_matrix(-heading)): pose f32 (B,3), orientation f64 (B,2) [elev, heading] ->
  * T f32 (B,4,4), rot f32 (B,3,3).  fp64 sin/cos on device, rounded to fp32. */

@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <stdlib.h>
 #include <new>
 #include "../../include/ivln_hip.h"
 
@@ -189,13 +190,16 @@ __global__ __launch_bounds__(kThreads) void k_local_minmax(const Cam cm, uint8_t
                                                            int* __restrict__ bmmL) {
     const int64_t total = (int64_t)cm.B * cm.H * cm.W;
     int rmin = INT32_MAX, cmin = INT32_MAX, rmax = INT32_MIN, cmax = INT32_MIN;
+    const int64_t nchunks = (total + kThreads * kPPT - 1) / (kThreads * kPPT);
+    for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {  // (a narrow grid walks several chunks)
 #pragma unroll
-    for (int i = 0; i < kPPT; ++i) {
-        const int64_t pix = ((int64_t)blockIdx.x * kPPT + i) * kThreads + threadIdx.x;
-        float w[3];
-        int b, r, c;
-        if (pix < total && unproject(cm, pix, w, b, r, c)) {
-            rmin = min(rmin, r); cmin = min(cmin, c); rmax = max(rmax, r); cmax = max(cmax, c);
+        for (int i = 0; i < kPPT; ++i) {
+            const int64_t pix = (chunk * kPPT + i) * kThreads + threadIdx.x;
+            float w[3];
+            int b, r, c;
+            if (pix < total && unproject(cm, pix, w, b, r, c)) {
+                rmin = min(rmin, r); cmin = min(cmin, c); rmax = max(rmax, r); cmax = max(cmax, c);
+            }
         }
     }
     block_minmax_store(rmin, cmin, rmax, cmax, bmmL + 4 * blockIdx.x);
@@ -229,20 +233,23 @@ __global__ __launch_bounds__(kThreads) void k_local_argmax(const Cam cm, Scalars
         }
     }
     const int64_t total = (int64_t)cm.B * cm.H * cm.W;
+    const int64_t nchunks = (total + kThreads * kPPT - 1) / (kThreads * kPPT);
+    for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
 #pragma unroll
-    for (int i = 0; i < kPPT; ++i) {
-        const int64_t pix = ((int64_t)blockIdx.x * kPPT + i) * kThreads + threadIdx.x;
-        float w[3];
-        int b, r, c;
-        if (pix < total && unproject(cm, pix, w, b, r, c)) {
-            const int64_t key = make_key(b, r, c, mm);
-            if (key < 0 || key >= table_cells) {
-                sc->err = IVLN_E_KEYSPACE;
-                continue;
+        for (int i = 0; i < kPPT; ++i) {
+            const int64_t pix = (chunk * kPPT + i) * kThreads + threadIdx.x;
+            float w[3];
+            int b, r, c;
+            if (pix < total && unproject(cm, pix, w, b, r, c)) {
+                const int64_t key = make_key(b, r, c, mm);
+                if (key < 0 || key >= table_cells) {
+                    sc->err = IVLN_E_KEYSPACE;
+                    continue;
+                }
+                const unsigned long long packed =
+                    ((unsigned long long)ord_f32(w[1]) << 32) | (0xFFFFFFFFull - (unsigned long long)pix);
+                atomicMax(&tab64[key], packed);
             }
-            const unsigned long long packed =
-                ((unsigned long long)ord_f32(w[1]) << 32) | (0xFFFFFFFFull - (unsigned long long)pix);
-            atomicMax(&tab64[key], packed);
         }
     }
 }
@@ -258,8 +265,10 @@ __global__ __launch_bounds__(kThreads) void k_local_select(const Cam cm, const u
     int64_t* rsrc = cur ? r1 : r0;
     const int64_t total = (int64_t)cm.B * cm.H * cm.W;
     int rmin = INT32_MAX, cmin = INT32_MAX, rmax = INT32_MIN, cmax = INT32_MIN;
+    const int64_t nchunks = (total + kThreads * kPPT - 1) / (kThreads * kPPT);
+    for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x)
     for (int i = 0; i < kPPT; ++i) {
-        const int64_t pix = ((int64_t)blockIdx.x * kPPT + i) * kThreads + threadIdx.x;
+        const int64_t pix = (chunk * kPPT + i) * kThreads + threadIdx.x;
         float w[3] = {0.f, 0.f, 0.f};
         int b = 0, r = 0, c = 0;
         int64_t key = 0;
@@ -558,6 +567,7 @@ struct ivln_mapper {
     int* bmmA;   // per-block partials of the points appended this step (k_local_select)
     int* bbox;   // per-block, per-env boxes of the surviving world (k_world_select), read by the NEXT step
     int n_blocks_local;
+    int local_blocks, world_blocks;  // launch width of the local- / world-cloud kernels (0: full width)
     int64_t known_rank;
 };
 
@@ -615,6 +625,7 @@ int ivln_mapper_create(int B_max, int H, int W, double vfov_rad, double height_m
     m->table_cells = table_cells > 0 ? table_cells : (int64_t)(16 << 20);
     if (m->table_cells > (1ll << 31)) m->table_cells = 1ll << 31;  // ranks = keys must fit 31 bits (k_world_max)
     m->known_rank = 0;
+    m->local_blocks = m->world_blocks = 0;
     // core.py:70-115: intrinsics in python doubles -> fp32; (u + 0.5 - cx) / fx in fp32
     double hfov = (double)W / (double)H * vfov_rad;
     float fx = (float)((double)W / (2.0 * tan(hfov / 2.0)));
@@ -690,7 +701,8 @@ int ivln_mapper_step(ivln_mapper* m, const float* depth, const uint8_t* labels, 
     if (!m || B <= 0 || B > m->B_max) return IVLN_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
     const int64_t npix = (int64_t)B * m->H * m->W;
-    const int lb = (int)((npix + kThreads * kPPT - 1) / (kThreads * kPPT));  // local-cloud blocks: 4 pixels / thread
+    int lb = (int)((npix + kThreads * kPPT - 1) / (kThreads * kPPT));  // local-cloud chunks: 4 pixels / thread
+    if (m->local_blocks > 0 && m->local_blocks < lb) lb = m->local_blocks;  // narrow launch: a block walks several chunks
     const int map_cells = B * m->rows * m->cols;
     const Cam cm{depth, T, pose, m->xs, m->ys, B, m->H, m->W, m->half_res};
     const unsigned cap = (unsigned)m->capacity;
@@ -699,15 +711,23 @@ int ivln_mapper_step(ivln_mapper* m, const float* depth, const uint8_t* labels, 
                        m->bbox, m->B_max, not_done);
     hipLaunchKernelGGL(k_local_select, dim3(lb), dim3(kThreads), 0, s, cm, labels, m->sc, m->tab64, m->table_cells,
                        m->wbuf[0], m->wbuf[1], m->rbuf[0], m->rbuf[1], cap, m->bmmA);
-    hipLaunchKernelGGL(k_world_max, dim3(kWorldBlocks), dim3(kThreads), 0, s, m->wbuf[0], m->wbuf[1], m->rbuf[0],
+    const int wb = (m->world_blocks > 0 && m->world_blocks < kWorldBlocks) ? m->world_blocks : kWorldBlocks;
+    hipLaunchKernelGGL(k_world_max, dim3(wb), dim3(kThreads), 0, s, m->wbuf[0], m->wbuf[1], m->rbuf[0],
                        m->rbuf[1], B, not_done, m->half_res, m->sc, m->tab64, m->table_cells, cap, m->bmmA, lb);
-    hipLaunchKernelGGL(k_world_select, dim3(kWorldBlocks), dim3(kThreads), 0, s, m->wbuf[0], m->wbuf[1], m->rbuf[0],
+    hipLaunchKernelGGL(k_world_select, dim3(wb), dim3(kThreads), 0, s, m->wbuf[0], m->wbuf[1], m->rbuf[0],
                        m->rbuf[1], B, not_done, m->half_res, m->sc, m->tab64, m->table_cells, cap, pose, rot, m->rows,
                        m->cols, m->res, m->half_h, m->half_w, occ_out, m->cell, m->bbox, m->B_max);
     const int fin_blocks = (map_cells + kThreads - 1) / kThreads;
     hipLaunchKernelGGL(k_finalize, dim3(fin_blocks), dim3(kThreads), 0, s, m->cell, sem_out, map_cells, m->sc, 1, cap,
-                       kWorldBlocks, B);
+                       wb, B);
     return hipGetLastError() == hipSuccess ? IVLN_OK : IVLN_E_HIP;
+}
+
+int ivln_mapper_set_launch_width(ivln_mapper* m, int local_blocks, int world_blocks) {
+    if (!m || local_blocks < 0 || world_blocks < 0) return IVLN_E_INVALID;
+    m->local_blocks = local_blocks;
+    m->world_blocks = world_blocks;
+    return IVLN_OK;
 }
 
 int ivln_mapper_known_begin(ivln_mapper* m, const uint8_t* not_done, int B, void* stream) {

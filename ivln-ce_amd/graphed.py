@@ -183,6 +183,15 @@ class GraphedRollout:
             run_A()
         main.wait_stream(s)
         torch.cuda.synchronize()
+        # A ground-truth-semantics mapper runs beside the depth-ResNet chain with time to spare (gB1 285 us, gA 580):
+        # launched narrow it takes ~150 instead of ~60 us but no longer crowds the chain off the CUs (0.767 -> 0.731
+        # ms per step at 4 envs).  With predicted semantics RedNet -> mapper IS the critical path: full width.
+        lw = os.environ.get("IVLN_MAPPER_WIDTH", "64,32")
+        for t in self.transforms:
+            mm = getattr(t, "mapping_module", None)
+            if mm is not None and hasattr(mm, "set_launch_width"):
+                narrow = getattr(mm, "semantics_module", None) is None and lw != "0"
+                mm.set_launch_width(*([int(v) for v in lw.split(",")] if narrow else [0, 0]))
         ops.settle_packed_weights()
         self.gA = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.gA, stream=self.sA):

@@ -132,6 +132,8 @@ class MappingModule:
                 "ivln_mapper_create",
             )
         self._h, self._hw = h, (H, W)
+        if getattr(self, "_width", (0, 0)) != (0, 0):
+            check(lib().ivln_mapper_set_launch_width(self._h, *self._width), "ivln_mapper_set_launch_width")
 
     def __del__(self):
         try:
@@ -225,6 +227,13 @@ class MappingModule:
         n = C.c_int64(0)
         code = lib().ivln_mapper_status(self._h, C.byref(n), stream_ptr())
         return code, n.value
+
+    def set_launch_width(self, local_blocks: int = 0, world_blocks: int = 0):
+        """Workgroups of the local- / world-cloud kernels (0 = full width).  Narrow when the mapper runs beside a
+        latency-bound chain on another stream (graphed.py, split replay); results do not depend on it."""
+        self._width = (int(local_blocks), int(world_blocks))
+        if self._h is not None:
+            check(lib().ivln_mapper_set_launch_width(self._h, *self._width), "ivln_mapper_set_launch_width")
 
     def check_status(self):
         code, n = self.status()

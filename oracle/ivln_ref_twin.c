@@ -76,6 +76,10 @@ int ivln_mapper_destroy(ivln_mapper *m) {
     return IVLN_OK;
 }
 
+int ivln_mapper_set_launch_width(ivln_mapper *m, int local_blocks, int world_blocks) {  /* a launch hint: nothing on the host */
+    return (!m || local_blocks < 0 || world_blocks < 0) ? IVLN_E_INVALID : IVLN_OK;
+}
+
 int ivln_mapper_reset(ivln_mapper *m, void *stream) {
     (void)stream;
     if (!m) return IVLN_E_INVALID;

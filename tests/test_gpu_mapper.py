@@ -67,15 +67,17 @@ def test_device_frames_match_reference():
         assert np.array_equal(rot.cpu().numpy().view(np.uint32), g[f"rot_{t}"].view(np.uint32))
 
 
-@pytest.mark.parametrize("B,steps,reset_every", [(4, 12, 0), (8, 8, 3)])
-def test_hip_mapper_matches_oracle_fullsize(B, steps, reset_every):
-    """BASELINE configs[1]/[2] sizes: 256x256 depth, B = 4 / 8 envs, random-walk poses."""
+@pytest.mark.parametrize("B,steps,reset_every,width", [(4, 12, 0, (0, 0)), (8, 8, 3, (0, 0)), (4, 8, 3, (64, 32)), (4, 6, 0, (3, 1))])
+def test_hip_mapper_matches_oracle_fullsize(B, steps, reset_every, width):
+    """BASELINE configs[1]/[2] sizes: 256x256 depth, B = 4 / 8 envs, random-walk poses; also with the narrow launch
+    widths the split replay uses beside the depth-ResNet chain (ivln_mapper_set_launch_width): same bits."""
     from ivln_ce_amd.synthetic import SyntheticRollout
     from oracle.mapper_ref import MapperRef
 
     dev = torch.device("cuda:0")
     roll = SyntheticRollout(B=B, seed=77 + B, reset_every=reset_every)
     m = _mk(256, 256, b_max=B)
+    m.set_launch_width(*width)
     ref = MapperRef(256, 256)
     for t in range(steps):
         obs = roll.step()
