@@ -379,7 +379,8 @@ class ResNetEncoder(nn.Module):
         assert Cd == 1, "depth-only encoder"
         x = ops.pool2d(depth.view(B, 1, H, W), 2, 2, 0, "avg")  # F.avg_pool2d(x, 2)
         c, gn = self.compression[0], self.compression[1]
-        y = self.backbone.forward_chain(x, (c.weight, 1, 1)) if (ops.CHAIN_GN_CONV and B <= ops.CHAIN_MAX_IMAGES) else None
+        chain = ops.CHAIN_GN_CONV and B <= ops.CHAIN_MAX_IMAGES and getattr(self, "latency_bound", True)
+        y = self.backbone.forward_chain(x, (c.weight, 1, 1)) if chain else None
         if y is None:
             x = self.backbone.forward_hip(x)
             y = ops.conv2d(x, c.weight, pad=1, defer=True)

@@ -42,6 +42,12 @@ def _policy_masks(batch):
 
 
 class GraphedRollout:
+    """mapper + `policy.act` of one env step as replayable hipGraphs (see the module docstring).  Side effect of the
+    split capture: it fixes how the pieces that run beside each other are launched - the gt-semantics mapper narrow
+    (`MappingModule.set_launch_width`), the policy's depth encoder as its launch-saving chain when it is the critical
+    path and as conv + GroupNorm pairs when RedNet is (`visual_encoder.latency_bound`); eager calls afterwards run the
+    same kernels, so replay and eager stay bit-identical."""
+
     def __init__(self, policy, obs_transforms, example_obs: Dict, deterministic: bool = True, streams: bool = True,
                  warmup: int = 2):
         self.policy = policy
@@ -173,6 +179,13 @@ class GraphedRollout:
                 net._rnn_out_buffer = None
                 self.policy._action_out_buffer = None
 
+        # With predicted semantics the depth encoder is NOT the critical path (RedNet is): its launch-saving chain of 16
+        # partial slabs per conv would only take HBM bandwidth from RedNet (6.84 vs 6.69 ms per step at 8 envs), so it
+        # runs the conv + GroupNorm pairs there.  (Decided before the warm-up: every lazily built cache of the path
+        # that will be captured has to exist before the capture.)
+        venc = getattr(getattr(net, "depth_encoder", None), "visual_encoder", None)
+        if venc is not None:
+            venc.latency_bound = not any(getattr(t, "predicted_semantics", False) for t in self.transforms)
         s = _stream(dev, "warmup")
         s.wait_stream(main)
         with torch.cuda.stream(s):  # warm-up: tables, workspaces (per stream), folded weights

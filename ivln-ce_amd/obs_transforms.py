@@ -126,6 +126,8 @@ class GTSemanticsIterativeMapper(Mapper):
 
 @baseline_registry.register_obs_transformer()
 class PredictedSemanticsIterativeMapper(Mapper):
+    predicted_semantics = True  # RedNet runs inside the transformer: it, not the policy's depth encoder, bounds the step
+
     def setup_mapping_module(self, observations):
         if self.mapping_module is None:
             self.mapping_module = create_predicted_semantics_iterative_mapper(
