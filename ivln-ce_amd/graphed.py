@@ -184,8 +184,10 @@ class GraphedRollout:
         # runs the conv + GroupNorm pairs there.  (Decided before the warm-up: every lazily built cache of the path
         # that will be captured has to exist before the capture.)
         venc = getattr(getattr(net, "depth_encoder", None), "visual_encoder", None)
+        predicted = any(getattr(t, "predicted_semantics", False) for t in self.transforms)
         if venc is not None:
-            venc.latency_bound = not any(getattr(t, "predicted_semantics", False) for t in self.transforms)
+            venc.latency_bound = not predicted
+        net._txt_with_dep = predicted  # ... and the instruction encoder leaves RedNet's stream for the side graph
         s = _stream(dev, "warmup")
         s.wait_stream(main)
         with torch.cuda.stream(s):  # warm-up: tables, workspaces (per stream), folded weights
@@ -210,11 +212,13 @@ class GraphedRollout:
         with torch.cuda.graph(self.gA, stream=self.sA):
             run_A()
         self._dep = net._stash_dep  # (depth features, k/v) live in gA's pool
+        self._txt = getattr(net, "_stash_txt", None)  # (predicted semantics: the instruction features too)
         # the previous action (read by the embedding in gB1) ping-pongs with the state: one gB1 per phase
         self.gB1, pool = [], None
         for src in (0, 1):
             g1 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1, pool=pool):
+                net._stash_txt = self._txt
                 batch = run_B1(src)
             pool = g1.pool()
             stash = net._stash

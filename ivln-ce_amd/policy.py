@@ -283,11 +283,14 @@ class MapCMANet(Net):
             # graphed.py, split mode: depth ResNet + its k/v projection + depth_linear as one graph on a side
             # stream (they depend on nothing but the new depth image); results land in the persistent buffers
             self._stash_dep = _dep_branch()
+            if getattr(self, "_txt_with_dep", False):
+                # predicted semantics: the main stream is RedNet's critical path, the instruction encoder moves here
+                self._stash_txt = _txt_branch(None)
             return None, None
         if stage == "pre":
             # ... while the instruction and map branches (and the previous-action embedding) run as a second
             # graph on the main stream
-            txt, lengths, tk = _txt_branch(None)
+            txt, lengths, tk = self._stash_txt if getattr(self, "_txt_with_dep", False) else _txt_branch(None)
             mp, mkv = _map_branch(None)
             ops.prev_action_embed(prev_actions, masks_u8, self.prev_action_embedding.weight,
                                   state_in[:, d_out + m_out:], x2[:, o_prev:])
