@@ -1,4 +1,5 @@
-"""Where the split-graph step spends its time: event timestamps at the end of each of the three graphs."""
+"""Where the split-graph step spends its time: event timestamps at the end of each of the three graphs.
+python tools/split_probe.py [pred [envs]]  (pred: BASELINE configs[2], RedNet labels, 8 envs)"""
 import os
 import sys
 
@@ -8,13 +9,14 @@ import torch  # noqa: E402
 
 from bench import gen_observations, make_policy  # noqa: E402
 from ivln_ce_amd.graphed import GraphedRollout  # noqa: E402
-from ivln_ce_amd.obs_transforms import GTSemanticsIterativeMapper  # noqa: E402
+from ivln_ce_amd.obs_transforms import GTSemanticsIterativeMapper, PredictedSemanticsIterativeMapper  # noqa: E402
 
-B = 4
+pred = len(sys.argv) > 1 and sys.argv[1] == "pred"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else (8 if pred else 4)
 dev = torch.device("cuda:0")
 cfg, policy = make_policy(dev)
-tr = GTSemanticsIterativeMapper.from_config(cfg)
-obs = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in o.items()} for o in gen_observations(B, 40, 1)]
+tr = (PredictedSemanticsIterativeMapper if pred else GTSemanticsIterativeMapper).from_config(cfg)
+obs = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in o.items()} for o in gen_observations(B, 40, 1, with_rgb=pred)]
 r = GraphedRollout(policy, [tr], obs[0], deterministic=True, streams="split")
 for i in range(20):
     r.step(obs[i % 40])
