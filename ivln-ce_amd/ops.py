@@ -546,8 +546,9 @@ CHAIN_GN_CONV = os.environ.get("IVLN_GN_CONV", "1") != "0"
 CHAIN_MAX_IMAGES = int(os.environ.get("IVLN_GN_CONV_MAX_IMAGES", "8"))
 # first bottleneck (0..16) that runs in the chain; earlier ones (large feature maps: 16 partial slabs of a 32x32 map
 # are more traffic than the launches they save) stay conv + GroupNorm pairs.  0 = the whole backbone incl. the stem;
-# 3 = from layer2 on (measured best at 4 envs: 0.790 ms/step vs 0.820 from the stem and 0.996 without the chain).
-CHAIN_FROM_BLOCK = int(os.environ.get("IVLN_GN_CONV_FROM", "3"))
+# 3 = from layer2 on (measured best at 4 envs: 0.790 ms/step vs 0.820 from the stem and 0.996 without the chain);
+# at 8 envs layer 2's slabs are twice as large and starting at layer 3 is better (1.046 vs 1.100 ms/step).
+CHAIN_FROM_BLOCK = int(os.environ.get("IVLN_GN_CONV_FROM", "-1"))  # -1: by batch size (3 up to 5 images, 7 = from layer 3 beyond)
 # first bottleneck whose GN2 -> conv3 -> GN3 tail -> next conv1 run as ONE launch (the block re-normalises the whole
 # 16-64 KB conv2 output of its image): 2 launches per bottleneck instead of 3.  Measured SLOWER (0.835 vs 0.805 ms per
 # step from layer 3 on, profiles/r02_gn_conv_ab.txt: the merged launch takes 20 us against 8.5 + 9.8), so 16 = never.
