@@ -43,3 +43,8 @@ print("envs", B)
 print("load only        host/step %.1f us   total/step %.1f us" % run(lambda i: r.load(obs[i % 40])))
 print("replay only      host/step %.1f us   total/step %.1f us" % run(replay_only))
 print("load + replay    host/step %.1f us   total/step %.1f us" % run(lambda i: r.step(obs[i % 40])))
+tr2 = GTSemanticsIterativeMapper.from_config(cfg)
+r2 = GraphedRollout(policy, [tr2], obs[0], deterministic=True, streams="split")
+for i in range(20):
+    r2.step(obs[i % 40])
+print("split replay (3 graphs, 2 streams): host/step %.1f us   total/step %.1f us" % run(lambda i: r2.step(obs[i % 40])))
