@@ -484,8 +484,9 @@ def main():
     cfg, policy = make_policy(dev)
     if args.only_update:
         uel, uinfo = bench_update(policy, dev, world, barrier, iters=max(5, min(K, 20)))
+        uel = max_over_ranks(uel)  # (a collective: every rank)
         if rank == 0:
-            print(json.dumps({"update_step": {"ms_per_update": round(1e3 * max_over_ranks(uel) / uinfo["iters"], 3),
+            print(json.dumps({"update_step": {"ms_per_update": round(1e3 * uel / uinfo["iters"], 3),
                                               "roofline": uinfo["roofline"]}}), flush=True)
         return
     mode = False if args.no_graph else (True if args.streams else (False if args.single_stream else "split"))
