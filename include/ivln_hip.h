@@ -251,6 +251,47 @@ typedef struct ivln_gn_conv_desc {
 int ivln_gn_conv_f32(const ivln_gn_conv_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Convolution with GroupNorm applied to its INPUT on load and the GroupNorm statistics of its OUTPUT emitted as
+ * partials (csrc/gn_conv.hip, k_nconv) - for the large feature maps of the depth ResNet's layer 1, where the
+ * 16-slab scheme of ivln_gn_conv_f32 costs more bytes than it saves launches.  One launch per conv layer:
+ *   in  = act( GN(x; stats, gamma, beta) [+ GN(x2; stats2, gamma2, beta2)] [+ residual] )      (stats == NULL: in = x)
+ *   ya  = conv_a(in)   (k = 1 | 3, stride 1, pad (k-1)/2),   yb = conv_b(in)   (1x1, optional)
+ * A workgroup owns a strip of `rows_per_block` output rows of one image with its halo, over ALL channels, so the
+ * outputs are complete (no slabs).  stats layout: [parts][N][groups][3] = (count, mean, M2) of one (image, group)
+ * per producing workgroup; the consumer merges them in part order (Chan), i.e. the variance is the two-pass one.
+ * act_out (N, C, H, W) optionally receives `in` (a later block's identity).  habitat-lab ResNetEncoder Bottleneck,
+ * models/encoders/resnet_encoders.py:31-43, 95.  IVLN_E_UNSUPPORTED: W > 32*k ... see gn_conv.hip (strip + weights
+ * + output tile must fit 152 KB of LDS, C and Cout multiples of 2 * groups). */
+typedef struct ivln_nconv_desc {
+    const float* x;        /* raw (pre-GroupNorm) input [C][N][H][W] - the one-slab layout of the deferred ivln_gemm_f32 /
+                              ivln_gn_conv_f32 outputs - or, when stats == NULL, the activated input (N, C, H, W) */
+    const float* stats;    /* [parts][N][groups][3] or NULL */
+    int parts;
+    const float* gamma;
+    const float* beta;
+    const float* x2;       /* second raw operand [C][N][H][W] with its own statistics, or NULL */
+    const float* stats2;
+    int parts2;
+    const float* gamma2;
+    const float* beta2;
+    const float* residual; /* (N, C, H, W) or NULL */
+    int N, C, H, W, groups;
+    float eps;
+    int relu;
+    float* act_out;        /* (N, C, H, W) or NULL */
+    const float* wa;       /* (Cout_a, C, ka, ka) */
+    int Cout_a, ka, groups_a;
+    float* ya;             /* raw output [Cout_a][N][H][W] */
+    float* stats_a;        /* [strips][N][groups_a][3], strips = ceil(H / rows_per_block) */
+    const float* wb;       /* (Cout_b, C, 1, 1) or NULL */
+    int Cout_b, groups_b;
+    float* yb;
+    float* stats_b;
+    int rows_per_block;    /* 0 = default (64 output pixels per workgroup) */
+} ivln_nconv_desc;
+int ivln_nconv_f32(const ivln_nconv_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Non-GEMM forward kernels (csrc/nn_ops.hip).  All tensors fp32 NCHW unless noted.
  * ------------------------------------------------------------------------------------------ */
 /* nn.GroupNorm (+ residual add) (+ ReLU): habitat-lab ddppo resnet Bottleneck / ResNetEncoder

@@ -241,7 +241,8 @@ template <int KSZ>
 __device__ __forceinline__ void partial_conv(const float* act, int cpg, int H, int W, const float* __restrict__ w, int C,
                                              int c0, int co_beg, int co_end, int stride, int pad, int Ho, int Wo,
                                              float* __restrict__ yslab, int64_t NHWo, int n, float* wl, int wl_floats,
-                                             bool prestaged, int zero_off, float* part) {
+                                             bool prestaged, int zero_off, float* part, int pad_h = -1) {
+    if (pad_h < 0) pad_h = pad;  // (k_nconv's strips carry their halo rows: vertical padding 0, horizontal as the conv's)
     constexpr int KK = KSZ * KSZ;
     const int HWo = Ho * Wo, HW = H * W;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
@@ -278,11 +279,24 @@ __device__ __forceinline__ void partial_conv(const float* act, int cpg, int H, i
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
             for (int t = 0; t < KK; ++t) {
-                const int ih = oh * stride - pad + t / KSZ, iw = ow * stride - pad + t % KSZ;
+                const int ih = oh * stride - pad_h + t / KSZ, iw = ow * stride - pad + t % KSZ;
                 const bool in = live && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
                 const float* ap = act + (in ? ih * W + iw + half * HW : zero_off);
                 const int cstr = in ? 2 * HW : 0;
-                for (int cp = cp0; cp < cp1; ++cp)
+                int cp = cp0;
+                for (; cp + 4 <= cp1; cp += 4) {  // four channel pairs at a time: eight LDS reads in flight, then four MFMAs
+                    float a[4], b[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        a[u] = wrow[2 * (cp + u) * KK + t];
+                        b[u] = ap[(cp + u) * cstr];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise sinks every read to its MFMA: one LDS latency per step)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                for (; cp < cp1; ++cp)
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[2 * cp * KK + t], ap[cp * cstr], acc, 0, 0, 0);
             }
             // acc[r] -> row (r & 3) + 8 * (r >> 2) + 4 * half, column l31
@@ -470,6 +484,257 @@ __global__ __launch_bounds__(GT) void k_gn_conv(const Desc D, const Geo G) {
     STAMP(5);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// k_nconv: convolution with GroupNorm applied to its input ON LOAD and the GroupNorm statistics of its output emitted as
+// per-workgroup partials (ivln_nconv_f32).  For the large maps of layer 1: a workgroup owns a strip of output rows of
+// one image (with its halo rows) over ALL input channels, so its outputs are complete - no slabs - and the launch
+// chain is still one launch per conv layer.  The statistics the consumer needs are the (count, mean, M2) partials its
+// producer left per (strip, image, group), merged in strip order with Chan's formula (a two-pass variance).
+// ------------------------------------------------------------------------------------------------------------------
+typedef ivln_nconv_desc NDesc;
+struct NGeo {
+    int RS, strips, Hs;      // output rows per workgroup, strips per image, staged input rows (RS + KSZ - 1)
+    int part_floats, wthr;   // partial-tile scratch of partial_conv; threads that stage the weights
+    int kbp_a, kbp_b;
+};
+constexpr int NC_E4 = 6;     // float4 of the strip per loader thread (registers)
+
+// sum over the 16 lanes of a DPP row, in every lane of the row
+__device__ __forceinline__ float row_sum16(float v) {
+#define IVLN_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
+    IVLN_DPP_ADD(0xB1);   // quad_perm [1,0,3,2]
+    IVLN_DPP_ADD(0x4E);   // quad_perm [2,3,0,1]
+    IVLN_DPP_ADD(0x141);  // row_half_mirror
+    IVLN_DPP_ADD(0x140);  // row_mirror
+#undef IVLN_DPP_ADD
+    return v;
+}
+
+// (count, mean, M2) partials of one (image, group) -> mean, rstd.  Two loops in part order, no division inside:
+// mean = sum(n_p mean_p) / n, M2 = sum(M2_p + n_p (mean_p - mean)^2) - Chan's merge written as the two-pass formula
+// it is equal to.  st: this image's [parts][groups][3] in LDS.
+__device__ __forceinline__ void merge_stats(const float* st, int parts, int groups, int g, float eps, float& mean, float& rstd) {
+    float cnt = 0.f, sm = 0.f;
+    for (int p = 0; p < parts; ++p) {
+        const float* q = st + (p * groups + g) * 3;
+        cnt += q[0];
+        sm = fmaf(q[0], q[1], sm);
+    }
+    const float m = sm / cnt;
+    float M2 = 0.f;
+    for (int p = 0; p < parts; ++p) {
+        const float* q = st + (p * groups + g) * 3;
+        const float d = q[1] - m;
+        M2 += fmaf(q[0] * d, d, q[2]);
+    }
+    mean = m;
+    rstd = rsqrtf(M2 / cnt + eps);
+}
+
+template <int KSZ>
+__global__ __launch_bounds__(GT) void k_nconv(const NDesc D, const NGeo G) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int PH = KSZ / 2;  // halo rows above / below, horizontal padding
+    const int C = D.C, W = D.W, HW = D.H * D.W, Cp = (C + 3) & ~3;
+    const int strip = blockIdx.x, n = blockIdx.y;
+    const int r0 = strip * G.RS, rows = min(G.RS, D.H - r0);
+    const int SW = G.Hs * W;     // floats of one channel of the staged strip
+    float* red = smem;           // 64 (zero word at ZW)
+    float* pst = red + 64;       // this image's statistics partials [parts][groups][3] of x, then of x2
+    const int pfl = D.stats ? ((D.parts * D.groups * 3 + 3) & ~3) : 0, pfl2 = D.x2 ? ((D.parts2 * D.groups * 3 + 3) & ~3) : 0;
+    float* gst = pst + pfl + pfl2;  // mean, rstd per group of x, then of x2
+    float* gab = gst + 4 * ((D.groups + 3) & ~3);  // gamma, beta, gamma2, beta2
+    float* tab = gab + 4 * Cp;   // scale, shift, scale2, shift2 per channel
+    float* in = tab + 4 * Cp;    // [C][Hs*W] transformed input strip
+    float* outa = in + ((C * SW + 3) & ~3);
+    float* outb = outa + ((D.Cout_a * G.RS * W + 3) & ~3);
+    float* part = outb + (D.wb ? ((D.Cout_b * G.RS * W + 3) & ~3) : 0);
+    float* wl = part + G.part_floats;
+    float* wl_b = wl + D.Cout_a * G.kbp_a;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nload = GT - G.wthr;
+
+    STAMP(0);
+    // ---- every global load up front: statistics partials, the raw strip (registers), weights, affine ----
+    if (tid == 0) red[ZW] = 0.f;
+    if (D.stats) {  // [parts][N][groups][3] -> this image's rows, all in flight at once
+        const int row = D.groups * 3;
+        const fdiv by_row(row);
+        for (int i = tid; i < D.parts * row; i += GT) {
+            const int pp = by_row(i);
+            pst[i] = D.stats[((int64_t)pp * D.N + n) * row + (i - pp * row)];
+        }
+        if (D.x2)
+            for (int i = tid; i < D.parts2 * row; i += GT) {
+                const int pp = by_row(i);
+                pst[pfl + i] = D.stats2[((int64_t)pp * D.N + n) * row + (i - pp * row)];
+            }
+    }
+    float4 xr[NC_E4], x2r[NC_E4], rr[NC_E4];
+    const int w4 = W >> 2, nv = C * G.Hs * w4;  // float4 of the strip
+    if (tid < nload) {
+        const fdiv by_w4(w4), by_hs(G.Hs);
+#pragma unroll
+        for (int e = 0; e < NC_E4; ++e) {
+            const int v = tid + e * nload;
+            xr[e] = x2r[e] = rr[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (v < nv) {
+                const int ch = by_w4(v), q = v - ch * w4, c = by_hs(ch), hs = ch - c * G.Hs;  // v = (c*Hs + hs)*w4 + q
+                const int row = r0 - PH + hs;
+                if ((unsigned)row < (unsigned)D.H) {
+                    // raw conv outputs are channel-major over the batch ([C][N][H][W], the slab layout of ivln_gemm_f32 /
+                    // ivln_gn_conv_f32 with one slab); activations (plain input, residual, act_out) are NCHW
+                    const int64_t o = ((int64_t)n * C + c) * HW + (int64_t)row * W + 4 * q;
+                    const int64_t oc = ((int64_t)c * D.N + n) * HW + (int64_t)row * W + 4 * q;
+                    xr[e] = *reinterpret_cast<const float4*>(D.x + (D.stats ? oc : o));
+                    if (D.x2) x2r[e] = *reinterpret_cast<const float4*>(D.x2 + oc);
+                    if (D.residual) rr[e] = *reinterpret_cast<const float4*>(D.residual + o);
+                }
+            }
+        }
+    } else {
+        const int t0 = nload, nt = GT - nload;
+        if (D.stats)
+            for (int c = tid - t0; c < C; c += nt) {
+                gab[c] = D.gamma[c];
+                gab[Cp + c] = D.beta[c];
+                if (D.x2) {
+                    gab[2 * Cp + c] = D.gamma2[c];
+                    gab[3 * Cp + c] = D.beta2[c];
+                }
+            }
+        stage_weights(D.wa, C * KSZ * KSZ, 0, C * KSZ * KSZ, G.kbp_a, 0, D.Cout_a, wl, t0, nt);
+        if (D.wb) stage_weights(D.wb, C, 0, C, G.kbp_b, 0, D.Cout_b, wl_b, t0, nt);
+    }
+    __syncthreads();
+    STAMP(1);
+    // ---- per-channel scale / shift of this image ----
+    if (D.stats) {
+        // merge the partials: a DPP row of 16 lanes per group (lane = part) when there are at most 16 parts - no loop -,
+        // threads [0, 256) for x and [256, 512) for x2; otherwise one thread per group walks its parts
+        const int half_t = tid & 255, which = tid >> 8;
+        if (which == 0 || D.x2) {
+            const float* ps = which ? pst + pfl : pst;
+            const int np_ = which ? D.parts2 : D.parts;
+            float* go = gst + which * 2 * D.groups;
+            if (np_ <= 16 && D.groups <= 16) {
+                const int g = half_t >> 4, pp = half_t & 15;
+                const bool have = g < D.groups && pp < np_;
+                const float* q = ps + (pp * D.groups + (g < D.groups ? g : 0)) * 3;
+                const float nb = have ? q[0] : 0.f, mb = have ? q[1] : 0.f, Mb = have ? q[2] : 0.f;
+                const float cnt = row_sum16(nb), mean = row_sum16(nb * mb) / cnt;
+                const float dd = mb - mean;
+                const float M2 = row_sum16(fmaf(nb * dd, dd, Mb));
+                if (pp == 0 && g < D.groups) {
+                    go[2 * g] = mean;
+                    go[2 * g + 1] = rsqrtf(M2 / cnt + D.eps);
+                }
+            } else if (half_t < D.groups) {
+                merge_stats(ps, np_, D.groups, half_t, D.eps, go[2 * half_t], go[2 * half_t + 1]);
+            }
+        }
+        __syncthreads();
+        const fdiv by_cpg(C / D.groups);
+        for (int c = tid; c < C; c += GT) {
+            const int g = by_cpg(c);
+            const float sc = gab[c] * gst[2 * g + 1];
+            tab[c] = sc;
+            tab[Cp + c] = gab[Cp + c] - gst[2 * g] * sc;
+            if (D.x2) {
+                const float s2 = gab[2 * Cp + c] * gst[2 * D.groups + 2 * g + 1];
+                tab[2 * Cp + c] = s2;
+                tab[3 * Cp + c] = gab[3 * Cp + c] - gst[2 * D.groups + 2 * g] * s2;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- transform the strip into LDS (rows outside the image stay 0), hand out the activation ----
+    if (tid < nload) {
+        const fdiv by_w4(w4), by_hs(G.Hs);
+#pragma unroll
+        for (int e = 0; e < NC_E4; ++e) {
+            const int v = tid + e * nload;
+            if (v < nv) {
+                const int ch = by_w4(v), q = v - ch * w4, c = by_hs(ch), hs = ch - c * G.Hs;
+                const int row = r0 - PH + hs;
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+                if ((unsigned)row < (unsigned)D.H) {
+                    a = xr[e];
+                    if (D.stats) {
+                        const float sc = tab[c], sh = tab[Cp + c];
+                        a.x = fmaf(a.x, sc, sh); a.y = fmaf(a.y, sc, sh); a.z = fmaf(a.z, sc, sh); a.w = fmaf(a.w, sc, sh);
+                        if (D.x2) {
+                            const float s2 = tab[2 * Cp + c], h2 = tab[3 * Cp + c];
+                            a.x += fmaf(x2r[e].x, s2, h2); a.y += fmaf(x2r[e].y, s2, h2);
+                            a.z += fmaf(x2r[e].z, s2, h2); a.w += fmaf(x2r[e].w, s2, h2);
+                        }
+                    }
+                    if (D.residual) { a.x += rr[e].x; a.y += rr[e].y; a.z += rr[e].z; a.w += rr[e].w; }
+                    if (D.relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+                    if (D.act_out && hs >= PH && hs < PH + rows)
+                        *reinterpret_cast<float4*>(D.act_out + ((int64_t)n * C + c) * HW + (int64_t)row * W + 4 * q) = a;
+                }
+                *reinterpret_cast<float4*>(&in[(c * G.Hs + hs) * W + 4 * q]) = a;
+            }
+        }
+    }
+    __syncthreads();
+    STAMP(2);
+    // ---- the convolution(s) over the full K: complete output tiles in LDS ----
+    const int zoff = (int)(red + ZW - in);
+    partial_conv<KSZ>(in, C, G.Hs, W, D.wa, C, 0, 0, D.Cout_a, 1, PH, rows, W, outa, G.RS * W, 0, wl, D.Cout_a * G.kbp_a, true,
+                      zoff, G.part_floats ? part : nullptr, 0);
+    if (D.wb) {
+        // conv B is 1x1: it reads the strip's own rows only
+        partial_conv<1>(in + PH * W, C, G.Hs, W, D.wb, C, 0, 0, D.Cout_b, 1, 0, rows, W, outb, G.RS * W, 0, wl_b,
+                        D.Cout_b * G.kbp_b, true, (int)(red + ZW - (in + PH * W)), G.part_floats ? part : nullptr, 0);
+    }
+    __syncthreads();
+    STAMP(3);
+    // ---- outputs to memory (whole rows) and the statistics partials of this strip ----
+    const int npx = rows * W, npx4 = npx >> 2;
+    for (int pass = 0; pass < (D.wb ? 2 : 1); ++pass) {
+        const float* o = pass ? outb : outa;
+        float* y = pass ? D.yb : D.ya;
+        const int Co = pass ? D.Cout_b : D.Cout_a, ng = pass ? D.groups_b : D.groups_a;
+        float* so = pass ? D.stats_b : D.stats_a;
+        const fdiv by_px4(npx4);
+        for (int v = tid; v < Co * npx4; v += GT) {
+            const int co = by_px4(v), q = v - co * npx4;
+            *reinterpret_cast<float4*>(y + ((int64_t)co * D.N + n) * HW + (int64_t)r0 * W + 4 * q) =
+                *reinterpret_cast<const float4*>(&o[co * (G.RS * W) + 4 * q]);
+        }
+        if (so) {
+            const int cpo = Co / ng, nel = cpo * npx;
+            for (int g = wave; g < ng; g += NW) {  // one wave per group, ONE pass over its cpo x npx values, shifted by
+                // the group's first value so that sum-of-squares minus squared-sum does not cancel
+                const float* og = o + g * cpo * (G.RS * W);
+                const float pilot = og[0];
+                float s1 = 0.f, s2 = 0.f;
+                const fdiv by_npx(npx);
+                for (int i = lane; i < nel; i += 64) {
+                    const int cl = by_npx(i);
+                    const float dd = og[cl * (G.RS * W) + (i - cl * npx)] - pilot;
+                    s1 += dd;
+                    s2 = fmaf(dd, dd, s2);
+                }
+                s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_sum(s1)), 63));
+                s2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_sum(s2)), 63));
+                const float mean = pilot + s1 / (float)nel;
+                const float M2 = fmaxf(s2 - s1 * s1 / (float)nel, 0.f);
+                if (lane == 0) {
+                    float* dst = so + ((int64_t)(strip * D.N + n) * ng + g) * 3;
+                    dst[0] = (float)nel;
+                    dst[1] = mean;
+                    dst[2] = M2;
+                }
+            }
+        }
+    }
+    STAMP(4);
+}
+
 typedef void (*gn_conv_fn)(const Desc, const Geo);
 
 }  // namespace
@@ -590,6 +855,56 @@ int ivln_gn_conv_f32(const ivln_gn_conv_desc* d, void* stream) {
     G.part_floats = (int)part;
     if (d->N > 65535) return IVLN_E_UNSUPPORTED;
     hipLaunchKernelGGL(fn, dim3(d->groups, d->N, S), dim3(GT), bytes, (hipStream_t)stream, *d, G);
+    return hipGetLastError() == hipSuccess ? IVLN_OK : IVLN_E_HIP;
+}
+
+int ivln_nconv_f32(const ivln_nconv_desc* d, void* stream) {
+    if (!d || !d->x || !d->wa || !d->ya || d->N <= 0 || d->C <= 0 || d->H <= 0 || d->W <= 0 || d->Cout_a <= 0) return IVLN_E_INVALID;
+    if (d->stats && (!d->gamma || !d->beta || d->parts < 1 || d->groups <= 0 || d->C % d->groups)) return IVLN_E_INVALID;
+    if (d->x2 && (!d->stats || !d->stats2 || !d->gamma2 || !d->beta2 || d->parts2 < 1)) return IVLN_E_INVALID;
+    if (d->stats_a && (d->groups_a <= 0 || d->Cout_a % d->groups_a)) return IVLN_E_INVALID;
+    if (d->wb && (!d->yb || d->Cout_b <= 0 || (d->stats_b && (d->groups_b <= 0 || d->Cout_b % d->groups_b)))) return IVLN_E_INVALID;
+    if ((d->ka != 1 && d->ka != 3) || (d->W & 3) || (d->C & 1) || d->groups > 32 || d->N > 65535) return IVLN_E_UNSUPPORTED;
+    NGeo G = {};
+    G.RS = d->rows_per_block > 0 ? d->rows_per_block : (d->W >= 64 ? 1 : 64 / d->W);
+    if (G.RS > d->H) G.RS = d->H;
+    if ((G.RS * d->W) & 3) return IVLN_E_UNSUPPORTED;
+    G.strips = (d->H + G.RS - 1) / G.RS;
+    G.Hs = G.RS + d->ka - 1;
+    G.kbp_a = (((d->C * d->ka * d->ka) + 3) & ~3) + 4;
+    G.kbp_b = d->wb ? ((d->C + 3) & ~3) + 4 : 0;
+    const int Cp = (d->C + 3) & ~3;
+    const int tiles_a = ((d->Cout_a + 31) / 32) * ((G.RS * d->W + 31) / 32);
+    const int tiles_b = d->wb ? ((d->Cout_b + 31) / 32) * ((G.RS * d->W + 31) / 32) : NW;
+    G.part_floats = (tiles_a < NW || tiles_b < NW) ? 8 * 1024 : 0;
+    const size_t strip = (size_t)d->C * G.Hs * d->W;
+    const size_t wfl = (size_t)d->Cout_a * G.kbp_a + (d->wb ? (size_t)d->Cout_b * G.kbp_b : 0);
+    const size_t pfl = (d->stats ? (size_t)((d->parts * d->groups * 3 + 3) & ~3) : 0) + (d->x2 ? (size_t)((d->parts2 * d->groups * 3 + 3) & ~3) : 0);
+    size_t fl = 64 + pfl + 4 * (size_t)((d->groups + 3) & ~3) + 8 * (size_t)Cp + ((strip + 3) & ~3) +
+                (((size_t)d->Cout_a * G.RS * d->W + 3) & ~3) + (d->wb ? (((size_t)d->Cout_b * G.RS * d->W + 3) & ~3) : 0) + wfl;
+    if (fl + G.part_floats > kLdsFloats) G.part_floats = 0;
+    fl += G.part_floats;
+    if (fl > kLdsFloats) return IVLN_E_UNSUPPORTED;
+    // loader threads keep their share of the strip in registers (NC_E4 float4 each)
+    int nw = (int)((double)NW * wfl / (double)(wfl + strip * (1 + (d->x2 ? 1 : 0) + (d->residual ? 1 : 0))) + 0.5);
+    nw = nw < 1 ? 1 : (nw > NW - 2 ? NW - 2 : nw);
+    while (nw > 1 && (size_t)(GT - 64 * nw) * NC_E4 * 4 < strip) --nw;
+    if ((size_t)(GT - 64 * nw) * NC_E4 * 4 < strip) return IVLN_E_UNSUPPORTED;
+    G.wthr = 64 * nw;
+    typedef void (*nconv_fn)(const NDesc, const NGeo);
+    nconv_fn fn = d->ka == 3 ? k_nconv<3> : k_nconv<1>;
+    {
+        static std::mutex mu;
+        static std::set<const void*> raised;
+        std::lock_guard<std::mutex> lk(mu);
+        if (!raised.count((const void*)fn)) {
+            if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsFloats * sizeof(float))) !=
+                hipSuccess)
+                return IVLN_E_HIP;
+            raised.insert((const void*)fn);
+        }
+    }
+    hipLaunchKernelGGL(fn, dim3(G.strips, d->N), dim3(GT), fl * sizeof(float), (hipStream_t)stream, *d, G);
     return hipGetLastError() == hipSuccess ? IVLN_OK : IVLN_E_HIP;
 }
 

@@ -299,16 +299,25 @@ class _ResNet50GN(nn.Module):
             r0 = ops.gn_conv(y, gn, relu=True, pool=True, want_act=True)  # stem GroupNorm + ReLU + MaxPool in one launch
             act = r0[0] if r0 is not None else \
                 ops.pool2d(ops.groupnorm(y, gn.weight, gn.bias, gn.num_groups, gn.eps, relu=True), 3, 2, 1, "max")
-            for blk in blocks[:first - 1]:
-                act = blk.forward_hip(act)
-            # the last pairwise block hands over: its final GroupNorm is the chain's first launch
-            blk = blocks[first - 1]
-            y3, ds = blk.body_hip(act)
             nxt = feeds(blocks[first]) if first < len(blocks) else dict(conv_a=tail)
-            if ds is not None:
-                r = ops.gn_conv(y3, blk.convs[7], x2=ds, gn2=blk.downsample[1], **nxt)
-            else:
-                r = ops.gn_conv(y3, blk.convs[7], residual=act, **nxt)
+            done = 0  # leading stride-1 blocks (layer 1) as ivln_nconv_f32 launches; a strided block ends that run
+            while ops.NCONV_FRONT and done < first and blocks[done].stride == 1:
+                done += 1
+            r = self._front_blocks_nconv(blocks[:done], act, nxt if done == first else None) if done else None
+            if r is not None and done < first:
+                act, r = r, None  # (the run ended before the chain starts: `r` is the activated output of its last block)
+            elif r is None:
+                done = 0
+            if r is None:
+                for blk in blocks[done:first - 1]:
+                    act = blk.forward_hip(act)
+                # the last pairwise block hands over: its final GroupNorm is the chain's first launch
+                blk = blocks[first - 1]
+                y3, ds = blk.body_hip(act)
+                if ds is not None:
+                    r = ops.gn_conv(y3, blk.convs[7], x2=ds, gn2=blk.downsample[1], **nxt)
+                else:
+                    r = ops.gn_conv(y3, blk.convs[7], residual=act, **nxt)
         for i, blk in enumerate(blocks):
             if i < first:
                 continue
@@ -331,6 +340,54 @@ class _ResNet50GN(nn.Module):
                 r2 = ops.gn_conv(r[1], c[7], **tail_in, **nxt)
             r = r2
         return None if r is None else r[1]
+
+    @staticmethod
+    def _front_blocks_nconv(blocks, act, nxt):
+        """The bottlenecks BEFORE the gn_conv chain (large maps: layer 1) as one ivln_nconv_f32 launch per conv layer:
+        every conv normalises its input on load from the statistics partials its producer left and emits those of its
+        own output - complete tensors, no slabs, no GroupNorm launches.  `act`: the activated input of the first block;
+        `nxt`: what the chain's first launch has to emit.  Returns that launch's result, or None (a stride or a shape
+        outside the kernel's envelope: the caller runs the conv + GroupNorm pairs).  With `nxt` None the run ends before
+        the chain starts: the activated output of the last block is returned instead."""
+        if any(b.stride != 1 for b in blocks):
+            return None
+        identity, x1, xds = act, None, None
+        for i, blk in enumerate(blocks):
+            c = blk.convs
+            G1, G3 = c[1].num_groups, c[7].num_groups
+            if i == 0:  # first block: its convs read the activated tensor as it is
+                ds = None if blk.downsample is None else (blk.downsample[0].weight, blk.downsample[1].num_groups)
+                r = ops.nconv(act, None, relu=False, conv_a=(c[0].weight, G1), conv_b=ds)
+                if r is None:
+                    return None
+                x1, xds = r[1], r[2]
+            r = ops.nconv(x1, c[1], conv_a=(c[3].weight, c[4].num_groups))      # GroupNorm 1 + ReLU on load -> 3x3
+            if r is None:
+                return None
+            r = ops.nconv(r[1], c[4], conv_a=(c[6].weight, G3))                  # GroupNorm 2 + ReLU on load -> 1x1
+            if r is None:
+                return None
+            x3 = r[1]
+            tail = dict(x2=xds, gn2=blk.downsample[1]) if blk.downsample is not None else dict(residual=identity)
+            if i + 1 < len(blocks):  # the block's tail is built on load by the next block's first conv(s)
+                nb = blocks[i + 1]
+                ds = None if nb.downsample is None else (nb.downsample[0].weight, nb.downsample[1].num_groups)
+                r = ops.nconv(x3, c[7], conv_a=(nb.convs[0].weight, nb.convs[1].num_groups), conv_b=ds,
+                              want_act=nb.downsample is None, **tail)
+                if r is None:
+                    return None
+                identity, x1, xds = r[0], r[1], r[2]
+            elif nxt is not None:  # hand over to the chain: its first launch takes the raw tensors as one-slab inputs
+                if blk.downsample is not None:
+                    return ops.gn_conv(x3.deferred(), c[7], x2=xds.deferred(), gn2=blk.downsample[1], **nxt)
+                return ops.gn_conv(x3.deferred(), c[7], residual=identity, **nxt)
+            else:  # hand over to conv + GroupNorm pairs: materialise the block's output
+                if blk.downsample is not None:
+                    gd = blk.downsample[1]
+                    return ops.groupnorm(x3.deferred(), c[7].weight, c[7].bias, G3, c[7].eps, relu=True, x2=xds.deferred(),
+                                         gamma2=gd.weight, beta2=gd.bias)
+                return ops.groupnorm(x3.deferred(), c[7].weight, c[7].bias, G3, c[7].eps, relu=True, residual=identity)
+        return None
 
     def forward_hip(self, x):
         c, gn = self.conv1[0], self.conv1[1]

@@ -544,6 +544,9 @@ CHAIN_GN_CONV = os.environ.get("IVLN_GN_CONV", "1") != "0"
 # measured 4 envs 5.1 K vs 4.0 K env-steps/s, 8 envs 7.5 K vs 6.9 K, but 16 envs 9.5 K vs 10.1 K and 32 envs 11.1 K vs
 # 15.2 K - beyond 8 images per GPU the conv + GroupNorm pairs run.
 CHAIN_MAX_IMAGES = int(os.environ.get("IVLN_GN_CONV_MAX_IMAGES", "8"))
+# the bottlenecks before the chain (layer 1) as ivln_nconv_f32 launches: GroupNorm on load, statistics out, no slabs
+NCONV_FRONT = os.environ.get("IVLN_NCONV_FRONT", "1") != "0"
+NCONV_ROWS = int(os.environ.get("IVLN_NCONV_ROWS", "0"))  # output rows per workgroup (0: 64 pixels)
 # first bottleneck (0..16) that runs in the chain; earlier ones (large feature maps: 16 partial slabs of a 32x32 map
 # are more traffic than the launches they save) stay conv + GroupNorm pairs.  0 = the whole backbone incl. the stem;
 # 3 = from layer2 on (measured best at 4 envs: 0.790 ms/step vs 0.820 from the stem and 0.996 without the chain);
@@ -625,6 +628,84 @@ def gn_conv(x, gn, relu=True, pool=False, x2=None, gn2=None, residual=None, want
         return None
     check(code, "ivln_gn_conv_f32")
     return act, ya, yb
+
+
+class NconvDesc(C.Structure):
+    """Mirror of `ivln_nconv_desc` (include/ivln_hip.h) - field order must match."""
+
+    _fields_ = [
+        ("x", vp), ("stats", vp), ("parts", i32), ("gamma", vp), ("beta", vp),
+        ("x2", vp), ("stats2", vp), ("parts2", i32), ("gamma2", vp), ("beta2", vp),
+        ("residual", vp),
+        ("N", i32), ("C", i32), ("H", i32), ("W", i32), ("groups", i32), ("eps", f32), ("relu", i32),
+        ("act_out", vp),
+        ("wa", vp), ("Cout_a", i32), ("ka", i32), ("groups_a", i32), ("ya", vp), ("stats_a", vp),
+        ("wb", vp), ("Cout_b", i32), ("groups_b", i32), ("yb", vp), ("stats_b", vp),
+        ("rows_per_block", i32),
+    ]
+
+
+class RawStats:
+    """A conv output that has not been group-normalised yet, channel-major over the batch ([C][N][H][W]), + the (count,
+    mean, M2) partials its producer left per (strip, image, group): what the next ivln_nconv_f32 launch normalises on
+    load; `deferred()` views it as the one-slab `Deferred` the ivln_gn_conv_f32 chain takes."""
+
+    def __init__(self, y, stats, parts, groups):
+        self.y, self.stats, self.parts, self.groups = y, stats, parts, groups
+
+    def deferred(self):
+        Cc, N, H, W = self.y.shape
+        return Deferred(self.y.view(-1), 1, N, Cc, H, W)
+
+
+def nconv(x, gn=None, x2=None, gn2=None, residual=None, relu=True, want_act=False, conv_a=None, conv_b=None, rows_per_block=0):
+    """Conv with GroupNorm on its input applied on load and the GroupNorm statistics of its output(s) emitted as partials
+    (csrc/gn_conv.hip k_nconv): in = act(GN(x) [+ GN2(x2)] [+ residual]); conv_a = (weight (Co, C, k, k), groups of the
+    GroupNorm that follows) with k = 1 | 3, stride 1, pad (k-1)/2; conv_b likewise (1x1).  x: a `RawStats` with `gn`, or an
+    activated NCHW tensor (gn None).  Returns (act | None, RawStats a, RawStats b | None), or None outside the envelope."""
+    d = NconvDesc()
+    xt = x.y if isinstance(x, RawStats) else x
+    if isinstance(x, RawStats):
+        Cc, N, H, W = xt.shape  # raw conv outputs are [C][N][H][W] (the one-slab layout of the deferred convs)
+    else:
+        N, Cc, H, W = xt.shape
+    dev = xt.device
+    d.x = _p(xt)
+    if isinstance(x, RawStats):
+        d.stats, d.parts, d.gamma, d.beta, d.groups, d.eps = _p(x.stats), x.parts, dptr(gn.weight), dptr(gn.bias), x.groups, gn.eps
+        assert gn.num_groups == x.groups
+    if x2 is not None:
+        d.x2, d.stats2, d.parts2, d.gamma2, d.beta2 = _p(x2.y), _p(x2.stats), x2.parts, dptr(gn2.weight), dptr(gn2.bias)
+        assert x2.groups == x.groups and tuple(x2.y.shape) == (Cc, N, H, W)
+    d.residual = _p(residual)
+    d.N, d.C, d.H, d.W, d.relu = N, Cc, H, W, int(bool(relu))
+    act = torch.empty((N, Cc, H, W), dtype=torch.float32, device=dev) if want_act else None
+    d.act_out = _p(act)
+    rs = rows_per_block if rows_per_block > 0 else (NCONV_ROWS if NCONV_ROWS > 0 else (1 if W >= 64 else 64 // W))
+    rs = min(rs, H)
+    strips = (H + rs - 1) // rs
+    d.rows_per_block = rs
+    outs = []
+    for key, cw in (("a", conv_a), ("b", conv_b)):
+        if cw is None:
+            outs.append(None)
+            continue
+        w, g_out = cw
+        Co = w.shape[0]
+        y = torch.empty((Co, N, H, W), dtype=torch.float32, device=dev)
+        st = torch.empty((strips, N, g_out, 3), dtype=torch.float32, device=dev)
+        if key == "a":
+            d.wa, d.Cout_a, d.ka, d.groups_a, d.ya, d.stats_a = dptr(w), Co, w.shape[2], g_out, _p(y), _p(st)
+        else:
+            d.wb, d.Cout_b, d.groups_b, d.yb, d.stats_b = dptr(w), Co, g_out, _p(y), _p(st)
+        outs.append(RawStats(y, st, strips, g_out))
+    L = _L()
+    L.ivln_nconv_f32.argtypes = [C.POINTER(NconvDesc), vp]
+    code = L.ivln_nconv_f32(C.byref(d), stream_ptr())
+    if code == IVLN_E_UNSUPPORTED:
+        return None
+    check(code, "ivln_nconv_f32")
+    return act, outs[0], outs[1]
 
 
 class CmaStepDesc(C.Structure):

@@ -211,3 +211,86 @@ def test_depth_encoder_chain_matches_pairwise_path_and_oracle(B, first, pair):
         r = ref({"depth": depth})
     assert float((a - r).abs().max()) < 2e-4, float((a - r).abs().max())
     assert np.isfinite(a.numpy()).all()
+
+
+@pytest.mark.parametrize("N,Cc,H,W,ca,cb,mode", [
+    (4, 32, 32, 32, (32, 1), (128, 1), "plain_in"),     # layer1.0: conv1 + downsample of the pooled stem activation
+    (4, 32, 32, 32, (32, 3), None, "gn"),               # GN1 on load -> 3x3
+    (2, 32, 32, 32, (128, 1), None, "gn"),              # GN2 on load -> 1x1 x4
+    (2, 128, 32, 32, (32, 1), None, "gn_second"),       # tail of block 0: GN3 + GN_ds on load -> next conv1
+    (2, 128, 32, 32, (32, 1), None, "gn_residual"),     # tail of an identity block
+    (3, 64, 16, 16, (32, 3), None, "gn"),               # 16x16 maps: four rows per strip
+    (1, 16, 8, 12, (6, 3), (10, 1), "gn_residual"),     # odd sizes, ragged last strip (rows_per_block 5)
+])
+def test_conv_with_groupnorm_on_load_and_statistics_out(N, Cc, H, W, ca, cb, mode):
+    """ivln_nconv_f32: in = relu(GN(x) [+ GN2(x2)] [+ res]) built on load from the producer's (count, mean, M2)
+    partials, conv(s) over the full K, raw outputs + the partials of THEIR statistics - against F.group_norm / F.conv2d;
+    the emitted partials, merged, must reproduce the two-pass mean / variance of the outputs."""
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(Cc + H + ca[0])
+    groups = 16 if Cc % 32 == 0 else 8
+    rs = 5 if H == 8 else 0
+    x = torch.randn(N, Cc, H, W, generator=g) * 1.7 + 0.4
+
+    def partials(t, ngroups, strips, rows):
+        """what a producer would have left: per strip (count, mean, M2) of every (image, group)"""
+        n_, c_, h_, w_ = t.shape
+        out = torch.zeros(strips, n_, ngroups, 3)
+        for s in range(strips):
+            blk = t[:, :, s * rows:(s + 1) * rows].reshape(n_, ngroups, -1)
+            out[s, :, :, 0] = blk.shape[2]
+            out[s, :, :, 1] = blk.mean(2)
+            out[s, :, :, 2] = ((blk - blk.mean(2, keepdim=True)) ** 2).sum(2)
+        return out
+
+    rows_in = max(1, 64 // W) if rs == 0 else rs
+    rows_in = min(rows_in, H)
+    strips_in = (H + rows_in - 1) // rows_in
+    kw, ref = {}, x
+    gn = None
+    if mode != "plain_in":
+        gn = _gn(Cc, groups, g)
+        ref = F.group_norm(x, groups, gn.weight, gn.bias, 1e-5)
+        cnhw = lambda t: t.permute(1, 0, 2, 3).contiguous()  # noqa: E731  raw tensors are [C][N][H][W]
+        xin = ops.RawStats(cnhw(x).to(DEV), partials(x, groups, strips_in, rows_in).to(DEV), strips_in, groups)
+        if mode == "gn_second":
+            x2, gn2 = torch.randn(N, Cc, H, W, generator=g) * 0.8 - 0.3, _gn(Cc, groups, g)
+            ref = ref + F.group_norm(x2, groups, gn2.weight, gn2.bias, 1e-5)
+            kw = dict(x2=ops.RawStats(cnhw(x2).to(DEV), partials(x2, groups, strips_in, rows_in).to(DEV), strips_in, groups), gn2=gn2.to(DEV))
+        elif mode == "gn_residual":
+            res = torch.randn(N, Cc, H, W, generator=g)
+            ref = ref + res
+            kw = dict(residual=res.to(DEV))
+        ref = F.relu(ref)
+        gn = gn.to(DEV)
+    else:
+        xin = x.to(DEV)
+    ref = ref.detach()
+    ga = 16 if ca[0] % 32 == 0 else (2 if ca[0] % 2 == 0 else 1)
+    wa = torch.randn(ca[0], Cc, ca[1], ca[1], generator=g) / (Cc * ca[1] ** 2) ** 0.5
+    ref_a = F.conv2d(ref, wa, None, 1, ca[1] // 2)
+    conv_b = ref_b = None
+    if cb is not None:
+        gb = 16 if cb[0] % 32 == 0 else 2
+        wb = torch.randn(cb[0], Cc, 1, 1, generator=g) / Cc ** 0.5
+        ref_b = F.conv2d(ref, wb)
+        conv_b = (wb.to(DEV), gb)
+    r = ops.nconv(xin, gn, relu=(mode != "plain_in"), want_act=(mode != "plain_in"), conv_a=(wa.to(DEV), ga), conv_b=conv_b,
+                  rows_per_block=rs, **kw)
+    assert r is not None, "shape must be inside the kernel's envelope"
+    act, a, b = r
+    tol = 5e-5 * max(1.0, float(ref.abs().max()))
+    if act is not None:
+        assert float((act.cpu() - ref).abs().max()) < tol
+    for out, rr, ng in ((a, ref_a, ga), (b, ref_b, None if cb is None else gb)):
+        if out is None:
+            continue
+        assert float((out.y.permute(1, 0, 2, 3).cpu() - rr).abs().max()) < 2 * tol
+        st = out.stats.cpu().double()  # (strips, N, groups, 3): merge and compare with the direct statistics
+        cnt = st[..., 0].sum(0)
+        mean = (st[..., 0] * st[..., 1]).sum(0) / cnt
+        M2 = (st[..., 2] + st[..., 0] * (st[..., 1] - mean) ** 2).sum(0)
+        blk = rr.double().reshape(N, ng, -1)
+        assert float((mean - blk.mean(2)).abs().max()) < 1e-5
+        assert float((M2 / cnt - blk.var(2, unbiased=False)).abs().max()) < 1e-4 * max(1.0, float(blk.var(2).max()))
