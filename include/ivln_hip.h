@@ -255,7 +255,7 @@ int ivln_gn_conv_f32(const ivln_gn_conv_desc* d, void* stream);
  * partials (csrc/gn_conv.hip, k_nconv) - for the large feature maps of the depth ResNet's layer 1, where the
  * 16-slab scheme of ivln_gn_conv_f32 costs more bytes than it saves launches.  One launch per conv layer:
  *   in  = act( GN(x; stats, gamma, beta) [+ GN(x2; stats2, gamma2, beta2)] [+ residual] )      (stats == NULL: in = x)
- *   ya  = conv_a(in)   (k = 1 | 3, stride 1, pad (k-1)/2),   yb = conv_b(in)   (1x1, optional)
+ *   ya  = conv_a(in)   (k = 1 | 3, stride 1 | 2, pad (k-1)/2),   yb = conv_b(in)   (1x1, stride 1 | 2, optional)
  * A workgroup owns a strip of `rows_per_block` output rows of one image with its halo, over ALL channels, so the
  * outputs are complete (no slabs).  stats layout: [parts][N][groups][3] = (count, mean, M2) of one (image, group)
  * per producing workgroup; the consumer merges them in part order (Chan), i.e. the variance is the two-pass one.
@@ -281,13 +281,14 @@ typedef struct ivln_nconv_desc {
     float* act_out;        /* (N, C, H, W) or NULL */
     const float* wa;       /* (Cout_a, C, ka, ka) */
     int Cout_a, ka, groups_a;
-    float* ya;             /* raw output [Cout_a][N][H][W] */
-    float* stats_a;        /* [strips][N][groups_a][3], strips = ceil(H / rows_per_block) */
+    float* ya;             /* raw output [Cout_a][N][Ho][Wo] */
+    float* stats_a;        /* [strips][N][groups_a][3], strips = ceil(Ho / rows_per_block); stats_b has the same strips */
     const float* wb;       /* (Cout_b, C, 1, 1) or NULL */
     int Cout_b, groups_b;
     float* yb;
     float* stats_b;
     int rows_per_block;    /* 0 = default (64 output pixels per workgroup) */
+    int stride_a, stride_b; /* 0 | 1 | 2; act_out and conv B need stride_a == 1 */
 } ivln_nconv_desc;
 int ivln_nconv_f32(const ivln_nconv_desc* d, void* stream);
 

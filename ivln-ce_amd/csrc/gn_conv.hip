@@ -494,9 +494,12 @@ __global__ __launch_bounds__(GT) void k_gn_conv(const Desc D, const Geo G) {
 // ------------------------------------------------------------------------------------------------------------------
 typedef ivln_nconv_desc NDesc;
 struct NGeo {
-    int RS, strips, Hs;      // output rows per workgroup, strips per image, staged input rows (RS + KSZ - 1)
+    int RS, strips, Hs;      // output rows (of conv A) per workgroup, strips per image, staged input rows
     int part_floats, wthr;   // partial-tile scratch of partial_conv; threads that stage the weights
     int kbp_a, kbp_b;
+    int sa, sb;              // strides
+    int Ho_a, Wo_a, Ho_b, Wo_b, RSb;  // output sizes; conv B's output rows per workgroup
+    int per_a, per_b;        // output channels per blockIdx.z
 };
 constexpr int NC_E4 = 6;     // float4 of the strip per loader thread (registers)
 
@@ -537,8 +540,12 @@ __global__ __launch_bounds__(GT) void k_nconv(const NDesc D, const NGeo G) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int PH = KSZ / 2;  // halo rows above / below, horizontal padding
     const int C = D.C, W = D.W, HW = D.H * D.W, Cp = (C + 3) & ~3;
-    const int strip = blockIdx.x, n = blockIdx.y;
-    const int r0 = strip * G.RS, rows = min(G.RS, D.H - r0);
+    const int strip = blockIdx.x, n = blockIdx.y, mz = blockIdx.z;
+    const int r0 = strip * G.RS, rows = min(G.RS, G.Ho_a - r0);  // output rows of conv A
+    const int rin0 = r0 * G.sa - PH;                             // first staged input row
+    const int a_beg = mz * G.per_a, a_end = min(D.Cout_a, a_beg + G.per_a), na = max(a_end - a_beg, 0);
+    const int b_beg = mz * G.per_b, b_end = min(D.Cout_b, b_beg + G.per_b), nb = D.wb ? max(b_end - b_beg, 0) : 0;
+    const int rb0 = r0 * G.sa / max(G.sb, 1), rows_b = D.wb ? min(G.RSb, G.Ho_b - rb0) : 0;
     const int SW = G.Hs * W;     // floats of one channel of the staged strip
     float* red = smem;           // 64 (zero word at ZW)
     float* pst = red + 64;       // this image's statistics partials [parts][groups][3] of x, then of x2
@@ -548,10 +555,11 @@ __global__ __launch_bounds__(GT) void k_nconv(const NDesc D, const NGeo G) {
     float* tab = gab + 4 * Cp;   // scale, shift, scale2, shift2 per channel
     float* in = tab + 4 * Cp;    // [C][Hs*W] transformed input strip
     float* outa = in + ((C * SW + 3) & ~3);
-    float* outb = outa + ((D.Cout_a * G.RS * W + 3) & ~3);
-    float* part = outb + (D.wb ? ((D.Cout_b * G.RS * W + 3) & ~3) : 0);
+    const int ta = G.RS * G.Wo_a, tb = G.RSb * G.Wo_b;  // floats per output channel of the LDS output tiles
+    float* outb = outa + ((G.per_a * ta + 3) & ~3);
+    float* part = outb + (D.wb ? ((G.per_b * tb + 3) & ~3) : 0);
     float* wl = part + G.part_floats;
-    float* wl_b = wl + D.Cout_a * G.kbp_a;
+    float* wl_b = wl + G.per_a * G.kbp_a;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nload = GT - G.wthr;
 
@@ -581,7 +589,7 @@ __global__ __launch_bounds__(GT) void k_nconv(const NDesc D, const NGeo G) {
             xr[e] = x2r[e] = rr[e] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (v < nv) {
                 const int ch = by_w4(v), q = v - ch * w4, c = by_hs(ch), hs = ch - c * G.Hs;  // v = (c*Hs + hs)*w4 + q
-                const int row = r0 - PH + hs;
+                const int row = rin0 + hs;
                 if ((unsigned)row < (unsigned)D.H) {
                     // raw conv outputs are channel-major over the batch ([C][N][H][W], the slab layout of ivln_gemm_f32 /
                     // ivln_gn_conv_f32 with one slab); activations (plain input, residual, act_out) are NCHW
@@ -604,8 +612,8 @@ __global__ __launch_bounds__(GT) void k_nconv(const NDesc D, const NGeo G) {
                     gab[3 * Cp + c] = D.beta2[c];
                 }
             }
-        stage_weights(D.wa, C * KSZ * KSZ, 0, C * KSZ * KSZ, G.kbp_a, 0, D.Cout_a, wl, t0, nt);
-        if (D.wb) stage_weights(D.wb, C, 0, C, G.kbp_b, 0, D.Cout_b, wl_b, t0, nt);
+        stage_weights(D.wa, C * KSZ * KSZ, 0, C * KSZ * KSZ, G.kbp_a, a_beg, na, wl, t0, nt);
+        if (nb) stage_weights(D.wb, C, 0, C, G.kbp_b, b_beg, nb, wl_b, t0, nt);
     }
     __syncthreads();
     STAMP(1);
@@ -657,7 +665,7 @@ __global__ __launch_bounds__(GT) void k_nconv(const NDesc D, const NGeo G) {
             const int v = tid + e * nload;
             if (v < nv) {
                 const int ch = by_w4(v), q = v - ch * w4, c = by_hs(ch), hs = ch - c * G.Hs;
-                const int row = r0 - PH + hs;
+                const int row = rin0 + hs;
                 float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
                 if ((unsigned)row < (unsigned)D.H) {
                     a = xr[e];
@@ -672,7 +680,7 @@ __global__ __launch_bounds__(GT) void k_nconv(const NDesc D, const NGeo G) {
                     }
                     if (D.residual) { a.x += rr[e].x; a.y += rr[e].y; a.z += rr[e].z; a.w += rr[e].w; }
                     if (D.relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
-                    if (D.act_out && hs >= PH && hs < PH + rows)
+                    if (D.act_out && mz == 0 && hs >= PH && hs < PH + rows)  // (stride 1 only: host)
                         *reinterpret_cast<float4*>(D.act_out + ((int64_t)n * C + c) * HW + (int64_t)row * W + 4 * q) = a;
                 }
                 *reinterpret_cast<float4*>(&in[(c * G.Hs + hs) * W + 4 * q]) = a;
@@ -683,39 +691,48 @@ __global__ __launch_bounds__(GT) void k_nconv(const NDesc D, const NGeo G) {
     STAMP(2);
     // ---- the convolution(s) over the full K: complete output tiles in LDS ----
     const int zoff = (int)(red + ZW - in);
-    partial_conv<KSZ>(in, C, G.Hs, W, D.wa, C, 0, 0, D.Cout_a, 1, PH, rows, W, outa, G.RS * W, 0, wl, D.Cout_a * G.kbp_a, true,
-                      zoff, G.part_floats ? part : nullptr, 0);
-    if (D.wb) {
-        // conv B is 1x1: it reads the strip's own rows only
-        partial_conv<1>(in + PH * W, C, G.Hs, W, D.wb, C, 0, 0, D.Cout_b, 1, 0, rows, W, outb, G.RS * W, 0, wl_b,
-                        D.Cout_b * G.kbp_b, true, (int)(red + ZW - (in + PH * W)), G.part_floats ? part : nullptr, 0);
+    // (yslab offsets: partial_conv addresses rows by their global index cb0 + row)
+    if (na)
+        partial_conv<KSZ>(in, C, G.Hs, W, D.wa, C, 0, a_beg, a_end, G.sa, PH, rows, G.Wo_a, outa - (int64_t)a_beg * ta, ta, 0, wl,
+                          na * G.kbp_a, true, zoff, G.part_floats ? part : nullptr, 0);
+    if (nb) {
+        // conv B is 1x1 (stride sb): it reads the strip's own rows only
+        partial_conv<1>(in + PH * W, C, G.Hs, W, D.wb, C, 0, b_beg, b_end, G.sb, 0, rows_b, G.Wo_b, outb - (int64_t)b_beg * tb, tb, 0,
+                        wl_b, nb * G.kbp_b, true, (int)(red + ZW - (in + PH * W)), G.part_floats ? part : nullptr, 0);
     }
     __syncthreads();
     STAMP(3);
     // ---- outputs to memory (whole rows) and the statistics partials of this strip ----
-    const int npx = rows * W, npx4 = npx >> 2;
     for (int pass = 0; pass < (D.wb ? 2 : 1); ++pass) {
         const float* o = pass ? outb : outa;
         float* y = pass ? D.yb : D.ya;
-        const int Co = pass ? D.Cout_b : D.Cout_a, ng = pass ? D.groups_b : D.groups_a;
+        const int Co = pass ? nb : na, cbeg = pass ? b_beg : a_beg, ng = pass ? D.groups_b : D.groups_a;
+        const int tw = pass ? tb : ta, npx = pass ? rows_b * G.Wo_b : rows * G.Wo_a, npx4 = npx >> 2;
+        const int HWo = pass ? G.Ho_b * G.Wo_b : G.Ho_a * G.Wo_a, row0 = pass ? rb0 * G.Wo_b : r0 * G.Wo_a;
+        const int Ctot = pass ? D.Cout_b : D.Cout_a;
         float* so = pass ? D.stats_b : D.stats_a;
+        if (Co <= 0) continue;
+        if (npx <= 0) {  // (a strip below conv B's last output row: an empty partial)
+            if (so && tid < Co / (Ctot / ng) * 3) so[((int64_t)(strip * D.N + n) * ng + cbeg / (Ctot / ng)) * 3 + tid] = 0.f;
+            continue;
+        }
         const fdiv by_px4(npx4);
         for (int v = tid; v < Co * npx4; v += GT) {
             const int co = by_px4(v), q = v - co * npx4;
-            *reinterpret_cast<float4*>(y + ((int64_t)co * D.N + n) * HW + (int64_t)r0 * W + 4 * q) =
-                *reinterpret_cast<const float4*>(&o[co * (G.RS * W) + 4 * q]);
+            *reinterpret_cast<float4*>(y + ((int64_t)(cbeg + co) * D.N + n) * HWo + row0 + 4 * q) =
+                *reinterpret_cast<const float4*>(&o[co * tw + 4 * q]);
         }
         if (so) {
-            const int cpo = Co / ng, nel = cpo * npx;
-            for (int g = wave; g < ng; g += NW) {  // one wave per group, ONE pass over its cpo x npx values, shifted by
+            const int cpo = Ctot / ng, nel = cpo * npx, g0 = cbeg / cpo;
+            for (int g = wave; g < Co / cpo; g += NW) {  // one wave per group, ONE pass over its cpo x npx values, shifted by
                 // the group's first value so that sum-of-squares minus squared-sum does not cancel
-                const float* og = o + g * cpo * (G.RS * W);
+                const float* og = o + g * cpo * tw;
                 const float pilot = og[0];
                 float s1 = 0.f, s2 = 0.f;
                 const fdiv by_npx(npx);
                 for (int i = lane; i < nel; i += 64) {
                     const int cl = by_npx(i);
-                    const float dd = og[cl * (G.RS * W) + (i - cl * npx)] - pilot;
+                    const float dd = og[cl * tw + (i - cl * npx)] - pilot;
                     s1 += dd;
                     s2 = fmaf(dd, dd, s2);
                 }
@@ -724,7 +741,7 @@ __global__ __launch_bounds__(GT) void k_nconv(const NDesc D, const NGeo G) {
                 const float mean = pilot + s1 / (float)nel;
                 const float M2 = fmaxf(s2 - s1 * s1 / (float)nel, 0.f);
                 if (lane == 0) {
-                    float* dst = so + ((int64_t)(strip * D.N + n) * ng + g) * 3;
+                    float* dst = so + ((int64_t)(strip * D.N + n) * ng + g0 + g) * 3;
                     dst[0] = (float)nel;
                     dst[1] = mean;
                     dst[2] = M2;
@@ -864,28 +881,69 @@ int ivln_nconv_f32(const ivln_nconv_desc* d, void* stream) {
     if (d->x2 && (!d->stats || !d->stats2 || !d->gamma2 || !d->beta2 || d->parts2 < 1)) return IVLN_E_INVALID;
     if (d->stats_a && (d->groups_a <= 0 || d->Cout_a % d->groups_a)) return IVLN_E_INVALID;
     if (d->wb && (!d->yb || d->Cout_b <= 0 || (d->stats_b && (d->groups_b <= 0 || d->Cout_b % d->groups_b)))) return IVLN_E_INVALID;
-    if ((d->ka != 1 && d->ka != 3) || (d->W & 3) || (d->C & 1) || d->groups > 32 || d->N > 65535) return IVLN_E_UNSUPPORTED;
+    const int sa = d->stride_a > 0 ? d->stride_a : 1, sb = d->stride_b > 0 ? d->stride_b : 1;
+    if ((d->ka != 1 && d->ka != 3) || (d->W & 3) || (d->C & 1) || d->groups > 32 || d->N > 65535 || sa > 2 || sb > 2) return IVLN_E_UNSUPPORTED;
+    if (d->act_out && sa != 1) return IVLN_E_UNSUPPORTED;
+    if (d->wb && sa != 1) return IVLN_E_UNSUPPORTED;  // conv B shares conv A's input strip: only beside a stride-1 conv A
     NGeo G = {};
-    G.RS = d->rows_per_block > 0 ? d->rows_per_block : (d->W >= 64 ? 1 : 64 / d->W);
-    if (G.RS > d->H) G.RS = d->H;
-    if ((G.RS * d->W) & 3) return IVLN_E_UNSUPPORTED;
-    G.strips = (d->H + G.RS - 1) / G.RS;
-    G.Hs = G.RS + d->ka - 1;
+    const int ph = d->ka / 2;
+    G.sa = sa;
+    G.sb = sb;
+    G.Ho_a = (d->H + 2 * ph - d->ka) / sa + 1;
+    G.Wo_a = (d->W + 2 * ph - d->ka) / sa + 1;
+    G.Ho_b = d->wb ? (d->H - 1) / sb + 1 : 0;
+    G.Wo_b = d->wb ? (d->W - 1) / sb + 1 : 0;
+    if ((G.Wo_a & 3) || (d->wb && (G.Wo_b & 3))) return IVLN_E_UNSUPPORTED;
+    const int Cp = (d->C + 3) & ~3;
+    const int cpo_a = d->stats_a ? d->Cout_a / d->groups_a : 1, cpo_b = (d->wb && d->stats_b) ? d->Cout_b / d->groups_b : 1;
+    const size_t pfl = (d->stats ? (size_t)((d->parts * d->groups * 3 + 3) & ~3) : 0) + (d->x2 ? (size_t)((d->parts2 * d->groups * 3 + 3) & ~3) : 0);
     G.kbp_a = (((d->C * d->ka * d->ka) + 3) & ~3) + 4;
     G.kbp_b = d->wb ? ((d->C + 3) & ~3) + 4 : 0;
-    const int Cp = (d->C + 3) & ~3;
-    const int tiles_a = ((d->Cout_a + 31) / 32) * ((G.RS * d->W + 31) / 32);
-    const int tiles_b = d->wb ? ((d->Cout_b + 31) / 32) * ((G.RS * d->W + 31) / 32) : NW;
-    G.part_floats = (tiles_a < NW || tiles_b < NW) ? 8 * 1024 : 0;
-    const size_t strip = (size_t)d->C * G.Hs * d->W;
-    const size_t wfl = (size_t)d->Cout_a * G.kbp_a + (d->wb ? (size_t)d->Cout_b * G.kbp_b : 0);
-    const size_t pfl = (d->stats ? (size_t)((d->parts * d->groups * 3 + 3) & ~3) : 0) + (d->x2 ? (size_t)((d->parts2 * d->groups * 3 + 3) & ~3) : 0);
-    size_t fl = 64 + pfl + 4 * (size_t)((d->groups + 3) & ~3) + 8 * (size_t)Cp + ((strip + 3) & ~3) +
-                (((size_t)d->Cout_a * G.RS * d->W + 3) & ~3) + (d->wb ? (((size_t)d->Cout_b * G.RS * d->W + 3) & ~3) : 0) + wfl;
-    if (fl + G.part_floats > kLdsFloats) G.part_floats = 0;
+    int mz = 1;
+    size_t fl = 0, strip = 0;
+    // rows per workgroup: as asked (the consumer counts on the strips it was told), else 64 output pixels, halved until
+    // the strip (registers of the loader threads, LDS) and the weight slice fit
+    int rs = d->rows_per_block > 0 ? d->rows_per_block : (G.Wo_a >= 64 ? 1 : 64 / G.Wo_a);
+    for (bool ok = false; !ok; rs /= 2) {
+        if (rs < 1) return IVLN_E_UNSUPPORTED;
+        G.RS = rs > G.Ho_a ? G.Ho_a : rs;
+        if (d->wb && (G.RS % sb)) G.RS = (G.RS + sb - 1) / sb * sb;  // conv B's rows start on its stride
+        G.RSb = d->wb ? G.RS / sb : 0;
+        G.strips = (G.Ho_a + G.RS - 1) / G.RS;
+        G.Hs = (G.RS - 1) * sa + d->ka;
+        strip = (size_t)d->C * G.Hs * d->W;
+        const size_t base = 64 + pfl + 4 * (size_t)((d->groups + 3) & ~3) + 8 * (size_t)Cp + ((strip + 3) & ~3);
+        // output channels over blockIdx.z until weights + output tiles fit (slices keep whole GroupNorm groups and whole
+        // 32-row MFMA tiles), and further while the grid is small
+        for (mz = 1;; mz *= 2) {
+            G.per_a = (d->Cout_a + mz - 1) / mz;
+            G.per_b = d->wb ? (d->Cout_b + mz - 1) / mz : 0;
+            const bool whole = (mz == 1) || (G.per_a % cpo_a == 0 && G.per_a % 32 == 0 && d->Cout_a % G.per_a == 0 &&
+                                             (!d->wb || (G.per_b % cpo_b == 0 && G.per_b % 32 == 0 && d->Cout_b % G.per_b == 0)));
+            if (!whole) break;
+            const int tiles_a = ((G.per_a + 31) / 32) * ((G.RS * G.Wo_a + 31) / 32);
+            const int tiles_b = d->wb ? ((G.per_b + 31) / 32) * ((G.RSb * G.Wo_b + 31) / 32) : NW;
+            G.part_floats = (tiles_a < NW || tiles_b < NW) ? 8 * 1024 : 0;
+            fl = base + (((size_t)G.per_a * G.RS * G.Wo_a + 3) & ~3) + (d->wb ? (((size_t)G.per_b * G.RSb * G.Wo_b + 3) & ~3) : 0) +
+                 (size_t)G.per_a * G.kbp_a + (d->wb ? (size_t)G.per_b * G.kbp_b : 0);
+            if (fl + G.part_floats > kLdsFloats && fl <= kLdsFloats) G.part_floats = 0;
+            const bool fits = fl + G.part_floats <= kLdsFloats;
+            const bool more = (int64_t)G.strips * d->N * mz * 2 <= 256 && G.per_a >= 64 && G.per_a % 64 == 0 && (!d->wb || G.per_b % 64 == 0);
+            if (fits && !more) {
+                ok = true;
+                break;
+            }
+            if (mz >= 16) {
+                ok = fits;
+                break;
+            }
+        }
+        // loader threads keep their share of the strip in registers (NC_E4 float4 each)
+        if (ok && (size_t)(GT - 64) * NC_E4 * 4 < strip) ok = false;
+        if (!ok && d->rows_per_block > 0) return IVLN_E_UNSUPPORTED;
+    }
     fl += G.part_floats;
-    if (fl > kLdsFloats) return IVLN_E_UNSUPPORTED;
-    // loader threads keep their share of the strip in registers (NC_E4 float4 each)
+    const size_t wfl = (size_t)G.per_a * G.kbp_a + (d->wb ? (size_t)G.per_b * G.kbp_b : 0);
     int nw = (int)((double)NW * wfl / (double)(wfl + strip * (1 + (d->x2 ? 1 : 0) + (d->residual ? 1 : 0))) + 0.5);
     nw = nw < 1 ? 1 : (nw > NW - 2 ? NW - 2 : nw);
     while (nw > 1 && (size_t)(GT - 64 * nw) * NC_E4 * 4 < strip) --nw;
@@ -904,7 +962,7 @@ int ivln_nconv_f32(const ivln_nconv_desc* d, void* stream) {
             raised.insert((const void*)fn);
         }
     }
-    hipLaunchKernelGGL(fn, dim3(G.strips, d->N), dim3(GT), fl * sizeof(float), (hipStream_t)stream, *d, G);
+    hipLaunchKernelGGL(fn, dim3(G.strips, d->N, mz), dim3(GT), fl * sizeof(float), (hipStream_t)stream, *d, G);
     return hipGetLastError() == hipSuccess ? IVLN_OK : IVLN_E_HIP;
 }
 

@@ -300,9 +300,9 @@ class _ResNet50GN(nn.Module):
             act = r0[0] if r0 is not None else \
                 ops.pool2d(ops.groupnorm(y, gn.weight, gn.bias, gn.num_groups, gn.eps, relu=True), 3, 2, 1, "max")
             nxt = feeds(blocks[first]) if first < len(blocks) else dict(conv_a=tail)
-            done = 0  # leading stride-1 blocks (layer 1) as ivln_nconv_f32 launches; a strided block ends that run
-            while ops.NCONV_FRONT and done < first and blocks[done].stride == 1:
-                done += 1
+            # the leading blocks as ivln_nconv_f32 launches (layer 1, or more: NCONV_BLOCKS), then pairs up to `first`
+            nb_auto = ops.NCONV_BLOCKS if ops.NCONV_BLOCKS >= 0 else (3 if x.shape[0] <= 5 else 7)
+            done = min(first, nb_auto) if ops.NCONV_FRONT else 0
             r = self._front_blocks_nconv(blocks[:done], act, nxt if done == first else None) if done else None
             if r is not None and done < first:
                 act, r = r, None  # (the run ended before the chain starts: `r` is the activated output of its last block)
@@ -349,19 +349,17 @@ class _ResNet50GN(nn.Module):
         `nxt`: what the chain's first launch has to emit.  Returns that launch's result, or None (a stride or a shape
         outside the kernel's envelope: the caller runs the conv + GroupNorm pairs).  With `nxt` None the run ends before
         the chain starts: the activated output of the last block is returned instead."""
-        if any(b.stride != 1 for b in blocks):
-            return None
         identity, x1, xds = act, None, None
         for i, blk in enumerate(blocks):
             c = blk.convs
             G1, G3 = c[1].num_groups, c[7].num_groups
             if i == 0:  # first block: its convs read the activated tensor as it is
-                ds = None if blk.downsample is None else (blk.downsample[0].weight, blk.downsample[1].num_groups)
+                ds = None if blk.downsample is None else (blk.downsample[0].weight, blk.downsample[1].num_groups, blk.stride)
                 r = ops.nconv(act, None, relu=False, conv_a=(c[0].weight, G1), conv_b=ds)
                 if r is None:
                     return None
                 x1, xds = r[1], r[2]
-            r = ops.nconv(x1, c[1], conv_a=(c[3].weight, c[4].num_groups))      # GroupNorm 1 + ReLU on load -> 3x3
+            r = ops.nconv(x1, c[1], conv_a=(c[3].weight, c[4].num_groups, blk.stride))  # GroupNorm 1 + ReLU on load -> 3x3
             if r is None:
                 return None
             r = ops.nconv(r[1], c[4], conv_a=(c[6].weight, G3))                  # GroupNorm 2 + ReLU on load -> 1x1
@@ -371,7 +369,7 @@ class _ResNet50GN(nn.Module):
             tail = dict(x2=xds, gn2=blk.downsample[1]) if blk.downsample is not None else dict(residual=identity)
             if i + 1 < len(blocks):  # the block's tail is built on load by the next block's first conv(s)
                 nb = blocks[i + 1]
-                ds = None if nb.downsample is None else (nb.downsample[0].weight, nb.downsample[1].num_groups)
+                ds = None if nb.downsample is None else (nb.downsample[0].weight, nb.downsample[1].num_groups, nb.stride)
                 r = ops.nconv(x3, c[7], conv_a=(nb.convs[0].weight, nb.convs[1].num_groups), conv_b=ds,
                               want_act=nb.downsample is None, **tail)
                 if r is None:

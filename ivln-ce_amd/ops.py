@@ -546,6 +546,8 @@ CHAIN_GN_CONV = os.environ.get("IVLN_GN_CONV", "1") != "0"
 CHAIN_MAX_IMAGES = int(os.environ.get("IVLN_GN_CONV_MAX_IMAGES", "8"))
 # the bottlenecks before the chain (layer 1) as ivln_nconv_f32 launches: GroupNorm on load, statistics out, no slabs
 NCONV_FRONT = os.environ.get("IVLN_NCONV_FRONT", "1") != "0"
+NCONV_BLOCKS = int(os.environ.get("IVLN_NCONV_BLOCKS", "-1"))  # bottlenecks from the stem that run this way; -1: layer 1 (3) up to
+# 5 images, layers 1-2 (7) beyond (measured at 8 envs: 1.017 -> 0.997 ms per step; at 4 envs the slab chain wins layer 2)
 NCONV_ROWS = int(os.environ.get("IVLN_NCONV_ROWS", "0"))  # output rows per workgroup (0: 64 pixels)
 # first bottleneck (0..16) that runs in the chain; earlier ones (large feature maps: 16 partial slabs of a 32x32 map
 # are more traffic than the launches they save) stay conv + GroupNorm pairs.  0 = the whole backbone incl. the stem;
@@ -641,7 +643,7 @@ class NconvDesc(C.Structure):
         ("act_out", vp),
         ("wa", vp), ("Cout_a", i32), ("ka", i32), ("groups_a", i32), ("ya", vp), ("stats_a", vp),
         ("wb", vp), ("Cout_b", i32), ("groups_b", i32), ("yb", vp), ("stats_b", vp),
-        ("rows_per_block", i32),
+        ("rows_per_block", i32), ("stride_a", i32), ("stride_b", i32),
     ]
 
 
@@ -661,7 +663,7 @@ class RawStats:
 def nconv(x, gn=None, x2=None, gn2=None, residual=None, relu=True, want_act=False, conv_a=None, conv_b=None, rows_per_block=0):
     """Conv with GroupNorm on its input applied on load and the GroupNorm statistics of its output(s) emitted as partials
     (csrc/gn_conv.hip k_nconv): in = act(GN(x) [+ GN2(x2)] [+ residual]); conv_a = (weight (Co, C, k, k), groups of the
-    GroupNorm that follows) with k = 1 | 3, stride 1, pad (k-1)/2; conv_b likewise (1x1).  x: a `RawStats` with `gn`, or an
+    GroupNorm that follows[, stride 1 | 2]) with k = 1 | 3, pad (k-1)/2; conv_b likewise (1x1; needs a stride-1 conv_a).  x: a `RawStats` with `gn`, or an
     activated NCHW tensor (gn None).  Returns (act | None, RawStats a, RawStats b | None), or None outside the envelope."""
     d = NconvDesc()
     xt = x.y if isinstance(x, RawStats) else x
@@ -681,31 +683,43 @@ def nconv(x, gn=None, x2=None, gn2=None, residual=None, relu=True, want_act=Fals
     d.N, d.C, d.H, d.W, d.relu = N, Cc, H, W, int(bool(relu))
     act = torch.empty((N, Cc, H, W), dtype=torch.float32, device=dev) if want_act else None
     d.act_out = _p(act)
-    rs = rows_per_block if rows_per_block > 0 else (NCONV_ROWS if NCONV_ROWS > 0 else (1 if W >= 64 else 64 // W))
-    rs = min(rs, H)
-    strips = (H + rs - 1) // rs
-    d.rows_per_block = rs
-    outs = []
-    for key, cw in (("a", conv_a), ("b", conv_b)):
-        if cw is None:
-            outs.append(None)
-            continue
-        w, g_out = cw
-        Co = w.shape[0]
-        y = torch.empty((Co, N, H, W), dtype=torch.float32, device=dev)
-        st = torch.empty((strips, N, g_out, 3), dtype=torch.float32, device=dev)
-        if key == "a":
-            d.wa, d.Cout_a, d.ka, d.groups_a, d.ya, d.stats_a = dptr(w), Co, w.shape[2], g_out, _p(y), _p(st)
-        else:
-            d.wb, d.Cout_b, d.groups_b, d.yb, d.stats_b = dptr(w), Co, g_out, _p(y), _p(st)
-        outs.append(RawStats(y, st, strips, g_out))
+    def cw3(cw):  # (weight, groups of the following GroupNorm[, stride])
+        return (cw[0], cw[1], cw[2] if len(cw) > 2 else 1)
+
+    wa, ga, sa = cw3(conv_a)
+    k = wa.shape[2]
+    Ho, Wo = (H + 2 * (k // 2) - k) // sa + 1, (W + 2 * (k // 2) - k) // sa + 1
+    sb = cw3(conv_b)[2] if conv_b is not None else 1
+    rs = rows_per_block if rows_per_block > 0 else (NCONV_ROWS if NCONV_ROWS > 0 else (1 if Wo >= 64 else 64 // Wo))
+    rs = min(rs, Ho)
+    ya = torch.empty((wa.shape[0], N, Ho, Wo), dtype=torch.float32, device=dev)
+    d.wa, d.Cout_a, d.ka, d.groups_a, d.ya = dptr(wa), wa.shape[0], k, ga, _p(ya)
+    yb = None
+    if conv_b is not None:
+        wb, gb, _ = cw3(conv_b)
+        yb = torch.empty((wb.shape[0], N, (H - 1) // sb + 1, (W - 1) // sb + 1), dtype=torch.float32, device=dev)
+        d.wb, d.Cout_b, d.groups_b, d.yb = dptr(wb), wb.shape[0], gb, _p(yb)
     L = _L()
     L.ivln_nconv_f32.argtypes = [C.POINTER(NconvDesc), vp]
-    code = L.ivln_nconv_f32(C.byref(d), stream_ptr())
-    if code == IVLN_E_UNSUPPORTED:
-        return None
+    while True:  # rows per workgroup: halved until the strip and the weight slice fit the workgroup
+        if conv_b is not None and rs % sb:
+            rs = (rs + sb - 1) // sb * sb
+        strips = (Ho + rs - 1) // rs
+        d.rows_per_block, d.stride_a, d.stride_b = rs, sa, sb
+        sta = torch.empty((strips, N, ga, 3), dtype=torch.float32, device=dev)
+        d.stats_a = _p(sta)
+        stb = None
+        if conv_b is not None:
+            stb = torch.empty((strips, N, gb, 3), dtype=torch.float32, device=dev)
+            d.stats_b = _p(stb)
+        code = L.ivln_nconv_f32(C.byref(d), stream_ptr())
+        if code != IVLN_E_UNSUPPORTED:
+            break
+        if rows_per_block > 0 or rs <= sb:
+            return None
+        rs //= 2
     check(code, "ivln_nconv_f32")
-    return act, outs[0], outs[1]
+    return act, RawStats(ya, sta, strips, ga), (RawStats(yb, stb, strips, gb) if conv_b is not None else None)
 
 
 class CmaStepDesc(C.Structure):

@@ -174,7 +174,8 @@ def test_refuses_shapes_outside_its_envelope():
     assert ops.gn_conv(_slabs(torch.randn(1, 32, 96, 96, generator=g), 1, g), _gn(32, 16, g).to(DEV), conv_a=(w, 1, 0)) is None  # tile > LDS budget
 
 
-@pytest.mark.parametrize("B,first,pair", [(1, 0, 16), (4, 0, 0), (8, 0, 16), (4, 3, 7), (4, 7, 7), (2, 16, 16), (8, 3, 3), (4, 3, 13)])
+@pytest.mark.parametrize("B,first,pair", [(1, 0, 16), (4, 0, 0), (8, 0, 16), (4, 3, 7), (4, 7, 7), (2, 16, 16), (8, 3, 3), (4, 3, 13),
+                                          (8, -1, 16), (4, -1, 16), (6, 9, 16)])
 def test_depth_encoder_chain_matches_pairwise_path_and_oracle(B, first, pair):
     """The whole ResNetEncoder through the gn_conv chain == the deferred conv + GroupNorm pairs == the oracle's
     torch restatement (oracle/habitat_ext_ref.py), random-init weights, fp32."""
@@ -221,6 +222,9 @@ def test_depth_encoder_chain_matches_pairwise_path_and_oracle(B, first, pair):
     (2, 128, 32, 32, (32, 1), None, "gn_residual"),     # tail of an identity block
     (3, 64, 16, 16, (32, 3), None, "gn"),               # 16x16 maps: four rows per strip
     (1, 16, 8, 12, (6, 3), (10, 1), "gn_residual"),     # odd sizes, ragged last strip (rows_per_block 5)
+    (2, 64, 32, 32, (64, 3, 2), None, "gn"),            # layer2.0 conv2: 3x3 stride 2
+    (2, 128, 32, 32, (64, 1), (256, 1, 2), "gn_residual"),  # layer1 tail -> layer2.0 conv1 + stride-2 downsample
+    (2, 64, 16, 16, (256, 1), None, "gn"),              # 256 output channels: split over blockIdx.z
 ])
 def test_conv_with_groupnorm_on_load_and_statistics_out(N, Cc, H, W, ca, cb, mode):
     """ivln_nconv_f32: in = relu(GN(x) [+ GN2(x2)] [+ res]) built on load from the producer's (count, mean, M2)
@@ -268,15 +272,17 @@ def test_conv_with_groupnorm_on_load_and_statistics_out(N, Cc, H, W, ca, cb, mod
         xin = x.to(DEV)
     ref = ref.detach()
     ga = 16 if ca[0] % 32 == 0 else (2 if ca[0] % 2 == 0 else 1)
+    sa = ca[2] if len(ca) > 2 else 1
     wa = torch.randn(ca[0], Cc, ca[1], ca[1], generator=g) / (Cc * ca[1] ** 2) ** 0.5
-    ref_a = F.conv2d(ref, wa, None, 1, ca[1] // 2)
+    ref_a = F.conv2d(ref, wa, None, sa, ca[1] // 2)
     conv_b = ref_b = None
     if cb is not None:
         gb = 16 if cb[0] % 32 == 0 else 2
+        sb = cb[2] if len(cb) > 2 else 1
         wb = torch.randn(cb[0], Cc, 1, 1, generator=g) / Cc ** 0.5
-        ref_b = F.conv2d(ref, wb)
-        conv_b = (wb.to(DEV), gb)
-    r = ops.nconv(xin, gn, relu=(mode != "plain_in"), want_act=(mode != "plain_in"), conv_a=(wa.to(DEV), ga), conv_b=conv_b,
+        ref_b = F.conv2d(ref, wb, None, sb)
+        conv_b = (wb.to(DEV), gb, sb)
+    r = ops.nconv(xin, gn, relu=(mode != "plain_in"), want_act=(mode != "plain_in" and sa == 1), conv_a=(wa.to(DEV), ga, sa), conv_b=conv_b,
                   rows_per_block=rs, **kw)
     assert r is not None, "shape must be inside the kernel's envelope"
     act, a, b = r
