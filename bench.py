@@ -34,7 +34,7 @@ import torch  # noqa: E402
 METRIC = "env-steps/sec (batched MapCMA fwd+bwd) at 1/2/4/8 MI355X; t-nDTW parity"
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
 PEAK_HBM_GBS = 8000.0  # same guide: HBM3E 8 TB/s spec (6.3 TB/s achievable)
-MFMA_FAMILY = "fp32 MFMA family (k_gemm / k_gemm_vec / k_conv_direct / k_gn_conv)"
+MFMA_FAMILY = "fp32 MFMA family (k_gemm / k_gemm_vec / k_conv_direct / k_gn_conv / k_nconv)"
 
 
 def log(*a):
@@ -111,13 +111,31 @@ class GemmTimer:
                         self.flops += 2 * w.shape[0] * (y.N * y.H * y.W) * w.shape[1] * w.shape[2] * w.shape[3]
             return r
 
+        self.orig_nconv = ops.nconv
+
+        def timed_nconv(x, gn=None, **kw):
+            """GroupNorm-on-load conv of layer 1 (k_nconv): full-K convs on the matrix cores"""
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            r = self.orig_nconv(x, gn, **kw)
+            b.record()
+            if r is not None:
+                self.events.append((a, b))
+                for y, cw in ((r[1], kw.get("conv_a")), (r[2], kw.get("conv_b"))):
+                    if y is not None:
+                        w = cw[0]
+                        self.flops += 2 * w.shape[0] * (y.y.shape[1] * y.y.shape[2] * y.y.shape[3]) * w.shape[1] * w.shape[2] * w.shape[3]
+            return r
+
         ops.gemm = timed
         ops.gn_conv = timed_gn_conv
+        ops.nconv = timed_nconv
         return self
 
     def __exit__(self, *a):
         self.ops.gemm = self.orig
         self.ops.gn_conv = self.orig_gn_conv
+        self.ops.nconv = self.orig_nconv
 
     def total_ms(self):
         """Sum of the event-pair times.  A pair brackets one launch on the launch stream, so it carries the

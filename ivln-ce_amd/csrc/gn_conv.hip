@@ -620,39 +620,38 @@ __global__ __launch_bounds__(GT) void k_nconv(const NDesc D, const NGeo G) {
     // ---- per-channel scale / shift of this image ----
     if (D.stats) {
         // merge the partials: a DPP row of 16 lanes per group (lane = part) when there are at most 16 parts - no loop -,
-        // threads [0, 256) for x and [256, 512) for x2; otherwise one thread per group walks its parts
-        const int half_t = tid & 255, which = tid >> 8;
+        // threads [0, 256) for x and [256, 512) for x2; otherwise one thread per group walks its parts.  Every lane of
+        // the row ends up with the group's mean / rstd, so the row writes its channels' scale / shift straight away.
+        const int half_t = tid & 255, which = tid >> 8, cpg = C / D.groups;
         if (which == 0 || D.x2) {
             const float* ps = which ? pst + pfl : pst;
             const int np_ = which ? D.parts2 : D.parts;
-            float* go = gst + which * 2 * D.groups;
+            float* sc_o = tab + which * 2 * Cp;
+            const float* ga_i = gab + which * 2 * Cp;
             if (np_ <= 16 && D.groups <= 16) {
                 const int g = half_t >> 4, pp = half_t & 15;
                 const bool have = g < D.groups && pp < np_;
                 const float* q = ps + (pp * D.groups + (g < D.groups ? g : 0)) * 3;
-                const float nb = have ? q[0] : 0.f, mb = have ? q[1] : 0.f, Mb = have ? q[2] : 0.f;
-                const float cnt = row_sum16(nb), mean = row_sum16(nb * mb) / cnt;
+                const float nb_ = have ? q[0] : 0.f, mb = have ? q[1] : 0.f, Mb = have ? q[2] : 0.f;
+                const float cnt = row_sum16(nb_), mean = row_sum16(nb_ * mb) / cnt;
                 const float dd = mb - mean;
-                const float M2 = row_sum16(fmaf(nb * dd, dd, Mb));
-                if (pp == 0 && g < D.groups) {
-                    go[2 * g] = mean;
-                    go[2 * g + 1] = rsqrtf(M2 / cnt + D.eps);
-                }
+                const float rstd = rsqrtf(row_sum16(fmaf(nb_ * dd, dd, Mb)) / cnt + D.eps);
+                if (g < D.groups)
+                    for (int cc = pp; cc < cpg; cc += 16) {
+                        const int c = g * cpg + cc;
+                        const float sc = ga_i[c] * rstd;
+                        sc_o[c] = sc;
+                        sc_o[Cp + c] = ga_i[Cp + c] - mean * sc;
+                    }
             } else if (half_t < D.groups) {
-                merge_stats(ps, np_, D.groups, half_t, D.eps, go[2 * half_t], go[2 * half_t + 1]);
-            }
-        }
-        __syncthreads();
-        const fdiv by_cpg(C / D.groups);
-        for (int c = tid; c < C; c += GT) {
-            const int g = by_cpg(c);
-            const float sc = gab[c] * gst[2 * g + 1];
-            tab[c] = sc;
-            tab[Cp + c] = gab[Cp + c] - gst[2 * g] * sc;
-            if (D.x2) {
-                const float s2 = gab[2 * Cp + c] * gst[2 * D.groups + 2 * g + 1];
-                tab[2 * Cp + c] = s2;
-                tab[3 * Cp + c] = gab[3 * Cp + c] - gst[2 * D.groups + 2 * g] * s2;
+                float mean, rstd;
+                merge_stats(ps, np_, D.groups, half_t, D.eps, mean, rstd);
+                for (int cc = 0; cc < cpg; ++cc) {
+                    const int c = half_t * cpg + cc;
+                    const float sc = ga_i[c] * rstd;
+                    sc_o[c] = sc;
+                    sc_o[Cp + c] = ga_i[Cp + c] - mean * sc;
+                }
             }
         }
         __syncthreads();

@@ -6,7 +6,7 @@ import csv
 import json
 import sys
 
-MFMA = ("k_gemm", "k_conv_direct", "k_wgrad", "k_conv_gn", "k_gn_conv")
+MFMA = ("k_gemm", "k_conv_direct", "k_wgrad", "k_conv_gn", "k_gn_conv", "k_nconv")
 MAPPER = ("k_local_", "k_world_", "k_finalize", "k_frames")
 
 
