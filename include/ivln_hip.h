@@ -43,10 +43,12 @@ int ivln_mapper_destroy(ivln_mapper* m);
 /* Forget the world cloud (new process / new eval). */
 int ivln_mapper_reset(ivln_mapper* m, void* stream);
 
-/* Launch width of the step's kernels: the local-cloud kernels on `local_blocks` workgroups and the world-cloud kernels
- * on `world_blocks` (0 = full width: one chunk of 1024 pixels per workgroup / 1024 workgroups).  Results do not depend
- * on it.  A mapper that runs BESIDE a latency-bound kernel chain on another stream (the depth ResNet of the rollout
- * step) should be narrow - e.g. 64 / 32: it then takes ~150 instead of ~60 us but leaves the chip to the chain. */
+/* Launch width of the step's kernels: the local-cloud kernels on `local_blocks` workgroups; the world-cloud kernels on
+ * at most `world_blocks` workgroups that take 16 points per thread, so that they cover few CUs while the cloud is
+ * small and more as it grows (0, 0 = full width: one chunk of 1024 pixels per workgroup / up to 1024 workgroups, one
+ * point per thread).  Results do not depend on it.  A mapper that runs BESIDE a latency-bound kernel chain on another
+ * stream (the depth ResNet of the rollout step) should be narrow - e.g. 16 per env / 256: it then takes ~140 instead
+ * of ~60 us at 4 envs but leaves the chip to the chain. */
 int ivln_mapper_set_launch_width(ivln_mapper* m, int local_blocks, int world_blocks);
 
 /* core.py:6-37 (_transform3D with elevation + pi, mapper.py:132-138) and mapper.py:38-48

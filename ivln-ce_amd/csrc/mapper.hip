@@ -295,6 +295,13 @@ __global__ __launch_bounds__(kThreads) void k_local_select(const Cam cm, const u
     block_minmax_store(rmin, cmin, rmax, cmax, bmmA + 4 * blockIdx.x);
 }
 
+// workgroups of a world-cloud kernel that take part: enough for `wpt` points per thread, at most the grid
+__device__ __forceinline__ unsigned working_blocks(unsigned n, int wpt) {
+    const unsigned per = (unsigned)kThreads * (unsigned)(wpt > 0 ? wpt : 1);
+    const unsigned need = (n + per - 1) / per;
+    return need < 1u ? 1u : (need < gridDim.x ? need : gridDim.x);
+}
+
 __device__ __forceinline__ bool world_alive(const Pt& p, unsigned i, unsigned cnt_old, int B, const uint8_t* not_done) {
     const int b = (int)(p.meta >> 8);
     if (i >= cnt_old) return true;  // appended this step
@@ -311,7 +318,7 @@ __global__ __launch_bounds__(kThreads) void k_world_max(const Pt* __restrict__ w
                                                         int B, const uint8_t* __restrict__ not_done, float half_res,
                                                         Scalars* sc, unsigned long long* __restrict__ tab64,
                                                         int64_t table_cells, unsigned capacity,
-                                                        const int* __restrict__ bmmA, int n_partials) {
+                                                        const int* __restrict__ bmmA, int n_partials, int wpt) {
     __shared__ int mm[4];
     block_minmax_fold(bmmA, n_partials, sc->mmWold, mm, sc->mmW);
     const int cur = sc->cur;
@@ -319,7 +326,9 @@ __global__ __launch_bounds__(kThreads) void k_world_max(const Pt* __restrict__ w
     const int64_t* rsrc = cur ? r1 : r0;
     const unsigned n = min(sc->cnt[cur], capacity);
     const unsigned cnt_old = sc->cnt_old;
-    for (unsigned i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
+    const unsigned nbw = working_blocks(n, wpt);  // (a narrow launch grows with the cloud: wpt points per thread)
+    if (blockIdx.x >= nbw) return;
+    for (unsigned i = blockIdx.x * kThreads + threadIdx.x; i < n; i += nbw * kThreads) {
         const Pt p = wsrc[i];
         if (!world_alive(p, i, cnt_old, B, not_done)) continue;
         const int64_t key = make_key((int)(p.meta >> 8), cell_index(p.z, half_res), cell_index(p.x, half_res), mm);
@@ -364,7 +373,7 @@ __global__ __launch_bounds__(kThreads) void k_world_select(
     Pt* w0, Pt* w1, int64_t* r0, int64_t* r1, int B, const uint8_t* __restrict__ not_done, float half_res, Scalars* sc, unsigned long long* __restrict__ tab64,
     int64_t table_cells, unsigned capacity, const float* __restrict__ pose, const float* __restrict__ rot, int rows,
     int cols, float res, float half_h, float half_w, uint8_t* __restrict__ occ, unsigned long long* __restrict__ cell,
-    int* __restrict__ bbox, int bbox_B) {
+    int* __restrict__ bbox, int bbox_B, int wpt) {
     __shared__ int box[kBoxEnvs][4];
     for (int i = threadIdx.x; i < B * 4; i += kThreads) box[i >> 2][i & 3] = (i & 2) ? INT32_MIN : INT32_MAX;
     __syncthreads();
@@ -375,9 +384,10 @@ __global__ __launch_bounds__(kThreads) void k_world_select(
     int64_t* rdst = cur ? r0 : r1;
     const unsigned n = min(sc->cnt[cur], capacity);
     const unsigned cnt_old = sc->cnt_old;
-    const unsigned iters = (n + gridDim.x * kThreads - 1) / (gridDim.x * kThreads);
+    const unsigned nbw = working_blocks(n, wpt);
+    const unsigned iters = blockIdx.x < nbw ? (n + nbw * kThreads - 1) / (nbw * kThreads) : 0;  // (idle blocks leave empty boxes)
     for (unsigned it = 0; it < iters; ++it) {
-        const unsigned i = (it * gridDim.x + blockIdx.x) * kThreads + threadIdx.x;
+        const unsigned i = (it * nbw + blockIdx.x) * kThreads + threadIdx.x;
         bool win = false;
         Pt p;
         p.x = p.y = p.z = 0.f;
@@ -711,12 +721,15 @@ int ivln_mapper_step(ivln_mapper* m, const float* depth, const uint8_t* labels, 
                        m->bbox, m->B_max, not_done);
     hipLaunchKernelGGL(k_local_select, dim3(lb), dim3(kThreads), 0, s, cm, labels, m->sc, m->tab64, m->table_cells,
                        m->wbuf[0], m->wbuf[1], m->rbuf[0], m->rbuf[1], cap, m->bmmA);
+    // world-cloud kernels: full width = up to 1024 workgroups, one point per thread; a narrow launch (set_launch_width) =
+    // at most world_blocks workgroups that take 16 points per thread, so few CUs while the cloud is small
     const int wb = (m->world_blocks > 0 && m->world_blocks < kWorldBlocks) ? m->world_blocks : kWorldBlocks;
+    const int wpt = m->world_blocks > 0 ? 16 : 1;
     hipLaunchKernelGGL(k_world_max, dim3(wb), dim3(kThreads), 0, s, m->wbuf[0], m->wbuf[1], m->rbuf[0],
-                       m->rbuf[1], B, not_done, m->half_res, m->sc, m->tab64, m->table_cells, cap, m->bmmA, lb);
+                       m->rbuf[1], B, not_done, m->half_res, m->sc, m->tab64, m->table_cells, cap, m->bmmA, lb, wpt);
     hipLaunchKernelGGL(k_world_select, dim3(wb), dim3(kThreads), 0, s, m->wbuf[0], m->wbuf[1], m->rbuf[0],
                        m->rbuf[1], B, not_done, m->half_res, m->sc, m->tab64, m->table_cells, cap, pose, rot, m->rows,
-                       m->cols, m->res, m->half_h, m->half_w, occ_out, m->cell, m->bbox, m->B_max);
+                       m->cols, m->res, m->half_h, m->half_w, occ_out, m->cell, m->bbox, m->B_max, wpt);
     const int fin_blocks = (map_cells + kThreads - 1) / kThreads;
     hipLaunchKernelGGL(k_finalize, dim3(fin_blocks), dim3(kThreads), 0, s, m->cell, sem_out, map_cells, m->sc, 1, cap,
                        wb, B);

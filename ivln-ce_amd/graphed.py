@@ -201,7 +201,9 @@ class GraphedRollout:
         # A ground-truth-semantics mapper runs beside the depth-ResNet chain with time to spare (gB1 285 us, gA 580):
         # launched narrow it takes ~150 instead of ~60 us but no longer crowds the chain off the CUs (0.767 -> 0.731
         # ms per step at 4 envs).  With predicted semantics RedNet -> mapper IS the critical path: full width.
-        lw = os.environ.get("IVLN_MAPPER_WIDTH", "64,32")
+        # Width: 16 workgroups per env for the local-cloud kernels; the world-cloud kernels may use as many
+        # but take 16 points per thread, i.e. 27 workgroups at 109 k points and more only as the cloud grows.
+        lw = os.environ.get("IVLN_MAPPER_WIDTH", f"{16 * B},{16 * B}")
         for t in self.transforms:
             mm = getattr(t, "mapping_module", None)
             if mm is not None and hasattr(mm, "set_launch_width"):
