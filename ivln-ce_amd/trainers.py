@@ -149,6 +149,10 @@ class TrajectoryStore:
     def __len__(self):
         return len([f for f in os.listdir(self.path) if f.endswith(".npz")])
 
+    def entries(self):
+        """lmdb's `stat()["entries"]`: every key, the tour table under "0" included."""
+        return len(self) + int(os.path.exists(os.path.join(self.path, "0.json")))
+
     def clear(self):
         for f in os.listdir(self.path):
             if f.endswith(".npz") or f == "0.json":
@@ -290,6 +294,7 @@ class BaseVLNCETrainer:
         self.device = torch.device("cuda", self.local_rank if self.world > 1 else config.TORCH_GPU_ID)
         self.obs_transforms = []
         self.start_epoch = 0
+        self.start_dagger_it = 0
         self.step_id = 0
         self.flush_secs = 30
 
@@ -325,6 +330,7 @@ class BaseVLNCETrainer:
             if config.IL.is_requeue:
                 self.optimizer.load_state_dict(ckpt["optim_state"])
                 self.start_epoch = ckpt["epoch"] + 1
+                self.start_dagger_it = ckpt.get("dagger_it", 0)
                 self.step_id = ckpt["step_id"]
 
     def save_checkpoint(self, file_name, dagger_it=0, epoch=0, step_id=0):
@@ -423,58 +429,235 @@ class BaseVLNCETrainer:
             out.append(self._eval_checkpoint(os.path.join(path, f), None, i))
         return out
 
-    def _eval_checkpoint(self, checkpoint_path, writer=None, checkpoint_index=0):
-        """Episodic / iterative evaluation (base_il_trainer.py:313-583, 585-928): deterministic
-        policy, per-episode stats aggregated over all envs, dtw_data dumped per tour and t-nDTW
-        against the gt paths; map reset follows EVAL.ITERATIVE_MAP_RESET through the masks handed to
-        the mapper.  Scenes/envs are sharded over ranks; rank 0 merges."""
-        D.init()
-        config = self.config
-        split = config.EVAL.SPLIT
-        iterative = bool(config.TASK_CONFIG.ENVIRONMENT.ITERATIVE.ENABLED)
-        prefix = "iterative_stats" if iterative else "stats"
-        if iterative:
-            assert config.EVAL.ITERATIVE_MAP_RESET in ["episodic", "iterative"], "config.EVAL.ITERATIVE_MAP_RESET not valid"
-        if config.EVAL.SAVE_RESULTS:
-            self._make_results_dir()
-            fname = os.path.join(config.RESULTS_DIR, f"{prefix}_ckpt_{checkpoint_index}_{split}.json")
-            if os.path.exists(fname):
-                return json.load(open(fname))
-        envs = construct_envs(config, None, auto_reset_done=False, rank=self.rank, world=self.world)
+    def _setup_eval_config(self, checkpoint_config):
+        """BaseILTrainer._setup_eval_config (habitat-lab, Appendix D): the checkpoint's config, overlaid with the
+        evaluation config and both command-line option lists."""
+        config = self.config.clone()
+        config.defrost()
+        ckpt_opts = list(getattr(checkpoint_config, "CMD_TRAILING_OPTS", []) or [])
+        eval_opts = list(getattr(config, "CMD_TRAILING_OPTS", []) or [])
+        config.merge_from_other_cfg(checkpoint_config)
+        config.merge_from_other_cfg(self.config)
+        config.merge_from_list(ckpt_opts)
+        config.merge_from_list(eval_opts)
+        config.freeze()
+        return config
+
+    def _load_eval_policy(self, config, envs, checkpoint_path):
         observation_space, action_space = self._get_spaces(config, envs=envs)
         self._initialize_policy(config, load_from_ckpt=False, observation_space=observation_space,
                                 action_space=action_space)
+        # (the reference requires the file; evaluating a freshly initialised policy is how the synthetic runs work)
         if checkpoint_path and os.path.exists(checkpoint_path):
             self.policy.load_state_dict(self.load_checkpoint(checkpoint_path, map_location="cpu")["state_dict"])
         self.policy.eval()
+
+    def _eval_checkpoint(self, checkpoint_path, writer=None, checkpoint_index=0, metrics=None):
+        """Evaluate one checkpoint (base_il_trainer.py:313-583; dispatches to `_eval_checkpoint_iterative` when
+        TASK_CONFIG.ENVIRONMENT.ITERATIVE.ENABLED).  The loop is the reference's, statement for statement - envs
+        constructed with auto-reset off, `reset_at` after every finished episode, an env paused once its next episode
+        has already been scored - and pinned to a run of the reference's own loop (tests/golden/iterative_golden.json,
+        case "episodic").  MI355X-native differences: mapper + `policy.act` replay as captured hipGraphs when the step
+        is eligible (`_graph_eligible`); envs are sharded over ranks and rank 0 merges the statistics.  Returns the
+        aggregated statistics (the reference returns None)."""
+        import contextlib
+
+        D.init()
+        if metrics is None:
+            metrics = "distance_to_goal success spl ndtw path_length oracle_success steps_taken".split()
+        with contextlib.suppress(Exception):  # sometimes the index does not align with the actual ckpt number
+            checkpoint_index = int(checkpoint_path.split(".")[-2])
+        if checkpoint_index < getattr(self.config.EVAL, "START_FROM", 0):
+            return None
+        if self.config.EVAL.USE_CKPT_CONFIG:
+            config = self._setup_eval_config(self.load_checkpoint(checkpoint_path, map_location="cpu")["config"])
+        else:
+            config = self.config.clone()
+        config.defrost()
+        config.TASK_CONFIG.DATASET.SPLIT = config.EVAL.SPLIT
+        config.TASK_CONFIG.DATASET.ROLES = ["guide"]
+        config.TASK_CONFIG.DATASET.LANGUAGES = config.EVAL.LANGUAGES
+        config.TASK_CONFIG.TASK.NDTW.SPLIT = config.EVAL.SPLIT
+        config.TASK_CONFIG.ENVIRONMENT.ITERATOR_OPTIONS.SHUFFLE = False
+        config.TASK_CONFIG.ENVIRONMENT.ITERATOR_OPTIONS.MAX_SCENE_REPEAT_STEPS = -1
+        config.TASK_CONFIG.ENVIRONMENT.ITERATOR_OPTIONS.SHUFFLE_TOURS = False
+        config.TASK_CONFIG.ENVIRONMENT.ITERATOR_OPTIONS.SHUFFLE_EPISODES = False
+        config.IL.ckpt_to_load = checkpoint_path
+        config.use_pbar = False
+        if len(config.VIDEO_OPTION) > 0:
+            os.makedirs(config.VIDEO_DIR, exist_ok=True)
+        config.freeze()
+        if config.TASK_CONFIG.ENVIRONMENT.ITERATIVE.ENABLED:
+            return self._eval_checkpoint_iterative(config, writer, checkpoint_index)
+
+        split = config.TASK_CONFIG.DATASET.SPLIT
+        fname = os.path.join(config.RESULTS_DIR, f"stats_ckpt_{checkpoint_index}_{split}.json")
+        if config.EVAL.SAVE_RESULTS:
+            self._make_results_dir()
+            if os.path.exists(fname):  # "skipping -- evaluation exists."
+                return json.load(open(fname))
+        envs = construct_envs(config, None, auto_reset_done=False, rank=self.rank, world=self.world, iterative=False)
+        self._load_eval_policy(config, envs, checkpoint_path)
         n = envs.num_envs
         rnn_states = torch.zeros(n, self.policy.net.num_recurrent_layers, config.MODEL.STATE_ENCODER.hidden_size,
                                  device=self.device)
         prev_actions = torch.zeros(n, 1, device=self.device, dtype=torch.long)
         not_done_masks = torch.zeros(n, 1, dtype=torch.uint8, device=self.device)
-        tour_masks = torch.zeros(n, 1, dtype=torch.uint8, device=self.device)
-        # iterative evaluation (base_il_trainer.py:585-928): the maps live for a whole tour unless
-        # ITERATIVE_MAP_RESET == "episodic"; the policy gets the episode AND the tour masks (act_iterative)
-        maps_by_tour = iterative and config.EVAL.ITERATIVE_MAP_RESET == "iterative"
-        tour_policy = bool(config.MODEL.tour_memory or config.MODEL.tour_memory_variant)
+        use_graph = self._graph_eligible()
         observations = envs.reset()
-        # a captured step has one policy mask (+ one mapper mask): policies with a tour memory run eagerly
-        use_graph = self._graph_eligible() and not (iterative and tour_policy)
+        observations, batch = self._batch(observations, not_done_masks, transform=not use_graph)
+        stats_episodes = {}
+        episodes_to_eval = sum(envs.number_of_episodes)
+        if config.EVAL.EPISODE_COUNT > -1:
+            episodes_to_eval = min(config.EVAL.EPISODE_COUNT, episodes_to_eval)
+        runner, captured = None, False
+        t0 = time.time()
+        while envs.num_envs > 0 and len(stats_episodes) < episodes_to_eval:
+            current_episodes = envs.current_episodes()
+            if use_graph:  # mapper + policy.act replayed as captured graphs; the state lives in the runner's buffers
+                if runner is None:
+                    runner = self._make_runner(batch, rnn_states, prev_actions, first=not captured)
+                    captured = True
+                actions = runner.step(batch)
+                rnn_states, prev_actions = runner.rnn_states, actions
+            else:
+                with torch.no_grad():
+                    actions, rnn_states = self.policy.act(batch, rnn_states, prev_actions, not_done_masks,
+                                                          deterministic=not config.EVAL.SAMPLE)
+                    prev_actions.copy_(actions)
+            outputs = envs.step([a[0].item() for a in actions])
+            observations, _, dones, infos = [list(x) for x in zip(*outputs)]
+            not_done_masks = torch.tensor([[0] if done else [1] for done in dones], dtype=torch.uint8,
+                                          device=self.device)
+            if any(dones):
+                self._check_mappers()  # episode boundary; the stream was just synchronised by the actions' .item()
+            for i in range(envs.num_envs):  # reset envs and observations if necessary
+                if not dones[i]:
+                    continue
+                stats_episodes[current_episodes[i].episode_id] = {k: infos[i][k] for k in metrics}
+                observations[i] = envs.reset_at(i)[0]
+                prev_actions[i] = torch.zeros(1, dtype=torch.long)
+            observations, batch = self._batch(observations, not_done_masks, transform=not use_graph)
+            next_episodes = envs.current_episodes()
+            envs_to_pause = [i for i in range(envs.num_envs) if next_episodes[i].episode_id in stats_episodes]
+            envs, rnn_states, not_done_masks, prev_actions, batch, _ = self._pause_envs(
+                envs_to_pause, envs, rnn_states, not_done_masks, prev_actions, batch)
+            if envs_to_pause:
+                runner = None  # fewer rows: capture again for the new batch size, seeded with the kept rows
+        self._check_mappers()
+        tours = (envs.dtw_data(), envs.gt_paths()) if hasattr(envs, "dtw_data") else ({}, {})
+        gathered = D.gather_objects((stats_episodes, tours))
+        envs.close()
+        if self.rank != 0:
+            return None
+        stats_episodes, agent_paths, gt_paths = {}, {}, {}
+        for s, (a, g) in gathered:
+            stats_episodes.update(s)
+            agent_paths.update(a)
+            gt_paths.update(g)
+        aggregated_stats = {}
+        num_episodes = len(stats_episodes)
+        for stat_key in next(iter(stats_episodes.values())).keys():
+            aggregated_stats[stat_key] = sum(v[stat_key] for v in stats_episodes.values()) / num_episodes
+        if agent_paths:  # (not in the reference's episodic report) the synthetic env logs whole tours: t-nDTW too
+            aggregated_stats["t_ndtw"] = compute_tour_ndtw(agent_paths, gt_paths,
+                                                           config.TASK_CONFIG.TASK.NDTW.SUCCESS_DISTANCE)
+        if config.EVAL.SAVE_RESULTS:
+            with open(fname, "w") as f:
+                json.dump(aggregated_stats, f, indent=4)
+        if writer is not None:
+            for k, v in aggregated_stats.items():
+                writer.add_scalar(f"eval_{split}_{k}", v, checkpoint_index + 1)
+        return dict(aggregated_stats, episodes=num_episodes, eval_seconds=time.time() - t0)
+
+    def _pause_iterative_envs(self, envs_to_pause, envs, recurrent_hidden_states, agent_episode_not_done_masks,
+                              sim_episode_not_done_masks, tour_not_done_masks, action_masks, prev_actions, batch,
+                              rgb_frames=None):
+        """base_il_trainer.py:258-311: drop the paused envs' rows from every per-env tensor and tell the policy
+        (`net.delete_batch_idx`, the Latent-CMA tour memory) which rows went away."""
+        if len(envs_to_pause) > 0:
+            state_index = list(range(envs.num_envs))
+            for idx in reversed(envs_to_pause):
+                state_index.pop(idx)
+                envs.pause_at(idx)
+            recurrent_hidden_states = recurrent_hidden_states[state_index]
+            agent_episode_not_done_masks = agent_episode_not_done_masks[state_index]
+            sim_episode_not_done_masks = sim_episode_not_done_masks[state_index]
+            tour_not_done_masks = tour_not_done_masks[state_index]
+            action_masks = action_masks[state_index]
+            prev_actions = prev_actions[state_index]
+            for k, v in batch.items():
+                batch[k] = v[state_index] if torch.is_tensor(v) else [v[i] for i in state_index]
+            if rgb_frames is not None:
+                rgb_frames = [rgb_frames[i] for i in state_index]
+            del_idxs_fn = getattr(self.policy.net, "delete_batch_idx", None)
+            if callable(del_idxs_fn):
+                del_idxs_fn(envs_to_pause)
+        return (envs, recurrent_hidden_states, agent_episode_not_done_masks, sim_episode_not_done_masks,
+                tour_not_done_masks, action_masks, prev_actions, batch, rgb_frames)
+
+    def masks_to_tensors(self, agent_episode_dones, sim_episode_dones, tour_dones, produce_actions):
+        """iterative_collection_dagger_trainer.py:82-114 (the eval loop builds the same four, :715-744): (n, 1) uint8
+        agent-episode / sim-episode / tour not-done masks and the action mask."""
+        def nd(dones):
+            return torch.tensor([[0] if done else [1] for done in dones], dtype=torch.uint8, device=self.device)
+
+        return (nd(agent_episode_dones), nd(sim_episode_dones), nd(tour_dones),
+                torch.tensor(produce_actions, dtype=torch.uint8, device=self.device))
+
+    def _eval_checkpoint_iterative(self, config, writer=None, checkpoint_index=0):
+        """Tour-by-tour evaluation (base_il_trainer.py:585-928), statement for statement and pinned to runs of the
+        reference's own loop (tests/golden/iterative_golden.json, cases "iterative_*"): the 7-tuple step protocol,
+        four masks handed to `act_iterative`, maps reset by the agent-episode or the tour mask
+        (EVAL.ITERATIVE_MAP_RESET), statistics taken from the step that ends the agent's episode, `dtw_data` from the
+        step that ends the sim episode, `reset_at` + mask patch-up, pause once the next episode has been scored;
+        reports `iterative_stats_…`, `iterative_all_stats_…`, `dtw_data_…`; t-nDTW against
+        EVAL.ITERATIVE_GT_PATHS[split] (or, for the synthetic env, the expert paths it exposes)."""
+        import numbers
+
+        if "Iterative" not in config.ENV_NAME:
+            config.defrost()
+            config.ENV_NAME = config.TASK_CONFIG.ENVIRONMENT.ITERATIVE.ENV_NAME
+            config.freeze()
+        split = config.TASK_CONFIG.DATASET.SPLIT
+        fname = os.path.join(config.RESULTS_DIR, f"iterative_stats_ckpt_{checkpoint_index}_{split}.json")
+        if config.EVAL.SAVE_RESULTS:
+            self._make_results_dir()
+            if os.path.exists(fname):  # "skipping -- evaluation exists."
+                return json.load(open(fname))
+        assert self.config.EVAL.ITERATIVE_MAP_RESET in ["episodic", "iterative"], "config.EVAL.ITERATIVE_MAP_RESET not valid"
+        episodic_maps = self.config.EVAL.ITERATIVE_MAP_RESET == "episodic"
+        envs = construct_envs(config, None, auto_reset_done=False, rank=self.rank, world=self.world, iterative=True)
+        self._load_eval_policy(config, envs, config.IL.ckpt_to_load)
+        n = envs.num_envs
+        rnn_states = torch.zeros(n, self.policy.net.num_recurrent_layers, config.MODEL.STATE_ENCODER.hidden_size,
+                                 device=self.device)
+        prev_actions = torch.zeros(n, 1, device=self.device, dtype=torch.long)
+        agent_episode_not_done_masks = torch.zeros(n, 1, dtype=torch.uint8, device=self.device)
+        sim_episode_not_done_masks = torch.zeros(n, 1, dtype=torch.uint8, device=self.device)
+        tour_not_done_masks = torch.zeros(n, 1, dtype=torch.uint8, device=self.device)
+        action_masks = torch.ones(n, 1, dtype=torch.uint8, device=self.device)
+        # a captured step carries ONE policy mask (the agent-episode one, all MapCMA reads: quirk Q11) besides the
+        # mapper's reset mask; policies with a tour memory read the tour mask too and run eagerly
+        tour_policy = bool(config.MODEL.tour_memory or config.MODEL.tour_memory_variant)
+        use_graph = self._graph_eligible() and not tour_policy
 
         def make_batch(observations):
-            if maps_by_tour:  # the mapper resets on `not_done_masks`; the policy keeps its own episode masks
-                observations = add_batched_data_to_observations(observations, not_done_masks, "episode_not_done_masks")
-            return self._batch(observations, tour_masks if maps_by_tour else not_done_masks, transform=not use_graph)
+            reset_masks = agent_episode_not_done_masks if episodic_maps else tour_not_done_masks
+            if use_graph and not episodic_maps:  # the mapper resets on `not_done_masks`, the policy on its own key
+                observations = add_batched_data_to_observations(observations, agent_episode_not_done_masks,
+                                                                "episode_not_done_masks")
+            return self._batch(observations, reset_masks, transform=not use_graph)
 
+        observations, _, _ = [list(x) for x in zip(*envs.reset())]
         observations, batch = make_batch(observations)
+        stats_tours = defaultdict(dict)  # tour id -> episode id -> stats
+        dtw_data = defaultdict(list)     # tour id -> positions
         runner, captured = None, False
-        stats_episodes = {}
-        stats_tours = defaultdict(dict)
-        remaining = list(envs.number_of_episodes)
         t0 = time.time()
         while envs.num_envs > 0:
+            current_episodes = envs.current_episodes()
             if use_graph:
-                # mapper + policy.act replayed as captured graphs; state lives in the runner's buffers
                 if runner is None:
                     runner = self._make_runner(batch, rnn_states, prev_actions, first=not captured)
                     captured = True
@@ -483,67 +666,77 @@ class BaseVLNCETrainer:
             else:
                 with torch.no_grad():
                     actions, rnn_states = self.policy.act_iterative(
-                        batch, rnn_states, prev_actions, not_done_masks, not_done_masks,
-                        tour_masks if iterative else not_done_masks, torch.ones_like(not_done_masks),
-                        deterministic=not config.EVAL.SAMPLE,
-                    )
+                        batch, rnn_states, prev_actions, agent_episode_not_done_masks, sim_episode_not_done_masks,
+                        tour_not_done_masks, action_masks, deterministic=not config.EVAL.SAMPLE)
                     prev_actions.copy_(actions)
-            current_episodes = envs.current_episodes()
             outputs = envs.step([a[0].item() for a in actions])
-            observations, _, dones, infos = [list(x) for x in zip(*outputs)]
-            not_done_masks = torch.tensor([[0] if d else [1] for d in dones], dtype=torch.uint8, device=self.device)
-            next_episodes = envs.current_episodes()
-            tour_masks = torch.tensor(
-                [[0] if (d and getattr(a, "tour_id", None) != getattr(b, "tour_id", None)) else [1]
-                 for d, a, b in zip(dones, next_episodes, current_episodes)], dtype=torch.uint8, device=self.device)
-            envs_to_pause = []
-            if any(dones):
-                self._check_mappers()  # episode boundary; the stream was just synchronised by the actions' .item()
-            for i in range(envs.num_envs):
-                if dones[i]:
-                    stats_episodes[current_episodes[i].episode_id] = infos[i]
-                    stats_tours[str(getattr(current_episodes[i], "tour_id", ""))][current_episodes[i].episode_id] = infos[i]
-                    remaining[i] -= 1
-                    if remaining[i] <= 0:
-                        envs_to_pause.append(i)
+            (observations, _, agent_episode_dones, sim_episode_dones, tour_dones, produce_actions,
+             infos) = [list(x) for x in zip(*outputs)]
+            (agent_episode_not_done_masks, sim_episode_not_done_masks, tour_not_done_masks,
+             action_masks) = self.masks_to_tensors(agent_episode_dones, sim_episode_dones, tour_dones, produce_actions)
+            if any(agent_episode_dones):
+                self._check_mappers()
+            for i in range(envs.num_envs):  # reset envs and observations if necessary
+                if not agent_episode_dones[i]:
+                    continue
+                ep_id, tour_id = current_episodes[i].episode_id, current_episodes[i].tour_id
+                if ep_id not in stats_tours[tour_id] and len(infos[i]) > 1:  # the step that ended the agent's episode
+                    stats_tours[tour_id][ep_id] = {k: v for k, v in infos[i].items() if isinstance(v, numbers.Number)}
+                if not sim_episode_dones[i]:
+                    continue
+                if "dtw_data" in infos[i]:
+                    dtw_data[tour_id].extend(infos[i]["dtw_data"])
+                observations[i], tour_done, produce_action = envs.reset_at(i)[0]
+                tour_not_done_masks[i] = int(not tour_done)
+                action_masks[i] = int(produce_action)
+                prev_actions[i] = torch.zeros(1, dtype=torch.long)
             observations, batch = make_batch(observations)
+            next_episodes = envs.current_episodes()
+            envs_to_pause = [i for i in range(envs.num_envs)
+                             if sim_episode_dones[i] and next_episodes[i].episode_id in stats_tours[next_episodes[i].tour_id]]
+            (envs, rnn_states, agent_episode_not_done_masks, sim_episode_not_done_masks, tour_not_done_masks,
+             action_masks, prev_actions, batch, _) = self._pause_iterative_envs(
+                envs_to_pause, envs, rnn_states, agent_episode_not_done_masks, sim_episode_not_done_masks,
+                tour_not_done_masks, action_masks, prev_actions, batch)
             if envs_to_pause:
-                for idx in reversed(envs_to_pause):
-                    remaining.pop(idx)
-                keep = [i for i in range(envs.num_envs) if i not in envs_to_pause]
-                tour_masks = tour_masks[keep]
-                envs, rnn_states, not_done_masks, prev_actions, batch, _ = self._pause_envs(
-                    envs_to_pause, envs, rnn_states, not_done_masks, prev_actions, batch)
-                runner = None  # fewer rows: capture again for the new batch size, seeded with the kept rows
+                runner = None
         self._check_mappers()
-        agent_paths, gt_paths = envs.dtw_data(), envs.gt_paths()
-        gathered = D.gather_objects((stats_episodes, agent_paths, gt_paths, dict(stats_tours)))
+        gt_local = envs.gt_paths() if hasattr(envs, "gt_paths") else {}
+        gathered = D.gather_objects((dict(stats_tours), dict(dtw_data), gt_local))
         envs.close()
         if self.rank != 0:
             return None
-        stats_episodes, agent_paths, gt_paths, stats_tours = {}, {}, {}, {}
-        for s, a, g, st in gathered:
-            stats_episodes.update(s)
-            agent_paths.update(a)
-            gt_paths.update(g)
+        stats_tours, dtw_data, gt_paths = {}, {}, {}
+        for st, dd, gt in gathered:
             for tour, eps in st.items():
                 stats_tours.setdefault(tour, {}).update(eps)
-        agg = {}
-        num = max(1, len(stats_episodes))
-        for k in next(iter(stats_episodes.values())).keys():
-            agg[k] = sum(v[k] for v in stats_episodes.values()) / num
-        agg["t_ndtw"] = compute_tour_ndtw(agent_paths, gt_paths)
-        if iterative:
-            agg["tndtw"] = agg["t_ndtw"]  # the key the reference's iterative report uses (base_il_trainer.py:911)
-        agg["episodes"] = len(stats_episodes)
-        agg["eval_seconds"] = time.time() - t0
+            for tour, pts in dd.items():
+                dtw_data.setdefault(tour, []).extend(pts)
+            gt_paths.update(gt)
+        if config.EVAL.SAVE_RESULTS:  # DTW evaluation data and every episode's stats, for further analysis
+            with open(os.path.join(config.RESULTS_DIR, f"dtw_data_ckpt_{checkpoint_index}_{split}.json"), "w") as f:
+                json.dump(dtw_data, f, indent=2)
+            with open(os.path.join(config.RESULTS_DIR, f"iterative_all_stats_ckpt_{checkpoint_index}_{split}.json"), "w") as f:
+                json.dump(stats_tours, f, indent=2)
+        aggregated_stats = defaultdict(float)
+        for stats_episodes in stats_tours.values():
+            for stat_key in next(iter(stats_episodes.values())).keys():
+                aggregated_stats[stat_key] += sum(v[stat_key] for v in stats_episodes.values())
+        episodes_evaluated = sum(len(v) for v in stats_tours.values())
+        for stat_key in aggregated_stats:
+            aggregated_stats[stat_key] /= episodes_evaluated
+        if os.path.exists(config.EVAL.ITERATIVE_GT_PATHS):
+            with open(config.EVAL.ITERATIVE_GT_PATHS, "r") as f:
+                gt_paths = json.load(f)[split]
+        aggregated_stats["tndtw"] = compute_tour_ndtw(
+            agent_paths=dtw_data, gt_paths=gt_paths, success_distance=config.TASK_CONFIG.TASK.NDTW.SUCCESS_DISTANCE)
         if config.EVAL.SAVE_RESULTS:
-            json.dump(agg, open(fname, "w"), indent=4)
-            json.dump(agent_paths, open(os.path.join(config.RESULTS_DIR, f"dtw_data_ckpt_{checkpoint_index}_{split}.json"), "w"))
-            if iterative:  # every episode's stats, grouped by tour (base_il_trainer.py:889-895)
-                json.dump(stats_tours, open(os.path.join(
-                    config.RESULTS_DIR, f"iterative_all_stats_ckpt_{checkpoint_index}_{split}.json"), "w"), indent=2)
-        return agg
+            with open(fname, "w") as f:
+                json.dump(aggregated_stats, f, indent=4)
+        if writer is not None:
+            for k, v in aggregated_stats.items():
+                writer.add_scalar(f"eval_{split}_{k}", v, checkpoint_index + 1)
+        return dict(aggregated_stats, episodes=episodes_evaluated, eval_seconds=time.time() - t0)
 
     def inference(self):
         raise NotImplementedError("quirk Q10: no reference trainer defines inference() either")
@@ -640,14 +833,47 @@ class DaggerTrainer(BaseVLNCETrainer):
         if self.config.EVAL.SAVE_RESULTS:
             self._make_results_dir()
 
-    tour_masked_maps = False  # IterativeCollectionDaggerTrainer resets maps with the tour mask
+    # -- pieces shared by the two collection loops -------------------------------------------------------------
+    def _compact_host_rows(self):
+        """Quirk Q12 (reference bug, reproduced by default).  When envs pause during a beta == 1 collection the
+        reference compacts the device-side rows (`_pause_envs`, base_il_trainer.py:221-311) but NOT its host-side
+        per-env lists (`observations`, `episodes`: dagger_trainer.py:397-412, iterative_collection_dagger_trainer.py:
+        275-298): for one step the surviving envs are paired with a neighbour's stale observation, and their
+        partial trajectories shift onto the wrong env for the rest of the collection (the last few records of a
+        teacher-forcing pass).  Stored data is part of the parity contract, so the default follows the reference;
+        `IL.DAGGER.compact_paused_rows: True` (not a reference key) re-indexes the host lists as well."""
+        return bool(getattr(self.config.IL.DAGGER, "compact_paused_rows", False))
 
-    def _update_dataset(self, data_it, save_tour_idx_data=False):
-        """dagger_trainer.py:251-504 / iterative_collection_dagger_trainer.py:131-397: roll the policy out with
-        beta-mixed expert actions, cache the frozen encoders' features through forward hooks, store finished
-        trajectories; with `save_tour_idx_data` also the {tour_id: [record indices]} table, which is returned.
+    def _feature_hooks(self):
+        """dagger_trainer.py:301-323 / iterative_collection_dagger_trainer.py:184-210: forward hooks that keep the
+        frozen encoders' output of the current step on the host (`feats["depth"]`, `feats["rgb"]`), so that stored
+        trajectories carry features instead of frames."""
+        cfg = self.config
+        feats, hooks = {}, []
+        if not cfg.MODEL.DEPTH_ENCODER.trainable and cfg.MODEL.DEPTH_ENCODER.cnn_type == "VlnResnetDepthEncoder":
+            hooks.append(self.policy.net.depth_encoder.visual_encoder.register_forward_hook(
+                lambda m, i, o: feats.__setitem__("depth", o.detach().cpu())))
+        if not cfg.MODEL.RGB_ENCODER.trainable and hasattr(self.policy.net, "rgb_encoder"):
+            hooks.append(self.policy.net.rgb_encoder.cnn.register_forward_hook(
+                lambda m, i, o: feats.__setitem__("rgb", o.detach().cpu())))
+        return feats, hooks
 
-        The episodic flow follows the reference statement by statement and is pinned to it by
+    def _store_episode(self, episode, idx, expert_uuid):
+        """`save_episode_to_disk` (iterative_collection_dagger_trainer.py:60-80, dagger_trainer.py:352-371): record
+        `idx` = [obs{key: (T, ...)} without the expert sensor, prev_actions i64 (T,), oracle_actions i64 (T,)]."""
+        traj_obs = batch_obs([step[0] for step in episode], device=torch.device("cpu"))
+        del traj_obs[expert_uuid]
+        traj_obs = {k: v.numpy() for k, v in traj_obs.items() if torch.is_tensor(v)}
+        if self.config.IL.DAGGER.lmdb_fp16:
+            traj_obs = {k: v.astype(np.float16) for k, v in traj_obs.items()}
+        self.store.put(idx, traj_obs, [step[1] for step in episode], [step[2] for step in episode],
+                       tour_id=episode[0][3])
+
+    def _update_dataset(self, data_it):
+        """dagger_trainer.py:251-504: roll the policy out with beta-mixed expert actions, cache the frozen encoders'
+        features through forward hooks, store finished trajectories.  Returns the number stored.
+
+        The flow follows the reference statement by statement and is pinned to it by
         tests/golden/rollout_golden.json (the reference's own `_update_dataset` on a scripted env): beta = p^it
         with 0^0 = 0 (:295-299), `where(rand < beta, expert, policy)` (:423-427; the draw comes from the host
         generator so that a seeded run is reproducible whatever the device), expert -1 => step with action 0 and
@@ -655,7 +881,7 @@ class DaggerTrainer(BaseVLNCETrainer):
         every per-env state row compacted (:312-316, 392-412), a pass over the envs stores EVERY finished episode
         even past `update_size` (:349-386)."""
         cfg = self.config
-        envs = construct_envs(cfg, None, rank=self.rank, world=self.world)
+        envs = construct_envs(cfg, None, rank=self.rank, world=self.world, iterative=False)
         expert_uuid = cfg.IL.DAGGER.expert_policy_sensor_uuid
         n = envs.num_envs
         rnn_states = torch.zeros(n, self.policy.net.num_recurrent_layers, cfg.MODEL.STATE_ENCODER.hidden_size,
@@ -670,22 +896,9 @@ class DaggerTrainer(BaseVLNCETrainer):
         p = cfg.IL.DAGGER.p
         beta = 0.0 if p == 0.0 else p ** data_it
         ensure_unique_episodes = beta == 1.0
-        feats = {}
-        hooks = []
-        cache_depth = not cfg.MODEL.DEPTH_ENCODER.trainable  # dagger_trainer.py:317-323: frozen encoders only
-        if cache_depth:
-            hooks.append(self.policy.net.depth_encoder.visual_encoder.register_forward_hook(
-                lambda m, i, o: feats.__setitem__("depth", o.detach().cpu())))
-        if hasattr(self.policy.net, "rgb_encoder") and not cfg.MODEL.RGB_ENCODER.trainable:
-            hooks.append(self.policy.net.rgb_encoder.cnn.register_forward_hook(
-                lambda m, i, o: feats.__setitem__("rgb", o.detach().cpu())))
+        feats, hooks = self._feature_hooks()
         collected, start_id = 0, len(self.store)
         ep_ids_collected = {ep.episode_id for ep in envs.current_episodes()} if ensure_unique_episodes else None
-        tours_to_idxs = defaultdict(list)
-        if save_tour_idx_data:
-            tours_to_idxs.update(self.store.get_tour_index())
-            start_id += 1  # record 0 is the tour table
-        tour_masks = torch.zeros(n, 1, dtype=torch.uint8, device=self.device)
         target = max(1, cfg.IL.DAGGER.update_size // self.world)
         with torch.no_grad():
             while collected < target:
@@ -695,13 +908,7 @@ class DaggerTrainer(BaseVLNCETrainer):
                     # data-parallel ranks stop exactly at their share (no reference counterpart; a single process
                     # stores every episode that finished in this pass, like the reference)
                     if dones[i] and not skips[i] and (self.world == 1 or collected < target):
-                        ep = episodes[i]
-                        traj_obs = batch_obs([s[0] for s in ep], device=torch.device("cpu"))
-                        del traj_obs[expert_uuid]
-                        traj_obs = {k: v.numpy() for k, v in traj_obs.items() if torch.is_tensor(v)}
-                        self.store.put(start_id + collected, traj_obs, [s[1] for s in ep], [s[2] for s in ep],
-                                       tour_id=ep[0][3])
-                        tours_to_idxs[str(ep[0][3])].append(start_id + collected)
+                        self._store_episode(episodes[i], start_id + collected, expert_uuid)
                         collected += 1
                         if ensure_unique_episodes:
                             if current_episodes[i].episode_id in ep_ids_collected:
@@ -714,23 +921,15 @@ class DaggerTrainer(BaseVLNCETrainer):
                     keep = [i for i in range(envs.num_envs) if i not in envs_to_pause]
                     envs, rnn_states, not_done_masks, prev_actions, batch, _ = self._pause_envs(
                         envs_to_pause, envs, rnn_states, not_done_masks, prev_actions, batch)
-                    # per-env host state follows the same compaction
-                    observations = [observations[i] for i in keep]
-                    episodes = [episodes[i] for i in keep]
-                    skips = [skips[i] for i in keep]
-                    dones = [dones[i] for i in keep]
-                    tour_masks = tour_masks[keep]
+                    if self._compact_host_rows():
+                        observations = [observations[i] for i in keep]
+                        episodes = [episodes[i] for i in keep]
                     if envs.num_envs == 0:
                         break
                 if self.world > 1 and collected >= target:
                     break
-                if self.tour_masked_maps:  # tour-by-tour collection: the policy sees episode AND tour boundaries
-                    actions, rnn_states = self.policy.act_iterative(
-                        batch, rnn_states, prev_actions, not_done_masks, not_done_masks, tour_masks,
-                        torch.ones_like(not_done_masks), deterministic=False)
-                else:
-                    actions, rnn_states = self.policy.act(batch, rnn_states, prev_actions, not_done_masks,
-                                                          deterministic=False)
+                actions, rnn_states = self.policy.act(batch, rnn_states, prev_actions, not_done_masks,
+                                                      deterministic=False)
                 expert = batch[expert_uuid].long()
                 draw = torch.rand(actions.shape, dtype=torch.float).to(actions.device)
                 actions = torch.where(draw < beta, expert, actions)
@@ -746,7 +945,7 @@ class DaggerTrainer(BaseVLNCETrainer):
                     if "rgb" in feats:
                         o["rgb_features"] = feats["rgb"][i].clone()
                         o.pop("rgb", None)
-                    if cache_depth:
+                    if "depth" in feats:
                         o["depth_features"] = feats["depth"][i].clone()
                         o.pop("depth", None)
                     if occ is not None:
@@ -759,24 +958,15 @@ class DaggerTrainer(BaseVLNCETrainer):
                 actions = torch.where(skips_t, torch.zeros_like(actions), actions)
                 skips = skips_t.squeeze(-1).cpu().tolist()
                 prev_actions.copy_(actions)
-                tours_before = [getattr(e, "tour_id", None) for e in envs.current_episodes()]
                 outputs = envs.step([a[0].item() for a in actions])
                 observations, _, dones, _ = [list(x) for x in zip(*outputs)]
                 not_done_masks = torch.tensor([[0] if d else [1] for d in dones], dtype=torch.uint8,
                                               device=self.device)
-                tours_after = [getattr(e, "tour_id", None) for e in envs.current_episodes()]
-                tour_masks = torch.tensor(
-                    [[0] if (d and a != b) else [1] for d, a, b in zip(dones, tours_after, tours_before)],
-                    dtype=torch.uint8, device=self.device)
-                # maps persist across the episodes of a tour when collecting tour by tour (:166-168, 373-375)
-                observations, batch = self._batch(observations, tour_masks if self.tour_masked_maps else not_done_masks)
+                observations, batch = self._batch(observations, not_done_masks)
         for h in hooks:
             h.remove()
         envs.close()
         self._check_mappers()
-        if save_tour_idx_data:
-            self.store.put_tour_index(tours_to_idxs)
-            return dict(tours_to_idxs)
         return collected
 
     def train(self):
@@ -784,7 +974,9 @@ class DaggerTrainer(BaseVLNCETrainer):
         cfg = self.config
         D.init()
         self._make_dirs()
-        if not cfg.IL.DAGGER.preload_lmdb_features and cfg.IL.DAGGER.drop_existing_lmdb_features:
+        # (a requeued run continues on the trajectories it already collected)
+        if (not cfg.IL.DAGGER.preload_lmdb_features and cfg.IL.DAGGER.drop_existing_lmdb_features
+                and not (cfg.IL.load_from_ckpt and cfg.IL.is_requeue)):
             self.store.clear()
         envs = construct_envs(cfg, None, rank=self.rank, world=self.world)
         observation_space, action_space = self._get_spaces(cfg, envs=envs)
@@ -792,12 +984,25 @@ class DaggerTrainer(BaseVLNCETrainer):
         self._initialize_policy(cfg, cfg.IL.load_from_ckpt, observation_space, action_space)
         return self._train_loop()
 
+    def _resume_point(self, dagger_it):
+        """Requeue (`IL.is_requeue`, base_il_trainer.py:98-106): the checkpoint names the (dagger_it, epoch) it was
+        written after.  The run continues with the next epoch of THAT iteration on the trajectories already in the
+        store, and every later iteration starts at epoch 0 with a fresh collection.  (The reference restores
+        `start_epoch` but its loops never read it - a requeued reference run starts over at iteration 0, epoch 0
+        and overwrites its checkpoints; resuming where the checkpoint says is the evident intent.)
+        Returns (collect?, first_epoch)."""
+        first = getattr(self, "start_dagger_it", 0)
+        if dagger_it == first and self.start_epoch > 0:
+            return False, self.start_epoch
+        return True, 0
+
     def _train_loop(self):
         cfg = self.config
         log = []
-        for dagger_it in range(cfg.IL.DAGGER.iterations):
+        for dagger_it in range(getattr(self, "start_dagger_it", 0), cfg.IL.DAGGER.iterations):
             step_id = 0
-            if not cfg.IL.DAGGER.preload_lmdb_features:
+            collect, first_epoch = self._resume_point(dagger_it)
+            if collect and not cfg.IL.DAGGER.preload_lmdb_features:
                 self._update_dataset(dagger_it + (1 if cfg.IL.load_from_ckpt else 0))
             dataset = IWTrajectoryDataset(self.store, cfg.IL.use_iw, cfg.IL.inflection_weight_coef, cfg.IL.batch_size)
             loader = torch.utils.data.DataLoader(dataset, batch_size=cfg.IL.batch_size, shuffle=False,
@@ -806,8 +1011,6 @@ class DaggerTrainer(BaseVLNCETrainer):
             # MIN batch count, so no rank issues a gradient all-reduce the others never join
             n_batches = D.allreduce_min_int(dataset.length // cfg.IL.batch_size, self.device)
             AuxLosses.activate()  # only around the updates, never during rollouts (dagger_trainer.py:579)
-            # a requeued run resumes its interrupted iteration at start_epoch; later iterations start at 0
-            first_epoch = self.start_epoch if dagger_it == 0 else 0
             for epoch in range(first_epoch, cfg.IL.epochs):
                 for bi, (obs_b, prev_b, nd_b, _, corr_b, w_b) in enumerate(PrefetchLoader(loader, self.device)):
                     if bi >= n_batches:
@@ -825,11 +1028,143 @@ class DaggerTrainer(BaseVLNCETrainer):
 
 @baseline_registry.register_trainer(name="iterative_collection_dagger")
 class IterativeCollectionDaggerTrainer(DaggerTrainer):
-    """iterative_collection_dagger_trainer.py:24-397: same update, but trajectories are collected
-    tour by tour with the maps carried across the episodes of a tour (the env's `not_done_masks`
-    handed to the mapper are the TOUR masks; the policy state still resets per episode)."""
+    """iterative_collection_dagger_trainer.py:24-397 - the trainer every MapCMA experiment YAML names: the update is
+    DaggerTrainer's, the collection runs tour by tour on the iterative env protocol (7-tuple steps, oracle phases
+    between the episodes of a tour).  Maps are reset by the TOUR mask, so they persist across a tour's episodes
+    (:166-168, 373-375); the policy gets all four masks through `act_iterative`; only steps in which the agent
+    itself acts are stored (:320-321); with `save_tour_idx_data` the {tour: [record ids]} table is kept as record
+    "0" and the trajectories are numbered from 1 (:228-235, 377-385).  Pinned to runs of the reference's own
+    `_update_dataset` on a scripted iterative env (tests/golden/iterative_golden.json, "collect")."""
 
-    tour_masked_maps = True
+    def add_map_to_observations(self, observations, batch, num_envs):
+        """:28-58: copy this step's maps into the per-env observation dicts (what gets stored) and drop the keys
+        that only served to build them."""
+        map_k_sum = int("occupancy_map" in batch) + int("semantic_map" in batch)
+        if map_k_sum == 1:
+            raise RuntimeError("either both map keys should exist in the batch or neither")
+        if map_k_sum != 2:
+            return observations
+        occ, sem = batch["occupancy_map"].cpu().numpy(), batch["semantic_map"].cpu().numpy()
+        for i in range(num_envs):
+            observations[i]["occupancy_map"], observations[i]["semantic_map"] = occ[i], sem[i]
+            for k in ["semantic", "semantic12", "world_robot_pose", "world_robot_orientation", "env_name"]:
+                observations[i].pop(k, None)
+        return observations
+
+    def batch_and_transform(self, observations, not_done_masks):
+        """:116-129.  `not_done_masks` is what resets the maps: with the tour masks they live for a whole tour."""
+        observations, batch = self._batch(observations, not_done_masks)
+        return batch, observations
+
+    def _update_dataset(self, data_it, save_tour_idx_data=False):
+        cfg = self.config
+        envs = construct_envs(cfg, None, rank=self.rank, world=self.world, iterative=True)
+        expert_uuid = cfg.IL.DAGGER.expert_policy_sensor_uuid
+        n = envs.num_envs
+        rnn_states = torch.zeros(n, self.policy.net.num_recurrent_layers, cfg.MODEL.STATE_ENCODER.hidden_size,
+                                 device=self.device)
+        prev_actions = torch.zeros(n, 1, device=self.device, dtype=torch.long)
+        agent_episode_not_done_masks = torch.zeros(n, 1, dtype=torch.uint8, device=self.device)
+        sim_episode_not_done_masks = torch.zeros(n, 1, dtype=torch.uint8, device=self.device)
+        tour_not_done_masks = torch.zeros(n, 1, dtype=torch.uint8, device=self.device)
+        action_masks = torch.ones(n, 1, dtype=torch.uint8, device=self.device)
+        observations, _, _ = [list(x) for x in zip(*envs.reset())]
+        batch, observations = self.batch_and_transform(observations, tour_not_done_masks)
+        episodes = [[] for _ in range(n)]
+        skips = [False for _ in range(n)]
+        sim_episode_dones = [False for _ in range(n)]
+        p = cfg.IL.DAGGER.p
+        beta = 0.0 if p == 0.0 else p ** data_it  # in Python 0.0 ** 0.0 == 1.0, but we want 0.0
+        ensure_unique_episodes = beta == 1.0
+        feats, hooks = self._feature_hooks()
+        collected_eps = 0
+        ep_ids_collected = {ep.episode_id for ep in envs.current_episodes()} if ensure_unique_episodes else None
+        # record numbering (:225-235): lmdb's entry count includes the tour table, which claims key "0" the first
+        # time a table is asked for
+        tours_to_idxs = defaultdict(list)
+        start_id = self.store.entries()
+        if save_tour_idx_data:
+            if start_id:
+                tours_to_idxs.update(self.store.get_tour_index())
+            else:
+                start_id += 1
+        target = max(1, cfg.IL.DAGGER.update_size // self.world)
+        with torch.no_grad():
+            while collected_eps < target:
+                envs_to_pause = [] if ensure_unique_episodes else None
+                current_episodes = envs.current_episodes() if ensure_unique_episodes else None
+                for i in range(envs.num_envs):  # when a sim episode is done, save it
+                    if not sim_episode_dones[i]:
+                        continue
+                    if skips[i]:
+                        episodes[i] = []
+                        continue
+                    if self.world > 1 and collected_eps >= target:  # data-parallel ranks stop exactly at their share
+                        episodes[i] = []
+                        continue
+                    idx = start_id + collected_eps
+                    self._store_episode(episodes[i], idx, expert_uuid)
+                    tours_to_idxs[str(episodes[i][0][3])].append(idx)
+                    collected_eps += 1
+                    if ensure_unique_episodes:
+                        if current_episodes[i].episode_id in ep_ids_collected:
+                            envs_to_pause.append(i)
+                        else:
+                            ep_ids_collected.add(current_episodes[i].episode_id)
+                    episodes[i] = []
+                if ensure_unique_episodes:
+                    if envs_to_pause and self._compact_host_rows():
+                        keep = [i for i in range(envs.num_envs) if i not in envs_to_pause]
+                        observations = [observations[i] for i in keep]
+                        episodes = [episodes[i] for i in keep]
+                    (envs, rnn_states, agent_episode_not_done_masks, sim_episode_not_done_masks, tour_not_done_masks,
+                     action_masks, prev_actions, batch, _) = self._pause_iterative_envs(
+                        envs_to_pause, envs, rnn_states, agent_episode_not_done_masks, sim_episode_not_done_masks,
+                        tour_not_done_masks, action_masks, prev_actions, batch)
+                    if envs.num_envs == 0:
+                        break
+                if self.world > 1 and collected_eps >= target:
+                    break
+                actions, rnn_states = self.policy.act_iterative(
+                    batch, rnn_states, prev_actions, agent_episode_not_done_masks, sim_episode_not_done_masks,
+                    tour_not_done_masks, action_masks, deterministic=False)
+                draw = torch.rand(actions.shape, dtype=torch.float).to(actions.device)
+                actions = torch.where(draw < beta, batch[expert_uuid].long(), actions)
+                observations = self.add_map_to_observations(observations, batch, envs.num_envs)
+                acting = action_masks.view(-1).cpu().tolist()
+                prev_cpu = prev_actions.cpu()
+                expert_cpu = batch[expert_uuid].cpu()
+                for i, current_episode in enumerate(envs.current_episodes()):
+                    if not acting[i]:  # only add steps if the agent is acting: skip oracle phases
+                        continue
+                    if "depth" in feats:
+                        observations[i]["depth_features"] = feats["depth"][i]
+                        del observations[i]["depth"]
+                    if "rgb" in feats:
+                        observations[i]["rgb_features"] = feats["rgb"][i]
+                    if "rgb" in observations[i]:
+                        del observations[i]["rgb"]
+                    episodes[i].append((observations[i], prev_cpu[i].item(), expert_cpu[i].item(),
+                                        current_episode.tour_id))
+                skips_t = batch[expert_uuid].long() == -1
+                actions = torch.where(skips_t, torch.zeros_like(actions), actions)
+                skips = skips_t.squeeze(-1).cpu().tolist()
+                prev_actions.copy_(actions)
+                outputs = envs.step([a[0].item() for a in actions])
+                (observations, _, agent_episode_dones, sim_episode_dones, tour_dones, produce_actions,
+                 _) = [list(x) for x in zip(*outputs)]
+                (agent_episode_not_done_masks, sim_episode_not_done_masks, tour_not_done_masks,
+                 action_masks) = self.masks_to_tensors(agent_episode_dones, sim_episode_dones, tour_dones,
+                                                       produce_actions)
+                batch, observations = self.batch_and_transform(observations, tour_not_done_masks)
+        for h in hooks:
+            h.remove()
+        envs.close()
+        self._check_mappers()
+        if save_tour_idx_data:
+            self.store.put_tour_index(tours_to_idxs)
+            return dict(tours_to_idxs)
+        return collected_eps
 
 
 @baseline_registry.register_trainer(name="iterative_dagger")
@@ -860,15 +1195,16 @@ class IterativeDaggerTrainer(IterativeCollectionDaggerTrainer):
 
         cfg = self.config
         log = []
-        for dagger_it in range(cfg.IL.DAGGER.iterations):
+        for dagger_it in range(getattr(self, "start_dagger_it", 0), cfg.IL.DAGGER.iterations):
             step_id = 0
-            if cfg.IL.DAGGER.preload_lmdb_features:
+            collect, first_epoch = self._resume_point(dagger_it)
+            if cfg.IL.DAGGER.preload_lmdb_features or not collect:
                 tours_to_idxs = self.store.get_tour_index()
             else:
                 tours_to_idxs = self._update_dataset(dagger_it + (1 if cfg.IL.load_from_ckpt else 0),
                                                      save_tour_idx_data=True)
             AuxLosses.activate()
-            for epoch in range(self.start_epoch if dagger_it == 0 else 0, cfg.IL.epochs):
+            for epoch in range(first_epoch, cfg.IL.epochs):
                 dataset = TourTrajectoryDataset(self.store, cfg.IL.use_iw, cfg.IL.inflection_weight_coef)
                 sampler = TourSampler({k: list(v) for k, v in tours_to_idxs.items()}, batch_size=cfg.IL.batch_size,
                                       shuffle=True, drop_last=True)

@@ -50,7 +50,7 @@ class _Txn:
     def __exit__(self, *a):
         return False
 
-    def put(self, k, v):
+    def put(self, k, v, overwrite=True):
         self.db[k] = v
 
     def get(self, k):

@@ -109,14 +109,16 @@ class ScriptedPolicy:
 
 
 SCRIPTS = [
+    [[1, 0], [1, 3, 0]],                      # runs out of new episodes first, while the others are mid-episode: its
+    #                                           pause shifts their rows (quirk Q12: the reference compacts the device
+    #                                           rows but not its host-side `observations` / `episodes` lists)
     [[1, 2, 1, 0], [3, 0], [1, 1, 0]],
     [[-1], [2, 2, 3, 1, 0], [1, 0]],          # first episode: expert cannot reach the goal -> skipped
-    [[1, 0], [1, 3, 3, 0]],
 ]
 
 CASES = {
     # name: (p, data_it, update_size, torch seed)
-    "teacher_forcing_unique": (1.0, 0, 6, 11),   # beta = 1: expert actions only, envs pause on repeated episodes
+    "teacher_forcing_unique": (1.0, 0, 7, 11),   # beta = 1: expert actions only, envs pause on repeated episodes
     "beta_quarter": (0.5, 2, 7, 12),             # beta = 0.25: mostly the policy's own actions
     "policy_only": (0.0, 3, 5, 13),              # beta = 0
 }

@@ -240,7 +240,8 @@ def test_iterative_dagger_trainer_end_to_end(tmp_path, policy):
     log = tr.train()
     assert len(log) >= 2 and all(np.isfinite(l["loss"]) for l in log), log
     table = tr.store.get_tour_index()
-    assert sum(len(v) for v in table.values()) == 12 and min(min(v) for v in table.values()) == 1
+    # (a pass over the envs stores every episode that finished in it, so the count can exceed update_size)
+    assert 12 <= sum(len(v) for v in table.values()) <= 13 and min(min(v) for v in table.values()) == 1
     obs, prev, expert = tr.store.get(1)
     assert "depth_features" in obs and ("rgb_features" in obs) == latent and "rgb" not in obs
     if latent:

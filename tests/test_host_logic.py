@@ -454,3 +454,213 @@ def test_collate_block_shuffle_and_iw_dataset_match_reference_run(tmp_path):
         assert ds.length == c["length"]
         got = [{"id": int(obs["instruction"][0, 0]) - 1, "weights": [float(x) for x in w]} for obs, _, _, w in ds]
         assert got == c["yielded"]
+
+
+def _iter_trainer(cls, cfg, tmp_path, with_rgb=True):
+    """A trainer of this package wired to the scripted stand-ins of tests/golden/iterative_script.py, on the CPU
+    (host logic only: the policy / mapper stand-ins carry no arithmetic)."""
+    import torch
+
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import iterative_script as IS
+
+    from ivln_ce_amd import trainers
+
+    tr = cls.__new__(cls)
+    tr.config, tr.device = cfg, torch.device("cpu")
+    tr.rank, tr.local_rank, tr.world = 0, 0, 1
+    tr.obs_transforms = [IS.ScriptedMapper()]
+    tr.policy = IS.ScriptedIterativePolicy(with_rgb=with_rgb)
+    tr.store = trainers.TrajectoryStore(str(tmp_path / "traj"))
+    return tr, IS
+
+
+@pytest.mark.parametrize("case", ["tf_unique_oracle", "beta_half_oracle", "policy_no_oracle"])
+def test_iterative_collection_matches_reference_run(case, tmp_path, monkeypatch):
+    """A18: `IterativeCollectionDaggerTrainer._update_dataset(save_tour_idx_data=True)` - the trainer every MapCMA
+    YAML names - against what the REFERENCE's own `_update_dataset`, `masks_to_tensors`, `add_map_to_observations` and
+    `_pause_iterative_envs` stored, stepped and fed to `policy.act_iterative` on the same scripted iterative env
+    (oracle phases, four masks, tour ids, an expert -1, env pauses; tests/golden/gen_iterative_golden.py ->
+    iterative_golden.json): records numbered from 1, the tour table under "0", only agent-phase steps stored, maps
+    carried across the episodes of a tour, a second collection continuing the numbering, quirk Q12 included."""
+    import json
+
+    import numpy as np
+    import torch
+
+    from ivln_ce_amd import trainers
+    from ivln_ce_amd.config import get_config
+
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "iterative_golden.json")))["collect"][case]
+    cfg = get_config(opts=["IL.DAGGER.p", g["p"], "IL.DAGGER.update_size", g["update_size"]])
+    tr, IS = _iter_trainer(trainers.IterativeCollectionDaggerTrainer, cfg, tmp_path)
+    assert IS.COLLECT_CASES[case][:3] == (g["p"], g["runs"][0]["data_it"], g["update_size"])
+    for run in g["runs"]:
+        tr.obs_transforms = [IS.ScriptedMapper()]
+        envs = IS.ScriptedVectorEnv(IS.scripts(), iterative=True, auto_reset=True, oracle_phases=g["oracle_phases"])
+        monkeypatch.setattr(trainers, "construct_envs", lambda *a, **k: envs)
+        del tr.policy.calls[:], tr.policy.deleted[:]
+        torch.manual_seed(run["seed"])
+        table = tr._update_dataset(run["data_it"], save_tour_idx_data=True)
+        assert table == run["tour_table"] == tr.store.get_tour_index()
+        assert envs.action_log == run["env_actions"]           # what the simulator was told to do, step by step
+        assert tr.policy.calls == run["policy_calls"]          # four masks / previous actions / state rows / map per call
+        assert tr.policy.deleted == run["deleted_batch_idx"]   # rows reported to net.delete_batch_idx on pause
+        assert len(tr.store) == len(run["records"]) and tr.store.entries() == len(run["records"]) + 1
+        for idx, rec in run["records"].items():
+            obs, prev, oracle = tr.store.get(int(idx))
+            assert sorted(obs) == sorted(rec["obs"]), (idx, sorted(obs), sorted(rec["obs"]))
+            for k, v in rec["obs"].items():
+                ref = _np(v)
+                assert obs[k].dtype == ref.dtype and np.array_equal(obs[k], ref), (idx, k)
+            assert np.array_equal(prev, _np(rec["prev_actions"])) and np.array_equal(oracle, _np(rec["oracle_actions"]))
+
+
+@pytest.mark.parametrize("case", ["episodic", "iterative_tour_maps", "iterative_episode_maps", "iterative_no_oracle"])
+def test_eval_loops_match_reference_run(case, tmp_path, monkeypatch):
+    """A18: `_eval_checkpoint` (episodic) and `_eval_checkpoint_iterative` against runs of the REFERENCE's own loops
+    (base_il_trainer.py:313-583, 585-928) on the scripted env: the actions the envs received, every `reset_at`, what
+    each `act` / `act_iterative` call saw (masks, previous actions, compacted state rows, the map under either
+    ITERATIVE_MAP_RESET), rows reported on pause, the report files and TensorBoard scalars, and the ARGUMENTS handed
+    to `compute_tour_ndtw` (dtw-python itself is absent from the image)."""
+    import json
+
+    from ivln_ce_amd import trainers
+    from ivln_ce_amd.config import get_config
+
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "iterative_golden.json")))["eval"][case]
+    gt = {"val_seen": {"T0": [[0.0, 0.0, 0.0]], "T1": [[1.0, 0.0, 0.0]]}}
+    gt_file = str(tmp_path / "gt.json")
+    json.dump(gt, open(gt_file, "w"))
+    res_dir = str(tmp_path / "results")
+    cfg = get_config(opts=["RESULTS_DIR", res_dir, "EVAL.SPLIT", "val_seen", "EVAL.ITERATIVE_MAP_RESET", g["map_reset"],
+                           "EVAL.ITERATIVE_GT_PATHS", gt_file, "EVAL.SAVE_RESULTS", True,
+                           "TASK_CONFIG.ENVIRONMENT.ITERATIVE.ENABLED", g["iterative"], "VIDEO_OPTION", []])
+    tr, IS = _iter_trainer(trainers.BaseVLNCETrainer, cfg, tmp_path, with_rgb=False)
+    tr._load_eval_policy = lambda *a, **k: None
+    envs = IS.ScriptedVectorEnv(IS.scripts(), iterative=g["iterative"], auto_reset=False, oracle_phases=g["oracle_phases"])
+    monkeypatch.setattr(trainers, "construct_envs", lambda *a, **k: envs)
+    ndtw_calls = []
+
+    def record(agent_paths, gt_paths, success_distance):
+        ndtw_calls.append({"agent_paths": json.loads(json.dumps(agent_paths)), "gt_paths": gt_paths,
+                           "success_distance": success_distance})
+        return 0.4242
+
+    monkeypatch.setattr(trainers, "compute_tour_ndtw", record)
+
+    class Writer:
+        scalars = []
+
+        def add_scalar(self, k, v, step):
+            self.scalars.append([k, float(v), int(step)])
+
+    w = Writer()
+    res = tr._eval_checkpoint("data/checkpoints/ckpt.3.pth", w, checkpoint_index=0)
+    assert envs.action_log == g["env_actions"]
+    assert [list(x) for x in envs.reset_at_log] == g["reset_at"]
+    assert tr.policy.calls == g["policy_calls"]
+    assert tr.policy.deleted == g["deleted_batch_idx"]
+    assert ndtw_calls == g["tour_ndtw_calls"]
+    assert sorted(os.listdir(res_dir)) == sorted(g["files"])
+    for f, content in g["files"].items():
+        assert json.load(open(os.path.join(res_dir, f))) == content, f
+    assert w.scalars == g["scalars"]
+    stats = g["files"][("iterative_stats" if g["iterative"] else "stats") + "_ckpt_3_val_seen.json"]
+    assert {k: res[k] for k in stats} == stats and res["episodes"] == 10
+
+
+def test_tour_ndtw_matches_reference_bookkeeping():
+    """t-nDTW against the reference's own `compute_tour_ndtw` on seeded random tours (oracle phases, in-place turns,
+    one-step episodes that close the alignment window; tests/golden/gen_tour_ndtw_golden.py): the reference's
+    filtering / alignment / window / weighting ran around a plain numpy DTW standing in for dtw-python."""
+    import json
+
+    from ivln_ce_amd.tour_ndtw import compute_tour_ndtw
+
+    for c in json.load(open(os.path.join(ROOT, "tests", "golden", "tour_ndtw.json"))):
+        assert abs(compute_tour_ndtw(c["agent"], c["gt"], c["success_distance"]) - c["score"]) < 1e-12
+
+
+def test_synthetic_iterative_env_walks_the_reference_phases():
+    """The synthetic env's iterative protocol (environments.py:36-356 restated on a kinematic agent): 7-tuple steps,
+    agent -> oracle_goal -> oracle_start -> agent, `agent_episode_done` in every oracle step, `produce_action` off
+    while the oracle drives, `tour_done` only from a reset that changes tour, `dtw_data` at episode ends; following
+    the expert (env 0) or stopping early (env 1) and letting the oracle do its part scores a sensible t-nDTW against
+    the env's own expert paths."""
+    from ivln_ce_amd.envs import SyntheticVectorEnv
+    from ivln_ce_amd.tour_ndtw import compute_tour_ndtw
+
+    cfg = get_config(opts=["ENV_NAME", "VLNCEIterativeEnv"])
+    for auto_reset in (True, False):
+        envs = SyntheticVectorEnv(cfg, num_envs=2, n_episodes=5, episodes_per_tour=2, min_len=3, max_len=6,
+                                  auto_reset_done=auto_reset)
+        assert envs.iterative
+        out = envs.reset()
+        obs = [o[0] for o in out]
+        assert all(o[1] is True and o[2] is True for o in out)  # first reset: "tour done", the agent acts
+        dtw, phases_seen, tour_resets, finished = {}, set(), 0, [0, 0]
+        acting = [True, True]
+        for _ in range(600):
+            if min(finished) >= 5:
+                break
+            eps = envs.current_episodes()
+            acts = [int(o["shortest_path_sensor"][0]) for o in obs]
+            if acting[1] and float(obs[1]["progress"][0]) > 0.3:
+                acts[1] = 0  # env 1 stops early: the oracle has to convey it to the goal
+            out = envs.step(acts)
+            assert all(len(o) == 7 for o in out)
+            for i, (o, _, agent_done, sim_done, tour_done, produce, info) in enumerate(out):
+                if not acting[i]:   # an oracle step: the agent's episode stays "done", its action was ignored
+                    assert agent_done and len(info) <= 1
+                if agent_done or sim_done:
+                    assert "dtw_data" in info
+                    phases_seen.update(p["phase"] for p in info["dtw_data"])
+                if sim_done:
+                    if finished[i] < 5:
+                        dtw.setdefault(eps[i].tour_id, []).extend(info["dtw_data"])
+                    finished[i] += 1
+                    if not auto_reset:
+                        o, tour_done, produce = envs.reset_at(i)[0]
+                    nxt = envs.current_episodes()[i]
+                    assert tour_done == (nxt.tour_id != eps[i].tour_id)
+                    tour_resets += int(tour_done)
+                else:
+                    assert tour_done is False
+                obs[i], acting[i] = o, bool(produce)
+        assert min(finished) >= 5 and phases_seen == {"agent", "oracle_goal", "oracle_start"} and tour_resets >= 4
+        gt = envs.gt_paths()
+        score = compute_tour_ndtw(dtw, {k: gt[k] for k in dtw})
+        assert 0.6 < score < 1.0, score
+
+
+def test_requeue_resumes_at_the_checkpointed_iteration_and_epoch(tmp_path, monkeypatch):
+    """a run requeued from a checkpoint written after (dagger_it = 1, epoch = 1) continues with epoch 2 of
+    iteration 1 on the stored trajectories (no new collection), then runs iteration 2 from epoch 0 with a fresh
+    collection - and never touches the checkpoints of what was already done."""
+    import numpy as np
+    import torch
+
+    from ivln_ce_amd import trainers
+    from ivln_ce_amd.config import get_config
+
+    cfg = get_config(opts=["IL.DAGGER.iterations", 3, "IL.epochs", 3, "IL.batch_size", 2, "IL.load_from_ckpt", True,
+                           "IL.is_requeue", True])
+    tr = trainers.DaggerTrainer.__new__(trainers.DaggerTrainer)
+    tr.config, tr.device = cfg, torch.device("cpu")
+    tr.rank, tr.local_rank, tr.world = 0, 0, 1
+    tr.step_id, tr.start_epoch, tr.start_dagger_it = 40, 2, 1   # what _initialize_policy restores from the checkpoint
+    tr.store = trainers.TrajectoryStore(str(tmp_path / "traj"))
+    for i in range(4):
+        tr.store.put(i, {"feat": np.zeros((3, 2), np.float32), "instruction": np.ones((3, 4), np.int64)},
+                     np.zeros(3, np.int64), np.array([1, 1, 0]))
+    collected, saved = [], []
+    monkeypatch.setattr(tr, "_update_dataset", lambda it, **k: collected.append(it), raising=False)
+    monkeypatch.setattr(tr, "_update_agent", lambda *a, **k: (0.0, 0.0, 0.0), raising=False)
+    monkeypatch.setattr(tr, "save_checkpoint", lambda name, dagger_it, epoch, step_id: saved.append((name, dagger_it, epoch)),
+                        raising=False)
+    log = tr._train_loop()
+    assert collected == [3]                       # only iteration 2 collects (data_it = dagger_it + 1 after a load)
+    assert saved == [("ckpt.5.pth", 1, 2), ("ckpt.6.pth", 2, 0), ("ckpt.7.pth", 2, 1), ("ckpt.8.pth", 2, 2)]
+    assert [(e["dagger_it"], e["epoch"]) for e in log] == [(1, 2)] * 2 + [(2, 0)] * 2 + [(2, 1)] * 2 + [(2, 2)] * 2
+    assert tr.step_id == 48
