@@ -371,10 +371,21 @@ int ivln_gru_step_f32(const float* x, int64_t ldx, int I, const float* gi_pre, i
 /* The masked GRU over a whole time-major (T*N rows) sequence batch in ONE call (habitat-lab RNNStateEncoder
  * seq_forward; BPTT forward of base_il_trainer.py:173-219): gi = W_ih x + b_ih for all rows (caller's GEMM), h0 (N, H)
  * row stride ld_h0, masks u8 (T*N) -> out (T*N, H) row stride ldo, state_out (N, H) = the last step; optional saves
- * r / z / n / gh_n (T*N, H) for ivln_cma_seq_bwd_f32.  T dependent launches enqueued from C. */
+ * r / z / n / gh_n (T*N, H) for ivln_cma_seq_bwd_f32.
+ * sync_ws: 256 bytes of device memory owned by the caller (one per stream), or NULL.  With a workspace and a shape
+ * inside ivln_cma_seq_persistent_ok the whole sequence is ONE persistent launch (csrc/gru_seq.hip: W_hh resident in
+ * registers over 32 workgroups, h_t exchanged through `out` with write-through stores and one counter per step);
+ * otherwise T dependent per-step launches are enqueued.  Both paths compute the same values (same summation order;
+ * 2e-7 apart). */
 int ivln_cma_seq_fwd_f32(const float* gi, const float* h0, int64_t ld_h0, const uint8_t* masks, const float* w_hh,
                          const float* b_hh, float* out, int64_t ldo, float* state_out, int64_t ld_so, int T, int N,
-                         int H, float* save_r, float* save_z, float* save_n, float* save_ghn, void* stream);
+                         int H, float* save_r, float* save_z, float* save_n, float* save_ghn, void* sync_ws,
+                         void* stream);
+/* 1 when the single-launch path serves (N, H) (backward != 0: the BPTT kernel's envelope). */
+int ivln_cma_seq_persistent_ok(int N, int H, int backward);
+/* Synchronises `stream` and returns IVLN_OK, or IVLN_E_HIP when a bounded spin of the last persistent launch that
+ * used `sync_ws` timed out (its outputs are then undefined; the launch itself always terminates). */
+int ivln_seq_sync_status(const void* sync_ws, void* stream);
 /* MapCMANet._attn (map_cma_policy.py:266-274); k (rows,Ck,I), v (rows,Cv,I) channel-major. */
 int ivln_attn_fwd_f32(const float* q, int64_t ldq, const float* k, int64_t k_img_stride, const float* v,
                       int64_t v_img_stride, const int* valid_len, float scale, int rows, int Ck, int Cv,
@@ -403,6 +414,14 @@ int ivln_prev_action_embed_f32(const int64_t* prev_actions, const uint8_t* mask,
  * common/utils.py:149-185): logits = W x + b (O <= 8 actions), action[r] = first arg-max; logits_out optional
  * (rows, O). */
 int ivln_linear_argmax_f32(const float* x, int64_t ldx, const float* W, const float* bias, int rows, int K, int O,
+                           int64_t* action, float* logits_out, void* stream);
+/* The SAMPLED action of a DAgger collection step in one launch (models/policy.py:28-46 with deterministic=False;
+ * dagger_trainer.py:416-427, 469-472): a ~ softmax(W x + b) by inverse CDF with the caller's uniform u_sample[r]
+ * (p_o = exp(l_o - max); the first o whose running sum exceeds u * sum), then - when `expert` (rows, f64: the
+ * shortest-path sensor as batched) is given - `where(u_beta[r] < beta, expert[r], a)` (u_beta NULL: no mixing) and 0
+ * where expert[r] == -1.  A pure function of its inputs, so the step can be captured in a hipGraph. */
+int ivln_linear_sample_f32(const float* x, int64_t ldx, const float* W, const float* bias, int rows, int K, int O,
+                           const float* u_sample, const float* u_beta, float beta, const double* expert,
                            int64_t* action, float* logits_out, void* stream);
 /* Tour-long memory slot of the Latent-CMA `tour_memory_variant` (models/latent_cma_policy.py:395-399, 433-439):
  * out[n] = mask[n] * (h ? max(mem[n], h[n]) : mem[n]) - the previous step's max-pool with the first GRU's new
@@ -516,11 +535,12 @@ int ivln_gru_bwd_step_f32(const float* dgh_t, int64_t ld_dgh, const float* whh_t
                           const float* ghn, const float* h_prev, int64_t ldh, const uint8_t* mask_prev, int rows, int H,
                           float* dhz, float* dgi_prev, float* dgh_prev, float* hp_prev, void* stream);
 /* BPTT of ivln_cma_seq_fwd_f32 in one call (whh_t = W_hh^T (H, 3H)): d_out (T*N, H) row stride ld_dout, the forward's
- * saves and outputs -> dgi, dgh (T*N, 3H), hp = h_prev * mask (T*N, H); dhz (N, H) scratch. */
+ * saves and outputs -> dgi, dgh (T*N, 3H), hp = h_prev * mask (T*N, H); dhz (N, H) scratch of the per-step path.
+ * sync_ws as in the forward (one persistent launch, dgh rows exchanged write-through) or NULL (T launches). */
 int ivln_cma_seq_bwd_f32(const float* d_out, int64_t ld_dout, const float* r, const float* z, const float* n,
                          const float* ghn, const float* out, int64_t ld_out, const float* h0, int64_t ld_h0,
                          const uint8_t* masks, const float* whh_t, int T, int N, int H, float* dgi, float* dgh, float* hp,
-                         float* dhz, void* stream);
+                         float* dhz, void* sync_ws, void* stream);
 /* y[r][o] = (W[o].x[r] + add[r][o]) * (rowmask[r] != 0)  (dh_prev of the GRU BPTT) */
 int ivln_linear_skinny_ex_f32(const float* x, int64_t ldx, const float* W, const float* add, int64_t ld_add,
                               const uint8_t* rowmask, float* y, int64_t ldy, int rows, int K, int O,

@@ -18,6 +18,7 @@ SOURCES = {
     "conv_gn.hip": [],
     "gn_conv.hip": [],
     "cma_step.hip": [],
+    "gru_seq.hip": [],
     "nn_ops.hip": [],
     "train_ops.hip": [],
     "dtw.cpp": [],

@@ -8,6 +8,7 @@
 #include <stdint.h>
 #include <math.h>
 #include "../../include/ivln_hip.h"
+#include "gru_seq.h"
 
 namespace {
 
@@ -1076,10 +1077,21 @@ __global__ void k_argmax_rows(const float* __restrict__ x, int rows, int C, int6
 // Action head of a deterministic rollout step in one launch: wave w computes the logits of actions w and w+4
 // (lanes split K, one shuffle reduction per row), then the first arg-max per row (distribution.mode(),
 // common/utils.py:149-185).  One block, O <= 8 actions; rows processed 8 at a time.
+//
+// SAMPLE: the sampled step of a DAgger collection instead (models/policy.py:28-46 with deterministic=False, then
+// dagger_trainer.py:416-427, 469-472): the action is drawn from softmax(logits) by inverse CDF with the caller's
+// uniform u_sample[r] - p_o = exp(l_o - max), the first o whose running sum exceeds u * sum - then mixed with the
+// expert, `where(u_beta[r] < beta, expert[r], a)`, and replaced by 0 where the expert says -1 (the episode is being
+// skipped).  Host-supplied uniforms make the step a pure function of its inputs: capturable in a hipGraph and
+// bit-identical between replay and eager launches.  u_beta == nullptr: no mixing (plain sampling).
+template <bool SAMPLE>
 __global__ __launch_bounds__(256) void k_linear_argmax(const float* __restrict__ x, int64_t ldx,
                                                        const float* __restrict__ W, const float* __restrict__ bias,
                                                        int rows, int K, int O, int64_t* __restrict__ action,
-                                                       float* __restrict__ logits_out) {
+                                                       float* __restrict__ logits_out,
+                                                       const float* __restrict__ u_sample,
+                                                       const float* __restrict__ u_beta, float beta,
+                                                       const double* __restrict__ expert) {
     __shared__ float lg[SK_ROWS][8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int r0 = 0; r0 < rows; r0 += SK_ROWS) {
@@ -1121,6 +1133,28 @@ __global__ __launch_bounds__(256) void k_linear_argmax(const float* __restrict__
                     bv = lg[r][o];
                     best = o;
                 }
+            if (SAMPLE) {
+                float p[8], total = 0.f;
+                for (int o = 0; o < O; ++o) {
+                    p[o] = expf(lg[r][o] - bv);
+                    total += p[o];
+                }
+                const float target = u_sample[r0 + r] * total;
+                float run = 0.f;
+                best = O - 1;
+                for (int o = 0; o < O; ++o) {
+                    run += p[o];
+                    if (run > target) {
+                        best = o;
+                        break;
+                    }
+                }
+                if (expert) {
+                    const long long e = (long long)expert[r0 + r];
+                    if (u_beta && u_beta[r0 + r] < beta) best = (int)e;
+                    if (e == -1) best = 0;
+                }
+            }
             action[r0 + r] = best;
         }
         __syncthreads();
@@ -1424,9 +1458,15 @@ int ivln_gru_step_f32(const float* x, int64_t ldx, int I, const float* gi_pre, i
  * GPU-bound.  gi = W_ih x + b_ih for all T*N rows (one GEMM, done by the caller). */
 int ivln_cma_seq_fwd_f32(const float* gi, const float* h0, int64_t ld_h0, const uint8_t* masks, const float* w_hh,
                          const float* b_hh, float* out, int64_t ldo, float* state_out, int64_t ld_so, int T, int N,
-                         int H, float* save_r, float* save_z, float* save_n, float* save_ghn, void* stream) {
+                         int H, float* save_r, float* save_z, float* save_n, float* save_ghn, void* sync_ws,
+                         void* stream) {
     if (!gi || !h0 || !masks || !w_hh || !b_hh || !out || T <= 0 || N <= 0 || (H & 3) || (ld_h0 & 3) || (ldo & 3))
         return IVLN_E_INVALID;
+    if (sync_ws && T > 1 && ivln_cma_seq_persistent_ok(N, H, 0)) {   // one persistent launch (gru_seq.hip)
+        const int rc = ivln_gru_seq_fwd_persistent(gi, h0, ld_h0, masks, w_hh, b_hh, out, ldo, state_out, ld_so, T, N,
+                                                   save_r, save_z, save_n, save_ghn, sync_ws, stream);
+        if (rc != IVLN_E_UNSUPPORTED) return rc;
+    }
     for (int t = 0; t < T; ++t) {
         const int64_t r0 = (int64_t)t * N;
         const float* h_in = t == 0 ? h0 : out + (r0 - N) * ldo;
@@ -1517,8 +1557,18 @@ int ivln_argmax_rows(const float* x, int rows, int C, int64_t* out, void* stream
 int ivln_linear_argmax_f32(const float* x, int64_t ldx, const float* W, const float* bias, int rows, int K, int O,
                            int64_t* action, float* logits_out, void* stream) {
     if (O > 8 || O <= 0 || (K & 3) || (ldx & 3) || rows <= 0) return IVLN_E_UNSUPPORTED;
-    hipLaunchKernelGGL(k_linear_argmax, dim3(1), dim3(256), 0, (hipStream_t)stream, x, ldx, W, bias, rows, K, O, action,
-                       logits_out);
+    hipLaunchKernelGGL(k_linear_argmax<false>, dim3(1), dim3(256), 0, (hipStream_t)stream, x, ldx, W, bias, rows, K, O,
+                       action, logits_out, (const float*)nullptr, (const float*)nullptr, 0.f, (const double*)nullptr);
+    return LAUNCH_OK();
+}
+
+int ivln_linear_sample_f32(const float* x, int64_t ldx, const float* W, const float* bias, int rows, int K, int O,
+                           const float* u_sample, const float* u_beta, float beta, const double* expert,
+                           int64_t* action, float* logits_out, void* stream) {
+    if (O > 8 || O <= 0 || (K & 3) || (ldx & 3) || rows <= 0) return IVLN_E_UNSUPPORTED;
+    if (!u_sample || (u_beta && !expert)) return IVLN_E_INVALID;
+    hipLaunchKernelGGL(k_linear_argmax<true>, dim3(1), dim3(256), 0, (hipStream_t)stream, x, ldx, W, bias, rows, K, O,
+                       action, logits_out, u_sample, u_beta, beta, expert);
     return LAUNCH_OK();
 }
 

@@ -8,6 +8,7 @@
 #include <stdint.h>
 #include <math.h>
 #include "../../include/ivln_hip.h"
+#include "gru_seq.h"
 
 namespace {
 
@@ -865,9 +866,14 @@ int ivln_gru_bwd_step_f32(const float* dgh_t, int64_t ld_dgh, const float* whh_t
 int ivln_cma_seq_bwd_f32(const float* d_out, int64_t ld_dout, const float* r, const float* z, const float* n,
                          const float* ghn, const float* out, int64_t ld_out, const float* h0, int64_t ld_h0,
                          const uint8_t* masks, const float* whh_t, int T, int N, int H, float* dgi, float* dgh, float* hp,
-                         float* dhz, void* stream) {
+                         float* dhz, void* sync_ws, void* stream) {
     if (!d_out || !r || !out || !h0 || !masks || !whh_t || !dgi || !dgh || !hp || !dhz || T <= 0 || N <= 0 || (H & 3))
         return IVLN_E_INVALID;
+    if (sync_ws && T > 1 && ivln_cma_seq_persistent_ok(N, H, 1)) {   // one persistent launch (gru_seq.hip)
+        const int rc = ivln_gru_seq_bwd_persistent(d_out, ld_dout, r, z, n, ghn, out, ld_out, h0, ld_h0, masks, whh_t, T, N,
+                                                   dgi, dgh, hp, sync_ws, stream);
+        if (rc != IVLN_E_UNSUPPORTED) return rc;
+    }
     hipStream_t s = (hipStream_t)stream;
     auto hprev = [&](int t, int64_t& ld) -> const float* {  // hidden state entering step t
         ld = t == 0 ? ld_h0 : ld_out;

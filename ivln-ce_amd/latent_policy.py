@@ -477,7 +477,7 @@ class LatentCMAPolicy(ILPolicy):
             observations, rnn_hidden_states, prev_actions, action_masks=agent_episode_not_done_masks,
             episode_masks=episode_masks, tour_masks=tour_masks,
         )
-        return self._act(features, deterministic), rnn_hidden_states
+        return self._act(features, deterministic, observations), rnn_hidden_states
 
     def build_distribution(self, observations, rnn_hidden_states, prev_actions, agent_episode_not_done_masks,
                            tour_not_done_masks=None) -> Tuple:

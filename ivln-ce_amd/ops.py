@@ -913,24 +913,52 @@ def gru_step(x, gi_pre, h_in, mask_u8, w_ih, w_hh, b_ih, b_hh, h_out, h_out2=Non
     )
 
 
+SEQ_PERSISTENT = os.environ.get("IVLN_SEQ_PERSISTENT", "1") != "0"  # A/B: 0 = one launch per timestep
+_seq_sync_ws = {}
+
+
+def _seq_ws(device):
+    """256-byte counter / error workspace of the single-launch sequence GRU (csrc/gru_seq.hip), one per stream: two
+    sequences in flight on different streams must not share a counter.  None -> the per-timestep launches."""
+    if not SEQ_PERSISTENT:
+        return None
+    key = (str(device), torch.cuda.current_stream().cuda_stream)
+    ws = _seq_sync_ws.get(key)
+    if ws is None:
+        ws = _seq_sync_ws[key] = torch.zeros(64, dtype=torch.int32, device=device)
+    return ws
+
+
+def check_seq_sync():
+    """Raise if a bounded spin of a persistent sequence launch timed out (synchronises the stream: call where the
+    host waits anyway, e.g. after reading the loss).  A timed-out launch ends on its own; its outputs are garbage."""
+    L = _L()
+    L.ivln_seq_sync_status.argtypes = [vp, vp]
+    for ws in _seq_sync_ws.values():
+        check(L.ivln_seq_sync_status(dptr(ws), stream_ptr()), "ivln_seq_sync_status (persistent GRU spin timed out)")
+
+
 def gru_seq(gi, h0, masks_u8, w_hh, b_hh, out, state_out, T, N, saves=None):
-    """Masked GRU over T timesteps of N rows in one C-ABI call (T dependent launches enqueued from C)."""
+    """Masked GRU over T timesteps of N rows in one C-ABI call: ONE persistent launch inside the kernel's envelope
+    (H = 512, N <= 64), else T dependent launches enqueued from C."""
     H = w_hh.shape[1]
     sv = saves or (None, None, None, None)
     L = _L()
-    L.ivln_cma_seq_fwd_f32.argtypes = [vp, vp, i64, vp, vp, vp, vp, i64, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp]
+    L.ivln_cma_seq_fwd_f32.argtypes = [vp, vp, i64, vp, vp, vp, vp, i64, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp]
     check(L.ivln_cma_seq_fwd_f32(dptr(gi), _p(h0), h0.stride(0), dptr(masks_u8), dptr(w_hh), dptr(b_hh), _p(out),
                                  out.stride(0), _p(state_out), state_out.stride(0) if state_out is not None else 0, T, N,
-                                 H, _p(sv[0]), _p(sv[1]), _p(sv[2]), _p(sv[3]), stream_ptr()), "ivln_cma_seq_fwd_f32")
+                                 H, _p(sv[0]), _p(sv[1]), _p(sv[2]), _p(sv[3]), _p(_seq_ws(gi.device)), stream_ptr()),
+          "ivln_cma_seq_fwd_f32")
 
 
 def gru_seq_bwd(d_out, r, z, n, ghn, out, h0, masks_u8, whh_t, T, N, dgi, dgh, hp, dhz):
     H = r.shape[1]
     L = _T()
-    L.ivln_cma_seq_bwd_f32.argtypes = [vp, i64, vp, vp, vp, vp, vp, i64, vp, i64, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]
+    L.ivln_cma_seq_bwd_f32.argtypes = [vp, i64, vp, vp, vp, vp, vp, i64, vp, i64, vp, vp, i32, i32, i32, vp, vp, vp, vp,
+                                       vp, vp]
     check(L.ivln_cma_seq_bwd_f32(_p(d_out), d_out.stride(0), dptr(r), dptr(z), dptr(n), dptr(ghn), _p(out), out.stride(0),
                                  _p(h0), h0.stride(0), dptr(masks_u8), dptr(whh_t), T, N, H, dptr(dgi), dptr(dgh), dptr(hp),
-                                 dptr(dhz), stream_ptr()), "ivln_cma_seq_bwd_f32")
+                                 dptr(dhz), _p(_seq_ws(r.device)), stream_ptr()), "ivln_cma_seq_bwd_f32")
 
 
 def attn(q, k, v, valid_len, scale, out, save_attn=None, row_index=None):
@@ -970,6 +998,21 @@ def linear_argmax(x, w, bias, out=None):
     L.ivln_linear_argmax_f32.argtypes = [vp, i64, vp, vp, i32, i32, i32, vp, vp, vp]
     check(L.ivln_linear_argmax_f32(_p(x), x.stride(0), dptr(w), _p(bias), rows, K, w.shape[0], dptr(out), None,
                                    stream_ptr()), "ivln_linear_argmax_f32")
+    return out
+
+
+def linear_sample(x, w, bias, u_sample, u_beta=None, beta=0.0, expert=None, out=None, logits_out=None):
+    """Sampled action head in one launch: inverse-CDF draw from softmax(x . w^T + b) with the uniforms `u_sample`
+    (rows,) f32, beta-mixed with `expert` (rows,) f64 through `u_beta` (rows,) f32 and zeroed where expert == -1
+    (ivln_linear_sample_f32); out (rows, 1) int64."""
+    rows, K = x.shape
+    if out is None:
+        out = torch.empty((rows, 1), dtype=torch.int64, device=x.device)
+    L = _L()
+    L.ivln_linear_sample_f32.argtypes = [vp, i64, vp, vp, i32, i32, i32, vp, vp, f32, vp, vp, vp, vp]
+    check(L.ivln_linear_sample_f32(_p(x), x.stride(0), dptr(w), _p(bias), rows, K, w.shape[0], dptr(u_sample),
+                                   _p(u_beta), float(beta), _p(expert), dptr(out), _p(logits_out), stream_ptr()),
+          "ivln_linear_sample_f32")
     return out
 
 

@@ -431,19 +431,35 @@ class ILPolicy(Policy):
     def forward(self, *x):
         raise NotImplementedError
 
-    def _act(self, features, deterministic):
+    # keys a collection loop adds to the observation dict to have the sampled action drawn (and beta-mixed) on the
+    # device from host-supplied uniforms; without them `sample()` is torch's own Categorical draw
+    U_SAMPLE, U_BETA = "_u_sample", "_u_beta"
+    collect_mix = None  # {"beta": float, "expert_uuid": str} while a DAgger collection mixes in-kernel
+
+    def _act(self, features, deterministic, observations=None):
+        lin = self.action_distribution.linear
+        small = features.is_cuda and lin.out_features <= 8 and features.stride(-1) == 1
+        out = getattr(self, "_action_out_buffer", None)
         if deterministic:  # distribution.mode() == argmax of probs == argmax of logits: head + argmax, one launch
-            lin = self.action_distribution.linear
-            if features.is_cuda and lin.out_features <= 8 and features.stride(-1) == 1:
-                return ops.linear_argmax(features, lin.weight, lin.bias, out=getattr(self, "_action_out_buffer", None))
+            if small:
+                return ops.linear_argmax(features, lin.weight, lin.bias, out=out)
             logits = self.action_distribution.raw_logits(features)
-            return ops.argmax_rows(logits.contiguous(), out=getattr(self, "_action_out_buffer", None))
+            return ops.argmax_rows(logits.contiguous(), out=out)
+        if small and observations is not None and self.U_SAMPLE in observations:
+            # inverse-CDF draw from the caller's uniforms (+ expert mixing / the -1 rule of a DAgger collection) in the
+            # head's own launch: a pure function of the step's inputs, so the sampled step replays as a hipGraph
+            mix = self.collect_mix
+            u_beta = observations.get(self.U_BETA) if mix else None
+            expert = observations[mix["expert_uuid"]].view(-1) if mix else None
+            return ops.linear_sample(features, lin.weight, lin.bias, observations[self.U_SAMPLE].view(-1),
+                                     None if u_beta is None else u_beta.view(-1), mix["beta"] if mix else 0.0, expert,
+                                     out=out)
         logits = self.action_distribution.raw_logits(features)
         return CustomFixedCategorical(logits=logits).sample()
 
     def act(self, observations, rnn_states, prev_actions, masks, deterministic=False):
         features, rnn_states = self.net(observations, rnn_states, prev_actions, masks)
-        return self._act(features, deterministic), rnn_states
+        return self._act(features, deterministic, observations), rnn_states
 
     def act_iterative(self, observations, rnn_hidden_states, prev_actions, agent_episode_not_done_masks,
                       sim_episode_not_done_masks, tour_not_done_masks, action_masks, deterministic=False):
@@ -476,7 +492,7 @@ class MapCMAPolicy(ILPolicy):
             observations, rnn_hidden_states, prev_actions, action_masks=agent_episode_not_done_masks,
             episode_masks=None, tour_masks=None,
         )
-        return self._act(features, deterministic), rnn_hidden_states
+        return self._act(features, deterministic, observations), rnn_hidden_states
 
     def build_features(self, observations, rnn_hidden_states, prev_actions, agent_episode_not_done_masks,
                        tour_not_done_masks=None) -> Tuple[Tensor, Tensor]:

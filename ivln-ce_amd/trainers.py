@@ -130,6 +130,8 @@ def update_agent(policy, optimizer: FlatAdam, observations, prev_actions, not_do
         optimizer.step(world)
     al = float(action_loss.item())
     ax = float(aux_loss.item()) if isinstance(aux_loss, torch.Tensor) else float(aux_loss)
+    if dev.type == "cuda":
+        ops.check_seq_sync()  # the stream was just synchronised by .item(): a timed-out persistent GRU is an error
     if carry:
         return (al + ax) * scale, al, ax, rnn_out.detach()
     return (al + ax) * scale, al, ax
