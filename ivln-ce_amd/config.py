@@ -181,6 +181,10 @@ def _experiment_defaults() -> Config:
     _C.IL.DAGGER.preload_lmdb_features = False
     _C.IL.DAGGER.lmdb_features_dir = "data/trajectories_dirs/debug/trajectories.lmdb"
     _C.IL.DAGGER.drop_existing_lmdb_features = True
+    # (not reference keys) replay the sampled collection step - mapper + policy.act + beta-mixing - as captured hipGraphs
+    # (trainers._RolloutStepper); re-index the host-side per-env lists when envs pause (quirk Q12, trainers.py)
+    _C.IL.DAGGER.USE_HIP_GRAPH = True
+    _C.IL.DAGGER.compact_paused_rows = False
     # --- RL.POLICY.OBS_TRANSFORMS (default.py:87-93) ---
     _C.RL = CN()
     _C.RL.POLICY = CN()

@@ -33,8 +33,11 @@ def _stream(device, role, **kw):
 
 # `not_done_masks` resets the mapper (and the policy, unless `episode_not_done_masks` is given too: iterative
 # evaluation keeps the maps for a whole tour while the policy state still resets per episode)
+# `_u_sample` / `_u_beta` (+ the expert sensor named by `extra_keys`): the host-supplied uniforms of a SAMPLED step (DAgger
+# collection): with them the action head draws and beta-mixes on the device (policy.ILPolicy._act), so that the sampled
+# step is a pure function of its inputs and replays like the deterministic one
 _STEP_KEYS = ("depth", "semantic12", "rgb", "instruction", "world_robot_pose", "world_robot_orientation",
-              "not_done_masks", "episode_not_done_masks")
+              "not_done_masks", "episode_not_done_masks", "_u_sample", "_u_beta")
 
 
 def _policy_masks(batch):
@@ -49,14 +52,17 @@ class GraphedRollout:
     same kernels, so replay and eager stay bit-identical."""
 
     def __init__(self, policy, obs_transforms, example_obs: Dict, deterministic: bool = True, streams: bool = True,
-                 warmup: int = 2):
+                 warmup: int = 2, extra_keys=()):
         self.policy = policy
         self.transforms = list(obs_transforms)
         self.deterministic = deterministic
         dev = next(policy.parameters()).device
         self.device = dev
         self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in example_obs.items()
-                       if (k in _STEP_KEYS or not torch.is_tensor(v))}
+                       if (k in _STEP_KEYS or k in extra_keys or not torch.is_tensor(v))}
+        # the action kernel writes straight into the next step's previous-action buffer: deterministic steps and
+        # sampled steps whose uniforms come with the observations (torch's own Categorical.sample cannot)
+        self._direct_actions = deterministic or "_u_sample" in self.static
         B = example_obs["depth"].shape[0]
         H = policy.net._hidden_size
         L = policy.net.num_recurrent_layers
@@ -102,7 +108,8 @@ class GraphedRollout:
             for t in self.transforms:
                 batch = t(batch)
         net._rnn_out_buffer = self.rnn[dst]
-        self.policy._action_out_buffer = self.prev[dst] if self.deterministic else None
+        self.policy._action_out_buffer = self.prev[dst] if self._direct_actions else None
+        self._last_batch = batch
         try:
             with torch.no_grad():
                 actions, rnn = self.policy.act(batch, self.rnn[src], self.prev[src], _policy_masks(batch),
@@ -165,7 +172,7 @@ class GraphedRollout:
             batch = dict(batch)
             net._stage, net._persist = "post", self._persist
             net._rnn_out_buffer = self.rnn[dst]
-            self.policy._action_out_buffer = self.prev[dst] if self.deterministic else None
+            self.policy._action_out_buffer = self.prev[dst] if self._direct_actions else None
             try:
                 with torch.no_grad():
                     actions, rnn = self.policy.act(batch, self.rnn[src], self.prev[src], _policy_masks(batch),
@@ -289,6 +296,21 @@ class GraphedRollout:
             self.graphs[self.phase].replay()
         self.phase ^= 1
         return self.actions
+
+    def maps(self):
+        """(occupancy_map, semantic_map) of the last replayed step: the mapper's persistent (B, 64, 64) u8 buffers, as
+        the captured batch holds them (None, None without a mapper)."""
+        batch = self._keep[0] if self.split else getattr(self, "_last_batch", {})
+        return batch.get("occupancy_map"), batch.get("semantic_map")
+
+    def depth_features(self):
+        """(B, 128, 4, 4) output of `net.depth_encoder.visual_encoder` of the last replayed step - what the collection
+        loops cache per step (dagger_trainer.py:317-323; a forward hook cannot fire inside a replay): the leading
+        channels of the depth branch's (B, 192, 4, 4) buffer in the side graph's pool."""
+        if not self.split:
+            return None
+        dep = self._dep[0]
+        return dep[:, : self.policy.net.depth_encoder.visual_encoder.output_shape[0]]
 
     def reset_state(self):
         for t in self.rnn + self.prev:

@@ -385,11 +385,14 @@ class BaseVLNCETrainer:
         batch = batch_obs(observations, self.device)
         return observations, (apply_obs_transforms_batch(batch, self.obs_transforms) if transform else batch)
 
-    def _graph_eligible(self):
-        """The step can be captured when actions are deterministic and every transformer is an iterative
-        mapper (the known-map ones read files on episode reset: host work that cannot live in a graph)."""
+    def _graph_eligible(self, sampled=False):
+        """The step can be captured when actions are deterministic - or sampled on the device from host uniforms
+        (`sampled`: the collection loops, see _RolloutStepper) - and every transformer is an iterative mapper (the
+        known-map ones read files on episode reset: host work that cannot live in a graph)."""
         cfg = self.config
-        if not (bool(getattr(cfg.EVAL, "USE_HIP_GRAPH", True)) and not cfg.EVAL.SAMPLE and self.device.type == "cuda"):
+        if self.device.type != "cuda":
+            return False
+        if not sampled and not (bool(getattr(cfg.EVAL, "USE_HIP_GRAPH", True)) and not cfg.EVAL.SAMPLE):
             return False
         if len(cfg.VIDEO_OPTION) > 0:  # the *_viz frames are host-side numpy (a D2H copy per step)
             return False
@@ -398,21 +401,28 @@ class BaseVLNCETrainer:
         # MapCMA needs its mapper in the step; the map-free policies (Latent-CMA) are captured as they are
         return len(self.obs_transforms) > 0 or cfg.MODEL.policy_name != "MapCMAPolicy"
 
-    def _make_runner(self, batch, rnn_states, prev_actions, first):
+    def _make_runner(self, batch, rnn_states, prev_actions, first, deterministic=True, extra_keys=()):
         """GraphedRollout for the current number of active envs, seeded with the carried state.  The first
         capture warms up by running the step (the mapper is reset afterwards: nothing has been mapped yet
         and the first real step arrives with not_done_masks == 0 anyway); later captures - envs were paused,
-        the batch shrank - must not touch the mapper's world cloud, so they capture without executing."""
+        the batch shrank - must not touch the mapper's world cloud, so they capture without executing.
+        A policy in train mode (the collection loops: quirk Q6, BatchNorm batch statistics during rollouts) updates
+        its running statistics in every executed step: the warm-up's updates are undone."""
         from .graphed import GraphedRollout
 
         # the three-graph split is MapCMANet's staging; other policies replay one graph on one stream
         split = type(self.policy).__name__ == "MapCMAPolicy"
-        runner = GraphedRollout(self.policy, self.obs_transforms, batch, deterministic=True,
-                                streams="split" if split else False, warmup=2 if first else 0)
+        keep = {k: v.clone() for k, v in self.policy.named_buffers()} if (first and self.policy.training) else None
+        runner = GraphedRollout(self.policy, self.obs_transforms, batch, deterministic=deterministic,
+                                streams="split" if split else False, warmup=2 if first else 0, extra_keys=extra_keys)
         if first:
             for t in self.obs_transforms:
                 if getattr(t, "mapping_module", None) is not None:
                     t.mapping_module.reset()
+        if keep is not None:
+            with torch.no_grad():
+                for k, v in self.policy.named_buffers():
+                    v.copy_(keep[k])
         runner.rnn[runner.phase].copy_(rnn_states)
         runner.prev[runner.phase].copy_(prev_actions)
         return runner
@@ -821,6 +831,110 @@ class PrefetchLoader:
             th.join(timeout=5.0)
 
 
+class _RolloutStepper:
+    """One sampled, expert-mixed policy step of a DAgger collection loop (dagger_trainer.py:416-427, 469-472;
+    iterative_collection_dagger_trainer.py:300-348) and the per-step host copies the loops store.
+
+    Two ways to the same values:
+      reference statements  `policy.act(...)` (torch's Categorical draw) then `where(rand < beta, expert, a)` and
+                            `where(expert == -1, 0, .)` in torch - what the scripted stand-in policies of the
+                            host-logic goldens run, and any policy without a device sampler;
+      device mixing         (`ILPolicy` on a GPU) the action head's own launch draws by inverse CDF from a host
+                            uniform, mixes and applies the -1 rule (ivln_linear_sample_f32).  The step is then a pure
+                            function of its inputs: mapper + policy replay as captured hipGraphs
+                            (`IL.DAGGER.USE_HIP_GRAPH`, default on), bit-identical to the eager launches for the
+                            same uniforms (tests/test_gpu_train.py).
+    The beta draw always comes from the default host generator (one `rand` per step, like the reference's
+    `rand_like`), the sampling uniforms from a generator of their own, so a seeded run mixes identically either way.
+    Per step ONE stream synchronisation: actions, the two maps and the frozen encoder's features are copied to pinned
+    host buffers together (the reference's hooks did a blocking `.cpu()` each)."""
+
+    def __init__(self, trainer, beta, expert_uuid, iterative):
+        self.tr, self.beta, self.expert_uuid, self.iterative = trainer, float(beta), expert_uuid, iterative
+        cfg, pol = trainer.config, trainer.policy
+        self.dev = trainer.device
+        self.on_gpu = self.dev.type == "cuda"
+        self.device_mix = self.on_gpu and hasattr(pol, "U_SAMPLE")
+        self.feats, self.hooks = trainer._feature_hooks(to_host=not self.on_gpu)
+        self.use_graph = (self.device_mix and bool(getattr(cfg.IL.DAGGER, "USE_HIP_GRAPH", True))
+                          and trainer._graph_eligible(sampled=True) and type(pol).__name__ == "MapCMAPolicy")
+        self.runner, self.captured = None, False
+        self.gen = torch.Generator().manual_seed(int(cfg.TASK_CONFIG.SEED) + 7919 * (trainer.rank + 1))
+        self.pinned = {}
+        if self.device_mix:
+            pol.collect_mix = {"beta": self.beta, "expert_uuid": expert_uuid}
+
+    def close(self):
+        for h in self.hooks:
+            h.remove()
+        if self.device_mix:
+            self.tr.policy.collect_mix = None
+
+    def on_pause(self):
+        self.runner = None  # fewer rows: capture again for the new batch size, seeded with the kept rows
+
+    def _to_host(self, name, t):
+        """Asynchronous D2H into a pinned buffer (one per name and shape); valid after the step's synchronise."""
+        if not self.on_gpu:
+            return t
+        key = (name, tuple(t.shape), t.dtype)
+        buf = self.pinned.get(key)
+        if buf is None:
+            buf = self.pinned[key] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        buf.copy_(t, non_blocking=True)
+        return buf
+
+    def step(self, batch, rnn_states, prev_actions, masks):
+        """masks: (not_done,) or the four iterative masks.  Returns (final actions (n, 1) i64 on the device - what the
+        envs are stepped with and the next step's previous actions -, rnn_states, host dict with `actions` (list of
+        int), `occ` / `sem` (numpy or None), `depth` / `rgb` (CPU tensors or None))."""
+        tr, pol = self.tr, self.tr.policy
+        n = prev_actions.shape[0]
+        draw = torch.rand((n, 1), dtype=torch.float)  # default generator: the reference's rand_like(actions)
+        if self.device_mix:
+            batch[pol.U_SAMPLE] = torch.rand((n, 1), dtype=torch.float, generator=self.gen).to(self.dev)
+            batch[pol.U_BETA] = draw.to(self.dev)
+        if self.use_graph:
+            if self.runner is None:
+                self.runner = tr._make_runner(batch, rnn_states, prev_actions, first=not self.captured,
+                                              deterministic=False, extra_keys=(self.expert_uuid,))
+                self.captured = True
+            actions = self.runner.step(batch)
+            rnn_states = self.runner.rnn_states
+            occ, sem = self.runner.maps()
+            depth = self.runner.depth_features() if tr._caches_depth() else None
+            rgb = None
+        else:
+            if self.iterative:
+                actions, rnn_states = pol.act_iterative(batch, rnn_states, prev_actions, *masks, deterministic=False)
+            else:
+                actions, rnn_states = pol.act(batch, rnn_states, prev_actions, masks[0], deterministic=False)
+            if not self.device_mix:  # the reference's statements
+                expert = batch[self.expert_uuid].long()
+                actions = torch.where(draw.to(actions.device) < self.beta, expert, actions)
+                actions = torch.where(expert == -1, torch.zeros_like(actions), actions)
+            prev_actions.copy_(actions)
+            actions = prev_actions
+            occ, sem = batch.get("occupancy_map"), batch.get("semantic_map")
+            depth, rgb = self.feats.get("depth"), self.feats.get("rgb")
+        if (occ is None) != (sem is None):
+            raise RuntimeError("either both map keys should exist in the batch or neither")
+        host = {"actions": self._to_host("a", actions), "occ": None if occ is None else self._to_host("o", occ),
+                "sem": None if sem is None else self._to_host("s", sem),
+                "depth": None if depth is None else self._to_host("d", depth),
+                "rgb": None if rgb is None else self._to_host("r", rgb)}
+        if self.on_gpu:
+            torch.cuda.current_stream().synchronize()
+        host["actions"] = [int(a) for a in host["actions"].view(-1).tolist()]
+        for k in ("occ", "sem"):
+            if host[k] is not None:
+                host[k] = host[k].numpy().copy()
+        for k in ("depth", "rgb"):
+            if host[k] is not None:
+                host[k] = host[k].clone() if self.on_gpu else host[k]
+        return actions, rnn_states, host
+
+
 @baseline_registry.register_trainer(name="dagger")
 class DaggerTrainer(BaseVLNCETrainer):
     def __init__(self, config=None):
@@ -846,18 +960,26 @@ class DaggerTrainer(BaseVLNCETrainer):
         `IL.DAGGER.compact_paused_rows: True` (not a reference key) re-indexes the host lists as well."""
         return bool(getattr(self.config.IL.DAGGER, "compact_paused_rows", False))
 
-    def _feature_hooks(self):
+    def _caches_depth(self):
+        cfg = self.config
+        return not cfg.MODEL.DEPTH_ENCODER.trainable and cfg.MODEL.DEPTH_ENCODER.cnn_type == "VlnResnetDepthEncoder"
+
+    def _feature_hooks(self, to_host=True):
         """dagger_trainer.py:301-323 / iterative_collection_dagger_trainer.py:184-210: forward hooks that keep the
-        frozen encoders' output of the current step on the host (`feats["depth"]`, `feats["rgb"]`), so that stored
-        trajectories carry features instead of frames."""
+        frozen encoders' output of the current step (`feats["depth"]`, `feats["rgb"]`), so that stored trajectories
+        carry features instead of frames.  `to_host` False: the device tensor is kept and the stepper copies it to
+        pinned memory together with the step's other outputs (one synchronisation per step instead of a blocking
+        `.cpu()` per hook)."""
         cfg = self.config
         feats, hooks = {}, []
-        if not cfg.MODEL.DEPTH_ENCODER.trainable and cfg.MODEL.DEPTH_ENCODER.cnn_type == "VlnResnetDepthEncoder":
-            hooks.append(self.policy.net.depth_encoder.visual_encoder.register_forward_hook(
-                lambda m, i, o: feats.__setitem__("depth", o.detach().cpu())))
+
+        def keep(name):
+            return lambda m, i, o: feats.__setitem__(name, o.detach().cpu() if to_host else o.detach())
+
+        if self._caches_depth():
+            hooks.append(self.policy.net.depth_encoder.visual_encoder.register_forward_hook(keep("depth")))
         if not cfg.MODEL.RGB_ENCODER.trainable and hasattr(self.policy.net, "rgb_encoder"):
-            hooks.append(self.policy.net.rgb_encoder.cnn.register_forward_hook(
-                lambda m, i, o: feats.__setitem__("rgb", o.detach().cpu())))
+            hooks.append(self.policy.net.rgb_encoder.cnn.register_forward_hook(keep("rgb")))
         return feats, hooks
 
     def _store_episode(self, episode, idx, expert_uuid):
@@ -898,10 +1020,14 @@ class DaggerTrainer(BaseVLNCETrainer):
         p = cfg.IL.DAGGER.p
         beta = 0.0 if p == 0.0 else p ** data_it
         ensure_unique_episodes = beta == 1.0
-        feats, hooks = self._feature_hooks()
+        stepper = _RolloutStepper(self, beta, expert_uuid, iterative=False)
         collected, start_id = 0, len(self.store)
         ep_ids_collected = {ep.episode_id for ep in envs.current_episodes()} if ensure_unique_episodes else None
         target = max(1, cfg.IL.DAGGER.update_size // self.world)
+        # host mirrors of two device rows the loop records per step (compacted with them on a pause): the previous
+        # actions and the expert's action of the CURRENT batch - no device-to-host copy per step for either
+        prev_host = [0] * n
+        expert_host = [o[expert_uuid].item() for o in observations]
         with torch.no_grad():
             while collected < target:
                 envs_to_pause = []
@@ -909,7 +1035,8 @@ class DaggerTrainer(BaseVLNCETrainer):
                 for i in range(envs.num_envs):
                     # data-parallel ranks stop exactly at their share (no reference counterpart; a single process
                     # stores every episode that finished in this pass, like the reference)
-                    if dones[i] and not skips[i] and (self.world == 1 or collected < target):
+                    # (an EMPTY list can only be met after a quirk-Q12 shift - the reference dies in batch_obs there)
+                    if dones[i] and not skips[i] and episodes[i] and (self.world == 1 or collected < target):
                         self._store_episode(episodes[i], start_id + collected, expert_uuid)
                         collected += 1
                         if ensure_unique_episodes:
@@ -923,6 +1050,9 @@ class DaggerTrainer(BaseVLNCETrainer):
                     keep = [i for i in range(envs.num_envs) if i not in envs_to_pause]
                     envs, rnn_states, not_done_masks, prev_actions, batch, _ = self._pause_envs(
                         envs_to_pause, envs, rnn_states, not_done_masks, prev_actions, batch)
+                    prev_host = [prev_host[i] for i in keep]
+                    expert_host = [expert_host[i] for i in keep]
+                    stepper.on_pause()
                     if self._compact_host_rows():
                         observations = [observations[i] for i in keep]
                         episodes = [episodes[i] for i in keep]
@@ -930,43 +1060,33 @@ class DaggerTrainer(BaseVLNCETrainer):
                         break
                 if self.world > 1 and collected >= target:
                     break
-                actions, rnn_states = self.policy.act(batch, rnn_states, prev_actions, not_done_masks,
-                                                      deterministic=False)
-                expert = batch[expert_uuid].long()
-                draw = torch.rand(actions.shape, dtype=torch.float).to(actions.device)
-                actions = torch.where(draw < beta, expert, actions)
-                occ = batch["occupancy_map"].cpu().numpy() if "occupancy_map" in batch else None
-                sem = batch["semantic_map"].cpu().numpy() if "semantic_map" in batch else None
-                if (occ is None) != (sem is None):
-                    raise RuntimeError("either both map keys should exist in the batch or neither")
-                prev_cpu = prev_actions.cpu()
-                expert_cpu = batch[expert_uuid].cpu()
+                actions, rnn_states, host = stepper.step(batch, rnn_states, prev_actions, (not_done_masks,))
                 tours_now = [getattr(e, "tour_id", None) for e in envs.current_episodes()]
+                experts = expert_host
                 for i in range(envs.num_envs):
                     o = dict(observations[i])
-                    if "rgb" in feats:
-                        o["rgb_features"] = feats["rgb"][i].clone()
+                    if host["rgb"] is not None:
+                        o["rgb_features"] = host["rgb"][i]
                         o.pop("rgb", None)
-                    if "depth" in feats:
-                        o["depth_features"] = feats["depth"][i].clone()
+                    if host["depth"] is not None:
+                        o["depth_features"] = host["depth"][i]
                         o.pop("depth", None)
-                    if occ is not None:
-                        o["occupancy_map"], o["semantic_map"] = occ[i].copy(), sem[i].copy()
+                    if host["occ"] is not None:
+                        o["occupancy_map"], o["semantic_map"] = host["occ"][i], host["sem"][i]
                         for k in ["semantic", "semantic12", "world_robot_pose", "world_robot_orientation", "env_name",
                                   "rgb"]:
                             o.pop(k, None)
-                    episodes[i].append((o, prev_cpu[i].item(), expert_cpu[i].item(), tours_now[i]))
-                skips_t = expert == -1
-                actions = torch.where(skips_t, torch.zeros_like(actions), actions)
-                skips = skips_t.squeeze(-1).cpu().tolist()
-                prev_actions.copy_(actions)
-                outputs = envs.step([a[0].item() for a in actions])
+                    episodes[i].append((o, prev_host[i], experts[i], tours_now[i]))
+                skips = [int(e) == -1 for e in experts]
+                prev_actions = actions
+                prev_host = host["actions"]
+                outputs = envs.step(host["actions"])
                 observations, _, dones, _ = [list(x) for x in zip(*outputs)]
                 not_done_masks = torch.tensor([[0] if d else [1] for d in dones], dtype=torch.uint8,
                                               device=self.device)
-                observations, batch = self._batch(observations, not_done_masks)
-        for h in hooks:
-            h.remove()
+                observations, batch = self._batch(observations, not_done_masks, transform=not stepper.use_graph)
+                expert_host = [o[expert_uuid].item() for o in observations]
+        stepper.close()
         envs.close()
         self._check_mappers()
         return collected
@@ -1078,7 +1198,7 @@ class IterativeCollectionDaggerTrainer(DaggerTrainer):
         p = cfg.IL.DAGGER.p
         beta = 0.0 if p == 0.0 else p ** data_it  # in Python 0.0 ** 0.0 == 1.0, but we want 0.0
         ensure_unique_episodes = beta == 1.0
-        feats, hooks = self._feature_hooks()
+        stepper = _RolloutStepper(self, beta, expert_uuid, iterative=True)
         collected_eps = 0
         ep_ids_collected = {ep.episode_id for ep in envs.current_episodes()} if ensure_unique_episodes else None
         # record numbering (:225-235): lmdb's entry count includes the tour table, which claims key "0" the first
@@ -1091,6 +1211,23 @@ class IterativeCollectionDaggerTrainer(DaggerTrainer):
             else:
                 start_id += 1
         target = max(1, cfg.IL.DAGGER.update_size // self.world)
+        use_graph = stepper.use_graph
+
+        def make_batch(observations):
+            # the maps are reset by the TOUR masks; a captured step carries the policy's own mask beside them
+            if use_graph:
+                observations = add_batched_data_to_observations(observations, agent_episode_not_done_masks,
+                                                                "episode_not_done_masks")
+                observations, batch = self._batch(observations, tour_not_done_masks, transform=False)
+                return batch, observations
+            return self.batch_and_transform(observations, tour_not_done_masks)
+
+        if use_graph:
+            batch, observations = make_batch(observations)
+        # host mirrors of the device rows the loop records per step, compacted with them on a pause
+        prev_host = [0] * n
+        expert_host = [o[expert_uuid].item() for o in observations]
+        acting = [True] * n
         with torch.no_grad():
             while collected_eps < target:
                 envs_to_pause = [] if ensure_unique_episodes else None
@@ -1104,6 +1241,8 @@ class IterativeCollectionDaggerTrainer(DaggerTrainer):
                     if self.world > 1 and collected_eps >= target:  # data-parallel ranks stop exactly at their share
                         episodes[i] = []
                         continue
+                    if not episodes[i]:  # only after a quirk-Q12 shift (the reference dies in batch_obs there)
+                        continue
                     idx = start_id + collected_eps
                     self._store_episode(episodes[i], idx, expert_uuid)
                     tours_to_idxs[str(episodes[i][0][3])].append(idx)
@@ -1115,10 +1254,15 @@ class IterativeCollectionDaggerTrainer(DaggerTrainer):
                             ep_ids_collected.add(current_episodes[i].episode_id)
                     episodes[i] = []
                 if ensure_unique_episodes:
-                    if envs_to_pause and self._compact_host_rows():
+                    if envs_to_pause:
                         keep = [i for i in range(envs.num_envs) if i not in envs_to_pause]
-                        observations = [observations[i] for i in keep]
-                        episodes = [episodes[i] for i in keep]
+                        prev_host = [prev_host[i] for i in keep]
+                        expert_host = [expert_host[i] for i in keep]
+                        acting = [acting[i] for i in keep]
+                        stepper.on_pause()
+                        if self._compact_host_rows():
+                            observations = [observations[i] for i in keep]
+                            episodes = [episodes[i] for i in keep]
                     (envs, rnn_states, agent_episode_not_done_masks, sim_episode_not_done_masks, tour_not_done_masks,
                      action_masks, prev_actions, batch, _) = self._pause_iterative_envs(
                         envs_to_pause, envs, rnn_states, agent_episode_not_done_masks, sim_episode_not_done_masks,
@@ -1127,40 +1271,39 @@ class IterativeCollectionDaggerTrainer(DaggerTrainer):
                         break
                 if self.world > 1 and collected_eps >= target:
                     break
-                actions, rnn_states = self.policy.act_iterative(
-                    batch, rnn_states, prev_actions, agent_episode_not_done_masks, sim_episode_not_done_masks,
-                    tour_not_done_masks, action_masks, deterministic=False)
-                draw = torch.rand(actions.shape, dtype=torch.float).to(actions.device)
-                actions = torch.where(draw < beta, batch[expert_uuid].long(), actions)
-                observations = self.add_map_to_observations(observations, batch, envs.num_envs)
-                acting = action_masks.view(-1).cpu().tolist()
-                prev_cpu = prev_actions.cpu()
-                expert_cpu = batch[expert_uuid].cpu()
+                actions, rnn_states, host = stepper.step(
+                    batch, rnn_states, prev_actions,
+                    (agent_episode_not_done_masks, sim_episode_not_done_masks, tour_not_done_masks, action_masks))
+                if host["occ"] is not None:  # add_map_to_observations (:28-58) from the step's host copies
+                    for i in range(envs.num_envs):
+                        observations[i]["occupancy_map"], observations[i]["semantic_map"] = host["occ"][i], host["sem"][i]
+                        for k in ["semantic", "semantic12", "world_robot_pose", "world_robot_orientation", "env_name"]:
+                            observations[i].pop(k, None)
                 for i, current_episode in enumerate(envs.current_episodes()):
                     if not acting[i]:  # only add steps if the agent is acting: skip oracle phases
                         continue
-                    if "depth" in feats:
-                        observations[i]["depth_features"] = feats["depth"][i]
+                    if host["depth"] is not None:
+                        observations[i]["depth_features"] = host["depth"][i]
                         del observations[i]["depth"]
-                    if "rgb" in feats:
-                        observations[i]["rgb_features"] = feats["rgb"][i]
+                    if host["rgb"] is not None:
+                        observations[i]["rgb_features"] = host["rgb"][i]
                     if "rgb" in observations[i]:
                         del observations[i]["rgb"]
-                    episodes[i].append((observations[i], prev_cpu[i].item(), expert_cpu[i].item(),
-                                        current_episode.tour_id))
-                skips_t = batch[expert_uuid].long() == -1
-                actions = torch.where(skips_t, torch.zeros_like(actions), actions)
-                skips = skips_t.squeeze(-1).cpu().tolist()
-                prev_actions.copy_(actions)
-                outputs = envs.step([a[0].item() for a in actions])
+                    observations[i].pop("episode_not_done_masks", None)  # (the captured step's extra mask key)
+                    episodes[i].append((observations[i], prev_host[i], expert_host[i], current_episode.tour_id))
+                skips = [int(e) == -1 for e in expert_host]
+                prev_actions = actions
+                prev_host = host["actions"]
+                outputs = envs.step(host["actions"])
                 (observations, _, agent_episode_dones, sim_episode_dones, tour_dones, produce_actions,
                  _) = [list(x) for x in zip(*outputs)]
                 (agent_episode_not_done_masks, sim_episode_not_done_masks, tour_not_done_masks,
                  action_masks) = self.masks_to_tensors(agent_episode_dones, sim_episode_dones, tour_dones,
                                                        produce_actions)
-                batch, observations = self.batch_and_transform(observations, tour_not_done_masks)
-        for h in hooks:
-            h.remove()
+                acting = [bool(p) for p in produce_actions]
+                batch, observations = make_batch(observations)
+                expert_host = [o[expert_uuid].item() for o in observations]
+        stepper.close()
         envs.close()
         self._check_mappers()
         if save_tour_idx_data:

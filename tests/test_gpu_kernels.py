@@ -832,3 +832,37 @@ def test_persistent_sequence_gru_is_reproducible_under_load():
         for x, y in zip(first, again):
             assert torch.equal(x, y), rep
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("rows", [1, 4, 8, 13])
+def test_sampled_action_head_inverse_cdf_mixing_and_skip_rule(rows):
+    """ivln_linear_sample_f32: a = first o with cumsum(exp(l - max))[o] > u * sum (torch restatement, exact on the
+    kernel's own logits), `where(u_beta < beta, expert, a)`, 0 where the expert says -1; and the draws follow
+    softmax(logits) (20 000 uniforms, 3 sigma)."""
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(rows)
+    K, O = 512, 4
+    x = torch.randn(rows, K, generator=g).to(DEV)
+    w = (torch.randn(O, K, generator=g) * 0.05).to(DEV)
+    b = torch.randn(O, generator=g).to(DEV)
+    u = torch.rand(rows, generator=g).to(DEV)
+    ub = torch.rand(rows, generator=g).to(DEV)
+    expert = torch.randint(-1, 4, (rows,), generator=g).double().to(DEV)
+    logits = torch.empty(rows, O, device=DEV)
+    a = ops.linear_sample(x, w, b, u, ub, 0.4, expert, logits_out=logits)
+    _close(logits, x.cpu() @ w.cpu().t() + b.cpu(), atol=1e-5)
+    p = torch.exp(logits - logits.max(1, keepdim=True).values)
+    pick = (torch.cumsum(p, 1) > (u * p.sum(1)).unsqueeze(1)).float().argmax(1)
+    ref = torch.where(ub < 0.4, expert.long(), pick)
+    ref = torch.where(expert.long() == -1, torch.zeros_like(ref), ref)
+    assert torch.equal(a.view(-1), ref)
+    plain = ops.linear_sample(x, w, b, u)   # no mixing: the bare draw
+    assert torch.equal(plain.view(-1), pick)
+    # distribution: one row, many uniforms
+    n = 20000
+    xs = x[:1].expand(n, K).contiguous()
+    draws = ops.linear_sample(xs, w, b, torch.rand(n, generator=g).to(DEV)).view(-1)
+    probs = torch.softmax(logits[0].double().cpu(), 0)
+    freq = torch.bincount(draws.cpu(), minlength=O).double() / n
+    assert ((freq - probs).abs() < 3 * (probs * (1 - probs) / n).sqrt() + 1e-3).all(), (freq, probs)

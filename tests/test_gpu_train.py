@@ -487,3 +487,59 @@ def test_update_with_deduplicated_instruction_rows_is_the_same_update():
         a, b = g0[k], g1[k]
         tol = 1e-5 * max(1.0, float(a.abs().max()))
         assert float((a - b).abs().max()) <= tol, (k, float((a - b).abs().max()), float(a.abs().max()))
+
+
+@pytest.mark.parametrize("trainer", ["dagger", "iterative_collection_dagger"])
+def test_sampled_collection_replays_as_graphs_bit_identical_to_eager(tmp_path, trainer):
+    """DAgger collection (`policy.act(deterministic=False)` + beta-mixing, dagger_trainer.py:416-427) with the action
+    drawn and mixed in the head's own launch from host uniforms: mapper + policy replay as captured hipGraphs
+    (IL.DAGGER.USE_HIP_GRAPH) and every stored trajectory - cached depth features, maps, previous and expert actions -
+    equals the eager collection's bit for bit, across the re-captures when envs pause (beta == 1 second pass)."""
+    import ivln_ce_amd  # noqa: F401
+    from ivln_ce_amd import trainers  # noqa: F401
+    from ivln_ce_amd.registry import baseline_registry
+
+    stores = {}
+    real = trainers.construct_envs
+    # three episodes per env: the beta == 1 pass runs every env out of new episodes (pauses, re-captures)
+    trainers.construct_envs = lambda *a, **k: real(*a, n_episodes=3, episodes_per_tour=2, **k)
+    request_cleanup = lambda: setattr(trainers, "construct_envs", real)  # noqa: E731
+    for mode in (True, False):
+        cfg = _tiny_cfg(tmp_path / f"g{int(mode)}", trainer)
+        cfg.defrost()
+        cfg.NUM_ENVIRONMENTS = 3
+        cfg.IL.DAGGER.update_size = 7
+        cfg.IL.DAGGER.USE_HIP_GRAPH = mode
+        cfg.freeze()
+        torch.manual_seed(0)
+        tr = baseline_registry.get_trainer(trainer)(cfg)
+        envs = trainers.construct_envs(cfg, None, iterative=trainer != "dagger")
+        observation_space, action_space = tr._get_spaces(cfg, envs=envs)
+        envs.close()
+        tr._initialize_policy(cfg, False, observation_space, action_space)
+        recs = []
+        for data_it, p in ((1, 0.5), (0, 1.0)):   # beta = 0.5 (sampled + mixed), then beta = 1 (unique episodes, pauses)
+            cfg.defrost()
+            cfg.IL.DAGGER.p = p
+            cfg.freeze()
+            torch.manual_seed(5 + data_it)
+            n0 = len(tr.store)
+            tr._update_dataset(data_it)
+            assert len(tr.store) - n0 >= 5
+        first = 0 if trainer == "dagger" else 0
+        for i in range(first, len(tr.store)):
+            recs.append(tr.store.get(i))
+        stores[mode] = recs
+        bufs = {k: v.clone() for k, v in tr.policy.named_buffers()}
+        stores[(mode, "buffers")] = bufs
+    request_cleanup()
+    assert len(stores[True]) == len(stores[False])
+    for (oa, pa, ea), (ob, pb, eb) in zip(stores[True], stores[False]):
+        assert sorted(oa) == sorted(ob)
+        for k in oa:
+            assert oa[k].dtype == ob[k].dtype and np.array_equal(oa[k], ob[k]), k
+        assert np.array_equal(pa, pb) and np.array_equal(ea, eb)
+    # quirk Q6: BatchNorm runs on batch statistics during collection and updates its running statistics - the
+    # captured steps must leave exactly the eager loop's buffers behind (the capture warm-up's updates are undone)
+    for k, v in stores[(True, "buffers")].items():
+        assert torch.equal(v, stores[(False, "buffers")][k]), k
