@@ -146,13 +146,21 @@ class GemmTimer:
 
 
 def mfma_roofline(gt, ms, n_steps, traffic, what):
+    """`traffic` arrives as the committed PMC figure per LAUNCH (the contract's unit: per launch, like `achieved`); the
+    per-STEP total is spelled out beside it, and so is the time basis of `achieved` / `frac`."""
     ach = (gt.flops / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
+    per_launch, per_step = traffic if isinstance(traffic, tuple) else (traffic, None)
     return {
         "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 5), "traffic": traffic,
+        "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 5), "traffic": per_launch,
+        "traffic_unit": "HBM bytes per launch of the family (rocprofv3 PMC passes committed under profiles/)",
+        "traffic_bytes_per_step": per_step,
         "kernel": MFMA_FAMILY + ": " + what,
         "flops_per_step": int(gt.flops / n_steps), "launches_per_step": round(len(gt.events) / n_steps, 1),
         "kernel_ms_per_step": round(ms / n_steps, 4),
+        "time_basis": "sum of per-launch HIP-event pairs in an instrumented EAGER single-stream pass outside the timed "
+                      "region (each pair includes ~2.5 us of dispatch); the timed replay overlaps two streams, so this "
+                      "sum can exceed ms_per_step - frac is conservative",
     }
 
 
@@ -239,11 +247,18 @@ def cpu_baseline(obs_cpu, B, budget_s=12.0, pred=False):
     }
 
 
+def pmc_traffic_pair(name, family="mfma_family"):
+    """(bytes per launch, bytes per step) of a kernel family from a committed PMC summary, or None."""
+    a = pmc_traffic(name, (family, "hbm_bytes_per_launch_corrected"))
+    b = pmc_traffic(name, (family, "hbm_bytes_per_step_corrected"))
+    return None if a is None else (a, b)
+
+
 def pmc_traffic(name, key):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs,
     gfx950 FETCH correction applied; profiles/<name>).  A counter pass cannot run inside the timed bench, so the
     figure is the committed one and only for its workload; None when no such profile is committed."""
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_{name}")
         if os.path.exists(path):
             try:
@@ -327,6 +342,62 @@ def bench_update(policy, dev, world, barrier, T=64, N=8, iters=5, warm=2):
     return el, {"rows_per_step_per_gpu": TN, "T": T, "N": N, "iters": iters, "roofline": roof}
 
 
+def bench_collect(cfg, policy, dev, rank, barrier, B=8, K=100, W=10, graph=True, seed=99):
+    """One step of a DAgger COLLECTION (dagger_trainer.py:416-494; configs[3]'s per-GPU shard of 8 envs): mapper +
+    `policy.act(deterministic=False)` + beta-mixing with the expert + the -1 rule, then what the loop keeps of the step
+    on the host - actions, the two maps, the frozen depth encoder's features - through trainers._RolloutStepper,
+    exactly as `_update_dataset` drives it (policy in train mode: quirk Q6).  Env stepping and trajectory storage
+    are host work outside the hot path.  Observations are resident in HBM when the clock starts."""
+    from ivln_ce_amd import trainers
+    from ivln_ce_amd.obs_transforms import GTSemanticsIterativeMapper
+
+    cfg = cfg.clone()
+    cfg.defrost()
+    cfg.IL.DAGGER.USE_HIP_GRAPH = bool(graph)
+    cfg.freeze()
+    tr = trainers.DaggerTrainer.__new__(trainers.DaggerTrainer)
+    tr.config, tr.device, tr.policy = cfg, dev, policy
+    tr.rank, tr.local_rank, tr.world = rank, dev.index or 0, 1
+    tr.obs_transforms = [GTSemanticsIterativeMapper.from_config(cfg)]
+    uuid = cfg.IL.DAGGER.expert_policy_sensor_uuid
+    n_pool = min(W + K, 120)
+    g = torch.Generator().manual_seed(seed + rank)
+    obs = to_dev(gen_observations(B, n_pool, seed=seed + rank), dev)
+    for o in obs:
+        o[uuid] = torch.randint(0, 4, (B, 1), generator=g).double().to(dev)
+    was_training = policy.training
+    policy.train()
+    stepper = trainers._RolloutStepper(tr, beta=0.75, expert_uuid=uuid, iterative=False)
+    rnn = torch.zeros(B, 2, 512, device=dev)
+    prev = torch.zeros(B, 1, dtype=torch.long, device=dev)
+
+    def do_step(i):
+        nonlocal rnn, prev
+        batch = dict(obs[i % n_pool])
+        if not stepper.use_graph:
+            batch = tr.obs_transforms[0](batch)
+        with torch.no_grad():
+            prev, rnn, host = stepper.step(batch, rnn, prev, (batch["not_done_masks"],))
+        return host
+
+    try:
+        for i in range(W):
+            do_step(i)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(K):
+            host = do_step(W + i)
+        barrier()
+        el = time.perf_counter() - t0
+        assert host["depth"].shape == (B, 128, 4, 4) and host["occ"].shape == (B, 64, 64) and len(host["actions"]) == B
+        tr.obs_transforms[0].mapping_module.check_status()
+        used_graph = stepper.use_graph
+    finally:
+        stepper.close()
+        policy.train(was_training)
+    return el, used_graph
+
+
 def mapper_roofline(mapper_tr, obs_dev, B, n_steps=20):
     """HBM roofline of the egocentric mapper (north_star: "achieved HBM GB/s for the scatter against gfx950
     peak").  Event pair around the mapper's launches of one step, the GPU parked on a spin kernel while the host
@@ -388,6 +459,21 @@ def capture(policy, transforms, example, mode, rank):
     return None, None
 
 
+def kfd_gpu_nodes():
+    """GPUs the kernel driver exposes, counted from sysfs (KFD topology nodes with SIMDs; CPU nodes have none).  None
+    when the topology is not readable - the children then find out themselves."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(base):
+            with open(os.path.join(base, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+        return n
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def spawn_ranks(n):
     """--gpus N without a launcher: start N ranks (one per GPU) through torch.distributed.run BEFORE this process
     initialises HIP, stream their output through and exit with their status."""
@@ -398,9 +484,9 @@ def spawn_ranks(n):
         port = s.getsockname()[1]
     env = dict(os.environ)
     if not env.get("IVLN_BENCH_ONE_DEVICE") and "--plumbing-only" not in sys.argv:
-        have = torch.cuda.device_count()  # does not initialise the runtime
-        if have < n:
-            log(f"--gpus {n} but only {have} visible device(s)")
+        have = kfd_gpu_nodes()  # a sysfs read: the parent never touches the HIP runtime
+        if have is not None and have < n:
+            log(f"--gpus {n} but only {have} GPU node(s) under /sys/class/kfd")
             return 2
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
@@ -441,6 +527,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pred-leg", action="store_true", help="skip the pred-semantics leg (extra JSON object)")
     ap.add_argument("--no-update", action="store_true", help="skip the DAgger update-step leg (extra JSON object)")
+    ap.add_argument("--no-collect", action="store_true", help="skip the DAgger collection-step leg (extra JSON object)")
+    ap.add_argument("--collect-envs", type=int, default=8, help="envs per GPU of the collection leg (configs[3]: 64 / 8)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--single-stream", action="store_true",
                     help="one graph on one stream instead of the default three graphs on two streams (depth ResNet || "
@@ -562,12 +650,10 @@ def main():
     if rank == 0:
         if head_pred:
             roofline = instrumented_mfma(head, min(6, K), "RedNet + depth ResNet + map CNN launches of one step",
-                                         pmc_traffic(f"predsem_B{B}_pmc_traffic.json",
-                                                     ("mfma_family", "hbm_bytes_per_launch_corrected")))
+                                         pmc_traffic_pair(f"predsem_B{B}_pmc_traffic.json"))
         else:
             roofline = instrumented_mfma(head, min(20, K), "all conv/linear launches of one step",
-                                         pmc_traffic("rollout_pmc_traffic.json",
-                                                     ("mfma_family", "hbm_bytes_per_launch_corrected")) if B == 4 else None)
+                                         pmc_traffic_pair("rollout_pmc_traffic.json") if B == 4 else None)
             mapper_roof = mapper_roofline(head["tr"], head["obs_dev"], B)
 
     # ---- configs[2]: RedNet-predicted semantics feeding the mapper, at its stated 8 envs ----
@@ -586,7 +672,7 @@ def main():
         if rank == 0:
             pred_leg["roofline"] = instrumented_mfma(
                 pl, 4, "RedNet + depth ResNet + map CNN launches of one step",
-                pmc_traffic(f"predsem_B{Bp}_pmc_traffic.json", ("mfma_family", "hbm_bytes_per_launch_corrected")))
+                pmc_traffic_pair(f"predsem_B{Bp}_pmc_traffic.json"))
             if world == 1 and not args.no_cpu_baseline:
                 log("cpu baseline (pred-semantics) ...")
                 pred_leg["cpu_baseline"] = cpu_baseline(pl["obs_cpu"], Bp, budget_s=12.0, pred=True)
@@ -606,6 +692,25 @@ def main():
                           "inflection-weighted CE + progress-monitor aux loss, HIP backward, "
                           + ("one flat RCCL all-reduce, " if world > 1 else "") + "Adam",
                   "roofline": uinfo["roofline"]}
+
+    # ---- DAgger collection step (sampled action + beta-mix + host copies): the rollout half of configs[3] ----
+    collect = None
+    if not args.no_collect and not head_pred:
+        Bc, ck, cw = args.collect_envs, 100, 10
+        log(f"rank {rank}: collection-step leg ({Bc} envs)")
+        cel, used_graph = bench_collect(cfg, policy, dev, rank, barrier, B=Bc, K=ck, W=cw, graph=not args.no_graph)
+        cel = max_over_ranks(cel)
+        collect = {"value": round(world * Bc * ck / cel, 1), "unit": "env-steps/s", "ms_per_step": round(1e3 * cel / ck, 4),
+                   "steps": ck, "warmup": cw, "envs_per_gpu": Bc,
+                   "launch": "hipGraph replay, 3 graphs on 2 streams" if used_graph else "eager",
+                   "what": "DAgger collection step of configs[3]'s per-GPU shard: gt-semantics mapper + MapCMAPolicy.act "
+                           "SAMPLED on the device from host uniforms, beta-mixed with the expert action (beta = 0.75) "
+                           "and zeroed where the expert says -1 in the action head's launch, policy in train mode "
+                           "(BatchNorm batch statistics, quirk Q6); actions, both maps and the cached depth features "
+                           "land in pinned host memory behind ONE synchronisation per step"}
+        if used_graph and rank == 0 and world == 1:  # the same step as eager launches, for the record
+            eel, _ = bench_collect(cfg, policy, dev, rank, barrier, B=Bc, K=30, W=5, graph=False)
+            collect["eager_ms_per_step"] = round(1e3 * eel / 30, 4)
 
     why = ("headline = configs[2] by request (--pred-semantics)" if head_pred else
            "headline = configs[1], the single-GPU configuration BASELINE.json's env-steps/s metric is quoted on "
@@ -630,6 +735,8 @@ def main():
         out["mapper_roofline"] = mapper_roof
     if update is not None:
         out["update_step"] = update
+    if collect is not None:
+        out["dagger_collect_step"] = collect
     if pred_leg is not None:
         out["pred_semantics_step"] = pred_leg
     if rank == 0:

@@ -401,6 +401,15 @@ class BaseVLNCETrainer:
         # MapCMA needs its mapper in the step; the map-free policies (Latent-CMA) are captured as they are
         return len(self.obs_transforms) > 0 or cfg.MODEL.policy_name != "MapCMAPolicy"
 
+    def _map_before_pause(self, batch):
+        """Graph replay runs the mapper INSIDE the step, i.e. after a pause has compacted the batch rows - while the
+        reference (and the eager loop) mapped the full batch before the pause.  The mapper keys its world clouds by
+        batch row and never re-indexes them (quirk Q5), so the first step after a pause would see other maps than the
+        reference's.  When envs are about to pause, the replaying loops therefore map the uncompacted batch eagerly,
+        take that one policy step eagerly too, and capture again for the smaller batch afterwards - every step then
+        equals the eager loop's bit for bit (tests/test_gpu_train.py)."""
+        return apply_obs_transforms_batch(batch, self.obs_transforms)
+
     def _make_runner(self, batch, rnn_states, prev_actions, first, deterministic=True, extra_keys=()):
         """GraphedRollout for the current number of active envs, seeded with the carried state.  The first
         capture warms up by running the step (the mapper is reset afterwards: nothing has been mapped yet
@@ -522,17 +531,18 @@ class BaseVLNCETrainer:
         episodes_to_eval = sum(envs.number_of_episodes)
         if config.EVAL.EPISODE_COUNT > -1:
             episodes_to_eval = min(config.EVAL.EPISODE_COUNT, episodes_to_eval)
-        runner, captured = None, False
+        runner, captured, eager_once = None, False, False
         t0 = time.time()
         while envs.num_envs > 0 and len(stats_episodes) < episodes_to_eval:
             current_episodes = envs.current_episodes()
-            if use_graph:  # mapper + policy.act replayed as captured graphs; the state lives in the runner's buffers
-                if runner is None:
+            if use_graph and not eager_once:  # mapper + policy.act replayed as captured graphs; the state lives in
+                if runner is None:            # the runner's buffers
                     runner = self._make_runner(batch, rnn_states, prev_actions, first=not captured)
                     captured = True
                 actions = runner.step(batch)
                 rnn_states, prev_actions = runner.rnn_states, actions
             else:
+                eager_once = False
                 with torch.no_grad():
                     actions, rnn_states = self.policy.act(batch, rnn_states, prev_actions, not_done_masks,
                                                           deterministic=not config.EVAL.SAMPLE)
@@ -552,10 +562,10 @@ class BaseVLNCETrainer:
             observations, batch = self._batch(observations, not_done_masks, transform=not use_graph)
             next_episodes = envs.current_episodes()
             envs_to_pause = [i for i in range(envs.num_envs) if next_episodes[i].episode_id in stats_episodes]
+            if envs_to_pause and use_graph:
+                batch, runner, eager_once = self._map_before_pause(batch), None, True
             envs, rnn_states, not_done_masks, prev_actions, batch, _ = self._pause_envs(
                 envs_to_pause, envs, rnn_states, not_done_masks, prev_actions, batch)
-            if envs_to_pause:
-                runner = None  # fewer rows: capture again for the new batch size, seeded with the kept rows
         self._check_mappers()
         tours = (envs.dtw_data(), envs.gt_paths()) if hasattr(envs, "dtw_data") else ({}, {})
         gathered = D.gather_objects((stats_episodes, tours))
@@ -665,17 +675,18 @@ class BaseVLNCETrainer:
         observations, batch = make_batch(observations)
         stats_tours = defaultdict(dict)  # tour id -> episode id -> stats
         dtw_data = defaultdict(list)     # tour id -> positions
-        runner, captured = None, False
+        runner, captured, eager_once = None, False, False
         t0 = time.time()
         while envs.num_envs > 0:
             current_episodes = envs.current_episodes()
-            if use_graph:
+            if use_graph and not eager_once:
                 if runner is None:
                     runner = self._make_runner(batch, rnn_states, prev_actions, first=not captured)
                     captured = True
                 actions = runner.step(batch)
                 rnn_states, prev_actions = runner.rnn_states, actions
             else:
+                eager_once = False
                 with torch.no_grad():
                     actions, rnn_states = self.policy.act_iterative(
                         batch, rnn_states, prev_actions, agent_episode_not_done_masks, sim_episode_not_done_masks,
@@ -706,12 +717,12 @@ class BaseVLNCETrainer:
             next_episodes = envs.current_episodes()
             envs_to_pause = [i for i in range(envs.num_envs)
                              if sim_episode_dones[i] and next_episodes[i].episode_id in stats_tours[next_episodes[i].tour_id]]
+            if envs_to_pause and use_graph:
+                batch, runner, eager_once = self._map_before_pause(batch), None, True
             (envs, rnn_states, agent_episode_not_done_masks, sim_episode_not_done_masks, tour_not_done_masks,
              action_masks, prev_actions, batch, _) = self._pause_iterative_envs(
                 envs_to_pause, envs, rnn_states, agent_episode_not_done_masks, sim_episode_not_done_masks,
                 tour_not_done_masks, action_masks, prev_actions, batch)
-            if envs_to_pause:
-                runner = None
         self._check_mappers()
         gt_local = envs.gt_paths() if hasattr(envs, "gt_paths") else {}
         gathered = D.gather_objects((dict(stats_tours), dict(dtw_data), gt_local))
@@ -858,7 +869,7 @@ class _RolloutStepper:
         self.feats, self.hooks = trainer._feature_hooks(to_host=not self.on_gpu)
         self.use_graph = (self.device_mix and bool(getattr(cfg.IL.DAGGER, "USE_HIP_GRAPH", True))
                           and trainer._graph_eligible(sampled=True) and type(pol).__name__ == "MapCMAPolicy")
-        self.runner, self.captured = None, False
+        self.runner, self.captured, self.eager_once = None, False, False
         self.gen = torch.Generator().manual_seed(int(cfg.TASK_CONFIG.SEED) + 7919 * (trainer.rank + 1))
         self.pinned = {}
         if self.device_mix:
@@ -870,8 +881,13 @@ class _RolloutStepper:
         if self.device_mix:
             self.tr.policy.collect_mix = None
 
-    def on_pause(self):
-        self.runner = None  # fewer rows: capture again for the new batch size, seeded with the kept rows
+    def before_pause(self, batch):
+        """Envs are about to pause: a replaying loop maps the still uncompacted batch now, steps eagerly once and
+        captures again for the smaller batch afterwards (BaseVLNCETrainer._map_before_pause)."""
+        if self.use_graph:
+            batch = self.tr._map_before_pause(batch)
+            self.runner, self.eager_once = None, True
+        return batch
 
     def _to_host(self, name, t):
         """Asynchronous D2H into a pinned buffer (one per name and shape); valid after the step's synchronise."""
@@ -894,7 +910,7 @@ class _RolloutStepper:
         if self.device_mix:
             batch[pol.U_SAMPLE] = torch.rand((n, 1), dtype=torch.float, generator=self.gen).to(self.dev)
             batch[pol.U_BETA] = draw.to(self.dev)
-        if self.use_graph:
+        if self.use_graph and not self.eager_once:
             if self.runner is None:
                 self.runner = tr._make_runner(batch, rnn_states, prev_actions, first=not self.captured,
                                               deterministic=False, extra_keys=(self.expert_uuid,))
@@ -905,6 +921,7 @@ class _RolloutStepper:
             depth = self.runner.depth_features() if tr._caches_depth() else None
             rgb = None
         else:
+            self.eager_once = False
             if self.iterative:
                 actions, rnn_states = pol.act_iterative(batch, rnn_states, prev_actions, *masks, deterministic=False)
             else:
@@ -1012,15 +1029,15 @@ class DaggerTrainer(BaseVLNCETrainer):
                                  device=self.device)
         prev_actions = torch.zeros(n, 1, device=self.device, dtype=torch.long)
         not_done_masks = torch.zeros(n, 1, dtype=torch.uint8, device=self.device)
-        observations = envs.reset()
-        observations, batch = self._batch(observations, not_done_masks)
-        episodes = [[] for _ in range(n)]
-        skips = [False] * n
-        dones = [False] * n
         p = cfg.IL.DAGGER.p
         beta = 0.0 if p == 0.0 else p ** data_it
         ensure_unique_episodes = beta == 1.0
         stepper = _RolloutStepper(self, beta, expert_uuid, iterative=False)
+        observations = envs.reset()
+        observations, batch = self._batch(observations, not_done_masks, transform=not stepper.use_graph)
+        episodes = [[] for _ in range(n)]
+        skips = [False] * n
+        dones = [False] * n
         collected, start_id = 0, len(self.store)
         ep_ids_collected = {ep.episode_id for ep in envs.current_episodes()} if ensure_unique_episodes else None
         target = max(1, cfg.IL.DAGGER.update_size // self.world)
@@ -1048,11 +1065,11 @@ class DaggerTrainer(BaseVLNCETrainer):
                         episodes[i] = []
                 if ensure_unique_episodes and envs_to_pause:
                     keep = [i for i in range(envs.num_envs) if i not in envs_to_pause]
+                    batch = stepper.before_pause(batch)
                     envs, rnn_states, not_done_masks, prev_actions, batch, _ = self._pause_envs(
                         envs_to_pause, envs, rnn_states, not_done_masks, prev_actions, batch)
                     prev_host = [prev_host[i] for i in keep]
                     expert_host = [expert_host[i] for i in keep]
-                    stepper.on_pause()
                     if self._compact_host_rows():
                         observations = [observations[i] for i in keep]
                         episodes = [episodes[i] for i in keep]
@@ -1190,15 +1207,26 @@ class IterativeCollectionDaggerTrainer(DaggerTrainer):
         sim_episode_not_done_masks = torch.zeros(n, 1, dtype=torch.uint8, device=self.device)
         tour_not_done_masks = torch.zeros(n, 1, dtype=torch.uint8, device=self.device)
         action_masks = torch.ones(n, 1, dtype=torch.uint8, device=self.device)
-        observations, _, _ = [list(x) for x in zip(*envs.reset())]
-        batch, observations = self.batch_and_transform(observations, tour_not_done_masks)
-        episodes = [[] for _ in range(n)]
-        skips = [False for _ in range(n)]
-        sim_episode_dones = [False for _ in range(n)]
         p = cfg.IL.DAGGER.p
         beta = 0.0 if p == 0.0 else p ** data_it  # in Python 0.0 ** 0.0 == 1.0, but we want 0.0
         ensure_unique_episodes = beta == 1.0
         stepper = _RolloutStepper(self, beta, expert_uuid, iterative=True)
+        use_graph = stepper.use_graph
+
+        def make_batch(observations):
+            # the maps are reset by the TOUR masks; a captured step carries the policy's own mask beside them
+            if use_graph:
+                observations = add_batched_data_to_observations(observations, agent_episode_not_done_masks,
+                                                                "episode_not_done_masks")
+                observations, batch = self._batch(observations, tour_not_done_masks, transform=False)
+                return batch, observations
+            return self.batch_and_transform(observations, tour_not_done_masks)
+
+        observations, _, _ = [list(x) for x in zip(*envs.reset())]
+        batch, observations = make_batch(observations)
+        episodes = [[] for _ in range(n)]
+        skips = [False for _ in range(n)]
+        sim_episode_dones = [False for _ in range(n)]
         collected_eps = 0
         ep_ids_collected = {ep.episode_id for ep in envs.current_episodes()} if ensure_unique_episodes else None
         # record numbering (:225-235): lmdb's entry count includes the tour table, which claims key "0" the first
@@ -1211,19 +1239,6 @@ class IterativeCollectionDaggerTrainer(DaggerTrainer):
             else:
                 start_id += 1
         target = max(1, cfg.IL.DAGGER.update_size // self.world)
-        use_graph = stepper.use_graph
-
-        def make_batch(observations):
-            # the maps are reset by the TOUR masks; a captured step carries the policy's own mask beside them
-            if use_graph:
-                observations = add_batched_data_to_observations(observations, agent_episode_not_done_masks,
-                                                                "episode_not_done_masks")
-                observations, batch = self._batch(observations, tour_not_done_masks, transform=False)
-                return batch, observations
-            return self.batch_and_transform(observations, tour_not_done_masks)
-
-        if use_graph:
-            batch, observations = make_batch(observations)
         # host mirrors of the device rows the loop records per step, compacted with them on a pause
         prev_host = [0] * n
         expert_host = [o[expert_uuid].item() for o in observations]
@@ -1259,7 +1274,7 @@ class IterativeCollectionDaggerTrainer(DaggerTrainer):
                         prev_host = [prev_host[i] for i in keep]
                         expert_host = [expert_host[i] for i in keep]
                         acting = [acting[i] for i in keep]
-                        stepper.on_pause()
+                        batch = stepper.before_pause(batch)
                         if self._compact_host_rows():
                             observations = [observations[i] for i in keep]
                             episodes = [episodes[i] for i in keep]
