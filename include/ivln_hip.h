@@ -446,6 +446,9 @@ int ivln_add_f32(const float* a, const float* b, float* y, int64_t n, int relu, 
  * an env step -> the captured input buffers of the step graph; replaces per-tensor Tensor.copy_ at
  * base_il_trainer.py:688-703's batch_obs hand-over). */
 int ivln_copy_multi(const void* const* srcs, void* const* dsts, const int64_t* bytes, int n, void* stream);
+/* dsts[j][i] += srcs[j][i] (counts[j] floats, n <= 64 contiguous tensors) in one launch: the parameter gradients of
+ * one backward pass added onto the flat gradient bucket (`loss.backward()` accumulation, base_il_trainer.py:211). */
+int ivln_add_multi_f32(const float* const* srcs, float* const* dsts, const int64_t* counts, int n, void* stream);
 int ivln_copy2d_f32(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int rows, int cols,
                     int broadcast_rows, void* stream);
 
@@ -566,6 +569,14 @@ int ivln_pm_loss_fwd_f32(const float* pre, const float* progress, int n, float* 
                          void* stream);
 int ivln_pm_loss_bwd_f32(const float* dL, const float* hat, const float* progress, int n, float* dpre,
                          void* stream);
+/* The same loss as the update consumes it (AuxLosses.reduce, aux_losses.py:22-29): the mean over the entries the (n,)
+ * u8 mask selects (whole columns i) of L[j][i] = (tanh(pre_i) - progress_j)^2, without materialising the matrix.
+ * out2[0] = mean, out2[1] = number of selected entries; hat / dsum (n) are saved for the backward, which returns
+ * dpre = gout[0] * alpha * d(mean)/d(pre) (gout: the upstream gradient, a device scalar). */
+int ivln_pm_masked_mean_fwd_f32(const float* pre, const float* progress, const uint8_t* mask, int n, float* hat,
+                                float* dsum, float* out2, void* stream);
+int ivln_pm_masked_mean_bwd_f32(const float* gout, const float* hat, const float* dsum, const uint8_t* mask,
+                                const float* out2, int n, float alpha, float* dpre, void* stream);
 /* torch.optim.Adam step on a flat fp32 bucket (base_il_trainer.py:78-94, 213-215); seg_of/seg_lr give
  * per-segment learning rates (SEMANTIC_MAP_ENCODER.custom_lr) or NULL; zero_grad clears the grads. */
 int ivln_adam_step_f32(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,

@@ -13,7 +13,10 @@ import torch
 
 
 class _Term(NamedTuple):
-    values: torch.Tensor  # per-element loss, any shape `mask` broadcasts against under masked_select
+    # per-element loss, any shape `mask` broadcasts against under masked_select - or an object that offers
+    # `.values` (the same tensor, built on demand) and `.masked_mean(mask, alpha)` (the reduction done directly,
+    # e.g. train.PMLossTerm: no (TN, TN) matrix, no masked_select, no host synchronisation in the middle of an update)
+    values: object
     alpha: float
 
 
@@ -50,16 +53,21 @@ class AuxLossRegistry:
         self._terms[name] = _Term(loss, float(alpha))
 
     def get_loss(self, name: str) -> torch.Tensor:
-        return self._terms[name].values
+        v = self._terms[name].values
+        return v if torch.is_tensor(v) else v.values
 
     def reduce(self, mask: torch.Tensor):
         """sum_k alpha_k * mean(values_k[mask]); 0.0 when nothing is registered."""
         if not self._enabled:
             raise AssertionError("AuxLosses.reduce while inactive")
-        total = 0.0
+        total = None
         for term in self._terms.values():
-            total = total + term.alpha * torch.masked_select(term.values, mask).mean()
-        return total
+            if torch.is_tensor(term.values):
+                t = term.alpha * torch.masked_select(term.values, mask).mean()
+            else:
+                t = term.values.masked_mean(mask, term.alpha)
+            total = t if total is None else total + t
+        return 0.0 if total is None else total
 
 
 AuxLosses = AuxLossRegistry()

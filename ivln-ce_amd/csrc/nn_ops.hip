@@ -1290,6 +1290,39 @@ __global__ __launch_bounds__(256) void k_copy_multi(const CopyJobs J) {
     }
 }
 
+// dst[j][i] += src[j][i] for up to 64 float tensors in one launch: the hand-off of one backward pass's parameter
+// gradients to the flat gradient bucket (autograd's own accumulation is one elementwise launch per parameter: 54 per
+// MapCMA update, profiles/r02_update_T64N8_kernel_stats.csv).
+struct AddJobs {
+    const float* src[64];
+    float* dst[64];
+    int64_t n[64];
+    int first_block[65];
+    int count;
+};
+constexpr int ADD_CHUNK = 256 * 4 * 4;  // floats per block: 4 x float4 per thread
+
+__global__ __launch_bounds__(256) void k_add_multi(const AddJobs J) {
+    int j = 0;
+    while (j + 1 < J.count && (int)blockIdx.x >= J.first_block[j + 1]) ++j;
+    const int64_t off = (int64_t)((int)blockIdx.x - J.first_block[j]) * ADD_CHUNK;
+    const int64_t end = min(J.n[j], off + ADD_CHUNK);
+    const float* s = J.src[j];
+    float* d = J.dst[j];
+    if ((((uintptr_t)s | (uintptr_t)d) & 15) == 0) {
+        const int64_t vend = off + ((end - off) & ~(int64_t)3);
+        for (int64_t i = off + (int64_t)threadIdx.x * 4; i < vend; i += 256 * 4) {
+            const float4 a = *reinterpret_cast<const float4*>(s + i);
+            float4 b = *reinterpret_cast<float4*>(d + i);
+            b.x += a.x, b.y += a.y, b.z += a.z, b.w += a.w;
+            *reinterpret_cast<float4*>(d + i) = b;
+        }
+        for (int64_t i = vend + threadIdx.x; i < end; i += 256) d[i] += s[i];
+    } else {
+        for (int64_t i = off + threadIdx.x; i < end; i += 256) d[i] += s[i];
+    }
+}
+
 }  // namespace
 
 #define LAUNCH_OK() (hipGetLastError() == hipSuccess ? IVLN_OK : IVLN_E_HIP)
@@ -1636,6 +1669,27 @@ int ivln_copy_multi(const void* const* srcs, void* const* dsts, const int64_t* b
     J.first_block[m] = blocks;
     J.n = m;
     hipLaunchKernelGGL(k_copy_multi, dim3(blocks), dim3(256), 0, (hipStream_t)stream, J);
+    return LAUNCH_OK();
+}
+
+int ivln_add_multi_f32(const float* const* srcs, float* const* dsts, const int64_t* counts, int n, void* stream) {
+    if (n < 0 || n > 64) return IVLN_E_INVALID;
+    AddJobs J;
+    int blocks = 0, m = 0;
+    for (int j = 0; j < n; ++j) {
+        if (counts[j] <= 0) continue;
+        if (!srcs[j] || !dsts[j]) return IVLN_E_INVALID;
+        J.src[m] = srcs[j];
+        J.dst[m] = dsts[j];
+        J.n[m] = counts[j];
+        J.first_block[m] = blocks;
+        blocks += (int)((counts[j] + ADD_CHUNK - 1) / ADD_CHUNK);
+        ++m;
+    }
+    if (m == 0) return IVLN_OK;
+    J.first_block[m] = blocks;
+    J.count = m;
+    hipLaunchKernelGGL(k_add_multi, dim3(blocks), dim3(256), 0, (hipStream_t)stream, J);
     return LAUNCH_OK();
 }
 

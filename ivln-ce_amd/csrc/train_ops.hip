@@ -702,13 +702,91 @@ __global__ __launch_bounds__(256) void k_pm_loss_fwd(const float* __restrict__ p
     float d = h - p[j];
     Lm[idx] = d * d;
 }
+// dpre[i] = (1 - hat_i^2) * sum_j dL[j][i] * 2 (hat_i - p_j).  A block owns 16 columns; its 16 row slices walk j = s,
+// s + 16, ... and are summed in slice order through LDS (deterministic).  (One thread per column looping over all n
+// rows left the (512, 512) case on two workgroups: 118 us of serial load latency per update.)
 __global__ __launch_bounds__(256) void k_pm_loss_bwd(const float* __restrict__ dL, const float* __restrict__ hat,
                                                      const float* __restrict__ p, int n, float* __restrict__ dpre) {
-    int i = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float part[16][17];
+    const int c = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + c;
+    float s = 0.f;
+    if (i < n) {
+        const float h = hat[i];
+        for (int j = sl; j < n; j += 16) s += dL[(int64_t)j * n + i] * 2.f * (h - p[j]);
+    }
+    part[sl][c] = s;
+    __syncthreads();
+    if (sl == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += part[k][c];
+        const float h = hat[i];
+        dpre[i] = t * (1.f - h * h);
+    }
+}
+
+// The progress monitor's aux loss as the update step consumes it (quirk Q7 + AuxLosses.reduce; map_cma_policy.py:355-366,
+// aux_losses.py:22-29): mean over the SELECTED entries of L[j][i] = (tanh(pre_i) - p_j)^2, where the (n,) mask selects
+// whole columns i.  One workgroup; the (n, n) matrix is never written: thread i walks the p_j (LDS) for its columns,
+// keeping sum_j (h_i - p_j)^2 for the loss and sum_j (h_i - p_j) for the gradient, then a fixed-order block sum.
+//   out2[0] = mean, out2[1] = number of selected entries (n * #masked).  An empty selection gives 0 / 0 = NaN, like
+//   torch's mean of an empty tensor.
+__global__ __launch_bounds__(1024) void k_pm_masked_mean_fwd(const float* __restrict__ pre, const float* __restrict__ p,
+                                                             const uint8_t* __restrict__ mask, int n,
+                                                             float* __restrict__ hat, float* __restrict__ dsum,
+                                                             float* __restrict__ out2) {
+    extern __shared__ float s_p[];   // n progress values, then 32 reduction slots
+    float* red = s_p + n;
+    for (int j = threadIdx.x; j < n; j += 1024) s_p[j] = p[j];
+    __syncthreads();
+    float tot = 0.f, cnt = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const float h = tanhf(pre[i]);
+        float sq = 0.f, d1 = 0.f;
+        for (int j = 0; j < n; ++j) {
+            const float d = h - s_p[j];
+            sq = fmaf(d, d, sq);
+            d1 += d;
+        }
+        hat[i] = h;
+        dsum[i] = d1;
+        if (mask[i]) {
+            tot += sq;
+            cnt += (float)n;
+        }
+    }
+    // block sums in a fixed order: wave shuffles, then the 16 wave totals by thread 0
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        tot += __shfl_xor(tot, o, 64);
+        cnt += __shfl_xor(cnt, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6] = tot;
+        red[16 + (threadIdx.x >> 6)] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f, c = 0.f;
+        for (int w = 0; w < 16; ++w) {
+            t += red[w];
+            c += red[16 + w];
+        }
+        out2[0] = t / c;
+        out2[1] = c;
+    }
+}
+// d(mean)/d(pre_i) = mask_i * 2 * sum_j (h_i - p_j) * (1 - h_i^2) / count, times the upstream gradient (a device scalar)
+__global__ __launch_bounds__(256) void k_pm_masked_mean_bwd(const float* __restrict__ gout, const float* __restrict__ hat,
+                                                            const float* __restrict__ dsum,
+                                                            const uint8_t* __restrict__ mask,
+                                                            const float* __restrict__ out2, int n, float alpha,
+                                                            float* __restrict__ dpre) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    float h = hat[i], s = 0.f;
-    for (int j = 0; j < n; ++j) s += dL[(int64_t)j * n + i] * 2.f * (h - p[j]);
-    dpre[i] = s * (1.f - h * h);
+    const float h = hat[i];
+    dpre[i] = mask[i] ? gout[0] * alpha * 2.f * dsum[i] * (1.f - h * h) / out2[1] : 0.f;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -802,6 +880,20 @@ static int chan_splits(int N, int HW, int C, int K, int64_t ws_floats) {
 int ivln_nchw_chansum_f32(const float* x, int N, int C, int HW, float* out, float* ws, int64_t ws_floats,
                           void* stream) {
     if (!ws || ws_floats < C) return IVLN_E_INVALID;
+    // Short rows (the Conv1d(k=1) bias gradients of the update: HW = 16 positions or an 80-token axis): a block per
+    // channel would walk N images with HW/4 lanes busy (99 us for 12 MB at T*N = 512 rows).  The tensor is an
+    // (N, C*HW) row-major matrix: column sums by the two-stage colsum kernels into the workspace tail, then each
+    // channel adds its HW columns (fixed order throughout).
+    const int64_t cols = (int64_t)C * HW;
+    const int64_t splits_max = (N + 255) / 256 < 128 ? (N + 255) / 256 : 128;   // what ivln_colsum_f32 will use
+    if (HW <= 128 && cols <= 1 << 20 && ws_floats >= (splits_max + 1) * cols) {
+        float* col = ws + splits_max * cols;   // colsum's partials live in ws[0, splits * cols)
+        const int rc = ivln_colsum_f32(x, cols, N, (int)cols, col, 0, ws, splits_max * cols, stream);
+        if (rc != IVLN_OK) return rc;
+        hipLaunchKernelGGL(k_chan_final, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, col, HW, C, 1, out,
+                           (float*)nullptr);
+        return LAUNCH_OK();
+    }
     int S = chan_splits(N, HW, C, 1, ws_floats);
     const int ips = (N + S - 1) / S;
     S = (N + ips - 1) / ips;
@@ -967,8 +1059,24 @@ int ivln_pm_loss_fwd_f32(const float* pre, const float* progress, int n, float* 
 
 int ivln_pm_loss_bwd_f32(const float* dL, const float* hat, const float* progress, int n, float* dpre,
                          void* stream) {
-    hipLaunchKernelGGL(k_pm_loss_bwd, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, dL, hat, progress, n,
+    hipLaunchKernelGGL(k_pm_loss_bwd, dim3((n + 15) / 16), dim3(256), 0, (hipStream_t)stream, dL, hat, progress, n,
                        dpre);
+    return LAUNCH_OK();
+}
+
+int ivln_pm_masked_mean_fwd_f32(const float* pre, const float* progress, const uint8_t* mask, int n, float* hat,
+                                float* dsum, float* out2, void* stream) {
+    if (!pre || !progress || !mask || !hat || !dsum || !out2 || n <= 0 || n > 15000) return IVLN_E_INVALID;
+    hipLaunchKernelGGL(k_pm_masked_mean_fwd, dim3(1), dim3(1024), (size_t)(n + 32) * sizeof(float), (hipStream_t)stream,
+                       pre, progress, mask, n, hat, dsum, out2);
+    return LAUNCH_OK();
+}
+
+int ivln_pm_masked_mean_bwd_f32(const float* gout, const float* hat, const float* dsum, const uint8_t* mask,
+                                const float* out2, int n, float alpha, float* dpre, void* stream) {
+    if (!gout || !hat || !dsum || !mask || !out2 || !dpre || n <= 0) return IVLN_E_INVALID;
+    hipLaunchKernelGGL(k_pm_masked_mean_bwd, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, gout, hat, dsum,
+                       mask, out2, n, alpha, dpre);
     return LAUNCH_OK();
 }
 

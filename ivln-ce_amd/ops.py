@@ -1088,6 +1088,23 @@ def copy_multi(pairs):
         check(L.ivln_copy_multi(srcs, dsts, nb, n, stream_ptr()), "ivln_copy_multi")
 
 
+def add_multi(pairs):
+    """[(src, dst)]: dst += src for contiguous float32 device tensors of equal size, 64 per launch."""
+    L = _L()
+    L.ivln_add_multi_f32.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int,
+                                     C.c_void_p]
+    for k in range(0, len(pairs), 64):
+        chunk = pairs[k:k + 64]
+        n = len(chunk)
+        srcs, dsts, cnt = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_int64 * n)()
+        for i, (s, d) in enumerate(chunk):
+            if (s.numel() != d.numel() or s.dtype != torch.float32 or d.dtype != torch.float32
+                    or not s.is_contiguous() or not d.is_contiguous()):
+                raise _lib.IvlnError("add_multi needs contiguous float32 tensors of identical size")
+            srcs[i], dsts[i], cnt[i] = _p(s), _p(d), s.numel()
+        check(L.ivln_add_multi_f32(srcs, dsts, cnt, n, stream_ptr()), "ivln_add_multi_f32")
+
+
 def tour_memory(mem, h, mask_u8, out1, out2=None):
     """out = mask * max(mem, h) (h optional), row-strided (N,H) views; see ivln_tour_memory_f32."""
     N, H = mem.shape
@@ -1327,6 +1344,30 @@ def pm_loss_fwd(pre, progress):
     check(_T().ivln_pm_loss_fwd_f32(dptr(pre), dptr(progress), n, dptr(hat), dptr(Lm), stream_ptr()),
           "ivln_pm_loss_fwd_f32")
     return hat, Lm
+
+
+def pm_masked_mean_fwd(pre, progress, mask):
+    """mean over the mask-selected columns of the (n, n) progress-monitor matrix, never materialised; returns
+    (out2 = [mean, count] device tensor, hat, dsum)."""
+    n = pre.numel()
+    hat = torch.empty((n,), dtype=torch.float32, device=pre.device)
+    dsum = torch.empty((n,), dtype=torch.float32, device=pre.device)
+    out2 = torch.empty((2,), dtype=torch.float32, device=pre.device)
+    L = _T()
+    L.ivln_pm_masked_mean_fwd_f32.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp]
+    check(L.ivln_pm_masked_mean_fwd_f32(dptr(pre), dptr(progress), dptr(mask), n, dptr(hat), dptr(dsum), dptr(out2),
+                                        stream_ptr()), "ivln_pm_masked_mean_fwd_f32")
+    return out2, hat, dsum
+
+
+def pm_masked_mean_bwd(gout, hat, dsum, mask, out2, alpha):
+    n = hat.numel()
+    dpre = torch.empty((n,), dtype=torch.float32, device=hat.device)
+    L = _T()
+    L.ivln_pm_masked_mean_bwd_f32.argtypes = [vp, vp, vp, vp, vp, i32, f32, vp, vp]
+    check(L.ivln_pm_masked_mean_bwd_f32(dptr(gout), dptr(hat), dptr(dsum), dptr(mask), dptr(out2), n, float(alpha),
+                                        dptr(dpre), stream_ptr()), "ivln_pm_masked_mean_bwd_f32")
+    return dpre
 
 
 def pm_loss_bwd(dL, hat, progress):

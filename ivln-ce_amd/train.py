@@ -82,10 +82,48 @@ class _PMLossFn(torch.autograd.Function):
         return ops.pm_loss_bwd(dL.contiguous(), hat, progress), None
 
 
+class _PMMaskedMeanFn(torch.autograd.Function):
+    """alpha * mean(L[:, mask]) of the same matrix in one workgroup, without writing the matrix (what
+    AuxLosses.reduce makes of the term: aux_losses.py:22-29).  The upstream gradient stays a device scalar."""
+
+    @staticmethod
+    def forward(ctx, pre, progress, mask, alpha):
+        out2, hat, dsum = ops.pm_masked_mean_fwd(pre.contiguous(), progress, mask)
+        ctx.save_for_backward(hat, dsum, mask, out2)
+        ctx.alpha = float(alpha)
+        return out2[0] * ctx.alpha if ctx.alpha != 1.0 else out2[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        hat, dsum, mask, out2 = ctx.saved_tensors
+        g = g.to(torch.float32).reshape(1).contiguous()
+        return ops.pm_masked_mean_bwd(g, hat, dsum, mask, out2, ctx.alpha), None, None, None
+
+
+class PMLossTerm:
+    """The progress monitor's loss term as the registry holds it: lazily the reference's (TN, TN) matrix
+    (`values`, for `AuxLosses.get_loss`), and - what the update actually asks for - its masked mean computed
+    directly (`masked_mean`), with no matrix, no masked_select and no host synchronisation."""
+
+    def __init__(self, pre, progress):
+        self.pre = pre
+        self.progress = progress.to(torch.float32).reshape(-1).contiguous()
+
+    @property
+    def values(self):
+        return _PMLossFn.apply(self.pre, self.progress)
+
+    def masked_mean(self, mask, alpha):
+        mask = mask.reshape(-1)
+        if mask.numel() != self.pre.numel() or not self.pre.is_cuda:
+            return alpha * torch.masked_select(self.values, mask).mean()
+        return _PMMaskedMeanFn.apply(self.pre, self.progress, mask.to(torch.uint8).contiguous(), alpha)
+
+
 def progress_monitor_loss(net, feats, progress):
     pm = net.progress_monitor
     pre = LinearFn.apply(feats, pm.weight, pm.bias)  # (rows, 1)
-    return _PMLossFn.apply(pre.reshape(-1), progress)
+    return PMLossTerm(pre.reshape(-1), progress)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -286,10 +324,22 @@ class MapCMAForwardFn(torch.autograd.Function):
         with torch.no_grad():
             G = getattr(ctx.net, "backward_hip", None)
             G = (G or (lambda S, d: net_backward(ctx.net, S, d)))(ctx.saves, d_feats)
+        # Parameters whose .grad already exists as a contiguous device tensor (FlatAdam: views of the flat bucket) get
+        # their gradient ADDED there by one multi-tensor launch and report None to autograd (a None gradient leaves
+        # .grad alone); autograd's own accumulation is one elementwise launch per parameter.  Anything else - no
+        # .grad yet, a foreign layout - goes back through autograd as before.
         grads: List = []
+        direct = []
         for p, need in zip(ctx.params, ctx.needs_input_grad[1:]):
             g = G.get(p) if need else None
-            grads.append(g.view_as(p) if g is not None else None)
+            if (g is not None and p.grad is not None and p.grad.is_cuda and p.grad.is_contiguous()
+                    and g.is_contiguous() and g.dtype == torch.float32 and p.grad.dtype == torch.float32):
+                direct.append((g, p.grad))
+                grads.append(None)
+            else:
+                grads.append(g.view_as(p) if g is not None else None)
+        if direct:
+            ops.add_multi(direct)
         ctx.saves = None
         return (None, *grads)
 

@@ -98,6 +98,18 @@ class FlatAdam:
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
 
 
+_scalars = {}
+
+
+def _scalar(value, device):
+    """Cached 0-d device tensor (the loss scale handed to autograd.backward: no H2D copy per update)."""
+    key = (float(value), str(device))
+    t = _scalars.get(key)
+    if t is None:
+        t = _scalars[key] = torch.tensor(float(value), device=device)
+    return t
+
+
 def update_agent(policy, optimizer: FlatAdam, observations, prev_actions, not_done_masks, corrected_actions, weights,
                  hidden_size=512, step_grad=True, loss_accumulation_scalar=1, world=1, tour_not_done_masks=None,
                  rnn_states=None):
@@ -124,7 +136,7 @@ def update_agent(policy, optimizer: FlatAdam, observations, prev_actions, not_do
         with torch.enable_grad():
             aux_loss = AuxLosses.reduce((weights > 0).view(-1))  # the reference's own reduction
         roots.append(aux_loss)
-        grads.append(torch.tensor(scale, device=dev))
+        grads.append(_scalar(scale, dev))
     torch.autograd.backward(roots, grads)
     if step_grad:
         optimizer.step(world)
