@@ -38,7 +38,7 @@ class Config(dict):
             raise AttributeError(name)
 
     def __setattr__(self, name, value):
-        if object.__getattribute__(self, Config._FROZEN):
+        if self.is_frozen():
             raise AttributeError(
                 f"Attempted to set {name} to {value}, but Config is immutable"
             )
@@ -49,10 +49,13 @@ class Config(dict):
 
     # yacs API ----------------------------------------------------------
     def is_frozen(self):
-        return object.__getattribute__(self, Config._FROZEN)
+        d = object.__getattribute__(self, "__dict__")
+        # (an instance unpickled from a yacs CfgNode carries `__immutable__` instead of this class's flag)
+        return bool(d.get(Config._FROZEN, d.get("__immutable__", False)))
 
     def _set_frozen(self, flag):
         object.__setattr__(self, Config._FROZEN, flag)
+        object.__getattribute__(self, "__dict__").pop("__immutable__", None)
         for v in self.values():
             if isinstance(v, Config):
                 v._set_frozen(flag)
@@ -118,6 +121,44 @@ class Config(dict):
 
 
 CN = Config
+
+
+class habitat_config_unpickle_shim:
+    """Context manager: while active, `habitat.config.default.Config` and `yacs.config.CfgNode` - the classes a
+    reference checkpoint's "config" entry pickles as (base_il_trainer.py:158-168) - resolve to this package's
+    `Config` if the real modules are not importable.  Unpickling a CfgNode sets its instance __dict__
+    (`__immutable__` & co.) and its items directly, which a `Config` holds just as well."""
+
+    NAMES = {"habitat": None, "habitat.config": None, "habitat.config.default": "Config", "yacs": None,
+             "yacs.config": "CfgNode"}
+
+    def __enter__(self):
+        import importlib
+        import sys
+        import types
+
+        self._made = []
+        for name, cls in self.NAMES.items():
+            if name in sys.modules:
+                continue
+            try:
+                importlib.import_module(name)
+                continue
+            except Exception:  # noqa: BLE001 - absent (or broken) package: stand in for it
+                pass
+            mod = types.ModuleType(name)
+            if cls:
+                setattr(mod, cls, Config)
+            sys.modules[name] = mod
+            self._made.append(name)
+        return self
+
+    def __exit__(self, *exc):
+        import sys
+
+        for name in self._made:
+            sys.modules.pop(name, None)
+        return False
 
 
 def _experiment_defaults() -> Config:

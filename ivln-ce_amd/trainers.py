@@ -45,6 +45,7 @@ class FlatAdam:
     (MODEL.SEMANTIC_MAP_ENCODER.custom_lr)."""
 
     def __init__(self, policy, lr=2.5e-4, betas=(0.9, 0.999), eps=1e-8, sem_lr: Optional[float] = None):
+        self.all_names = [k for k, _ in policy.named_parameters()]
         named = [(k, p) for k, p in policy.named_parameters() if p.requires_grad]
         self.names = [k for k, _ in named]
         self.params = [p for _, p in named]
@@ -64,6 +65,7 @@ class FlatAdam:
             p.grad = self.grad[o:o + p.numel()].view_as(p)
         self.lr, self.betas, self.eps, self.step_count = lr, betas, eps, 0
         self.seg_of = self.seg_lr = None
+        self.sem_lr = sem_lr
         if sem_lr is not None:
             seg = torch.zeros(n, dtype=torch.int32)
             for k, p, o in zip(self.names, self.params, self.offsets):
@@ -88,14 +90,61 @@ class FlatAdam:
     def zero_grad(self):
         self.grad.zero_()
 
+    # -- checkpoint format: torch.optim.Adam's own -----------------------------------------------------------------
+    def _torch_order(self):
+        """Parameter names in the index order of the reference's optimizer (base_il_trainer.py:78-94):
+        `Adam(policy.parameters())` numbers EVERY parameter, frozen ones included (they just never get state); with
+        SEMANTIC_MAP_ENCODER.custom_lr the map encoder's parameters form group 0 and come first."""
+        if self.seg_of is None:
+            return [self.all_names], self.all_names
+        sem = [k for k in self.all_names if k.startswith("net.map_encoder")]
+        reg = [k for k in self.all_names if not k.startswith("net.map_encoder")]
+        return [sem, reg], sem + reg
+
     def state_dict(self):
-        return {"step": self.step_count, "exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu(),
-                "names": self.names, "offsets": self.offsets, "lr": self.lr}
+        """`torch.optim.Adam.state_dict()` of the reference's optimizer over the same policy - the "optim_state" of a
+        checkpoint either implementation can resume from (base_il_trainer.py:98-106, 158-168)."""
+        groups, order = self._torch_order()
+        index = {k: i for i, k in enumerate(order)}
+        state = {}
+        for k, p, o in zip(self.names, self.params, self.offsets):
+            n = p.numel()
+            state[index[k]] = {"step": torch.tensor(float(self.step_count)),
+                               "exp_avg": self.exp_avg[o:o + n].view_as(p).cpu().clone(),
+                               "exp_avg_sq": self.exp_avg_sq[o:o + n].view_as(p).cpu().clone()}
+        lrs = [self.lr] if self.seg_of is None else [float(self.sem_lr), self.lr]
+        pg = [{"lr": lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0, "amsgrad": False,
+               "params": [index[k] for k in names]} for lr, names in zip(lrs, groups)]
+        return {"state": state, "param_groups": pg}
 
     def load_state_dict(self, sd):
-        self.step_count = sd["step"]
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        """Accepts torch.optim.Adam's format (a reference checkpoint, or one of ours) and the flat format this class
+        wrote in earlier rounds.  Moments land in the flat buckets by parameter NAME through the reference's index
+        order; one shared step count (the reference steps every parameter together)."""
+        if "param_groups" not in sd:  # rounds 1-2: {"step", "exp_avg", "exp_avg_sq", "names", "offsets", "lr"}
+            self.step_count = sd["step"]
+            self.exp_avg.copy_(sd["exp_avg"])
+            self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+            return
+        _, order = self._torch_order()
+        if sum(len(g["params"]) for g in sd["param_groups"]) != len(order):
+            raise ValueError(f"optimizer state numbers {sum(len(g['params']) for g in sd['param_groups'])} parameters, "
+                             f"the policy has {len(order)}")
+        where = {k: (p, o) for k, p, o in zip(self.names, self.params, self.offsets)}
+        steps = set()
+        for i, st in sd["state"].items():
+            k = order[int(i)]
+            if k not in where:
+                raise ValueError(f"optimizer state for `{k}`, which does not train here")
+            p, o = where[k]
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError(f"optimizer state of `{k}` has shape {tuple(st['exp_avg'].shape)}, expected {tuple(p.shape)}")
+            self.exp_avg[o:o + p.numel()].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[o:o + p.numel()].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(int(st["step"]))
+        if len(steps) > 1:
+            raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): not a state of one Adam over the policy")
+        self.step_count = steps.pop() if steps else 0
 
 
 _scalars = {}
@@ -358,8 +407,14 @@ class BaseVLNCETrainer:
         )
 
     def load_checkpoint(self, checkpoint_path, *args, **kwargs):
+        """`torch.load` of a trainer checkpoint (base_il_trainer.py:170-171).  A checkpoint written by the reference
+        pickles its "config" entry as `habitat.config.default.Config` (a yacs CfgNode); where habitat is not installed
+        that name resolves to this package's `Config` for the duration of the load, so `pred_it.pth` & co. open."""
+        from .config import habitat_config_unpickle_shim
+
         kwargs.setdefault("weights_only", False)
-        return torch.load(checkpoint_path, *args, **kwargs)
+        with habitat_config_unpickle_shim():
+            return torch.load(checkpoint_path, *args, **kwargs)
 
     def _update_agent(self, observations, prev_actions, not_done_masks, corrected_actions, weights, step_grad=True,
                       loss_accumulation_scalar=1):
