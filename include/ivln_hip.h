@@ -452,6 +452,33 @@ int ivln_add_multi_f32(const float* const* srcs, float* const* dsts, const int64
 int ivln_copy2d_f32(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int rows, int cols,
                     int broadcast_rows, void* stream);
 
+/* RedNet forward as ONE C call (PredictSemantics.forward, mapper.py:781-800, over
+ * RedNet.forward, mapping_module/rednet.py:190-263): the caller hands a packed table of the launches one forward is
+ * made of - built once per (weights, batch shape) with every weight, BN fold, activation buffer and split-K workspace
+ * pointer resolved - and the library walks it: no host code between the ~170 launches.  Table entries:
+ *   IVLN_OP_GEMM       `gemm` as ivln_gemm_f32 takes it (every conv / transposed-conv class, fused BN + ReLU +
+ *                      residual epilogues)
+ *   IVLN_OP_ADD        dst = src0 + src1 (n floats, relu = i[0])               the encoder fusion / decoder skip adds
+ *   IVLN_OP_POOL       ivln_pool2d_f32(src0, dst, NC = i[0], H, W, k, s, p, mode = i[6])
+ *   IVLN_OP_RGB_NORM   ivln_rgb_resize_normalize_f32(src0 | the call's `rgb`, B = i[0], Hi, Wi, Ho, Wo, dst)
+ *   IVLN_OP_AFFINE     dst = (src0 | the call's `depth` - f[0]) / f[1]   (n floats)
+ *   IVLN_OP_ARGMAX_U8  ivln_argmax_channels_u8(src0, N = i[0], C, HW, dst | the call's `labels_out`)
+ * A NULL src0 of RGB_NORM / AFFINE and a NULL dst of ARGMAX_U8 stand for the per-call arguments, so one table serves
+ * every step.  Returns the first failing launch's status. */
+enum { IVLN_OP_GEMM = 0, IVLN_OP_ADD = 1, IVLN_OP_POOL = 2, IVLN_OP_RGB_NORM = 3, IVLN_OP_AFFINE = 4, IVLN_OP_ARGMAX_U8 = 5 };
+typedef struct ivln_rednet_op {
+    int32_t kind;
+    int32_t i[7];
+    float f[2];
+    int64_t n;
+    const void* src0;
+    const void* src1;
+    void* dst;
+    ivln_gemm_desc gemm;
+} ivln_rednet_op;
+int ivln_rednet_fwd(const ivln_rednet_op* table, int n_ops, const uint8_t* rgb, const float* depth, uint8_t* labels_out,
+                    void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Fused recurrent / attention head of one rollout step (csrc/cma_step.hip): everything MapCMANet.forward does
  * after its encoders (ivlnce_baselines/models/map_cma_policy.py:305-353, `_attn` :266-274; two single-step

@@ -1672,6 +1672,48 @@ int ivln_copy_multi(const void* const* srcs, void* const* dsts, const int64_t* b
     return LAUNCH_OK();
 }
 
+int ivln_rednet_fwd(const ivln_rednet_op* table, int n_ops, const uint8_t* rgb, const float* depth, uint8_t* labels_out,
+                    void* stream) {
+    if (!table || n_ops <= 0) return IVLN_E_INVALID;
+    for (int k = 0; k < n_ops; ++k) {
+        const ivln_rednet_op& op = table[k];
+        int rc = IVLN_E_INVALID;
+        switch (op.kind) {
+            case IVLN_OP_GEMM:
+                rc = ivln_gemm_f32(&op.gemm, stream);
+                break;
+            case IVLN_OP_ADD:
+                rc = ivln_add_f32((const float*)op.src0, (const float*)op.src1, (float*)op.dst, op.n, op.i[0], stream);
+                break;
+            case IVLN_OP_POOL:
+                rc = ivln_pool2d_f32((const float*)op.src0, (float*)op.dst, op.i[0], op.i[1], op.i[2], op.i[3], op.i[4],
+                                     op.i[5], op.i[6], stream);
+                break;
+            case IVLN_OP_RGB_NORM: {
+                const uint8_t* src = op.src0 ? (const uint8_t*)op.src0 : rgb;
+                if (src)
+                    rc = ivln_rgb_resize_normalize_f32(src, op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], (float*)op.dst,
+                                                       stream);
+                break;
+            }
+            case IVLN_OP_AFFINE: {
+                const float* src = op.src0 ? (const float*)op.src0 : depth;
+                if (src) rc = ivln_affine_f32(src, (float*)op.dst, op.n, op.f[0], op.f[1], stream);
+                break;
+            }
+            case IVLN_OP_ARGMAX_U8: {
+                uint8_t* dst = op.dst ? (uint8_t*)op.dst : labels_out;
+                if (dst) rc = ivln_argmax_channels_u8((const float*)op.src0, op.i[0], op.i[1], op.i[2], dst, stream);
+                break;
+            }
+            default:
+                break;
+        }
+        if (rc != IVLN_OK) return rc;
+    }
+    return IVLN_OK;
+}
+
 int ivln_add_multi_f32(const float* const* srcs, float* const* dsts, const int64_t* counts, int n, void* stream) {
     if (n < 0 || n > 64) return IVLN_E_INVALID;
     AddJobs J;

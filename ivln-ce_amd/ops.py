@@ -10,7 +10,8 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import check, dptr, f32, i32, i64, lib, stream_ptr, vp
+from ._lib import check, f32, i32, i64, lib, stream_ptr, vp
+from ._lib import dptr as _dptr
 
 
 class GemmDesc(C.Structure):
@@ -37,6 +38,61 @@ class GemmDesc(C.Structure):
         ("no_xcd_remap", i32),
         ("grp_imgs", i32), ("a_grp_stride", i64), ("a_packed_grp_stride", i64),
     ]
+
+
+class RednetOp(C.Structure):
+    """include/ivln_hip.h: ivln_rednet_op."""
+    _fields_ = [("kind", i32), ("i", i32 * 7), ("f", f32 * 2), ("n", i64), ("src0", vp), ("src1", vp), ("dst", vp),
+                ("gemm", GemmDesc)]
+
+
+OP_GEMM, OP_ADD, OP_POOL, OP_RGB_NORM, OP_AFFINE, OP_ARGMAX_U8 = range(6)
+
+
+class OpRecorder:
+    """While active (`with ops.recording() as rec:`) every launch of the kinds ivln_rednet_fwd knows is ALSO appended
+    to `rec.ops` with its pointers resolved, and every tensor whose pointer was handed to the library is kept alive in
+    `rec.keep` - so the recorded table stays valid and one C call can repeat the whole sequence (rednet.RedNetPlan)."""
+
+    def __init__(self):
+        self.ops, self.keep, self.unsupported = [], [], []
+
+    def table(self):
+        arr = (RednetOp * len(self.ops))()
+        for k, op in enumerate(self.ops):
+            C.memmove(C.byref(arr, k * C.sizeof(RednetOp)), C.byref(op), C.sizeof(RednetOp))
+        return arr
+
+
+_REC = None
+
+
+class recording:
+    def __enter__(self):
+        global _REC
+        if _REC is not None:
+            raise _lib.IvlnError("ops.recording() does not nest")
+        _REC = OpRecorder()
+        return _REC
+
+    def __exit__(self, *exc):
+        global _REC
+        _REC = None
+        return False
+
+
+def _rec(kind, ints=(), floats=(), n=0, src0=None, src1=None, dst=None, gemm=None):
+    op = RednetOp()
+    op.kind = kind
+    for k, v in enumerate(ints):
+        op.i[k] = int(v)
+    for k, v in enumerate(floats):
+        op.f[k] = float(v)
+    op.n, op.src0, op.src1, op.dst = int(n), src0, src1, dst
+    if gemm is not None:
+        C.memmove(C.byref(op, RednetOp.gemm.offset), C.byref(gemm), C.sizeof(GemmDesc))
+        op.gemm.splits_used = None  # an output of the direct call only
+    _REC.ops.append(op)
 
 
 A_MK, A_KM, A_NCHW_P = 0, 1, 2
@@ -76,12 +132,21 @@ def _L():
     return L
 
 
+def dptr(t: torch.Tensor) -> int:
+    """Device pointer of a contiguous GPU tensor (kept alive by an active OpRecorder)."""
+    if _REC is not None:
+        _REC.keep.append(t)
+    return _dptr(t)
+
+
 def _p(t: Optional[torch.Tensor]):
     """Device pointer; unlike dptr() allows strided views (caller passes the strides)."""
     if t is None:
         return None
     if not t.is_cuda:
         raise _lib.IvlnError("HIP hot path needs GPU tensors (no CPU fallback); got " + str(t.device))
+    if _REC is not None:
+        _REC.keep.append(t)
     return t.data_ptr()
 
 
@@ -131,6 +196,8 @@ def gemm(desc: GemmDesc):
     if NO_XCD_REMAP:
         desc.no_xcd_remap = 1
     check(_L().ivln_gemm_f32(C.byref(desc), stream_ptr()), "ivln_gemm_f32")
+    if _REC is not None:
+        _rec(OP_GEMM, gemm=desc)
 
 
 def _epilogue(d: GemmDesc, scale, shift, residual, relu, accumulate=False):
@@ -830,6 +897,8 @@ def pool2d(x, k, s, p, mode, out=None):
         out = torch.empty((N, Cc, Ho, Wo), dtype=torch.float32, device=x.device)
     check(_L().ivln_pool2d_f32(dptr(x), dptr(out), N * Cc, H, W, k, s, p, 0 if mode == "max" else 1, stream_ptr()),
           "ivln_pool2d_f32")
+    if _REC is not None:
+        _rec(OP_POOL, (N * Cc, H, W, k, s, p, 0 if mode == "max" else 1), src0=x.data_ptr(), dst=out.data_ptr())
     return out
 
 
@@ -1016,6 +1085,14 @@ def linear_sample(x, w, bias, u_sample, u_beta=None, beta=0.0, expert=None, out=
     return out
 
 
+def rednet_fwd(table, n_ops, rgb_u8, depth, labels_out):
+    """One C call walks a recorded op table (ivln_rednet_fwd): RedNet's whole forward for this step's frames."""
+    L = _L()
+    L.ivln_rednet_fwd.argtypes = [vp, i32, vp, vp, vp, vp]
+    check(L.ivln_rednet_fwd(C.addressof(table), n_ops, _dptr(rgb_u8), _dptr(depth), _dptr(labels_out), stream_ptr()),
+          "ivln_rednet_fwd")
+
+
 def argmax_rows(x, out=None):
     rows, Cc = x.shape
     if out is None:
@@ -1028,6 +1105,8 @@ def argmax_channels_u8(x):
     N, Cc, H, W = x.shape
     out = torch.empty((N, 1, H, W), dtype=torch.uint8, device=x.device)
     check(_L().ivln_argmax_channels_u8(dptr(x), N, Cc, H * W, dptr(out), stream_ptr()), "ivln_argmax_channels_u8")
+    if _REC is not None:  # dst NULL: the labels go where the replaying call says
+        _rec(OP_ARGMAX_U8, (N, Cc, H * W), src0=x.data_ptr(), dst=None)
     return out
 
 
@@ -1036,6 +1115,8 @@ def rgb_resize_normalize(rgb_u8_nhwc, Ho, Wo):
     out = torch.empty((B, 3, Ho, Wo), dtype=torch.float32, device=rgb_u8_nhwc.device)
     check(_L().ivln_rgb_resize_normalize_f32(dptr(rgb_u8_nhwc), B, Hi, Wi, Ho, Wo, dptr(out), stream_ptr()),
           "ivln_rgb_resize_normalize_f32")
+    if _REC is not None:  # src NULL: this step's frames come with the replaying call
+        _rec(OP_RGB_NORM, (B, Hi, Wi, Ho, Wo), src0=None, dst=out.data_ptr())
     return out
 
 
@@ -1062,6 +1143,8 @@ def adaptive_avgpool2d(x, OH, OW, out=None, out_ctot=0):
 def affine(x, sub, div):
     out = torch.empty_like(x)
     check(_L().ivln_affine_f32(dptr(x), dptr(out), x.numel(), sub, div, stream_ptr()), "ivln_affine_f32")
+    if _REC is not None:  # src NULL: this step's depth comes with the replaying call
+        _rec(OP_AFFINE, floats=(sub, div), n=x.numel(), src0=None, dst=out.data_ptr())
     return out
 
 
@@ -1069,6 +1152,8 @@ def add(a, b, relu=False, out=None):
     if out is None:
         out = torch.empty_like(a)
     check(_L().ivln_add_f32(dptr(a), dptr(b), dptr(out), a.numel(), int(bool(relu)), stream_ptr()), "ivln_add_f32")
+    if _REC is not None:
+        _rec(OP_ADD, (int(bool(relu)),), n=a.numel(), src0=a.data_ptr(), src1=b.data_ptr(), dst=out.data_ptr())
     return out
 
 

@@ -68,3 +68,45 @@ def test_rednet_fullsize_matches_oracle_and_pred_mapper_is_exact():
                                 obs["world_robot_orientation"].numpy(), obs["not_done_masks"].numpy())
         assert np.array_equal(mem.occupancy.cpu().numpy(), occ_r)
         assert np.array_equal(mem.semantic.cpu().numpy(), sem_r)
+
+
+def test_rednet_forward_as_one_c_call_equals_the_layer_walk():
+    """ivln_rednet_fwd: the first step of a batch shape records the layer walk's launches into a packed table, later
+    steps replay it with ONE C call on new frames.  Labels must equal the layer walk's exactly (same kernels, same
+    buffers), for frames the table was not recorded on, and the table must refuse to outlive a weight change."""
+    import time
+
+    from ivln_ce_amd import ops
+    from ivln_ce_amd.synthetic import SyntheticRollout
+
+    ps = _net()
+    B = 2
+    roll = SyntheticRollout(B=B, seed=33, with_rgb=True)
+    steps = [{k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in roll.step().items()} for _ in range(4)]
+    ps.USE_PLAN = False
+    walk = [ps(o).clone() for o in steps]
+    ps.USE_PLAN = True
+    first = ps(steps[0]).clone()              # records
+    assert len(ps._plans) == 1
+    table, n_ops, _ = next(iter(ps._plans.values()))
+    assert n_ops > 100
+    replay = [ps(o).clone() for o in steps]   # replays (incl. step 0 again)
+    assert torch.equal(first, walk[0])
+    for a, b in zip(replay, walk):
+        assert torch.equal(a, b)
+    # host cost per forward: the point of the C entry (printed, not asserted: box-dependent)
+    torch.cuda.synchronize()
+    for use, name in ((False, "layer walk"), (True, "ivln_rednet_fwd")):
+        ps.USE_PLAN = use
+        t0 = time.perf_counter()
+        for _ in range(10):
+            ps(steps[1])
+        host = (time.perf_counter() - t0) / 10
+        torch.cuda.synchronize()
+        print(f"rednet host enqueue per forward, {name}: {1e3 * host:.2f} ms")
+    # new weights -> a new table (the old one points at stale BN folds)
+    ops.WEIGHT_EPOCH += 1
+    ps.model.invalidate_folded()
+    ps.USE_PLAN = True
+    again = ps(steps[2])
+    assert len(ps._plans) == 2 and torch.equal(again, walk[2])

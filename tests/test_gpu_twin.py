@@ -112,3 +112,109 @@ def test_ivln_mapper_entry_points_device_vs_twin(path):
         assert nt.value == ndv.value == int(g[f"world_n_{t}"])
     Lt.ivln_mapper_destroy(ht)
     Ld.ivln_mapper_destroy(hd)
+
+
+# ---- round-2 entry points: device library vs CPU twin on the same bytes -----------------------------------------------
+def _pair(c):
+    """device copies of a case's numpy operands"""
+    return {k: (_dev(v) if isinstance(v, np.ndarray) else v) for k, v in c.items()}
+
+
+def _ptr_dev(t):
+    return None if t is None else t.data_ptr()
+
+
+@pytest.mark.parametrize("N,Cc,H,W,second,residual,pool,ka,sa,Ca,Cb,sb", [
+    (4, 256, 16, 16, False, False, False, 3, 1, 64, 0, 1),     # layer-2 conv2 input: GN + 3x3
+    (4, 256, 16, 16, False, True, False, 1, 1, 64, 0, 1),      # block tail + identity -> next conv1
+    (4, 512, 8, 8, True, False, False, 1, 1, 128, 0, 1),       # tail with the downsample GroupNorm as second operand
+    (4, 512, 8, 8, False, True, False, 1, 1, 256, 1024, 2),    # layer change: conv1 (A) + strided downsample (B)
+    (2, 32, 64, 64, False, False, True, 1, 1, 32, 128, 1),     # stem: GN + ReLU + MaxPool -> layer-1 convs
+])
+def test_ivln_gn_conv_f32_device_vs_twin(N, Cc, H, W, second, residual, pool, ka, sa, Ca, Cb, sb):
+    from ivln_ce_amd._lib import lib, stream_ptr
+
+    G = 16
+    c = T.gn_conv_case(N + Cc + ka, N, Cc, H, W, G, 16 if not pool else 1, second, residual, pool, ka, sa, Ca, Cb, sb)
+    shp_act, shp_a = (N, Cc, c["Hp"], c["Wp"]), (G, Ca, N * c["Ho"] * c["Wo"])
+    shp_b = (G, max(Cb, 1), N * max(c["Hb"] * c["Wb"], 1))
+    act_h, ya_h, yb_h = np.zeros(shp_act, np.float32), np.zeros(shp_a, np.float32), np.zeros(shp_b, np.float32)
+    Lt = T._sigs2(T.twin())
+    T.check(Lt, Lt.ivln_gn_conv_f32(C.byref(T.gn_conv_desc(T.hp, c, act_h, ya_h, yb_h)), None), "twin")
+    cd = _pair(c)
+    act_d, ya_d, yb_d = torch.zeros(shp_act, device=DEV), torch.zeros(shp_a, device=DEV), torch.zeros(shp_b, device=DEV)
+    Ld = T._sigs2(T._sigs(lib()))
+    T.check(Ld, Ld.ivln_gn_conv_f32(C.byref(T.gn_conv_desc(_ptr_dev, cd, act_d, ya_d, yb_d)), stream_ptr()), "device")
+    assert float(np.abs(act_d.cpu().numpy() - act_h).max()) < 3e-5
+    assert float(np.abs(ya_d.cpu().numpy() - ya_h).max()) < 5e-5      # every partial slab, not just their sum
+    if Cb:
+        assert float(np.abs(yb_d.cpu().numpy() - yb_h).max()) < 5e-5
+
+
+@pytest.mark.parametrize("N,Cc,H,W,second,residual,ka,sa,Ca,ga,Cb,gb,sb,rows", [
+    (4, 32, 32, 32, False, False, 3, 1, 32, 16, 0, 16, 1, 2),       # layer-1 conv2
+    (4, 32, 32, 32, False, False, 1, 1, 128, 16, 0, 16, 1, 2),      # layer-1 conv3
+    (4, 128, 32, 32, True, False, 1, 1, 32, 16, 0, 16, 1, 2),       # first block's tail (+ downsample GN) -> conv1
+    (4, 128, 32, 32, False, True, 1, 1, 64, 16, 256, 16, 2, 2),     # layer-1 exit: conv1 of layer 2 + its downsample
+    (2, 64, 32, 32, False, False, 3, 2, 64, 16, 0, 16, 1, 2),       # the stride-2 3x3 of layer 2
+])
+def test_ivln_nconv_f32_device_vs_twin(N, Cc, H, W, second, residual, ka, sa, Ca, ga, Cb, gb, sb, rows):
+    from ivln_ce_amd._lib import lib, stream_ptr
+
+    c = T.nconv_case(N + Cc + ka + Ca, N, Cc, H, W, 16, second, residual, ka, sa, Ca, ga, Cb, gb, sb, rows)
+    sa_, sb_ = (Ca, N, c["Ho"], c["Wo"]), (max(Cb, 1), N, max(c["Hb"], 1), max(c["Wb"], 1))
+    act_h = np.zeros((N, Cc, H, W), np.float32) if sa == 1 else None
+    ya_h, yb_h = np.zeros(sa_, np.float32), np.zeros(sb_, np.float32)
+    sta_h, stb_h = np.zeros((c["strips"], N, ga, 3), np.float32), np.zeros((c["strips"], N, gb, 3), np.float32)
+    Lt = T._sigs2(T.twin())
+    T.check(Lt, Lt.ivln_nconv_f32(C.byref(T.nconv_desc(T.hp, c, act_h, ya_h, sta_h, yb_h, stb_h)), None), "twin")
+    cd = _pair(c)
+    act_d = torch.zeros((N, Cc, H, W), device=DEV) if sa == 1 else None
+    ya_d, yb_d = torch.zeros(sa_, device=DEV), torch.zeros(sb_, device=DEV)
+    sta_d, stb_d = torch.zeros((c["strips"], N, ga, 3), device=DEV), torch.zeros((c["strips"], N, gb, 3), device=DEV)
+    Ld = T._sigs2(T._sigs(lib()))
+    T.check(Ld, Ld.ivln_nconv_f32(C.byref(T.nconv_desc(_ptr_dev, cd, act_d, ya_d, sta_d, yb_d, stb_d)), stream_ptr()), "device")
+    if act_h is not None:
+        assert float(np.abs(act_d.cpu().numpy() - act_h).max()) < 5e-5
+    assert float(np.abs(ya_d.cpu().numpy() - ya_h).max()) < 1e-4
+    sd = sta_d.cpu().numpy()
+    assert np.array_equal(sd[..., 0], sta_h[..., 0])                               # counts
+    assert np.allclose(sd[..., 1], sta_h[..., 1], atol=2e-5)                       # per-strip means
+    assert np.allclose(sd[..., 2], sta_h[..., 2], rtol=2e-4, atol=1e-4)            # per-strip M2
+    if Cb:
+        assert float(np.abs(yb_d.cpu().numpy() - yb_h).max()) < 1e-4
+        assert np.allclose(stb_d.cpu().numpy(), stb_h, rtol=2e-4, atol=1e-4)
+
+
+def test_ivln_kv_linear_and_cma_step_device_vs_twin():
+    from ivln_ce_amd._lib import lib, stream_ptr
+
+    rs = np.random.RandomState(6)
+    rows, Cc, P, Ckv, O = 4, 192, 16, 384, 128   # the depth branch of the head
+    feat = rs.randn(rows, Cc, P).astype(np.float32)
+    wkv, bkv = (rs.randn(Ckv, Cc) / np.sqrt(Cc)).astype(np.float32), rs.randn(Ckv).astype(np.float32)
+    wl, bl = (rs.randn(O, Cc * P) / np.sqrt(Cc * P)).astype(np.float32), rs.randn(O).astype(np.float32)
+    kv_h, lin_h = np.zeros((rows, Ckv, P), np.float32), np.zeros((rows, O), np.float32)
+    Lt, Ld = T._sigs2(T.twin()), T._sigs2(T._sigs(lib()))
+    T.check(Lt, Lt.ivln_kv_linear_f32(T.hp(feat), rows, Cc, P, T.hp(wkv), T.hp(bkv), Ckv, T.hp(kv_h), T.hp(wl), T.hp(bl), O, 1,
+                                      T.hp(lin_h), O, None), "twin")
+    d = [_dev(a) for a in (feat, wkv, bkv, wl, bl)]
+    kv_d, lin_d = torch.zeros((rows, Ckv, P), device=DEV), torch.zeros((rows, O), device=DEV)
+    T.check(Ld, Ld.ivln_kv_linear_f32(_dp(d[0]), rows, Cc, P, _dp(d[1]), _dp(d[2]), Ckv, _dp(kv_d), _dp(d[3]), _dp(d[4]), O, 1,
+                                      _dp(lin_d), O, stream_ptr()), "device")
+    assert float(np.abs(kv_d.cpu().numpy() - kv_h).max()) < 2e-5 and float(np.abs(lin_d.cpu().numpy() - lin_h).max()) < 2e-5
+
+    for rows, L in ((4, 80), (8, 200), (1, 24)):
+        c = T.cma_step_case(rows + L, rows=rows, L=L, P=16)
+        x2_h = np.zeros((rows, c["x2w"]), np.float32)
+        x2_h[:, -c["E"]:] = c["prev"]
+        ho_h, f_h = np.zeros((rows, 2, c["H"]), np.float32), np.zeros((rows, c["H"]), np.float32)
+        T.check(Lt, Lt.ivln_cma_step_fwd(C.byref(T.cma_step_desc(T.hp, c, x2_h, ho_h, f_h, None)), 0, None), "twin")
+        cd = _pair(c)
+        x2_d = torch.zeros((rows, c["x2w"]), device=DEV)
+        x2_d[:, -c["E"]:] = cd["prev"]
+        ho_d, f_d = torch.zeros((rows, 2, c["H"]), device=DEV), torch.zeros((rows, c["H"]), device=DEV)
+        ws = torch.zeros(int(Ld.ivln_cma_step_ws_floats(rows, L, 16, c["H"])) + 64, device=DEV)
+        T.check(Ld, Ld.ivln_cma_step_fwd(C.byref(T.cma_step_desc(_ptr_dev, cd, x2_d, ho_d, f_d, ws)), 0, stream_ptr()), "device")
+        assert float(np.abs(x2_d.cpu().numpy() - x2_h).max()) < 2e-5, (rows, L)
+        assert float(np.abs(f_d.cpu().numpy() - f_h).max()) < 2e-5 and float(np.abs(ho_d.cpu().numpy() - ho_h).max()) < 2e-5

@@ -22,7 +22,8 @@ def test_twin_exports_the_header_symbols_it_claims():
     for name in ["ivln_strerror", "ivln_version", "ivln_gemm_f32", "ivln_groupnorm_f32", "ivln_mapper_create",
                  "ivln_mapper_destroy", "ivln_mapper_reset", "ivln_mapper_frames", "ivln_mapper_step",
                  "ivln_mapper_known_begin", "ivln_mapper_load_known", "ivln_mapper_known_raster", "ivln_mapper_status",
-                 "ivln_mapper_world_export"]:
+                 "ivln_mapper_world_export", "ivln_gn_conv_f32", "ivln_nconv_f32", "ivln_kv_linear_f32",
+                 "ivln_cma_step_fwd", "ivln_cma_step_ws_floats"]:
         assert hasattr(L, name) and name + "(" in header, name
     assert L.ivln_strerror(-5) == b"unsupported configuration"
 
@@ -108,3 +109,125 @@ def test_twin_mapper_entry_points_match_reference_golden(path):
         T.check(L, L.ivln_mapper_status(h, C.byref(n), None), "status")
         assert n.value == int(g[f"world_n_{t}"])
     L.ivln_mapper_destroy(h)
+
+
+# ---- round-2 entry points -------------------------------------------------------------------------------------------
+def _gn(x, G, gamma, beta):
+    return F.group_norm(x, G, torch.from_numpy(gamma), torch.from_numpy(beta), 1e-5)
+
+
+@pytest.mark.parametrize("second,residual,pool,ka,sa,Cb,sb", [(False, False, False, 3, 1, 0, 1), (True, False, False, 1, 1, 12, 2),
+                                                              (False, True, False, 3, 2, 0, 1), (False, False, True, 1, 1, 8, 1)])
+def test_twin_gn_conv_matches_torch(second, residual, pool, ka, sa, Cb, sb):
+    """GroupNorm (+ second operand / residual / ReLU / MaxPool) and the NEXT conv as per-group partial slabs
+    (ivln_gn_conv_f32) against F.group_norm + F.max_pool2d + F.conv2d over each group's channel slice."""
+    N, Cc, H, W, G, Ca = 2, 8, 6, 8, 4, 6
+    c = T.gn_conv_case(7 + ka + Cb, N, Cc, H, W, G, 3, second, residual, pool, ka, sa, Ca, Cb, sb)
+    act = np.zeros((N, Cc, c["Hp"], c["Wp"]), np.float32)
+    ya = np.zeros((G, Ca, N * c["Ho"] * c["Wo"]), np.float32)
+    yb = np.zeros((G, max(Cb, 1), N * max(c["Hb"] * c["Wb"], 1)), np.float32)
+    L = T._sigs2(T.twin())
+    d = T.gn_conv_desc(T.hp, c, act, ya, yb)
+    T.check(L, L.ivln_gn_conv_f32(C.byref(d), None), "twin gn_conv")
+    x = torch.from_numpy(c["x"].sum(0)).view(Cc, N, H, W).permute(1, 0, 2, 3)
+    ref = _gn(x, G, c["gamma"], c["beta"])
+    if second:
+        ref = ref + _gn(torch.from_numpy(c["x2"].sum(0)).view(Cc, N, H, W).permute(1, 0, 2, 3), G, c["gamma2"], c["beta2"])
+    if residual:
+        ref = ref + torch.from_numpy(c["residual"])
+    ref = F.relu(ref)
+    if pool:
+        ref = F.max_pool2d(ref, 3, 2, 1)
+    assert np.allclose(act, ref.numpy(), atol=2e-5)
+    cpg = Cc // G
+    for g in range(G):
+        sl = slice(g * cpg, (g + 1) * cpg)
+        ra = F.conv2d(ref[:, sl], torch.from_numpy(c["wa"][:, sl]), None, sa, ka // 2)
+        assert np.allclose(ya[g], ra.permute(1, 0, 2, 3).reshape(Ca, -1).numpy(), atol=3e-5), g
+        if Cb:
+            rb = F.conv2d(ref[:, sl], torch.from_numpy(c["wb"][:, sl]), None, sb, 0)
+            assert np.allclose(yb[g], rb.permute(1, 0, 2, 3).reshape(Cb, -1).numpy(), atol=3e-5), g
+
+
+@pytest.mark.parametrize("second,residual,ka,sa,Cb,sb", [(False, False, 3, 1, 0, 1), (True, True, 1, 1, 8, 2), (False, False, 3, 2, 0, 1)])
+def test_twin_nconv_matches_torch(second, residual, ka, sa, Cb, sb):
+    """GroupNorm-on-load conv (ivln_nconv_f32): statistics merged from per-strip (count, mean, M2) partials, conv
+    outputs in the [C][N][H][W] raw layout, and the OUTPUT's own partials - against torch on the full tensors."""
+    N, Cc, H, W, G, Ca, ga, gb = 2, 8, 8, 8, 4, 8, 4, 2
+    c = T.nconv_case(11 + ka + Cb, N, Cc, H, W, G, second, residual, ka, sa, Ca, ga, Cb, gb, sb, rows=4)
+    act = np.zeros((N, Cc, H, W), np.float32) if sa == 1 else None
+    ya, sta = np.zeros((Ca, N, c["Ho"], c["Wo"]), np.float32), np.zeros((c["strips"], N, ga, 3), np.float32)
+    yb = np.zeros((max(Cb, 1), N, max(c["Hb"], 1), max(c["Wb"], 1)), np.float32)
+    stb = np.zeros((c["strips"], N, gb, 3), np.float32)
+    L = T._sigs2(T.twin())
+    d = T.nconv_desc(T.hp, c, act, ya, sta, yb, stb)
+    T.check(L, L.ivln_nconv_f32(C.byref(d), None), "twin nconv")
+    ref = _gn(torch.from_numpy(c["x"]).permute(1, 0, 2, 3), G, c["gamma"], c["beta"])
+    if second:
+        ref = ref + _gn(torch.from_numpy(c["x2"]).permute(1, 0, 2, 3), G, c["gamma2"], c["beta2"])
+    if residual:
+        ref = ref + torch.from_numpy(c["residual"])
+    ref = F.relu(ref)
+    if act is not None:
+        assert np.allclose(act, ref.numpy(), atol=3e-5)
+    ra = F.conv2d(ref, torch.from_numpy(c["wa"]), None, sa, ka // 2).permute(1, 0, 2, 3)
+    assert np.allclose(ya, ra.numpy(), atol=5e-5)
+    mean, var = T.merged(sta)
+    v = ra.reshape(ga, Ca // ga, N, -1).permute(2, 0, 1, 3).reshape(N, ga, -1).double()
+    assert np.allclose(mean, v.mean(2).numpy(), atol=1e-5) and np.allclose(var, v.var(2, unbiased=False).numpy(), atol=1e-5)
+    if Cb:
+        rb = F.conv2d(ref, torch.from_numpy(c["wb"]), None, sb, 0).permute(1, 0, 2, 3)
+        assert np.allclose(yb, rb.numpy(), atol=5e-5)
+        mean, var = T.merged(stb)
+        v = rb.reshape(gb, Cb // gb, N, -1).permute(2, 0, 1, 3).reshape(N, gb, -1).double()
+        assert np.allclose(mean, v.mean(2).numpy(), atol=1e-5) and np.allclose(var, v.var(2, unbiased=False).numpy(), atol=1e-5)
+
+
+def test_twin_kv_linear_and_cma_step_match_torch():
+    """ivln_kv_linear_f32 against F.conv1d + F.linear, ivln_cma_step_fwd against the head's arithmetic in torch
+    (map_cma_policy.py:305-353 on the folded operands: nn.GRUCell, masked softmax attention, compress, nn.GRUCell)."""
+    rs = np.random.RandomState(4)
+    rows, Cc, P, Ckv, O = 3, 6, 16, 10, 5
+    feat = rs.randn(rows, Cc, P).astype(np.float32)
+    wkv, bkv = rs.randn(Ckv, Cc).astype(np.float32), rs.randn(Ckv).astype(np.float32)
+    wl, bl = (rs.randn(O, Cc * P) / 8).astype(np.float32), rs.randn(O).astype(np.float32)
+    kv, lin = np.zeros((rows, Ckv, P), np.float32), np.zeros((rows, O), np.float32)
+    L = T._sigs2(T.twin())
+    T.check(L, L.ivln_kv_linear_f32(T.hp(feat), rows, Cc, P, T.hp(wkv), T.hp(bkv), Ckv, T.hp(kv), T.hp(wl), T.hp(bl), O, 1,
+                                    T.hp(lin), O, None), "twin kv_linear")
+    ft = torch.from_numpy(feat)
+    assert np.allclose(kv, F.conv1d(ft, torch.from_numpy(wkv).unsqueeze(-1), torch.from_numpy(bkv)).numpy(), atol=2e-5)
+    assert np.allclose(lin, F.relu(F.linear(ft.flatten(1), torch.from_numpy(wl), torch.from_numpy(bl))).numpy(), atol=2e-5)
+
+    c = T.cma_step_case(9, rows=3, L=12, P=16, H=8, Hq=4, Ct=6, d_out=4, m_out=6, E=2)
+    x2 = np.zeros((c["rows"], c["x2w"]), np.float32)
+    x2[:, -c["E"]:] = c["prev"]
+    h_out, feats = np.zeros((c["rows"], 2, c["H"]), np.float32), np.zeros((c["rows"], c["H"]), np.float32)
+    d = T.cma_step_desc(T.hp, c, x2, h_out, feats, None)
+    T.check(L, L.ivln_cma_step_fwd(C.byref(d), 0, None), "twin cma_step")
+    t = {k: torch.from_numpy(v) for k, v in c.items() if isinstance(v, np.ndarray)}
+    H, Hq = c["H"], c["Hq"]
+
+    def gru(x, h, wi, wh, bi, bh):
+        cell = torch.nn.GRUCell(x.shape[1], H)
+        with torch.no_grad():
+            cell.weight_ih.copy_(wi), cell.weight_hh.copy_(wh), cell.bias_ih.copy_(bi), cell.bias_hh.copy_(bh)
+            return cell(x, h)
+
+    mk = t["mask"].float().unsqueeze(1)
+    state = gru(t["state_in"], t["h_in"][:, 0] * mk, t["w_ih1"], t["w_hh1"], t["b_ih1"], t["b_hh1"])
+    logits = torch.einsum("rh,rhl->rl", state, t["Mq"][:, :H]) + t["Mq"][:, H]
+    pad = (torch.arange(c["L"]).unsqueeze(0) >= t["lengths"].unsqueeze(1)).float()
+    a = torch.softmax((logits - pad * 1e8) / 16.0, 1)
+    text = torch.einsum("rl,rcl->rc", a, t["txt"])
+    q2 = torch.einsum("rl,rcl->rc", a, t["TQb"])
+    outs = []
+    for kv_t in (t["dkv"], t["mkv"]):
+        aa = torch.softmax(torch.einsum("rc,rcp->rp", q2, kv_t[:, :Hq]) / 16.0, 1)
+        outs.append(torch.einsum("rp,rcp->rc", aa, kv_t[:, Hq:]))
+    x2_ref = torch.cat([state, text, outs[0], outs[1], t["prev"]], 1)
+    c2 = F.relu(F.linear(x2_ref, t["w_c"], t["b_c"]))
+    f_ref = gru(c2, t["h_in"][:, 1] * mk, t["w_ih2"], t["w_hh2"], t["b_ih2"], t["b_hh2"])
+    assert np.allclose(x2, x2_ref.detach().numpy(), atol=2e-5)
+    assert np.allclose(feats, f_ref.detach().numpy(), atol=2e-5)
+    assert np.allclose(h_out[:, 0], state.detach().numpy(), atol=2e-5) and np.allclose(h_out[:, 1], feats, atol=0)
