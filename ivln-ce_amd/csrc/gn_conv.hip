@@ -32,6 +32,9 @@ namespace {
 #define GN_CONV_THREADS 512
 #endif
 constexpr int GT = GN_CONV_THREADS;  // threads per block
+// k_nconv's statistics merge gives threads [0, 256) to the first operand and [256, 512) to the second, and the loader /
+// MFMA split counts whole waves: other block sizes are not a tuning knob without touching those
+static_assert(GT >= 512 && GT % 256 == 0, "GN_CONV_THREADS must be a multiple of 256 and at least 512");
 constexpr int NW = GT / 64;      // waves per block
 constexpr int ZW = 2 * NW;       // index of the zero word in the reduction scratch
 constexpr int TILE_MAX = 8192;   // cpg * H * W floats held in LDS

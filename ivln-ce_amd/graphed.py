@@ -72,12 +72,23 @@ class GraphedRollout:
         self.side = (_stream(dev, "fork_txt"), _stream(dev, "fork_map")) if (streams and not self.split) else None
         self.graphs = []
         self.phase = 0  # which buffer set holds the current state
-        if hasattr(policy.net, "prepare_capture"):
-            policy.net.prepare_capture(self.static)
-        if self.split:
-            self._capture_split(warmup)
-        else:
-            self._capture(warmup)
+        # the fused head's scratch is baked into the captured graphs: this runner owns one (ops.cma_step_ws)
+        prev_owner, ops.CMA_WS_OWNER = ops.CMA_WS_OWNER, id(self)
+        try:
+            if hasattr(policy.net, "prepare_capture"):
+                policy.net.prepare_capture(self.static)
+            if self.split:
+                self._capture_split(warmup)
+            else:
+                self._capture(warmup)
+        finally:
+            ops.CMA_WS_OWNER = prev_owner
+
+    def __del__(self):
+        try:
+            ops.release_cma_ws(id(self))
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
 
     @property
     def actions(self):

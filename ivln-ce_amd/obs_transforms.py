@@ -101,6 +101,13 @@ class Mapper(ObservationTransformer):
             map_sensor_params=config.RL.POLICY.OBS_TRANSFORMS.EGOCENTRIC_MAPPER,
         )
         dims = extract_egocentric_map_parameters(config.RL.POLICY.OBS_TRANSFORMS.EGOCENTRIC_MAPPER)
+        if len(config.VIDEO_OPTION) > 0 or visualize:
+            # fail at set-up, not on the first mapper step of a rollout: the *_viz colour frames of the reference
+            # (obs_transforms.py:105-113 over visualize_semantic_map.py: cv2 / imutils rendering) are outside the hot
+            # path this package replaces
+            raise NotImplementedError(
+                "VIDEO_OPTION / visualize=True: map visualisation frames are not part of the MI355X hot path; run with "
+                "VIDEO_OPTION [] and render `occupancy_map` / `semantic_map` with the reference's visualize_semantic_map.py")
         tr = cls(
             camera_parameters=camera_parameters,
             map_dimensions=dims,

@@ -808,18 +808,21 @@ class CmaStepDesc(C.Structure):
 # (A/B switch IVLN_CMA_STEP_MODE; measured 0.977 vs 0.988 ms per 4-env step)
 CMA_STEP_MODE = int(os.environ.get("IVLN_CMA_STEP_MODE", "0"))
 _cma_ws = {}
+CMA_WS_OWNER = 0  # graphed.GraphedRollout sets its own id while it warms up / captures: every runner owns a workspace
 
 
 def cma_step_ws(rows, L, P, H, device):
-    """Scratch of the fused head, one per (device, shape): a policy's head
-    never runs concurrently with itself.  Not keyed by stream on purpose: the buffer must not be born inside a stream
-    capture (it would belong to that graph's private pool and outlive it in this cache); the warm-up steps that
-    precede every capture create it."""
+    """Scratch of the fused head, one per (device, shape, OWNER): phases 2-5 of ivln_cma_step_fwd hand logits / tables /
+    partial states to each other through it, so two heads in flight at once - a graph replay on one stream beside an
+    eager act() on another, two runners of two policies - must not share it.  The owner is 0 for eager calls and the
+    capturing GraphedRollout's id for a captured step (its pointer is baked into that graph).  Not keyed by stream:
+    the buffer must not be born inside a stream capture (it would belong to that graph's private pool and outlive it
+    in this cache) - the warm-up steps that precede every capture create it, on another stream than the capture."""
     L_ = _L()
     L_.ivln_cma_step_ws_floats.restype = i64
     L_.ivln_cma_step_ws_floats.argtypes = [i32, i32, i32, i32]
     n = L_.ivln_cma_step_ws_floats(rows, L, P, H)
-    key = (str(device), rows, L, P, H)
+    key = (str(device), rows, L, P, H, CMA_WS_OWNER)
     w = _cma_ws.get(key)
     if w is None:
         if torch.cuda.is_current_stream_capturing():
@@ -827,6 +830,11 @@ def cma_step_ws(rows, L, P, H, device):
         w = torch.zeros(n, dtype=torch.float32, device=device)
         _cma_ws[key] = w
     return w
+
+
+def release_cma_ws(owner):
+    for k in [k for k in _cma_ws if k[-1] == owner]:
+        del _cma_ws[k]
 
 
 def cma_step(d: CmaStepDesc, mode=None):

@@ -187,8 +187,11 @@ class MapCMANet(Net):
         if ops.CMA_STEP_MODE < 0 or "instruction" not in example_obs:
             return
         rows, L = example_obs["instruction"].shape[0], example_obs["instruction"].shape[1]
+        P = self.depth_encoder.output_shape[1] * self.depth_encoder.output_shape[2]
+        if P > 16 or L > 512:
+            return  # outside the fused head's envelope: forward_hip takes the unfused chain
         self._cma_fold_weights()
-        ops.cma_step_ws(rows, L, 16, self._hidden_size, example_obs["instruction"].device)
+        ops.cma_step_ws(rows, L, P, self._hidden_size, example_obs["instruction"].device)
 
     def _init_layers(self):
         if self.model_config.PROGRESS_MONITOR.use:
@@ -225,8 +228,18 @@ class MapCMANet(Net):
         dl, ml = self.depth_linear[1], self.map_linear[1]
         o_txt, o_dep, o_map, o_prev = H, H + 256, H + 256 + d_out, H + 256 + d_out + m_out
 
+        # The fused recurrent head (ivln_cma_step_fwd) wants the instruction branch to emit the folded [Mq | TQb] operand
+        # instead of text_k, so its eligibility is decided HERE, from shapes known before any branch runs (the encoders'
+        # static output shapes, the token axis, the widths' divisibility rules of csrc/cma_step.hip) - anything
+        # outside the kernel's envelope takes the unfused chain with a real text_k.
+        P_static = self.depth_encoder.output_shape[1] * self.depth_encoder.output_shape[2]
+        L_static = observations["instruction"].shape[-1] if "instruction" in observations else 0
         fused_head = (save is None and ops.CMA_STEP_MODE >= 0
-                      and not (mc.ablate_instruction or mc.ablate_depth or mc.ablate_map))
+                      and not (mc.ablate_instruction or mc.ablate_depth or mc.ablate_map)
+                      and P_static <= 16 and 0 < L_static <= 512
+                      and self.map_encoder.output_shape[1] * self.map_encoder.output_shape[2] == P_static
+                      and H % 64 == 0 and h2 % 64 == 0 and d_out % 16 == 0 and m_out % 16 == 0
+                      and self.instruction_encoder.output_size % 64 == 0)
 
         # update batches: the instruction of a trajectory is the same at every timestep, so the loader hands over the
         # UNIQUE token rows and each row's index into them (trainers.PrefetchLoader); the encoder, text_k and their
