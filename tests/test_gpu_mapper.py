@@ -119,11 +119,14 @@ def test_obs_transform_boundary_deletes_keys_and_aliases_buffers():
     assert int(out["occupancy_map"].sum()) > 0
     assert "occupancy_map_viz" not in out
     # the *_viz colour frames (visualize_semantic_map.py) are out of scope: asking for
-    # them is a loud error, not a silent no-op
-    tr_v = GTSemanticsIterativeMapper.from_config(cfg, visualize=True)
-    obs = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in roll.step().items()}
+    # them is a loud error at set-up (not in the middle of a rollout), not a silent no-op
     with pytest.raises(NotImplementedError):
-        tr_v(obs)
+        GTSemanticsIterativeMapper.from_config(cfg, visualize=True)
+    cfg_v = cfg.clone()
+    cfg_v.defrost()
+    cfg_v.VIDEO_OPTION = ["disk"]
+    with pytest.raises(NotImplementedError):
+        GTSemanticsIterativeMapper.from_config(cfg_v)
 
 
 def test_mapper_raises_without_gpu_tensor():
