@@ -317,6 +317,9 @@ def bench_update(policy, dev, world, barrier, T=64, N=8, iters=5, warm=2):
         t0 = time.perf_counter()
         for _ in range(iters):
             update_agent(policy, opt, obs, prev, nd, tgt, w, world=world)
+            if os.environ.get("IVLN_BENCH_DEBUG"):
+                torch.cuda.synchronize()
+                log(f"update iter at {1e3 * (time.perf_counter() - t0):.2f} ms")
         barrier()
         el = time.perf_counter() - t0
         # MFMA kernel family of one update (instrumented pass, outside the timed region).  The event pairs sum
@@ -633,11 +636,19 @@ def main():
         """MFMA-family roofline of a leg: eager pass with an event pair per GEMM-family launch, the GPU parked on a
         spin kernel while the host enqueues each step so that pairs time back-to-back kernels (what rocprofv3's
         per-kernel durations show) and not the host's launch gaps.  Not part of any `value`."""
-        with GemmTimer() as gt:
-            for i in range(n_inst):
-                torch.cuda._sleep(12_000_000)
-                rollout_step(leg["tr"], policy, leg["obs_dev"][i % leg["n_pool"]], leg["state"])
-            ms = gt.total_ms()
+        from ivln_ce_amd.rednet import PredictSemantics
+
+        # the timed configuration replays RedNet's recorded launch table through ONE C call (ivln_rednet_fwd), which
+        # the per-launch event pairs cannot see: the instrumented pass walks the same launches from Python instead
+        plan, PredictSemantics.USE_PLAN = PredictSemantics.USE_PLAN, False
+        try:
+            with GemmTimer() as gt:
+                for i in range(n_inst):
+                    torch.cuda._sleep(12_000_000)
+                    rollout_step(leg["tr"], policy, leg["obs_dev"][i % leg["n_pool"]], leg["state"])
+                ms = gt.total_ms()
+        finally:
+            PredictSemantics.USE_PLAN = plan
         return mfma_roofline(gt, ms, n_inst, traffic, what)
 
     head_pred = args.pred_semantics

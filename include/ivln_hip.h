@@ -160,6 +160,10 @@ typedef struct ivln_gemm_desc {
      * IVLN_E_UNSUPPORTED). */
     int grp_imgs;
     int64_t a_grp_stride, a_packed_grp_stride;
+    /* 1: keep the per-lane 4-byte stores of the MFMA layout for NCHW outputs instead of sending the tile through LDS
+     * and writing 16 bytes per lane along the pixel index (csrc/gemm_vec.hip; A/B measurements and tests).  Results
+     * are identical either way. */
+    int no_wide_epilogue;
 } ivln_gemm_desc;
 
 int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream);

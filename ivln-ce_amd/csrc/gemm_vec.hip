@@ -29,8 +29,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_vec(const ivln_gemm_desc p) {
     constexpr int A_WORDS = ALAY == LAY_K ? BM * LDK : BKV * BM;
     constexpr int B_WORDS = BLAY == LAY_K ? BN * LDK : BKV * BN;
     constexpr int EA = BM * BKV / 1024, EB = BN * BKV / 1024;  // float4 per thread per tile
-    __shared__ __attribute__((aligned(16))) float As[A_WORDS];
-    __shared__ __attribute__((aligned(16))) float Bs[B_WORDS];
+    // one LDS block: the operand tiles during the K loop, the output tile during the wide epilogue
+    constexpr int LDC = BN + 4;
+    constexpr bool WIDE_FITS = BM * LDC <= A_WORDS + B_WORDS;
+    __shared__ __attribute__((aligned(16))) float smem[A_WORDS + B_WORDS];
+    float* const As = smem;
+    float* const Bs = smem + A_WORDS;
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int half = lane >> 5, l31 = lane & 31;
@@ -191,6 +195,53 @@ __global__ __launch_bounds__(256, 2) void k_gemm_vec(const ivln_gemm_desc p) {
         }
     }
 
+    // ---- wide epilogue (NCHW outputs written directly): the MFMA leaves a lane with 4 consecutive ROWS of one column,
+    // i.e. 4-byte stores of which a wave instruction covers two 128-byte segments - the store path, not HBM, bounds
+    // the short-K 1x1 convolutions that way (64 -> 256 channels at 64x64: 67 MB of output in 84 us = 0.8 TB/s).  The
+    // tile goes through LDS once and leaves as 16 bytes per lane along the pixel index: a wave instruction writes
+    // four 256-byte row segments, a quarter of the store instructions, and the residual comes in as float4 too.
+    if constexpr (WIDE_FITS) {
+        const bool wide = p.dmode == DMODE_NCHW && p.splits == 1 && !p.defer_epilogue && (p.HoWo & 3) == 0 &&
+                          (((uintptr_t)p.D | (uintptr_t)p.residual) & 15) == 0 && !p.no_wide_epilogue;
+        if (wide) {   // (uniform: every thread takes the same side)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        smem[((wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * LDC + (wn * TN + tn) * 32 + l31] =
+                            acc[tm][tn][r];
+            __syncthreads();
+            for (int idx = t; idx < BM * (BN / 4); idx += 256) {
+                const int ml = idx / (BN / 4), c4 = idx - ml * (BN / 4);
+                const int m = m0 + ml, n = n0 + c4 * 4;
+                if (m >= p.M || n >= p.N) continue;   // N % 4 == 0 here (HoWo % 4 == 0): a float4 is in or out whole
+                float4 v = *reinterpret_cast<const float4*>(&smem[ml * LDC + c4 * 4]);
+                const int img = n / p.HoWo, pp = n - img * p.HoWo;
+                const int64_t addr = ((int64_t)img * p.Ctot + m) * p.HoWo + pp;
+                const int me = p.grp_imgs > 0 ? (img / p.grp_imgs) * p.M + m : m;
+                if (p.scale) {
+                    const float sc = p.scale[me], sh = p.shift[me];
+                    v.x = fmaf(v.x, sc, sh), v.y = fmaf(v.y, sc, sh), v.z = fmaf(v.z, sc, sh), v.w = fmaf(v.w, sc, sh);
+                } else if (p.shift) {
+                    const float sh = p.shift[me];
+                    v.x += sh, v.y += sh, v.z += sh, v.w += sh;
+                }
+                if (p.residual) {
+                    const float4 rr = *reinterpret_cast<const float4*>(p.residual + addr);
+                    v.x += rr.x, v.y += rr.y, v.z += rr.z, v.w += rr.w;
+                }
+                if (p.accumulate) {
+                    const float4 rr = *reinterpret_cast<const float4*>(p.D + addr);
+                    v.x += rr.x, v.y += rr.y, v.z += rr.z, v.w += rr.w;
+                }
+                if (p.relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+                *reinterpret_cast<float4*>(p.D + addr) = v;
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll

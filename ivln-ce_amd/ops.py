@@ -37,6 +37,7 @@ class GemmDesc(C.Structure):
         ("A_packed", vp),
         ("no_xcd_remap", i32),
         ("grp_imgs", i32), ("a_grp_stride", i64), ("a_packed_grp_stride", i64),
+        ("no_wide_epilogue", i32),
     ]
 
 
@@ -187,6 +188,7 @@ def splitk_ws(device, floats=8 << 20, slot=0):
 TILE_OVERRIDE = 0  # tuning/tests: force a block tile (1..5), see ivln_gemm_desc.tile_override
 LINEAR_BWD_SPLIT = not bool(os.environ.get("IVLN_LINEAR_BWD_NO_SPLIT"))  # A/B: split-K in Linear dX / accumulating dW
 NO_XCD_REMAP = False  # tests / A-B: identity workgroup -> tile mapping (ivln_gemm_desc.no_xcd_remap)
+NO_WIDE_EPILOGUE = bool(os.environ.get("IVLN_NO_WIDE_EPILOGUE"))  # A/B: 4-byte MFMA-layout stores for NCHW outputs
 PACK_WEIGHTS = True  # A/B switch: pre-arranged weights for the direct conv kernel
 
 
@@ -195,6 +197,8 @@ def gemm(desc: GemmDesc):
         desc.tile_override = TILE_OVERRIDE
     if NO_XCD_REMAP:
         desc.no_xcd_remap = 1
+    if NO_WIDE_EPILOGUE:
+        desc.no_wide_epilogue = 1
     check(_L().ivln_gemm_f32(C.byref(desc), stream_ptr()), "ivln_gemm_f32")
     if _REC is not None:
         _rec(OP_GEMM, gemm=desc)
