@@ -98,15 +98,19 @@ enum { IVLN_B_CONV = 0,    /* im2col gather from NCHW via koff/kpos tables      
        IVLN_B_IM2COL_T = 4,/* B[k = out pixel][n = (ci,kh,kw)] (conv weight gradient) */
        IVLN_B_CONVT = 5,   /* transposed-conv gather (koff = ci*Hin*Win)              */
        IVLN_B_CONV_K3 = 6, /* 3x3, dilation 1: tap indices by constant division, no tables */
-       IVLN_B_CONV_K7 = 7  /* 7x7, dilation 1                                            */ };
+       IVLN_B_CONV_K7 = 7, /* 7x7, dilation 1                                            */
+       IVLN_B_CONV_K2 = 8  /* 2x2, dilation 1 (taps at input offsets 0..1 with pad 0 and Hout = Hin: the row / column
+                              past the edge reads as zero - the window of a stride-2 3x3 transposed conv's parity
+                              classes) */ };
 enum { IVLN_D_NCHW = 0,    /* D[(img*Ctot + m)*HoWo + pp], n = img*HoWo + pp          */
        IVLN_D_DENSE = 1,   /* D[m*sDm + n*sDn]                                        */
        IVLN_D_NCHW_UP2 = 2,/* one output-parity class of a stride-2 transposed conv: pixel (ho,wo) of the
                               (Hout x Wout) class grid lands at (2*ho + sDm, 2*wo + sDn) of a
                               (2*Hout x 2*Wout) NCHW destination (sDm, sDn in {0,1} = row/col parity) */
-       IVLN_D_NCHW_UP2X4 = 3 /* all four parity classes in ONE GEMM: rows m = cls*(M/4) + channel, cls = 2*a + b;
-                              pixel (ho,wo) of row m lands at (2*ho + a, 2*wo + b) of channel m % (M/4); the
-                              epilogue parameters are indexed by the channel (rednet.py:210-216, 262-279) */ };
+       IVLN_D_NCHW_UP2X4 = 3 /* all four parity classes in ONE GEMM: rows m = 4*channel + cls, cls = 2*a + b;
+                              pixel (ho,wo) of row m lands at (2*ho + a, 2*wo + b) of channel m / 4; the epilogue
+                              parameters are indexed by the channel (rednet.py:210-216, 262-279).  Interleaved so
+                              that an output tile holds whole 2x2 output blocks and leaves as 16-byte stores */ };
 
 typedef struct ivln_gemm_desc {
     const float* A;
@@ -144,7 +148,7 @@ typedef struct ivln_gemm_desc {
      * 7 insist on the float4-staged GEMM (gemm_vec.hip).  6/7 return IVLN_E_UNSUPPORTED when the shape is
      * not eligible (tuning, tests). */
     int tile_override;
-    /* optional (stride-1 3x3 / 7x7 convs): the weights pre-arranged by ivln_conv_pack_weights_f32; when set and
+    /* optional (stride-1 3x3 / 7x7 / 2x2 convs): the weights pre-arranged by ivln_conv_pack_weights_f32; when set and
      * the direct kernel is chosen, its weight staging becomes a linear float4 copy.  A must still be given. */
     const float* A_packed;
     /* 0 (default): workgroup ids are remapped so that each XCD (hardware places workgroup b on XCD b % 8, each

@@ -1,5 +1,6 @@
-// Direct stride-1 3x3 / 7x7 convolution on the fp32 MFMA pipe (gfx950): the map CNN of the MapCMA policy
-// (4 x 7x7, forward and input-gradient), the 3x3 convs of the DD-PPO ResNet and of RedNet.
+// Direct stride-1 3x3 / 7x7 / 2x2 convolution on the fp32 MFMA pipe (gfx950): the map CNN of the MapCMA policy
+// (4 x 7x7, forward and input-gradient), the 3x3 convs of the DD-PPO ResNet and of RedNet, and RedNet's stride-2 3x3
+// transposed convs as ONE 2x2-window conv over their four stacked output-parity classes (ops.convt_s2_stack).
 //
 // The implicit GEMM in gemm_conv.hip gathers every B element (one input pixel per (ci,kh,kw)) with its own
 // address computation and bounds test; on 7x7 that VALU work competes with the MFMA issue slots.  Here a
@@ -26,7 +27,7 @@ namespace {
 template <int KS, int PTW, int PTH, int IMGS, int WM, bool PACKED>
 __global__ __launch_bounds__(256) void k_conv_direct(const ivln_gemm_desc p, int tiles_w, int tiles_h, int nimg,
                                                      int chunks_per_split) {
-    constexpr int CI = KS == 7 ? 2 : 8;  // input channels per chunk (even: channel pairs fill the k slots)
+    constexpr int CI = conv_direct_ci(KS);  // input channels per chunk (even: channel pairs fill the k slots)
     constexpr int KK = KS * KS;
     constexpr int KC = CI * KK;   // k extent of a chunk
     constexpr int NQ = KC / 2;    // MFMA steps per chunk
@@ -37,8 +38,14 @@ __global__ __launch_bounds__(256) void k_conv_direct(const ivln_gemm_desc p, int
     constexpr int PATCH = IMGS * CI * PLANE;
     constexpr int LDA = PACKED ? BM + 4 : BM + 1;
     constexpr int NA = PACKED ? (KC * LDA / 4 + 255) / 256 * 4 : (BM * KC + 255) / 256, NP = (PATCH + 255) / 256;
-    __shared__ __attribute__((aligned(16))) float As[KC * LDA];
-    __shared__ float Ps[PATCH];
+    // KS == 2 serves the stacked parity classes of a stride-2 transposed conv (DMODE_NCHW_UP2X4): its output tile
+    // goes through the same LDS block once more to leave as 16-byte stores (up2x4_wide_store, gemm_common.h)
+    constexpr int LDC = BN + 4;
+    constexpr int OPER = (KC * LDA + 3) / 4 * 4 + PATCH;
+    constexpr int SMEM = (KS == 2 && BM * LDC > OPER) ? BM * LDC : OPER;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+    float* const As = smem;
+    float* const Ps = smem + (KC * LDA + 3) / 4 * 4;
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int half = lane >> 5, l31 = lane & 31;
@@ -159,6 +166,22 @@ __global__ __launch_bounds__(256) void k_conv_direct(const ivln_gemm_desc p, int
     }
 
     // ---- epilogue: acc[r] -> channel (r&3) + 8*(r>>2) + 4*half, pixel l31 of the sub-tile ----
+    if constexpr (KS == 2) {
+        if (up2x4_wide_ok(p)) {   // (uniform; the K loop ended on a barrier, the operand tiles are dead)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    smem[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * LDC + (wn * TN + tn) * 32 + l31] = acc[tn][r];
+            __syncthreads();
+            up2x4_wide_store<BM, BN, LDC>(p, smem, m0, [&](int nl, int& img, int& ho, int& wo) {
+                const int il = nl / (PTH * PTW), ph = (nl / PTW) % PTH, pw = nl % PTW;
+                img = img0 + il, ho = ho0 + ph, wo = wo0 + pw;
+                return img < nimg && ho < p.Hout && wo < p.Wout;
+            });
+            return;
+        }
+    }
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int nl = (wn * TN + tn) * 32 + l31;
@@ -182,7 +205,7 @@ __global__ __launch_bounds__(256) void k_conv_direct(const ivln_gemm_desc p, int
 // channels past M are zero.
 __global__ __launch_bounds__(256) void k_conv_pack_weights(const float* __restrict__ W, int M, int Cin, int KS, int BM,
                                                            float* __restrict__ out) {
-    const int KK = KS * KS, CI = KS == 7 ? 2 : 8, KC = CI * KK, LDA = BM + 4;
+    const int KK = KS * KS, CI = conv_direct_ci(KS), KC = CI * KK, LDA = BM + 4;
     const int nch = Cin / CI;
     const int64_t total = (int64_t)((M + BM - 1) / BM) * nch * KC * LDA;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -424,9 +447,9 @@ void launch_wgrad_ks(const ivln_gemm_desc& d, hipStream_t s, int nimg, int ntile
 
 int ivln_conv_direct_launch(ivln_gemm_desc& d, hipStream_t s) {
     static const bool disabled = getenv("IVLN_NO_DIRECT_CONV") != nullptr;
-    const int KS = d.bmode == BMODE_CONV_K7 ? 7 : (d.bmode == BMODE_CONV_K3 ? 3 : 0);
+    const int KS = conv_ks(d.bmode);
     if (disabled || KS == 0 || d.amode != AMODE_MK || d.stride != 1 || d.dil != 1) return IVLN_E_UNSUPPORTED;
-    const int CI = KS == 7 ? 2 : 8;
+    const int CI = conv_direct_ci(KS);
     if (d.Cin % CI != 0 || d.K != d.Cin * KS * KS || d.HoWo != d.Hout * d.Wout || d.N % d.HoWo != 0)
         return IVLN_E_UNSUPPORTED;
     const int nimg = d.N / d.HoWo;
@@ -463,6 +486,7 @@ int ivln_conv_direct_launch(ivln_gemm_desc& d, hipStream_t s) {
     splits = (nch + cps - 1) / cps;
     d.splits = splits;
     if (KS == 7) launch_ks<7>(d, s, nimg, cps);
+    else if (KS == 2) launch_ks<2>(d, s, nimg, cps);
     else launch_ks<3>(d, s, nimg, cps);
     return IVLN_OK;
 }
@@ -507,8 +531,8 @@ int ivln_wgrad_direct_launch(ivln_gemm_desc& d, hipStream_t s) {
 }
 
 extern "C" int64_t ivln_conv_packed_floats(int M, int Cin, int KS) {
-    if ((KS != 3 && KS != 7) || M <= 0) return 0;
-    const int CI = KS == 7 ? 2 : 8, BM = M <= 32 ? 32 : 64;
+    if ((KS != 2 && KS != 3 && KS != 7) || M <= 0) return 0;
+    const int CI = conv_direct_ci(KS), BM = M <= 32 ? 32 : 64;
     if (Cin % CI) return 0;
     return (int64_t)((M + BM - 1) / BM) * (Cin / CI) * (CI * KS * KS) * (BM + 4);
 }

@@ -10,7 +10,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 enum { AMODE_MK = 0, AMODE_KM = 1, AMODE_NCHW_P = 2 };
 enum { BMODE_CONV = 0, BMODE_CONV1X1 = 1, BMODE_KN = 2, BMODE_NK = 3, BMODE_IM2COL_T = 4, BMODE_CONVT = 5,
-       BMODE_CONV_K3 = 6, BMODE_CONV_K7 = 7 };  // 3x3 / 7x7, dilation 1: (ci,kh,kw) by constant division, no tables
+       BMODE_CONV_K3 = 6, BMODE_CONV_K7 = 7,  // 3x3 / 7x7, dilation 1: (ci,kh,kw) by constant division, no tables
+       BMODE_CONV_K2 = 8 };                   // 2x2 likewise (the stacked parity classes of a stride-2 3x3 transposed conv)
+__host__ __device__ constexpr int conv_ks(int bmode) {
+    return bmode == BMODE_CONV_K7 ? 7 : (bmode == BMODE_CONV_K3 ? 3 : (bmode == BMODE_CONV_K2 ? 2 : 0));
+}
+// input channels per chunk of the direct kernels (even: channel pairs fill the two k slots of the MFMA)
+__host__ __device__ constexpr int conv_direct_ci(int KS) { return KS == 7 ? 2 : (KS == 2 ? 16 : 8); }
 enum { DMODE_NCHW = 0, DMODE_DENSE = 1, DMODE_NCHW_UP2 = 2, DMODE_NCHW_UP2X4 = 3 };
 
 constexpr int BK = 16;
@@ -55,9 +61,9 @@ __device__ __forceinline__ void epilogue_store(const ivln_gemm_desc& p, int m, i
         int pp = n - img * p.HoWo;
         int ho = pp / p.Wout, wo = pp - ho * p.Wout;
         addr = (((int64_t)img * p.Ctot + m) * (2 * p.Hout) + 2 * ho + (int)p.sDm) * (2 * p.Wout) + 2 * wo + (int)p.sDn;
-    } else if (p.dmode == DMODE_NCHW_UP2X4) {  // four output-parity classes stacked along M
-        const int cq = p.M >> 2, cls = m / cq;
-        me = m - cls * cq;
+    } else if (p.dmode == DMODE_NCHW_UP2X4) {  // four output-parity classes interleaved along M: m = 4*channel + cls
+        const int cls = m & 3;
+        me = m >> 2;
         int img = n / p.HoWo;
         int pp = n - img * p.HoWo;
         int ho = pp / p.Wout, wo = pp - ho * p.Wout;
@@ -120,6 +126,52 @@ __device__ __forceinline__ void epilogue_tile(const ivln_gemm_desc& p, int m_bas
             }
         }
     }
+}
+
+// DMODE_NCHW_UP2X4 tile -> D through LDS.  Row m = 4*channel + 2*a + b of the GEMM holds output pixel
+// (2*ho + a, 2*wo + b), so the four rows of a channel x two horizontally adjacent input pixels are 2 x 4 consecutive
+// output floats: T ([BM][LDC] in LDS, rows m - m0, columns = the tile's pixels in an order where 2j and 2j+1 are
+// horizontal neighbours) leaves as one 16-byte store per (channel, a, pixel pair) - whole 64-byte segments instead of
+// the stride-2 4-byte stores of the MFMA layout, which touch every segment of the output twice.
+// pix(nl, img, ho, wo) -> false when column nl of the tile is outside the problem.
+template <int BM, int BN, int LDC, typename Pix>
+__device__ __forceinline__ void up2x4_wide_store(const ivln_gemm_desc& p, const float* T, int m0, Pix pix) {
+    constexpr int PAIRS = BN / 2;
+    for (int f = threadIdx.x; f < (BM / 2) * PAIRS; f += 256) {
+        const int j = f % PAIRS, r = f / PAIRS;   // r = 2*(channel of the tile) + a
+        const int ml = 2 * r;                     // row of b = 0; b = 1 is the next one
+        if (m0 + ml >= p.M) continue;             // M % 4 == 0: both rows are in or out together
+        int img, ho, wo;
+        if (!pix(2 * j, img, ho, wo)) continue;
+        const int co = (m0 + ml) >> 2, a = r & 1;
+        const int64_t addr = (((int64_t)img * p.Ctot + co) * (2 * p.Hout) + 2 * ho + a) * (2 * p.Wout) + 2 * wo;
+        const float2 t0 = *reinterpret_cast<const float2*>(T + ml * LDC + 2 * j);
+        const float2 t1 = *reinterpret_cast<const float2*>(T + (ml + 1) * LDC + 2 * j);
+        float4 v = make_float4(t0.x, t1.x, t0.y, t1.y);
+        if (p.scale) {
+            const float sc = p.scale[co], sh = p.shift[co];
+            v.x = fmaf(v.x, sc, sh), v.y = fmaf(v.y, sc, sh), v.z = fmaf(v.z, sc, sh), v.w = fmaf(v.w, sc, sh);
+        } else if (p.shift) {
+            const float sh = p.shift[co];
+            v.x += sh, v.y += sh, v.z += sh, v.w += sh;
+        }
+        if (p.residual) {
+            const float4 rr = *reinterpret_cast<const float4*>(p.residual + addr);
+            v.x += rr.x, v.y += rr.y, v.z += rr.z, v.w += rr.w;
+        }
+        if (p.accumulate) {
+            const float4 rr = *reinterpret_cast<const float4*>(p.D + addr);
+            v.x += rr.x, v.y += rr.y, v.z += rr.z, v.w += rr.w;
+        }
+        if (p.relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+        *reinterpret_cast<float4*>(p.D + addr) = v;
+    }
+}
+// (uniform) may this launch use up2x4_wide_store: even class-grid width so that pixel pairs share a row and every
+// 16-byte store is aligned
+__device__ __forceinline__ bool up2x4_wide_ok(const ivln_gemm_desc& p) {
+    return p.dmode == DMODE_NCHW_UP2X4 && p.splits == 1 && !p.defer_epilogue && (p.Wout & 1) == 0 &&
+           (((uintptr_t)p.D | (uintptr_t)p.residual) & 15) == 0 && !p.no_wide_epilogue;
 }
 
 }  // namespace

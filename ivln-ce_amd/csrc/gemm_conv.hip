@@ -59,8 +59,7 @@ __global__ __launch_bounds__(256) void k_gemm(const ivln_gemm_desc p) {
     int64_t pix_base = 0;
     int hi0 = 0, wi0 = 0;
     bool n_ok = false;
-    if constexpr (BMODE == BMODE_CONV || BMODE == BMODE_CONV1X1 || BMODE == BMODE_CONVT || BMODE == BMODE_CONV_K3 ||
-                  BMODE == BMODE_CONV_K7) {
+    if constexpr (BMODE == BMODE_CONV || BMODE == BMODE_CONV1X1 || BMODE == BMODE_CONVT || conv_ks(BMODE) != 0) {
         int n = n0 + b_n;
         n_ok = n < p.N;
         int nn = n_ok ? n : 0;
@@ -142,9 +141,9 @@ __global__ __launch_bounds__(256) void k_gemm(const ivln_gemm_desc p) {
                 const float v = p.B[ok ? pix_base + p.koff[kc] + (int64_t)hi0 * p.Win + wi0 : 0];
                 rb[e] = ok ? v : 0.f;
             }
-        } else if constexpr (BMODE == BMODE_CONV_K3 || BMODE == BMODE_CONV_K7) {
+        } else if constexpr (conv_ks(BMODE) != 0) {
             // (ci,kh,kw) from constant divisions: no dependent table load on the per-tile critical path
-            constexpr int KS = BMODE == BMODE_CONV_K3 ? 3 : 7;
+            constexpr int KS = conv_ks(BMODE);
             const int HWin = p.Hin * p.Win;
 #pragma unroll
             for (int e = 0; e < EB; ++e) {
@@ -310,6 +309,7 @@ int launch_tile(const ivln_gemm_desc& d, hipStream_t s) {
     IVLN_CASE(AMODE_MK, BMODE_CONV1X1)
     IVLN_CASE(AMODE_MK, BMODE_CONV_K3)
     IVLN_CASE(AMODE_MK, BMODE_CONV_K7)
+    IVLN_CASE(AMODE_MK, BMODE_CONV_K2)
     IVLN_CASE(AMODE_MK, BMODE_CONVT)
     IVLN_CASE(AMODE_MK, BMODE_NK)
     IVLN_CASE(AMODE_MK, BMODE_KN)

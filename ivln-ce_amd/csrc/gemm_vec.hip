@@ -203,7 +203,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_vec(const ivln_gemm_desc p) {
     if constexpr (WIDE_FITS) {
         const bool wide = p.dmode == DMODE_NCHW && p.splits == 1 && !p.defer_epilogue && (p.HoWo & 3) == 0 &&
                           (((uintptr_t)p.D | (uintptr_t)p.residual) & 15) == 0 && !p.no_wide_epilogue;
-        if (wide) {   // (uniform: every thread takes the same side)
+        const bool wide_up = up2x4_wide_ok(p);   // the four parity classes of a stride-2 transposed conv (gemm_common.h)
+        if (wide || wide_up) {   // (uniform: every thread takes the same side)
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -213,6 +214,17 @@ __global__ __launch_bounds__(256, 2) void k_gemm_vec(const ivln_gemm_desc p) {
                         smem[((wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * LDC + (wn * TN + tn) * 32 + l31] =
                             acc[tm][tn][r];
             __syncthreads();
+            if (wide_up) {
+                up2x4_wide_store<BM, BN, LDC>(p, smem, m0, [&](int nl, int& img, int& ho, int& wo) {
+                    const int n = n0 + nl;
+                    if (n >= p.N) return false;
+                    img = n / p.HoWo;
+                    const int pp = n - img * p.HoWo;
+                    ho = pp / p.Wout, wo = pp - ho * p.Wout;
+                    return true;
+                });
+                return;
+            }
             for (int idx = t; idx < BM * (BN / 4); idx += 256) {
                 const int ml = idx / (BN / 4), c4 = idx - ml * (BN / 4);
                 const int m = m0 + ml, n = n0 + c4 * 4;

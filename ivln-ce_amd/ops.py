@@ -4,6 +4,7 @@ Every function takes/returns torch GPU tensors, launches on torch's current stre
 no arithmetic itself; tensor allocation and views are the only torch operations used.
 """
 import ctypes as C
+import contextlib
 import os
 from typing import Optional
 
@@ -97,7 +98,7 @@ def _rec(kind, ints=(), floats=(), n=0, src0=None, src1=None, dst=None, gemm=Non
 
 
 A_MK, A_KM, A_NCHW_P = 0, 1, 2
-B_CONV, B_CONV1X1, B_KN, B_NK, B_IM2COL_T, B_CONVT, B_CONV_K3, B_CONV_K7 = 0, 1, 2, 3, 4, 5, 6, 7
+B_CONV, B_CONV1X1, B_KN, B_NK, B_IM2COL_T, B_CONVT, B_CONV_K3, B_CONV_K7, B_CONV_K2 = 0, 1, 2, 3, 4, 5, 6, 7, 8
 D_NCHW, D_DENSE, D_NCHW_UP2, D_NCHW_UP2X4 = 0, 1, 2, 3
 
 _sigs_done = False
@@ -204,6 +205,41 @@ def gemm(desc: GemmDesc):
         _rec(OP_GEMM, gemm=desc)
 
 
+_WORK_STREAMS = {}
+OFF_NULL_STREAM = os.environ.get("IVLN_OFF_NULL_STREAM", "1") != "0"
+
+
+@contextlib.contextmanager
+def off_null_stream(device=None):
+    """Run an eager many-launch region on a dedicated non-blocking stream when the caller is on the NULL stream.
+    HIP's null stream orders itself against every other blocking stream of the device, and the runtime pays for
+    that on each launch once the process has used side streams or replayed graphs: the same DAgger update measured
+    13.6 ms per step in a fresh process and 17.5 ms after a graph-replayed collection (about 2 us more on each of
+    its ~2000 launches), 14.1 ms on a non-null stream (profiles/README.md, round 3).  The region is ordered behind
+    the caller's stream on entry and the caller's stream behind it on exit, so surrounding code sees no difference;
+    a caller already on a stream of its own is left alone."""
+    if not OFF_NULL_STREAM or not torch.cuda.is_available():
+        yield
+        return
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.type != "cuda":
+        yield
+        return
+    cur = torch.cuda.current_stream(dev)
+    if cur != torch.cuda.default_stream(dev) or torch.cuda.is_current_stream_capturing():
+        yield
+        return
+    work = _WORK_STREAMS.get(dev.index)
+    if work is None:
+        work = _WORK_STREAMS[dev.index] = torch.cuda.Stream(dev)
+    work.wait_stream(cur)
+    try:
+        with torch.cuda.stream(work):
+            yield
+    finally:
+        cur.wait_stream(work)
+
+
 def _epilogue(d: GemmDesc, scale, shift, residual, relu, accumulate=False):
     d.scale, d.shift, d.residual = _p(scale), _p(shift), _p(residual)
     d.relu, d.accumulate = int(bool(relu)), int(bool(accumulate))
@@ -213,7 +249,7 @@ _packed = {}
 
 
 def packed_conv_weights(w, cache=True):
-    """Weights of a stride-1 3x3 / 7x7 conv in the direct kernel's LDS order.  Long-lived tensors (module
+    """Weights of a stride-1 3x3 / 7x7 / 2x2 conv in the direct kernel's LDS order.  Long-lived tensors (module
     parameters) are cached until they change (tensor version / WEIGHT_EPOCH) or die (weak reference: a freed
     address may be handed to another tensor); temporaries (`cache=False`, e.g. the flipped weights of an input
     gradient) are packed into a fresh buffer every call so that nothing accumulates."""
@@ -398,14 +434,16 @@ def convt_s2_classes(w_t, pad):
 
 
 def convt_s2_stack(classes):
-    """The four parity classes of convt_s2_classes as ONE weight (4*Cout, Cin, t, t), rows cls*Cout + co with
-    cls = 2a + b; classes with fewer taps are zero-padded to the common (t x t) window (k=3: 16 instead of 9 tap
-    products per input pixel, bought back by one launch that reads the input once and writes whole output rows)."""
+    """The four parity classes of convt_s2_classes as ONE weight (4*Cout, Cin, t, t), rows 4*co + cls with
+    cls = 2a + b (include/ivln_hip.h IVLN_D_NCHW_UP2X4: the four rows of a channel are one 2x2 output block per input
+    pixel, so a tile leaves as 16-byte stores); classes with fewer taps are zero-padded to the common (t x t) window
+    (k=3: 16 instead of 9 tap products per input pixel, bought back by one launch that reads the input once and
+    writes whole output rows)."""
     t = max(max(w.shape[2], w.shape[3]) for _, _, w in classes)
     Cout, Cin = classes[0][2].shape[:2]
-    W = torch.zeros((4, Cout, Cin, t, t), dtype=torch.float32, device=classes[0][2].device)
+    W = torch.zeros((Cout, 4, Cin, t, t), dtype=torch.float32, device=classes[0][2].device)
     for a, b, w in classes:
-        W[2 * a + b, :, :, :w.shape[2], :w.shape[3]] = w
+        W[:, 2 * a + b, :, :w.shape[2], :w.shape[3]] = w
     return W.view(4 * Cout, Cin, t, t).contiguous()
 
 
@@ -436,6 +474,12 @@ def conv_transpose2d_s2(x, classes, scale=None, shift=None, residual=None, relu=
         d.sDm, d.sDn = a, b
         if ta == 1 and tb == 1:
             d.bmode = B_CONV1X1
+        elif ta == 2 and tb == 2:  # the 2x2 window: LDS-staged direct kernel, no tap tables (csrc/conv_direct.hip)
+            d.bmode = B_CONV_K2
+            if PACK_WEIGHTS and w.is_contiguous():
+                pk = packed_conv_weights(w)
+                if pk is not None:
+                    d.A_packed = dptr(pk)
         else:  # taps at input offsets (0..ta-1, 0..tb-1); rows/cols past the edge read as zero
             d.bmode = B_CONV
             koff, kpos = conv_tables(Cin, ta, tb, H, W, 1, x.device)

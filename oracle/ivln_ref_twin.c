@@ -179,9 +179,10 @@ static float b_at(const ivln_gemm_desc *d, int k, int n) {
         }
         case IVLN_B_CONV:
         case IVLN_B_CONV_K3:
-        case IVLN_B_CONV_K7: {
+        case IVLN_B_CONV_K7:
+        case IVLN_B_CONV_K2: {
             int kk = d->K / d->Cin; /* taps per channel */
-            int ks = kk == 9 ? 3 : (kk == 49 ? 7 : 0), kh, kw, ci = k / kk, t = k - ci * kk;
+            int ks = kk == 9 ? 3 : (kk == 49 ? 7 : (kk == 4 ? 2 : 0)), kh, kw, ci = k / kk, t = k - ci * kk;
             if (d->bmode == IVLN_B_CONV) {
                 int32_t pos = d->kpos[k];
                 kh = pos >> 16;
@@ -222,10 +223,10 @@ int ivln_gemm_f32(const ivln_gemm_desc *desc, void *stream) {
                 int ho = pp / d.Wout, wo = pp - ho * d.Wout;
                 addr = (((int64_t)img * d.Ctot + m) * (2 * d.Hout) + 2 * ho + (int)d.sDm) * (2 * d.Wout) + 2 * wo + (int)d.sDn;
             } else if (d.dmode == IVLN_D_NCHW_UP2X4) {
-                int cq = d.M / 4, cls = m / cq, ho = pp / d.Wout, wo = pp - ho * d.Wout;
-                addr = (((int64_t)img * d.Ctot + (m - cls * cq)) * (2 * d.Hout) + 2 * ho + (cls >> 1)) * (2 * d.Wout) + 2 * wo + (cls & 1);
+                int cls = m & 3, ho = pp / d.Wout, wo = pp - ho * d.Wout;
+                addr = (((int64_t)img * d.Ctot + (m >> 2)) * (2 * d.Hout) + 2 * ho + (cls >> 1)) * (2 * d.Wout) + 2 * wo + (cls & 1);
             } else addr = (int64_t)m * d.sDm + (int64_t)n * d.sDn;
-            int me = (d.dmode == IVLN_D_NCHW && d.grp_imgs > 0) ? grp * d.M + m : (d.dmode == IVLN_D_NCHW_UP2X4 ? m % (d.M / 4) : m);
+            int me = (d.dmode == IVLN_D_NCHW && d.grp_imgs > 0) ? grp * d.M + m : (d.dmode == IVLN_D_NCHW_UP2X4 ? m >> 2 : m);
             float v = acc;
             if (d.scale) v = fmaf(v, d.scale[me], d.shift[me]);
             else if (d.shift) v += d.shift[me];

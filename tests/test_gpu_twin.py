@@ -56,6 +56,36 @@ def test_ivln_gemm_f32_device_vs_twin(N, Cin, H, W, Cout, k, s, p, grouped):
     assert err < 3e-5, err  # same fmaf arithmetic, different summation order (MFMA tiles vs a straight k loop)
 
 
+@pytest.mark.parametrize("N,Cin,H,W,Cout,k,narrow", [
+    (2, 64, 32, 32, 32, 3, False),   # 2x2-window direct kernel, 16-byte stores of whole 2x2 output blocks
+    (2, 64, 32, 32, 32, 3, True),    # ... the same launch with the MFMA layout's 4-byte stores
+    (4, 128, 8, 8, 64, 3, False),    # 8x8 class grid: two images per pixel tile, channel chunks split over blockIdx.z
+    (2, 32, 16, 16, 16, 3, False),
+    (1, 24, 6, 10, 8, 3, False),     # Cin % 16 != 0: the implicit GEMM's constant-division gather
+    (2, 16, 5, 7, 8, 3, False),      # odd class-grid width: scalar stores
+    (2, 64, 32, 32, 16, 2, False),   # k=2: a 1x1 GEMM per class, float4-staged kernel + wide stores
+    (2, 64, 32, 32, 16, 2, True),
+    (1, 20, 6, 6, 5, 2, False),
+])
+def test_stacked_transposed_conv_device_vs_twin(N, Cin, H, W, Cout, k, narrow):
+    from ivln_ce_amd._lib import lib, stream_ptr
+
+    c = T.convt_case(N * 5 + Cin + k, N, Cin, H, W, Cout, k)
+    out_h = np.zeros(c["ref"].shape, np.float32)
+    Lt = T.twin()
+    T.check(Lt, Lt.ivln_gemm_f32(C.byref(T.convt_desc(T.hp, c, c["x"], c["w"], out_h, c["scale"], c["shift"],
+                                                     c["residual"])), None), "twin")
+    assert np.allclose(out_h, c["ref"], atol=3e-5, rtol=1e-5)
+    xd, wd, scd, shd, resd = (_dev(c[k_]) for k_ in ("x", "w", "scale", "shift", "residual"))
+    out_d = torch.zeros(c["ref"].shape, device=DEV)
+    dd = T.convt_desc(_dp, c, xd, wd, out_d, scd, shd, resd)
+    dd.no_wide_epilogue = int(narrow)
+    Ld = T._sigs(lib())
+    T.check(Ld, Ld.ivln_gemm_f32(C.byref(dd), stream_ptr()), "device")
+    err = float(np.abs(out_d.cpu().numpy() - out_h).max())
+    assert err < 3e-5, err
+
+
 def test_ivln_groupnorm_f32_device_vs_twin():
     from ivln_ce_amd._lib import lib, stream_ptr
 

@@ -45,6 +45,18 @@ def test_twin_conv_matches_torch(N, Cin, H, W, Cout, k, s, p):
     assert np.allclose(out, ref.numpy(), atol=2e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("N,Cin,H,W,Cout,k", [(2, 6, 5, 4, 3, 3), (1, 4, 3, 6, 5, 2), (2, 3, 4, 5, 2, 3)])
+def test_twin_stacked_transposed_conv_matches_torch(N, Cin, H, W, Cout, k):
+    """RedNet's stride-2 transposed convs (rednet.py:210-216, 262-279) as ONE GEMM over the four output-parity classes:
+    2x2 window (k=3) or 1x1 (k=2) into IVLN_D_NCHW_UP2X4, rows 4*channel + class."""
+    c = T.convt_case(N * 5 + Cin + k, N, Cin, H, W, Cout, k)
+    out = np.zeros(c["ref"].shape, np.float32)
+    d = T.convt_desc(T.hp, c, c["x"], c["w"], out, c["scale"], c["shift"], c["residual"])
+    L = T.twin()
+    T.check(L, L.ivln_gemm_f32(C.byref(d), None), "twin stacked transposed conv")
+    assert np.allclose(out, c["ref"], atol=2e-5, rtol=1e-5)
+
+
 def test_twin_linear_and_image_grouped_conv_match_torch():
     from ivln_ce_amd import ops
 

@@ -77,6 +77,48 @@ def conv_desc(ptr, x, w, out, stride=1, pad=0, scale=None, shift=None, residual=
     return d
 
 
+def convt_case(seed, N, Cin, H, W, Cout, k):
+    """nn.ConvTranspose2d(Cin, Cout, k, stride=2) with output exactly (2H, 2W) (k=3: padding 1, output_padding 1; k=2:
+    padding 0) as ops.conv_transpose2d_s2 launches it: the four output-parity classes stacked into one
+    (4*Cout, Cin, t, t) weight, rows 4*co + cls.  Returns numpy operands and the torch result."""
+    import torch
+    import torch.nn.functional as F
+
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cin, Cout, k, k, generator=g) / (Cin * k * k / 4) ** 0.5
+    sc, sh = 1 + 0.2 * torch.randn(Cout, generator=g), torch.randn(Cout, generator=g)
+    pad, op = (1, 1) if k == 3 else (0, 0)
+    ref = F.conv_transpose2d(x, w, None, stride=2, padding=pad, output_padding=op)
+    res = torch.randn(ref.shape, generator=g)
+    ref = F.relu(ref * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) + res)
+    stacked = ops.convt_s2_stack(ops.convt_s2_classes(w, pad))
+    return {"x": np32(x), "w": np32(stacked), "scale": np32(sc), "shift": np32(sh), "residual": np32(res),
+            "ref": ref.numpy(), "Cout": Cout}
+
+
+def convt_desc(ptr, c, x, w, out, scale, shift, residual):
+    """ivln_gemm_desc of the stacked transposed conv (IVLN_B_CONV_K2 / IVLN_B_CONV1X1 into IVLN_D_NCHW_UP2X4)."""
+    from ivln_ce_amd import ops
+
+    N, Cin, H, W = c["x"].shape
+    t = c["w"].shape[2]
+    d = desc_type()()
+    d.A, d.B, d.D = ptr(w), ptr(x), ptr(out)
+    d.M, d.N, d.K = 4 * c["Cout"], N * H * W, Cin * t * t
+    d.amode, d.dmode = ops.A_MK, ops.D_NCHW_UP2X4
+    d.bmode = ops.B_CONV_K2 if t == 2 else ops.B_CONV1X1
+    d.lda = d.K
+    d.Cin, d.Hin, d.Win, d.Hout, d.Wout = Cin, H, W, H, W
+    d.stride, d.pad, d.dil = 1, 0, 1
+    d.HoWo, d.Ctot = H * W, c["Cout"]
+    d.scale, d.shift, d.residual = ptr(scale), ptr(shift), ptr(residual)
+    d.relu, d.splits = 1, 1
+    return d
+
+
 def check(L, code, what):
     assert code == 0, f"{what}: {L.ivln_strerror(code).decode()} ({code})"
 
