@@ -565,6 +565,8 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
+    if os.environ.get("IVLN_BENCH_STREAM"):  # experiment: the whole bench off HIP's null stream
+        torch.cuda.set_stream(torch.cuda.Stream())
     dev = torch.device("cuda", local_rank)
 
     import __graft_entry__ as ge
@@ -641,8 +643,12 @@ def main():
         # the timed configuration replays RedNet's recorded launch table through ONE C call (ivln_rednet_fwd), which
         # the per-launch event pairs cannot see: the instrumented pass walks the same launches from Python instead
         plan, PredictSemantics.USE_PLAN = PredictSemantics.USE_PLAN, False
+        from ivln_ce_amd import ops
+
         try:
-            with GemmTimer() as gt:
+            # (on a stream that has not launched graphs: eager launches behind graph replays carry extra host time
+            #  per launch, ops.eager_work_stream, which the event pairs would count as kernel time)
+            with ops.eager_work_stream(), GemmTimer() as gt:
                 for i in range(n_inst):
                     torch.cuda._sleep(12_000_000)
                     rollout_step(leg["tr"], policy, leg["obs_dev"][i % leg["n_pool"]], leg["state"])

@@ -93,17 +93,14 @@ __global__ __launch_bounds__(256) void k_conv_direct(const ivln_gemm_desc p, int
                 const int idx = t + i * 256;
                 const int co = idx / KC, kk = idx - co * KC;
                 const bool ok = idx < BM * KC && m0 + co < p.M;
-                const float v = Ag[ok ? (int64_t)(m0 + co) * p.lda + kbase + kk : 0];
-                ra[i] = ok ? v : 0.f;
+                ra[i] = Ag[ok ? (int64_t)(m0 + co) * p.lda + kbase + kk : 0];
             }
         }
         const int cbase = c * CI * HW;
+        // (no select here: the zero of a padding element is chosen in stage(), after the MFMA phase these loads fly
+        //  under - a select next to the load makes hipcc wait for the load before that phase starts)
 #pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const bool ok = poff[i] >= 0;
-            const float v = p.B[ok ? poff[i] + cbase : 0];
-            rp[i] = ok ? v : 0.f;
-        }
+        for (int i = 0; i < NP; ++i) rp[i] = p.B[poff[i] >= 0 ? poff[i] + cbase : 0];
     };
     auto stage = [&]() {
         if constexpr (PACKED) {
@@ -119,13 +116,13 @@ __global__ __launch_bounds__(256) void k_conv_direct(const ivln_gemm_desc p, int
                 const int idx = t + i * 256;
                 const int co = idx / KC, kk = idx - co * KC;
                 const int ci = kk / KK, r = kk - ci * KK;
-                if (idx < BM * KC) As[((((ci >> 1) * KK + r) << 1) + (ci & 1)) * LDA + co] = ra[i];
+                if (idx < BM * KC) As[((((ci >> 1) * KK + r) << 1) + (ci & 1)) * LDA + co] = m0 + co < p.M ? ra[i] : 0.f;
             }
         }
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int idx = t + i * 256;
-            if (idx < PATCH) Ps[idx] = rp[i];
+            if (idx < PATCH) Ps[idx] = poff[i] >= 0 ? rp[i] : 0.f;
         }
     };
 
@@ -294,9 +291,15 @@ __global__ __launch_bounds__(256) void k_wgrad_direct(const ivln_gemm_desc p, in
     const int t_end = min(ntiles, t_beg + tiles_per_split);
 
     float ra[NA], rp[NP];
+    // validity of what the last load_tile fetched, one bit per load: the loads are unconditional from clamped addresses
+    // and the zero of an out-of-range element is chosen in stage(), after the MFMA phase the loads fly under (a select
+    // next to the load makes hipcc wait for the load before that phase starts)
+    uint32_t oka = 0, okp = 0;
+    static_assert((VEC ? NA / 4 : NA) <= 32 && NP <= 32, "validity masks are 32 bits");
     auto load_tile = [&](int tile) {
         const int tw = tile % tiles_w, th = (tile / tiles_w) % tiles_h, ig = tile / (tiles_w * tiles_h);
         const int img0 = ig * IMGS, ho0 = th * PTH, wo0 = tw * PTW;
+        oka = 0, okp = 0;
         if constexpr (VEC) {
 #pragma unroll
             for (int i = 0; i < NA / 4; ++i) {
@@ -307,8 +310,8 @@ __global__ __launch_bounds__(256) void k_wgrad_direct(const ivln_gemm_desc p, in
                 const bool ok = m0 + co < p.M && img < nimg && ho < p.Hout && wo < p.Wout;
                 const float4 v = *reinterpret_cast<const float4*>(
                     p.A + (ok ? ((int64_t)img * p.M + m0 + co) * p.HoWo + ho * p.Wout + wo : 0));
-                ra[4 * i] = ok ? v.x : 0.f, ra[4 * i + 1] = ok ? v.y : 0.f;
-                ra[4 * i + 2] = ok ? v.z : 0.f, ra[4 * i + 3] = ok ? v.w : 0.f;
+                ra[4 * i] = v.x, ra[4 * i + 1] = v.y, ra[4 * i + 2] = v.z, ra[4 * i + 3] = v.w;
+                oka |= (uint32_t)ok << i;
             }
         } else {
 #pragma unroll
@@ -318,8 +321,8 @@ __global__ __launch_bounds__(256) void k_wgrad_direct(const ivln_gemm_desc p, in
                 const int il = px / (PTH * PTW), ph = (px / PTW) % PTH, pw = px % PTW;
                 const int img = img0 + il, ho = ho0 + ph, wo = wo0 + pw;
                 const bool ok = m0 + co < p.M && img < nimg && ho < p.Hout && wo < p.Wout;
-                const float v = p.A[ok ? ((int64_t)img * p.M + m0 + co) * p.HoWo + ho * p.Wout + wo : 0];
-                ra[i] = ok ? v : 0.f;
+                ra[i] = p.A[ok ? ((int64_t)img * p.M + m0 + co) * p.HoWo + ho * p.Wout + wo : 0];
+                oka |= (uint32_t)ok << i;
             }
         }
 #pragma unroll
@@ -331,8 +334,8 @@ __global__ __launch_bounds__(256) void k_wgrad_direct(const ivln_gemm_desc p, in
             const int img = img0 + il, ci = c_lo + cl, hi = ho0 - p.pad + y, wi = wo0 - p.pad + x;
             const bool ok = idx < PATCH && img < nimg && ci < p.Cin && (unsigned)hi < (unsigned)p.Hin &&
                             (unsigned)wi < (unsigned)p.Win;
-            const float v = p.B[ok ? (int64_t)img * p.in_img_stride + (int64_t)ci * HW + hi * p.Win + wi : 0];
-            rp[i] = ok ? v : 0.f;
+            rp[i] = p.B[ok ? (int64_t)img * p.in_img_stride + (int64_t)ci * HW + hi * p.Win + wi : 0];
+            okp |= (uint32_t)ok << i;
         }
     };
     auto stage = [&]() {
@@ -341,21 +344,22 @@ __global__ __launch_bounds__(256) void k_wgrad_direct(const ivln_gemm_desc p, in
             for (int i = 0; i < NA / 4; ++i) {
                 const int f = t + i * 256;
                 const int co = (f >> 3) % BM, px = ((f & 7) + 8 * (f / (8 * BM))) * 4;
+                const bool ok = (oka >> i) & 1;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) Ds[co * LDP + px + k] = ra[4 * i + k];
+                for (int k = 0; k < 4; ++k) Ds[co * LDP + px + k] = ok ? ra[4 * i + k] : 0.f;
             }
         } else {
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 const int idx = t + i * 256;
                 const int co = idx / NPX, px = idx - co * NPX;
-                Ds[px * LDA + co] = ra[i];
+                Ds[px * LDA + co] = (oka >> i) & 1 ? ra[i] : 0.f;
             }
         }
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int idx = t + i * 256;
-            if (idx < PATCH) Ps[idx] = rp[i];
+            if (idx < PATCH) Ps[idx] = (okp >> i) & 1 ? rp[i] : 0.f;
         }
     };
 

@@ -88,12 +88,17 @@ __global__ __launch_bounds__(256) void k_gemm(const ivln_gemm_desc p) {
     }
 
     float ra0[EA], rb0[EB], ra1[EA], rb1[EB];
+    uint32_t ma0 = 0, mb0 = 0, ma1 = 0, mb1 = 0;  // validity of each loaded element (bit e), applied by stage()
+    static_assert(EA <= 32 && EB <= 32, "validity masks are 32 bits");
     const float* __restrict__ Ag = p.A + (int64_t)tile_group(p, n0) * p.a_grp_stride;  // this tile's weight set
 
     // Branch-free tile loads: every lane ALWAYS issues its load from a clamped (valid) address and the
-    // out-of-range / padding case is a select afterwards.  With the loads unconditional hipcc can count
-    // them and emits partial s_waitcnt vmcnt(N) for the older register set instead of vmcnt(0).
-    auto load_tile = [&](int k0, float (&ra)[EA], float (&rb)[EB]) {
+    // out-of-range / padding case is a select - made in stage(), two compute phases later, from a validity bit
+    // kept per element.  With the loads unconditional hipcc can count them and emits partial s_waitcnt vmcnt(N)
+    // for the older register set instead of vmcnt(0); with no instruction that depends on the loaded value before
+    // stage() it does not park a wait in front of the MFMA phase the loads are meant to fly under.
+    auto load_tile = [&](int k0, float (&ra)[EA], float (&rb)[EB], uint32_t& ma, uint32_t& mb) {
+        ma = 0, mb = 0;
         // ---------------- A ----------------
         if constexpr (AMODE == AMODE_MK) {
             const int k = k0 + a_k;
@@ -103,7 +108,7 @@ __global__ __launch_bounds__(256) void k_gemm(const ivln_gemm_desc p) {
                 const int m = m0 + a_m + e * A_STEP;
                 const bool ok = kok && m < p.M;
                 const float v = Ag[ok ? (int64_t)m * p.lda + k : 0];
-                ra[e] = ok ? v : 0.f;
+                ra[e] = v, ma |= (uint32_t)ok << e;
             }
         } else if constexpr (AMODE == AMODE_KM) {
             const int m = m0 + a_m;
@@ -112,7 +117,7 @@ __global__ __launch_bounds__(256) void k_gemm(const ivln_gemm_desc p) {
                 const int k = k0 + a_k + e * A_STEP;
                 const bool ok = m < p.M && k < kend;
                 const float v = p.A[ok ? (int64_t)k * p.lda + m : 0];
-                ra[e] = ok ? v : 0.f;
+                ra[e] = v, ma |= (uint32_t)ok << e;
             }
         } else {  // AMODE_NCHW_P: A[m = channel][k = pixel] of an NCHW gradient tensor
             const int k = k0 + a_k;
@@ -125,7 +130,7 @@ __global__ __launch_bounds__(256) void k_gemm(const ivln_gemm_desc p) {
                 const int m = m0 + a_m + e * A_STEP;
                 const bool ok = kok && m < p.M;
                 const float v = p.A[ok ? ((int64_t)img * p.M + m) * p.HoWo + pp : 0];
-                ra[e] = ok ? v : 0.f;
+                ra[e] = v, ma |= (uint32_t)ok << e;
             }
         }
         // ---------------- B ----------------
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(256) void k_gemm(const ivln_gemm_desc p) {
                 const int hi = hi0 + (kp >> 16) * p.dil, wi = wi0 + (kp & 0xFFFF) * p.dil;
                 const bool ok = kok && (unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win;
                 const float v = p.B[ok ? pix_base + p.koff[kc] + (int64_t)hi0 * p.Win + wi0 : 0];
-                rb[e] = ok ? v : 0.f;
+                rb[e] = v, mb |= (uint32_t)ok << e;
             }
         } else if constexpr (conv_ks(BMODE) != 0) {
             // (ci,kh,kw) from constant divisions: no dependent table load on the per-tile critical path
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(256) void k_gemm(const ivln_gemm_desc p) {
                 const int hi = hi0 + kh, wi = wi0 + kw;
                 const bool ok = n_ok && k < kend && (unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win;
                 const float v = p.B[ok ? pix_base + (int64_t)ci * HWin + (int64_t)hi * p.Win + wi : 0];
-                rb[e] = ok ? v : 0.f;
+                rb[e] = v, mb |= (uint32_t)ok << e;
             }
         } else if constexpr (BMODE == BMODE_CONV1X1) {
             const int64_t HWin = (int64_t)p.Hin * p.Win;
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(256) void k_gemm(const ivln_gemm_desc p) {
                 const int k = k0 + b_k + e * B_STEP;
                 const bool ok = n_ok && k < kend;
                 const float v = p.B[ok ? pbase + (int64_t)k * HWin : 0];
-                rb[e] = ok ? v : 0.f;
+                rb[e] = v, mb |= (uint32_t)ok << e;
             }
         } else if constexpr (BMODE == BMODE_CONVT) {
             // y[oh] += x[(oh + pad - kh)/stride] * w[kh] when divisible (nn.ConvTranspose2d)
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(256) void k_gemm(const ivln_gemm_desc p) {
                 const bool ok = kok && th >= 0 && tw >= 0 && hi * p.stride == th && wi * p.stride == tw &&
                                 hi < p.Hin && wi < p.Win;
                 const float v = p.B[ok ? pix_base + p.koff[kc] + (int64_t)hi * p.Win + wi : 0];
-                rb[e] = ok ? v : 0.f;
+                rb[e] = v, mb |= (uint32_t)ok << e;
             }
         } else if constexpr (BMODE == BMODE_KN) {
             const int n = n0 + b_n;
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(256) void k_gemm(const ivln_gemm_desc p) {
                 const int k = k0 + b_k + e * B_STEP;
                 const bool ok = n < p.N && k < kend;
                 const float v = p.B[ok ? (int64_t)k * p.ldb + n : 0];
-                rb[e] = ok ? v : 0.f;
+                rb[e] = v, mb |= (uint32_t)ok << e;
             }
         } else if constexpr (BMODE == BMODE_NK) {
             const int k = k0 + b_k;
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(256) void k_gemm(const ivln_gemm_desc p) {
                 const int n = n0 + b_n + e * B_STEP;
                 const bool ok = kok && n < p.N;
                 const float v = p.B[ok ? (int64_t)n * p.ldb + k : 0];
-                rb[e] = ok ? v : 0.f;
+                rb[e] = v, mb |= (uint32_t)ok << e;
             }
         } else {  // BMODE_IM2COL_T: B[k = output pixel][n = (ci,kh,kw)] gathered from the NCHW input
             const int k = k0 + b_k;
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(256) void k_gemm(const ivln_gemm_desc p) {
                 const int hi = h0 + (w_kpos[e] >> 16), wi = w0 + (w_kpos[e] & 0xFFFF);
                 const bool ok = kok && w_kpos[e] >= 0 && (unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win;
                 const float v = p.B[ok ? base + w_koff[e] : 0];
-                rb[e] = ok ? v : 0.f;
+                rb[e] = v, mb |= (uint32_t)ok << e;
             }
         }
     };
@@ -230,16 +235,18 @@ __global__ __launch_bounds__(256) void k_gemm(const ivln_gemm_desc p) {
     // that the sets swap roles without register copies: a copy (ra0 = ra1) made hipcc wait vmcnt(0) at
     // the loop top, i.e. the loads issued one iteration earlier had only ONE MFMA phase (~512 cycles) to
     // land and every tile stalled on L2/MALL latency (MFMA pipe 47 % busy on a 1024x4096x1024 GEMM).
-    auto stage = [&](float (&ra)[EA], float (&rb)[EB]) {
+    auto stage = [&](float (&ra)[EA], float (&rb)[EB], uint32_t ma, uint32_t mb) {
 #pragma unroll
         for (int e = 0; e < EA; ++e) {
-            if constexpr (A_KFAST) As[a_k * LDA_S + a_m + e * A_STEP] = ra[e];
-            else As[(a_k + e * A_STEP) * LDA_S + a_m] = ra[e];
+            const float v = (ma >> e) & 1 ? ra[e] : 0.f;
+            if constexpr (A_KFAST) As[a_k * LDA_S + a_m + e * A_STEP] = v;
+            else As[(a_k + e * A_STEP) * LDA_S + a_m] = v;
         }
 #pragma unroll
         for (int e = 0; e < EB; ++e) {
-            if constexpr (B_KFAST) Bs[b_k * LDB_S + b_n + e * B_STEP] = rb[e];
-            else Bs[(b_k + e * B_STEP) * LDB_S + b_n] = rb[e];
+            const float v = (mb >> e) & 1 ? rb[e] : 0.f;
+            if constexpr (B_KFAST) Bs[b_k * LDB_S + b_n + e * B_STEP] = v;
+            else Bs[(b_k + e * B_STEP) * LDB_S + b_n] = v;
         }
     };
     auto compute = [&]() {
@@ -260,18 +267,18 @@ __global__ __launch_bounds__(256) void k_gemm(const ivln_gemm_desc p) {
         }
     };
     if (kbeg < kend) {
-        load_tile(kbeg, ra0, rb0);
-        load_tile(kbeg + BK, ra1, rb1);  // past-the-end tiles load clamped addresses and select zeros
+        load_tile(kbeg, ra0, rb0, ma0, mb0);
+        load_tile(kbeg + BK, ra1, rb1, ma1, mb1);  // past-the-end tiles load clamped addresses and select zeros
         for (int k0 = kbeg; k0 < kend; k0 += 2 * BK) {
-            stage(ra0, rb0);
+            stage(ra0, rb0, ma0, mb0);
             __syncthreads();
-            load_tile(k0 + 2 * BK, ra0, rb0);
+            load_tile(k0 + 2 * BK, ra0, rb0, ma0, mb0);
             compute();
             __syncthreads();
             if (k0 + BK >= kend) break;
-            stage(ra1, rb1);
+            stage(ra1, rb1, ma1, mb1);
             __syncthreads();
-            load_tile(k0 + 3 * BK, ra1, rb1);
+            load_tile(k0 + 3 * BK, ra1, rb1, ma1, mb1);
             compute();
             __syncthreads();
         }

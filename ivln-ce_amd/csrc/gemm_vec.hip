@@ -97,31 +97,37 @@ __global__ __launch_bounds__(256, 2) void k_gemm_vec(const ivln_gemm_desc p) {
     const int64_t b_kstep = BLAY == LAY_K ? 1 : brow;
 
     float4 ra0[EA], rb0[EB], ra1[EA], rb1[EB];
-    // (component-wise selects: `ok ? v : zero4` on float4 lvalues became a pointer select through scratch)
+    // Tile loads are unconditional from a clamped (valid) address and carry NO dependent instruction: the zero for
+    // an out-of-range row / k is selected when the registers are staged, two compute phases later.  (With the select
+    // next to the load hipcc parks an s_waitcnt vmcnt(0) in front of the MFMA phase that follows - every tile then
+    // waits out the full latency of the loads it has just issued.)
     auto load_tile = [&](int k0, float4 (&ra)[EA], float4 (&rb)[EB]) {
 #pragma unroll
         for (int e = 0; e < EA; ++e) {
             const bool ok = a_ok[e] && k0 + a_k[e] < kend;
-            const float4 v = *reinterpret_cast<const float4*>(Ag + (ok ? a_off[e] + (int64_t)k0 * a_kstep : 0));
-            ra[e] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+            ra[e] = *reinterpret_cast<const float4*>(Ag + (ok ? a_off[e] + (int64_t)k0 * a_kstep : 0));
         }
 #pragma unroll
         for (int e = 0; e < EB; ++e) {
             const bool ok = b_ok[e] && k0 + b_k[e] < kend;
-            const float4 v = *reinterpret_cast<const float4*>(p.B + (ok ? b_off[e] + (int64_t)k0 * b_kstep : 0));
-            rb[e] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+            rb[e] = *reinterpret_cast<const float4*>(p.B + (ok ? b_off[e] + (int64_t)k0 * b_kstep : 0));
         }
     };
-    auto stage = [&](float4 (&ra)[EA], float4 (&rb)[EB]) {
+    // (component-wise selects: `ok ? v : zero4` on float4 lvalues became a pointer select through scratch)
+    auto stage = [&](int k0, float4 (&ra)[EA], float4 (&rb)[EB]) {
 #pragma unroll
         for (int e = 0; e < EA; ++e) {
-            if constexpr (ALAY == LAY_K) *reinterpret_cast<float4*>(&As[((t >> 3) + 32 * e) * LDK + (t & 7) * 4]) = ra[e];
-            else *reinterpret_cast<float4*>(&As[(t / AR4 + (256 / AR4) * e) * BM + (t % AR4) * 4]) = ra[e];
+            const bool ok = a_ok[e] && k0 + a_k[e] < kend;
+            const float4 v = make_float4(ok ? ra[e].x : 0.f, ok ? ra[e].y : 0.f, ok ? ra[e].z : 0.f, ok ? ra[e].w : 0.f);
+            if constexpr (ALAY == LAY_K) *reinterpret_cast<float4*>(&As[((t >> 3) + 32 * e) * LDK + (t & 7) * 4]) = v;
+            else *reinterpret_cast<float4*>(&As[(t / AR4 + (256 / AR4) * e) * BM + (t % AR4) * 4]) = v;
         }
 #pragma unroll
         for (int e = 0; e < EB; ++e) {
-            if constexpr (BLAY == LAY_K) *reinterpret_cast<float4*>(&Bs[((t >> 3) + 32 * e) * LDK + (t & 7) * 4]) = rb[e];
-            else *reinterpret_cast<float4*>(&Bs[(t / BR4 + (256 / BR4) * e) * BN + (t % BR4) * 4]) = rb[e];
+            const bool ok = b_ok[e] && k0 + b_k[e] < kend;
+            const float4 v = make_float4(ok ? rb[e].x : 0.f, ok ? rb[e].y : 0.f, ok ? rb[e].z : 0.f, ok ? rb[e].w : 0.f);
+            if constexpr (BLAY == LAY_K) *reinterpret_cast<float4*>(&Bs[((t >> 3) + 32 * e) * LDK + (t & 7) * 4]) = v;
+            else *reinterpret_cast<float4*>(&Bs[(t / BR4 + (256 / BR4) * e) * BN + (t % BR4) * 4]) = v;
         }
     };
 
@@ -181,13 +187,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_vec(const ivln_gemm_desc p) {
         load_tile(kbeg, ra0, rb0);
         load_tile(kbeg + BKV, ra1, rb1);
         for (int k0 = kbeg; k0 < kend; k0 += 2 * BKV) {
-            stage(ra0, rb0);
+            stage(k0, ra0, rb0);
             __syncthreads();
             load_tile(k0 + 2 * BKV, ra0, rb0);
             compute();
             __syncthreads();
             if (k0 + BKV >= kend) break;
-            stage(ra1, rb1);
+            stage(k0 + BKV, ra1, rb1);
             __syncthreads();
             load_tile(k0 + 3 * BKV, ra1, rb1);
             compute();

@@ -206,32 +206,31 @@ def gemm(desc: GemmDesc):
 
 
 _WORK_STREAMS = {}
-OFF_NULL_STREAM = os.environ.get("IVLN_OFF_NULL_STREAM", "1") != "0"
+EAGER_WORK_STREAM = os.environ.get("IVLN_EAGER_WORK_STREAM", "1") != "0"
 
 
 @contextlib.contextmanager
-def off_null_stream(device=None):
-    """Run an eager many-launch region on a dedicated non-blocking stream when the caller is on the NULL stream.
-    HIP's null stream orders itself against every other blocking stream of the device, and the runtime pays for
-    that on each launch once the process has used side streams or replayed graphs: the same DAgger update measured
-    13.6 ms per step in a fresh process and 17.5 ms after a graph-replayed collection (about 2 us more on each of
-    its ~2000 launches), 14.1 ms on a non-null stream (profiles/README.md, round 3).  The region is ordered behind
-    the caller's stream on entry and the caller's stream behind it on exit, so surrounding code sees no difference;
-    a caller already on a stream of its own is left alone."""
-    if not OFF_NULL_STREAM or not torch.cuda.is_available():
+def eager_work_stream(device=None):
+    """Run an eager many-launch region on a dedicated stream that never launches hipGraphs.  Measured on MI355X /
+    ROCm 7.2 (profiles/README.md, round 3): the same DAgger update takes 13.6 ms per step in a fresh process and 17.5 ms
+    once the stream it runs on has replayed the rollout step's graphs - about 2 us more of host time on each of its
+    ~2000 launches, with identical kernel time - whether that stream is the null stream or a stream of the caller's;
+    on a stream of its own it is back at 13.8 ms.  The region is ordered behind the caller's stream on entry and the
+    caller's stream behind it on exit, so surrounding code sees no difference."""
+    if not EAGER_WORK_STREAM or not torch.cuda.is_available():
         yield
         return
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    if dev.type != "cuda":
-        yield
-        return
-    cur = torch.cuda.current_stream(dev)
-    if cur != torch.cuda.default_stream(dev) or torch.cuda.is_current_stream_capturing():
+    if dev.type != "cuda" or torch.cuda.is_current_stream_capturing():
         yield
         return
     work = _WORK_STREAMS.get(dev.index)
     if work is None:
         work = _WORK_STREAMS[dev.index] = torch.cuda.Stream(dev)
+    cur = torch.cuda.current_stream(dev)
+    if cur == work:
+        yield
+        return
     work.wait_stream(cur)
     try:
         with torch.cuda.stream(work):

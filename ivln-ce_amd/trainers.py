@@ -167,7 +167,7 @@ def update_agent(policy, optimizer: FlatAdam, observations, prev_actions, not_do
     reference (loss, action_loss, aux_loss).  With `rnn_states` (IterativeDaggerTrainer._update_agent,
     iterative_dagger_trainer.py:33-94) the recurrent state carried from the previous batch of the same tours
     seeds the forward (no gradient through it) and the new state is returned as a fourth value."""
-    with ops.off_null_stream(corrected_actions.device):  # ~2000 eager launches: not on HIP's null stream (ops.py)
+    with ops.eager_work_stream(corrected_actions.device):  # ~2000 eager launches: on a stream without graph launches
         return _update_agent(policy, optimizer, observations, prev_actions, not_done_masks, corrected_actions, weights,
                              hidden_size, step_grad, loss_accumulation_scalar, world, tour_not_done_masks, rnn_states)
 
