@@ -24,8 +24,11 @@ namespace {
 // PACKED: the weights arrive pre-arranged by ivln_conv_pack_weights_f32 - per (64- or 32-channel block, chunk)
 // the exact LDS image [k slot order][BM + 4] - so staging the weight slice is a linear copy of float4s
 // (7 loads + 7 ds_write_b128 per thread instead of 25 scalar loads with their address arithmetic).
+// (launch bounds: the packed 3x3 / 2x2 variants are held to 128 registers - 94 used, accumulators in VGPRs - so that a
+//  SIMD keeps four or five waves instead of three: RedNet's 64-channel 128x128 convs launch 1024 blocks, exactly four
+//  per CU, which at three resident blocks ran a second, quarter-full round)
 template <int KS, int PTW, int PTH, int IMGS, int WM, bool PACKED>
-__global__ __launch_bounds__(256) void k_conv_direct(const ivln_gemm_desc p, int tiles_w, int tiles_h, int nimg,
+__global__ __launch_bounds__(256, (PACKED && KS != 7) ? 4 : 1) void k_conv_direct(const ivln_gemm_desc p, int tiles_w, int tiles_h, int nimg,
                                                      int chunks_per_split) {
     constexpr int CI = conv_direct_ci(KS);  // input channels per chunk (even: channel pairs fill the k slots)
     constexpr int KK = KS * KS;
