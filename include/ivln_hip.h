@@ -64,6 +64,13 @@ int ivln_mapper_step(ivln_mapper* m, const float* depth, const uint8_t* labels, 
                      const float* pose, const float* rot, const uint8_t* not_done, int B,
                      uint8_t* occ_out, uint8_t* sem_out, void* stream);
 
+/* The same step from the sensor pose itself: ivln_mapper_frames + ivln_mapper_step in six launches instead of seven
+ * (the transforms are derived inside the first kernel).  pose f32 (B,3), orientation f64 (B,2) [elevation, heading] (mapper.py:132-138, obs_transforms.py:79-103);
+ * T_out f32 (B,4,4) and rot_out f32 (B,3,3) receive what ivln_mapper_frames would have produced (bit-identical). */
+int ivln_mapper_step_posed(ivln_mapper* m, const float* depth, const uint8_t* labels, const float* pose,
+                           const double* orientation, const uint8_t* not_done, int B, uint8_t* occ_out,
+                           uint8_t* sem_out, float* T_out, float* rot_out, void* stream);
+
 /* Known-map mode (mapper.py:851-881): begin = clear finished/paused envs; load = append the
  * pre-built cloud of env b (xyz f32 (n,3), sem u8 (n), device); raster = maps from the cloud. */
 int ivln_mapper_known_begin(ivln_mapper* m, const uint8_t* not_done, int B, void* stream);

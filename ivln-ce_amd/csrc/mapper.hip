@@ -31,6 +31,7 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kPPT = 4;                       // pixels per thread in the local-cloud kernels
 constexpr uint32_t kLocalRankBit = 1u << 31;  // rank of a point that entered the cloud this step = bit | local key
+constexpr int kFrameEnvs = 64;                // envs a workgroup derives camera transforms for (B_max <= 64)
 
 struct Scalars {       // device-side scalars of one mapper
     int mmL[4];        // local cloud: rmin, cmin, rmax, cmax   (published by k_local_argmax)
@@ -152,6 +153,25 @@ __device__ __forceinline__ int64_t make_key(int b, int r, int c, const int* mm) 
     return (int64_t)b * (R * C) + (int64_t)(r - mm[0]) * C + (int64_t)(c - mm[1]);  // mapper.py:469
 }
 
+// Slot of a key in the dense arg-max table.  The KEY (above) is the reference's flattened cell number - with its
+// multipliers rows.max() / cols.max() (not max + 1: cell (r, C) and cell (r + 1, 0) share a key, quirk Q2) - and it is
+// the rank that orders the cloud and breaks ties: it stays what it was.  The table SLOT only has to be a bijection of
+// the key, and slot = key makes every probe of a point whose neighbours in the cloud differ in r a separate 64-byte
+// line (consecutive points come from consecutive pixels: a wall runs along r as often as along c).  Slots therefore
+// tile the key plane (q = key / C, kc = key % C) 4 x 4 = 16 slots = 128 bytes, so that neighbours in either direction
+// share lines (counted HBM bytes of the mapper: profiles/README.md, round 3).  -1: outside the table
+// (IVLN_E_KEYSPACE; keys are ranks as well and must fit the same 31 bits).
+__device__ __forceinline__ int64_t table_slot(int b, int r, int c, const int* mm, int64_t table_cells) {
+    const int64_t key = make_key(b, r, c, mm);
+    if (key < 0 || key >= table_cells) return -1;
+    const int64_t C = (int64_t)mm[3] - mm[1];
+    if (C <= 0) return key;  // (one column of cells: every key is a row number already)
+    const uint32_t q = (uint32_t)key / (uint32_t)C, kc = (uint32_t)key - q * (uint32_t)C;
+    const int64_t Ct = (C + 3) >> 2;
+    const int64_t slot = ((((int64_t)(q >> 2)) * Ct + (kc >> 2)) << 4) | ((q & 3) << 2) | (kc & 3);
+    return slot < table_cells ? slot : -1;
+}
+
 // Unproject + filter one pixel (GenerateSemanticPointCloud.forward, mapper.py:387-425; core.py:137-171).  The three
 // local-cloud kernels each RE-DERIVE the point from the depth value (a dozen flops) instead of passing a float4
 // record per pixel between them: 4 bytes read per pixel and kernel instead of 16 written + 2 x 16 read.
@@ -185,9 +205,45 @@ __device__ __forceinline__ bool unproject(const Cam& cm, int64_t pix, float (&w)
     return true;
 }
 
-// ---- A: local min/max of the cell indices; zero the occupancy output ----
-__global__ __launch_bounds__(kThreads) void k_local_minmax(const Cam cm, uint8_t* __restrict__ occ, int map_cells,
-                                                           int* __restrict__ bmmL) {
+// Camera-to-world transform of env b (core.py:20-36 with elevation + pi, mapper.py:135): fp64 sin / cos, rounded to fp32.
+__device__ __forceinline__ void frame_T(const float* __restrict__ pose, const double* __restrict__ orient, int b, float* t) {
+    const double elev = orient[2 * b + 0] + 3.141592653589793;
+    const double head = orient[2 * b + 1];
+    const double cx = cos(elev), sx = sin(elev), cy = cos(head), sy = sin(head);
+    t[0] = (float)cy;    t[1] = (float)(sx * sy); t[2] = (float)(cx * sy);  t[3] = pose[3 * b + 0];
+    t[4] = 0.f;          t[5] = (float)cx;        t[6] = (float)(-sx);      t[7] = pose[3 * b + 1];
+    t[8] = (float)(-sy); t[9] = (float)(cy * sx); t[10] = (float)(cy * cx); t[11] = pose[3 * b + 2];
+    t[12] = 0.f; t[13] = 0.f; t[14] = 0.f; t[15] = 1.f;
+}
+// mapper.py:266 rotate_around_y(-origin.heading)
+__device__ __forceinline__ void frame_rot(const double* __restrict__ orient, int b, float* r) {
+    const double a = -orient[2 * b + 1];
+    r[0] = (float)cos(a);    r[1] = 0.f; r[2] = (float)sin(a);
+    r[3] = 0.f;              r[4] = 1.f; r[5] = 0.f;
+    r[6] = (float)(-sin(a)); r[7] = 0.f; r[8] = (float)cos(a);
+}
+
+// ---- A: local min/max of the cell indices; zero the occupancy output.  FRAMES: the step was given (pose,
+// orientation) instead of ready transforms - every workgroup derives the B camera transforms it unprojects with into
+// LDS (B <= 64 threads, a few fp64 sin / cos each) and workgroup 0 also leaves T and rot in global memory for the
+// kernels behind it: the former k_frames launch in front of the step is gone. ----
+template <bool FRAMES>
+__global__ __launch_bounds__(kThreads) void k_local_minmax(Cam cm, uint8_t* __restrict__ occ, int map_cells,
+                                                           int* __restrict__ bmmL, const double* __restrict__ orient,
+                                                           float* __restrict__ T_out, float* __restrict__ rot_out) {
+    if constexpr (FRAMES) {
+        __shared__ float Ts[kFrameEnvs * 16];
+        if ((int)threadIdx.x < cm.B) {
+            frame_T(cm.pose, orient, threadIdx.x, Ts + 16 * threadIdx.x);
+            if (blockIdx.x == 0) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) T_out[16 * threadIdx.x + k] = Ts[16 * threadIdx.x + k];
+                frame_rot(orient, threadIdx.x, rot_out + 9 * threadIdx.x);
+            }
+        }
+        __syncthreads();
+        cm.T = Ts;
+    }
     const int64_t total = (int64_t)cm.B * cm.H * cm.W;
     int rmin = INT32_MAX, cmin = INT32_MAX, rmax = INT32_MIN, cmax = INT32_MIN;
     const int64_t nchunks = (total + kThreads * kPPT - 1) / (kThreads * kPPT);
@@ -241,14 +297,14 @@ __global__ __launch_bounds__(kThreads) void k_local_argmax(const Cam cm, Scalars
             float w[3];
             int b, r, c;
             if (pix < total && unproject(cm, pix, w, b, r, c)) {
-                const int64_t key = make_key(b, r, c, mm);
-                if (key < 0 || key >= table_cells) {
+                const int64_t slot = table_slot(b, r, c, mm, table_cells);
+                if (slot < 0) {
                     sc->err = IVLN_E_KEYSPACE;
                     continue;
                 }
                 const unsigned long long packed =
                     ((unsigned long long)ord_f32(w[1]) << 32) | (0xFFFFFFFFull - (unsigned long long)pix);
-                atomicMax(&tab64[key], packed);
+                atomicMax(&tab64[slot], packed);
             }
         }
     }
@@ -271,18 +327,19 @@ __global__ __launch_bounds__(kThreads) void k_local_select(const Cam cm, const u
         const int64_t pix = (chunk * kPPT + i) * kThreads + threadIdx.x;
         float w[3] = {0.f, 0.f, 0.f};
         int b = 0, r = 0, c = 0;
-        int64_t key = 0;
+        int64_t key = 0, tslot = -1;
         bool win = false;
         if (pix < total && unproject(cm, pix, w, b, r, c)) {
             key = make_key(b, r, c, sc->mmL);
-            if (key >= 0 && key < table_cells) {
+            tslot = table_slot(b, r, c, sc->mmL, table_cells);
+            if (tslot >= 0) {
                 const unsigned long long packed =
                     ((unsigned long long)ord_f32(w[1]) << 32) | (0xFFFFFFFFull - (unsigned long long)pix);
-                win = (tab64[key] == packed);
+                win = (tab64[tslot] == packed);
             }
         }
         const unsigned slot = wave_append(win, &sc->cnt[cur], capacity, &sc->err);
-        if (win) tab64[key] = 0ull;  // leave the table clean for the world phase
+        if (win) tab64[tslot] = 0ull;  // leave the table clean for the world phase
         if (win && slot != 0xFFFFFFFFu) {
             Pt q;
             q.x = w[0]; q.y = w[1]; q.z = w[2];
@@ -331,13 +388,13 @@ __global__ __launch_bounds__(kThreads) void k_world_max(const Pt* __restrict__ w
     for (unsigned i = blockIdx.x * kThreads + threadIdx.x; i < n; i += nbw * kThreads) {
         const Pt p = wsrc[i];
         if (!world_alive(p, i, cnt_old, B, not_done)) continue;
-        const int64_t key = make_key((int)(p.meta >> 8), cell_index(p.z, half_res), cell_index(p.x, half_res), mm);
-        if (key < 0 || key >= table_cells) {
+        const int64_t slot = table_slot((int)(p.meta >> 8), cell_index(p.z, half_res), cell_index(p.x, half_res), mm, table_cells);
+        if (slot < 0) {
             sc->err = IVLN_E_KEYSPACE;
             continue;
         }
         const unsigned long long packed = ((unsigned long long)ord_f32(p.y) << 32) | (unsigned long long)(~(uint32_t)rsrc[i]);
-        atomicMax(&tab64[key], packed);
+        atomicMax(&tab64[slot], packed);
     }
 }
 
@@ -367,7 +424,24 @@ __device__ __forceinline__ void raster_point(const Pt& p, uint64_t rank, const f
     }
 }
 
-// ---- E: world survivors -> the other buffer + raster + per-env bounding boxes for the next step ----
+__device__ __forceinline__ void finalize_scalars(Scalars* sc, int swap, unsigned capacity, int n_bbox, int n_bbox_envs) {
+    if (swap) {
+        const int cur = sc->cur;
+        sc->cnt[cur ^ 1] = min(sc->cnt[cur ^ 1], capacity);
+        sc->cnt[cur] = 0;
+        sc->cur = cur ^ 1;
+        sc->n_bbox = n_bbox;
+        sc->n_bbox_envs = n_bbox_envs;
+    }
+    sc->mmL[0] = sc->mmL[1] = sc->mmW[0] = sc->mmW[1] = sc->mmWold[0] = sc->mmWold[1] = INT32_MAX;
+    sc->mmL[2] = sc->mmL[3] = sc->mmW[2] = sc->mmW[3] = sc->mmWold[2] = sc->mmWold[3] = INT32_MIN;
+    sc->cnt_old = 0;
+}
+
+// ---- E: world survivors -> the other buffer + raster + per-env bounding boxes for the next step.
+// (Folding F into this kernel - the last workgroup to finish converts the cells - was built and measured in round 3:
+//  the release fence every one of the 1024 workgroups then needs in front of its ticket, an L2 write-back each, took
+//  the kernel from 48 us to 123 us (69 us on an empty cloud); a launch of its own costs F 4.8 us.  profiles/README.md) ----
 constexpr int kBoxEnvs = 64;  // envs whose box a block tracks in LDS (B_max <= 64)
 __global__ __launch_bounds__(kThreads) void k_world_select(
     Pt* w0, Pt* w1, int64_t* r0, int64_t* r1, int B, const uint8_t* __restrict__ not_done, float half_res, Scalars* sc, unsigned long long* __restrict__ tab64,
@@ -392,7 +466,7 @@ __global__ __launch_bounds__(kThreads) void k_world_select(
         Pt p;
         p.x = p.y = p.z = 0.f;
         p.meta = 0;
-        int64_t key = 0;
+        int64_t key = 0, tslot = -1;
         int r = 0, c = 0;
         if (i < n) {
             p = wsrc[i];
@@ -400,16 +474,17 @@ __global__ __launch_bounds__(kThreads) void k_world_select(
                 r = cell_index(p.z, half_res);
                 c = cell_index(p.x, half_res);
                 key = make_key((int)(p.meta >> 8), r, c, sc->mmW);
-                if (key >= 0 && key < table_cells) {
+                tslot = table_slot((int)(p.meta >> 8), r, c, sc->mmW, table_cells);
+                if (tslot >= 0) {
                     const unsigned long long packed =
                         ((unsigned long long)ord_f32(p.y) << 32) | (unsigned long long)(~(uint32_t)rsrc[i]);
-                    win = (tab64[key] == packed);
+                    win = (tab64[tslot] == packed);
                 }
             }
         }
         const unsigned slot = wave_append(win, &sc->cnt[cur ^ 1], capacity, &sc->err);
         if (win) {
-            tab64[key] = 0ull;
+            tab64[tslot] = 0ull;
             if (slot != 0xFFFFFFFFu) {
                 wdst[slot] = p;
                 rdst[slot] = key;
@@ -440,19 +515,7 @@ __global__ __launch_bounds__(kThreads) void k_finalize(unsigned long long* __res
         sem[i] = (uint8_t)(v & 0xFFull);
         cell[i] = 0ull;
     }
-    if (i == 0) {
-        if (swap) {
-            const int cur = sc->cur;
-            sc->cnt[cur ^ 1] = min(sc->cnt[cur ^ 1], capacity);
-            sc->cnt[cur] = 0;
-            sc->cur = cur ^ 1;
-            sc->n_bbox = n_bbox;
-            sc->n_bbox_envs = n_bbox_envs;
-        }
-        sc->mmL[0] = sc->mmL[1] = sc->mmW[0] = sc->mmW[1] = sc->mmWold[0] = sc->mmWold[1] = INT32_MAX;
-        sc->mmL[2] = sc->mmL[3] = sc->mmW[2] = sc->mmW[3] = sc->mmWold[2] = sc->mmWold[3] = INT32_MIN;
-        sc->cnt_old = 0;
-    }
+    if (i == 0) finalize_scalars(sc, swap, capacity, n_bbox, n_bbox_envs);
 }
 
 // ---- known-map mode ----
@@ -546,19 +609,8 @@ __global__ void k_frames(const float* __restrict__ pose, const double* __restric
                          float* __restrict__ T, float* __restrict__ rot) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    double elev = orient[2 * b + 0] + 3.141592653589793;  // mapper.py:135 elevation + torch.pi
-    double head = orient[2 * b + 1];
-    double cx = cos(elev), sx = sin(elev), cy = cos(head), sy = sin(head);
-    float* t = T + 16 * b;  // core.py:20-36
-    t[0] = (float)cy;    t[1] = (float)(sx * sy); t[2] = (float)(cx * sy);  t[3] = pose[3 * b + 0];
-    t[4] = 0.f;          t[5] = (float)cx;        t[6] = (float)(-sx);      t[7] = pose[3 * b + 1];
-    t[8] = (float)(-sy); t[9] = (float)(cy * sx); t[10] = (float)(cy * cx); t[11] = pose[3 * b + 2];
-    t[12] = 0.f; t[13] = 0.f; t[14] = 0.f; t[15] = 1.f;
-    double a = -head;  // mapper.py:266 rotate_around_y(-origin.heading)
-    float* r = rot + 9 * b;
-    r[0] = (float)cos(a);    r[1] = 0.f; r[2] = (float)sin(a);
-    r[3] = 0.f;              r[4] = 1.f; r[5] = 0.f;
-    r[6] = (float)(-sin(a)); r[7] = 0.f; r[8] = (float)cos(a);
+    frame_T(pose, orient, b, T + 16 * b);
+    frame_rot(orient, b, rot + 9 * b);
 }
 
 }  // namespace
@@ -705,18 +757,27 @@ int ivln_mapper_frames(const float* pose, const double* orientation, int B, floa
     return hipGetLastError() == hipSuccess ? IVLN_OK : IVLN_E_HIP;
 }
 
-int ivln_mapper_step(ivln_mapper* m, const float* depth, const uint8_t* labels, const float* T, const float* pose,
-                     const float* rot, const uint8_t* not_done, int B, uint8_t* occ_out, uint8_t* sem_out,
-                     void* stream) {
+static int mapper_step(ivln_mapper* m, const float* depth, const uint8_t* labels, const float* T, const float* pose,
+                       const float* rot, const double* orientation, float* T_out, float* rot_out,
+                       const uint8_t* not_done, int B, uint8_t* occ_out, uint8_t* sem_out, void* stream) {
     if (!m || B <= 0 || B > m->B_max) return IVLN_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
     const int64_t npix = (int64_t)B * m->H * m->W;
     int lb = (int)((npix + kThreads * kPPT - 1) / (kThreads * kPPT));  // local-cloud chunks: 4 pixels / thread
     if (m->local_blocks > 0 && m->local_blocks < lb) lb = m->local_blocks;  // narrow launch: a block walks several chunks
     const int map_cells = B * m->rows * m->cols;
-    const Cam cm{depth, T, pose, m->xs, m->ys, B, m->H, m->W, m->half_res};
     const unsigned cap = (unsigned)m->capacity;
-    hipLaunchKernelGGL(k_local_minmax, dim3(lb), dim3(kThreads), 0, s, cm, occ_out, map_cells, m->bmmL);
+    if (orientation) {  // posed entry: transforms derived inside the first kernel
+        const Cam c0{depth, nullptr, pose, m->xs, m->ys, B, m->H, m->W, m->half_res};
+        hipLaunchKernelGGL(k_local_minmax<true>, dim3(lb), dim3(kThreads), 0, s, c0, occ_out, map_cells, m->bmmL,
+                           orientation, T_out, rot_out);
+        T = T_out;
+        rot = rot_out;
+    }
+    const Cam cm{depth, T, pose, m->xs, m->ys, B, m->H, m->W, m->half_res};
+    if (!orientation)
+        hipLaunchKernelGGL(k_local_minmax<false>, dim3(lb), dim3(kThreads), 0, s, cm, occ_out, map_cells, m->bmmL,
+                           (const double*)nullptr, (float*)nullptr, (float*)nullptr);
     hipLaunchKernelGGL(k_local_argmax, dim3(lb), dim3(kThreads), 0, s, cm, m->sc, m->tab64, m->table_cells, m->bmmL, lb,
                        m->bbox, m->B_max, not_done);
     hipLaunchKernelGGL(k_local_select, dim3(lb), dim3(kThreads), 0, s, cm, labels, m->sc, m->tab64, m->table_cells,
@@ -734,6 +795,21 @@ int ivln_mapper_step(ivln_mapper* m, const float* depth, const uint8_t* labels, 
     hipLaunchKernelGGL(k_finalize, dim3(fin_blocks), dim3(kThreads), 0, s, m->cell, sem_out, map_cells, m->sc, 1, cap,
                        wb, B);
     return hipGetLastError() == hipSuccess ? IVLN_OK : IVLN_E_HIP;
+}
+
+int ivln_mapper_step(ivln_mapper* m, const float* depth, const uint8_t* labels, const float* T, const float* pose,
+                     const float* rot, const uint8_t* not_done, int B, uint8_t* occ_out, uint8_t* sem_out,
+                     void* stream) {
+    if (!T || !rot) return IVLN_E_INVALID;
+    return mapper_step(m, depth, labels, T, pose, rot, nullptr, nullptr, nullptr, not_done, B, occ_out, sem_out, stream);
+}
+
+int ivln_mapper_step_posed(ivln_mapper* m, const float* depth, const uint8_t* labels, const float* pose,
+                           const double* orientation, const uint8_t* not_done, int B, uint8_t* occ_out,
+                           uint8_t* sem_out, float* T_out, float* rot_out, void* stream) {
+    if (!orientation || !T_out || !rot_out) return IVLN_E_INVALID;
+    return mapper_step(m, depth, labels, nullptr, pose, nullptr, orientation, T_out, rot_out, not_done, B, occ_out, sem_out,
+                       stream);
 }
 
 int ivln_mapper_set_launch_width(ivln_mapper* m, int local_blocks, int world_blocks) {

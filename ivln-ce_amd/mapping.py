@@ -14,6 +14,10 @@ import torch
 from . import _lib
 from ._lib import check, dptr, lib, stream_ptr
 
+# ivln_mapper_step_posed: camera transforms derived inside the step's first kernel (6 launches per step instead of
+# frames + 6); IVLN_MAPPER_POSED=0 keeps the separate ivln_mapper_frames launch (A/B, tests of the older entry points)
+STEP_POSED = os.environ.get("IVLN_MAPPER_POSED", "1") != "0"
+
 
 @dataclass
 class CameraParameters:  # mapper.py:336-340
@@ -173,7 +177,11 @@ class MappingModule:
         self._ensure_handle(H, W)
         depth = depth.to(torch.float32).contiguous()
         not_done = observations["not_done_masks"].reshape(-1).to(torch.uint8).contiguous()
-        if T is None:
+        posed = T is None and self.mode == "iterative" and STEP_POSED
+        if posed:  # the transforms are derived inside the step's first kernel (ivln_mapper_step_posed)
+            pose = observations["world_robot_pose"].to(self.device, torch.float32).contiguous()
+            orientation = observations["world_robot_orientation"].to(self.device, torch.float64).contiguous()
+        elif T is None:
             T, rot, pose = self.frames(observations["world_robot_pose"], observations["world_robot_orientation"])
         else:
             pose = observations["world_robot_pose"].to(self.device, torch.float32).contiguous()
@@ -190,13 +198,22 @@ class MappingModule:
                     raise Exception("Semantic Sensor not in use")  # mapper.py:660-661
                 labels = observations["semantic12"]
             labels = labels.reshape(B, H, W).to(torch.uint8).contiguous()
-            check(
-                lib().ivln_mapper_step(
-                    self._h, dptr(depth), dptr(labels), dptr(T), dptr(pose), dptr(rot), dptr(not_done), B,
-                    dptr(mem._occ), dptr(mem._sem), s,
-                ),
-                "ivln_mapper_step",
-            )
+            if posed:
+                check(
+                    lib().ivln_mapper_step_posed(
+                        self._h, dptr(depth), dptr(labels), dptr(pose), dptr(orientation), dptr(not_done), B,
+                        dptr(mem._occ), dptr(mem._sem), dptr(self._T), dptr(self._rot), s,
+                    ),
+                    "ivln_mapper_step_posed",
+                )
+            else:
+                check(
+                    lib().ivln_mapper_step(
+                        self._h, dptr(depth), dptr(labels), dptr(T), dptr(pose), dptr(rot), dptr(not_done), B,
+                        dptr(mem._occ), dptr(mem._sem), s,
+                    ),
+                    "ivln_mapper_step",
+                )
         else:
             check(lib().ivln_mapper_known_begin(self._h, dptr(not_done), B, s), "ivln_mapper_known_begin")
             finished = (not_done == 0).nonzero().reshape(-1).tolist()

@@ -106,6 +106,14 @@ int ivln_mapper_step(ivln_mapper *m, const float *depth, const uint8_t *labels, 
     return mapper_ref_step(m->ref, B, depth, labels, T, pose, rot, not_done, occ_out, sem_out) == 0 ? IVLN_OK : IVLN_E_INVALID;
 }
 
+int ivln_mapper_step_posed(ivln_mapper *m, const float *depth, const uint8_t *labels, const float *pose,
+                           const double *orientation, const uint8_t *not_done, int B, uint8_t *occ_out, uint8_t *sem_out,
+                           float *T_out, float *rot_out, void *stream) {
+    if (!orientation || !T_out || !rot_out) return IVLN_E_INVALID;
+    int rc = ivln_mapper_frames(pose, orientation, B, T_out, rot_out, stream);
+    return rc != IVLN_OK ? rc : ivln_mapper_step(m, depth, labels, T_out, pose, rot_out, not_done, B, occ_out, sem_out, stream);
+}
+
 int ivln_mapper_known_begin(ivln_mapper *m, const uint8_t *not_done, int B, void *stream) {
     (void)stream;
     if (!m || B <= 0 || B > m->B_max) return IVLN_E_INVALID;

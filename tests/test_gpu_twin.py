@@ -103,10 +103,11 @@ def test_ivln_groupnorm_f32_device_vs_twin():
     assert float(np.abs(yd.cpu().numpy() - yh).max()) < 2e-5
 
 
+@pytest.mark.parametrize("posed", [False, True], ids=["frames+step", "step_posed"])
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "mapper_b*.npz"))), ids=lambda p: os.path.basename(p)[7:-4])
-def test_ivln_mapper_entry_points_device_vs_twin(path):
-    """create / frames / step / status through the raw C ABI of both libraries: maps bit-identical every step, frames
-    bit-identical, world-cloud size equal."""
+def test_ivln_mapper_entry_points_device_vs_twin(path, posed):
+    """create / frames / step (or step_posed: the same from the sensor pose, six launches) / status through the raw C
+    ABI of both libraries: maps bit-identical every step, frames bit-identical, world-cloud size equal."""
     from ivln_ce_amd._lib import lib, stream_ptr
 
     g = np.load(path)
@@ -131,9 +132,13 @@ def test_ivln_mapper_entry_points_device_vs_twin(path):
         Td, rotd = torch.zeros((B, 4, 4), device=DEV), torch.zeros((B, 3, 3), device=DEV)
         occd = torch.zeros((B, 64, 64), dtype=torch.uint8, device=DEV)
         semd = torch.zeros((B, 64, 64), dtype=torch.uint8, device=DEV)
-        T.check(Ld, Ld.ivln_mapper_frames(_dp(pd), _dp(od), B, _dp(Td), _dp(rotd), s), "device frames")
-        T.check(Ld, Ld.ivln_mapper_step(hd, _dp(dd), _dp(ld), _dp(Td), _dp(pd), _dp(rotd), _dp(ndd), B, _dp(occd), _dp(semd), s),
-                "device step")
+        if posed:
+            T.check(Ld, Ld.ivln_mapper_step_posed(hd, _dp(dd), _dp(ld), _dp(pd), _dp(od), _dp(ndd), B, _dp(occd), _dp(semd),
+                                                  _dp(Td), _dp(rotd), s), "device step_posed")
+        else:
+            T.check(Ld, Ld.ivln_mapper_frames(_dp(pd), _dp(od), B, _dp(Td), _dp(rotd), s), "device frames")
+            T.check(Ld, Ld.ivln_mapper_step(hd, _dp(dd), _dp(ld), _dp(Td), _dp(pd), _dp(rotd), _dp(ndd), B, _dp(occd),
+                                            _dp(semd), s), "device step")
         nt, ndv = C.c_int64(0), C.c_int64(0)
         T.check(Lt, Lt.ivln_mapper_status(ht, C.byref(nt), None), "twin status")
         T.check(Ld, Ld.ivln_mapper_status(hd, C.byref(ndv), s), "device status")
