@@ -258,6 +258,9 @@ class GraphedRollout:
         with torch.cuda.stream(self.sA):
             self.gA.replay()
             self.ev_A.record(self.sA)
+        # (launching gB1 - RedNet with predicted semantics, the critical chain there - BEFORE gA was measured in round 3:
+        #  5.485 vs 5.480 ms per step at 8 envs, no difference; the 0.8 ms hole in front of RedNet in a traced timeline is
+        #  the tracer's slower graph launches)
         self.gB1[self.phase].replay()
         main.wait_event(self.ev_A)
         self.graphs[self.phase].replay()
