@@ -72,36 +72,39 @@ def to_dev(obs_list, dev):
 
 
 class GemmTimer:
-    """Wraps ops.gemm with event pairs on the launch stream; also accumulates algorithmic FLOPs."""
+    """Kernel time and algorithmic FLOPs of the MFMA-family launches made while it is active.  Time: the library's
+    duration sink (ivln_family_timing_begin / _end, include/ivln_hip.h) - every family launch goes out with a start /
+    stop event of its own (hipExtLaunchKernelGGL: the dispatch's begin and end timestamps, the per-kernel figure
+    rocprofv3 reports), summed.  FLOPs: counted at the Python entry points from the shapes."""
+
+    MAX_LAUNCHES = 1 << 15
 
     def __init__(self):
-        self.events = []
         self.flops = 0
+        self.launches = 0
+        self._ms = None
 
     def __enter__(self):
-        from ivln_ce_amd import ops
+        import ctypes as C
 
-        self.ops = ops
+        from ivln_ce_amd import ops
+        from ivln_ce_amd._lib import check, lib
+
+        self.ops, self._C, self._lib, self._check = ops, C, lib(), check
+        self._lib.ivln_family_timing_begin.argtypes = [C.c_int]
+        self._lib.ivln_family_timing_end.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         self.orig = ops.gemm
 
         def timed(desc):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
             self.orig(desc)
-            b.record()
-            self.events.append((a, b))
             self.flops += 2 * desc.M * desc.N * desc.K
 
         self.orig_gn_conv = ops.gn_conv
 
         def timed_gn_conv(x, gn, **kw):
             """GroupNorm + next-conv launch of the depth ResNet chain: its convs run on the same matrix cores"""
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
             r = self.orig_gn_conv(x, gn, **kw)
-            b.record()
             if r is not None:
-                self.events.append((a, b))
                 if kw.get("front") is not None:  # the 1x1 conv of the front stage (full K, per group block)
                     x0, _, w0 = kw["front"]
                     self.flops += 2 * w0.shape[0] * w0.shape[1] * x0.N * x0.H * x0.W
@@ -115,12 +118,8 @@ class GemmTimer:
 
         def timed_nconv(x, gn=None, **kw):
             """GroupNorm-on-load conv of layer 1 (k_nconv): full-K convs on the matrix cores"""
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
             r = self.orig_nconv(x, gn, **kw)
-            b.record()
             if r is not None:
-                self.events.append((a, b))
                 for y, cw in ((r[1], kw.get("conv_a")), (r[2], kw.get("conv_b"))):
                     if y is not None:
                         w = cw[0]
@@ -130,19 +129,27 @@ class GemmTimer:
         ops.gemm = timed
         ops.gn_conv = timed_gn_conv
         ops.nconv = timed_nconv
+        self._check(self._lib.ivln_family_timing_begin(self.MAX_LAUNCHES), "ivln_family_timing_begin")
         return self
 
     def __exit__(self, *a):
         self.ops.gemm = self.orig
         self.ops.gn_conv = self.orig_gn_conv
         self.ops.nconv = self.orig_nconv
+        if self._ms is None:
+            self.total_ms()
 
     def total_ms(self):
-        """Sum of the event-pair times.  A pair brackets one launch on the launch stream, so it carries the
-        launch's dispatch latency as well (about 2.5 us more per launch than rocprofv3's kernel durations):
-        the reported TFLOP/s is the conservative figure."""
-        torch.cuda.synchronize()
-        return sum(a.elapsed_time(b) for a, b in self.events)
+        """Sum of the family's kernel durations since __enter__ (waits for them); closes the sink."""
+        if self._ms is None:
+            C = self._C
+            ms, n, dropped = C.c_double(0.0), C.c_int(0), C.c_int(0)
+            self._check(self._lib.ivln_family_timing_end(C.byref(ms), C.byref(n), C.byref(dropped)),
+                        "ivln_family_timing_end")
+            if dropped.value:
+                raise RuntimeError(f"GemmTimer: {dropped.value} launches beyond MAX_LAUNCHES went untimed")
+            self._ms, self.launches = ms.value, n.value
+        return self._ms
 
 
 def mfma_roofline(gt, ms, n_steps, traffic, what):
@@ -156,11 +163,11 @@ def mfma_roofline(gt, ms, n_steps, traffic, what):
         "traffic_unit": "HBM bytes per launch of the family (rocprofv3 PMC passes committed under profiles/)",
         "traffic_bytes_per_step": per_step,
         "kernel": MFMA_FAMILY + ": " + what,
-        "flops_per_step": int(gt.flops / n_steps), "launches_per_step": round(len(gt.events) / n_steps, 1),
+        "flops_per_step": int(gt.flops / n_steps), "launches_per_step": round(gt.launches / n_steps, 1),
         "kernel_ms_per_step": round(ms / n_steps, 4),
-        "time_basis": "sum of per-launch HIP-event pairs in an instrumented EAGER single-stream pass outside the timed "
-                      "region (each pair includes ~2.5 us of dispatch); the timed replay overlaps two streams, so this "
-                      "sum can exceed ms_per_step - frac is conservative",
+        "time_basis": "sum of the family's kernel durations - a start / stop HIP event on every dispatch "
+                      "(hipExtLaunchKernelGGL through ivln_family_timing_begin / _end), the per-kernel figure rocprofv3 "
+                      "reports - in an instrumented EAGER single-stream pass outside the timed region",
     }
 
 
@@ -339,7 +346,7 @@ def bench_update(policy, dev, world, barrier, T=64, N=8, iters=5, warm=2):
     ach = (gt.flops / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
     roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "flops_per_update": int(gt.flops),
-            "launches_per_update": len(gt.events), "kernel_ms_per_update": round(ms, 3),
+            "launches_per_update": gt.launches, "kernel_ms_per_update": round(ms, 3),
             "kernel": "fp32 MFMA family: k_conv_direct / k_wgrad_direct / k_gemm_vec / k_gemm"}
     policy.eval()
     return el, {"rows_per_step_per_gpu": TN, "T": T, "N": N, "iters": iters, "roofline": roof}

@@ -178,6 +178,15 @@ typedef struct ivln_gemm_desc {
 } ivln_gemm_desc;
 
 int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream);
+
+/* Duration sink of the MFMA family's launches (ivln_gemm_f32 - its split-K reduction excluded -, ivln_gn_conv_f32,
+ * ivln_nconv_f32, ivln_conv_gn_f32): between _begin and _end every such launch carries a start / stop event of its own
+ * (hipExtLaunchKernelGGL: the dispatch's begin and end timestamps, what rocprofv3 reports per kernel).  _end waits for
+ * the launches, returns the SUM of their durations and their number; `dropped` (optional) = launches beyond
+ * max_launches that went out untimed.  One user at a time, not for captured streams: it is how bench.py measures
+ * `roofline.achieved` live. */
+int ivln_family_timing_begin(int max_launches);
+int ivln_family_timing_end(double* total_ms, int* launches, int* dropped);
 /* Pre-arrangement of OIHW conv weights (M, Cin, KS, KS), KS in {3, 7}, Cin % (KS == 7 ? 2 : 8) == 0, into the
  * LDS image of the direct convolution kernel; `out` holds ivln_conv_packed_floats(M, Cin, KS) floats (0 = shape
  * not eligible).  Re-run whenever the weights change. */

@@ -228,15 +228,15 @@ void launch_wm(const ivln_gemm_desc& d, hipStream_t s, int nimg, int cps) {
     if (d.M <= 32) {
         dim3 grid(tiles_w * tiles_h * groups, (d.M + 31) / 32, d.splits);
         if (d.A_packed)
-            hipLaunchKernelGGL((k_conv_direct<KS, PTW, PTH, IMGS, 1, true>), grid, dim3(256), 0, s, d, tiles_w, tiles_h, nimg, cps);
+            IVLN_LAUNCH_FAMILY((k_conv_direct<KS, PTW, PTH, IMGS, 1, true>), grid, dim3(256), 0, s, d, tiles_w, tiles_h, nimg, cps);
         else
-            hipLaunchKernelGGL((k_conv_direct<KS, PTW, PTH, IMGS, 1, false>), grid, dim3(256), 0, s, d, tiles_w, tiles_h, nimg, cps);
+            IVLN_LAUNCH_FAMILY((k_conv_direct<KS, PTW, PTH, IMGS, 1, false>), grid, dim3(256), 0, s, d, tiles_w, tiles_h, nimg, cps);
     } else {
         dim3 grid(tiles_w * tiles_h * groups, (d.M + 63) / 64, d.splits);
         if (d.A_packed)
-            hipLaunchKernelGGL((k_conv_direct<KS, PTW, PTH, IMGS, 2, true>), grid, dim3(256), 0, s, d, tiles_w, tiles_h, nimg, cps);
+            IVLN_LAUNCH_FAMILY((k_conv_direct<KS, PTW, PTH, IMGS, 2, true>), grid, dim3(256), 0, s, d, tiles_w, tiles_h, nimg, cps);
         else
-            hipLaunchKernelGGL((k_conv_direct<KS, PTW, PTH, IMGS, 2, false>), grid, dim3(256), 0, s, d, tiles_w, tiles_h, nimg, cps);
+            IVLN_LAUNCH_FAMILY((k_conv_direct<KS, PTW, PTH, IMGS, 2, false>), grid, dim3(256), 0, s, d, tiles_w, tiles_h, nimg, cps);
     }
 }
 
@@ -426,18 +426,18 @@ void launch_wgrad_wm(const ivln_gemm_desc& d, hipStream_t s, int nimg, int ntile
     if (d.M <= 32) {
         dim3 grid((d.N + 127) / 128, (d.M + 31) / 32, d.splits);
         if (vec)
-            hipLaunchKernelGGL((k_wgrad_direct<KS, PTW, PTH, IMGS, 1, true>), grid, dim3(256), 0, s, d, tiles_w, tiles_h,
+            IVLN_LAUNCH_FAMILY((k_wgrad_direct<KS, PTW, PTH, IMGS, 1, true>), grid, dim3(256), 0, s, d, tiles_w, tiles_h,
                                nimg, ntiles, tps);
         else
-            hipLaunchKernelGGL((k_wgrad_direct<KS, PTW, PTH, IMGS, 1, false>), grid, dim3(256), 0, s, d, tiles_w, tiles_h,
+            IVLN_LAUNCH_FAMILY((k_wgrad_direct<KS, PTW, PTH, IMGS, 1, false>), grid, dim3(256), 0, s, d, tiles_w, tiles_h,
                                nimg, ntiles, tps);
     } else {
         dim3 grid((d.N + 127) / 128, (d.M + 63) / 64, d.splits);
         if (vec)
-            hipLaunchKernelGGL((k_wgrad_direct<KS, PTW, PTH, IMGS, 2, true>), grid, dim3(256), 0, s, d, tiles_w, tiles_h,
+            IVLN_LAUNCH_FAMILY((k_wgrad_direct<KS, PTW, PTH, IMGS, 2, true>), grid, dim3(256), 0, s, d, tiles_w, tiles_h,
                                nimg, ntiles, tps);
         else
-            hipLaunchKernelGGL((k_wgrad_direct<KS, PTW, PTH, IMGS, 2, false>), grid, dim3(256), 0, s, d, tiles_w, tiles_h,
+            IVLN_LAUNCH_FAMILY((k_wgrad_direct<KS, PTW, PTH, IMGS, 2, false>), grid, dim3(256), 0, s, d, tiles_w, tiles_h,
                                nimg, ntiles, tps);
     }
 }

@@ -20,6 +20,7 @@
 #include <stdint.h>
 #include <math.h>
 #include "../../include/ivln_hip.h"
+#include "family_timing.h"
 
 namespace {
 
@@ -424,7 +425,7 @@ int ivln_conv_gn_f32(const ivln_conv_gn_desc* d, void* stream) {
     A.px_log2 = px_log2;
     A.eps = d->eps;
     A.relu = d->relu;
-    hipLaunchKernelGGL(fn, dim3(d->N * d->groups), dim3(CG_THREADS), bytes, (hipStream_t)stream, A);
+    IVLN_LAUNCH_FAMILY(fn, dim3(d->N * d->groups), dim3(CG_THREADS), bytes, (hipStream_t)stream, A);
     return hipGetLastError() == hipSuccess ? IVLN_OK : IVLN_E_HIP;
 }
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/ivln_hip.h"
+#include "family_timing.h"
 
 namespace {
 

@@ -18,6 +18,8 @@
 // * Epilogue fused: per-channel scale/shift (folded BatchNorm or bias), residual add, ReLU.
 #include <stdlib.h>
 
+#include <vector>
+
 #include "gemm_common.h"
 
 namespace {
@@ -356,7 +358,7 @@ int launch_tile(const ivln_gemm_desc& d, hipStream_t s) {
     dim3 block(256);
 #define IVLN_CASE(AM, BMD)                                                              \
     if (d.amode == AM && d.bmode == BMD) {                                              \
-        hipLaunchKernelGGL((k_gemm<WM, WN, TM, TN, AM, BMD>), grid, block, 0, s, d);            \
+        IVLN_LAUNCH_FAMILY((k_gemm<WM, WN, TM, TN, AM, BMD>), grid, block, 0, s, d);            \
         return IVLN_OK;                                                                 \
     }
     IVLN_CASE(AMODE_MK, BMODE_CONV)
@@ -375,6 +377,54 @@ int launch_tile(const ivln_gemm_desc& d, hipStream_t s) {
 }
 
 }  // namespace
+
+// ---- duration sink of the family's launches (family_timing.h).  One user at a time (bench.py's instrumented pass). ----
+namespace {
+std::vector<hipEvent_t> g_timing_events;
+int g_timing_used = -1;  // -1: not armed
+int g_timing_dropped = 0;
+}  // namespace
+
+bool ivln_family_timing_next(hipEvent_t* start, hipEvent_t* stop) {
+    if (g_timing_used < 0) return false;
+    if ((size_t)g_timing_used + 2 > g_timing_events.size()) {
+        ++g_timing_dropped;
+        return false;
+    }
+    *start = g_timing_events[g_timing_used];
+    *stop = g_timing_events[g_timing_used + 1];
+    g_timing_used += 2;
+    return true;
+}
+
+extern "C" int ivln_family_timing_begin(int max_launches) {
+    if (max_launches <= 0 || g_timing_used >= 0) return IVLN_E_INVALID;
+    while (g_timing_events.size() < (size_t)max_launches * 2) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return IVLN_E_HIP;
+        g_timing_events.push_back(e);
+    }
+    g_timing_used = 0;
+    g_timing_dropped = 0;
+    return IVLN_OK;
+}
+
+extern "C" int ivln_family_timing_end(double* total_ms, int* launches, int* dropped) {
+    if (g_timing_used < 0 || !total_ms || !launches) return IVLN_E_INVALID;
+    const int used = g_timing_used;
+    g_timing_used = -1;
+    double sum = 0.0;
+    for (int i = 0; i < used; i += 2) {
+        if (hipEventSynchronize(g_timing_events[i + 1]) != hipSuccess) return IVLN_E_HIP;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g_timing_events[i], g_timing_events[i + 1]) != hipSuccess) return IVLN_E_HIP;
+        sum += ms;
+    }
+    *total_ms = sum;
+    *launches = used / 2;
+    if (dropped) *dropped = g_timing_dropped;
+    return IVLN_OK;
+}
 
 extern "C" int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream) {
     if (!desc || !desc->A || !desc->B || !desc->D || desc->M <= 0 || desc->N <= 0 || desc->K <= 0)

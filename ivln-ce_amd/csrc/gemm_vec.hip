@@ -273,7 +273,7 @@ void launch_vec(const ivln_gemm_desc& d, hipStream_t s, int alay, int blay) {
     dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM, d.splits);
 #define IVLN_VCASE(AL, BL)                                                                          \
     if (alay == AL && blay == BL) {                                                                 \
-        hipLaunchKernelGGL((k_gemm_vec<WM, WN, TM, TN, AL, BL>), grid, dim3(256), 0, s, d);          \
+        IVLN_LAUNCH_FAMILY((k_gemm_vec<WM, WN, TM, TN, AL, BL>), grid, dim3(256), 0, s, d);          \
         return;                                                                                     \
     }
     IVLN_VCASE(LAY_K, LAY_R)

@@ -866,3 +866,30 @@ def test_sampled_action_head_inverse_cdf_mixing_and_skip_rule(rows):
     probs = torch.softmax(logits[0].double().cpu(), 0)
     freq = torch.bincount(draws.cpu(), minlength=O).double() / n
     assert ((freq - probs).abs() < 3 * (probs * (1 - probs) / n).sqrt() + 1e-3).all(), (freq, probs)
+
+
+def test_family_timing_sink_counts_launches_and_leaves_results_alone():
+    """ivln_family_timing_begin / _end (include/ivln_hip.h): every MFMA-family launch in between carries its own start /
+    stop event; the sum of the durations and the number of launches come back, the kernels' results do not change."""
+    import ctypes as C
+
+    from ivln_ce_amd import ops
+    from ivln_ce_amd._lib import check, lib
+
+    L = lib()
+    L.ivln_family_timing_begin.argtypes = [C.c_int]
+    L.ivln_family_timing_end.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(4, 64, 32, 32, generator=g).to(DEV)
+    w3 = (torch.randn(64, 64, 3, 3, generator=g) / 24).to(DEV)
+    w1 = (torch.randn(128, 64, 1, 1, generator=g) / 8).to(DEV)
+    ref3, ref1 = ops.conv2d(x, w3, pad=1), ops.conv2d(x, w1)
+    check(L.ivln_family_timing_begin(2), "begin")
+    assert L.ivln_family_timing_begin(2) != 0  # one user at a time
+    got3, got1 = ops.conv2d(x, w3, pad=1), ops.conv2d(x, w1)
+    extra = ops.conv2d(x, w1)  # a third launch: beyond max_launches, goes out untimed
+    ms, n, dropped = C.c_double(0), C.c_int(0), C.c_int(0)
+    check(L.ivln_family_timing_end(C.byref(ms), C.byref(n), C.byref(dropped)), "end")
+    assert n.value == 2 and dropped.value == 1 and 0.0 < ms.value < 5.0
+    assert torch.equal(got3, ref3) and torch.equal(got1, ref1) and torch.equal(extra, ref1)
+    assert L.ivln_family_timing_end(C.byref(ms), C.byref(n), C.byref(dropped)) != 0  # not armed any more
