@@ -27,9 +27,13 @@ namespace {
 // (launch bounds: the packed 3x3 / 2x2 variants are held to 128 registers - 94 used, accumulators in VGPRs - so that a
 //  SIMD keeps four or five waves instead of three: RedNet's 64-channel 128x128 convs launch 1024 blocks, exactly four
 //  per CU, which at three resident blocks ran a second, quarter-full round)
-template <int KS, int PTW, int PTH, int IMGS, int WM, bool PACKED>
-__global__ __launch_bounds__(256, (PACKED && KS != 7) ? 4 : 1) void k_conv_direct(const ivln_gemm_desc p, int tiles_w, int tiles_h, int nimg,
+// S = 2 (3x3 only: RedNet's down-sampling convs): the patch spans (2*PTH + 1) x (2*PTW + 1) input pixels and is staged
+// with its even columns in front of its odd ones, so that the 32 lanes of an operand fetch - consecutive OUTPUT pixels,
+// i.e. every second input column - still read consecutive LDS words.
+template <int KS, int PTW, int PTH, int IMGS, int WM, bool PACKED, int S = 1>
+__global__ __launch_bounds__(256, (PACKED && KS != 7 && S == 1) ? 4 : 1) void k_conv_direct(const ivln_gemm_desc p, int tiles_w, int tiles_h, int nimg,
                                                      int chunks_per_split) {
+    static_assert(S == 1 || (S == 2 && KS == 3), "stride 2 is built for 3x3");
     constexpr int CI = conv_direct_ci(KS);  // input channels per chunk (even: channel pairs fill the k slots)
     constexpr int KK = KS * KS;
     constexpr int KC = CI * KK;   // k extent of a chunk
@@ -37,7 +41,10 @@ __global__ __launch_bounds__(256, (PACKED && KS != 7) ? 4 : 1) void k_conv_direc
     constexpr int WN = 4 / WM, TN = WM == 2 ? 2 : 1;
     constexpr int BM = 32 * WM, BN = 32 * WN * TN;
     static_assert(IMGS * PTH * PTW == BN, "pixel tile must hold 128 outputs");
-    constexpr int PH = PTH + KS - 1, PW = PTW + KS - 1, PLANE = PH * PW;
+    constexpr int PH = (PTH - 1) * S + KS, PWR = (PTW - 1) * S + KS;  // input rows / columns under the tile
+    constexpr int PWH = (PWR + 1) / 2;                                // S = 2: even columns of a row (the odd ones follow)
+    constexpr int PW = S == 2 ? 2 * PWH : PWR;                        // row stride of the staged patch
+    constexpr int PLANE = PH * PW;
     constexpr int PATCH = IMGS * CI * PLANE;
     constexpr int LDA = PACKED ? BM + 4 : BM + 1;
     constexpr int NA = PACKED ? (KC * LDA / 4 + 255) / 256 * 4 : (BM * KC + 255) / 256, NP = (PATCH + 255) / 256;
@@ -72,9 +79,10 @@ __global__ __launch_bounds__(256, (PACKED && KS != 7) ? 4 : 1) void k_conv_direc
         const int idx = t + i * 256;
         const int il = idx / (CI * PLANE), rem = idx - il * (CI * PLANE);
         const int ci = rem / PLANE, rem2 = rem - ci * PLANE;
-        const int y = rem2 / PW, x = rem2 - y * PW;
-        const int hi = ho0 - p.pad + y, wi = wo0 - p.pad + x, img = img0 + il;
-        const bool ok = idx < PATCH && img < nimg && (unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win;
+        const int y = rem2 / PW, xs = rem2 - y * PW;
+        const int x = S == 2 ? (xs < PWH ? 2 * xs : 2 * (xs - PWH) + 1) : xs;  // staged column -> input column
+        const int hi = ho0 * S - p.pad + y, wi = wo0 * S - p.pad + x, img = img0 + il;
+        const bool ok = idx < PATCH && x < PWR && img < nimg && (unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win;
         poff[i] = ok ? (int)((int64_t)img * p.in_img_stride + (int64_t)ci * HW + hi * p.Win + wi) : -1;
     }
 
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(256, (PACKED && KS != 7) ? 4 : 1) void k_conv_direc
     for (int tn = 0; tn < TN; ++tn) {
         const int nl = (wn * TN + tn) * 32 + l31;
         const int il = nl / (PTH * PTW), ph = (nl / PTW) % PTH, pw = nl % PTW;
-        bbase[tn] = il * CI * PLANE + half * PLANE + ph * PW + pw;
+        bbase[tn] = il * CI * PLANE + half * PLANE + ph * S * PW + pw;
     }
 
     f32x16 acc[TN];
@@ -157,7 +165,7 @@ __global__ __launch_bounds__(256, (PACKED && KS != 7) ? 4 : 1) void k_conv_direc
                 const float a = As[abase + q * 2 * LDA];
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) {
-                    const float b = Ps[bbase[tn] + cp * 2 * PLANE + kh * PW + kw];
+                    const float b = Ps[bbase[tn] + cp * 2 * PLANE + kh * PW + (S == 2 ? (kw & 1) * PWH + (kw >> 1) : kw)];
                     acc[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[tn], 0, 0, 0);
                 }
             }
@@ -221,31 +229,31 @@ __global__ __launch_bounds__(256) void k_conv_pack_weights(const float* __restri
     out[idx] = (col < BM && m < M) ? W[((int64_t)m * Cin + ci) * KK + r] : 0.f;
 }
 
-template <int KS, int PTW, int PTH, int IMGS>
+template <int KS, int PTW, int PTH, int IMGS, int S = 1>
 void launch_wm(const ivln_gemm_desc& d, hipStream_t s, int nimg, int cps) {
     const int tiles_w = (d.Wout + PTW - 1) / PTW, tiles_h = (d.Hout + PTH - 1) / PTH;
     const int groups = (nimg + IMGS - 1) / IMGS;
     if (d.M <= 32) {
         dim3 grid(tiles_w * tiles_h * groups, (d.M + 31) / 32, d.splits);
         if (d.A_packed)
-            IVLN_LAUNCH_FAMILY((k_conv_direct<KS, PTW, PTH, IMGS, 1, true>), grid, dim3(256), 0, s, d, tiles_w, tiles_h, nimg, cps);
+            IVLN_LAUNCH_FAMILY((k_conv_direct<KS, PTW, PTH, IMGS, 1, true, S>), grid, dim3(256), 0, s, d, tiles_w, tiles_h, nimg, cps);
         else
-            IVLN_LAUNCH_FAMILY((k_conv_direct<KS, PTW, PTH, IMGS, 1, false>), grid, dim3(256), 0, s, d, tiles_w, tiles_h, nimg, cps);
+            IVLN_LAUNCH_FAMILY((k_conv_direct<KS, PTW, PTH, IMGS, 1, false, S>), grid, dim3(256), 0, s, d, tiles_w, tiles_h, nimg, cps);
     } else {
         dim3 grid(tiles_w * tiles_h * groups, (d.M + 63) / 64, d.splits);
         if (d.A_packed)
-            IVLN_LAUNCH_FAMILY((k_conv_direct<KS, PTW, PTH, IMGS, 2, true>), grid, dim3(256), 0, s, d, tiles_w, tiles_h, nimg, cps);
+            IVLN_LAUNCH_FAMILY((k_conv_direct<KS, PTW, PTH, IMGS, 2, true, S>), grid, dim3(256), 0, s, d, tiles_w, tiles_h, nimg, cps);
         else
-            IVLN_LAUNCH_FAMILY((k_conv_direct<KS, PTW, PTH, IMGS, 2, false>), grid, dim3(256), 0, s, d, tiles_w, tiles_h, nimg, cps);
+            IVLN_LAUNCH_FAMILY((k_conv_direct<KS, PTW, PTH, IMGS, 2, false, S>), grid, dim3(256), 0, s, d, tiles_w, tiles_h, nimg, cps);
     }
 }
 
-template <int KS>
+template <int KS, int S = 1>
 void launch_ks(const ivln_gemm_desc& d, hipStream_t s, int nimg, int cps) {
-    if (d.Wout > 16) launch_wm<KS, 32, 4, 1>(d, s, nimg, cps);
-    else if (d.Wout > 8) launch_wm<KS, 16, 8, 1>(d, s, nimg, cps);
-    else if (d.Wout > 4) launch_wm<KS, 8, 8, 2>(d, s, nimg, cps);
-    else launch_wm<KS, 4, 4, 8>(d, s, nimg, cps);
+    if (d.Wout > 16) launch_wm<KS, 32, 4, 1, S>(d, s, nimg, cps);
+    else if (d.Wout > 8) launch_wm<KS, 16, 8, 1, S>(d, s, nimg, cps);
+    else if (d.Wout > 4) launch_wm<KS, 8, 8, 2, S>(d, s, nimg, cps);
+    else launch_wm<KS, 4, 4, 8, S>(d, s, nimg, cps);
 }
 
 
@@ -455,7 +463,9 @@ void launch_wgrad_ks(const ivln_gemm_desc& d, hipStream_t s, int nimg, int ntile
 int ivln_conv_direct_launch(ivln_gemm_desc& d, hipStream_t s) {
     static const bool disabled = getenv("IVLN_NO_DIRECT_CONV") != nullptr;
     const int KS = conv_ks(d.bmode);
-    if (disabled || KS == 0 || d.amode != AMODE_MK || d.stride != 1 || d.dil != 1) return IVLN_E_UNSUPPORTED;
+    static const bool no_s2 = getenv("IVLN_NO_DIRECT_CONV_S2") != nullptr;  // A/B switch
+    if (disabled || KS == 0 || d.amode != AMODE_MK || d.dil != 1) return IVLN_E_UNSUPPORTED;
+    if (d.stride != 1 && !(d.stride == 2 && KS == 3 && !no_s2)) return IVLN_E_UNSUPPORTED;
     const int CI = conv_direct_ci(KS);
     if (d.Cin % CI != 0 || d.K != d.Cin * KS * KS || d.HoWo != d.Hout * d.Wout || d.N % d.HoWo != 0)
         return IVLN_E_UNSUPPORTED;
@@ -494,6 +504,7 @@ int ivln_conv_direct_launch(ivln_gemm_desc& d, hipStream_t s) {
     d.splits = splits;
     if (KS == 7) launch_ks<7>(d, s, nimg, cps);
     else if (KS == 2) launch_ks<2>(d, s, nimg, cps);
+    else if (d.stride == 2) launch_ks<3, 2>(d, s, nimg, cps);
     else launch_ks<3>(d, s, nimg, cps);
     return IVLN_OK;
 }

@@ -23,6 +23,10 @@ def _close(got, ref, atol, rtol=1e-4):
         (3, 128, 32, 32, 64, 1, 1, 0),    # 1x1
         (2, 128, 32, 32, 256, 1, 2, 0),   # strided 1x1 downsample
         (2, 64, 32, 32, 64, 3, 2, 1),     # strided 3x3
+        (8, 128, 32, 32, 128, 3, 2, 1),   # strided 3x3 on the direct kernel (patch staged as even | odd column planes)
+        (4, 64, 64, 64, 64, 3, 2, 1),     # ... 32-wide output rows
+        (8, 64, 30, 30, 64, 3, 2, 1),     # ... ragged 15x15 output
+        (16, 256, 16, 16, 128, 3, 2, 1),  # ... 8x8 output, two images per pixel tile, channel chunks split
         (1, 256, 4, 4, 1024, 1, 1, 0),    # pixel-starved (N<=32 -> 128x32 tile)
         (4, 1024, 4, 4, 128, 3, 1, 1),    # compression conv: split-K
         (2, 14, 64, 64, 32, 7, 1, 3),     # map CNN layer 1
@@ -694,6 +698,7 @@ def test_conv_groupnorm_refuses_shapes_outside_its_envelope():
 
 @pytest.mark.parametrize("B,Cin,H,W,Cout,k,s,p", [(4, 64, 16, 16, 64, 3, 1, 1), (2, 256, 8, 8, 64, 1, 1, 0), (3, 64, 8, 8, 256, 1, 1, 0),
                                                    (2, 128, 16, 16, 128, 3, 2, 1), (2, 256, 16, 16, 512, 1, 2, 0),
+                                                   (8, 128, 32, 32, 128, 3, 2, 1),
                                                    (8, 512, 8, 8, 512, 3, 1, 1), (1, 64, 32, 32, 64, 3, 1, 1)])
 def test_image_grouped_conv_matches_two_separate_convs(B, Cin, H, W, Cout, k, s, p):
     """ivln_gemm_desc.grp_imgs: images [0, B) with weight set 0 and [B, 2B) with set 1 in ONE launch (RedNet's RGB and

@@ -30,6 +30,9 @@ def _dp(t):
     (2, 128, 16, 16, 256, 1, 2, 0, False),  # strided 1x1: gather GEMM
     (2, 1, 64, 64, 32, 7, 2, 3, False),     # stem
     (2, 64, 16, 16, 64, 3, 2, 1, False),
+    (8, 128, 32, 32, 128, 3, 2, 1, False),  # stride-2 3x3 on the direct kernel (even / odd column planes in LDS)
+    (4, 64, 64, 64, 64, 3, 2, 1, False),
+    (8, 64, 30, 30, 64, 3, 2, 1, False),    # ... with a ragged 15x15 output
     (4, 64, 8, 8, 64, 3, 1, 1, True),       # image-grouped weight sets
     (4, 128, 8, 8, 64, 1, 1, 0, True),
 ])
