@@ -22,13 +22,17 @@ namespace {
 constexpr int BKV = 32;
 enum { LAY_K = 0, LAY_R = 1 };
 
-template <int WM, int WN, int TM, int TN, int ALAY, int BLAY>
+// BS2 (B = a 1x1 conv read at stride 2, RedNet's down-sampling shortcuts): n and n + 1 are input columns 2*wo and
+// 2*wo + 2, so a 16-byte load yields TWO operand elements (.x and .z) instead of four - twice the loads per tile, the
+// same staging and MFMA loop, in place of the scalar-gather GEMM these convs ran on (42 -> ~70 TFLOP/s).
+template <int WM, int WN, int TM, int TN, int ALAY, int BLAY, bool BS2 = false>
 __global__ __launch_bounds__(256, 2) void k_gemm_vec(const ivln_gemm_desc p) {
+    static_assert(!BS2 || BLAY == LAY_R, "stride-2 pixels are the n-contiguous layout");
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
     constexpr int LDK = BKV + 4;  // [row][k] layout row stride (words)
     constexpr int A_WORDS = ALAY == LAY_K ? BM * LDK : BKV * BM;
     constexpr int B_WORDS = BLAY == LAY_K ? BN * LDK : BKV * BN;
-    constexpr int EA = BM * BKV / 1024, EB = BN * BKV / 1024;  // float4 per thread per tile
+    constexpr int EA = BM * BKV / 1024, EB = BN * BKV / 1024 * (BS2 ? 2 : 1);  // 16-byte loads per thread per tile
     // one LDS block: the operand tiles during the K loop, the output tile during the wide epilogue
     constexpr int LDC = BN + 4;
     constexpr bool WIDE_FITS = BM * LDC <= A_WORDS + B_WORDS;
@@ -49,7 +53,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_vec(const ivln_gemm_desc p) {
     // ---- per-thread staging coordinates (tile-invariant) ----
     // [row][k] operands: 8 float4 per row, thread -> (row = t/8 + 32 e, kq = t%8)
     // [k][row] operands: R4 = rows/4 float4 per k, thread -> (k = t/R4 + (256/R4) e, rq = t%R4)
-    constexpr int AR4 = BM / 4, BR4 = BN / 4;
+    constexpr int AR4 = BM / 4, BR4 = BS2 ? BN / 2 : BN / 4, BNV = BS2 ? 2 : 4;  // (BNV: columns one B load yields)
     int64_t a_off[EA], b_off[EB];
     bool a_ok[EA], b_ok[EB];
     int a_k[EA], b_k[EB];  // k offset of the element inside the tile
@@ -68,7 +72,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_vec(const ivln_gemm_desc p) {
         }
     }
     const bool bconv = p.bmode == BMODE_CONV1X1;
-    const int64_t brow = bconv ? (int64_t)p.HoWo : p.ldb;  // stride of k for [k][n] operands
+    const int64_t brow = BS2 ? (int64_t)p.Hin * p.Win : (bconv ? (int64_t)p.HoWo : p.ldb);  // stride of k for [k][n] operands
 #pragma unroll
     for (int e = 0; e < EB; ++e) {
         if constexpr (BLAY == LAY_K) {
@@ -77,12 +81,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm_vec(const ivln_gemm_desc p) {
             b_ok[e] = n < p.N;
             b_off[e] = b_ok[e] ? (int64_t)n * p.ldb + b_k[e] : 0;
         } else {
-            const int n = n0 + (t % BR4) * 4;
+            const int n = n0 + (t % BR4) * BNV;
             b_k[e] = t / BR4 + (256 / BR4) * e;
             b_ok[e] = n < p.N;
             int64_t base = 0;
             if (b_ok[e]) {
-                if (bconv) {
+                if constexpr (BS2) {
+                    const int img = n / p.HoWo, pp = n - img * p.HoWo;
+                    const int ho = pp / p.Wout, wo = pp - ho * p.Wout;
+                    base = (int64_t)img * p.in_img_stride + (int64_t)(2 * ho) * p.Win + 2 * wo;
+                } else if (bconv) {
                     const int img = n / p.HoWo;
                     base = (int64_t)img * p.in_img_stride + (n - img * p.HoWo);
                 } else {
@@ -127,6 +135,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_vec(const ivln_gemm_desc p) {
             const bool ok = b_ok[e] && k0 + b_k[e] < kend;
             const float4 v = make_float4(ok ? rb[e].x : 0.f, ok ? rb[e].y : 0.f, ok ? rb[e].z : 0.f, ok ? rb[e].w : 0.f);
             if constexpr (BLAY == LAY_K) *reinterpret_cast<float4*>(&Bs[((t >> 3) + 32 * e) * LDK + (t & 7) * 4]) = v;
+            else if constexpr (BS2) *reinterpret_cast<float2*>(&Bs[(t / BR4 + (256 / BR4) * e) * BN + (t % BR4) * 2]) = make_float2(v.x, v.z);
             else *reinterpret_cast<float4*>(&Bs[(t / BR4 + (256 / BR4) * e) * BN + (t % BR4) * 4]) = v;
         }
     };
@@ -276,6 +285,12 @@ void launch_vec(const ivln_gemm_desc& d, hipStream_t s, int alay, int blay) {
         IVLN_LAUNCH_FAMILY((k_gemm_vec<WM, WN, TM, TN, AL, BL>), grid, dim3(256), 0, s, d);          \
         return;                                                                                     \
     }
+    if (d.bmode == BMODE_CONV1X1 && d.stride == 2) {
+        if constexpr (TM * TN == 1) {  // (eligibility keeps the stride-2 form to the one-accumulator tiles)
+            IVLN_LAUNCH_FAMILY((k_gemm_vec<WM, WN, TM, TN, LAY_K, LAY_R, true>), grid, dim3(256), 0, s, d);
+        }
+        return;
+    }
     IVLN_VCASE(LAY_K, LAY_R)
     IVLN_VCASE(LAY_K, LAY_K)
     IVLN_VCASE(LAY_R, LAY_R)
@@ -300,7 +315,13 @@ bool ivln_gemm_vec_eligible(const ivln_gemm_desc& d) {
     } else {
         return false;
     }
-    if (d.bmode == BMODE_CONV1X1) {
+    static const bool no_s2 = getenv("IVLN_NO_VEC_GEMM_S2") != nullptr;  // A/B switch
+    if (d.bmode == BMODE_CONV1X1 && d.stride == 2) {
+        // 16-byte loads at input column 2*wo (wo even): rows of 2*Wout columns, every row / plane / image 16-byte aligned
+        if (no_s2 || d.amode != AMODE_MK || d.pad != 0 || d.Win != 2 * d.Wout || d.Hin < 2 * d.Hout - 1 || (d.Wout & 1) ||
+            d.HoWo != d.Hout * d.Wout || (d.Win & 3) || (((int64_t)d.Hin * d.Win) & 3) || (d.in_img_stride & 3))
+            return false;
+    } else if (d.bmode == BMODE_CONV1X1) {
         if (d.stride != 1 || d.pad != 0 || d.Hin * d.Win != d.HoWo || (d.HoWo & 3) || (d.in_img_stride & 3)) return false;
     } else if (d.bmode == BMODE_KN) {
         if ((d.N & 3) || (d.ldb & 3)) return false;
@@ -316,6 +337,7 @@ bool ivln_gemm_vec_eligible(const ivln_gemm_desc& d) {
 int ivln_gemm_vec_launch(const ivln_gemm_desc& d, hipStream_t s, int tile) {
     const int alay = d.amode == AMODE_MK ? LAY_K : LAY_R;
     const int blay = d.bmode == BMODE_NK ? LAY_K : LAY_R;
+    if (d.bmode == BMODE_CONV1X1 && d.stride == 2 && (tile == 3 || tile == 4)) tile = 0;  // built for the one-accumulator tiles
     switch (tile) {
         case 1: launch_vec<1, 4, 1, 1>(d, s, alay, blay); break;
         case 2: launch_vec<4, 1, 1, 1>(d, s, alay, blay); break;

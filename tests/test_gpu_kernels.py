@@ -21,7 +21,9 @@ def _close(got, ref, atol, rtol=1e-4):
         (2, 1, 128, 128, 32, 7, 2, 3),    # DD-PPO stem
         (4, 32, 32, 32, 32, 3, 1, 1),     # layer1 3x3 (M<=32 -> 32x128 tile)
         (3, 128, 32, 32, 64, 1, 1, 0),    # 1x1
-        (2, 128, 32, 32, 256, 1, 2, 0),   # strided 1x1 downsample
+        (2, 128, 32, 32, 256, 1, 2, 0),   # strided 1x1 downsample (float4-staged GEMM, two columns per 16-byte load)
+        (8, 256, 64, 64, 512, 1, 2, 0),   # ... RedNet's size
+        (3, 64, 30, 30, 96, 1, 2, 0),     # ... odd output width: the scalar-gather GEMM
         (2, 64, 32, 32, 64, 3, 2, 1),     # strided 3x3
         (8, 128, 32, 32, 128, 3, 2, 1),   # strided 3x3 on the direct kernel (patch staged as even | odd column planes)
         (4, 64, 64, 64, 64, 3, 2, 1),     # ... 32-wide output rows
