@@ -33,7 +33,7 @@ namespace {
 template <int KS, int PTW, int PTH, int IMGS, int WM, bool PACKED, int S = 1>
 __global__ __launch_bounds__(256, (PACKED && KS != 7 && S == 1) ? 4 : 1) void k_conv_direct(const ivln_gemm_desc p, int tiles_w, int tiles_h, int nimg,
                                                      int chunks_per_split) {
-    static_assert(S == 1 || (S == 2 && KS == 3), "stride 2 is built for 3x3");
+    static_assert(S == 1 || (S == 2 && KS != 2), "stride 2 is built for 3x3 and 7x7");
     constexpr int CI = conv_direct_ci(KS);  // input channels per chunk (even: channel pairs fill the k slots)
     constexpr int KK = KS * KS;
     constexpr int KC = CI * KK;   // k extent of a chunk
@@ -52,7 +52,9 @@ __global__ __launch_bounds__(256, (PACKED && KS != 7 && S == 1) ? 4 : 1) void k_
     // goes through the same LDS block once more to leave as 16-byte stores (up2x4_wide_store, gemm_common.h)
     constexpr int LDC = BN + 4;
     constexpr int OPER = (KC * LDA + 3) / 4 * 4 + PATCH;
-    constexpr int SMEM = (KS == 2 && BM * LDC > OPER) ? BM * LDC : OPER;
+    // ... and so do NCHW output tiles whose rows hold whole pixel quads (nchw_wide_store): 16-byte stores along the row
+    constexpr bool WIDE_NCHW = PTW % 4 == 0;
+    constexpr int SMEM = ((KS == 2 || WIDE_NCHW) && BM * LDC > OPER) ? BM * LDC : OPER;
     __shared__ __attribute__((aligned(16))) float smem[SMEM];
     float* const As = smem;
     float* const Ps = smem + (KC * LDA + 3) / 4 * 4;
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(256, (PACKED && KS != 7 && S == 1) ? 4 : 1) void k_
     const int tw = bx % tiles_w, th = (bx / tiles_w) % tiles_h, ig = bx / (tiles_w * tiles_h);
     const int img0 = ig * IMGS, ho0 = th * PTH, wo0 = tw * PTW;
     const int m0 = bid.y * BM;
-    const int nch = p.Cin / CI;
+    const int nch = (p.Cin + CI - 1) / CI;  // (a ragged last chunk - the 1- and 3-channel stems - reads its missing channels as zero)
     const int c_beg = bid.z * chunks_per_split;
     const int c_end = min(nch, c_beg + chunks_per_split);
     const int HW = p.Hin * p.Win;
@@ -74,11 +76,14 @@ __global__ __launch_bounds__(256, (PACKED && KS != 7 && S == 1) ? 4 : 1) void k_
 
     // patch elements of this thread: chunk-invariant source offsets (-1 = zero padding / no such image)
     int poff[NP];
+    uint32_t tail = 0;  // bit i: element i's channel exists in the LAST chunk too (all ones unless Cin % CI != 0)
+    static_assert(NP <= 32, "one validity bit per patch element of a thread");
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         const int idx = t + i * 256;
         const int il = idx / (CI * PLANE), rem = idx - il * (CI * PLANE);
         const int ci = rem / PLANE, rem2 = rem - ci * PLANE;
+        tail |= (uint32_t)((nch - 1) * CI + ci < p.Cin) << i;
         const int y = rem2 / PW, xs = rem2 - y * PW;
         const int x = S == 2 ? (xs < PWH ? 2 * xs : 2 * (xs - PWH) + 1) : xs;  // staged column -> input column
         const int hi = ho0 * S - p.pad + y, wi = wo0 * S - p.pad + x, img = img0 + il;
@@ -103,17 +108,18 @@ __global__ __launch_bounds__(256, (PACKED && KS != 7 && S == 1) ? 4 : 1) void k_
             for (int i = 0; i < NA; ++i) {
                 const int idx = t + i * 256;
                 const int co = idx / KC, kk = idx - co * KC;
-                const bool ok = idx < BM * KC && m0 + co < p.M;
+                const bool ok = idx < BM * KC && m0 + co < p.M && kbase + kk < p.K;
                 ra[i] = Ag[ok ? (int64_t)(m0 + co) * p.lda + kbase + kk : 0];
             }
         }
         const int cbase = c * CI * HW;
         // (no select here: the zero of a padding element is chosen in stage(), after the MFMA phase these loads fly
         //  under - a select next to the load makes hipcc wait for the load before that phase starts)
+        const uint32_t live = c == nch - 1 ? tail : 0xFFFFFFFFu;
 #pragma unroll
-        for (int i = 0; i < NP; ++i) rp[i] = p.B[poff[i] >= 0 ? poff[i] + cbase : 0];
+        for (int i = 0; i < NP; ++i) rp[i] = p.B[(poff[i] >= 0 && ((live >> i) & 1)) ? poff[i] + cbase : 0];
     };
-    auto stage = [&]() {
+    auto stage = [&](int c) {
         if constexpr (PACKED) {
 #pragma unroll
             for (int i = 0; i < NA / 4; ++i) {
@@ -127,13 +133,15 @@ __global__ __launch_bounds__(256, (PACKED && KS != 7 && S == 1) ? 4 : 1) void k_
                 const int idx = t + i * 256;
                 const int co = idx / KC, kk = idx - co * KC;
                 const int ci = kk / KK, r = kk - ci * KK;
-                if (idx < BM * KC) As[((((ci >> 1) * KK + r) << 1) + (ci & 1)) * LDA + co] = m0 + co < p.M ? ra[i] : 0.f;
+                if (idx < BM * KC)
+                    As[((((ci >> 1) * KK + r) << 1) + (ci & 1)) * LDA + co] = (m0 + co < p.M && c * KC + kk < p.K) ? ra[i] : 0.f;
             }
         }
+        const uint32_t live = c == nch - 1 ? tail : 0xFFFFFFFFu;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int idx = t + i * 256;
-            if (idx < PATCH) Ps[idx] = poff[i] >= 0 ? rp[i] : 0.f;
+            if (idx < PATCH) Ps[idx] = (poff[i] >= 0 && ((live >> i) & 1)) ? rp[i] : 0.f;
         }
     };
 
@@ -156,7 +164,7 @@ __global__ __launch_bounds__(256, (PACKED && KS != 7 && S == 1) ? 4 : 1) void k_
     if (c_beg < c_end) {
         load_chunk(c_beg);
         for (int c = c_beg; c < c_end; ++c) {
-            stage();
+            stage(c);
             __syncthreads();
             if (c + 1 < c_end) load_chunk(c + 1);  // in flight under the MFMA phase
 #pragma unroll
@@ -174,6 +182,26 @@ __global__ __launch_bounds__(256, (PACKED && KS != 7 && S == 1) ? 4 : 1) void k_
     }
 
     // ---- epilogue: acc[r] -> channel (r&3) + 8*(r>>2) + 4*half, pixel l31 of the sub-tile ----
+    if constexpr (WIDE_NCHW) {
+        const bool wide = p.dmode == DMODE_NCHW && p.splits == 1 && !p.defer_epilogue && (p.Wout & 3) == 0 &&
+                          (((uintptr_t)p.D | (uintptr_t)p.residual) & 15) == 0 && !p.no_wide_epilogue;
+        if (wide) {   // (uniform; the K loop ended on a barrier, the operand tiles are dead)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    smem[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * LDC + (wn * TN + tn) * 32 + l31] = acc[tn][r];
+            __syncthreads();
+            nchw_wide_store<BM, BN, LDC>(p, smem, m0, [&](int nl, int& img, int& pp) {
+                const int il = nl / (PTH * PTW), ph = (nl / PTW) % PTH, pw = nl % PTW;
+                img = img0 + il;
+                const int ho = ho0 + ph, wo = wo0 + pw;
+                pp = ho * p.Wout + wo;
+                return img < nimg && ho < p.Hout && wo < p.Wout;   // (Wout % 4 == 0: a quad is in or out whole)
+            });
+            return;
+        }
+    }
     if constexpr (KS == 2) {
         if (up2x4_wide_ok(p)) {   // (uniform; the K loop ended on a barrier, the operand tiles are dead)
 #pragma unroll
@@ -214,7 +242,7 @@ __global__ __launch_bounds__(256, (PACKED && KS != 7 && S == 1) ? 4 : 1) void k_
 __global__ __launch_bounds__(256) void k_conv_pack_weights(const float* __restrict__ W, int M, int Cin, int KS, int BM,
                                                            float* __restrict__ out) {
     const int KK = KS * KS, CI = conv_direct_ci(KS), KC = CI * KK, LDA = BM + 4;
-    const int nch = Cin / CI;
+    const int nch = (Cin + CI - 1) / CI;
     const int64_t total = (int64_t)((M + BM - 1) / BM) * nch * KC * LDA;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
@@ -226,7 +254,7 @@ __global__ __launch_bounds__(256) void k_conv_pack_weights(const float* __restri
     const int cp = q / KK, r = q - cp * KK;
     const int ci = c * CI + cp * 2 + par;
     const int m = mb * BM + col;
-    out[idx] = (col < BM && m < M) ? W[((int64_t)m * Cin + ci) * KK + r] : 0.f;
+    out[idx] = (col < BM && m < M && ci < Cin) ? W[((int64_t)m * Cin + ci) * KK + r] : 0.f;
 }
 
 template <int KS, int PTW, int PTH, int IMGS, int S = 1>
@@ -465,9 +493,11 @@ int ivln_conv_direct_launch(ivln_gemm_desc& d, hipStream_t s) {
     const int KS = conv_ks(d.bmode);
     static const bool no_s2 = getenv("IVLN_NO_DIRECT_CONV_S2") != nullptr;  // A/B switch
     if (disabled || KS == 0 || d.amode != AMODE_MK || d.dil != 1) return IVLN_E_UNSUPPORTED;
-    if (d.stride != 1 && !(d.stride == 2 && KS == 3 && !no_s2)) return IVLN_E_UNSUPPORTED;
+    if (d.stride != 1 && !(d.stride == 2 && KS != 2 && !no_s2)) return IVLN_E_UNSUPPORTED;
     const int CI = conv_direct_ci(KS);
-    if (d.Cin % CI != 0 || d.K != d.Cin * KS * KS || d.HoWo != d.Hout * d.Wout || d.N % d.HoWo != 0)
+    // (channel counts that do not fill the last chunk: only the stride-2 7x7 stems - 1 and 3 input channels)
+    if ((d.Cin % CI != 0 && !(KS == 7 && d.stride == 2)) || d.K != d.Cin * KS * KS || d.HoWo != d.Hout * d.Wout ||
+        d.N % d.HoWo != 0)
         return IVLN_E_UNSUPPORTED;
     const int nimg = d.N / d.HoWo;
     if ((int64_t)nimg * d.in_img_stride >= (int64_t)1 << 31) return IVLN_E_UNSUPPORTED;  // 32-bit patch offsets
@@ -478,7 +508,7 @@ int ivln_conv_direct_launch(ivln_gemm_desc& d, hipStream_t s) {
     const int64_t tiles = (int64_t)((d.Wout + PTW - 1) / PTW) * ((d.Hout + PTH - 1) / PTH) * ((nimg + IMGS - 1) / IMGS);
     const int BM = d.M <= 32 ? 32 : 64;
     const int64_t blocks = tiles * ((d.M + BM - 1) / BM);
-    const int nch = d.Cin / CI;
+    const int nch = (d.Cin + CI - 1) / CI;
     // pixel-starved shapes (rollout batch, 4x4 / 8x8 tails): the implicit GEMM splits K far deeper than the
     // 16 channel-chunk splits available here and measured faster below these grid sizes
     if (d.tile_override == 0 && (KS == 7 ? blocks < 16 : blocks * (nch < 16 ? nch : 16) < 128)) return IVLN_E_UNSUPPORTED;
@@ -502,7 +532,8 @@ int ivln_conv_direct_launch(ivln_gemm_desc& d, hipStream_t s) {
     const int cps = (nch + splits - 1) / splits;
     splits = (nch + cps - 1) / cps;
     d.splits = splits;
-    if (KS == 7) launch_ks<7>(d, s, nimg, cps);
+    if (KS == 7 && d.stride == 2) launch_ks<7, 2>(d, s, nimg, cps);
+    else if (KS == 7) launch_ks<7>(d, s, nimg, cps);
     else if (KS == 2) launch_ks<2>(d, s, nimg, cps);
     else if (d.stride == 2) launch_ks<3, 2>(d, s, nimg, cps);
     else launch_ks<3>(d, s, nimg, cps);
@@ -551,8 +582,8 @@ int ivln_wgrad_direct_launch(ivln_gemm_desc& d, hipStream_t s) {
 extern "C" int64_t ivln_conv_packed_floats(int M, int Cin, int KS) {
     if ((KS != 2 && KS != 3 && KS != 7) || M <= 0) return 0;
     const int CI = conv_direct_ci(KS), BM = M <= 32 ? 32 : 64;
-    if (Cin % CI) return 0;
-    return (int64_t)((M + BM - 1) / BM) * (Cin / CI) * (CI * KS * KS) * (BM + 4);
+    if (Cin % CI && KS != 7) return 0;  // (ragged channel chunks: the 7x7 stems only)
+    return (int64_t)((M + BM - 1) / BM) * ((Cin + CI - 1) / CI) * (CI * KS * KS) * (BM + 4);
 }
 
 extern "C" int ivln_conv_pack_weights_f32(const float* W, int M, int Cin, int KS, float* out, void* stream) {

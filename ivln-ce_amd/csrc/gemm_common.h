@@ -168,6 +168,40 @@ __device__ __forceinline__ void up2x4_wide_store(const ivln_gemm_desc& p, const 
         *reinterpret_cast<float4*>(p.D + addr) = v;
     }
 }
+// DMODE_NCHW tile -> D through LDS: T ([BM][LDC], rows m - m0, columns = the tile's pixels in an order where 4j .. 4j+3
+// are four horizontally adjacent pixels) leaves as one 16-byte store per (channel, pixel quad) instead of the MFMA
+// layout's 4-byte stores (a lane holds four ROWS of one column).  pix(nl, img, pp) -> false when column nl of the
+// tile is outside the problem; pp = pixel index inside the image.
+template <int BM, int BN, int LDC, typename Pix>
+__device__ __forceinline__ void nchw_wide_store(const ivln_gemm_desc& p, const float* T, int m0, Pix pix) {
+    for (int idx = threadIdx.x; idx < BM * (BN / 4); idx += 256) {
+        const int ml = idx / (BN / 4), c4 = idx - ml * (BN / 4);
+        const int m = m0 + ml;
+        int img, pp;
+        if (m >= p.M || !pix(4 * c4, img, pp)) continue;
+        float4 v = *reinterpret_cast<const float4*>(T + ml * LDC + c4 * 4);
+        const int64_t addr = ((int64_t)img * p.Ctot + m) * p.HoWo + pp;
+        const int me = p.grp_imgs > 0 ? (img / p.grp_imgs) * p.M + m : m;
+        if (p.scale) {
+            const float sc = p.scale[me], sh = p.shift[me];
+            v.x = fmaf(v.x, sc, sh), v.y = fmaf(v.y, sc, sh), v.z = fmaf(v.z, sc, sh), v.w = fmaf(v.w, sc, sh);
+        } else if (p.shift) {
+            const float sh = p.shift[me];
+            v.x += sh, v.y += sh, v.z += sh, v.w += sh;
+        }
+        if (p.residual) {
+            const float4 rr = *reinterpret_cast<const float4*>(p.residual + addr);
+            v.x += rr.x, v.y += rr.y, v.z += rr.z, v.w += rr.w;
+        }
+        if (p.accumulate) {
+            const float4 rr = *reinterpret_cast<const float4*>(p.D + addr);
+            v.x += rr.x, v.y += rr.y, v.z += rr.z, v.w += rr.w;
+        }
+        if (p.relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+        *reinterpret_cast<float4*>(p.D + addr) = v;
+    }
+}
+
 // (uniform) may this launch use up2x4_wide_store: even class-grid width so that pixel pairs share a row and every
 // 16-byte store is aligned
 __device__ __forceinline__ bool up2x4_wide_ok(const ivln_gemm_desc& p) {

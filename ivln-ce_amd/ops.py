@@ -359,7 +359,7 @@ def conv2d(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, 
         d.bmode = B_CONV1X1
     elif KH == KW and KH in (3, 7) and dil == 1:
         d.bmode = B_CONV_K3 if KH == 3 else B_CONV_K7
-        if (stride == 1 or (stride == 2 and KH == 3)) and PACK_WEIGHTS and w.is_contiguous():
+        if stride in (1, 2) and PACK_WEIGHTS and w.is_contiguous():
             pk = packed_conv_weights(w, cache=not weight_is_temp)
             if pk is not None:
                 d.A_packed = dptr(pk)

@@ -18,7 +18,9 @@ def _close(got, ref, atol, rtol=1e-4):
 @pytest.mark.parametrize(
     "N,Cin,H,W,Cout,k,s,p",
     [
-        (2, 1, 128, 128, 32, 7, 2, 3),    # DD-PPO stem
+        (2, 1, 128, 128, 32, 7, 2, 3),    # DD-PPO stem (direct 7x7 at stride 2; the one input channel half-fills a chunk)
+        (4, 3, 256, 256, 64, 7, 2, 3),    # RedNet's RGB stem: three channels = a full chunk + a ragged one
+        (3, 1, 250, 250, 64, 7, 2, 3),    # RedNet's depth stem, ragged 125x125 output
         (4, 32, 32, 32, 32, 3, 1, 1),     # layer1 3x3 (M<=32 -> 32x128 tile)
         (3, 128, 32, 32, 64, 1, 1, 0),    # 1x1
         (2, 128, 32, 32, 256, 1, 2, 0),   # strided 1x1 downsample (float4-staged GEMM, two columns per 16-byte load)
