@@ -25,6 +25,14 @@
 //    step against 0.977 ms for the phase launches and 0.988 ms for the unfused chain - four barriers over 512
 //    workgroups cost ~25 us each, five times a kernel boundary inside a replayed graph - and its replays under
 //    hipGraph were not bit-reproducible in the test suite.  It was dropped; DESIGN.md section 3 keeps the numbers.
+//    Round 3 priced that barrier on its own (tools/barrier_bench.hip, profiles/r03_barrier_bench.txt): the form used
+//    here - flat counter, fences on both sides - costs 26.6 us at 512 workgroups, which is the 25 us seen; the
+//    XCD-hierarchical form 6.7 us, the fence-free form with write-through payload 4.2 us at 256 workgroups.  Four of the
+//    best of those (the phases need ~512 workgroups: 15 MB of weights, one output per workgroup) still cost more than
+//    four launch boundaries of a replayed graph (3-4 us each, tools/chain_bench.hip), so the phase launches stay.  (The
+//    replay irreproducibility was not chased once the form had lost on time; the persistent sequence GRU, csrc/gru_seq.hip,
+//    where the exchange is small enough to win, zeroes its counters with a memset node per launch, reads the exchanged
+//    state with sc1 loads only, and is tested for reproducibility under load.)
 //
 // Weights (15 MB fp32) are spread over the grid: a WORKGROUP owns one output (hidden unit / linear output), 64 / 32 /
 // 16 lanes share a batch row and split K in 16-byte loads (4 / 8 / 16 rows in flight); nothing here is MFMA-shaped
