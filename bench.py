@@ -77,7 +77,7 @@ class GemmTimer:
     stop event of its own (hipExtLaunchKernelGGL: the dispatch's begin and end timestamps, the per-kernel figure
     rocprofv3 reports), summed.  FLOPs: counted at the Python entry points from the shapes."""
 
-    MAX_LAUNCHES = 1 << 15
+    MAX_LAUNCHES = 1 << 12
 
     def __init__(self):
         self.flops = 0
