@@ -902,3 +902,30 @@ def test_family_timing_sink_counts_launches_and_leaves_results_alone():
     assert n.value == 2 and dropped.value == 1 and 0.0 < ms.value < 5.0
     assert torch.equal(got3, ref3) and torch.equal(got1, ref1) and torch.equal(extra, ref1)
     assert L.ivln_family_timing_end(C.byref(ms), C.byref(n), C.byref(dropped)) != 0  # not armed any more
+
+
+@pytest.mark.parametrize("N,Cin,H,W,Cout,k,s,p", [(8, 512, 8, 8, 512, 3, 1, 1), (4, 256, 16, 16, 256, 3, 1, 1), (2, 64, 64, 64, 64, 3, 1, 1),
+                                                   (2, 64, 64, 64, 256, 1, 1, 0), (4, 3, 128, 128, 64, 7, 2, 3)])
+def test_wide_and_narrow_epilogues_store_the_same_values(N, Cin, H, W, Cout, k, s, p):
+    """NCHW tiles through LDS as 16-byte stores (k_gemm_vec, k_conv_direct, the 16-byte split-K reduction) against the
+    MFMA layout's 4-byte stores (`ivln_gemm_desc.no_wide_epilogue`): bit-identical outputs, fused scale / shift /
+    residual / ReLU included, split or not."""
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(N + Cin + k)
+    x = torch.randn(N, Cin, H, W, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).to(DEV)
+    sc, sh = (torch.rand(Cout, generator=g) + 0.5).to(DEV), torch.randn(Cout, generator=g).to(DEV)
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    res = torch.randn(N, Cout, Ho, Wo, generator=g).to(DEV)
+    saved = ops.NO_WIDE_EPILOGUE
+    out = []
+    try:
+        for narrow in (False, True):
+            ops.NO_WIDE_EPILOGUE = narrow
+            out.append(ops.conv2d(x, w, stride=s, pad=p, scale=sc, shift=sh, residual=res, relu=True))
+    finally:
+        ops.NO_WIDE_EPILOGUE = saved
+    assert torch.equal(out[0], out[1])
+    ref = F.relu(F.conv2d(x.cpu(), w.cpu(), None, s, p) * sc.cpu().view(1, -1, 1, 1) + sh.cpu().view(1, -1, 1, 1) + res.cpu())
+    _close(out[0], ref, 3e-5)

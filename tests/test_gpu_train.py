@@ -543,3 +543,53 @@ def test_sampled_collection_replays_as_graphs_bit_identical_to_eager(tmp_path, t
     # captured steps must leave exactly the eager loop's buffers behind (the capture warm-up's updates are undone)
     for k, v in stores[(True, "buffers")].items():
         assert torch.equal(v, stores[(False, "buffers")][k]), k
+
+
+def test_update_on_the_dedicated_work_stream_equals_the_update_on_the_callers_stream():
+    """`ops.eager_work_stream` (trainers.update_agent): the update runs on a stream that never launches hipGraphs and is
+    ordered behind / in front of the caller's stream - same loss, same gradients as with the switch off, and the
+    caller's stream sees the results without any synchronisation of its own."""
+    from test_gpu_policy import make_policy
+
+    from ivln_ce_amd import ops
+    from ivln_ce_amd.aux_losses import AuxLosses
+    from ivln_ce_amd.trainers import FlatAdam, update_agent
+
+    T, N = 6, 3
+    TN = T * N
+    g = torch.Generator().manual_seed(21)
+    instr = torch.zeros(N, 200)
+    instr[:, :25] = torch.randint(2, 2504, (N, 25), generator=g).float()
+    obs_h = {"depth_features": torch.randn(TN, 128, 4, 4, generator=g),
+             "occupancy_map": (torch.rand(TN, 64, 64, generator=g) < 0.3).float(),
+             "semantic_map": torch.randint(0, 13, (TN, 64, 64), generator=g).float(),
+             "instruction": instr.repeat(T, 1), "progress": torch.rand(TN, 1, generator=g)}
+    prev = torch.randint(0, 4, (TN, 1), generator=g)
+    nd = torch.ones(T, N, dtype=torch.uint8)
+    nd[0] = 0
+    tgt = torch.randint(0, 4, (T, N), generator=g)
+    w = torch.ones(T, N)
+    res = []
+    saved = ops.EAGER_WORK_STREAM
+    try:
+        for on in (False, True):
+            ops.EAGER_WORK_STREAM = on
+            pol = make_policy(use_pm=True, train=True)
+            opt = FlatAdam(pol, lr=2.5e-4)
+            obs = {k: v.float().to(DEV) for k, v in obs_h.items()}
+            AuxLosses.activate()
+            try:
+                loss = update_agent(pol, opt, obs, prev.to(DEV), nd.view(-1, 1).to(DEV), tgt.to(DEV), w.to(DEV),
+                                    step_grad=False)
+            finally:
+                AuxLosses.deactivate()
+            # read on the caller's (null) stream, no synchronize: the region's exit ordered it behind the work stream
+            res.append((loss, {k: p.grad.detach().clone() for k, p in pol.named_parameters() if p.requires_grad}))
+            assert torch.cuda.current_stream() == torch.cuda.default_stream()
+    finally:
+        ops.EAGER_WORK_STREAM = saved
+    (l0, g0), (l1, g1) = res
+    assert l0 == l1, (l0, l1)
+    for k in g0:  # (the embedding gradient accumulates with atomics: equal to the last bits, not bit for bit)
+        a, b = g0[k], g1[k]
+        assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(a.abs().max())), k
