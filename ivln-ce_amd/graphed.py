@@ -261,6 +261,8 @@ class GraphedRollout:
         # (launching gB1 - RedNet with predicted semantics, the critical chain there - BEFORE gA was measured in round 3:
         #  5.485 vs 5.480 ms per step at 8 envs, no difference; the 0.8 ms hole in front of RedNet in a traced timeline is
         #  the tracer's slower graph launches)
+        # (gB1 on a third, CU-masked stream - hipExtStreamCreateWithCUMask, 32..192 CUs, contiguous or strided masks - so that
+        #  the map CNN's large grids stop crowding the chain: measured 0.79-0.83 ms per step against 0.708, round 3)
         self.gB1[self.phase].replay()
         main.wait_event(self.ev_A)
         self.graphs[self.phase].replay()
