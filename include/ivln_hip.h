@@ -175,6 +175,14 @@ typedef struct ivln_gemm_desc {
      * and writing 16 bytes per lane along the pixel index (csrc/gemm_vec.hip; A/B measurements and tests).  Results
      * are identical either way. */
     int no_wide_epilogue;
+    /* Optional per-tile statistics of what the launch STORES (BatchNorm in train mode right behind the conv, map_encoder.py:
+     * 13-20): when the direct conv kernel takes its wide NCHW epilogue (stride-1/2 3x3 / 7x7 / 2x2, splits == 1,
+     * Wout % 4 == 0) every (pixel tile, output channel) leaves {count, mean, M2} = Welford partials of its <= 128 stored
+     * values in stat_partials[(tile*M + m)*3 ..]; *stat_tiles (host) receives the number of pixel tiles, or 0 when the
+     * launch went another way and wrote nothing (the caller then runs ivln_bn_train_stats_f32).  Merged in a fixed order
+     * by ivln_bn_stats_from_partials_f32. */
+    float* stat_partials;
+    int* stat_tiles;
 } ivln_gemm_desc;
 
 int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream);
@@ -351,6 +359,13 @@ int ivln_bn_train_stats_f32(const float* x, int N, int C, int HW, const float* g
                             float* scale, float* shift, float* save_mean, float* save_rstd,
                             float* ws /* scratch, >= 3*C floats (3*C*64 for full parallelism) */,
                             int64_t ws_floats, void* stream);
+
+/* The same outputs from the per-tile partials a conv launch left behind (ivln_gemm_desc.stat_partials: [tiles][C][3] =
+ * {count, mean, M2}), merged per channel in a fixed order with Chan's formula - the statistics pass over the conv's
+ * output (two reads of the whole tensor) is not needed. */
+int ivln_bn_stats_from_partials_f32(const float* partials, int tiles, int C, const float* gamma, const float* beta,
+                                    float* running_mean, float* running_var, float momentum, float eps, float* scale,
+                                    float* shift, float* save_mean, float* save_rstd, void* stream);
 /* CBRA tail: relu(x*scale+shift) then AvgPool2d(2) (map_encoder.py:16-19). */
 int ivln_scale_shift_relu_avgpool2_f32(const float* x, const float* scale, const float* shift, float* y,
                                        int N, int C, int H, int W, int64_t img_stride, int64_t chan_stride,

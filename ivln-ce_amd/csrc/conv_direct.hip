@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256, (PACKED && KS != 7 && S == 1) ? 4 : 1) void k_
                 const int ho = ho0 + ph, wo = wo0 + pw;
                 pp = ho * p.Wout + wo;
                 return img < nimg && ho < p.Hout && wo < p.Wout;   // (Wout % 4 == 0: a quad is in or out whole)
-            });
+            }, p.stat_partials ? p.stat_partials + (int64_t)bx * p.M * 3 : nullptr);
             return;
         }
     }
@@ -532,6 +532,11 @@ int ivln_conv_direct_launch(ivln_gemm_desc& d, hipStream_t s) {
     const int cps = (nch + splits - 1) / splits;
     splits = (nch + cps - 1) / cps;
     d.splits = splits;
+    // per-tile statistics ride in the wide NCHW epilogue only (same test as in the kernel)
+    const bool wide = d.dmode == DMODE_NCHW && splits == 1 && !d.defer_epilogue && (d.Wout & 3) == 0 &&
+                      (((uintptr_t)d.D | (uintptr_t)d.residual) & 15) == 0 && !d.no_wide_epilogue;
+    if (!wide) d.stat_partials = nullptr;
+    if (d.stat_tiles) *d.stat_tiles = d.stat_partials ? (int)tiles : 0;
     if (KS == 7 && d.stride == 2) launch_ks<7, 2>(d, s, nimg, cps);
     else if (KS == 7) launch_ks<7>(d, s, nimg, cps);
     else if (KS == 2) launch_ks<2>(d, s, nimg, cps);

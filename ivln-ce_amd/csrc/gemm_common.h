@@ -173,32 +173,53 @@ __device__ __forceinline__ void up2x4_wide_store(const ivln_gemm_desc& p, const 
 // layout's 4-byte stores (a lane holds four ROWS of one column).  pix(nl, img, pp) -> false when column nl of the
 // tile is outside the problem; pp = pixel index inside the image.
 template <int BM, int BN, int LDC, typename Pix>
-__device__ __forceinline__ void nchw_wide_store(const ivln_gemm_desc& p, const float* T, int m0, Pix pix) {
+__device__ __forceinline__ void nchw_wide_store(const ivln_gemm_desc& p, const float* T, int m0, Pix pix,
+                                                float* stats = nullptr) {
+    static_assert(BN == 128 && (BM * (BN / 4)) % 256 == 0, "a row of the tile = the 32 lanes of a half-wave");
     for (int idx = threadIdx.x; idx < BM * (BN / 4); idx += 256) {
         const int ml = idx / (BN / 4), c4 = idx - ml * (BN / 4);
         const int m = m0 + ml;
-        int img, pp;
-        if (m >= p.M || !pix(4 * c4, img, pp)) continue;
-        float4 v = *reinterpret_cast<const float4*>(T + ml * LDC + c4 * 4);
-        const int64_t addr = ((int64_t)img * p.Ctot + m) * p.HoWo + pp;
-        const int me = p.grp_imgs > 0 ? (img / p.grp_imgs) * p.M + m : m;
-        if (p.scale) {
-            const float sc = p.scale[me], sh = p.shift[me];
-            v.x = fmaf(v.x, sc, sh), v.y = fmaf(v.y, sc, sh), v.z = fmaf(v.z, sc, sh), v.w = fmaf(v.w, sc, sh);
-        } else if (p.shift) {
-            const float sh = p.shift[me];
-            v.x += sh, v.y += sh, v.z += sh, v.w += sh;
+        int img = 0, pp = 0;
+        const bool ok = m < p.M && pix(4 * c4, img, pp);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) {
+            v = *reinterpret_cast<const float4*>(T + ml * LDC + c4 * 4);
+            const int64_t addr = ((int64_t)img * p.Ctot + m) * p.HoWo + pp;
+            const int me = p.grp_imgs > 0 ? (img / p.grp_imgs) * p.M + m : m;
+            if (p.scale) {
+                const float sc = p.scale[me], sh = p.shift[me];
+                v.x = fmaf(v.x, sc, sh), v.y = fmaf(v.y, sc, sh), v.z = fmaf(v.z, sc, sh), v.w = fmaf(v.w, sc, sh);
+            } else if (p.shift) {
+                const float sh = p.shift[me];
+                v.x += sh, v.y += sh, v.z += sh, v.w += sh;
+            }
+            if (p.residual) {
+                const float4 rr = *reinterpret_cast<const float4*>(p.residual + addr);
+                v.x += rr.x, v.y += rr.y, v.z += rr.z, v.w += rr.w;
+            }
+            if (p.accumulate) {
+                const float4 rr = *reinterpret_cast<const float4*>(p.D + addr);
+                v.x += rr.x, v.y += rr.y, v.z += rr.z, v.w += rr.w;
+            }
+            if (p.relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+            *reinterpret_cast<float4*>(p.D + addr) = v;
         }
-        if (p.residual) {
-            const float4 rr = *reinterpret_cast<const float4*>(p.residual + addr);
-            v.x += rr.x, v.y += rr.y, v.z += rr.z, v.w += rr.w;
+        if (stats) {  // (uniform) {count, mean, M2} of the row's stored values: two half-wave reductions, like the two passes
+                      // of k_bn_stats_partial, on values that are in registers anyway
+            float cnt = ok ? 4.f : 0.f, sum = ok ? (v.x + v.y) + (v.z + v.w) : 0.f;
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o), sum += __shfl_xor(sum, o);
+            const float mean = cnt > 0.f ? sum / cnt : 0.f;
+            const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+            float q = ok ? (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) : 0.f;
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o);
+            if ((threadIdx.x & 31) == 0 && m < p.M) {
+                stats[m * 3 + 0] = cnt;
+                stats[m * 3 + 1] = mean;
+                stats[m * 3 + 2] = q;
+            }
         }
-        if (p.accumulate) {
-            const float4 rr = *reinterpret_cast<const float4*>(p.D + addr);
-            v.x += rr.x, v.y += rr.y, v.z += rr.z, v.w += rr.w;
-        }
-        if (p.relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
-        *reinterpret_cast<float4*>(p.D + addr) = v;
     }
 }
 

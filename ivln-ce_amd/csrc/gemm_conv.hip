@@ -435,6 +435,7 @@ extern "C" int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream) {
     if (no_xcd_env) d.no_xcd_remap = 1;
     if (d.HoWo <= 0) d.HoWo = 1;
     if (d.dil <= 0) d.dil = 1;
+    if (d.stat_tiles) *d.stat_tiles = 0;  // (only the direct conv's wide epilogue produces statistics and says so)
     if (d.dmode == DMODE_NCHW_UP2X4 && (d.M & 3)) return IVLN_E_INVALID;
     if (d.Ctot <= 0) d.Ctot = d.dmode == DMODE_NCHW_UP2X4 ? d.M / 4 : d.M;
     if (d.in_img_stride <= 0) d.in_img_stride = (int64_t)d.Cin * d.Hin * d.Win;

@@ -366,6 +366,60 @@ __global__ void k_bn_stats_final(const float* __restrict__ partial, int S, int C
     }
 }
 
+// The same finish from the per-tile partials a conv launch left in its epilogue (ivln_gemm_desc.stat_partials:
+// [tiles][C][3]): one block per channel; thread t folds tiles t, t+256, ... in order, then the 256 running triples are
+// folded pairwise in LDS (a fixed tree: the result does not depend on the launch).
+__global__ __launch_bounds__(256) void k_bn_stats_from_tiles(const float* __restrict__ partial, int tiles, int C,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float* __restrict__ rmean,
+                                                             float* __restrict__ rvar, float momentum, float eps,
+                                                             float* __restrict__ scale, float* __restrict__ shift,
+                                                             float* __restrict__ save_mean,
+                                                             float* __restrict__ save_rstd) {
+    __shared__ float sn[256], sm[256], sq[256];
+    const int c = blockIdx.x, t = threadIdx.x;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int i = t; i < tiles; i += 256) {
+        const float* o = partial + ((int64_t)i * C + c) * 3;
+        const float nb = o[0];
+        if (nb <= 0.f) continue;
+        const float delta = o[1] - mean, nn = n + nb;
+        mean += delta * (nb / nn);
+        m2 += o[2] + delta * delta * (n * nb / nn);
+        n = nn;
+    }
+    sn[t] = n, sm[t] = mean, sq[t] = m2;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (t < w) {
+            const float na = sn[t], nb = sn[t + w];
+            if (nb > 0.f) {
+                const float delta = sm[t + w] - sm[t], nn = na + nb;
+                sm[t] += delta * (nb / nn);
+                sq[t] += sq[t + w] + delta * delta * (na * nb / nn);
+                sn[t] = nn;
+            }
+        }
+        __syncthreads();
+    }
+    if (t != 0) return;
+    n = sn[0], mean = sm[0], m2 = sq[0];
+    const float var = n > 0.f ? m2 / n : 0.f;
+    const float rstd = 1.f / sqrtf(var + eps);
+    const float sc = gamma[c] * rstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - mean * sc;
+    if (save_mean) {
+        save_mean[c] = mean;
+        save_rstd[c] = rstd;
+    }
+    if (rmean) {
+        const float unbiased = n > 1.f ? m2 / (n - 1.f) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * unbiased;
+    }
+}
+
 // y[n,c,ho,wo] = mean over the 2x2 window of relu(x*scale[c] + shift[c])   (CBRA tail:
 // BatchNorm2d -> ReLU -> AvgPool2d(2), models/encoders/map_encoder.py:13-20).  x is NCHW
 // (chan_stride = H*W, img_stride = C*H*W) or the producing conv's split-K slabs ([C][N*H*W]:
@@ -1382,6 +1436,15 @@ int ivln_bn_train_stats_f32(const float* x, int N, int C, int HW, const float* g
     S = (N + ips - 1) / ips;
     hipLaunchKernelGGL(k_bn_stats_partial, dim3(C, S), dim3(256), 0, (hipStream_t)stream, x, N, C, HW, ips, ws);
     hipLaunchKernelGGL(k_bn_stats_final, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, ws, S, C, gamma, beta,
+                       running_mean, running_var, momentum, eps, scale, shift, save_mean, save_rstd);
+    return LAUNCH_OK();
+}
+
+int ivln_bn_stats_from_partials_f32(const float* partials, int tiles, int C, const float* gamma, const float* beta,
+                                    float* running_mean, float* running_var, float momentum, float eps, float* scale,
+                                    float* shift, float* save_mean, float* save_rstd, void* stream) {
+    if (!partials || tiles <= 0 || C <= 0 || !gamma || !beta || !scale || !shift) return IVLN_E_INVALID;
+    hipLaunchKernelGGL(k_bn_stats_from_tiles, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, tiles, C, gamma, beta,
                        running_mean, running_var, momentum, eps, scale, shift, save_mean, save_rstd);
     return LAUNCH_OK();
 }

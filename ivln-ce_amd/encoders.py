@@ -36,7 +36,10 @@ class CBRA(nn.Module):
 
     def forward_hip(self, x, save=None):
         conv, bn = self.conv[0], self.conv[1]
-        y = ops.conv2d(x, conv.weight, stride=1, pad=3, shift=conv.bias)
+        # train mode: the conv's epilogue leaves per-tile {count, mean, M2} of what it stores, so the BatchNorm statistics
+        # need no pass of their own over y (two reads of the largest tensors of the update)
+        stats = [] if (bn.training and ops.CONV_STATS) else None
+        y = ops.conv2d(x, conv.weight, stride=1, pad=3, shift=conv.bias, stats=stats)
         C = bn.num_features
         scale = torch.empty(C, dtype=torch.float32, device=x.device)
         shift = torch.empty(C, dtype=torch.float32, device=x.device)
@@ -45,7 +48,10 @@ class CBRA(nn.Module):
             if save is not None:
                 sm = torch.empty(C, dtype=torch.float32, device=x.device)
                 sr = torch.empty(C, dtype=torch.float32, device=x.device)
-            ops.bn_train_stats(y, bn, scale, shift, sm, sr)
+            if stats:
+                ops.bn_stats_from_partials(stats[0][0], stats[0][1], bn, scale, shift, sm, sr)
+            else:  # (the launch went another way - split K, scalar-gather GEMM: statistics from y)
+                ops.bn_train_stats(y, bn, scale, shift, sm, sr)
             if bn.num_batches_tracked is not None:
                 bn.num_batches_tracked += 1
             if save is not None:

@@ -39,6 +39,7 @@ class GemmDesc(C.Structure):
         ("no_xcd_remap", i32),
         ("grp_imgs", i32), ("a_grp_stride", i64), ("a_packed_grp_stride", i64),
         ("no_wide_epilogue", i32),
+        ("stat_partials", vp), ("stat_tiles", C.POINTER(i32)),
     ]
 
 
@@ -329,8 +330,22 @@ class Deferred:
         self.ws, self.splits, self.N, self.C, self.H, self.W = ws, splits, N, C, H, W
 
 
+_stat_ws = {}
+CONV_STATS = os.environ.get("IVLN_CONV_STATS", "1") != "0"  # A/B: BatchNorm statistics from the conv's epilogue
+
+
+def conv_stat_ws(device, floats):
+    """Per-(device, stream) buffer for the per-tile statistics a conv launch leaves behind (ivln_gemm_desc.stat_partials)."""
+    key = (str(device), torch.cuda.current_stream().cuda_stream)
+    w = _stat_ws.get(key)
+    if w is None or w.numel() < floats:
+        w = torch.empty(floats, dtype=torch.float32, device=device)
+        _stat_ws[key] = w
+    return w
+
+
 def conv2d(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, relu=False, out=None, out_ctot=0,
-           in_img_stride=0, splitk=True, defer=False, ws_slot=0, weight_is_temp=False):
+           in_img_stride=0, splitk=True, defer=False, ws_slot=0, weight_is_temp=False, stats=None):
     """NCHW conv: x (N,Cin,H,W) [contiguous per image, image stride `in_img_stride`], w OIHW.
     out: optional destination (a channel slice of an (N,out_ctot,Ho,Wo) buffer)."""
     N, Cin, H, W = x.shape
@@ -381,8 +396,32 @@ def conv2d(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, 
         d.ws, d.ws_floats, d.splits = dptr(ws), ws.numel(), 0
     else:
         d.splits = 1
+    if stats is not None:  # `stats` = a list: receives (partials, tiles) when the launch produced per-tile statistics
+        tiles_max = (N * Ho * Wo + 31) // 32  # (pixel tiles hold 128 outputs; 4x headroom for ragged tilings)
+        sp = conv_stat_ws(x.device, tiles_max * Cout * 3)
+        n_tiles = i32(0)
+        d.stat_partials, d.stat_tiles = dptr(sp), C.pointer(n_tiles)
+        gemm(d)
+        if n_tiles.value > 0:
+            stats.append((sp, n_tiles.value))
+        return out
     gemm(d)
     return out
+
+
+def bn_stats_from_partials(partials, tiles, bn, scale, shift, save_mean=None, save_rstd=None, update_running=True):
+    """BatchNorm (train mode) scale / shift / saved statistics / running statistics from the per-tile partials the
+    producing conv left behind (conv2d(..., stats=[])): no pass over the conv's output."""
+    mom = bn.momentum if bn.momentum is not None else 0.1
+    L = _L()
+    L.ivln_bn_stats_from_partials_f32.argtypes = [vp, i32, i32, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp]
+    check(
+        L.ivln_bn_stats_from_partials_f32(dptr(partials), tiles, bn.num_features, dptr(bn.weight), dptr(bn.bias),
+                                          dptr(bn.running_mean) if update_running else None,
+                                          dptr(bn.running_var) if update_running else None, mom, bn.eps, dptr(scale),
+                                          dptr(shift), _p(save_mean), _p(save_rstd), stream_ptr()),
+        "ivln_bn_stats_from_partials_f32",
+    )
 
 
 def conv_transpose2d(x, w_oihw, stride, pad, out_pad, scale=None, shift=None, residual=None, relu=False, out=None):

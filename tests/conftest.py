@@ -10,6 +10,16 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The host sides of the end-to-end tests (synthetic env, batch_obs) are thousands of small CPU tensor ops; with one
+    # OpenMP thread per core of a host shared with other jobs each of them pays a crowded barrier (torch.stack of two
+    # depth frames: 1.8 ms instead of 0.1 - 400 s instead of 120 for the GPU suite on a busy box).  The oracle ports that
+    # want more threads set them themselves.
+    try:
+        import torch
+
+        torch.set_num_threads(min(4, max(1, torch.get_num_threads())))
+    except Exception:  # noqa: BLE001
+        pass
 
 
 @pytest.fixture(scope="session")
