@@ -208,8 +208,11 @@ def test_depth_encoder_chain_matches_pairwise_path_and_oracle(B, first, pair):
     space = types.SimpleNamespace(spaces={"depth": types.SimpleNamespace(shape=(256, 256, 1))})
     ref = R.ResNetEncoder(space, baseplanes=32, ngroups=16, make_backbone=R.resnet50)
     ref.load_state_dict({k: v.cpu() for k, v in enc.state_dict().items()})
+    # fp64 restatement: the fp32 CPU run is itself 1-1.5e-4 off after 50 layers, in a direction that depends on how many
+    # threads torch splits its reductions over - the bar is the HIP path's distance from the exact arithmetic
+    ref = ref.double()
     with torch.no_grad():
-        r = ref({"depth": depth})
+        r = ref({"depth": depth.double()}).float()
     assert float((a - r).abs().max()) < 2e-4, float((a - r).abs().max())
     assert np.isfinite(a.numpy()).all()
 
