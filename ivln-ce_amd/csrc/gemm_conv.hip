@@ -304,8 +304,8 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const ivln_gemm_desc p)
     epilogue_store(p, m, n, v);
 }
 
-// The same reduction four columns at a time for NCHW destinations whose images hold a multiple of four pixels: 16-byte
-// loads from every slab and one 16-byte store (RedNet's split 3x3 convs: 38 of these per forward, 6.5 -> ~4 us each).
+// The same reduction four columns at a time - NCHW destinations whose images hold a multiple of four pixels, dense ones
+// with unit column stride (weight gradients) -: 16-byte loads from every slab and one 16-byte store.
 __global__ __launch_bounds__(256) void k_splitk_epilogue4(const ivln_gemm_desc p) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int n4 = p.N >> 2;
@@ -316,9 +316,15 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue4(const ivln_gemm_desc p
         const float4 w = *reinterpret_cast<const float4*>(p.ws + ((int64_t)z * p.M + m) * p.N + n);
         v.x += w.x, v.y += w.y, v.z += w.z, v.w += w.w;
     }
-    const int img = n / p.HoWo, pp = n - img * p.HoWo;
-    const int64_t addr = ((int64_t)img * p.Ctot + m) * p.HoWo + pp;
-    const int me = p.grp_imgs > 0 ? (img / p.grp_imgs) * p.M + m : m;
+    int64_t addr;
+    int me = m;
+    if (p.dmode == DMODE_NCHW) {
+        const int img = n / p.HoWo, pp = n - img * p.HoWo;
+        addr = ((int64_t)img * p.Ctot + m) * p.HoWo + pp;
+        if (p.grp_imgs > 0) me = (img / p.grp_imgs) * p.M + m;
+    } else {  // DMODE_DENSE with unit column stride (weight gradients: D[m][n])
+        addr = (int64_t)m * p.sDm + n;
+    }
     if (p.scale) {
         const float sc = p.scale[me], sh = p.shift[me];
         v.x = fmaf(v.x, sc, sh), v.y = fmaf(v.y, sc, sh), v.z = fmaf(v.z, sc, sh), v.w = fmaf(v.w, sc, sh);
@@ -340,7 +346,8 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue4(const ivln_gemm_desc p
 
 // reduce the split-K slabs of d into D with the fused epilogue
 void launch_splitk_epilogue(const ivln_gemm_desc& d, hipStream_t s) {
-    const bool vec4 = d.dmode == DMODE_NCHW && (d.HoWo & 3) == 0 && (d.N & 3) == 0 && !d.no_wide_epilogue &&
+    const bool lay = (d.dmode == DMODE_NCHW && (d.HoWo & 3) == 0) || (d.dmode == DMODE_DENSE && d.sDn == 1 && (d.sDm & 3) == 0);
+    const bool vec4 = lay && (d.N & 3) == 0 && !d.no_wide_epilogue &&
                       (((uintptr_t)d.D | (uintptr_t)d.residual | (uintptr_t)d.ws) & 15) == 0;
     if (vec4) {
         const int64_t total = (int64_t)d.M * (d.N >> 2);
