@@ -324,9 +324,6 @@ def bench_update(policy, dev, world, barrier, T=64, N=8, iters=5, warm=2):
         t0 = time.perf_counter()
         for _ in range(iters):
             update_agent(policy, opt, obs, prev, nd, tgt, w, world=world)
-            if os.environ.get("IVLN_BENCH_DEBUG"):
-                torch.cuda.synchronize()
-                log(f"update iter at {1e3 * (time.perf_counter() - t0):.2f} ms")
         barrier()
         el = time.perf_counter() - t0
         # MFMA kernel family of one update (instrumented pass, outside the timed region).  The event pairs sum
@@ -572,8 +569,6 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
-    if os.environ.get("IVLN_BENCH_STREAM"):  # experiment: the whole bench off HIP's null stream
-        torch.cuda.set_stream(torch.cuda.Stream())
     dev = torch.device("cuda", local_rank)
 
     import __graft_entry__ as ge
