@@ -56,8 +56,15 @@ def check(code: int, what: str = ""):
         raise IvlnError(f"{what}: {lib().ivln_strerror(code).decode()} ({code})")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr() -> int:
-    """hipStream_t of torch's current stream (so torch.cuda.graph capture sees our launches)."""
+    """hipStream_t of torch's current stream (so torch.cuda.graph capture sees our launches).  Through torch's raw
+    accessor when it exists: `torch.cuda.current_stream()` builds a Stream object and resolves the device index on every
+    call (~10 us - as much as the dispatch of the launch it precedes in an eager rollout step)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

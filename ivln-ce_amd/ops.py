@@ -179,7 +179,7 @@ def splitk_ws(device, floats=8 << 20, slot=0):
     """Split-K / deferred-epilogue workspace, one per (device, stream): concurrent branches of the
     captured step graph must not share it.  slot 1 is a second workspace for a deferred conv whose slabs
     must outlive later deferred convs (the bottleneck's downsample branch)."""
-    key = (str(device), torch.cuda.current_stream().cuda_stream, slot)
+    key = (str(device), stream_ptr(), slot)
     w = _ws.get(key)
     if w is None or w.numel() < floats:
         w = torch.empty(floats, dtype=torch.float32, device=device)
@@ -336,7 +336,7 @@ CONV_STATS = os.environ.get("IVLN_CONV_STATS", "1") != "0"  # A/B: BatchNorm sta
 
 def conv_stat_ws(device, floats):
     """Per-(device, stream) buffer for the per-tile statistics a conv launch leaves behind (ivln_gemm_desc.stat_partials)."""
-    key = (str(device), torch.cuda.current_stream().cuda_stream)
+    key = (str(device), stream_ptr())
     w = _stat_ws.get(key)
     if w is None or w.numel() < floats:
         w = torch.empty(floats, dtype=torch.float32, device=device)
@@ -946,7 +946,7 @@ _red_ws = {}
 
 def _reduce_ws(device):
     """Scratch for the two-stage per-channel reductions (C * 64 splits * 3 values, per stream)."""
-    key = (str(device), torch.cuda.current_stream().cuda_stream)
+    key = (str(device), stream_ptr())
     w = _red_ws.get(key)
     if w is None:
         w = torch.empty(1 << 20, dtype=torch.float32, device=device)
@@ -1085,7 +1085,7 @@ def _seq_ws(device):
     sequences in flight on different streams must not share a counter.  None -> the per-timestep launches."""
     if not SEQ_PERSISTENT:
         return None
-    key = (str(device), torch.cuda.current_stream().cuda_stream)
+    key = (str(device), stream_ptr())
     ws = _seq_sync_ws.get(key)
     if ws is None:
         ws = _seq_sync_ws[key] = torch.zeros(64, dtype=torch.int32, device=device)
@@ -1362,7 +1362,7 @@ def colsum(x, out=None, accumulate=False):
     rows, cols = x.shape
     if out is None:
         out = torch.empty((cols,), dtype=torch.float32, device=x.device)
-    key = (str(x.device), torch.cuda.current_stream().cuda_stream)  # per stream: the training pass runs two at once
+    key = (str(x.device), stream_ptr())  # per stream: the training pass runs two at once
     ws = _colsum_ws.get(key)
     if ws is None or ws.numel() < 128 * cols:
         ws = torch.empty(max(128 * cols, 1 << 18), dtype=torch.float32, device=x.device)

@@ -358,7 +358,7 @@ class PredictSemantics:
     USE_PLAN = os.environ.get("IVLN_REDNET_PLAN", "1") != "0"
 
     def _plan_key(self, rgb, depth):
-        return (tuple(rgb.shape), tuple(depth.shape), str(depth.device), torch.cuda.current_stream().cuda_stream,
+        return (tuple(rgb.shape), tuple(depth.shape), str(depth.device), ops.stream_ptr(),
                 ops.WEIGHT_EPOCH, ops.TILE_OVERRIDE)
 
     def __call__(self, observations):
