@@ -565,7 +565,12 @@ int ivln_wgrad_direct_launch(ivln_gemm_desc& d, hipStream_t s) {
     int splits = 1;
     if (d.splits == 0) {
         if (d.ws && ntiles >= 2) {
-            splits = (int)((1024 + blocks - 1) / blocks);  // ~4 blocks per CU
+            static const int want_env = getenv("IVLN_WGRAD_BLOCKS") ? atoi(getenv("IVLN_WGRAD_BLOCKS")) : 0;  // tuning
+            // 8-16 blocks per CU: shorter blocks even out the tail of the one long wave of work (measured on the map
+            // CNN's four layers at 512 images, 1024 / 2048 / 4096 wanted blocks: layer 1 - six column tiles - 1152 /
+            // 1086 / 1009 us, layer 2 1165 / 1122 / 1135 us, layers 3-4 unchanged)
+            const int64_t want = want_env > 0 ? want_env : (blocks <= 8 ? 4096 : 2048);
+            splits = (int)((want + blocks - 1) / blocks);
             if (splits > ntiles) splits = ntiles;
             if (splits > 512) splits = 512;
             const int64_t cap = d.ws_floats / ((int64_t)d.M * d.N);
