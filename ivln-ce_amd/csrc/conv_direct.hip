@@ -516,8 +516,10 @@ int ivln_conv_direct_launch(ivln_gemm_desc& d, hipStream_t s) {
     if (d.defer_epilogue && (!d.ws || d.ws_floats < (int64_t)d.M * d.N)) return IVLN_E_INVALID;
     if (d.splits == 0) {
         // split the channel chunks over blockIdx.z until the grid covers the chip
-        const int64_t want = d.defer_epilogue ? 256 : 512;
-        if (d.ws && blocks < 256 && nch >= 2) {
+        static const int want_env = getenv("IVLN_DIRECT_SPLIT_WANT") ? atoi(getenv("IVLN_DIRECT_SPLIT_WANT")) : 0;  // tuning
+        static const int below_env = getenv("IVLN_DIRECT_SPLIT_BELOW") ? atoi(getenv("IVLN_DIRECT_SPLIT_BELOW")) : 0;
+        const int64_t want = (want_env > 0 && !d.defer_epilogue) ? want_env : (d.defer_epilogue ? 256 : 512);
+        if (d.ws && blocks < (below_env > 0 && !d.defer_epilogue ? below_env : 256) && nch >= 2) {
             splits = (int)((want + blocks - 1) / blocks);
             if (splits > nch) splits = nch;
             if (splits > 16) splits = 16;
