@@ -367,19 +367,19 @@ __global__ void k_bn_stats_final(const float* __restrict__ partial, int S, int C
 }
 
 // The same finish from the per-tile partials a conv launch left in its epilogue (ivln_gemm_desc.stat_partials:
-// [tiles][C][3]): one block per channel; thread t folds tiles t, t+256, ... in order, then the 256 running triples are
+// [tiles][C][3]): one block per channel; thread t folds tiles t, t+1024, ... in order, then the 1024 running triples are
 // folded pairwise in LDS (a fixed tree: the result does not depend on the launch).
-__global__ __launch_bounds__(256) void k_bn_stats_from_tiles(const float* __restrict__ partial, int tiles, int C,
+__global__ __launch_bounds__(1024) void k_bn_stats_from_tiles(const float* __restrict__ partial, int tiles, int C,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float* __restrict__ rmean,
                                                              float* __restrict__ rvar, float momentum, float eps,
                                                              float* __restrict__ scale, float* __restrict__ shift,
                                                              float* __restrict__ save_mean,
                                                              float* __restrict__ save_rstd) {
-    __shared__ float sn[256], sm[256], sq[256];
+    __shared__ float sn[1024], sm[1024], sq[1024];
     const int c = blockIdx.x, t = threadIdx.x;
     float n = 0.f, mean = 0.f, m2 = 0.f;
-    for (int i = t; i < tiles; i += 256) {
+    for (int i = t; i < tiles; i += 1024) {
         const float* o = partial + ((int64_t)i * C + c) * 3;
         const float nb = o[0];
         if (nb <= 0.f) continue;
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256) void k_bn_stats_from_tiles(const float* __rest
     }
     sn[t] = n, sm[t] = mean, sq[t] = m2;
     __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
+    for (int w = 512; w > 0; w >>= 1) {
         if (t < w) {
             const float na = sn[t], nb = sn[t + w];
             if (nb > 0.f) {
@@ -1444,7 +1444,7 @@ int ivln_bn_stats_from_partials_f32(const float* partials, int tiles, int C, con
                                     float* running_mean, float* running_var, float momentum, float eps, float* scale,
                                     float* shift, float* save_mean, float* save_rstd, void* stream) {
     if (!partials || tiles <= 0 || C <= 0 || !gamma || !beta || !scale || !shift) return IVLN_E_INVALID;
-    hipLaunchKernelGGL(k_bn_stats_from_tiles, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, tiles, C, gamma, beta,
+    hipLaunchKernelGGL(k_bn_stats_from_tiles, dim3(C), dim3(1024), 0, (hipStream_t)stream, partials, tiles, C, gamma, beta,
                        running_mean, running_var, momentum, eps, scale, shift, save_mean, save_rstd);
     return LAUNCH_OK();
 }

@@ -5,6 +5,7 @@
 // +ReLU+AvgPool backward, conv weight flip for dgrad, embedding scatter, inflection-weighted
 // cross-entropy (+ gradient), progress-monitor loss, fused flat-bucket Adam.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include <math.h>
 #include "../../include/ivln_hip.h"
@@ -111,17 +112,26 @@ __global__ __launch_bounds__(256) void k_nchw_chansum_partial(const float* __res
     s = block_sum(s, red);
     if (threadIdx.x == 0) partial[(int64_t)c * S + sp] = s;
 }
-__global__ void k_chan_final(const float* __restrict__ partial, int S, int C, int K, float* __restrict__ out0,
-                             float* __restrict__ out1) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
+// one 64-lane wave per channel: lane l adds partials l, l + 64, ... in order, then a fixed shuffle tree - the result does not
+// depend on the launch (a single thread walking all S partials took 11-30 us once the passes ran 256 splits per channel)
+__global__ __launch_bounds__(64) void k_chan_final(const float* __restrict__ partial, int S, int C, int K,
+                                                   float* __restrict__ out0, float* __restrict__ out1) {
+    const int c = blockIdx.x, l = threadIdx.x;
     if (c >= C) return;
     float a = 0.f, b2 = 0.f;
-    for (int sp = 0; sp < S; ++sp) {
+    for (int sp = l; sp < S; sp += 64) {
         a += partial[((int64_t)c * S + sp) * K];
         if (K > 1) b2 += partial[((int64_t)c * S + sp) * K + 1];
     }
-    out0[c] = a;
-    if (K > 1) out1[c] = b2;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o);
+        b2 += __shfl_xor(b2, o);
+    }
+    if (l == 0) {
+        out0[c] = a;
+        if (K > 1) out1[c] = b2;
+    }
 }
 
 // (R, C) -> (C, R)
@@ -870,9 +880,13 @@ int ivln_colsum_f32(const float* x, int64_t ld, int rows, int cols, float* out, 
 }
 
 static int chan_splits(int N, int HW, int C, int K, int64_t ws_floats) {
-    int S = (int)(((int64_t)N * HW + 16383) / 16384);
+    // >= 4 K elements per block, up to 256 blocks per channel (16 K / 64 left the BatchNorm backward statistics at 1.5-1.9
+    // TB/s on the 268 MB layer: 32 x 64 blocks of 32 serial trips each; 90 -> 47 us per launch with 256)
+    static const int gran = getenv("IVLN_CHAN_GRAN") ? atoi(getenv("IVLN_CHAN_GRAN")) : 4096;  // tuning
+    static const int cap = getenv("IVLN_CHAN_CAP") ? atoi(getenv("IVLN_CHAN_CAP")) : 256;
+    int S = (int)(((int64_t)N * HW + gran - 1) / gran);
     if (S > N) S = N;
-    if (S > 64) S = 64;
+    if (S > cap) S = cap;
     if ((int64_t)S * C * K > ws_floats) S = (int)(ws_floats / ((int64_t)C * K));
     return S < 1 ? 1 : S;
 }
@@ -890,7 +904,7 @@ int ivln_nchw_chansum_f32(const float* x, int N, int C, int HW, float* out, floa
         float* col = ws + splits_max * cols;   // colsum's partials live in ws[0, splits * cols)
         const int rc = ivln_colsum_f32(x, cols, N, (int)cols, col, 0, ws, splits_max * cols, stream);
         if (rc != IVLN_OK) return rc;
-        hipLaunchKernelGGL(k_chan_final, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, col, HW, C, 1, out,
+        hipLaunchKernelGGL(k_chan_final, dim3(C), dim3(64), 0, (hipStream_t)stream, col, HW, C, 1, out,
                            (float*)nullptr);
         return LAUNCH_OK();
     }
@@ -898,7 +912,7 @@ int ivln_nchw_chansum_f32(const float* x, int N, int C, int HW, float* out, floa
     const int ips = (N + S - 1) / S;
     S = (N + ips - 1) / ips;
     hipLaunchKernelGGL(k_nchw_chansum_partial, dim3(C, S), dim3(256), 0, (hipStream_t)stream, x, N, C, HW, ips, ws);
-    hipLaunchKernelGGL(k_chan_final, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, ws, S, C, 1, out,
+    hipLaunchKernelGGL(k_chan_final, dim3(C), dim3(64), 0, (hipStream_t)stream, ws, S, C, 1, out,
                        (float*)nullptr);
     return LAUNCH_OK();
 }
@@ -1016,7 +1030,7 @@ int ivln_cbra_bwd_f32(const float* dout, const float* y, const float* scale, con
     S = (N + ips - 1) / ips;
     hipLaunchKernelGGL(k_cbra_bwd_stats, dim3(C, S), dim3(256), 0, (hipStream_t)stream, dout, y, scale, shift, mean,
                        rstd, N, C, H, W, ips, ws);
-    hipLaunchKernelGGL(k_chan_final, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, ws, S, C, 2, dbeta, dgamma);
+    hipLaunchKernelGGL(k_chan_final, dim3(C), dim3(64), 0, (hipStream_t)stream, ws, S, C, 2, dbeta, dgamma);
     if ((W & 3) == 0 && (((uintptr_t)y | (uintptr_t)dout | (uintptr_t)dy) & 15) == 0)
         hipLaunchKernelGGL(k_cbra_bwd_apply4, dim3(nblk((int64_t)N * C * H * W / 4)), dim3(256), 0, (hipStream_t)stream,
                            dout, y, scale, shift, mean, rstd, dgamma, dbeta, N, C, H, W, train, dy);
