@@ -505,6 +505,28 @@ __global__ __launch_bounds__(256) void k_map_features(const uint8_t* __restrict_
     y[idx] = v;
 }
 
+// four cells per thread: one 4-byte load of the labels, one 16-byte store (cells % 4 == 0, aligned tensors); the update
+// batch writes 117 MB of features here - 1.9 TB/s with 4-byte stores
+__global__ __launch_bounds__(256) void k_map_features4(const uint8_t* __restrict__ occ, const uint8_t* __restrict__ sem,
+                                                       float* __restrict__ y, int B, int cells, int classes) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int cq = cells >> 2;
+    const int64_t total = (int64_t)B * (1 + classes) * cq;
+    if (q >= total) return;
+    const int p4 = (int)(q % cq);
+    const int c = (int)((q / cq) % (1 + classes));
+    const int b = (int)(q / ((int64_t)cq * (1 + classes)));
+    const uchar4 s4 = *reinterpret_cast<const uchar4*>((c == 0 ? occ : sem) + (int64_t)b * cells + 4 * p4);
+    float4 v;
+    if (c == 0) {
+        v = make_float4((float)s4.x, (float)s4.y, (float)s4.z, (float)s4.w);
+    } else {
+        const uint8_t k = (uint8_t)(c - 1);
+        v = make_float4(s4.x == k ? 1.f : 0.f, s4.y == k ? 1.f : 0.f, s4.z == k ? 1.f : 0.f, s4.w == k ? 1.f : 0.f);
+    }
+    *reinterpret_cast<float4*>(y + 4 * q) = v;
+}
+
 // ------------------------------------------------------------------------------------------
 // Instruction encoder front end (models/encoders/instruction_encoder.py:70-82): embedding gather
 // and lengths = number of tokens whose embedding row has any non-zero entry.
@@ -1475,8 +1497,12 @@ int ivln_pool2d_f32(const float* x, float* y, int NC, int H, int W, int k, int s
 int ivln_map_features_f32(const uint8_t* occ, const uint8_t* sem, float* y, int B, int cells, int classes,
                           void* stream) {
     int64_t total = (int64_t)B * (1 + classes) * cells;
-    hipLaunchKernelGGL(k_map_features, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, occ, sem, y, B, cells,
-                       classes);
+    if ((cells & 3) == 0 && (((uintptr_t)occ | (uintptr_t)sem) & 3) == 0 && ((uintptr_t)y & 15) == 0)
+        hipLaunchKernelGGL(k_map_features4, dim3(nblk(total / 4)), dim3(256), 0, (hipStream_t)stream, occ, sem, y, B, cells,
+                           classes);
+    else
+        hipLaunchKernelGGL(k_map_features, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, occ, sem, y, B, cells,
+                           classes);
     return LAUNCH_OK();
 }
 

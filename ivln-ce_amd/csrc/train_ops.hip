@@ -824,23 +824,35 @@ __global__ __launch_bounds__(256) void k_adam_flat(float* __restrict__ p, float*
     if (zero_grad) g[i] = 0.f;
 }
 
-// dst[u][m] = sum over rows with index[row] == u of src[row][m], rows in ascending order (deterministic): the
-// per-row gradients of a key/value image shared by several rows (k_attn_bwd with row_index) folded onto the image.
-// One thread per 4 consecutive m; the index vector (<= a few thousand ints) is scanned from L1 / scalar cache.
+// dst[u][m] = sum over rows with index[row] == u of src[row][m] in a fixed order: the per-row gradients of a key/value
+// image shared by several rows (k_attn_bwd with row_index) folded onto the image.  A block = 32 float4 columns x 8 row
+// chunks: every thread scans one eighth of the rows (one thread walking all 512 rows was a chain of 64 dependent-issue
+// loads, 48 us per call), the eight partial sums are added in chunk order through LDS.
 __global__ __launch_bounds__(256) void k_index_sum(const float* __restrict__ src, const int* __restrict__ index, int rows,
                                                    int64_t M4, int U, float* __restrict__ dst) {
-    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= M4 * U) return;
-    const int u = (int)(gid / M4);
-    const int64_t m = gid - (int64_t)u * M4;
+    __shared__ float4 part[8][32];
+    const int col = threadIdx.x & 31, chunk = threadIdx.x >> 5, u = blockIdx.y;
+    const int64_t m = (int64_t)blockIdx.x * 32 + col;
+    const int rpc = (rows + 7) / 8, r0 = chunk * rpc, r1 = min(rows, r0 + rpc);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int r = 0; r < rows; ++r) {
-        if (index[r] == u) {
-            const float4 v = reinterpret_cast<const float4*>(src)[(int64_t)r * M4 + m];
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    if (m < M4) {
+        for (int r = r0; r < r1; ++r) {
+            if (index[r] == u) {
+                const float4 v = reinterpret_cast<const float4*>(src)[(int64_t)r * M4 + m];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
         }
     }
-    reinterpret_cast<float4*>(dst)[gid] = acc;
+    part[chunk][col] = acc;
+    __syncthreads();
+    if (chunk == 0 && m < M4) {
+#pragma unroll
+        for (int c = 1; c < 8; ++c) {
+            const float4 v = part[c][col];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        reinterpret_cast<float4*>(dst)[(int64_t)u * M4 + m] = acc;
+    }
 }
 
 }  // namespace
@@ -1108,8 +1120,8 @@ int ivln_adam_step_f32(float* params, float* grads, float* exp_avg, float* exp_a
 int ivln_index_sum_f32(const float* src, const int* index, int rows, int64_t M, int U, float* dst, void* stream) {
     if (!src || !index || !dst || rows <= 0 || U <= 0 || M <= 0 || (M & 3)) return IVLN_E_INVALID;
     if ((((uintptr_t)src | (uintptr_t)dst) & 15) != 0) return IVLN_E_INVALID;
-    hipLaunchKernelGGL(k_index_sum, dim3(nblk((M / 4) * U)), dim3(256), 0, (hipStream_t)stream, src, index, rows, M / 4, U,
-                       dst);
+    hipLaunchKernelGGL(k_index_sum, dim3((unsigned)((M / 4 + 31) / 32), U), dim3(256), 0, (hipStream_t)stream, src, index,
+                       rows, M / 4, U, dst);
     return LAUNCH_OK();
 }
 
