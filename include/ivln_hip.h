@@ -488,6 +488,12 @@ int ivln_copy_multi(const void* const* srcs, void* const* dsts, const int64_t* b
 /* dsts[j][i] += srcs[j][i] (counts[j] floats, n <= 64 contiguous tensors) in one launch: the parameter gradients of
  * one backward pass added onto the flat gradient bucket (`loss.backward()` accumulation, base_il_trainer.py:211). */
 int ivln_add_multi_f32(const float* const* srcs, float* const* dsts, const int64_t* counts, int n, void* stream);
+/* Up to 32 column sums out[j][c] = sum_r x[j][r*ld[j] + c] in two launches (the bias gradients of one DAgger update:
+ * autograd's `grad_output.sum(0)` of every nn.Linear / GRU / LSTM gate matrix, base_il_trainer.py:211); partials and
+ * sums in the fixed order of ivln_colsum_f32 (bit-identical to calling it per matrix).  The arrays are host arrays;
+ * ws holds sum_j splits_j * cols_j floats (splits_j = min(128, ceil(rows_j / 256))). */
+int ivln_colsum_multi_f32(const float* const* xs, const int64_t* lds, const int* rows, const int* cols,
+                          float* const* outs, int n, float* ws, int64_t ws_floats, void* stream);
 int ivln_copy2d_f32(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int rows, int cols,
                     int broadcast_rows, void* stream);
 

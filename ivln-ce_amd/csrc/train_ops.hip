@@ -85,6 +85,61 @@ __global__ void k_colsum_final(const float* __restrict__ partial, int splits, in
     out[c] = accumulate ? out[c] + s : s;
 }
 
+// Up to 32 column sums in TWO launches (ivln_colsum_multi_f32): the bias gradients of the update's Linear layers and
+// GRU / LSTM gates used to be two launches each (17 x 2 per update, 0.19 ms of dependent launches).  Stage 1 block ->
+// job by its first-block table; the arithmetic (four row sub-lanes, fixed-order partials and final) is k_colsum_*'s.
+struct ColsumJobs {
+    const float* x[32];
+    float* out[32];
+    int64_t ld[32];
+    int rows[32], cols[32], splits[32], rps[32];
+    int first_block[33];   // stage 1: blocks [first_block[j], first_block[j+1]) = job j, (col tile, split) row-major
+    int64_t ws_off[32];    // partials of job j: ws[ws_off[j] + split*cols + c]
+    int first_col[33];     // stage 2: columns [first_col[j], first_col[j+1]) of the concatenated column axis
+    int n;
+};
+__global__ __launch_bounds__(256) void k_colsum_multi_partial(const ColsumJobs J, float* __restrict__ ws) {
+    __shared__ float red[4][64];
+    int j = 0;
+    while (j + 1 < J.n && (int)blockIdx.x >= J.first_block[j + 1]) ++j;
+    const int local = blockIdx.x - J.first_block[j];
+    const int tiles = (J.cols[j] + 63) / 64;
+    const int tile = local % tiles, split = local / tiles;
+    const float* __restrict__ x = J.x[j];
+    const int64_t ld = J.ld[j];
+    const int cols = J.cols[j], rows = J.rows[j];
+    const int c = tile * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+    const int r0 = split * J.rps[j], r1 = min(rows, r0 + J.rps[j]);
+    float s = 0.f;
+    if (c < cols) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int r = r0 + sub;
+        for (; r + 12 < r1; r += 16) {
+            a0 += x[(int64_t)r * ld + c];
+            a1 += x[(int64_t)(r + 4) * ld + c];
+            a2 += x[(int64_t)(r + 8) * ld + c];
+            a3 += x[(int64_t)(r + 12) * ld + c];
+        }
+        for (; r < r1; r += 4) a0 += x[(int64_t)r * ld + c];
+        s = (a0 + a1) + (a2 + a3);
+    }
+    red[sub][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (sub == 0 && c < cols)
+        ws[J.ws_off[j] + (int64_t)split * cols + c] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void k_colsum_multi_final(const ColsumJobs J, const float* __restrict__ ws) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= J.first_col[J.n]) return;
+    int j = 0;
+    while (j + 1 < J.n && g >= J.first_col[j + 1]) ++j;
+    const int c = g - J.first_col[j], cols = J.cols[j];
+    float s = 0.f;
+    for (int z = 0; z < J.splits[j]; ++z) s += ws[J.ws_off[j] + (int64_t)z * cols + c];
+    J.out[j][c] = s;
+}
+
 // per-channel sum over (N, HW) of an NCHW tensor (conv bias grad): grid (C, S) partials over image
 // slices, then a fixed-order final sum (deterministic)
 __global__ __launch_bounds__(256) void k_nchw_chansum_partial(const float* __restrict__ x, int N, int C, int HW,
@@ -888,6 +943,32 @@ int ivln_colsum_f32(const float* x, int64_t ld, int rows, int cols, float* out, 
                        cols, rps, ws);
     hipLaunchKernelGGL(k_colsum_final, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, splits, cols,
                        out, accumulate);
+    return LAUNCH_OK();
+}
+
+int ivln_colsum_multi_f32(const float* const* xs, const int64_t* lds, const int* rows, const int* cols, float* const* outs,
+                          int n, float* ws, int64_t ws_floats, void* stream) {
+    if (!xs || !lds || !rows || !cols || !outs || !ws || n <= 0 || n > 32) return IVLN_E_INVALID;
+    ColsumJobs J;
+    J.n = n;
+    int blocks = 0, colsum = 0;
+    int64_t off = 0;
+    for (int j = 0; j < n; ++j) {
+        if (!xs[j] || !outs[j] || rows[j] <= 0 || cols[j] <= 0) return IVLN_E_INVALID;
+        int splits = (rows[j] + 255) / 256;  // (the split rule of ivln_colsum_f32: same partials, same sums)
+        if (splits > 128) splits = 128;
+        const int rps = (rows[j] + splits - 1) / splits;
+        splits = (rows[j] + rps - 1) / rps;
+        J.x[j] = xs[j], J.out[j] = outs[j], J.ld[j] = lds[j], J.rows[j] = rows[j], J.cols[j] = cols[j];
+        J.splits[j] = splits, J.rps[j] = rps, J.first_block[j] = blocks, J.first_col[j] = colsum, J.ws_off[j] = off;
+        blocks += ((cols[j] + 63) / 64) * splits;
+        colsum += cols[j];
+        off += (int64_t)splits * cols[j];
+    }
+    if (off > ws_floats) return IVLN_E_INVALID;
+    J.first_block[n] = blocks, J.first_col[n] = colsum;
+    hipLaunchKernelGGL(k_colsum_multi_partial, dim3(blocks), dim3(256), 0, (hipStream_t)stream, J, ws);
+    hipLaunchKernelGGL(k_colsum_multi_final, dim3((colsum + 255) / 256), dim3(256), 0, (hipStream_t)stream, J, ws);
     return LAUNCH_OK();
 }
 

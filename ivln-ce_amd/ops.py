@@ -1372,6 +1372,55 @@ def colsum(x, out=None, accumulate=False):
     return out
 
 
+class ColsumQueue:
+    """Column sums whose results are only needed at the end of a backward pass (the bias gradients): `add(x)` hands out
+    the result tensor at once and keeps `x` alive, `flush()` computes all of them in two launches
+    (ivln_colsum_multi_f32) instead of two per matrix."""
+
+    def __init__(self):
+        self.jobs = []
+
+    def add(self, x):
+        rows, cols = x.shape
+        out = torch.empty((cols,), dtype=torch.float32, device=x.device)
+        if not COLSUM_MULTI or x.stride(1) != 1:
+            return colsum(x, out)
+        self.jobs.append((x, out))
+        if len(self.jobs) == 32:
+            self.flush()
+        return out
+
+    def flush(self):
+        jobs, self.jobs = self.jobs, []
+        if not jobs:
+            return
+        n = len(jobs)
+        dev = jobs[0][0].device
+        cur = torch.cuda.current_stream(dev)
+        for x, o in jobs:  # (queued on the instruction branch's side stream, summed on this one)
+            x.record_stream(cur)
+            o.record_stream(cur)
+        need = sum(min(128, (x.shape[0] + 255) // 256) * x.shape[1] for x, _ in jobs)
+        key = (str(dev), stream_ptr())
+        ws = _colsum_ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(max(need, 1 << 18), dtype=torch.float32, device=dev)
+            _colsum_ws[key] = ws
+        xs = (vp * n)(*[x.data_ptr() for x, _ in jobs])
+        outs = (vp * n)(*[o.data_ptr() for _, o in jobs])
+        lds = (i64 * n)(*[x.stride(0) for x, _ in jobs])
+        rows = (i32 * n)(*[x.shape[0] for x, _ in jobs])
+        cols = (i32 * n)(*[x.shape[1] for x, _ in jobs])
+        L = _T()
+        L.ivln_colsum_multi_f32.argtypes = [C.POINTER(vp), C.POINTER(i64), C.POINTER(i32), C.POINTER(i32), C.POINTER(vp), i32,
+                                            vp, i64, vp]
+        check(L.ivln_colsum_multi_f32(xs, lds, rows, cols, outs, n, dptr(ws), ws.numel(), stream_ptr()),
+              "ivln_colsum_multi_f32")
+
+
+COLSUM_MULTI = os.environ.get("IVLN_COLSUM_MULTI", "1") != "0"  # A/B: one pair of launches for all bias gradients
+
+
 def nchw_chansum(x):
     N, Cc, H, W = x.shape
     out = torch.empty((Cc,), dtype=torch.float32, device=x.device)

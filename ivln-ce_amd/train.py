@@ -146,9 +146,9 @@ def _gru_backward(enc, s, d_out, G):
     # enqueued by one C-ABI call (ivln_cma_seq_bwd_f32)
     ops.gru_seq_bwd(d_out, s["r"], s["z"], s["n"], s["ghn"], out, h0, masks, whh_t, T, N, dgi, dgh, hp, dhz)
     G[rnn.weight_ih_l0] = ops.linear_bwd_weight(dgi, x_in)
-    G[rnn.bias_ih_l0] = ops.colsum(dgi)
+    G[rnn.bias_ih_l0] = _colsum(dgi)
     G[rnn.weight_hh_l0] = ops.linear_bwd_weight(dgh, hp)
-    G[rnn.bias_hh_l0] = ops.colsum(dgh)
+    G[rnn.bias_hh_l0] = _colsum(dgh)
     return ops.linear_bwd_input(dgi, rnn.weight_ih_l0)
 
 
@@ -172,7 +172,7 @@ def instruction_backward(ie, st, d_txt, rows, L, G):
     G[rnn.weight_ih_l0_reverse] = ops.linear_bwd_weight(dgx_r, emb_x)
     G[rnn.weight_hh_l0] = ops.linear_bwd_weight(dgx_f, hp_f)
     G[rnn.weight_hh_l0_reverse] = ops.linear_bwd_weight(dgx_r, hp_r)
-    bf, br = ops.colsum(dgx_f), ops.colsum(dgx_r)
+    bf, br = _colsum(dgx_f), _colsum(dgx_r)
     G[rnn.bias_ih_l0], G[rnn.bias_hh_l0] = bf, bf
     G[rnn.bias_ih_l0_reverse], G[rnn.bias_hh_l0_reverse] = br, br
     if ie.embedding_layer.weight.requires_grad:
@@ -183,8 +183,26 @@ def instruction_backward(ie, st, d_txt, rows, L, G):
         G[ie.embedding_layer.weight] = g
 
 
+_CS = None  # the running backward pass's queue of deferred column sums (bias gradients), see ops.ColsumQueue
+
+
+def _colsum(x):
+    return _CS.add(x) if _CS is not None else ops.colsum(x)
+
+
 def net_backward(net, S: Dict, d_feats: torch.Tensor) -> Dict:
     """Gradients of every parameter of MapCMANet given d(loss)/d(features).  S = saves of forward_hip."""
+    global _CS
+    _CS = ops.ColsumQueue()  # bias gradients: queued here, computed by two launches at the end (ops.ColsumQueue)
+    try:
+        G = _net_backward(net, S, d_feats)
+        _CS.flush()
+        return G
+    finally:
+        _CS = None
+
+
+def _net_backward(net, S: Dict, d_feats: torch.Tensor) -> Dict:
     G: Dict = {}
     rows, L, P = S["rows"], S["L"], S["P"]
     H = net._hidden_size
@@ -201,7 +219,7 @@ def net_backward(net, S: Dict, d_feats: torch.Tensor) -> Dict:
     d_pre = ops.relu_bwd(d_c2, S["c2"])
     sc = net.second_state_compress[0]
     G[sc.weight] = ops.linear_bwd_weight(d_pre, x2)
-    G[sc.bias] = ops.colsum(d_pre)
+    G[sc.bias] = _colsum(d_pre)
     dx2 = ops.linear_bwd_input(d_pre, sc.weight)  # (rows, 1184): [state | text | dep' | map' | prev]
 
     # ---- depth / map attentions keyed by the attended text --------------------------------------
@@ -217,7 +235,7 @@ def net_backward(net, S: Dict, d_feats: torch.Tensor) -> Dict:
     dq2 = ops.add2d(dq2_d, dq2_m)
     text = x2[:, o_txt:o_txt + 256]
     G[net.text_q.weight] = ops.linear_bwd_weight(dq2, text)
-    G[net.text_q.bias] = ops.colsum(dq2)
+    G[net.text_q.bias] = _colsum(dq2)
     d_text = dx2[:, o_txt:o_txt + 256]
     ops.linear_bwd_input(dq2, net.text_q.weight, out=d_text, accumulate=True)
 
@@ -242,7 +260,7 @@ def net_backward(net, S: Dict, d_feats: torch.Tensor) -> Dict:
             instruction_backward(net.instruction_encoder, S["txt"], d_txt, U, L, G_txt)
     state = x2[:, :H]
     G[net.state_q.weight] = ops.linear_bwd_weight(dq1, state)
-    G[net.state_q.bias] = ops.colsum(dq1)
+    G[net.state_q.bias] = _colsum(dq1)
     d_state = dx2[:, :H]
     ops.linear_bwd_input(dq1, net.state_q.weight, out=d_state, accumulate=True)
 
@@ -258,18 +276,18 @@ def net_backward(net, S: Dict, d_feats: torch.Tensor) -> Dict:
     dl, ml = net.depth_linear[1], net.map_linear[1]
     d_pre_d = ops.relu_bwd(d_state_in[:, :d_out_dep], state_in[:, :d_out_dep])
     G[dl.weight] = ops.linear_bwd_weight(d_pre_d, dep.view(rows, -1))
-    G[dl.bias] = ops.colsum(d_pre_d)
+    G[dl.bias] = _colsum(d_pre_d)
     d_dep = ops.linear_bwd_input(d_pre_d, dl.weight)  # (rows, 192*16)
     d_dep = _conv1d_backward(net.dep_kv, d_dkv.view(rows, -1, 1, P), dep.view(rows, Cd, 1, P),
                              d_dep.view(rows, Cd, 1, P), G)
     se = net.depth_encoder.spatial_embeddings
     c_vis = Cd - se.embedding_dim
-    G[se.weight] = ops.colsum(d_dep.view(rows, -1)[:, c_vis * P:]).view_as(se.weight)
+    G[se.weight] = _colsum(d_dep.view(rows, -1)[:, c_vis * P:]).view_as(se.weight)
 
     # ---- map branch: map_linear + map_kv -> map CNN -----------------------------------------------
     d_pre_m = ops.relu_bwd(d_state_in[:, d_out_dep:d_out_dep + m_out], state_in[:, d_out_dep:d_out_dep + m_out])
     G[ml.weight] = ops.linear_bwd_weight(d_pre_m, mp.view(rows, -1))
-    G[ml.bias] = ops.colsum(d_pre_m)
+    G[ml.bias] = _colsum(d_pre_m)
     d_mp = ops.linear_bwd_input(d_pre_m, ml.weight)
     d_mp = _conv1d_backward(net.map_kv, d_mkv.view(rows, -1, 1, P), mp.view(rows, Cm, 1, P),
                             d_mp.view(rows, Cm, 1, P), G)
