@@ -344,8 +344,53 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue4(const ivln_gemm_desc p
     *reinterpret_cast<float4*>(p.D + addr) = v;
 }
 
+// (64 float4 columns x 4 slab groups per block: weight gradients come as up to 512 slabs of a SMALL matrix - 22 K floats
+//  for the map CNN's first layer - so a thread per element left 21 blocks walking 382 slabs each; the four group sums are
+//  added in group order through LDS)
+__global__ __launch_bounds__(256) void k_splitk_epilogue_flat4(const ivln_gemm_desc p) {
+    __shared__ float4 part[4][64];
+    const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int64_t q = (int64_t)blockIdx.x * 64 + col, MN = (int64_t)p.M * p.N;
+    const bool ok = q * 4 < MN;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) {
+        for (int z = grp; z < p.splits; z += 4) {
+            const float4 w = *reinterpret_cast<const float4*>(p.ws + (int64_t)z * MN + q * 4);
+            v.x += w.x, v.y += w.y, v.z += w.z, v.w += w.w;
+        }
+    }
+    part[grp][col] = v;
+    __syncthreads();
+    if (grp != 0 || !ok) return;
+#pragma unroll
+    for (int g = 1; g < 4; ++g) {
+        const float4 w = part[g][col];
+        v.x += w.x, v.y += w.y, v.z += w.z, v.w += w.w;
+    }
+    if (p.residual) {
+        const float4 r = *reinterpret_cast<const float4*>(p.residual + q * 4);
+        v.x += r.x, v.y += r.y, v.z += r.z, v.w += r.w;
+    }
+    if (p.accumulate) {
+        const float4 r = *reinterpret_cast<const float4*>(p.D + q * 4);
+        v.x += r.x, v.y += r.y, v.z += r.z, v.w += r.w;
+    }
+    if (p.relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+    *reinterpret_cast<float4*>(p.D + q * 4) = v;
+}
+
 // reduce the split-K slabs of d into D with the fused epilogue
 void launch_splitk_epilogue(const ivln_gemm_desc& d, hipStream_t s) {
+    // (a 32 x 32 LDS-transposing form for dense outputs with unit ROW stride - Linear activations - was measured: 10.4 us
+    //  per call against 7 us for the element-per-thread form on the update's shapes; not kept)
+    // fully contiguous dense outputs without per-row parameters (weight gradients): the matrix as one flat vector, so
+    // that N need not be a multiple of four (the map CNN's first layer: N = 14 x 49 = 686)
+    if (d.dmode == DMODE_DENSE && d.sDn == 1 && d.sDm == d.N && (((int64_t)d.M * d.N) & 3) == 0 && !d.scale && !d.shift &&
+        !d.no_wide_epilogue && (((uintptr_t)d.D | (uintptr_t)d.residual | (uintptr_t)d.ws) & 15) == 0) {
+        const int64_t total4 = (int64_t)d.M * d.N / 4;
+        hipLaunchKernelGGL(k_splitk_epilogue_flat4, dim3((unsigned)((total4 + 63) / 64)), dim3(256), 0, s, d);
+        return;
+    }
     const bool lay = (d.dmode == DMODE_NCHW && (d.HoWo & 3) == 0) || (d.dmode == DMODE_DENSE && d.sDn == 1 && (d.sDm & 3) == 0);
     const bool vec4 = lay && (d.N & 3) == 0 && !d.no_wide_epilogue &&
                       (((uintptr_t)d.D | (uintptr_t)d.residual | (uintptr_t)d.ws) & 15) == 0;
