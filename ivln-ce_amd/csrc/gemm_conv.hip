@@ -561,7 +561,11 @@ extern "C" int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream) {
             splits = (int)((want + blocks - 1) / blocks);
             if (splits > nk / min_tiles) splits = nk / min_tiles;
             // weight gradients reduce over millions of pixels with a tiny M x N: allow deep splits there
-            const int max_splits = d.defer_epilogue ? (blocks <= 8 ? 64 : (blocks <= 32 ? 32 : 16)) : (nk >= 4096 ? 256 : 16);
+            // (deep K with a small M x N - the LSTM / Conv1d weight gradients of the update, K = 40 960 rows: 16 splits left
+            //  128 blocks on 256 CUs, 167 us for 2 GFLOP)
+            static const int deep_env = getenv("IVLN_SPLIT_DEEP") ? atoi(getenv("IVLN_SPLIT_DEEP")) : 64;  // tuning
+            const int max_splits = d.defer_epilogue ? (blocks <= 8 ? 64 : (blocks <= 32 ? 32 : 16))
+                                                    : (nk >= 4096 ? 256 : (nk >= 512 ? deep_env : 16));
             if (splits > max_splits) splits = max_splits;
             int64_t cap = d.ws_floats / ((int64_t)d.M * d.N);
             if (splits > cap) splits = (int)cap;
