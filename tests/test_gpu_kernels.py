@@ -929,3 +929,55 @@ def test_wide_and_narrow_epilogues_store_the_same_values(N, Cin, H, W, Cout, k, 
     assert torch.equal(out[0], out[1])
     ref = F.relu(F.conv2d(x.cpu(), w.cpu(), None, s, p) * sc.cpu().view(1, -1, 1, 1) + sh.cpu().view(1, -1, 1, 1) + res.cpu())
     _close(out[0], ref, 3e-5)
+
+
+def test_colsum_queue_equals_per_matrix_colsums_bit_for_bit():
+    """ivln_colsum_multi_f32 (ops.ColsumQueue): many column sums in two launches, same partial / final order as
+    ivln_colsum_f32 per matrix - bias gradients of one update (autograd's grad_output.sum(0))."""
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    shapes = [(512, 1536), (40960, 50), (512, 128), (7, 5), (4097, 513), (300, 64)]
+    xs = [torch.randn(r, c, generator=g).to(DEV) for r, c in shapes]
+    wide = torch.randn(512, 640, generator=g).to(DEV)
+    xs.append(wide[:, 128:])  # a column slice: row stride != cols
+    ref = [ops.colsum(x).clone() for x in xs]
+    q = ops.ColsumQueue()
+    outs = [q.add(x) for x in xs]
+    q.flush()
+    for o, r, x in zip(outs, ref, xs):
+        assert torch.equal(o, r)
+        _close(o, x.double().sum(0).float(), 2e-3 * max(1.0, x.shape[0] ** 0.5 / 20))
+
+
+@pytest.mark.parametrize("N,C,H,W", [(64, 32, 64, 64), (64, 64, 32, 32), (512, 128, 8, 8), (256, 128, 16, 16), (3, 128, 16, 16)])
+def test_batchnorm_statistics_from_the_conv_epilogue_match_the_pass_over_its_output(N, C, H, W):
+    """conv2d(..., stats=[]) leaves per-tile {count, mean, M2} of what it stores; ivln_bn_stats_from_partials_f32 merges
+    them into the scale / shift / saved statistics / running statistics that ivln_bn_train_stats_f32 computes from a
+    pass over the conv's output (map_encoder.py:13-20 in train mode)."""
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(N + C)
+    Cin = 32
+    x = torch.randn(N, Cin, H, W, generator=g).to(DEV)
+    w = (torch.randn(C, Cin, 7, 7, generator=g) / (Cin * 49) ** 0.5).to(DEV)
+    b = torch.randn(C, generator=g).to(DEV)
+    stats = []
+    y = ops.conv2d(x, w, stride=1, pad=3, shift=b, stats=stats)
+    res = []
+    for use_partials in (False, True):
+        bn = torch.nn.BatchNorm2d(C).to(DEV).train()
+        sc, sh, sm, sr = (torch.empty(C, device=DEV) for _ in range(4))
+        if use_partials:
+            if not stats:
+                pytest.skip("this shape did not take the direct kernel's wide epilogue")
+            ops.bn_stats_from_partials(stats[0][0], stats[0][1], bn, sc, sh, sm, sr)
+        else:
+            ops.bn_train_stats(y, bn, sc, sh, sm, sr)
+        res.append([t.clone() for t in (sc, sh, sm, sr, bn.running_mean, bn.running_var)])
+    ref_mean, ref_var = y.double().mean((0, 2, 3)), y.double().var((0, 2, 3), unbiased=False)
+    for r in res:
+        _close(r[2], ref_mean.float(), 1e-5)
+        _close(r[3], (1.0 / torch.sqrt(ref_var + 1e-5)).float(), 1e-4)
+    for a, b in zip(res[0], res[1]):  # scale, shift, saved mean / rstd, running mean / var
+        _close(a, b, 1e-5)
