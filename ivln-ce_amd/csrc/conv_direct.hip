@@ -518,7 +518,9 @@ int ivln_conv_direct_launch(ivln_gemm_desc& d, hipStream_t s) {
         // split the channel chunks over blockIdx.z until the grid covers the chip
         static const int want_env = getenv("IVLN_DIRECT_SPLIT_WANT") ? atoi(getenv("IVLN_DIRECT_SPLIT_WANT")) : 0;  // tuning
         static const int below_env = getenv("IVLN_DIRECT_SPLIT_BELOW") ? atoi(getenv("IVLN_DIRECT_SPLIT_BELOW")) : 0;
-        const int64_t want = (want_env > 0 && !d.defer_epilogue) ? want_env : (d.defer_epilogue ? 256 : 512);
+        static const int defer_env = getenv("IVLN_DIRECT_DEFER_WANT") ? atoi(getenv("IVLN_DIRECT_DEFER_WANT")) : 0;  // tuning
+        const int64_t want = (want_env > 0 && !d.defer_epilogue) ? want_env
+                             : (d.defer_epilogue ? (defer_env > 0 ? defer_env : 256) : 512);
         if (d.ws && blocks < (below_env > 0 && !d.defer_epilogue ? below_env : 256) && nch >= 2) {
             splits = (int)((want + blocks - 1) / blocks);
             if (splits > nch) splits = nch;
