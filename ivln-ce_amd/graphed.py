@@ -263,6 +263,8 @@ class GraphedRollout:
         #  the tracer's slower graph launches)
         # (gB1 on a third, CU-masked stream - hipExtStreamCreateWithCUMask, 32..192 CUs, contiguous or strided masks - so that
         #  the map CNN's large grids stop crowding the chain: measured 0.79-0.83 ms per step against 0.708, round 3)
+        # (... and gB2 replayed BEHIND gA on the chain's stream, so that the critical edge gA -> gB2 stays inside one queue:
+        #  0.726 vs 0.714 ms per step, slower)
         self.gB1[self.phase].replay()
         main.wait_event(self.ev_A)
         self.graphs[self.phase].replay()
