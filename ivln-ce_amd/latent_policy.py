@@ -189,9 +189,10 @@ class LatentCMANet(Net):
         """Same signature/return as latent_cma_policy.py:375-497.  rows == envs: one step; rows == T*envs: a
         time-major trajectory batch (every mode, including the tour-memory variant the reference unrolls in Python).
         Under autograd the whole net is one Function whose backward is `backward_hip`."""
-        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        from .train import MapCMAForwardFn, all_params
+
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in all_params(self))
         if needs_grad:
-            from .train import MapCMAForwardFn
 
             feats, rnn_out = MapCMAForwardFn.run(self, observations, rnn_states, prev_actions, action_masks,
                                                  episode_masks, tour_masks)

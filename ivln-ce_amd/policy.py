@@ -417,9 +417,10 @@ class MapCMANet(Net):
     def forward(self, observations, rnn_states, prev_actions, action_masks, episode_masks=None, tour_masks=None):
         """Same signature/return as the reference forward (map_cma_policy.py:276-368); the MapCMA net
         only consumes `action_masks` (episode/tour masks default to it, :284-287)."""
-        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        from .train import MapCMAForwardFn, all_params
+
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in all_params(self))
         if needs_grad:
-            from .train import MapCMAForwardFn
 
             feats, rnn_out = MapCMAForwardFn.run(self, observations, rnn_states, prev_actions, action_masks)
         else:

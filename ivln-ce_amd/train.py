@@ -323,6 +323,14 @@ def _net_backward(net, S: Dict, d_feats: torch.Tensor) -> Dict:
     return G
 
 
+def all_params(net):
+    """list(net.parameters()), built once per module (the tree is fixed after construction; flags may change)."""
+    every = net.__dict__.get("_all_params_cache")
+    if every is None:
+        every = net.__dict__["_all_params_cache"] = list(net.parameters())
+    return every
+
+
 class MapCMAForwardFn(torch.autograd.Function):
     """`holder` = (net, *forward_hip arguments); the net's `backward_hip` (default: net_backward) turns
     d(features) into the parameter gradients."""
@@ -365,10 +373,7 @@ class MapCMAForwardFn(torch.autograd.Function):
     def run(net, *args):
         # (Module.parameters() walks the module tree with de-duplication: 0.4 ms of host time per update, paid while the
         #  GPU idles behind the previous update's .item(); the tree is fixed after construction, only the flags can change)
-        every = net.__dict__.get("_all_params_cache")
-        if every is None:
-            every = net.__dict__["_all_params_cache"] = list(net.parameters())
-        params = [p for p in every if p.requires_grad]
+        params = [p for p in all_params(net) if p.requires_grad]
         # Every trainable parameter already owns a contiguous fp32 .grad on the device (FlatAdam's flat bucket): the
         # gradients are added there by backward itself, so autograd only has to CALL it - one anchor tensor goes through
         # Function.apply instead of ~270 parameters (0.2 ms of host time per update in front of the first kernel).
