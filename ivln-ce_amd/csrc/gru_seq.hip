@@ -17,8 +17,10 @@
 //     flight at once, into LDS.  No fences: every exchanged word is write-through stored and sc1 loaded
 //     (MI355X_MICROARCH.md, "valid forms").  Stores nobody waits for (saved gates, dgi, hp) and the next step's
 //     prefetches are issued between the arrival and the poll.
-//   * The counter and an error word live in a caller-provided 256-byte `sync_ws`, zeroed by a memset node in front of
-//     the launch (stream-ordered, so replay-safe).  Every spin is bounded: on a timeout the error word is set, all
+//   * The counter and a give-up flag live in a caller-provided 256-byte `sync_ws` whose first 192 bytes a memset node
+//     zeroes in front of the launch (stream-ordered, so replay-safe); word 48 is the STICKY error word the host reads -
+//     several launches share one workspace (four per update), and a flag the next launch's memset erased would hide a
+//     timed-out earlier one.  Every spin is bounded: on a timeout the error word is set, all
 //     workgroups leave, and `ivln_seq_sync_status` reports it - a lost workgroup can never hang the GPU.
 //   * Same lane -> K mapping, fma chains and element formulas as the per-step kernels; the cross-lane sums run on the
 //     DPP path in a different association.  The two paths agree to ~2e-7 (tests/test_gpu_kernels.py, bar 1e-6), and the
@@ -107,7 +109,10 @@ __device__ __forceinline__ bool grid_wait(unsigned* sync_ws, unsigned target, in
             if (__hip_atomic_load(&sync_ws[32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;  // someone gave up
             __builtin_amdgcn_s_sleep(1);
         }
-        if (!ok) __hip_atomic_store(&sync_ws[32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!ok) {
+            __hip_atomic_store(&sync_ws[32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // this launch: everybody out
+            __hip_atomic_store(&sync_ws[48], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sticky: what the host reads
+        }
         *s_fail = ok ? 0 : 1;
     }
     __syncthreads();
@@ -401,7 +406,7 @@ int ivln_gru_seq_fwd_persistent(const float* gi, const float* h0, int64_t ld_h0,
                                 void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if ((int64_t)T * N * ldo * (int64_t)sizeof(float) >= (int64_t)1 << 31) return IVLN_E_UNSUPPORTED;  // 32-bit buffer offsets
-    if (hipMemsetAsync(sync_ws, 0, 256, s) != hipSuccess) return IVLN_E_HIP;
+    if (hipMemsetAsync(sync_ws, 0, 192, s) != hipSuccess) return IVLN_E_HIP;
     const size_t lds = (size_t)N * HH * sizeof(float) + 16;
     static bool attr_set = false;
     if (!attr_set) {
@@ -428,7 +433,7 @@ int ivln_gru_seq_bwd_persistent(const float* d_out, int64_t ld_dout, const float
                                 void* sync_ws, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if ((int64_t)T * N * 3 * HH * (int64_t)sizeof(float) >= (int64_t)1 << 31) return IVLN_E_UNSUPPORTED;
-    if (hipMemsetAsync(sync_ws, 0, 256, s) != hipSuccess) return IVLN_E_HIP;
+    if (hipMemsetAsync(sync_ws, 0, 192, s) != hipSuccess) return IVLN_E_HIP;
     const size_t lds = (size_t)N * 3 * HH * sizeof(float) + 16;
     static bool attr_set = false;
     if (!attr_set) {
@@ -459,7 +464,7 @@ int ivln_gru_seq_stamps(void* host, int bytes) {
  * last persistent launch timed out (its outputs are then undefined). */
 int ivln_seq_sync_status(const void* sync_ws, void* stream) {
     unsigned err = 0;
-    if (hipMemcpyAsync(&err, (const unsigned*)sync_ws + 32, sizeof(err), hipMemcpyDeviceToHost, (hipStream_t)stream) !=
+    if (hipMemcpyAsync(&err, (const unsigned*)sync_ws + 48, sizeof(err), hipMemcpyDeviceToHost, (hipStream_t)stream) !=
         hipSuccess)
         return IVLN_E_HIP;
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return IVLN_E_HIP;

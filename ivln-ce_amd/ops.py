@@ -1101,6 +1101,28 @@ def check_seq_sync():
         check(L.ivln_seq_sync_status(dptr(ws), stream_ptr()), "ivln_seq_sync_status (persistent GRU spin timed out)")
 
 
+_seq_polls = {}
+
+
+def seq_sync_poll():
+    """Non-blocking form of check_seq_sync: raises if an EARLIER poll's read of a workspace's sticky error word has
+    arrived non-zero, then queues a fresh asynchronous read of every workspace on the current stream.  A timed-out
+    persistent launch is therefore reported at the latest one call late, without the host ever waiting for the GPU."""
+    for key, ws in _seq_sync_ws.items():
+        slot = _seq_polls.get(key)
+        if slot is None:
+            slot = _seq_polls[key] = [torch.zeros(1, dtype=torch.int32).pin_memory(), torch.cuda.Event(), False]
+        pin, ev, pending = slot
+        if pending and ev.query():
+            slot[2] = False
+            if int(pin[0]) != 0:
+                raise _lib.IvlnError("persistent sequence GRU: a bounded spin timed out (ivln_seq_sync_status)")
+        if not slot[2]:
+            pin.copy_(ws[48:49], non_blocking=True)
+            ev.record()
+            slot[2] = True
+
+
 def gru_seq(gi, h0, masks_u8, w_hh, b_hh, out, state_out, T, N, saves=None):
     """Masked GRU over T timesteps of N rows in one C-ABI call: ONE persistent launch inside the kernel's envelope
     (H = 512, N <= 64), else T dependent launches enqueued from C."""
