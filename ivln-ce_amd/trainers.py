@@ -159,7 +159,12 @@ def _scalar(value, device):
     return t
 
 
-EARLY_LOSS_READBACK = os.environ.get("IVLN_EARLY_LOSS", "1") != "0"  # A/B: `.item()` after Adam, as the reference does
+# Opt-in (IVLN_EARLY_LOSS=1): read the two loss values back as soon as the forward is done and let the host run ahead of
+# backward + Adam.  In a process that only trains it takes the update from 12.2 to 11.8 ms (the GPU never idles behind
+# `.item()`); in a process that has REPLAYED HIPGRAPHS before (every DAgger run: collection, then updates) the same
+# pipelined stream runs 25 % slower - 15.4 ms, ~13 us more per launch, on any stream, with or without the side stream,
+# the persistent GRU or more hardware queues (measured, round 3) - so the default stays the reference's `.item()` after Adam.
+EARLY_LOSS_READBACK = os.environ.get("IVLN_EARLY_LOSS", "0") != "0"
 _loss_pins = {}
 
 
