@@ -411,17 +411,26 @@ int ivln_gru_step_f32(const float* x, int64_t ldx, int I, const float* gi_pre, i
  * seq_forward; BPTT forward of base_il_trainer.py:173-219): gi = W_ih x + b_ih for all rows (caller's GEMM), h0 (N, H)
  * row stride ld_h0, masks u8 (T*N) -> out (T*N, H) row stride ldo, state_out (N, H) = the last step; optional saves
  * r / z / n / gh_n (T*N, H) for ivln_cma_seq_bwd_f32.
- * sync_ws: 256 bytes of device memory owned by the caller (one per stream), or NULL.  With a workspace and a shape
- * inside ivln_cma_seq_persistent_ok the whole sequence is ONE persistent launch (csrc/gru_seq.hip: W_hh resident in
- * registers over 32 workgroups, h_t exchanged through `out` with write-through stores and one counter per step);
- * otherwise T dependent per-step launches are enqueued.  Both paths compute the same values (same summation order;
- * 2e-7 apart). */
+ * sync_ws: 256 bytes of device memory owned by the caller (one per stream), or NULL.  The caller ZEROES the 256 bytes
+ * once after allocating them (ivln_seq_sync_init, or any memset): every launch clears the step counters (bytes 0..191)
+ * itself, but byte 192 is a STICKY error word that only a timed-out spin ever writes and nothing in the library
+ * clears - ivln_seq_sync_status on a never-zeroed workspace reports a timeout that did not happen.  With a workspace
+ * and a shape inside ivln_cma_seq_persistent_ok the whole sequence is ONE persistent launch (csrc/gru_seq.hip: W_hh
+ * resident in registers over 64 workgroups of 256 threads - 32 of 512 with IVLN_SEQ_UPB=16 -, h_t exchanged through
+ * `out` with write-through stores and one counter per step).  The single launch is taken only when the whole grid can
+ * be resident at once (occupancy query x CU count >= grid: not on a 32-CU partition or with N so large that LDS admits
+ * fewer workgroups than the grid) and `out` / h0 / dgh are 16-byte aligned (they are read with 16-byte buffer loads);
+ * otherwise, and always without a workspace, T dependent per-step launches are enqueued.  Both paths compute the same
+ * values (2e-7 apart: different reduction tree).  After a timeout the run is unrecoverable: outputs of that launch are
+ * undefined and the word stays set. */
 int ivln_cma_seq_fwd_f32(const float* gi, const float* h0, int64_t ld_h0, const uint8_t* masks, const float* w_hh,
                          const float* b_hh, float* out, int64_t ldo, float* state_out, int64_t ld_so, int T, int N,
                          int H, float* save_r, float* save_z, float* save_n, float* save_ghn, void* sync_ws,
                          void* stream);
 /* 1 when the single-launch path serves (N, H) (backward != 0: the BPTT kernel's envelope). */
 int ivln_cma_seq_persistent_ok(int N, int H, int backward);
+/* Zeroes a 256-byte sync workspace on `stream` (counters and the sticky error word): call once per workspace. */
+int ivln_seq_sync_init(void* sync_ws, void* stream);
 /* Synchronises `stream` and returns IVLN_OK, or IVLN_E_HIP when a bounded spin of the last persistent launch that
  * used `sync_ws` timed out (its outputs are then undefined; the launch itself always terminates). */
 int ivln_seq_sync_status(const void* sync_ws, void* stream);

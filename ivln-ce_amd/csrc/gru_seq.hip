@@ -38,6 +38,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <map>
+#include <mutex>
+#include <utility>
 #include <stdlib.h>
 #include "../../include/ivln_hip.h"
 #include "gru_seq.h"
@@ -393,11 +396,39 @@ static int units_per_wg() {
     return v;
 }
 
+
+// The persistent kernels spin on counters that every workgroup of the grid feeds: the whole grid has to be resident at
+// once.  On a partitioned device (CPX: 32 CUs), a CU-masked stream or a large N (up to 128 KB of LDS per workgroup)
+// it may not be - then the caller runs the per-step launches (IVLN_E_UNSUPPORTED), instead of every grid_wait spinning
+// to its bound.  Answer cached per (kernel, LDS bytes).
+static bool grid_fits(const void* fn, int threads, size_t lds, int grid) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, size_t>, int> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    const auto key = std::make_pair(fn, lds);
+    auto it = cache.find(key);
+    if (it == cache.end()) {
+        int per_cu = 0, dev = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            per_cu = cus = 0;
+        it = cache.emplace(key, per_cu * cus).first;
+    }
+    return it->second >= grid;
+}
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
 extern "C" {
 
 /* 1 when ivln_cma_seq_fwd_f32 / _bwd_f32 take the single-launch path for this shape (given a sync_ws). */
 int ivln_cma_seq_persistent_ok(int N, int H, int backward) {
     return H == HH && N >= 1 && N <= (backward ? 16 : 64);
+}
+
+/* Zeroes a sync workspace (256 bytes), including the sticky error word that the launches never clear. */
+int ivln_seq_sync_init(void* sync_ws, void* stream) {
+    if (!sync_ws) return IVLN_E_INVALID;
+    return hipMemsetAsync(sync_ws, 0, 256, (hipStream_t)stream) == hipSuccess ? IVLN_OK : IVLN_E_HIP;
 }
 
 int ivln_gru_seq_fwd_persistent(const float* gi, const float* h0, int64_t ld_h0, const uint8_t* masks, const float* w_hh,
@@ -406,7 +437,8 @@ int ivln_gru_seq_fwd_persistent(const float* gi, const float* h0, int64_t ld_h0,
                                 void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if ((int64_t)T * N * ldo * (int64_t)sizeof(float) >= (int64_t)1 << 31) return IVLN_E_UNSUPPORTED;  // 32-bit buffer offsets
-    if (hipMemsetAsync(sync_ws, 0, 192, s) != hipSuccess) return IVLN_E_HIP;
+    // the exchange reads `out` / h0 with 16-byte buffer loads
+    if (!aligned16(out) || !aligned16(h0) || (ldo & 3) || (ld_h0 & 3)) return IVLN_E_UNSUPPORTED;
     const size_t lds = (size_t)N * HH * sizeof(float) + 16;
     static bool attr_set = false;
     if (!attr_set) {
@@ -418,6 +450,10 @@ int ivln_gru_seq_fwd_persistent(const float* gi, const float* h0, int64_t ld_h0,
             return IVLN_E_HIP;
         attr_set = true;
     }
+    if (units_per_wg() == 8 ? !grid_fits(reinterpret_cast<const void*>(k_gru_seq_fwd<8>), 8 * LPU, lds, HH / 8)
+                            : !grid_fits(reinterpret_cast<const void*>(k_gru_seq_fwd<16>), 16 * LPU, lds, HH / 16))
+        return IVLN_E_UNSUPPORTED;
+    if (hipMemsetAsync(sync_ws, 0, 192, s) != hipSuccess) return IVLN_E_HIP;
     if (units_per_wg() == 8)
         hipLaunchKernelGGL(k_gru_seq_fwd<8>, dim3(HH / 8), dim3(8 * LPU), lds, s, gi, h0, ld_h0, masks, w_hh, b_hh, out,
                            ldo, state_out, ld_so, T, N, save_r, save_z, save_n, save_ghn, (unsigned*)sync_ws);
@@ -433,7 +469,7 @@ int ivln_gru_seq_bwd_persistent(const float* d_out, int64_t ld_dout, const float
                                 void* sync_ws, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if ((int64_t)T * N * 3 * HH * (int64_t)sizeof(float) >= (int64_t)1 << 31) return IVLN_E_UNSUPPORTED;
-    if (hipMemsetAsync(sync_ws, 0, 192, s) != hipSuccess) return IVLN_E_HIP;
+    if (!aligned16(dgh)) return IVLN_E_UNSUPPORTED;  // (16-byte buffer loads of the exchanged dgh rows)
     const size_t lds = (size_t)N * 3 * HH * sizeof(float) + 16;
     static bool attr_set = false;
     if (!attr_set) {
@@ -445,6 +481,10 @@ int ivln_gru_seq_bwd_persistent(const float* d_out, int64_t ld_dout, const float
             return IVLN_E_HIP;
         attr_set = true;
     }
+    if (units_per_wg() == 8 ? !grid_fits(reinterpret_cast<const void*>(k_gru_seq_bwd<8>), 8 * LPU, lds, HH / 8)
+                            : !grid_fits(reinterpret_cast<const void*>(k_gru_seq_bwd<16>), 16 * LPU, lds, HH / 16))
+        return IVLN_E_UNSUPPORTED;
+    if (hipMemsetAsync(sync_ws, 0, 192, s) != hipSuccess) return IVLN_E_HIP;
     if (units_per_wg() == 8)
         hipLaunchKernelGGL(k_gru_seq_bwd<8>, dim3(HH / 8), dim3(8 * LPU), lds, s, d_out, ld_dout, r, z, n, ghn, out, ld_out,
                            h0, ld_h0, masks, whh_t, T, N, dgi, dgh, hp, (unsigned*)sync_ws);

@@ -324,11 +324,17 @@ def _net_backward(net, S: Dict, d_feats: torch.Tensor) -> Dict:
 
 
 def all_params(net):
-    """list(net.parameters()), built once per module (the tree is fixed after construction; flags may change)."""
-    every = net.__dict__.get("_all_params_cache")
-    if every is None:
-        every = net.__dict__["_all_params_cache"] = list(net.parameters())
-    return every
+    """list(net.parameters()), cached per module.  The cache is keyed by the identity of every sub-module's `_parameters`
+    / `_modules` entries' count and of the Parameter objects themselves (a cheap walk over ~40 modules, no tensor work):
+    replacing a sub-module or re-assigning a Parameter after the first forward (e.g. swapping in a pretrained encoder)
+    rebuilds the list instead of silently training the old objects.  Note for users of autograd hooks: with FlatAdam the
+    HIP backward adds gradients straight into the existing `.grad` views (MapCMAForwardFn.backward) and reports None
+    to autograd for those parameters, so per-parameter hooks / torch.autograd.grad do not see them."""
+    stamp = tuple(id(p) for m in net.modules() for p in m._parameters.values())
+    ent = net.__dict__.get("_all_params_cache")
+    if ent is None or ent[0] != stamp:
+        ent = net.__dict__["_all_params_cache"] = (stamp, list(net.parameters()))
+    return ent[1]
 
 
 class MapCMAForwardFn(torch.autograd.Function):

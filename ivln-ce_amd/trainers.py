@@ -74,10 +74,12 @@ class FlatAdam:
             self.seg_of = seg.to(dev)
             self.seg_lr = torch.tensor([lr, sem_lr], dtype=torch.float32, device=dev)
 
-    def step(self, world: int = 1):
+    def step(self, world: int = 1, allreduce: bool = True):
         """all-reduce (sum) the flat grads when world > 1, then Adam with the 1/world mean folded in;
-        the same kernel zeroes the grads (optimizer.zero_grad())."""
-        if world > 1:
+        the same kernel zeroes the grads (optimizer.zero_grad()).  `allreduce=False`: the bucket already holds the sum
+        over the `world` shards (one process that accumulated them - the reference form the data-parallel step is
+        tested against, tools/dp_equiv.py)."""
+        if world > 1 and allreduce:
             D.allreduce_sum_(self.grad)
         self.step_count += 1
         ops.WEIGHT_EPOCH += 1  # invalidates folded-BN caches (parameters change through raw pointers)

@@ -19,8 +19,14 @@ def run():
                            False, "MODEL.DEPTH_ENCODER.ddppo_checkpoint", "NONE"])
     space = Dict({"depth": Box(0.0, 1.0, (256, 256, 1), np.float32), "occupancy_map": Box(0, 255, (64, 64), np.uint8),
                   "semantic_map": Box(0, 255, (64, 64), np.uint8), "instruction": Box(0, 2504, (200,), np.int64)})
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from det_init import det_fill  # crc32(key)-seeded weights: O(1) logits (the default head gain of 0.01 gives logits ~ 0)
+
     torch.manual_seed(0)
-    pol = MapCMAPolicy.from_config(cfg, space, Discrete(4))
+    pol = det_fill(MapCMAPolicy.from_config(cfg, space, Discrete(4)), seed=0)
     ref = MapCMAPolicyRef()
     ref.load_state_dict(pol.state_dict())
     pol, ref = pol.to(dev).eval(), ref.eval()
@@ -31,12 +37,16 @@ def run():
     obs["semantic_map"] = (torch.randint(0, 13, (B, 64, 64), generator=g) * obs["occupancy_map"]).to(torch.uint8)
     rnn, prev, masks = torch.zeros(B, 2, 512), torch.zeros(B, 1, dtype=torch.long), torch.zeros(B, 1, dtype=torch.uint8)
     with torch.no_grad():
-        lr, sr, _ = ref.logits(obs, rnn, prev, masks)
+        lr, sr, fr = ref.logits(obs, rnn, prev, masks)
         dobs = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in obs.items()}
         f, s = pol.net(dobs, rnn.to(dev), prev.to(dev), masks.to(dev))
         lg = pol.action_distribution.raw_logits(f)
     err = float((lg.cpu() - lr).abs().max())
+    ferr, serr = float((f.cpu() - fr).abs().max()), float((s.cpu() - sr).abs().max())
+    spread = float(lr.max() - lr.min())
+    assert spread > 0.05, f"degenerate smoke weights: oracle logits span only {spread}"
     assert err < 1e-4, f"policy logits mismatch vs oracle: {err}"
+    assert ferr < 2e-4 and serr < 2e-4, f"policy features / recurrent state mismatch vs oracle: {ferr} / {serr}"
     # one tiny DAgger update (T=3, N=2) with cached depth features
     pol.train()
     T, N = 3, 2
@@ -50,4 +60,5 @@ def run():
     loss, _, _ = update_agent(pol, opt, tr, torch.randint(0, 4, (T * N, 1), generator=g).to(dev), nd.view(-1, 1).to(dev),
                               torch.randint(0, 4, (T, N), generator=g).to(dev), torch.ones(T, N).to(dev))
     assert np.isfinite(loss)
-    print(f"smoke: HIP policy logits within {err:.1e} of the oracle; one HIP DAgger update, loss {loss:.4f}")
+    print(f"smoke: HIP policy logits within {err:.1e} (span {spread:.2f}), features {ferr:.1e}, recurrent state {serr:.1e} of "
+          f"the oracle; one HIP DAgger update, loss {loss:.4f}")

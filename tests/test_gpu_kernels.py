@@ -931,6 +931,31 @@ def test_wide_and_narrow_epilogues_store_the_same_values(N, Cin, H, W, Cout, k, 
     _close(out[0], ref, 3e-5)
 
 
+def test_pixel_starved_conv_leaves_no_partials_and_the_block_falls_back_to_the_statistics_pass():
+    """3 images of 16x16 are 12 direct-conv blocks: ivln_gemm_f32 sends the 7x7 conv to the split-K implicit GEMM, which
+    has no statistics epilogue and says so (`stat_tiles` = 0).  CBRA.forward_hip then computes the BatchNorm statistics
+    from a pass over the conv's output: same block output and running statistics as torch's train-mode BatchNorm."""
+    import copy
+
+    from ivln_ce_amd import ops
+    from ivln_ce_amd.encoders import CBRA
+
+    torch.manual_seed(11)
+    x = torch.randn(3, 32, 16, 16)
+    blk = CBRA(32, 128).train()
+    ref_blk = copy.deepcopy(blk)
+    ref = ref_blk.conv(x)
+    blk = blk.to(DEV)
+    stats = []
+    ops.conv2d(x.to(DEV), blk.conv[0].weight, stride=1, pad=3, shift=blk.conv[0].bias, stats=stats)
+    assert stats == []
+    with torch.no_grad():
+        got = blk.forward_hip(x.to(DEV))
+    _close(got, ref, 3e-5)
+    _close(blk.conv[1].running_mean, ref_blk.conv[1].running_mean, 1e-6)
+    _close(blk.conv[1].running_var, ref_blk.conv[1].running_var, 1e-6)
+
+
 def test_colsum_queue_equals_per_matrix_colsums_bit_for_bit():
     """ivln_colsum_multi_f32 (ops.ColsumQueue): many column sums in two launches, same partial / final order as
     ivln_colsum_f32 per matrix - bias gradients of one update (autograd's grad_output.sum(0))."""
@@ -950,7 +975,7 @@ def test_colsum_queue_equals_per_matrix_colsums_bit_for_bit():
         _close(o, x.double().sum(0).float(), 2e-3 * max(1.0, x.shape[0] ** 0.5 / 20))
 
 
-@pytest.mark.parametrize("N,C,H,W", [(64, 32, 64, 64), (64, 64, 32, 32), (512, 128, 8, 8), (256, 128, 16, 16), (3, 128, 16, 16)])
+@pytest.mark.parametrize("N,C,H,W", [(64, 32, 64, 64), (64, 64, 32, 32), (512, 128, 8, 8), (256, 128, 16, 16)])
 def test_batchnorm_statistics_from_the_conv_epilogue_match_the_pass_over_its_output(N, C, H, W):
     """conv2d(..., stats=[]) leaves per-tile {count, mean, M2} of what it stores; ivln_bn_stats_from_partials_f32 merges
     them into the scale / shift / saved statistics / running statistics that ivln_bn_train_stats_f32 computes from a
@@ -969,8 +994,7 @@ def test_batchnorm_statistics_from_the_conv_epilogue_match_the_pass_over_its_out
         bn = torch.nn.BatchNorm2d(C).to(DEV).train()
         sc, sh, sm, sr = (torch.empty(C, device=DEV) for _ in range(4))
         if use_partials:
-            if not stats:
-                pytest.skip("this shape did not take the direct kernel's wide epilogue")
+            assert stats, "a trajectory-batch shape must take the direct kernel's wide epilogue and leave its partials"
             ops.bn_stats_from_partials(stats[0][0], stats[0][1], bn, sc, sh, sm, sr)
         else:
             ops.bn_train_stats(y, bn, sc, sh, sm, sr)

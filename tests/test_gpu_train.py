@@ -593,3 +593,228 @@ def test_update_on_the_dedicated_work_stream_equals_the_update_on_the_callers_st
     for k in g0:  # (the embedding gradient accumulates with atomics: equal to the last bits, not bit for bit)
         a, b = g0[k], g1[k]
         assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(a.abs().max())), k
+
+
+# ------------------------------------------------------------------------------------------------
+# the BENCHED update path (update_agent: HIP loss + HIP backward + FlatAdam) pinned end to end
+# ------------------------------------------------------------------------------------------------
+_ZERO_GRAD_BIAS = lambda k: k.startswith("net.map_encoder.cnn.") and k.endswith(".conv.0.bias")  # noqa: E731
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("custom_lr", [False, True], ids=["one_group", "custom_lr_two_groups"])
+def test_three_hip_updates_track_oracle_plus_torch_adam(custom_lr):
+    """Three consecutive `update_agent` + `FlatAdam` steps (what bench.py's update leg and the trainers run) against
+    the oracle's loss + autograd + `torch.optim.Adam` built exactly as base_il_trainer.py:78-94 builds it (one group, or
+    the two-group MODEL.SEMANTIC_MAP_ENCODER.custom_lr form): every trainable parameter and every BatchNorm buffer
+    after every step.
+
+    Bars, per step:
+      * Adam's moments (`exp_avg`, `exp_avg_sq` of EVERY trainable element, read out of the flat buckets) against
+        torch.optim.Adam's state: they are linear / quadratic in the gradients, so the gradient tolerance carries over
+        (exp_avg: atol 1e-6 + rtol 2e-3; exp_avg_sq: atol 1e-10 + rtol 5e-3);
+      * parameters: allclose(atol=3e-6) on every element whose reference gradient was at least 1e-5 in magnitude in each
+        of the steps so far, and within steps * lr everywhere.  Adam's step is lr * m / (sqrt(v) + eps), i.e. lr * sign(g)
+        in the first steps: where |g| is of the order of the gradient's own rounding noise (the gradient tests allow
+        2e-6 absolute) the SIGN is noise and the two implementations legitimately move such an element in opposite
+        directions by lr each - first observed on net.map_encoder.cnn.0.conv.0.weight, 4.9e-4 = 2 lr apart at |g| ~ 1e-6.
+    The conv biases in front of a train-mode BatchNorm are such elements by construction: their gradient is
+    analytically zero, the reference's autograd leaves rounding noise there (so its Adam random-walks them by +-lr per
+    step, with no effect on any output), the HIP backward writes an exact zero and they do not move."""
+    from det_init import det_fill
+    from test_gpu_policy import make_policy
+
+    from ivln_ce_amd.aux_losses import AuxLosses
+    from ivln_ce_amd.trainers import FlatAdam, update_agent
+    from oracle.policy_ref import MapCMAPolicyRef
+
+    torch.set_num_threads(8)
+    lr, sem_lr, steps = 2.5e-4, 1e-3, 3
+    g = np.load(os.path.join(G, "policy_update.npz"))
+    obs, prev, nd, tgt, w = _batch(g)
+    obs_h = {k: v.cpu() for k, v in obs.items()}
+    ref = det_fill(MapCMAPolicyRef(use_pm=True), seed=0).train()
+    if custom_lr:
+        sem = [p for k, p in ref.named_parameters() if k.startswith("net.map_encoder")]
+        reg = [p for k, p in ref.named_parameters() if not k.startswith("net.map_encoder")]
+        opt_r = torch.optim.Adam([{"params": sem}, {"params": reg}], lr=lr)
+        opt_r.param_groups[0]["lr"] = sem_lr
+    else:
+        opt_r = torch.optim.Adam(ref.parameters(), lr=lr)
+    pol = make_policy(use_pm=True, train=True)
+    opt = FlatAdam(pol, lr=lr, sem_lr=sem_lr if custom_lr else None)
+    gmin = {}
+    log = []
+    AuxLosses.activate()
+    try:
+        for s in range(1, steps + 1):
+            opt_r.zero_grad()
+            loss_r, act_r, aux_r, _ = ref.update_loss(obs_h, prev.cpu(), nd.cpu(), tgt.cpu(), w.cpu())
+            loss_r.backward()
+            for k, p in ref.named_parameters():
+                if p.grad is not None:
+                    a = p.grad.detach().abs()
+                    gmin[k] = a if k not in gmin else torch.minimum(gmin[k], a)
+            opt_r.step()
+            loss, act, aux = update_agent(pol, opt, obs, prev, nd, tgt, w, hidden_size=512)
+            assert abs(loss - float(loss_r)) < 2e-5 and abs(aux - float(aux_r)) < 2e-5, (s, loss, float(loss_r))
+            ref_p = dict(ref.named_parameters())
+            tot = low = 0
+            worst = (0.0, "")
+            for k, p in pol.named_parameters():
+                if not p.requires_grad:
+                    continue
+                d = (p.detach().cpu() - ref_p[k].detach()).abs()
+                firm = gmin[k] >= 1e-5
+                tot += d.numel()
+                low += int((~firm).sum())
+                if _ZERO_GRAD_BIAS(k):
+                    continue  # (analytically zero gradient, see the docstring)
+                if firm.any():
+                    e = float(d[firm].max())
+                    if e > worst[0]:
+                        worst = (e, k)
+                    assert e <= 3e-6, f"step {s}: {k} differs by {e:.3e} on elements with |grad| >= 1e-5"
+                assert float(d.max()) <= 2 * s * max(lr, sem_lr if custom_lr else lr) * 1.001 + 1e-7, f"step {s}: {k} moved too far"
+            for k, b in pol.named_buffers():
+                rb = dict(ref.named_buffers())[k]
+                if b.dtype.is_floating_point:
+                    assert torch.allclose(b.cpu(), rb, atol=2e-6, rtol=1e-5), f"step {s}: buffer {k}"
+                else:
+                    assert int(b) == int(rb), k
+            # Adam's moments, every trainable element
+            m_err = v_err = 0.0
+            st = opt_r.state
+            for k, p, o in zip(opt.names, opt.params, opt.offsets):
+                if _ZERO_GRAD_BIAS(k) or ref_p[k] not in st:
+                    continue
+                n = p.numel()
+                m_h, v_h = opt.exp_avg[o:o + n].cpu(), opt.exp_avg_sq[o:o + n].cpu()
+                m_r, v_r = st[ref_p[k]]["exp_avg"].reshape(-1), st[ref_p[k]]["exp_avg_sq"].reshape(-1)
+                em = float(((m_h - m_r).abs() - 2e-3 * m_r.abs()).max())
+                ev = float(((v_h - v_r).abs() - 5e-3 * v_r.abs()).max())
+                m_err, v_err = max(m_err, em), max(v_err, ev)
+                assert em <= 1e-6, f"step {s}: exp_avg of {k} off by {em:.3e} beyond rtol"
+                assert ev <= 1e-10, f"step {s}: exp_avg_sq of {k} off by {ev:.3e} beyond rtol"
+            log.append(f"step {s}: loss {loss:.7f} ref {float(loss_r):.7f}; worst firm element {worst[0]:.2e} ({worst[1]}); "
+                       f"{low} of {tot} elements below the 1e-5 gradient bar; moments beyond rtol: exp_avg {m_err:.2e}, exp_avg_sq {v_err:.2e}")
+            assert low < 0.6 * tot, log[-1]
+    finally:
+        AuxLosses.deactivate()
+    os.makedirs("gpurun_out", exist_ok=True)
+    open(f"gpurun_out/update_3steps_{'custom_lr' if custom_lr else 'one_group'}.log", "w").write("\n".join(log) + "\n")
+    print("\n".join(log))
+
+
+_bench_case_cache = {}
+
+
+def _bench_shape_case():
+    """T = 64 x N = 8 trajectory batch of the bench shape + the oracle's loss and FULL gradients (computed once)."""
+    if _bench_case_cache:
+        return _bench_case_cache
+    from det_init import det_fill
+
+    from oracle.policy_ref import MapCMAPolicyRef
+
+    torch.set_num_threads(8)
+    T, N = 64, 8
+    TN = T * N
+    g = torch.Generator().manual_seed(65)
+    lens = [64, 64, 51, 40, 64, 33, 64, 57]
+    instr = torch.zeros(N, 200)
+    for n in range(N):
+        L = 80 - 7 * n
+        instr[n, :L] = torch.randint(2, 2504, (L,), generator=g).float()
+    obs = {"depth_features": torch.randn(TN, 128, 4, 4, generator=g),
+           "occupancy_map": (torch.rand(TN, 64, 64, generator=g) < 0.3).float(),
+           "semantic_map": torch.randint(0, 13, (TN, 64, 64), generator=g).float(),
+           "instruction": instr.repeat(T, 1), "progress": torch.rand(TN, 1, generator=g)}
+    prev = torch.randint(0, 4, (TN, 1), generator=g)
+    nd = torch.ones(T, N, dtype=torch.uint8)
+    nd[0] = 0
+    nd = nd.view(-1, 1)
+    tgt = torch.randint(0, 4, (T, N), generator=g)
+    infl = torch.ones(T, N, dtype=torch.bool)
+    infl[1:] = tgt[1:] != tgt[:-1]
+    w = torch.where(infl, torch.tensor(3.2), torch.tensor(1.0))
+    for n, L in enumerate(lens):
+        w[L:, n] = 0
+        tgt[L:, n] = 0
+        for k in obs:
+            obs[k].view(T, N, *obs[k].shape[1:])[L:, n] = 1.0
+        prev.view(T, N)[L:, n] = 0
+    ref = det_fill(MapCMAPolicyRef(use_pm=True), seed=0).train()
+    loss_r, act_r, aux_r, _ = ref.update_loss(obs, prev, nd, tgt, w)
+    loss_r.backward()
+    _bench_case_cache.update(T=T, N=N, obs=obs, prev=prev, nd=nd, tgt=tgt, w=w, loss=float(loss_r), aux=float(aux_r),
+                             grads={k: p.grad.detach().clone() for k, p in ref.named_parameters() if p.grad is not None})
+    return _bench_case_cache
+
+
+@pytest.mark.gpu
+def test_benched_update_path_full_gradients_at_T64_N8():
+    """`update_agent` itself (HIP cross-entropy + inflection weights, HIP backward, persistent sequence GRUs, de-duplicated
+    instruction rows - the path bench.py's update leg times) at the bench shape, FULL gradient tensors against the
+    oracle's autograd, not norms: the map CNN's conv weights, both GRUs, the instruction bi-LSTM and every other trainable
+    tensor.  Per tensor: max |got - ref| <= 1e-3 * max |ref| + 2e-7, and the direction cosine >= 1 - 1e-6 (a permuted
+    or mis-indexed gradient fails both)."""
+    from test_gpu_policy import make_policy
+
+    from ivln_ce_amd.aux_losses import AuxLosses
+    from ivln_ce_amd.trainers import FlatAdam, update_agent
+    from ivln_ce_amd.utils import dedupe_instructions, trim_instruction_padding
+
+    c = _bench_shape_case()
+    N = c["N"]
+    pol = make_policy(use_pm=True, train=True)
+    opt = FlatAdam(pol, lr=2.5e-4)
+    dobs = dedupe_instructions(trim_instruction_padding(dict(c["obs"]), first_rows=N))
+    dobs = {k: v.to(DEV) for k, v in dobs.items()}
+    AuxLosses.activate()
+    try:
+        loss, act, aux = update_agent(pol, opt, dobs, c["prev"].to(DEV), c["nd"].to(DEV), c["tgt"].to(DEV), c["w"].to(DEV),
+                                      hidden_size=512, step_grad=False)
+    finally:
+        AuxLosses.deactivate()
+    assert abs(loss - c["loss"]) < 2e-5 and abs(aux - c["aux"]) < 2e-5, (loss, c["loss"], aux, c["aux"])
+    must = ["net.map_encoder.cnn.0.conv.0.weight", "net.map_encoder.cnn.1.conv.0.weight", "net.map_encoder.cnn.2.conv.0.weight",
+            "net.map_encoder.cnn.3.conv.0.weight", "net.state_encoder.rnn.weight_hh_l0", "net.second_state_encoder.rnn.weight_hh_l0",
+            "net.instruction_encoder.encoder_rnn.weight_ih_l0", "net.instruction_encoder.encoder_rnn.weight_hh_l0",
+            "net.instruction_encoder.encoder_rnn.weight_ih_l0_reverse", "net.instruction_encoder.encoder_rnn.weight_hh_l0_reverse"]
+    params = dict(pol.named_parameters())
+    assert all(k in params and params[k].requires_grad for k in must)
+    log, bad = [], []
+    for k, p in params.items():
+        if not p.requires_grad or k not in c["grads"]:
+            continue
+        got, ref = p.grad.detach().cpu().double().reshape(-1), c["grads"][k].double().reshape(-1)
+        if _ZERO_GRAD_BIAS(k):
+            assert float(got.abs().max()) == 0.0, k  # analytically zero: exact 0 here, rounding noise in the oracle
+            continue
+        scale = float(ref.abs().max())
+        err = float((got - ref).abs().max())
+        cos = float(torch.dot(got, ref) / (got.norm() * ref.norm()).clamp_min(1e-300)) if scale > 0 else 1.0
+        log.append(f"{k}: max|ref| {scale:.3e} max|err| {err:.3e} cos-1 {cos - 1:.1e}")
+        if not (err <= 1e-3 * scale + 2e-7 and (cos >= 1 - 1e-6 or scale < 1e-6)):
+            bad.append(log[-1])
+    os.makedirs("gpurun_out", exist_ok=True)
+    open("gpurun_out/update_T64N8_full_grads.log", "w").write("\n".join(log) + "\n")
+    assert not bad, "\n".join(bad)
+    assert all(any(line.startswith(k + ":") for line in log) for k in must)
+
+
+@pytest.mark.gpu
+def test_two_rank_update_equals_single_process_accumulation(tmp_path):
+    """Data-parallel equivalence (tools/dp_equiv.py): two gloo ranks on this GPU, 4 trajectories each, one
+    all-reduced update == one process accumulating both shards' gradients and stepping with 1/2 folded into Adam."""
+    env = dict(os.environ, IVLN_DIST_BACKEND="gloo", IVLN_ONE_DEVICE="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29571", os.path.join(root, "tools", "dp_equiv.py")]
+    import subprocess
+
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "dist smoke ok: dp_equiv world 2" in r.stdout
+    print(r.stdout[-600:])
