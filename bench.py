@@ -7,16 +7,22 @@ With N > 1 and no WORLD_SIZE in the environment the parent spawns N ranks itself
 the driver launches it under torch.distributed.run the ranks are used as they come.
 
 A "step" = one pass of the hot path over one batch of synthetic observations already resident in HBM.
-Headline (`value`): BASELINE.json configs[1] - egocentric mapper (gt semantics) + MapCMAPolicy.act for `--envs`
-(default 4) parallel envs per GPU, env-steps/s over all ranks (weak scaling: envs per GPU fixed).
+Headline (`value`, `roofline`, `cpu_baseline`): BASELINE.json configs[2], the largest single-GPU configuration -
+RedNet-predicted semantics (rgb 224x224 + depth 256x256) -> egocentric mapper -> MapCMAPolicy.act for `--pred-envs`
+(default 8) parallel envs per GPU, env-steps/s over all ranks (weak scaling: envs per GPU fixed).  Every leg is timed
+as R = 5 repetitions of W warm-up + EXACTLY K steps, each bracketed by barrier + synchronize with the MAX over ranks
+taken per repetition; `value` / `ms_per_step` are the MEDIAN repetition and `repetitions` carries min / max.
 The JSON line also carries
-  roofline             fp32-MFMA implicit-GEMM family of the headline step: algorithmic FLOPs / summed kernel time
-                       (HIP events on the launch stream) against the 157.3 TFLOP/s fp32-matrix peak
-  mapper_roofline      the egocentric mapper's kernels: algorithmic bytes per step / kernel time against 8 TB/s
-  cpu_baseline         the CPU oracle (torch-CPU policy port + C mapper) on this box's host cores, bounded sample
-  pred_semantics_step  BASELINE configs[2] at its stated size (8 envs): RedNet + mapper + policy, with its own
-                       `roofline` (RedNet's MFMA launches) and `cpu_baseline` (oracle RedNet + C mapper + port)
-  update_step          DAgger update T=64 x N=8 per GPU (fwd + bwd + all-reduce + Adam) with its MFMA roofline
+  roofline             fp32-MFMA family of the headline step: algorithmic FLOPs of one step / the step's WALL time (the
+                       step replays on two overlapping streams, so summed kernel durations are not a denominator; the
+                       kernel-time figure of an instrumented single-stream pass is given beside it as `kernel_time`)
+  cpu_baseline         the CPU oracle (torch-CPU RedNet port + C mapper + torch-CPU policy port) on this box's host cores
+  gt_semantics_step    BASELINE configs[1] (gt semantics, 4 envs): its own value / roofline / mapper_roofline / cpu_baseline
+  update_step          DAgger update T=64 x N=8 per GPU (fwd + bwd + all-reduce + Adam): MFMA roofline with PMC traffic,
+                       and the oracle's update (torch-CPU loss + autograd + torch.optim.Adam) as its cpu_baseline
+  dagger_collect_step  sampled DAgger collection step at 8 envs (replayed), with the eager figure
+  dagger_iteration     64 replayed collection steps alternating with 4 eager updates in ONE process, against the sum of
+                       the two legs timed on their own (the graph-replay / eager-update interaction)
 """
 import argparse
 import json
@@ -152,10 +158,22 @@ class GemmTimer:
         return self._ms
 
 
-def mfma_roofline(gt, ms, n_steps, traffic, what):
-    """`traffic` arrives as the committed PMC figure per LAUNCH (the contract's unit: per launch, like `achieved`); the
-    per-STEP total is spelled out beside it, and so is the time basis of `achieved` / `frac`."""
-    ach = (gt.flops / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
+def stats_of(ms_list):
+    """median / min / max of the repetitions' per-step times."""
+    v = sorted(ms_list)
+    med = v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
+    return med, v[0], v[-1]
+
+
+def mfma_roofline(gt, ms, n_steps, traffic, what, wall_ms_per_step=None):
+    """`achieved` / `frac`: algorithmic FLOPs of one step over the step's WALL time when the timed step overlaps streams
+    (`wall_ms_per_step` given: summed kernel durations of two concurrent queues are not a denominator - VERDICT r3), else
+    over the summed kernel durations.  The kernel-time figure of the instrumented pass is always carried as
+    `kernel_time`.  `traffic` arrives as the committed PMC figure per LAUNCH (the contract's unit: per launch, like
+    `achieved`); the per-STEP total is spelled out beside it."""
+    flops_step = gt.flops / n_steps
+    k_ach = (gt.flops / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
+    ach = (flops_step / (wall_ms_per_step * 1e-3)) / 1e12 if wall_ms_per_step else k_ach
     per_launch, per_step = traffic if isinstance(traffic, tuple) else (traffic, None)
     return {
         "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -163,11 +181,17 @@ def mfma_roofline(gt, ms, n_steps, traffic, what):
         "traffic_unit": "HBM bytes per launch of the family (rocprofv3 PMC passes committed under profiles/)",
         "traffic_bytes_per_step": per_step,
         "kernel": MFMA_FAMILY + ": " + what,
-        "flops_per_step": int(gt.flops / n_steps), "launches_per_step": round(gt.launches / n_steps, 1),
-        "kernel_ms_per_step": round(ms / n_steps, 4),
-        "time_basis": "sum of the family's kernel durations - a start / stop HIP event on every dispatch "
-                      "(hipExtLaunchKernelGGL through ivln_family_timing_begin / _end), the per-kernel figure rocprofv3 "
-                      "reports - in an instrumented EAGER single-stream pass outside the timed region",
+        "flops_per_step": int(flops_step), "launches_per_step": round(gt.launches / n_steps, 1),
+        "basis": ("algorithmic FLOPs of one step / WALL time of the timed step (median repetition): the step replays on "
+                  "two overlapping streams, every other kernel of the step is inside the denominator" if wall_ms_per_step
+                  else "algorithmic FLOPs / summed kernel durations of the family"),
+        "kernel_time": {
+            "achieved": round(k_ach, 3), "frac": round(k_ach / PEAK_F32_MFMA_TFLOPS, 5),
+            "kernel_ms_per_step": round(ms / n_steps, 4),
+            "time_basis": "sum of the family's kernel durations - a start / stop HIP event on every dispatch "
+                          "(hipExtLaunchKernelGGL through ivln_family_timing_begin / _end), the per-kernel figure rocprofv3 "
+                          "reports - in an instrumented EAGER single-stream pass outside the timed region",
+        },
     }
 
 
@@ -265,7 +289,7 @@ def pmc_traffic(name, key):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs,
     gfx950 FETCH correction applied; profiles/<name>).  A counter pass cannot run inside the timed bench, so the
     figure is the committed one and only for its workload; None when no such profile is committed."""
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_{name}")
         if os.path.exists(path):
             try:
@@ -286,17 +310,12 @@ def inflection_weights(targets_TN, coef=3.2):
     return torch.where(infl, torch.tensor(coef), torch.tensor(1.0))
 
 
-def bench_update(policy, dev, world, barrier, T=64, N=8, iters=5, warm=2):
-    """DAgger update step (base_il_trainer.py:173-219) on SURVEY section 8d's synthetic batch: forward over T*N rows
-    with BPTT, inflection-weighted CE + progress-monitor aux loss (quirk Q7), hand-written HIP backward, one
-    flat-bucket RCCL all-reduce (world > 1), Adam.  Same barrier / max-over-ranks clock as the rollout leg."""
-    from ivln_ce_amd.aux_losses import AuxLosses
-    from ivln_ce_amd.trainers import FlatAdam, update_agent
+def update_batch(T, N, seed=7):
+    """SURVEY section 8d's synthetic update batch on the host: (obs incl. de-duplicated, trimmed instructions, prev, nd,
+    targets, weights) plus the un-trimmed per-row instruction tensor the oracle takes."""
     from ivln_ce_amd.utils import dedupe_instructions, trim_instruction_padding
 
-    policy.train()
-    opt = FlatAdam(policy, lr=2.5e-4)
-    g = torch.Generator().manual_seed(7)
+    g = torch.Generator().manual_seed(seed)
     TN = T * N
     instr = torch.zeros(N, 200)
     instr[:, :80] = torch.randint(2, 2504, (N, 80), generator=g).float()
@@ -304,105 +323,230 @@ def bench_update(policy, dev, world, barrier, T=64, N=8, iters=5, warm=2):
     # like the reference's packed LSTM, the update only ever sees the batch's longest instruction (80 of 200)
     # ... and hands the policy the batch's UNIQUE token rows + each row's index (one encoding per trajectory)
     host = dedupe_instructions(trim_instruction_padding({"instruction": instr.repeat(T, 1)}, first_rows=N))
-    obs = {"depth_features": torch.randn(TN, 128, 4, 4, generator=g).to(dev),
-           "occupancy_map": (torch.rand(TN, 64, 64, generator=g) < 0.3).float().to(dev),
-           "semantic_map": torch.randint(0, 13, (TN, 64, 64), generator=g).float().to(dev),
-           "progress": torch.rand(TN, 1, generator=g).to(dev)}
-    obs.update({k: v.float().to(dev) for k, v in host.items()})  # batch_to casts every observation to float32
-    prev = torch.randint(0, 4, (TN, 1), generator=g).to(dev)
+    obs = {"depth_features": torch.randn(TN, 128, 4, 4, generator=g),
+           "occupancy_map": (torch.rand(TN, 64, 64, generator=g) < 0.3).float(),
+           "semantic_map": torch.randint(0, 13, (TN, 64, 64), generator=g).float(),
+           "progress": torch.rand(TN, 1, generator=g)}
+    obs.update({k: v.float() for k, v in host.items()})  # batch_to casts every observation to float32
+    prev = torch.randint(0, 4, (TN, 1), generator=g)
     nd = torch.ones(T, N, dtype=torch.uint8)
     nd[0] = 0
-    nd = nd.view(-1, 1).to(dev)
-    tgt_cpu = torch.randint(0, 4, (T, N), generator=g)
-    tgt = tgt_cpu.to(dev)
-    w = inflection_weights(tgt_cpu).to(dev)
-    AuxLosses.activate()
-    try:
-        for _ in range(warm):
-            update_agent(policy, opt, obs, prev, nd, tgt, w, world=world)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            update_agent(policy, opt, obs, prev, nd, tgt, w, world=world)
-        barrier()
-        el = time.perf_counter() - t0
-        # MFMA kernel family of one update (instrumented pass, outside the timed region).  The event pairs sum
-        # per-launch elapsed times, so the pass runs everything on one stream: with the instruction branch on its
-        # side stream (the timed configuration) concurrent launches would be counted twice over the same wall time.
+    nd = nd.view(-1, 1)
+    tgt = torch.randint(0, 4, (T, N), generator=g)
+    return obs, prev, nd, tgt, inflection_weights(tgt), instr.repeat(T, 1)
+
+
+class UpdateLeg:
+    """DAgger update step (base_il_trainer.py:173-219) on SURVEY section 8d's synthetic batch: forward over T*N rows
+    with BPTT, inflection-weighted CE + progress-monitor aux loss (quirk Q7), hand-written HIP backward, one
+    flat-bucket RCCL all-reduce (world > 1), Adam."""
+
+    def __init__(self, policy, dev, world, T=64, N=8):
+        from ivln_ce_amd.trainers import FlatAdam
+
+        self.policy, self.dev, self.world, self.T, self.N = policy, dev, world, T, N
+        policy.train()
+        self.opt = FlatAdam(policy, lr=2.5e-4)
+        obs, prev, nd, tgt, w, self.instr_rows = update_batch(T, N)
+        self.host = (obs, prev, nd, tgt, w)
+        self.args = ({k: v.to(dev) for k, v in obs.items()}, prev.to(dev), nd.to(dev), tgt.to(dev), w.to(dev))
+
+    def once(self):
+        from ivln_ce_amd.trainers import update_agent
+
+        return update_agent(self.policy, self.opt, *self.args, world=self.world)
+
+    def timed(self, barrier, max_over_ranks, iters=5, warm=2, reps=5):
+        """`reps` repetitions of `iters` updates, each bracketed by the barrier; -> list of ms per update."""
+        from ivln_ce_amd.aux_losses import AuxLosses
+
+        AuxLosses.activate()
+        try:
+            for _ in range(warm):
+                self.once()
+            out = []
+            for _ in range(reps):
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(iters):
+                    self.once()
+                barrier()
+                out.append(1e3 * max_over_ranks(time.perf_counter() - t0) / iters)
+        finally:
+            AuxLosses.deactivate()
+        return out
+
+    def roofline(self):
+        """MFMA kernel family of one update (instrumented pass, outside the timed region).  The durations are summed, so the
+        pass runs everything on one stream: with the instruction branch on its side stream (the timed configuration)
+        concurrent launches would be counted twice over the same wall time."""
         from ivln_ce_amd import train as _train
+        from ivln_ce_amd.aux_losses import AuxLosses
 
         overlap, _train.OVERLAP_INSTRUCTION = _train.OVERLAP_INSTRUCTION, False
+        AuxLosses.activate()
         try:
             with GemmTimer() as gt:
-                update_agent(policy, opt, obs, prev, nd, tgt, w, world=world)
+                self.once()
                 ms = gt.total_ms()
         finally:
             _train.OVERLAP_INSTRUCTION = overlap
-    finally:
-        AuxLosses.deactivate()
-    ach = (gt.flops / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
-    roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "flops_per_update": int(gt.flops),
-            "launches_per_update": gt.launches, "kernel_ms_per_update": round(ms, 3),
-            "kernel": "fp32 MFMA family: k_conv_direct / k_wgrad_direct / k_gemm_vec / k_gemm"}
-    policy.eval()
-    return el, {"rows_per_step_per_gpu": TN, "T": T, "N": N, "iters": iters, "roofline": roof}
+            AuxLosses.deactivate()
+        ach = (gt.flops / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
+        tr = pmc_traffic_pair("update_pmc_traffic.json")
+        return {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None if tr is None else tr[0],
+                "traffic_unit": "HBM bytes per launch of the family (rocprofv3 PMC passes committed under profiles/)",
+                "traffic_bytes_per_update": None if tr is None else tr[1],
+                "flops_per_update": int(gt.flops), "launches_per_update": gt.launches, "kernel_ms_per_update": round(ms, 3),
+                "basis": "algorithmic FLOPs / summed kernel durations of the family (single-stream instrumented pass)",
+                "kernel": "fp32 MFMA family: k_conv_direct / k_wgrad_direct / k_gemm_vec / k_gemm"}
+
+    def cpu_baseline(self, budget_s=25.0):
+        """The oracle's update on the host cores: `MapCMAPolicyRef.update_loss` (base_il_trainer.py:173-219 restated
+        in torch CPU) + autograd backward + torch.optim.Adam on the same T x N batch."""
+        from oracle.policy_ref import MapCMAPolicyRef
+
+        ncores = usable_cores()
+        torch.set_num_threads(ncores)
+        torch.manual_seed(0)
+        ref = MapCMAPolicyRef(use_pm=True).train()
+        opt = torch.optim.Adam(ref.parameters(), lr=2.5e-4)
+        obs, prev, nd, tgt, w = self.host
+        obs = {k: v for k, v in obs.items() if not k.startswith("instruction_")}
+        obs["instruction"] = self.instr_rows  # (the oracle encodes every row's own 200-token instruction tensor)
+
+        def one():
+            opt.zero_grad()
+            loss = ref.update_loss(obs, prev, nd, tgt, w)[0]
+            loss.backward()
+            opt.step()
+
+        one()  # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            one()
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget_s or n >= 8:
+                break
+        rows = self.T * self.N
+        return {"value": round(rows * n / el, 2), "unit": "rows/s", "cores": ncores, "kind": "port",
+                "ms_per_update": round(1e3 * el / n, 1),
+                "sample": f"{n} update(s) of T={self.T} x N={self.N} rows after 1 warm-up: oracle/policy_ref.py update_loss + "
+                          f"autograd backward + torch.optim.Adam, {ncores} threads"}
 
 
-def bench_collect(cfg, policy, dev, rank, barrier, B=8, K=100, W=10, graph=True, seed=99):
+class CollectLeg:
     """One step of a DAgger COLLECTION (dagger_trainer.py:416-494; configs[3]'s per-GPU shard of 8 envs): mapper +
     `policy.act(deterministic=False)` + beta-mixing with the expert + the -1 rule, then what the loop keeps of the step
     on the host - actions, the two maps, the frozen depth encoder's features - through trainers._RolloutStepper,
     exactly as `_update_dataset` drives it (policy in train mode: quirk Q6).  Env stepping and trajectory storage
     are host work outside the hot path.  Observations are resident in HBM when the clock starts."""
-    from ivln_ce_amd import trainers
-    from ivln_ce_amd.obs_transforms import GTSemanticsIterativeMapper
 
-    cfg = cfg.clone()
-    cfg.defrost()
-    cfg.IL.DAGGER.USE_HIP_GRAPH = bool(graph)
-    cfg.freeze()
-    tr = trainers.DaggerTrainer.__new__(trainers.DaggerTrainer)
-    tr.config, tr.device, tr.policy = cfg, dev, policy
-    tr.rank, tr.local_rank, tr.world = rank, dev.index or 0, 1
-    tr.obs_transforms = [GTSemanticsIterativeMapper.from_config(cfg)]
-    uuid = cfg.IL.DAGGER.expert_policy_sensor_uuid
-    n_pool = min(W + K, 120)
-    g = torch.Generator().manual_seed(seed + rank)
-    obs = to_dev(gen_observations(B, n_pool, seed=seed + rank), dev)
-    for o in obs:
-        o[uuid] = torch.randint(0, 4, (B, 1), generator=g).double().to(dev)
-    was_training = policy.training
-    policy.train()
-    stepper = trainers._RolloutStepper(tr, beta=0.75, expert_uuid=uuid, iterative=False)
-    rnn = torch.zeros(B, 2, 512, device=dev)
-    prev = torch.zeros(B, 1, dtype=torch.long, device=dev)
+    def __init__(self, cfg, policy, dev, rank, B=8, n_pool=110, graph=True, seed=99):
+        from ivln_ce_amd import trainers
+        from ivln_ce_amd.obs_transforms import GTSemanticsIterativeMapper
 
-    def do_step(i):
-        nonlocal rnn, prev
-        batch = dict(obs[i % n_pool])
-        if not stepper.use_graph:
-            batch = tr.obs_transforms[0](batch)
+        cfg = cfg.clone()
+        cfg.defrost()
+        cfg.IL.DAGGER.USE_HIP_GRAPH = bool(graph)
+        cfg.freeze()
+        self.trainers = trainers
+        tr = trainers.DaggerTrainer.__new__(trainers.DaggerTrainer)
+        tr.config, tr.device, tr.policy = cfg, dev, policy
+        tr.rank, tr.local_rank, tr.world = rank, dev.index or 0, 1
+        tr.obs_transforms = [GTSemanticsIterativeMapper.from_config(cfg)]
+        self.tr, self.B, self.dev, self.policy, self.n_pool = tr, B, dev, policy, n_pool
+        self.uuid = cfg.IL.DAGGER.expert_policy_sensor_uuid
+        g = torch.Generator().manual_seed(seed + rank)
+        self.obs = to_dev(gen_observations(B, n_pool, seed=seed + rank), dev)
+        for o in self.obs:
+            o[self.uuid] = torch.randint(0, 4, (B, 1), generator=g).double().to(dev)
+        self.stepper = None
+        self.i = 0
+
+    def open(self):
+        """A collection phase starts (`_update_dataset`): policy in train mode, a fresh stepper (fresh capture)."""
+        self.was_training = self.policy.training
+        self.policy.train()
+        self.stepper = self.trainers._RolloutStepper(self.tr, beta=0.75, expert_uuid=self.uuid, iterative=False)
+        self.rnn = torch.zeros(self.B, 2, 512, device=self.dev)
+        self.prev = torch.zeros(self.B, 1, dtype=torch.long, device=self.dev)
+
+    def step(self):
+        batch = dict(self.obs[self.i % self.n_pool])
+        self.i += 1
+        if not self.stepper.use_graph:
+            batch = self.tr.obs_transforms[0](batch)
         with torch.no_grad():
-            prev, rnn, host = stepper.step(batch, rnn, prev, (batch["not_done_masks"],))
+            self.prev, self.rnn, host = self.stepper.step(batch, self.rnn, self.prev, (batch["not_done_masks"],))
         return host
 
+    def close(self):
+        used = self.stepper.use_graph
+        self.tr.obs_transforms[0].mapping_module.check_status()
+        self.stepper.close()
+        self.stepper = None
+        self.policy.train(self.was_training)
+        return used
+
+    def timed(self, barrier, max_over_ranks, K, W, reps):
+        """-> (list of ms per step over `reps` repetitions of K steps, replayed as graphs?)"""
+        self.open()
+        try:
+            for _ in range(W):
+                self.step()
+            out = []
+            for _ in range(reps):
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(K):
+                    host = self.step()
+                barrier()
+                out.append(1e3 * max_over_ranks(time.perf_counter() - t0) / K)
+            assert host["depth"].shape == (self.B, 128, 4, 4) and host["occ"].shape == (self.B, 64, 64) and len(host["actions"]) == self.B
+        finally:
+            used = self.close()
+        return out, used
+
+
+def dagger_iteration_leg(collect, update, barrier, max_over_ranks, n_collect=64, n_update=4, iters=5):
+    """What a DAgger iteration alternates, in ONE process: a collection phase replayed as hipGraphs (`n_collect` steps
+    after a fresh capture, like every `_update_dataset`) and `n_update` eager updates (ops.eager_work_stream).  Round 3
+    saw updates run 25 % slower on a stream that had replayed graphs; this leg is the number of record for the
+    alternation.  The capture itself (once per collection phase of thousands of steps in a real run) and its two
+    warm-up steps are outside the clock."""
+    from ivln_ce_amd.aux_losses import AuxLosses
+
+    c_ms, u_ms = [], []
+    AuxLosses.activate()
     try:
-        for i in range(W):
-            do_step(i)
-        barrier()
-        t0 = time.perf_counter()
-        for i in range(K):
-            host = do_step(W + i)
-        barrier()
-        el = time.perf_counter() - t0
-        assert host["depth"].shape == (B, 128, 4, 4) and host["occ"].shape == (B, 64, 64) and len(host["actions"]) == B
-        tr.obs_transforms[0].mapping_module.check_status()
-        used_graph = stepper.use_graph
+        for it in range(iters + 1):  # iteration 0 = warm-up
+            collect.open()
+            try:
+                for _ in range(2):
+                    collect.step()
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(n_collect):
+                    collect.step()
+                barrier()
+                t1 = time.perf_counter()
+            finally:
+                collect.close()
+            barrier()
+            t2 = time.perf_counter()
+            for _ in range(n_update):
+                update.once()
+            barrier()
+            t3 = time.perf_counter()
+            if it:
+                c_ms.append(1e3 * max_over_ranks(t1 - t0) / n_collect)
+                u_ms.append(1e3 * max_over_ranks(t3 - t2) / n_update)
     finally:
-        stepper.close()
-        policy.train(was_training)
-    return el, used_graph
+        AuxLosses.deactivate()
+    return c_ms, u_ms
 
 
 def mapper_roofline(mapper_tr, obs_dev, B, n_steps=20):
@@ -525,16 +669,19 @@ def plumbing_only(args, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--envs", type=int, default=4, help="parallel envs per GPU of the headline (configs[1]: 4)")
-    ap.add_argument("--pred-envs", type=int, default=8, help="envs per GPU of the pred-semantics leg (configs[2]: 8)")
-    ap.add_argument("--pred-semantics", action="store_true",
-                    help="make BASELINE configs[2] (RedNet-predicted semantics, --pred-envs envs) the headline `value`")
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--reps", type=int, default=5, help="repetitions of the K-step timed region per leg (median reported)")
+    ap.add_argument("--envs", type=int, default=4, help="parallel envs per GPU of the gt-semantics leg (configs[1]: 4)")
+    ap.add_argument("--pred-envs", type=int, default=8, help="envs per GPU of the pred-semantics headline (configs[2]: 8)")
+    ap.add_argument("--pred-semantics", action="store_true", help="(default since round 4) configs[2] is the headline")
+    ap.add_argument("--gt-semantics", action="store_true",
+                    help="profiling aid: make BASELINE configs[1] (gt semantics, --envs envs) the headline `value`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-pred-leg", action="store_true", help="skip the pred-semantics leg (extra JSON object)")
+    ap.add_argument("--no-pred-leg", action="store_true", help="skip the OTHER rollout leg (the one that is not the headline)")
+    ap.add_argument("--no-gt-leg", action="store_true", help="same as --no-pred-leg")
     ap.add_argument("--no-update", action="store_true", help="skip the DAgger update-step leg (extra JSON object)")
-    ap.add_argument("--no-collect", action="store_true", help="skip the DAgger collection-step leg (extra JSON object)")
+    ap.add_argument("--no-collect", action="store_true", help="skip the DAgger collection-step and iteration legs")
     ap.add_argument("--collect-envs", type=int, default=8, help="envs per GPU of the collection leg (configs[3]: 64 / 8)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--single-stream", action="store_true",
@@ -593,23 +740,30 @@ def main():
             return float(t.item())
         return seconds
 
-    K, W = args.steps, args.warmup
+    K, W, R = args.steps, args.warmup, max(1, args.reps)
     cfg, policy = make_policy(dev)
+
+    def rep_obj(ms_list, per="step"):
+        med, lo, hi = stats_of(ms_list)
+        return {"n": len(ms_list), f"ms_per_{per}_median": round(med, 4), f"ms_per_{per}_min": round(lo, 4),
+                f"ms_per_{per}_max": round(hi, 4),
+                "note": f"each repetition = barrier + synchronize, EXACTLY the stated number of {per}s, barrier + synchronize, "
+                        "MAX over ranks; the leg's value is the median repetition"}
+
     if args.only_update:
-        uel, uinfo = bench_update(policy, dev, world, barrier, iters=max(5, min(K, 20)))
-        uel = max_over_ranks(uel)  # (a collective: every rank)
+        ul = UpdateLeg(policy, dev, world)
+        ums = ul.timed(barrier, max_over_ranks, iters=max(5, min(K, 20)), reps=1)  # (a collective: every rank)
         if rank == 0:
-            print(json.dumps({"update_step": {"ms_per_update": round(1e3 * uel / uinfo["iters"], 3),
-                                              "roofline": uinfo["roofline"]}}), flush=True)
+            print(json.dumps({"update_step": {"ms_per_update": round(ums[0], 3), "roofline": ul.roofline()}}), flush=True)
         return
     mode = False if args.no_graph else (True if args.streams else (False if args.single_stream else "split"))
 
     def run_leg(pred, B, K, W, seed):
-        """Time K steps of one workload after W warm-up steps: barrier + synchronize on both sides, max over
-        ranks.  Returns the leg's dict of results and what the instrumented passes need."""
+        """R repetitions of: K steps of one workload, barrier + synchronize on both sides, max over ranks (W warm-up
+        steps once, after the capture).  Returns the leg's dict of results and what the instrumented passes need."""
         cls = PredictedSemanticsIterativeMapper if pred else GTSemanticsIterativeMapper
         tr = cls.from_config(cfg)
-        n_pool = min(W + K, 240 if not pred else 32)
+        n_pool = min(W + K * R, 240 if not pred else 32)
         obs_cpu = gen_observations(B, n_pool, seed=seed + rank, with_rgb=pred)
         obs_dev = to_dev(obs_cpu, dev)
         state = {"rnn": torch.zeros(B, 2, 512, device=dev), "prev": torch.zeros(B, 1, dtype=torch.long, device=dev)}
@@ -625,21 +779,24 @@ def main():
                 rollout_step(tr, policy, obs_dev[i % n_pool], state)
         for i in range(W):
             do_step(i)
-        barrier()
-        t0 = time.perf_counter()
-        for i in range(K):
-            do_step(W + i)
-        barrier()
-        el = max_over_ranks(time.perf_counter() - t0)
+        ms, i = [], W
+        for _ in range(R):
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(K):
+                do_step(i)
+                i += 1
+            barrier()
+            ms.append(1e3 * max_over_ranks(time.perf_counter() - t0) / K)
         tr.mapping_module.check_status()
         del runner  # graphs hold the activation pools
-        return {"el": el, "tr": tr, "obs_cpu": obs_cpu, "obs_dev": obs_dev, "state": state, "n_pool": n_pool,
-                "launch": ("hipGraph replay, " + note) if note else "eager"}
+        return {"ms": ms, "tr": tr, "obs_cpu": obs_cpu, "obs_dev": obs_dev, "state": state, "n_pool": n_pool, "B": B,
+                "launch": ("hipGraph replay, " + note) if note else "eager", "overlapped": note is not None and "2 streams" in note}
 
     def instrumented_mfma(leg, n_inst, what, traffic):
-        """MFMA-family roofline of a leg: eager pass with an event pair per GEMM-family launch, the GPU parked on a
-        spin kernel while the host enqueues each step so that pairs time back-to-back kernels (what rocprofv3's
-        per-kernel durations show) and not the host's launch gaps.  Not part of any `value`."""
+        """MFMA-family figures of a leg from an eager pass with a start / stop event on every GEMM-family dispatch, the GPU
+        parked on a spin kernel while the host enqueues each step so that the durations are those of back-to-back kernels
+        (what rocprofv3's per-kernel durations show) and not the host's launch gaps.  Not part of any `value`."""
         from ivln_ce_amd.rednet import PredictSemantics
 
         # the timed configuration replays RedNet's recorded launch table through ONE C call (ivln_rednet_fwd), which
@@ -657,70 +814,77 @@ def main():
                 ms = gt.total_ms()
         finally:
             PredictSemantics.USE_PLAN = plan
-        return mfma_roofline(gt, ms, n_inst, traffic, what)
+        med = stats_of(leg["ms"])[0]
+        return mfma_roofline(gt, ms, n_inst, traffic, what, wall_ms_per_step=med)
 
-    head_pred = args.pred_semantics
-    B = args.pred_envs if head_pred else args.envs
-    log(f"rank {rank}: headline leg ({'configs[2] pred-semantics' if head_pred else 'configs[1] gt-semantics'}, {B} envs)")
-    head = run_leg(head_pred, B, K, W, seed=1234)
-    log(f"rank {rank}: timed region {head['el']:.3f}s")
-
-    roofline = mapper_roof = None
-    if rank == 0:
-        if head_pred:
-            roofline = instrumented_mfma(head, min(6, K), "RedNet + depth ResNet + map CNN launches of one step",
-                                         pmc_traffic_pair(f"predsem_B{B}_pmc_traffic.json"))
-        else:
-            roofline = instrumented_mfma(head, min(20, K), "all conv/linear launches of one step",
-                                         pmc_traffic_pair("rollout_pmc_traffic.json") if B == 4 else None)
-            mapper_roof = mapper_roofline(head["tr"], head["obs_dev"], B)
-
-    # ---- configs[2]: RedNet-predicted semantics feeding the mapper, at its stated 8 envs ----
-    pred_leg = None
-    if not head_pred and not args.no_pred_leg:
-        Bp, pk, pw = args.pred_envs, 30, 5
-        log(f"rank {rank}: pred-semantics leg ({Bp} envs)")
-        pl = run_leg(True, Bp, pk, pw, seed=4321)
-        pred_leg = {
-            "value": round(world * Bp * pk / pl["el"], 1), "unit": "env-steps/s",
-            "ms_per_step": round(1e3 * pl["el"] / pk, 3), "steps": pk, "warmup": pw, "envs_per_gpu": Bp,
-            "config": {"workload": f"BASELINE configs[2]: RedNet(rgb 224x224 -> 256x256, depth) -> arg-max labels -> "
-                                   f"egocentric mapper -> MapCMAPolicy.act, {Bp} envs per GPU",
-                       "launch": pl["launch"]},
-        }
+    def leg_object(leg, pred, what_cfg):
+        med = stats_of(leg["ms"])[0]
+        Bl = leg["B"]
+        obj = {"value": round(world * Bl / (med * 1e-3), 2), "unit": "env-steps/s", "ms_per_step": round(med, 4),
+               "steps": K, "warmup": W, "repetitions": rep_obj(leg["ms"]), "envs_per_gpu": Bl,
+               "config": {"workload": what_cfg, "envs_per_gpu": Bl, "launch": leg["launch"]}}
         if rank == 0:
-            pred_leg["roofline"] = instrumented_mfma(
-                pl, 4, "RedNet + depth ResNet + map CNN launches of one step",
-                pmc_traffic_pair(f"predsem_B{Bp}_pmc_traffic.json"))
+            if pred:
+                obj["roofline"] = instrumented_mfma(leg, min(6, K), "RedNet + depth ResNet + map CNN launches of one step",
+                                                    pmc_traffic_pair(f"predsem_B{Bl}_pmc_traffic.json"))
+            else:
+                obj["roofline"] = instrumented_mfma(leg, min(20, K), "all conv/linear launches of one step",
+                                                    pmc_traffic_pair("rollout_pmc_traffic.json") if Bl == 4 else None)
+                obj["mapper_roofline"] = mapper_roofline(leg["tr"], leg["obs_dev"], Bl)
             if world == 1 and not args.no_cpu_baseline:
-                log("cpu baseline (pred-semantics) ...")
-                pred_leg["cpu_baseline"] = cpu_baseline(pl["obs_cpu"], Bp, budget_s=12.0, pred=True)
-        del pl
+                log(f"cpu baseline ({'pred' if pred else 'gt'}-semantics) ...")
+                obj["cpu_baseline"] = cpu_baseline(leg["obs_cpu"], Bl, budget_s=12.0, pred=pred)
+        return obj
+
+    W_PRED = ("BASELINE configs[2] (the largest single-GPU configuration): MapCMA pred-semantics eval step = RedNet(rgb "
+              "224x224 -> 256x256, depth) -> arg-max labels -> egocentric mapper -> MapCMAPolicy.act, {B} parallel envs per GPU, "
+              "256x256 depth + 224x224 rgb, 80-token instruction, random-init weights of the reference architecture")
+    W_GT = ("BASELINE configs[1]: MapCMA gt-semantics eval step = egocentric mapper + MapCMAPolicy.act, {B} parallel envs per "
+            "GPU, 256x256 depth + semantic12, 80-token instruction, random-init weights of the reference architecture")
+    head_pred = not args.gt_semantics
+    other = not (args.no_pred_leg or args.no_gt_leg)
+    legs = {}
+    for pred in ((True, False) if head_pred else (False, True)):
+        if pred != head_pred and not other:
+            continue
+        Bl = args.pred_envs if pred else args.envs
+        log(f"rank {rank}: {'configs[2] pred-semantics' if pred else 'configs[1] gt-semantics'} leg, {Bl} envs"
+            + (" (headline)" if pred == head_pred else ""))
+        leg = run_leg(pred, Bl, K, W, seed=4321 if pred else 1234)
+        log(f"rank {rank}: ms per step over {R} repetitions of {K} steps: " + ", ".join(f"{m:.4f}" for m in leg["ms"]))
+        legs[pred] = leg_object(leg, pred, (W_PRED if pred else W_GT).format(B=Bl))
+        del leg
 
     # ---- DAgger update step (fwd + bwd + all-reduce + Adam): reported beside the headline ----
-    update = None
+    update = ul = None
     if not args.no_update:
         log(f"rank {rank}: update-step leg")
-        uel, uinfo = bench_update(policy, dev, world, barrier)
-        uel = max_over_ranks(uel)
-        update = {"value": round(world * uinfo["rows_per_step_per_gpu"] * uinfo["iters"] / uel, 1), "unit": "rows/s",
-                  "ms_per_update": round(1e3 * uel / uinfo["iters"], 3),
-                  "rows_per_update_per_gpu": uinfo["rows_per_step_per_gpu"],
-                  "what": f"DAgger update T={uinfo['T']} x N={uinfo['N']} per GPU from cached depth features (SURVEY 8d "
+        ul = UpdateLeg(policy, dev, world)
+        ums = ul.timed(barrier, max_over_ranks, iters=5, warm=2, reps=R)
+        umed = stats_of(ums)[0]
+        rows = ul.T * ul.N
+        update = {"value": round(world * rows / (umed * 1e-3), 1), "unit": "rows/s", "ms_per_update": round(umed, 3),
+                  "repetitions": rep_obj(ums, per="update"), "updates_per_repetition": 5, "rows_per_update_per_gpu": rows,
+                  "what": f"DAgger update T={ul.T} x N={ul.N} per GPU from cached depth features (SURVEY 8d "
                           "batch: inflection weights 3.2 from the targets, progress U(0,1)): MapCMA forward with BPTT, "
                           "inflection-weighted CE + progress-monitor aux loss, HIP backward, "
-                          + ("one flat RCCL all-reduce, " if world > 1 else "") + "Adam",
-                  "roofline": uinfo["roofline"]}
+                          + ("one flat RCCL all-reduce, " if world > 1 else "") + "Adam"}
+        if rank == 0:
+            update["roofline"] = ul.roofline()
+            if world == 1 and not args.no_cpu_baseline:
+                log("cpu baseline (update) ...")
+                update["cpu_baseline"] = ul.cpu_baseline()
 
     # ---- DAgger collection step (sampled action + beta-mix + host copies): the rollout half of configs[3] ----
-    collect = None
-    if not args.no_collect and not head_pred:
-        Bc, ck, cw = args.collect_envs, 100, 10
+    collect = iteration = None
+    if not args.no_collect:
+        Bc, ck, cw = args.collect_envs, K, W
         log(f"rank {rank}: collection-step leg ({Bc} envs)")
-        cel, used_graph = bench_collect(cfg, policy, dev, rank, barrier, B=Bc, K=ck, W=cw, graph=not args.no_graph)
-        cel = max_over_ranks(cel)
-        collect = {"value": round(world * Bc * ck / cel, 1), "unit": "env-steps/s", "ms_per_step": round(1e3 * cel / ck, 4),
-                   "steps": ck, "warmup": cw, "envs_per_gpu": Bc,
+        cl = CollectLeg(cfg, policy, dev, rank, B=Bc, graph=not args.no_graph)
+        cms, used_graph = cl.timed(barrier, max_over_ranks, ck, cw, R)
+        cmed = stats_of(cms)[0]
+        collect = {"value": round(world * Bc / (cmed * 1e-3), 1), "unit": "env-steps/s", "ms_per_step": round(cmed, 4),
+                   "steps": ck, "warmup": cw, "repetitions": rep_obj(cms), "envs_per_gpu": Bc,
                    "launch": "hipGraph replay, 3 graphs on 2 streams" if used_graph else "eager",
                    "what": "DAgger collection step of configs[3]'s per-GPU shard: gt-semantics mapper + MapCMAPolicy.act "
                            "SAMPLED on the device from host uniforms, beta-mixed with the expert action (beta = 0.75) "
@@ -728,40 +892,52 @@ def main():
                            "(BatchNorm batch statistics, quirk Q6); actions, both maps and the cached depth features "
                            "land in pinned host memory behind ONE synchronisation per step"}
         if used_graph and rank == 0 and world == 1:  # the same step as eager launches, for the record
-            eel, _ = bench_collect(cfg, policy, dev, rank, barrier, B=Bc, K=30, W=5, graph=False)
-            collect["eager_ms_per_step"] = round(1e3 * eel / 30, 4)
+            ce = CollectLeg(cfg, policy, dev, rank, B=Bc, graph=False)
+            ems, _ = ce.timed(barrier, max_over_ranks, min(30, ck), 5, 1)
+            collect["eager_ms_per_step"] = round(ems[0], 4)
+            del ce
+        if ul is not None and used_graph:
+            log(f"rank {rank}: DAgger-iteration leg (64 replayed collection steps <-> 4 eager updates)")
+            c_ms, u_ms = dagger_iteration_leg(cl, ul, barrier, max_over_ranks)
+            cm, um = stats_of(c_ms)[0], stats_of(u_ms)[0]
+            iteration = {
+                "value": round(1e3 / (64 * cm + 4 * um), 3), "unit": "iterations/s (64 collection steps + 4 updates)",
+                "ms_per_iteration": round(64 * cm + 4 * um, 3), "iterations": len(c_ms),
+                "collect_ms_per_step": round(cm, 4), "collect_ms_per_step_min_max": [round(min(c_ms), 4), round(max(c_ms), 4)],
+                "update_ms_per_update": round(um, 3), "update_ms_per_update_min_max": [round(min(u_ms), 3), round(max(u_ms), 3)],
+                "legs_alone": {"collect_ms_per_step": collect["ms_per_step"], "update_ms_per_update": update["ms_per_update"],
+                               "ms_per_iteration": round(64 * collect["ms_per_step"] + 4 * update["ms_per_update"], 3)},
+                "what": "one process alternating a collection phase replayed as hipGraphs (fresh capture per phase, outside "
+                        f"the clock; {Bc} envs, sampled actions, host copies) with 4 eager DAgger updates (T=64 x N=8) on "
+                        "ops.eager_work_stream - the graph-replay / eager-update interaction of a real DAgger iteration; "
+                        "`legs_alone` = the same two legs timed on their own earlier in this run"}
+        del cl
 
-    why = ("headline = configs[2] by request (--pred-semantics)" if head_pred else
-           "headline = configs[1], the single-GPU configuration BASELINE.json's env-steps/s metric is quoted on "
-           "(configs[0] is the CPU plumbing case); configs[2] at its stated 8 envs is `pred_semantics_step` with its "
-           "own roofline and cpu_baseline, the DAgger update of configs[3]'s per-GPU shard is `update_step`")
+    head = legs[head_pred]
     out = {
-        "metric": METRIC, "value": round(world * B * K / head["el"], 2), "unit": "env-steps/s", "n_gpus": world,
-        "steps": K, "warmup": W, "ms_per_step": round(1e3 * head["el"] / K, 4), "higher_is_better": True,
+        "metric": METRIC, "value": head["value"], "unit": "env-steps/s", "n_gpus": world,
+        "steps": K, "warmup": W, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {
-            "workload": ("BASELINE configs[2]: MapCMA pred-semantics eval step = RedNet(rgb 224x224, depth) + egocentric "
-                         "mapper + MapCMAPolicy.act, " if head_pred else
-                         "BASELINE configs[1]: MapCMA gt-semantics eval step = egocentric mapper + MapCMAPolicy.act, ")
-                        + f"{B} parallel envs per GPU, 256x256 depth" + (" + 224x224 rgb" if head_pred else " + semantic12")
-                        + ", 80-token instruction, random-init weights of the reference architecture; " + why,
-            "envs_per_gpu": B, "parallelism": f"dp{world} (envs sharded, no data-path collective)",
-            "launch": head["launch"],
-        },
-        "roofline": roofline,
+        "repetitions": head["repetitions"],
+        "config": dict(head["config"], parallelism=f"dp{world} (envs sharded, no data-path collective)",
+                       headline=("configs[2], the largest single-GPU configuration of BASELINE.json (configs[0] is the CPU "
+                                 "plumbing case, configs[1] = `gt_semantics_step`, the DAgger update of configs[3]'s per-GPU "
+                                 "shard = `update_step`)" if head_pred else "configs[1] by request (--gt-semantics)")),
+        "roofline": head.get("roofline"),
     }
-    if mapper_roof is not None:
-        out["mapper_roofline"] = mapper_roof
+    if "cpu_baseline" in head:
+        out["cpu_baseline"] = head["cpu_baseline"]
+    if (not head_pred) and "mapper_roofline" in head:
+        out["mapper_roofline"] = head["mapper_roofline"]
+    if (not head_pred) in legs:
+        out["gt_semantics_step" if head_pred else "pred_semantics_step"] = legs[not head_pred]
     if update is not None:
         out["update_step"] = update
     if collect is not None:
         out["dagger_collect_step"] = collect
-    if pred_leg is not None:
-        out["pred_semantics_step"] = pred_leg
+    if iteration is not None:
+        out["dagger_iteration"] = iteration
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            log("cpu baseline ...")
-            out["cpu_baseline"] = cpu_baseline(head["obs_cpu"], B, pred=head_pred)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -606,20 +606,25 @@ _ZERO_GRAD_BIAS = lambda k: k.startswith("net.map_encoder.cnn.") and k.endswith(
 def test_three_hip_updates_track_oracle_plus_torch_adam(custom_lr):
     """Three consecutive `update_agent` + `FlatAdam` steps (what bench.py's update leg and the trainers run) against
     the oracle's loss + autograd + `torch.optim.Adam` built exactly as base_il_trainer.py:78-94 builds it (one group, or
-    the two-group MODEL.SEMANTIC_MAP_ENCODER.custom_lr form): every trainable parameter and every BatchNorm buffer
-    after every step.
+    the two-group MODEL.SEMANTIC_MAP_ENCODER.custom_lr form): every trainable parameter, both Adam moments of every
+    element and every BatchNorm buffer after every step.
+
+    The oracle runs in FLOAT64 here: the exact arithmetic both fp32 implementations approximate.  Measured in this
+    container on this batch (policy_update.npz): the reference-equivalent torch-CPU fp32 autograd is itself up to
+    5.9e-5 (4e-3 of the tensor's largest element) away from its own float64 run on net.map_encoder.cnn.2.conv.0.weight
+    (BatchNorm backward cancellation), and the first GPU run of this test found the HIP gradient 5.943e-5 away from the
+    fp32 oracle at that same element - i.e. ON the float64 value.  Against fp32 torch the chain could only be pinned to
+    the oracle's own noise; against float64 it is pinned to the arithmetic.
 
     Bars, per step:
       * Adam's moments (`exp_avg`, `exp_avg_sq` of EVERY trainable element, read out of the flat buckets) against
-        torch.optim.Adam's state: they are linear / quadratic in the gradients, so the gradient tolerance carries over
-        (exp_avg: atol 1e-6 + rtol 2e-3; exp_avg_sq: atol 1e-10 + rtol 5e-3);
+        torch.optim.Adam's state: exp_avg atol 3e-7 + rtol 1e-3 (the gradient to 3e-6), exp_avg_sq atol 1e-11 + rtol 2e-3;
       * parameters: allclose(atol=3e-6) on every element whose reference gradient was at least 1e-5 in magnitude in each
-        of the steps so far, and within steps * lr everywhere.  Adam's step is lr * m / (sqrt(v) + eps), i.e. lr * sign(g)
-        in the first steps: where |g| is of the order of the gradient's own rounding noise (the gradient tests allow
-        2e-6 absolute) the SIGN is noise and the two implementations legitimately move such an element in opposite
-        directions by lr each - first observed on net.map_encoder.cnn.0.conv.0.weight, 4.9e-4 = 2 lr apart at |g| ~ 1e-6.
+        of the steps so far, and within 2 * steps * lr everywhere.  Adam's step is lr * m / (sqrt(v) + eps), i.e. lr * sign(g)
+        in the first steps: where |g| is of the order of fp32 rounding noise the SIGN is noise and an element may
+        legitimately move the other way by lr.
     The conv biases in front of a train-mode BatchNorm are such elements by construction: their gradient is
-    analytically zero, the reference's autograd leaves rounding noise there (so its Adam random-walks them by +-lr per
+    analytically zero, autograd leaves rounding noise there (so the reference's Adam random-walks them by +-lr per
     step, with no effect on any output), the HIP backward writes an exact zero and they do not move."""
     from det_init import det_fill
     from test_gpu_policy import make_policy
@@ -632,8 +637,8 @@ def test_three_hip_updates_track_oracle_plus_torch_adam(custom_lr):
     lr, sem_lr, steps = 2.5e-4, 1e-3, 3
     g = np.load(os.path.join(G, "policy_update.npz"))
     obs, prev, nd, tgt, w = _batch(g)
-    obs_h = {k: v.cpu() for k, v in obs.items()}
-    ref = det_fill(MapCMAPolicyRef(use_pm=True), seed=0).train()
+    obs_h = {k: (v.cpu().double() if v.is_floating_point() else v.cpu()) for k, v in obs.items()}
+    ref = det_fill(MapCMAPolicyRef(use_pm=True), seed=0).train().double()  # (filled in fp32: the HIP policy's exact weights)
     if custom_lr:
         sem = [p for k, p in ref.named_parameters() if k.startswith("net.map_encoder")]
         reg = [p for k, p in ref.named_parameters() if not k.startswith("net.map_encoder")]
@@ -649,8 +654,12 @@ def test_three_hip_updates_track_oracle_plus_torch_adam(custom_lr):
     try:
         for s in range(1, steps + 1):
             opt_r.zero_grad()
-            loss_r, act_r, aux_r, _ = ref.update_loss(obs_h, prev.cpu(), nd.cpu(), tgt.cpu(), w.cpu())
-            loss_r.backward()
+            torch.set_default_dtype(torch.float64)  # (tensors the oracle creates itself: initial state, one-hot maps)
+            try:
+                loss_r, act_r, aux_r, _ = ref.update_loss(obs_h, prev.cpu(), nd.cpu(), tgt.cpu(), w.cpu().double())
+                loss_r.backward()
+            finally:
+                torch.set_default_dtype(torch.float32)
             for k, p in ref.named_parameters():
                 if p.grad is not None:
                     a = p.grad.detach().abs()
@@ -658,13 +667,35 @@ def test_three_hip_updates_track_oracle_plus_torch_adam(custom_lr):
             opt_r.step()
             loss, act, aux = update_agent(pol, opt, obs, prev, nd, tgt, w, hidden_size=512)
             assert abs(loss - float(loss_r)) < 2e-5 and abs(aux - float(aux_r)) < 2e-5, (s, loss, float(loss_r))
+            # Adam's moments, every trainable element
+            m_err = v_err = 0.0
+            st = opt_r.state
             ref_p = dict(ref.named_parameters())
+            diag = []
+            for k, p, o in zip(opt.names, opt.params, opt.offsets):
+                if _ZERO_GRAD_BIAS(k) or ref_p[k] not in st:
+                    continue
+                n = p.numel()
+                m_h, v_h = opt.exp_avg[o:o + n].cpu(), opt.exp_avg_sq[o:o + n].cpu()
+                m_r, v_r = st[ref_p[k]]["exp_avg"].reshape(-1), st[ref_p[k]]["exp_avg_sq"].reshape(-1)
+                m_h, v_h = m_h.double(), v_h.double()
+                em = float(((m_h - m_r).abs() - 1e-3 * m_r.abs()).max())
+                ev = float(((v_h - v_r).abs() - 2e-3 * v_r.abs()).max())
+                m_err, v_err = max(m_err, em), max(v_err, ev)
+                diag.append((float((m_h - m_r).abs().max()), float(m_r.abs().max()), em, ev, k))
+            diag.sort(reverse=True)
+            for e_abs, m_max, em, ev, k in diag[:8]:
+                log.append(f"  step {s} exp_avg {k}: max|err| {e_abs:.3e} (max|ref| {m_max:.3e}); beyond rtol: {em:.2e} / sq {ev:.2e}")
+            os.makedirs("gpurun_out", exist_ok=True)
+            open(f"gpurun_out/update_3steps_{'custom_lr' if custom_lr else 'one_group'}.log", "w").write("\n".join(log) + "\n")
+            bad_m = [d for d in diag if d[2] > 3e-7 or d[3] > 1e-11]
+            assert not bad_m, f"step {s}: Adam moments off: " + "; ".join(f"{d[4]} exp_avg {d[2]:.2e} sq {d[3]:.2e}" for d in bad_m[:6])
             tot = low = 0
             worst = (0.0, "")
             for k, p in pol.named_parameters():
                 if not p.requires_grad:
                     continue
-                d = (p.detach().cpu() - ref_p[k].detach()).abs()
+                d = (p.detach().cpu().double() - ref_p[k].detach()).abs()
                 firm = gmin[k] >= 1e-5
                 tot += d.numel()
                 low += int((~firm).sum())
@@ -674,28 +705,22 @@ def test_three_hip_updates_track_oracle_plus_torch_adam(custom_lr):
                     e = float(d[firm].max())
                     if e > worst[0]:
                         worst = (e, k)
-                    assert e <= 3e-6, f"step {s}: {k} differs by {e:.3e} on elements with |grad| >= 1e-5"
+                    if e > 3e-6:
+                        i = int(torch.where(firm, d, torch.zeros_like(d)).reshape(-1).argmax())
+                        o = opt.offsets[opt.names.index(k)]
+                        raise AssertionError(
+                            f"step {s}: {k} differs by {e:.3e} on elements with |grad| >= 1e-5: element {i}, min |g_ref| "
+                            f"{float(gmin[k].reshape(-1)[i]):.3e}, exp_avg hip {float(opt.exp_avg[o + i]):.4e} ref "
+                            f"{float(st[ref_p[k]]['exp_avg'].reshape(-1)[i]):.4e}, exp_avg_sq hip {float(opt.exp_avg_sq[o + i]):.4e} ref "
+                            f"{float(st[ref_p[k]]['exp_avg_sq'].reshape(-1)[i]):.4e}, p hip {float(p.detach().reshape(-1)[i]):.6e} ref "
+                            f"{float(ref_p[k].detach().reshape(-1)[i]):.6e}")
                 assert float(d.max()) <= 2 * s * max(lr, sem_lr if custom_lr else lr) * 1.001 + 1e-7, f"step {s}: {k} moved too far"
             for k, b in pol.named_buffers():
                 rb = dict(ref.named_buffers())[k]
                 if b.dtype.is_floating_point:
-                    assert torch.allclose(b.cpu(), rb, atol=2e-6, rtol=1e-5), f"step {s}: buffer {k}"
+                    assert torch.allclose(b.cpu().double(), rb, atol=2e-6, rtol=1e-5), f"step {s}: buffer {k}"
                 else:
                     assert int(b) == int(rb), k
-            # Adam's moments, every trainable element
-            m_err = v_err = 0.0
-            st = opt_r.state
-            for k, p, o in zip(opt.names, opt.params, opt.offsets):
-                if _ZERO_GRAD_BIAS(k) or ref_p[k] not in st:
-                    continue
-                n = p.numel()
-                m_h, v_h = opt.exp_avg[o:o + n].cpu(), opt.exp_avg_sq[o:o + n].cpu()
-                m_r, v_r = st[ref_p[k]]["exp_avg"].reshape(-1), st[ref_p[k]]["exp_avg_sq"].reshape(-1)
-                em = float(((m_h - m_r).abs() - 2e-3 * m_r.abs()).max())
-                ev = float(((v_h - v_r).abs() - 5e-3 * v_r.abs()).max())
-                m_err, v_err = max(m_err, em), max(v_err, ev)
-                assert em <= 1e-6, f"step {s}: exp_avg of {k} off by {em:.3e} beyond rtol"
-                assert ev <= 1e-10, f"step {s}: exp_avg_sq of {k} off by {ev:.3e} beyond rtol"
             log.append(f"step {s}: loss {loss:.7f} ref {float(loss_r):.7f}; worst firm element {worst[0]:.2e} ({worst[1]}); "
                        f"{low} of {tot} elements below the 1e-5 gradient bar; moments beyond rtol: exp_avg {m_err:.2e}, exp_avg_sq {v_err:.2e}")
             assert low < 0.6 * tot, log[-1]
