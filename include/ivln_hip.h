@@ -285,6 +285,49 @@ typedef struct ivln_gn_conv_desc {
 int ivln_gn_conv_f32(const ivln_gn_conv_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The whole DD-PPO depth encoder (habitat-lab ResNetEncoder: avg_pool2d(2) -> GroupNorm ResNet-50 -> compression conv ->
+ * GroupNorm(1) + ReLU; models/encoders/resnet_encoders.py:31-43, 95) for 1..8 images as ONE persistent launch
+ * (csrc/depth_net.hip): a cluster of 32 workgroups per image walks a table of conv "ops", GroupNorm (+ residual /
+ * downsample branch, ReLU, MaxPool, the input's avg-pool) applied on load, complete outputs + GroupNorm statistics
+ * partials stored per op, a counter barrier per cluster between dependent ops.  The op table, the packed weights and
+ * the parameter blob are built once per model by the host (ivln-ce_amd/depth_net.py documents the packing); all
+ * offsets are in floats, `*_off` into the per-image arena unless stated otherwise.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ivln_depthnet_op {
+    int kind;            /* 0: conv op; 1: final GroupNorm(1 group) + ReLU over `nslab` slabs -> out (workgroup 0) */
+    int Cin, Cout, ks, stride, pad;
+    int Hin, Win;        /* input map the conv sees (after the MaxPool when pool = 1, after the avg-pool when avg_in = 1) */
+    int wout_shift;      /* output map is (1 << wout_shift) squared */
+    int M;               /* rows of an output-channel tile: 16, or 8 (half-filled MFMA rows) */
+    int WCT, WPT, P, KW; /* a workgroup's 8 waves = WCT channel tiles x WPT pixel-tile groups x KW K ranges; P pixel tiles (of 16) per wave */
+    int kwg;             /* K split over workgroups (slabs of the output; 1 = none) */
+    int n_ctg, n_ptg;    /* task grid: channel-tile groups x pixel groups; n_ctg * n_ptg * kwg <= 32 */
+    int ksteps;          /* K / 4: (Cin / 4) * ks * ks, or 13 for the one-channel 7x7 stem (taps padded to 52) */
+    int cs, wp;          /* LDS tile: channel stride and row pitch (Win + 2 pad) in floats */
+    int src_off, nslab, slab_stride;           /* raw input [Cin][Hin*Win] (pool: [Cin][2 Hin * 2 Win]); slabs summed on load */
+    int st_off, st_parts;                      /* its statistics partials [16][st_parts][3]; st_parts = 0: no GroupNorm */
+    int gamma_off, beta_off;                   /* into the parameter blob */
+    int src2_off, st2_off, st2_parts, gamma2_off, beta2_off;   /* second normalised operand (downsample branch) or src2_off = -1 */
+    int res_off;         /* identity activation added after the GroupNorm(s), or -1 */
+    int relu, pool, avg_in;
+    int act_out_off;     /* >= 0: the transformed input is also stored here (a later block's identity) */
+    int dst_off, dst_slab_stride;              /* raw output [Cout][HWout] (slab kwg_i at + kwg_i * dst_slab_stride) */
+    int st_out_off, st_out_parts;              /* statistics partials of the output [16][st_out_parts][3]; 0: none */
+    int w_off;           /* packed weights of this op, into the weight blob */
+    int barrier_before;  /* 1: the op reads what the previous ops of the cluster stored */
+} ivln_depthnet_op;
+/* ops_dev / ops_host: the same table in device and host memory.  depth (N, 2 Hin0, 2 Win0) raw images, image stride
+ * depth_img_stride; arena: N per-image work areas of arena_stride floats; out: image stride out_img_stride.  sync_ws: 2048
+ * bytes of device memory ZEROED ONCE by the caller (the launch leaves the counters zero again; word 256 is a sticky
+ * error flag set when a bounded spin times out - ivln_depth_net_status).  IVLN_E_UNSUPPORTED: N > 8, or the 256
+ * workgroups of the launch cannot all be resident (partitioned / masked device): the caller then runs the per-layer
+ * launches (ivln_nconv_f32 / ivln_gn_conv_f32). */
+int ivln_depth_net_f32(const ivln_depthnet_op* ops_dev, const ivln_depthnet_op* ops_host, int n_ops, const float* weights,
+                       const float* params, const float* depth, int64_t depth_img_stride, float* arena, int64_t arena_stride,
+                       float* out, int64_t out_img_stride, int N, float eps, void* sync_ws, void* stream);
+int ivln_depth_net_status(const void* sync_ws, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Convolution with GroupNorm applied to its INPUT on load and the GroupNorm statistics of its OUTPUT emitted as
  * partials (csrc/gn_conv.hip, k_nconv) - for the large feature maps of the depth ResNet's layer 1, where the
  * 16-slab scheme of ivln_gn_conv_f32 costs more bytes than it saves launches.  One launch per conv layer:
@@ -633,7 +676,8 @@ int ivln_linear_skinny_ex_f32(const float* x, int64_t ldx, const float* W, const
 int ivln_lstm_bidir_bwd_f32(const float* dout, const float* out, const float* gates, const float* cs,
                             const float* whh_f, const float* whh_r, const int* lengths, int B, int L, int H,
                             float* dgx_f, float* dgx_r, float* hprev_f, float* hprev_r, void* stream);
-/* backward of BatchNorm2d(train|eval) -> ReLU -> AvgPool2d(2) (CBRA, map_encoder.py:13-20) */
+/* backward of BatchNorm2d(train|eval) -> ReLU -> AvgPool2d(2) (CBRA, map_encoder.py:13-20).  ws: scratch of at least
+ * 4 * C + 2 floats (the per-channel sums are accumulated and merged in double: 4 floats per (channel, split)). */
 int ivln_cbra_bwd_f32(const float* dout, const float* y, const float* scale, const float* shift,
                       const float* mean, const float* rstd, int N, int C, int H, int W, int train,
                       float* dgamma, float* dbeta, float* dy, float* ws, int64_t ws_floats, void* stream);

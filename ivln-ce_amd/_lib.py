@@ -15,6 +15,9 @@ f32 = C.c_float
 f64 = C.c_double
 
 
+IVLN_E_UNSUPPORTED = -5  # include/ivln_hip.h: the entry point declines this shape / device (callers take their other path)
+
+
 class IvlnError(RuntimeError):
     pass
 

@@ -17,6 +17,7 @@ SOURCES = {
     "gemm_vec.hip": [],
     "conv_gn.hip": [],
     "gn_conv.hip": [],
+    "depth_net.hip": [],
     "cma_step.hip": [],
     "gru_seq.hip": [],
     "nn_ops.hip": [],

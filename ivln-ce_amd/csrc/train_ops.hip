@@ -28,6 +28,16 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     for (int i = 0; i < nw; ++i) s += red[i];
     return s;
 }
+__device__ __forceinline__ double block_sum_d(double v, double* red) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int i = 0; i < nw; ++i) s += red[i];
+    return s;
+}
 inline unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 // dx = dy * (y > 0)
@@ -548,16 +558,21 @@ __global__ __launch_bounds__(256) void k_cbra_bwd_stats(const float* __restrict_
                                                         const float* __restrict__ shift,
                                                         const float* __restrict__ mean,
                                                         const float* __restrict__ rstd, int N, int C, int H, int W,
-                                                        int imgs_per_split, float* __restrict__ partial) {
-    __shared__ float red[16];
+                                                        int imgs_per_split, double* __restrict__ partial) {
+    // The two channel sums are accumulated in DOUBLE.  They become the per-channel means that BatchNorm's backward
+    // subtracts from every element, so an error e in one of them is the SAME for all N*H*W elements of the channel
+    // and adds up coherently in the conv's weight gradient (sum over pixels of x * e): with float accumulators the
+    // weight gradients of the map CNN were 2e-3 of their largest element away from a float64 run of the reference
+    // arithmetic (the reference's own fp32 autograd: 4e-3), with double 1e-4 (tests/test_gpu_train.py).
+    __shared__ double red[16];
     const int c = blockIdx.x, sp = blockIdx.y, S = gridDim.y;
     const int i0 = sp * imgs_per_split, i1 = min(N, i0 + imgs_per_split);
     const int Ho = H / 2, Wo = W / 2, HW = H * W;
     const float sc = scale[c], sh = shift[c], mu = mean[c], rs = rstd[c];
-    float s1 = 0.f, s2 = 0.f;
+    double s1 = 0.0, s2 = 0.0;
     if ((W & 3) == 0 && (((uintptr_t)y | (uintptr_t)dout) & 15) == 0) {
         // four consecutive pixels of a row per thread: one float4 of y, one float2 of the pooled gradient
-        float t1 = 0.f, t2 = 0.f;
+        double t1 = 0.0, t2 = 0.0;
         for (int img = i0; img < i1; ++img) {
             const float* yp = y + ((int64_t)img * C + c) * HW;
             const float* dp = dout + ((int64_t)img * C + c) * Ho * Wo;
@@ -569,10 +584,10 @@ __global__ __launch_bounds__(256) void k_cbra_bwd_stats(const float* __restrict_
                 const float d1 = fmaf(yv.y, sc, sh) > 0.f ? 0.25f * dv.x : 0.f;
                 const float d2 = fmaf(yv.z, sc, sh) > 0.f ? 0.25f * dv.y : 0.f;
                 const float d3 = fmaf(yv.w, sc, sh) > 0.f ? 0.25f * dv.y : 0.f;
-                s1 += d0 + d1;
-                t1 += d2 + d3;
-                s2 += d0 * (yv.x - mu) * rs + d1 * (yv.y - mu) * rs;
-                t2 += d2 * (yv.z - mu) * rs + d3 * (yv.w - mu) * rs;
+                s1 += (double)d0 + (double)d1;
+                t1 += (double)d2 + (double)d3;
+                s2 += (double)(d0 * ((yv.x - mu) * rs)) + (double)(d1 * ((yv.y - mu) * rs));
+                t2 += (double)(d2 * ((yv.z - mu) * rs)) + (double)(d3 * ((yv.w - mu) * rs));
             }
         }
         s1 += t1;
@@ -585,16 +600,35 @@ __global__ __launch_bounds__(256) void k_cbra_bwd_stats(const float* __restrict_
                 int h = i / W, w = i - h * W;
                 float yv = yp[i];
                 float dz = fmaf(yv, sc, sh) > 0.f ? 0.25f * dp[(h >> 1) * Wo + (w >> 1)] : 0.f;
-                s1 += dz;
-                s2 += dz * (yv - mu) * rs;
+                s1 += (double)dz;
+                s2 += (double)(dz * ((yv - mu) * rs));
             }
         }
     }
-    s1 = block_sum(s1, red);
-    s2 = block_sum(s2, red);
+    s1 = block_sum_d(s1, red);
+    s2 = block_sum_d(s2, red);
     if (threadIdx.x == 0) {
         partial[((int64_t)c * S + sp) * 2] = s1;      // -> dbeta
         partial[((int64_t)c * S + sp) * 2 + 1] = s2;  // -> dgamma
+    }
+}
+
+// one 64-lane wave per channel: the S double partials of both sums in a fixed order -> dbeta, dgamma (float)
+__global__ __launch_bounds__(64) void k_cbra_bwd_final(const double* __restrict__ partial, int S, int C, float* __restrict__ dbeta,
+                                                       float* __restrict__ dgamma) {
+    const int c = blockIdx.x, l = threadIdx.x;
+    double a = 0.0, b = 0.0;
+    for (int sp = l; sp < S; sp += 64) {
+        a += partial[((int64_t)c * S + sp) * 2];
+        b += partial[((int64_t)c * S + sp) * 2 + 1];
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o);
+        b += __shfl_xor(b, o);
+    }
+    if (l == 0) {
+        dbeta[c] = (float)a;
+        dgamma[c] = (float)b;
     }
 }
 
@@ -1117,13 +1151,14 @@ int ivln_lstm_bidir_bwd_f32(const float* dout, const float* out, const float* ga
 int ivln_cbra_bwd_f32(const float* dout, const float* y, const float* scale, const float* shift, const float* mean,
                       const float* rstd, int N, int C, int H, int W, int train, float* dgamma, float* dbeta,
                       float* dy, float* ws, int64_t ws_floats, void* stream) {
-    if (!ws || ws_floats < (int64_t)2 * C) return IVLN_E_INVALID;
-    int S = chan_splits(N, H * W, C, 2, ws_floats);
+    if (!ws || ws_floats < (int64_t)4 * C + 2 || ((uintptr_t)ws & 3)) return IVLN_E_INVALID;
+    double* wsd = reinterpret_cast<double*>(((uintptr_t)ws + 7) & ~(uintptr_t)7);  // partials are doubles: 4 floats per (channel, split)
+    int S = chan_splits(N, H * W, C, 4, ws_floats - 2);
     const int ips = (N + S - 1) / S;
     S = (N + ips - 1) / ips;
     hipLaunchKernelGGL(k_cbra_bwd_stats, dim3(C, S), dim3(256), 0, (hipStream_t)stream, dout, y, scale, shift, mean,
-                       rstd, N, C, H, W, ips, ws);
-    hipLaunchKernelGGL(k_chan_final, dim3(C), dim3(64), 0, (hipStream_t)stream, ws, S, C, 2, dbeta, dgamma);
+                       rstd, N, C, H, W, ips, wsd);
+    hipLaunchKernelGGL(k_cbra_bwd_final, dim3(C), dim3(64), 0, (hipStream_t)stream, wsd, S, C, dbeta, dgamma);
     if ((W & 3) == 0 && (((uintptr_t)y | (uintptr_t)dout | (uintptr_t)dy) & 15) == 0)
         hipLaunchKernelGGL(k_cbra_bwd_apply4, dim3(nblk((int64_t)N * C * H * W / 4)), dim3(256), 0, (hipStream_t)stream,
                            dout, y, scale, shift, mean, rstd, dgamma, dbeta, N, C, H, W, train, dy);

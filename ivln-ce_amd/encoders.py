@@ -16,7 +16,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import depth_net, ops
 
 
 # ------------------------------------------------------------------------------------------------
@@ -439,14 +439,22 @@ class ResNetEncoder(nn.Module):
         depth = observations["depth"].to(torch.float32).contiguous()
         B, H, W, Cd = depth.shape
         assert Cd == 1, "depth-only encoder"
-        x = ops.pool2d(depth.view(B, 1, H, W), 2, 2, 0, "avg")  # F.avg_pool2d(x, 2)
         c, gn = self.compression[0], self.compression[1]
+        hw = self.output_shape[1] * self.output_shape[2]
+        if (ops.DEPTH_NET and B <= depth_net.DepthNetPlan.MAX_IMAGES and (H, W) == (256, 256) and not torch.is_grad_enabled()
+                and getattr(self, "latency_bound", True)):
+            # rollout batches: the whole encoder as ONE persistent launch, a cluster of 32 workgroups per image
+            # (csrc/depth_net.hip); declined (False) when the device cannot keep all its workgroups resident
+            plan = depth_net.plan_for(self, depth.device)
+            dst = out if out is not None else torch.empty((B,) + tuple(self.output_shape), dtype=torch.float32, device=depth.device)
+            if plan is not None and plan.run(depth, dst, out_ctot * hw if out is not None else self.output_shape[0] * hw):
+                return dst
+        x = ops.pool2d(depth.view(B, 1, H, W), 2, 2, 0, "avg")  # F.avg_pool2d(x, 2)
         chain = ops.CHAIN_GN_CONV and B <= ops.CHAIN_MAX_IMAGES and getattr(self, "latency_bound", True)
         y = self.backbone.forward_chain(x, (c.weight, 1, 1)) if chain else None
         if y is None:
             x = self.backbone.forward_hip(x)
             y = ops.conv2d(x, c.weight, pad=1, defer=True)
-        hw = self.output_shape[1] * self.output_shape[2]
         if out is None:
             return ops.groupnorm(y, gn.weight, gn.bias, gn.num_groups, gn.eps, relu=True)
         return ops.groupnorm(y, gn.weight, gn.bias, gn.num_groups, gn.eps, relu=True, out=out,

@@ -692,6 +692,9 @@ def conv_gn(x, w, gn, stride=1, pad=0, relu=False, residual=None, ds=None, out=N
 
 # depth ResNet as a chain of GroupNorm+next-conv launches (csrc/gn_conv.hip); IVLN_GN_CONV=0 selects the deferred
 # conv + GroupNorm pairs
+# the whole depth encoder of a rollout batch (<= 8 images) as ONE persistent launch (csrc/depth_net.hip); 0: the per-layer
+# launch chain below (A/B switch, and what runs where the persistent grid cannot be resident)
+DEPTH_NET = os.environ.get("IVLN_DEPTH_NET", "1") != "0"
 CHAIN_GN_CONV = os.environ.get("IVLN_GN_CONV", "1") != "0"
 # The chain trades launches for slab bytes (16 partial slabs per conv), which pays while the step is latency-bound:
 # measured 4 envs 5.1 K vs 4.0 K env-steps/s, 8 envs 7.5 K vs 6.9 K, but 16 envs 9.5 K vs 10.1 K and 32 envs 11.1 K vs

@@ -24,6 +24,7 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch
 
+from . import depth_net
 from . import dist as D
 from . import ops
 from .aux_losses import AuxLosses
@@ -491,6 +492,7 @@ class BaseVLNCETrainer:
             mm = getattr(t, "mapping_module", None)
             if mm is not None and getattr(mm, "_h", None) is not None:
                 mm.check_status()
+        depth_net.check_all()  # sticky error word of the persistent depth encoder (a cluster barrier timed out)
 
     # -- observations -> batch ----------------------------------------------------------------
     def _batch(self, observations, not_done_masks, transform=True):
