@@ -305,14 +305,14 @@ typedef struct ivln_depthnet_op {
     int ksteps;          /* K / 4: (Cin / 4) * ks * ks, or 13 for the one-channel 7x7 stem (taps padded to 52) */
     int cs, wp;          /* LDS tile: channel stride and row pitch (Win + 2 pad) in floats */
     int src_off, nslab, slab_stride;           /* raw input [Cin][Hin*Win] (pool: [Cin][2 Hin * 2 Win]); slabs summed on load */
-    int st_off, st_parts;                      /* its statistics partials [16][st_parts][3]; st_parts = 0: no GroupNorm */
+    int st_off, st_parts;                      /* its statistics partials [16][st_parts][4] = (count, mean, M2, -); st_parts = 0: no GroupNorm */
     int gamma_off, beta_off;                   /* into the parameter blob */
     int src2_off, st2_off, st2_parts, gamma2_off, beta2_off;   /* second normalised operand (downsample branch) or src2_off = -1 */
     int res_off;         /* identity activation added after the GroupNorm(s), or -1 */
     int relu, pool, avg_in;
     int act_out_off;     /* >= 0: the transformed input is also stored here (a later block's identity) */
     int dst_off, dst_slab_stride;              /* raw output [Cout][HWout] (slab kwg_i at + kwg_i * dst_slab_stride) */
-    int st_out_off, st_out_parts;              /* statistics partials of the output [16][st_out_parts][3]; 0: none */
+    int st_out_off, st_out_parts;              /* statistics partials of the output [16][st_out_parts][4]; 0: none */
     int w_off;           /* packed weights of this op, into the weight blob */
     int barrier_before;  /* 1: the op reads what the previous ops of the cluster stored */
 } ivln_depthnet_op;

@@ -44,6 +44,13 @@ namespace {
 constexpr int NT = 512;   // threads per workgroup
 constexpr int CL = 32;    // workgroups per image
 constexpr unsigned SPIN_MAX = 1u << 22;
+#ifndef DEPTH_NET_MIN_BLOCKS
+#define DEPTH_NET_MIN_BLOCKS 1
+#endif
+#ifndef DEPTH_NET_LOCAL_ATOMICS
+#define DEPTH_NET_LOCAL_ATOMICS 1
+#endif
+constexpr bool LOCAL_ATOMICS = DEPTH_NET_LOCAL_ATOMICS != 0;  // A/B switch of the XCD-local arrival (cluster_arrive)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef ivln_depthnet_op Op;
@@ -64,6 +71,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* p) {
 __device__ __forceinline__ float4 ld4_x(__amdgpu_buffer_rsrc_t r, int float_off) {
     const v4i x = __builtin_amdgcn_raw_buffer_load_b128(r, float_off * 4, 0, 16);
     return make_float4(__int_as_float(x.x), __int_as_float(x.y), __int_as_float(x.z), __int_as_float(x.w));
+}
+// plain (cached) 16-byte / 4-byte loads through a resource: weights, parameters
+__device__ __forceinline__ float4 ld4_w(__amdgpu_buffer_rsrc_t r, int float_off) {
+    const v4i x = __builtin_amdgcn_raw_buffer_load_b128(r, float_off * 4, 0, 0);
+    return make_float4(__int_as_float(x.x), __int_as_float(x.y), __int_as_float(x.z), __int_as_float(x.w));
+}
+__device__ __forceinline__ float ld1_w(__amdgpu_buffer_rsrc_t r, int float_off) {
+    return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, float_off * 4, 0, 0));
 }
 __device__ __forceinline__ float ld1_x(__amdgpu_buffer_rsrc_t r, int float_off) {
     return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, float_off * 4, 0, 16));
@@ -100,8 +115,18 @@ __device__ __forceinline__ float half_sum32(float v) {  // sum over the 32 lanes
     return v;
 }
 
+#ifdef DEPTH_NET_TIMING  // tools/depth_net_phases.py: per-op phase stamps (100 MHz wall clock) of cluster 0's workgroups
+__device__ unsigned long long g_dn_stamp[CL * 64 * 12];
+#define DN_STAMP(k)                                                                                        \
+    do {                                                                                                   \
+        if (cluster == 0 && threadIdx.x == 0 && oi < 64) g_dn_stamp[(rank * 64 + oi) * 12 + (k)] = wall_clock64(); \
+    } while (0)
+#else
+#define DN_STAMP(k)
+#endif
+
 struct Lds {  // float offsets into the dynamic LDS block (host-computed maxima over the program)
-    int tab, tile, otile, scratch;
+    int tab, btab, tile, otile, scratch;
 };
 
 // cluster barrier: wait until `target` arrivals.  false: timed out (sticky error set)
@@ -122,81 +147,106 @@ __device__ __forceinline__ bool cluster_wait(unsigned* sy, int cluster, unsigned
     __syncthreads();
     return *s_flag != 0;
 }
-__device__ __forceinline__ void cluster_arrive(unsigned* sy, int cluster) {
+// `local`: the cluster has proved to sit on one XCD - the arrival is then an atomic of that XCD's L2 (workgroup scope: no
+// sc1, executed in the L2 every poller's L1-bypassing load is served from) instead of a memory-side agent-scope one
+__device__ __forceinline__ void cluster_arrive(unsigned* sy, int cluster, bool local) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's stores have left (write-through) / reached L2
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(&sy[cluster * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
+        if (local) __hip_atomic_fetch_add(&sy[cluster * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else __hip_atomic_fetch_add(&sy[cluster * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // One wave's share of the matrix product of an op: acc[p] += A(co tile, k range) x B(pixel tile p, k range).
-//   A: packed weights, chunk c of this wave = 4 k-steps = one float4 per lane (M = 8: lanes with (lane & 15) >= 8 hold 0)
-//   B: the LDS tile, address = lane_base[p] + 4 q CS + tap offset for k-step (q, t); KS = 7: one input channel, the four
-//      k slots of a step are four TAPS (per-lane offsets)
-template <int KS, int P>
-__device__ __forceinline__ void wave_mma(const Op& op, const float* __restrict__ wts, int a_chunk0, int nch, int kbeg, int kend,
-                                         const float* tile, const int* lane_base, f32x4* acc, float4* abuf, bool a_lane, int q_lo) {
-    constexpr int KK = KS * KS;
-    const int lane = threadIdx.x & 63, kq = lane >> 4;
-    const int CS = op.cs, Wp = op.wp;
-    const int a_stride = op.M == 16 ? 256 : 128;  // floats per chunk
-    const int a_lane_off = op.M == 16 ? lane * 4 : ((lane & 7) + 8 * kq) * 4;
-    int q = 0, t = 0;
-    if (KS != 7) {
-        q = kbeg / KK;
-        t = kbeg - q * KK;
-    }
-    int k = kbeg;
-    for (int c0 = 0; c0 < nch; c0 += 8) {
+//   A: packed weights, chunk c of this wave = 4 k-steps = one float4 per lane (M = 8: lanes with (lane & 15) >= 8 contribute 0),
+//      eight chunks deep in registers; refills are unconditional loads on clamped chunk indices
+//   B: the LDS tile at lane_base[p] + btab[chunk][kq][u], the per-op table of k-step -> tile offsets the workgroup built
+//      while staging (one 16-byte LDS read per chunk and lane; k-steps past the range repeat the last valid offset and
+//      meet zero weights).  One generic body for 1x1 / 3x3 / the 7x7 stem: the kernel is instruction-fetch bound when
+//      every kernel size and every chunk has code of its own (first version: 57 KB of code, 140 instructions per chunk).
+constexpr int MAXCH = 18;  // chunks (of 4 k-steps) per wave and op: 72 k-steps (the 3x3 convs of layer 4, the compression conv)
+constexpr int ADEPTH = 8;  // weight chunks in flight per wave
+
+template <int P>
+struct MmaState {
+    float4 abuf[MAXCH + ADEPTH];
+    int4 off[MAXCH + 2];
+    float b[MAXCH + 1][4][P];
+};
+
+// chunk C of the wave's K range, then chunk C + 1 ... (template recursion: every buffer index is a compile-time constant, so
+// the buffers live in registers under their own names - a `#pragma unroll` loop with an early exit stayed rolled and put
+// them in scratch memory; a rolled loop with rotating registers got its refills serialised behind s_waitcnt vmcnt(0))
+template <int P, int C>
+__device__ __forceinline__ void mma_chunk(MmaState<P>& S, __amdgpu_buffer_rsrc_t rW, int a_off0, int a_stride, int nch, const float* tile,
+                                          const int4* bt, const int* lane_base, f32x4* acc, float a_mask) {
+    if constexpr (C < MAXCH) {
+        if (C >= nch) return;  // (wave-uniform)
+        // issue: the weight chunk ADEPTH ahead, the offsets two chunks ahead, the activations of the next chunk
+        S.abuf[C + ADEPTH] = ld4_w(rW, a_off0 + min(C + ADEPTH, nch - 1) * a_stride);
+        S.off[C + 2] = bt[4 * min(C + 2, nch - 1)];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (c0 + u < nch) {  // (wave-uniform)
-                const float4 a4 = abuf[u];
-                if (c0 + u + 8 < nch && a_lane)
-                    abuf[u] = *reinterpret_cast<const float4*>(wts + (int64_t)(a_chunk0 + c0 + u + 8) * a_stride + a_lane_off);
-                const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    int boff;
-                    if (KS == 7) {  // k slot = tap 4 k + kq (clamped: the packed weight of a tap >= 49 is 0)
-                        const int tap = min(4 * min(k, kend - 1) + kq, KK - 1);
-                        const int dy = (tap * 37) >> 8;  // tap / 7 for tap < 49
-                        boff = dy * Wp + (tap - dy * 7);
-                    } else {
-                        boff = 4 * (q - q_lo) * CS + (KS == 3 ? (t / 3) * Wp + (t % 3) : 0);
-                    }
-#pragma unroll
-                    for (int p = 0; p < P; ++p)
-                        acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], tile[lane_base[p] + boff], acc[p], 0, 0, 0);
-                    if (k + 1 < kend) {  // (k-steps past the range: zero weights, keep the last valid address)
-                        ++k;
-                        if (KS != 7 && ++t == KK) {
-                            t = 0;
-                            ++q;
-                        }
-                    }
-                }
-            }
+        for (int p = 0; p < P; ++p) {
+            S.b[C + 1][0][p] = tile[lane_base[p] + S.off[C + 1].x];
+            S.b[C + 1][1][p] = tile[lane_base[p] + S.off[C + 1].y];
+            S.b[C + 1][2][p] = tile[lane_base[p] + S.off[C + 1].z];
+            S.b[C + 1][3][p] = tile[lane_base[p] + S.off[C + 1].w];
         }
+        __builtin_amdgcn_sched_barrier(0);  // (otherwise every LDS read sinks to its MFMA: one LDS latency per k-step)
+        const float av[4] = {S.abuf[C].x * a_mask, S.abuf[C].y * a_mask, S.abuf[C].z * a_mask, S.abuf[C].w * a_mask};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int p = 0; p < P; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], S.b[C][e][p], acc[p], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_chunk<P, C + 1>(S, rW, a_off0, a_stride, nch, tile, bt, lane_base, acc, a_mask);
     }
 }
 
-__global__ __launch_bounds__(NT) void k_depth_net(const Op* __restrict__ ops, int n_ops, const float* __restrict__ wts,
-                                                  const float* __restrict__ prm, const float* __restrict__ depth,
+template <int P>
+__device__ __forceinline__ void wave_mma(__amdgpu_buffer_rsrc_t rW, int a_off0, int a_stride, int nch, const float* tile,
+                                         const int* btab_w, const int* lane_base, f32x4* acc, const float4* apre, float a_mask) {
+    const int kq = (threadIdx.x & 63) >> 4;
+    const int4* bt = reinterpret_cast<const int4*>(btab_w) + kq;  // chunk c: bt[4 c]
+    MmaState<P> S;
+#pragma unroll
+    for (int u = 0; u < ADEPTH; ++u) S.abuf[u] = apre[u];
+    S.off[0] = bt[0];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        S.b[0][0][p] = tile[lane_base[p] + S.off[0].x];
+        S.b[0][1][p] = tile[lane_base[p] + S.off[0].y];
+        S.b[0][2][p] = tile[lane_base[p] + S.off[0].z];
+        S.b[0][3][p] = tile[lane_base[p] + S.off[0].w];
+    }
+    S.off[1] = bt[4 * min(1, nch - 1)];
+    mma_chunk<P, 0>(S, rW, a_off0, a_stride, nch, tile, bt, lane_base, acc, a_mask);
+}
+
+__global__ __launch_bounds__(NT, DEPTH_NET_MIN_BLOCKS) void k_depth_net(const Op* __restrict__ ops, int n_ops, const float* wts, const float* prm,
+                                                  const float* __restrict__ depth,
                                                   int64_t depth_img_stride, float* __restrict__ arena, int64_t arena_stride,
                                                   float* __restrict__ out, int64_t out_img_stride, int N, float eps,
                                                   unsigned* __restrict__ sy, const Lds L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int cluster = blockIdx.x & 7, rank = blockIdx.x >> 3;
     if (cluster >= N) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave-uniform: scalar registers)
     int* s_flag = reinterpret_cast<int*>(smem);        // [0]: barrier verdict
     float* red = smem + 8;                              // 16 floats of block-reduction scratch
     float* tab = smem + L.tab;                          // scale | shift | scale2 | shift2, CMAX each
+    int* btab = reinterpret_cast<int*>(smem + L.btab);  // k-step -> tile offset, [K range of a wave][chunk][kq][4]
     float* tile = smem + L.tile;
     float* otile = smem + L.otile;
     float* scratch = smem + L.scratch;
     float* A = arena + (int64_t)cluster * arena_stride;
     const __amdgpu_buffer_rsrc_t rA = rsrc(A);
+    // Weights and affine parameters are read through buffer resources too, NOT through `const __restrict__` pointers: loads
+    // from memory the compiler knows to be read-only and unaliased are free to SINK to their first use - past the cluster
+    // barrier they are issued in front of, which is the whole point of issuing them there (measured: the first version's
+    // MFMA phase waited a full L2 round trip per chunk; tools/depth_net_phases.py).
+    const __amdgpu_buffer_rsrc_t rW = rsrc(wts), rP = rsrc(prm);
     const float* dimg = depth + (int64_t)cluster * depth_img_stride;
     if (tid == 0) {
         unsigned xcc;
@@ -222,19 +272,81 @@ __global__ __launch_bounds__(NT) void k_depth_net(const Op* __restrict__ ops, in
         const int nch = (kend - kbeg + 3) >> 2;
         const int ctile = ctg * op.WCT + wct;
         const int a_chunk0 = (ctile * KWT + kwt) * cpk;  // chunk index from the op's weight base
-        const float* wbase = wts + op.w_off;
         const bool a_lane = op.M == 16 || (lane & 15) < 8;
+        DN_STAMP(0);
         // ---- 1. weight prefetch: independent of what the other workgroups are still storing ----
-        float4 abuf[8];
-        if (op.kind == 0 && has_task) {
-            const int a_stride = op.M == 16 ? 256 : 128;
-            const int a_lane_off = op.M == 16 ? lane * 4 : ((lane & 7) + 8 * (lane >> 4)) * 4;
+        float4 abuf[ADEPTH];
+        const int a_stride = op.M == 16 ? 256 : 128;  // floats per chunk
+        // (M = 8: the lanes of accumulator rows 8..15 read a valid address too and are multiplied by 0)
+        const int a_off0 = op.w_off + a_chunk0 * a_stride + (op.M == 16 ? lane * 4 : ((lane & 7) + 8 * (lane >> 4)) * 4);
+        const float a_mask = a_lane ? 1.f : 0.f;
+        if (op.kind == 0 && has_task && nch > 0) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                abuf[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (u < nch && a_lane) abuf[u] = *reinterpret_cast<const float4*>(wbase + (int64_t)(a_chunk0 + u) * a_stride + a_lane_off);
-            }
+            for (int u = 0; u < ADEPTH; ++u) abuf[u] = ld4_w(rW, a_off0 + min(u, nch - 1) * a_stride);
         }
+        // ... and the GroupNorm affine parameters of the channels this thread will write into the scale / shift table
+        float gab[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, beb[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+        if (op.kind == 0 && has_task && op.st_parts > 0) {
+            const int cpg = op.Cin >> 4, g = tid >> 5, part = tid & 31;
+#pragma unroll
+            for (int which = 0; which < 2; ++which)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int ccn = part + 32 * h;
+                    if (ccn < cpg && (which == 0 || op.src2_off >= 0)) {
+                        gab[which][h] = ld1_w(rP, (which ? op.gamma2_off : op.gamma_off) + g * cpg + ccn);
+                        beb[which][h] = ld1_w(rP, (which ? op.beta2_off : op.beta_off) + g * cpg + ccn);
+                    }
+                }
+        }
+        const int Cin = op.Cin, Win = op.Win, Hin = op.Hin, Wp = op.wp, CS = op.cs, pad = op.pad;
+        const int PG = 16 * op.WPT * op.P;          // output pixels of this task
+        const int rows_out = PG >> op.wout_shift;   // whole output rows
+        const int oy0 = ptg * rows_out;
+        // a 1x1 stride-2 conv only ever reads every second row / column: the tile holds the sub-sampled map
+        const bool sub = op.ks == 1 && op.stride == 2;
+        const int s_eff = sub ? 1 : op.stride;
+        const int Rs = (rows_out - 1) * s_eff + op.ks, iy0 = oy0 * s_eff - pad;
+        const int HWin = Hin * Win;
+        // a workgroup that owns a K slice (kwg > 1) stages the channels of that slice only
+        int c_lo = 0, c_n = Cin;
+        if (op.kwg > 1) {
+            const int KK = op.ks * op.ks, kb_wg = min(kwg_i * op.KW * per, op.ksteps), ke_wg = min(kb_wg + op.KW * per, op.ksteps);
+            c_lo = 4 * (kb_wg / KK);
+            c_n = 4 * ((ke_wg + KK - 1) / KK) - c_lo;
+        }
+        const int CM = (L.btab - L.tab) >> 2;  // table stride
+        const bool gn = op.st_parts > 0, two = op.src2_off >= 0, resid = op.res_off >= 0;
+        const bool general = !op.avg_in && !op.pool;
+        const int W4 = Win >> 2, per_c = Rs * W4, total = general ? c_n * per_c : 0;
+        const fdiv by_pc(per_c), by_w4(W4);
+        const bool wr_act = op.act_out_off >= 0 && ctg == 0 && kwg_i == 0;
+        float4 xv[4], yv[4];  // yv: the second operand - the downsample branch's raw output OR the identity (never both)
+        const int off2 = two ? op.src2_off : op.res_off;
+        auto load_batch = [&](int i0, bool first_op, bool second_op) {  // four elements per thread, all their loads in flight together
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = min(i0 + e * NT, total - 1);
+                const int cl = by_pc(i), c = c_lo + cl, rem = i - cl * per_c, r = by_w4(rem), x4 = rem - r * W4;
+                const int iy = sub ? 2 * (oy0 + r) : iy0 + r;
+                if (first_op) xv[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (second_op) yv[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if ((unsigned)iy < (unsigned)Hin) {
+                    const int o = c * HWin + iy * Win + 4 * x4;
+                    if (first_op) {
+                        xv[e] = ld4_x(rA, op.src_off + o);
+                        for (int z = 1; z < op.nslab; ++z) {
+                            const float4 w = ld4_x(rA, op.src_off + z * op.slab_stride + o);
+                            xv[e].x += w.x, xv[e].y += w.y, xv[e].z += w.z, xv[e].w += w.w;
+                        }
+                    }
+                    if (second_op && (two || resid)) yv[e] = ld4_x(rA, off2 + o);
+                }
+            }
+        };
+        // the second operand of a block tail (downsample branch or identity) was stored at least one barrier ago: its
+        // first batch is loaded in front of the barrier wait, like the weights
+        if (op.kind == 0 && has_task && total > 0 && (two || resid)) load_batch(tid, false, true);
         // ---- 2. the cluster has stored everything this op reads ----
         if (op.barrier_before) {
             if (!cluster_wait(sy, cluster, arrivals * CL, s_flag)) {
@@ -246,6 +358,7 @@ __global__ __launch_bounds__(NT) void k_depth_net(const Op* __restrict__ ops, in
                 plain = __builtin_popcount(m) == 1;
             }
         }
+        DN_STAMP(1);
         if (op.kind == 1) {
             // ---- final GroupNorm(1 group) + ReLU over the `nslab` slabs of the compression conv: workgroup 0 ----
             if (rank == 0) {
@@ -285,7 +398,7 @@ __global__ __launch_bounds__(NT) void k_depth_net(const Op* __restrict__ ops, in
                     const int i = tid + e * NT;
                     if (i < nel) {
                         const int c = by_hw(i);
-                        const float ga = prm[op.gamma_off + c] * rstd, be = prm[op.beta_off + c] - mean * ga;
+                        const float ga = ld1_w(rP, op.gamma_off + c) * rstd, be = ld1_w(rP, op.beta_off + c) - mean * ga;
                         out[(int64_t)cluster * out_img_stride + i] = fmaxf(fmaf(v[e], ga, be), 0.f);
                     }
                 }
@@ -293,52 +406,67 @@ __global__ __launch_bounds__(NT) void k_depth_net(const Op* __restrict__ ops, in
             continue;
         }
         if (has_task) {
-            const int Cin = op.Cin, Win = op.Win, Hin = op.Hin, Wp = op.wp, CS = op.cs, pad = op.pad;
-            const int PG = 16 * op.WPT * op.P;          // output pixels of this task
-            const int rows_out = PG >> op.wout_shift;   // whole output rows
-            const int oy0 = ptg * rows_out;
-            // a 1x1 stride-2 conv only ever reads every second row / column: the tile holds the sub-sampled map
-            const bool sub = op.ks == 1 && op.stride == 2;
-            const int s_eff = sub ? 1 : op.stride;
-            const int Rs = (rows_out - 1) * s_eff + op.ks, iy0 = oy0 * s_eff - pad;
-            const int HWin = Hin * Win;
-            // a workgroup that owns a K slice (kwg > 1) stages the channels of that slice only
-            int c_lo = 0, c_n = Cin;
-            if (op.kwg > 1) {
-                const int KK = op.ks * op.ks, kb_wg = min(kwg_i * op.KW * per, op.ksteps), ke_wg = min(kb_wg + op.KW * per, op.ksteps);
-                c_lo = 4 * (kb_wg / KK);
-                c_n = 4 * ((ke_wg + KK - 1) / KK) - c_lo;
-            }
-            // ---- 3a. GroupNorm statistics of the input(s): 16 groups x up to 32 parts, one half wave per group ----
-            if (op.st_parts > 0) {
-                const int CM = (L.tile - L.tab) >> 2;  // table stride
-                for (int which = 0; which < (op.src2_off >= 0 ? 2 : 1); ++which) {
+            // ---- 3. input rows -> LDS tile [channels][Rs][Wp] (zero halo), transformed on load.  Every global load of
+            // the phase is issued first - the statistics partials, then the first batch of input float4s - so that the
+            // scale / shift table is computed under the inputs' flight ----
+            const int sg = tid >> 5, spart = tid & 31;
+            float sn[2] = {0.f, 0.f}, sm[2] = {0.f, 0.f}, sM[2] = {0.f, 0.f};
+            if (gn) {
+#pragma unroll
+                for (int which = 0; which < 2; ++which) {
                     const int parts = which ? op.st2_parts : op.st_parts, soff = which ? op.st2_off : op.st_off;
-                    const int goff = which ? op.gamma2_off : op.gamma_off, boff = which ? op.beta2_off : op.beta_off;
-                    const int g = tid >> 5, part = tid & 31;
-                    float n = 0.f, m = 0.f, M2 = 0.f;
-                    if (part < parts) {
-                        const int o = soff + (g * parts + part) * 3;
-                        n = ld1_x(rA, o);
-                        m = ld1_x(rA, o + 1);
-                        M2 = ld1_x(rA, o + 2);
+                    if ((which == 0 || two) && spart < parts) {  // one 16-byte record (count, mean, M2, -) per (group, part)
+                        const float4 rec = ld4_x(rA, soff + (sg * parts + spart) * 4);
+                        sn[which] = rec.x, sm[which] = rec.y, sM[which] = rec.z;
                     }
-                    const float cnt = half_sum32(n), mean = half_sum32(n * m) / cnt;
-                    const float dd = m - mean;
-                    const float rstd = rsqrtf(half_sum32(fmaf(n * dd, dd, M2)) / cnt + eps);
-                    const int cpg = Cin >> 4;
-                    for (int cc = part; cc < cpg; cc += 32) {
-                        const int c = g * cpg + cc;
-                        const float sc = prm[goff + c] * rstd;
-                        tab[(2 * which) * CM + c] = sc;
-                        tab[(2 * which + 1) * CM + c] = prm[boff + c] - mean * sc;
+                }
+            }
+            if (total > 0) load_batch(tid, true, false);
+            // ---- scale / shift tables: 16 groups x up to 32 parts, one half wave per group (Chan's merge as the two-pass formula) ----
+            if (gn) {
+#pragma unroll
+                for (int which = 0; which < 2; ++which) {
+                    if (which == 0 || two) {
+                        const float n = sn[which], m = sm[which];
+                        const float cnt = half_sum32(n), mean = half_sum32(n * m) / cnt;
+                        const float dd = m - mean;
+                        const float rstd = rsqrtf(half_sum32(fmaf(n * dd, dd, sM[which])) / cnt + eps);
+                        const int cpg = Cin >> 4;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int ccn = spart + 32 * h;
+                            if (ccn < cpg) {
+                                const int c = sg * cpg + ccn;
+                                const float sc = gab[which][h] * rstd;
+                                tab[(2 * which) * CM + c] = sc;
+                                tab[(2 * which + 1) * CM + c] = beb[which][h] - mean * sc;
+                            }
+                        }
                     }
                 }
                 __syncthreads();
             }
-            const int CM = (L.tile - L.tab) >> 2;
-            const bool gn = op.st_parts > 0, two = op.src2_off >= 0, resid = op.res_off >= 0;
-            // ---- 3b. input rows -> LDS tile [Cin][Rs][Wp] (zero halo), transformed on load ----
+            // ---- k-step -> tile offset table of this workgroup's K ranges (pure ALU; the barrier below publishes it) ----
+            {
+                const int KK = op.ks * op.ks, q_lo = c_lo >> 2, n_ent = op.KW * cpk * 16;
+                for (int e = tid; e < n_ent; e += NT) {
+                    const int u = e & 3, kq_ = (e >> 2) & 3, ch = (e >> 4) % cpk, kw_ = (e >> 4) / cpk;
+                    const int kb = min((kwg_i * op.KW + kw_) * per, op.ksteps), ke = min(kb + per, op.ksteps);
+                    int off = 0;
+                    if (ke > kb) {
+                        const int k = min(kb + 4 * ch + u, ke - 1);
+                        if (op.ks == 7) {
+                            const int tap = min(4 * k + kq_, KK - 1), dy = tap / 7;
+                            off = dy * Wp + (tap - 7 * dy);
+                        } else {
+                            const int q = k / KK, t = k - q * KK, dy = t / op.ks;
+                            off = (4 * (q - q_lo) + kq_) * CS + dy * Wp + (t - dy * op.ks);
+                        }
+                    }
+                    btab[e] = off;
+                }
+            }
+            DN_STAMP(2);
             if (op.avg_in) {
                 // op 0: F.avg_pool2d(depth, 2) of the raw 2 Hin x 2 Win image, rows iy0 .. iy0 + Rs
                 const int Wr = 2 * Win;
@@ -359,6 +487,14 @@ __global__ __launch_bounds__(NT) void k_depth_net(const Op* __restrict__ ops, in
                 for (int i = tid; i < Cin * Rs * Win; i += NT) {
                     const int c = by_row(i), rem = i - c * Rs * Win, r = by_w(rem), x = rem - r * Win, iy = iy0 + r;
                     const float sc = tab[c], sh = tab[CM + c];
+                    float v9[9];
+#pragma unroll
+                    for (int a = 0; a < 3; ++a)
+#pragma unroll
+                        for (int b = 0; b < 3; ++b) {  // nine independent loads (clamped addresses), then the maximum of the valid ones
+                            const int hh = min(max(2 * iy - 1 + a, 0), Hr - 1), ww = min(max(2 * x - 1 + b, 0), Wr - 1);
+                            v9[a * 3 + b] = ld1_x(rA, op.src_off + c * Hr * Wr + hh * Wr + ww);
+                        }
                     float m = -INFINITY;
 #pragma unroll
                     for (int a = 0; a < 3; ++a)
@@ -366,7 +502,7 @@ __global__ __launch_bounds__(NT) void k_depth_net(const Op* __restrict__ ops, in
                         for (int b = 0; b < 3; ++b) {
                             const int hh = 2 * iy - 1 + a, ww = 2 * x - 1 + b;
                             if ((unsigned)hh < (unsigned)Hr && (unsigned)ww < (unsigned)Wr) {
-                                float v = fmaf(ld1_x(rA, op.src_off + c * Hr * Wr + hh * Wr + ww), sc, sh);
+                                float v = fmaf(v9[a * 3 + b], sc, sh);
                                 if (op.relu) v = fmaxf(v, 0.f);
                                 m = fmaxf(m, v);
                             }
@@ -374,34 +510,14 @@ __global__ __launch_bounds__(NT) void k_depth_net(const Op* __restrict__ ops, in
                     tile[c * CS + r * Wp + pad + x] = m;
                 }
             } else {
-                const int W4 = Win >> 2, per_c = Rs * W4, total = c_n * per_c;
-                const fdiv by_pc(per_c), by_w4(W4);
-                const bool wr_act = op.act_out_off >= 0 && ctg == 0 && kwg_i == 0;
                 for (int i0 = tid; i0 < total; i0 += NT * 4) {
-                    float4 xv[4], x2v[4], rv[4];
-                    int cc[4], rr[4], xx[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {  // all loads of four elements in flight before the first is used
-                        const int i = min(i0 + e * NT, total - 1);
-                        const int cl = by_pc(i), c = c_lo + cl, rem = i - cl * per_c, r = by_w4(rem), x4 = rem - r * W4;
-                        const int iy = sub ? 2 * (oy0 + r) : iy0 + r;
-                        cc[e] = c, rr[e] = r, xx[e] = x4;
-                        xv[e] = x2v[e] = rv[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if ((unsigned)iy < (unsigned)Hin) {
-                            const int o = c * HWin + iy * Win + 4 * x4;
-                            xv[e] = ld4_x(rA, op.src_off + o);
-                            for (int z = 1; z < op.nslab; ++z) {
-                                const float4 w = ld4_x(rA, op.src_off + z * op.slab_stride + o);
-                                xv[e].x += w.x, xv[e].y += w.y, xv[e].z += w.z, xv[e].w += w.w;
-                            }
-                            if (two) x2v[e] = ld4_x(rA, op.src2_off + o);
-                            if (resid) rv[e] = ld4_x(rA, op.res_off + o);
-                        }
-                    }
+                    if (i0 != tid) load_batch(i0, true, true);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if (i0 + e * NT < total) {
-                            const int c = cc[e], r = rr[e], x4 = xx[e], iy = sub ? 2 * (oy0 + r) : iy0 + r;
+                            const int i = i0 + e * NT;  // (indices recomputed: cheaper than 12 live registers)
+                            const int cl = by_pc(i), c = c_lo + cl, rem = i - cl * per_c, r = by_w4(rem), x4 = rem - r * W4;
+                            const int iy = sub ? 2 * (oy0 + r) : iy0 + r;
                             float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
                             if ((unsigned)iy < (unsigned)Hin) {
                                 a = xv[e];
@@ -410,11 +526,11 @@ __global__ __launch_bounds__(NT) void k_depth_net(const Op* __restrict__ ops, in
                                     a.x = fmaf(a.x, sc, sh), a.y = fmaf(a.y, sc, sh), a.z = fmaf(a.z, sc, sh), a.w = fmaf(a.w, sc, sh);
                                     if (two) {
                                         const float s2 = tab[2 * CM + c], h2 = tab[3 * CM + c];
-                                        a.x += fmaf(x2v[e].x, s2, h2), a.y += fmaf(x2v[e].y, s2, h2);
-                                        a.z += fmaf(x2v[e].z, s2, h2), a.w += fmaf(x2v[e].w, s2, h2);
+                                        a.x += fmaf(yv[e].x, s2, h2), a.y += fmaf(yv[e].y, s2, h2);
+                                        a.z += fmaf(yv[e].z, s2, h2), a.w += fmaf(yv[e].w, s2, h2);
                                     }
                                 }
-                                if (resid) a.x += rv[e].x, a.y += rv[e].y, a.z += rv[e].z, a.w += rv[e].w;
+                                if (resid) a.x += yv[e].x, a.y += yv[e].y, a.z += yv[e].z, a.w += yv[e].w;
                                 if (op.relu) a.x = fmaxf(a.x, 0.f), a.y = fmaxf(a.y, 0.f), a.z = fmaxf(a.z, 0.f), a.w = fmaxf(a.w, 0.f);
                                 if (wr_act) st4_x(rA, op.act_out_off + c * HWin + iy * Win + 4 * x4, a, plain);
                             }
@@ -424,8 +540,10 @@ __global__ __launch_bounds__(NT) void k_depth_net(const Op* __restrict__ ops, in
                                 continue;
                             }
                             float* tp = tile + (c - c_lo) * CS + r * Wp + pad + 4 * x4;
-                            tp[0] = a.x, tp[1] = a.y, tp[2] = a.z, tp[3] = a.w;
-                            if (pad) {
+                            if (pad == 0) {
+                                *reinterpret_cast<float4*>(tp) = a;  // (CS, Wp multiples of 4: 16-byte aligned)
+                            } else {
+                                tp[0] = a.x, tp[1] = a.y, tp[2] = a.z, tp[3] = a.w;
                                 if (x4 == 0)
                                     for (int z = 1; z <= pad; ++z) tp[-z] = 0.f;
                                 if (x4 == W4 - 1)
@@ -436,6 +554,7 @@ __global__ __launch_bounds__(NT) void k_depth_net(const Op* __restrict__ ops, in
                 }
             }
             __syncthreads();
+            DN_STAMP(3);
             // ---- 4. matrix product ----
             const int kq = lane >> 4, j = lane & 15;
             int lane_base[2];
@@ -444,20 +563,18 @@ __global__ __launch_bounds__(NT) void k_depth_net(const Op* __restrict__ ops, in
             for (int p = 0; p < 2; ++p) {
                 const int qpx = (wpt * op.P + p) * 16 + j;
                 const int oyl = qpx >> op.wout_shift, ox = qpx & ((1 << op.wout_shift) - 1);
-                lane_base[p] = oyl * s_eff * Wp + ox * s_eff + (op.ks == 7 ? 0 : kq * CS);
+                lane_base[p] = oyl * s_eff * Wp + ox * s_eff;
                 acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            if (op.ks == 1) {
-                if (op.P == 2) wave_mma<1, 2>(op, wbase, a_chunk0, nch, kbeg, kend, tile, lane_base, acc, abuf, a_lane, c_lo >> 2);
-                else wave_mma<1, 1>(op, wbase, a_chunk0, nch, kbeg, kend, tile, lane_base, acc, abuf, a_lane, c_lo >> 2);
-            } else if (op.ks == 3) {
-                if (op.P == 2) wave_mma<3, 2>(op, wbase, a_chunk0, nch, kbeg, kend, tile, lane_base, acc, abuf, a_lane, c_lo >> 2);
-                else wave_mma<3, 1>(op, wbase, a_chunk0, nch, kbeg, kend, tile, lane_base, acc, abuf, a_lane, c_lo >> 2);
-            } else {
-                if (op.P == 2) wave_mma<7, 2>(op, wbase, a_chunk0, nch, kbeg, kend, tile, lane_base, acc, abuf, a_lane, c_lo >> 2);
-                else wave_mma<7, 1>(op, wbase, a_chunk0, nch, kbeg, kend, tile, lane_base, acc, abuf, a_lane, c_lo >> 2);
+            DN_STAMP(8);
+            if (nch > 0) {
+                const int* btab_w = btab + kw * cpk * 16;
+                if (op.P == 2) wave_mma<2>(rW, a_off0, a_stride, nch, tile, btab_w, lane_base, acc, abuf, a_mask);
+                else wave_mma<1>(rW, a_off0, a_stride, nch, tile, btab_w, lane_base, acc, abuf, a_mask);
             }
+            DN_STAMP(9);
             __syncthreads();  // every wave is done with the input tile: the output tile and the K-range scratch reuse its LDS
+            DN_STAMP(4);
             // ---- 5. complete output tile in LDS: otile[WCT * M rows][PG + 4] ----
             const int M = op.M, OP_ = PG + 4, rows_t = op.WCT * M;
             const bool row_lane = M == 16 || kq < 2;  // (M = 8: accumulator rows 8..15 are padding)
@@ -485,6 +602,7 @@ __global__ __launch_bounds__(NT) void k_depth_net(const Op* __restrict__ ops, in
                 }
                 __syncthreads();
             }
+            DN_STAMP(5);
             // raw outputs: whole pixel rows, 16 bytes per lane
             const int HWo = 1 << (2 * op.wout_shift), co0 = ctg * rows_t, px0 = ptg * PG;
             {
@@ -519,18 +637,18 @@ __global__ __launch_bounds__(NT) void k_depth_net(const Op* __restrict__ ops, in
                     s2 = wave_sum(s2);
                     if (lane == 0) {
                         const int g = co0 / cpo + (cpo > rows_t ? 0 : lg);
-                        const int o = op.st_out_off + (g * op.st_out_parts + part) * 3;
-                        st1_x(rA, o, (float)nel, plain);
-                        st1_x(rA, o + 1, pilot + s1 / (float)nel, plain);
-                        st1_x(rA, o + 2, fmaxf(s2 - s1 * s1 / (float)nel, 0.f), plain);
+                        st4_x(rA, op.st_out_off + (g * op.st_out_parts + part) * 4,
+                              make_float4((float)nel, pilot + s1 / (float)nel, fmaxf(s2 - s1 * s1 / (float)nel, 0.f), 0.f), plain);
                     }
                 }
             }
         }
         // ---- arrive when the next op (or the end of the program) has to see these stores ----
+        DN_STAMP(6);
         if (oi + 1 < n_ops && ops[oi + 1].barrier_before) {
-            cluster_arrive(sy, cluster);
+            cluster_arrive(sy, cluster, plain && LOCAL_ATOMICS);
             ++arrivals;
+            DN_STAMP(7);
         } else {
             __syncthreads();  // (LDS is reused by the next op)
         }
@@ -556,7 +674,7 @@ int ivln_depth_net_f32(const ivln_depthnet_op* ops_dev, const ivln_depthnet_op* 
     if (!ops_dev || !ops_host || n_ops <= 0 || !weights || !params || !depth || !arena || !out || !sync_ws) return IVLN_E_INVALID;
     if (N < 1 || N > 8) return IVLN_E_UNSUPPORTED;  // one image per XCD-sized cluster
     // LDS layout from the program's maxima
-    int cmax = 0, tile = 0, otile = 0, scr = 0;
+    int cmax = 0, tile = 0, otile = 0, scr = 0, btab_max = 0;
     for (int i = 0; i < n_ops; ++i) {
         const ivln_depthnet_op& o = ops_host[i];
         if (o.kind != 0) continue;
@@ -575,18 +693,25 @@ int ivln_depth_net_f32(const ivln_depthnet_op* ops_dev, const ivln_depthnet_op* 
         }
         const int need = o.ks == 7 ? Rs * o.wp : c_n * o.cs;
         if (o.cs < Rs * o.wp || (sub && (o.act_out_off >= 0 || o.pool || o.wp != (1 << o.wout_shift)))) return IVLN_E_INVALID;
-        if (o.st_parts > 32 || o.st2_parts > 32 || o.st_out_parts > 32) return IVLN_E_INVALID;
+        if (o.st_parts > 32 || o.st2_parts > 32 || o.st_out_parts > 32 || (o.src2_off >= 0 && o.res_off >= 0)) return IVLN_E_INVALID;
         cmax = o.Cin > cmax ? o.Cin : cmax;
         tile = need > tile ? need : tile;
         const int ot = o.WCT * o.M * (PG + 4);
         otile = ot > otile ? ot : otile;
+        {
+            const int KWT = o.KW * o.kwg, per = (o.ksteps + KWT - 1) / KWT, cpk = (per + 3) >> 2;
+            if (cpk > MAXCH) return IVLN_E_UNSUPPORTED;
+            const int bt = o.KW * cpk * 16;
+            btab_max = bt > btab_max ? bt : btab_max;
+        }
         const int sc = o.KW > 1 ? (NT / 64) * o.P * 256 : 0;
         scr = sc > scr ? sc : scr;
     }
     Lds L;
     L.tab = 32;
     cmax = (cmax + 3) & ~3;
-    L.tile = L.tab + 4 * cmax;
+    L.btab = L.tab + 4 * cmax;
+    L.tile = L.btab + btab_max;
     L.otile = L.tile;  // the output tile and the K-range scratch reuse the input tile's LDS (a barrier separates the phases)
     L.scratch = L.otile + ((otile + 3) & ~3);
     const int body = tile > ((otile + 3) & ~3) + scr ? tile : ((otile + 3) & ~3) + scr;
@@ -607,10 +732,21 @@ int ivln_depth_net_f32(const ivln_depthnet_op* ops_dev, const ivln_depthnet_op* 
         }
     }
     if (resident < 8 * CL) return IVLN_E_UNSUPPORTED;  // the clusters spin on each other's arrivals: all of them resident, or none
+#ifdef DEPTH_NET_TIMING
+    hipLaunchKernelGGL(k_depth_net, dim3(8 * CL), dim3(NT), lds, (hipStream_t)stream, ops_dev, n_ops, weights, params, depth,
+                       depth_img_stride, arena, arena_stride, out, out_img_stride, N, eps, (unsigned*)sync_ws, L);
+#else
     IVLN_LAUNCH_FAMILY(k_depth_net, dim3(8 * CL), dim3(NT), lds, (hipStream_t)stream, ops_dev, n_ops, weights, params, depth,
                        depth_img_stride, arena, arena_stride, out, out_img_stride, N, eps, (unsigned*)sync_ws, L);
+#endif
     return hipGetLastError() == hipSuccess ? IVLN_OK : IVLN_E_HIP;
 }
+
+#ifdef DEPTH_NET_TIMING
+int ivln_depth_net_stamps(unsigned long long* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_dn_stamp), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
+}
+#endif
 
 /* Synchronises `stream` and reads the sticky error word of a depth-net sync workspace. */
 int ivln_depth_net_status(const void* sync_ws, void* stream) {

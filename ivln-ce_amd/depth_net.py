@@ -35,7 +35,7 @@ class DepthNetOp(C.Structure):
 
 
 NWAVES, CLUSTER = 8, 32
-ST_FLOATS = 16 * 32 * 3  # statistics partials of one tensor: [16 groups][<= 32 parts][3]
+ST_FLOATS = 16 * 32 * 4  # statistics partials of one tensor: [16 groups][<= 32 parts][4] = (count, mean, M2, -)
 
 
 def _pow2_ge(x):
@@ -300,7 +300,7 @@ def emulate(prog, depth):
         Wout = 1 << op["wout_shift"]
 
         def merged(st_off, parts, C_):
-            st = arena[st_off: st_off + 16 * parts * 3].view(16, parts, 3)
+            st = arena[st_off: st_off + 16 * parts * 4].view(16, parts, 4)
             n, m, M2 = st[..., 0], st[..., 1], st[..., 2]
             cnt = n.sum(1)
             mean = (n * m).sum(1) / cnt
@@ -354,7 +354,7 @@ def emulate(prog, depth):
             continue
         if op["st_out_parts"]:
             parts = op["st_out_parts"]
-            st = arena[op["st_out_off"]: op["st_out_off"] + 16 * parts * 3].view(16, parts, 3)
+            st = arena[op["st_out_off"]: op["st_out_off"] + 16 * parts * 4].view(16, parts, 4)
             rows_t, PG, cpo = op["WCT"] * op["M"], 16 * op["WPT"] * op["P"], Cout // 16
             yf = y.reshape(Cout, HWo)
             for ctg in range(op["n_ctg"]):

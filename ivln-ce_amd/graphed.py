@@ -205,6 +205,7 @@ class GraphedRollout:
         predicted = any(getattr(t, "predicted_semantics", False) for t in self.transforms)
         if venc is not None:
             venc.latency_bound = not predicted
+            venc.beside_other_work = True  # (its graph replays beside the mapper / map-CNN graph: ops.DEPTH_NET's policy)
         net._txt_with_dep = predicted  # ... and the instruction encoder leaves RedNet's stream for the side graph
         s = _stream(dev, "warmup")
         s.wait_stream(main)
@@ -250,6 +251,8 @@ class GraphedRollout:
             self.graphs.append(g2)
         self._keep = (batch, stash)
         self.phase = 0
+        if venc is not None:
+            venc.beside_other_work = False  # (the captured launches are what they are; eager calls decide for themselves)
 
     def _replay_split(self):
         main = torch.cuda.current_stream()

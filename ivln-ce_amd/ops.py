@@ -694,7 +694,13 @@ def conv_gn(x, w, gn, stride=1, pad=0, relu=False, residual=None, ds=None, out=N
 # conv + GroupNorm pairs
 # the whole depth encoder of a rollout batch (<= 8 images) as ONE persistent launch (csrc/depth_net.hip); 0: the per-layer
 # launch chain below (A/B switch, and what runs where the persistent grid cannot be resident)
-DEPTH_NET = os.environ.get("IVLN_DEPTH_NET", "1") != "0"
+#   "1" (default) where it measured faster: eager / single-stream execution at <= 8 images (one launch instead of 54:
+#       526 vs 565 us of GPU time, and no 54 host enqueues), and inside the split replay from DEPTH_NET_SPLIT_MIN images
+#       (beside the mapper / map-CNN graph the persistent workgroups hold their CUs - 512 threads x 218 VGPRs, ~105 KB LDS -
+#       so at 4 images the other graph is squeezed onto the remaining XCDs: 0.81 vs 0.72 ms per step; at 8: 0.90 vs 0.91);
+#   "2" always (<= 8 images); "0" never.
+DEPTH_NET = int(os.environ.get("IVLN_DEPTH_NET", "1"))
+DEPTH_NET_SPLIT_MIN = int(os.environ.get("IVLN_DEPTH_NET_SPLIT_MIN", "6"))
 CHAIN_GN_CONV = os.environ.get("IVLN_GN_CONV", "1") != "0"
 # The chain trades launches for slab bytes (16 partial slabs per conv), which pays while the step is latency-bound:
 # measured 4 envs 5.1 K vs 4.0 K env-steps/s, 8 envs 7.5 K vs 6.9 K, but 16 envs 9.5 K vs 10.1 K and 32 envs 11.1 K vs

@@ -36,3 +36,20 @@ def pytest_sessionstart(session):
     import __graft_entry__ as ge
 
     ge.build()
+
+
+@pytest.fixture
+def same_depth_path():
+    """Tests that demand BIT-identical results from a captured replay and from eager execution pin the depth encoder to
+    ONE implementation for both: by default (ops.DEPTH_NET = 1) eager and single-stream execution take the persistent
+    launch (csrc/depth_net.hip) while the split replay below DEPTH_NET_SPLIT_MIN images keeps the launch chain - the same
+    arithmetic in a different summation order (1e-5 apart).  Yields a function that sets the mode; restored afterwards."""
+    from ivln_ce_amd import ops
+
+    old = ops.DEPTH_NET
+
+    def pin(mode):
+        ops.DEPTH_NET = mode
+
+    yield pin
+    ops.DEPTH_NET = old

@@ -46,13 +46,13 @@ def test_persistent_depth_encoder_matches_the_launch_chain_and_the_oracle(B):
     d = depth.to(DEV)
     old = ops.DEPTH_NET
     try:
-        ops.DEPTH_NET = True
+        ops.DEPTH_NET = 2
         with torch.no_grad():
             a = enc({"depth": d}).cpu()
             a2 = enc({"depth": d}).cpu()
         plan = depth_net.plan_for(enc, DEV)
         plan.check_status()
-        ops.DEPTH_NET = False
+        ops.DEPTH_NET = 0
         with torch.no_grad():
             b = enc({"depth": d}).cpu()
     finally:
@@ -72,6 +72,7 @@ def test_persistent_depth_encoder_writes_into_a_strided_output_and_replays_in_a_
     from ivln_ce_amd import depth_net, ops
 
     enc = _encoder(7)
+    assert ops.DEPTH_NET >= 1  # (eager and single-stream captures take the persistent launch by default)
     B = 4
     d = torch.rand(B, 256, 256, 1, generator=torch.Generator().manual_seed(11)).to(DEV)
     wide = torch.full((B, 192, 4, 4), -7.0, device=DEV)

@@ -123,10 +123,11 @@ def test_act_matches_oracle_other_batches(B):
     assert float((lg.cpu() - lr).abs().max()) < 1e-4
 
 
-@pytest.mark.parametrize("streams", [True, False, "split"])
-def test_graphed_multistream_rollout_is_bit_identical_to_eager(streams):
+@pytest.mark.parametrize("streams,depth_mode", [(True, 0), (False, 2), ("split", 0), ("split", 2)])
+def test_graphed_multistream_rollout_is_bit_identical_to_eager(streams, depth_mode, same_depth_path):
     """hipGraph replay (forked streams / one stream / three graphs on two streams) must not change a single
-    bit of actions / states / maps."""
+    bit of actions / states / maps - with the depth encoder as the launch chain (0) and as the persistent launch (2)."""
+    same_depth_path(depth_mode)
     from ivln_ce_amd.config import get_config
     from ivln_ce_amd.graphed import GraphedRollout
     from ivln_ce_amd.obs_transforms import GTSemanticsIterativeMapper

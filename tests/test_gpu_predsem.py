@@ -113,9 +113,10 @@ def test_predsem_plugin_B8_rednet_mapper_policy_match_oracle():
 
 
 @pytest.mark.parametrize("streams", ["split", False])
-def test_predsem_graph_replay_is_bit_identical_to_eager_B8(streams):
+def test_predsem_graph_replay_is_bit_identical_to_eager_B8(streams, same_depth_path):
     from ivln_ce_amd.graphed import GraphedRollout
 
+    same_depth_path(0)  # (the single-stream capture would otherwise take the persistent depth encoder, the eager pass the pairs)
     cfg = _cfg()
     _, dev = _obs(5, seed=78)
     pol = _policy()
