@@ -15,6 +15,7 @@ SOURCES = {
     "gemm_conv.hip": [],
     "conv_direct.hip": [],
     "gemm_vec.hip": [],
+    "conv1x1_stream.hip": [],
     "conv_gn.hip": [],
     "gn_conv.hip": [],
     "depth_net.hip": [],

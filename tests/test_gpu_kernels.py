@@ -456,6 +456,45 @@ def test_vector_load_gemm_conv1x1(N, Cin, H, W, Cout):
     _close(slabs.permute(1, 0, 2, 3), ref0, 3e-5)
 
 
+@pytest.mark.parametrize("N,Cin,H,W,Cout,groups", [(2, 64, 64, 64, 256, 0), (1, 64, 128, 128, 64, 0), (4, 128, 32, 32, 512, 0),
+                                                   (16, 256, 16, 16, 1024, 0), (1, 64, 128, 128, 52, 0), (8, 64, 64, 64, 256, 2),
+                                                   (2, 256, 64, 64, 64, 0), (16, 128, 32, 32, 128, 2)])
+def test_streaming_conv1x1_short_k_matches_torch_and_the_tiled_kernel(N, Cin, H, W, Cout, groups):
+    """conv1x1_stream.hip (weights in registers, activations streamed as 16-byte loads, four interleaved pixel tiles per
+    load; taken by ivln_gemm_f32 for K = 64 / 128 / 256 over >= 4096 pixels) against F.conv2d and against the float4-
+    staged tiled kernel (tile_override 7) on RedNet's 1x1 shapes (rednet.py:190-263) - with the fused epilogue (folded
+    BatchNorm, residual, ReLU), a channel count that does not fill the last row tile, image-grouped weights (the stacked
+    rgb / depth encoders) and an output that is a channel slice of a wider buffer."""
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(N + Cin + Cout)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    G = max(groups, 1)
+    w = torch.randn(G, Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    sc, sh = torch.rand(G, Cout, generator=g) + 0.5, torch.randn(G, Cout, generator=g)
+    per = N // G
+    ref0 = torch.cat([F.conv2d(x[i * per:(i + 1) * per], w[i]) for i in range(G)])
+    res = torch.randn_like(ref0)
+    scb = torch.cat([sc[i].view(1, -1, 1, 1).expand(per, -1, 1, 1) for i in range(G)])
+    shb = torch.cat([sh[i].view(1, -1, 1, 1).expand(per, -1, 1, 1) for i in range(G)])
+    want = F.relu(ref0 * scb + shb + res)
+    wd = (w if groups else w[0]).to(DEV).contiguous()
+    scd, shd = (sc if groups else sc[0]).to(DEV).contiguous(), (sh if groups else sh[0]).to(DEV).contiguous()
+    got = ops.conv2d(x.to(DEV), wd, scale=scd, shift=shd, residual=res.to(DEV), relu=True)
+    _close(got, want, 3e-5)
+    try:
+        ops.TILE_OVERRIDE = 7
+        tiled = ops.conv2d(x.to(DEV), wd, scale=scd, shift=shd, residual=res.to(DEV), relu=True)
+    finally:
+        ops.TILE_OVERRIDE = 0
+    _close(got, tiled, 2e-5)  # (same products, different summation order: k pairs in sequence vs 32-deep K tiles)
+    if not groups:  # into a channel slice of a wider NCHW buffer, no epilogue
+        wide = torch.full((N, Cout + 8, H, W), -3.0, device=DEV)
+        ops.conv2d(x.to(DEV), wd, out=wide[:, 8:], out_ctot=Cout + 8)
+        _close(wide[:, 8:], ref0, 3e-5)
+        assert float(wide[:, :8].max()) == -3.0
+
+
 def test_vector_load_gemm_refuses_unaligned_shapes():
     from ivln_ce_amd import ops
     from ivln_ce_amd._lib import IvlnError
