@@ -593,7 +593,20 @@ int ivln_wgrad_direct_launch(ivln_gemm_desc& d, hipStream_t s) {
     return IVLN_OK;
 }
 
+// 1x1 convs with K = 64 / 128 / 256 (conv1x1_stream.hip): the per-lane register image of the weights,
+// out[((mt * K/2 + q) * 64) + lane] = W[min(32 mt + (lane & 31), M - 1)][2 q + (lane >> 5)] - one coalesced 256-byte row per MFMA step
+__global__ __launch_bounds__(256) void k_conv1x1_pack_weights(const float* __restrict__ W, int M, int K, float* __restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int NQ = K / 2;
+    const int64_t total = (int64_t)((M + 31) / 32) * NQ * 64;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63), q = (int)((idx >> 6) % NQ), mt = (int)((idx >> 6) / NQ);
+    const int m = min(32 * mt + (lane & 31), M - 1);
+    out[idx] = W[(int64_t)m * K + 2 * q + (lane >> 5)];
+}
+
 extern "C" int64_t ivln_conv_packed_floats(int M, int Cin, int KS) {
+    if (KS == 1) return (M > 0 && (Cin == 64 || Cin == 128 || Cin == 256)) ? (int64_t)((M + 31) / 32) * 32 * Cin : 0;
     if ((KS != 2 && KS != 3 && KS != 7) || M <= 0) return 0;
     const int CI = conv_direct_ci(KS), BM = M <= 32 ? 32 : 64;
     if (Cin % CI && KS != 7) return 0;  // (ragged channel chunks: the 7x7 stems only)
@@ -603,6 +616,10 @@ extern "C" int64_t ivln_conv_packed_floats(int M, int Cin, int KS) {
 extern "C" int ivln_conv_pack_weights_f32(const float* W, int M, int Cin, int KS, float* out, void* stream) {
     const int64_t total = ivln_conv_packed_floats(M, Cin, KS);
     if (!W || !out || total <= 0) return IVLN_E_INVALID;
+    if (KS == 1) {
+        hipLaunchKernelGGL(k_conv1x1_pack_weights, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, M, Cin, out);
+        return hipGetLastError() == hipSuccess ? IVLN_OK : IVLN_E_HIP;
+    }
     hipLaunchKernelGGL(k_conv_pack_weights, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, M,
                        Cin, KS, M <= 32 ? 32 : 64, out);
     return hipGetLastError() == hipSuccess ? IVLN_OK : IVLN_E_HIP;

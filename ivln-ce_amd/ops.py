@@ -372,6 +372,12 @@ def conv2d(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, 
         d.grp_imgs, d.a_grp_stride = N // G, Cout * Cin * KH * KW
     if KH == 1 and KW == 1 and pad == 0:
         d.bmode = B_CONV1X1
+        # short-K 1x1 convs over many pixels: the streaming kernel's per-lane weight image (conv1x1_stream.hip)
+        if stride == 1 and Cin in (128, 256) and N * Ho * Wo >= 4096 and PACK_WEIGHTS and w.is_contiguous() and not defer:
+            pk = packed_conv_weights(w, cache=not weight_is_temp)
+            if pk is not None:
+                d.A_packed = dptr(pk)
+                d.a_packed_grp_stride = pk.numel() // max(G, 1)
     elif KH == KW and KH in (3, 7) and dil == 1:
         d.bmode = B_CONV_K3 if KH == 3 else B_CONV_K7
         if stride in (1, 2) and PACK_WEIGHTS and w.is_contiguous():
