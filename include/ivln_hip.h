@@ -152,11 +152,13 @@ typedef struct ivln_gemm_desc {
     /* 0 = heuristic (direct conv / vector-load GEMM where eligible, else the scalar-gather implicit GEMM);
      * 1..5 force the scalar-gather kernel with block tile 64x64 / 32x128 / 128x32 / 128x128 / 64x128;
      * 6 insist on the LDS-patch direct conv / weight-gradient kernels (conv_direct.hip);
-     * 7 insist on the float4-staged GEMM (gemm_vec.hip).  6/7 return IVLN_E_UNSUPPORTED when the shape is
-     * not eligible (tuning, tests). */
+     * 7 insist on the float4-staged GEMM (gemm_vec.hip); 8 insist on the streaming short-K 1x1 conv
+     * (conv1x1_stream.hip: K = 64 / 128 / 256, NCHW, whole 128-pixel strips).  6/7/8 return IVLN_E_UNSUPPORTED when
+     * the shape is not eligible (tuning, tests). */
     int tile_override;
     /* optional (stride-1 3x3 / 7x7 / 2x2 convs): the weights pre-arranged by ivln_conv_pack_weights_f32; when set and
-     * the direct kernel is chosen, its weight staging becomes a linear float4 copy.  A must still be given. */
+     * the direct kernel is chosen, its weight staging becomes a linear float4 copy.  A must still be given.
+     * 1x1 convs with K = 64 / 128 / 256 (KS = 1 in the pack call): the streaming kernel's per-lane register image. */
     const float* A_packed;
     /* 0 (default): workgroup ids are remapped so that each XCD (hardware places workgroup b on XCD b % 8, each
      * with its own 4 MB L2) works on one contiguous range of output tiles - neighbouring tiles share operand rows /

@@ -241,4 +241,4 @@ int ivln_wgrad_direct_launch(ivln_gemm_desc& d, hipStream_t s);
 bool ivln_gemm_vec_eligible(const ivln_gemm_desc& d);
 int ivln_gemm_vec_launch(const ivln_gemm_desc& d, hipStream_t s, int tile);
 // conv1x1_stream.hip: short-K (64 / 128 / 256) 1x1 convs over many pixels, weights in registers; IVLN_E_UNSUPPORTED otherwise
-int ivln_conv1x1_stream_launch(const ivln_gemm_desc& d, hipStream_t s);
+int ivln_conv1x1_stream_launch(const ivln_gemm_desc& d, hipStream_t s, bool force);

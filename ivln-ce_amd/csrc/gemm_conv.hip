@@ -510,13 +510,13 @@ extern "C" int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream) {
         if (rc != IVLN_E_UNSUPPORTED || d.tile_override == 6) return rc;
     }
     // short-K 1x1 convs over many pixels: weights in registers, activations streamed (conv1x1_stream.hip)
-    if (d.tile_override == 0 && d.splits <= 1) {
-        const int rc = ivln_conv1x1_stream_launch(d, s);
+    if ((d.tile_override == 0 || d.tile_override == 8) && d.splits <= 1) {  // (tile_override 8 insists on it: tests)
+        const int rc = ivln_conv1x1_stream_launch(d, s, d.tile_override == 8);
         if (rc == IVLN_OK) {
             if (d.splits_used) *d.splits_used = 1;
             return hipGetLastError() == hipSuccess ? IVLN_OK : IVLN_E_HIP;
         }
-        if (rc != IVLN_E_UNSUPPORTED) return rc;
+        if (rc != IVLN_E_UNSUPPORTED || d.tile_override == 8) return rc;
     }
     // tile shape: channel-starved -> 32x128, pixel-starved -> 128x32; otherwise 64x128 when that still
     // gives >= 2 blocks per CU (512 blocks), else 64x64

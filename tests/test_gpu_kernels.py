@@ -480,8 +480,13 @@ def test_streaming_conv1x1_short_k_matches_torch_and_the_tiled_kernel(N, Cin, H,
     want = F.relu(ref0 * scb + shb + res)
     wd = (w if groups else w[0]).to(DEV).contiguous()
     scd, shd = (sc if groups else sc[0]).to(DEV).contiguous(), (sh if groups else sh[0]).to(DEV).contiguous()
-    got = ops.conv2d(x.to(DEV), wd, scale=scd, shift=shd, residual=res.to(DEV), relu=True)
+    try:
+        ops.TILE_OVERRIDE = 8  # insist on the streaming kernel (by default K = 64 stays with the tiled one)
+        got = ops.conv2d(x.to(DEV), wd, scale=scd, shift=shd, residual=res.to(DEV), relu=True)
+    finally:
+        ops.TILE_OVERRIDE = 0
     _close(got, want, 3e-5)
+    _close(ops.conv2d(x.to(DEV), wd, scale=scd, shift=shd, residual=res.to(DEV), relu=True), want, 3e-5)  # the default route
     try:
         ops.TILE_OVERRIDE = 7
         tiled = ops.conv2d(x.to(DEV), wd, scale=scd, shift=shd, residual=res.to(DEV), relu=True)
@@ -490,7 +495,11 @@ def test_streaming_conv1x1_short_k_matches_torch_and_the_tiled_kernel(N, Cin, H,
     _close(got, tiled, 2e-5)  # (same products, different summation order: k pairs in sequence vs 32-deep K tiles)
     if not groups:  # into a channel slice of a wider NCHW buffer, no epilogue
         wide = torch.full((N, Cout + 8, H, W), -3.0, device=DEV)
-        ops.conv2d(x.to(DEV), wd, out=wide[:, 8:], out_ctot=Cout + 8)
+        try:
+            ops.TILE_OVERRIDE = 8
+            ops.conv2d(x.to(DEV), wd, out=wide[:, 8:], out_ctot=Cout + 8)
+        finally:
+            ops.TILE_OVERRIDE = 0
         _close(wide[:, 8:], ref0, 3e-5)
         assert float(wide[:, :8].max()) == -3.0
 
