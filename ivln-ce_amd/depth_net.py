@@ -403,9 +403,23 @@ class DepthNetPlan:
 
     @staticmethod
     def stamp_of(encoder):
+        """Changes when the encoder's weights may have changed: tensor versions / addresses, and - only when some of its
+        parameters train (FlatAdam then updates them through raw pointers without touching `_version`) - ops.WEIGHT_EPOCH.
+        The DD-PPO depth encoder is frozen in every reference configuration (resnet_encoders.py:45-46)."""
         from . import ops
 
-        return (ops.WEIGHT_EPOCH,) + tuple((p._version, p.data_ptr()) for p in encoder.parameters())
+        ps = list(encoder.parameters())
+        epoch = ops.WEIGHT_EPOCH if any(p.requires_grad for p in ps) else 0
+        return (epoch,) + tuple((p._version, p.data_ptr()) for p in ps)
+
+    def refresh(self, encoder):
+        """New weights, same architecture: repack into the SAME device buffers (a captured graph keeps raw pointers to
+        them; the op table does not depend on the weights' values)."""
+        prog = build_program(encoder)
+        assert prog.w_floats == self.weights.numel() and prog.p_floats == self.params.numel()
+        self.weights.copy_(torch.cat(prog.wchunks))
+        self.params.copy_(torch.cat(prog.pchunks))
+        self.stamp = self.stamp_of(encoder)
 
     def run(self, depth, out, out_img_stride):
         """depth (B, H, W, 1) float32 contiguous on the device -> out[b * out_img_stride + ...] (C, h, w) per image.
@@ -435,18 +449,27 @@ _PLANS = {}
 
 def plan_for(encoder, device):
     """The encoder's plan on `device`, rebuilt when its parameters change.  None while a graph is being captured and no
-    plan exists yet (building one allocates and uploads: the warm-up step before a capture creates it)."""
+    plan exists yet (building one allocates and uploads: the warm-up step before a capture creates it).  Plans of encoders
+    that no longer exist are dropped (each holds ~100 MB: arena for 8 images + packed weights)."""
+    import weakref
+
+    for k in [k for k, (ref, _) in _PLANS.items() if ref() is None]:
+        del _PLANS[k]
     key = (id(encoder), str(device))
     ent = _PLANS.get(key)
     stamp = DepthNetPlan.stamp_of(encoder)
-    if ent is None or ent.stamp != stamp:
+    if ent is not None and ent[0]() is encoder and ent[1].stamp != stamp:
         if torch.cuda.is_current_stream_capturing():
             return None
-        ent = _PLANS[key] = DepthNetPlan(encoder, device)
-    return ent
+        ent[1].refresh(encoder)
+    elif ent is None or ent[0]() is not encoder:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        ent = _PLANS[key] = (weakref.ref(encoder), DepthNetPlan(encoder, device))
+    return ent[1]
 
 
 def check_all():
     """Raises when a cluster barrier of any plan's launches timed out (sticky word); synchronises the current stream."""
-    for plan in _PLANS.values():
+    for _, plan in list(_PLANS.values()):
         plan.check_status()

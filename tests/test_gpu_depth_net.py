@@ -97,3 +97,30 @@ def test_persistent_depth_encoder_writes_into_a_strided_output_and_replays_in_a_
         assert torch.equal(out, want)
     depth_net.plan_for(enc, DEV).check_status()
     assert int(depth_net.plan_for(enc, DEV).sync.abs().sum()) == 0
+
+
+def test_persistent_depth_encoder_follows_weight_changes_in_place():
+    """Loading new weights into the encoder (a checkpoint) refreshes the plan's packed weights in the SAME device buffers -
+    a graph captured earlier keeps raw pointers to them - and the next launch computes with the new weights."""
+    from ivln_ce_amd import depth_net, ops
+
+    enc = _encoder(9)
+    d = torch.rand(2, 256, 256, 1, generator=torch.Generator().manual_seed(5)).to(DEV)
+    old = ops.DEPTH_NET
+    try:
+        ops.DEPTH_NET = 2
+        with torch.no_grad():
+            a = enc({"depth": d}).clone()
+        plan = depth_net.plan_for(enc, DEV)
+        wptr = plan.weights.data_ptr()
+        enc.load_state_dict({k: v * 1.01 for k, v in enc.state_dict().items()})
+        with torch.no_grad():
+            b = enc({"depth": d}).clone()
+        assert depth_net.plan_for(enc, DEV) is plan and plan.weights.data_ptr() == wptr
+        ops.DEPTH_NET = 0
+        with torch.no_grad():
+            c = enc({"depth": d})
+    finally:
+        ops.DEPTH_NET = old
+    assert float((a - b).abs().max()) > 1e-3, "the new weights must change the features"
+    assert float((b - c).abs().max()) < 2e-4
