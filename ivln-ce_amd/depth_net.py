@@ -134,7 +134,7 @@ class Program:
     """ops (list of dict), weight blob, parameter blob, arena layout."""
 
     def __init__(self):
-        self.ops, self.wchunks, self.pchunks = [], [], []
+        self.ops, self.wchunks, self.pchunks, self.names = [], [], [], []  # names: the conv module each op runs (state_dict path)
         self.w_floats = self.p_floats = 0
         self.arena = 0
         self.flops_per_image = 0
@@ -164,7 +164,7 @@ class Program:
         return arr
 
 
-def _conv_op(prog, w, stride, pad, Hin, Win, src, barrier, allow_kwg=False, pool=False, avg_in=False):
+def _conv_op(prog, w, stride, pad, Hin, Win, src, barrier, allow_kwg=False, pool=False, avg_in=False, name=""):
     """One conv op reading `src` = dict(off, nslab, slab_stride, st_off, st_parts, gn, x2 (off, st_off, st_parts, gn) | None,
     res_off | None, relu, act_out_off | None).  Returns (op dict, out descriptor)."""
     Cout, Cin, ks, _ = w.shape
@@ -205,6 +205,7 @@ def _conv_op(prog, w, stride, pad, Hin, Win, src, barrier, allow_kwg=False, pool
     if src.get("res_off") is not None:
         op["res_off"] = src["res_off"]
     prog.ops.append(op)
+    prog.names.append(name)
     prog.flops_per_image += 2 * Cout * Hout * Wout * Cin * ks * ks
     out = dict(off=dst, st_off=st_out, st_parts=st_out_parts, C=Cout, H=Hout, W=Wout, nslab=t["kwg"], slab_stride=Cout * Hout * Wout)
     return op, out
@@ -221,7 +222,7 @@ def build_program(encoder):
     c1, g1 = bb.conv1[0], bb.conv1[1]
     assert c1.in_channels == 1 and c1.kernel_size == (7, 7) and g1.num_groups == 16
     Hin = Win = 128
-    _, x = _conv_op(prog, c1.weight, 2, 3, Hin, Win, dict(off=0), barrier=False, avg_in=True)
+    _, x = _conv_op(prog, c1.weight, 2, 3, Hin, Win, dict(off=0), barrier=False, avg_in=True, name="backbone.conv1.0")
     stem_gn = gn_of(g1)
     # the stem's GroupNorm + ReLU + MaxPool(3, 2, 1) happen on load in the first block's convs
     cur = dict(kind="pool", x=x, gn=stem_gn)
@@ -230,6 +231,7 @@ def build_program(encoder):
     act_i = 0
     identity_off = None
     blocks = [b for layer in (bb.layer1, bb.layer2, bb.layer3, bb.layer4) for b in layer]
+    bnames = [f"backbone.layer{li + 1}.{bi}" for li, layer in enumerate((bb.layer1, bb.layer2, bb.layer3, bb.layer4)) for bi in range(len(layer))]
 
     def tail_src(cur, want_act):
         """How the consumer of a block output reads it."""
@@ -250,30 +252,34 @@ def build_program(encoder):
         c = blk.convs
         has_ds = blk.downsample is not None
         src, pool = tail_src(cur, want_act=not has_ds)
-        _, x1 = _conv_op(prog, c[0].weight, 1, 0, H, W, src, barrier=True, pool=pool)
+        _, x1 = _conv_op(prog, c[0].weight, 1, 0, H, W, src, barrier=True, pool=pool, name=bnames[bi] + ".convs.0")
         identity = src.get("act_out_off")
         xds = gnds = None
         if has_ds:
             src_ds = dict(src)
             src_ds.pop("act_out_off", None)
-            _, xds = _conv_op(prog, blk.downsample[0].weight, blk.stride, 0, H, W, src_ds, barrier=False, pool=pool)
+            _, xds = _conv_op(prog, blk.downsample[0].weight, blk.stride, 0, H, W, src_ds, barrier=False, pool=pool,
+                              name=bnames[bi] + ".downsample.0")
             gnds = gn_of(blk.downsample[1])
         _, x2 = _conv_op(prog, c[3].weight, blk.stride, 1, H, W,
-                         dict(off=x1["off"], st_off=x1["st_off"], st_parts=x1["st_parts"], gn=gn_of(c[1]), relu=1), barrier=True)
+                         dict(off=x1["off"], st_off=x1["st_off"], st_parts=x1["st_parts"], gn=gn_of(c[1]), relu=1), barrier=True,
+                         name=bnames[bi] + ".convs.3")
         H, W = x2["H"], x2["W"]
         _, x3 = _conv_op(prog, c[6].weight, 1, 0, H, W,
-                         dict(off=x2["off"], st_off=x2["st_off"], st_parts=x2["st_parts"], gn=gn_of(c[4]), relu=1), barrier=True)
+                         dict(off=x2["off"], st_off=x2["st_off"], st_parts=x2["st_parts"], gn=gn_of(c[4]), relu=1), barrier=True,
+                         name=bnames[bi] + ".convs.6")
         cur = dict(kind="block", x3=x3, gn3=gn_of(c[7]), xds=xds, gnds=gnds, identity=identity)
     # --- compression: 3x3, K split over workgroups (slabs), then GroupNorm(1) + ReLU ---
     comp, gcomp = encoder.compression[0], encoder.compression[1]
     assert gcomp.num_groups == 1
     src, _ = tail_src(cur, want_act=False)
-    _, xc = _conv_op(prog, comp.weight, 1, 1, H, W, src, barrier=True, allow_kwg=True)
+    _, xc = _conv_op(prog, comp.weight, 1, 1, H, W, src, barrier=True, allow_kwg=True, name="compression.0")
     fin = {f: 0 for f in _FIELDS}
     fin.update(kind=1, Cin=xc["C"], Hin=xc["H"], Win=xc["W"], src_off=xc["off"], nslab=xc["nslab"], slab_stride=xc["slab_stride"],
                gamma_off=prog.add_params(gcomp.weight), beta_off=prog.add_params(gcomp.bias), barrier_before=1, src2_off=-1, res_off=-1,
                act_out_off=-1, WCT=1, WPT=1, P=1, KW=8, kwg=1, n_ctg=1, n_ptg=1, M=16)
     prog.ops.append(fin)
+    prog.names.append("compression.1")
     prog.out_shape = (xc["C"], xc["H"], xc["W"])
     prog.eps = float(g1.eps)
     return prog

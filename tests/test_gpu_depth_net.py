@@ -124,3 +124,55 @@ def test_persistent_depth_encoder_follows_weight_changes_in_place():
         ops.DEPTH_NET = old
     assert float((a - b).abs().max()) > 1e-3, "the new weights must change the features"
     assert float((b - c).abs().max()) < 2e-4
+
+
+def test_persistent_depth_encoder_per_layer_error_budget():
+    """Per-layer error budget of the persistent launch ("add a per-layer error budget test before
+    touching the chain again"): every conv's RAW output, read back from the arena, against the same conv's output in the
+    oracle's float64 restatement (forward hooks) - relative to the layer's largest value.  The error may not grow faster
+    than a budget that is linear in depth and ends at 1.2e-5 (an eighth of the 1e-4 feature bar; measured 2e-6)."""
+    from ivln_ce_amd import depth_net, ops
+    from oracle import habitat_ext_ref as R
+
+    enc = _encoder(3)
+    depth = torch.rand(2, 256, 256, 1, generator=torch.Generator().manual_seed(17))
+    old = ops.DEPTH_NET
+    try:
+        ops.DEPTH_NET = 2
+        with torch.no_grad():
+            feats = enc({"depth": depth.to(DEV)}).cpu()
+    finally:
+        ops.DEPTH_NET = old
+    plan = depth_net.plan_for(enc, DEV)
+    plan.check_status()
+    arena = plan.arena.cpu()
+    space = types.SimpleNamespace(spaces={"depth": types.SimpleNamespace(shape=(256, 256, 1))})
+    ref = R.ResNetEncoder(space, baseplanes=32, ngroups=16, make_backbone=R.resnet50)
+    ref.load_state_dict({k: v.cpu() for k, v in enc.state_dict().items()})
+    ref = ref.double()
+    raw = {}
+    mods = dict(ref.named_modules())
+    hooks = [mods[n].register_forward_hook(lambda m, i, o, n=n: raw.__setitem__(n, o.detach())) for n in plan.prog.names
+             if n in mods and isinstance(mods[n], torch.nn.Conv2d)]
+    with torch.no_grad():
+        want = ref({"depth": depth.double()}).float()
+    for h in hooks:
+        h.remove()
+    lines, worst = [], 0.0
+    convs = [(i, o, n) for i, (o, n) in enumerate(zip(plan.prog.ops, plan.prog.names)) if o["kind"] == 0]
+    for depth_i, (i, op, name) in enumerate(convs):
+        r = raw[name]                                 # (2, Cout, Ho, Wo) float64
+        n = r[0].numel()
+        for img in range(2):
+            base = img * plan.arena_stride + op["dst_off"]
+            got = sum(arena[base + z * op["dst_slab_stride"]: base + z * op["dst_slab_stride"] + n] for z in range(op["kwg"]))
+            err = float((got.double() - r[img].reshape(-1)).abs().max() / r[img].abs().max())
+            budget = 1.2e-5 * (depth_i + 8) / (len(convs) + 8)  # measured: 3e-7 at the stem, at most 3.8e-6 (layer 3), 2e-6 at the end
+            lines.append(f"{i:2d} {name:32s} image {img}: rel err {err:.2e} (budget {budget:.2e})")
+            assert err <= budget, lines[-1]
+            worst = max(worst, err)
+    os.makedirs("gpurun_out", exist_ok=True)
+    open("gpurun_out/depth_net_layer_errors.log", "w").write("\n".join(lines) + "\n")
+    e = float((feats - want).abs().max())
+    print(f"per-layer worst relative error {worst:.2e}; features {e:.2e}")
+    assert e < 1e-4
