@@ -705,7 +705,11 @@ def conv_gn(x, w, gn, stride=1, pad=0, relu=False, residual=None, ds=None, out=N
 #       (beside the mapper / map-CNN graph the persistent workgroups hold their CUs - 512 threads x 218 VGPRs, ~105 KB LDS -
 #       so at 4 images the other graph is squeezed onto the remaining XCDs: 0.81 vs 0.72 ms per step; at 8: 0.90 vs 0.91);
 #   "2" always (<= 8 images); "0" never.
-DEPTH_NET = int(os.environ.get("IVLN_DEPTH_NET", "1"))
+# The persistent launch spins on its own workgroups' arrivals: all 32 workgroups of a cluster have to be resident, which
+# the residency check guarantees only when this process has the GPU to itself.  Two processes on one device (the one-device
+# multi-rank smoke tests: IVLN_ONE_DEVICE / IVLN_BENCH_ONE_DEVICE) could each get half of the CUs and time each other out,
+# so the default there is the launch chain; set IVLN_DEPTH_NET=0 for any other shared-GPU deployment.
+DEPTH_NET = int(os.environ.get("IVLN_DEPTH_NET", "0" if (os.environ.get("IVLN_ONE_DEVICE") or os.environ.get("IVLN_BENCH_ONE_DEVICE")) else "1"))
 DEPTH_NET_SPLIT_MIN = int(os.environ.get("IVLN_DEPTH_NET_SPLIT_MIN", "6"))
 CHAIN_GN_CONV = os.environ.get("IVLN_GN_CONV", "1") != "0"
 # The chain trades launches for slab bytes (16 partial slabs per conv), which pays while the step is latency-bound:
