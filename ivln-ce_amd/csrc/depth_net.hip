@@ -228,7 +228,7 @@ __global__ __launch_bounds__(NT, DEPTH_NET_MIN_BLOCKS) void k_depth_net(const Op
                                                   const float* __restrict__ depth,
                                                   int64_t depth_img_stride, float* __restrict__ arena, int64_t arena_stride,
                                                   float* __restrict__ out, int64_t out_img_stride, int N, float eps,
-                                                  unsigned* __restrict__ sy, const Lds L) {
+                                                  unsigned* __restrict__ sy, const Lds L, int allow_plain) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int cluster = blockIdx.x & 7, rank = blockIdx.x >> 3;
     if (cluster >= N) return;
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(NT, DEPTH_NET_MIN_BLOCKS) void k_depth_net(const Op
             }
             if (!plain && arrivals == 1) {  // first barrier passed: every workgroup of the cluster has reported its XCC
                 const unsigned m = __hip_atomic_load(&sy[cluster * 32 + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                plain = __builtin_popcount(m) == 1;
+                plain = allow_plain && __builtin_popcount(m) == 1;
             }
         }
         DN_STAMP(1);
@@ -731,13 +731,15 @@ int ivln_depth_net_f32(const ivln_depthnet_op* ops_dev, const ivln_depthnet_op* 
             resident = per_cu * cus;
         }
     }
-    if (resident < 8 * CL) return IVLN_E_UNSUPPORTED;  // the clusters spin on each other's arrivals: all of them resident, or none
+    if (resident < 8 * CL) return IVLN_E_UNSUPPORTED;
+    // (the clusters spin on each other's arrivals: all of them resident, or none)
+    static const int allow_plain = getenv("IVLN_DEPTH_NET_WRITE_THROUGH") ? 0 : 1;  // A/B switch: write-through stores only (519 -> 545 us)
 #ifdef DEPTH_NET_TIMING
     hipLaunchKernelGGL(k_depth_net, dim3(8 * CL), dim3(NT), lds, (hipStream_t)stream, ops_dev, n_ops, weights, params, depth,
-                       depth_img_stride, arena, arena_stride, out, out_img_stride, N, eps, (unsigned*)sync_ws, L);
+                       depth_img_stride, arena, arena_stride, out, out_img_stride, N, eps, (unsigned*)sync_ws, L, allow_plain);
 #else
     IVLN_LAUNCH_FAMILY(k_depth_net, dim3(8 * CL), dim3(NT), lds, (hipStream_t)stream, ops_dev, n_ops, weights, params, depth,
-                       depth_img_stride, arena, arena_stride, out, out_img_stride, N, eps, (unsigned*)sync_ws, L);
+                       depth_img_stride, arena, arena_stride, out, out_img_stride, N, eps, (unsigned*)sync_ws, L, allow_plain);
 #endif
     return hipGetLastError() == hipSuccess ? IVLN_OK : IVLN_E_HIP;
 }

@@ -144,7 +144,7 @@ class GraphedRollout:
     def _capture_split(self, warmup):
         dev = self.device
         net = self.policy.net
-        self.sA = _stream(dev, "depth", priority=-1)  # the critical chain wins dispatch when both queues are ready
+        self.sA = _stream(dev, "depth", priority=int(os.environ.get("IVLN_DEPTH_STREAM_PRIORITY", "-1")))  # the critical chain wins dispatch when both queues are ready
         self.ev_in, self.ev_A = torch.cuda.Event(), torch.cuda.Event()
         main = torch.cuda.current_stream()
 
