@@ -436,6 +436,14 @@ int ivln_embed_gates_f32(const int64_t* tokens, const float* table, const uint8_
 int ivln_lstm_bidir_fwd_f32(const float* gx_f, const float* gx_r, const float* whh_f, const float* whh_r,
                             const float* bhh_f, const float* bhh_r, const int* lengths, int B, int L, int H,
                             float* out, float* save_gates, float* save_c, void* stream);
+/* The same recurrence launched with 2B * spare blocks for its 2B (sequence, direction) items: a block takes the next item
+ * when it STARTS (atomic ticket in *ticket, a zeroed u32 the caller owns; the last block re-arms it), blocks past 2B
+ * leave.  For a replay beside a kernel that saturates some XCDs (ivln_depth_net_f32 with fewer than 8 images): the blocks on
+ * the free XCDs do all the work instead of half of it waiting for the neighbour to end.  Same results as the plain entry
+ * point for every item; spare 1..8; one launch in flight per ticket word. */
+int ivln_lstm_bidir_fwd_spread_f32(const float* gx_f, const float* gx_r, const float* whh_f, const float* whh_r,
+                                   const float* bhh_f, const float* bhh_r, const int* lengths, int B, int L, int H,
+                                   float* out, float* save_gates, float* save_c, unsigned* ticket, int spare, void* stream);
 /* The two consumers of an encoder's feature map in the MapCMA head in ONE launch (models/map_cma_policy.py:156-171,
  * 180-185, 276-296): feat (rows, C, P) contiguous ->  kv (rows, Ckv, P) = nn.Conv1d(C, Ckv, 1)  and
  * lin[r*ld_lin + o] = act(nn.Linear(C*P, O) of the flattened row).  rows <= 8 and rows*C*P*4 B <= 150 KB of LDS,

@@ -45,7 +45,7 @@ constexpr int NT = 512;   // threads per workgroup
 constexpr int CL = 32;    // workgroups per image
 constexpr unsigned SPIN_MAX = 1u << 22;
 #ifndef DEPTH_NET_MIN_BLOCKS
-#define DEPTH_NET_MIN_BLOCKS 1
+#define DEPTH_NET_MIN_BLOCKS 3  // minimum waves per SIMD the register allocation must allow (3 -> at most 170 VGPRs)
 #endif
 #ifndef DEPTH_NET_LOCAL_ATOMICS
 #define DEPTH_NET_LOCAL_ATOMICS 1
@@ -166,7 +166,17 @@ __device__ __forceinline__ void cluster_arrive(unsigned* sy, int cluster, bool l
 //      meet zero weights).  One generic body for 1x1 / 3x3 / the 7x7 stem: the kernel is instruction-fetch bound when
 //      every kernel size and every chunk has code of its own (first version: 57 KB of code, 140 instructions per chunk).
 constexpr int MAXCH = 18;  // chunks (of 4 k-steps) per wave and op: 72 k-steps (the 3x3 convs of layer 4, the compression conv)
-constexpr int ADEPTH = 8;  // weight chunks in flight per wave
+// Register diet (round 4, measured): 8 weight chunks + 4 input float4s in flight cost 218 VGPRs - two waves per SIMD then
+// leave 76 registers per lane, and the first kernel of the neighbouring graph that needs more (the map CNN's convs: 137-189)
+// waits for this launch to END.  4 + 2 in flight under __launch_bounds__(512, 3) are 150 VGPRs without a spill: 212 left.
+#ifndef DEPTH_NET_ADEPTH
+#define DEPTH_NET_ADEPTH 4
+#endif
+#ifndef DEPTH_NET_SB
+#define DEPTH_NET_SB 2
+#endif
+constexpr int ADEPTH = DEPTH_NET_ADEPTH;  // weight chunks in flight per wave
+constexpr int SB = DEPTH_NET_SB;          // input float4s in flight per thread while staging
 
 template <int P>
 struct MmaState {
@@ -321,11 +331,11 @@ __global__ __launch_bounds__(NT, DEPTH_NET_MIN_BLOCKS) void k_depth_net(const Op
         const int W4 = Win >> 2, per_c = Rs * W4, total = general ? c_n * per_c : 0;
         const fdiv by_pc(per_c), by_w4(W4);
         const bool wr_act = op.act_out_off >= 0 && ctg == 0 && kwg_i == 0;
-        float4 xv[4], yv[4];  // yv: the second operand - the downsample branch's raw output OR the identity (never both)
+        float4 xv[SB], yv[SB];  // yv: the second operand - the downsample branch's raw output OR the identity (never both)
         const int off2 = two ? op.src2_off : op.res_off;
         auto load_batch = [&](int i0, bool first_op, bool second_op) {  // four elements per thread, all their loads in flight together
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < SB; ++e) {
                 const int i = min(i0 + e * NT, total - 1);
                 const int cl = by_pc(i), c = c_lo + cl, rem = i - cl * per_c, r = by_w4(rem), x4 = rem - r * W4;
                 const int iy = sub ? 2 * (oy0 + r) : iy0 + r;
@@ -510,10 +520,10 @@ __global__ __launch_bounds__(NT, DEPTH_NET_MIN_BLOCKS) void k_depth_net(const Op
                     tile[c * CS + r * Wp + pad + x] = m;
                 }
             } else {
-                for (int i0 = tid; i0 < total; i0 += NT * 4) {
+                for (int i0 = tid; i0 < total; i0 += NT * SB) {
                     if (i0 != tid) load_batch(i0, true, true);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
+                    for (int e = 0; e < SB; ++e) {
                         if (i0 + e * NT < total) {
                             const int i = i0 + e * NT;  // (indices recomputed: cheaper than 12 live registers)
                             const int cl = by_pc(i), c = c_lo + cl, rem = i - cl * per_c, r = by_w4(rem), x4 = rem - r * W4;

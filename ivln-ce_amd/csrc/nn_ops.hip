@@ -628,8 +628,25 @@ __global__ __launch_bounds__(4 * H) void k_lstm_bidir(const float* __restrict__ 
                                                       const float* __restrict__ bhh_r,
                                                       const int* __restrict__ lengths, int L,
                                                       float* __restrict__ out, float* __restrict__ save_gates,
-                                                      float* __restrict__ save_c) {
+                                                      float* __restrict__ save_c, int B, unsigned* __restrict__ ticket) {
     constexpr int G = 4 * H;
+    // Which (sequence, direction) this block runs: its index, or - with `ticket` - the order in which the blocks START.
+    // The launcher then over-subscribes the grid (2B * spare blocks for 2B items): beside a kernel that fills some XCDs
+    // (the persistent depth encoder; this kernel's 340 registers per SIMD lane do not fit next to it) the blocks the
+    // dispatcher handed to the free XCDs start first and take all the work, the others start when the neighbour ends and
+    // leave at once.  The block that draws the last ticket re-arms the counter for the next launch.
+    __shared__ int s_item;
+    int item = blockIdx.x;
+    if (ticket) {
+        if (threadIdx.x == 0) {
+            const unsigned t = atomicAdd(ticket, 1u);
+            if (t == gridDim.x - 1) atomicExch(ticket, 0u);
+            s_item = (int)t;
+        }
+        __syncthreads();
+        item = s_item;
+        if (item >= 2 * B) return;
+    }
     // Quad j (threads 4j..4j+3) owns hidden unit j: lane q multiplies the 4 gate rows {i,f,g,o} of unit j
     // with ITS quarter of h (a 4 x H/4 block of W_hh = H weights in registers), the quad adds the partial
     // sums by DPP, lane q activates gate q, the quad exchanges the four activations by DPP and every lane
@@ -638,7 +655,7 @@ __global__ __launch_bounds__(4 * H) void k_lstm_bidir(const float* __restrict__ 
     // barrier (h for the next step).
     constexpr int HQ = H / 4, HQP = HQ + 4;  // +4 words per quarter: the 4 quarters hit different banks
     __shared__ __attribute__((aligned(16))) float hs[2][4 * HQP];  // double-buffered: one barrier per step
-    const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
+    const int b = item % B, dir = item / B, tid = threadIdx.x;
     const int q = tid & 3, j = tid >> 2;
     const int g = q * H + j;  // this lane's gate row (PyTorch order i,f,g,o)
     const float* gx = (dir == 0 ? gx_f : gx_r) + (int64_t)b * L * G;
@@ -1525,9 +1542,17 @@ int ivln_embed_gates_f32(const int64_t* tokens, const float* table, const uint8_
 int ivln_lstm_bidir_fwd_f32(const float* gx_f, const float* gx_r, const float* whh_f, const float* whh_r,
                             const float* bhh_f, const float* bhh_r, const int* lengths, int B, int L, int H,
                             float* out, float* save_gates, float* save_c, void* stream) {
+    return ivln_lstm_bidir_fwd_spread_f32(gx_f, gx_r, whh_f, whh_r, bhh_f, bhh_r, lengths, B, L, H, out, save_gates, save_c,
+                                          nullptr, 1, stream);
+}
+
+int ivln_lstm_bidir_fwd_spread_f32(const float* gx_f, const float* gx_r, const float* whh_f, const float* whh_r,
+                                   const float* bhh_f, const float* bhh_r, const int* lengths, int B, int L, int H,
+                                   float* out, float* save_gates, float* save_c, unsigned* ticket, int spare, void* stream) {
     if (H != 128) return IVLN_E_UNSUPPORTED;
-    hipLaunchKernelGGL((k_lstm_bidir<128>), dim3(B, 2), dim3(512), 0, (hipStream_t)stream, gx_f, gx_r, whh_f, whh_r,
-                       bhh_f, bhh_r, lengths, L, out, save_gates, save_c);
+    if (B <= 0 || spare < 1 || spare > 8 || (spare > 1 && !ticket)) return IVLN_E_INVALID;
+    hipLaunchKernelGGL((k_lstm_bidir<128>), dim3(2 * B * (ticket ? spare : 1)), dim3(512), 0, (hipStream_t)stream, gx_f, gx_r,
+                       whh_f, whh_r, bhh_f, bhh_r, lengths, L, out, save_gates, save_c, B, ticket);
     return LAUNCH_OK();
 }
 

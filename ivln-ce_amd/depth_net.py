@@ -181,8 +181,11 @@ def _conv_op(prog, w, stride, pad, Hin, Win, src, barrier, allow_kwg=False, pool
     wp = Wout if sub else Win + 2 * pad
     cs = Rs * wp
     if ks != 7:
-        while cs % 32 != 16:  # k slots of an MFMA step (4 channels) land on different LDS banks
-            cs += 1
+        if ks == 3 and stride == 2:
+            cs = (cs + 3) // 4 * 4  # (the largest tiles of the program - 256 channels x 9 x 10 at layer 4: bank spread given up for 18 KB)
+        else:
+            while cs % 32 != 16:  # k slots of an MFMA step (4 channels) land on different LDS banks
+                cs += 1
     rows_t = t["WCT"] * t["M"]
     cpo = Cout // 16
     st_out_parts = t["n_ptg"] * max(1, cpo // rows_t) if t["kwg"] == 1 else 0

@@ -188,7 +188,7 @@ class InstructionEncoder(nn.Module):
             gx_r = ops.linear_gemm(emb, rnn.weight_ih_l0_reverse, rnn.bias_ih_l0_reverse)
         out, gates, cs = ops.lstm_bidir(
             gx_f, gx_r, rnn.weight_hh_l0, rnn.weight_hh_l0_reverse, rnn.bias_hh_l0, rnn.bias_hh_l0_reverse, lengths,
-            B, L, H, save=save is not None,
+            B, L, H, save=save is not None, spare=getattr(self, "lstm_spare", 1), ticket=getattr(self, "lstm_ticket", None),
         )
         if save is not None:
             save.update(emb=emb, lengths=lengths, gates=gates, cs=cs, out=out, tokens=tokens)

@@ -207,6 +207,18 @@ class GraphedRollout:
             venc.latency_bound = not predicted
             venc.beside_other_work = True  # (its graph replays beside the mapper / map-CNN graph: ops.DEPTH_NET's policy)
         net._txt_with_dep = predicted  # ... and the instruction encoder leaves RedNet's stream for the side graph
+        net._txt_last = os.environ.get("IVLN_TXT_LAST", "1") != "0"
+        # ... and with fewer than 8 images some XCDs stay free of it: the bi-LSTM's blocks that land there take all the work
+        # (ops.lstm_bidir spare) instead of half of them waiting for the depth encoder to end
+        ienc = net.instruction_encoder
+        # (2B * spare blocks so that 2B of them land on the 8 - B free XCDs; measured at 4 and 5 images: 667 -> 620 us per
+        #  step; at 6 and 7 - spare 4 and 8 - the recurrence still started only when the depth encoder ended: left alone)
+        spare = int(os.environ.get("IVLN_LSTM_SPARE", str(2 if B <= 4 else 3 if B == 5 else 1)))
+        if not predicted and os.environ.get("IVLN_TXT_FIRST", "0") == "1":
+            net._txt_with_dep = "first"
+        if net._txt_last and not predicted and spare > 1 and B < 8:
+            ienc.lstm_ticket = torch.zeros((1,), dtype=torch.int32, device=dev)
+            ienc.lstm_spare = spare
         s = _stream(dev, "warmup")
         s.wait_stream(main)
         with torch.cuda.stream(s):  # warm-up: tables, workspaces (per stream), folded weights
@@ -253,6 +265,7 @@ class GraphedRollout:
         self.phase = 0
         if venc is not None:
             venc.beside_other_work = False  # (the captured launches are what they are; eager calls decide for themselves)
+        ienc.lstm_spare = 1  # (the ticket word stays with the module: the captured launches hold its address)
 
     def _replay_split(self):
         main = torch.cuda.current_stream()

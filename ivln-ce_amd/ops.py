@@ -700,17 +700,22 @@ def conv_gn(x, w, gn, stride=1, pad=0, relu=False, residual=None, ds=None, out=N
 # conv + GroupNorm pairs
 # the whole depth encoder of a rollout batch (<= 8 images) as ONE persistent launch (csrc/depth_net.hip); 0: the per-layer
 # launch chain below (A/B switch, and what runs where the persistent grid cannot be resident)
-#   "1" (default) where it measured faster: eager / single-stream execution at <= 8 images (one launch instead of 54:
-#       526 vs 565 us of GPU time, and no 54 host enqueues), and inside the split replay from DEPTH_NET_SPLIT_MIN images
-#       (beside the mapper / map-CNN graph the persistent workgroups hold their CUs - 512 threads x 218 VGPRs, ~105 KB LDS -
-#       so at 4 images the other graph is squeezed onto the remaining XCDs: 0.81 vs 0.72 ms per step; at 8: 0.90 vs 0.91);
+#   "1" (default): whenever the encoder is the latency-bound part of the step and the batch is <= 8 images - eager and
+#       single-stream execution (one launch instead of 54: 512 vs 565 us of GPU time and no 54 host enqueues) and the split
+#       replay (600-620 us per step at 1-5 envs against 640-715 for the chain, 743 against 811 at 8).  Beside the mapper /
+#       map-CNN graph the persistent workgroups hold their CUs: with 218 VGPRs (two waves per SIMD leave 76 registers per
+#       lane) the first neighbour kernel that needed more waited for this launch to end and the replay LOST (0.81 vs 0.72
+#       ms at 4 envs); at 150 VGPRs and 117 KB of LDS the map CNN's convs fit beside it, the bi-LSTM (340 registers per
+#       SIMD lane, fits beside nothing) is ordered last in its graph and, below 6 images, drawn by the blocks that land on
+#       the free XCDs (lstm_bidir spare);  IVLN_DEPTH_NET_SPLIT_MIN raises the image count from which the split replay
+#       takes it (A/B);
 #   "2" always (<= 8 images); "0" never.
 # The persistent launch spins on its own workgroups' arrivals: all 32 workgroups of a cluster have to be resident, which
 # the residency check guarantees only when this process has the GPU to itself.  Two processes on one device (the one-device
 # multi-rank smoke tests: IVLN_ONE_DEVICE / IVLN_BENCH_ONE_DEVICE) could each get half of the CUs and time each other out,
 # so the default there is the launch chain; set IVLN_DEPTH_NET=0 for any other shared-GPU deployment.
 DEPTH_NET = int(os.environ.get("IVLN_DEPTH_NET", "0" if (os.environ.get("IVLN_ONE_DEVICE") or os.environ.get("IVLN_BENCH_ONE_DEVICE")) else "1"))
-DEPTH_NET_SPLIT_MIN = int(os.environ.get("IVLN_DEPTH_NET_SPLIT_MIN", "6"))
+DEPTH_NET_SPLIT_MIN = int(os.environ.get("IVLN_DEPTH_NET_SPLIT_MIN", "1"))
 CHAIN_GN_CONV = os.environ.get("IVLN_GN_CONV", "1") != "0"
 # The chain trades launches for slab bytes (16 partial slabs per conv), which pays while the step is latency-bound:
 # measured 4 envs 5.1 K vs 4.0 K env-steps/s, 8 envs 7.5 K vs 6.9 K, but 16 envs 9.5 K vs 10.1 K and 32 envs 11.1 K vs
@@ -1049,8 +1054,20 @@ def embed_gates(tokens_i64, table, row_nonzero):
     return gx_f, gx_r, lengths
 
 
-def lstm_bidir(gx_f, gx_r, whh_f, whh_r, bhh_f, bhh_r, lengths, B, L, H, save=False):
+def lstm_bidir(gx_f, gx_r, whh_f, whh_r, bhh_f, bhh_r, lengths, B, L, H, save=False, spare=1, ticket=None):
+    """spare > 1: ivln_lstm_bidir_fwd_spread_f32 - 2B * spare blocks draw the 2B items in the order they start (for a
+    replay beside a launch that fills some XCDs).  ticket: the caller's zeroed int32 word (one launch in flight per word)."""
     out = torch.empty((B, 2 * H, L), dtype=torch.float32, device=gx_f.device)
+    if spare > 1 and not save:
+        tk = ticket
+        if tk is None or tk.dtype != torch.int32 or tk.device != gx_f.device:
+            raise ValueError("lstm_bidir(spare>1) needs the caller's int32 ticket word on the same device")
+        Lb = _L()
+        Lb.ivln_lstm_bidir_fwd_spread_f32.argtypes = [vp] * 7 + [i32, i32, i32, vp, vp, vp, vp, i32, vp]
+        check(Lb.ivln_lstm_bidir_fwd_spread_f32(dptr(gx_f), dptr(gx_r), dptr(whh_f), dptr(whh_r), dptr(bhh_f), dptr(bhh_r),
+                                                dptr(lengths), B, L, H, dptr(out), None, None, dptr(tk), int(spare),
+                                                stream_ptr()), "ivln_lstm_bidir_fwd_spread_f32")
+        return out, None, None
     gates = cs = None
     if save:
         gates = torch.zeros((B, 2, L, 4 * H), dtype=torch.float32, device=gx_f.device)

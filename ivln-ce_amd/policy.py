@@ -295,16 +295,25 @@ class MapCMANet(Net):
         if stage == "dep":
             # graphed.py, split mode: depth ResNet + its k/v projection + depth_linear as one graph on a side
             # stream (they depend on nothing but the new depth image); results land in the persistent buffers
+            if getattr(self, "_txt_with_dep", False) == "first":
+                # 8 images: the persistent depth encoder leaves no XCD for the bi-LSTM, which then runs in front of it
+                self._stash_txt = _txt_branch(None)
             self._stash_dep = _dep_branch()
-            if getattr(self, "_txt_with_dep", False):
+            if getattr(self, "_txt_with_dep", False) is True:
                 # predicted semantics: the main stream is RedNet's critical path, the instruction encoder moves here
                 self._stash_txt = _txt_branch(None)
             return None, None
         if stage == "pre":
             # ... while the instruction and map branches (and the previous-action embedding) run as a second
             # graph on the main stream
-            txt, lengths, tk = self._stash_txt if getattr(self, "_txt_with_dep", False) else _txt_branch(None)
+            # (order: when the persistent depth encoder is the neighbour, the bi-LSTM - 340 registers per SIMD lane - cannot
+            #  be scheduled before that launch ends; last in this graph it delays nothing else - graphed.py sets _txt_last)
+            last = getattr(self, "_txt_last", False) and not getattr(self, "_txt_with_dep", False)
+            if not last:
+                txt, lengths, tk = self._stash_txt if getattr(self, "_txt_with_dep", False) else _txt_branch(None)
             mp, mkv = _map_branch(None)
+            if last:
+                txt, lengths, tk = _txt_branch(None)
             ops.prev_action_embed(prev_actions, masks_u8, self.prev_action_embedding.weight,
                                   state_in[:, d_out + m_out:], x2[:, o_prev:])
             self._stash = dict(txt=(txt, lengths, tk), map=(mp, mkv))

@@ -40,10 +40,11 @@ def pytest_sessionstart(session):
 
 @pytest.fixture
 def same_depth_path():
-    """Tests that demand BIT-identical results from a captured replay and from eager execution pin the depth encoder to
-    ONE implementation for both: by default (ops.DEPTH_NET = 1) eager and single-stream execution take the persistent
-    launch (csrc/depth_net.hip) while the split replay below DEPTH_NET_SPLIT_MIN images keeps the launch chain - the same
-    arithmetic in a different summation order (1e-5 apart).  Yields a function that sets the mode; restored afterwards."""
+    """Tests that demand BIT-identical results from two executions of the depth encoder pin it to ONE implementation for
+    both: the persistent launch (csrc/depth_net.hip, the default up to 8 images where the encoder is latency-bound) and
+    the launch chain are the same arithmetic in a different summation order (1e-5 apart), and which of them runs depends
+    on batch size, IVLN_DEPTH_NET_SPLIT_MIN and whether semantics are predicted.  Yields a function that sets the mode;
+    restored afterwards."""
     from ivln_ce_amd import ops
 
     old = ops.DEPTH_NET

@@ -57,7 +57,7 @@ def test_program_covers_the_network_and_fits_the_cluster():
         assert o["n_ctg"] * o["WCT"] * o["M"] == o["Cout"]
         assert o["n_ptg"] * o["WPT"] * o["P"] * 16 == (1 << (2 * o["wout_shift"]))
         assert o["st_parts"] <= 32 and o["st_out_parts"] <= 32
-        if o["ks"] != 7:
+        if o["ks"] != 7 and not (o["ks"] == 3 and o["stride"] == 2):
             assert o["cs"] % 32 == 16
     # algorithmic work: SURVEY 8d's 0.699 GFLOP per image for the depth encoder
     assert abs(prog.flops_per_image / 1e9 - 0.699) < 0.005, prog.flops_per_image

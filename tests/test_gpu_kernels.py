@@ -171,6 +171,18 @@ def test_lstm_bidir_matches_packed_torch_lstm():
     out, _, _ = ops.lstm_bidir(gx_f, gx_r, p["weight_hh_l0"], p["weight_hh_l0_reverse"], p["bias_hh_l0"],
                                p["bias_hh_l0_reverse"], lengths, B, L, H)
     _close(out, ref, 2e-5)
+    # the over-subscribed launch (blocks draw their item when they start): the same bits for every item, whichever
+    # block ran it, and the ticket word re-armed after each launch
+    ticket = torch.zeros((1,), dtype=torch.int32, device=DEV)
+    for spare in (2, 3, 8):
+        for _ in range(3):
+            o2, _, _ = ops.lstm_bidir(gx_f, gx_r, p["weight_hh_l0"], p["weight_hh_l0_reverse"], p["bias_hh_l0"],
+                                      p["bias_hh_l0_reverse"], lengths, B, L, H, spare=spare, ticket=ticket)
+            assert torch.equal(o2, out)
+            assert int(ticket.item()) == 0
+    with pytest.raises(ValueError):
+        ops.lstm_bidir(gx_f, gx_r, p["weight_hh_l0"], p["weight_hh_l0_reverse"], p["bias_hh_l0"], p["bias_hh_l0_reverse"],
+                       lengths, B, L, H, spare=2)
 
 
 @pytest.mark.parametrize("rows,I", [(3, 416), (8, 512), (11, 416)])
