@@ -21,6 +21,14 @@ timeout 100 tools/graph_eager_repro > $O/graph_eager_repro.txt 2>&1
 timeout 200 python tools/depth_net_phases.py 4 > $O/depth_net_phases_N4.txt 2>&1
 timeout 100 python tools/depth_net_phases.py 8 2>&1 | grep "per launch\|sum of" > $O/depth_net_phases_N8.txt
 timeout 600 python bench.py > $O/bench_full.json 2> $O/bench_full.err
+timeout 300 python bench.py --gt-semantics --envs 8 --no-update --no-collect --no-pred-leg --no-cpu-baseline > $O/bench_gt_B8.json 2> $O/bench_gt_B8.err
+IVLN_REDNET_PLAN=0 timeout 200 python tools/gemm_shapes.py rednet > $O/rednet_B8_gemm_shapes.txt 2>&1
+# where the split replay's time goes (end of each graph, per step), default build and the launch chain it replaced
+for B in 4 8; do
+  for m in 1 0; do echo "== envs $B IVLN_DEPTH_NET=$m"; IVLN_DEPTH_NET=$m timeout 200 python tools/split_probe.py gt $B 2>&1 | tail -2; done
+  echo "== envs $B IVLN_TXT_LAST=0 (bi-LSTM in front of the map branch)"; IVLN_TXT_LAST=0 timeout 200 python tools/split_probe.py gt $B 2>&1 | tail -2
+  echo "== envs $B IVLN_LSTM_SPARE=1 (no over-subscribed bi-LSTM grid)"; IVLN_LSTM_SPARE=1 timeout 200 python tools/split_probe.py gt $B 2>&1 | tail -2
+done > $O/split_probe.txt 2>&1
 # --- kernel traces ---
 run predsem --kernel-trace -d $O/predsem -- python3 bench.py --steps 50 --warmup 5 --reps 1 $PRED;               stats predsem predsem_B8_graph_kernel_stats.csv
 run graph   --kernel-trace -d $O/graph   -- python3 bench.py --steps 200 --warmup 20 --reps 1 $GT;               stats graph rollout_graph_kernel_stats.csv
