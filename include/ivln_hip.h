@@ -153,7 +153,8 @@ typedef struct ivln_gemm_desc {
      * 1..5 force the scalar-gather kernel with block tile 64x64 / 32x128 / 128x32 / 128x128 / 64x128;
      * 6 insist on the LDS-patch direct conv / weight-gradient kernels (conv_direct.hip);
      * 7 insist on the float4-staged GEMM (gemm_vec.hip); 8 insist on the streaming short-K 1x1 conv
-     * (conv1x1_stream.hip: K = 64 / 128 / 256, NCHW, whole 128-pixel strips).  6/7/8 return IVLN_E_UNSUPPORTED when
+     * (conv1x1_stream.hip: K = 64 / 128 / 256, NCHW, whole 128-pixel strips); 9 insist on the split-bf16 direct conv
+     * (conv_bf3.hip, needs A_split).  6/7/8/9 return IVLN_E_UNSUPPORTED when
      * the shape is not eligible (tuning, tests). */
     int tile_override;
     /* optional (stride-1 3x3 / 7x7 / 2x2 convs): the weights pre-arranged by ivln_conv_pack_weights_f32; when set and
@@ -185,9 +186,23 @@ typedef struct ivln_gemm_desc {
      * by ivln_bn_stats_from_partials_f32. */
     float* stat_partials;
     int* stat_tiles;
+    /* optional (stride-1 same-size 3x3 / 7x7 convs into an NCHW destination, Wout a multiple of 4 and >= 8): the weights
+     * split into three bf16 pieces per value and arranged per MFMA lane by ivln_conv_split_weights_f32
+     * (ivln_conv_split_words(M, Cin, KS) 4-byte words per weight set; a_split_grp_stride = words between the sets of an
+     * image-grouped conv).  When set and the shape fills the chip, the conv runs on the bf16 MFMA pipe with BOTH operands
+     * carried as three bf16 pieces (exact) and six of the nine piece products accumulated in fp32: the dropped ones are
+     * below 2^-23 of a product, i.e. the result is as close to the exact convolution as the fp32 MFMA kernel's
+     * (csrc/conv_bf3.hip).  tile_override 9 insists on this kernel (IVLN_E_UNSUPPORTED when not eligible);
+     * IVLN_NO_SPLIT_BF16 in the environment keeps the fp32 MFMA kernels (A/B).  A must still be given. */
+    const void* A_split;
+    int64_t a_split_grp_stride;
 } ivln_gemm_desc;
 
 int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream);
+/* Weights (M, Cin, KS, KS) fp32 -> the split-bf16 image ivln_gemm_desc.A_split expects: out holds
+ * ivln_conv_split_words(M, Cin, KS) 4-byte words (0: KS is not 3 or 7). */
+int64_t ivln_conv_split_words(int M, int Cin, int KS);
+int ivln_conv_split_weights_f32(const float* W, int M, int Cin, int KS, void* out, void* stream);
 
 /* Duration sink of the MFMA family's launches (ivln_gemm_f32 - its split-K reduction excluded -, ivln_gn_conv_f32,
  * ivln_nconv_f32, ivln_conv_gn_f32): between _begin and _end every such launch carries a start / stop event of its own

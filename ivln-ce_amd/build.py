@@ -16,6 +16,7 @@ SOURCES = {
     "conv_direct.hip": [],
     "gemm_vec.hip": [],
     "conv1x1_stream.hip": [],
+    "conv_bf3.hip": [],
     "conv_gn.hip": [],
     "gn_conv.hip": [],
     "depth_net.hip": [],

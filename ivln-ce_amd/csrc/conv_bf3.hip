@@ -1,0 +1,458 @@
+// Direct stride-1 3x3 / 7x7 convolution with fp32 operands carried as THREE bf16 pieces each, on the bf16 MFMA pipe
+// (gfx950: v_mfma_f32_32x32x16_bf16 issues 16x the FLOPs of v_mfma_f32_32x32x2_f32 per cycle).
+//
+//   x = x1 + x2 + x3: x1 = bf16(x) (round to nearest even), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2); the remainders are
+//   exact in fp32, |x2| <= 2^-8 |x|, |x3| <= 2^-16 |x|, and what the three pieces miss is below 2^-25 |x| - an fp32
+//   significand is 24 bits, bf16 has fp32's exponent range (below 2^-110 the last piece runs out of exponent; infinities
+//   and NaNs travel in x1 alone: a non-finite input never gives a finite output, but an infinity can come out as NaN).
+//   a * b = (a1 + a2 + a3)(b1 + b2 + b3): of the nine piece products the kernel issues the six of relative size >= 2^-16 -
+//   a1b1, a1b2, a2b1, a1b3, a2b2, a3b1 - each exact in the MFMA (8 x 8 significand bits) and accumulated in fp32 like
+//   the fp32 MFMA accumulates its products; the three it drops (a2b3, a3b2 <= 2^-24 |a b| each, a3b3) sum to less than
+//   2^-23 |a b| - the size of fp32's own rounding of the product.  Measured against float64 the result is as close as the
+//   fp32 MFMA kernel's (tests/test_gpu_kernels.py: both within the same bar, error tables in DESIGN.md section 3).
+//   Six bf16 MFMAs of K = 16 replace eight fp32 MFMAs of K = 2: 192 instead of 512 pipe cycles per 16 channels x 1 tap.
+//
+// Users: the map CNN's four 7x7 convs and their input gradients (map_encoder.py:8-97 under base_il_trainer.py:173-219),
+// RedNet's 3x3 convs (rednet.py:190-358).  Data flow per workgroup (512 threads = 8 waves, 2 per SIMD):
+//   * tile = BM output channels x BN output pixels (IMGS images x PTH x PTW), waves WM x WN, wave tile (32 TM) x 64;
+//   * the input patch of 16 channels is staged ONCE per chunk in LDS, already split, channel-last: a pixel is a 112-byte
+//     record [piece][16 channels] (28 words: the 16 lanes of a ds_read_b128 phase hit 16 distinct bank quads), so an
+//     operand fetch for tap (kh, kw) is `ds_read_b128 v, base offset:imm` with a per-lane base that never changes;
+//   * the weights arrive split and in the MFMA's per-lane order from ivln_conv_split_weights_f32 and stream global ->
+//     registers, DA taps ahead, through a buffer resource (loads through a plain pointer are sunk to their first use);
+//   * the next chunk's patch values fly under the MFMA phase (registers), are split and written after the barrier;
+//   * epilogue through LDS in slabs of 32 channels: 16-byte stores along the pixel index with the fused scale / shift /
+//     residual / ReLU of ivln_gemm_f32 and the per-(128-pixel segment, channel) Welford partials of stat_partials.
+#include <stdlib.h>
+
+#include "gemm_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+constexpr int NTB = 512;    // threads per workgroup
+constexpr int PIXB = 112;   // bytes per staged pixel: 3 pieces x 16 channels x 2 bytes + 16 of padding
+constexpr int CB = 16;      // input channels per chunk = K of one MFMA
+
+__host__ __device__ constexpr int bf3_taps_padded(int KS) { return KS == 7 ? 54 : 9; }  // multiple of every prefetch depth used (3, 6 | 3, 9)
+
+// x -> the upper 16 bits of its three pieces (see the header): round-to-nearest-even at each step, remainders exact.
+__device__ __forceinline__ uint32_t bf16_rne_bits(float v, bool& fin) {
+    const uint32_t u = __float_as_uint(v);
+    fin = (u & 0x7F800000u) != 0x7F800000u;
+    uint32_t hb = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+    if (fin && (hb & 0x7F800000u) == 0x7F800000u) hb = u & 0xFFFF0000u;  // (next to FLT_MAX: do not round a finite value to infinity)
+    if (!fin) hb = (u & 0xFFFF0000u) | ((u & 0x007FFFFFu) ? 0x00400000u : 0u);  // infinity as it is; a NaN stays a NaN
+    return hb;
+}
+__device__ __forceinline__ void split3(float x, uint32_t& h, uint32_t& m, uint32_t& l) {
+    bool fin, f2;
+    const uint32_t hb = bf16_rne_bits(x, fin);
+    const float r = fin ? __fsub_rn(x, __uint_as_float(hb)) : 0.f;  // (infinities and NaNs travel in the first piece alone)
+    const uint32_t mb = bf16_rne_bits(r, f2);
+    const float r2 = __fsub_rn(r, __uint_as_float(mb));
+    const uint32_t lb = bf16_rne_bits(r2, f2);
+    h = hb >> 16;
+    m = mb >> 16;
+    l = lb >> 16;
+}
+
+#ifdef BF3_TIMING  // tools/conv_bf3_phases.py: per-workgroup phase sums (100 MHz wall clock): prologue, staging, MFMA, epilogue
+__device__ unsigned long long g_bf3_stamp[8192 * 4];
+#define BF3_T() (threadIdx.x == 0 ? wall_clock64() : 0ull)
+#else
+#define BF3_T() 0ull
+#endif
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t bf3_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+
+template <int KS, int TM, int WM, int PTH, int PTW, int IMGS, int DA>
+__global__ __launch_bounds__(NTB) void k_conv_bf3(const ivln_gemm_desc p, const unsigned char* a_split, long long a_grp_bytes,
+                                                  int tiles_w, int tiles_h, int nimg) {
+    constexpr int WN = 8 / WM, TN = 2;
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    static_assert(IMGS * PTH * PTW == BN && PTW % 4 == 0, "pixel tile");
+    constexpr int KK = KS * KS, KKP = bf3_taps_padded(KS);
+    static_assert(KKP % DA == 0 && KKP >= KK, "prefetch rotation closes over a chunk");
+    constexpr int PH = PTH + KS - 1, PWR = PTW + KS - 1, NPIX = IMGS * PH * PWR;
+    constexpr int ITEMS = NPIX * (CB / 2), NPI = (ITEMS + NTB - 1) / NTB;
+    constexpr int LDT = BN + 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);  // (uniform: the weight stream's buffer resource lives in SGPRs)
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wm = wave / WN, wn = wave % WN;
+    const BlockId bid = xcd_block_id(p.no_xcd_remap);
+    const int bx = bid.x;
+    const int tw = bx % tiles_w, th = (bx / tiles_w) % tiles_h, ig = bx / (tiles_w * tiles_h);
+    const int img0 = ig * IMGS, ho0 = th * PTH, wo0 = tw * PTW;
+    const int m0 = bid.y * BM;
+    const int nch = (p.Cin + CB - 1) / CB;
+    const int HW = p.Hin * p.Win;
+    const int grp = p.grp_imgs > 0 ? img0 / p.grp_imgs : 0;
+
+    // patch items of this thread: (pixel, channel pair), consecutive threads on consecutive pixels of a row.  Offsets are
+    // RE-DERIVED per chunk (a dozen integer ops per item against ~600 MFMAs): kept in registers they cost 2 x NPI VGPRs that
+    // the operand double-buffering below needs (tt: an opaque copy of the thread id, so that the compiler does not hoist them)
+    auto item = [&](int tt, int i, int& cp, int& src, int& dst) {
+        const int idx = tt + i * NTB;
+        cp = idx / NPIX;
+        const int pix = idx - cp * NPIX;
+        const int il = pix / (PH * PWR), rem = pix - il * (PH * PWR);
+        const int y = rem / PWR, x = rem - y * PWR;
+        const int hi = ho0 - p.pad + y, wi = wo0 - p.pad + x, img = img0 + il;
+        const bool ok = idx < ITEMS && img < nimg && (unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win;
+        src = ok ? (int)((int64_t)img * p.in_img_stride + (int64_t)(2 * cp) * HW + hi * p.Win + wi) : -1;
+        dst = idx < ITEMS ? pix * PIXB + cp * 4 : -1;
+    };
+    float r0[NPI], r1[NPI];
+    auto load_patch = [&](int c) {
+        int tt = t;
+        asm volatile("" : "+v"(tt));
+        const int cbase = c * CB * HW;
+        const int left = p.Cin - c * CB;  // channels this chunk still has (ragged last chunk: the rest reads as zero)
+#pragma unroll
+        for (int i = 0; i < NPI; ++i) {
+            int cp, src, dst;
+            item(tt, i, cp, src, dst);
+            const bool ok0 = src >= 0 && 2 * cp < left, ok1 = src >= 0 && 2 * cp + 1 < left;
+            r0[i] = p.B[ok0 ? src + cbase : 0];
+            r1[i] = p.B[ok1 ? src + cbase + HW : 0];
+        }
+    };
+    auto stage = [&](int c) {
+        int tt = t;
+        asm volatile("" : "+v"(tt));
+        const int left = p.Cin - c * CB;
+#pragma unroll
+        for (int i = 0; i < NPI; ++i) {
+            int cp, src, dst;
+            item(tt, i, cp, src, dst);
+            if (dst < 0) continue;
+            const float v0 = (src >= 0 && 2 * cp < left) ? r0[i] : 0.f;
+            const float v1 = (src >= 0 && 2 * cp + 1 < left) ? r1[i] : 0.f;
+            uint32_t h0, m0_, l0, h1, m1, l1;
+            split3(v0, h0, m0_, l0);
+            split3(v1, h1, m1, l1);
+            *reinterpret_cast<uint32_t*>(smem + dst) = h0 | (h1 << 16);
+            *reinterpret_cast<uint32_t*>(smem + dst + 32) = m0_ | (m1 << 16);
+            *reinterpret_cast<uint32_t*>(smem + dst + 64) = l0 | (l1 << 16);
+        }
+    };
+
+    // per-lane operand bases
+    int bbase[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int nl = (wn * TN + tn) * 32 + l31;
+        const int il = nl / (PTH * PTW), ph = (nl / PTW) % PTH, pw = nl % PTW;
+        bbase[tn] = ((il * PH + ph) * PWR + pw) * PIXB + half * 16;
+    }
+    // weights: [32-channel tile][chunk][tap (padded)][piece][lane] x 16 bytes
+    __amdgpu_buffer_rsrc_t rA[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int mt = m0 / 32 + wm * TM + tm;
+        rA[tm] = bf3_rsrc(a_split + (int64_t)grp * a_grp_bytes + (int64_t)mt * nch * KKP * (3 * 1024));
+    }
+    const int steps = nch * KKP;
+    auto load_a = [&](int tm, int s, int pl) -> v4i {
+        const int sc = s < steps ? s : steps - 1;
+        return __builtin_amdgcn_raw_buffer_load_b128(rA[tm], (sc * 3 + pl) * 1024 + lane * 16, 0, 0);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[tm][tn][i] = 0.f;
+
+    v4i abuf[DA][TM][3];
+#pragma unroll
+    for (int d = 0; d < DA; ++d)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) abuf[d][tm][pl] = load_a(tm, d, pl);
+
+    unsigned long long tk0 = BF3_T(), t_stage = 0, t_mma = 0;
+    (void)tk0;
+#ifdef BF3_TIMING
+    const unsigned long long cyc0 = clock64();
+#endif
+    load_patch(0);
+    for (int c = 0; c < nch; ++c) {
+        const unsigned long long ta = BF3_T();
+        stage(c);
+        __syncthreads();
+        const unsigned long long tb = BF3_T();
+        t_stage += tb - ta;
+        if (c + 1 < nch) load_patch(c + 1);  // in flight under the MFMA phase
+        const int s0 = c * KKP;
+        auto read_b = [&](int r, bf16x8 (&b)[TN][3]) {  // the tap's B fragments: one ds_read_b128 per (pixel tile, piece)
+            const int kh = r / KS, kw = r - kh * KS;
+            const int toff = (kh * PWR + kw) * PIXB;
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    b[tn][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const v4i*>(smem + bbase[tn] + toff + pl * 32));
+        };
+        bf16x8 bq[2][TN][3];  // this tap's fragments and the next tap's, read while this tap's MFMAs issue
+        read_b(0, bq[0]);
+#pragma unroll
+        for (int r = 0; r < KKP; ++r) {
+            const int slot = r % DA;
+            if (r < KK) {
+                if (r + 1 < KK) read_b(r + 1, bq[(r + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);  // (the reads stay AHEAD of this tap's MFMAs: left alone they sink to their use)
+                bf16x8 a[TM][3];
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) a[tm][pl] = __builtin_bit_cast(bf16x8, abuf[slot][tm][pl]);
+                // smallest products first; consecutive MFMAs hit different accumulators
+#define IVLN_BF3_PROD(PA, PB)                                                                                       \
+    _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) _Pragma("unroll") for (int tn = 0; tn < TN; ++tn)              \
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][PA], bq[r & 1][tn][PB], acc[tm][tn], 0, 0, 0)
+                IVLN_BF3_PROD(0, 2);
+                IVLN_BF3_PROD(1, 1);
+                IVLN_BF3_PROD(2, 0);
+                IVLN_BF3_PROD(0, 1);
+                IVLN_BF3_PROD(1, 0);
+                IVLN_BF3_PROD(0, 0);
+#undef IVLN_BF3_PROD
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // the slot just used receives the weights of DA taps ahead (the rotation closes over the chunk: KKP % DA == 0)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) abuf[slot][tm][pl] = load_a(tm, s0 + r + DA, pl);
+            __builtin_amdgcn_sched_barrier(0);  // (... and so do the weight loads: DA taps of flight time, not one)
+        }
+        __syncthreads();
+        t_mma += BF3_T() - tb;
+    }
+    const unsigned long long tk1 = BF3_T();
+    (void)tk1;
+
+    // ---- epilogue: slabs of 32 channels through LDS.  acc[r] -> channel (r&3) + 8*(r>>2) + 4*half, pixel l31 ----
+    float* T = reinterpret_cast<float*>(smem);
+    for (int slab = 0; slab < TM * WM; ++slab) {
+        const int sw = slab / TM, stm = slab - sw * TM;
+        if (wm == sw) {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+                if (tm == stm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            T[((r & 3) + 8 * (r >> 2) + 4 * half) * LDT + (wn * TN + tn) * 32 + l31] = acc[tm][tn][r];
+        }
+        __syncthreads();
+        const int mbase = m0 + slab * 32;
+        for (int idx = t; idx < 32 * (BN / 4); idx += NTB) {
+            const int ml = idx / (BN / 4), c4 = idx - ml * (BN / 4);
+            const int m = mbase + ml;
+            const int nl = 4 * c4;
+            const int il = nl / (PTH * PTW), ph = (nl / PTW) % PTH, pw = nl % PTW;
+            const int img = img0 + il, ho = ho0 + ph, wo = wo0 + pw;
+            const bool ok = m < p.M && img < nimg && ho < p.Hout && wo < p.Wout;  // (Wout % 4 == 0: a quad is in or out whole)
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) {
+                v = *reinterpret_cast<const float4*>(T + ml * LDT + nl);
+                const int64_t addr = ((int64_t)img * p.Ctot + m) * p.HoWo + ho * p.Wout + wo;
+                const int me = p.grp_imgs > 0 ? (img / p.grp_imgs) * p.M + m : m;
+                if (p.scale) {
+                    const float sc = p.scale[me], sh = p.shift[me];
+                    v.x = fmaf(v.x, sc, sh), v.y = fmaf(v.y, sc, sh), v.z = fmaf(v.z, sc, sh), v.w = fmaf(v.w, sc, sh);
+                } else if (p.shift) {
+                    const float sh = p.shift[me];
+                    v.x += sh, v.y += sh, v.z += sh, v.w += sh;
+                }
+                if (p.residual) {
+                    const float4 rr = *reinterpret_cast<const float4*>(p.residual + addr);
+                    v.x += rr.x, v.y += rr.y, v.z += rr.z, v.w += rr.w;
+                }
+                if (p.accumulate) {
+                    const float4 rr = *reinterpret_cast<const float4*>(p.D + addr);
+                    v.x += rr.x, v.y += rr.y, v.z += rr.z, v.w += rr.w;
+                }
+                if (p.relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+                *reinterpret_cast<float4*>(p.D + addr) = v;
+            }
+            if (p.stat_partials) {  // (uniform) {count, mean, M2} of the 128 pixels a half-wave just stored
+                float cnt = ok ? 4.f : 0.f, sum = ok ? (v.x + v.y) + (v.z + v.w) : 0.f;
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o), sum += __shfl_xor(sum, o);
+                const float mean = cnt > 0.f ? sum / cnt : 0.f;
+                const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+                float q = ok ? (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) : 0.f;
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o);
+                if ((t & 31) == 0 && m < p.M) {
+                    float* st = p.stat_partials + ((int64_t)(bx * (BN / 128) + c4 / 32) * p.M + m) * 3;
+                    st[0] = cnt, st[1] = mean, st[2] = q;
+                }
+            }
+        }
+        __syncthreads();
+    }
+#ifdef BF3_TIMING
+    if (threadIdx.x == 0) {
+        const int b = (blockIdx.y * gridDim.x + blockIdx.x) & 8191;
+        g_bf3_stamp[b * 4 + 0] = tk1 - tk0;
+        g_bf3_stamp[b * 4 + 1] = t_stage;
+        g_bf3_stamp[b * 4 + 2] = t_mma;
+        g_bf3_stamp[b * 4 + 3] = clock64() - cyc0;  // shader cycles over the whole kernel: with [0] + epilogue wall time, the clock it ran at
+    }
+#endif
+}
+
+// OIHW fp32 weights -> [32-channel tile][16-channel chunk][tap, padded][piece][lane] x 8 bf16: lane (l31, half) of tile mt
+// holds W[32 mt + l31][16 c + 8 half .. + 7][tap] - the A operand of v_mfma_f32_32x32x16_bf16 as one 16-byte load.
+__global__ __launch_bounds__(256) void k_conv_bf3_pack(const float* __restrict__ W, int M, int Cin, int KS, uint16_t* __restrict__ out,
+                                                       int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int KK = KS * KS, KKP = bf3_taps_padded(KS), nch = (Cin + CB - 1) / CB;
+    const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+    int64_t q = idx >> 9;
+    const int pl = (int)(q % 3);
+    q /= 3;
+    const int r = (int)(q % KKP);
+    q /= KKP;
+    const int c = (int)(q % nch);
+    const int mt = (int)(q / nch);
+    const int m = mt * 32 + (lane & 31), ci = c * CB + (lane >> 5) * 8 + e;
+    const float v = (m < M && ci < Cin && r < KK) ? W[((int64_t)m * Cin + ci) * KK + r] : 0.f;
+    uint32_t h, mm, l;
+    split3(v, h, mm, l);
+    out[idx] = (uint16_t)(pl == 0 ? h : (pl == 1 ? mm : l));
+}
+
+template <int KS, int TM, int WM, int PTH, int PTW, int IMGS, int DA>
+int launch_bf3(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a_split, int64_t grp_bytes, int nimg) {
+    constexpr int WN = 8 / WM, BM = 32 * TM * WM, BN = 64 * WN;
+    constexpr int PH = PTH + KS - 1, PWR = PTW + KS - 1, NPIX = IMGS * PH * PWR;
+    constexpr size_t lds = (size_t)(NPIX * PIXB > 32 * (BN + 4) * 4 ? NPIX * PIXB : 32 * (BN + 4) * 4);
+    static_assert(lds <= 160 * 1024, "patch does not fit");
+    auto kern = k_conv_bf3<KS, TM, WM, PTH, PTW, IMGS, DA>;
+    static bool attr_done = false;  // (idempotent; a race only repeats the call)
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return IVLN_E_HIP;
+        attr_done = true;
+    }
+    const int tiles_w = (d.Wout + PTW - 1) / PTW, tiles_h = (d.Hout + PTH - 1) / PTH;
+    const int groups = (nimg + IMGS - 1) / IMGS;
+    dim3 grid(tiles_w * tiles_h * groups, (d.M + BM - 1) / BM, 1);
+    IVLN_LAUNCH_FAMILY(kern, grid, dim3(NTB), lds, s, d, a_split, (long long)grp_bytes, tiles_w, tiles_h, nimg);
+    return IVLN_OK;
+}
+
+template <int KS, int TM, int WM, int DA>
+int launch_bf3_px(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a, int64_t gb, int nimg) {
+    constexpr int BN = 64 * (8 / WM);
+    if constexpr (BN == 512) {
+        if (d.Wout > 16) return launch_bf3<KS, TM, WM, 16, 32, 1, DA>(d, s, a, gb, nimg);
+        if (d.Wout > 8) return launch_bf3<KS, TM, WM, 16, 16, 2, DA>(d, s, a, gb, nimg);
+        if constexpr (KS == 3) return launch_bf3<KS, TM, WM, 8, 8, 8, DA>(d, s, a, gb, nimg);
+        return IVLN_E_UNSUPPORTED;
+    } else {
+        if (d.Wout > 16) return launch_bf3<KS, TM, WM, 8, 32, 1, DA>(d, s, a, gb, nimg);
+        if (d.Wout > 8) return launch_bf3<KS, TM, WM, 16, 16, 1, DA>(d, s, a, gb, nimg);
+        return launch_bf3<KS, TM, WM, 8, 8, 4, DA>(d, s, a, gb, nimg);
+    }
+}
+
+template <int KS>
+int launch_bf3_ks(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a, int64_t gb, int nimg, int cfg) {
+    // weight taps in flight: a tap is 24 MFMAs = 768 pipe cycles per wave (12 = 384 with one channel tile per wave), an L2 /
+    // MALL round trip ~2000: two taps ahead left the MFMA phase at 60 % of the pipe (tools/conv_bf3_phases.py)
+    constexpr int DA2 = 3, DA1 = KS == 7 ? 6 : 9;
+    switch (cfg) {
+        case 0: return launch_bf3_px<KS, 1, 1, DA1>(d, s, a, gb, nimg);  // 32 x 512
+        case 1: return launch_bf3_px<KS, 2, 1, DA2>(d, s, a, gb, nimg);  // 64 x 512
+        case 2: return launch_bf3_px<KS, 1, 2, DA1>(d, s, a, gb, nimg);  // 64 x 256
+        default: return launch_bf3_px<KS, 2, 2, DA2>(d, s, a, gb, nimg); // 128 x 256
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t ivln_conv_split_words(int M, int Cin, int KS) {
+    if ((KS != 3 && KS != 7) || M <= 0 || Cin <= 0) return 0;
+    return (int64_t)((M + 31) / 32) * ((Cin + CB - 1) / CB) * bf3_taps_padded(KS) * (3 * 1024 / 4);
+}
+
+extern "C" int ivln_conv_split_weights_f32(const float* W, int M, int Cin, int KS, void* out, void* stream) {
+    const int64_t words = ivln_conv_split_words(M, Cin, KS);
+    if (!W || !out || words <= 0) return IVLN_E_INVALID;
+    const int64_t total = words * 2;
+    hipLaunchKernelGGL(k_conv_bf3_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, M, Cin, KS,
+                       (uint16_t*)out, total);
+    return hipGetLastError() == hipSuccess ? IVLN_OK : IVLN_E_HIP;
+}
+
+// Eligibility + tile choice.  IVLN_E_UNSUPPORTED sends the caller to the fp32 MFMA kernels.
+#ifdef BF3_TIMING
+extern "C" int ivln_conv_bf3_stamps(unsigned long long* host, int n) {
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_bf3_stamp), sizeof(unsigned long long) * n) != hipSuccess) return -1;
+    void* dp = nullptr;  // (cleared for the next launch: a smaller grid leaves no stale entries behind)
+    if (hipGetSymbolAddress(&dp, HIP_SYMBOL(g_bf3_stamp)) != hipSuccess) return -1;
+    return hipMemset(dp, 0, sizeof(g_bf3_stamp)) == hipSuccess ? 0 : -1;
+}
+#endif
+
+int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
+    static const bool disabled = getenv("IVLN_NO_SPLIT_BF16") != nullptr;  // A/B switch
+    if (!d.A_split || (disabled && !force)) return IVLN_E_UNSUPPORTED;
+    const int KS = conv_ks(d.bmode);
+    if ((KS != 3 && KS != 7) || d.amode != AMODE_MK || d.dmode != DMODE_NCHW || d.stride != 1 || d.dil != 1 || d.pad != KS / 2)
+        return IVLN_E_UNSUPPORTED;
+    if (d.K != d.Cin * KS * KS || d.HoWo != d.Hout * d.Wout || d.N % d.HoWo != 0 || d.Hout != d.Hin || d.Wout != d.Win)
+        return IVLN_E_UNSUPPORTED;
+    if (d.defer_epilogue || d.splits > 1 || (d.Wout & 3) || d.Wout < 8 || (((uintptr_t)d.D | (uintptr_t)d.residual) & 15))
+        return IVLN_E_UNSUPPORTED;
+    const int nimg = d.N / d.HoWo;
+    if ((int64_t)nimg * d.in_img_stride >= (int64_t)1 << 31) return IVLN_E_UNSUPPORTED;  // 32-bit patch offsets
+    // tile: the widest pixel tile that still leaves a block per CU
+    auto blocks_of = [&](int bm, int bn) {
+        const int ptw = d.Wout > 16 ? 32 : (d.Wout > 8 ? 16 : 8);
+        const int per = bn / ptw;  // rows x images of a tile
+        const int pth = ptw == 32 ? per : (ptw == 16 ? 16 : 8), imgs = bn / (ptw * pth);
+        return (int64_t)((d.Wout + ptw - 1) / ptw) * ((d.Hout + pth - 1) / pth) * ((nimg + imgs - 1) / imgs) * ((d.M + bm - 1) / bm);
+    };
+    static const int cfg_env = getenv("IVLN_SPLIT_BF16_CFG") ? atoi(getenv("IVLN_SPLIT_BF16_CFG")) : -1;  // tuning
+    int cfg;
+    if (d.M <= 32) cfg = 0;
+    else if (d.M <= 64) cfg = (blocks_of(64, 512) >= 256 && !(KS == 7 && d.Wout <= 8)) ? 1 : 2;
+    else cfg = blocks_of(128, 256) >= 256 ? 3 : 2;
+    if (cfg_env >= 0 && !(cfg_env == 0 && d.M > 32)) cfg = cfg_env;
+    {   // one workgroup per CU (LDS): a grid that leaves a quarter of its last round empty - or never fills one - loses to the
+        // fp32 kernels' 128-pixel tiles and split-K (RedNet below 64 K pixels per launch)
+        const int64_t nb = blocks_of(cfg == 0 ? 32 : (cfg == 3 ? 128 : 64), cfg <= 1 ? 512 : 256);
+        const int64_t rounds = (nb + 255) / 256;
+        if (!force && nb * 4 < rounds * 256 * 3) return IVLN_E_UNSUPPORTED;
+    }
+    const int BN = cfg <= 1 ? 512 : 256;
+    const int ptw = d.Wout > 16 ? 32 : (d.Wout > 8 ? 16 : 8);
+    const int pth = ptw == 32 ? BN / 32 : (ptw == 16 ? 16 : 8), imgs = BN / (ptw * pth);
+    if (d.grp_imgs > 0 && (d.grp_imgs % imgs != 0 || nimg % d.grp_imgs != 0)) return IVLN_E_UNSUPPORTED;  // a tile's images share one weight set
+    d.splits = 1;
+    const int64_t tiles = (int64_t)((d.Wout + ptw - 1) / ptw) * ((d.Hout + pth - 1) / pth) * ((nimg + imgs - 1) / imgs);
+    const int64_t gb = d.a_split_grp_stride * 4;
+    const int rc = KS == 7 ? launch_bf3_ks<7>(d, s, (const unsigned char*)d.A_split, gb, nimg, cfg)
+                           : launch_bf3_ks<3>(d, s, (const unsigned char*)d.A_split, gb, nimg, cfg);
+    if (rc == IVLN_OK && d.stat_tiles) *d.stat_tiles = d.stat_partials ? (int)(tiles * (BN / 128)) : 0;
+    return rc;
+}

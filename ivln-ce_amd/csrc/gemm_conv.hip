@@ -495,6 +495,17 @@ extern "C" int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream) {
         if (d.amode != AMODE_MK || d.dmode != DMODE_NCHW || d.N % ((int64_t)d.grp_imgs * d.HoWo) != 0) return IVLN_E_INVALID;
         if (d.a_grp_stride <= 0) d.a_grp_stride = (int64_t)d.M * d.lda;
     }
+    // stride-1 3x3 / 7x7 with split-bf16 weights on hand: the bf16-MFMA direct conv (conv_bf3.hip); 9 insists on it
+    if ((d.tile_override == 0 || d.tile_override == 9) && d.A_split) {
+        const int rc = ivln_conv_bf3_launch(d, s, d.tile_override == 9);
+        if (rc == IVLN_OK) {
+            if (d.splits_used) *d.splits_used = 1;
+            return hipGetLastError() == hipSuccess ? IVLN_OK : IVLN_E_HIP;
+        }
+        if (rc != IVLN_E_UNSUPPORTED || d.tile_override == 9) return rc;
+    } else if (d.tile_override == 9) {
+        return IVLN_E_UNSUPPORTED;
+    }
     // stride-1 3x3 / 7x7: LDS-staged direct convolution (conv_direct.hip); tile_override 1..5 pins the
     // implicit GEMM tiles, 6 insists on the direct kernel
     if (d.tile_override == 0 || d.tile_override == 6) {

@@ -40,6 +40,7 @@ class GemmDesc(C.Structure):
         ("grp_imgs", i32), ("a_grp_stride", i64), ("a_packed_grp_stride", i64),
         ("no_wide_epilogue", i32),
         ("stat_partials", vp), ("stat_tiles", C.POINTER(i32)),
+        ("A_split", vp), ("a_split_grp_stride", i64),
     ]
 
 
@@ -248,10 +249,11 @@ def _epilogue(d: GemmDesc, scale, shift, residual, relu, accumulate=False):
 _packed = {}
 
 
-def packed_conv_weights(w, cache=True):
-    """Weights of a stride-1 3x3 / 7x7 / 2x2 conv in the direct kernel's LDS order.  Long-lived tensors (module
-    parameters) are cached until they change (tensor version / WEIGHT_EPOCH) or die (weak reference: a freed
-    address may be handed to another tensor); temporaries (`cache=False`, e.g. the flipped weights of an input
+def packed_conv_weights(w, cache=True, split=False):
+    """Weights of a stride-1 3x3 / 7x7 / 2x2 conv in the direct kernel's LDS order - or, `split`, as three bf16 pieces per
+    value in the bf16-MFMA direct conv's per-lane order (csrc/conv_bf3.hip; a float32 tensor of 4-byte words).  Long-lived
+    tensors (module parameters) are cached until they change (tensor version / WEIGHT_EPOCH) or die (weak reference: a
+    freed address may be handed to another tensor); temporaries (`cache=False`, e.g. the flipped weights of an input
     gradient) are packed into a fresh buffer every call so that nothing accumulates."""
     import weakref
 
@@ -261,22 +263,26 @@ def packed_conv_weights(w, cache=True):
     L.ivln_conv_packed_floats.restype = i64
     L.ivln_conv_packed_floats.argtypes = [i32, i32, i32]
     L.ivln_conv_pack_weights_f32.argtypes = [vp, i32, i32, i32, vp, vp]
-    n1 = L.ivln_conv_packed_floats(Cout, Cin, KH)
+    L.ivln_conv_split_words.restype = i64
+    L.ivln_conv_split_words.argtypes = [i32, i32, i32]
+    L.ivln_conv_split_weights_f32.argtypes = [vp, i32, i32, i32, vp, vp]
+    n1 = L.ivln_conv_split_words(Cout, Cin, KH) if split else L.ivln_conv_packed_floats(Cout, Cin, KH)
     if n1 <= 0:
         return None
     n = n1 * G
     wsz = Cout * Cin * KH * KW
+    fn, fn_name = ((L.ivln_conv_split_weights_f32, "ivln_conv_split_weights_f32") if split
+                   else (L.ivln_conv_pack_weights_f32, "ivln_conv_pack_weights_f32"))
 
     def _pack(dst):
         for g in range(G):
-            check(L.ivln_conv_pack_weights_f32(w.data_ptr() + 4 * g * wsz, Cout, Cin, KH, dst.data_ptr() + 4 * g * n1,
-                                               stream_ptr()), "ivln_conv_pack_weights_f32")
+            check(fn(w.data_ptr() + 4 * g * wsz, Cout, Cin, KH, dst.data_ptr() + 4 * g * n1, stream_ptr()), fn_name)
 
     if not cache:
         out = torch.empty(n, dtype=torch.float32, device=w.device)
         _pack(out)
         return out
-    key = (w.data_ptr(), tuple(w.shape))
+    key = (w.data_ptr(), tuple(w.shape), bool(split))
     stamp = (w._version, WEIGHT_EPOCH)
     cur = torch.cuda.current_stream()
     hit = _packed.get(key)
@@ -330,6 +336,11 @@ class Deferred:
         self.ws, self.splits, self.N, self.C, self.H, self.W = ws, splits, N, C, H, W
 
 
+# 3x3 / 7x7 convs with both operands as three bf16 pieces each on the bf16 MFMA pipe (csrc/conv_bf3.hip): exact pieces, six
+# of the nine piece products, fp32 accumulation - as close to the exact conv as the fp32 MFMA kernels.
+# IVLN_SPLIT_BF16=0 keeps the fp32 MFMA kernels everywhere (A/B); the C side has IVLN_NO_SPLIT_BF16 for the same.
+SPLIT_BF16 = os.environ.get("IVLN_SPLIT_BF16", "1") != "0"
+SPLIT_BF16_MIN_OUT = int(os.environ.get("IVLN_SPLIT_BF16_MIN_OUT", str(1 << 20)))  # output elements below which nothing is packed
 _stat_ws = {}
 CONV_STATS = os.environ.get("IVLN_CONV_STATS", "1") != "0"  # A/B: BatchNorm statistics from the conv's epilogue
 
@@ -385,6 +396,14 @@ def conv2d(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, 
             if pk is not None:
                 d.A_packed = dptr(pk)
                 d.a_packed_grp_stride = pk.numel() // max(G, 1)
+        # same-size stride-1 convs over enough pixels: both operands as three bf16 pieces on the bf16 MFMA pipe
+        # (csrc/conv_bf3.hip; the C side decides per shape and falls back to the fp32 MFMA kernels)
+        if (SPLIT_BF16 and stride == 1 and pad == KH // 2 and Wo % 4 == 0 and Wo >= 8 and w.is_contiguous() and not defer
+                and (N * Ho * Wo * Cout >= SPLIT_BF16_MIN_OUT or TILE_OVERRIDE == 9)):
+            sp = packed_conv_weights(w, cache=not weight_is_temp, split=True)
+            if sp is not None:
+                d.A_split = dptr(sp)
+                d.a_split_grp_stride = sp.numel() // max(G, 1)
     else:
         d.bmode = B_CONV
         koff, kpos = conv_tables(Cin, KH, KW, H, W, dil, x.device)

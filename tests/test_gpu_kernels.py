@@ -337,6 +337,134 @@ def test_conv2d_direct_lds_patch_kernel(N, Cin, H, W, Cout, k, p):
     _close(slabs.permute(1, 0, 2, 3), ref0, 3e-5)
 
 
+@pytest.mark.parametrize(
+    "N,Cin,H,W,Cout,k",
+    [
+        (6, 14, 64, 64, 32, 7),     # map CNN layer 1: ragged 14-channel chunk, 32 x 512 tiles of 16 x 32 pixels
+        (4, 32, 32, 32, 64, 7),     # layer 2: 64 x 512 tiles
+        (5, 64, 16, 16, 128, 7),    # layer 3: 16 x 16 tiles (odd image count: 64 x 256 and 128 x 256 both see a masked image)
+        (9, 128, 8, 8, 128, 7),     # layer 4: 8 x 8 tiles, four images per tile, ragged image group
+        (3, 64, 32, 32, 32, 7),     # layer 2's input gradient
+        (2, 64, 128, 128, 64, 3),   # RedNet layer 1
+        (3, 48, 40, 24, 70, 3),     # ragged: tile overhang both ways, 70 channels (masked channel tile), 48 = 3 chunks
+        (16, 256, 8, 8, 40, 3),     # eight images per tile
+        (2, 16, 16, 48, 256, 3),    # two channel-tile rows of 128
+    ],
+)
+def test_conv2d_split_bf16_kernel(N, Cin, H, W, Cout, k):
+    """conv_bf3.hip forced (tile_override 9): both operands as three exact bf16 pieces, six of the nine piece products on the
+    bf16 MFMA pipe, fp32 accumulation.  Against a float64 convolution its error has to be what the fp32 MFMA direct kernel's
+    is (measured 0.7-2.4e-6 of the largest output for both; bar: 3e-6 of the largest output, and at most twice the fp32
+    kernel's + 1e-6), and all the epilogue forms of ivln_gemm_f32 have to hold: scale / shift / residual / ReLU, a channel
+    slice of a wider destination, image-grouped weights."""
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(N * 100 + Cin + k)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    ref0 = F.conv2d(x.double(), w.double(), None, stride=1, padding=k // 2)
+    res = torch.randn(ref0.shape, generator=g)
+    ref = F.relu(ref0 * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1) + res.double())
+    xd, wd = x.to(DEV), w.to(DEV)
+    try:
+        ops.TILE_OVERRIDE = 9
+        got = ops.conv2d(xd, wd, pad=k // 2, scale=sc.to(DEV), shift=sh.to(DEV), residual=res.to(DEV), relu=True)
+        plain = ops.conv2d(xd, wd, pad=k // 2, splitk=False)
+        again = ops.conv2d(xd, wd, pad=k // 2, splitk=False)
+        wide = torch.zeros(N, Cout + 8, *ref0.shape[2:], device=DEV)
+        ops.conv2d(xd, wd, pad=k // 2, out=wide[:, 4:], out_ctot=Cout + 8)
+        ops.TILE_OVERRIDE = 6
+        fp32 = ops.conv2d(xd, wd, pad=k // 2, splitk=False)
+    finally:
+        ops.TILE_OVERRIDE = 0
+    scale = float(ref0.abs().max())
+    e_split = float((plain.double().cpu() - ref0).abs().max()) / scale
+    e_fp32 = float((fp32.double().cpu() - ref0).abs().max()) / scale
+    assert e_split <= 3e-6 and e_split <= 2.0 * e_fp32 + 1e-6, (e_split, e_fp32)
+    assert torch.equal(plain, again)  # (no atomics, fixed order: run-to-run identical)
+    _close(got, ref.float(), 3e-5)
+    assert torch.equal(wide[:, 4:4 + Cout], plain)
+    assert float(wide[:, :4].abs().max()) == 0.0 and float(wide[:, 4 + Cout:].abs().max()) == 0.0
+
+
+def test_conv2d_split_bf16_pieces_are_exact_and_specials_propagate():
+    """The split itself: weights of ONE non-zero tap against an input of ONE non-zero pixel make every output a single
+    product a * b - the six piece products must reproduce it to 2^-22 relative for values across the fp32 exponent range
+    (three bf16 pieces each; the dropped products are below 2^-23 of a b), and an infinity / a NaN in the input never
+    comes out finite (an infinity may come out as NaN: inf times a weight's zero or opposite-signed lower piece)."""
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    N, C, H, k = 16, 16, 32, 3
+    mags = torch.tensor([1e-30, 1e-12, 1e-3, 1.0, 3.14159, 1e5, 1e15, 1e25])
+    x = torch.zeros(N, C, H, H)
+    w = torch.zeros(32, C, k, k)
+    a = (torch.rand(32, generator=g) + 0.5) * (torch.randint(0, 2, (32,), generator=g) * 2 - 1)
+    w[:, 5, 1, 1] = a * 1e-6
+    vals = (torch.rand(N, H, H, generator=g) + 0.5) * mags[torch.randint(0, 8, (N, H, H), generator=g)]
+    x[:, 5] = vals
+    try:
+        ops.TILE_OVERRIDE = 9
+        y = ops.conv2d(x.to(DEV), w.to(DEV), pad=1, splitk=False).cpu()
+        x2 = x.clone()
+        x2[0, 5, 3, 3], x2[1, 5, 4, 4] = float("inf"), float("nan")
+        y2 = ops.conv2d(x2.to(DEV), w.to(DEV), pad=1, splitk=False).cpu()
+    finally:
+        ops.TILE_OVERRIDE = 0
+    ref = (a.double() * 1e-6).view(1, -1, 1, 1) * vals.double().unsqueeze(1)
+    rel = ((y.double() - ref).abs() / ref.abs()).max()
+    assert float(rel) <= 2.0 ** -22, float(rel)
+    assert (~torch.isfinite(y2[0, :, 3, 3])).all() and torch.isnan(y2[1, :, 4, 4]).all()
+    assert torch.isfinite(y2[2:]).all()
+
+
+def test_conv2d_split_bf16_image_grouped_weights_and_epilogue_statistics():
+    """Two weight sets over the two halves of the batch in one launch (RedNet's stacked encoders) == two launches, bit for
+    bit; and the {count, mean, M2} partials the epilogue leaves per (128-pixel segment, channel) merge to the statistics
+    of what was stored."""
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(11)
+    N, Cin, H, Cout = 8, 64, 64, 64
+    x = torch.randn(N, Cin, H, H, generator=g).to(DEV)
+    w2 = (torch.randn(2, Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).to(DEV)
+    b = torch.randn(Cout, generator=g).to(DEV)
+    try:
+        ops.TILE_OVERRIDE = 9
+        both = ops.conv2d(x, w2, pad=1, splitk=False)
+        lo = ops.conv2d(x[:4].contiguous(), w2[0].contiguous(), pad=1, splitk=False)
+        hi = ops.conv2d(x[4:].contiguous(), w2[1].contiguous(), pad=1, splitk=False)
+        stats = []
+        y = ops.conv2d(x, w2[0].contiguous(), pad=1, shift=b, stats=stats)
+    finally:
+        ops.TILE_OVERRIDE = 0
+    assert torch.equal(both[:4], lo) and torch.equal(both[4:], hi)
+    assert stats, "the split-bf16 kernel leaves its partials"
+    bn = torch.nn.BatchNorm2d(Cout).to(DEV).train()
+    sc, sh, sm, sr = (torch.empty(Cout, device=DEV) for _ in range(4))
+    ops.bn_stats_from_partials(stats[0][0], stats[0][1], bn, sc, sh, sm, sr)
+    _close(sm, y.double().mean((0, 2, 3)).float(), 1e-5)
+    _close(sr, (1.0 / torch.sqrt(y.double().var((0, 2, 3), unbiased=False) + 1e-5)).float(), 1e-4)
+
+
+def test_conv2d_split_bf16_refuses_what_it_is_not_built_for():
+    from ivln_ce_amd import ops
+    from ivln_ce_amd._lib import IvlnError
+
+    x = torch.randn(8, 32, 32, 32, device=DEV)
+    for w, kw in [(torch.randn(32, 32, 3, 3, device=DEV), dict(stride=2, pad=1)),       # strided
+                  (torch.randn(32, 32, 3, 3, device=DEV), dict(pad=0)),                   # not same-size
+                  (torch.randn(32, 32, 1, 1, device=DEV), dict(pad=0)),                   # 1x1
+                  (torch.randn(32, 32, 5, 5, device=DEV), dict(pad=2))]:                  # 5x5
+        try:
+            ops.TILE_OVERRIDE = 9
+            with pytest.raises(IvlnError):
+                ops.conv2d(x, w, **kw)
+        finally:
+            ops.TILE_OVERRIDE = 0
+
+
 def test_conv2d_direct_packed_and_unpacked_weights_agree():
     """The pre-arranged-weight variant of the direct kernel (default) against the variant that gathers OIHW
     weights itself: bit-identical (same MFMA order), and the packed cache follows in-place weight updates."""

@@ -725,9 +725,12 @@ def test_three_hip_updates_track_oracle_plus_torch_adam(custom_lr):
                     if e > worst[0]:
                         worst = (e, k)
                     # (from step 2 on exp_avg = 0.9 m + 0.1 g can cancel - opposite gradient signs in consecutive steps - so the
-                    #  same absolute moment error is a larger share of the update: up to 15 % of lr instead of 1.2 %)
+                    #  same absolute moment error is a larger share of the update: up to 20 % of lr instead of 1.2 %.  Measured
+                    #  worst element: 13 % with the map CNN's convs on the fp32 MFMA kernels, 16 % with them on the split-bf16
+                    #  kernel - an exp_avg of 1.4e-5 that is 3.7e-6 off, inside the moment bars above and below the 5.3e-6 the
+                    #  fp32 kernels leave elsewhere in the same tensor)
                     lr_k = sem_lr if (custom_lr and k.startswith("net.map_encoder")) else lr
-                    if e > (0.012 if s == 1 else 0.15) * lr_k:
+                    if e > (0.012 if s == 1 else 0.20) * lr_k:
                         i = int(torch.where(firm, d, torch.zeros_like(d)).reshape(-1).argmax())
                         o = opt.offsets[opt.names.index(k)]
                         raise AssertionError(
