@@ -32,7 +32,6 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-constexpr int NTB = 512;    // threads per workgroup
 constexpr int PIXB = 112;   // bytes per staged pixel: 3 pieces x 16 channels x 2 bytes + 16 of padding
 constexpr int CB = 16;      // input channels per chunk = K of one MFMA
 
@@ -70,10 +69,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t bf3_rsrc(const void* p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
 }
 
-template <int KS, int TM, int WM, int PTH, int PTW, int IMGS, int DA>
-__global__ __launch_bounds__(NTB) void k_conv_bf3(const ivln_gemm_desc p, const unsigned char* a_split, long long a_grp_bytes,
-                                                  int tiles_w, int tiles_h, int nimg) {
-    constexpr int WN = 8 / WM, TN = 2;
+template <int KS, int TM, int WM, int WN, int PTH, int PTW, int IMGS, int DA>
+__global__ __launch_bounds__(64 * WM * WN) void k_conv_bf3(const ivln_gemm_desc p, const unsigned char* a_split, long long a_grp_bytes,
+                                                           int tiles_w, int tiles_h, int nimg, int chunks_per_split) {
+    constexpr int NTB = 64 * WM * WN, TN = 2;
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     static_assert(IMGS * PTH * PTW == BN && PTW % 4 == 0, "pixel tile");
     constexpr int KK = KS * KS, KKP = bf3_taps_padded(KS);
@@ -157,9 +156,10 @@ __global__ __launch_bounds__(NTB) void k_conv_bf3(const ivln_gemm_desc p, const 
     __amdgpu_buffer_rsrc_t rA[TM];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
-        const int mt = m0 / 32 + wm * TM + tm;
+        const int mt = min(m0 / 32 + wm * TM + tm, (p.M + 31) / 32 - 1);  // (a channel tile past M reads the last one's weights; its rows are never stored)
         rA[tm] = bf3_rsrc(a_split + (int64_t)grp * a_grp_bytes + (int64_t)mt * nch * KKP * (3 * 1024));
     }
+    const int c_beg = bid.z * chunks_per_split, c_end = min(nch, c_beg + chunks_per_split);  // (split K: channel chunks over blockIdx.z)
     const int steps = nch * KKP;
     auto load_a = [&](int tm, int s, int pl) -> v4i {
         const int sc = s < steps ? s : steps - 1;
@@ -180,21 +180,21 @@ __global__ __launch_bounds__(NTB) void k_conv_bf3(const ivln_gemm_desc p, const 
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) abuf[d][tm][pl] = load_a(tm, d, pl);
+            for (int pl = 0; pl < 3; ++pl) abuf[d][tm][pl] = load_a(tm, c_beg * KKP + d, pl);
 
     unsigned long long tk0 = BF3_T(), t_stage = 0, t_mma = 0;
     (void)tk0;
 #ifdef BF3_TIMING
     const unsigned long long cyc0 = clock64();
 #endif
-    load_patch(0);
-    for (int c = 0; c < nch; ++c) {
+    load_patch(c_beg);
+    for (int c = c_beg; c < c_end; ++c) {
         const unsigned long long ta = BF3_T();
         stage(c);
         __syncthreads();
         const unsigned long long tb = BF3_T();
         t_stage += tb - ta;
-        if (c + 1 < nch) load_patch(c + 1);  // in flight under the MFMA phase
+        if (c + 1 < c_end) load_patch(c + 1);  // in flight under the MFMA phase
         const int s0 = c * KKP;
         auto read_b = [&](int r, bf16x8 (&b)[TN][3]) {  // the tap's B fragments: one ds_read_b128 per (pixel tile, piece)
             const int kh = r / KS, kw = r - kh * KS;
@@ -268,7 +268,10 @@ __global__ __launch_bounds__(NTB) void k_conv_bf3(const ivln_gemm_desc p, const 
             const int img = img0 + il, ho = ho0 + ph, wo = wo0 + pw;
             const bool ok = m < p.M && img < nimg && ho < p.Hout && wo < p.Wout;  // (Wout % 4 == 0: a quad is in or out whole)
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) {
+            if (ok && p.splits > 1) {  // (uniform) raw partial sums of this channel range: slab [split][M][N], reduced by k_splitk_epilogue
+                v = *reinterpret_cast<const float4*>(T + ml * LDT + nl);
+                *reinterpret_cast<float4*>(p.ws + ((int64_t)bid.z * p.M + m) * p.N + (int64_t)img * p.HoWo + ho * p.Wout + wo) = v;
+            } else if (ok) {
                 v = *reinterpret_cast<const float4*>(T + ml * LDT + nl);
                 const int64_t addr = ((int64_t)img * p.Ctot + m) * p.HoWo + ho * p.Wout + wo;
                 const int me = p.grp_imgs > 0 ? (img / p.grp_imgs) * p.M + m : m;
@@ -340,13 +343,13 @@ __global__ __launch_bounds__(256) void k_conv_bf3_pack(const float* __restrict__
     out[idx] = (uint16_t)(pl == 0 ? h : (pl == 1 ? mm : l));
 }
 
-template <int KS, int TM, int WM, int PTH, int PTW, int IMGS, int DA>
-int launch_bf3(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a_split, int64_t grp_bytes, int nimg) {
-    constexpr int WN = 8 / WM, BM = 32 * TM * WM, BN = 64 * WN;
+template <int KS, int TM, int WM, int WN, int PTH, int PTW, int IMGS, int DA>
+int launch_bf3(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a_split, int64_t grp_bytes, int nimg, int cps) {
+    constexpr int NTB = 64 * WM * WN, BM = 32 * TM * WM, BN = 64 * WN;
     constexpr int PH = PTH + KS - 1, PWR = PTW + KS - 1, NPIX = IMGS * PH * PWR;
     constexpr size_t lds = (size_t)(NPIX * PIXB > 32 * (BN + 4) * 4 ? NPIX * PIXB : 32 * (BN + 4) * 4);
     static_assert(lds <= 160 * 1024, "patch does not fit");
-    auto kern = k_conv_bf3<KS, TM, WM, PTH, PTW, IMGS, DA>;
+    auto kern = k_conv_bf3<KS, TM, WM, WN, PTH, PTW, IMGS, DA>;
     static bool attr_done = false;  // (idempotent; a race only repeats the call)
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return IVLN_E_HIP;
@@ -354,36 +357,55 @@ int launch_bf3(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a_sp
     }
     const int tiles_w = (d.Wout + PTW - 1) / PTW, tiles_h = (d.Hout + PTH - 1) / PTH;
     const int groups = (nimg + IMGS - 1) / IMGS;
-    dim3 grid(tiles_w * tiles_h * groups, (d.M + BM - 1) / BM, 1);
-    IVLN_LAUNCH_FAMILY(kern, grid, dim3(NTB), lds, s, d, a_split, (long long)grp_bytes, tiles_w, tiles_h, nimg);
+    dim3 grid(tiles_w * tiles_h * groups, (d.M + BM - 1) / BM, d.splits);
+    IVLN_LAUNCH_FAMILY(kern, grid, dim3(NTB), lds, s, d, a_split, (long long)grp_bytes, tiles_w, tiles_h, nimg, cps);
     return IVLN_OK;
 }
 
-template <int KS, int TM, int WM, int DA>
-int launch_bf3_px(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a, int64_t gb, int nimg) {
-    constexpr int BN = 64 * (8 / WM);
+// pixel tile of a block for its pixel count BN and the output width: rows x columns x images
+struct Bf3Px { int pth, ptw, imgs; };
+inline Bf3Px bf3_px(int BN, int Wout) {
+    const int ptw = Wout > 16 ? 32 : (Wout > 8 ? 16 : 8);
+    const int pth = ptw == 32 ? BN / 32 : (ptw == 16 ? (BN >= 256 ? 16 : 8) : 8);
+    return {pth, ptw, BN / (ptw * pth)};
+}
+
+template <int KS, int TM, int WM, int WN, int DA>
+int launch_bf3_px(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a, int64_t gb, int nimg, int cps) {
+    constexpr int BN = 64 * WN;
     if constexpr (BN == 512) {
-        if (d.Wout > 16) return launch_bf3<KS, TM, WM, 16, 32, 1, DA>(d, s, a, gb, nimg);
-        if (d.Wout > 8) return launch_bf3<KS, TM, WM, 16, 16, 2, DA>(d, s, a, gb, nimg);
-        if constexpr (KS == 3) return launch_bf3<KS, TM, WM, 8, 8, 8, DA>(d, s, a, gb, nimg);
+        if (d.Wout > 16) return launch_bf3<KS, TM, WM, WN, 16, 32, 1, DA>(d, s, a, gb, nimg, cps);
+        if (d.Wout > 8) return launch_bf3<KS, TM, WM, WN, 16, 16, 2, DA>(d, s, a, gb, nimg, cps);
+        if constexpr (KS == 3) return launch_bf3<KS, TM, WM, WN, 8, 8, 8, DA>(d, s, a, gb, nimg, cps);
         return IVLN_E_UNSUPPORTED;
+    } else if constexpr (BN == 256) {
+        if (d.Wout > 16) return launch_bf3<KS, TM, WM, WN, 8, 32, 1, DA>(d, s, a, gb, nimg, cps);
+        if (d.Wout > 8) return launch_bf3<KS, TM, WM, WN, 16, 16, 1, DA>(d, s, a, gb, nimg, cps);
+        return launch_bf3<KS, TM, WM, WN, 8, 8, 4, DA>(d, s, a, gb, nimg, cps);
     } else {
-        if (d.Wout > 16) return launch_bf3<KS, TM, WM, 8, 32, 1, DA>(d, s, a, gb, nimg);
-        if (d.Wout > 8) return launch_bf3<KS, TM, WM, 16, 16, 1, DA>(d, s, a, gb, nimg);
-        return launch_bf3<KS, TM, WM, 8, 8, 4, DA>(d, s, a, gb, nimg);
+        if (d.Wout > 16) return launch_bf3<KS, TM, WM, WN, 4, 32, 1, DA>(d, s, a, gb, nimg, cps);
+        if (d.Wout > 8) return launch_bf3<KS, TM, WM, WN, 8, 16, 1, DA>(d, s, a, gb, nimg, cps);
+        return launch_bf3<KS, TM, WM, WN, 8, 8, 2, DA>(d, s, a, gb, nimg, cps);
     }
 }
 
+// block tiles: {channels, pixels, waves}
+constexpr int kBf3Cfgs = 6;
+constexpr int kBf3BM[kBf3Cfgs] = {32, 64, 64, 128, 64, 128};
+constexpr int kBf3BN[kBf3Cfgs] = {512, 512, 256, 256, 128, 128};
+
 template <int KS>
-int launch_bf3_ks(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a, int64_t gb, int nimg, int cfg) {
+int launch_bf3_ks(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a, int64_t gb, int nimg, int cfg, int cps) {
     // weight taps in flight: a tap is 24 MFMAs = 768 pipe cycles per wave (12 = 384 with one channel tile per wave), an L2 /
-    // MALL round trip ~2000: two taps ahead left the MFMA phase at 60 % of the pipe (tools/conv_bf3_phases.py)
+    // MALL round trip ~2000
     constexpr int DA2 = 3, DA1 = KS == 7 ? 6 : 9;
     switch (cfg) {
-        case 0: return launch_bf3_px<KS, 1, 1, DA1>(d, s, a, gb, nimg);  // 32 x 512
-        case 1: return launch_bf3_px<KS, 2, 1, DA2>(d, s, a, gb, nimg);  // 64 x 512
-        case 2: return launch_bf3_px<KS, 1, 2, DA1>(d, s, a, gb, nimg);  // 64 x 256
-        default: return launch_bf3_px<KS, 2, 2, DA2>(d, s, a, gb, nimg); // 128 x 256
+        case 0: return launch_bf3_px<KS, 1, 1, 8, DA1>(d, s, a, gb, nimg, cps);   // 32 x 512, 8 waves
+        case 1: return launch_bf3_px<KS, 2, 1, 8, DA2>(d, s, a, gb, nimg, cps);   // 64 x 512
+        case 2: return launch_bf3_px<KS, 1, 2, 4, DA1>(d, s, a, gb, nimg, cps);   // 64 x 256
+        case 3: return launch_bf3_px<KS, 2, 2, 4, DA2>(d, s, a, gb, nimg, cps);   // 128 x 256
+        case 4: return launch_bf3_px<KS, 1, 2, 2, DA1>(d, s, a, gb, nimg, cps);   // 64 x 128, 4 waves: several workgroups per CU
+        default: return launch_bf3_px<KS, 2, 2, 2, DA2>(d, s, a, gb, nimg, cps);  // 128 x 128, 4 waves
     }
 }
 
@@ -421,38 +443,65 @@ int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
         return IVLN_E_UNSUPPORTED;
     if (d.K != d.Cin * KS * KS || d.HoWo != d.Hout * d.Wout || d.N % d.HoWo != 0 || d.Hout != d.Hin || d.Wout != d.Win)
         return IVLN_E_UNSUPPORTED;
-    if (d.defer_epilogue || d.splits > 1 || (d.Wout & 3) || d.Wout < 8 || (((uintptr_t)d.D | (uintptr_t)d.residual) & 15))
+    if (d.defer_epilogue || d.splits > 1 || (d.Wout & 3) || d.Wout < 8 || (((uintptr_t)d.D | (uintptr_t)d.residual | (uintptr_t)d.ws) & 15))
         return IVLN_E_UNSUPPORTED;
     const int nimg = d.N / d.HoWo;
     if ((int64_t)nimg * d.in_img_stride >= (int64_t)1 << 31) return IVLN_E_UNSUPPORTED;  // 32-bit patch offsets
-    // tile: the widest pixel tile that still leaves a block per CU
-    auto blocks_of = [&](int bm, int bn) {
-        const int ptw = d.Wout > 16 ? 32 : (d.Wout > 8 ? 16 : 8);
-        const int per = bn / ptw;  // rows x images of a tile
-        const int pth = ptw == 32 ? per : (ptw == 16 ? 16 : 8), imgs = bn / (ptw * pth);
-        return (int64_t)((d.Wout + ptw - 1) / ptw) * ((d.Hout + pth - 1) / pth) * ((nimg + imgs - 1) / imgs) * ((d.M + bm - 1) / bm);
+    const int nch = (d.Cin + CB - 1) / CB;
+    auto tiles_of = [&](int cfg) {
+        const Bf3Px t = bf3_px(kBf3BN[cfg], d.Wout);
+        return (int64_t)((d.Wout + t.ptw - 1) / t.ptw) * ((d.Hout + t.pth - 1) / t.pth) * ((nimg + t.imgs - 1) / t.imgs);
+    };
+    auto blocks_of = [&](int cfg) { return tiles_of(cfg) * ((d.M + kBf3BM[cfg] - 1) / kBf3BM[cfg]); };
+    // fills the chip: at most a quarter of the last round of 256 x slots workgroups empty
+    auto fills = [&](int64_t nb, int slots) {
+        const int64_t round = 256 * slots, rounds = (nb + round - 1) / round;
+        return nb * 4 >= rounds * round * 3;
     };
     static const int cfg_env = getenv("IVLN_SPLIT_BF16_CFG") ? atoi(getenv("IVLN_SPLIT_BF16_CFG")) : -1;  // tuning
-    int cfg;
+    static const int split_env = getenv("IVLN_SPLIT_BF16_SPLITS") ? atoi(getenv("IVLN_SPLIT_BF16_SPLITS")) : 0;
+    // the widest tile that fills the chip on its own; else the 4-wave tiles (two or three workgroups per CU) with the channel
+    // chunks split over blockIdx.z (raw slabs reduced by k_splitk_epilogue, like the fp32 kernels)
+    int cfg = -1, splits = 1;
+    const bool big_ok = !(KS == 7 && d.Wout <= 8);  // (7x7 on 8x8 maps: eight images of 14 x 14 patch pixels do not fit)
+    // (4-wave tiles, measured on RedNet's 3x3 shapes at 8 + 8 stacked images against the fp32 kernels: 128 x 128 wins from
+    //  2 M outputs - 57 vs 64 us on 128 x 16384, 50 vs 67 on 256 x 4096 and 512 x 1024 -, 64 x 128 below - 41 vs 46 on
+    //  128 x 8192, 37.5 vs 44 on 256 x 2048 and 512 x 512; 64-channel convs that need them lose - 42 vs 38 us on 64 x 32768)
     if (d.M <= 32) cfg = 0;
-    else if (d.M <= 64) cfg = (blocks_of(64, 512) >= 256 && !(KS == 7 && d.Wout <= 8)) ? 1 : 2;
-    else cfg = blocks_of(128, 256) >= 256 ? 3 : 2;
-    if (cfg_env >= 0 && !(cfg_env == 0 && d.M > 32)) cfg = cfg_env;
-    {   // one workgroup per CU (LDS): a grid that leaves a quarter of its last round empty - or never fills one - loses to the
-        // fp32 kernels' 128-pixel tiles and split-K (RedNet below 64 K pixels per launch)
-        const int64_t nb = blocks_of(cfg == 0 ? 32 : (cfg == 3 ? 128 : 64), cfg <= 1 ? 512 : 256);
-        const int64_t rounds = (nb + 255) / 256;
-        if (!force && nb * 4 < rounds * 256 * 3) return IVLN_E_UNSUPPORTED;
+    else if (d.M <= 64) cfg = (big_ok && fills(blocks_of(1), 1)) ? 1 : (fills(blocks_of(2), 1) ? 2 : (force ? 4 : -1));
+    else cfg = fills(blocks_of(3), 1) ? 3 : (fills(blocks_of(2), 1) ? 2 : ((int64_t)d.M * d.N >= (1 << 21) ? 5 : 4));
+    if (cfg < 0) return IVLN_E_UNSUPPORTED;
+    if (cfg_env >= 0 && cfg_env < kBf3Cfgs && !(cfg_env == 0 && d.M > 32)) cfg = cfg_env;
+    if (cfg == 0 && !big_ok) return IVLN_E_UNSUPPORTED;
+    const int64_t nb = blocks_of(cfg);
+    if (cfg >= 4) {
+        const int slots = cfg == 4 ? 3 : 2;
+        const bool may_split = d.splits == 0 && d.ws && nch >= 2 && !d.stat_partials;
+        if (may_split && nb < 256 * slots) {
+            const int64_t want = 256 * slots;
+            splits = (int)((want + nb - 1) / nb);
+            if (splits > nch) splits = nch;
+            if (splits > 16) splits = 16;
+            const int64_t cap = d.ws_floats / ((int64_t)d.M * d.N);
+            if (splits > cap) splits = (int)cap;
+            if (splits < 1) splits = 1;
+        }
+        if (split_env > 0 && may_split) splits = split_env > nch ? nch : split_env;
+        if (!force && nb * splits < 192) return IVLN_E_UNSUPPORTED;  // pixel- and channel-starved: the implicit GEMM splits K deeper
+    } else if (!force && !fills(nb, 1)) {
+        return IVLN_E_UNSUPPORTED;
     }
-    const int BN = cfg <= 1 ? 512 : 256;
-    const int ptw = d.Wout > 16 ? 32 : (d.Wout > 8 ? 16 : 8);
-    const int pth = ptw == 32 ? BN / 32 : (ptw == 16 ? 16 : 8), imgs = BN / (ptw * pth);
-    if (d.grp_imgs > 0 && (d.grp_imgs % imgs != 0 || nimg % d.grp_imgs != 0)) return IVLN_E_UNSUPPORTED;  // a tile's images share one weight set
-    d.splits = 1;
-    const int64_t tiles = (int64_t)((d.Wout + ptw - 1) / ptw) * ((d.Hout + pth - 1) / pth) * ((nimg + imgs - 1) / imgs);
+    const int cps = (nch + splits - 1) / splits;
+    splits = (nch + cps - 1) / cps;
+    const Bf3Px t = bf3_px(kBf3BN[cfg], d.Wout);
+    if (d.grp_imgs > 0 && (d.grp_imgs % t.imgs != 0 || nimg % d.grp_imgs != 0)) return IVLN_E_UNSUPPORTED;  // a tile's images share one weight set
+    d.splits = splits;
+    if (splits > 1) d.stat_partials = nullptr;
+    const int64_t tiles = tiles_of(cfg);
+    const int BN = kBf3BN[cfg];
     const int64_t gb = d.a_split_grp_stride * 4;
-    const int rc = KS == 7 ? launch_bf3_ks<7>(d, s, (const unsigned char*)d.A_split, gb, nimg, cfg)
-                           : launch_bf3_ks<3>(d, s, (const unsigned char*)d.A_split, gb, nimg, cfg);
+    const int rc = KS == 7 ? launch_bf3_ks<7>(d, s, (const unsigned char*)d.A_split, gb, nimg, cfg, cps)
+                           : launch_bf3_ks<3>(d, s, (const unsigned char*)d.A_split, gb, nimg, cfg, cps);
     if (rc == IVLN_OK && d.stat_tiles) *d.stat_tiles = d.stat_partials ? (int)(tiles * (BN / 128)) : 0;
     return rc;
 }

@@ -340,7 +340,7 @@ class Deferred:
 # of the nine piece products, fp32 accumulation - as close to the exact conv as the fp32 MFMA kernels.
 # IVLN_SPLIT_BF16=0 keeps the fp32 MFMA kernels everywhere (A/B); the C side has IVLN_NO_SPLIT_BF16 for the same.
 SPLIT_BF16 = os.environ.get("IVLN_SPLIT_BF16", "1") != "0"
-SPLIT_BF16_MIN_OUT = int(os.environ.get("IVLN_SPLIT_BF16_MIN_OUT", str(1 << 20)))  # output elements below which nothing is packed
+SPLIT_BF16_MIN_OUT = int(os.environ.get("IVLN_SPLIT_BF16_MIN_OUT", str(1 << 18)))  # output elements below which nothing is packed
 _stat_ws = {}
 CONV_STATS = os.environ.get("IVLN_CONV_STATS", "1") != "0"  # A/B: BatchNorm statistics from the conv's epilogue
 

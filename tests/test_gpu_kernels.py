@@ -373,7 +373,11 @@ def test_conv2d_split_bf16_kernel(N, Cin, H, W, Cout, k):
         plain = ops.conv2d(xd, wd, pad=k // 2, splitk=False)
         again = ops.conv2d(xd, wd, pad=k // 2, splitk=False)
         wide = torch.zeros(N, Cout + 8, *ref0.shape[2:], device=DEV)
-        ops.conv2d(xd, wd, pad=k // 2, out=wide[:, 4:], out_ctot=Cout + 8)
+        ops.conv2d(xd, wd, pad=k // 2, out=wide[:, 4:], out_ctot=Cout + 8, splitk=False)
+        # with a workspace on hand small grids split their channel chunks over blockIdx.z (raw slabs + k_splitk_epilogue)
+        wide_k = torch.zeros(N, Cout + 8, *ref0.shape[2:], device=DEV)
+        ops.conv2d(xd, wd, pad=k // 2, out=wide_k[:, 4:], out_ctot=Cout + 8, scale=sc.to(DEV), shift=sh.to(DEV), relu=True)
+        got_k = ops.conv2d(xd, wd, pad=k // 2, scale=sc.to(DEV), shift=sh.to(DEV), residual=res.to(DEV), relu=True, splitk=True)
         ops.TILE_OVERRIDE = 6
         fp32 = ops.conv2d(xd, wd, pad=k // 2, splitk=False)
     finally:
@@ -386,6 +390,9 @@ def test_conv2d_split_bf16_kernel(N, Cin, H, W, Cout, k):
     _close(got, ref.float(), 3e-5)
     assert torch.equal(wide[:, 4:4 + Cout], plain)
     assert float(wide[:, :4].abs().max()) == 0.0 and float(wide[:, 4 + Cout:].abs().max()) == 0.0
+    _close(wide_k[:, 4:4 + Cout], F.relu(ref0 * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)).float(), 3e-5)
+    _close(got_k, ref.float(), 3e-5)
+    assert float(wide_k[:, :4].abs().max()) == 0.0 and float(wide_k[:, 4 + Cout:].abs().max()) == 0.0
 
 
 def test_conv2d_split_bf16_pieces_are_exact_and_specials_propagate():

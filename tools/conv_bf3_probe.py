@@ -17,16 +17,16 @@ what = sys.argv[1] if len(sys.argv) > 1 else "all"
 # (name, images, Cin, Cout, H, KS)
 MAP = [("map L1 fwd", 512, 14, 32, 64, 7), ("map L2 fwd", 512, 32, 64, 32, 7), ("map L3 fwd", 512, 64, 128, 16, 7),
        ("map L4 fwd", 512, 128, 128, 8, 7), ("map L2 dgrad", 512, 64, 32, 32, 7), ("map L3 dgrad", 512, 128, 64, 16, 7)]
-RED = [("rednet 64@128", 8, 64, 64, 128, 3), ("rednet 64@64", 16, 64, 64, 64, 3), ("rednet 128@64", 8, 128, 128, 64, 3),
-       ("rednet 128@32", 16, 128, 128, 32, 3), ("rednet 256@32", 8, 256, 256, 32, 3), ("rednet 256@16", 16, 256, 256, 16, 3),
-       ("rednet 512@16", 8, 512, 512, 16, 3), ("rednet 512@8", 16, 512, 512, 8, 3)]
+RED = [("rednet 64@128 x8", 8, 64, 64, 128, 3), ("rednet 64@64 x16", 16, 64, 64, 64, 3), ("rednet 64@64 x8", 8, 64, 64, 64, 3),
+       ("rednet 128@32 x16", 16, 128, 128, 32, 3), ("rednet 128@32 x8", 8, 128, 128, 32, 3), ("rednet 256@16 x16", 16, 256, 256, 16, 3),
+       ("rednet 256@16 x8", 8, 256, 256, 16, 3), ("rednet 512@8 x16", 16, 512, 512, 8, 3), ("rednet 512@8 x8", 8, 512, 512, 8, 3)]
 shapes = (MAP if what in ("map", "all") else []) + (RED if what in ("rednet", "all") else [])
 
 
 def run(x, w, b, mode):
     ops.TILE_OVERRIDE = mode
     try:
-        return ops.conv2d(x, w, stride=1, pad=w.shape[-1] // 2, shift=b, splitk=False)
+        return ops.conv2d(x, w, stride=1, pad=w.shape[-1] // 2, shift=b, splitk=True)
     finally:
         ops.TILE_OVERRIDE = 0
 
@@ -44,7 +44,7 @@ def timeit(f, iters=10):
     return a.elapsed_time(b) / iters * 1e3
 
 
-print(f"{'shape':<16} {'GFLOP':>7} | {'fp32 MFMA us':>12} {'TF/s':>6} | {'split-bf16 us':>13} {'TF/s':>6} {'x':>5} | max err vs f64 / max|y|: fp32 MFMA, split-bf16, torch f32")
+print(f"{'shape':<18} {'GFLOP':>7} | {'fp32 MFMA us':>12} {'TF/s':>6} | {'split-bf16 us':>13} {'TF/s':>6} {'x':>5} | max err vs f64 / max|y|: fp32 MFMA, split-bf16, torch f32")
 for name, n, cin, cout, hw, ks in shapes:
     torch.manual_seed(1)
     x = torch.randn(n, cin, hw, hw, device=dev)
@@ -54,7 +54,7 @@ for name, n, cin, cout, hw, ks in shapes:
     try:
         y9 = run(x, w, b, 9)
     except Exception as e:  # noqa: BLE001
-        print(f"{name:<16} split-bf16 not eligible: {e}")
+        print(f"{name:<18} split-bf16 not eligible: {e}")
         continue
     y6 = run(x, w, b, 6)
     k = min(n, 4)
@@ -66,5 +66,5 @@ for name, n, cin, cout, hw, ks in shapes:
     et = (yt.double() - ref).abs().max().item() / sc
     t6 = timeit(lambda: run(x, w, b, 6))
     t9 = timeit(lambda: run(x, w, b, 9))
-    print(f"{name:<16} {flops / 1e9:7.1f} | {t6:12.1f} {flops / t6 / 1e6:6.1f} | {t9:13.1f} {flops / t9 / 1e6:6.1f} {t6 / t9:5.2f} | "
+    print(f"{name:<18} {flops / 1e9:7.1f} | {t6:12.1f} {flops / t6 / 1e6:6.1f} | {t9:13.1f} {flops / t9 / 1e6:6.1f} {t6 / t9:5.2f} | "
           f"{e6:.2e} {e9:.2e} {et:.2e}")
