@@ -35,7 +35,8 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 constexpr int PIXB = 112;   // bytes per staged pixel: 3 pieces x 16 channels x 2 bytes + 16 of padding
 constexpr int CB = 16;      // input channels per chunk = K of one MFMA
 
-__host__ __device__ constexpr int bf3_taps_padded(int KS) { return KS == 7 ? 54 : 9; }  // multiple of every prefetch depth used (3, 6 | 3, 9)
+__host__ __device__ constexpr int bf3_taps_padded(int KS) { return KS == 7 ? 54 : (KS == 3 ? 9 : 1); }  // multiple of every prefetch depth used (3, 6 | 3, 9)
+__host__ __device__ constexpr int bf3_stage_chunks(int KS) { return KS == 1 ? 4 : 1; }  // 16-channel chunks staged per barrier pair (1x1: one tap per chunk)
 
 // x -> the upper 16 bits of its three pieces (see the header): round-to-nearest-even at each step, remainders exact.
 __device__ __forceinline__ uint32_t bf16_rne_bits(float v, bool& fin) {
@@ -75,10 +76,11 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_bf3(const ivln_gemm_desc 
     constexpr int NTB = 64 * WM * WN, TN = 2;
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     static_assert(IMGS * PTH * PTW == BN && PTW % 4 == 0, "pixel tile");
-    constexpr int KK = KS * KS, KKP = bf3_taps_padded(KS);
-    static_assert(KKP % DA == 0 && KKP >= KK, "prefetch rotation closes over a chunk");
+    constexpr int KK = KS * KS, KKP = bf3_taps_padded(KS), CS = bf3_stage_chunks(KS);
+    constexpr int RP = KKP * CS;  // taps (padded) between two barriers: a STAGE = CS chunks of 16 channels
+    static_assert(RP % DA == 0 && KKP >= KK && (CS == 1 || KK == 1), "prefetch rotation closes over a stage");
     constexpr int PH = PTH + KS - 1, PWR = PTW + KS - 1, NPIX = IMGS * PH * PWR;
-    constexpr int ITEMS = NPIX * (CB / 2), NPI = (ITEMS + NTB - 1) / NTB;
+    constexpr int ITEMS = NPIX * (CB / 2) * CS, NPI = (ITEMS + NTB - 1) / NTB;
     constexpr int LDT = BN + 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -98,23 +100,25 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_bf3(const ivln_gemm_desc 
     // patch items of this thread: (pixel, channel pair), consecutive threads on consecutive pixels of a row.  Offsets are
     // RE-DERIVED per chunk (a dozen integer ops per item against ~600 MFMAs): kept in registers they cost 2 x NPI VGPRs that
     // the operand double-buffering below needs (tt: an opaque copy of the thread id, so that the compiler does not hoist them)
+    // (cp: channel pair inside the STAGE, 0 .. 8 CS - 1; a 1x1 conv may be strided - no halo, the patch is the output tile)
     auto item = [&](int tt, int i, int& cp, int& src, int& dst) {
         const int idx = tt + i * NTB;
         cp = idx / NPIX;
         const int pix = idx - cp * NPIX;
         const int il = pix / (PH * PWR), rem = pix - il * (PH * PWR);
         const int y = rem / PWR, x = rem - y * PWR;
-        const int hi = ho0 - p.pad + y, wi = wo0 - p.pad + x, img = img0 + il;
+        const int hi = KS == 1 ? (ho0 + y) * p.stride : ho0 - p.pad + y, wi = KS == 1 ? (wo0 + x) * p.stride : wo0 - p.pad + x;
+        const int img = img0 + il;
         const bool ok = idx < ITEMS && img < nimg && (unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win;
         src = ok ? (int)((int64_t)img * p.in_img_stride + (int64_t)(2 * cp) * HW + hi * p.Win + wi) : -1;
-        dst = idx < ITEMS ? pix * PIXB + cp * 4 : -1;
+        dst = idx < ITEMS ? (cp >> 3) * (NPIX * PIXB) + pix * PIXB + (cp & 7) * 4 : -1;
     };
     float r0[NPI], r1[NPI];
     auto load_patch = [&](int c) {
         int tt = t;
         asm volatile("" : "+v"(tt));
-        const int cbase = c * CB * HW;
-        const int left = p.Cin - c * CB;  // channels this chunk still has (ragged last chunk: the rest reads as zero)
+        const int cbase = c * (CB * CS) * HW;
+        const int left = p.Cin - c * (CB * CS);  // channels this stage still has (ragged last chunk: the rest reads as zero)
 #pragma unroll
         for (int i = 0; i < NPI; ++i) {
             int cp, src, dst;
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_bf3(const ivln_gemm_desc 
     auto stage = [&](int c) {
         int tt = t;
         asm volatile("" : "+v"(tt));
-        const int left = p.Cin - c * CB;
+        const int left = p.Cin - c * (CB * CS);
 #pragma unroll
         for (int i = 0; i < NPI; ++i) {
             int cp, src, dst;
@@ -159,7 +163,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_bf3(const ivln_gemm_desc 
         const int mt = min(m0 / 32 + wm * TM + tm, (p.M + 31) / 32 - 1);  // (a channel tile past M reads the last one's weights; its rows are never stored)
         rA[tm] = bf3_rsrc(a_split + (int64_t)grp * a_grp_bytes + (int64_t)mt * nch * KKP * (3 * 1024));
     }
-    const int c_beg = bid.z * chunks_per_split, c_end = min(nch, c_beg + chunks_per_split);  // (split K: channel chunks over blockIdx.z)
+    const int nst = (nch + CS - 1) / CS;  // stages
+    const int c_beg = bid.z * chunks_per_split, c_end = min(nst, c_beg + chunks_per_split);  // (split K: stages over blockIdx.z)
     const int steps = nch * KKP;
     auto load_a = [&](int tm, int s, int pl) -> v4i {
         const int sc = s < steps ? s : steps - 1;
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_bf3(const ivln_gemm_desc 
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) abuf[d][tm][pl] = load_a(tm, c_beg * KKP + d, pl);
+            for (int pl = 0; pl < 3; ++pl) abuf[d][tm][pl] = load_a(tm, c_beg * RP + d, pl);
 
     unsigned long long tk0 = BF3_T(), t_stage = 0, t_mma = 0;
     (void)tk0;
@@ -195,10 +200,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_bf3(const ivln_gemm_desc 
         const unsigned long long tb = BF3_T();
         t_stage += tb - ta;
         if (c + 1 < c_end) load_patch(c + 1);  // in flight under the MFMA phase
-        const int s0 = c * KKP;
+        const int s0 = c * RP;
         auto read_b = [&](int r, bf16x8 (&b)[TN][3]) {  // the tap's B fragments: one ds_read_b128 per (pixel tile, piece)
             const int kh = r / KS, kw = r - kh * KS;
-            const int toff = (kh * PWR + kw) * PIXB;
+            const int toff = KS == 1 ? r * (NPIX * PIXB) : (kh * PWR + kw) * PIXB;  // (1x1: tap r = chunk r of the stage)
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
@@ -208,10 +213,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_bf3(const ivln_gemm_desc 
         bf16x8 bq[2][TN][3];  // this tap's fragments and the next tap's, read while this tap's MFMAs issue
         read_b(0, bq[0]);
 #pragma unroll
-        for (int r = 0; r < KKP; ++r) {
+        for (int r = 0; r < RP; ++r) {
             const int slot = r % DA;
-            if (r < KK) {
-                if (r + 1 < KK) read_b(r + 1, bq[(r + 1) & 1]);
+            if (r < KK * CS && (KS != 1 || c * CS + r < nch)) {  // (padding taps, and 1x1: chunks past the last one, issue nothing)
+                if (r + 1 < KK * CS) read_b(r + 1, bq[(r + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);  // (the reads stay AHEAD of this tap's MFMAs: left alone they sink to their use)
                 bf16x8 a[TM][3];
 #pragma unroll
@@ -231,7 +236,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_bf3(const ivln_gemm_desc 
 #undef IVLN_BF3_PROD
             }
             __builtin_amdgcn_sched_barrier(0);
-            // the slot just used receives the weights of DA taps ahead (the rotation closes over the chunk: KKP % DA == 0)
+            // the slot just used receives the weights of DA taps ahead (the rotation closes over the stage: RP % DA == 0)
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -346,7 +351,7 @@ __global__ __launch_bounds__(256) void k_conv_bf3_pack(const float* __restrict__
 template <int KS, int TM, int WM, int WN, int PTH, int PTW, int IMGS, int DA>
 int launch_bf3(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a_split, int64_t grp_bytes, int nimg, int cps) {
     constexpr int NTB = 64 * WM * WN, BM = 32 * TM * WM, BN = 64 * WN;
-    constexpr int PH = PTH + KS - 1, PWR = PTW + KS - 1, NPIX = IMGS * PH * PWR;
+    constexpr int PH = PTH + KS - 1, PWR = PTW + KS - 1, NPIX = IMGS * PH * PWR * bf3_stage_chunks(KS);
     constexpr size_t lds = (size_t)(NPIX * PIXB > 32 * (BN + 4) * 4 ? NPIX * PIXB : 32 * (BN + 4) * 4);
     static_assert(lds <= 160 * 1024, "patch does not fit");
     auto kern = k_conv_bf3<KS, TM, WM, WN, PTH, PTW, IMGS, DA>;
@@ -373,7 +378,9 @@ inline Bf3Px bf3_px(int BN, int Wout) {
 template <int KS, int TM, int WM, int WN, int DA>
 int launch_bf3_px(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a, int64_t gb, int nimg, int cps) {
     constexpr int BN = 64 * WN;
-    if constexpr (BN == 512) {
+    if constexpr (BN == 512 && KS == 1) {
+        return IVLN_E_UNSUPPORTED;  // (four staged chunks of 512 pixels do not fit the LDS)
+    } else if constexpr (BN == 512) {
         if (d.Wout > 16) return launch_bf3<KS, TM, WM, WN, 16, 32, 1, DA>(d, s, a, gb, nimg, cps);
         if (d.Wout > 8) return launch_bf3<KS, TM, WM, WN, 16, 16, 2, DA>(d, s, a, gb, nimg, cps);
         if constexpr (KS == 3) return launch_bf3<KS, TM, WM, WN, 8, 8, 8, DA>(d, s, a, gb, nimg, cps);
@@ -398,7 +405,7 @@ template <int KS>
 int launch_bf3_ks(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a, int64_t gb, int nimg, int cfg, int cps) {
     // weight taps in flight: a tap is 24 MFMAs = 768 pipe cycles per wave (12 = 384 with one channel tile per wave), an L2 /
     // MALL round trip ~2000
-    constexpr int DA2 = 3, DA1 = KS == 7 ? 6 : 9;
+    constexpr int DA2 = KS == 1 ? 2 : 3, DA1 = KS == 7 ? 6 : (KS == 3 ? 9 : 4);
     switch (cfg) {
         case 0: return launch_bf3_px<KS, 1, 1, 8, DA1>(d, s, a, gb, nimg, cps);   // 32 x 512, 8 waves
         case 1: return launch_bf3_px<KS, 2, 1, 8, DA2>(d, s, a, gb, nimg, cps);   // 64 x 512
@@ -412,7 +419,7 @@ int launch_bf3_ks(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a
 }  // namespace
 
 extern "C" int64_t ivln_conv_split_words(int M, int Cin, int KS) {
-    if ((KS != 3 && KS != 7) || M <= 0 || Cin <= 0) return 0;
+    if ((KS != 1 && KS != 3 && KS != 7) || M <= 0 || Cin <= 0) return 0;
     return (int64_t)((M + 31) / 32) * ((Cin + CB - 1) / CB) * bf3_taps_padded(KS) * (3 * 1024 / 4);
 }
 
@@ -438,16 +445,20 @@ extern "C" int ivln_conv_bf3_stamps(unsigned long long* host, int n) {
 int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
     static const bool disabled = getenv("IVLN_NO_SPLIT_BF16") != nullptr;  // A/B switch
     if (!d.A_split || (disabled && !force)) return IVLN_E_UNSUPPORTED;
-    const int KS = conv_ks(d.bmode);
-    if ((KS != 3 && KS != 7) || d.amode != AMODE_MK || d.dmode != DMODE_NCHW || d.stride != 1 || d.dil != 1 || d.pad != KS / 2)
+    const int KS = d.bmode == BMODE_CONV1X1 ? 1 : conv_ks(d.bmode);
+    if ((KS != 1 && KS != 3 && KS != 7) || d.amode != AMODE_MK || d.dmode != DMODE_NCHW || d.dil != 1) return IVLN_E_UNSUPPORTED;
+    if (KS == 1) {  // 1x1, stride 1 or 2, no padding
+        if ((d.stride != 1 && d.stride != 2) || d.pad != 0 || d.Hout != (d.Hin - 1) / d.stride + 1 || d.Wout != (d.Win - 1) / d.stride + 1 || d.M < 64)
+            return IVLN_E_UNSUPPORTED;
+    } else if (d.stride != 1 || d.pad != KS / 2 || d.Hout != d.Hin || d.Wout != d.Win) {
         return IVLN_E_UNSUPPORTED;
-    if (d.K != d.Cin * KS * KS || d.HoWo != d.Hout * d.Wout || d.N % d.HoWo != 0 || d.Hout != d.Hin || d.Wout != d.Win)
-        return IVLN_E_UNSUPPORTED;
+    }
+    if (d.K != d.Cin * KS * KS || d.HoWo != d.Hout * d.Wout || d.N % d.HoWo != 0) return IVLN_E_UNSUPPORTED;
     if (d.defer_epilogue || d.splits > 1 || (d.Wout & 3) || d.Wout < 8 || (((uintptr_t)d.D | (uintptr_t)d.residual | (uintptr_t)d.ws) & 15))
         return IVLN_E_UNSUPPORTED;
     const int nimg = d.N / d.HoWo;
     if ((int64_t)nimg * d.in_img_stride >= (int64_t)1 << 31) return IVLN_E_UNSUPPORTED;  // 32-bit patch offsets
-    const int nch = (d.Cin + CB - 1) / CB;
+    const int nch = ((d.Cin + CB - 1) / CB + bf3_stage_chunks(KS) - 1) / bf3_stage_chunks(KS);  // stages: what blockIdx.z can split
     auto tiles_of = [&](int cfg) {
         const Bf3Px t = bf3_px(kBf3BN[cfg], d.Wout);
         return (int64_t)((d.Wout + t.ptw - 1) / t.ptw) * ((d.Hout + t.pth - 1) / t.pth) * ((nimg + t.imgs - 1) / t.imgs);
@@ -468,11 +479,11 @@ int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
     //  2 M outputs - 57 vs 64 us on 128 x 16384, 50 vs 67 on 256 x 4096 and 512 x 1024 -, 64 x 128 below - 41 vs 46 on
     //  128 x 8192, 37.5 vs 44 on 256 x 2048 and 512 x 512; 64-channel convs that need them lose - 42 vs 38 us on 64 x 32768)
     if (d.M <= 32) cfg = 0;
-    else if (d.M <= 64) cfg = (big_ok && fills(blocks_of(1), 1)) ? 1 : (fills(blocks_of(2), 1) ? 2 : (force ? 4 : -1));
+    else if (d.M <= 64) cfg = (big_ok && KS != 1 && fills(blocks_of(1), 1)) ? 1 : (fills(blocks_of(2), 1) ? 2 : (force ? 4 : -1));
     else cfg = fills(blocks_of(3), 1) ? 3 : (fills(blocks_of(2), 1) ? 2 : ((int64_t)d.M * d.N >= (1 << 21) ? 5 : 4));
     if (cfg < 0) return IVLN_E_UNSUPPORTED;
     if (cfg_env >= 0 && cfg_env < kBf3Cfgs && !(cfg_env == 0 && d.M > 32)) cfg = cfg_env;
-    if (cfg == 0 && !big_ok) return IVLN_E_UNSUPPORTED;
+    if ((cfg == 0 && !big_ok) || (KS == 1 && cfg <= 1)) return IVLN_E_UNSUPPORTED;
     const int64_t nb = blocks_of(cfg);
     if (cfg >= 4) {
         const int slots = cfg == 4 ? 3 : 2;
@@ -500,8 +511,9 @@ int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
     const int64_t tiles = tiles_of(cfg);
     const int BN = kBf3BN[cfg];
     const int64_t gb = d.a_split_grp_stride * 4;
-    const int rc = KS == 7 ? launch_bf3_ks<7>(d, s, (const unsigned char*)d.A_split, gb, nimg, cfg, cps)
-                           : launch_bf3_ks<3>(d, s, (const unsigned char*)d.A_split, gb, nimg, cfg, cps);
+    const int rc = KS == 7   ? launch_bf3_ks<7>(d, s, (const unsigned char*)d.A_split, gb, nimg, cfg, cps)
+                   : KS == 3 ? launch_bf3_ks<3>(d, s, (const unsigned char*)d.A_split, gb, nimg, cfg, cps)
+                             : launch_bf3_ks<1>(d, s, (const unsigned char*)d.A_split, gb, nimg, cfg, cps);
     if (rc == IVLN_OK && d.stat_tiles) *d.stat_tiles = d.stat_partials ? (int)(tiles * (BN / 128)) : 0;
     return rc;
 }

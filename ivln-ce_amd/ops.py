@@ -340,6 +340,7 @@ class Deferred:
 # of the nine piece products, fp32 accumulation - as close to the exact conv as the fp32 MFMA kernels.
 # IVLN_SPLIT_BF16=0 keeps the fp32 MFMA kernels everywhere (A/B); the C side has IVLN_NO_SPLIT_BF16 for the same.
 SPLIT_BF16 = os.environ.get("IVLN_SPLIT_BF16", "1") != "0"
+SPLIT_BF16_1X1 = os.environ.get("IVLN_SPLIT_BF16_1X1", "0") == "1"
 SPLIT_BF16_MIN_OUT = int(os.environ.get("IVLN_SPLIT_BF16_MIN_OUT", str(1 << 18)))  # output elements below which nothing is packed
 _stat_ws = {}
 CONV_STATS = os.environ.get("IVLN_CONV_STATS", "1") != "0"  # A/B: BatchNorm statistics from the conv's epilogue
@@ -389,6 +390,15 @@ def conv2d(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, 
             if pk is not None:
                 d.A_packed = dptr(pk)
                 d.a_packed_grp_stride = pk.numel() // max(G, 1)
+        # 1x1 convs on the split-bf16 kernel (four 16-channel chunks staged per barrier pair): built, bit-checked, and SLOWER
+        # than the float4-staged fp32 GEMM on every RedNet shape (0.47-1.14x: 2-4 GFLOP calls with 4 taps between barriers) -
+        # off unless asked for (IVLN_SPLIT_BF16_1X1=1, or tile_override 9 in tests)
+        if ((SPLIT_BF16_1X1 or TILE_OVERRIDE == 9) and SPLIT_BF16 and stride in (1, 2) and Cin >= 128 and Cout >= 64 and Wo % 4 == 0 and Wo >= 8 and w.is_contiguous()
+                and not defer and (N * Ho * Wo * Cout >= SPLIT_BF16_MIN_OUT or TILE_OVERRIDE == 9)):
+            sp = packed_conv_weights(w, cache=not weight_is_temp, split=True)
+            if sp is not None:
+                d.A_split = dptr(sp)
+                d.a_split_grp_stride = sp.numel() // max(G, 1)
     elif KH == KW and KH in (3, 7) and dil == 1:
         d.bmode = B_CONV_K3 if KH == 3 else B_CONV_K7
         if stride in (1, 2) and PACK_WEIGHTS and w.is_contiguous():

@@ -455,6 +455,27 @@ def test_conv2d_split_bf16_image_grouped_weights_and_epilogue_statistics():
     _close(sr, (1.0 / torch.sqrt(y.double().var((0, 2, 3), unbiased=False) + 1e-5)).float(), 1e-4)
 
 
+@pytest.mark.parametrize("N,Cin,H,Cout,stride", [(16, 256, 16, 1024, 1), (8, 200, 32, 128, 1), (4, 128, 64, 512, 2), (16, 2048, 8, 64, 1)])
+def test_conv2d_split_bf16_1x1_form(N, Cin, H, Cout, stride):
+    """The kernel's 1x1 form (four 16-channel chunks staged per barrier pair, stride 1 or 2, ragged channel count): not on
+    by default - the float4-staged fp32 GEMM is faster on these shapes - but it has to be right."""
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = torch.randn(N, Cin, H, H, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=stride)
+    try:
+        ops.TILE_OVERRIDE = 9
+        got = ops.conv2d(x.to(DEV), w.to(DEV), stride=stride, shift=b.to(DEV))
+        one = ops.conv2d(x.to(DEV), w.to(DEV), stride=stride, shift=b.to(DEV), splitk=False)
+    finally:
+        ops.TILE_OVERRIDE = 0
+    for y in (got, one):
+        assert float((y.double().cpu() - ref).abs().max()) <= 3e-6 * float(ref.abs().max())
+
+
 def test_conv2d_split_bf16_refuses_what_it_is_not_built_for():
     from ivln_ce_amd import ops
     from ivln_ce_amd._lib import IvlnError
@@ -462,7 +483,7 @@ def test_conv2d_split_bf16_refuses_what_it_is_not_built_for():
     x = torch.randn(8, 32, 32, 32, device=DEV)
     for w, kw in [(torch.randn(32, 32, 3, 3, device=DEV), dict(stride=2, pad=1)),       # strided
                   (torch.randn(32, 32, 3, 3, device=DEV), dict(pad=0)),                   # not same-size
-                  (torch.randn(32, 32, 1, 1, device=DEV), dict(pad=0)),                   # 1x1
+                  (torch.randn(32, 32, 1, 1, device=DEV), dict(pad=0)),                   # 1x1 into 32 channels (below its 64-channel tiles)
                   (torch.randn(32, 32, 5, 5, device=DEV), dict(pad=2))]:                  # 5x5
         try:
             ops.TILE_OVERRIDE = 9

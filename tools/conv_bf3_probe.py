@@ -20,13 +20,30 @@ MAP = [("map L1 fwd", 512, 14, 32, 64, 7), ("map L2 fwd", 512, 32, 64, 32, 7), (
 RED = [("rednet 64@128 x8", 8, 64, 64, 128, 3), ("rednet 64@64 x16", 16, 64, 64, 64, 3), ("rednet 64@64 x8", 8, 64, 64, 64, 3),
        ("rednet 128@32 x16", 16, 128, 128, 32, 3), ("rednet 128@32 x8", 8, 128, 128, 32, 3), ("rednet 256@16 x16", 16, 256, 256, 16, 3),
        ("rednet 256@16 x8", 8, 256, 256, 16, 3), ("rednet 512@8 x16", 16, 512, 512, 8, 3), ("rednet 512@8 x8", 8, 512, 512, 8, 3)]
-shapes = (MAP if what in ("map", "all") else []) + (RED if what in ("rednet", "all") else [])
+ONE = [("1x1 1024<-256 @16 x16", 16, 256, 1024, 16, 1), ("1x1 256<-1024 @16 x16", 16, 1024, 256, 16, 1), ("1x1 512<-128 @32 x16", 16, 128, 512, 32, 1),
+       ("1x1 2048<-512 @8 x16", 16, 512, 2048, 8, 1), ("1x1 128<-512 @32 x16", 16, 512, 128, 32, 1), ("1x1 512<-2048 @8 x16", 16, 2048, 512, 8, 1),
+       ("1x1 128<-256 @64 x16", 16, 256, 128, 64, 1), ("1x1 512<-1024 @16 x16", 16, 1024, 512, 16, 1), ("1x1 256<-512 @32 x16", 16, 512, 256, 32, 1),
+       ("1x1 1024<-256 @16 x8", 8, 256, 1024, 16, 1), ("1x1 256<-1024 @16 x8", 8, 1024, 256, 16, 1)]
+RED = RED + ONE if what in ("rednet", "all", "one") else RED
+if what == "one":
+    RED = ONE
+shapes = (MAP if what in ("map", "all") else []) + (RED if what in ("rednet", "all", "one") else [])
 
 
 def run(x, w, b, mode):
     ops.TILE_OVERRIDE = mode
     try:
         return ops.conv2d(x, w, stride=1, pad=w.shape[-1] // 2, shift=b, splitk=True)
+    except Exception:  # noqa: BLE001
+        if mode == 6:  # (1x1: the fp32 path is the float4-staged GEMM, not the direct kernel)
+            ops.TILE_OVERRIDE = 0
+            sb = ops.SPLIT_BF16
+            ops.SPLIT_BF16 = False
+            try:
+                return ops.conv2d(x, w, stride=1, pad=w.shape[-1] // 2, shift=b, splitk=True)
+            finally:
+                ops.SPLIT_BF16 = sb
+        raise
     finally:
         ops.TILE_OVERRIDE = 0
 
