@@ -397,9 +397,9 @@ int launch_bf3_px(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a
 }
 
 // block tiles: {channels, pixels, waves}
-constexpr int kBf3Cfgs = 6;
-constexpr int kBf3BM[kBf3Cfgs] = {32, 64, 64, 128, 64, 128};
-constexpr int kBf3BN[kBf3Cfgs] = {512, 512, 256, 256, 128, 128};
+constexpr int kBf3Cfgs = 7;
+constexpr int kBf3BM[kBf3Cfgs] = {32, 64, 64, 128, 64, 128, 32};
+constexpr int kBf3BN[kBf3Cfgs] = {512, 512, 256, 256, 128, 128, 256};
 
 template <int KS>
 int launch_bf3_ks(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a, int64_t gb, int nimg, int cfg, int cps) {
@@ -412,7 +412,8 @@ int launch_bf3_ks(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a
         case 2: return launch_bf3_px<KS, 1, 2, 4, DA1>(d, s, a, gb, nimg, cps);   // 64 x 256
         case 3: return launch_bf3_px<KS, 2, 2, 4, DA2>(d, s, a, gb, nimg, cps);   // 128 x 256
         case 4: return launch_bf3_px<KS, 1, 2, 2, DA1>(d, s, a, gb, nimg, cps);   // 64 x 128, 4 waves: several workgroups per CU
-        default: return launch_bf3_px<KS, 2, 2, 2, DA2>(d, s, a, gb, nimg, cps);  // 128 x 128, 4 waves
+        case 5: return launch_bf3_px<KS, 2, 2, 2, DA2>(d, s, a, gb, nimg, cps);   // 128 x 128, 4 waves
+        default: return launch_bf3_px<KS, 1, 1, 4, DA1>(d, s, a, gb, nimg, cps);  // 32 x 256, 4 waves: two workgroups per CU
     }
 }
 
@@ -478,12 +479,13 @@ int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
     // (4-wave tiles, measured on RedNet's 3x3 shapes at 8 + 8 stacked images against the fp32 kernels: 128 x 128 wins from
     //  2 M outputs - 57 vs 64 us on 128 x 16384, 50 vs 67 on 256 x 4096 and 512 x 1024 -, 64 x 128 below - 41 vs 46 on
     //  128 x 8192, 37.5 vs 44 on 256 x 2048 and 512 x 512; 64-channel convs that need them lose - 42 vs 38 us on 64 x 32768)
-    if (d.M <= 32) cfg = 0;
+    static const int cfg32_env = getenv("IVLN_SPLIT_BF16_CFG32") ? atoi(getenv("IVLN_SPLIT_BF16_CFG32")) : -1;  // tuning: 0 | 6
+    if (d.M <= 32) cfg = cfg32_env >= 0 ? cfg32_env : 6;
     else if (d.M <= 64) cfg = (big_ok && KS != 1 && fills(blocks_of(1), 1)) ? 1 : (fills(blocks_of(2), 1) ? 2 : (force ? 4 : -1));
     else cfg = fills(blocks_of(3), 1) ? 3 : (fills(blocks_of(2), 1) ? 2 : ((int64_t)d.M * d.N >= (1 << 21) ? 5 : 4));
     if (cfg < 0) return IVLN_E_UNSUPPORTED;
-    if (cfg_env >= 0 && cfg_env < kBf3Cfgs && !(cfg_env == 0 && d.M > 32)) cfg = cfg_env;
-    if ((cfg == 0 && !big_ok) || (KS == 1 && cfg <= 1)) return IVLN_E_UNSUPPORTED;
+    if (cfg_env >= 0 && cfg_env < kBf3Cfgs && !((cfg_env == 0 || cfg_env == 6) && d.M > 32)) cfg = cfg_env;
+    if ((cfg == 0 && !big_ok) || (KS == 1 && (cfg <= 1 || cfg == 6))) return IVLN_E_UNSUPPORTED;
     const int64_t nb = blocks_of(cfg);
     if (cfg >= 4) {
         const int slots = cfg == 4 ? 3 : 2;
@@ -499,7 +501,7 @@ int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
         }
         if (split_env > 0 && may_split) splits = split_env > nch ? nch : split_env;
         if (!force && nb * splits < 192) return IVLN_E_UNSUPPORTED;  // pixel- and channel-starved: the implicit GEMM splits K deeper
-    } else if (!force && !fills(nb, 1)) {
+    } else if (!force && !fills(nb, cfg == 6 ? 2 : 1)) {
         return IVLN_E_UNSUPPORTED;
     }
     const int cps = (nch + splits - 1) / splits;
