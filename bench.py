@@ -39,8 +39,12 @@ import torch  # noqa: E402
 
 METRIC = "env-steps/sec (batched MapCMA fwd+bwd) at 1/2/4/8 MI355X; t-nDTW parity"
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+# the same guide's dense bf16 MFMA peak; a conv on the split-bf16 kernel (csrc/conv_bf3.hip) issues SIX bf16 MFMA FLOPs per
+# algorithmic fp32 FLOP, so its share of a step is bounded by this / 6 = 416.7 "fp32-equivalent" TFLOP/s
+PEAK_BF16_MFMA_TFLOPS = 2500.0
+SPLIT_PRODUCTS = 6
 PEAK_HBM_GBS = 8000.0  # same guide: HBM3E 8 TB/s spec (6.3 TB/s achievable)
-MFMA_FAMILY = "fp32 MFMA family (k_gemm / k_gemm_vec / k_conv_direct / k_depth_net / k_gn_conv / k_nconv)"
+MFMA_FAMILY = "MFMA family (fp32: k_gemm / k_gemm_vec / k_conv_direct / k_depth_net / k_gn_conv / k_nconv; split-bf16: k_conv_bf3)"
 
 
 def log(*a):
@@ -149,6 +153,9 @@ class GemmTimer:
         ops.gemm = timed
         ops.gn_conv = timed_gn_conv
         ops.nconv = timed_nconv
+        self._lib.ivln_conv_split_counters.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]
+        self._lib.ivln_conv_split_counters(None, None, 1)  # the convs that take the split-bf16 kernel are tallied by the library
+        self.split_flops, self.split_launches = 0.0, 0
         self._check(self._lib.ivln_family_timing_begin(self.MAX_LAUNCHES), "ivln_family_timing_begin")
         return self
 
@@ -170,6 +177,9 @@ class GemmTimer:
             if dropped.value:
                 raise RuntimeError(f"GemmTimer: {dropped.value} launches beyond MAX_LAUNCHES went untimed")
             self._ms, self.launches = ms.value, n.value
+            f, k = C.c_double(0.0), C.c_longlong(0)
+            self._lib.ivln_conv_split_counters(C.byref(f), C.byref(k), 0)
+            self.split_flops, self.split_launches = f.value, k.value
         return self._ms
 
 
@@ -178,6 +188,27 @@ def stats_of(ms_list):
     v = sorted(ms_list)
     med = v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
     return med, v[0], v[-1]
+
+
+def split_bf16_part(gt, n_steps, ms_per_step):
+    """The family's convs that ran on the split-bf16 kernel (csrc/conv_bf3.hip): their algorithmic fp32 FLOPs are inside
+    `flops_per_step` / `achieved` like everybody else's, but the matrix cores executed SIX bf16 FLOPs for each of them, and
+    the bound they are up against is the bf16 peak / 6, not the fp32 MFMA peak - `frac` (priced on the fp32 peak, as the
+    contract asks for the dtype) can therefore pass 1.  `frac_of_mixed_bound` prices each part on its own pipe rate:
+    (fp32 part / 157.3 + split part / 416.7) / measured time, always <= 1."""
+    sf = getattr(gt, "split_flops", 0.0) / n_steps
+    if sf <= 0:
+        return None
+    rest = max(gt.flops / n_steps - sf, 0.0)
+    bound_ms = (rest / (PEAK_F32_MFMA_TFLOPS * 1e12) + sf * SPLIT_PRODUCTS / (PEAK_BF16_MFMA_TFLOPS * 1e12)) * 1e3
+    return {
+        "algorithmic_flops_per_step": int(sf), "share_of_family_flops": round(sf / (gt.flops / n_steps), 4),
+        "launches_per_step": round(getattr(gt, "split_launches", 0) / n_steps, 1),
+        "executed_bf16_flops_per_step": int(sf * SPLIT_PRODUCTS), "bf16_peak": PEAK_BF16_MFMA_TFLOPS,
+        "frac_of_mixed_bound": round(bound_ms / ms_per_step, 5) if ms_per_step > 0 else None,
+        "what": "3x3 / 7x7 convs with both operands as three bf16 pieces each, six piece products per fp32 product on "
+                "v_mfma_f32_32x32x16_bf16, fp32 accumulation: as close to the exact conv as the fp32 MFMA kernels (tests)",
+    }
 
 
 def mfma_roofline(gt, ms, n_steps, traffic, what, wall_ms_per_step=None):
@@ -190,7 +221,9 @@ def mfma_roofline(gt, ms, n_steps, traffic, what, wall_ms_per_step=None):
     k_ach = (gt.flops / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
     ach = (flops_step / (wall_ms_per_step * 1e-3)) / 1e12 if wall_ms_per_step else k_ach
     per_launch, per_step = traffic if isinstance(traffic, tuple) else (traffic, None)
+    split = split_bf16_part(gt, n_steps, wall_ms_per_step if wall_ms_per_step else ms / n_steps)
     return {
+        "split_bf16": split,
         "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
         "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 5), "traffic": per_launch,
         "traffic_unit": "HBM bytes per launch of the family (rocprofv3 PMC passes committed under profiles/)",
@@ -409,13 +442,15 @@ class UpdateLeg:
             AuxLosses.deactivate()
         ach = (gt.flops / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
         tr = pmc_traffic_pair("update_pmc_traffic.json")
-        return {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+        return {"split_bf16": split_bf16_part(gt, 1, ms),
+                "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None if tr is None else tr[0],
                 "traffic_unit": "HBM bytes per launch of the family (rocprofv3 PMC passes committed under profiles/)",
                 "traffic_bytes_per_update": None if tr is None else tr[1],
                 "flops_per_update": int(gt.flops), "launches_per_update": gt.launches, "kernel_ms_per_update": round(ms, 3),
                 "basis": "algorithmic FLOPs / summed kernel durations of the family (single-stream instrumented pass)",
-                "kernel": "fp32 MFMA family: k_conv_direct / k_wgrad_direct / k_gemm_vec / k_gemm"}
+                "kernel": "MFMA family: k_conv_bf3 (split-bf16: the map CNN's forward convs and input gradients) / k_wgrad_direct / "
+                          "k_gemm_vec / k_gemm (fp32 MFMA)"}
 
     def cpu_baseline(self, budget_s=25.0):
         """The oracle's update on the host cores: `MapCMAPolicyRef.update_loss` (base_il_trainer.py:173-219 restated
@@ -933,6 +968,10 @@ def main():
         "metric": METRIC, "value": head["value"], "unit": "env-steps/s", "n_gpus": world,
         "steps": K, "warmup": W, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "dtype_note": "fp32 in, fp32 out, fp32 accumulation everywhere; the large 3x3 / 7x7 convs form their fp32 products from "
+                      "three bf16 pieces per operand on the bf16 MFMA pipe (six piece products, the dropped ones < 2^-23 of a "
+                      "product: error vs float64 at or below the fp32 MFMA kernels', tests/test_gpu_kernels.py; IVLN_SPLIT_BF16=0 "
+                      "keeps every conv on the fp32 MFMA kernels)",
         "repetitions": head["repetitions"],
         "config": dict(head["config"], parallelism=f"dp{world} (envs sharded, no data-path collective)",
                        headline=("configs[2], the largest single-GPU configuration of BASELINE.json (configs[0] is the CPU "

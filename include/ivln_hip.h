@@ -188,7 +188,7 @@ typedef struct ivln_gemm_desc {
     int* stat_tiles;
     /* optional (stride-1 same-size 3x3 / 7x7 convs into an NCHW destination, Wout a multiple of 4 and >= 8): the weights
      * split into three bf16 pieces per value and arranged per MFMA lane by ivln_conv_split_weights_f32
-     * (ivln_conv_split_words(M, Cin, KS) 4-byte words per weight set; a_split_grp_stride = words between the sets of an
+     * (ivln_conv_split_words(M, Cin, KS) 4-byte words per weight set, KS 1 / 3 / 7; a_split_grp_stride = words between the sets of an
      * image-grouped conv).  When set and the shape fills the chip, the conv runs on the bf16 MFMA pipe with BOTH operands
      * carried as three bf16 pieces (exact) and six of the nine piece products accumulated in fp32: the dropped ones are
      * below 2^-23 of a product, i.e. the result is as close to the exact convolution as the fp32 MFMA kernel's
@@ -200,9 +200,12 @@ typedef struct ivln_gemm_desc {
 
 int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream);
 /* Weights (M, Cin, KS, KS) fp32 -> the split-bf16 image ivln_gemm_desc.A_split expects: out holds
- * ivln_conv_split_words(M, Cin, KS) 4-byte words (0: KS is not 3 or 7). */
+ * ivln_conv_split_words(M, Cin, KS) 4-byte words (0: KS is not 1, 3 or 7). */
 int64_t ivln_conv_split_words(int M, int Cin, int KS);
 int ivln_conv_split_weights_f32(const float* W, int M, int Cin, int KS, void* out, void* stream);
+/* Tally of the convs ivln_gemm_f32 sent to the split-bf16 kernel since the last reset: algorithmic FLOPs (2 M N K) and
+ * launches (host side, at enqueue; measurement aid of bench.py - a captured graph's replays are not counted). */
+int ivln_conv_split_counters(double* flops, long long* launches, int reset);
 
 /* Duration sink of the MFMA family's launches (ivln_gemm_f32 - its split-K reduction excluded -, ivln_gn_conv_f32,
  * ivln_nconv_f32, ivln_conv_gn_f32): between _begin and _end every such launch carries a start / stop event of its own

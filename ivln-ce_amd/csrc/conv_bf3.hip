@@ -434,6 +434,17 @@ extern "C" int ivln_conv_split_weights_f32(const float* W, int M, int Cin, int K
 }
 
 // Eligibility + tile choice.  IVLN_E_UNSUPPORTED sends the caller to the fp32 MFMA kernels.
+// What went through this kernel since the last reset: algorithmic FLOPs (2 M N K of the convs it took) and launches -
+// bench.py prices them against the bf16 peak / 6 instead of the fp32 MFMA peak.  Host-side tally, not thread-safe.
+static double g_bf3_flops = 0.0;
+static long long g_bf3_launches = 0;
+extern "C" int ivln_conv_split_counters(double* flops, long long* launches, int reset) {
+    if (flops) *flops = g_bf3_flops;
+    if (launches) *launches = g_bf3_launches;
+    if (reset) g_bf3_flops = 0.0, g_bf3_launches = 0;
+    return IVLN_OK;
+}
+
 #ifdef BF3_TIMING
 extern "C" int ivln_conv_bf3_stamps(unsigned long long* host, int n) {
     if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_bf3_stamp), sizeof(unsigned long long) * n) != hipSuccess) return -1;
@@ -516,6 +527,7 @@ int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
     const int rc = KS == 7   ? launch_bf3_ks<7>(d, s, (const unsigned char*)d.A_split, gb, nimg, cfg, cps)
                    : KS == 3 ? launch_bf3_ks<3>(d, s, (const unsigned char*)d.A_split, gb, nimg, cfg, cps)
                              : launch_bf3_ks<1>(d, s, (const unsigned char*)d.A_split, gb, nimg, cfg, cps);
+    if (rc == IVLN_OK) g_bf3_flops += 2.0 * d.M * (double)d.N * d.K, ++g_bf3_launches;
     if (rc == IVLN_OK && d.stat_tiles) *d.stat_tiles = d.stat_partials ? (int)(tiles * (BN / 128)) : 0;
     return rc;
 }

@@ -32,11 +32,16 @@ def test_bench_line_carries_the_contract_at_one_gpu():
     # wall-clock basis: achieved = flops per step / ms per step of the timed (median) repetition
     assert abs(roof["achieved"] - roof["flops_per_step"] / (d["ms_per_step"] * 1e-3) / 1e12) < 0.02 * roof["achieved"]
     assert roof["kernel_time"]["frac"] > 0 and roof["traffic"] is not None
+    # the convs that ran on the split-bf16 kernel are spelled out, and priced on their own pipe rate the step stays below 1
+    sp = roof["split_bf16"]
+    assert sp is not None and 0.0 < sp["share_of_family_flops"] < 1.0 and 0.0 < sp["frac_of_mixed_bound"] < 1.0
+    assert sp["executed_bf16_flops_per_step"] == 6 * sp["algorithmic_flops_per_step"] and "dtype_note" in d
     gt = d["gt_semantics_step"]
     assert "configs[1]" in gt["config"]["workload"] and gt["envs_per_gpu"] == 4 and gt["roofline"]["frac"] > 0
     assert gt["mapper_roofline"]["bound"] == "hbm"
     up = d["update_step"]
     assert up["unit"] == "rows/s" and up["repetitions"]["n"] == 3 and up["roofline"]["traffic"] is not None
+    assert 0.0 < up["roofline"]["split_bf16"]["frac_of_mixed_bound"] < 1.0
     assert d["dagger_collect_step"]["envs_per_gpu"] == 8
     it = d["dagger_iteration"]
     assert it["iterations"] >= 3 and it["ms_per_iteration"] > 0 and it["legs_alone"]["ms_per_iteration"] > 0
