@@ -23,6 +23,10 @@ timeout 100 python tools/depth_net_phases.py 8 2>&1 | grep "per launch\|sum of" 
 timeout 600 python bench.py > $O/bench_full.json 2> $O/bench_full.err
 timeout 300 python bench.py --gt-semantics --envs 8 --no-update --no-collect --no-pred-leg --no-cpu-baseline > $O/bench_gt_B8.json 2> $O/bench_gt_B8.err
 IVLN_REDNET_PLAN=0 timeout 200 python tools/gemm_shapes.py rednet > $O/rednet_B8_gemm_shapes.txt 2>&1
+# the split-bf16 conv against the fp32 MFMA kernels: time, error against float64, and where its workgroups spend their time
+timeout 300 python tools/conv_bf3_probe.py all > $O/conv_bf3_probe.txt 2>&1
+timeout 300 python tools/conv_bf3_phases.py > $O/conv_bf3_phases.txt 2>&1
+IVLN_SPLIT_BF16=0 timeout 300 python bench.py --no-cpu-baseline --no-collect --reps 3 > $O/bench_fp32_only.json 2> $O/bench_fp32_only.err
 # where the split replay's time goes (end of each graph, per step), default build and the launch chain it replaced
 for B in 4 8; do
   for m in 1 0; do echo "== envs $B IVLN_DEPTH_NET=$m"; IVLN_DEPTH_NET=$m timeout 200 python tools/split_probe.py gt $B 2>&1 | tail -2; done
