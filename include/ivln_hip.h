@@ -196,6 +196,10 @@ typedef struct ivln_gemm_desc {
      * IVLN_NO_SPLIT_BF16 in the environment keeps the fp32 MFMA kernels (A/B).  A must still be given. */
     const void* A_split;
     int64_t a_split_grp_stride;
+    /* 1: the weight gradient of a 7x7 same-size conv (A_NCHW_P x B_IM2COL_T -> dense) may run on the same split-bf16
+     * arithmetic (k_wgrad_bf3: both operands are activations, split while they are staged - nothing to pre-arrange);
+     * tile_override 9 insists on it. */
+    int split_ok;
 } ivln_gemm_desc;
 
 int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream);

@@ -59,6 +59,24 @@ __device__ __forceinline__ void split3(float x, uint32_t& h, uint32_t& m, uint32
     l = lb >> 16;
 }
 
+// Two values at once, on v_cvt_pk_bf16_f32 (round to nearest even, two floats -> one packed word: first value in the low half):
+// 11 VALU operations per pair and piece set instead of ~40.  What the staging passes use; non-finite values: the first piece
+// carries them, the remainders turn NaN (the header's "an infinity can come out as NaN"), and a finite value within 2^-9 of
+// FLT_MAX rounds its first piece to infinity.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ void split3_pair(float v0, float v1, uint32_t& H, uint32_t& M, uint32_t& L) {
+    H = cvt_pk_bf16(v0, v1);
+    const float r0 = __fsub_rn(v0, __uint_as_float(H << 16)), r1 = __fsub_rn(v1, __uint_as_float(H & 0xFFFF0000u));
+    M = cvt_pk_bf16(r0, r1);
+    const float q0 = __fsub_rn(r0, __uint_as_float(M << 16)), q1 = __fsub_rn(r1, __uint_as_float(M & 0xFFFF0000u));
+    L = cvt_pk_bf16(q0, q1);
+}
+
 #ifdef BF3_TIMING  // tools/conv_bf3_phases.py: per-workgroup phase sums (100 MHz wall clock): prologue, staging, MFMA, epilogue
 __device__ unsigned long long g_bf3_stamp[8192 * 4];
 #define BF3_T() (threadIdx.x == 0 ? wall_clock64() : 0ull)
@@ -139,12 +157,11 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_bf3(const ivln_gemm_desc 
             if (dst < 0) continue;
             const float v0 = (src >= 0 && 2 * cp < left) ? r0[i] : 0.f;
             const float v1 = (src >= 0 && 2 * cp + 1 < left) ? r1[i] : 0.f;
-            uint32_t h0, m0_, l0, h1, m1, l1;
-            split3(v0, h0, m0_, l0);
-            split3(v1, h1, m1, l1);
-            *reinterpret_cast<uint32_t*>(smem + dst) = h0 | (h1 << 16);
-            *reinterpret_cast<uint32_t*>(smem + dst + 32) = m0_ | (m1 << 16);
-            *reinterpret_cast<uint32_t*>(smem + dst + 64) = l0 | (l1 << 16);
+            uint32_t H, M, L;
+            split3_pair(v0, v1, H, M, L);
+            *reinterpret_cast<uint32_t*>(smem + dst) = H;
+            *reinterpret_cast<uint32_t*>(smem + dst + 32) = M;
+            *reinterpret_cast<uint32_t*>(smem + dst + 64) = L;
         }
     };
 
@@ -417,6 +434,245 @@ int launch_bf3_ks(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Weight gradient of a 7x7 same-size conv on the same arithmetic (map CNN, base_il_trainer.py:173-219):
+//   dW[co][(ci,kh,kw)] = sum over pixels p of dy[co][p] * x[ci][p + (kh,kw) - pad]      M = Cout, N = Cin * 49, K = pixels.
+// K of an MFMA = 16 consecutive pixels of an output row (W = 8: two rows of 8), a lane's 8 k-values = 8 consecutive pixels.
+//   * A = dy: a STRIP of 128 pixels (2 / 4 / 8 rows of one image, or two 8x8 images) per (channel, piece) as a row of 256 + 16
+//     bytes in LDS: one ds_read_b128 per fragment, 16 lanes on 16 distinct bank quads;
+//   * B = x: the column's (kh, kw) moves the fragment by kw PIXELS = 2 kw bytes in a bf16 row, which ds_read_b128 cannot
+//     address.  The patch of the strip ((rows + 6) x (W + 6) pixels of the <= 7 / 12 input channels the column tile touches)
+//     is kept as TWO copies per piece, pixel pairs (2j, 2j+1) and (2j+1, 2j+2): every kw is 4-byte aligned in one of them and
+//     a fragment is four ds_read_b32 from a per-lane base ((ci, kh, kw) of the lane's column) + an immediate (the k-step);
+//   * strips are split over blockIdx.z (M x N is tiny, K is millions of pixels): raw slabs, reduced in fixed order by the
+//     family's k_splitk_epilogue like the fp32 weight-gradient kernel's;
+//   * the next strip's dy pairs and x triples fly under the MFMA phase in registers, are split and written after the barrier.
+// ------------------------------------------------------------------------------------------------------------------
+template <int TM, int WM, int WN, int W>
+__global__ __launch_bounds__(512) void k_wgrad_bf3(const ivln_gemm_desc p, int nimg, int strips_total, int strips_per_split) {
+    static_assert(WM * WN == 8, "eight waves");
+    constexpr int NTB = 512, TN = 2, KS = 7, KK = 49;
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr int IMS = W == 8 ? 2 : 1, ROWS = 128 / (W * IMS);   // a strip: IMS images x ROWS rows x W columns = 128 pixels
+    constexpr int PR = ROWS + KS - 1, PRT = IMS * PR, PWP = W + KS - 1;
+    constexpr int XW = PWP / 2 + 1;                                // pixel-pair words a patch row needs in either copy
+    constexpr int XP = (XW | 1);                                   // row pitch in words (odd)
+    constexpr int NCIB = (BN + KK - 1) / KK + 1;                   // input channels a column tile can touch
+    constexpr int DP = 272;                                        // bytes per (channel, piece) row of dy: 128 bf16 + 16
+    constexpr int CHB = PRT * XP * 4, PLB = NCIB * CHB, CPYB = 3 * PLB;
+    constexpr int DYB = 3 * BM * DP;                               // dy region in front of the x region
+    constexpr int NDI = BM * 64 / NTB, NX = NCIB * PRT * XW, NXI = (NX + NTB - 1) / NTB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const xS = smem + DYB;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wm = wave / WN, wn = wave % WN;
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    const int ci_lo = n0 / KK;
+    const int spi = p.Hout / ROWS;  // strips per image (W = 8: one strip = two whole images)
+    const int HWo = p.HoWo, HWi = p.Hin * p.Win;
+    const float* __restrict__ dy = p.A;
+    const float* __restrict__ x = p.B;
+
+    // per-lane operand bases
+    int abase[TM], bbase[TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) abase[tm] = ((wm * TM + tm) * 32 + l31) * DP + half * 16;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int n = min(n0 + (wn * TN + tn) * 32 + l31, p.N - 1);  // (columns past N compute a duplicate; never stored)
+        const int ci = n / KK, rem = n - ci * KK, kh = rem / KS, kw = rem - kh * KS, sft = kw & 1;
+        bbase[tn] = sft * CPYB + (ci - ci_lo) * CHB + kh * (XP * 4) + ((kw - sft) >> 1) * 4 + (W >= 16 ? half * 16 : half * (XP * 4));
+    }
+
+    float2 dyv[NDI];
+    float xv[NXI][3];
+    auto strip_origin = [&](int st, int& img0, int& row0) {
+        img0 = (st / spi) * IMS;
+        row0 = (st - (st / spi) * spi) * ROWS;
+    };
+    auto load_strip = [&](int st) {
+        int img0, row0;
+        strip_origin(st, img0, row0);
+        int tt = t;
+        asm volatile("" : "+v"(tt));
+#pragma unroll
+        for (int i = 0; i < NDI; ++i) {  // dy: (channel, pixel pair)
+            const int idx = tt + i * NTB;
+            const int co = idx >> 6, px = (idx & 63) * 2;
+            const int il = px / (ROWS * W), q = px - il * (ROWS * W);
+            const int img = img0 + il;
+            const bool ok = m0 + co < p.M && img < nimg;
+            dyv[i] = ok ? *reinterpret_cast<const float2*>(dy + ((int64_t)img * p.M + m0 + co) * HWo + row0 * W + q) : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < NXI; ++i) {  // x: (channel, patch row, pixel-pair word): columns 2j, 2j+1, 2j+2 of the patch
+            const int idx = tt + i * NTB;
+            const int cl = idx / (PRT * XW), rem = idx - cl * (PRT * XW);
+            const int prow = rem / XW, j = rem - prow * XW;
+            const int il = prow / PR, pr = prow - il * PR;
+            const int img = img0 + il, hi = row0 + pr - p.pad, ci = ci_lo + cl;
+            const bool rok = idx < NX && ci < p.Cin && img < nimg && (unsigned)hi < (unsigned)p.Hin;
+            const float* src = x + (int64_t)img * p.in_img_stride + (int64_t)ci * HWi + hi * p.Win;
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                const int wi = 2 * j + e - p.pad;
+                xv[i][e] = (rok && (unsigned)wi < (unsigned)p.Win) ? src[wi] : 0.f;
+            }
+        }
+    };
+    auto stage_strip = [&]() {
+        int tt = t;
+        asm volatile("" : "+v"(tt));
+#pragma unroll
+        for (int i = 0; i < NDI; ++i) {
+            const int idx = tt + i * NTB;
+            const int co = idx >> 6, pr = idx & 63;
+            uint32_t H, M, L;
+            split3_pair(dyv[i].x, dyv[i].y, H, M, L);
+            unsigned char* d = smem + co * DP + pr * 4;
+            *reinterpret_cast<uint32_t*>(d) = H;
+            *reinterpret_cast<uint32_t*>(d + BM * DP) = M;
+            *reinterpret_cast<uint32_t*>(d + 2 * BM * DP) = L;
+        }
+#pragma unroll
+        for (int i = 0; i < NXI; ++i) {
+            const int idx = tt + i * NTB;
+            if (idx >= NX) continue;
+            const int cl = idx / (PRT * XW), rem = idx - cl * (PRT * XW);
+            const int prow = rem / XW, j = rem - prow * XW;
+            uint32_t pa[3], pb[3];
+            split3_pair(xv[i][0], xv[i][1], pa[0], pa[1], pa[2]);  // pairs (2j, 2j+1)
+            split3_pair(xv[i][1], xv[i][2], pb[0], pb[1], pb[2]);  // pairs (2j+1, 2j+2)
+            unsigned char* d = xS + cl * CHB + prow * (XP * 4) + j * 4;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                *reinterpret_cast<uint32_t*>(d + pl * PLB) = pa[pl];
+                *reinterpret_cast<uint32_t*>(d + CPYB + pl * PLB) = pb[pl];
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[tm][tn][i] = 0.f;
+
+    const int s_beg = blockIdx.z * strips_per_split, s_end = min(strips_total, s_beg + strips_per_split);
+    unsigned long long tk0 = BF3_T(), t_stage = 0, t_mma = 0;
+    (void)tk0;
+#ifdef BF3_TIMING
+    const unsigned long long cyc0 = clock64();
+#endif
+    if (s_beg < s_end) load_strip(s_beg);
+    for (int st = s_beg; st < s_end; ++st) {
+        const unsigned long long ta = BF3_T();
+        stage_strip();
+        __syncthreads();
+        const unsigned long long tb = BF3_T();
+        t_stage += tb - ta;
+        if (st + 1 < s_end) load_strip(st + 1);  // in flight under the MFMA phase
+        auto read_ab = [&](int ks, bf16x8 (&a)[TM][3], bf16x8 (&b)[TN][3]) {
+            // the k-step's 16 pixels: W >= 16 a run of a row (the lane halves take its two octets), W = 8 two rows of an image
+            const int aoff = ks * 32;
+            const int boff = W >= 16 ? ((ks * 16) / W) * (XP * 4) + (((ks * 16) % W) >> 1) * 4
+                                     : ((ks / 4) * PR + (ks % 4) * 2) * (XP * 4);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    a[tm][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const v4i*>(smem + pl * (BM * DP) + abase[tm] + aoff));
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    const uint32_t* q = reinterpret_cast<const uint32_t*>(xS + bbase[tn] + pl * PLB + boff);
+                    v4i v;
+                    v.x = (int)q[0], v.y = (int)q[1], v.z = (int)q[2], v.w = (int)q[3];
+                    b[tn][pl] = __builtin_bit_cast(bf16x8, v);
+                }
+        };
+        bf16x8 aq[2][TM][3], bq[2][TN][3];
+        read_ab(0, aq[0], bq[0]);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            if (ks + 1 < 8) read_ab(ks + 1, aq[(ks + 1) & 1], bq[(ks + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#define IVLN_BF3_PROD(PA, PB)                                                                                       \
+    _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) _Pragma("unroll") for (int tn = 0; tn < TN; ++tn)              \
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[ks & 1][tm][PA], bq[ks & 1][tn][PB], acc[tm][tn], 0, 0, 0)
+            IVLN_BF3_PROD(0, 2);
+            IVLN_BF3_PROD(1, 1);
+            IVLN_BF3_PROD(2, 0);
+            IVLN_BF3_PROD(0, 1);
+            IVLN_BF3_PROD(1, 0);
+            IVLN_BF3_PROD(0, 0);
+#undef IVLN_BF3_PROD
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        t_mma += BF3_T() - tb;
+    }
+#ifdef BF3_TIMING
+    if (threadIdx.x == 0) {
+        const int b = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) & 8191;
+        g_bf3_stamp[b * 4 + 0] = wall_clock64() - tk0;
+        g_bf3_stamp[b * 4 + 1] = t_stage;
+        g_bf3_stamp[b * 4 + 2] = t_mma;
+        g_bf3_stamp[b * 4 + 3] = clock64() - cyc0;
+    }
+#endif
+
+    // acc[r] -> channel (r&3) + 8*(r>>2) + 4*half, column l31 of the sub-tile: 32 consecutive columns per store instruction
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int n = n0 + (wn * TN + tn) * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m < p.M && n < p.N) {
+                    if (p.splits > 1) p.ws[((int64_t)blockIdx.z * p.M + m) * p.N + n] = acc[tm][tn][r];
+                    else epilogue_store(p, m, n, acc[tm][tn][r]);
+                }
+            }
+        }
+}
+
+template <int TM, int WM, int WN, int W>
+int launch_wgrad_bf3(const ivln_gemm_desc& d, hipStream_t s, int nimg, int strips, int sps) {
+    constexpr int BM = 32 * TM * WM, BN = 64 * WN, IMS = W == 8 ? 2 : 1, ROWS = 128 / (W * IMS);
+    constexpr int PRT = IMS * (ROWS + 6), XP = ((W + 6) / 2 + 1) | 1, NCIB = (BN + 48) / 49 + 1;
+    constexpr size_t lds = (size_t)3 * BM * 272 + (size_t)6 * NCIB * PRT * XP * 4;
+    static_assert(lds <= 160 * 1024, "strip does not fit");
+    auto kern = k_wgrad_bf3<TM, WM, WN, W>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return IVLN_E_HIP;
+        attr_done = true;
+    }
+    dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM, d.splits);
+    IVLN_LAUNCH_FAMILY(kern, grid, dim3(512), lds, s, d, nimg, strips, sps);
+    return IVLN_OK;
+}
+
+template <int TM, int WM, int WN>
+int launch_wgrad_bf3_w(const ivln_gemm_desc& d, hipStream_t s, int nimg, int strips, int sps) {
+    switch (d.Wout) {
+        case 64: return launch_wgrad_bf3<TM, WM, WN, 64>(d, s, nimg, strips, sps);
+        case 32: return launch_wgrad_bf3<TM, WM, WN, 32>(d, s, nimg, strips, sps);
+        case 16: return launch_wgrad_bf3<TM, WM, WN, 16>(d, s, nimg, strips, sps);
+        default: return launch_wgrad_bf3<TM, WM, WN, 8>(d, s, nimg, strips, sps);
+    }
+}
+
 }  // namespace
 
 extern "C" int64_t ivln_conv_split_words(int M, int Cin, int KS) {
@@ -529,5 +785,52 @@ int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
                              : launch_bf3_ks<1>(d, s, (const unsigned char*)d.A_split, gb, nimg, cfg, cps);
     if (rc == IVLN_OK) g_bf3_flops += 2.0 * d.M * (double)d.N * d.K, ++g_bf3_launches;
     if (rc == IVLN_OK && d.stat_tiles) *d.stat_tiles = d.stat_partials ? (int)(tiles * (BN / 128)) : 0;
+    return rc;
+}
+
+// The 7x7 weight gradient on the split-bf16 arithmetic (k_wgrad_bf3).  IVLN_E_UNSUPPORTED -> the fp32 MFMA weight-gradient kernel.
+int ivln_wgrad_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
+    static const bool disabled = getenv("IVLN_NO_SPLIT_BF16") != nullptr || getenv("IVLN_NO_SPLIT_BF16_WGRAD") != nullptr;  // A/B switches
+    if ((!d.split_ok && !force) || (disabled && !force)) return IVLN_E_UNSUPPORTED;
+    if (d.amode != AMODE_NCHW_P || d.bmode != BMODE_IM2COL_T || d.dmode != DMODE_DENSE || d.stride != 1 || d.dil != 1 || d.Cin <= 0 ||
+        d.N != d.Cin * 49 || d.defer_epilogue || d.pad != 3)
+        return IVLN_E_UNSUPPORTED;
+    if (d.HoWo != d.Hout * d.Wout || d.K % d.HoWo != 0 || d.Hout != d.Hin || d.Wout != d.Win) return IVLN_E_UNSUPPORTED;
+    if (d.Wout != 64 && d.Wout != 32 && d.Wout != 16 && d.Wout != 8) return IVLN_E_UNSUPPORTED;
+    const int ims = d.Wout == 8 ? 2 : 1, rows = 128 / (d.Wout * ims);
+    if (d.Hout % rows != 0 || (d.Wout == 8 && d.Hout != 8) || (((uintptr_t)d.A) & 7)) return IVLN_E_UNSUPPORTED;
+    const int nimg = d.K / d.HoWo;
+    if ((int64_t)nimg * d.in_img_stride >= (int64_t)1 << 31 || (int64_t)nimg * d.M * d.HoWo >= (int64_t)1 << 31) return IVLN_E_UNSUPPORTED;
+    const int strips = ((nimg + ims - 1) / ims) * (d.Hout / rows);
+    // tile: 32 x 512, 64 x 512 or 128 x 256 (channels x columns); strips over blockIdx.z until a workgroup per CU
+    const int BM = d.M <= 32 ? 32 : (d.M <= 64 ? 64 : 128), BN = d.M <= 64 ? 512 : 256;
+    const int64_t blocks = (int64_t)((d.N + BN - 1) / BN) * ((d.M + BM - 1) / BM);
+    int splits = 1;
+    if (d.splits == 0) {
+        if (d.ws) {
+            static const int want_env = getenv("IVLN_WGRAD_BF3_BLOCKS") ? atoi(getenv("IVLN_WGRAD_BF3_BLOCKS")) : 0;  // tuning
+            // one workgroup per CU (LDS): as many splits as keep the grid inside whole rounds of 256 (13 column tiles x 20
+            // splits = 260 workgroups ran a second round for four of them)
+            const int64_t want = want_env > 0 ? want_env : 256;
+            splits = (int)(want / blocks);
+            if (splits < 1) splits = 1;
+            if (splits > strips) splits = strips;
+            const int64_t cap = d.ws_floats / ((int64_t)d.M * d.N);
+            if (splits > cap) splits = (int)cap;
+            if (splits < 1) splits = 1;
+        }
+    } else {
+        splits = d.splits > strips ? strips : d.splits;
+        if (splits > 1 && (!d.ws || d.ws_floats < (int64_t)splits * d.M * d.N)) return IVLN_E_INVALID;
+    }
+    if (!force && blocks * splits < 128) return IVLN_E_UNSUPPORTED;  // (a rollout-sized batch: nothing to win)
+    const int sps = (strips + splits - 1) / splits;
+    splits = (strips + sps - 1) / sps;
+    d.splits = splits;
+    int rc;
+    if (d.M <= 32) rc = launch_wgrad_bf3_w<1, 1, 8>(d, s, nimg, strips, sps);
+    else if (d.M <= 64) rc = launch_wgrad_bf3_w<2, 1, 8>(d, s, nimg, strips, sps);
+    else rc = launch_wgrad_bf3_w<2, 2, 4>(d, s, nimg, strips, sps);
+    if (rc == IVLN_OK) g_bf3_flops += 2.0 * d.M * (double)d.N * d.K, ++g_bf3_launches;
     return rc;
 }

@@ -242,5 +242,7 @@ bool ivln_gemm_vec_eligible(const ivln_gemm_desc& d);
 int ivln_gemm_vec_launch(const ivln_gemm_desc& d, hipStream_t s, int tile);
 // conv_bf3.hip: stride-1 3x3 / 7x7 conv with both operands as three bf16 pieces on the bf16 MFMA pipe (needs d.A_split)
 int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force);
+// same file: 7x7 weight gradient on the same arithmetic (d.split_ok)
+int ivln_wgrad_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force);
 // conv1x1_stream.hip: short-K (64 / 128 / 256) 1x1 convs over many pixels, weights in registers; IVLN_E_UNSUPPORTED otherwise
 int ivln_conv1x1_stream_launch(const ivln_gemm_desc& d, hipStream_t s, bool force);

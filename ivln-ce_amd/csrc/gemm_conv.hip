@@ -508,6 +508,16 @@ extern "C" int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream) {
         d.splits = splits_asked;  // (not taken: the fp32 kernels decide for themselves)
         d.stat_partials = stats_asked;
         if (rc != IVLN_E_UNSUPPORTED || d.tile_override == 9) return rc;
+    } else if ((d.tile_override == 0 || d.tile_override == 9) && d.bmode == BMODE_IM2COL_T) {
+        const int splits_asked = d.splits;
+        const int rc = ivln_wgrad_bf3_launch(d, s, d.tile_override == 9);
+        if (rc == IVLN_OK) {
+            if (d.splits_used) *d.splits_used = d.splits;
+            if (d.splits > 1) launch_splitk_epilogue(d, s);
+            return hipGetLastError() == hipSuccess ? IVLN_OK : IVLN_E_HIP;
+        }
+        d.splits = splits_asked;
+        if (rc != IVLN_E_UNSUPPORTED || d.tile_override == 9) return rc;
     } else if (d.tile_override == 9) {
         return IVLN_E_UNSUPPORTED;
     }

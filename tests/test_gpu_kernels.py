@@ -476,6 +476,42 @@ def test_conv2d_split_bf16_1x1_form(N, Cin, H, Cout, stride):
         assert float((y.double().cpu() - ref).abs().max()) <= 3e-6 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize(
+    "N,Cin,H,Cout",
+    [(6, 14, 64, 32),      # map CNN layer 1: 32 x 512 tile, two column tiles (686 columns: ragged), strips of two rows
+     (8, 32, 32, 64),      # layer 2: 64 x 512
+     (16, 64, 16, 128),    # layer 3: 128 x 256, strips of eight rows
+     (33, 128, 8, 128),    # layer 4: strips of two whole images, odd image count (a half-empty last strip)
+     (5, 20, 16, 70)],     # ragged everything: 70 channels, 980 columns
+)
+def test_conv2d_weight_gradient_split_bf16_kernel(N, Cin, H, Cout):
+    """k_wgrad_bf3 forced (tile_override 9): the 7x7 weight gradient with dy and x as three bf16 pieces each.  Against the
+    float64 weight gradient: as close as the fp32 MFMA weight-gradient kernel (bar: twice its error + 1e-6 of the largest
+    element, and 5e-6 of it outright), deterministic, and with one slab or many."""
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(N + Cin + Cout)
+    x = torch.randn(N, Cin, H, H, generator=g)
+    dy = torch.randn(N, Cout, H, H, generator=g)
+    w = torch.zeros(Cout, Cin, 7, 7, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), w, padding=3).backward(dy.double())
+    ref = w.grad
+    xd, dyd = x.to(DEV), dy.to(DEV)
+    try:
+        ops.TILE_OVERRIDE = 9
+        got = ops.conv2d_bwd_weight(dyd, xd, 7, 7, pad=3)
+        again = ops.conv2d_bwd_weight(dyd, xd, 7, 7, pad=3)
+        ops.TILE_OVERRIDE = 6
+        fp32 = ops.conv2d_bwd_weight(dyd, xd, 7, 7, pad=3)
+    finally:
+        ops.TILE_OVERRIDE = 0
+    scale = float(ref.abs().max())
+    e_split = float((got.double().cpu() - ref).abs().max()) / scale
+    e_fp32 = float((fp32.double().cpu() - ref).abs().max()) / scale
+    assert e_split <= 5e-6 and e_split <= 2.0 * e_fp32 + 1e-6, (e_split, e_fp32)
+    assert torch.equal(got, again)
+
+
 def test_conv2d_split_bf16_refuses_what_it_is_not_built_for():
     from ivln_ce_amd import ops
     from ivln_ce_amd._lib import IvlnError

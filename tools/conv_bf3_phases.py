@@ -53,3 +53,26 @@ for name, n, cin, cout, hw, ks in SH:
     med = np.median(st, axis=0)
     print(f"{name:<16} {len(st):6d} {a.elapsed_time(b) * 1e3:9.1f} | {med[0]:8.1f} = {med[1]:7.1f} + {med[2]:7.1f} | shader cycles over "
           f"K loop + epilogue {med[3]:9.0f} (= {med[3] / med[0] / 1e3:.2f} GHz if the epilogue were free)")
+
+print(f"{'7x7 weight gradient':<16} {'blocks':>6} {'launch us':>9} | per workgroup, us (median): whole loop = staging + MFMA phase | shader cycles")
+for name, n, cin, cout, hw in [("map L1", 512, 14, 32, 64), ("map L2", 512, 32, 64, 32), ("map L3", 512, 64, 128, 16), ("map L4", 512, 128, 128, 8)]:
+    x = torch.randn(n, cin, hw, hw, device=dev)
+    dy = torch.randn(n, cout, hw, hw, device=dev)
+    ops.TILE_OVERRIDE = 9
+    for _ in range(3):
+        ops.conv2d_bwd_weight(dy, x, 7, 7, pad=3)
+    torch.cuda.synchronize()
+    st = np.zeros(8192 * 4, dtype=np.uint64)
+    L.ivln_conv_bf3_stamps(st.ctypes.data, st.size)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    ops.conv2d_bwd_weight(dy, x, 7, 7, pad=3)
+    b.record()
+    torch.cuda.synchronize()
+    ops.TILE_OVERRIDE = 0
+    assert L.ivln_conv_bf3_stamps(st.ctypes.data, st.size) == 0
+    st = st.reshape(8192, 4).astype(np.float64)
+    st[:, :3] /= 100.0
+    st = st[st[:, 0] > 0]
+    med = np.median(st, axis=0)
+    print(f"{name:<16} {len(st):6d} {a.elapsed_time(b) * 1e3:9.1f} | {med[0]:8.1f} = {med[1]:7.1f} + {med[2]:7.1f} | {med[3]:9.0f} (= {med[3] / med[0] / 1e3:.2f} GHz)")

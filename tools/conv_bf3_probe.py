@@ -61,6 +61,36 @@ def timeit(f, iters=10):
     return a.elapsed_time(b) / iters * 1e3
 
 
+if what in ("wgrad",):
+    print(f"{'7x7 weight gradient':<22} {'GFLOP':>7} | {'fp32 MFMA us':>12} {'TF/s':>6} | {'split-bf16 us':>13} {'TF/s':>6} {'x':>5} | max err vs f64 / max|dW|: fp32 MFMA, split-bf16")
+    for name, n, cin, cout, hw in [("map L1", 512, 14, 32, 64), ("map L2", 512, 32, 64, 32), ("map L3", 512, 64, 128, 16), ("map L4", 512, 128, 128, 8)]:
+        torch.manual_seed(2)
+        x = torch.randn(n, cin, hw, hw, device=dev)
+        dy = torch.randn(n, cout, hw, hw, device=dev)
+
+        def wg(mode):
+            ops.TILE_OVERRIDE = mode
+            try:
+                return ops.conv2d_bwd_weight(dy, x, 7, 7, pad=3)
+            finally:
+                ops.TILE_OVERRIDE = 0
+
+        g9, g6 = wg(9), wg(6)
+        k = 16
+        w = torch.zeros(cout, cin, 7, 7, dtype=torch.float64, requires_grad=True)
+        F.conv2d(x[:k].double().cpu(), w, padding=3).backward(dy[:k].double().cpu())
+        ops.TILE_OVERRIDE = 9
+        s9 = ops.conv2d_bwd_weight(dy[:k].contiguous(), x[:k].contiguous(), 7, 7, pad=3)
+        ops.TILE_OVERRIDE = 6
+        s6 = ops.conv2d_bwd_weight(dy[:k].contiguous(), x[:k].contiguous(), 7, 7, pad=3)
+        ops.TILE_OVERRIDE = 0
+        sc = w.grad.abs().max().item()
+        e9 = (s9.double().cpu() - w.grad).abs().max().item() / sc
+        e6 = (s6.double().cpu() - w.grad).abs().max().item() / sc
+        flops = 2.0 * n * hw * hw * cout * cin * 49
+        t6, t9 = timeit(lambda: wg(6)), timeit(lambda: wg(9))
+        print(f"{name:<22} {flops / 1e9:7.1f} | {t6:12.1f} {flops / t6 / 1e6:6.1f} | {t9:13.1f} {flops / t9 / 1e6:6.1f} {t6 / t9:5.2f} | {e6:.2e} {e9:.2e}")
+    sys.exit(0)
 print(f"{'shape':<18} {'GFLOP':>7} | {'fp32 MFMA us':>12} {'TF/s':>6} | {'split-bf16 us':>13} {'TF/s':>6} {'x':>5} | max err vs f64 / max|y|: fp32 MFMA, split-bf16, torch f32")
 for name, n, cin, cout, hw, ks in shapes:
     torch.manual_seed(1)
