@@ -205,7 +205,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_bf3(const ivln_gemm_desc 
             for (int pl = 0; pl < 3; ++pl) abuf[d][tm][pl] = load_a(tm, c_beg * RP + d, pl);
 
     unsigned long long tk0 = BF3_T(), t_stage = 0, t_mma = 0;
-    (void)tk0;
+    (void)tk0, (void)t_stage, (void)t_mma;
 #ifdef BF3_TIMING
     const unsigned long long cyc0 = clock64();
 #endif
@@ -541,17 +541,19 @@ __global__ __launch_bounds__(512) void k_wgrad_bf3(const ivln_gemm_desc p, int n
 #pragma unroll
         for (int i = 0; i < NXI; ++i) {
             const int idx = tt + i * NTB;
-            if (idx >= NX) continue;
             const int cl = idx / (PRT * XW), rem = idx - cl * (PRT * XW);
             const int prow = rem / XW, j = rem - prow * XW;
-            uint32_t pa[3], pb[3];
-            split3_pair(xv[i][0], xv[i][1], pa[0], pa[1], pa[2]);  // pairs (2j, 2j+1)
-            split3_pair(xv[i][1], xv[i][2], pb[0], pb[1], pb[2]);  // pairs (2j+1, 2j+2)
+            uint32_t pa0, pa1, pa2, pb0, pb1, pb2;
+            split3_pair(xv[i][0], xv[i][1], pa0, pa1, pa2);  // pairs (2j, 2j+1)
+            split3_pair(xv[i][1], xv[i][2], pb0, pb1, pb2);  // pairs (2j+1, 2j+2)
             unsigned char* d = xS + cl * CHB + prow * (XP * 4) + j * 4;
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                *reinterpret_cast<uint32_t*>(d + pl * PLB) = pa[pl];
-                *reinterpret_cast<uint32_t*>(d + CPYB + pl * PLB) = pb[pl];
+            if (idx < NX) {
+                *reinterpret_cast<uint32_t*>(d) = pa0;
+                *reinterpret_cast<uint32_t*>(d + PLB) = pa1;
+                *reinterpret_cast<uint32_t*>(d + 2 * PLB) = pa2;
+                *reinterpret_cast<uint32_t*>(d + CPYB) = pb0;
+                *reinterpret_cast<uint32_t*>(d + CPYB + PLB) = pb1;
+                *reinterpret_cast<uint32_t*>(d + CPYB + 2 * PLB) = pb2;
             }
         }
     };
@@ -566,7 +568,7 @@ __global__ __launch_bounds__(512) void k_wgrad_bf3(const ivln_gemm_desc p, int n
 
     const int s_beg = blockIdx.z * strips_per_split, s_end = min(strips_total, s_beg + strips_per_split);
     unsigned long long tk0 = BF3_T(), t_stage = 0, t_mma = 0;
-    (void)tk0;
+    (void)tk0, (void)t_stage, (void)t_mma;
 #ifdef BF3_TIMING
     const unsigned long long cyc0 = clock64();
 #endif
@@ -630,20 +632,19 @@ __global__ __launch_bounds__(512) void k_wgrad_bf3(const ivln_gemm_desc p, int n
 #endif
 
     // acc[r] -> channel (r&3) + 8*(r>>2) + 4*half, column l31 of the sub-tile: 32 consecutive columns per store instruction
+    // always a raw slab, even a single one (the reduction launch applies the epilogue): ivln_gemm_f32's epilogue_store inlined
+    // 64 times made the nest too large to unroll, and the accumulators, then indexed dynamically, lived in scratch
+    float* const slab = p.ws + (int64_t)blockIdx.z * p.M * p.N;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int n = n0 + (wn * TN + tn) * 32 + l31;
+        for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
+                const int n = n0 + (wn * TN + tn) * 32 + l31;
                 const int m = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m < p.M && n < p.N) {
-                    if (p.splits > 1) p.ws[((int64_t)blockIdx.z * p.M + m) * p.N + n] = acc[tm][tn][r];
-                    else epilogue_store(p, m, n, acc[tm][tn][r]);
-                }
+                if (m < p.M && n < p.N) slab[(int64_t)m * p.N + n] = acc[tm][tn][r];
             }
-        }
 }
 
 template <int TM, int WM, int WN, int W>
@@ -805,6 +806,7 @@ int ivln_wgrad_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
     // tile: 32 x 512, 64 x 512 or 128 x 256 (channels x columns); strips over blockIdx.z until a workgroup per CU
     const int BM = d.M <= 32 ? 32 : (d.M <= 64 ? 64 : 128), BN = d.M <= 64 ? 512 : 256;
     const int64_t blocks = (int64_t)((d.N + BN - 1) / BN) * ((d.M + BM - 1) / BM);
+    if (!d.ws || d.ws_floats < (int64_t)d.M * d.N) return IVLN_E_UNSUPPORTED;  // (the kernel always leaves raw slabs)
     int splits = 1;
     if (d.splits == 0) {
         if (d.ws) {

@@ -513,7 +513,7 @@ extern "C" int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream) {
         const int rc = ivln_wgrad_bf3_launch(d, s, d.tile_override == 9);
         if (rc == IVLN_OK) {
             if (d.splits_used) *d.splits_used = d.splits;
-            if (d.splits > 1) launch_splitk_epilogue(d, s);
+            launch_splitk_epilogue(d, s);  // (the kernel leaves raw slabs even when there is one)
             return hipGetLastError() == hipSuccess ? IVLN_OK : IVLN_E_HIP;
         }
         d.splits = splits_asked;

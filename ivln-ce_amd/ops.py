@@ -341,11 +341,8 @@ class Deferred:
 # of the nine piece products, fp32 accumulation - as close to the exact conv as the fp32 MFMA kernels.
 # IVLN_SPLIT_BF16=0 keeps the fp32 MFMA kernels everywhere (A/B); the C side has IVLN_NO_SPLIT_BF16 for the same.
 SPLIT_BF16 = os.environ.get("IVLN_SPLIT_BF16", "1") != "0"
-# the 7x7 weight gradients on the same arithmetic (k_wgrad_bf3): right to the last bit of the bar, and SLOWER than the fp32 MFMA
-# weight-gradient kernel (0.75-0.84x at the update's shapes): K = pixels, the column's kw shifts a bf16 row by 2 kw bytes, so
-# the fragments come as 4 x ds_read_b32 from two pre-shifted copies - two waves per SIMD do not reach the LDS rate that needs
-# (MFMA phase at 38 % of the pipe; tools/conv_bf3_phases.py).  Off unless asked for.
-SPLIT_BF16_WGRAD = os.environ.get("IVLN_SPLIT_BF16_WGRAD", "0") == "1"
+# the 7x7 weight gradients on the same arithmetic (k_wgrad_bf3; 1.1-1.7x the fp32 MFMA weight-gradient kernel at the update's shapes)
+SPLIT_BF16_WGRAD = os.environ.get("IVLN_SPLIT_BF16_WGRAD", "1") != "0"
 SPLIT_BF16_1X1 = os.environ.get("IVLN_SPLIT_BF16_1X1", "0") == "1"
 SPLIT_BF16_MIN_OUT = int(os.environ.get("IVLN_SPLIT_BF16_MIN_OUT", str(1 << 18)))  # output elements below which nothing is packed
 _stat_ws = {}
