@@ -450,9 +450,8 @@ int launch_bf3_ks(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a
 //   * the next strip's dy pairs and x triples fly under the MFMA phase in registers, are split and written after the barrier.
 // ------------------------------------------------------------------------------------------------------------------
 template <int TM, int WM, int WN, int W>
-__global__ __launch_bounds__(512) void k_wgrad_bf3(const ivln_gemm_desc p, int nimg, int strips_total, int strips_per_split) {
-    static_assert(WM * WN == 8, "eight waves");
-    constexpr int NTB = 512, TN = 2, KS = 7, KK = 49;
+__global__ __launch_bounds__(64 * WM * WN) void k_wgrad_bf3(const ivln_gemm_desc p, int nimg, int strips_total, int strips_per_split) {
+    constexpr int NTB = 64 * WM * WN, TN = 2, KS = 7, KK = 49;
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int IMS = W == 8 ? 2 : 1, ROWS = 128 / (W * IMS);   // a strip: IMS images x ROWS rows x W columns = 128 pixels
     constexpr int PR = ROWS + KS - 1, PRT = IMS * PR, PWP = W + KS - 1;
@@ -462,7 +461,7 @@ __global__ __launch_bounds__(512) void k_wgrad_bf3(const ivln_gemm_desc p, int n
     constexpr int DP = 272;                                        // bytes per (channel, piece) row of dy: 128 bf16 + 16
     constexpr int CHB = PRT * XP * 4, PLB = NCIB * CHB, CPYB = 3 * PLB;
     constexpr int DYB = 3 * BM * DP;                               // dy region in front of the x region
-    constexpr int NDI = BM * 64 / NTB, NX = NCIB * PRT * XW, NXI = (NX + NTB - 1) / NTB;
+    constexpr int ND = BM * 64, NDI = (ND + NTB - 1) / NTB, NX = NCIB * PRT * XW, NXI = (NX + NTB - 1) / NTB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const xS = smem + DYB;
 
@@ -505,7 +504,7 @@ __global__ __launch_bounds__(512) void k_wgrad_bf3(const ivln_gemm_desc p, int n
             const int co = idx >> 6, px = (idx & 63) * 2;
             const int il = px / (ROWS * W), q = px - il * (ROWS * W);
             const int img = img0 + il;
-            const bool ok = m0 + co < p.M && img < nimg;
+            const bool ok = idx < ND && m0 + co < p.M && img < nimg;
             dyv[i] = ok ? *reinterpret_cast<const float2*>(dy + ((int64_t)img * p.M + m0 + co) * HWo + row0 * W + q) : make_float2(0.f, 0.f);
         }
 #pragma unroll
@@ -534,9 +533,11 @@ __global__ __launch_bounds__(512) void k_wgrad_bf3(const ivln_gemm_desc p, int n
             uint32_t H, M, L;
             split3_pair(dyv[i].x, dyv[i].y, H, M, L);
             unsigned char* d = smem + co * DP + pr * 4;
-            *reinterpret_cast<uint32_t*>(d) = H;
-            *reinterpret_cast<uint32_t*>(d + BM * DP) = M;
-            *reinterpret_cast<uint32_t*>(d + 2 * BM * DP) = L;
+            if (ND % NTB == 0 || idx < ND) {
+                *reinterpret_cast<uint32_t*>(d) = H;
+                *reinterpret_cast<uint32_t*>(d + BM * DP) = M;
+                *reinterpret_cast<uint32_t*>(d + 2 * BM * DP) = L;
+            }
         }
 #pragma unroll
         for (int i = 0; i < NXI; ++i) {
@@ -660,7 +661,7 @@ int launch_wgrad_bf3(const ivln_gemm_desc& d, hipStream_t s, int nimg, int strip
         attr_done = true;
     }
     dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM, d.splits);
-    IVLN_LAUNCH_FAMILY(kern, grid, dim3(512), lds, s, d, nimg, strips, sps);
+    IVLN_LAUNCH_FAMILY(kern, grid, dim3(64 * WM * WN), lds, s, d, nimg, strips, sps);
     return IVLN_OK;
 }
 
@@ -804,7 +805,11 @@ int ivln_wgrad_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
     if ((int64_t)nimg * d.in_img_stride >= (int64_t)1 << 31 || (int64_t)nimg * d.M * d.HoWo >= (int64_t)1 << 31) return IVLN_E_UNSUPPORTED;
     const int strips = ((nimg + ims - 1) / ims) * (d.Hout / rows);
     // tile: 32 x 512, 64 x 512 or 128 x 256 (channels x columns); strips over blockIdx.z until a workgroup per CU
-    const int BM = d.M <= 32 ? 32 : (d.M <= 64 ? 64 : 128), BN = d.M <= 64 ? 512 : 256;
+    // (32-channel outputs: 14 x 49 = 686 columns are two tiles of 384 - six waves - with 11 % of the columns idle; two tiles of
+    //  512 left 33 % idle)
+    static const int l1_env = getenv("IVLN_WGRAD_BF3_WN32") ? atoi(getenv("IVLN_WGRAD_BF3_WN32")) : 0;  // tuning: 6 | 8
+    const bool six = d.M <= 32 && (l1_env ? l1_env == 6 : (d.N + 383) / 384 * 384 < (d.N + 511) / 512 * 512);
+    const int BM = d.M <= 32 ? 32 : (d.M <= 64 ? 64 : 128), BN = d.M <= 32 ? (six ? 384 : 512) : (d.M <= 64 ? 512 : 256);
     const int64_t blocks = (int64_t)((d.N + BN - 1) / BN) * ((d.M + BM - 1) / BM);
     if (!d.ws || d.ws_floats < (int64_t)d.M * d.N) return IVLN_E_UNSUPPORTED;  // (the kernel always leaves raw slabs)
     int splits = 1;
@@ -830,7 +835,8 @@ int ivln_wgrad_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
     splits = (strips + sps - 1) / sps;
     d.splits = splits;
     int rc;
-    if (d.M <= 32) rc = launch_wgrad_bf3_w<1, 1, 8>(d, s, nimg, strips, sps);
+    if (d.M <= 32 && six) rc = launch_wgrad_bf3_w<1, 1, 6>(d, s, nimg, strips, sps);
+    else if (d.M <= 32) rc = launch_wgrad_bf3_w<1, 1, 8>(d, s, nimg, strips, sps);
     else if (d.M <= 64) rc = launch_wgrad_bf3_w<2, 1, 8>(d, s, nimg, strips, sps);
     else rc = launch_wgrad_bf3_w<2, 2, 4>(d, s, nimg, strips, sps);
     if (rc == IVLN_OK) g_bf3_flops += 2.0 * d.M * (double)d.N * d.K, ++g_bf3_launches;
