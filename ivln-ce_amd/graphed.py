@@ -217,7 +217,9 @@ class GraphedRollout:
         if not predicted and os.environ.get("IVLN_TXT_FIRST", "0") == "1":
             net._txt_with_dep = "first"
         if net._txt_last and not predicted and spare > 1 and B < 8:
-            ienc.lstm_ticket = torch.zeros((1,), dtype=torch.int32, device=dev)
+            # (the captured launches hold this word's ADDRESS: it lives as long as this object's graphs, whatever a later
+            #  capture of the same policy hangs on the module)
+            self._lstm_ticket = ienc.lstm_ticket = torch.zeros((1,), dtype=torch.int32, device=dev)
             ienc.lstm_spare = spare
         s = _stream(dev, "warmup")
         s.wait_stream(main)
