@@ -395,6 +395,42 @@ def test_conv2d_split_bf16_kernel(N, Cin, H, W, Cout, k):
     assert float(wide_k[:, :4].abs().max()) == 0.0 and float(wide_k[:, 4 + Cout:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("case", ["offset_input_zero_sum_filters", "wide_dynamic_range", "tiny_values"])
+def test_conv2d_split_bf16_accuracy_where_fp32_struggles(case):
+    """Inputs that expose a lossy product: (1) activations 1000 + N(0, 1) against zero-sum filters - the exact result is O(1)
+    while every product is O(1000), so a product error of 2^-16 (a bf16 x 3 scheme without the cross terms) would show as 1e-2
+    and fp32's own 2^-24 as ~1e-4; (2) activations and weights spread over 12 decades; (3) values near 1e-30.  The split-bf16
+    kernel has to stay within twice the fp32 MFMA kernel's error against float64 (+ 1e-7 of the product scale)."""
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(7)
+    N, Cin, H, Cout, k = 4, 64, 32, 64, 3
+    if case == "offset_input_zero_sum_filters":
+        x = 1000.0 + torch.randn(N, Cin, H, H, generator=g)
+        w = torch.randn(Cout, Cin, k, k, generator=g)
+        w = w - w.mean(dim=(1, 2, 3), keepdim=True)
+        prod = 1000.0 * float(w.abs().max())
+    elif case == "wide_dynamic_range":
+        x = torch.randn(N, Cin, H, H, generator=g) * 10.0 ** torch.randint(-6, 7, (N, Cin, H, H), generator=g).float()
+        w = torch.randn(Cout, Cin, k, k, generator=g) * 10.0 ** torch.randint(-6, 7, (Cout, Cin, k, k), generator=g).float()
+        prod = float(x.abs().max()) * float(w.abs().max())
+    else:
+        x = torch.randn(N, Cin, H, H, generator=g) * 1e-30
+        w = torch.randn(Cout, Cin, k, k, generator=g) * 1e-3
+        prod = 1e-33
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    try:
+        ops.TILE_OVERRIDE = 9
+        got = ops.conv2d(x.to(DEV), w.to(DEV), pad=1, splitk=False)
+        ops.TILE_OVERRIDE = 6
+        fp32 = ops.conv2d(x.to(DEV), w.to(DEV), pad=1, splitk=False)
+    finally:
+        ops.TILE_OVERRIDE = 0
+    e_split = float((got.double().cpu() - ref).abs().max())
+    e_fp32 = float((fp32.double().cpu() - ref).abs().max())
+    assert e_split <= 2.0 * e_fp32 + 1e-7 * prod * (Cin * k * k) ** 0.5, (case, e_split, e_fp32, prod)
+
+
 def test_conv2d_split_bf16_pieces_are_exact_and_specials_propagate():
     """The split itself: weights of ONE non-zero tap against an input of ONE non-zero pixel make every output a single
     product a * b - the six piece products must reproduce it to 2^-22 relative for values across the fp32 exponent range
