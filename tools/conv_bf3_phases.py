@@ -31,7 +31,8 @@ dev = torch.device("cuda:0")
 SH = [("map L1 fwd", 512, 14, 32, 64, 7), ("map L2 fwd", 512, 32, 64, 32, 7), ("map L3 fwd", 512, 64, 128, 16, 7),
       ("map L4 fwd", 512, 128, 128, 8, 7), ("map L2 dgrad", 512, 64, 32, 32, 7), ("rednet 64@128", 8, 64, 64, 128, 3),
       ("rednet 128@64", 8, 128, 128, 64, 3), ("rednet 256@32", 8, 256, 256, 32, 3), ("rednet 64@64 x8", 8, 64, 64, 64, 3),
-      ("rednet 128@32 x8", 8, 128, 128, 32, 3), ("rednet 512@8 x8", 8, 512, 512, 8, 3)]
+      ("rednet 128@32 x8", 8, 128, 128, 32, 3), ("rednet 512@8 x8", 8, 512, 512, 8, 3),
+      ("1x1 1024<-256@16", 16, 256, 1024, 16, 1), ("1x1 256<-1024@16", 16, 1024, 256, 16, 1), ("1x1 512<-128@32", 16, 128, 512, 32, 1)]
 print(f"{'shape':<16} {'blocks':>6} {'launch us':>9} | per workgroup, us (median): K loop = staging + MFMA phase | epilogue")
 for name, n, cin, cout, hw, ks in SH:
     x = torch.randn(n, cin, hw, hw, device=dev)
