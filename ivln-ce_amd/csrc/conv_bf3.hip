@@ -89,7 +89,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t bf3_rsrc(const void* p) {
 }
 
 template <int KS, int TM, int WM, int WN, int PTH, int PTW, int IMGS, int DA>
-__global__ __launch_bounds__(64 * WM * WN) void k_conv_bf3(const ivln_gemm_desc p, const unsigned char* a_split, long long a_grp_bytes,
+__global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_desc p, const unsigned char* a_split, long long a_grp_bytes,
                                                            int tiles_w, int tiles_h, int nimg, int chunks_per_split) {
     constexpr int NTB = 64 * WM * WN, TN = 2;
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_bf3(const ivln_gemm_desc 
     constexpr int RP = KKP * CS;  // taps (padded) between two barriers: a STAGE = CS chunks of 16 channels
     static_assert(RP % DA == 0 && KKP >= KK && (CS == 1 || KK == 1), "prefetch rotation closes over a stage");
     constexpr int PH = PTH + KS - 1, PWR = PTW + KS - 1, NPIX = IMGS * PH * PWR;
-    constexpr int ITEMS = NPIX * (CB / 2) * CS, NPI = (ITEMS + NTB - 1) / NTB;
+    constexpr int ITEMS = NPIX * (CB / 2) * CS;
     constexpr int LDT = BN + 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -115,17 +115,31 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_bf3(const ivln_gemm_desc 
     const int HW = p.Hin * p.Win;
     const int grp = p.grp_imgs > 0 ? img0 / p.grp_imgs : 0;
 
-    // patch items of this thread: (pixel, channel pair), consecutive threads on consecutive pixels of a row.  Offsets are
-    // RE-DERIVED per chunk (a dozen integer ops per item against ~600 MFMAs): kept in registers they cost 2 x NPI VGPRs that
-    // the operand double-buffering below needs (tt: an opaque copy of the thread id, so that the compiler does not hoist them)
-    // (cp: channel pair inside the STAGE, 0 .. 8 CS - 1; a 1x1 conv may be strided - no halo, the patch is the output tile)
-    auto item = [&](int tt, int i, int& cp, int& src, int& dst) {
+    // Staging work of a thread.  3x3 / 7x7: PPT patch PIXELS (consecutive threads on consecutive pixels of a row), all 8 channel
+    // pairs of the chunk for each - the pixel's source offset, validity and LDS record are derived ONCE (a handful of registers)
+    // and an item costs two adds; the first version re-derived (pixel, pair) per item: ~25 integer operations around an
+    // 11-operation split, and staging was 20 % of RedNet's 3x3 launches.  1x1 (CS chunks per stage, no halo): the flat
+    // (pixel, pair) enumeration with offsets re-derived per stage (tt: an opaque copy of the thread id against hoisting).
+    constexpr int PPT = (NPIX + NTB - 1) / NTB;
+    constexpr int NPI = KS == 1 ? (ITEMS + NTB - 1) / NTB : PPT * (CB / 2);
+    int psrc[PPT], pdst[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int pix = t + j * NTB;
+        const int il = pix / (PH * PWR), rem = pix - il * (PH * PWR);
+        const int y = rem / PWR, x = rem - y * PWR;
+        const int hi = ho0 - p.pad + y, wi = wo0 - p.pad + x, img = img0 + il;
+        const bool ok = pix < NPIX && img < nimg && (unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win;
+        psrc[j] = ok ? (int)((int64_t)img * p.in_img_stride + hi * p.Win + wi) : -1;
+        pdst[j] = pix < NPIX ? pix * PIXB : -1;
+    }
+    auto item = [&](int tt, int i, int& cp, int& src, int& dst) {  // (1x1 only)
         const int idx = tt + i * NTB;
         cp = idx / NPIX;
         const int pix = idx - cp * NPIX;
         const int il = pix / (PH * PWR), rem = pix - il * (PH * PWR);
         const int y = rem / PWR, x = rem - y * PWR;
-        const int hi = KS == 1 ? (ho0 + y) * p.stride : ho0 - p.pad + y, wi = KS == 1 ? (wo0 + x) * p.stride : wo0 - p.pad + x;
+        const int hi = (ho0 + y) * p.stride, wi = (wo0 + x) * p.stride;
         const int img = img0 + il;
         const bool ok = idx < ITEMS && img < nimg && (unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win;
         src = ok ? (int)((int64_t)img * p.in_img_stride + (int64_t)(2 * cp) * HW + hi * p.Win + wi) : -1;
@@ -133,35 +147,65 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_bf3(const ivln_gemm_desc 
     };
     float r0[NPI], r1[NPI];
     auto load_patch = [&](int c) {
-        int tt = t;
-        asm volatile("" : "+v"(tt));
         const int cbase = c * (CB * CS) * HW;
         const int left = p.Cin - c * (CB * CS);  // channels this stage still has (ragged last chunk: the rest reads as zero)
+        if constexpr (KS == 1) {
+            int tt = t;
+            asm volatile("" : "+v"(tt));
 #pragma unroll
-        for (int i = 0; i < NPI; ++i) {
-            int cp, src, dst;
-            item(tt, i, cp, src, dst);
-            const bool ok0 = src >= 0 && 2 * cp < left, ok1 = src >= 0 && 2 * cp + 1 < left;
-            r0[i] = p.B[ok0 ? src + cbase : 0];
-            r1[i] = p.B[ok1 ? src + cbase + HW : 0];
+            for (int i = 0; i < NPI; ++i) {
+                int cp, src, dst;
+                item(tt, i, cp, src, dst);
+                const bool ok0 = src >= 0 && 2 * cp < left, ok1 = src >= 0 && 2 * cp + 1 < left;
+                r0[i] = p.B[ok0 ? src + cbase : 0];
+                r1[i] = p.B[ok1 ? src + cbase + HW : 0];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < PPT; ++j)
+#pragma unroll
+                for (int q = 0; q < CB / 2; ++q) {
+                    const bool ok0 = psrc[j] >= 0 && 2 * q < left, ok1 = psrc[j] >= 0 && 2 * q + 1 < left;
+                    const int o = psrc[j] + cbase + 2 * q * HW;
+                    r0[j * (CB / 2) + q] = p.B[ok0 ? o : 0];
+                    r1[j * (CB / 2) + q] = p.B[ok1 ? o + HW : 0];
+                }
         }
     };
     auto stage = [&](int c) {
-        int tt = t;
-        asm volatile("" : "+v"(tt));
         const int left = p.Cin - c * (CB * CS);
+        if constexpr (KS == 1) {
+            int tt = t;
+            asm volatile("" : "+v"(tt));
 #pragma unroll
-        for (int i = 0; i < NPI; ++i) {
-            int cp, src, dst;
-            item(tt, i, cp, src, dst);
-            if (dst < 0) continue;
-            const float v0 = (src >= 0 && 2 * cp < left) ? r0[i] : 0.f;
-            const float v1 = (src >= 0 && 2 * cp + 1 < left) ? r1[i] : 0.f;
-            uint32_t H, M, L;
-            split3_pair(v0, v1, H, M, L);
-            *reinterpret_cast<uint32_t*>(smem + dst) = H;
-            *reinterpret_cast<uint32_t*>(smem + dst + 32) = M;
-            *reinterpret_cast<uint32_t*>(smem + dst + 64) = L;
+            for (int i = 0; i < NPI; ++i) {
+                int cp, src, dst;
+                item(tt, i, cp, src, dst);
+                const float v0 = (src >= 0 && 2 * cp < left) ? r0[i] : 0.f;
+                const float v1 = (src >= 0 && 2 * cp + 1 < left) ? r1[i] : 0.f;
+                uint32_t H, M, L;
+                split3_pair(v0, v1, H, M, L);
+                if (dst >= 0) {
+                    *reinterpret_cast<uint32_t*>(smem + dst) = H;
+                    *reinterpret_cast<uint32_t*>(smem + dst + 32) = M;
+                    *reinterpret_cast<uint32_t*>(smem + dst + 64) = L;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < PPT; ++j)
+#pragma unroll
+                for (int q = 0; q < CB / 2; ++q) {
+                    const float v0 = (psrc[j] >= 0 && 2 * q < left) ? r0[j * (CB / 2) + q] : 0.f;
+                    const float v1 = (psrc[j] >= 0 && 2 * q + 1 < left) ? r1[j * (CB / 2) + q] : 0.f;
+                    uint32_t H, M, L;
+                    split3_pair(v0, v1, H, M, L);
+                    if (PPT * NTB == NPIX || pdst[j] >= 0) {
+                        *reinterpret_cast<uint32_t*>(smem + pdst[j] + q * 4) = H;
+                        *reinterpret_cast<uint32_t*>(smem + pdst[j] + q * 4 + 32) = M;
+                        *reinterpret_cast<uint32_t*>(smem + pdst[j] + q * 4 + 64) = L;
+                    }
+                }
         }
     };
 
@@ -422,7 +466,7 @@ template <int KS>
 int launch_bf3_ks(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a, int64_t gb, int nimg, int cfg, int cps) {
     // weight taps in flight: a tap is 24 MFMAs = 768 pipe cycles per wave (12 = 384 with one channel tile per wave), an L2 /
     // MALL round trip ~2000
-    constexpr int DA2 = KS == 1 ? 2 : 3, DA1 = KS == 7 ? 6 : (KS == 3 ? 9 : 4);
+    constexpr int DA2 = KS == 1 ? 2 : 3, DA1 = KS == 1 ? 4 : 3;  // (6 / 9 taps ahead measured the same as 3 and cost 36-72 registers)
     switch (cfg) {
         case 0: return launch_bf3_px<KS, 1, 1, 8, DA1>(d, s, a, gb, nimg, cps);   // 32 x 512, 8 waves
         case 1: return launch_bf3_px<KS, 2, 1, 8, DA2>(d, s, a, gb, nimg, cps);   // 64 x 512
