@@ -533,6 +533,24 @@ __global__ __launch_bounds__(64 * WM * WN) void k_wgrad_bf3(const ivln_gemm_desc
 
     float2 dyv[NDI];
     float xv[NXI][3];
+    // x items of this thread, derived once: offset of patch column 2j relative to the strip's (image 0, row 0) origin, the
+    // LDS word, and what does not depend on the strip - channel and column validity (bits 0-2), image of the pair (bit 3),
+    // patch row (bits 4..) - so that a strip costs an add and a row test per item, not three divisions
+    int xrel[NXI], xdst[NXI], xinf[NXI];
+#pragma unroll
+    for (int i = 0; i < NXI; ++i) {
+        const int idx = t + i * NTB;
+        const int cl = idx / (PRT * XW), rem = idx - cl * (PRT * XW);
+        const int prow = rem / XW, j = rem - prow * XW;
+        const int il = prow / PR, pr = prow - il * PR;
+        const bool cok = idx < NX && ci_lo + cl < p.Cin;
+        int m = 0;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) m |= (cok && (unsigned)(2 * j + e - p.pad) < (unsigned)p.Win) ? (1 << e) : 0;
+        xinf[i] = m | (il << 3) | (pr << 4);
+        xrel[i] = (int)((int64_t)il * p.in_img_stride + (int64_t)(ci_lo + cl) * HWi + (pr - p.pad) * p.Win + 2 * j - p.pad);
+        xdst[i] = idx < NX ? cl * CHB + prow * (XP * 4) + j * 4 : -1;
+    }
     auto strip_origin = [&](int st, int& img0, int& row0) {
         img0 = (st / spi) * IMS;
         row0 = (st - (st / spi) * spi) * ROWS;
@@ -551,20 +569,14 @@ __global__ __launch_bounds__(64 * WM * WN) void k_wgrad_bf3(const ivln_gemm_desc
             const bool ok = idx < ND && m0 + co < p.M && img < nimg;
             dyv[i] = ok ? *reinterpret_cast<const float2*>(dy + ((int64_t)img * p.M + m0 + co) * HWo + row0 * W + q) : make_float2(0.f, 0.f);
         }
+        const float* const xo = x + (int64_t)img0 * p.in_img_stride + row0 * p.Win;
 #pragma unroll
         for (int i = 0; i < NXI; ++i) {  // x: (channel, patch row, pixel-pair word): columns 2j, 2j+1, 2j+2 of the patch
-            const int idx = tt + i * NTB;
-            const int cl = idx / (PRT * XW), rem = idx - cl * (PRT * XW);
-            const int prow = rem / XW, j = rem - prow * XW;
-            const int il = prow / PR, pr = prow - il * PR;
-            const int img = img0 + il, hi = row0 + pr - p.pad, ci = ci_lo + cl;
-            const bool rok = idx < NX && ci < p.Cin && img < nimg && (unsigned)hi < (unsigned)p.Hin;
-            const float* src = x + (int64_t)img * p.in_img_stride + (int64_t)ci * HWi + hi * p.Win;
+            const int inf = xinf[i];
+            const int hi = row0 + (inf >> 4) - p.pad;
+            const bool rok = img0 + ((inf >> 3) & 1) < nimg && (unsigned)hi < (unsigned)p.Hin;
 #pragma unroll
-            for (int e = 0; e < 3; ++e) {
-                const int wi = 2 * j + e - p.pad;
-                xv[i][e] = (rok && (unsigned)wi < (unsigned)p.Win) ? src[wi] : 0.f;
-            }
+            for (int e = 0; e < 3; ++e) xv[i][e] = (rok && ((inf >> e) & 1)) ? xo[xrel[i] + e] : 0.f;
         }
     };
     auto stage_strip = [&]() {
@@ -585,14 +597,11 @@ __global__ __launch_bounds__(64 * WM * WN) void k_wgrad_bf3(const ivln_gemm_desc
         }
 #pragma unroll
         for (int i = 0; i < NXI; ++i) {
-            const int idx = tt + i * NTB;
-            const int cl = idx / (PRT * XW), rem = idx - cl * (PRT * XW);
-            const int prow = rem / XW, j = rem - prow * XW;
             uint32_t pa0, pa1, pa2, pb0, pb1, pb2;
             split3_pair(xv[i][0], xv[i][1], pa0, pa1, pa2);  // pairs (2j, 2j+1)
             split3_pair(xv[i][1], xv[i][2], pb0, pb1, pb2);  // pairs (2j+1, 2j+2)
-            unsigned char* d = xS + cl * CHB + prow * (XP * 4) + j * 4;
-            if (idx < NX) {
+            unsigned char* d = xS + xdst[i];
+            if (xdst[i] >= 0) {
                 *reinterpret_cast<uint32_t*>(d) = pa0;
                 *reinterpret_cast<uint32_t*>(d + PLB) = pa1;
                 *reinterpret_cast<uint32_t*>(d + 2 * PLB) = pa2;
