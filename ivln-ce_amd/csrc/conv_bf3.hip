@@ -121,7 +121,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
     // 11-operation split, and staging was 20 % of RedNet's 3x3 launches.  1x1 (CS chunks per stage, no halo): the flat
     // (pixel, pair) enumeration with offsets re-derived per stage (tt: an opaque copy of the thread id against hoisting).
     constexpr int PPT = (NPIX + NTB - 1) / NTB;
-    constexpr int NPI = KS == 1 ? (ITEMS + NTB - 1) / NTB : PPT * (CB / 2);
+    constexpr int NPI = KS == 1 ? ITEMS / NTB : PPT * (CB / 2);
     int psrc[PPT], pdst[PPT];
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
@@ -133,33 +133,36 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
         psrc[j] = ok ? (int)((int64_t)img * p.in_img_stride + hi * p.Win + wi) : -1;
         pdst[j] = pix < NPIX ? pix * PIXB : -1;
     }
-    auto item = [&](int tt, int i, int& cp, int& src, int& dst) {  // (1x1 only)
-        const int idx = tt + i * NTB;
-        cp = idx / NPIX;
-        const int pix = idx - cp * NPIX;
+    // 1x1: the patch is the output tile itself (no halo, maybe strided); NTB / NPIX thread groups share a pixel set and take
+    // every (NTB / NPIX)-th chunk of the stage, all 8 channel pairs of each
+    constexpr int G1 = KS == 1 ? NTB / NPIX : 1;
+    static_assert(KS != 1 || (NTB % NPIX == 0 && CS % G1 == 0), "1x1: whole thread groups per pixel set");
+    int src1 = -1, dst1 = 0, g1 = 0;
+    if constexpr (KS == 1) {
+        const int pix = t % NPIX;
+        g1 = t / NPIX;
         const int il = pix / (PH * PWR), rem = pix - il * (PH * PWR);
         const int y = rem / PWR, x = rem - y * PWR;
-        const int hi = (ho0 + y) * p.stride, wi = (wo0 + x) * p.stride;
-        const int img = img0 + il;
-        const bool ok = idx < ITEMS && img < nimg && (unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win;
-        src = ok ? (int)((int64_t)img * p.in_img_stride + (int64_t)(2 * cp) * HW + hi * p.Win + wi) : -1;
-        dst = idx < ITEMS ? (cp >> 3) * (NPIX * PIXB) + pix * PIXB + (cp & 7) * 4 : -1;
-    };
+        const int hi = (ho0 + y) * p.stride, wi = (wo0 + x) * p.stride, img = img0 + il;
+        const bool ok = img < nimg && (unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win;
+        src1 = ok ? (int)((int64_t)img * p.in_img_stride + hi * p.Win + wi) : -1;
+        dst1 = pix * PIXB;
+    }
     float r0[NPI], r1[NPI];
     auto load_patch = [&](int c) {
         const int cbase = c * (CB * CS) * HW;
         const int left = p.Cin - c * (CB * CS);  // channels this stage still has (ragged last chunk: the rest reads as zero)
         if constexpr (KS == 1) {
-            int tt = t;
-            asm volatile("" : "+v"(tt));
 #pragma unroll
-            for (int i = 0; i < NPI; ++i) {
-                int cp, src, dst;
-                item(tt, i, cp, src, dst);
-                const bool ok0 = src >= 0 && 2 * cp < left, ok1 = src >= 0 && 2 * cp + 1 < left;
-                r0[i] = p.B[ok0 ? src + cbase : 0];
-                r1[i] = p.B[ok1 ? src + cbase + HW : 0];
-            }
+            for (int jj = 0; jj < CS / G1; ++jj)
+#pragma unroll
+                for (int q = 0; q < CB / 2; ++q) {
+                    const int ch = (g1 + jj * G1) * CB + 2 * q;  // channel of the pair inside the stage
+                    const bool ok0 = src1 >= 0 && ch < left, ok1 = src1 >= 0 && ch + 1 < left;
+                    const int o = src1 + cbase + ch * HW;
+                    r0[jj * (CB / 2) + q] = p.B[ok0 ? o : 0];
+                    r1[jj * (CB / 2) + q] = p.B[ok1 ? o + HW : 0];
+                }
         } else {
 #pragma unroll
             for (int j = 0; j < PPT; ++j)
@@ -175,22 +178,20 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
     auto stage = [&](int c) {
         const int left = p.Cin - c * (CB * CS);
         if constexpr (KS == 1) {
-            int tt = t;
-            asm volatile("" : "+v"(tt));
 #pragma unroll
-            for (int i = 0; i < NPI; ++i) {
-                int cp, src, dst;
-                item(tt, i, cp, src, dst);
-                const float v0 = (src >= 0 && 2 * cp < left) ? r0[i] : 0.f;
-                const float v1 = (src >= 0 && 2 * cp + 1 < left) ? r1[i] : 0.f;
-                uint32_t H, M, L;
-                split3_pair(v0, v1, H, M, L);
-                if (dst >= 0) {
-                    *reinterpret_cast<uint32_t*>(smem + dst) = H;
-                    *reinterpret_cast<uint32_t*>(smem + dst + 32) = M;
-                    *reinterpret_cast<uint32_t*>(smem + dst + 64) = L;
+            for (int jj = 0; jj < CS / G1; ++jj)
+#pragma unroll
+                for (int q = 0; q < CB / 2; ++q) {
+                    const int ch = (g1 + jj * G1) * CB + 2 * q;
+                    const float v0 = (src1 >= 0 && ch < left) ? r0[jj * (CB / 2) + q] : 0.f;
+                    const float v1 = (src1 >= 0 && ch + 1 < left) ? r1[jj * (CB / 2) + q] : 0.f;
+                    uint32_t H, M, L;
+                    split3_pair(v0, v1, H, M, L);
+                    unsigned char* d = smem + (g1 + jj * G1) * (NPIX * PIXB) + dst1 + q * 4;
+                    *reinterpret_cast<uint32_t*>(d) = H;
+                    *reinterpret_cast<uint32_t*>(d + 32) = M;
+                    *reinterpret_cast<uint32_t*>(d + 64) = L;
                 }
-            }
         } else {
 #pragma unroll
             for (int j = 0; j < PPT; ++j)

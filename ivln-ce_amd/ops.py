@@ -343,7 +343,7 @@ class Deferred:
 SPLIT_BF16 = os.environ.get("IVLN_SPLIT_BF16", "1") != "0"
 # the 7x7 weight gradients on the same arithmetic (k_wgrad_bf3; 1.1-1.7x the fp32 MFMA weight-gradient kernel at the update's shapes)
 SPLIT_BF16_WGRAD = os.environ.get("IVLN_SPLIT_BF16_WGRAD", "1") != "0"
-SPLIT_BF16_1X1 = os.environ.get("IVLN_SPLIT_BF16_1X1", "0") == "1"
+SPLIT_BF16_1X1 = int(os.environ.get("IVLN_SPLIT_BF16_1X1", "-1"))  # -1: by measured rule (ops.conv2d), 0 never, 1 always
 SPLIT_BF16_MIN_OUT = int(os.environ.get("IVLN_SPLIT_BF16_MIN_OUT", str(1 << 18)))  # output elements below which nothing is packed
 _stat_ws = {}
 CONV_STATS = os.environ.get("IVLN_CONV_STATS", "1") != "0"  # A/B: BatchNorm statistics from the conv's epilogue
@@ -393,10 +393,13 @@ def conv2d(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, 
             if pk is not None:
                 d.A_packed = dptr(pk)
                 d.a_packed_grp_stride = pk.numel() // max(G, 1)
-        # 1x1 convs on the split-bf16 kernel (four 16-channel chunks staged per barrier pair): built, bit-checked, and SLOWER
-        # than the float4-staged fp32 GEMM on every RedNet shape (0.47-1.14x: 2-4 GFLOP calls with 4 taps between barriers) -
-        # off unless asked for (IVLN_SPLIT_BF16_1X1=1, or tile_override 9 in tests)
-        if ((SPLIT_BF16_1X1 or TILE_OVERRIDE == 9) and SPLIT_BF16 and stride in (1, 2) and Cin >= 128 and Cout >= 64 and Wo % 4 == 0 and Wo >= 8 and w.is_contiguous()
+        # 1x1 convs on the split-bf16 kernel (four 16-channel chunks staged per barrier pair): an activation element is
+        # re-used only Cout times, so the split's VALU work is a large share - measured inside RedNet it wins on the stride-2
+        # and the >= 4 GFLOP launches (53 vs 76, 50 vs 66, 42 vs 56, 46 vs 53 us) and ties or loses on the 2 GFLOP ones
+        # (36-39 vs 32-37): on for the former only (IVLN_SPLIT_BF16_1X1=0 / 1 = never / always, tile_override 9 in tests)
+        big_1x1 = stride == 2 or 2.0 * Cout * Cin * N * Ho * Wo >= 4e9
+        want_1x1 = TILE_OVERRIDE == 9 or SPLIT_BF16_1X1 == 1 or (SPLIT_BF16_1X1 != 0 and big_1x1)
+        if (want_1x1 and SPLIT_BF16 and stride in (1, 2) and Cin >= 128 and Cout >= 64 and Wo % 4 == 0 and Wo >= 8 and w.is_contiguous()
                 and not defer and (N * Ho * Wo * Cout >= SPLIT_BF16_MIN_OUT or TILE_OVERRIDE == 9)):
             sp = packed_conv_weights(w, cache=not weight_is_temp, split=True)
             if sp is not None:
