@@ -6,7 +6,7 @@ import csv
 import json
 import sys
 
-MFMA = ("k_gemm", "k_conv_direct", "k_wgrad", "k_conv_gn", "k_gn_conv", "k_nconv", "k_depth_net")
+MFMA = ("k_gemm", "k_conv_direct", "k_conv_bf3", "k_conv1x1_stream", "k_wgrad", "k_conv_gn", "k_gn_conv", "k_nconv", "k_depth_net")
 MAPPER = ("k_local_", "k_world_", "k_finalize", "k_frames")
 
 
