@@ -13,8 +13,9 @@ MAPPER = ("k_local_", "k_world_", "k_finalize", "k_frames")
 def load(path, family=MFMA):
     rows = list(csv.DictReader(open(path)))
     tot = sum(float(r["Total"]) for r in rows) * 1024
-    mf = sum(float(r["Total"]) for r in rows if r["Name"].startswith(family)) * 1024
-    launches = sum(int(r["Launches"]) for r in rows if r["Name"].startswith(family))
+    fam = [r for r in rows if r["Name"].startswith(family) and "_pack" not in r["Name"]]  # (weight-packing helpers are not MFMA launches)
+    mf = sum(float(r["Total"]) for r in fam) * 1024
+    launches = sum(int(r["Launches"]) for r in fam)
     return tot, mf, launches
 
 
