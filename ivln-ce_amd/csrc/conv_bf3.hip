@@ -25,6 +25,8 @@
 //     residual / ReLU of ivln_gemm_f32 and the per-(128-pixel segment, channel) Welford partials of stat_partials.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "gemm_common.h"
 
 namespace {
@@ -100,6 +102,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
     constexpr int PH = PTH + KS - 1, PWR = PTW + KS - 1, NPIX = IMGS * PH * PWR;
     constexpr int ITEMS = NPIX * (CB / 2) * CS;
     constexpr int LDT = BN + 4;
+    constexpr bool HAS_LITE = KS == 7 && TM == 1;  // (a second copy of the unrolled tap loop: only where one-hot inputs occur)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int t = threadIdx.x, lane = t & 63;
@@ -175,7 +178,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
                 }
         }
     };
-    auto stage = [&](int c) {
+    auto stage = [&](int c) -> uint32_t {  // returns the OR of the lower pieces this thread wrote (0: its values were bf16-exact)
+        uint32_t nz = 0;
         const int left = p.Cin - c * (CB * CS);
         if constexpr (KS == 1) {
 #pragma unroll
@@ -187,6 +191,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
                     const float v1 = (src1 >= 0 && ch + 1 < left) ? r1[jj * (CB / 2) + q] : 0.f;
                     uint32_t H, M, L;
                     split3_pair(v0, v1, H, M, L);
+                    nz |= M | L;
                     unsigned char* d = smem + (g1 + jj * G1) * (NPIX * PIXB) + dst1 + q * 4;
                     *reinterpret_cast<uint32_t*>(d) = H;
                     *reinterpret_cast<uint32_t*>(d + 32) = M;
@@ -201,6 +206,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
                     const float v1 = (psrc[j] >= 0 && 2 * q + 1 < left) ? r1[j * (CB / 2) + q] : 0.f;
                     uint32_t H, M, L;
                     split3_pair(v0, v1, H, M, L);
+                    nz |= M | L;
                     if (PPT * NTB == NPIX || pdst[j] >= 0) {
                         *reinterpret_cast<uint32_t*>(smem + pdst[j] + q * 4) = H;
                         *reinterpret_cast<uint32_t*>(smem + pdst[j] + q * 4 + 32) = M;
@@ -208,6 +214,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
                     }
                 }
         }
+        return nz;
     };
 
     // per-lane operand bases
@@ -257,53 +264,68 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
     load_patch(c_beg);
     for (int c = c_beg; c < c_end; ++c) {
         const unsigned long long ta = BF3_T();
-        stage(c);
-        __syncthreads();
+        const uint32_t nz = stage(c);
+        // A chunk whose staged values are all bf16-exact (one-hot map features: the map CNN's first layer) has zero second and
+        // third pieces: the three products against them are exact zeros and are not issued - same bits, half the MFMAs and a
+        // third of the operand reads.  The block-wide OR rides in the barrier the staging needs anyway.
+        const bool lite = HAS_LITE ? __syncthreads_or((int)(nz != 0)) == 0 : (__syncthreads(), false);
         const unsigned long long tb = BF3_T();
         t_stage += tb - ta;
         if (c + 1 < c_end) load_patch(c + 1);  // in flight under the MFMA phase
         const int s0 = c * RP;
-        auto read_b = [&](int r, bf16x8 (&b)[TN][3]) {  // the tap's B fragments: one ds_read_b128 per (pixel tile, piece)
-            const int kh = r / KS, kw = r - kh * KS;
-            const int toff = KS == 1 ? r * (NPIX * PIXB) : (kh * PWR + kw) * PIXB;  // (1x1: tap r = chunk r of the stage)
+        auto taps = [&](auto lite_tag) {
+            constexpr bool LITE = decltype(lite_tag)::value;
+            constexpr int NPL = LITE ? 1 : 3;
+            auto read_b = [&](int r, bf16x8 (&b)[TN][3]) {  // the tap's B fragments: one ds_read_b128 per (pixel tile, piece)
+                const int kh = r / KS, kw = r - kh * KS;
+                const int toff = KS == 1 ? r * (NPIX * PIXB) : (kh * PWR + kw) * PIXB;  // (1x1: tap r = chunk r of the stage)
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
+                for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    b[tn][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const v4i*>(smem + bbase[tn] + toff + pl * 32));
-        };
-        bf16x8 bq[2][TN][3];  // this tap's fragments and the next tap's, read while this tap's MFMAs issue
-        read_b(0, bq[0]);
+                    for (int pl = 0; pl < NPL; ++pl)
+                        b[tn][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const v4i*>(smem + bbase[tn] + toff + pl * 32));
+            };
+            bf16x8 bq[2][TN][3];  // this tap's fragments and the next tap's, read while this tap's MFMAs issue
+            read_b(0, bq[0]);
 #pragma unroll
-        for (int r = 0; r < RP; ++r) {
-            const int slot = r % DA;
-            if (r < KK * CS && (KS != 1 || c * CS + r < nch)) {  // (padding taps, and 1x1: chunks past the last one, issue nothing)
-                if (r + 1 < KK * CS) read_b(r + 1, bq[(r + 1) & 1]);
-                __builtin_amdgcn_sched_barrier(0);  // (the reads stay AHEAD of this tap's MFMAs: left alone they sink to their use)
-                bf16x8 a[TM][3];
+            for (int r = 0; r < RP; ++r) {
+                const int slot = r % DA;
+                if (r < KK * CS && (KS != 1 || c * CS + r < nch)) {  // (padding taps, and 1x1: chunks past the last one, issue nothing)
+                    if (r + 1 < KK * CS) read_b(r + 1, bq[(r + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);  // (the reads stay AHEAD of this tap's MFMAs: left alone they sink to their use)
+                    bf16x8 a[TM][3];
 #pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
+                    for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) a[tm][pl] = __builtin_bit_cast(bf16x8, abuf[slot][tm][pl]);
-                // smallest products first; consecutive MFMAs hit different accumulators
+                        for (int pl = 0; pl < 3; ++pl) a[tm][pl] = __builtin_bit_cast(bf16x8, abuf[slot][tm][pl]);
+                    // smallest products first; consecutive MFMAs hit different accumulators
 #define IVLN_BF3_PROD(PA, PB)                                                                                       \
     _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) _Pragma("unroll") for (int tn = 0; tn < TN; ++tn)              \
         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][PA], bq[r & 1][tn][PB], acc[tm][tn], 0, 0, 0)
-                IVLN_BF3_PROD(0, 2);
-                IVLN_BF3_PROD(1, 1);
-                IVLN_BF3_PROD(2, 0);
-                IVLN_BF3_PROD(0, 1);
-                IVLN_BF3_PROD(1, 0);
-                IVLN_BF3_PROD(0, 0);
+                    if constexpr (!LITE) {
+                        IVLN_BF3_PROD(0, 2);
+                        IVLN_BF3_PROD(1, 1);
+                    }
+                    IVLN_BF3_PROD(2, 0);
+                    if constexpr (!LITE) IVLN_BF3_PROD(0, 1);
+                    IVLN_BF3_PROD(1, 0);
+                    IVLN_BF3_PROD(0, 0);
 #undef IVLN_BF3_PROD
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // the slot just used receives the weights of DA taps ahead (the rotation closes over the stage: RP % DA == 0)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) abuf[slot][tm][pl] = load_a(tm, s0 + r + DA, pl);
+                __builtin_amdgcn_sched_barrier(0);  // (... and so do the weight loads: DA taps of flight time, not one)
             }
-            __builtin_amdgcn_sched_barrier(0);
-            // the slot just used receives the weights of DA taps ahead (the rotation closes over the stage: RP % DA == 0)
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) abuf[slot][tm][pl] = load_a(tm, s0 + r + DA, pl);
-            __builtin_amdgcn_sched_barrier(0);  // (... and so do the weight loads: DA taps of flight time, not one)
+        };
+        if constexpr (HAS_LITE) {
+            if (lite) taps(std::true_type{});
+            else taps(std::false_type{});
+        } else {
+            taps(std::false_type{});
         }
         __syncthreads();
         t_mma += BF3_T() - tb;
@@ -467,7 +489,7 @@ template <int KS>
 int launch_bf3_ks(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a, int64_t gb, int nimg, int cfg, int cps) {
     // weight taps in flight: a tap is 24 MFMAs = 768 pipe cycles per wave (12 = 384 with one channel tile per wave), an L2 /
     // MALL round trip ~2000
-    constexpr int DA2 = KS == 1 ? 2 : 3, DA1 = KS == 1 ? 4 : 3;  // (6 / 9 taps ahead measured the same as 3 and cost 36-72 registers)
+    constexpr int DA2 = KS == 1 ? 2 : 3, DA1 = KS == 1 ? 4 : (KS == 7 ? 2 : 3);  // (6 / 9 taps ahead measured the same as 3 and cost 36-72 registers)
     switch (cfg) {
         case 0: return launch_bf3_px<KS, 1, 1, 8, DA1>(d, s, a, gb, nimg, cps);   // 32 x 512, 8 waves
         case 1: return launch_bf3_px<KS, 2, 1, 8, DA2>(d, s, a, gb, nimg, cps);   // 64 x 512
@@ -507,6 +529,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_wgrad_bf3(const ivln_gemm_desc
     constexpr int CHB = PRT * XP * 4, PLB = NCIB * CHB, CPYB = 3 * PLB;
     constexpr int DYB = 3 * BM * DP;                               // dy region in front of the x region
     constexpr int ND = BM * 64, NDI = (ND + NTB - 1) / NTB, NX = NCIB * PRT * XW, NXI = (NX + NTB - 1) / NTB;
+    constexpr bool HAS_LITE = TM == 1;  // (the 32-channel layer: the one whose x is the one-hot map features)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const xS = smem + DYB;
 
@@ -580,7 +603,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_wgrad_bf3(const ivln_gemm_desc
             for (int e = 0; e < 3; ++e) xv[i][e] = (rok && ((inf >> e) & 1)) ? xo[xrel[i] + e] : 0.f;
         }
     };
-    auto stage_strip = [&]() {
+    auto stage_strip = [&]() -> uint32_t {  // returns the OR of the x values' lower pieces (0: the strip's patch is bf16-exact)
+        uint32_t nzx = 0;
         int tt = t;
         asm volatile("" : "+v"(tt));
 #pragma unroll
@@ -601,6 +625,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_wgrad_bf3(const ivln_gemm_desc
             uint32_t pa0, pa1, pa2, pb0, pb1, pb2;
             split3_pair(xv[i][0], xv[i][1], pa0, pa1, pa2);  // pairs (2j, 2j+1)
             split3_pair(xv[i][1], xv[i][2], pb0, pb1, pb2);  // pairs (2j+1, 2j+2)
+            nzx |= pa1 | pa2 | pb1 | pb2;
             unsigned char* d = xS + xdst[i];
             if (xdst[i] >= 0) {
                 *reinterpret_cast<uint32_t*>(d) = pa0;
@@ -611,6 +636,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_wgrad_bf3(const ivln_gemm_desc
                 *reinterpret_cast<uint32_t*>(d + CPYB + 2 * PLB) = pb2;
             }
         }
+        return nzx;
     };
 
     f32x16 acc[TM][TN];
@@ -630,48 +656,62 @@ __global__ __launch_bounds__(64 * WM * WN) void k_wgrad_bf3(const ivln_gemm_desc
     if (s_beg < s_end) load_strip(s_beg);
     for (int st = s_beg; st < s_end; ++st) {
         const unsigned long long ta = BF3_T();
-        stage_strip();
-        __syncthreads();
+        const uint32_t nzx = stage_strip();
+        // (a strip whose x patch is bf16-exact - the first layer's one-hot map features - has zero lower pieces: the products
+        //  against them are not issued and their fragments not read: a third of the 4-byte LDS reads that bound this kernel)
+        const bool lite = HAS_LITE ? __syncthreads_or((int)(nzx != 0)) == 0 : (__syncthreads(), false);
         const unsigned long long tb = BF3_T();
         t_stage += tb - ta;
         if (st + 1 < s_end) load_strip(st + 1);  // in flight under the MFMA phase
-        auto read_ab = [&](int ks, bf16x8 (&a)[TM][3], bf16x8 (&b)[TN][3]) {
-            // the k-step's 16 pixels: W >= 16 a run of a row (the lane halves take its two octets), W = 8 two rows of an image
-            const int aoff = ks * 32;
-            const int boff = W >= 16 ? ((ks * 16) / W) * (XP * 4) + (((ks * 16) % W) >> 1) * 4
-                                     : ((ks / 4) * PR + (ks % 4) * 2) * (XP * 4);
+        auto ksteps = [&](auto lite_tag) {
+            constexpr bool LITE = decltype(lite_tag)::value;
+            constexpr int NPL = LITE ? 1 : 3;
+            auto read_ab = [&](int ks, bf16x8 (&a)[TM][3], bf16x8 (&b)[TN][3]) {
+                // the k-step's 16 pixels: W >= 16 a run of a row (the lane halves take its two octets), W = 8 two rows of an image
+                const int aoff = ks * 32;
+                const int boff = W >= 16 ? ((ks * 16) / W) * (XP * 4) + (((ks * 16) % W) >> 1) * 4
+                                         : ((ks / 4) * PR + (ks % 4) * 2) * (XP * 4);
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
+                for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    a[tm][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const v4i*>(smem + pl * (BM * DP) + abase[tm] + aoff));
+                    for (int pl = 0; pl < 3; ++pl)
+                        a[tm][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const v4i*>(smem + pl * (BM * DP) + abase[tm] + aoff));
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
+                for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
-                    const uint32_t* q = reinterpret_cast<const uint32_t*>(xS + bbase[tn] + pl * PLB + boff);
-                    v4i v;
-                    v.x = (int)q[0], v.y = (int)q[1], v.z = (int)q[2], v.w = (int)q[3];
-                    b[tn][pl] = __builtin_bit_cast(bf16x8, v);
-                }
-        };
-        bf16x8 aq[2][TM][3], bq[2][TN][3];
-        read_ab(0, aq[0], bq[0]);
+                    for (int pl = 0; pl < NPL; ++pl) {
+                        const uint32_t* q = reinterpret_cast<const uint32_t*>(xS + bbase[tn] + pl * PLB + boff);
+                        v4i v;
+                        v.x = (int)q[0], v.y = (int)q[1], v.z = (int)q[2], v.w = (int)q[3];
+                        b[tn][pl] = __builtin_bit_cast(bf16x8, v);
+                    }
+            };
+            bf16x8 aq[2][TM][3], bq[2][TN][3];
+            read_ab(0, aq[0], bq[0]);
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            if (ks + 1 < 8) read_ab(ks + 1, aq[(ks + 1) & 1], bq[(ks + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int ks = 0; ks < 8; ++ks) {
+                if (ks + 1 < 8) read_ab(ks + 1, aq[(ks + 1) & 1], bq[(ks + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
 #define IVLN_BF3_PROD(PA, PB)                                                                                       \
     _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) _Pragma("unroll") for (int tn = 0; tn < TN; ++tn)              \
         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[ks & 1][tm][PA], bq[ks & 1][tn][PB], acc[tm][tn], 0, 0, 0)
-            IVLN_BF3_PROD(0, 2);
-            IVLN_BF3_PROD(1, 1);
-            IVLN_BF3_PROD(2, 0);
-            IVLN_BF3_PROD(0, 1);
-            IVLN_BF3_PROD(1, 0);
-            IVLN_BF3_PROD(0, 0);
+                if constexpr (!LITE) {
+                    IVLN_BF3_PROD(0, 2);
+                    IVLN_BF3_PROD(1, 1);
+                }
+                IVLN_BF3_PROD(2, 0);
+                if constexpr (!LITE) IVLN_BF3_PROD(0, 1);
+                IVLN_BF3_PROD(1, 0);
+                IVLN_BF3_PROD(0, 0);
 #undef IVLN_BF3_PROD
-            __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if constexpr (HAS_LITE) {
+            if (lite) ksteps(std::true_type{});
+            else ksteps(std::false_type{});
+        } else {
+            ksteps(std::false_type{});
         }
         __syncthreads();
         t_mma += BF3_T() - tb;

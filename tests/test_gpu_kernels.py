@@ -431,6 +431,31 @@ def test_conv2d_split_bf16_accuracy_where_fp32_struggles(case):
     assert e_split <= 2.0 * e_fp32 + 1e-7 * prod * (Cin * k * k) ** 0.5, (case, e_split, e_fp32, prod)
 
 
+def test_conv2d_split_bf16_one_hot_input_takes_the_three_product_path_with_the_same_bits():
+    """A chunk whose staged values are all exact in one bf16 piece (the map CNN's first layer reads occupancy + one-hot
+    labels) skips the three products against the zero pieces.  Exact zeros add nothing: the result has to equal, bit for
+    bit, the six-product result - forced here by making ONE input value inexact far away from the compared region."""
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(2)
+    N, Cin, H, Cout = 6, 14, 64, 32
+    x = (torch.rand(N, Cin, H, H, generator=g) > 0.85).float()
+    w = torch.randn(Cout, Cin, 7, 7, generator=g) / (Cin * 49) ** 0.5
+    x_full = x.clone()
+    x_full[:, :, 0, 0] = 0.3   # an inexact value in the corner of every image: every chunk of its tile takes the six-product path
+    ref = F.conv2d(x.double(), w.double(), padding=3)
+    try:
+        ops.TILE_OVERRIDE = 9
+        lite = ops.conv2d(x.to(DEV), w.to(DEV), pad=3, splitk=False)
+        full = ops.conv2d(x_full.to(DEV), w.to(DEV), pad=3, splitk=False)
+    finally:
+        ops.TILE_OVERRIDE = 0
+    assert float((lite.double().cpu() - ref).abs().max()) <= 3e-6 * float(ref.abs().max())
+    # rows 8.. of every image are computed by tiles whose patches never see pixel (0, 0) in the lite run, and outputs more than
+    # 3 pixels away from (0, 0) do not depend on it in the full run: same inputs, different product count, same bits
+    assert torch.equal(lite[:, :, 4:8, 4:], full[:, :, 4:8, 4:])
+
+
 def test_conv2d_split_bf16_pieces_are_exact_and_specials_propagate():
     """The split itself: weights of ONE non-zero tap against an input of ONE non-zero pixel make every output a single
     product a * b - the six piece products must reproduce it to 2^-22 relative for values across the fp32 exponent range

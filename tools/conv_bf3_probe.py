@@ -15,7 +15,7 @@ from ivln_ce_amd import ops  # noqa: E402
 dev = torch.device("cuda:0")
 what = sys.argv[1] if len(sys.argv) > 1 else "all"
 # (name, images, Cin, Cout, H, KS)
-MAP = [("map L1 fwd", 512, 14, 32, 64, 7), ("map L2 fwd", 512, 32, 64, 32, 7), ("map L3 fwd", 512, 64, 128, 16, 7),
+MAP = [("map L1 fwd", 512, 14, 32, 64, 7), ("map L1 fwd one-hot", 512, 14, 32, 64, 7), ("map L2 fwd", 512, 32, 64, 32, 7), ("map L3 fwd", 512, 64, 128, 16, 7),
        ("map L4 fwd", 512, 128, 128, 8, 7), ("map L2 dgrad", 512, 64, 32, 32, 7), ("map L3 dgrad", 512, 128, 64, 16, 7)]
 RED = [("rednet 64@128 x8", 8, 64, 64, 128, 3), ("rednet 64@64 x16", 16, 64, 64, 64, 3), ("rednet 64@64 x8", 8, 64, 64, 64, 3),
        ("rednet 128@32 x16", 16, 128, 128, 32, 3), ("rednet 128@32 x8", 8, 128, 128, 32, 3), ("rednet 256@16 x16", 16, 256, 256, 16, 3),
@@ -63,9 +63,11 @@ def timeit(f, iters=10):
 
 if what in ("wgrad",):
     print(f"{'7x7 weight gradient':<22} {'GFLOP':>7} | {'fp32 MFMA us':>12} {'TF/s':>6} | {'split-bf16 us':>13} {'TF/s':>6} {'x':>5} | max err vs f64 / max|dW|: fp32 MFMA, split-bf16")
-    for name, n, cin, cout, hw in [("map L1", 512, 14, 32, 64), ("map L2", 512, 32, 64, 32), ("map L3", 512, 64, 128, 16), ("map L4", 512, 128, 128, 8)]:
+    for name, n, cin, cout, hw in [("map L1", 512, 14, 32, 64), ("map L1 one-hot x", 512, 14, 32, 64), ("map L2", 512, 32, 64, 32), ("map L3", 512, 64, 128, 16), ("map L4", 512, 128, 128, 8)]:
         torch.manual_seed(2)
         x = torch.randn(n, cin, hw, hw, device=dev)
+        if "one-hot" in name:
+            x = (torch.rand(n, cin, hw, hw, device=dev) > 0.9).float()
         dy = torch.randn(n, cout, hw, hw, device=dev)
 
         def wg(mode):
@@ -95,6 +97,8 @@ print(f"{'shape':<18} {'GFLOP':>7} | {'fp32 MFMA us':>12} {'TF/s':>6} | {'split-
 for name, n, cin, cout, hw, ks in shapes:
     torch.manual_seed(1)
     x = torch.randn(n, cin, hw, hw, device=dev)
+    if "one-hot" in name:  # the map CNN's real first-layer input: occupancy + one-hot labels, exact in one bf16 piece
+        x = (torch.rand(n, cin, hw, hw, device=dev) > 0.9).float()
     w = torch.randn(cout, cin, ks, ks, device=dev) / (cin * ks * ks) ** 0.5
     b = torch.randn(cout, device=dev)
     flops = 2.0 * n * hw * hw * cout * cin * ks * ks
