@@ -864,7 +864,12 @@ int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
             if (splits > cap) splits = (int)cap;
             if (splits < 1) splits = 1;
         }
-        if (split_env > 0 && may_split) splits = split_env > nch ? nch : split_env;
+        if (split_env > 0 && may_split) {
+            splits = split_env > nch ? nch : split_env;
+            const int64_t cap = d.ws_floats / ((int64_t)d.M * d.N);  // (the slabs have to fit the workspace whatever the tuning knob says)
+            if (splits > cap) splits = (int)cap;
+            if (splits < 1) splits = 1;
+        }
         if (!force && nb * splits < 192) return IVLN_E_UNSUPPORTED;  // pixel- and channel-starved: the implicit GEMM splits K deeper
     } else if (!force && !fills(nb, cfg == 6 ? 2 : 1)) {
         return IVLN_E_UNSUPPORTED;
