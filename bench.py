@@ -13,13 +13,16 @@ RedNet-predicted semantics (rgb 224x224 + depth 256x256) -> egocentric mapper ->
 as R = 5 repetitions of W warm-up + EXACTLY K steps, each bracketed by barrier + synchronize with the MAX over ranks
 taken per repetition; `value` / `ms_per_step` are the MEDIAN repetition and `repetitions` carries min / max.
 The JSON line also carries
-  roofline             fp32-MFMA family of the headline step: algorithmic FLOPs of one step / the step's WALL time (the
-                       step replays on two overlapping streams, so summed kernel durations are not a denominator; the
-                       kernel-time figure of an instrumented single-stream pass is given beside it as `kernel_time`)
+  roofline             MFMA family of the headline step: achieved = algorithmic FLOPs of one step / the step's WALL time;
+                       peak = the rate of the step's FLOP mix with the fp32 MFMA pipe (157.3 TF) and the bf16 MFMA pipe
+                       (2.5 PF, six executed FLOPs per algorithmic FLOP of a split-bf16 conv) at their dense peaks;
+                       frac = achieved / peak = bound time / wall time (never above 1).  Secondary: `fp32_peak_basis`
+                       (rounds 1-4's figure), `kernel_time` (instrumented single-stream pass), `mfma_busy` (committed PMC)
   cpu_baseline         the CPU oracle (torch-CPU RedNet port + C mapper + torch-CPU policy port) on this box's host cores
   gt_semantics_step    BASELINE configs[1] (gt semantics, 4 envs): its own value / roofline / mapper_roofline / cpu_baseline
-  update_step          DAgger update T=64 x N=8 per GPU (fwd + bwd + all-reduce + Adam): MFMA roofline with PMC traffic,
-                       and the oracle's update (torch-CPU loss + autograd + torch.optim.Adam) as its cpu_baseline
+  update_step          DAgger update T=64 x N=8 per GPU (fwd + bwd + all-reduce + Adam): the same roofline object on the
+                       update's WALL time with PMC traffic, `allreduce` (bytes / ms / bus GB/s of the one collective,
+                       populated when world > 1), the oracle's update (torch-CPU loss + autograd + Adam) as cpu_baseline
   dagger_collect_step  sampled DAgger collection step at 8 envs (replayed), with the eager figure
   dagger_iteration     64 replayed collection steps alternating with 4 eager updates in ONE process, against the sum of
                        the two legs timed on their own (the graph-replay / eager-update interaction)
@@ -43,7 +46,10 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f
 # algorithmic fp32 FLOP, so its share of a step is bounded by this / 6 = 416.7 "fp32-equivalent" TFLOP/s
 PEAK_BF16_MFMA_TFLOPS = 2500.0
 SPLIT_PRODUCTS = 6
+# the arithmetic type of the path: fp32 in / out / accumulate; the qualifier is part of the value since round 5
+DTYPE = "f32 (bf16x3 split on 3x3/7x7)"
 PEAK_HBM_GBS = 8000.0  # same guide: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+PROFILE_ROUNDS = ("r05", "r04", "r03", "r02", "r01")  # committed rocprofv3 summaries, newest first
 MFMA_FAMILY = "MFMA family (fp32: k_gemm / k_gemm_vec / k_conv_direct / k_depth_net / k_gn_conv / k_nconv; split-bf16: k_conv_bf3)"
 
 
@@ -190,52 +196,108 @@ def stats_of(ms_list):
     return med, v[0], v[-1]
 
 
-def split_bf16_part(gt, n_steps, ms_per_step):
-    """The family's convs that ran on the split-bf16 kernel (csrc/conv_bf3.hip): their algorithmic fp32 FLOPs are inside
-    `flops_per_step` / `achieved` like everybody else's, but the matrix cores executed SIX bf16 FLOPs for each of them, and
-    the bound they are up against is the bf16 peak / 6, not the fp32 MFMA peak - `frac` (priced on the fp32 peak, as the
-    contract asks for the dtype) can therefore pass 1.  `frac_of_mixed_bound` prices each part on its own pipe rate:
-    (fp32 part / 157.3 + split part / 416.7) / measured time, always <= 1."""
-    sf = getattr(gt, "split_flops", 0.0) / n_steps
+def mixed_bound(flops, split_flops):
+    """(bound in ms, peak in TFLOP/s) of a FLOP mix on the matrix cores: the part that ran on the fp32 MFMA kernels is
+    priced on the fp32 MFMA peak, the part that ran on the split-bf16 kernels (csrc/conv_bf3.hip) on the bf16 peak at SIX
+    executed bf16 FLOPs per algorithmic fp32 FLOP.  `peak` = flops / bound: the rate this mix would run at with both pipes
+    at their dense peaks - the denominator of every `roofline.frac` in the line, which therefore cannot pass 1."""
+    rest = max(flops - split_flops, 0.0)
+    bound_ms = (rest / (PEAK_F32_MFMA_TFLOPS * 1e12) + split_flops * SPLIT_PRODUCTS / (PEAK_BF16_MFMA_TFLOPS * 1e12)) * 1e3
+    peak = (flops / (bound_ms * 1e-3)) / 1e12 if bound_ms > 0 else PEAK_F32_MFMA_TFLOPS
+    return bound_ms, peak
+
+
+PEAKS = {"f32_mfma_tflops": PEAK_F32_MFMA_TFLOPS, "bf16_mfma_tflops": PEAK_BF16_MFMA_TFLOPS,
+         "bf16_flops_executed_per_split_flop": SPLIT_PRODUCTS,
+         "source": "/opt/skills/guides/MI355X_MICROARCH.md (dense peaks: v_mfma_f32_32x32x2_f32, v_mfma_f32_32x32x16_bf16)"}
+
+
+def split_bf16_part(flops, split_flops, split_launches, n_steps):
+    """The family's convs that ran on the split-bf16 kernels: their algorithmic fp32 FLOPs are inside `flops_per_step` /
+    `achieved` like everybody else's, but the matrix cores executed SIX bf16 FLOPs for each of them (`mixed_bound`)."""
+    sf = split_flops / n_steps
     if sf <= 0:
         return None
-    rest = max(gt.flops / n_steps - sf, 0.0)
-    bound_ms = (rest / (PEAK_F32_MFMA_TFLOPS * 1e12) + sf * SPLIT_PRODUCTS / (PEAK_BF16_MFMA_TFLOPS * 1e12)) * 1e3
     return {
-        "algorithmic_flops_per_step": int(sf), "share_of_family_flops": round(sf / (gt.flops / n_steps), 4),
-        "launches_per_step": round(getattr(gt, "split_launches", 0) / n_steps, 1),
-        "executed_bf16_flops_per_step": int(sf * SPLIT_PRODUCTS), "bf16_peak": PEAK_BF16_MFMA_TFLOPS,
-        "frac_of_mixed_bound": round(bound_ms / ms_per_step, 5) if ms_per_step > 0 else None,
+        "algorithmic_flops_per_step": int(sf), "share_of_family_flops": round(sf / (flops / n_steps), 4),
+        "launches_per_step": round(split_launches / n_steps, 1),
+        "executed_bf16_flops_per_step": int(sf * SPLIT_PRODUCTS),
         "what": "3x3 / 7x7 convs with both operands as three bf16 pieces each, six piece products per fp32 product on "
                 "v_mfma_f32_32x32x16_bf16, fp32 accumulation: as close to the exact conv as the fp32 MFMA kernels (tests)",
     }
 
 
-def mfma_roofline(gt, ms, n_steps, traffic, what, wall_ms_per_step=None):
-    """`achieved` / `frac`: algorithmic FLOPs of one step over the step's WALL time when the timed step overlaps streams
-    (`wall_ms_per_step` given: summed kernel durations of two concurrent queues are not a denominator - VERDICT r3), else
-    over the summed kernel durations.  The kernel-time figure of the instrumented pass is always carried as
-    `kernel_time`.  `traffic` arrives as the committed PMC figure per LAUNCH (the contract's unit: per launch, like
-    `achieved`); the per-STEP total is spelled out beside it."""
+def pmc_mfma_busy(name):
+    """MFMA-pipe busy fraction of the DOMINANT kernel of a committed PMC pass (profiles/rNN_<name>: one rocprofv3 run with
+    `--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES`, summarised by tools/pmc_stats.py): busy cycles of the 1024 matrix
+    pipes / (1024 x SQ_BUSY_CYCLES / 32 shader engines).  Dominant = the family kernel with the most SQ-busy cycles in
+    the pass.  A counter pass cannot run inside the timed bench: the figure is the committed one, None without a file."""
+    import csv
+
+    for rnd in PROFILE_ROUNDS:
+        path = os.path.join(ROOT, "profiles", f"{rnd}_{name}")
+        if not os.path.exists(path):
+            continue
+        try:
+            busy, sq = {}, {}
+            for row in csv.DictReader(open(path)):
+                base = row["Name"].split("<")[0].split("(")[0]  # every instantiation of a kernel template counts as that kernel
+                d = busy if row["Counter"] == "SQ_VALU_MFMA_BUSY_CYCLES" else sq
+                d[base] = d.get(base, 0.0) + float(row["Total"])
+            fam = [k for k in sq if busy.get(k, 0.0) > 0 and k.startswith(("k_conv", "k_gemm", "k_wgrad", "k_depth_net",
+                                                                           "k_gn_conv", "k_nconv"))]
+            if not fam:
+                return None
+            k = max(fam, key=lambda n: sq[n])
+            return {"kernel": k, "mfma_busy": round(busy[k] / (1024.0 * sq[k] / 32.0), 4),
+                    "source": f"profiles/{rnd}_{name}",
+                    "formula": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 pipes x SQ_BUSY_CYCLES / 32 shader engines), summed over the "
+                               "kernel's template instantiations; dominant = most SQ-busy cycles in the pass"}
+        except Exception:  # noqa: BLE001
+            return None
+    return None
+
+
+def mfma_roofline(gt, ms, n_steps, traffic, what, wall_ms_per_step=None, busy=None, per="step"):
+    """The contract's roofline object for the MFMA family of one step (or update).
+      achieved  algorithmic FLOPs of one step / the step's WALL time (`wall_ms_per_step`: the timed, median repetition -
+                the step overlaps streams, so summed kernel durations are not a denominator), TFLOP/s
+      peak      the rate THIS FLOP mix would run at with the fp32 MFMA pipe and the bf16 MFMA pipe at their dense peaks
+                (`mixed_bound`; the per-pipe peaks are in `peaks`)
+      frac      achieved / peak = bound time / wall time; never above 1
+    Secondary figures: `fp32_peak_basis` (the same FLOPs priced on the fp32 MFMA peak alone - rounds 1-4's `frac`; a
+    RATIO that can pass 1 where the split-bf16 kernels run faster than the fp32 pipe could), `kernel_time` (the family's
+    summed kernel durations from the instrumented single-stream pass instead of wall time), `mfma_busy` (committed PMC
+    pass).  `traffic` arrives as the committed PMC figure per LAUNCH; the per-step total is spelled out beside it."""
     flops_step = gt.flops / n_steps
-    k_ach = (gt.flops / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
-    ach = (flops_step / (wall_ms_per_step * 1e-3)) / 1e12 if wall_ms_per_step else k_ach
+    split_step = getattr(gt, "split_flops", 0.0) / n_steps
+    bound_ms, peak = mixed_bound(flops_step, split_step)
+    k_ms = ms / n_steps
+    wall = wall_ms_per_step if wall_ms_per_step else k_ms
+    ach = (flops_step / (wall * 1e-3)) / 1e12 if wall > 0 else 0.0
+    k_ach = (flops_step / (k_ms * 1e-3)) / 1e12 if k_ms > 0 else 0.0
     per_launch, per_step = traffic if isinstance(traffic, tuple) else (traffic, None)
-    split = split_bf16_part(gt, n_steps, wall_ms_per_step if wall_ms_per_step else ms / n_steps)
     return {
-        "split_bf16": split,
-        "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 5), "traffic": per_launch,
+        "bound": "mfma", "achieved": round(ach, 3), "peak": round(peak, 2), "unit": "TFLOP/s",
+        "frac": round(min(bound_ms / wall, 1.0), 5) if wall > 0 else None, "traffic": per_launch,
+        "peaks": PEAKS, "bound_ms_per_" + per: round(bound_ms, 4),
         "traffic_unit": "HBM bytes per launch of the family (rocprofv3 PMC passes committed under profiles/)",
-        "traffic_bytes_per_step": per_step,
+        "traffic_bytes_per_" + per: per_step,
         "kernel": MFMA_FAMILY + ": " + what,
-        "flops_per_step": int(flops_step), "launches_per_step": round(gt.launches / n_steps, 1),
-        "basis": ("algorithmic FLOPs of one step / WALL time of the timed step (median repetition): the step replays on "
-                  "two overlapping streams, every other kernel of the step is inside the denominator" if wall_ms_per_step
-                  else "algorithmic FLOPs / summed kernel durations of the family"),
+        "flops_per_" + per: int(flops_step), "launches_per_" + per: round(gt.launches / n_steps, 1),
+        "basis": ("algorithmic FLOPs of one " + per + " / WALL time of the timed " + per + " (median repetition; every other "
+                  "kernel and every gap of the " + per + " is inside the denominator), against the peak of its fp32 / "
+                  "split-bf16 FLOP mix" if wall_ms_per_step else
+                  "algorithmic FLOPs / summed kernel durations of the family, against the peak of its FLOP mix"),
+        "split_bf16": split_bf16_part(gt.flops, getattr(gt, "split_flops", 0.0), getattr(gt, "split_launches", 0), n_steps),
+        "mfma_busy": busy,
+        "fp32_peak_basis": {"peak": PEAK_F32_MFMA_TFLOPS, "ratio_to_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 5),
+                            "note": "the same algorithmic FLOPs priced on the fp32 MFMA peak alone (what rounds 1-4 printed "
+                                    "as `frac`): a ratio, not a fraction of a bound - the split-bf16 convs run on a pipe "
+                                    "with 16x the fp32 pipe's rate at 6x the work"},
         "kernel_time": {
-            "achieved": round(k_ach, 3), "frac": round(k_ach / PEAK_F32_MFMA_TFLOPS, 5),
-            "kernel_ms_per_step": round(ms / n_steps, 4),
+            "achieved": round(k_ach, 3), "frac": round(min(bound_ms / k_ms, 1.0), 5) if k_ms > 0 else None,
+            "kernel_ms_per_" + per: round(k_ms, 4),
             "time_basis": "sum of the family's kernel durations - a start / stop HIP event on every dispatch "
                           "(hipExtLaunchKernelGGL through ivln_family_timing_begin / _end), the per-kernel figure rocprofv3 "
                           "reports - in an instrumented EAGER single-stream pass outside the timed region",
@@ -337,7 +399,7 @@ def pmc_traffic(name, key):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs,
     gfx950 FETCH correction applied; profiles/<name>).  A counter pass cannot run inside the timed bench, so the
     figure is the committed one and only for its workload; None when no such profile is committed."""
-    for rnd in ("r04", "r03", "r02", "r01"):
+    for rnd in PROFILE_ROUNDS:
         path = os.path.join(ROOT, "profiles", f"{rnd}_{name}")
         if os.path.exists(path):
             try:
@@ -406,6 +468,7 @@ class UpdateLeg:
 
     def timed(self, barrier, max_over_ranks, iters=5, warm=2, reps=5):
         """`reps` repetitions of `iters` updates, each bracketed by the barrier; -> list of ms per update."""
+        from ivln_ce_amd import dist as D
         from ivln_ce_amd.aux_losses import AuxLosses
 
         AuxLosses.activate()
@@ -413,6 +476,7 @@ class UpdateLeg:
             for _ in range(warm):
                 self.once()
             out = []
+            D.ALLREDUCE_EVENTS = [] if self.world > 1 else None  # (event pairs around the collective of the timed updates)
             for _ in range(reps):
                 barrier()
                 t0 = time.perf_counter()
@@ -422,12 +486,15 @@ class UpdateLeg:
                 out.append(1e3 * max_over_ranks(time.perf_counter() - t0) / iters)
         finally:
             AuxLosses.deactivate()
+            self._allreduce = self.allreduce_object()
+            D.ALLREDUCE_EVENTS = None
         return out
 
-    def roofline(self):
-        """MFMA kernel family of one update (instrumented pass, outside the timed region).  The durations are summed, so the
-        pass runs everything on one stream: with the instruction branch on its side stream (the timed configuration)
-        concurrent launches would be counted twice over the same wall time."""
+    def roofline(self, wall_ms_per_update=None):
+        """MFMA kernel family of one update: `frac` on the update's WALL time (the timed median repetition) against the
+        peak of its fp32 / split-bf16 FLOP mix; the summed kernel durations of the instrumented pass are the secondary
+        `kernel_time`.  The durations are summed, so that pass runs everything on one stream: with the instruction
+        branch on its side stream (the timed configuration) concurrent launches would be counted twice."""
         from ivln_ce_amd import train as _train
         from ivln_ce_amd.aux_losses import AuxLosses
 
@@ -440,17 +507,32 @@ class UpdateLeg:
         finally:
             _train.OVERLAP_INSTRUCTION = overlap
             AuxLosses.deactivate()
-        ach = (gt.flops / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
-        tr = pmc_traffic_pair("update_pmc_traffic.json")
-        return {"split_bf16": split_bf16_part(gt, 1, ms),
-                "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None if tr is None else tr[0],
-                "traffic_unit": "HBM bytes per launch of the family (rocprofv3 PMC passes committed under profiles/)",
-                "traffic_bytes_per_update": None if tr is None else tr[1],
-                "flops_per_update": int(gt.flops), "launches_per_update": gt.launches, "kernel_ms_per_update": round(ms, 3),
-                "basis": "algorithmic FLOPs / summed kernel durations of the family (single-stream instrumented pass)",
-                "kernel": "MFMA family: k_conv_bf3 (split-bf16: the map CNN's forward convs and input gradients) / k_wgrad_direct / "
-                          "k_gemm_vec / k_gemm (fp32 MFMA)"}
+        return mfma_roofline(gt, ms, 1, pmc_traffic_pair("update_pmc_traffic.json"),
+                             "k_conv_bf3 / k_wgrad_bf3 (split-bf16: the map CNN's forward convs, input gradients and weight "
+                             "gradients), k_gemm_vec / k_gemm (fp32 MFMA: linears, Conv1d, their gradients) of one update",
+                             wall_ms_per_step=wall_ms_per_update, busy=pmc_mfma_busy("update_pmc_mfma_util.csv"), per="update")
+
+    def allreduce_object(self):
+        """The update's ONE collective (flat fp32 gradient bucket, sum) by itself: event pair around the call inside
+        the timed updates (ivln_ce_amd.dist.ALLREDUCE_EVENTS).  Populated when world > 1."""
+        from ivln_ce_amd import dist as D
+
+        nbytes = int(self.opt.grad.numel()) * 4
+        obj = {"bytes": nbytes, "calls_per_update": 1, "world": self.world, "ms": None, "bus_GBps": None, "algo_GBps": None,
+               "what": "torch.distributed.all_reduce(SUM) of the flat gradient bucket between backward and Adam "
+                       "(backend nccl = RCCL over xGMI; 1/world folded into the Adam kernel); ms = median over the timed "
+                       "updates of a HIP event pair around the call on the update's stream; bus = 2 (n-1)/n x bytes / time"}
+        ev = D.ALLREDUCE_EVENTS
+        if self.world > 1 and ev:
+            torch.cuda.synchronize()
+            t = sorted(a.elapsed_time(b) for a, b in ev)
+            med = t[len(t) // 2]
+            obj["ms"] = round(med, 4)
+            obj["samples"] = len(t)
+            if med > 0:
+                obj["algo_GBps"] = round(nbytes / (med * 1e-3) / 1e9, 2)
+                obj["bus_GBps"] = round(2.0 * (self.world - 1) / self.world * nbytes / (med * 1e-3) / 1e9, 2)
+        return obj
 
     def cpu_baseline(self, budget_s=25.0):
         """The oracle's update on the host cores: `MapCMAPolicyRef.update_loss` (base_il_trainer.py:173-219 restated
@@ -804,7 +886,8 @@ def main():
         ul = UpdateLeg(policy, dev, world)
         ums = ul.timed(barrier, max_over_ranks, iters=max(5, min(K, 20)), reps=1)  # (a collective: every rank)
         if rank == 0:
-            print(json.dumps({"update_step": {"ms_per_update": round(ums[0], 3), "roofline": ul.roofline()}}), flush=True)
+            print(json.dumps({"update_step": {"ms_per_update": round(ums[0], 3), "roofline": ul.roofline(ums[0]),
+                                              "allreduce": ul._allreduce}}), flush=True)
         return
     mode = False if args.no_graph else (True if args.streams else (False if args.single_stream else "split"))
 
@@ -843,7 +926,7 @@ def main():
         return {"ms": ms, "tr": tr, "obs_cpu": obs_cpu, "obs_dev": obs_dev, "state": state, "n_pool": n_pool, "B": B,
                 "launch": ("hipGraph replay, " + note) if note else "eager", "overlapped": note is not None and "2 streams" in note}
 
-    def instrumented_mfma(leg, n_inst, what, traffic):
+    def instrumented_mfma(leg, n_inst, what, traffic, busy=None):
         """MFMA-family figures of a leg from an eager pass with a start / stop event on every GEMM-family dispatch, the GPU
         parked on a spin kernel while the host enqueues each step so that the durations are those of back-to-back kernels
         (what rocprofv3's per-kernel durations show) and not the host's launch gaps.  Not part of any `value`."""
@@ -865,7 +948,7 @@ def main():
         finally:
             PredictSemantics.USE_PLAN = plan
         med = stats_of(leg["ms"])[0]
-        return mfma_roofline(gt, ms, n_inst, traffic, what, wall_ms_per_step=med)
+        return mfma_roofline(gt, ms, n_inst, traffic, what, wall_ms_per_step=med, busy=busy)
 
     def leg_object(leg, pred, what_cfg):
         med = stats_of(leg["ms"])[0]
@@ -876,10 +959,12 @@ def main():
         if rank == 0:
             if pred:
                 obj["roofline"] = instrumented_mfma(leg, min(6, K), "RedNet + depth ResNet + map CNN launches of one step",
-                                                    pmc_traffic_pair(f"predsem_B{Bl}_pmc_traffic.json"))
+                                                    pmc_traffic_pair(f"predsem_B{Bl}_pmc_traffic.json"),
+                                                    busy=pmc_mfma_busy(f"predsem_B{Bl}_pmc_mfma_util.csv"))
             else:
                 obj["roofline"] = instrumented_mfma(leg, min(20, K), "all conv/linear launches of one step",
-                                                    pmc_traffic_pair("rollout_pmc_traffic.json") if Bl == 4 else None)
+                                                    pmc_traffic_pair("rollout_pmc_traffic.json") if Bl == 4 else None,
+                                                    busy=pmc_mfma_busy("rollout_pmc_mfma_util.csv") if Bl == 4 else None)
                 obj["mapper_roofline"] = mapper_roofline(leg["tr"], leg["obs_dev"], Bl)
             if world == 1 and not args.no_cpu_baseline:
                 log(f"cpu baseline ({'pred' if pred else 'gt'}-semantics) ...")
@@ -919,8 +1004,9 @@ def main():
                           "batch: inflection weights 3.2 from the targets, progress U(0,1)): MapCMA forward with BPTT, "
                           "inflection-weighted CE + progress-monitor aux loss, HIP backward, "
                           + ("one flat RCCL all-reduce, " if world > 1 else "") + "Adam"}
+        update["allreduce"] = ul._allreduce
         if rank == 0:
-            update["roofline"] = ul.roofline()
+            update["roofline"] = ul.roofline(umed)
             if world == 1 and not args.no_cpu_baseline:
                 log("cpu baseline (update) ...")
                 update["cpu_baseline"] = ul.cpu_baseline()
@@ -967,7 +1053,7 @@ def main():
     out = {
         "metric": METRIC, "value": head["value"], "unit": "env-steps/s", "n_gpus": world,
         "steps": K, "warmup": W, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
         "dtype_note": "fp32 in, fp32 out, fp32 accumulation everywhere; the large 3x3 / 7x7 convs form their fp32 products from "
                       "three bf16 pieces per operand on the bf16 MFMA pipe (six piece products, the dropped ones < 2^-23 of a "
                       "product: error vs float64 at or below the fp32 MFMA kernels', tests/test_gpu_kernels.py; IVLN_SPLIT_BF16=0 "

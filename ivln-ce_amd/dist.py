@@ -43,10 +43,24 @@ def _require_group(what: str) -> bool:
     return False
 
 
+# bench.py sets this to a list for the timed updates: every gradient all-reduce then leaves a (start, stop) HIP event pair
+# recorded on the calling stream around the ONE collective call - the collective's own cost inside an update
+# (`update_step.allreduce`); None = no events (the normal case)
+ALLREDUCE_EVENTS = None
+
+
 def allreduce_sum_(flat: torch.Tensor):
-    """In-place sum all-reduce of the flat gradient bucket (26.3 MB fp32 for MapCMA)."""
+    """In-place sum all-reduce of the flat gradient bucket (26.3 MB fp32 for MapCMA): ONE collective call on the calling
+    stream (the update runs on ops.eager_work_stream; torch's RCCL work is ordered against it on both sides)."""
     if _require_group("allreduce_sum_"):
+        timed = ALLREDUCE_EVENTS is not None and flat.is_cuda
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        if timed:
+            e1.record()
+            ALLREDUCE_EVENTS.append((e0, e1))
     return flat
 
 

@@ -179,6 +179,31 @@ def _loss_pin(dev):
     return _loss_pins[k]
 
 
+def merge_episodic_shards(gathered):
+    """Rank 0's view of an episodic evaluation: `gathered` = one (stats_episodes, (agent tours, ground-truth tours)) per
+    rank in rank order (dist.gather_objects).  Scenes / envs are sharded by index modulo world (env_utils.py:77-99), so
+    episode ids and tour ids never repeat across ranks: plain dictionary unions."""
+    stats_episodes, agent_paths, gt_paths = {}, {}, {}
+    for s, (a, g) in gathered:
+        stats_episodes.update(s)
+        agent_paths.update(a)
+        gt_paths.update(g)
+    return stats_episodes, agent_paths, gt_paths
+
+
+def merge_iterative_shards(gathered):
+    """The same for the iterative evaluation: one (stats per tour, dtw_data per tour, ground-truth tours) per rank.  A
+    rank runs whole tours (tour memory never crosses ranks), so a tour's records come from one rank, in step order."""
+    stats_tours, dtw_data, gt_paths = {}, {}, {}
+    for st, dd, gt in gathered:
+        for tour, eps in st.items():
+            stats_tours.setdefault(tour, {}).update(eps)
+        for tour, pts in dd.items():
+            dtw_data.setdefault(tour, []).extend(pts)
+        gt_paths.update(gt)
+    return stats_tours, dtw_data, gt_paths
+
+
 def update_agent(policy, optimizer: FlatAdam, observations, prev_actions, not_done_masks, corrected_actions, weights,
                  hidden_size=512, step_grad=True, loss_accumulation_scalar=1, world=1, tour_not_done_masks=None,
                  rnn_states=None):
@@ -688,11 +713,7 @@ class BaseVLNCETrainer:
         envs.close()
         if self.rank != 0:
             return None
-        stats_episodes, agent_paths, gt_paths = {}, {}, {}
-        for s, (a, g) in gathered:
-            stats_episodes.update(s)
-            agent_paths.update(a)
-            gt_paths.update(g)
+        stats_episodes, agent_paths, gt_paths = merge_episodic_shards(gathered)
         aggregated_stats = {}
         num_episodes = len(stats_episodes)
         for stat_key in next(iter(stats_episodes.values())).keys():
@@ -845,13 +866,7 @@ class BaseVLNCETrainer:
         envs.close()
         if self.rank != 0:
             return None
-        stats_tours, dtw_data, gt_paths = {}, {}, {}
-        for st, dd, gt in gathered:
-            for tour, eps in st.items():
-                stats_tours.setdefault(tour, {}).update(eps)
-            for tour, pts in dd.items():
-                dtw_data.setdefault(tour, []).extend(pts)
-            gt_paths.update(gt)
+        stats_tours, dtw_data, gt_paths = merge_iterative_shards(gathered)
         if config.EVAL.SAVE_RESULTS:  # DTW evaluation data and every episode's stats, for further analysis
             with open(os.path.join(config.RESULTS_DIR, f"dtw_data_ckpt_{checkpoint_index}_{split}.json"), "w") as f:
                 json.dump(dtw_data, f, indent=2)

@@ -22,26 +22,60 @@ def _bench(args, env=None, timeout=900):
 
 def test_bench_line_carries_the_contract_at_one_gpu():
     d = _bench(["--steps", "4", "--warmup", "2", "--reps", "3", "--no-cpu-baseline"])
-    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["unit"] == "env-steps/s" and d["dtype"] == "f32"
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["unit"] == "env-steps/s"
+    assert d["dtype"].startswith("f32") and "bf16x3" in d["dtype"]  # (the split-bf16 qualifier is part of the value)
     assert "configs[2]" in d["config"]["workload"] and d["config"]["envs_per_gpu"] == 8
     assert d["repetitions"]["n"] == 3
     assert d["repetitions"]["ms_per_step_min"] <= d["ms_per_step"] <= d["repetitions"]["ms_per_step_max"]
     assert abs(d["value"] - 8 / (d["ms_per_step"] * 1e-3)) < 0.01 * d["value"]
     roof = d["roofline"]
-    assert roof["bound"] == "mfma" and roof["peak"] == 157.3 and 0.0 < roof["frac"] < 1.0
-    # wall-clock basis: achieved = flops per step / ms per step of the timed (median) repetition
-    assert abs(roof["achieved"] - roof["flops_per_step"] / (d["ms_per_step"] * 1e-3) / 1e12) < 0.02 * roof["achieved"]
-    assert roof["kernel_time"]["frac"] > 0 and roof["traffic"] is not None
-    # the convs that ran on the split-bf16 kernel are spelled out, and priced on their own pipe rate the step stays below 1
-    sp = roof["split_bf16"]
-    assert sp is not None and 0.0 < sp["share_of_family_flops"] < 1.0 and 0.0 < sp["frac_of_mixed_bound"] < 1.0
+
+    def check_mixed(roof, flops_key, wall_ms):
+        """`frac` = achieved / peak on the step's WALL time, where `peak` is the rate of the leg's fp32 / split-bf16 FLOP mix
+        with each pipe at its dense peak - (fp32 FLOPs / 157.3 T + 6 x split FLOPs / 2500 T) / wall: never above 1."""
+        assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and 0.0 < roof["frac"] < 1.0
+        pk = roof["peaks"]
+        assert pk["f32_mfma_tflops"] == 157.3 and pk["bf16_mfma_tflops"] == 2500.0 and pk["bf16_flops_executed_per_split_flop"] == 6
+        flops = roof[flops_key]
+        sp = roof["split_bf16"]
+        split = sp["algorithmic_flops_per_step"] if sp else 0
+        bound_ms = ((flops - split) / 157.3e12 + 6 * split / 2500e12) * 1e3
+        assert abs(roof["achieved"] - flops / (wall_ms * 1e-3) / 1e12) < 0.02 * roof["achieved"]
+        assert abs(roof["frac"] - bound_ms / wall_ms) < 0.02 * roof["frac"]
+        assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 0.02 * roof["frac"]
+        assert 157.3 - 0.01 <= roof["peak"] <= 2500.0 / 6 + 0.01
+        assert 0.0 < roof["kernel_time"]["frac"] <= 1.0
+        assert roof["fp32_peak_basis"]["peak"] == 157.3 and roof["fp32_peak_basis"]["ratio_to_fp32_mfma_peak"] > 0
+        return sp
+
+    sp = check_mixed(roof, "flops_per_step", d["ms_per_step"])
+    assert roof["traffic"] is not None
+    # the convs that ran on the split-bf16 kernel are spelled out
+    assert sp is not None and 0.0 < sp["share_of_family_flops"] < 1.0
     assert sp["executed_bf16_flops_per_step"] == 6 * sp["algorithmic_flops_per_step"] and "dtype_note" in d
+    # MFMA-pipe busy of the dominant kernel from the committed PMC pass
+    mb = roof["mfma_busy"]
+    assert mb is not None and 0.0 < mb["mfma_busy"] <= 1.0 and mb["kernel"].startswith("k_") and mb["source"].startswith("profiles/")
     gt = d["gt_semantics_step"]
-    assert "configs[1]" in gt["config"]["workload"] and gt["envs_per_gpu"] == 4 and gt["roofline"]["frac"] > 0
+    assert "configs[1]" in gt["config"]["workload"] and gt["envs_per_gpu"] == 4
+    check_mixed(gt["roofline"], "flops_per_step", gt["ms_per_step"])
     assert gt["mapper_roofline"]["bound"] == "hbm"
     up = d["update_step"]
     assert up["unit"] == "rows/s" and up["repetitions"]["n"] == 3 and up["roofline"]["traffic"] is not None
-    assert 0.0 < up["roofline"]["split_bf16"]["frac_of_mixed_bound"] < 1.0
+    # the update's fraction is on its WALL time too (the kernel-time figure is the secondary), and below 1
+    check_mixed(up["roofline"], "flops_per_update", up["ms_per_update"])
+    assert up["roofline"]["kernel_time"]["kernel_ms_per_update"] <= up["ms_per_update"] * 1.05
+    ar = up["allreduce"]
+    assert ar["bytes"] > 20e6 and ar["world"] == 1 and ar["ms"] is None  # (populated when world > 1)
+
+    def no_frac_above_one(o):
+        if isinstance(o, dict):
+            for k, v in o.items():
+                if k == "frac" and v is not None:
+                    assert 0.0 <= v <= 1.0, (k, v)
+                no_frac_above_one(v)
+
+    no_frac_above_one(d)
     assert d["dagger_collect_step"]["envs_per_gpu"] == 8
     it = d["dagger_iteration"]
     assert it["iterations"] >= 3 and it["ms_per_iteration"] > 0 and it["legs_alone"]["ms_per_iteration"] > 0
