@@ -212,7 +212,7 @@ int ivln_conv_split_weights_f32(const float* W, int M, int Cin, int KS, void* ou
 int ivln_conv_split_counters(double* flops, long long* launches, int reset);
 
 /* Duration sink of the MFMA family's launches (ivln_gemm_f32 - its split-K reduction excluded -, ivln_gn_conv_f32,
- * ivln_nconv_f32, ivln_conv_gn_f32): between _begin and _end every such launch carries a start / stop event of its own
+ * ivln_nconv_f32): between _begin and _end every such launch carries a start / stop event of its own
  * (hipExtLaunchKernelGGL: the dispatch's begin and end timestamps, what rocprofv3 reports per kernel).  _end waits for
  * the launches, returns the SUM of their durations and their number; `dropped` (optional) = launches beyond
  * max_launches that went out untimed.  One user at a time, not for captured streams: it is how bench.py measures
@@ -224,37 +224,6 @@ int ivln_family_timing_end(double* total_ms, int* launches, int* dropped);
  * not eligible).  Re-run whenever the weights change. */
 int64_t ivln_conv_packed_floats(int M, int Cin, int KS);
 int ivln_conv_pack_weights_f32(const float* W, int M, int Cin, int KS, float* out, void* stream);
-
-/* ------------------------------------------------------------------------------------------
- * Conv2d (bias-free, k = 1 | 3 | 7, square, dilation 1) + GroupNorm (+ ReLU) in ONE launch (csrc/conv_gn.hip):
- * one workgroup per (image, group) owns the [C/groups x Hout*Wout] output tile with the whole K reduction, so the
- * statistics never leave the block.  Replaces the conv -> GroupNorm(16, C) -> ReLU triples of habitat-lab's
- * DD-PPO ResNetEncoder (call site models/encoders/resnet_encoders.py:31-43, 95; conv1 + the three convs of every
- * Bottleneck).  Optional second conv (1x1, stride2, pad 0, its own gamma2/beta2, same Cout / groups / output size):
- *   y = act( GN(conv(x)) + GN2(conv2(x2)) + residual )
- * = the Bottleneck tail `relu(convs(x) + downsample(x))` / `relu(convs(x) + x)`.  *_img_stride = 0 -> dense NCHW.
- * Returns IVLN_E_UNSUPPORTED for shapes outside its envelope (C/groups not in {2,4,8,16,32,64}, Hout*Wout > 4096
- * with wide groups, tile + partials > 160 KB of LDS): the caller then runs ivln_gemm_f32 (deferred) +
- * ivln_groupnorm_f32. */
-typedef struct ivln_conv_gn_desc {
-    const float* x;      /* (N, Cin, Hin, Win) */
-    const float* w;      /* (Cout, Cin, ksize, ksize) */
-    const float* gamma;  /* (Cout) */
-    const float* beta;
-    float* y;            /* (N, Cout, Hout, Wout) */
-    const float* residual; /* like y, or NULL */
-    int N, Cin, Hin, Win, Cout, ksize, stride, pad, groups;
-    float eps;
-    int relu;
-    int64_t x_img_stride, y_img_stride, r_img_stride;
-    const float* x2;     /* second conv input (N, Cin2, Hin2, Win2) or NULL */
-    const float* w2;     /* (Cout, Cin2, 1, 1) */
-    const float* gamma2;
-    const float* beta2;
-    int Cin2, Hin2, Win2, stride2;
-    int64_t x2_img_stride;
-} ivln_conv_gn_desc;
-int ivln_conv_gn_f32(const ivln_conv_gn_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * GroupNorm (+ second normalised operand) (+ residual) (+ ReLU) (+ MaxPool2d(3, 2, 1)) fused with the NEXT

@@ -19,7 +19,6 @@ SOURCES = {
     "gemm_vec.hip": ["-mllvm", "-pragma-unroll-threshold=200000"],
     "conv1x1_stream.hip": [],
     "conv_bf3.hip": [],
-    "conv_gn.hip": [],
     "gn_conv.hip": [],
     "depth_net.hip": [],
     "cma_step.hip": [],

@@ -28,6 +28,7 @@
 #include <type_traits>
 
 #include "gemm_common.h"
+#include "residency.h"
 
 namespace {
 
@@ -829,8 +830,9 @@ int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
     };
     auto blocks_of = [&](int cfg) { return tiles_of(cfg) * ((d.M + kBf3BM[cfg] - 1) / kBf3BM[cfg]); };
     // fills the chip: at most a quarter of the last round of 256 x slots workgroups empty
+    const int CUS = ivln_cu_count();  // (256 on MI355X; a partition mode or another part gets its own count)
     auto fills = [&](int64_t nb, int slots) {
-        const int64_t round = 256 * slots, rounds = (nb + round - 1) / round;
+        const int64_t round = (int64_t)CUS * slots, rounds = (nb + round - 1) / round;
         return nb * 4 >= rounds * round * 3;
     };
     static const int cfg_env = getenv("IVLN_SPLIT_BF16_CFG") ? atoi(getenv("IVLN_SPLIT_BF16_CFG")) : -1;  // tuning
@@ -855,8 +857,8 @@ int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
     if (cfg >= 4) {
         const int slots = cfg == 4 ? 3 : 2;
         const bool may_split = d.splits == 0 && d.ws && nch >= 2 && !d.stat_partials;
-        if (may_split && nb < 256 * slots) {
-            const int64_t want = 256 * slots;
+        if (may_split && nb < (int64_t)CUS * slots) {
+            const int64_t want = (int64_t)CUS * slots;
             splits = (int)((want + nb - 1) / nb);
             if (splits > nch) splits = nch;
             if (splits > 16) splits = 16;
@@ -870,7 +872,7 @@ int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
             if (splits > cap) splits = (int)cap;
             if (splits < 1) splits = 1;
         }
-        if (!force && nb * splits < 192) return IVLN_E_UNSUPPORTED;  // pixel- and channel-starved: the implicit GEMM splits K deeper
+        if (!force && nb * splits < CUS * 3 / 4) return IVLN_E_UNSUPPORTED;  // pixel- and channel-starved: the implicit GEMM splits K deeper
     } else if (!force && !fills(nb, cfg == 6 ? 2 : 1)) {
         return IVLN_E_UNSUPPORTED;
     }
@@ -919,7 +921,7 @@ int ivln_wgrad_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
             static const int want_env = getenv("IVLN_WGRAD_BF3_BLOCKS") ? atoi(getenv("IVLN_WGRAD_BF3_BLOCKS")) : 0;  // tuning
             // one workgroup per CU (LDS): as many splits as keep the grid inside whole rounds of 256 (13 column tiles x 20
             // splits = 260 workgroups ran a second round for four of them)
-            const int64_t want = want_env > 0 ? want_env : 256;
+            const int64_t want = want_env > 0 ? want_env : ivln_cu_count();
             splits = (int)(want / blocks);
             if (splits < 1) splits = 1;
             if (splits > strips) splits = strips;
@@ -931,7 +933,7 @@ int ivln_wgrad_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
         splits = d.splits > strips ? strips : d.splits;
         if (splits > 1 && (!d.ws || d.ws_floats < (int64_t)splits * d.M * d.N)) return IVLN_E_INVALID;
     }
-    if (!force && blocks * splits < 128) return IVLN_E_UNSUPPORTED;  // (a rollout-sized batch: nothing to win)
+    if (!force && blocks * splits < ivln_cu_count() / 2) return IVLN_E_UNSUPPORTED;  // (a rollout-sized batch: nothing to win)
     const int sps = (strips + splits - 1) / splits;
     splits = (strips + sps - 1) / sps;
     d.splits = splits;

@@ -38,6 +38,7 @@
 #include <mutex>
 #include "../../include/ivln_hip.h"
 #include "family_timing.h"
+#include "residency.h"
 
 namespace {
 
@@ -728,19 +729,18 @@ int ivln_depth_net_f32(const ivln_depthnet_op* ops_dev, const ivln_depthnet_op* 
     const size_t lds = sizeof(float) * (size_t)(L.tile + body + 8);
     if (lds > 156 * 1024) return IVLN_E_UNSUPPORTED;
     static std::mutex mu;
-    static int resident = -1;
+    static bool attr_done = false;
     {
         std::lock_guard<std::mutex> lk(mu);
-        if (resident < 0) {
+        if (!attr_done) {
             if (hipFuncSetAttribute((const void*)k_depth_net, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
                 return IVLN_E_HIP;
-            int per_cu = 0, dev = 0, cus = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_depth_net, NT, 120 * 1024) != hipSuccess ||
-                hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-                return IVLN_E_HIP;
-            resident = per_cu * cus;
+            attr_done = true;
         }
     }
+    // residency with THIS launch's LDS footprint on THIS device (csrc/residency.h; the first version asked once, for
+    // 120 KB, on whichever device was current)
+    const int resident = ivln_resident_blocks((const void*)k_depth_net, NT, lds);
     if (resident < 8 * CL) return IVLN_E_UNSUPPORTED;
     // (the clusters spin on each other's arrivals: all of them resident, or none)
     static const int allow_plain = getenv("IVLN_DEPTH_NET_WRITE_THROUGH") ? 0 : 1;  // A/B switch: write-through stores only (519 -> 545 us)

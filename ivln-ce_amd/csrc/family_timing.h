@@ -1,5 +1,5 @@
 // Launch macro of the MFMA-family kernels (k_gemm / k_gemm_vec / k_conv_direct / k_wgrad_direct / k_gn_conv / k_nconv /
-// k_conv_gn) with an optional per-dispatch duration sink.
+// k_conv_bf3 / k_depth_net) with an optional per-dispatch duration sink.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>

@@ -44,6 +44,7 @@
 #include <stdlib.h>
 #include "../../include/ivln_hip.h"
 #include "gru_seq.h"
+#include "residency.h"
 
 namespace {
 
@@ -402,19 +403,7 @@ static int units_per_wg() {
 // it may not be - then the caller runs the per-step launches (IVLN_E_UNSUPPORTED), instead of every grid_wait spinning
 // to its bound.  Answer cached per (kernel, LDS bytes).
 static bool grid_fits(const void* fn, int threads, size_t lds, int grid) {
-    static std::mutex mu;
-    static std::map<std::pair<const void*, size_t>, int> cache;
-    std::lock_guard<std::mutex> lk(mu);
-    const auto key = std::make_pair(fn, lds);
-    auto it = cache.find(key);
-    if (it == cache.end()) {
-        int per_cu = 0, dev = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-            per_cu = cus = 0;
-        it = cache.emplace(key, per_cu * cus).first;
-    }
-    return it->second >= grid;
+    return ivln_resident_blocks(fn, threads, lds) >= grid;  // (csrc/residency.h: cached per device, kernel and LDS bytes)
 }
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

@@ -14,14 +14,13 @@
   * the PARAMETER BLOB (GroupNorm gammas / betas) and the per-image ARENA layout (raw conv outputs, identity
     activations, statistics partials).
 
-`emulate()` replays a program on the CPU with torch - from the PACKED weights and through the statistics-partial
-layout - so that the packing and the wiring are testable without a GPU (tests/test_depth_net_program.py); it is host
-logic, not a fallback: `DepthNetPlan.run` only ever launches the HIP kernel."""
+The packing and the wiring are testable without a GPU: tests/depth_net_emulator.py replays a program on the CPU with torch
+from the PACKED weights and through the statistics-partial layout (tests/test_depth_net_program.py).  That emulator is
+test infrastructure and lives under tests/; `DepthNetPlan.run` only ever launches the HIP kernel."""
 import ctypes as C
 import math
 
 import torch
-import torch.nn.functional as F
 
 I32 = C.c_int
 _FIELDS = ["kind", "Cin", "Cout", "ks", "stride", "pad", "Hin", "Win", "wout_shift", "M", "WCT", "WPT", "P", "KW", "kwg",
@@ -111,25 +110,6 @@ def pack_weights(w, M, KWT):
     return out.reshape(-1)
 
 
-def unpack_weights(blob, Cout, Cin, ks, M, KWT):
-    """Inverse of pack_weights (emulator / tests)."""
-    ksteps = 13 if ks == 7 else (Cin // 4) * ks * ks
-    per, cpk, ranges = _k_ranges(ksteps, KWT)
-    nct, ent = Cout // M, (64 if M == 16 else 32)
-    v = blob.view(nct, KWT, cpk, 4, M, 4)  # tile, kwt, chunk, kq, i, u
-    A = torch.zeros(Cout, ksteps, 4)
-    for kwt, (kb, ke) in enumerate(ranges):
-        n = ke - kb
-        if n <= 0:
-            continue
-        blk = v[:, kwt].permute(0, 3, 1, 4, 2).reshape(Cout, cpk * 4, 4)  # tile, i, chunk, u, kq
-        A[:, kb:ke] = blk[:, :n]
-    if ks == 7:
-        return A.reshape(Cout, 52)[:, :49].reshape(Cout, 1, 7, 7)
-    KK = ks * ks
-    return A.view(Cout, Cin // 4, KK, 4).permute(0, 1, 3, 2).reshape(Cout, Cin, ks, ks).contiguous()
-
-
 class Program:
     """ops (list of dict), weight blob, parameter blob, arena layout."""
 
@@ -214,6 +194,48 @@ def _conv_op(prog, w, stride, pad, Hin, Win, src, barrier, allow_kwg=False, pool
     return op, out
 
 
+_UNSUPPORTED = None  # weak set of encoders whose architecture the persistent kernel does not cover (negative cache)
+
+
+def supported(encoder):
+    """True when `encoder` is the architecture csrc/depth_net.hip is written for - the DD-PPO default the reference
+    builds (resnet_encoders.py:31-43): one-channel 7x7 stride-2 stem, GroupNorm with 16 groups, bottlenecks [3, 4, 6, 3]
+    on 32 base planes (every tiling of `choose_tiling` and the kernel's statistics layout assume 16 groups), a 3x3
+    compression conv with GroupNorm(1).  Anything else (`resnet_baseplanes` = 64 gives 32 groups) runs the launch chain /
+    the conv + GroupNorm pairs as before; the verdict is cached per encoder object."""
+    global _UNSUPPORTED
+    import weakref
+
+    if _UNSUPPORTED is None:
+        _UNSUPPORTED = weakref.WeakSet()
+    if encoder in _UNSUPPORTED:
+        return False
+    ok = getattr(encoder, "_depth_net_ok", None)
+    if ok is None:
+        try:
+            bb = encoder.backbone
+            c1, g1 = bb.conv1[0], bb.conv1[1]
+            layers = (bb.layer1, bb.layer2, bb.layer3, bb.layer4)
+            ok = (c1.in_channels == 1 and c1.kernel_size == (7, 7) and c1.stride == (2, 2) and c1.out_channels == 32
+                  and g1.num_groups == 16 and [len(l) for l in layers] == [3, 4, 6, 3])
+            for li, layer in enumerate(layers):
+                for bi, blk in enumerate(layer):
+                    c = blk.convs
+                    planes = 32 * 2 ** li
+                    ok = ok and len(c) == 8 and c[0].kernel_size == (1, 1) and c[3].kernel_size == (3, 3) and c[6].kernel_size == (1, 1)
+                    ok = ok and c[0].out_channels == planes and c[3].out_channels == planes and c[6].out_channels == 4 * planes
+                    ok = ok and all(c[i].num_groups == 16 for i in (1, 4, 7)) and all(c[i].bias is None for i in (0, 3, 6))
+                    ok = ok and (blk.downsample is None or (blk.downsample[0].kernel_size == (1, 1) and blk.downsample[1].num_groups == 16))
+                    ok = ok and (blk.downsample is not None) == (bi == 0)
+            comp, gcomp = encoder.compression[0], encoder.compression[1]
+            ok = bool(ok and comp.kernel_size == (3, 3) and comp.in_channels == 1024 and gcomp.num_groups == 1)
+        except (AttributeError, IndexError, TypeError):
+            ok = False
+        if not ok:
+            _UNSUPPORTED.add(encoder)
+    return bool(ok)
+
+
 def build_program(encoder):
     """`encoder`: ivln_ce_amd.encoders.ResNetEncoder (depth-only).  One image's program; every image of a batch runs it
     on its own arena."""
@@ -230,7 +252,10 @@ def build_program(encoder):
     # the stem's GroupNorm + ReLU + MaxPool(3, 2, 1) happen on load in the first block's convs
     cur = dict(kind="pool", x=x, gn=stem_gn)
     H, W = x["H"] // 2, x["W"] // 2
-    act_slots = [prog.alloc(128 * 32 * 32), prog.alloc(128 * 32 * 32)]
+    # identity activations ping-pong between two slots sized for the largest block output of the model (layer 1's)
+    act_floats = max(b.convs[6].out_channels * (x["H"] // 2 // max(1, 2 ** li)) ** 2
+                     for li, layer in enumerate((bb.layer1, bb.layer2, bb.layer3, bb.layer4)) for b in layer)
+    act_slots = [prog.alloc(act_floats), prog.alloc(act_floats)]
     act_i = 0
     identity_off = None
     blocks = [b for layer in (bb.layer1, bb.layer2, bb.layer3, bb.layer4) for b in layer]
@@ -289,103 +314,13 @@ def build_program(encoder):
 
 
 # ------------------------------------------------------------------------------------------------
-# CPU emulation of a program (host-logic tests): packed weights -> dense, statistics through the partial layout
-# ------------------------------------------------------------------------------------------------
-def emulate(prog, depth):
-    """depth (256, 256) float32 of ONE image -> (C, h, w) features, executing `prog` op by op with torch on the CPU."""
-    arena = torch.zeros(prog.arena, dtype=torch.float32)
-    wts = torch.cat(prog.wchunks)
-    prm = torch.cat(prog.pchunks)
-    eps = prog.eps
-    out = None
-    for op in prog.ops:
-        if op["kind"] == 1:
-            n = op["Cin"] * op["Hin"] * op["Win"]
-            v = sum(arena[op["src_off"] + z * op["slab_stride"]: op["src_off"] + z * op["slab_stride"] + n] for z in range(op["nslab"]))
-            v = v.view(1, op["Cin"], op["Hin"], op["Win"])
-            out = F.relu(F.group_norm(v, 1, prm[op["gamma_off"]:op["gamma_off"] + op["Cin"]], prm[op["beta_off"]:op["beta_off"] + op["Cin"]], eps))[0]
-            continue
-        Cin, Cout, ks, s, pad, Hin, Win = (op[k] for k in ("Cin", "Cout", "ks", "stride", "pad", "Hin", "Win"))
-        Wout = 1 << op["wout_shift"]
-
-        def merged(st_off, parts, C_):
-            st = arena[st_off: st_off + 16 * parts * 4].view(16, parts, 4)
-            n, m, M2 = st[..., 0], st[..., 1], st[..., 2]
-            cnt = n.sum(1)
-            mean = (n * m).sum(1) / cnt
-            var = (M2 + n * (m - mean[:, None]) ** 2).sum(1) / cnt
-            return mean.repeat_interleave(C_ // 16), torch.rsqrt(var + eps).repeat_interleave(C_ // 16)
-
-        if op["avg_in"]:
-            x = F.avg_pool2d(depth.view(1, 1, 2 * Hin, 2 * Win), 2)
-        else:
-            Hr, Wr = (2 * Hin, 2 * Win) if op["pool"] else (Hin, Win)
-            n = Cin * Hr * Wr
-            x = sum(arena[op["src_off"] + z * op["slab_stride"]: op["src_off"] + z * op["slab_stride"] + n] for z in range(op["nslab"]))
-            x = x.view(1, Cin, Hr, Wr).clone()
-            if op["st_parts"]:
-                mean, rstd = merged(op["st_off"], op["st_parts"], Cin)
-                ga, be = prm[op["gamma_off"]:op["gamma_off"] + Cin], prm[op["beta_off"]:op["beta_off"] + Cin]
-                x = (x - mean.view(1, -1, 1, 1)) * (rstd * ga).view(1, -1, 1, 1) + be.view(1, -1, 1, 1)
-                if op["src2_off"] >= 0:
-                    x2 = arena[op["src2_off"]: op["src2_off"] + n].view(1, Cin, Hr, Wr)
-                    mean2, rstd2 = merged(op["st2_off"], op["st2_parts"], Cin)
-                    g2, b2 = prm[op["gamma2_off"]:op["gamma2_off"] + Cin], prm[op["beta2_off"]:op["beta2_off"] + Cin]
-                    x = x + (x2 - mean2.view(1, -1, 1, 1)) * (rstd2 * g2).view(1, -1, 1, 1) + b2.view(1, -1, 1, 1)
-            if op["res_off"] >= 0:
-                x = x + arena[op["res_off"]: op["res_off"] + n].view(1, Cin, Hr, Wr)
-            if op["relu"]:
-                x = F.relu(x)
-            if op["pool"]:
-                x = F.max_pool2d(x, 3, 2, 1)
-            if op["act_out_off"] >= 0:
-                arena[op["act_out_off"]: op["act_out_off"] + Cin * Hin * Win] = x.reshape(-1)
-        KWT = op["KW"] * op["kwg"]
-        ksteps = op["ksteps"]
-        per, cpk, ranges = _k_ranges(ksteps, KWT)
-        ent = 64 if op["M"] == 16 else 32
-        nblob = (Cout // op["M"]) * KWT * cpk * ent * 4
-        w = unpack_weights(wts[op["w_off"]: op["w_off"] + nblob], Cout, Cin, ks, op["M"], KWT)
-        HWo = Wout * Wout
-        if op["kwg"] == 1:
-            y = F.conv2d(x, w, None, s, pad)[0]
-            arena[op["dst_off"]: op["dst_off"] + Cout * HWo] = y.reshape(-1)
-        else:  # slabs: workgroup K slices = contiguous ranges of the packed k order
-            A = weight_matrix(w)  # (Cout, ksteps, 4)
-            for kg in range(op["kwg"]):
-                kb, ke = ranges[kg * op["KW"]][0], ranges[(kg + 1) * op["KW"] - 1][1]
-                Ak = torch.zeros_like(A)
-                Ak[:, kb:ke] = A[:, kb:ke]
-                KK = ks * ks
-                wk = Ak.view(Cout, Cin // 4, KK, 4).permute(0, 1, 3, 2).reshape(Cout, Cin, ks, ks)
-                arena[op["dst_off"] + kg * op["dst_slab_stride"]: op["dst_off"] + kg * op["dst_slab_stride"] + Cout * HWo] = \
-                    F.conv2d(x, wk, None, s, pad)[0].reshape(-1)
-            continue
-        if op["st_out_parts"]:
-            parts = op["st_out_parts"]
-            st = arena[op["st_out_off"]: op["st_out_off"] + 16 * parts * 4].view(16, parts, 4)
-            rows_t, PG, cpo = op["WCT"] * op["M"], 16 * op["WPT"] * op["P"], Cout // 16
-            yf = y.reshape(Cout, HWo)
-            for ctg in range(op["n_ctg"]):
-                for ptg in range(op["n_ptg"]):
-                    co0 = ctg * rows_t
-                    rows_lg = min(cpo, rows_t)
-                    cparts = max(1, cpo // rows_t)
-                    part = ptg * cparts + ((co0 % cpo) // rows_t if cpo > rows_t else 0)
-                    for lg in range(rows_t // rows_lg):
-                        blk = yf[co0 + lg * rows_lg: co0 + (lg + 1) * rows_lg, ptg * PG:(ptg + 1) * PG]
-                        g = co0 // cpo + (0 if cpo > rows_t else lg)
-                        st[g, part, 0] = blk.numel()
-                        st[g, part, 1] = blk.mean()
-                        st[g, part, 2] = ((blk - blk.mean()) ** 2).sum()
-    return out
-
-
-# ------------------------------------------------------------------------------------------------
 # device plan
 # ------------------------------------------------------------------------------------------------
 class DepthNetPlan:
-    """Device-side state of one encoder: op table, packed weights, parameters, arena for up to 8 images, sync words."""
+    """Device-side state of one encoder: op table, packed weights and parameters (shared by every launch), and PER STREAM an
+    arena for up to 8 images + the cluster sync words.  Two launches that may overlap on the device - the side-stream graph
+    of a split replay and an eager act() on the main stream, two runners captured on one policy - never share an arena or
+    arrival counters; launches on ONE stream are ordered by the stream (the contract the workspaces of ops.py follow)."""
 
     MAX_IMAGES = 8
 
@@ -401,8 +336,7 @@ class DepthNetPlan:
         self.weights = torch.cat(self.prog.wchunks).to(device)
         self.params = torch.cat(self.prog.pchunks).to(device)
         self.arena_stride = (self.prog.arena + 255) // 256 * 256
-        self.arena = torch.zeros(self.MAX_IMAGES * self.arena_stride, dtype=torch.float32, device=device)
-        self.sync = torch.zeros(512, dtype=torch.int32, device=device)
+        self._per_stream = {}  # stream handle -> (arena, sync words)
         self.stamp = self.stamp_of(encoder)
         L = lib()
         vp, i64 = C.c_void_p, C.c_int64
@@ -423,12 +357,27 @@ class DepthNetPlan:
 
     def refresh(self, encoder):
         """New weights, same architecture: repack into the SAME device buffers (a captured graph keeps raw pointers to
-        them; the op table does not depend on the weights' values)."""
+        them; the op table does not depend on the weights' values).  The copies are ordered behind every launch that may
+        still read the old weights (the device is drained first: this is a rare, host-heavy path - a frozen encoder, the
+        only kind the reference configures, never comes here) and in front of the next launch on any stream."""
         prog = build_program(encoder)
         assert prog.w_floats == self.weights.numel() and prog.p_floats == self.params.numel()
+        torch.cuda.synchronize(self.device)
         self.weights.copy_(torch.cat(prog.wchunks))
         self.params.copy_(torch.cat(prog.pchunks))
+        torch.cuda.synchronize(self.device)
         self.stamp = self.stamp_of(encoder)
+
+    def stream_state(self, create=True):
+        """(arena, sync words) of the CURRENT stream; None when it does not exist yet and may not be created (a capture in
+        progress: the warm-up step on the capturing stream creates it)."""
+        key = self._ops.stream_ptr()
+        st = self._per_stream.get(key)
+        if st is None and create and not torch.cuda.is_current_stream_capturing():
+            st = self._per_stream[key] = (
+                torch.zeros(self.MAX_IMAGES * self.arena_stride, dtype=torch.float32, device=self.device),
+                torch.zeros(512, dtype=torch.int32, device=self.device))
+        return st
 
     def run(self, depth, out, out_img_stride):
         """depth (B, H, W, 1) float32 contiguous on the device -> out[b * out_img_stride + ...] (C, h, w) per image.
@@ -438,9 +387,13 @@ class DepthNetPlan:
         ops = self._ops
         B, H, W, _ = depth.shape
         assert B <= self.MAX_IMAGES and H == 256 and W == 256
+        st = self.stream_state()
+        if st is None:
+            return False
+        arena, sync = st
         rc = self._L.ivln_depth_net_f32(ops.dptr(self.ops_dev), self._ops_host, len(self.prog.ops), ops.dptr(self.weights),
-                                        ops.dptr(self.params), ops.dptr(depth), H * W, ops.dptr(self.arena), self.arena_stride,
-                                        out.data_ptr(), out_img_stride, B, self.prog.eps, ops.dptr(self.sync), ops.stream_ptr())  # (`out`: a channel slice of a wider buffer)
+                                        ops.dptr(self.params), ops.dptr(depth), H * W, ops.dptr(arena), self.arena_stride,
+                                        out.data_ptr(), out_img_stride, B, self.prog.eps, ops.dptr(sync), ops.stream_ptr())  # (`out`: a channel slice of a wider buffer)
         if rc == IVLN_E_UNSUPPORTED:
             return False
         check(rc, "ivln_depth_net_f32")
@@ -449,11 +402,16 @@ class DepthNetPlan:
     def check_status(self):
         from ._lib import check
 
-        check(self._L.ivln_depth_net_status(self._ops.dptr(self.sync), self._ops.stream_ptr()),
-              "ivln_depth_net_status (a cluster barrier of the persistent depth encoder timed out)")
+        for _, sync in list(self._per_stream.values()):
+            check(self._L.ivln_depth_net_status(self._ops.dptr(sync), self._ops.stream_ptr()),
+                  "ivln_depth_net_status (a cluster barrier of the persistent depth encoder timed out)")
 
 
 _PLANS = {}
+
+
+def ops_weight_flags(encoder):
+    return tuple(p.requires_grad for p in encoder.parameters())
 
 
 def plan_for(encoder, device):
@@ -462,6 +420,17 @@ def plan_for(encoder, device):
     that no longer exist are dropped (each holds ~100 MB: arena for 8 images + packed weights)."""
     import weakref
 
+    if not supported(encoder):
+        return None
+    # A trainable encoder changes after every optimizer step: each change would cost a host-side repack of 23 M weights
+    # (hundreds of ms) - it runs the launch chain.  (The reference freezes the DD-PPO encoder, resnet_encoders.py:45-46;
+    # checked once per encoder object and requires_grad pattern.)
+    rg = getattr(encoder, "_depth_net_rg", None)
+    if rg is None or rg[0] != ops_weight_flags(encoder):
+        flags = ops_weight_flags(encoder)
+        encoder._depth_net_rg = rg = (flags, any(flags))
+    if rg[1]:
+        return None
     for k in [k for k, (ref, _) in _PLANS.items() if ref() is None]:
         del _PLANS[k]
     key = (id(encoder), str(device))

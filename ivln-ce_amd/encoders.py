@@ -220,19 +220,6 @@ class _Bottleneck(nn.Module):
         """conv -> GroupNorm(+ReLU) pairs: the conv leaves raw (split-K) slabs in the workspace and the
         GroupNorm kernel reduces + normalises them, 2 launches per pair."""
         c = self.convs
-        # one launch per conv + GroupNorm (+ReLU) pair; the block's last launch also runs the downsample branch
-        # (conv + its GroupNorm) or adds the identity: 3 launches per bottleneck instead of 6-7
-        y = ops.conv_gn(x, c[0].weight, c[1], relu=True)
-        if y is not None:
-            y2 = ops.conv_gn(y, c[3].weight, c[4], stride=self.stride, pad=1, relu=True)
-            if y2 is not None:
-                if self.downsample is not None:
-                    out = ops.conv_gn(y2, c[6].weight, c[7], relu=True,
-                                      ds=(x, self.downsample[0].weight, self.downsample[1], self.stride))
-                else:
-                    out = ops.conv_gn(y2, c[6].weight, c[7], relu=True, residual=x)
-                if out is not None:
-                    return out
         y, ds = self.body_hip(x)
         if ds is not None:
             gn = self.downsample[1]
@@ -395,10 +382,8 @@ class _ResNet50GN(nn.Module):
 
     def forward_hip(self, x):
         c, gn = self.conv1[0], self.conv1[1]
-        y = ops.conv_gn(x, c.weight, gn, stride=2, pad=3, relu=True)
-        if y is None:
-            y = ops.conv2d(x, c.weight, stride=2, pad=3, defer=True)
-            y = ops.groupnorm(y, gn.weight, gn.bias, gn.num_groups, gn.eps, relu=True)
+        y = ops.conv2d(x, c.weight, stride=2, pad=3, defer=True)
+        y = ops.groupnorm(y, gn.weight, gn.bias, gn.num_groups, gn.eps, relu=True)
         y = ops.pool2d(y, 3, 2, 1, "max")
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
             for blk in layer:

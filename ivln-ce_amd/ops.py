@@ -674,61 +674,7 @@ def groupnorm(x, gamma, beta, groups, eps=1e-5, relu=False, residual=None, out=N
     return out
 
 
-class ConvGnDesc(C.Structure):
-    """Mirror of `ivln_conv_gn_desc` (include/ivln_hip.h) - field order must match."""
-
-    _fields_ = [
-        ("x", vp), ("w", vp), ("gamma", vp), ("beta", vp), ("y", vp), ("residual", vp),
-        ("N", i32), ("Cin", i32), ("Hin", i32), ("Win", i32), ("Cout", i32), ("ksize", i32), ("stride", i32),
-        ("pad", i32), ("groups", i32),
-        ("eps", f32), ("relu", i32),
-        ("x_img_stride", i64), ("y_img_stride", i64), ("r_img_stride", i64),
-        ("x2", vp), ("w2", vp), ("gamma2", vp), ("beta2", vp),
-        ("Cin2", i32), ("Hin2", i32), ("Win2", i32), ("stride2", i32),
-        ("x2_img_stride", i64),
-    ]
-
-
-# conv + GroupNorm as ONE launch (csrc/conv_gn.hip).  Measured SLOWER than the deferred-conv + GroupNorm pair on every
-# shape of the depth ResNet at 4-8 envs (profiles/r02_conv_gn_ab.txt: 214 vs 150 us over the 13 shapes, the step 1.20
-# vs 0.99 ms), so it is off by default; IVLN_CONV_GN=1 or ops.FUSE_CONV_GN = True selects it (tests do).
-FUSE_CONV_GN = bool(os.environ.get("IVLN_CONV_GN"))
 IVLN_E_UNSUPPORTED = -5
-
-
-def conv_gn(x, w, gn, stride=1, pad=0, relu=False, residual=None, ds=None, out=None, y_img_stride=0, force=False):
-    """act(GroupNorm(conv2d(x, w))) [+ GroupNorm_ds(conv1x1_ds(x0))] [+ residual] in ONE launch: a workgroup per
-    (image, group) owns the whole reduction of its output tile (csrc/conv_gn.hip).  `gn`: nn.GroupNorm of the conv;
-    `ds` = (x0, w_ds, gn_ds, stride_ds): the bottleneck's downsample branch.  Returns None when the shape is
-    outside the kernel's envelope (the caller then runs the deferred conv + GroupNorm pair)."""
-    if not FUSE_CONV_GN and not force:
-        return None
-    N, Cin, H, W = x.shape
-    Cout, _, KH, KW = w.shape
-    if KH != KW:
-        return None
-    Ho = (H + 2 * pad - KH) // stride + 1
-    Wo = (W + 2 * pad - KW) // stride + 1
-    if out is None:
-        out = torch.empty((N, Cout, Ho, Wo), dtype=torch.float32, device=x.device)
-    d = ConvGnDesc()
-    d.x, d.w, d.gamma, d.beta, d.y, d.residual = dptr(x), dptr(w), dptr(gn.weight), dptr(gn.bias), _p(out), _p(residual)
-    d.N, d.Cin, d.Hin, d.Win, d.Cout, d.ksize, d.stride, d.pad, d.groups = N, Cin, H, W, Cout, KH, stride, pad, gn.num_groups
-    d.eps, d.relu = gn.eps, int(bool(relu))
-    d.y_img_stride = y_img_stride
-    if ds is not None:
-        x0, w0, gn0, s0 = ds
-        if gn0.num_groups != gn.num_groups or gn0.eps != gn.eps or w0.shape[2] != 1:
-            return None
-        d.x2, d.w2, d.gamma2, d.beta2 = dptr(x0), dptr(w0), dptr(gn0.weight), dptr(gn0.bias)
-        d.Cin2, d.Hin2, d.Win2, d.stride2 = x0.shape[1], x0.shape[2], x0.shape[3], s0
-    L = _L()
-    L.ivln_conv_gn_f32.argtypes = [C.POINTER(ConvGnDesc), vp]
-    code = L.ivln_conv_gn_f32(C.byref(d), stream_ptr())
-    if code == IVLN_E_UNSUPPORTED:
-        return None
-    check(code, "ivln_conv_gn_f32")
-    return out
 
 
 # depth ResNet as a chain of GroupNorm+next-conv launches (csrc/gn_conv.hip); IVLN_GN_CONV=0 selects the deferred

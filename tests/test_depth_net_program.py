@@ -1,5 +1,5 @@
 """Host logic of the persistent depth encoder (ivln-ce_amd/depth_net.py), no GPU: the op table, the MFMA-order weight
-packing and the statistics-partial wiring, replayed on the CPU by `depth_net.emulate` (from the PACKED weights and
+packing and the statistics-partial wiring, replayed on the CPU by tests/depth_net_emulator.py (from the PACKED weights and
 through the partial layout) against the oracle's torch restatement of habitat-lab's ResNetEncoder
 (oracle/habitat_ext_ref.py; resnet_encoders.py:31-43, 95)."""
 import os
@@ -9,6 +9,7 @@ import types
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.dirname(__file__))
 
 
 def _encoder(seed=5):
@@ -25,6 +26,7 @@ def _encoder(seed=5):
 
 
 def test_weight_packing_round_trips_for_every_tile_form():
+    import depth_net_emulator as E
     from ivln_ce_amd import depth_net as D
 
     g = torch.Generator().manual_seed(0)
@@ -32,7 +34,7 @@ def test_weight_packing_round_trips_for_every_tile_form():
                                     (128, 1024, 3, 16, 32), (128, 32, 1, 16, 1), (512, 256, 1, 16, 2)]:
         w = torch.randn(Cout, Cin, ks, ks, generator=g)
         blob = D.pack_weights(w, M, KWT)
-        assert torch.equal(D.unpack_weights(blob, Cout, Cin, ks, M, KWT), w), (Cout, Cin, ks, M, KWT)
+        assert torch.equal(E.unpack_weights(blob, Cout, Cin, ks, M, KWT), w), (Cout, Cin, ks, M, KWT)
         # the kernel's own index formula for one element: A[tile*M + i][kbeg + 4 chunk + u][kq]
         A = D.weight_matrix(w)
         per, cpk, ranges = D._k_ranges(A.shape[1], KWT)
@@ -46,6 +48,7 @@ def test_weight_packing_round_trips_for_every_tile_form():
 
 
 def test_program_covers_the_network_and_fits_the_cluster():
+    import depth_net_emulator as E
     from ivln_ce_amd import depth_net as D
 
     prog = D.build_program(_encoder())
@@ -65,6 +68,7 @@ def test_program_covers_the_network_and_fits_the_cluster():
 
 
 def test_emulated_program_matches_the_oracle_encoder():
+    import depth_net_emulator as E
     from ivln_ce_amd import depth_net as D
     from oracle import habitat_ext_ref as R
 
@@ -76,7 +80,23 @@ def test_emulated_program_matches_the_oracle_encoder():
     depth = torch.rand(1, 256, 256, 1, generator=torch.Generator().manual_seed(3))
     with torch.no_grad():
         want = ref({"depth": depth})[0]
-        got = D.emulate(prog, depth[0, :, :, 0].contiguous())
+        got = E.emulate(prog, depth[0, :, :, 0].contiguous())
     assert got.shape == want.shape == (128, 4, 4)
     err = float((got - want).abs().max())
     assert err < 2e-4, err
+
+
+def test_supported_is_the_reference_default_architecture_only():
+    """anything but the DD-PPO default (16 GroupNorm groups on 32 base planes, [3, 4, 6, 3] bottlenecks, a
+    one-channel 7x7 stem) is declined up front - such an encoder runs the launch chain instead of tripping an assertion of
+    `build_program` inside forward - and the verdict is cached on the encoder."""
+    from ivln_ce_amd import depth_net as D
+    from ivln_ce_amd.encoders import ResNetEncoder
+
+    assert D.supported(_encoder())
+    wide = ResNetEncoder((256, 256, 1), baseplanes=64, ngroups=32)
+    assert not D.supported(wide) and not D.supported(wide)
+    assert D.plan_for(wide, torch.device("cpu")) is None
+    assert not D.supported(torch.nn.Linear(2, 2))
+    prog = D.build_program(_encoder())
+    assert len(prog.ops) == 55 and prog.arena * 4 < 16 << 20

@@ -96,7 +96,8 @@ def test_persistent_depth_encoder_writes_into_a_strided_output_and_replays_in_a_
         torch.cuda.synchronize()
         assert torch.equal(out, want)
     depth_net.plan_for(enc, DEV).check_status()
-    assert int(depth_net.plan_for(enc, DEV).sync.abs().sum()) == 0
+    states = list(depth_net.plan_for(enc, DEV)._per_stream.values())
+    assert len(states) >= 1 and all(int(sync.abs().sum()) == 0 for _, sync in states)  # (arena + sync words per stream)
 
 
 def test_persistent_depth_encoder_follows_weight_changes_in_place():
@@ -145,7 +146,7 @@ def test_persistent_depth_encoder_per_layer_error_budget():
         ops.DEPTH_NET = old
     plan = depth_net.plan_for(enc, DEV)
     plan.check_status()
-    arena = plan.arena.cpu()
+    arena = plan.stream_state()[0].cpu()
     space = types.SimpleNamespace(spaces={"depth": types.SimpleNamespace(shape=(256, 256, 1))})
     ref = R.ResNetEncoder(space, baseplanes=32, ngroups=16, make_backbone=R.resnet50)
     ref.load_state_dict({k: v.cpu() for k, v in enc.state_dict().items()})
@@ -176,3 +177,70 @@ def test_persistent_depth_encoder_per_layer_error_budget():
     e = float((feats - want).abs().max())
     print(f"per-layer worst relative error {worst:.2e}; features {e:.2e}")
     assert e < 1e-4
+
+
+def test_unsupported_architectures_and_trainable_encoders_run_the_launch_chain():
+    """`VlnResnetDepthEncoder` accepts `resnet_baseplanes` - 64 base planes give 32 GroupNorm groups, which the
+    persistent kernel's tilings and statistics layout do not cover.  Such an encoder (and one whose parameters train: every
+    optimizer step would cost a host-side repack) has to run the launch chain as it did before the persistent kernel
+    existed, not die inside `build_program`."""
+    from ivln_ce_amd import depth_net, ops
+    from ivln_ce_amd.encoders import ResNetEncoder
+    from oracle import habitat_ext_ref as R
+
+    torch.manual_seed(3)
+    wide = ResNetEncoder((256, 256, 1), baseplanes=64, ngroups=32).eval().to(DEV)
+    assert not depth_net.supported(wide) and depth_net.plan_for(wide, DEV) is None
+    depth = torch.rand(2, 256, 256, 1, generator=torch.Generator().manual_seed(2))
+    old = ops.DEPTH_NET
+    try:
+        ops.DEPTH_NET = 2
+        with torch.no_grad():
+            got = wide({"depth": depth.to(DEV)}).cpu()
+    finally:
+        ops.DEPTH_NET = old
+    space = types.SimpleNamespace(spaces={"depth": types.SimpleNamespace(shape=(256, 256, 1))})
+    ref = R.ResNetEncoder(space, baseplanes=64, ngroups=32, make_backbone=R.resnet50)
+    ref.load_state_dict({k: v.cpu() for k, v in wide.state_dict().items()})
+    with torch.no_grad():
+        want = ref.double()({"depth": depth.double()}).float()
+    assert got.shape == want.shape and float((got - want).abs().max()) < 2e-4
+    # the default architecture is supported; with trainable parameters it stays on the chain
+    enc = _encoder(11)
+    assert depth_net.supported(enc) and depth_net.plan_for(enc, DEV) is not None
+    for p in enc.parameters():
+        p.requires_grad_(True)
+    assert depth_net.plan_for(enc, DEV) is None
+    for p in enc.parameters():
+        p.requires_grad_(False)
+    assert depth_net.plan_for(enc, DEV) is not None
+
+
+def test_overlapping_launches_on_two_streams_do_not_share_an_arena():
+    """a replay in flight on a side stream and an eager forward on the main stream used to share ONE arena and
+    ONE set of cluster counters.  State is per (encoder, stream) now: both launches, overlapped on purpose, give the
+    features each of them gives alone."""
+    from ivln_ce_amd import depth_net, ops
+
+    enc = _encoder(13)
+    g0, g1 = torch.Generator().manual_seed(31), torch.Generator().manual_seed(32)
+    da, db = torch.rand(4, 256, 256, 1, generator=g0).to(DEV), torch.rand(4, 256, 256, 1, generator=g1).to(DEV)
+    side = torch.cuda.Stream(DEV)
+    old = ops.DEPTH_NET
+    try:
+        ops.DEPTH_NET = 2
+        with torch.no_grad():
+            wa, wb = enc({"depth": da}).clone(), enc({"depth": db}).clone()
+            torch.cuda.synchronize()
+            for _ in range(10):
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    a = enc({"depth": da})
+                b = enc({"depth": db})  # (4 + 4 images: both grids fit the chip together)
+                torch.cuda.synchronize()
+                assert torch.equal(a, wa) and torch.equal(b, wb)
+        plan = depth_net.plan_for(enc, DEV)
+        plan.check_status()
+        assert len(plan._per_stream) == 2
+    finally:
+        ops.DEPTH_NET = old

@@ -917,102 +917,6 @@ def test_xcd_aware_workgroup_remap_is_a_pure_permutation(N, Cin, H, W, Cout, k, 
     _close(out[False], F.relu(F.conv2d(x.cpu(), w.cpu(), sh.cpu(), stride=s, padding=p)), 3e-5)
 
 
-# every conv + GroupNorm(16) pair of the DD-PPO depth ResNet at 256x256 depth (baseplanes 32), plus the shapes a
-# 64x64 test depth image produces (tiny tiles: several K slices inside one wave) and non-power-of-two pixel counts
-_CONV_GN_SHAPES = [
-    # N, Cin, H, W, Cout, k, s, p
-    (2, 1, 128, 128, 32, 7, 2, 3),      # stem: 4096 px, 2 channels per group, 8 pixels per thread
-    (3, 32, 32, 32, 32, 1, 1, 0),       # layer1 conv1 (block 0)
-    (2, 128, 32, 32, 32, 1, 1, 0),      # layer1 conv1: 1024 px
-    (2, 32, 32, 32, 32, 3, 1, 1),       # layer1 conv2
-    (2, 32, 32, 32, 128, 1, 1, 0),      # layer1 conv3: cpg 8 x 1024 px
-    (2, 128, 32, 32, 64, 1, 1, 0),      # layer2 block 0 conv1
-    (2, 64, 32, 32, 64, 3, 2, 1),       # layer2 stride-2 3x3
-    (4, 256, 16, 16, 64, 1, 1, 0),
-    (2, 64, 16, 16, 256, 1, 1, 0),
-    (2, 128, 16, 16, 128, 3, 2, 1),     # layer3
-    (4, 512, 8, 8, 128, 1, 1, 0),
-    (2, 128, 8, 8, 512, 1, 1, 0),       # cpg 32
-    (2, 256, 8, 8, 256, 3, 2, 1),       # layer4: 16 px, 32 K slices
-    (4, 1024, 4, 4, 256, 1, 1, 0),
-    (2, 256, 4, 4, 1024, 1, 1, 0),      # cpg 64
-    (2, 256, 4, 4, 256, 3, 1, 1),
-    (2, 64, 7, 7, 64, 3, 1, 1),         # 49 px: not a power of two
-    (3, 256, 2, 2, 128, 1, 1, 0),       # 4 px
-    (2, 512, 1, 1, 256, 1, 1, 0),       # 1 px: every lane a K slice
-]
-
-
-@pytest.mark.parametrize("N,Cin,H,W,Cout,k,s,p", _CONV_GN_SHAPES)
-@pytest.mark.parametrize("tail", ["relu", "residual"])
-def test_conv_groupnorm_one_launch(N, Cin, H, W, Cout, k, s, p, tail):
-    """ivln_conv_gn_f32: workgroup per (image, group) with the whole K reduction inside the block, against
-    F.conv2d + F.group_norm (fp32, torch CPU)."""
-    from ivln_ce_amd import ops
-
-    g = torch.Generator().manual_seed(Cin * 7 + Cout + k + H)
-    x = torch.randn(N, Cin, H, W, generator=g)
-    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
-    gn = torch.nn.GroupNorm(16, Cout)
-    gn.weight.data, gn.bias.data = torch.randn(Cout, generator=g), torch.randn(Cout, generator=g)
-    y = F.conv2d(x, w, None, stride=s, padding=p)
-    ref = F.group_norm(y, 16, gn.weight, gn.bias, 1e-5)
-    res = None
-    if tail == "residual":
-        res = torch.randn(y.shape, generator=g)
-        ref = ref + res
-    ref = F.relu(ref).detach()
-    got = ops.conv_gn(x.to(DEV), w.to(DEV), gn.to(DEV), stride=s, pad=p, relu=True,
-                      residual=res.to(DEV) if res is not None else None, force=True)
-    assert got is not None, "shape must be inside the fused kernel's envelope"
-    _close(got, ref, 3e-5)
-
-
-@pytest.mark.parametrize("N,Cin,H,W,planes,stride", [(2, 32, 32, 32, 32, 1), (2, 128, 32, 32, 64, 2), (3, 256, 16, 16, 128, 2),
-                                                     (2, 64, 8, 8, 32, 2)])
-def test_conv_groupnorm_with_downsample_branch_in_the_same_launch(N, Cin, H, W, planes, stride):
-    """Bottleneck tail relu(GN(conv3(y)) + GN_ds(conv_ds(x))) (habitat-lab ddppo resnet) as one launch; also written
-    into a channel slice of a wider buffer."""
-    from ivln_ce_amd import ops
-
-    g = torch.Generator().manual_seed(Cin + planes)
-    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
-    x0 = torch.randn(N, Cin, H, W, generator=g)
-    y2 = torch.randn(N, planes, Ho, Wo, generator=g)
-    w3 = torch.randn(planes * 4, planes, 1, 1, generator=g) / planes ** 0.5
-    wd = torch.randn(planes * 4, Cin, 1, 1, generator=g) / Cin ** 0.5
-    gn3, gnd = torch.nn.GroupNorm(16, planes * 4), torch.nn.GroupNorm(16, planes * 4)
-    for m in (gn3, gnd):
-        m.weight.data, m.bias.data = torch.randn(planes * 4, generator=g), torch.randn(planes * 4, generator=g)
-    ref = F.relu(F.group_norm(F.conv2d(y2, w3), 16, gn3.weight, gn3.bias, 1e-5)
-                 + F.group_norm(F.conv2d(x0, wd, stride=stride), 16, gnd.weight, gnd.bias, 1e-5)).detach()
-    got = ops.conv_gn(y2.to(DEV), w3.to(DEV), gn3.to(DEV), relu=True, ds=(x0.to(DEV), wd.to(DEV), gnd.to(DEV), stride),
-                      force=True)
-    assert got is not None
-    _close(got, ref, 3e-5)
-    wide = torch.full((N, planes * 4 + 5, Ho, Wo), 7.0, device=DEV)
-    ops.conv_gn(y2.to(DEV), w3.to(DEV), gn3.to(DEV), relu=True, ds=(x0.to(DEV), wd.to(DEV), gnd.to(DEV), stride),
-                out=wide[:, :planes * 4], y_img_stride=(planes * 4 + 5) * Ho * Wo, force=True)
-    _close(wide[:, :planes * 4], ref, 3e-5)
-    assert float((wide[:, planes * 4:] - 7.0).abs().max()) == 0.0
-
-
-def test_conv_groupnorm_refuses_shapes_outside_its_envelope():
-    from ivln_ce_amd import ops
-
-    gn = torch.nn.GroupNorm(1, 128).to(DEV)  # the compression conv: one group of 128 channels
-    x, w = torch.randn(2, 1024, 4, 4, device=DEV), torch.randn(128, 1024, 3, 3, device=DEV)
-    assert ops.conv_gn(x, w, gn, pad=1, relu=True, force=True) is None
-    gn = torch.nn.GroupNorm(16, 48).to(DEV)  # 3 channels per group
-    assert ops.conv_gn(torch.randn(1, 8, 8, 8, device=DEV), torch.randn(48, 8, 1, 1, device=DEV), gn, force=True) is None
-    # layer4's first bottleneck tail: 64 channels per group x K = 512 of the downsample conv = 128 KB of staged
-    # weights + the partial tiles do not fit the 160 KB of LDS -> the caller runs the unfused pair
-    gn3, gnd = torch.nn.GroupNorm(16, 1024).to(DEV), torch.nn.GroupNorm(16, 1024).to(DEV)
-    assert ops.conv_gn(torch.randn(2, 256, 4, 4, device=DEV), torch.randn(1024, 256, 1, 1, device=DEV), gn3, relu=True,
-                       ds=(torch.randn(2, 512, 8, 8, device=DEV), torch.randn(1024, 512, 1, 1, device=DEV), gnd, 2),
-                       force=True) is None
-
-
 @pytest.mark.parametrize("B,Cin,H,W,Cout,k,s,p", [(4, 64, 16, 16, 64, 3, 1, 1), (2, 256, 8, 8, 64, 1, 1, 0), (3, 64, 8, 8, 256, 1, 1, 0),
                                                    (2, 128, 16, 16, 128, 3, 2, 1), (2, 256, 16, 16, 512, 1, 2, 0),
                                                    (8, 128, 32, 32, 128, 3, 2, 1),
