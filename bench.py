@@ -113,6 +113,12 @@ class GemmTimer:
 
         def timed(desc):
             self.orig(desc)
+            flags = getattr(desc, "_run_flags", None)
+            if flags is not None:
+                # per-image run flags (the folded attention operands of the cached instruction encoding): only the rows
+                # whose tokens changed are computed - count what ran (a read-back: this pass is outside the timed region)
+                self.flops += 2 * desc.M * desc.N * desc.K * float(flags.float().mean().item())
+                return
             self.flops += 2 * desc.M * desc.N * desc.K
 
         self.orig_gn_conv = ops.gn_conv

@@ -200,6 +200,13 @@ typedef struct ivln_gemm_desc {
      * arithmetic (k_wgrad_bf3: both operands are activations, split while they are staged - nothing to pre-arrange);
      * tile_override 9 insists on it. */
     int split_ok;
+    /* optional (D_NCHW destinations, splits forced to 1): one int32 per image of the destination (N / HoWo of them); an
+     * output tile ALL of whose images carry 0 is skipped - neither computed nor stored, the destination keeps what it
+     * held.  Device memory, read by the kernel: the decision replays in a hipGraph.  User: the folded attention operands of
+     * the instruction (map_cma_policy.py:293, 320-325), recomputed only for rows whose tokens changed
+     * (ivln_embed_gates_cached_f32).  Only the float4-staged GEMM and the scalar-gather implicit GEMM honour it: the
+     * dispatcher sends such a call to one of them. */
+    const int32_t* img_run_flags;
 } ivln_gemm_desc;
 
 int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream);
@@ -422,6 +429,14 @@ int ivln_embed_lengths(const int64_t* tokens, const float* table, int B, int L, 
  * tokens i64 (B,L) -> gx_f, gx_r (B*L, G) = the two halves of the token's table row, lengths i32 (B). */
 int ivln_embed_gates_f32(const int64_t* tokens, const float* table, const uint8_t* row_nonzero, int B, int L, int G, int V,
                          float* gx_f, float* gx_r, int* lengths, void* stream);
+/* The same with a per-row cache: the reference re-encodes an episode's instruction at every step (map_cma_policy.py:293,
+ * instruction_encoder.py:72-94); the encoding is a pure function of the tokens.  cache_tokens i64 (B,L) = the tokens each
+ * row encoded last (caller-owned, persistent across steps; fill with -1 to invalidate, e.g. when the weights change), dirty
+ * i32 (B) = output: 1 where the row's tokens differ from the cache (the row is then encoded and the cache updated), 0 where
+ * they are equal (NOTHING of the row is written: gx_f / gx_r / lengths keep their values, which therefore have to be
+ * persistent buffers too).  Both NULL = ivln_embed_gates_f32. */
+int ivln_embed_gates_cached_f32(const int64_t* tokens, const float* table, const uint8_t* row_nonzero, int B, int L, int G, int V,
+                                float* gx_f, float* gx_r, int* lengths, int64_t* cache_tokens, int* dirty, void* stream);
 /* nn.LSTM(bidirectional) over packed sequences (instruction_encoder.py:84-94): gx_* = W_ih x + b_ih
  * for all (b,t) as (B*L, 4H); out (B, 2H, L), zero for t >= lengths[b].  H must be 128. */
 int ivln_lstm_bidir_fwd_f32(const float* gx_f, const float* gx_r, const float* whh_f, const float* whh_r,
@@ -435,6 +450,12 @@ int ivln_lstm_bidir_fwd_f32(const float* gx_f, const float* gx_r, const float* w
 int ivln_lstm_bidir_fwd_spread_f32(const float* gx_f, const float* gx_r, const float* whh_f, const float* whh_r,
                                    const float* bhh_f, const float* bhh_r, const int* lengths, int B, int L, int H,
                                    float* out, float* save_gates, float* save_c, unsigned* ticket, int spare, void* stream);
+/* ... and with the per-row cache of ivln_embed_gates_cached_f32: `dirty` i32 (B) or NULL; the (sequence, direction) items
+ * of a row with dirty == 0 are not run and `out` keeps that row's values of the last step it was run. */
+int ivln_lstm_bidir_fwd_cached_f32(const float* gx_f, const float* gx_r, const float* whh_f, const float* whh_r,
+                                   const float* bhh_f, const float* bhh_r, const int* lengths, int B, int L, int H,
+                                   float* out, float* save_gates, float* save_c, unsigned* ticket, int spare, const int* dirty,
+                                   void* stream);
 /* The two consumers of an encoder's feature map in the MapCMA head in ONE launch (models/map_cma_policy.py:156-171,
  * 180-185, 276-296): feat (rows, C, P) contiguous ->  kv (rows, Ckv, P) = nn.Conv1d(C, Ckv, 1)  and
  * lin[r*ld_lin + o] = act(nn.Linear(C*P, O) of the flattened row).  rows <= 8 and rows*C*P*4 B <= 150 KB of LDS,

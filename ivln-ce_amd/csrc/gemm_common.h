@@ -20,6 +20,17 @@ __host__ __device__ constexpr int conv_ks(int bmode) {
 __host__ __device__ constexpr int conv_direct_ci(int KS) { return KS == 7 ? 2 : (KS == 2 ? 16 : 8); }
 enum { DMODE_NCHW = 0, DMODE_DENSE = 1, DMODE_NCHW_UP2 = 2, DMODE_NCHW_UP2X4 = 3 };
 
+// ivln_gemm_desc.img_run_flags: true when every image the tile's columns [n0, n0 + BN) belong to carries 0 (uniform over the
+// workgroup; called before the first barrier)
+__device__ __forceinline__ bool ivln_tile_skipped(const ivln_gemm_desc& p, int n0, int BN) {
+    if (!p.img_run_flags) return false;
+    const int last = min(p.N, n0 + BN) - 1;
+    if (last < n0) return true;
+    for (int i = n0 / p.HoWo; i <= last / p.HoWo; ++i)
+        if (p.img_run_flags[i]) return false;
+    return true;
+}
+
 constexpr int BK = 16;
 
 // XCD-aware workgroup id (guide technique T1).  The dispatcher places workgroup b on XCD b % 8 and every XCD has

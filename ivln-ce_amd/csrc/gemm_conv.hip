@@ -40,6 +40,7 @@ __global__ __launch_bounds__(256) void k_gemm(const ivln_gemm_desc p) {
     const int wm = wave / WN, wn = wave % WN;
     const BlockId bid = xcd_block_id(p.no_xcd_remap);
     const int m0 = bid.y * BM, n0 = bid.x * BN;
+    if (ivln_tile_skipped(p, n0, BN)) return;  // (optional per-image run flags: nothing to do for this tile)
 
     // K range of this split
     const int nk = (p.K + BK - 1) / BK;
@@ -494,6 +495,14 @@ extern "C" int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream) {
     if (d.grp_imgs > 0) {  // image-grouped weights: forward convs into an NCHW destination only
         if (d.amode != AMODE_MK || d.dmode != DMODE_NCHW || d.N % ((int64_t)d.grp_imgs * d.HoWo) != 0) return IVLN_E_INVALID;
         if (d.a_grp_stride <= 0) d.a_grp_stride = (int64_t)d.M * d.lda;
+    }
+    if (d.img_run_flags) {  // per-image run flags: the two GEMM kernels below honour them, one slab, no deferred epilogue
+        if (d.dmode != DMODE_NCHW || d.defer_epilogue || d.N % d.HoWo != 0 || d.tile_override == 6 || d.tile_override == 8 ||
+            d.tile_override == 9)
+            return IVLN_E_INVALID;
+        d.splits = 1;
+        d.A_split = nullptr;
+        if (d.tile_override == 0) d.tile_override = ivln_gemm_vec_eligible(d) ? 7 : 1;
     }
     // stride-1 3x3 / 7x7 with split-bf16 weights on hand: the bf16-MFMA direct conv (conv_bf3.hip); 9 insists on it
     if ((d.tile_override == 0 || d.tile_override == 9) && d.A_split) {

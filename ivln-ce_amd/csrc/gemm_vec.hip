@@ -45,6 +45,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_vec(const ivln_gemm_desc p) {
     const int wm = wave / WN, wn = wave % WN;
     const BlockId bid = xcd_block_id(p.no_xcd_remap);
     const int m0 = bid.y * BM, n0 = bid.x * BN;
+    if (ivln_tile_skipped(p, n0, BN)) return;  // (optional per-image run flags: nothing to do for this tile)
     const int nk = (p.K + BKV - 1) / BKV;
     const int tps = (nk + p.splits - 1) / p.splits;
     const int kbeg = bid.z * tps * BKV;

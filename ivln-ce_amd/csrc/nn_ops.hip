@@ -566,13 +566,29 @@ __global__ __launch_bounds__(1024) void k_embed_lengths(const int64_t* __restric
 // once per weight version by the MFMA GEMM).  One block per sequence, a wave per token: the first G floats of the
 // token's row go to gx_f, the next G to gx_r; lengths counts the tokens whose EMBEDDING row has a non-zero element
 // (row_nonzero[v], the reference's `(instruction != 0).sum(2) != 0` quirk, instruction_encoder.py:70-78).
+//
+// Per-episode cache (`cache_tokens` + `dirty`, both or neither): the reference re-encodes the same instruction at every step
+// of an episode (map_cma_policy.py:293).  The encoding is a pure function of the tokens, so the block first compares its
+// row with the tokens it encoded last time: equal -> dirty[b] = 0 and NOTHING is written (gx, lengths and - in the
+// launches that follow and read dirty[b] - the bi-LSTM's output and the folded attention operands keep last step's
+// values); different (a new episode, a changed instruction, a compacted batch row, an invalidated cache: tokens < 0) ->
+// the row is copied into the cache, dirty[b] = 1 and the row is encoded.  Decided on the device, so it replays in hipGraphs.
 __global__ __launch_bounds__(1024) void k_embed_gates(const int64_t* __restrict__ tokens, const float* __restrict__ table,
                                                       const uint8_t* __restrict__ row_nonzero, int L, int G, int V,
                                                       float* __restrict__ gx_f, float* __restrict__ gx_r,
-                                                      int* __restrict__ lengths) {
+                                                      int* __restrict__ lengths, int64_t* __restrict__ cache_tokens,
+                                                      int* __restrict__ dirty) {
     __shared__ int cnt;
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (cache_tokens) {
+        int diff = 0;
+        for (int t = threadIdx.x; t < L; t += blockDim.x) diff |= tokens[(int64_t)b * L + t] != cache_tokens[(int64_t)b * L + t];
+        diff = __syncthreads_or(diff);
+        if (threadIdx.x == 0) dirty[b] = diff ? 1 : 0;
+        if (!diff) return;
+        for (int t = threadIdx.x; t < L; t += blockDim.x) cache_tokens[(int64_t)b * L + t] = tokens[(int64_t)b * L + t];
+    }
     if (threadIdx.x == 0) cnt = 0;
     __syncthreads();
     int local = 0;
@@ -628,7 +644,8 @@ __global__ __launch_bounds__(4 * H) void k_lstm_bidir(const float* __restrict__ 
                                                       const float* __restrict__ bhh_r,
                                                       const int* __restrict__ lengths, int L,
                                                       float* __restrict__ out, float* __restrict__ save_gates,
-                                                      float* __restrict__ save_c, int B, unsigned* __restrict__ ticket) {
+                                                      float* __restrict__ save_c, int B, unsigned* __restrict__ ticket,
+                                                      const int* __restrict__ dirty) {
     constexpr int G = 4 * H;
     // Which (sequence, direction) this block runs: its index, or - with `ticket` - the order in which the blocks START.
     // The launcher then over-subscribes the grid (2B * spare blocks for 2B items): beside a kernel that fills some XCDs
@@ -647,6 +664,7 @@ __global__ __launch_bounds__(4 * H) void k_lstm_bidir(const float* __restrict__ 
         item = s_item;
         if (item >= 2 * B) return;
     }
+    if (dirty && !dirty[item % B]) return;  // (per-episode cache, k_embed_gates: this row's output of last step stands)
     // Quad j (threads 4j..4j+3) owns hidden unit j: lane q multiplies the 4 gate rows {i,f,g,o} of unit j
     // with ITS quarter of h (a 4 x H/4 block of W_hh = H weights in registers), the quad adds the partial
     // sums by DPP, lane q activates gate q, the quad exchanges the four activations by DPP and every lane
@@ -1532,27 +1550,41 @@ int ivln_embed_lengths(const int64_t* tokens, const float* table, int B, int L, 
 
 int ivln_embed_gates_f32(const int64_t* tokens, const float* table, const uint8_t* row_nonzero, int B, int L, int G, int V,
                          float* gx_f, float* gx_r, int* lengths, void* stream) {
+    return ivln_embed_gates_cached_f32(tokens, table, row_nonzero, B, L, G, V, gx_f, gx_r, lengths, nullptr, nullptr, stream);
+}
+
+int ivln_embed_gates_cached_f32(const int64_t* tokens, const float* table, const uint8_t* row_nonzero, int B, int L, int G, int V,
+                                float* gx_f, float* gx_r, int* lengths, int64_t* cache_tokens, int* dirty, void* stream) {
     if (!tokens || !table || !row_nonzero || !gx_f || !gx_r || !lengths || B <= 0 || L <= 0 || G <= 0 || (G & 3) || V <= 0)
         return IVLN_E_INVALID;
+    if ((cache_tokens == nullptr) != (dirty == nullptr)) return IVLN_E_INVALID;
     hipLaunchKernelGGL(k_embed_gates, dim3(B), dim3(1024), 0, (hipStream_t)stream, tokens, table, row_nonzero, L, G, V, gx_f,
-                       gx_r, lengths);
+                       gx_r, lengths, cache_tokens, dirty);
     return LAUNCH_OK();
 }
 
 int ivln_lstm_bidir_fwd_f32(const float* gx_f, const float* gx_r, const float* whh_f, const float* whh_r,
                             const float* bhh_f, const float* bhh_r, const int* lengths, int B, int L, int H,
                             float* out, float* save_gates, float* save_c, void* stream) {
-    return ivln_lstm_bidir_fwd_spread_f32(gx_f, gx_r, whh_f, whh_r, bhh_f, bhh_r, lengths, B, L, H, out, save_gates, save_c,
-                                          nullptr, 1, stream);
+    return ivln_lstm_bidir_fwd_cached_f32(gx_f, gx_r, whh_f, whh_r, bhh_f, bhh_r, lengths, B, L, H, out, save_gates, save_c,
+                                          nullptr, 1, nullptr, stream);
 }
 
 int ivln_lstm_bidir_fwd_spread_f32(const float* gx_f, const float* gx_r, const float* whh_f, const float* whh_r,
                                    const float* bhh_f, const float* bhh_r, const int* lengths, int B, int L, int H,
                                    float* out, float* save_gates, float* save_c, unsigned* ticket, int spare, void* stream) {
+    return ivln_lstm_bidir_fwd_cached_f32(gx_f, gx_r, whh_f, whh_r, bhh_f, bhh_r, lengths, B, L, H, out, save_gates, save_c,
+                                          ticket, spare, nullptr, stream);
+}
+
+int ivln_lstm_bidir_fwd_cached_f32(const float* gx_f, const float* gx_r, const float* whh_f, const float* whh_r,
+                                   const float* bhh_f, const float* bhh_r, const int* lengths, int B, int L, int H,
+                                   float* out, float* save_gates, float* save_c, unsigned* ticket, int spare, const int* dirty,
+                                   void* stream) {
     if (H != 128) return IVLN_E_UNSUPPORTED;
     if (B <= 0 || spare < 1 || spare > 8 || (spare > 1 && !ticket)) return IVLN_E_INVALID;
     hipLaunchKernelGGL((k_lstm_bidir<128>), dim3(2 * B * (ticket ? spare : 1)), dim3(512), 0, (hipStream_t)stream, gx_f, gx_r,
-                       whh_f, whh_r, bhh_f, bhh_r, lengths, L, out, save_gates, save_c, B, ticket);
+                       whh_f, whh_r, bhh_f, bhh_r, lengths, L, out, save_gates, save_c, B, ticket, dirty);
     return LAUNCH_OK();
 }
 

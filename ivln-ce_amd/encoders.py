@@ -170,15 +170,55 @@ class InstructionEncoder(nn.Module):
             c = self.__dict__["_gate_cache"] = (key, (table, nz))
         return c[1]
 
+    def step_cache(self, rows, L, device):
+        """The per-episode cache of a rollout batch shape (ops.InstructionStepCache), or None: switched off, a capture in
+        progress that would have to create or invalidate it (the warm-up steps before a capture do that), no folded table.
+        A cache made for other weights (LSTM / embedding versions, ops.WEIGHT_EPOCH) is invalidated, not rebuilt: captured
+        graphs hold its buffers."""
+        if not ops.CACHE_INSTRUCTION:
+            return None
+        gate_key = (self.__dict__.get("_gate_cache") or (None,))[0]
+        rnn = self.encoder_rnn
+        ps = (rnn.weight_hh_l0, rnn.weight_hh_l0_reverse, rnn.bias_hh_l0, rnn.bias_hh_l0_reverse)
+        key = (gate_key,) + tuple(p._version for p in ps) + tuple(p.data_ptr() for p in ps)
+        caches = self.__dict__.setdefault("_step_caches", {})
+        c = caches.get((rows, L, str(device)))
+        capturing = torch.cuda.is_current_stream_capturing()
+        if c is None:
+            if capturing:
+                return None
+            if len(caches) >= 4:  # (batch shapes come and go as envs pause: keep the table small)
+                caches.pop(next(iter(caches)))
+            c = caches[(rows, L, str(device))] = ops.InstructionStepCache(rows, L, 4 * rnn.hidden_size, rnn.hidden_size, device, key)
+        elif c.key != key:
+            if capturing:
+                return None
+            c.invalidate()
+            c.key = key
+        return c
+
     def forward(self, observations, save=None):
         """(B, L) tokens -> (B, 2H, L) channel-major outputs, zero for t >= length; also returns
         lengths (device int32).  The reference returns (B, 2H, Lmax); the extra columns here are
-        exactly the masked (zero-weight) attention positions."""
+        exactly the masked (zero-weight) attention positions.
+        Rollout steps (no `save`, no autograd): the encoding is cached per row and recomputed only where the tokens
+        changed (`step_cache`; the decision is taken on the device, ops.embed_gates) - `self.last_cache` then names the
+        cache whose `dirty` flags belong to this call, else it is None."""
         tokens = observations["instruction"].long().contiguous()
         B, L = tokens.shape
         rnn = self.encoder_rnn
         H = rnn.hidden_size
         fold = self._gate_table() if (save is None and ops.FOLD_INSTRUCTION_GATES) else None
+        self.last_cache = None
+        if fold is not None and tokens.is_cuda and not torch.is_grad_enabled():
+            cache = self.step_cache(B, L, tokens.device)
+            if cache is not None:
+                gx_f, gx_r, lengths = ops.embed_gates(tokens, *fold, cache=cache)
+                out, _, _ = ops.lstm_bidir(gx_f, gx_r, rnn.weight_hh_l0, rnn.weight_hh_l0_reverse, rnn.bias_hh_l0,
+                                           rnn.bias_hh_l0_reverse, lengths, B, L, H, spare=getattr(self, "lstm_spare", 1),
+                                           ticket=getattr(self, "lstm_ticket", None), cache=cache)
+                self.last_cache = cache
+                return out, lengths
         if fold is not None:  # inference: embedding lookup + both W_ih projections = one lookup in a folded table
             emb = None
             gx_f, gx_r, lengths = ops.embed_gates(tokens, *fold)

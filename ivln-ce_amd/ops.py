@@ -42,6 +42,7 @@ class GemmDesc(C.Structure):
         ("stat_partials", vp), ("stat_tiles", C.POINTER(i32)),
         ("A_split", vp), ("a_split_grp_stride", i64),
         ("split_ok", i32),
+        ("img_run_flags", vp),
     ]
 
 
@@ -360,9 +361,11 @@ def conv_stat_ws(device, floats):
 
 
 def conv2d(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, relu=False, out=None, out_ctot=0,
-           in_img_stride=0, splitk=True, defer=False, ws_slot=0, weight_is_temp=False, stats=None):
+           in_img_stride=0, splitk=True, defer=False, ws_slot=0, weight_is_temp=False, stats=None, run_flags=None):
     """NCHW conv: x (N,Cin,H,W) [contiguous per image, image stride `in_img_stride`], w OIHW.
-    out: optional destination (a channel slice of an (N,out_ctot,Ho,Wo) buffer)."""
+    out: optional destination (a channel slice of an (N,out_ctot,Ho,Wo) buffer).
+    run_flags: optional int32 (N) on the device - output tiles all of whose images carry 0 are skipped and `out` (then a
+    persistent buffer of the caller) keeps what it held (ivln_gemm_desc.img_run_flags)."""
     N, Cin, H, W = x.shape
     G = w.shape[0] if w.dim() == 5 else 0  # (G, Cout, Cin, k, k): weight set g for images [g*N/G, (g+1)*N/G)
     Cout, _, KH, KW = w.shape[-4:]
@@ -425,6 +428,11 @@ def conv2d(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, 
         koff, kpos = conv_tables(Cin, KH, KW, H, W, dil, x.device)
         d.koff, d.kpos = dptr(koff), dptr(kpos)
     _epilogue(d, scale, shift, residual, relu)
+    if run_flags is not None:
+        if defer or run_flags.dtype != torch.int32 or run_flags.numel() < N or not run_flags.is_cuda:
+            raise _lib.IvlnError("conv2d(run_flags): int32 flags per image on the device, not with defer")
+        d.img_run_flags, splitk = dptr(run_flags), False
+        d._run_flags = run_flags  # (python-side handle: bench.py's instrumented pass reads it back to count executed FLOPs)
     if defer:
         ws = splitk_ws(x.device, slot=ws_slot)
         used = i32(0)
@@ -1020,24 +1028,82 @@ def embed_lengths(tokens_i64, table):
     return emb, lengths
 
 
-def embed_gates(tokens_i64, table, row_nonzero):
-    """tokens (B, L) -> gx_f, gx_r (B*L, G) looked up in the folded (V, 2G) table, lengths i32 (B) (k_embed_gates)."""
+def embed_gates(tokens_i64, table, row_nonzero, cache=None):
+    """tokens (B, L) -> gx_f, gx_r (B*L, G) looked up in the folded (V, 2G) table, lengths i32 (B) (k_embed_gates).
+    cache: an `InstructionStepCache` - its persistent gx / lengths buffers are the outputs and only the rows whose tokens
+    differ from the cached ones are written (ivln_embed_gates_cached_f32; cache.dirty says which)."""
     B, L = tokens_i64.shape
     V, G2 = table.shape
     G = G2 // 2
+    Lb = _L()
+    Lb.ivln_embed_gates_cached_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]
+    if cache is not None:
+        gx_f, gx_r, lengths = cache.gx_f, cache.gx_r, cache.lengths
+        check(Lb.ivln_embed_gates_cached_f32(dptr(tokens_i64), dptr(table), dptr(row_nonzero), B, L, G, V, dptr(gx_f), dptr(gx_r),
+                                             dptr(lengths), dptr(cache.tokens), dptr(cache.dirty), stream_ptr()),
+              "ivln_embed_gates_cached_f32")
+        return gx_f, gx_r, lengths
     gx_f = torch.empty((B * L, G), dtype=torch.float32, device=table.device)
     gx_r = torch.empty((B * L, G), dtype=torch.float32, device=table.device)
     lengths = torch.empty((B,), dtype=torch.int32, device=table.device)
-    Lb = _L()
-    Lb.ivln_embed_gates_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
-    check(Lb.ivln_embed_gates_f32(dptr(tokens_i64), dptr(table), dptr(row_nonzero), B, L, G, V, dptr(gx_f), dptr(gx_r),
-                                  dptr(lengths), stream_ptr()), "ivln_embed_gates_f32")
+    check(Lb.ivln_embed_gates_cached_f32(dptr(tokens_i64), dptr(table), dptr(row_nonzero), B, L, G, V, dptr(gx_f), dptr(gx_r),
+                                         dptr(lengths), None, None, stream_ptr()), "ivln_embed_gates_f32")
     return gx_f, gx_r, lengths
 
 
-def lstm_bidir(gx_f, gx_r, whh_f, whh_r, bhh_f, bhh_r, lengths, B, L, H, save=False, spare=1, ticket=None):
+class InstructionStepCache:
+    """Persistent device buffers of the per-episode instruction cache for one (rows, L) batch shape (rollout steps only:
+    map_cma_policy.py:293 re-encodes an episode's instruction at every step): the tokens every row encoded last, the per-row
+    dirty flags of the current step, and everything the instruction branch produces - gate inputs, lengths, the bi-LSTM's
+    output, the folded attention operands (`fold`, allocated by the policy on first use).  Allocated OUTSIDE any stream
+    capture and shared by every graph of the policy, so that what one replayed step leaves is what the next one finds."""
+
+    def __init__(self, rows, L, G, H, device, key):
+        self.rows, self.L, self.key = rows, L, key
+        self.tokens = torch.full((rows, L), -1, dtype=torch.int64, device=device)  # (-1: no row matches - everything dirty)
+        self.dirty = torch.ones((rows,), dtype=torch.int32, device=device)
+        self.gx_f = torch.zeros((rows * L, G), dtype=torch.float32, device=device)
+        self.gx_r = torch.zeros((rows * L, G), dtype=torch.float32, device=device)
+        self.lengths = torch.zeros((rows,), dtype=torch.int32, device=device)
+        self.out = torch.zeros((rows, 2 * H, L), dtype=torch.float32, device=device)
+        self.fold = None
+        self.fold_key = None
+        _STEP_CACHES.add(self)
+
+    def invalidate(self):
+        """Every row re-encodes at the next step (weights changed).  An eager fill on the current stream."""
+        self.tokens.fill_(-1)
+
+
+import weakref as _weakref  # noqa: E402
+
+_STEP_CACHES = _weakref.WeakSet()
+CACHE_INSTRUCTION = os.environ.get("IVLN_CACHE_INSTRUCTION", "1") != "0"  # A/B switch: 0 = re-encode at every step
+
+
+def invalidate_step_caches():
+    """Called when parameters changed behind torch's back (FlatAdam.step writes through raw pointers): a replayed graph
+    would otherwise keep serving instruction encodings of the old weights."""
+    for c in list(_STEP_CACHES):
+        c.invalidate()
+
+
+def lstm_bidir(gx_f, gx_r, whh_f, whh_r, bhh_f, bhh_r, lengths, B, L, H, save=False, spare=1, ticket=None, cache=None):
     """spare > 1: ivln_lstm_bidir_fwd_spread_f32 - 2B * spare blocks draw the 2B items in the order they start (for a
-    replay beside a launch that fills some XCDs).  ticket: the caller's zeroed int32 word (one launch in flight per word)."""
+    replay beside a launch that fills some XCDs).  ticket: the caller's zeroed int32 word (one launch in flight per word).
+    cache: the step cache whose `dirty` flags `embed_gates` just wrote - rows with dirty == 0 are not run and cache.out
+    (the returned tensor) keeps their values."""
+    if cache is not None and not save:
+        tk = ticket if spare > 1 else None
+        if spare > 1 and (tk is None or tk.dtype != torch.int32 or tk.device != gx_f.device):
+            raise ValueError("lstm_bidir(spare>1) needs the caller's int32 ticket word on the same device")
+        Lb = _L()
+        Lb.ivln_lstm_bidir_fwd_cached_f32.argtypes = [vp] * 7 + [i32, i32, i32, vp, vp, vp, vp, i32, vp, vp]
+        check(Lb.ivln_lstm_bidir_fwd_cached_f32(dptr(gx_f), dptr(gx_r), dptr(whh_f), dptr(whh_r), dptr(bhh_f), dptr(bhh_r),
+                                                dptr(lengths), B, L, H, dptr(cache.out), None, None, _p(tk),
+                                                int(spare) if tk is not None else 1, dptr(cache.dirty), stream_ptr()),
+              "ivln_lstm_bidir_fwd_cached_f32")
+        return cache.out, None, None
     out = torch.empty((B, 2 * H, L), dtype=torch.float32, device=gx_f.device)
     if spare > 1 and not save:
         tk = ticket

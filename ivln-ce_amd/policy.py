@@ -258,6 +258,23 @@ class MapCMANet(Net):
                 # rollout: text_k, state_q and text_q folded over the instruction (csrc/cma_step.hip): ONE 1x1 conv
                 # yields Mq (H+1 channels) and TQb (h2 channels) for the fused head, no text_k tensor is made
                 wf, bf = self._cma_fold_weights()
+                cache = self.instruction_encoder.last_cache if sv is None else None
+                if cache is not None:
+                    # per-episode cache (encoders.InstructionEncoder.step_cache): the folded operands live in the cache's
+                    # persistent buffer and only the rows the encoder just re-encoded (cache.dirty) are recomputed
+                    fkey = getattr(self, "_cma_fold_key", None)
+                    if cache.fold is None or cache.fold_key != fkey:
+                        if torch.cuda.is_current_stream_capturing():
+                            cache = None  # (cannot be created / invalidated inside a capture: plain conv below)
+                        else:
+                            if cache.fold is None:
+                                cache.fold = torch.zeros((r_, wf.shape[0], 1, L_), dtype=torch.float32, device=t.device)
+                            cache.fold_key = fkey
+                            cache.dirty.fill_(1)  # (folded for other weights, or never: every row's operands are made now)
+                if cache is not None:
+                    ops.conv2d(t.view(r_, -1, 1, L_), wf.view(wf.shape[0], -1, 1, 1), shift=bf, splitk=False, out=cache.fold,
+                               run_flags=cache.dirty)
+                    return t, ln, cache.fold.view(r_, -1, L_)
                 fold = ops.conv2d(t.view(r_, -1, 1, L_), wf.view(wf.shape[0], -1, 1, 1), shift=bf, splitk=False)
                 return t, ln, fold.view(r_, -1, L_)
             tk_ = ops.conv2d(t.view(r_, -1, 1, L_), self.text_k.weight.view(h2, -1, 1, 1), shift=self.text_k.bias,

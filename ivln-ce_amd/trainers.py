@@ -84,6 +84,7 @@ class FlatAdam:
             D.allreduce_sum_(self.grad)
         self.step_count += 1
         ops.WEIGHT_EPOCH += 1  # invalidates folded-BN caches (parameters change through raw pointers)
+        ops.invalidate_step_caches()  # ... and the per-episode instruction encodings a replayed graph would keep serving
         if self.flat.is_cuda:
             ops.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.lr, self.step_count,
                           self.betas[0], self.betas[1], self.eps, self.seg_of, self.seg_lr, 1.0 / world, True)

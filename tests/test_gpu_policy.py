@@ -276,6 +276,7 @@ def test_instruction_front_end_folded_into_a_table_lookup_is_the_same_encoder():
         ops.FOLD_INSTRUCTION_GATES = True
         with torch.no_grad():
             got, got_len = enc(obs)
+            got, got_len = got.clone(), got_len.clone()  # (no-grad outputs live in the per-episode cache's buffers: valid until the next call)
             assert enc.__dict__.get("_gate_cache") is not None
             assert torch.equal(got_len, ref_len) and ref_len.tolist()[:4] == [60, 10, 199, 0]
             assert float((got - ref).abs().max()) < 2e-6
@@ -286,3 +287,143 @@ def test_instruction_front_end_folded_into_a_table_lookup_is_the_same_encoder():
         assert float((got2 - ref2).abs().max()) < 2e-6 and float((got2 - got).abs().max()) > 1e-3
     finally:
         ops.FOLD_INSTRUCTION_GATES = old
+
+
+def _episode_script(B, steps, seed=5):
+    """Observations of a rollout in which the instruction behaves like an episode's: constant per env, except
+    step 10: env 1 starts a new episode (mask 0, NEW tokens); step 17: env 2's tokens change in mid-episode (no reset);
+    step 22: env 0 starts a new episode with the SAME tokens; step 25: env 3 gets a shorter instruction."""
+    from ivln_ce_amd.synthetic import SyntheticRollout
+
+    dev = torch.device("cuda:0")
+    roll = SyntheticRollout(B=B, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    obs, expect_dirty = [], []
+    for t in range(steps):
+        dirty = [t == 0] * B
+        if t == 10:
+            roll.instruction[1, :80] = torch.randint(2, 2504, (80,), generator=g)
+            dirty[1] = True
+        if t == 17:
+            roll.instruction[2, 5] = 1234 if int(roll.instruction[2, 5]) != 1234 else 1235
+            dirty[2] = True
+        if t == 25:
+            roll.instruction[3, 40:] = 0
+            dirty[3] = True
+        o = roll.step()
+        if t == 10:
+            o["not_done_masks"][1] = 0
+        if t == 22:
+            o["not_done_masks"][0] = 0
+        obs.append({k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in o.items()})
+        expect_dirty.append([int(d) for d in dirty])
+    return obs, expect_dirty
+
+
+def _eager_rollout(pol, obs, check_dirty=None):
+    from ivln_ce_amd.config import get_config
+    from ivln_ce_amd.obs_transforms import GTSemanticsIterativeMapper
+
+    dev = torch.device("cuda:0")
+    B = obs[0]["depth"].shape[0]
+    tr = GTSemanticsIterativeMapper.from_config(get_config())
+    rnn = torch.zeros(B, 2, 512, device=dev)
+    prev = torch.zeros(B, 1, dtype=torch.long, device=dev)
+    out = []
+    for t, o in enumerate(obs):
+        b = tr(dict(o))
+        with torch.no_grad():
+            a, rnn = pol.act(b, rnn, prev, b["not_done_masks"], deterministic=True)
+        prev = a
+        out.append((a.clone(), rnn.clone()))
+        if check_dirty is not None:
+            cache = pol.net.instruction_encoder.last_cache
+            assert cache is not None and cache.dirty.tolist() == check_dirty[t], (t, cache.dirty.tolist(), check_dirty[t])
+    return out
+
+
+def test_instruction_encoding_cached_per_episode_is_bit_identical_to_always_recompute(same_depth_path):
+    """the reference re-runs the instruction bi-LSTM on the same tokens at every step
+    (map_cma_policy.py:293, instruction_encoder.py:72-94).  Here a row is re-encoded only when its tokens differ from the
+    ones it encoded last (decided on the device: k_embed_gates compares, k_lstm_bidir and the fold conv read the flags).
+    Over a 30-step rollout with an episode change, a mid-episode token change, a reset with unchanged tokens and a
+    shortened instruction: the same actions and recurrent states, bit for bit, as re-encoding at every step - eagerly
+    and as the replayed split graphs - and exactly the expected rows are re-encoded."""
+    same_depth_path(0)
+    from ivln_ce_amd import ops
+    from ivln_ce_amd.config import get_config
+    from ivln_ce_amd.graphed import GraphedRollout
+    from ivln_ce_amd.obs_transforms import GTSemanticsIterativeMapper
+
+    pol = make_policy()
+    B, steps = 4, 30
+    obs, expect_dirty = _episode_script(B, steps)
+    old = ops.CACHE_INSTRUCTION
+    try:
+        ops.CACHE_INSTRUCTION = False
+        ref = _eager_rollout(pol, obs)
+        assert pol.net.instruction_encoder.last_cache is None
+        ops.CACHE_INSTRUCTION = True
+        got = _eager_rollout(pol, obs, check_dirty=expect_dirty)
+        for t in range(steps):
+            assert torch.equal(got[t][0], ref[t][0]) and torch.equal(got[t][1], ref[t][1]), f"eager step {t}"
+        # replayed: the cache's buffers are shared by the graphs of both phases; the capture's warm-up steps leave obs[0]'s
+        # tokens in the cache, the script's first step is all-dirty anyway (reset_state + a fresh mapper)
+        tr_g = GTSemanticsIterativeMapper.from_config(get_config())
+        runner = GraphedRollout(pol, [tr_g], obs[0], deterministic=True, streams="split")
+        tr_g.mapping_module.reset()
+        runner.reset_state()
+        cache = pol.net.instruction_encoder.step_cache(B, 200, torch.device("cuda:0"))
+        cache.invalidate()
+        for t, o in enumerate(obs):
+            a = runner.step(o)
+            torch.cuda.synchronize()
+            assert torch.equal(a, ref[t][0]) and torch.equal(runner.rnn_states, ref[t][1]), f"replayed step {t}"
+            assert cache.dirty.tolist() == expect_dirty[t], (t, cache.dirty.tolist())
+    finally:
+        ops.CACHE_INSTRUCTION = old
+
+
+def test_instruction_cache_follows_weight_changes_and_batch_rows():
+    """The cache is keyed by the tokens, so anything else that changes the encoding has to invalidate it: a weight update
+    (FlatAdam.step writes through raw pointers: ops.invalidate_step_caches), an in-place edit of an LSTM weight, and rows
+    that move when envs pause (quirks Q5 / Q12: the batch is compacted - the tokens of a row then differ)."""
+    from ivln_ce_amd import ops
+
+    pol = make_policy()
+    enc = pol.net.instruction_encoder
+    g = torch.Generator().manual_seed(9)
+    tokens = torch.zeros(4, 200, dtype=torch.long)
+    tokens[:, :50] = torch.randint(2, 2504, (4, 50), generator=g)
+    obs = {"instruction": tokens.to("cuda:0")}
+
+    def fresh(o):
+        old = ops.CACHE_INSTRUCTION
+        ops.CACHE_INSTRUCTION = False
+        try:
+            with torch.no_grad():
+                r, ln = enc(o)
+            return r.clone(), ln.clone()
+        finally:
+            ops.CACHE_INSTRUCTION = old
+
+    with torch.no_grad():
+        a, _ = enc(obs)
+        assert enc.last_cache.dirty.tolist() == [1, 1, 1, 1] and torch.equal(a, fresh(obs)[0])
+        a, _ = enc(obs)
+        assert enc.last_cache.dirty.tolist() == [0, 0, 0, 0] and torch.equal(a, fresh(obs)[0])
+        enc.encoder_rnn.weight_hh_l0.mul_(1.1)  # an in-place weight edit: new versions, every row re-encoded
+        a, _ = enc(obs)
+        assert enc.last_cache.dirty.tolist() == [1, 1, 1, 1] and torch.equal(a, fresh(obs)[0])
+        ops.invalidate_step_caches()  # what FlatAdam.step calls
+        a, _ = enc(obs)
+        assert enc.last_cache.dirty.tolist() == [1, 1, 1, 1]
+        # env 1 pauses: rows 2, 3 move up (a 3-row batch is another cache), then the 4-row batch comes back permuted
+        o3 = {"instruction": obs["instruction"][[0, 2, 3]].contiguous()}
+        a3, _ = enc(o3)
+        assert enc.last_cache.rows == 3 and torch.equal(a3, fresh(o3)[0])
+        o4 = {"instruction": obs["instruction"][[0, 2, 1, 3]].contiguous()}
+        a4, l4 = enc(o4)
+        assert enc.last_cache.dirty.tolist() == [0, 1, 1, 0]
+        r4, rl4 = fresh(o4)
+        assert torch.equal(a4, r4) and torch.equal(l4, rl4)
