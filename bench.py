@@ -505,13 +505,14 @@ class UpdateLeg:
         from ivln_ce_amd.aux_losses import AuxLosses
 
         overlap, _train.OVERLAP_INSTRUCTION = _train.OVERLAP_INSTRUCTION, False
+        overlap_w, _train.OVERLAP_WGRAD = _train.OVERLAP_WGRAD, False
         AuxLosses.activate()
         try:
             with GemmTimer() as gt:
                 self.once()
                 ms = gt.total_ms()
         finally:
-            _train.OVERLAP_INSTRUCTION = overlap
+            _train.OVERLAP_INSTRUCTION, _train.OVERLAP_WGRAD = overlap, overlap_w
             AuxLosses.deactivate()
         return mfma_roofline(gt, ms, 1, pmc_traffic_pair("update_pmc_traffic.json"),
                              "k_conv_bf3 / k_wgrad_bf3 (split-bf16: the map CNN's forward convs, input gradients and weight "

@@ -119,26 +119,46 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
     const int HW = p.Hin * p.Win;
     const int grp = p.grp_imgs > 0 ? img0 / p.grp_imgs : 0;
 
-    // Staging work of a thread.  3x3 / 7x7: PPT patch PIXELS (consecutive threads on consecutive pixels of a row), all 8 channel
-    // pairs of the chunk for each - the pixel's source offset, validity and LDS record are derived ONCE (a handful of registers)
-    // and an item costs two adds; the first version re-derived (pixel, pair) per item: ~25 integer operations around an
-    // 11-operation split, and staging was 20 % of RedNet's 3x3 launches.  1x1 (CS chunks per stage, no halo): the flat
-    // (pixel, pair) enumeration with offsets re-derived per stage (tt: an opaque copy of the thread id against hoisting).
-    constexpr int PPT = (NPIX + NTB - 1) / NTB;
-    constexpr int NPI = KS == 1 ? ITEMS / NTB : PPT * (CB / 2);
-    int psrc[PPT], pdst[PPT];
+    // Staging work of a thread.
+    // 3x3 / 7x7 (round 5): an ITEM = one aligned 16-byte group of four pixels of a patch row x one channel pair - two
+    // buffer_load_b128 (one per channel) through an SGPR descriptor with the chunk's channel base in the scalar offset.  W is
+    // a multiple of 4 and the groups start at multiples of 4 pixels of the image row, so a group lies wholly inside the
+    // row or wholly outside: what is outside (halo past the image, images past the batch, channels past Cin) gets an
+    // out-of-range offset and the hardware returns zeros - no selects, no per-element validity.  Item -> lane: the pair
+    // index fastest, then the group (the LDS writes of 32 lanes then hit 16 banks twice: free; a wave's loads touch whole
+    // 128-byte lines).  Six loads per thread and chunk where the first version issued 32 four-byte loads with ~10 address
+    // operations each, and - the loads being unconditional - the compiler knows how many are in flight at every tap: the
+    // first version's `if (c + 1 < c_end) load_patch` made it wait for the NEXT chunk's patch (an HBM round trip) at the
+    // first tap of every chunk (s_waitcnt vmcnt(13) with 50 loads in flight).
+    // 1x1 (CS chunks per stage, no halo): the flat (pixel, pair) enumeration with offsets re-derived per stage.
+    constexpr int XOFF = 4 - KS / 2;                 // patch column x is pixel x + XOFF of the aligned group grid
+    constexpr int NG = (XOFF + PWR + 3) / 4;         // 16-byte groups per patch row
+    constexpr int ITEMS3 = IMGS * PH * NG * (CB / 2);
+    constexpr int NI3 = KS == 1 ? 1 : (ITEMS3 + NTB - 1) / NTB;
+    constexpr unsigned OOB = 0x80000000u;            // (>= num_records of the descriptor: the load returns zeros)
+    static_assert(NTB % 8 == 0, "a thread keeps its channel pair over its items");
+    unsigned ivo[NI3];
+    int idst[NI3], imask[NI3];
+    const int qpair = t & 7;
+    if constexpr (KS != 1) {
 #pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-        const int pix = t + j * NTB;
-        const int il = pix / (PH * PWR), rem = pix - il * (PH * PWR);
-        const int y = rem / PWR, x = rem - y * PWR;
-        const int hi = ho0 - p.pad + y, wi = wo0 - p.pad + x, img = img0 + il;
-        const bool ok = pix < NPIX && img < nimg && (unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win;
-        psrc[j] = ok ? (int)((int64_t)img * p.in_img_stride + hi * p.Win + wi) : -1;
-        pdst[j] = pix < NPIX ? pix * PIXB : -1;
+        for (int j = 0; j < NI3; ++j) {
+            const int idx = t + j * NTB, rest = idx >> 3;
+            const int g = rest % NG, yy = rest / NG, il = yy / PH, y = yy - il * PH;
+            const int hi = ho0 - p.pad + y, wi = wo0 - 4 + 4 * g, img = img0 + il;
+            const bool ok = idx < ITEMS3 && img < nimg && (unsigned)hi < (unsigned)p.Hin && wi >= 0 && wi + 3 < p.Win;
+            ivo[j] = ok ? (unsigned)(((int64_t)img * p.in_img_stride + (int64_t)(2 * qpair) * HW + hi * p.Win + wi) * 4) : OOB;
+            idst[j] = ((il * PH + y) * PWR + 4 * g - XOFF) * PIXB + qpair * 4;  // pixel e of the group: + e * PIXB
+            int m = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m |= (idx < ITEMS3 && (unsigned)(4 * g + e - XOFF) < (unsigned)PWR) ? (1 << e) : 0;
+            imask[j] = m;
+        }
     }
+    const __amdgpu_buffer_rsrc_t rB = bf3_rsrc(p.B);
     // 1x1: the patch is the output tile itself (no halo, maybe strided); NTB / NPIX thread groups share a pixel set and take
     // every (NTB / NPIX)-th chunk of the stage, all 8 channel pairs of each
+    constexpr int NPI = KS == 1 ? ITEMS / NTB : 1;
     constexpr int G1 = KS == 1 ? NTB / NPIX : 1;
     static_assert(KS != 1 || (NTB % NPIX == 0 && CS % G1 == 0), "1x1: whole thread groups per pixel set");
     int src1 = -1, dst1 = 0, g1 = 0;
@@ -153,6 +173,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
         dst1 = pix * PIXB;
     }
     float r0[NPI], r1[NPI];
+    v4i rv[NI3][2];
     auto load_patch = [&](int c) {
         const int cbase = c * (CB * CS) * HW;
         const int left = p.Cin - c * (CB * CS);  // channels this stage still has (ragged last chunk: the rest reads as zero)
@@ -168,15 +189,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
                     r1[jj * (CB / 2) + q] = p.B[ok1 ? o + HW : 0];
                 }
         } else {
+            const unsigned hw4 = (unsigned)HW * 4u;
+            const bool ok0 = 2 * qpair < left, ok1 = 2 * qpair + 1 < left;
 #pragma unroll
-            for (int j = 0; j < PPT; ++j)
-#pragma unroll
-                for (int q = 0; q < CB / 2; ++q) {
-                    const bool ok0 = psrc[j] >= 0 && 2 * q < left, ok1 = psrc[j] >= 0 && 2 * q + 1 < left;
-                    const int o = psrc[j] + cbase + 2 * q * HW;
-                    r0[j * (CB / 2) + q] = p.B[ok0 ? o : 0];
-                    r1[j * (CB / 2) + q] = p.B[ok1 ? o + HW : 0];
-                }
+            for (int j = 0; j < NI3; ++j) {
+                const unsigned v0 = ok0 ? ivo[j] : OOB, v1 = ok1 ? (ivo[j] | hw4 * 0u) + ((ivo[j] & OOB) ? 0u : hw4) : OOB;
+                rv[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rB, (int)v0, cbase * 4, 0);
+                rv[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rB, (int)v1, cbase * 4, 0);
+            }
         }
     };
     auto stage = [&](int c) -> uint32_t {  // returns the OR of the lower pieces this thread wrote (0: its values were bf16-exact)
@@ -200,18 +220,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
                 }
         } else {
 #pragma unroll
-            for (int j = 0; j < PPT; ++j)
+            for (int j = 0; j < NI3; ++j)
 #pragma unroll
-                for (int q = 0; q < CB / 2; ++q) {
-                    const float v0 = (psrc[j] >= 0 && 2 * q < left) ? r0[j * (CB / 2) + q] : 0.f;
-                    const float v1 = (psrc[j] >= 0 && 2 * q + 1 < left) ? r1[j * (CB / 2) + q] : 0.f;
+                for (int e = 0; e < 4; ++e) {
                     uint32_t H, M, L;
-                    split3_pair(v0, v1, H, M, L);
-                    nz |= M | L;
-                    if (PPT * NTB == NPIX || pdst[j] >= 0) {
-                        *reinterpret_cast<uint32_t*>(smem + pdst[j] + q * 4) = H;
-                        *reinterpret_cast<uint32_t*>(smem + pdst[j] + q * 4 + 32) = M;
-                        *reinterpret_cast<uint32_t*>(smem + pdst[j] + q * 4 + 64) = L;
+                    split3_pair(__int_as_float(rv[j][0][e]), __int_as_float(rv[j][1][e]), H, M, L);
+                    if ((imask[j] >> e) & 1) {  // (pixels of the group outside the patch - or items past the last - are not staged)
+                        nz |= M | L;
+                        unsigned char* d = smem + idst[j] + e * PIXB;
+                        *reinterpret_cast<uint32_t*>(d) = H;
+                        *reinterpret_cast<uint32_t*>(d + 32) = M;
+                        *reinterpret_cast<uint32_t*>(d + 64) = L;
                     }
                 }
         }
@@ -272,7 +291,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
         const bool lite = HAS_LITE ? __syncthreads_or((int)(nz != 0)) == 0 : (__syncthreads(), false);
         const unsigned long long tb = BF3_T();
         t_stage += tb - ta;
-        if (c + 1 < c_end) load_patch(c + 1);  // in flight under the MFMA phase
+        // The next chunk's patch flies under the MFMA phase.  Unconditional (the last chunk re-loads itself, six loads nobody
+        // reads): with a branch around it the compiler cannot count the loads in flight and waits for ALL of them at the first
+        // tap.  3x3 / 7x7: issued PATCH_TAP taps into the phase, ~3 us of MFMA work before the staging pass that reads them -
+        // the weight loads of the taps in between (waited for in order, a tap after tap) then never queue behind an HBM miss.
+        constexpr int PATCH_TAP = KS == 1 ? -1 : (KK - (TM == 2 ? 4 : 8) > 0 ? KK - (TM == 2 ? 4 : 8) : 0);
+        if constexpr (KS == 1) load_patch(c + 1 < c_end ? c + 1 : c);
         const int s0 = c * RP;
         auto taps = [&](auto lite_tag) {
             constexpr bool LITE = decltype(lite_tag)::value;
@@ -319,6 +343,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl) abuf[slot][tm][pl] = load_a(tm, s0 + r + DA, pl);
+                if (r == PATCH_TAP) load_patch(min(c + 1, c_end - 1));  // (behind this tap's weight loads: every wait of this chunk is for loads older than these)
                 __builtin_amdgcn_sched_barrier(0);  // (... and so do the weight loads: DA taps of flight time, not one)
             }
         };

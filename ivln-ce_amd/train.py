@@ -20,11 +20,16 @@ from . import ops
 # leaves the chip idle, and it is independent of the map CNN's convolutions (3.5 / 5.5 ms, MFMA-bound): in a
 # training pass it runs on a side stream next to them.  A/B switch for measurements and tests.
 OVERLAP_INSTRUCTION = not bool(os.environ.get("IVLN_NO_TRAIN_OVERLAP"))
+# The map CNN's four weight gradients (2.4 ms of 9.4 per update at T64 x N8) have no consumer before Adam: they run on a
+# second side stream beside the chain that IS sequential - input gradient of layer i -> BatchNorm / ReLU / pooling backward of
+# layer i-1 (HBM-bound passes that leave the matrix cores idle) -> ...  Same kernels, same operands, same bits; the split-K
+# workspace is per stream.  A/B switch: IVLN_NO_WGRAD_OVERLAP=1.
+OVERLAP_WGRAD = not bool(os.environ.get("IVLN_NO_WGRAD_OVERLAP"))
 _side = {}
 
 
-def side_stream(device):
-    key = str(device)
+def side_stream(device, role="txt"):
+    key = (str(device), role)
     if key not in _side:
         _side[key] = torch.cuda.Stream(device)
     return _side[key]
@@ -291,9 +296,12 @@ def _net_backward(net, S: Dict, d_feats: torch.Tensor) -> Dict:
     d_mp = ops.linear_bwd_input(d_pre_m, ml.weight)
     d_mp = _conv1d_backward(net.map_kv, d_mkv.view(rows, -1, 1, P), mp.view(rows, Cm, 1, P),
                             d_mp.view(rows, Cm, 1, P), G)
+    wg_side, G_wg = None, None
     if any(p.requires_grad for p in net.map_encoder.parameters()):
         d = d_mp.view(mp.shape)
         blocks = list(net.map_encoder.cnn)
+        if OVERLAP_WGRAD and not torch.cuda.is_current_stream_capturing():
+            wg_side, G_wg = side_stream(dev, "wgrad"), {}
         for i in range(len(blocks) - 1, -1, -1):
             conv, bn = blocks[i].conv[0], blocks[i].conv[1]
             s = S["map"][i]
@@ -303,7 +311,13 @@ def _net_backward(net, S: Dict, d_feats: torch.Tensor) -> Dict:
                 mean, rstd = bn.running_mean, torch.rsqrt(bn.running_var + bn.eps)
             dy, dgamma, dbeta = ops.cbra_bwd(d.contiguous(), s["y"], s["scale"], s["shift"], mean, rstd, s["train"])
             G[bn.weight], G[bn.bias] = dgamma, dbeta
-            G[conv.weight] = ops.conv2d_bwd_weight(dy, s["x"], 7, 7, 1, 3)
+            if wg_side is not None:
+                wg_side.wait_stream(main)  # dy exists
+                share_with_stream((dy, s["x"]), wg_side)
+                with torch.cuda.stream(wg_side):
+                    G_wg[conv.weight] = ops.conv2d_bwd_weight(dy, s["x"], 7, 7, 1, 3)
+            else:
+                G[conv.weight] = ops.conv2d_bwd_weight(dy, s["x"], 7, 7, 1, 3)
             if s["train"]:
                 # train-mode BatchNorm: sum_{n,h,w} dy = gamma*rstd*(S1 - S1 - S2*sum(xhat)/M) and sum(xhat) = 0,
                 # so the gradient of a conv bias feeding it is identically zero (autograd in the reference
@@ -314,6 +328,10 @@ def _net_backward(net, S: Dict, d_feats: torch.Tensor) -> Dict:
             if i > 0:
                 d = ops.conv2d(dy, ops.weight_flip_transpose(conv.weight), pad=3, weight_is_temp=True)
 
+    if wg_side is not None:
+        main.wait_stream(wg_side)
+        share_with_stream(G_wg, main)
+        G.update(G_wg)
     if G_txt is None:
         instruction_backward(net.instruction_encoder, S["txt"], d_txt, U, L, G)
     else:

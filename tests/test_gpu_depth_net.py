@@ -24,6 +24,8 @@ def _encoder(seed=5):
             if isinstance(m, torch.nn.GroupNorm):
                 m.weight.normal_(1.0, 0.2)
                 m.bias.normal_(0.0, 0.2)
+    for p in enc.parameters():  # frozen, as the reference configures it (resnet_encoders.py:45-46): a trainable encoder runs the launch chain
+        p.requires_grad_(False)
     return enc.to(DEV)
 
 
