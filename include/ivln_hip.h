@@ -154,7 +154,8 @@ typedef struct ivln_gemm_desc {
      * 6 insist on the LDS-patch direct conv / weight-gradient kernels (conv_direct.hip);
      * 7 insist on the float4-staged GEMM (gemm_vec.hip); 8 insist on the streaming short-K 1x1 conv
      * (conv1x1_stream.hip: K = 64 / 128 / 256, NCHW, whole 128-pixel strips); 9 insist on the split-bf16 direct conv
-     * (conv_bf3.hip, needs A_split).  6/7/8/9 return IVLN_E_UNSUPPORTED when
+     * (conv_bf3.hip, needs A_split); 10 insist on its K-split-over-waves form for pixel-starved deep 3x3 convs
+     * (k_conv_bf3_ks).  6/7/8/9/10 return IVLN_E_UNSUPPORTED when
      * the shape is not eligible (tuning, tests). */
     int tile_override;
     /* optional (stride-1 3x3 / 7x7 / 2x2 convs): the weights pre-arranged by ivln_conv_pack_weights_f32; when set and
@@ -318,14 +319,21 @@ typedef struct ivln_depthnet_op {
 } ivln_depthnet_op;
 /* ops_dev / ops_host: the same table in device and host memory.  depth (N, 2 Hin0, 2 Win0) raw images, image stride
  * depth_img_stride; arena: N per-image work areas of arena_stride floats; out: image stride out_img_stride.  sync_ws: 2048
- * bytes of device memory ZEROED ONCE by the caller (the launch leaves the counters zero again; word 256 is a sticky
- * error flag set when a bounded spin times out - ivln_depth_net_status).  IVLN_E_UNSUPPORTED: N > 8, or the 256
- * workgroups of the launch cannot all be resident (partitioned / masked device): the caller then runs the per-layer
- * launches (ivln_nconv_f32 / ivln_gn_conv_f32). */
+ * bytes of device memory ZEROED ONCE by the caller (a launch that completes leaves the counters zero again).  Word 256 is
+ * a sticky error flag set when a bounded spin times out (~0.2 s: some workgroup of the grid never became resident); words
+ * 258-259 may hold the device address of a pinned host uint32 (ivln_host_device_ptr) that receives the same flag, so that
+ * the host sees a time-out at its next stream synchronisation without a read-back (word 257: test hook).  Time-out path: the
+ * launch winds down WITHOUT writing valid features, its counters stay where they were, and every later launch on that
+ * workspace returns at once (it checks word 256 before touching `out`) until the caller has run ivln_depth_net_reset -
+ * and computed the step again on the per-layer launches (ivln_nconv_f32 / ivln_gn_conv_f32).  IVLN_E_UNSUPPORTED: N > 8, or
+ * the 256 workgroups of the launch cannot all be resident for this launch's LDS footprint on this device (partitioned /
+ * masked device): the caller runs the per-layer launches. */
 int ivln_depth_net_f32(const ivln_depthnet_op* ops_dev, const ivln_depthnet_op* ops_host, int n_ops, const float* weights,
                        const float* params, const float* depth, int64_t depth_img_stride, float* arena, int64_t arena_stride,
                        float* out, int64_t out_img_stride, int N, float eps, void* sync_ws, void* stream);
 int ivln_depth_net_status(const void* sync_ws, void* stream);
+int ivln_depth_net_reset(void* sync_ws, void* stream);
+int ivln_host_device_ptr(void* host, void** dev);
 
 /* ------------------------------------------------------------------------------------------
  * Convolution with GroupNorm applied to its INPUT on load and the GroupNorm statistics of its OUTPUT emitted as

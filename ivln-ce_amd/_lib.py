@@ -5,7 +5,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libivln_hip.so")
+# (IVLN_HIP_LIB: another build of the same library - A/B measurements of a kernel variant in one gpurun call; never set in production)
+_SO = os.environ.get("IVLN_HIP_LIB") or os.path.join(_HERE, "libivln_hip.so")
 _LIB = None
 
 vp = C.c_void_p

@@ -436,6 +436,237 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same arithmetic for the PIXEL-STARVED deep 3x3 convs (RedNet's layers 3-4 and the decoder's first stages,
+// rednet.py:190-263: 128-512 channels on 8x8 ... 32x32 maps, N = 512 ... 8192 pixels, K = 1152 ... 4608): round 5.
+// The tiled kernel above fills the chip there only by splitting K over blockIdx.z - two or three 16-channel chunks per
+// workgroup between a prologue and a slab epilogue, then a reduction launch: 30 us + 6.5 us for 2.4 GFLOP.  Here K is split
+// over the WAVES of a workgroup instead:
+//   * a workgroup (8 waves) owns 32 output channels x 64 output pixels (a whole 8x8 image, 4 rows of a 16-wide or 2 rows of
+//     a 32-wide one) over the WHOLE K; wave w takes the contiguous range [w, w + 1) * ceil(nch / 8) of the 16-channel chunks;
+//   * everything a wave needs is wave-private: its chunk's input patch is loaded (aligned 16-byte buffer loads, zeros from
+//     out-of-range offsets - the scheme of the tiled kernel), split into the three bf16 pieces and written to ITS region of
+//     LDS, its weight stream comes global -> registers three taps ahead.  No workgroup barrier inside the K loop: LDS
+//     accesses of one wave execute in program order, so the waves run free of each other and hide one another's latencies;
+//   * at the end the eight partial tiles meet in LDS (a barrier, 8 x 8 KB, aliasing the patch regions), every thread sums
+//     four outputs over the waves in a fixed order and applies the fused epilogue of ivln_gemm_f32: no slabs, no reduction
+//     launch, the same bits on every run.
+// L2 -> CU traffic is the price: every workgroup streams its 32 channels' weights for the whole K (885 KB at K = 4608).
+// ------------------------------------------------------------------------------------------------------------------
+template <int PTH, int PTW>
+__global__ __launch_bounds__(512, 2) void k_conv_bf3_ks(const ivln_gemm_desc p, const unsigned char* a_split, long long a_grp_bytes,
+                                                        int tiles_w, int tiles_h, int nimg) {
+    constexpr int NW = 8, TN = 2, KS = 3, KK = 9, DA = 3;
+    static_assert(PTH * PTW == 32 * TN, "64 pixels per workgroup");
+    constexpr int PH = PTH + 2, PWR = PTW + 2, NPIX = PH * PWR;
+    constexpr int XOFF = 3, NG = (XOFF + PWR + 3) / 4;
+    constexpr int ITEMS = PH * NG * (CB / 2), NI = (ITEMS + 63) / 64;
+    constexpr int WREG = (NPIX * PIXB + 15) & ~15;  // bytes of a wave's patch region
+    constexpr int LDT = 64 + 4;
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const BlockId bid = xcd_block_id(p.no_xcd_remap);
+    const int bx = bid.x;
+    const int tw = bx % tiles_w, th = (bx / tiles_w) % tiles_h, img0 = bx / (tiles_w * tiles_h);
+    const int ho0 = th * PTH, wo0 = tw * PTW;
+    const int m0 = bid.y * 32;
+    const int nch = p.Cin / CB;
+    const int HW = p.Hin * p.Win;
+    const int grp = p.grp_imgs > 0 ? img0 / p.grp_imgs : 0;
+    const int cpw = (nch + NW - 1) / NW;
+    const int c0 = min(nch, wave * cpw), c1 = min(nch, c0 + cpw);
+    unsigned char* const wsm = smem + wave * WREG;
+
+    // staging items of a LANE (the wave stages its own patch): (patch row, aligned 16-byte group, channel pair)
+    unsigned ivo[NI];
+    int idst[NI], imask[NI];
+    const int qpair = lane & 7;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int idx = lane + j * 64, rest = idx >> 3;
+        const int g = rest % NG, y = rest / NG;
+        const int hi = ho0 - 1 + y, wi = wo0 - 4 + 4 * g;
+        const bool ok = idx < ITEMS && img0 < nimg && (unsigned)hi < (unsigned)p.Hin && wi >= 0 && wi + 3 < p.Win;
+        ivo[j] = ok ? (unsigned)(((int64_t)img0 * p.in_img_stride + (int64_t)(2 * qpair) * HW + hi * p.Win + wi) * 4) : OOB;
+        idst[j] = (y * PWR + 4 * g - XOFF) * PIXB + qpair * 4;
+        int m = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m |= (idx < ITEMS && (unsigned)(4 * g + e - XOFF) < (unsigned)PWR) ? (1 << e) : 0;
+        imask[j] = m;
+    }
+    const __amdgpu_buffer_rsrc_t rB = bf3_rsrc(p.B);
+    const unsigned hw4 = (unsigned)HW * 4u;
+    v4i rv[NI][2];
+    auto load_patch = [&](int c) {
+        const int so = c * CB * HW * 4;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            rv[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rB, (int)ivo[j], so, 0);
+            rv[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rB, (int)((ivo[j] & OOB) ? OOB : ivo[j] + hw4), so, 0);
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                uint32_t H, M, L;
+                split3_pair(__int_as_float(rv[j][0][e]), __int_as_float(rv[j][1][e]), H, M, L);
+                if ((imask[j] >> e) & 1) {
+                    unsigned char* d = wsm + idst[j] + e * PIXB;
+                    *reinterpret_cast<uint32_t*>(d) = H;
+                    *reinterpret_cast<uint32_t*>(d + 32) = M;
+                    *reinterpret_cast<uint32_t*>(d + 64) = L;
+                }
+            }
+    };
+    int bbase[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int nl = tn * 32 + l31, ph = nl / PTW, pw = nl % PTW;
+        bbase[tn] = (ph * PWR + pw) * PIXB + half * 16;
+    }
+    const int mt = min(m0 / 32, (p.M + 31) / 32 - 1);
+    const __amdgpu_buffer_rsrc_t rA = bf3_rsrc(a_split + (int64_t)grp * a_grp_bytes + (int64_t)mt * nch * KK * (3 * 1024));
+    const int s_last = max(c1 * KK - 1, 0);
+    auto load_a = [&](int s_, int pl) -> v4i {
+        return __builtin_amdgcn_raw_buffer_load_b128(rA, (min(s_, s_last) * 3 + pl) * 1024 + lane * 16, 0, 0);
+    };
+    f32x16 acc[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[tn][i] = 0.f;
+
+    if (c0 < c1) {
+        v4i abuf[DA][3];
+#pragma unroll
+        for (int d = 0; d < DA; ++d)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) abuf[d][pl] = load_a(c0 * KK + d, pl);
+        load_patch(c0);
+        for (int c = c0; c < c1; ++c) {
+            stage();
+            const int s0 = c * KK;
+            auto read_b = [&](int r, bf16x8 (&b)[TN][3]) {
+                const int kh = r / KS, kw = r - kh * KS, toff = (kh * PWR + kw) * PIXB;
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        b[tn][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const v4i*>(wsm + bbase[tn] + toff + pl * 32));
+            };
+            bf16x8 bq[2][TN][3];
+            read_b(0, bq[0]);
+#pragma unroll
+            for (int r = 0; r < KK; ++r) {
+                const int slot = r % DA;
+                if (r + 1 < KK) read_b(r + 1, bq[(r + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                bf16x8 a[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) a[pl] = __builtin_bit_cast(bf16x8, abuf[slot][pl]);
+#define IVLN_BF3_PROD(PA, PB)                            \
+    _Pragma("unroll") for (int tn = 0; tn < TN; ++tn)    \
+        acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA], bq[r & 1][tn][PB], acc[tn], 0, 0, 0)
+                IVLN_BF3_PROD(0, 2);
+                IVLN_BF3_PROD(1, 1);
+                IVLN_BF3_PROD(2, 0);
+                IVLN_BF3_PROD(0, 1);
+                IVLN_BF3_PROD(1, 0);
+                IVLN_BF3_PROD(0, 0);
+#undef IVLN_BF3_PROD
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) abuf[slot][pl] = load_a(s0 + r + DA, pl);
+                if (r == 1) load_patch(min(c + 1, c1 - 1));  // (next chunk's patch: 7 taps of MFMA work before the staging pass reads it)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    // ---- the eight partial tiles meet in LDS: red[wave][32 channels][64 pixels (+4)] over the patch regions ----
+    __syncthreads();  // every wave is done reading its patch
+    float* const red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            red[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * LDT + tn * 32 + l31] = acc[tn][r];
+    __syncthreads();
+    {
+        const int ml = t >> 4, c4 = t & 15;  // 512 threads = 32 channels x 16 pixel quads
+        const int m = m0 + ml, nl = 4 * c4;
+        const int ph = nl / PTW, pw = nl % PTW;
+        const int ho = ho0 + ph, wo = wo0 + pw;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {  // fixed order: the sum does not depend on the run
+            const float4 u = *reinterpret_cast<const float4*>(red + (w * 32 + ml) * LDT + nl);
+            v.x += u.x, v.y += u.y, v.z += u.z, v.w += u.w;
+        }
+        if (m < p.M && img0 < nimg && ho < p.Hout && wo < p.Wout) {
+            const int64_t addr = ((int64_t)img0 * p.Ctot + m) * p.HoWo + ho * p.Wout + wo;
+            const int me = p.grp_imgs > 0 ? (img0 / p.grp_imgs) * p.M + m : m;
+            if (p.scale) {
+                const float sc = p.scale[me], sh = p.shift[me];
+                v.x = fmaf(v.x, sc, sh), v.y = fmaf(v.y, sc, sh), v.z = fmaf(v.z, sc, sh), v.w = fmaf(v.w, sc, sh);
+            } else if (p.shift) {
+                const float sh = p.shift[me];
+                v.x += sh, v.y += sh, v.z += sh, v.w += sh;
+            }
+            if (p.residual) {
+                const float4 rr = *reinterpret_cast<const float4*>(p.residual + addr);
+                v.x += rr.x, v.y += rr.y, v.z += rr.z, v.w += rr.w;
+            }
+            if (p.accumulate) {
+                const float4 rr = *reinterpret_cast<const float4*>(p.D + addr);
+                v.x += rr.x, v.y += rr.y, v.z += rr.z, v.w += rr.w;
+            }
+            if (p.relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+            *reinterpret_cast<float4*>(p.D + addr) = v;
+        }
+    }
+}
+
+template <int PTH, int PTW>
+int launch_bf3_ks_tile(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a_split, int64_t grp_bytes, int nimg) {
+    constexpr int NPIX = (PTH + 2) * (PTW + 2), WREG = (NPIX * PIXB + 15) & ~15;
+    constexpr size_t lds = (size_t)(8 * WREG > 8 * 32 * 68 * 4 ? 8 * WREG : 8 * 32 * 68 * 4);
+    static_assert(lds <= 160 * 1024, "patch regions do not fit");
+    auto kern = k_conv_bf3_ks<PTH, PTW>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return IVLN_E_HIP;
+        attr_done = true;
+    }
+    const int tiles_w = d.Wout / PTW, tiles_h = d.Hout / PTH;
+    dim3 grid(tiles_w * tiles_h * nimg, (d.M + 31) / 32, 1);
+    IVLN_LAUNCH_FAMILY(kern, grid, dim3(512), lds, s, d, a_split, (long long)grp_bytes, tiles_w, tiles_h, nimg);
+    return IVLN_OK;
+}
+
+// Eligibility of the K-split-over-waves kernel: deep 3x3 convs over few pixels.  mode: 0 = heuristic, 1 = insist (tests, tuning)
+int bf3_ks_launch(ivln_gemm_desc& d, hipStream_t s, int nimg, int mode) {
+    if (d.Cin % CB != 0 || d.Cin < 8 * CB || d.stat_partials || d.splits > 1) return IVLN_E_UNSUPPORTED;
+    if (d.Wout != 8 && d.Wout != 16 && d.Wout != 32) return IVLN_E_UNSUPPORTED;
+    const int pth = 64 / d.Wout;
+    if (d.Hout % pth != 0 || (d.in_img_stride & 3) || (((uintptr_t)d.B) & 15)) return IVLN_E_UNSUPPORTED;
+    if ((int64_t)nimg * d.in_img_stride * 4 >= (int64_t)1 << 31) return IVLN_E_UNSUPPORTED;  // byte offsets of the buffer loads
+    const int64_t wgs = (int64_t)(d.N / 64) * ((d.M + 31) / 32);
+    if (d.grp_imgs > 0 && nimg % d.grp_imgs != 0) return IVLN_E_UNSUPPORTED;
+    if (mode == 0 && (wgs > 2 * (int64_t)ivln_cu_count() || wgs < ivln_cu_count() / 4)) return IVLN_E_UNSUPPORTED;  // (more pixels: the tiled kernel fills the chip by itself)
+    const int64_t gb = d.a_split_grp_stride * 4;
+    d.splits = 1;
+    const unsigned char* a = (const unsigned char*)d.A_split;
+    if (d.Wout == 8) return launch_bf3_ks_tile<8, 8>(d, s, a, gb, nimg);
+    if (d.Wout == 16) return launch_bf3_ks_tile<4, 16>(d, s, a, gb, nimg);
+    return launch_bf3_ks_tile<2, 32>(d, s, a, gb, nimg);
+}
+
 // OIHW fp32 weights -> [32-channel tile][16-channel chunk][tap, padded][piece][lane] x 8 bf16: lane (l31, half) of tile mt
 // holds W[32 mt + l31][16 c + 8 half .. + 7][tap] - the A operand of v_mfma_f32_32x32x16_bf16 as one 16-byte load.
 __global__ __launch_bounds__(256) void k_conv_bf3_pack(const float* __restrict__ W, int M, int Cin, int KS, uint16_t* __restrict__ out,
@@ -848,6 +1079,16 @@ int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
         return IVLN_E_UNSUPPORTED;
     const int nimg = d.N / d.HoWo;
     if ((int64_t)nimg * d.in_img_stride >= (int64_t)1 << 31) return IVLN_E_UNSUPPORTED;  // 32-bit patch offsets
+    // pixel-starved deep 3x3 convs: K split over the waves of a workgroup, no slabs (k_conv_bf3_ks); IVLN_BF3_KS=0 | 1 = never | wherever eligible
+    static const int ks_env = getenv("IVLN_BF3_KS") ? atoi(getenv("IVLN_BF3_KS")) : -1;
+    if (KS == 3 && (ks_env != 0 || d.tile_override == 10) && d.splits <= 1) {
+        const int rc = bf3_ks_launch(d, s, nimg, (ks_env == 1 || d.tile_override == 10) ? 1 : 0);
+        if (rc != IVLN_E_UNSUPPORTED || d.tile_override == 10) {
+            if (rc == IVLN_OK) g_bf3_flops += 2.0 * d.M * (double)d.N * d.K, ++g_bf3_launches;
+            if (rc == IVLN_OK && d.stat_tiles) *d.stat_tiles = 0;
+            return rc;
+        }
+    }
     const int nch = ((d.Cin + CB - 1) / CB + bf3_stage_chunks(KS) - 1) / bf3_stage_chunks(KS);  // stages: what blockIdx.z can split
     auto tiles_of = [&](int cfg) {
         const Bf3Px t = bf3_px(kBf3BN[cfg], d.Wout);
@@ -874,7 +1115,9 @@ int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
     else if (d.M <= 64)
         cfg = (big_ok && KS != 1 && fills(blocks_of(1), 1)) ? 1
               : (fills(blocks_of(2), 1) ? 2 : (force ? 4 : -1));  // (64 x 32768: 64 x 128 and 32 x 256 tiles measured 42 / 40 us against the fp32 kernel's 38)
-    else cfg = fills(blocks_of(3), 1) ? 3 : (fills(blocks_of(2), 1) ? 2 : ((int64_t)d.M * d.N >= (1 << 21) ? 5 : 4));
+    // (round 5, aligned-group staging: the 64 x 128 tile now beats 128 x 128 wherever the latter leaves CUs without a workgroup -
+    //  128 x 16384: 42.7 vs 50.9 us, 256 x 4096: 43.2 vs 45.3)
+    else cfg = fills(blocks_of(3), 1) ? 3 : (fills(blocks_of(2), 1) ? 2 : (((int64_t)d.M * d.N >= (1 << 21) && blocks_of(5) >= CUS) ? 5 : 4));
     if (cfg < 0) return IVLN_E_UNSUPPORTED;
     if (cfg_env >= 0 && cfg_env < kBf3Cfgs && !(cfg_env == 0 && d.M > 32)) cfg = cfg_env;
     if ((cfg == 0 && !big_ok) || (KS == 1 && (cfg <= 1 || cfg == 6))) return IVLN_E_UNSUPPORTED;

@@ -56,8 +56,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef ivln_depthnet_op Op;
 
-// sync workspace (uint32 words): cluster c owns words [32 c, 32 c + 32): +0 arrivals, +1 exits, +2 XCC mask; word 256 = sticky error
-constexpr int SY_ERR = 256;
+// sync workspace (uint32 words): cluster c owns words [32 c, 32 c + 32): +0 arrivals, +1 exits, +2 XCC mask; word 256 = sticky error;
+// word 257 = test hook (non-zero: workgroup 1 of cluster 0 leaves at entry without ever arriving - what a workgroup that is not
+// resident looks like to the others); words 258-259 = device address of a HOST-visible uint32 (pinned memory) that also
+// receives the error, or 0: the host then learns of a time-out at its next stream synchronisation without a read-back
+constexpr int SY_ERR = 256, SY_TEST = 257, SY_HOST = 258;
 
 struct fdiv {  // a / b for 0 <= a < 2^20 (see gn_conv.hip)
     float r;
@@ -139,6 +142,8 @@ __device__ __forceinline__ bool cluster_wait(unsigned* sy, int cluster, unsigned
             __builtin_amdgcn_s_sleep(1);
             if (++spins > SPIN_MAX || ((spins & 1023) == 0 && __hip_atomic_load(&sy[SY_ERR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
                 __hip_atomic_store(&sy[SY_ERR], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned* const host_flag = reinterpret_cast<unsigned*>(((unsigned long long)sy[SY_HOST + 1] << 32) | sy[SY_HOST]);
+                if (host_flag) __hip_atomic_store(host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 ok = 0;
                 break;
             }
@@ -259,6 +264,17 @@ __global__ __launch_bounds__(NT, DEPTH_NET_MIN_BLOCKS) void k_depth_net(const Op
     // MFMA phase waited a full L2 round trip per chunk; tools/depth_net_phases.py).
     const __amdgpu_buffer_rsrc_t rW = rsrc(wts), rP = rsrc(prm);
     const float* dimg = depth + (int64_t)cluster * depth_img_stride;
+    // A launch whose sync words carry the sticky error of an EARLIER launch must not run: that launch left its arrival
+    // counters wherever the time-out found them, every barrier here would pass at once and `out` would receive garbage without
+    // any error.  Every workgroup leaves before it touches anything; the host clears the words (ivln_depth_net_reset).
+    if (tid == 0) {
+        int bad = __hip_atomic_load(&sy[SY_ERR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        if (!bad && sy[SY_TEST] != 0 && cluster == 0 && rank == 1) bad = 2;  // (test hook: this workgroup "is not resident")
+        *s_flag = bad;
+    }
+    __syncthreads();
+    if (*s_flag) return;
+    __syncthreads();  // (s_flag is reused by the barrier verdicts)
     if (tid == 0) {
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -759,6 +775,19 @@ int ivln_depth_net_stamps(unsigned long long* host, int n) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_dn_stamp), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
 }
 #endif
+
+/* Clears the counters and the sticky error of a sync workspace (words 0..257; the host-flag address in words 258-259 stays)
+ * on `stream`: after a time-out, before the workspace is used again. */
+int ivln_depth_net_reset(void* sync_ws, void* stream) {
+    if (!sync_ws) return IVLN_E_INVALID;
+    return hipMemsetAsync(sync_ws, 0, sizeof(unsigned) * SY_HOST, (hipStream_t)stream) == hipSuccess ? IVLN_OK : IVLN_E_HIP;
+}
+
+/* Device-side address of a pinned host allocation (hipHostGetDevicePointer): what words 258-259 of a sync workspace hold. */
+int ivln_host_device_ptr(void* host, void** dev) {
+    if (!host || !dev) return IVLN_E_INVALID;
+    return hipHostGetDevicePointer(dev, host, 0) == hipSuccess ? IVLN_OK : IVLN_E_HIP;
+}
 
 /* Synchronises `stream` and reads the sticky error word of a depth-net sync workspace. */
 int ivln_depth_net_status(const void* sync_ws, void* stream) {

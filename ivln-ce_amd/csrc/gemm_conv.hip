@@ -505,10 +505,10 @@ extern "C" int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream) {
         if (d.tile_override == 0) d.tile_override = ivln_gemm_vec_eligible(d) ? 7 : 1;
     }
     // stride-1 3x3 / 7x7 with split-bf16 weights on hand: the bf16-MFMA direct conv (conv_bf3.hip); 9 insists on it
-    if ((d.tile_override == 0 || d.tile_override == 9) && d.A_split) {
+    if ((d.tile_override == 0 || d.tile_override == 9 || d.tile_override == 10) && d.A_split) {
         const int splits_asked = d.splits;
         float* const stats_asked = d.stat_partials;
-        const int rc = ivln_conv_bf3_launch(d, s, d.tile_override == 9);
+        const int rc = ivln_conv_bf3_launch(d, s, d.tile_override >= 9);
         if (rc == IVLN_OK) {
             if (d.splits_used) *d.splits_used = d.splits;
             if (d.splits > 1) launch_splitk_epilogue(d, s);
@@ -516,7 +516,7 @@ extern "C" int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream) {
         }
         d.splits = splits_asked;  // (not taken: the fp32 kernels decide for themselves)
         d.stat_partials = stats_asked;
-        if (rc != IVLN_E_UNSUPPORTED || d.tile_override == 9) return rc;
+        if (rc != IVLN_E_UNSUPPORTED || d.tile_override >= 9) return rc;
     } else if ((d.tile_override == 0 || d.tile_override == 9) && d.bmode == BMODE_IM2COL_T) {
         const int splits_asked = d.splits;
         const int rc = ivln_wgrad_bf3_launch(d, s, d.tile_override == 9);
@@ -527,7 +527,7 @@ extern "C" int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream) {
         }
         d.splits = splits_asked;
         if (rc != IVLN_E_UNSUPPORTED || d.tile_override == 9) return rc;
-    } else if (d.tile_override == 9) {
+    } else if (d.tile_override >= 9) {
         return IVLN_E_UNSUPPORTED;
     }
     // stride-1 3x3 / 7x7: LDS-staged direct convolution (conv_direct.hip); tile_override 1..5 pins the

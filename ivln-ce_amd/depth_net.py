@@ -337,12 +337,22 @@ class DepthNetPlan:
         self.params = torch.cat(self.prog.pchunks).to(device)
         self.arena_stride = (self.prog.arena + 255) // 256 * 256
         self._per_stream = {}  # stream handle -> (arena, sync words)
+        # a pinned host word every sync workspace of this plan points to: a launch that times out raises it, and the host reads
+        # it - a plain memory read - right after the stream synchronisation its loops perform anyway (`failed`)
+        self.host_flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.disabled = False  # set by `recover`: the rest of the run uses the launch chain
         self.stamp = self.stamp_of(encoder)
         L = lib()
         vp, i64 = C.c_void_p, C.c_int64
         L.ivln_depth_net_f32.argtypes = [vp, C.POINTER(DepthNetOp), I32, vp, vp, vp, i64, vp, i64, vp, i64, I32, C.c_float, vp, vp]
         L.ivln_depth_net_status.argtypes = [vp, vp]
+        L.ivln_depth_net_reset.argtypes = [vp, vp]
+        L.ivln_host_device_ptr.argtypes = [vp, C.POINTER(vp)]
         self._L, self._ops = L, ops
+        dp = vp()
+        from ._lib import check
+        check(L.ivln_host_device_ptr(self.host_flag.data_ptr(), C.byref(dp)), "ivln_host_device_ptr")
+        self._host_flag_dev = int(dp.value)
 
     @staticmethod
     def stamp_of(encoder):
@@ -374,10 +384,30 @@ class DepthNetPlan:
         key = self._ops.stream_ptr()
         st = self._per_stream.get(key)
         if st is None and create and not torch.cuda.is_current_stream_capturing():
+            sync = torch.zeros(512, dtype=torch.int32)
+            lo, hi = self._host_flag_dev & 0xFFFFFFFF, self._host_flag_dev >> 32
+            sync[258], sync[259] = (lo - (1 << 32) if lo >= 1 << 31 else lo), (hi - (1 << 32) if hi >= 1 << 31 else hi)
             st = self._per_stream[key] = (
-                torch.zeros(self.MAX_IMAGES * self.arena_stride, dtype=torch.float32, device=self.device),
-                torch.zeros(512, dtype=torch.int32, device=self.device))
+                torch.zeros(self.MAX_IMAGES * self.arena_stride, dtype=torch.float32, device=self.device), sync.to(self.device))
         return st
+
+    def failed(self):
+        """True when a launch of this plan timed out (a cluster barrier's bounded spin: some workgroup never became
+        resident).  A host memory read - meaningful after a synchronisation of the stream(s) the launches ran on."""
+        return int(self.host_flag[0]) != 0
+
+    def recover(self):
+        """After `failed`: clear every workspace's counters and error word (the device is drained first: the launch that
+        failed has wound down, the ones queued behind it returned at entry) and retire the plan - `plan_for` answers None
+        from now on, i.e. the encoder runs the launch chain for the rest of the run."""
+        torch.cuda.synchronize(self.device)
+        from ._lib import check
+
+        for _, sync in list(self._per_stream.values()):
+            check(self._L.ivln_depth_net_reset(self._ops.dptr(sync), self._ops.stream_ptr()), "ivln_depth_net_reset")
+        torch.cuda.synchronize(self.device)
+        self.host_flag.zero_()
+        self.disabled = True
 
     def run(self, depth, out, out_img_stride):
         """depth (B, H, W, 1) float32 contiguous on the device -> out[b * out_img_stride + ...] (C, h, w) per image.
@@ -436,6 +466,8 @@ def plan_for(encoder, device):
     key = (id(encoder), str(device))
     ent = _PLANS.get(key)
     stamp = DepthNetPlan.stamp_of(encoder)
+    if ent is not None and ent[0]() is encoder and ent[1].disabled:
+        return None
     if ent is not None and ent[0]() is encoder and ent[1].stamp != stamp:
         if torch.cuda.is_current_stream_capturing():
             return None
@@ -451,3 +483,31 @@ def check_all():
     """Raises when a cluster barrier of any plan's launches timed out (sticky word); synchronises the current stream."""
     for _, plan in list(_PLANS.values()):
         plan.check_status()
+
+
+def armed():
+    """A persistent launch may be part of the steps being run: some plan exists and has not been retired.  (Cheap: what the
+    loops ask before they spend a stream synchronisation on `any_failed`.)"""
+    return any(not plan.disabled for _, plan in _PLANS.values())
+
+
+def any_failed():
+    """A persistent launch of some plan timed out (host-visible flags: no device access; call after the step's stream
+    synchronisation)."""
+    return any(plan.failed() for _, plan in _PLANS.values())
+
+
+def recover_all():
+    """Clears and retires every plan that failed; returns how many."""
+    import logging
+
+    n = 0
+    for _, plan in list(_PLANS.values()):
+        if plan.failed():
+            plan.recover()
+            n += 1
+    if n:
+        logging.getLogger("ivln_ce_amd").warning(
+            "persistent depth encoder: a cluster barrier timed out (the launch's workgroups were not all resident); the step is "
+            "computed again on the launch chain and the persistent form stays off for the rest of the run")
+    return n

@@ -469,7 +469,7 @@ class ResNetEncoder(nn.Module):
         want = ops.DEPTH_NET == 2 or (ops.DEPTH_NET == 1 and (not getattr(self, "beside_other_work", False)
                                                                 or B >= ops.DEPTH_NET_SPLIT_MIN))
         if (want and B <= depth_net.DepthNetPlan.MAX_IMAGES and (H, W) == (256, 256) and not torch.is_grad_enabled()
-                and getattr(self, "latency_bound", True)):
+                and getattr(self, "latency_bound", True) and not getattr(self, "no_persistent", False)):
             # rollout batches: the whole encoder as ONE persistent launch, a cluster of 32 workgroups per image
             # (csrc/depth_net.hip); declined (False) when the device cannot keep all its workgroups resident
             plan = depth_net.plan_for(self, depth.device)

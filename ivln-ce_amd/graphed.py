@@ -206,6 +206,12 @@ class GraphedRollout:
         if venc is not None:
             venc.latency_bound = not predicted
             venc.beside_other_work = True  # (its graph replays beside the mapper / map-CNN graph: ops.DEPTH_NET's policy)
+            # measurement switch for the predicted-semantics step: how the policy's depth encoder runs beside RedNet -
+            # "pairs" (default: conv + GroupNorm launches), "chain" (GroupNorm + next conv per launch), "net" (persistent launch)
+            pd = os.environ.get("IVLN_PRED_DEPTH", "pairs") if predicted else None
+            venc.no_persistent = pd == "chain"
+            if pd in ("chain", "net"):
+                venc.latency_bound = True
         net._txt_with_dep = predicted  # ... and the instruction encoder leaves RedNet's stream for the side graph
         net._txt_last = os.environ.get("IVLN_TXT_LAST", "1") != "0"
         # ... and with fewer than 8 images some XCDs stay free of it: the bi-LSTM's blocks that land there take all the work
@@ -296,9 +302,12 @@ class GraphedRollout:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         ops.settle_packed_weights()
+        # captured on the stream the warm-up ran on: per-stream resources (split-K workspaces, the persistent depth
+        # encoder's arena and sync words) exist for it - a capture stream of torch's own would find none and could not
+        # create them inside the capture
         for src in (0, 1):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, stream=s):
                 self._body(src)
             self.graphs.append(g)
         self.phase = 0
@@ -331,6 +340,36 @@ class GraphedRollout:
         else:
             self.graphs[self.phase].replay()
         self.phase ^= 1
+        return self.actions
+
+    def redo_last_step_eagerly(self):
+        """The policy half of the LAST replayed step again, as eager launches, from the same inputs and the same recurrent
+        state: what a loop does after a persistent kernel of the step timed out (depth_net.any_failed -> recover_all, which
+        retires the persistent form: these launches take the launch chain).  The mapper's part of the step stands - it does
+        not depend on the depth encoder and its maps sit in the mapper's persistent buffers.  BatchNorm running statistics
+        (a policy in train mode: quirk Q6) were already updated by the replayed step and are not updated again.  Returns the
+        action tensor; `rnn_states` / `actions` then hold the recomputed values.  The runner must not be replayed afterwards
+        (its graphs still contain the retired launch): callers capture a new one."""
+        src, dst = self.phase ^ 1, self.phase  # (step() has flipped the phase)
+        batch = dict(self.static)
+        occ, sem = self.maps()
+        if occ is not None:
+            batch["occupancy_map"], batch["semantic_map"] = occ, sem
+        bns = [m for m in self.policy.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+        saved = [(m.momentum, m.num_batches_tracked.clone() if m.num_batches_tracked is not None else None) for m in bns]
+        for m in bns:
+            m.momentum = 0.0
+        try:
+            with torch.no_grad():
+                actions, rnn = self.policy.act(batch, self.rnn[src], self.prev[src], _policy_masks(batch),
+                                               deterministic=self.deterministic)
+                self.prev[dst].copy_(actions)
+                self.rnn[dst].copy_(rnn)
+        finally:
+            for m, (mom, nbt) in zip(bns, saved):
+                m.momentum = mom
+                if nbt is not None:
+                    m.num_batches_tracked.copy_(nbt)
         return self.actions
 
     def maps(self):

@@ -403,7 +403,7 @@ def conv2d(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, 
         big_1x1 = stride == 2 or 2.0 * Cout * Cin * N * Ho * Wo >= 4e9
         want_1x1 = TILE_OVERRIDE == 9 or SPLIT_BF16_1X1 == 1 or (SPLIT_BF16_1X1 != 0 and big_1x1)
         if (want_1x1 and SPLIT_BF16 and stride in (1, 2) and Cin >= 128 and Cout >= 64 and Wo % 4 == 0 and Wo >= 8 and w.is_contiguous()
-                and not defer and (N * Ho * Wo * Cout >= SPLIT_BF16_MIN_OUT or TILE_OVERRIDE == 9)):
+                and not defer and (N * Ho * Wo * Cout >= SPLIT_BF16_MIN_OUT or TILE_OVERRIDE >= 9)):
             sp = packed_conv_weights(w, cache=not weight_is_temp, split=True)
             if sp is not None:
                 d.A_split = dptr(sp)
@@ -418,7 +418,7 @@ def conv2d(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, 
         # same-size stride-1 convs over enough pixels: both operands as three bf16 pieces on the bf16 MFMA pipe
         # (csrc/conv_bf3.hip; the C side decides per shape and falls back to the fp32 MFMA kernels)
         if (SPLIT_BF16 and stride == 1 and pad == KH // 2 and Wo % 4 == 0 and Wo >= 8 and w.is_contiguous() and not defer
-                and (N * Ho * Wo * Cout >= SPLIT_BF16_MIN_OUT or TILE_OVERRIDE == 9)):
+                and (N * Ho * Wo * Cout >= SPLIT_BF16_MIN_OUT or TILE_OVERRIDE >= 9)):
             sp = packed_conv_weights(w, cache=not weight_is_temp, split=True)
             if sp is not None:
                 d.A_split = dptr(sp)

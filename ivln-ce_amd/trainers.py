@@ -511,6 +511,23 @@ class BaseVLNCETrainer:
                 batch[k] = v[state_index] if torch.is_tensor(v) else [v[i] for i in state_index]
         return envs, recurrent_hidden_states, not_done_masks, prev_actions, batch, rgb_frames
 
+    def _persistent_guard(self, runner, redo_eager):
+        """Call right after the stream synchronisation of a policy step.  None when nothing happened (the normal case: one
+        read of a pinned host word per plan).  When a persistent kernel of the step timed out - its workgroups were not all
+        resident - the failed plans are cleared and retired (depth_net.recover_all: the rest of the run uses the launch
+        chain, a warning is logged) and the step's (actions, rnn_states) are computed again from the same inputs:
+        `runner.redo_last_step_eagerly()` for a replayed step (the caller then drops the runner), `redo_eager()` else."""
+        if self.device.type != "cuda" or not depth_net.any_failed():
+            return None
+        depth_net.recover_all()
+        if runner is not None:
+            actions = runner.redo_last_step_eagerly()
+            out = (actions, runner.rnn_states)
+        else:
+            out = redo_eager()
+        torch.cuda.current_stream().synchronize()
+        return out
+
     def _check_mappers(self):
         """Raise if a mapper's device-side error flag is set (IVLN_E_KEYSPACE / IVLN_E_CAPACITY: points were
         dropped, so the maps of this rollout are wrong).  Called where the loops synchronise anyway."""
@@ -683,12 +700,26 @@ class BaseVLNCETrainer:
                     captured = True
                 actions = runner.step(batch)
                 rnn_states, prev_actions = runner.rnn_states, actions
+                if depth_net.armed():  # (a persistent launch is part of the step: its time-out flag is read after the sync)
+                    torch.cuda.current_stream().synchronize()
+                    fixed = self._persistent_guard(runner, None)
+                    if fixed is not None:
+                        (actions, rnn_states), prev_actions, runner = fixed, fixed[0], None
             else:
                 eager_once = False
-                with torch.no_grad():
-                    actions, rnn_states = self.policy.act(batch, rnn_states, prev_actions, not_done_masks,
-                                                          deterministic=not config.EVAL.SAMPLE)
-                    prev_actions.copy_(actions)
+
+                def act_once(rs=rnn_states, pa=prev_actions, b=batch, m=not_done_masks):
+                    with torch.no_grad():
+                        return self.policy.act(b, rs, pa, m, deterministic=not config.EVAL.SAMPLE)
+
+                actions, rnn_new = act_once()
+                if depth_net.armed():
+                    torch.cuda.current_stream().synchronize()
+                    fixed = self._persistent_guard(None, act_once)
+                    if fixed is not None:
+                        actions, rnn_new = fixed
+                rnn_states = rnn_new
+                prev_actions.copy_(actions)
             outputs = envs.step([a[0].item() for a in actions])
             observations, _, dones, infos = [list(x) for x in zip(*outputs)]
             not_done_masks = torch.tensor([[0] if done else [1] for done in dones], dtype=torch.uint8,
@@ -823,13 +854,27 @@ class BaseVLNCETrainer:
                     captured = True
                 actions = runner.step(batch)
                 rnn_states, prev_actions = runner.rnn_states, actions
+                if depth_net.armed():
+                    torch.cuda.current_stream().synchronize()
+                    fixed = self._persistent_guard(runner, None)
+                    if fixed is not None:
+                        (actions, rnn_states), prev_actions, runner = fixed, fixed[0], None
             else:
                 eager_once = False
-                with torch.no_grad():
-                    actions, rnn_states = self.policy.act_iterative(
-                        batch, rnn_states, prev_actions, agent_episode_not_done_masks, sim_episode_not_done_masks,
-                        tour_not_done_masks, action_masks, deterministic=not config.EVAL.SAMPLE)
-                    prev_actions.copy_(actions)
+
+                def act_once(rs=rnn_states, pa=prev_actions, b=batch, m=(agent_episode_not_done_masks, sim_episode_not_done_masks,
+                                                                        tour_not_done_masks, action_masks)):
+                    with torch.no_grad():
+                        return self.policy.act_iterative(b, rs, pa, *m, deterministic=not config.EVAL.SAMPLE)
+
+                actions, rnn_new = act_once()
+                if depth_net.armed():
+                    torch.cuda.current_stream().synchronize()
+                    fixed = self._persistent_guard(None, act_once)
+                    if fixed is not None:
+                        actions, rnn_new = fixed
+                rnn_states = rnn_new
+                prev_actions.copy_(actions)
             outputs = envs.step([a[0].item() for a in actions])
             (observations, _, agent_episode_dones, sim_episode_dones, tour_dones, produce_actions,
              infos) = [list(x) for x in zip(*outputs)]
@@ -1042,38 +1087,61 @@ class _RolloutStepper:
         if self.device_mix:
             batch[pol.U_SAMPLE] = torch.rand((n, 1), dtype=torch.float, generator=self.gen).to(self.dev)
             batch[pol.U_BETA] = draw.to(self.dev)
-        if self.use_graph and not self.eager_once:
+        replayed = self.use_graph and not self.eager_once
+        if replayed:
             if self.runner is None:
                 self.runner = tr._make_runner(batch, rnn_states, prev_actions, first=not self.captured,
                                               deterministic=False, extra_keys=(self.expert_uuid,))
                 self.captured = True
-            actions = self.runner.step(batch)
-            rnn_states = self.runner.rnn_states
-            occ, sem = self.runner.maps()
-            depth = self.runner.depth_features() if tr._caches_depth() else None
+            runner = self.runner
+            actions = runner.step(batch)
+            rnn_states = runner.rnn_states
+            occ, sem = runner.maps()
+            depth = runner.depth_features() if tr._caches_depth() else None
             rgb = None
         else:
             self.eager_once = False
-            if self.iterative:
-                actions, rnn_states = pol.act_iterative(batch, rnn_states, prev_actions, *masks, deterministic=False)
-            else:
-                actions, rnn_states = pol.act(batch, rnn_states, prev_actions, masks[0], deterministic=False)
-            if not self.device_mix:  # the reference's statements
-                expert = batch[self.expert_uuid].long()
-                actions = torch.where(draw.to(actions.device) < self.beta, expert, actions)
-                actions = torch.where(expert == -1, torch.zeros_like(actions), actions)
-            prev_actions.copy_(actions)
-            actions = prev_actions
+            rnn_in = rnn_states
+
+            def act_once():
+                if self.iterative:
+                    a, r = pol.act_iterative(batch, rnn_in, prev_actions, *masks, deterministic=False)
+                else:
+                    a, r = pol.act(batch, rnn_in, prev_actions, masks[0], deterministic=False)
+                if not self.device_mix:  # the reference's statements
+                    expert = batch[self.expert_uuid].long()
+                    a = torch.where(draw.to(a.device) < self.beta, expert, a)
+                    a = torch.where(expert == -1, torch.zeros_like(a), a)
+                return a, r
+
+            actions, rnn_states = act_once()
             occ, sem = batch.get("occupancy_map"), batch.get("semantic_map")
             depth, rgb = self.feats.get("depth"), self.feats.get("rgb")
         if (occ is None) != (sem is None):
             raise RuntimeError("either both map keys should exist in the batch or neither")
-        host = {"actions": self._to_host("a", actions), "occ": None if occ is None else self._to_host("o", occ),
-                "sem": None if sem is None else self._to_host("s", sem),
-                "depth": None if depth is None else self._to_host("d", depth),
-                "rgb": None if rgb is None else self._to_host("r", rgb)}
+
+        def host_copies():
+            return {"actions": self._to_host("a", actions), "occ": None if occ is None else self._to_host("o", occ),
+                    "sem": None if sem is None else self._to_host("s", sem),
+                    "depth": None if depth is None else self._to_host("d", depth),
+                    "rgb": None if rgb is None else self._to_host("r", rgb)}
+
+        host = host_copies()
         if self.on_gpu:
             torch.cuda.current_stream().synchronize()
+            fixed = tr._persistent_guard(runner if replayed else None, None if replayed else act_once) if depth_net.armed() else None
+            if fixed is not None:  # a persistent kernel of this step timed out: the values above are void, these are the step's
+                actions, rnn_states = fixed
+                if replayed:
+                    self.runner = None  # (its graphs contain the retired launch: the next step captures again)
+                    depth = self.feats.get("depth") if tr._caches_depth() else None  # (the redo ran eagerly: the encoder's hook kept them)
+                else:
+                    depth, rgb = self.feats.get("depth"), self.feats.get("rgb")
+                host = host_copies()
+                torch.cuda.current_stream().synchronize()
+        if not replayed:
+            prev_actions.copy_(actions)
+            actions = prev_actions
         host["actions"] = [int(a) for a in host["actions"].view(-1).tolist()]
         for k in ("occ", "sem"):
             if host[k] is not None:

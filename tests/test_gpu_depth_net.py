@@ -246,3 +246,48 @@ def test_overlapping_launches_on_two_streams_do_not_share_an_arena():
         assert len(plan._per_stream) == 2
     finally:
         ops.DEPTH_NET = old
+
+
+def test_timeout_of_the_persistent_launch_is_seen_by_the_host_and_recovered_on_the_launch_chain():
+    """VERDICT r4 item 7 / ADVICE r3: the cluster barriers need every workgroup of the launch resident.  A workgroup that never
+    arrives (word 257 of the sync workspace: workgroup 1 of cluster 0 leaves at entry - exactly what a workgroup the
+    dispatcher could not place looks like to the other 31 of its cluster) makes the bounded spins time out (~0.2 s).  Then
+      * the host sees it WITHOUT a device read: the kernel raised the plan's pinned host word (`plan.failed()`);
+      * a further launch on the poisoned workspace returns at entry and leaves its output alone (the counters are stale:
+        it would pass every barrier at once and write garbage, ADVICE r4);
+      * `recover_all` clears the words and retires the plan: the encoder then runs the launch chain - the features of the
+        SAME step, computed again, are the chain's, bit for bit, and within 2e-4 of what the healthy persistent launch gave."""
+    from ivln_ce_amd import depth_net, ops
+
+    enc = _encoder(21)
+    d = torch.rand(4, 256, 256, 1, generator=torch.Generator().manual_seed(8)).to(DEV)
+    old = ops.DEPTH_NET
+    try:
+        ops.DEPTH_NET = 0
+        with torch.no_grad():
+            chain = enc({"depth": d}).clone()
+        ops.DEPTH_NET = 2
+        with torch.no_grad():
+            good = enc({"depth": d}).clone()
+        plan = depth_net.plan_for(enc, DEV)
+        assert plan is not None and not plan.failed() and depth_net.armed() and not depth_net.any_failed()
+        _, sync = plan.stream_state()
+        sync[257] = 1
+        with torch.no_grad():
+            enc({"depth": d})
+        torch.cuda.synchronize()
+        assert plan.failed() and depth_net.any_failed() and int(sync[256]) == 1
+        marker = torch.full((4, 128, 4, 4), 7.0, device=DEV)
+        with torch.no_grad():
+            enc({"depth": d}, out=marker, out_ctot=128)
+        torch.cuda.synchronize()
+        assert bool((marker == 7.0).all()), "a launch on a poisoned workspace must not write its output"
+        assert depth_net.recover_all() == 1
+        assert plan.disabled and not plan.failed() and not depth_net.any_failed() and int(sync[:258].abs().sum()) == 0
+        assert depth_net.plan_for(enc, DEV) is None
+        with torch.no_grad():
+            again = enc({"depth": d})
+        assert torch.equal(again, chain)
+        assert float((again - good).abs().max()) < 2e-4
+    finally:
+        ops.DEPTH_NET = old

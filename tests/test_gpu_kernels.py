@@ -395,6 +395,55 @@ def test_conv2d_split_bf16_kernel(N, Cin, H, W, Cout, k):
     assert float(wide_k[:, :4].abs().max()) == 0.0 and float(wide_k[:, 4 + Cout:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("N,Cin,H,Cout,G", [(8, 512, 8, 512, 0), (8, 256, 16, 256, 0), (4, 128, 32, 128, 0), (16, 256, 16, 256, 2),
+                                           (3, 144, 8, 96, 0), (2, 128, 16, 40, 0)])
+def test_conv2d_split_bf16_k_split_over_waves(N, Cin, H, Cout, G):
+    """k_conv_bf3_ks (tile_override 10): the pixel-starved deep 3x3 convs of RedNet (rednet.py:190-263) with K split over the
+    eight WAVES of a workgroup - wave-private patches, no slabs, no reduction launch.  Same error bar against a float64
+    convolution as the tiled split-bf16 kernel and the fp32 MFMA kernel, every epilogue form (scale / shift / residual / ReLU,
+    a channel slice of a wider destination), image-grouped weights (the stacked RGB + depth encoders), channel counts that
+    leave some waves without a chunk (144 = 9 chunks) and a ragged channel tile (40 outputs), run-to-run identical bits."""
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(N * 100 + Cin + H)
+    x = torch.randn(N, Cin, H, H, generator=g)
+    wshape = (G, Cout, Cin, 3, 3) if G else (Cout, Cin, 3, 3)
+    w = torch.randn(*wshape, generator=g) / (Cin * 9) ** 0.5
+    sc, sh = torch.rand(max(G, 1) * Cout, generator=g) + 0.5, torch.randn(max(G, 1) * Cout, generator=g)
+    if G:
+        B = N // G
+        ref0 = torch.cat([F.conv2d(x[i * B:(i + 1) * B].double(), w[i].double(), None, padding=1) for i in range(G)])
+        scv = torch.cat([sc[i * Cout:(i + 1) * Cout].view(1, -1, 1, 1).expand(B, -1, 1, 1) for i in range(G)]).double()
+        shv = torch.cat([sh[i * Cout:(i + 1) * Cout].view(1, -1, 1, 1).expand(B, -1, 1, 1) for i in range(G)]).double()
+    else:
+        ref0 = F.conv2d(x.double(), w.double(), None, padding=1)
+        scv, shv = sc.double().view(1, -1, 1, 1), sh.double().view(1, -1, 1, 1)
+    res = torch.randn(ref0.shape, generator=g)
+    ref = F.relu(ref0 * scv + shv + res.double())
+    xd, wd = x.to(DEV), w.to(DEV)
+    try:
+        ops.TILE_OVERRIDE = 10
+        got = ops.conv2d(xd, wd, pad=1, scale=sc.to(DEV), shift=sh.to(DEV), residual=res.to(DEV), relu=True)
+        if not G:
+            plain = ops.conv2d(xd, wd, pad=1, splitk=False)
+            again = ops.conv2d(xd, wd, pad=1)
+            wide = torch.zeros(N, Cout + 8, H, H, device=DEV)
+            ops.conv2d(xd, wd, pad=1, out=wide[:, 4:], out_ctot=Cout + 8)
+            ops.TILE_OVERRIDE = 6
+            fp32 = ops.conv2d(xd, wd, pad=1, splitk=False)
+    finally:
+        ops.TILE_OVERRIDE = 0
+    _close(got, ref.float(), 3e-5)
+    if not G:
+        scale = float(ref0.abs().max())
+        e_split = float((plain.double().cpu() - ref0).abs().max()) / scale
+        e_fp32 = float((fp32.double().cpu() - ref0).abs().max()) / scale
+        assert e_split <= 3e-6 and e_split <= 2.0 * e_fp32 + 1e-6, (e_split, e_fp32)
+        assert torch.equal(plain, again)
+        assert torch.equal(wide[:, 4:4 + Cout], plain)
+        assert float(wide[:, :4].abs().max()) == 0.0 and float(wide[:, 4 + Cout:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("case", ["offset_input_zero_sum_filters", "wide_dynamic_range", "tiny_values"])
 def test_conv2d_split_bf16_accuracy_where_fp32_struggles(case):
     """Inputs that expose a lossy product: (1) activations 1000 + N(0, 1) against zero-sum filters - the exact result is O(1)

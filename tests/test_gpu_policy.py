@@ -427,3 +427,59 @@ def test_instruction_cache_follows_weight_changes_and_batch_rows():
         assert enc.last_cache.dirty.tolist() == [0, 1, 1, 0]
         r4, rl4 = fresh(o4)
         assert torch.equal(a4, r4) and torch.equal(l4, rl4)
+
+
+def test_replayed_step_whose_persistent_encoder_timed_out_is_redone_on_the_launch_chain(same_depth_path):
+    """The loops' guard (trainers._persistent_guard) on a replayed rollout: at step 3 a workgroup of the side graph's
+    persistent depth encoder "is not resident" (test hook, tests/test_gpu_depth_net.py), its barriers time out and the step's
+    features are void.  The host sees the pinned flag after the step's synchronisation, retires the plan and computes the
+    policy half of the SAME step again eagerly (GraphedRollout.redo_last_step_eagerly); the rollout goes on on the launch
+    chain.  Against the same script on a healthy runner: the same actions, recurrent states within the two encoders'
+    distance (2e-4)."""
+    same_depth_path(2)
+    from ivln_ce_amd import depth_net
+    from ivln_ce_amd.config import get_config
+    from ivln_ce_amd.graphed import GraphedRollout
+    from ivln_ce_amd.obs_transforms import GTSemanticsIterativeMapper
+
+    pol = make_policy()
+    for p in pol.net.depth_encoder.visual_encoder.parameters():
+        p.requires_grad_(False)
+    B, steps = 4, 7
+    obs, _ = _episode_script(B, steps, seed=11)
+
+    def run(fail_at):
+        tr = GTSemanticsIterativeMapper.from_config(get_config())
+        runner = GraphedRollout(pol, [tr], obs[0], deterministic=True, streams="split")
+        tr.mapping_module.reset()
+        runner.reset_state()
+        out, rnn, prev = [], None, None
+        for t, o in enumerate(obs):
+            if runner is not None:
+                if t == fail_at:
+                    plan = depth_net.plan_for(pol.net.depth_encoder.visual_encoder, torch.device("cuda:0"))
+                    with torch.cuda.stream(runner.sA):
+                        plan.stream_state()[1][257] = 1
+                a = runner.step(o)
+                torch.cuda.synchronize()
+                rnn = runner.rnn_states
+                if depth_net.any_failed():
+                    assert t == fail_at
+                    assert depth_net.recover_all() == 1
+                    a = runner.redo_last_step_eagerly()
+                    torch.cuda.synchronize()
+                    rnn, prev, runner = runner.rnn_states.clone(), a.clone(), None
+            else:  # the rest of the rollout: eager steps, the mapper keeps its state, the encoder runs the launch chain
+                b = tr(dict({k: (v.clone() if torch.is_tensor(v) else v) for k, v in o.items()}))
+                with torch.no_grad():
+                    a, rnn = pol.act(b, rnn, prev, b["not_done_masks"], deterministic=True)
+                prev = a.clone()
+            out.append((a.clone(), rnn.clone()))
+        return out
+
+    healthy = run(-1)
+    assert not depth_net.any_failed()
+    hurt = run(3)
+    for t in range(steps):
+        assert torch.equal(hurt[t][0], healthy[t][0]), f"actions step {t}"
+        assert float((hurt[t][1] - healthy[t][1]).abs().max()) < 2e-4, f"rnn step {t}"
