@@ -155,7 +155,7 @@ typedef struct ivln_gemm_desc {
      * 7 insist on the float4-staged GEMM (gemm_vec.hip); 8 insist on the streaming short-K 1x1 conv
      * (conv1x1_stream.hip: K = 64 / 128 / 256, NCHW, whole 128-pixel strips); 9 insist on the split-bf16 direct conv
      * (conv_bf3.hip, needs A_split); 10 insist on its K-split-over-waves form for pixel-starved deep 3x3 convs
-     * (k_conv_bf3_ks).  6/7/8/9/10 return IVLN_E_UNSUPPORTED when
+     * (k_conv_bf3_ks), 11 on the deep-K 1x1 form (k_conv1x1_bf3_ks).  6 ... 11 return IVLN_E_UNSUPPORTED when
      * the shape is not eligible (tuning, tests). */
     int tile_override;
     /* optional (stride-1 3x3 / 7x7 / 2x2 convs): the weights pre-arranged by ivln_conv_pack_weights_f32; when set and

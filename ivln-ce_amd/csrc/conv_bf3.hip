@@ -456,7 +456,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
 template <int PTH, int PTW>
 __global__ __launch_bounds__(512, 2) void k_conv_bf3_ks(const ivln_gemm_desc p, const unsigned char* a_split, long long a_grp_bytes,
                                                         int tiles_w, int tiles_h, int nimg) {
-    constexpr int NW = 8, TN = 2, KS = 3, KK = 9, DA = 3;
+    // DA: weight taps in flight.  A tap is only 12 MFMAs here (384 pipe cycles, 768 with the SIMD's other wave): three taps
+    // ahead were ~1 us of cover against an L2 round trip of 1-2 us under load - every tap waited (first version: 28 us for
+    // 512 x 512 x 4608 with 13 us of MFMA issue).  A whole chunk ahead (9 taps, 108 registers) covers it.
+    constexpr int NW = 8, TN = 2, KS = 3, KK = 9, DA = 9;
     static_assert(PTH * PTW == 32 * TN, "64 pixels per workgroup");
     constexpr int PH = PTH + 2, PWR = PTW + 2, NPIX = PH * PWR;
     constexpr int XOFF = 3, NG = (XOFF + PWR + 3) / 4;
@@ -665,6 +668,169 @@ int bf3_ks_launch(ivln_gemm_desc& d, hipStream_t s, int nimg, int mode) {
     if (d.Wout == 8) return launch_bf3_ks_tile<8, 8>(d, s, a, gb, nimg);
     if (d.Wout == 16) return launch_bf3_ks_tile<4, 16>(d, s, a, gb, nimg);
     return launch_bf3_ks_tile<2, 32>(d, s, a, gb, nimg);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// 1x1 convs with a deep K (RedNet's bottleneck reductions 1024 -> 256, 2048 -> 512, its 2048-channel expansions and skip
+// convs: rednet.py:20-65, 244-248) on the same arithmetic, K split over the waves of a workgroup, NO LDS in the K loop:
+//   * a workgroup (8 waves) owns 32 output channels x 128 consecutive pixels over the whole K, wave w the chunks
+//     [w, w + 1) * ceil(nch / 8);
+//   * a 1x1 conv needs no patch: the B fragment of v_mfma_f32_32x32x16_bf16 - column n, 8 consecutive k per lane - is
+//     built IN REGISTERS.  Lane (l31, half) loads, for its 8 channels (8 half ..) of the chunk, the four consecutive pixels
+//     4 l31 .. 4 l31 + 3 (one buffer_load_b128 per channel, 512 contiguous bytes per half-wave), splits channel pairs
+//     into the three bf16 pieces (v_cvt_pk_bf16_f32 packs a pair into the word the fragment wants) and has the B fragments
+//     of FOUR pixel tiles - tile e holds pixel 4 l31 + e in column l31 - without a single LDS access or barrier;
+//   * weights: the split image of ivln_conv_split_weights_f32 (KS = 1), global -> registers four chunks ahead;
+//   * the eight partial tiles meet in LDS at the end, summed in a fixed order, fused epilogue, 16-byte stores.
+// An activation element is split once per 32-channel tile that reads it (176 VALU operations per lane and chunk beside 24
+// MFMAs): the VALU work rides under the other wave's MFMAs.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void k_conv1x1_bf3_ks(const ivln_gemm_desc p, const unsigned char* a_split, long long a_grp_bytes) {
+    constexpr int NW = 8, TN = 4, DA = 4, BN = 128;
+    constexpr int LDT = BN + 4;
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const BlockId bid = xcd_block_id(p.no_xcd_remap);
+    const int n0 = bid.x * BN, m0 = bid.y * 32;
+    const int nch = p.Cin / CB;
+    const int HW = p.HoWo;
+    const int cpw = (nch + NW - 1) / NW;
+    const int c0 = min(nch, wave * cpw), c1 = min(nch, c0 + cpw);
+    const int n_img0 = n0 / HW;
+    const int grp = p.grp_imgs > 0 ? n_img0 / p.grp_imgs : 0;
+
+    const int nq = n0 + 4 * l31;  // this lane's four pixels (one image: HW is a multiple of 4)
+    const int qimg = nq / HW, qpp = nq - qimg * HW;
+    const unsigned hw4 = (unsigned)HW * 4u;
+    const unsigned xvo = nq < p.N ? (unsigned)(((int64_t)qimg * p.in_img_stride + qpp + (int64_t)(8 * half) * HW) * 4) : OOB;
+    const __amdgpu_buffer_rsrc_t rB = bf3_rsrc(p.B);
+    auto load_x = [&](int c, v4i (&xb)[8]) {
+        const int so = c * CB * HW * 4;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xb[j] = __builtin_amdgcn_raw_buffer_load_b128(rB, (int)((xvo & OOB) ? OOB : xvo + j * hw4), so, 0);
+    };
+    const int mt = min(m0 / 32, (p.M + 31) / 32 - 1);
+    const __amdgpu_buffer_rsrc_t rA = bf3_rsrc(a_split + (int64_t)grp * a_grp_bytes + (int64_t)mt * nch * (3 * 1024));
+    const int c_last = max(c1 - 1, 0);
+    auto load_a = [&](int c, v4i (&ab)[3]) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) ab[pl] = __builtin_amdgcn_raw_buffer_load_b128(rA, (min(c, c_last) * 3 + pl) * 1024 + lane * 16, 0, 0);
+    };
+    f32x16 acc[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[tn][i] = 0.f;
+
+    if (c0 < c1) {
+        v4i xb[2][8], ab[DA][3];
+#pragma unroll
+        for (int d = 0; d < DA; ++d) load_a(c0 + d, ab[d]);
+        load_x(c0, xb[0]);
+        load_x(min(c0 + 1, c_last), xb[1]);
+        for (int cc = c0; cc < c1; cc += DA) {
+#pragma unroll
+            for (int k = 0; k < DA; ++k) {
+                const int c = cc + k;
+                v4i bq[TN][3];
+                bf16x8 a[3];
+                // (loads stay outside the branch: the compiler then knows how many are in flight at every wait)
+                if (c < c1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            uint32_t H, M, L;
+                            split3_pair(__int_as_float(xb[k & 1][2 * i][e]), __int_as_float(xb[k & 1][2 * i + 1][e]), H, M, L);
+                            bq[e][0][i] = (int)H, bq[e][1][i] = (int)M, bq[e][2][i] = (int)L;
+                        }
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) a[pl] = __builtin_bit_cast(bf16x8, ab[k][pl]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                load_x(min(c + 2, c_last), xb[k & 1]);  // two chunks ahead
+                load_a(c + DA, ab[k]);                   // DA chunks ahead
+                __builtin_amdgcn_sched_barrier(0);
+                if (c < c1) {
+#define IVLN_BF3_PROD(PA, PB)                            \
+    _Pragma("unroll") for (int tn = 0; tn < TN; ++tn)    \
+        acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA], __builtin_bit_cast(bf16x8, bq[tn][PB]), acc[tn], 0, 0, 0)
+                    IVLN_BF3_PROD(0, 2);
+                    IVLN_BF3_PROD(1, 1);
+                    IVLN_BF3_PROD(2, 0);
+                    IVLN_BF3_PROD(0, 1);
+                    IVLN_BF3_PROD(1, 0);
+                    IVLN_BF3_PROD(0, 0);
+#undef IVLN_BF3_PROD
+                }
+            }
+        }
+    }
+    // ---- the eight partial tiles meet in LDS: red[wave][32 channels][4 tiles x 32 columns (+4)] ----
+    float* const red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            red[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * LDT + tn * 32 + l31] = acc[tn][r];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {  // 32 channels x 32 pixel quads = 1024 items over 512 threads
+        const int item = t + it * 512, ml = item >> 5, q = item & 31;
+        const int m = m0 + ml, n = n0 + 4 * q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {  // fixed order; tile e, column q = pixel 4 q + e
+            const float* rr = red + (w * 32 + ml) * LDT + q;
+            v.x += rr[0], v.y += rr[32], v.z += rr[64], v.w += rr[96];
+        }
+        if (m < p.M && n < p.N) {
+            const int img = n / HW, pp = n - img * HW;
+            const int64_t addr = ((int64_t)img * p.Ctot + m) * HW + pp;
+            const int me = p.grp_imgs > 0 ? (img / p.grp_imgs) * p.M + m : m;
+            if (p.scale) {
+                const float sc = p.scale[me], sh = p.shift[me];
+                v.x = fmaf(v.x, sc, sh), v.y = fmaf(v.y, sc, sh), v.z = fmaf(v.z, sc, sh), v.w = fmaf(v.w, sc, sh);
+            } else if (p.shift) {
+                const float sh = p.shift[me];
+                v.x += sh, v.y += sh, v.z += sh, v.w += sh;
+            }
+            if (p.residual) {
+                const float4 rr = *reinterpret_cast<const float4*>(p.residual + addr);
+                v.x += rr.x, v.y += rr.y, v.z += rr.z, v.w += rr.w;
+            }
+            if (p.accumulate) {
+                const float4 rr = *reinterpret_cast<const float4*>(p.D + addr);
+                v.x += rr.x, v.y += rr.y, v.z += rr.z, v.w += rr.w;
+            }
+            if (p.relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+            *reinterpret_cast<float4*>(p.D + addr) = v;
+        }
+    }
+}
+
+// Eligibility of the deep-K 1x1 kernel.  mode: 0 = heuristic, 1 = insist
+int bf3_1x1_ks_launch(ivln_gemm_desc& d, hipStream_t s, int mode) {
+    if (d.stride != 1 || d.pad != 0 || d.Cin % CB != 0 || d.Cin < (mode ? 8 : 32) * CB || d.stat_partials || d.splits > 1) return IVLN_E_UNSUPPORTED;
+    if ((d.HoWo & 3) || (d.in_img_stride & 3) || ((((uintptr_t)d.B) | ((uintptr_t)d.D) | ((uintptr_t)d.residual)) & 15)) return IVLN_E_UNSUPPORTED;
+    const int64_t nimg = d.N / d.HoWo;
+    if (nimg * d.in_img_stride * 4 >= (int64_t)1 << 31) return IVLN_E_UNSUPPORTED;
+    if (d.grp_imgs > 0 && ((int64_t)d.grp_imgs * d.HoWo) % 128 != 0) return IVLN_E_UNSUPPORTED;  // a tile's pixels share one weight set
+    const int64_t wgs = (int64_t)((d.N + 127) / 128) * ((d.M + 31) / 32);
+    if (mode == 0 && (wgs > 4 * (int64_t)ivln_cu_count() || wgs < ivln_cu_count() / 4)) return IVLN_E_UNSUPPORTED;
+    constexpr size_t lds = (size_t)8 * 32 * (128 + 4) * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)k_conv1x1_bf3_ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return IVLN_E_HIP;
+        attr_done = true;
+    }
+    d.splits = 1;
+    dim3 grid((unsigned)((d.N + 127) / 128), (unsigned)((d.M + 31) / 32), 1);
+    IVLN_LAUNCH_FAMILY(k_conv1x1_bf3_ks, grid, dim3(512), lds, s, d, (const unsigned char*)d.A_split, (long long)(d.a_split_grp_stride * 4));
+    return IVLN_OK;
 }
 
 // OIHW fp32 weights -> [32-channel tile][16-channel chunk][tap, padded][piece][lane] x 8 bf16: lane (l31, half) of tile mt
@@ -1068,6 +1234,19 @@ int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
     if (!d.A_split || (disabled && !force)) return IVLN_E_UNSUPPORTED;
     const int KS = d.bmode == BMODE_CONV1X1 ? 1 : conv_ks(d.bmode);
     if ((KS != 1 && KS != 3 && KS != 7) || d.amode != AMODE_MK || d.dmode != DMODE_NCHW || d.dil != 1) return IVLN_E_UNSUPPORTED;
+    // deep-K 1x1 convs: K split over the waves of a workgroup, fragments built in registers (k_conv1x1_bf3_ks);
+    // IVLN_BF3_1X1_KS=0 | 1 = never | wherever eligible, tile_override 11 insists
+    static const int ks1_env = getenv("IVLN_BF3_1X1_KS") ? atoi(getenv("IVLN_BF3_1X1_KS")) : -1;
+    if (KS == 1 && (ks1_env != 0 || d.tile_override == 11) && d.splits <= 1 && !d.defer_epilogue && d.HoWo == d.Hout * d.Wout &&
+        d.K == d.Cin && d.N % d.HoWo == 0 && d.Hout == d.Hin && d.Wout == d.Win) {
+        const int rc = bf3_1x1_ks_launch(d, s, (ks1_env == 1 || d.tile_override == 11) ? 1 : 0);
+        if (rc != IVLN_E_UNSUPPORTED || d.tile_override == 11) {
+            if (rc == IVLN_OK) g_bf3_flops += 2.0 * d.M * (double)d.N * d.K, ++g_bf3_launches;
+            if (rc == IVLN_OK && d.stat_tiles) *d.stat_tiles = 0;
+            return rc;
+        }
+    }
+    if (d.tile_override == 11 || (d.tile_override == 10 && KS != 3)) return IVLN_E_UNSUPPORTED;
     if (KS == 1) {  // 1x1, stride 1 or 2, no padding
         if ((d.stride != 1 && d.stride != 2) || d.pad != 0 || d.Hout != (d.Hin - 1) / d.stride + 1 || d.Wout != (d.Win - 1) / d.stride + 1 || d.M < 64)
             return IVLN_E_UNSUPPORTED;

@@ -505,7 +505,7 @@ extern "C" int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream) {
         if (d.tile_override == 0) d.tile_override = ivln_gemm_vec_eligible(d) ? 7 : 1;
     }
     // stride-1 3x3 / 7x7 with split-bf16 weights on hand: the bf16-MFMA direct conv (conv_bf3.hip); 9 insists on it
-    if ((d.tile_override == 0 || d.tile_override == 9 || d.tile_override == 10) && d.A_split) {
+    if ((d.tile_override == 0 || d.tile_override >= 9) && d.A_split) {
         const int splits_asked = d.splits;
         float* const stats_asked = d.stat_partials;
         const int rc = ivln_conv_bf3_launch(d, s, d.tile_override >= 9);

@@ -345,6 +345,7 @@ SPLIT_BF16 = os.environ.get("IVLN_SPLIT_BF16", "1") != "0"
 # the 7x7 weight gradients on the same arithmetic (k_wgrad_bf3; 1.1-1.7x the fp32 MFMA weight-gradient kernel at the update's shapes)
 SPLIT_BF16_WGRAD = os.environ.get("IVLN_SPLIT_BF16_WGRAD", "1") != "0"
 SPLIT_BF16_1X1 = int(os.environ.get("IVLN_SPLIT_BF16_1X1", "-1"))  # -1: by measured rule (ops.conv2d), 0 never, 1 always
+BF3_1X1_KS = os.environ.get("IVLN_BF3_1X1_KS", "1") != "0"  # A/B: 0 = deep-K 1x1 convs stay on the fp32 GEMM kernels
 SPLIT_BF16_MIN_OUT = int(os.environ.get("IVLN_SPLIT_BF16_MIN_OUT", str(1 << 18)))  # output elements below which nothing is packed
 _stat_ws = {}
 CONV_STATS = os.environ.get("IVLN_CONV_STATS", "1") != "0"  # A/B: BatchNorm statistics from the conv's epilogue
@@ -401,8 +402,12 @@ def conv2d(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, 
         # and the >= 4 GFLOP launches (53 vs 76, 50 vs 66, 42 vs 56, 46 vs 53 us) and ties or loses on the 2 GFLOP ones
         # (36-39 vs 32-37): on for the former only (IVLN_SPLIT_BF16_1X1=0 / 1 = never / always, tile_override 9 in tests)
         big_1x1 = stride == 2 or 2.0 * Cout * Cin * N * Ho * Wo >= 4e9
-        want_1x1 = TILE_OVERRIDE == 9 or SPLIT_BF16_1X1 == 1 or (SPLIT_BF16_1X1 != 0 and big_1x1)
-        if (want_1x1 and SPLIT_BF16 and stride in (1, 2) and Cin >= 128 and Cout >= 64 and Wo % 4 == 0 and Wo >= 8 and w.is_contiguous()
+        # (round 5) deep-K 1x1 convs (Cin >= 512, stride 1): the K-split-over-waves kernel builds its fragments in registers
+        # (k_conv1x1_bf3_ks; the C side decides by grid size)
+        deep_1x1 = stride == 1 and Cin >= 512 and Cin % 16 == 0 and (Ho * Wo) % 4 == 0 and BF3_1X1_KS
+        want_1x1 = TILE_OVERRIDE >= 9 or SPLIT_BF16_1X1 == 1 or (SPLIT_BF16_1X1 != 0 and (big_1x1 or deep_1x1))
+        if (want_1x1 and SPLIT_BF16 and stride in (1, 2) and Cin >= 128 and (Cout >= 64 or deep_1x1 or TILE_OVERRIDE == 11) and Wo % 4 == 0
+                and (Wo >= 8 or deep_1x1 or TILE_OVERRIDE == 11) and w.is_contiguous()
                 and not defer and (N * Ho * Wo * Cout >= SPLIT_BF16_MIN_OUT or TILE_OVERRIDE >= 9)):
             sp = packed_conv_weights(w, cache=not weight_is_temp, split=True)
             if sp is not None:

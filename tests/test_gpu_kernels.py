@@ -444,6 +444,55 @@ def test_conv2d_split_bf16_k_split_over_waves(N, Cin, H, Cout, G):
         assert float(wide[:, :4].abs().max()) == 0.0 and float(wide[:, 4 + Cout:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("N,Cin,H,Cout,G", [(8, 1024, 16, 256, 0), (16, 2048, 8, 512, 2), (3, 528, 8, 40, 0), (5, 512, 4, 96, 0),
+                                           (2, 512, 32, 128, 0)])
+def test_conv1x1_split_bf16_deep_k_split_over_waves(N, Cin, H, Cout, G):
+    """k_conv1x1_bf3_ks (tile_override 11): RedNet's deep-K 1x1 convs (bottleneck reductions 1024 -> 256 / 2048 -> 512, skip
+    convs: rednet.py:20-65, 244-248) with K split over the eight waves of a workgroup and the B fragments built in registers
+    (no LDS in the K loop).  Error bar of the other split-bf16 kernels against float64, every epilogue form, image-grouped
+    weights, chunk counts that leave waves idle (528 = 33 chunks), a ragged channel tile, pixel counts that are not a
+    multiple of the 128-pixel tile (3 x 64, 5 x 16), run-to-run identical bits."""
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(N * 10 + Cin + H)
+    x = torch.randn(N, Cin, H, H, generator=g)
+    wshape = (G, Cout, Cin, 1, 1) if G else (Cout, Cin, 1, 1)
+    w = torch.randn(*wshape, generator=g) / Cin ** 0.5
+    sc, sh = torch.rand(max(G, 1) * Cout, generator=g) + 0.5, torch.randn(max(G, 1) * Cout, generator=g)
+    if G:
+        B = N // G
+        ref0 = torch.cat([F.conv2d(x[i * B:(i + 1) * B].double(), w[i].double()) for i in range(G)])
+        scv = torch.cat([sc[i * Cout:(i + 1) * Cout].view(1, -1, 1, 1).expand(B, -1, 1, 1) for i in range(G)]).double()
+        shv = torch.cat([sh[i * Cout:(i + 1) * Cout].view(1, -1, 1, 1).expand(B, -1, 1, 1) for i in range(G)]).double()
+    else:
+        ref0 = F.conv2d(x.double(), w.double())
+        scv, shv = sc.double().view(1, -1, 1, 1), sh.double().view(1, -1, 1, 1)
+    res = torch.randn(ref0.shape, generator=g)
+    ref = F.relu(ref0 * scv + shv + res.double())
+    xd, wd = x.to(DEV), w.to(DEV)
+    try:
+        ops.TILE_OVERRIDE = 11
+        got = ops.conv2d(xd, wd, scale=sc.to(DEV), shift=sh.to(DEV), residual=res.to(DEV), relu=True)
+        if not G:
+            plain = ops.conv2d(xd, wd, splitk=False)
+            again = ops.conv2d(xd, wd)
+            wide = torch.zeros(N, Cout + 8, H, H, device=DEV)
+            ops.conv2d(xd, wd, out=wide[:, 4:], out_ctot=Cout + 8)
+            ops.TILE_OVERRIDE = 7
+            fp32 = ops.conv2d(xd, wd, splitk=False)
+    finally:
+        ops.TILE_OVERRIDE = 0
+    _close(got, ref.float(), 3e-5)
+    if not G:
+        scale = float(ref0.abs().max())
+        e_split = float((plain.double().cpu() - ref0).abs().max()) / scale
+        e_fp32 = float((fp32.double().cpu() - ref0).abs().max()) / scale
+        assert e_split <= 3e-6 and e_split <= 2.0 * e_fp32 + 1e-6, (e_split, e_fp32)
+        assert torch.equal(plain, again)
+        assert torch.equal(wide[:, 4:4 + Cout], plain)
+        assert float(wide[:, :4].abs().max()) == 0.0 and float(wide[:, 4 + Cout:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("case", ["offset_input_zero_sum_filters", "wide_dynamic_range", "tiny_values"])
 def test_conv2d_split_bf16_accuracy_where_fp32_struggles(case):
     """Inputs that expose a lossy product: (1) activations 1000 + N(0, 1) against zero-sum filters - the exact result is O(1)
