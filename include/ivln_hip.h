@@ -737,6 +737,13 @@ int ivln_pm_masked_mean_bwd_f32(const float* gout, const float* hat, const float
 int ivln_adam_step_f32(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                        const int* seg_of, const float* seg_lr, float beta1, float beta2, float eps, int step,
                        float grad_scale, int zero_grad, void* stream);
+/* The same with a device-side guard: *guard != 0 (e.g. word 48 of a sequence-GRU sync workspace: a bounded spin of this
+ * update's persistent launch timed out, its gradients are void) makes the launch do NOTHING - parameters, moments and
+ * gradients keep their values - so that the host can run the update again after it has seen the error at its next
+ * synchronisation.  guard NULL = ivln_adam_step_f32. */
+int ivln_adam_step_guarded_f32(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                               const int* seg_of, const float* seg_lr, float beta1, float beta2, float eps, int step,
+                               float grad_scale, int zero_grad, const void* guard, void* stream);
 
 /* Host-side (CPU) windowed DTW, step pattern symmetric1 (dtw-python 1.3.0 semantics; call site
  * habitat_extensions/tour_ndtw.py:118-124).  a (n,dim), b (m,dim) HOST doubles; window (n,m) u8 or NULL. */

@@ -685,8 +685,12 @@ int bf3_ks_launch(ivln_gemm_desc& d, hipStream_t s, int nimg, int mode) {
 // An activation element is split once per 32-channel tile that reads it (176 VALU operations per lane and chunk beside 24
 // MFMAs): the VALU work rides under the other wave's MFMAs.
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 2) void k_conv1x1_bf3_ks(const ivln_gemm_desc p, const unsigned char* a_split, long long a_grp_bytes) {
-    constexpr int NW = 8, TN = 4, DA = 4, BN = 128;
+// WT (wave tiles, short K: 64 ... 256 input channels - the bottleneck expansions 64 -> 256 ... 256 -> 1024 with their residual):
+// no K split at all - each of the workgroup's 4 waves owns its own 32 x 128 tile over the whole K and finishes it alone
+// (wave-private LDS for the transposing epilogue, no barrier anywhere); these launches are bound by their activation bytes.
+template <bool WT>
+__global__ __launch_bounds__(WT ? 256 : 512, 2) void k_conv1x1_bf3_ks(const ivln_gemm_desc p, const unsigned char* a_split, long long a_grp_bytes) {
+    constexpr int NW = WT ? 4 : 8, TN = 4, DA = 4, BN = 128;
     constexpr int LDT = BN + 4;
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -694,12 +698,16 @@ __global__ __launch_bounds__(512, 2) void k_conv1x1_bf3_ks(const ivln_gemm_desc 
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     const BlockId bid = xcd_block_id(p.no_xcd_remap);
-    const int n0 = bid.x * BN, m0 = bid.y * 32;
+    // grid = (channel tiles, pixel tiles): consecutive workgroup ids - one XCD's contiguous range after the remap - share their
+    // PIXELS.  A 1x1 conv's activation tile (128 pixels x Cin x 4 bytes: 512 KB at 1024 channels) outweighs a channel tile's
+    // weights (196 KB), and with the pixel tile as the fast index every XCD fetched every activation: 8 x the input bytes
+    // over the fabric, which is what bounded the first version (256 x 4096 x 1024: 134 MB in 23 us).
+    const int n0 = WT ? (bid.y * NW + wave) * BN : bid.y * BN, m0 = bid.x * 32;
     const int nch = p.Cin / CB;
     const int HW = p.HoWo;
-    const int cpw = (nch + NW - 1) / NW;
-    const int c0 = min(nch, wave * cpw), c1 = min(nch, c0 + cpw);
-    const int n_img0 = n0 / HW;
+    const int cpw = WT ? nch : (nch + NW - 1) / NW;
+    const int c0 = WT ? 0 : min(nch, wave * cpw), c1 = WT ? nch : min(nch, c0 + cpw);
+    const int n_img0 = min(n0, p.N - 1) / HW;
     const int grp = p.grp_imgs > 0 ? n_img0 / p.grp_imgs : 0;
 
     const int nq = n0 + 4 * l31;  // this lane's four pixels (one image: HW is a multiple of 4)
@@ -725,7 +733,7 @@ __global__ __launch_bounds__(512, 2) void k_conv1x1_bf3_ks(const ivln_gemm_desc 
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[tn][i] = 0.f;
 
-    if (c0 < c1) {
+    if (c0 < c1 && (!WT || n0 < p.N)) {
         v4i xb[2][8], ab[DA][3];
 #pragma unroll
         for (int d = 0; d < DA; ++d) load_a(c0 + d, ab[d]);
@@ -769,23 +777,30 @@ __global__ __launch_bounds__(512, 2) void k_conv1x1_bf3_ks(const ivln_gemm_desc 
             }
         }
     }
-    // ---- the eight partial tiles meet in LDS: red[wave][32 channels][4 tiles x 32 columns (+4)] ----
+    // ---- partial tiles through LDS: red[wave][32 channels][4 tiles x 32 columns (+4)]; KS: the eight waves' tiles are summed
+    //      in a fixed order; WT: every wave transposes its own tile (wave-private region, LDS accesses of one wave are in order) ----
     float* const red = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             red[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * LDT + tn * 32 + l31] = acc[tn][r];
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {  // 32 channels x 32 pixel quads = 1024 items over 512 threads
-        const int item = t + it * 512, ml = item >> 5, q = item & 31;
+    if constexpr (!WT) __syncthreads();
+    constexpr int ITEMS = WT ? 16 : 2;  // 32 channels x 32 pixel quads = 1024 items: over a wave's 64 lanes | the workgroup's 512 threads
+#pragma unroll 2
+    for (int it = 0; it < ITEMS; ++it) {
+        const int item = WT ? lane + it * 64 : t + it * 512, ml = item >> 5, q = item & 31;
         const int m = m0 + ml, n = n0 + 4 * q;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (WT) {
+            const float* rr = red + (wave * 32 + ml) * LDT + q;
+            v = make_float4(rr[0], rr[32], rr[64], rr[96]);  // tile e, column q = pixel 4 q + e
+        } else {
 #pragma unroll
-        for (int w = 0; w < NW; ++w) {  // fixed order; tile e, column q = pixel 4 q + e
-            const float* rr = red + (w * 32 + ml) * LDT + q;
-            v.x += rr[0], v.y += rr[32], v.z += rr[64], v.w += rr[96];
+            for (int w = 0; w < NW; ++w) {  // fixed order
+                const float* rr = red + (w * 32 + ml) * LDT + q;
+                v.x += rr[0], v.y += rr[32], v.z += rr[64], v.w += rr[96];
+            }
         }
         if (m < p.M && n < p.N) {
             const int img = n / HW, pp = n - img * HW;
@@ -812,24 +827,52 @@ __global__ __launch_bounds__(512, 2) void k_conv1x1_bf3_ks(const ivln_gemm_desc 
     }
 }
 
-// Eligibility of the deep-K 1x1 kernel.  mode: 0 = heuristic, 1 = insist
+// Eligibility of the 1x1 kernels in their two forms.  mode: 0 = heuristic, 1 = insist
 int bf3_1x1_ks_launch(ivln_gemm_desc& d, hipStream_t s, int mode) {
-    if (d.stride != 1 || d.pad != 0 || d.Cin % CB != 0 || d.Cin < (mode ? 8 : 32) * CB || d.stat_partials || d.splits > 1) return IVLN_E_UNSUPPORTED;
+    if (d.stride != 1 || d.pad != 0 || d.Cin % CB != 0 || d.Cin < 4 * CB || d.stat_partials || d.splits > 1) return IVLN_E_UNSUPPORTED;
     if ((d.HoWo & 3) || (d.in_img_stride & 3) || ((((uintptr_t)d.B) | ((uintptr_t)d.D) | ((uintptr_t)d.residual)) & 15)) return IVLN_E_UNSUPPORTED;
     const int64_t nimg = d.N / d.HoWo;
     if (nimg * d.in_img_stride * 4 >= (int64_t)1 << 31) return IVLN_E_UNSUPPORTED;
     if (d.grp_imgs > 0 && ((int64_t)d.grp_imgs * d.HoWo) % 128 != 0) return IVLN_E_UNSUPPORTED;  // a tile's pixels share one weight set
-    const int64_t wgs = (int64_t)((d.N + 127) / 128) * ((d.M + 31) / 32);
-    if (mode == 0 && (wgs > 4 * (int64_t)ivln_cu_count() || wgs < ivln_cu_count() / 4)) return IVLN_E_UNSUPPORTED;
-    constexpr size_t lds = (size_t)8 * 32 * (128 + 4) * 4;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)k_conv1x1_bf3_ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return IVLN_E_HIP;
-        attr_done = true;
+    const int nch = d.Cin / CB;
+    // wave tiles (no K split) up to 16 chunks, K split over the 8 waves from 32 (in between - 272 ... 496 channels - the K-split
+    // form with short slices); IVLN_BF3_1X1_FORM = ks | wt pins one (tuning)
+    static const char* form_env = getenv("IVLN_BF3_1X1_FORM");
+    bool wt = nch <= 16;
+    if (form_env) wt = form_env[0] == 'w';
+    if (wt && nch > 64) wt = false;
+    const int64_t mtiles = (d.M + 31) / 32;
+    const int64_t wgs = wt ? (int64_t)((d.N + 511) / 512) * mtiles : (int64_t)((d.N + 127) / 128) * mtiles;
+    static const int maxwg_env = getenv("IVLN_BF3_1X1_MAXWG") ? atoi(getenv("IVLN_BF3_1X1_MAXWG")) : 2;  // tuning: rounds of one workgroup per CU
+    if ((d.N + 127) / 128 > 65535) return IVLN_E_UNSUPPORTED;
+    if (mode == 0) {
+        // (measured inside RedNet: wins at 128 ... 512 workgroups - 256 x 4096 x 1024 35.7 -> 28 us, 256 x 2048 x 1024 28.4 -> 21.6 -,
+        //  loses at 64 - 512 x 512 x 2048 - and at 1024 - 256 x 16384 x 512, four rounds of one workgroup per CU)
+        if (!wt && (d.Cin < 32 * CB || wgs > maxwg_env * (int64_t)ivln_cu_count() || wgs < ivln_cu_count() / 2)) return IVLN_E_UNSUPPORTED;
+        if (wt && wgs < ivln_cu_count()) return IVLN_E_UNSUPPORTED;  // (too few wave tiles to fill the chip: the tiled GEMMs split K)
     }
     d.splits = 1;
-    dim3 grid((unsigned)((d.N + 127) / 128), (unsigned)((d.M + 31) / 32), 1);
-    IVLN_LAUNCH_FAMILY(k_conv1x1_bf3_ks, grid, dim3(512), lds, s, d, (const unsigned char*)d.A_split, (long long)(d.a_split_grp_stride * 4));
+    const unsigned char* a = (const unsigned char*)d.A_split;
+    const long long gb = (long long)(d.a_split_grp_stride * 4);
+    if (wt) {
+        constexpr size_t lds = (size_t)4 * 32 * (128 + 4) * 4;
+        static bool attr_done = false;
+        if (!attr_done) {
+            if (hipFuncSetAttribute((const void*)k_conv1x1_bf3_ks<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return IVLN_E_HIP;
+            attr_done = true;
+        }
+        dim3 grid((unsigned)mtiles, (unsigned)((d.N + 511) / 512), 1);
+        IVLN_LAUNCH_FAMILY(k_conv1x1_bf3_ks<true>, grid, dim3(256), lds, s, d, a, gb);
+    } else {
+        constexpr size_t lds = (size_t)8 * 32 * (128 + 4) * 4;
+        static bool attr_done = false;
+        if (!attr_done) {
+            if (hipFuncSetAttribute((const void*)k_conv1x1_bf3_ks<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return IVLN_E_HIP;
+            attr_done = true;
+        }
+        dim3 grid((unsigned)mtiles, (unsigned)((d.N + 127) / 128), 1);
+        IVLN_LAUNCH_FAMILY(k_conv1x1_bf3_ks<false>, grid, dim3(512), lds, s, d, a, gb);
+    }
     return IVLN_OK;
 }
 

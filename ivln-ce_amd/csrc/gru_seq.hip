@@ -135,6 +135,7 @@ k_gru_seq_fwd(const float* __restrict__ gi, const float* __restrict__ h0, int64_
               float* __restrict__ save_ghn, unsigned* sync_ws) {
     extern __shared__ __attribute__((aligned(16))) float s_h[];   // N x 512: h_{t-1} * mask_t, then one flag word
     int* s_fail_p = reinterpret_cast<int*>(s_h + N * HH);         // (no static LDS: the dynamic base stays 16-B aligned)
+    if (sync_ws[49] != 0 && blockIdx.x == 1) return;  // test hook (word 49): this workgroup "is not resident" - the others' waits time out
     constexpr int NT = UPB * LPU, NWG = HH / UPB;
     const int tid = threadIdx.x, u = tid / LPU, l = tid % LPU;
     const int j = blockIdx.x * UPB + u;
@@ -305,6 +306,7 @@ k_gru_seq_bwd(const float* __restrict__ d_out, int64_t ld_dout, const float* __r
               float* __restrict__ hp, unsigned* sync_ws) {
     extern __shared__ __attribute__((aligned(16))) float s_g[];   // N x 1536: dgh_t, then one flag word
     int* s_fail_p = reinterpret_cast<int*>(s_g + N * 3 * HH);
+    if (sync_ws[49] != 0 && blockIdx.x == 1) return;  // test hook (word 49): this workgroup "is not resident" - the others' waits time out
     constexpr int K = 3 * HH, NT = UPB * LPU, NWG = HH / UPB;
     const int tid = threadIdx.x, u = tid / LPU, l = tid % LPU;
     const int j = blockIdx.x * UPB + u;
@@ -491,6 +493,7 @@ int ivln_gru_seq_stamps(void* host, int bytes) {
 
 /* Synchronises `stream` and reads the error word of a sync workspace: IVLN_OK, or IVLN_E_HIP when a spin of the
  * last persistent launch timed out (its outputs are then undefined). */
+/* (word 49 of a sync workspace: test hook, see the kernels; cleared by ivln_seq_sync_init like everything else) */
 int ivln_seq_sync_status(const void* sync_ws, void* stream) {
     unsigned err = 0;
     if (hipMemcpyAsync(&err, (const unsigned*)sync_ws + 48, sizeof(err), hipMemcpyDeviceToHost, (hipStream_t)stream) !=

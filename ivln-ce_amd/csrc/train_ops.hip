@@ -898,9 +898,13 @@ __global__ __launch_bounds__(256) void k_adam_flat(float* __restrict__ p, float*
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                    float lr, const int* __restrict__ seg_of, const float* seg_lr,
                                                    float b1, float b2, float eps, float bc1, float bc2,
-                                                   float grad_scale, int zero_grad) {
+                                                   float grad_scale, int zero_grad, const unsigned* __restrict__ guard) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    // `guard`: a device word that is non-zero when the gradients in `g` are void (the persistent sequence GRU of this update
+    // timed out: ivln_seq_sync_status' sticky word).  The step is then skipped ON THE DEVICE - parameters, moments and
+    // gradients stay as they are - and the host, which learns of it after its next synchronisation, runs the update again.
+    if (guard && *guard != 0u) return;
     float gi = g[i] * grad_scale;
     float mi = b1 * m[i] + (1.f - b1) * gi;
     float vi = b2 * v[i] + (1.f - b2) * gi * gi;
@@ -1225,11 +1229,18 @@ int ivln_pm_masked_mean_bwd_f32(const float* gout, const float* hat, const float
 int ivln_adam_step_f32(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                        const int* seg_of, const float* seg_lr, float beta1, float beta2, float eps, int step,
                        float grad_scale, int zero_grad, void* stream) {
+    return ivln_adam_step_guarded_f32(params, grads, exp_avg, exp_avg_sq, n, lr, seg_of, seg_lr, beta1, beta2, eps, step, grad_scale,
+                                      zero_grad, nullptr, stream);
+}
+
+int ivln_adam_step_guarded_f32(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                               const int* seg_of, const float* seg_lr, float beta1, float beta2, float eps, int step,
+                               float grad_scale, int zero_grad, const void* guard, void* stream) {
     if (n <= 0 || step < 1) return IVLN_E_INVALID;
     float bc1 = 1.f - powf(beta1, (float)step);
     float bc2 = 1.f - powf(beta2, (float)step);
     hipLaunchKernelGGL(k_adam_flat, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
-                       exp_avg_sq, n, lr, seg_of, seg_lr, beta1, beta2, eps, bc1, bc2, grad_scale, zero_grad);
+                       exp_avg_sq, n, lr, seg_of, seg_lr, beta1, beta2, eps, bc1, bc2, grad_scale, zero_grad, (const unsigned*)guard);
     return LAUNCH_OK();
 }
 

@@ -402,9 +402,10 @@ def conv2d(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, 
         # and the >= 4 GFLOP launches (53 vs 76, 50 vs 66, 42 vs 56, 46 vs 53 us) and ties or loses on the 2 GFLOP ones
         # (36-39 vs 32-37): on for the former only (IVLN_SPLIT_BF16_1X1=0 / 1 = never / always, tile_override 9 in tests)
         big_1x1 = stride == 2 or 2.0 * Cout * Cin * N * Ho * Wo >= 4e9
-        # (round 5) deep-K 1x1 convs (Cin >= 512, stride 1): the K-split-over-waves kernel builds its fragments in registers
-        # (k_conv1x1_bf3_ks; the C side decides by grid size)
-        deep_1x1 = stride == 1 and Cin >= 512 and Cin % 16 == 0 and (Ho * Wo) % 4 == 0 and BF3_1X1_KS
+        # (round 5) stride-1 1x1 convs on k_conv1x1_bf3_ks, which builds its fragments in registers (no LDS in the K loop):
+        # K split over the waves of a workgroup from 512 input channels, a 32 x 128 tile per wave up to 256 (the C side decides
+        # by chunk count and grid size)
+        deep_1x1 = stride == 1 and Cin >= 64 and Cin % 16 == 0 and (Ho * Wo) % 4 == 0 and BF3_1X1_KS
         want_1x1 = TILE_OVERRIDE >= 9 or SPLIT_BF16_1X1 == 1 or (SPLIT_BF16_1X1 != 0 and (big_1x1 or deep_1x1))
         if (want_1x1 and SPLIT_BF16 and stride in (1, 2) and Cin >= 128 and (Cout >= 64 or deep_1x1 or TILE_OVERRIDE == 11) and Wo % 4 == 0
                 and (Wo >= 8 or deep_1x1 or TILE_OVERRIDE == 11) and w.is_contiguous()
@@ -1180,6 +1181,36 @@ def _seq_ws(device):
     return ws
 
 
+def seq_guard_word(device):
+    """The sticky error word (a one-element int32 view) of the CURRENT stream's sequence-GRU workspace, or None: what
+    FlatAdam hands the Adam kernel as its guard, so that an update whose persistent GRU timed out leaves the parameters
+    alone."""
+    ws = _seq_sync_ws.get((str(device), stream_ptr())) if SEQ_PERSISTENT else None
+    return None if ws is None else ws[48:49]
+
+
+def seq_failed():
+    """A persistent sequence launch timed out (reads each workspace's sticky word: a 4-byte copy per workspace - call
+    where the stream is idle anyway, e.g. right after the update's loss read-back)."""
+    return any(int(ws[48]) != 0 for ws in _seq_sync_ws.values())
+
+
+def seq_recover():
+    """After `seq_failed`: clear the workspaces and run the sequence GRUs as per-timestep launches for the rest of the run."""
+    global SEQ_PERSISTENT
+    import logging
+
+    L = _L()
+    L.ivln_seq_sync_init.argtypes = [vp, vp]
+    for ws in _seq_sync_ws.values():
+        check(L.ivln_seq_sync_init(dptr(ws), stream_ptr()), "ivln_seq_sync_init")
+    torch.cuda.synchronize()
+    SEQ_PERSISTENT = False
+    logging.getLogger("ivln_ce_amd").warning(
+        "persistent sequence GRU: a bounded spin timed out (its workgroups were not all resident); the update is computed again "
+        "with per-timestep launches, which stay on for the rest of the run")
+
+
 def check_seq_sync():
     """Raise if a bounded spin of a persistent sequence launch timed out (synchronises the stream: call where the
     host waits anyway, e.g. after reading the loss).  A timed-out launch ends on its own; its outputs are garbage."""
@@ -1717,11 +1748,14 @@ def pm_loss_bwd(dL, hat, progress):
 
 
 def adam_step(params, grads, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, seg_of=None,
-              seg_lr=None, grad_scale=1.0, zero_grad=True):
+              seg_lr=None, grad_scale=1.0, zero_grad=True, guard=None):
+    """guard: a one-word device tensor; non-zero at execution time = the step is skipped on the device (seq_guard_word)."""
+    T = _T()
+    T.ivln_adam_step_guarded_f32.argtypes = [vp, vp, vp, vp, i64, f32, vp, vp, f32, f32, f32, i32, f32, i32, vp, vp]
     check(
-        _T().ivln_adam_step_f32(dptr(params), dptr(grads), dptr(exp_avg), dptr(exp_avg_sq), params.numel(), lr,
-                                _p(seg_of), _p(seg_lr), beta1, beta2, eps, step, grad_scale, int(bool(zero_grad)),
-                                stream_ptr()),
+        T.ivln_adam_step_guarded_f32(dptr(params), dptr(grads), dptr(exp_avg), dptr(exp_avg_sq), params.numel(), lr,
+                                     _p(seg_of), _p(seg_lr), beta1, beta2, eps, step, grad_scale, int(bool(zero_grad)),
+                                     _p(guard), stream_ptr()),
         "ivln_adam_step_f32",
     )
 

@@ -189,6 +189,18 @@ def instruction_backward(ie, st, d_txt, rows, L, G):
         G[ie.embedding_layer.weight] = g
 
 
+_ZEROS = {}
+
+
+def _zeros_like_cached(p):
+    """A shared, never-written zero tensor of p's shape (exact-zero gradients: one fill per process instead of per update)."""
+    key = (tuple(p.shape), str(p.device))
+    z = _ZEROS.get(key)
+    if z is None:
+        z = _ZEROS[key] = torch.zeros_like(p)
+    return z
+
+
 _CS = None  # the running backward pass's queue of deferred column sums (bias gradients), see ops.ColsumQueue
 
 
@@ -323,7 +335,7 @@ def _net_backward(net, S: Dict, d_feats: torch.Tensor) -> Dict:
                 # train-mode BatchNorm: sum_{n,h,w} dy = gamma*rstd*(S1 - S1 - S2*sum(xhat)/M) and sum(xhat) = 0,
                 # so the gradient of a conv bias feeding it is identically zero (autograd in the reference
                 # returns ~1e-9 rounding noise there); no pass over the 270 MB dy tensor
-                G[conv.bias] = torch.zeros_like(conv.bias)
+                G[conv.bias] = _zeros_like_cached(conv.bias)
             else:
                 G[conv.bias] = ops.nchw_chansum(dy)
             if i > 0:

@@ -75,7 +75,7 @@ class FlatAdam:
             self.seg_of = seg.to(dev)
             self.seg_lr = torch.tensor([lr, sem_lr], dtype=torch.float32, device=dev)
 
-    def step(self, world: int = 1, allreduce: bool = True):
+    def step(self, world: int = 1, allreduce: bool = True, guard=None):
         """all-reduce (sum) the flat grads when world > 1, then Adam with the 1/world mean folded in;
         the same kernel zeroes the grads (optimizer.zero_grad()).  `allreduce=False`: the bucket already holds the sum
         over the `world` shards (one process that accumulated them - the reference form the data-parallel step is
@@ -87,11 +87,17 @@ class FlatAdam:
         ops.invalidate_step_caches()  # ... and the per-episode instruction encodings a replayed graph would keep serving
         if self.flat.is_cuda:
             ops.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.lr, self.step_count,
-                          self.betas[0], self.betas[1], self.eps, self.seg_of, self.seg_lr, 1.0 / world, True)
+                          self.betas[0], self.betas[1], self.eps, self.seg_of, self.seg_lr, 1.0 / world, True, guard=guard)
         else:  # CPU path exists only for the gloo multi-process tests of the bucket/all-reduce logic
             raise RuntimeError("FlatAdam.step needs the HIP library (no CPU fallback)")
 
     def zero_grad(self):
+        self.grad.zero_()
+
+    def undo_skipped_step(self):
+        """The last `step` was skipped on the device (its guard word was set: the gradients were void): take the step count
+        back and drop the void gradients, so that the update can be run again."""
+        self.step_count -= 1
         self.grad.zero_()
 
     # -- checkpoint format: torch.optim.Adam's own -----------------------------------------------------------------
@@ -259,11 +265,20 @@ def _update_agent(policy, optimizer, observations, prev_actions, not_done_masks,
         ops.seq_sync_poll()  # a timed-out persistent GRU raises here, at the latest one update late (sticky flag)
     else:
         torch.autograd.backward(roots, grads)
+        # single rank: the Adam kernel skips the step ON THE DEVICE when this update's persistent GRU timed out (void
+        # gradients); the host sees the sticky word after the loss read-back below and runs the update again on the
+        # per-timestep launches.  (Several ranks: a rank-local skip would split the replicas - the error is raised.)
+        guard = ops.seq_guard_word(dev) if (dev.type == "cuda" and world == 1 and step_grad) else None
         if step_grad:
-            optimizer.step(world)
+            optimizer.step(world, guard=guard)
         al = float(action_loss.item())
         ax = float(aux_loss.item()) if isinstance(aux_loss, torch.Tensor) else float(aux_loss)
         if dev.type == "cuda":
+            if guard is not None and int(guard) != 0:  # (one 4-byte read on a stream the loss read-back has just drained)
+                ops.seq_recover()
+                optimizer.undo_skipped_step()
+                return _update_agent(policy, optimizer, observations, prev_actions, not_done_masks, corrected_actions, weights,
+                                     hidden_size, step_grad, loss_accumulation_scalar, world, tour_not_done_masks, rnn_states)
             ops.check_seq_sync()  # the stream was just synchronised by .item(): a timed-out persistent GRU is an error
     if carry:
         return (al + ax) * scale, al, ax, rnn_out.detach()

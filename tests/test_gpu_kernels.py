@@ -445,7 +445,10 @@ def test_conv2d_split_bf16_k_split_over_waves(N, Cin, H, Cout, G):
 
 
 @pytest.mark.parametrize("N,Cin,H,Cout,G", [(8, 1024, 16, 256, 0), (16, 2048, 8, 512, 2), (3, 528, 8, 40, 0), (5, 512, 4, 96, 0),
-                                           (2, 512, 32, 128, 0)])
+                                           (2, 512, 32, 128, 0),
+                                           # wave tiles (no K split: 64 ... 256 input channels)
+                                           (4, 64, 64, 256, 0), (8, 128, 32, 512, 2), (4, 256, 16, 1024, 0), (3, 80, 8, 40, 0),
+                                           (2, 64, 16, 64, 0)])
 def test_conv1x1_split_bf16_deep_k_split_over_waves(N, Cin, H, Cout, G):
     """k_conv1x1_bf3_ks (tile_override 11): RedNet's deep-K 1x1 convs (bottleneck reductions 1024 -> 256 / 2048 -> 512, skip
     convs: rednet.py:20-65, 244-248) with K split over the eight waves of a workgroup and the B fragments built in registers
