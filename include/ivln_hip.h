@@ -218,6 +218,9 @@ int ivln_conv_split_weights_f32(const float* W, int M, int Cin, int KS, void* ou
 /* Tally of the convs ivln_gemm_f32 sent to the split-bf16 kernel since the last reset: algorithmic FLOPs (2 M N K) and
  * launches (host side, at enqueue; measurement aid of bench.py - a captured graph's replays are not counted). */
 int ivln_conv_split_counters(double* flops, long long* launches, int reset);
+/* ... by kernel form: out4 = launches of the tiled kernel, the 3x3 K-split-over-waves kernel, the 1x1 K-split-over-waves kernel and
+ * the 1x1 wave-tile kernel (csrc/conv_bf3.hip). */
+int ivln_conv_split_kinds(long long* out4, int reset);
 
 /* Duration sink of the MFMA family's launches (ivln_gemm_f32 - its split-K reduction excluded -, ivln_gn_conv_f32,
  * ivln_nconv_f32): between _begin and _end every such launch carries a start / stop event of its own

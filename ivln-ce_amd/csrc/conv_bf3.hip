@@ -1256,10 +1256,18 @@ extern "C" int ivln_conv_split_weights_f32(const float* W, int M, int Cin, int K
 // bench.py prices them against the bf16 peak / 6 instead of the fp32 MFMA peak.  Host-side tally, not thread-safe.
 static double g_bf3_flops = 0.0;
 static long long g_bf3_launches = 0;
+static long long g_bf3_kind[4] = {0, 0, 0, 0};  // launches by form: tiled | 3x3 K-split over waves | 1x1 K-split over waves | 1x1 wave tiles
 extern "C" int ivln_conv_split_counters(double* flops, long long* launches, int reset) {
     if (flops) *flops = g_bf3_flops;
     if (launches) *launches = g_bf3_launches;
     if (reset) g_bf3_flops = 0.0, g_bf3_launches = 0;
+    return IVLN_OK;
+}
+/* launches of the split-bf16 conv kernels by form since the last reset: [0] tiled (k_conv_bf3), [1] 3x3 with K split over the
+ * waves (k_conv_bf3_ks), [2] 1x1 with K split over the waves, [3] 1x1 wave tiles (k_conv1x1_bf3_ks) */
+extern "C" int ivln_conv_split_kinds(long long* out4, int reset) {
+    if (out4) for (int i = 0; i < 4; ++i) out4[i] = g_bf3_kind[i];
+    if (reset) for (int i = 0; i < 4; ++i) g_bf3_kind[i] = 0;
     return IVLN_OK;
 }
 
@@ -1284,7 +1292,7 @@ int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
         d.K == d.Cin && d.N % d.HoWo == 0 && d.Hout == d.Hin && d.Wout == d.Win) {
         const int rc = bf3_1x1_ks_launch(d, s, (ks1_env == 1 || d.tile_override == 11) ? 1 : 0);
         if (rc != IVLN_E_UNSUPPORTED || d.tile_override == 11) {
-            if (rc == IVLN_OK) g_bf3_flops += 2.0 * d.M * (double)d.N * d.K, ++g_bf3_launches;
+            if (rc == IVLN_OK) g_bf3_flops += 2.0 * d.M * (double)d.N * d.K, ++g_bf3_launches, ++g_bf3_kind[d.Cin / CB <= 16 ? 3 : 2];
             if (rc == IVLN_OK && d.stat_tiles) *d.stat_tiles = 0;
             return rc;
         }
@@ -1306,7 +1314,7 @@ int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
     if (KS == 3 && (ks_env != 0 || d.tile_override == 10) && d.splits <= 1) {
         const int rc = bf3_ks_launch(d, s, nimg, (ks_env == 1 || d.tile_override == 10) ? 1 : 0);
         if (rc != IVLN_E_UNSUPPORTED || d.tile_override == 10) {
-            if (rc == IVLN_OK) g_bf3_flops += 2.0 * d.M * (double)d.N * d.K, ++g_bf3_launches;
+            if (rc == IVLN_OK) g_bf3_flops += 2.0 * d.M * (double)d.N * d.K, ++g_bf3_launches, ++g_bf3_kind[1];
             if (rc == IVLN_OK && d.stat_tiles) *d.stat_tiles = 0;
             return rc;
         }
@@ -1378,7 +1386,7 @@ int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
     const int rc = KS == 7   ? launch_bf3_ks<7>(d, s, (const unsigned char*)d.A_split, gb, nimg, cfg, cps)
                    : KS == 3 ? launch_bf3_ks<3>(d, s, (const unsigned char*)d.A_split, gb, nimg, cfg, cps)
                              : launch_bf3_ks<1>(d, s, (const unsigned char*)d.A_split, gb, nimg, cfg, cps);
-    if (rc == IVLN_OK) g_bf3_flops += 2.0 * d.M * (double)d.N * d.K, ++g_bf3_launches;
+    if (rc == IVLN_OK) g_bf3_flops += 2.0 * d.M * (double)d.N * d.K, ++g_bf3_launches, ++g_bf3_kind[0];
     if (rc == IVLN_OK && d.stat_tiles) *d.stat_tiles = d.stat_partials ? (int)(tiles * (BN / 128)) : 0;
     return rc;
 }

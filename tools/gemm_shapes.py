@@ -57,6 +57,16 @@ for key, a, b in records:
     e[1] += a.elapsed_time(b) * 1e3
 tot = sum(e[1] for e in agg.values())
 print(f"{len(records)} GEMM-family calls, {tot / 1e3:.2f} ms (event pairs)")
+try:
+    import ctypes as _C
+
+    from ivln_ce_amd._lib import lib as _lib
+
+    _k = (_C.c_longlong * 4)()
+    _lib().ivln_conv_split_kinds(_k, 0)
+    print("split-bf16 launches since start (tiled, 3x3 K-split, 1x1 K-split, 1x1 wave tiles):", list(_k))
+except Exception as e:  # noqa: BLE001
+    print("kinds:", e)
 print(f"{'M':>6} {'N':>8} {'K':>7} am bm dm df s taps  calls   us/call   total us   TFLOP/s")
 for key, (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
     M, N, K, am, bm, dm, df, st, taps = key

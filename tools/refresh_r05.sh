@@ -51,20 +51,12 @@ for c in FETCH_SIZE WRITE_SIZE; do
   run r_$n --kernel-trace --pmc $c -d $O/r_$n -- python3 bench.py --steps 20 --warmup 5 --reps 1 $GT --no-graph;    pmc r_$n rollout_pmc_$n.csv
   run u_$n --kernel-trace --pmc $c -d $O/u_$n -- python3 bench.py --only-update --steps 5;                          pmc u_$n update_pmc_$n.csv
 done
-# the launch chain the persistent depth encoder replaces, for the traffic A/B (IVLN_DEPTH_NET=0 is read by the library's python side)
-export IVLN_DEPTH_NET=0
-for c in FETCH_SIZE WRITE_SIZE; do
-  n=$(echo $c | tr A-Z a-z)
-  run c_$n --kernel-trace --pmc $c -d $O/c_$n -- python3 bench.py --steps 20 --warmup 5 --reps 1 $GT --no-graph;    pmc c_$n rollout_chain_pmc_$n.csv
-done
-unset IVLN_DEPTH_NET
 run pmfma --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -d $O/p_mfma -- python3 bench.py --steps 10 --warmup 2 --reps 1 $PRED --no-graph; pmc p_mfma predsem_B8_pmc_mfma_util.csv
 run rmfma --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -d $O/r_mfma -- python3 bench.py --steps 20 --warmup 5 --reps 1 $GT --no-graph;  pmc r_mfma rollout_pmc_mfma_util.csv
 run umfma --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -d $O/u_mfma -- python3 bench.py --only-update --steps 5;                         pmc u_mfma update_pmc_mfma_util.csv
 find $O -name "*.db" -delete
 # steps traced per pass: gt = warm-up 5 + timed 20 + instrumented roofline passes 20 + 20 (mapper) = 65; pred = 2 + 10 + 6 = 18; update = 2 + 5 + 1 = 8
 python tools/pmc_traffic.py $O/rollout_pmc_fetch_size.csv $O/rollout_pmc_write_size.csv 65 $O/rollout_pmc_traffic.json "--gt-semantics --envs 4 --steps 20 --warmup 5 --reps 1 (depth encoder = the persistent launch, eager)" 45
-python tools/pmc_traffic.py $O/rollout_chain_pmc_fetch_size.csv $O/rollout_chain_pmc_write_size.csv 65 $O/rollout_chain_pmc_traffic.json "IVLN_DEPTH_NET=0 --gt-semantics --envs 4 --steps 20 --warmup 5 --reps 1 (depth encoder = the k_nconv / k_gn_conv launch chain)" 45
 python tools/pmc_traffic.py $O/predsem_B8_pmc_fetch_size.csv $O/predsem_B8_pmc_write_size.csv 18 $O/predsem_B8_pmc_traffic.json "--pred-envs 8 --steps 10 --warmup 2 --reps 1"
 python tools/pmc_traffic.py $O/update_pmc_fetch_size.csv $O/update_pmc_write_size.csv 8 $O/update_pmc_traffic.json "--only-update --steps 5 (8 updates traced; per-step keys read per UPDATE)"
 ls -la $O | grep -v "^d"
