@@ -91,7 +91,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t bf3_rsrc(const void* p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
 }
 
-template <int KS, int TM, int WM, int WN, int PTH, int PTW, int IMGS, int DA>
+template <int KS, int TM, int WM, int WN, int PTH, int PTW, int IMGS, int DA, bool DBUF = false>
 __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_desc p, const unsigned char* a_split, long long a_grp_bytes,
                                                            int tiles_w, int tiles_h, int nimg, int chunks_per_split) {
     constexpr int NTB = 64 * WM * WN, TN = 2;
@@ -104,6 +104,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
     constexpr int ITEMS = NPIX * (CB / 2) * CS;
     constexpr int LDT = BN + 4;
     constexpr bool HAS_LITE = KS == 7 && TM == 1;  // (a second copy of the unrolled tap loop: only where one-hot inputs occur)
+    // DBUF (3x3, round 5): TWO patch buffers.  The next chunk is split and written into the other buffer IN SLICES inside this
+    // chunk's tap loop - VALU and LDS-write work in the shadow of the MFMAs - instead of in a phase of its own between two
+    // barriers (11 % of a 64-channel conv's time, profiles/r05_conv_bf3_phases.txt); one barrier per chunk.
+    constexpr int BUFB = (IMGS * (PTH + KS - 1) * (PTW + KS - 1) * PIXB + 15) & ~15;
+    constexpr bool DB = DBUF && KS == 3 && 2 * BUFB <= 160 * 1024;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int t = threadIdx.x, lane = t & 63;
@@ -281,6 +286,84 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
 #ifdef BF3_TIMING
     const unsigned long long cyc0 = clock64();
 #endif
+    if constexpr (DB) {
+        constexpr int UNITS = NI3 * 4;            // (pixel of a group) x (this thread's channel pair): one split + three 4-byte writes each
+        constexpr int S = TM == 2 ? 4 : 2;        // taps that carry a staging slice
+        constexpr int UPT = (UNITS + S - 1) / S;  // units per tap
+        auto stage_slice = [&](int u0, int u1, int dst_off) {
+#pragma unroll
+            for (int j = 0; j < NI3; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int u = j * 4 + e;
+                    if (u >= u0 && u < u1) {  // (constant after the tap loop is unrolled)
+                        uint32_t H, M, L;
+                        split3_pair(__int_as_float(rv[j][0][e]), __int_as_float(rv[j][1][e]), H, M, L);
+                        if ((imask[j] >> e) & 1) {
+                            unsigned char* d = smem + dst_off + idst[j] + e * PIXB;
+                            *reinterpret_cast<uint32_t*>(d) = H;
+                            *reinterpret_cast<uint32_t*>(d + 32) = M;
+                            *reinterpret_cast<uint32_t*>(d + 64) = L;
+                        }
+                    }
+                }
+        };
+        load_patch(c_beg);
+        stage_slice(0, UNITS, 0);
+        load_patch(min(c_beg + 1, c_end - 1));
+        __syncthreads();
+        for (int c = c_beg; c < c_end; ++c) {
+            const unsigned long long tb = BF3_T();
+            const int cur = (c - c_beg) & 1;
+            const unsigned char* const sm = smem + cur * BUFB;
+            const int oth = (cur ^ 1) * BUFB;
+            const int s0 = c * RP;
+            auto read_b = [&](int r, bf16x8 (&b)[TN][3]) {
+                const int kh = r / KS, kw = r - kh * KS, toff = (kh * PWR + kw) * PIXB;
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        b[tn][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const v4i*>(sm + bbase[tn] + toff + pl * 32));
+            };
+            bf16x8 bq[2][TN][3];
+            read_b(0, bq[0]);
+#pragma unroll
+            for (int r = 0; r < KK; ++r) {
+                const int slot = r % DA;
+                if (r + 1 < KK) read_b(r + 1, bq[(r + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                bf16x8 a[TM][3];
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) a[tm][pl] = __builtin_bit_cast(bf16x8, abuf[slot][tm][pl]);
+#define IVLN_BF3_PROD(PA, PB)                                                                                       \
+    _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) _Pragma("unroll") for (int tn = 0; tn < TN; ++tn)              \
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][PA], bq[r & 1][tn][PB], acc[tm][tn], 0, 0, 0)
+                IVLN_BF3_PROD(0, 2);
+                IVLN_BF3_PROD(1, 1);
+                IVLN_BF3_PROD(2, 0);
+                // (the slice sits between the MFMAs: its VALU / LDS-write instructions issue while the matrix pipe works)
+                if (r < S) stage_slice(r * UPT, (r + 1) * UPT < UNITS ? (r + 1) * UPT : UNITS, oth);
+                IVLN_BF3_PROD(0, 1);
+                IVLN_BF3_PROD(1, 0);
+                IVLN_BF3_PROD(0, 0);
+#undef IVLN_BF3_PROD
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) abuf[slot][tm][pl] = load_a(tm, s0 + r + DA, pl);
+                // the registers the slices above have emptied receive the patch of the chunk AFTER the next one: KK - S taps and
+                // a barrier of flight time before the first slice of the next chunk reads them
+                if (r == S) load_patch(min(c + 2, c_end - 1));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();  // everybody is done reading this buffer and writing the other one
+            t_mma += BF3_T() - tb;
+        }
+    } else {
     load_patch(c_beg);
     for (int c = c_beg; c < c_end; ++c) {
         const unsigned long long ta = BF3_T();
@@ -356,6 +439,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
         __syncthreads();
         t_mma += BF3_T() - tb;
     }
+    }  // (!DB)
     const unsigned long long tk1 = BF3_T();
     (void)tk1;
 
@@ -898,13 +982,19 @@ __global__ __launch_bounds__(256) void k_conv_bf3_pack(const float* __restrict__
     out[idx] = (uint16_t)(pl == 0 ? h : (pl == 1 ? mm : l));
 }
 
-template <int KS, int TM, int WM, int WN, int PTH, int PTW, int IMGS, int DA>
+template <int KS, int TM, int WM, int WN, int PTH, int PTW, int IMGS, int DA, bool DBUF = false>
 int launch_bf3(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a_split, int64_t grp_bytes, int nimg, int cps) {
     constexpr int NTB = 64 * WM * WN, BM = 32 * TM * WM, BN = 64 * WN;
     constexpr int PH = PTH + KS - 1, PWR = PTW + KS - 1, NPIX = IMGS * PH * PWR * bf3_stage_chunks(KS);
-    constexpr size_t lds = (size_t)(NPIX * PIXB > 32 * (BN + 4) * 4 ? NPIX * PIXB : 32 * (BN + 4) * 4);
+    constexpr int BUFB = (NPIX * PIXB + 15) & ~15;
+    constexpr bool DB = DBUF && KS == 3 && 2 * BUFB <= 160 * 1024;
+    if constexpr (DBUF && !DB) {  // (two buffers do not fit: the single-buffer instantiation is the kernel)
+        return launch_bf3<KS, TM, WM, WN, PTH, PTW, IMGS, DA, false>(d, s, a_split, grp_bytes, nimg, cps);
+    } else {
+    constexpr size_t patch = DB ? 2 * (size_t)BUFB : (size_t)NPIX * PIXB;
+    constexpr size_t lds = patch > (size_t)32 * (BN + 4) * 4 ? patch : (size_t)32 * (BN + 4) * 4;
     static_assert(lds <= 160 * 1024, "patch does not fit");
-    auto kern = k_conv_bf3<KS, TM, WM, WN, PTH, PTW, IMGS, DA>;
+    auto kern = k_conv_bf3<KS, TM, WM, WN, PTH, PTW, IMGS, DA, DB>;
     static bool attr_done = false;  // (idempotent; a race only repeats the call)
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return IVLN_E_HIP;
@@ -915,6 +1005,7 @@ int launch_bf3(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a_sp
     dim3 grid(tiles_w * tiles_h * groups, (d.M + BM - 1) / BM, d.splits);
     IVLN_LAUNCH_FAMILY(kern, grid, dim3(NTB), lds, s, d, a_split, (long long)grp_bytes, tiles_w, tiles_h, nimg, cps);
     return IVLN_OK;
+    }
 }
 
 // pixel tile of a block for its pixel count BN and the output width: rows x columns x images
@@ -925,24 +1016,24 @@ inline Bf3Px bf3_px(int BN, int Wout) {
     return {pth, ptw, BN / (ptw * pth)};
 }
 
-template <int KS, int TM, int WM, int WN, int DA>
+template <int KS, int TM, int WM, int WN, int DA, bool DBUF = false>
 int launch_bf3_px(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a, int64_t gb, int nimg, int cps) {
     constexpr int BN = 64 * WN;
     if constexpr (BN == 512 && KS == 1) {
         return IVLN_E_UNSUPPORTED;  // (four staged chunks of 512 pixels do not fit the LDS)
     } else if constexpr (BN == 512) {
-        if (d.Wout > 16) return launch_bf3<KS, TM, WM, WN, 16, 32, 1, DA>(d, s, a, gb, nimg, cps);
-        if (d.Wout > 8) return launch_bf3<KS, TM, WM, WN, 16, 16, 2, DA>(d, s, a, gb, nimg, cps);
-        if constexpr (KS == 3) return launch_bf3<KS, TM, WM, WN, 8, 8, 8, DA>(d, s, a, gb, nimg, cps);
+        if (d.Wout > 16) return launch_bf3<KS, TM, WM, WN, 16, 32, 1, DA, DBUF>(d, s, a, gb, nimg, cps);
+        if (d.Wout > 8) return launch_bf3<KS, TM, WM, WN, 16, 16, 2, DA, DBUF>(d, s, a, gb, nimg, cps);
+        if constexpr (KS == 3) return launch_bf3<KS, TM, WM, WN, 8, 8, 8, DA, DBUF>(d, s, a, gb, nimg, cps);
         return IVLN_E_UNSUPPORTED;
     } else if constexpr (BN == 256) {
-        if (d.Wout > 16) return launch_bf3<KS, TM, WM, WN, 8, 32, 1, DA>(d, s, a, gb, nimg, cps);
-        if (d.Wout > 8) return launch_bf3<KS, TM, WM, WN, 16, 16, 1, DA>(d, s, a, gb, nimg, cps);
-        return launch_bf3<KS, TM, WM, WN, 8, 8, 4, DA>(d, s, a, gb, nimg, cps);
+        if (d.Wout > 16) return launch_bf3<KS, TM, WM, WN, 8, 32, 1, DA, DBUF>(d, s, a, gb, nimg, cps);
+        if (d.Wout > 8) return launch_bf3<KS, TM, WM, WN, 16, 16, 1, DA, DBUF>(d, s, a, gb, nimg, cps);
+        return launch_bf3<KS, TM, WM, WN, 8, 8, 4, DA, DBUF>(d, s, a, gb, nimg, cps);
     } else {
-        if (d.Wout > 16) return launch_bf3<KS, TM, WM, WN, 4, 32, 1, DA>(d, s, a, gb, nimg, cps);
-        if (d.Wout > 8) return launch_bf3<KS, TM, WM, WN, 8, 16, 1, DA>(d, s, a, gb, nimg, cps);
-        return launch_bf3<KS, TM, WM, WN, 8, 8, 2, DA>(d, s, a, gb, nimg, cps);
+        if (d.Wout > 16) return launch_bf3<KS, TM, WM, WN, 4, 32, 1, DA, DBUF>(d, s, a, gb, nimg, cps);
+        if (d.Wout > 8) return launch_bf3<KS, TM, WM, WN, 8, 16, 1, DA, DBUF>(d, s, a, gb, nimg, cps);
+        return launch_bf3<KS, TM, WM, WN, 8, 8, 2, DA, DBUF>(d, s, a, gb, nimg, cps);
     }
 }
 
@@ -951,22 +1042,21 @@ constexpr int kBf3Cfgs = 7;
 constexpr int kBf3BM[kBf3Cfgs] = {32, 64, 64, 128, 64, 128, 32};
 constexpr int kBf3BN[kBf3Cfgs] = {512, 512, 256, 256, 128, 128, 256};
 
-template <int KS>
+template <int KS, bool DBUF = false>
 int launch_bf3_ks(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a, int64_t gb, int nimg, int cfg, int cps) {
     // weight taps in flight: a tap is 24 MFMAs = 768 pipe cycles per wave (12 = 384 with one channel tile per wave), an L2 /
     // MALL round trip ~2000
     constexpr int DA2 = KS == 1 ? 2 : 3, DA1 = KS == 1 ? 4 : (KS == 7 ? 2 : 3);  // (6 / 9 taps ahead measured the same as 3 and cost 36-72 registers)
     switch (cfg) {
-        case 0: return launch_bf3_px<KS, 1, 1, 8, DA1>(d, s, a, gb, nimg, cps);   // 32 x 512, 8 waves
-        case 1: return launch_bf3_px<KS, 2, 1, 8, DA2>(d, s, a, gb, nimg, cps);   // 64 x 512
-        case 2: return launch_bf3_px<KS, 1, 2, 4, DA1>(d, s, a, gb, nimg, cps);   // 64 x 256
-        case 3: return launch_bf3_px<KS, 2, 2, 4, DA2>(d, s, a, gb, nimg, cps);   // 128 x 256
-        case 4: return launch_bf3_px<KS, 1, 2, 2, DA1>(d, s, a, gb, nimg, cps);   // 64 x 128, 4 waves: several workgroups per CU
-        case 5: return launch_bf3_px<KS, 2, 2, 2, DA2>(d, s, a, gb, nimg, cps);   // 128 x 128, 4 waves
-        default: return launch_bf3_px<KS, 1, 1, 4, DA1>(d, s, a, gb, nimg, cps);  // 32 x 256, 4 waves: two workgroups per CU
+        case 0: return launch_bf3_px<KS, 1, 1, 8, DA1, DBUF>(d, s, a, gb, nimg, cps);   // 32 x 512, 8 waves
+        case 1: return launch_bf3_px<KS, 2, 1, 8, DA2, DBUF>(d, s, a, gb, nimg, cps);   // 64 x 512
+        case 2: return launch_bf3_px<KS, 1, 2, 4, DA1, DBUF>(d, s, a, gb, nimg, cps);   // 64 x 256
+        case 3: return launch_bf3_px<KS, 2, 2, 4, DA2, DBUF>(d, s, a, gb, nimg, cps);   // 128 x 256
+        case 4: return launch_bf3_px<KS, 1, 2, 2, DA1, DBUF>(d, s, a, gb, nimg, cps);   // 64 x 128, 4 waves: several workgroups per CU
+        case 5: return launch_bf3_px<KS, 2, 2, 2, DA2, DBUF>(d, s, a, gb, nimg, cps);   // 128 x 128, 4 waves
+        default: return launch_bf3_px<KS, 1, 1, 4, DA1, DBUF>(d, s, a, gb, nimg, cps);  // 32 x 256, 4 waves: two workgroups per CU
     }
 }
-
 
 // ------------------------------------------------------------------------------------------------------------------
 // Weight gradient of a 7x7 same-size conv on the same arithmetic (map CNN, base_il_trainer.py:173-219):
@@ -1383,8 +1473,12 @@ int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
     const int64_t tiles = tiles_of(cfg);
     const int BN = kBf3BN[cfg];
     const int64_t gb = d.a_split_grp_stride * 4;
+    // 3x3: the double-buffered form with the staging interleaved into the tap loop (k_conv_bf3<..., DBUF>); IVLN_BF3_DBUF=0: the
+    // round-4 phases (A/B)
+    static const bool dbuf = !(getenv("IVLN_BF3_DBUF") && atoi(getenv("IVLN_BF3_DBUF")) == 0);
     const int rc = KS == 7   ? launch_bf3_ks<7>(d, s, (const unsigned char*)d.A_split, gb, nimg, cfg, cps)
-                   : KS == 3 ? launch_bf3_ks<3>(d, s, (const unsigned char*)d.A_split, gb, nimg, cfg, cps)
+                   : KS == 3 ? (dbuf ? launch_bf3_ks<3, true>(d, s, (const unsigned char*)d.A_split, gb, nimg, cfg, cps)
+                                     : launch_bf3_ks<3>(d, s, (const unsigned char*)d.A_split, gb, nimg, cfg, cps))
                              : launch_bf3_ks<1>(d, s, (const unsigned char*)d.A_split, gb, nimg, cfg, cps);
     if (rc == IVLN_OK) g_bf3_flops += 2.0 * d.M * (double)d.N * d.K, ++g_bf3_launches, ++g_bf3_kind[0];
     if (rc == IVLN_OK && d.stat_tiles) *d.stat_tiles = d.stat_partials ? (int)(tiles * (BN / 128)) : 0;
