@@ -91,7 +91,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t bf3_rsrc(const void* p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
 }
 
-template <int KS, int TM, int WM, int WN, int PTH, int PTW, int IMGS, int DA, bool DBUF = false>
+template <int KS, int TM, int WM, int WN, int PTH, int PTW, int IMGS, int DA>
 __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_desc p, const unsigned char* a_split, long long a_grp_bytes,
                                                            int tiles_w, int tiles_h, int nimg, int chunks_per_split) {
     constexpr int NTB = 64 * WM * WN, TN = 2;
@@ -104,11 +104,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
     constexpr int ITEMS = NPIX * (CB / 2) * CS;
     constexpr int LDT = BN + 4;
     constexpr bool HAS_LITE = KS == 7 && TM == 1;  // (a second copy of the unrolled tap loop: only where one-hot inputs occur)
-    // DBUF (3x3, round 5): TWO patch buffers.  The next chunk is split and written into the other buffer IN SLICES inside this
-    // chunk's tap loop - VALU and LDS-write work in the shadow of the MFMAs - instead of in a phase of its own between two
-    // barriers (11 % of a 64-channel conv's time, profiles/r05_conv_bf3_phases.txt); one barrier per chunk.
-    constexpr int BUFB = (IMGS * (PTH + KS - 1) * (PTW + KS - 1) * PIXB + 15) & ~15;
-    constexpr bool DB = DBUF && KS == 3 && 2 * BUFB <= 160 * 1024;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int t = threadIdx.x, lane = t & 63;
@@ -286,84 +281,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
 #ifdef BF3_TIMING
     const unsigned long long cyc0 = clock64();
 #endif
-    if constexpr (DB) {
-        constexpr int UNITS = NI3 * 4;            // (pixel of a group) x (this thread's channel pair): one split + three 4-byte writes each
-        constexpr int S = TM == 2 ? 4 : 2;        // taps that carry a staging slice
-        constexpr int UPT = (UNITS + S - 1) / S;  // units per tap
-        auto stage_slice = [&](int u0, int u1, int dst_off) {
-#pragma unroll
-            for (int j = 0; j < NI3; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int u = j * 4 + e;
-                    if (u >= u0 && u < u1) {  // (constant after the tap loop is unrolled)
-                        uint32_t H, M, L;
-                        split3_pair(__int_as_float(rv[j][0][e]), __int_as_float(rv[j][1][e]), H, M, L);
-                        if ((imask[j] >> e) & 1) {
-                            unsigned char* d = smem + dst_off + idst[j] + e * PIXB;
-                            *reinterpret_cast<uint32_t*>(d) = H;
-                            *reinterpret_cast<uint32_t*>(d + 32) = M;
-                            *reinterpret_cast<uint32_t*>(d + 64) = L;
-                        }
-                    }
-                }
-        };
-        load_patch(c_beg);
-        stage_slice(0, UNITS, 0);
-        load_patch(min(c_beg + 1, c_end - 1));
-        __syncthreads();
-        for (int c = c_beg; c < c_end; ++c) {
-            const unsigned long long tb = BF3_T();
-            const int cur = (c - c_beg) & 1;
-            const unsigned char* const sm = smem + cur * BUFB;
-            const int oth = (cur ^ 1) * BUFB;
-            const int s0 = c * RP;
-            auto read_b = [&](int r, bf16x8 (&b)[TN][3]) {
-                const int kh = r / KS, kw = r - kh * KS, toff = (kh * PWR + kw) * PIXB;
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
-                        b[tn][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const v4i*>(sm + bbase[tn] + toff + pl * 32));
-            };
-            bf16x8 bq[2][TN][3];
-            read_b(0, bq[0]);
-#pragma unroll
-            for (int r = 0; r < KK; ++r) {
-                const int slot = r % DA;
-                if (r + 1 < KK) read_b(r + 1, bq[(r + 1) & 1]);
-                __builtin_amdgcn_sched_barrier(0);
-                bf16x8 a[TM][3];
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) a[tm][pl] = __builtin_bit_cast(bf16x8, abuf[slot][tm][pl]);
-#define IVLN_BF3_PROD(PA, PB)                                                                                       \
-    _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) _Pragma("unroll") for (int tn = 0; tn < TN; ++tn)              \
-        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][PA], bq[r & 1][tn][PB], acc[tm][tn], 0, 0, 0)
-                IVLN_BF3_PROD(0, 2);
-                IVLN_BF3_PROD(1, 1);
-                IVLN_BF3_PROD(2, 0);
-                // (the slice sits between the MFMAs: its VALU / LDS-write instructions issue while the matrix pipe works)
-                if (r < S) stage_slice(r * UPT, (r + 1) * UPT < UNITS ? (r + 1) * UPT : UNITS, oth);
-                IVLN_BF3_PROD(0, 1);
-                IVLN_BF3_PROD(1, 0);
-                IVLN_BF3_PROD(0, 0);
-#undef IVLN_BF3_PROD
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) abuf[slot][tm][pl] = load_a(tm, s0 + r + DA, pl);
-                // the registers the slices above have emptied receive the patch of the chunk AFTER the next one: KK - S taps and
-                // a barrier of flight time before the first slice of the next chunk reads them
-                if (r == S) load_patch(min(c + 2, c_end - 1));
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            __syncthreads();  // everybody is done reading this buffer and writing the other one
-            t_mma += BF3_T() - tb;
-        }
-    } else {
     load_patch(c_beg);
     for (int c = c_beg; c < c_end; ++c) {
         const unsigned long long ta = BF3_T();
@@ -439,7 +356,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
         __syncthreads();
         t_mma += BF3_T() - tb;
     }
-    }  // (!DB)
     const unsigned long long tk1 = BF3_T();
     (void)tk1;
 
@@ -629,6 +545,10 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf3_ks(const ivln_gemm_desc p, 
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[tn][i] = 0.f;
 
+#ifdef BF3_TIMING
+    const unsigned long long ts0 = lane == 0 ? wall_clock64() : 0ull;
+    unsigned long long ts1 = ts0, t_stage = 0;
+#endif
     if (c0 < c1) {
         v4i abuf[DA][3];
 #pragma unroll
@@ -636,8 +556,19 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf3_ks(const ivln_gemm_desc p, 
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) abuf[d][pl] = load_a(c0 * KK + d, pl);
         load_patch(c0);
+#ifdef BF3_TIMING
+        __builtin_amdgcn_s_waitcnt(0);  // (timing build only: the prologue's round trip as a phase of its own)
+        ts1 = lane == 0 ? wall_clock64() : 0ull;
+#endif
         for (int c = c0; c < c1; ++c) {
+#ifdef BF3_TIMING
+            const unsigned long long tsa = lane == 0 ? wall_clock64() : 0ull;
+#endif
             stage();
+#ifdef BF3_TIMING
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+            t_stage += (lane == 0 ? wall_clock64() : 0ull) - tsa;
+#endif
             const int s0 = c * KK;
             auto read_b = [&](int r, bf16x8 (&b)[TN][3]) {
                 const int kh = r / KS, kw = r - kh * KS, toff = (kh * PWR + kw) * PIXB;
@@ -676,6 +607,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf3_ks(const ivln_gemm_desc p, 
         }
     }
     // ---- the eight partial tiles meet in LDS: red[wave][32 channels][64 pixels (+4)] over the patch regions ----
+#ifdef BF3_TIMING
+    const unsigned long long ts2 = lane == 0 ? wall_clock64() : 0ull;
+#endif
     __syncthreads();  // every wave is done reading its patch
     float* const red = reinterpret_cast<float*>(smem);
 #pragma unroll
@@ -717,6 +651,18 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf3_ks(const ivln_gemm_desc p, 
             *reinterpret_cast<float4*>(p.D + addr) = v;
         }
     }
+#ifdef BF3_TIMING
+    if (lane == 0) {  // one record per wave: prologue round trip, K loop (of which staging: [3] low half), reduction + epilogue, start
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long ts3 = wall_clock64();
+        const int b = ((blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) & 4095;
+        g_bf3_stamp[b * 8 + 0] = ts1 - ts0;
+        g_bf3_stamp[b * 8 + 1] = ts2 - ts1;
+        g_bf3_stamp[b * 8 + 2] = ts3 - ts2;
+        g_bf3_stamp[b * 8 + 3] = ts0;
+        g_bf3_stamp[b * 8 + 4] = t_stage;
+    }
+#endif
 }
 
 template <int PTH, int PTW>
@@ -817,18 +763,29 @@ __global__ __launch_bounds__(WT ? 256 : 512, 2) void k_conv1x1_bf3_ks(const ivln
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[tn][i] = 0.f;
 
+#ifdef BF3_TIMING
+    const unsigned long long ts0 = lane == 0 ? wall_clock64() : 0ull;
+    unsigned long long ts1 = ts0, tc_split = 0, tc_load = 0, tc_mfma = 0;  // (shader cycles inside the K loop: waits + split | load issue | MFMA issue)
+#endif
     if (c0 < c1 && (!WT || n0 < p.N)) {
         v4i xb[2][8], ab[DA][3];
 #pragma unroll
         for (int d = 0; d < DA; ++d) load_a(c0 + d, ab[d]);
         load_x(c0, xb[0]);
         load_x(min(c0 + 1, c_last), xb[1]);
+#ifdef BF3_TIMING
+        __builtin_amdgcn_s_waitcnt(0);  // (timing build only: the prologue's round trip as a phase of its own)
+        ts1 = lane == 0 ? wall_clock64() : 0ull;
+#endif
         for (int cc = c0; cc < c1; cc += DA) {
 #pragma unroll
             for (int k = 0; k < DA; ++k) {
                 const int c = cc + k;
                 v4i bq[TN][3];
                 bf16x8 a[3];
+#ifdef BF3_TIMING
+                const unsigned long long tl0 = __builtin_readcyclecounter();
+#endif
                 // (loads stay outside the branch: the compiler then knows how many are in flight at every wait)
                 if (c < c1) {
 #pragma unroll
@@ -836,33 +793,83 @@ __global__ __launch_bounds__(WT ? 256 : 512, 2) void k_conv1x1_bf3_ks(const ivln
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             uint32_t H, M, L;
+#ifdef BF3_PROBE_NO_SPLIT  // (tools/conv_bf3_ks_phases.py: what the K loop costs without its VALU work - wrong results)
+                            H = xb[k & 1][2 * i][e], M = xb[k & 1][2 * i + 1][e], L = H ^ M;
+#else
                             split3_pair(__int_as_float(xb[k & 1][2 * i][e]), __int_as_float(xb[k & 1][2 * i + 1][e]), H, M, L);
+#endif
                             bq[e][0][i] = (int)H, bq[e][1][i] = (int)M, bq[e][2][i] = (int)L;
                         }
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl) a[pl] = __builtin_bit_cast(bf16x8, ab[k][pl]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+#ifdef BF3_TIMING
+                const unsigned long long tl1 = __builtin_readcyclecounter();
+                __builtin_amdgcn_sched_barrier(0);
+#endif
                 load_x(min(c + 2, c_last), xb[k & 1]);  // two chunks ahead
                 load_a(c + DA, ab[k]);                   // DA chunks ahead
                 __builtin_amdgcn_sched_barrier(0);
+#ifdef BF3_TIMING
+                const unsigned long long tl2 = __builtin_readcyclecounter();
+                __builtin_amdgcn_sched_barrier(0);
+#endif
                 if (c < c1) {
 #define IVLN_BF3_PROD(PA, PB)                            \
     _Pragma("unroll") for (int tn = 0; tn < TN; ++tn)    \
         acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA], __builtin_bit_cast(bf16x8, bq[tn][PB]), acc[tn], 0, 0, 0)
+#ifdef BF3_PROBE_NO_MFMA  // (... and without its matrix work: one product of the six)
+                    IVLN_BF3_PROD(0, 0);
+#else
                     IVLN_BF3_PROD(0, 2);
                     IVLN_BF3_PROD(1, 1);
                     IVLN_BF3_PROD(2, 0);
                     IVLN_BF3_PROD(0, 1);
                     IVLN_BF3_PROD(1, 0);
                     IVLN_BF3_PROD(0, 0);
+#endif
 #undef IVLN_BF3_PROD
                 }
+#ifdef BF3_TIMING
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned long long tl3 = __builtin_readcyclecounter();
+                tc_split += tl1 - tl0, tc_load += tl2 - tl1, tc_mfma += tl3 - tl2;
+#endif
             }
         }
     }
     // ---- partial tiles through LDS: red[wave][32 channels][4 tiles x 32 columns (+4)]; KS: the eight waves' tiles are summed
     //      in a fixed order; WT: every wave transposes its own tile (wave-private region, LDS accesses of one wave are in order) ----
+    // The epilogue's global operands (residual quads, scale / shift) are requested FIRST, all of them, and land while the tile
+    // goes through LDS: with one wave per SIMD (a 256-workgroup launch) the 16 items of a wave tile otherwise pay one
+    // dependent memory round trip each - 8 x ~2 us at the end of a 20 us kernel.  Buffer loads whose offset is out of range
+    // for an absent operand or an item outside the tensor: no branch around any of them, so nothing makes the compiler drain
+    // the queue between two requests.
+#ifdef BF3_TIMING
+    const unsigned long long ts2 = lane == 0 ? wall_clock64() : 0ull;
+#endif
+    constexpr int ITEMS = WT ? 16 : 2;  // 32 channels x 32 pixel quads = 1024 items: over a wave's 64 lanes | the workgroup's 512 threads
+    constexpr int HALF_ITEMS = WT ? 8 : 2;  // WT: the second half's operands are requested once the accumulators have left for LDS (registers)
+    v4i rres[ITEMS];
+    float esc[ITEMS], esh[ITEMS];
+    int eoff[ITEMS];  // element offset of the item's quad in D / residual (< 2^29: checked by the launcher), -1 = outside
+    const __amdgpu_buffer_rsrc_t rR = bf3_rsrc(p.residual), rS = bf3_rsrc(p.scale), rH = bf3_rsrc(p.shift);
+    const bool has_res = p.residual != nullptr, has_sc = p.scale != nullptr, has_sh = p.shift != nullptr;
+    auto request = [&](int it) {
+        const int item = WT ? lane + it * 64 : t + it * 512, ml = item >> 5, q = item & 31;
+        const int m = m0 + ml, n = n0 + 4 * q;
+        const bool ok = m < p.M && n < p.N;
+        const int img = n / HW, pp = n - img * HW;
+        const int off = (img * p.Ctot + m) * HW + pp;
+        const int me = p.grp_imgs > 0 ? (img / p.grp_imgs) * p.M + m : m;
+        eoff[it] = ok ? off : -1;
+        esc[it] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rS, ok && has_sc ? me * 4 : (int)OOB, 0, 0));
+        esh[it] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rH, ok && has_sh ? me * 4 : (int)OOB, 0, 0));
+        rres[it] = __builtin_amdgcn_raw_buffer_load_b128(rR, ok && has_res ? off * 4 : (int)OOB, 0, 0);
+    };
+#pragma unroll
+    for (int it = 0; it < HALF_ITEMS; ++it) request(it);
     float* const red = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn)
@@ -870,11 +877,11 @@ __global__ __launch_bounds__(WT ? 256 : 512, 2) void k_conv1x1_bf3_ks(const ivln
         for (int r = 0; r < 16; ++r)
             red[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * LDT + tn * 32 + l31] = acc[tn][r];
     if constexpr (!WT) __syncthreads();
-    constexpr int ITEMS = WT ? 16 : 2;  // 32 channels x 32 pixel quads = 1024 items: over a wave's 64 lanes | the workgroup's 512 threads
-#pragma unroll 2
+#pragma unroll
+    for (int it = HALF_ITEMS; it < ITEMS; ++it) request(it);
+#pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
         const int item = WT ? lane + it * 64 : t + it * 512, ml = item >> 5, q = item & 31;
-        const int m = m0 + ml, n = n0 + 4 * q;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if constexpr (WT) {
             const float* rr = red + (wave * 32 + ml) * LDT + q;
@@ -886,29 +893,37 @@ __global__ __launch_bounds__(WT ? 256 : 512, 2) void k_conv1x1_bf3_ks(const ivln
                 v.x += rr[0], v.y += rr[32], v.z += rr[64], v.w += rr[96];
             }
         }
-        if (m < p.M && n < p.N) {
-            const int img = n / HW, pp = n - img * HW;
-            const int64_t addr = ((int64_t)img * p.Ctot + m) * HW + pp;
-            const int me = p.grp_imgs > 0 ? (img / p.grp_imgs) * p.M + m : m;
-            if (p.scale) {
-                const float sc = p.scale[me], sh = p.shift[me];
-                v.x = fmaf(v.x, sc, sh), v.y = fmaf(v.y, sc, sh), v.z = fmaf(v.z, sc, sh), v.w = fmaf(v.w, sc, sh);
-            } else if (p.shift) {
-                const float sh = p.shift[me];
-                v.x += sh, v.y += sh, v.z += sh, v.w += sh;
-            }
-            if (p.residual) {
-                const float4 rr = *reinterpret_cast<const float4*>(p.residual + addr);
-                v.x += rr.x, v.y += rr.y, v.z += rr.z, v.w += rr.w;
-            }
+        if (eoff[it] >= 0) {
+            const int64_t addr = eoff[it];
+            const float sc = esc[it], sh = esh[it];
+            if (p.scale) v.x = fmaf(v.x, sc, sh), v.y = fmaf(v.y, sc, sh), v.z = fmaf(v.z, sc, sh), v.w = fmaf(v.w, sc, sh);
+            else if (p.shift) v.x += sh, v.y += sh, v.z += sh, v.w += sh;
+            // (absent residual: the out-of-range loads returned zeros, but adding them would turn a -0 into +0: the branch stays)
+            if (p.residual)
+                v.x += __int_as_float(rres[it][0]), v.y += __int_as_float(rres[it][1]), v.z += __int_as_float(rres[it][2]),
+                    v.w += __int_as_float(rres[it][3]);
             if (p.accumulate) {
-                const float4 rr = *reinterpret_cast<const float4*>(p.D + addr);
-                v.x += rr.x, v.y += rr.y, v.z += rr.z, v.w += rr.w;
+                const float4 ra = *reinterpret_cast<const float4*>(p.D + addr);
+                v.x += ra.x, v.y += ra.y, v.z += ra.z, v.w += ra.w;
             }
             if (p.relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
             *reinterpret_cast<float4*>(p.D + addr) = v;
         }
     }
+#ifdef BF3_TIMING
+    if (lane == 0) {  // one record per wave: prologue round trip, K loop, epilogue (100 MHz wall clock), start offset of the wave
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long ts3 = wall_clock64();
+        const int b = ((blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) & 4095;
+        g_bf3_stamp[b * 8 + 0] = ts1 - ts0;
+        g_bf3_stamp[b * 8 + 1] = ts2 - ts1;
+        g_bf3_stamp[b * 8 + 2] = ts3 - ts2;
+        g_bf3_stamp[b * 8 + 3] = ts0;
+        g_bf3_stamp[b * 8 + 4] = tc_split;
+        g_bf3_stamp[b * 8 + 5] = tc_load;
+        g_bf3_stamp[b * 8 + 6] = tc_mfma;
+    }
+#endif
 }
 
 // Eligibility of the 1x1 kernels in their two forms.  mode: 0 = heuristic, 1 = insist
@@ -916,7 +931,7 @@ int bf3_1x1_ks_launch(ivln_gemm_desc& d, hipStream_t s, int mode) {
     if (d.stride != 1 || d.pad != 0 || d.Cin % CB != 0 || d.Cin < 4 * CB || d.stat_partials || d.splits > 1) return IVLN_E_UNSUPPORTED;
     if ((d.HoWo & 3) || (d.in_img_stride & 3) || ((((uintptr_t)d.B) | ((uintptr_t)d.D) | ((uintptr_t)d.residual)) & 15)) return IVLN_E_UNSUPPORTED;
     const int64_t nimg = d.N / d.HoWo;
-    if (nimg * d.in_img_stride * 4 >= (int64_t)1 << 31) return IVLN_E_UNSUPPORTED;
+    if (nimg * d.in_img_stride * 4 >= (int64_t)1 << 31 || nimg * d.Ctot * d.HoWo * 4 >= (int64_t)1 << 31) return IVLN_E_UNSUPPORTED;  // byte offsets of the buffer loads
     if (d.grp_imgs > 0 && ((int64_t)d.grp_imgs * d.HoWo) % 128 != 0) return IVLN_E_UNSUPPORTED;  // a tile's pixels share one weight set
     const int nch = d.Cin / CB;
     // wave tiles (no K split) up to 16 chunks, K split over the 8 waves from 32 (in between - 272 ... 496 channels - the K-split
@@ -982,19 +997,13 @@ __global__ __launch_bounds__(256) void k_conv_bf3_pack(const float* __restrict__
     out[idx] = (uint16_t)(pl == 0 ? h : (pl == 1 ? mm : l));
 }
 
-template <int KS, int TM, int WM, int WN, int PTH, int PTW, int IMGS, int DA, bool DBUF = false>
+template <int KS, int TM, int WM, int WN, int PTH, int PTW, int IMGS, int DA>
 int launch_bf3(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a_split, int64_t grp_bytes, int nimg, int cps) {
     constexpr int NTB = 64 * WM * WN, BM = 32 * TM * WM, BN = 64 * WN;
     constexpr int PH = PTH + KS - 1, PWR = PTW + KS - 1, NPIX = IMGS * PH * PWR * bf3_stage_chunks(KS);
-    constexpr int BUFB = (NPIX * PIXB + 15) & ~15;
-    constexpr bool DB = DBUF && KS == 3 && 2 * BUFB <= 160 * 1024;
-    if constexpr (DBUF && !DB) {  // (two buffers do not fit: the single-buffer instantiation is the kernel)
-        return launch_bf3<KS, TM, WM, WN, PTH, PTW, IMGS, DA, false>(d, s, a_split, grp_bytes, nimg, cps);
-    } else {
-    constexpr size_t patch = DB ? 2 * (size_t)BUFB : (size_t)NPIX * PIXB;
-    constexpr size_t lds = patch > (size_t)32 * (BN + 4) * 4 ? patch : (size_t)32 * (BN + 4) * 4;
+    constexpr size_t lds = (size_t)(NPIX * PIXB > 32 * (BN + 4) * 4 ? NPIX * PIXB : 32 * (BN + 4) * 4);
     static_assert(lds <= 160 * 1024, "patch does not fit");
-    auto kern = k_conv_bf3<KS, TM, WM, WN, PTH, PTW, IMGS, DA, DB>;
+    auto kern = k_conv_bf3<KS, TM, WM, WN, PTH, PTW, IMGS, DA>;
     static bool attr_done = false;  // (idempotent; a race only repeats the call)
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return IVLN_E_HIP;
@@ -1005,7 +1014,6 @@ int launch_bf3(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a_sp
     dim3 grid(tiles_w * tiles_h * groups, (d.M + BM - 1) / BM, d.splits);
     IVLN_LAUNCH_FAMILY(kern, grid, dim3(NTB), lds, s, d, a_split, (long long)grp_bytes, tiles_w, tiles_h, nimg, cps);
     return IVLN_OK;
-    }
 }
 
 // pixel tile of a block for its pixel count BN and the output width: rows x columns x images
@@ -1016,24 +1024,24 @@ inline Bf3Px bf3_px(int BN, int Wout) {
     return {pth, ptw, BN / (ptw * pth)};
 }
 
-template <int KS, int TM, int WM, int WN, int DA, bool DBUF = false>
+template <int KS, int TM, int WM, int WN, int DA>
 int launch_bf3_px(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a, int64_t gb, int nimg, int cps) {
     constexpr int BN = 64 * WN;
     if constexpr (BN == 512 && KS == 1) {
         return IVLN_E_UNSUPPORTED;  // (four staged chunks of 512 pixels do not fit the LDS)
     } else if constexpr (BN == 512) {
-        if (d.Wout > 16) return launch_bf3<KS, TM, WM, WN, 16, 32, 1, DA, DBUF>(d, s, a, gb, nimg, cps);
-        if (d.Wout > 8) return launch_bf3<KS, TM, WM, WN, 16, 16, 2, DA, DBUF>(d, s, a, gb, nimg, cps);
-        if constexpr (KS == 3) return launch_bf3<KS, TM, WM, WN, 8, 8, 8, DA, DBUF>(d, s, a, gb, nimg, cps);
+        if (d.Wout > 16) return launch_bf3<KS, TM, WM, WN, 16, 32, 1, DA>(d, s, a, gb, nimg, cps);
+        if (d.Wout > 8) return launch_bf3<KS, TM, WM, WN, 16, 16, 2, DA>(d, s, a, gb, nimg, cps);
+        if constexpr (KS == 3) return launch_bf3<KS, TM, WM, WN, 8, 8, 8, DA>(d, s, a, gb, nimg, cps);
         return IVLN_E_UNSUPPORTED;
     } else if constexpr (BN == 256) {
-        if (d.Wout > 16) return launch_bf3<KS, TM, WM, WN, 8, 32, 1, DA, DBUF>(d, s, a, gb, nimg, cps);
-        if (d.Wout > 8) return launch_bf3<KS, TM, WM, WN, 16, 16, 1, DA, DBUF>(d, s, a, gb, nimg, cps);
-        return launch_bf3<KS, TM, WM, WN, 8, 8, 4, DA, DBUF>(d, s, a, gb, nimg, cps);
+        if (d.Wout > 16) return launch_bf3<KS, TM, WM, WN, 8, 32, 1, DA>(d, s, a, gb, nimg, cps);
+        if (d.Wout > 8) return launch_bf3<KS, TM, WM, WN, 16, 16, 1, DA>(d, s, a, gb, nimg, cps);
+        return launch_bf3<KS, TM, WM, WN, 8, 8, 4, DA>(d, s, a, gb, nimg, cps);
     } else {
-        if (d.Wout > 16) return launch_bf3<KS, TM, WM, WN, 4, 32, 1, DA, DBUF>(d, s, a, gb, nimg, cps);
-        if (d.Wout > 8) return launch_bf3<KS, TM, WM, WN, 8, 16, 1, DA, DBUF>(d, s, a, gb, nimg, cps);
-        return launch_bf3<KS, TM, WM, WN, 8, 8, 2, DA, DBUF>(d, s, a, gb, nimg, cps);
+        if (d.Wout > 16) return launch_bf3<KS, TM, WM, WN, 4, 32, 1, DA>(d, s, a, gb, nimg, cps);
+        if (d.Wout > 8) return launch_bf3<KS, TM, WM, WN, 8, 16, 1, DA>(d, s, a, gb, nimg, cps);
+        return launch_bf3<KS, TM, WM, WN, 8, 8, 2, DA>(d, s, a, gb, nimg, cps);
     }
 }
 
@@ -1042,21 +1050,22 @@ constexpr int kBf3Cfgs = 7;
 constexpr int kBf3BM[kBf3Cfgs] = {32, 64, 64, 128, 64, 128, 32};
 constexpr int kBf3BN[kBf3Cfgs] = {512, 512, 256, 256, 128, 128, 256};
 
-template <int KS, bool DBUF = false>
+template <int KS>
 int launch_bf3_ks(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a, int64_t gb, int nimg, int cfg, int cps) {
     // weight taps in flight: a tap is 24 MFMAs = 768 pipe cycles per wave (12 = 384 with one channel tile per wave), an L2 /
     // MALL round trip ~2000
     constexpr int DA2 = KS == 1 ? 2 : 3, DA1 = KS == 1 ? 4 : (KS == 7 ? 2 : 3);  // (6 / 9 taps ahead measured the same as 3 and cost 36-72 registers)
     switch (cfg) {
-        case 0: return launch_bf3_px<KS, 1, 1, 8, DA1, DBUF>(d, s, a, gb, nimg, cps);   // 32 x 512, 8 waves
-        case 1: return launch_bf3_px<KS, 2, 1, 8, DA2, DBUF>(d, s, a, gb, nimg, cps);   // 64 x 512
-        case 2: return launch_bf3_px<KS, 1, 2, 4, DA1, DBUF>(d, s, a, gb, nimg, cps);   // 64 x 256
-        case 3: return launch_bf3_px<KS, 2, 2, 4, DA2, DBUF>(d, s, a, gb, nimg, cps);   // 128 x 256
-        case 4: return launch_bf3_px<KS, 1, 2, 2, DA1, DBUF>(d, s, a, gb, nimg, cps);   // 64 x 128, 4 waves: several workgroups per CU
-        case 5: return launch_bf3_px<KS, 2, 2, 2, DA2, DBUF>(d, s, a, gb, nimg, cps);   // 128 x 128, 4 waves
-        default: return launch_bf3_px<KS, 1, 1, 4, DA1, DBUF>(d, s, a, gb, nimg, cps);  // 32 x 256, 4 waves: two workgroups per CU
+        case 0: return launch_bf3_px<KS, 1, 1, 8, DA1>(d, s, a, gb, nimg, cps);   // 32 x 512, 8 waves
+        case 1: return launch_bf3_px<KS, 2, 1, 8, DA2>(d, s, a, gb, nimg, cps);   // 64 x 512
+        case 2: return launch_bf3_px<KS, 1, 2, 4, DA1>(d, s, a, gb, nimg, cps);   // 64 x 256
+        case 3: return launch_bf3_px<KS, 2, 2, 4, DA2>(d, s, a, gb, nimg, cps);   // 128 x 256
+        case 4: return launch_bf3_px<KS, 1, 2, 2, DA1>(d, s, a, gb, nimg, cps);   // 64 x 128, 4 waves: several workgroups per CU
+        case 5: return launch_bf3_px<KS, 2, 2, 2, DA2>(d, s, a, gb, nimg, cps);   // 128 x 128, 4 waves
+        default: return launch_bf3_px<KS, 1, 1, 4, DA1>(d, s, a, gb, nimg, cps);  // 32 x 256, 4 waves: two workgroups per CU
     }
 }
+
 
 // ------------------------------------------------------------------------------------------------------------------
 // Weight gradient of a 7x7 same-size conv on the same arithmetic (map CNN, base_il_trainer.py:173-219):
@@ -1473,12 +1482,8 @@ int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
     const int64_t tiles = tiles_of(cfg);
     const int BN = kBf3BN[cfg];
     const int64_t gb = d.a_split_grp_stride * 4;
-    // 3x3: the double-buffered form with the staging interleaved into the tap loop (k_conv_bf3<..., DBUF>); IVLN_BF3_DBUF=0: the
-    // round-4 phases (A/B)
-    static const bool dbuf = !(getenv("IVLN_BF3_DBUF") && atoi(getenv("IVLN_BF3_DBUF")) == 0);
     const int rc = KS == 7   ? launch_bf3_ks<7>(d, s, (const unsigned char*)d.A_split, gb, nimg, cfg, cps)
-                   : KS == 3 ? (dbuf ? launch_bf3_ks<3, true>(d, s, (const unsigned char*)d.A_split, gb, nimg, cfg, cps)
-                                     : launch_bf3_ks<3>(d, s, (const unsigned char*)d.A_split, gb, nimg, cfg, cps))
+                   : KS == 3 ? launch_bf3_ks<3>(d, s, (const unsigned char*)d.A_split, gb, nimg, cfg, cps)
                              : launch_bf3_ks<1>(d, s, (const unsigned char*)d.A_split, gb, nimg, cfg, cps);
     if (rc == IVLN_OK) g_bf3_flops += 2.0 * d.M * (double)d.N * d.K, ++g_bf3_launches, ++g_bf3_kind[0];
     if (rc == IVLN_OK && d.stat_tiles) *d.stat_tiles = d.stat_partials ? (int)(tiles * (BN / 128)) : 0;
