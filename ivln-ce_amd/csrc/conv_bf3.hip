@@ -81,7 +81,7 @@ __device__ __forceinline__ void split3_pair(float v0, float v1, uint32_t& H, uin
 }
 
 #ifdef BF3_TIMING  // tools/conv_bf3_phases.py: per-workgroup phase sums (100 MHz wall clock): prologue, staging, MFMA, epilogue
-__device__ unsigned long long g_bf3_stamp[8192 * 4];
+__device__ unsigned long long g_bf3_stamp[8192 * 8];  // records of 8 words
 #define BF3_T() (threadIdx.x == 0 ? wall_clock64() : 0ull)
 #else
 #define BF3_T() 0ull
@@ -94,6 +94,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t bf3_rsrc(const void* p) {
 template <int KS, int TM, int WM, int WN, int PTH, int PTW, int IMGS, int DA>
 __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_desc p, const unsigned char* a_split, long long a_grp_bytes,
                                                            int tiles_w, int tiles_h, int nimg, int chunks_per_split) {
+#ifdef BF3_TIMING
+    const unsigned long long t_entry = threadIdx.x == 0 ? wall_clock64() : 0ull;
+#endif
     constexpr int NTB = 64 * WM * WN, TN = 2;
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     static_assert(IMGS * PTH * PTW == BN && PTW % 4 == 0, "pixel tile");
@@ -428,10 +431,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
 #ifdef BF3_TIMING
     if (threadIdx.x == 0) {
         const int b = (blockIdx.y * gridDim.x + blockIdx.x) & 8191;
-        g_bf3_stamp[b * 4 + 0] = tk1 - tk0;
-        g_bf3_stamp[b * 4 + 1] = t_stage;
-        g_bf3_stamp[b * 4 + 2] = t_mma;
-        g_bf3_stamp[b * 4 + 3] = clock64() - cyc0;  // shader cycles over the whole kernel: with [0] + epilogue wall time, the clock it ran at
+        g_bf3_stamp[b * 8 + 0] = tk1 - tk0;
+        g_bf3_stamp[b * 8 + 1] = t_stage;
+        g_bf3_stamp[b * 8 + 2] = t_mma;
+        g_bf3_stamp[b * 8 + 3] = clock64() - cyc0;  // shader cycles over the whole kernel: with [0] + epilogue wall time, the clock it ran at
+        g_bf3_stamp[b * 8 + 4] = t_entry;
+        g_bf3_stamp[b * 8 + 5] = tk0;
+        __builtin_amdgcn_s_waitcnt(0);
+        g_bf3_stamp[b * 8 + 6] = wall_clock64();
     }
 #endif
 }
@@ -453,19 +460,21 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
 //     launch, the same bits on every run.
 // L2 -> CU traffic is the price: every workgroup streams its 32 channels' weights for the whole K (885 KB at K = 4608).
 // ------------------------------------------------------------------------------------------------------------------
-template <int PTH, int PTW>
+template <int PTH, int PTW, int TN = 2>
 __global__ __launch_bounds__(512, 2) void k_conv_bf3_ks(const ivln_gemm_desc p, const unsigned char* a_split, long long a_grp_bytes,
                                                         int tiles_w, int tiles_h, int nimg) {
     // DA: weight taps in flight.  A tap is only 12 MFMAs here (384 pipe cycles, 768 with the SIMD's other wave): three taps
     // ahead were ~1 us of cover against an L2 round trip of 1-2 us under load - every tap waited (first version: 28 us for
     // 512 x 512 x 4608 with 13 us of MFMA issue).  A whole chunk ahead (9 taps, 108 registers) covers it.
-    constexpr int NW = 8, TN = 2, KS = 3, KK = 9, DA = 9;
-    static_assert(PTH * PTW == 32 * TN, "64 pixels per workgroup");
+    // TN = 1 (32 pixels per workgroup): the launches that fill less than half the chip with 64-pixel tiles (512 x 512 x 4608:
+    // 128 workgroups) - twice the workgroups, half the MFMAs per wave, 20 % more halo per output.
+    constexpr int NW = 8, KS = 3, KK = 9, DA = 9;
+    static_assert(PTH * PTW == 32 * TN, "32 TN pixels per workgroup");
     constexpr int PH = PTH + 2, PWR = PTW + 2, NPIX = PH * PWR;
     constexpr int XOFF = 3, NG = (XOFF + PWR + 3) / 4;
     constexpr int ITEMS = PH * NG * (CB / 2), NI = (ITEMS + 63) / 64;
     constexpr int WREG = (NPIX * PIXB + 15) & ~15;  // bytes of a wave's patch region
-    constexpr int LDT = 64 + 4;
+    constexpr int LDT = 32 * TN + 4;
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -618,8 +627,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf3_ks(const ivln_gemm_desc p, 
         for (int r = 0; r < 16; ++r)
             red[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * LDT + tn * 32 + l31] = acc[tn][r];
     __syncthreads();
-    {
-        const int ml = t >> 4, c4 = t & 15;  // 512 threads = 32 channels x 16 pixel quads
+    if (t < 32 * 8 * TN) {
+        const int ml = t / (8 * TN), c4 = t % (8 * TN);  // 32 channels x 8 TN pixel quads
         const int m = m0 + ml, nl = 4 * c4;
         const int ph = nl / PTW, pw = nl % PTW;
         const int ho = ho0 + ph, wo = wo0 + pw;
@@ -655,7 +664,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf3_ks(const ivln_gemm_desc p, 
     if (lane == 0) {  // one record per wave: prologue round trip, K loop (of which staging: [3] low half), reduction + epilogue, start
         __builtin_amdgcn_s_waitcnt(0);
         const unsigned long long ts3 = wall_clock64();
-        const int b = ((blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) & 4095;
+        const int b = ((blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) & 8191;
         g_bf3_stamp[b * 8 + 0] = ts1 - ts0;
         g_bf3_stamp[b * 8 + 1] = ts2 - ts1;
         g_bf3_stamp[b * 8 + 2] = ts3 - ts2;
@@ -665,12 +674,12 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf3_ks(const ivln_gemm_desc p, 
 #endif
 }
 
-template <int PTH, int PTW>
+template <int PTH, int PTW, int TN = 2>
 int launch_bf3_ks_tile(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a_split, int64_t grp_bytes, int nimg) {
-    constexpr int NPIX = (PTH + 2) * (PTW + 2), WREG = (NPIX * PIXB + 15) & ~15;
-    constexpr size_t lds = (size_t)(8 * WREG > 8 * 32 * 68 * 4 ? 8 * WREG : 8 * 32 * 68 * 4);
+    constexpr int NPIX = (PTH + 2) * (PTW + 2), WREG = (NPIX * PIXB + 15) & ~15, RED = 8 * 32 * (32 * TN + 4) * 4;
+    constexpr size_t lds = (size_t)(8 * WREG > RED ? 8 * WREG : RED);
     static_assert(lds <= 160 * 1024, "patch regions do not fit");
-    auto kern = k_conv_bf3_ks<PTH, PTW>;
+    auto kern = k_conv_bf3_ks<PTH, PTW, TN>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return IVLN_E_HIP;
@@ -686,15 +695,23 @@ int launch_bf3_ks_tile(const ivln_gemm_desc& d, hipStream_t s, const unsigned ch
 int bf3_ks_launch(ivln_gemm_desc& d, hipStream_t s, int nimg, int mode) {
     if (d.Cin % CB != 0 || d.Cin < 8 * CB || d.stat_partials || d.splits > 1) return IVLN_E_UNSUPPORTED;
     if (d.Wout != 8 && d.Wout != 16 && d.Wout != 32) return IVLN_E_UNSUPPORTED;
-    const int pth = 64 / d.Wout;
+    const int64_t wgs = (int64_t)(d.N / 64) * ((d.M + 31) / 32);
+    // 32-pixel tiles where 64-pixel ones leave half of the CUs without a workgroup; IVLN_BF3_KS_TN = 1 | 2 pins one (tuning)
+    static const int tn_env = getenv("IVLN_BF3_KS_TN") ? atoi(getenv("IVLN_BF3_KS_TN")) : 0;
+    const bool small = tn_env ? tn_env == 1 : 2 * wgs <= ivln_cu_count();
+    const int pth = (small ? 32 : 64) / d.Wout;
     if (d.Hout % pth != 0 || (d.in_img_stride & 3) || (((uintptr_t)d.B) & 15)) return IVLN_E_UNSUPPORTED;
     if ((int64_t)nimg * d.in_img_stride * 4 >= (int64_t)1 << 31) return IVLN_E_UNSUPPORTED;  // byte offsets of the buffer loads
-    const int64_t wgs = (int64_t)(d.N / 64) * ((d.M + 31) / 32);
     if (d.grp_imgs > 0 && nimg % d.grp_imgs != 0) return IVLN_E_UNSUPPORTED;
     if (mode == 0 && (wgs > 2 * (int64_t)ivln_cu_count() || wgs < ivln_cu_count() / 4)) return IVLN_E_UNSUPPORTED;  // (more pixels: the tiled kernel fills the chip by itself)
     const int64_t gb = d.a_split_grp_stride * 4;
     d.splits = 1;
     const unsigned char* a = (const unsigned char*)d.A_split;
+    if (small) {
+        if (d.Wout == 8) return launch_bf3_ks_tile<4, 8, 1>(d, s, a, gb, nimg);
+        if (d.Wout == 16) return launch_bf3_ks_tile<2, 16, 1>(d, s, a, gb, nimg);
+        return launch_bf3_ks_tile<1, 32, 1>(d, s, a, gb, nimg);
+    }
     if (d.Wout == 8) return launch_bf3_ks_tile<8, 8>(d, s, a, gb, nimg);
     if (d.Wout == 16) return launch_bf3_ks_tile<4, 16>(d, s, a, gb, nimg);
     return launch_bf3_ks_tile<2, 32>(d, s, a, gb, nimg);
@@ -745,10 +762,10 @@ __global__ __launch_bounds__(WT ? 256 : 512, 2) void k_conv1x1_bf3_ks(const ivln
     const unsigned hw4 = (unsigned)HW * 4u;
     const unsigned xvo = nq < p.N ? (unsigned)(((int64_t)qimg * p.in_img_stride + qpp + (int64_t)(8 * half) * HW) * 4) : OOB;
     const __amdgpu_buffer_rsrc_t rB = bf3_rsrc(p.B);
-    auto load_x = [&](int c, v4i (&xb)[8]) {
+    auto load_x = [&](int c, v4i (&xb)[8]) {  // (the channel steps ride in the SCALAR offset, which the range check ignores: no VALU per load)
         const int so = c * CB * HW * 4;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) xb[j] = __builtin_amdgcn_raw_buffer_load_b128(rB, (int)((xvo & OOB) ? OOB : xvo + j * hw4), so, 0);
+        for (int j = 0; j < 8; ++j) xb[j] = __builtin_amdgcn_raw_buffer_load_b128(rB, (int)xvo, so + j * (int)hw4, 0);
     };
     const int mt = min(m0 / 32, (p.M + 31) / 32 - 1);
     const __amdgpu_buffer_rsrc_t rA = bf3_rsrc(a_split + (int64_t)grp * a_grp_bytes + (int64_t)mt * nch * (3 * 1024));
@@ -914,7 +931,7 @@ __global__ __launch_bounds__(WT ? 256 : 512, 2) void k_conv1x1_bf3_ks(const ivln
     if (lane == 0) {  // one record per wave: prologue round trip, K loop, epilogue (100 MHz wall clock), start offset of the wave
         __builtin_amdgcn_s_waitcnt(0);
         const unsigned long long ts3 = wall_clock64();
-        const int b = ((blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) & 4095;
+        const int b = ((blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) & 8191;
         g_bf3_stamp[b * 8 + 0] = ts1 - ts0;
         g_bf3_stamp[b * 8 + 1] = ts2 - ts1;
         g_bf3_stamp[b * 8 + 2] = ts3 - ts2;
@@ -1284,10 +1301,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_wgrad_bf3(const ivln_gemm_desc
 #ifdef BF3_TIMING
     if (threadIdx.x == 0) {
         const int b = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) & 8191;
-        g_bf3_stamp[b * 4 + 0] = wall_clock64() - tk0;
-        g_bf3_stamp[b * 4 + 1] = t_stage;
-        g_bf3_stamp[b * 4 + 2] = t_mma;
-        g_bf3_stamp[b * 4 + 3] = clock64() - cyc0;
+        g_bf3_stamp[b * 8 + 0] = wall_clock64() - tk0;
+        g_bf3_stamp[b * 8 + 1] = t_stage;
+        g_bf3_stamp[b * 8 + 2] = t_mma;
+        g_bf3_stamp[b * 8 + 3] = clock64() - cyc0;
     }
 #endif
 

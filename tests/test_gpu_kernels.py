@@ -396,13 +396,15 @@ def test_conv2d_split_bf16_kernel(N, Cin, H, W, Cout, k):
 
 
 @pytest.mark.parametrize("N,Cin,H,Cout,G", [(8, 512, 8, 512, 0), (8, 256, 16, 256, 0), (4, 128, 32, 128, 0), (16, 256, 16, 256, 2),
-                                           (3, 144, 8, 96, 0), (2, 128, 16, 40, 0)])
+                                           (3, 144, 8, 96, 0), (2, 128, 16, 40, 0), (1, 128, 32, 64, 0), (32, 128, 8, 256, 0)])
 def test_conv2d_split_bf16_k_split_over_waves(N, Cin, H, Cout, G):
     """k_conv_bf3_ks (tile_override 10): the pixel-starved deep 3x3 convs of RedNet (rednet.py:190-263) with K split over the
     eight WAVES of a workgroup - wave-private patches, no slabs, no reduction launch.  Same error bar against a float64
     convolution as the tiled split-bf16 kernel and the fp32 MFMA kernel, every epilogue form (scale / shift / residual / ReLU,
     a channel slice of a wider destination), image-grouped weights (the stacked RGB + depth encoders), channel counts that
-    leave some waves without a chunk (144 = 9 chunks) and a ragged channel tile (40 outputs), run-to-run identical bits."""
+    leave some waves without a chunk (144 = 9 chunks) and a ragged channel tile (40 outputs), run-to-run identical bits.  Both
+    tile sizes at every map width: 64 pixels per workgroup, and 32 where the 64-pixel grid would leave half of the CUs idle
+    (the 512-channel 8 x 8 case, the three small ones)."""
     from ivln_ce_amd import ops
 
     g = torch.Generator().manual_seed(N * 100 + Cin + H)

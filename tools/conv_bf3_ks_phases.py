@@ -50,7 +50,7 @@ for name, n, cin, cout, hw, res in SH:
         ops.TILE_OVERRIDE = 0
         continue
     torch.cuda.synchronize()
-    st = np.zeros(8192 * 4, dtype=np.uint64)
+    st = np.zeros(8192 * 8, dtype=np.uint64)
     L.ivln_conv_bf3_stamps(st.ctypes.data, st.size)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
@@ -59,7 +59,7 @@ for name, n, cin, cout, hw, res in SH:
     torch.cuda.synchronize()
     ops.TILE_OVERRIDE = 0
     assert L.ivln_conv_bf3_stamps(st.ctypes.data, st.size) == 0
-    st = st.reshape(4096, 8).astype(np.float64)
+    st = st.reshape(8192, 8).astype(np.float64)
     st[:, :4] /= 100.0
     st = st[st[:, 3] > 0]
     med = np.median(st[:, :3], axis=0)
@@ -87,7 +87,7 @@ for name, n, cin, cout, hw in SH3:
         ops.TILE_OVERRIDE = 0
         continue
     torch.cuda.synchronize()
-    st = np.zeros(8192 * 4, dtype=np.uint64)
+    st = np.zeros(8192 * 8, dtype=np.uint64)
     L.ivln_conv_bf3_stamps(st.ctypes.data, st.size)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
@@ -96,7 +96,7 @@ for name, n, cin, cout, hw in SH3:
     torch.cuda.synchronize()
     ops.TILE_OVERRIDE = 0
     assert L.ivln_conv_bf3_stamps(st.ctypes.data, st.size) == 0
-    st = st.reshape(4096, 8).astype(np.float64) / 100.0
+    st = st.reshape(8192, 8).astype(np.float64) / 100.0
     st = st[st[:, 3] > 0]
     med = np.median(st[:, [0, 1, 2, 4]], axis=0)
     t0 = st[:, 3].min()
