@@ -193,7 +193,8 @@ typedef struct ivln_gemm_desc {
      * image-grouped conv).  When set and the shape fills the chip, the conv runs on the bf16 MFMA pipe with BOTH operands
      * carried as three bf16 pieces (exact) and six of the nine piece products accumulated in fp32: the dropped ones are
      * below 2^-23 of a product, i.e. the result is as close to the exact convolution as the fp32 MFMA kernel's
-     * (csrc/conv_bf3.hip).  tile_override 9 insists on this kernel (IVLN_E_UNSUPPORTED when not eligible);
+     * (csrc/conv_bf3.hip).  tile_override 9 insists on this kernel (IVLN_E_UNSUPPORTED when not eligible), 20 + c on its tile
+     * configuration c = 0 ... 6 (tuning: tools/conv_cfg_sweep.py);
      * IVLN_NO_SPLIT_BF16 in the environment keeps the fp32 MFMA kernels (A/B).  A must still be given. */
     const void* A_split;
     int64_t a_split_grp_stride;

@@ -1456,22 +1456,26 @@ int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
     // (4-wave tiles, measured on RedNet's 3x3 shapes at 8 + 8 stacked images against the fp32 kernels: 128 x 128 wins from
     //  2 M outputs - 57 vs 64 us on 128 x 16384, 50 vs 67 on 256 x 4096 and 512 x 1024 -, 64 x 128 below - 41 vs 46 on
     //  128 x 8192, 37.5 vs 44 on 256 x 2048 and 512 x 512; 64-channel convs that need them lose - 42 vs 38 us on 64 x 32768)
+    static const bool nosplit4 = !(getenv("IVLN_BF3_NOSPLIT4") && getenv("IVLN_BF3_NOSPLIT4")[0] == '0');  // A/B: =0 restores the split 64 x 128 tiles
     static const int cfg32_env = getenv("IVLN_SPLIT_BF16_CFG32") ? atoi(getenv("IVLN_SPLIT_BF16_CFG32")) : -1;  // tuning: 0 | 6
     if (d.M <= 32) cfg = cfg32_env >= 0 ? cfg32_env : 6;
     else if (d.M <= 64)
         cfg = (big_ok && KS != 1 && fills(blocks_of(1), 1)) ? 1
-              : (fills(blocks_of(2), 1) ? 2 : (force ? 4 : -1));  // (64 x 32768: 64 x 128 and 32 x 256 tiles measured 42 / 40 us against the fp32 kernel's 38)
+              : (fills(blocks_of(2), 1) ? 2 : ((force || (nosplit4 && blocks_of(4) >= CUS)) ? 4 : -1));
+    // (64 x 32768, the decoder's 64-channel convs at 64 x 64: the 64 x 128 tile UNSPLIT - one workgroup per CU - 24.9 us against the
+    //  fp32 kernel's 37.2 and 35.8 with its channel chunks split three ways + the reduction launch: tools/conv_cfg_sweep.py)
     // (round 5, aligned-group staging: the 64 x 128 tile now beats 128 x 128 wherever the latter leaves CUs without a workgroup -
     //  128 x 16384: 42.7 vs 50.9 us, 256 x 4096: 43.2 vs 45.3)
     else cfg = fills(blocks_of(3), 1) ? 3 : (fills(blocks_of(2), 1) ? 2 : (((int64_t)d.M * d.N >= (1 << 21) && blocks_of(5) >= CUS) ? 5 : 4));
     if (cfg < 0) return IVLN_E_UNSUPPORTED;
     if (cfg_env >= 0 && cfg_env < kBf3Cfgs && !(cfg_env == 0 && d.M > 32)) cfg = cfg_env;
+    if (d.tile_override >= 20 && d.tile_override < 20 + kBf3Cfgs) cfg = d.tile_override - 20;  // (tuning: tools/conv_cfg_sweep.py pins a tile)
     if ((cfg == 0 && !big_ok) || (KS == 1 && (cfg <= 1 || cfg == 6))) return IVLN_E_UNSUPPORTED;
     const int64_t nb = blocks_of(cfg);
     if (cfg >= 4) {
         const int slots = cfg == 4 ? 3 : 2;
         const bool may_split = d.splits == 0 && d.ws && nch >= 2 && !d.stat_partials;
-        if (may_split && nb < (int64_t)CUS * slots) {
+        if (may_split && nb < (int64_t)CUS * slots && !(cfg == 4 && nosplit4 && nb >= CUS)) {  // (128 x 16384: 45.0 unsplit, 53.0 split two ways)
             const int64_t want = (int64_t)CUS * slots;
             splits = (int)((want + nb - 1) / nb);
             if (splits > nch) splits = nch;
