@@ -692,13 +692,13 @@ int launch_bf3_ks_tile(const ivln_gemm_desc& d, hipStream_t s, const unsigned ch
 }
 
 // Eligibility of the K-split-over-waves kernel: deep 3x3 convs over few pixels.  mode: 0 = heuristic, 1 = insist (tests, tuning)
-int bf3_ks_launch(ivln_gemm_desc& d, hipStream_t s, int nimg, int mode) {
+int bf3_ks_launch(ivln_gemm_desc& d, hipStream_t s, int nimg, int mode, int tn_pin = 0) {
     if (d.Cin % CB != 0 || d.Cin < 8 * CB || d.stat_partials || d.splits > 1) return IVLN_E_UNSUPPORTED;
     if (d.Wout != 8 && d.Wout != 16 && d.Wout != 32) return IVLN_E_UNSUPPORTED;
     const int64_t wgs = (int64_t)(d.N / 64) * ((d.M + 31) / 32);
     // 32-pixel tiles where 64-pixel ones leave half of the CUs without a workgroup; IVLN_BF3_KS_TN = 1 | 2 pins one (tuning)
     static const int tn_env = getenv("IVLN_BF3_KS_TN") ? atoi(getenv("IVLN_BF3_KS_TN")) : 0;
-    const bool small = tn_env ? tn_env == 1 : 2 * wgs <= ivln_cu_count();
+    const bool small = tn_pin ? tn_pin == 1 : (tn_env ? tn_env == 1 : 2 * wgs <= ivln_cu_count());
     const int pth = (small ? 32 : 64) / d.Wout;
     if (d.Hout % pth != 0 || (d.in_img_stride & 3) || (((uintptr_t)d.B) & 15)) return IVLN_E_UNSUPPORTED;
     if ((int64_t)nimg * d.in_img_stride * 4 >= (int64_t)1 << 31) return IVLN_E_UNSUPPORTED;  // byte offsets of the buffer loads
@@ -944,7 +944,7 @@ __global__ __launch_bounds__(WT ? 256 : 512, 2) void k_conv1x1_bf3_ks(const ivln
 }
 
 // Eligibility of the 1x1 kernels in their two forms.  mode: 0 = heuristic, 1 = insist
-int bf3_1x1_ks_launch(ivln_gemm_desc& d, hipStream_t s, int mode) {
+int bf3_1x1_ks_launch(ivln_gemm_desc& d, hipStream_t s, int mode, int form_pin = -1) {
     if (d.stride != 1 || d.pad != 0 || d.Cin % CB != 0 || d.Cin < 4 * CB || d.stat_partials || d.splits > 1) return IVLN_E_UNSUPPORTED;
     if ((d.HoWo & 3) || (d.in_img_stride & 3) || ((((uintptr_t)d.B) | ((uintptr_t)d.D) | ((uintptr_t)d.residual)) & 15)) return IVLN_E_UNSUPPORTED;
     const int64_t nimg = d.N / d.HoWo;
@@ -956,6 +956,7 @@ int bf3_1x1_ks_launch(ivln_gemm_desc& d, hipStream_t s, int mode) {
     static const char* form_env = getenv("IVLN_BF3_1X1_FORM");
     bool wt = nch <= 16;
     if (form_env) wt = form_env[0] == 'w';
+    if (form_pin >= 0) wt = form_pin == 1;
     if (wt && nch > 64) wt = false;
     const int64_t mtiles = (d.M + 31) / 32;
     const int64_t wgs = wt ? (int64_t)((d.N + 511) / 512) * mtiles : (int64_t)((d.N + 127) / 128) * mtiles;
@@ -1404,16 +1405,20 @@ int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
     // deep-K 1x1 convs: K split over the waves of a workgroup, fragments built in registers (k_conv1x1_bf3_ks);
     // IVLN_BF3_1X1_KS=0 | 1 = never | wherever eligible, tile_override 11 insists
     static const int ks1_env = getenv("IVLN_BF3_1X1_KS") ? atoi(getenv("IVLN_BF3_1X1_KS")) : -1;
-    if (KS == 1 && (ks1_env != 0 || d.tile_override == 11) && d.splits <= 1 && !d.defer_epilogue && d.HoWo == d.Hout * d.Wout &&
+    // (tuning, tools/conv_cfg_sweep.py: tile_override 12 / 13 insist on the K-split / wave-tile form, 14 / 15 on 32- / 64-pixel tiles
+    //  of the 3x3 K-split kernel, 20 + c on tile c of the tiled kernel)
+    const int ov = d.tile_override;
+    const bool ins1 = ov == 11 || ov == 12 || ov == 13, ins3 = ov == 10 || ov == 14 || ov == 15;
+    if (KS == 1 && ov < 20 && (ks1_env != 0 || ins1) && d.splits <= 1 && !d.defer_epilogue && d.HoWo == d.Hout * d.Wout &&
         d.K == d.Cin && d.N % d.HoWo == 0 && d.Hout == d.Hin && d.Wout == d.Win) {
-        const int rc = bf3_1x1_ks_launch(d, s, (ks1_env == 1 || d.tile_override == 11) ? 1 : 0);
-        if (rc != IVLN_E_UNSUPPORTED || d.tile_override == 11) {
-            if (rc == IVLN_OK) g_bf3_flops += 2.0 * d.M * (double)d.N * d.K, ++g_bf3_launches, ++g_bf3_kind[d.Cin / CB <= 16 ? 3 : 2];
+        const int rc = bf3_1x1_ks_launch(d, s, (ks1_env == 1 || ins1) ? 1 : 0, ov == 12 ? 0 : (ov == 13 ? 1 : -1));
+        if (rc != IVLN_E_UNSUPPORTED || ins1) {
+            if (rc == IVLN_OK) g_bf3_flops += 2.0 * d.M * (double)d.N * d.K, ++g_bf3_launches, ++g_bf3_kind[ov == 13 ? 3 : (ov == 12 ? 2 : (d.Cin / CB <= 16 ? 3 : 2))];
             if (rc == IVLN_OK && d.stat_tiles) *d.stat_tiles = 0;
             return rc;
         }
     }
-    if (d.tile_override == 11 || (d.tile_override == 10 && KS != 3)) return IVLN_E_UNSUPPORTED;
+    if (ins1 || (ins3 && KS != 3)) return IVLN_E_UNSUPPORTED;
     if (KS == 1) {  // 1x1, stride 1 or 2, no padding
         if ((d.stride != 1 && d.stride != 2) || d.pad != 0 || d.Hout != (d.Hin - 1) / d.stride + 1 || d.Wout != (d.Win - 1) / d.stride + 1 || d.M < 64)
             return IVLN_E_UNSUPPORTED;
@@ -1427,9 +1432,9 @@ int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
     if ((int64_t)nimg * d.in_img_stride >= (int64_t)1 << 31) return IVLN_E_UNSUPPORTED;  // 32-bit patch offsets
     // pixel-starved deep 3x3 convs: K split over the waves of a workgroup, no slabs (k_conv_bf3_ks); IVLN_BF3_KS=0 | 1 = never | wherever eligible
     static const int ks_env = getenv("IVLN_BF3_KS") ? atoi(getenv("IVLN_BF3_KS")) : -1;
-    if (KS == 3 && (ks_env != 0 || d.tile_override == 10) && d.splits <= 1) {
-        const int rc = bf3_ks_launch(d, s, nimg, (ks_env == 1 || d.tile_override == 10) ? 1 : 0);
-        if (rc != IVLN_E_UNSUPPORTED || d.tile_override == 10) {
+    if (KS == 3 && ov < 20 && (ks_env != 0 || ins3) && d.splits <= 1) {
+        const int rc = bf3_ks_launch(d, s, nimg, (ks_env == 1 || ins3) ? 1 : 0, ov == 14 ? 1 : (ov == 15 ? 2 : 0));
+        if (rc != IVLN_E_UNSUPPORTED || ins3) {
             if (rc == IVLN_OK) g_bf3_flops += 2.0 * d.M * (double)d.N * d.K, ++g_bf3_launches, ++g_bf3_kind[1];
             if (rc == IVLN_OK && d.stat_tiles) *d.stat_tiles = 0;
             return rc;

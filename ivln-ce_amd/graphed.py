@@ -146,8 +146,6 @@ class GraphedRollout:
         net = self.policy.net
         self.sA = _stream(dev, "depth", priority=int(os.environ.get("IVLN_DEPTH_STREAM_PRIORITY", "-1")))  # the critical chain wins dispatch when both queues are ready
         self.ev_in, self.ev_A = torch.cuda.Event(), torch.cuda.Event()
-        mp = os.environ.get("IVLN_MAIN_STREAM_PRIORITY")
-        self.sB = _stream(dev, "main_prio", priority=int(mp)) if mp else None
         main = torch.cuda.current_stream()
 
         B = self.rnn[0].shape[0]
@@ -291,14 +289,8 @@ class GraphedRollout:
         #  the map CNN's large grids stop crowding the chain: measured 0.79-0.83 ms per step against 0.708, round 3)
         # (... and gB2 replayed BEHIND gA on the chain's stream, so that the critical edge gA -> gB2 stays inside one queue:
         #  0.726 vs 0.714 ms per step, slower)
-        if self.sB is not None:  # (measurement switch IVLN_MAIN_STREAM_PRIORITY: the main graphs on a stream with a priority of its own)
-            self.sB.wait_event(self.ev_in)
-            with torch.cuda.stream(self.sB):
-                self.gB1[self.phase].replay()
-                self.sB.wait_event(self.ev_A)
-                self.graphs[self.phase].replay()
-            main.wait_stream(self.sB)
-            return
+        # (... and the main graphs on a third stream with a priority of its own, whatever the priorities: 8.2 ms per pred-semantics
+        #  step against 4.25, round 5 - the extra stream hop serialises the replay)
         self.gB1[self.phase].replay()
         main.wait_event(self.ev_A)
         self.graphs[self.phase].replay()

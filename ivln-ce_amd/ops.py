@@ -407,8 +407,8 @@ def conv2d(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, 
         # by chunk count and grid size)
         deep_1x1 = stride == 1 and Cin >= 64 and Cin % 16 == 0 and (Ho * Wo) % 4 == 0 and BF3_1X1_KS
         want_1x1 = TILE_OVERRIDE >= 9 or SPLIT_BF16_1X1 == 1 or (SPLIT_BF16_1X1 != 0 and (big_1x1 or deep_1x1))
-        if (want_1x1 and SPLIT_BF16 and stride in (1, 2) and (Cin >= 128 or deep_1x1) and (Cout >= 64 or deep_1x1 or TILE_OVERRIDE == 11) and Wo % 4 == 0
-                and (Wo >= 8 or deep_1x1 or TILE_OVERRIDE == 11) and w.is_contiguous()
+        if (want_1x1 and SPLIT_BF16 and stride in (1, 2) and (Cin >= 128 or deep_1x1) and (Cout >= 64 or deep_1x1 or TILE_OVERRIDE in (11, 12, 13)) and Wo % 4 == 0
+                and (Wo >= 8 or deep_1x1 or TILE_OVERRIDE in (11, 12, 13)) and w.is_contiguous()
                 and not defer and (N * Ho * Wo * Cout >= SPLIT_BF16_MIN_OUT or TILE_OVERRIDE >= 9)):
             sp = packed_conv_weights(w, cache=not weight_is_temp, split=True)
             if sp is not None:
