@@ -209,6 +209,18 @@ typedef struct ivln_gemm_desc {
      * (ivln_embed_gates_cached_f32).  Only the float4-staged GEMM and the scalar-gather implicit GEMM honour it: the
      * dispatcher sends such a call to one of them. */
     const int32_t* img_run_flags;
+    /* optional: a ResNet bottleneck's TAIL as one launch (rednet.py:20-65: conv2 3x3 + bn2 + ReLU, conv3 1x1 + bn3 + residual +
+     * ReLU).  The descriptor describes the 3x3 conv (A / A_split / M = planes = 64 or 128, stride 1, scale / shift = the folded
+     * bn2, relu = 1); fuse_A_split = the 1x1 conv's (fuse_M x planes) weights as ivln_conv_split_weights_f32(KS = 1) arranges
+     * them (fuse_a_grp_stride words between the sets of an image-grouped pair), fuse_scale / fuse_shift its folded bn3
+     * ([g * fuse_M + m] when grouped).  D / Ctot / residual then belong to the FINAL (fuse_M-channel) tensor; the
+     * planes-channel intermediate lives in LDS only.  Needs Wout % 32 == 0, Hout % 4 == 0, fuse_M % 32 == 0; anything else
+     * (or IVLN_BF3_FUSE=0 in the environment): IVLN_E_UNSUPPORTED, and the caller issues the two convs. */
+    const void* fuse_A_split;
+    int64_t fuse_a_grp_stride;
+    const float* fuse_scale;
+    const float* fuse_shift;
+    int fuse_M;
 } ivln_gemm_desc;
 
 int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream);

@@ -87,11 +87,23 @@ __device__ unsigned long long g_bf3_stamp[8192 * 8];  // records of 8 words
 #define BF3_T() 0ull
 #endif
 
+// Behind a 16-byte buffer store issued straight from computed registers: four wait states, pinned in place, before anything
+// may write the store's data registers again.  The store unit reads its data a few cycles after issue, 16 lanes at a time;
+// the compiler pads for that only in the cases its hazard table lists, and on this part a VALU write right behind such a
+// store (scalar channel offset in soffset) was seen to land first in lanes 48-63 - one register of one store stale, once in
+// a few thousand workgroups, run-to-run different (tools/dbg_fuse.py: the fused bottleneck tail against the two launches).
+#define BF3_STORE_GUARD()                       \
+    do {                                        \
+        __builtin_amdgcn_sched_barrier(0);      \
+        asm volatile("s_nop 3" ::: "memory");   \
+        __builtin_amdgcn_sched_barrier(0);      \
+    } while (0)
+
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t bf3_rsrc(const void* p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
 }
 
-template <int KS, int TM, int WM, int WN, int PTH, int PTW, int IMGS, int DA>
+template <int KS, int TM, int WM, int WN, int PTH, int PTW, int IMGS, int DA, bool FUSE = false>
 __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_desc p, const unsigned char* a_split, long long a_grp_bytes,
                                                            int tiles_w, int tiles_h, int nimg, int chunks_per_split) {
 #ifdef BF3_TIMING
@@ -361,6 +373,134 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
     }
     const unsigned long long tk1 = BF3_T();
     (void)tk1;
+
+    // ---- FUSE: the bottleneck's 1x1 expansion behind this 3x3 conv, in the same launch (ivln_gemm_desc.fuse_*).  The workgroup
+    // holds ALL of the conv's channels (M == BM) for its 128 pixels:
+    //   1. y = ReLU(scale * acc + shift) goes to LDS as fp32 [channel][pixel of the tile] - over the patch, which is dead;
+    //   2. every wave then runs the wave-tile 1x1 kernel's loop (k_conv1x1_bf3_ks<true>) on it for the 32-channel tiles
+    //      wave, wave + 4, ... of the fuse_M outputs: a lane reads four consecutive pixels of a channel (one ds_read_b128 where
+    //      that kernel issues a buffer load), builds the B fragments in registers, streams the 1x1 weights global -> registers;
+    //   3. and stores its tile straight from the accumulators (register r of the four tiles = a float4 along the pixel index)
+    //      with the folded bn3, the residual and the ReLU.
+    // Same arithmetic, same order per accumulator as the two separate launches; the planes-channel tensor never leaves the CU
+    // (written + read once per block before: 2 x 4 B x planes x pixels), one launch and one prologue / epilogue less. ----
+    if constexpr (FUSE) {
+        static_assert(KS == 3 && IMGS == 1 && PTW == 32 && BN == 128 && NTB == 256, "the fused tail is built for the 4 x 32 pixel tile");
+        constexpr int LDY = BN + 4;
+        float* const Y = reinterpret_cast<float*>(smem);
+        {
+            const __amdgpu_buffer_rsrc_t rS = bf3_rsrc(p.scale), rH = bf3_rsrc(p.shift);
+            const int me0 = grp * p.M + m0 + 4 * half;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int cl = 32 * (wm * TM + tm) + (r & 3) + 8 * (r >> 2);  // (+ 4 half: in me0 / below)
+                    const float sc = p.scale ? __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rS, me0 * 4, cl * 4, 0)) : 1.f;
+                    const float sh = p.shift ? __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rH, me0 * 4, cl * 4, 0)) : 0.f;
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) {
+                        float v = acc[tm][tn][r];
+                        v = p.scale ? fmaf(v, sc, sh) : v + sh;
+                        if (p.relu) v = fmaxf(v, 0.f);
+                        Y[(cl + 4 * half) * LDY + (wn * TN + tn) * 32 + l31] = v;
+                    }
+                }
+        }
+        __syncthreads();
+        constexpr int NCH2 = BM / CB, DA2 = 2;
+        const int ntile2 = p.fuse_M / 32;
+        // this lane's pixel quad: tile-linear pixels 4 l31 .. + 3 = row l31 / 8 of the tile, columns 4 (l31 % 8) ..
+        const int ph = l31 >> 3, pw = 4 * (l31 & 7);
+        const int ho = ho0 + ph, wo = wo0 + pw;
+        const bool pix_ok = img0 < nimg && ho < p.Hout && wo < p.Wout;
+        const unsigned char* const a2 = reinterpret_cast<const unsigned char*>(p.fuse_A_split) + (int64_t)grp * p.fuse_a_grp_stride * 4;
+        const __amdgpu_buffer_rsrc_t rR = bf3_rsrc(p.residual), rS3 = bf3_rsrc(p.fuse_scale), rH3 = bf3_rsrc(p.fuse_shift), rD = bf3_rsrc(p.D);
+        const bool has_res = p.residual != nullptr, has_sc = p.fuse_scale != nullptr, has_sh = p.fuse_shift != nullptr;
+        const float* const yl = Y + (8 * half) * LDY + 4 * l31;
+        for (int mt = wave; mt < ntile2; mt += NTB / 64) {
+            const __amdgpu_buffer_rsrc_t rA2 = bf3_rsrc(a2 + (int64_t)mt * NCH2 * 3072);
+            auto load_a2 = [&](int c, v4i (&ab)[3]) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) ab[pl] = __builtin_amdgcn_raw_buffer_load_b128(rA2, (min(c, NCH2 - 1) * 3 + pl) * 1024 + lane * 16, 0, 0);
+            };
+            v4i ab[DA2][3];
+#pragma unroll
+            for (int d = 0; d < DA2; ++d) load_a2(d, ab[d]);
+            // the tile's epilogue operands, requested before its K loop
+            const int mch = mt * 32 + 4 * half;
+            const int me3 = grp * p.fuse_M + mch;
+            const unsigned off0 = (unsigned)((((int64_t)img0 * p.Ctot + mch) * p.HoWo + ho * p.Wout + wo) * 4);
+            v4i rres[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                rres[r] = __builtin_amdgcn_raw_buffer_load_b128(rR, pix_ok && has_res ? (int)off0 : (int)OOB, ((r & 3) + 8 * (r >> 2)) * p.HoWo * 4, 0);
+            f32x16 acc2[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc2[e][i] = 0.f;
+#pragma unroll
+            for (int c = 0; c < NCH2; ++c) {
+                v4i bq[4][3];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const v4i x0 = *reinterpret_cast<const v4i*>(yl + (c * CB + 2 * i) * LDY);
+                    const v4i x1 = *reinterpret_cast<const v4i*>(yl + (c * CB + 2 * i + 1) * LDY);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        uint32_t H, M, L;
+                        split3_pair(__int_as_float(x0[e]), __int_as_float(x1[e]), H, M, L);
+                        bq[e][0][i] = (int)H, bq[e][1][i] = (int)M, bq[e][2][i] = (int)L;
+                    }
+                }
+                bf16x8 a[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) a[pl] = __builtin_bit_cast(bf16x8, ab[c % DA2][pl]);
+                __builtin_amdgcn_sched_barrier(0);
+                load_a2(c + DA2, ab[c % DA2]);
+                __builtin_amdgcn_sched_barrier(0);
+#define IVLN_BF3_PROD(PA, PB)                           \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e)       \
+        acc2[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA], __builtin_bit_cast(bf16x8, bq[e][PB]), acc2[e], 0, 0, 0)
+                IVLN_BF3_PROD(0, 2);
+                IVLN_BF3_PROD(1, 1);
+                IVLN_BF3_PROD(2, 0);
+                IVLN_BF3_PROD(0, 1);
+                IVLN_BF3_PROD(1, 0);
+                IVLN_BF3_PROD(0, 0);
+#undef IVLN_BF3_PROD
+            }
+            // (the folded bn3 of the tile's channels: 8 x 16 bytes per lane, L2-resident after the first workgroups - asked for
+            //  here, not before the K loop, because 32 more live registers there spill)
+            v4i esc4[4], esh4[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                esc4[g] = __builtin_amdgcn_raw_buffer_load_b128(rS3, has_sc ? me3 * 4 : (int)OOB, g * 32, 0);
+                esh4[g] = __builtin_amdgcn_raw_buffer_load_b128(rH3, has_sh ? me3 * 4 : (int)OOB, g * 32, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cs = (r & 3) + 8 * (r >> 2);
+                float4 v = make_float4(acc2[0][r], acc2[1][r], acc2[2][r], acc2[3][r]);
+                // STRAIGHT-LINE code between the stores (absent scale = 1, absent shift / residual = the zeros the out-of-range
+                // loads returned): a 16-byte buffer store with a scalar offset reads its data registers a few cycles after
+                // it issues, the compiler's hazard recognizer pads for that inside a basic block, and with uniform branches
+                // here it let a VALU write follow the store across a block boundary - lanes 48-63 of one register of one store
+                // stale, once in a few thousand workgroups (found by tools/dbg_fuse.py against the two-launch path).
+                const float sc = has_sc ? __int_as_float(esc4[r >> 2][r & 3]) : 1.f, sh = __int_as_float(esh4[r >> 2][r & 3]);
+                v.x = fmaf(v.x, sc, sh), v.y = fmaf(v.y, sc, sh), v.z = fmaf(v.z, sc, sh), v.w = fmaf(v.w, sc, sh);
+                v.x += __int_as_float(rres[r][0]), v.y += __int_as_float(rres[r][1]), v.z += __int_as_float(rres[r][2]),
+                    v.w += __int_as_float(rres[r][3]);
+                v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);  // (the block's closing ReLU)
+                v4i o;
+                o[0] = __float_as_int(v.x), o[1] = __float_as_int(v.y), o[2] = __float_as_int(v.z), o[3] = __float_as_int(v.w);
+                __builtin_amdgcn_raw_buffer_store_b128(o, rD, pix_ok ? (int)off0 : (int)OOB, cs * p.HoWo * 4, 0);
+                BF3_STORE_GUARD();
+            }
+        }
+        return;
+    }
 
     // ---- epilogue: slabs of 32 channels through LDS.  acc[r] -> channel (r&3) + 8*(r>>2) + 4*half, pixel l31 ----
     float* T = reinterpret_cast<float*>(smem);
@@ -856,25 +996,62 @@ __global__ __launch_bounds__(WT ? 256 : 512, 2) void k_conv1x1_bf3_ks(const ivln
             }
         }
     }
-    // ---- partial tiles through LDS: red[wave][32 channels][4 tiles x 32 columns (+4)]; KS: the eight waves' tiles are summed
-    //      in a fixed order; WT: every wave transposes its own tile (wave-private region, LDS accesses of one wave are in order) ----
-    // The epilogue's global operands (residual quads, scale / shift) are requested FIRST, all of them, and land while the tile
-    // goes through LDS: with one wave per SIMD (a 256-workgroup launch) the 16 items of a wave tile otherwise pay one
-    // dependent memory round trip each - 8 x ~2 us at the end of a 20 us kernel.  Buffer loads whose offset is out of range
-    // for an absent operand or an item outside the tensor: no branch around any of them, so nothing makes the compiler drain
-    // the queue between two requests.
+    // ---- epilogue.
+    // WT: straight from the accumulators.  Tile e holds pixel 4 l31 + e in column l31, so register r of the four tiles IS the
+    // float4 of channel (r & 3) + 8 (r >> 2) + 4 half at pixels 4 l31 .. + 3: one 16-byte store per register, 512 contiguous
+    // bytes per half-wave, no LDS, no transposition.  The channel step of register r rides in the scalar offset of the
+    // buffer accesses (the range check ignores it).  The operands (residual quads, scale / shift) are requested FIRST, all of
+    // them: with one wave per SIMD every dependent round trip would otherwise sit exposed at the end of a 20 us kernel.
+    // KS: the eight waves' partial tiles meet in LDS - red[wave][32 channels][4 tiles x 32 columns (+4)] -, summed in a fixed order. ----
 #ifdef BF3_TIMING
     const unsigned long long ts2 = lane == 0 ? wall_clock64() : 0ull;
 #endif
-    constexpr int ITEMS = WT ? 16 : 2;  // 32 channels x 32 pixel quads = 1024 items: over a wave's 64 lanes | the workgroup's 512 threads
-    constexpr int HALF_ITEMS = WT ? 8 : 2;  // WT: the second half's operands are requested once the accumulators have left for LDS (registers)
+    if constexpr (WT) {
+        const int n = n0 + 4 * l31;
+        const int img = min(n, p.N - 1) / HW, pp = n - img * HW;
+        const int mrem = n < p.N ? p.M - m0 - 4 * half : 0;  // register r is inside the tensor iff its channel step is below this
+        const int me0 = (p.grp_imgs > 0 ? (img / p.grp_imgs) * p.M : 0) + m0 + 4 * half;
+        const unsigned off0 = (unsigned)(((img * p.Ctot + m0 + 4 * half) * HW + pp) * 4);
+        const __amdgpu_buffer_rsrc_t rR = bf3_rsrc(p.residual), rS = bf3_rsrc(p.scale), rH = bf3_rsrc(p.shift), rD = bf3_rsrc(p.D);
+        const bool has_res = p.residual != nullptr, has_sc = p.scale != nullptr, has_sh = p.shift != nullptr;
+        const float relu_lo = p.relu ? 0.f : -__builtin_huge_valf();
+        v4i rres[16];
+        float esc[16], esh[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cs = (r & 3) + 8 * (r >> 2);  // channel step of the register
+            const bool ok = cs < mrem;
+            esc[r] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rS, ok && has_sc ? me0 * 4 : (int)OOB, cs * 4, 0));
+            esh[r] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rH, ok && has_sh ? me0 * 4 : (int)OOB, cs * 4, 0));
+            rres[r] = __builtin_amdgcn_raw_buffer_load_b128(rR, ok && has_res ? (int)off0 : (int)OOB, cs * HW * 4, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cs = (r & 3) + 8 * (r >> 2);
+            float4 v = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+            // STRAIGHT-LINE code between the stores (absent scale = 1, absent shift / residual = the zeros the out-of-range loads
+            // returned; `accumulate` is declined by the launcher): see the fused tail of k_conv_bf3 for what a uniform branch
+            // behind a 16-byte buffer store with a scalar offset does to the store's data registers.
+            const float sc = has_sc ? esc[r] : 1.f, sh = esh[r];
+            v.x = fmaf(v.x, sc, sh), v.y = fmaf(v.y, sc, sh), v.z = fmaf(v.z, sc, sh), v.w = fmaf(v.w, sc, sh);
+            v.x += __int_as_float(rres[r][0]), v.y += __int_as_float(rres[r][1]), v.z += __int_as_float(rres[r][2]),
+                v.w += __int_as_float(rres[r][3]);
+            const float lo = relu_lo;  // 0 with ReLU, -inf without: fmaxf(x, -inf) == x
+            v.x = fmaxf(v.x, lo), v.y = fmaxf(v.y, lo), v.z = fmaxf(v.z, lo), v.w = fmaxf(v.w, lo);
+            v4i o;
+            o[0] = __float_as_int(v.x), o[1] = __float_as_int(v.y), o[2] = __float_as_int(v.z), o[3] = __float_as_int(v.w);
+            __builtin_amdgcn_raw_buffer_store_b128(o, rD, cs < mrem ? (int)off0 : (int)OOB, cs * HW * 4, 0);
+            BF3_STORE_GUARD();
+        }
+    } else {
+    constexpr int ITEMS = 2;  // 32 channels x 32 pixel quads = 1024 items over the workgroup's 512 threads
     v4i rres[ITEMS];
     float esc[ITEMS], esh[ITEMS];
     int eoff[ITEMS];  // element offset of the item's quad in D / residual (< 2^29: checked by the launcher), -1 = outside
     const __amdgpu_buffer_rsrc_t rR = bf3_rsrc(p.residual), rS = bf3_rsrc(p.scale), rH = bf3_rsrc(p.shift);
     const bool has_res = p.residual != nullptr, has_sc = p.scale != nullptr, has_sh = p.shift != nullptr;
     auto request = [&](int it) {
-        const int item = WT ? lane + it * 64 : t + it * 512, ml = item >> 5, q = item & 31;
+        const int item = t + it * 512, ml = item >> 5, q = item & 31;
         const int m = m0 + ml, n = n0 + 4 * q;
         const bool ok = m < p.M && n < p.N;
         const int img = n / HW, pp = n - img * HW;
@@ -886,29 +1063,22 @@ __global__ __launch_bounds__(WT ? 256 : 512, 2) void k_conv1x1_bf3_ks(const ivln
         rres[it] = __builtin_amdgcn_raw_buffer_load_b128(rR, ok && has_res ? off * 4 : (int)OOB, 0, 0);
     };
 #pragma unroll
-    for (int it = 0; it < HALF_ITEMS; ++it) request(it);
+    for (int it = 0; it < ITEMS; ++it) request(it);
     float* const red = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             red[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * LDT + tn * 32 + l31] = acc[tn][r];
-    if constexpr (!WT) __syncthreads();
-#pragma unroll
-    for (int it = HALF_ITEMS; it < ITEMS; ++it) request(it);
+    __syncthreads();
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
-        const int item = WT ? lane + it * 64 : t + it * 512, ml = item >> 5, q = item & 31;
+        const int item = t + it * 512, ml = item >> 5, q = item & 31;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (WT) {
-            const float* rr = red + (wave * 32 + ml) * LDT + q;
-            v = make_float4(rr[0], rr[32], rr[64], rr[96]);  // tile e, column q = pixel 4 q + e
-        } else {
 #pragma unroll
-            for (int w = 0; w < NW; ++w) {  // fixed order
-                const float* rr = red + (w * 32 + ml) * LDT + q;
-                v.x += rr[0], v.y += rr[32], v.z += rr[64], v.w += rr[96];
-            }
+        for (int w = 0; w < NW; ++w) {  // fixed order; tile e, column q = pixel 4 q + e
+            const float* rr = red + (w * 32 + ml) * LDT + q;
+            v.x += rr[0], v.y += rr[32], v.z += rr[64], v.w += rr[96];
         }
         if (eoff[it] >= 0) {
             const int64_t addr = eoff[it];
@@ -926,6 +1096,7 @@ __global__ __launch_bounds__(WT ? 256 : 512, 2) void k_conv1x1_bf3_ks(const ivln
             if (p.relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
             *reinterpret_cast<float4*>(p.D + addr) = v;
         }
+    }
     }
 #ifdef BF3_TIMING
     if (lane == 0) {  // one record per wave: prologue round trip, K loop, epilogue (100 MHz wall clock), start offset of the wave
@@ -958,6 +1129,7 @@ int bf3_1x1_ks_launch(ivln_gemm_desc& d, hipStream_t s, int mode, int form_pin =
     if (form_env) wt = form_env[0] == 'w';
     if (form_pin >= 0) wt = form_pin == 1;
     if (wt && nch > 64) wt = false;
+    if (wt && d.accumulate) return IVLN_E_UNSUPPORTED;  // (the wave-tile epilogue is straight-line code: no D += form)
     const int64_t mtiles = (d.M + 31) / 32;
     const int64_t wgs = wt ? (int64_t)((d.N + 511) / 512) * mtiles : (int64_t)((d.N + 127) / 128) * mtiles;
     static const int maxwg_env = getenv("IVLN_BF3_1X1_MAXWG") ? atoi(getenv("IVLN_BF3_1X1_MAXWG")) : 2;  // tuning: rounds of one workgroup per CU
@@ -972,12 +1144,7 @@ int bf3_1x1_ks_launch(ivln_gemm_desc& d, hipStream_t s, int mode, int form_pin =
     const unsigned char* a = (const unsigned char*)d.A_split;
     const long long gb = (long long)(d.a_split_grp_stride * 4);
     if (wt) {
-        constexpr size_t lds = (size_t)4 * 32 * (128 + 4) * 4;
-        static bool attr_done = false;
-        if (!attr_done) {
-            if (hipFuncSetAttribute((const void*)k_conv1x1_bf3_ks<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return IVLN_E_HIP;
-            attr_done = true;
-        }
+        constexpr size_t lds = 0;  // (the wave-tile form keeps everything in registers)
         dim3 grid((unsigned)mtiles, (unsigned)((d.N + 511) / 512), 1);
         IVLN_LAUNCH_FAMILY(k_conv1x1_bf3_ks<true>, grid, dim3(256), lds, s, d, a, gb);
     } else {
@@ -1031,6 +1198,25 @@ int launch_bf3(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a_sp
     const int groups = (nimg + IMGS - 1) / IMGS;
     dim3 grid(tiles_w * tiles_h * groups, (d.M + BM - 1) / BM, d.splits);
     IVLN_LAUNCH_FAMILY(kern, grid, dim3(NTB), lds, s, d, a_split, (long long)grp_bytes, tiles_w, tiles_h, nimg, cps);
+    return IVLN_OK;
+}
+
+// The fused bottleneck tail (ivln_gemm_desc.fuse_*): the 64 x 128 / 128 x 128 tiles of the 3x3 kernel with the 1x1 expansion behind.
+template <int TM, int DA>
+int launch_bf3_fused(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a_split, int64_t grp_bytes, int nimg) {
+    constexpr int KS = 3, WM = 2, WN = 2, PTH = 4, PTW = 32, NTB = 256, BM = 32 * TM * WM, BN = 128;
+    constexpr int NPIX = (PTH + 2) * (PTW + 2);
+    constexpr size_t ybytes = (size_t)BM * (BN + 4) * 4, lds = (size_t)NPIX * PIXB > ybytes ? (size_t)NPIX * PIXB : ybytes;
+    auto kern = k_conv_bf3<KS, TM, WM, WN, PTH, PTW, 1, DA, true>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return IVLN_E_HIP;
+        attr_done = true;
+    }
+    const int tiles_w = d.Wout / PTW, tiles_h = d.Hout / PTH;
+    dim3 grid(tiles_w * tiles_h * nimg, 1, 1);
+    const int nch = d.Cin / CB;
+    IVLN_LAUNCH_FAMILY(kern, grid, dim3(NTB), lds, s, d, a_split, (long long)grp_bytes, tiles_w, tiles_h, nimg, nch);
     return IVLN_OK;
 }
 
@@ -1430,6 +1616,20 @@ int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
         return IVLN_E_UNSUPPORTED;
     const int nimg = d.N / d.HoWo;
     if ((int64_t)nimg * d.in_img_stride >= (int64_t)1 << 31) return IVLN_E_UNSUPPORTED;  // 32-bit patch offsets
+    if (d.fuse_A_split) {  // the bottleneck tail: this 3x3 conv + the 1x1 expansion behind it in one launch (k_conv_bf3<..., FUSE>)
+        static const bool fuse_off = getenv("IVLN_BF3_FUSE") && getenv("IVLN_BF3_FUSE")[0] == '0';  // A/B switch
+        if (fuse_off || KS != 3 || (d.M != 64 && d.M != 128) || d.Cin % CB != 0 || d.Wout % 32 != 0 || d.Hout % 4 != 0 || d.fuse_M <= 0 ||
+            d.fuse_M % 32 != 0 || d.stat_partials || d.accumulate || !d.relu || d.img_run_flags)
+            return IVLN_E_UNSUPPORTED;
+        if ((int64_t)nimg * d.Ctot * d.HoWo * 4 >= (int64_t)1 << 31 || (d.grp_imgs > 0 && nimg % d.grp_imgs != 0)) return IVLN_E_UNSUPPORTED;
+        d.splits = 1;
+        const unsigned char* a = (const unsigned char*)d.A_split;
+        const int64_t gb = d.a_split_grp_stride * 4;
+        const int rc = d.M == 64 ? launch_bf3_fused<1, 3>(d, s, a, gb, nimg) : launch_bf3_fused<2, 3>(d, s, a, gb, nimg);
+        if (rc == IVLN_OK) g_bf3_flops += 2.0 * d.M * (double)d.N * d.K + 2.0 * d.fuse_M * (double)d.N * d.M, ++g_bf3_launches, ++g_bf3_kind[0];
+        if (rc == IVLN_OK && d.stat_tiles) *d.stat_tiles = 0;
+        return rc;
+    }
     // pixel-starved deep 3x3 convs: K split over the waves of a workgroup, no slabs (k_conv_bf3_ks); IVLN_BF3_KS=0 | 1 = never | wherever eligible
     static const int ks_env = getenv("IVLN_BF3_KS") ? atoi(getenv("IVLN_BF3_KS")) : -1;
     if (KS == 3 && ov < 20 && (ks_env != 0 || ins3) && d.splits <= 1) {

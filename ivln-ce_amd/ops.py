@@ -43,6 +43,7 @@ class GemmDesc(C.Structure):
         ("A_split", vp), ("a_split_grp_stride", i64),
         ("split_ok", i32),
         ("img_run_flags", vp),
+        ("fuse_A_split", vp), ("fuse_a_grp_stride", i64), ("fuse_scale", vp), ("fuse_shift", vp), ("fuse_M", i32),
     ]
 
 
@@ -461,6 +462,50 @@ def conv2d(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, 
             stats.append((sp, n_tiles.value))
         return out
     gemm(d)
+    return out
+
+
+BF3_FUSE = os.environ.get("IVLN_BF3_FUSE", "1") != "0"
+
+
+def conv3x3_then_1x1(x, w2, scale2, shift2, w3, scale3, shift3, residual):
+    """A bottleneck's tail as ONE launch (rednet.py:20-65): relu(bn3(conv1x1(relu(bn2(conv3x3(x))))) + residual), the folded
+    BatchNorms given as scale / shift.  Weights (Cout, Cin, 3, 3) / (Cout3, Cout, 1, 1), or image-grouped (G, ...) pairs.
+    Returns None when the library declines the shape (ivln_gemm_desc.fuse_*: 64 or 128 mid channels, stride 1, width a
+    multiple of 32, height of 4) - the caller then issues the two convs."""
+    if not (BF3_FUSE and SPLIT_BF16) or TILE_OVERRIDE:
+        return None
+    N, Cin, H, W = x.shape
+    G = w2.shape[0] if w2.dim() == 5 else 0
+    Cmid, Cout = w2.shape[-4], w3.shape[-4]
+    if (Cmid not in (64, 128) or w2.shape[-1] != 3 or w3.shape[-1] != 1 or w3.shape[-3] != Cmid or W % 32 or H % 4 or Cin % 16 or Cout % 32
+            or (w3.dim() == 5) != bool(G) or not (w2.is_contiguous() and w3.is_contiguous() and x.is_contiguous()) or (G and N % G)):
+        return None
+    sp2, sp3 = packed_conv_weights(w2, split=True), packed_conv_weights(w3, split=True)
+    if sp2 is None or sp3 is None:
+        return None
+    out = torch.empty((N, Cout, H, W), dtype=torch.float32, device=x.device)
+    d = GemmDesc()
+    d.A, d.B, d.D = dptr(w2), _p(x), _p(out)
+    d.M, d.N, d.K = Cmid, N * H * W, Cin * 9
+    d.amode, d.bmode, d.dmode = A_MK, B_CONV_K3, D_NCHW
+    d.lda = d.K
+    d.Cin, d.Hin, d.Win, d.Hout, d.Wout = Cin, H, W, H, W
+    d.stride, d.pad, d.dil = 1, 1, 1
+    d.HoWo, d.Ctot = H * W, Cout
+    if G:
+        d.grp_imgs, d.a_grp_stride = N // G, Cmid * Cin * 9
+    d.A_split, d.a_split_grp_stride = dptr(sp2), sp2.numel() // max(G, 1)
+    d.fuse_A_split, d.fuse_a_grp_stride, d.fuse_M = dptr(sp3), sp3.numel() // max(G, 1), Cout
+    d.fuse_scale, d.fuse_shift = dptr(scale3), dptr(shift3)
+    _epilogue(d, scale2, shift2, residual, True)
+    d.splits = 1
+    rc = _L().ivln_gemm_f32(C.byref(d), stream_ptr())
+    if rc == _lib.IVLN_E_UNSUPPORTED:
+        return None
+    check(rc, "ivln_gemm_f32 (fused bottleneck tail)")
+    if _REC is not None:
+        _rec(OP_GEMM, gemm=d)
     return out
 
 

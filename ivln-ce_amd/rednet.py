@@ -98,9 +98,13 @@ class Bottleneck(nn.Module):
         s, b = f.bn(self.bn1)
         y = ops.conv2d(x, self.conv1.weight, scale=s, shift=b, relu=True)
         s, b = f.bn(self.bn2)
+        s3, b3 = f.bn(self.bn3)
+        if self.stride == 1:
+            out = ops.conv3x3_then_1x1(y, self.conv2.weight, s, b, self.conv3.weight, s3, b3, residual)
+            if out is not None:
+                return out
         y = ops.conv2d(y, self.conv2.weight, stride=self.stride, pad=1, scale=s, shift=b, relu=True)
-        s, b = f.bn(self.bn3)
-        return ops.conv2d(y, self.conv3.weight, scale=s, shift=b, residual=residual, relu=True)
+        return ops.conv2d(y, self.conv3.weight, scale=s3, shift=b3, residual=residual, relu=True)
 
 
 def _conv_pair(x2, w2, s2, b2, stride=1, pad=0, residual=None, relu=False):
@@ -130,9 +134,13 @@ def _bottleneck_pair(blk: Bottleneck, blk_d: Bottleneck, x2, f: _Folded):
     w, s, b = f.pair(blk.conv1, blk.bn1, blk_d.conv1, blk_d.bn1)
     y = _conv_pair(x2, w, s, b, relu=True)
     w, s, b = f.pair(blk.conv2, blk.bn2, blk_d.conv2, blk_d.bn2)
+    w3, s3, b3 = f.pair(blk.conv3, blk.bn3, blk_d.conv3, blk_d.bn3)
+    if blk.stride == 1:  # layers 1-2: conv2 + conv3 (+ residual + ReLU) as one launch, the narrow tensor stays on the CU
+        out = ops.conv3x3_then_1x1(y, w, s, b, w3, s3, b3, residual)
+        if out is not None:
+            return out
     y = _conv_pair(y, w, s, b, stride=blk.stride, pad=1, relu=True)
-    w, s, b = f.pair(blk.conv3, blk.bn3, blk_d.conv3, blk_d.bn3)
-    return _conv_pair(y, w, s, b, residual=residual, relu=True)
+    return _conv_pair(y, w3, s3, b3, residual=residual, relu=True)
 
 
 class TransBasicBlock(nn.Module):

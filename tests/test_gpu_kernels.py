@@ -395,6 +395,48 @@ def test_conv2d_split_bf16_kernel(N, Cin, H, W, Cout, k):
     assert float(wide_k[:, :4].abs().max()) == 0.0 and float(wide_k[:, 4 + Cout:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("N,Cin,Cmid,Cout,H,W,G", [(2, 64, 64, 256, 32, 32, 0), (2, 128, 128, 512, 8, 32, 0), (4, 64, 64, 256, 16, 64, 2),
+                                                   (3, 48, 64, 96, 4, 32, 0), (2, 128, 128, 512, 32, 32, 2)])
+def test_bottleneck_tail_as_one_launch(N, Cin, Cmid, Cout, H, W, G):
+    """k_conv_bf3<..., FUSE> (ivln_gemm_desc.fuse_*): a ResNet bottleneck's conv2 3x3 + bn2 + ReLU + conv3 1x1 + bn3 + residual +
+    ReLU (rednet.py:20-65) in one launch, the mid tensor in LDS only.  Against the float64 composition (the bar of the split-bf16
+    kernels) and against the two separate launches (same arithmetic, same order per accumulator: equal to rounding of the mid
+    tensor's different summation order at most); image-grouped weight pairs (the stacked RGB + depth encoders); a ragged
+    channel count in front (48) and behind (96); run-to-run identical bits."""
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(N * 1000 + Cmid + W)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    sh2, sh3 = ((G, Cmid, Cin, 3, 3), (G, Cout, Cmid, 1, 1)) if G else ((Cmid, Cin, 3, 3), (Cout, Cmid, 1, 1))
+    w2 = torch.randn(*sh2, generator=g) / (Cin * 9) ** 0.5
+    w3 = torch.randn(*sh3, generator=g) / Cmid ** 0.5
+    GG = max(G, 1)
+    s2, b2 = torch.rand(GG * Cmid, generator=g) + 0.5, torch.randn(GG * Cmid, generator=g)
+    s3, b3 = torch.rand(GG * Cout, generator=g) + 0.5, torch.randn(GG * Cout, generator=g)
+    res = torch.randn(N, Cout, H, W, generator=g)
+    B = N // GG
+    outs = []
+    for i in range(GG):
+        xi = x[i * B:(i + 1) * B].double()
+        wa, wb = (w2[i], w3[i]) if G else (w2, w3)
+        y = F.relu(F.conv2d(xi, wa.double(), None, padding=1) * s2[i * Cmid:(i + 1) * Cmid].double().view(1, -1, 1, 1)
+                   + b2[i * Cmid:(i + 1) * Cmid].double().view(1, -1, 1, 1))
+        z = F.conv2d(y, wb.double()) * s3[i * Cout:(i + 1) * Cout].double().view(1, -1, 1, 1) + b3[i * Cout:(i + 1) * Cout].double().view(1, -1, 1, 1)
+        outs.append(F.relu(z + res[i * B:(i + 1) * B].double()))
+    ref = torch.cat(outs)
+    d = [v.to(DEV) for v in (x, w2, s2, b2, w3, s3, b3, res)]
+    got = ops.conv3x3_then_1x1(*d)
+    assert got is not None, "the library declined an eligible shape"
+    again = ops.conv3x3_then_1x1(*d)
+    y = ops.conv2d(d[0], d[1], pad=1, scale=d[2], shift=d[3], relu=True)
+    two = ops.conv2d(y, d[4], scale=d[5], shift=d[6], residual=d[7], relu=True)
+    _close(got, ref.float(), 3e-5)
+    assert torch.equal(got, again)
+    assert float((got - two).abs().max()) <= 2e-5 * float(ref.abs().max())
+    # shapes the kernel does not take come back as None (the caller then issues the two convs)
+    assert ops.conv3x3_then_1x1(d[0][:, :, :, :16].contiguous(), *d[1:7], d[7][:, :, :, :16].contiguous()) is None
+
+
 @pytest.mark.parametrize("N,Cin,H,Cout,G", [(8, 512, 8, 512, 0), (8, 256, 16, 256, 0), (4, 128, 32, 128, 0), (16, 256, 16, 256, 2),
                                            (3, 144, 8, 96, 0), (2, 128, 16, 40, 0), (1, 128, 32, 64, 0), (32, 128, 8, 256, 0)])
 def test_conv2d_split_bf16_k_split_over_waves(N, Cin, H, Cout, G):
