@@ -465,6 +465,18 @@ def conv2d(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, 
     return out
 
 
+_ALL_ROWS = {}
+
+
+def all_rows_flags(rows, device):
+    """int32 ones (rows) on the device: the `run_flags` of a conv that recomputes every image (long-lived: captured graphs
+    hold the address)."""
+    k = (str(device), int(rows))
+    if k not in _ALL_ROWS:
+        _ALL_ROWS[k] = torch.ones((int(rows),), dtype=torch.int32, device=device)
+    return _ALL_ROWS[k]
+
+
 BF3_FUSE = os.environ.get("IVLN_BF3_FUSE", "1") != "0"
 
 

@@ -275,7 +275,10 @@ class MapCMANet(Net):
                     ops.conv2d(t.view(r_, -1, 1, L_), wf.view(wf.shape[0], -1, 1, 1), shift=bf, splitk=False, out=cache.fold,
                                run_flags=cache.dirty)
                     return t, ln, cache.fold.view(r_, -1, L_)
-                fold = ops.conv2d(t.view(r_, -1, 1, L_), wf.view(wf.shape[0], -1, 1, 1), shift=bf, splitk=False)
+                # (no cache: every row is "dirty" - the same kernel as the cached call, so that the two agree bit for bit
+                #  whatever the tile heuristics make of a plain 1x1 conv of this shape)
+                fold = ops.conv2d(t.view(r_, -1, 1, L_), wf.view(wf.shape[0], -1, 1, 1), shift=bf, splitk=False,
+                                  run_flags=ops.all_rows_flags(r_, t.device))
                 return t, ln, fold.view(r_, -1, L_)
             tk_ = ops.conv2d(t.view(r_, -1, 1, L_), self.text_k.weight.view(h2, -1, 1, 1), shift=self.text_k.bias,
                              splitk=False)

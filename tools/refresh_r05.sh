@@ -27,10 +27,14 @@ timeout 300 python tools/conv_bf3_phases.py > $O/conv_bf3_phases.txt 2>&1
 IVLN_SPLIT_BF16=0 timeout 300 python bench.py --no-cpu-baseline --no-collect --reps 3 > $O/bench_fp32_only.json 2> $O/bench_fp32_only.err
 # A/B of this round's kernels inside ONE call (boxes differ by ~6 %): the pred-semantics step without each of them
 P5="--no-update --no-collect --no-gt-leg --no-cpu-baseline --reps 3"
-for v in "IVLN_X=1" "IVLN_BF3_KS=0" "IVLN_BF3_1X1_KS=0" "IVLN_CACHE_INSTRUCTION=0" "IVLN_X=1"; do
+for v in "IVLN_X=1" "IVLN_BF3_KS=0" "IVLN_BF3_1X1_KS=0" "IVLN_BF3_FUSE=0" "IVLN_BF3_NOSPLIT4=0" "IVLN_BF3_KS_TN=2" "IVLN_CACHE_INSTRUCTION=0" "IVLN_X=1"; do
   env $v timeout 300 python bench.py $P5 2>/dev/null | grep -o '"ms_per_step": [0-9.]*' | head -1 | sed "s/^/$v /"
 done > $O/predsem_ab.txt 2>&1
 timeout 300 python tools/update_torch_ops.py > $O/update_torch_ops.txt 2>&1
+# the wave-split kernels' per-wave phases, the pipe's issue rate, and every candidate kernel / tile per RedNet shape as replayed graphs
+timeout 600 python tools/conv_bf3_ks_phases.py 2>&1 | grep -v amdgpu.ids > $O/conv_bf3_ks_phases.txt
+timeout 60 tools/mfma_rate > $O/mfma_rate.txt 2>&1
+timeout 900 python tools/conv_cfg_sweep.py 2>&1 | grep -v amdgpu.ids > $O/conv_cfg_sweep.txt
 # where the split replay's time goes (end of each graph, per step), with and without the per-episode instruction cache
 for B in 4 8; do
   for m in 1 0; do echo "== gt envs $B IVLN_CACHE_INSTRUCTION=$m"; IVLN_CACHE_INSTRUCTION=$m timeout 200 python tools/split_probe.py gt $B 2>&1 | tail -2; done
@@ -38,6 +42,7 @@ done > $O/split_probe.txt 2>&1
 echo "== pred envs 8" >> $O/split_probe.txt; timeout 200 python tools/split_probe.py pred 8 2>&1 | tail -2 >> $O/split_probe.txt
 # --- kernel traces ---
 run predsem --kernel-trace -d $O/predsem -- python3 bench.py --steps 50 --warmup 5 --reps 1 $PRED;               stats predsem predsem_B8_graph_kernel_stats.csv
+f=$(find $O/predsem -name "*.db" | head -1); [ -n "$f" ] && python tools/step_timeline.py $f > $O/predsem_B8_step_timeline.txt 2>&1
 run graph   --kernel-trace -d $O/graph   -- python3 bench.py --steps 200 --warmup 20 --reps 1 $GT;               stats graph rollout_graph_kernel_stats.csv
 run eager   --kernel-trace -d $O/eager   -- python3 bench.py --steps 200 --warmup 20 --reps 1 $GT --no-graph;    stats eager rollout_eager_kernel_stats.csv
 run update  --kernel-trace -d $O/update  -- python3 bench.py --only-update --steps 5;                            stats update update_T64N8_kernel_stats.csv
