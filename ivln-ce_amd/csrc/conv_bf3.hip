@@ -34,6 +34,7 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
 
 constexpr int PIXB = 112;   // bytes per staged pixel: 3 pieces x 16 channels x 2 bytes + 16 of padding
 constexpr int CB = 16;      // input channels per chunk = K of one MFMA
@@ -385,7 +386,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
     // Same arithmetic, same order per accumulator as the two separate launches; the planes-channel tensor never leaves the CU
     // (written + read once per block before: 2 x 4 B x planes x pixels), one launch and one prologue / epilogue less. ----
     if constexpr (FUSE) {
-        static_assert(KS == 3 && IMGS == 1 && PTW == 32 && BN == 128 && NTB == 256, "the fused tail is built for the 4 x 32 pixel tile");
+        static_assert(KS == 3 && IMGS == 1 && PTW == 32 && (BN == 128 || BN == 64) && NTB == 256, "the fused tail is built for the 4 x 32 and 2 x 32 pixel tiles");
+        constexpr int Q = BN / 32;  // consecutive pixels of a lane in the second stage = pixel tiles of its B fragments (4 | 2)
         constexpr int LDY = BN + 4;
         float* const Y = reinterpret_cast<float*>(smem);
         {
@@ -410,14 +412,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
         __syncthreads();
         constexpr int NCH2 = BM / CB, DA2 = 2;
         const int ntile2 = p.fuse_M / 32;
-        // this lane's pixel quad: tile-linear pixels 4 l31 .. + 3 = row l31 / 8 of the tile, columns 4 (l31 % 8) ..
-        const int ph = l31 >> 3, pw = 4 * (l31 & 7);
+        // this lane's pixels: tile-linear Q l31 .. + Q - 1 = row Q l31 / 32 of the tile, columns (Q l31) % 32 ..
+        const int ph = (Q * l31) >> 5, pw = (Q * l31) & 31;
         const int ho = ho0 + ph, wo = wo0 + pw;
         const bool pix_ok = img0 < nimg && ho < p.Hout && wo < p.Wout;
         const unsigned char* const a2 = reinterpret_cast<const unsigned char*>(p.fuse_A_split) + (int64_t)grp * p.fuse_a_grp_stride * 4;
         const __amdgpu_buffer_rsrc_t rR = bf3_rsrc(p.residual), rS3 = bf3_rsrc(p.fuse_scale), rH3 = bf3_rsrc(p.fuse_shift), rD = bf3_rsrc(p.D);
         const bool has_res = p.residual != nullptr, has_sc = p.fuse_scale != nullptr, has_sh = p.fuse_shift != nullptr;
-        const float* const yl = Y + (8 * half) * LDY + 4 * l31;
+        const float* const yl = Y + (8 * half) * LDY + Q * l31;
         for (int mt = wave; mt < ntile2; mt += NTB / 64) {
             const __amdgpu_buffer_rsrc_t rA2 = bf3_rsrc(a2 + (int64_t)mt * NCH2 * 3072);
             auto load_a2 = [&](int c, v4i (&ab)[3]) {
@@ -431,26 +433,44 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
             const int mch = mt * 32 + 4 * half;
             const int me3 = grp * p.fuse_M + mch;
             const unsigned off0 = (unsigned)((((int64_t)img0 * p.Ctot + mch) * p.HoWo + ho * p.Wout + wo) * 4);
-            v4i rres[16];
+            float rres[16][Q];
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                rres[r] = __builtin_amdgcn_raw_buffer_load_b128(rR, pix_ok && has_res ? (int)off0 : (int)OOB, ((r & 3) + 8 * (r >> 2)) * p.HoWo * 4, 0);
-            f32x16 acc2[4];
+            for (int r = 0; r < 16; ++r) {
+                const int ro = pix_ok && has_res ? (int)off0 : (int)OOB, so = ((r & 3) + 8 * (r >> 2)) * p.HoWo * 4;
+                if constexpr (Q == 4) {
+                    const v4i t4 = __builtin_amdgcn_raw_buffer_load_b128(rR, ro, so, 0);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                    for (int e = 0; e < Q; ++e) rres[r][e] = __int_as_float(t4[e]);
+                } else {
+                    const v2i t2 = __builtin_amdgcn_raw_buffer_load_b64(rR, ro, so, 0);
+#pragma unroll
+                    for (int e = 0; e < Q; ++e) rres[r][e] = __int_as_float(t2[e]);
+                }
+            }
+            f32x16 acc2[Q];
+#pragma unroll
+            for (int e = 0; e < Q; ++e)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc2[e][i] = 0.f;
 #pragma unroll
             for (int c = 0; c < NCH2; ++c) {
-                v4i bq[4][3];
+                v4i bq[Q][3];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const v4i x0 = *reinterpret_cast<const v4i*>(yl + (c * CB + 2 * i) * LDY);
-                    const v4i x1 = *reinterpret_cast<const v4i*>(yl + (c * CB + 2 * i + 1) * LDY);
+                    float x0[Q], x1[Q];
+                    if constexpr (Q == 4) {
+                        const v4i t0 = *reinterpret_cast<const v4i*>(yl + (c * CB + 2 * i) * LDY), t1 = *reinterpret_cast<const v4i*>(yl + (c * CB + 2 * i + 1) * LDY);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
+                        for (int e = 0; e < Q; ++e) x0[e] = __int_as_float(t0[e]), x1[e] = __int_as_float(t1[e]);
+                    } else {
+                        const v2i t0 = *reinterpret_cast<const v2i*>(yl + (c * CB + 2 * i) * LDY), t1 = *reinterpret_cast<const v2i*>(yl + (c * CB + 2 * i + 1) * LDY);
+#pragma unroll
+                        for (int e = 0; e < Q; ++e) x0[e] = __int_as_float(t0[e]), x1[e] = __int_as_float(t1[e]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < Q; ++e) {
                         uint32_t H, M, L;
-                        split3_pair(__int_as_float(x0[e]), __int_as_float(x1[e]), H, M, L);
+                        split3_pair(x0[e], x1[e], H, M, L);
                         bq[e][0][i] = (int)H, bq[e][1][i] = (int)M, bq[e][2][i] = (int)L;
                     }
                 }
@@ -461,7 +481,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
                 load_a2(c + DA2, ab[c % DA2]);
                 __builtin_amdgcn_sched_barrier(0);
 #define IVLN_BF3_PROD(PA, PB)                           \
-    _Pragma("unroll") for (int e = 0; e < 4; ++e)       \
+    _Pragma("unroll") for (int e = 0; e < Q; ++e)       \
         acc2[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA], __builtin_bit_cast(bf16x8, bq[e][PB]), acc2[e], 0, 0, 0)
                 IVLN_BF3_PROD(0, 2);
                 IVLN_BF3_PROD(1, 1);
@@ -482,20 +502,28 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int cs = (r & 3) + 8 * (r >> 2);
-                float4 v = make_float4(acc2[0][r], acc2[1][r], acc2[2][r], acc2[3][r]);
+                float v[Q];
+#pragma unroll
+                for (int e = 0; e < Q; ++e) v[e] = acc2[e][r];
                 // STRAIGHT-LINE code between the stores (absent scale = 1, absent shift / residual = the zeros the out-of-range
                 // loads returned): a 16-byte buffer store with a scalar offset reads its data registers a few cycles after
                 // it issues, the compiler's hazard recognizer pads for that inside a basic block, and with uniform branches
                 // here it let a VALU write follow the store across a block boundary - lanes 48-63 of one register of one store
                 // stale, once in a few thousand workgroups (found by tools/dbg_fuse.py against the two-launch path).
                 const float sc = has_sc ? __int_as_float(esc4[r >> 2][r & 3]) : 1.f, sh = __int_as_float(esh4[r >> 2][r & 3]);
-                v.x = fmaf(v.x, sc, sh), v.y = fmaf(v.y, sc, sh), v.z = fmaf(v.z, sc, sh), v.w = fmaf(v.w, sc, sh);
-                v.x += __int_as_float(rres[r][0]), v.y += __int_as_float(rres[r][1]), v.z += __int_as_float(rres[r][2]),
-                    v.w += __int_as_float(rres[r][3]);
-                v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);  // (the block's closing ReLU)
-                v4i o;
-                o[0] = __float_as_int(v.x), o[1] = __float_as_int(v.y), o[2] = __float_as_int(v.z), o[3] = __float_as_int(v.w);
-                __builtin_amdgcn_raw_buffer_store_b128(o, rD, pix_ok ? (int)off0 : (int)OOB, cs * p.HoWo * 4, 0);
+#pragma unroll
+                for (int e = 0; e < Q; ++e) v[e] = fmaxf(fmaf(v[e], sc, sh) + rres[r][e], 0.f);  // (bn3, residual, the block's closing ReLU)
+                if constexpr (Q == 4) {
+                    v4i o;
+#pragma unroll
+                    for (int e = 0; e < Q; ++e) o[e] = __float_as_int(v[e]);
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rD, pix_ok ? (int)off0 : (int)OOB, cs * p.HoWo * 4, 0);
+                } else {
+                    v2i o;
+#pragma unroll
+                    for (int e = 0; e < Q; ++e) o[e] = __float_as_int(v[e]);
+                    __builtin_amdgcn_raw_buffer_store_b64(o, rD, pix_ok ? (int)off0 : (int)OOB, cs * p.HoWo * 4, 0);
+                }
                 BF3_STORE_GUARD();
             }
         }
@@ -1202,9 +1230,10 @@ int launch_bf3(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a_sp
 }
 
 // The fused bottleneck tail (ivln_gemm_desc.fuse_*): the 64 x 128 / 128 x 128 tiles of the 3x3 kernel with the 1x1 expansion behind.
-template <int TM, int DA>
+template <int TM, int WM, int WN, int DA>
 int launch_bf3_fused(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a_split, int64_t grp_bytes, int nimg) {
-    constexpr int KS = 3, WM = 2, WN = 2, PTH = 4, PTW = 32, NTB = 256, BM = 32 * TM * WM, BN = 128;
+    constexpr int KS = 3, PTW = 32, NTB = 64 * WM * WN, BM = 32 * TM * WM, BN = 64 * WN, PTH = BN / PTW;
+    static_assert(NTB == 256, "four waves");
     constexpr int NPIX = (PTH + 2) * (PTW + 2);
     constexpr size_t ybytes = (size_t)BM * (BN + 4) * 4, lds = (size_t)NPIX * PIXB > ybytes ? (size_t)NPIX * PIXB : ybytes;
     auto kern = k_conv_bf3<KS, TM, WM, WN, PTH, PTW, 1, DA, true>;
@@ -1625,7 +1654,13 @@ int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
         d.splits = 1;
         const unsigned char* a = (const unsigned char*)d.A_split;
         const int64_t gb = d.a_split_grp_stride * 4;
-        const int rc = d.M == 64 ? launch_bf3_fused<1, 3>(d, s, a, gb, nimg) : launch_bf3_fused<2, 3>(d, s, a, gb, nimg);
+        // tiles: 64 or 128 channels x 128 pixels (4 x 32); 128 channels x 64 pixels (2 x 32, four waves of 32 channels) where the
+        // 128-pixel grid would leave CUs without a workgroup (layer 2 at 8 + 8 images: 128 workgroups); IVLN_BF3_FUSE_PX pins (tuning)
+        static const int px_env = getenv("IVLN_BF3_FUSE_PX") ? atoi(getenv("IVLN_BF3_FUSE_PX")) : 0;
+        const int64_t wg128 = (int64_t)nimg * (d.Wout / 32) * (d.Hout / 4);
+        const bool px64 = d.M == 128 && d.Hout % 2 == 0 && (px_env ? px_env == 64 : wg128 < ivln_cu_count());
+        const int rc = d.M == 64 ? launch_bf3_fused<1, 2, 2, 3>(d, s, a, gb, nimg)
+                       : (px64 ? launch_bf3_fused<1, 4, 1, 3>(d, s, a, gb, nimg) : launch_bf3_fused<2, 2, 2, 3>(d, s, a, gb, nimg));
         if (rc == IVLN_OK) g_bf3_flops += 2.0 * d.M * (double)d.N * d.K + 2.0 * d.fuse_M * (double)d.N * d.M, ++g_bf3_launches, ++g_bf3_kind[0];
         if (rc == IVLN_OK && d.stat_tiles) *d.stat_tiles = 0;
         return rc;

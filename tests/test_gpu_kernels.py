@@ -396,13 +396,15 @@ def test_conv2d_split_bf16_kernel(N, Cin, H, W, Cout, k):
 
 
 @pytest.mark.parametrize("N,Cin,Cmid,Cout,H,W,G", [(2, 64, 64, 256, 32, 32, 0), (2, 128, 128, 512, 8, 32, 0), (4, 64, 64, 256, 16, 64, 2),
-                                                   (3, 48, 64, 96, 4, 32, 0), (2, 128, 128, 512, 32, 32, 2)])
+                                                   (3, 48, 64, 96, 4, 32, 0), (2, 128, 128, 512, 32, 32, 2), (32, 128, 128, 256, 32, 32, 2)])
 def test_bottleneck_tail_as_one_launch(N, Cin, Cmid, Cout, H, W, G):
     """k_conv_bf3<..., FUSE> (ivln_gemm_desc.fuse_*): a ResNet bottleneck's conv2 3x3 + bn2 + ReLU + conv3 1x1 + bn3 + residual +
     ReLU (rednet.py:20-65) in one launch, the mid tensor in LDS only.  Against the float64 composition (the bar of the split-bf16
     kernels) and against the two separate launches (same arithmetic, same order per accumulator: equal to rounding of the mid
     tensor's different summation order at most); image-grouped weight pairs (the stacked RGB + depth encoders); a ragged
-    channel count in front (48) and behind (96); run-to-run identical bits."""
+    channel count in front (48) and behind (96); run-to-run identical bits.  128 mid channels take the 128 x 64-pixel tile
+    (four waves of 32 channels, two pixels per lane in the second stage) while the 128-pixel grid would leave CUs idle, the
+    128 x 128 tile from 256 workgroups on (the 32-image case)."""
     from ivln_ce_amd import ops
 
     g = torch.Generator().manual_seed(N * 1000 + Cmid + W)

@@ -26,6 +26,13 @@ CASES = [
     ("IVLN_NO_SPLIT_BF16_WGRAD", "1", UPDATE),           # fp32 MFMA weight gradients
     ("IVLN_BF3_KS", "0", ROLLOUT),                       # deep 3x3 convs on the tiled split-bf16 kernel + split-K slabs
     ("IVLN_BF3_KS", "1", ROLLOUT),                       # ... on the K-split-over-waves kernel wherever eligible
+    ("IVLN_BF3_KS_TN", "1", ROLLOUT),                    # ... with 32-pixel tiles everywhere
+    ("IVLN_BF3_KS_TN", "2", ROLLOUT),                    # ... with 64-pixel tiles everywhere
+    ("IVLN_BF3_1X1_KS", "0", ROLLOUT),                   # stride-1 1x1 convs without the register-built forms
+    ("IVLN_BF3_1X1_FORM", "ks", ROLLOUT),                # ... K split over waves wherever a form is taken
+    ("IVLN_BF3_1X1_FORM", "wt", ROLLOUT),                # ... wave tiles wherever a form is taken
+    ("IVLN_BF3_FUSE", "0", ROLLOUT),                     # bottleneck tails as two launches
+    ("IVLN_BF3_NOSPLIT4", "0", ROLLOUT + UPDATE),        # the 64 x 128 tile split over the channel chunks as in round 4
     ("IVLN_DEPTH_NET", "0", ROLLOUT),                    # depth encoder: launch chain
     ("IVLN_DEPTH_NET", "2", ROLLOUT),                    # ... persistent launch everywhere
     ("IVLN_GN_CONV", "0", ROLLOUT),                      # ... conv + GroupNorm pairs (with IVLN_DEPTH_NET=0 below)

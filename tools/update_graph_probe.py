@@ -15,6 +15,7 @@ from ivln_ce_amd.aux_losses import AuxLosses  # noqa: E402
 
 dev = torch.device("cuda:0")
 policy = bench.make_policy(dev)
+policy = policy[1] if isinstance(policy, tuple) else policy
 leg = bench.UpdateLeg(policy, dev, 1)
 AuxLosses.activate()
 obs, prev, nd, tgt, w = leg.args
