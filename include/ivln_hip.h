@@ -221,6 +221,11 @@ typedef struct ivln_gemm_desc {
     const float* fuse_scale;
     const float* fuse_shift;
     int fuse_M;
+    /* 1: `residual` is added AFTER the ReLU - D = relu(scale * acc + shift) + residual - the form of RedNet's decoder skips
+     * (rednet.py:244-263: x = deconv(x) + agant(fuse), the 1x1 "agant" conv ending in a ReLU): the separate add launch goes.
+     * Taken by the stride-1 1x1 split-bf16 kernels only (csrc/conv_bf3.hip: k_conv1x1_bf3_ks); any other route returns
+     * IVLN_E_UNSUPPORTED and the caller issues conv + add. */
+    int residual_after_relu;
 } ivln_gemm_desc;
 
 int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream);

@@ -1043,6 +1043,7 @@ __global__ __launch_bounds__(WT ? 256 : 512, 2) void k_conv1x1_bf3_ks(const ivln
         const __amdgpu_buffer_rsrc_t rR = bf3_rsrc(p.residual), rS = bf3_rsrc(p.scale), rH = bf3_rsrc(p.shift), rD = bf3_rsrc(p.D);
         const bool has_res = p.residual != nullptr, has_sc = p.scale != nullptr, has_sh = p.shift != nullptr;
         const float relu_lo = p.relu ? 0.f : -__builtin_huge_valf();
+        const bool res_post = p.residual_after_relu != 0;
         v4i rres[16];
         float esc[16], esh[16];
 #pragma unroll
@@ -1062,10 +1063,13 @@ __global__ __launch_bounds__(WT ? 256 : 512, 2) void k_conv1x1_bf3_ks(const ivln
             // behind a 16-byte buffer store with a scalar offset does to the store's data registers.
             const float sc = has_sc ? esc[r] : 1.f, sh = esh[r];
             v.x = fmaf(v.x, sc, sh), v.y = fmaf(v.y, sc, sh), v.z = fmaf(v.z, sc, sh), v.w = fmaf(v.w, sc, sh);
-            v.x += __int_as_float(rres[r][0]), v.y += __int_as_float(rres[r][1]), v.z += __int_as_float(rres[r][2]),
-                v.w += __int_as_float(rres[r][3]);
+            // the residual in front of the ReLU (a bottleneck's identity) or behind it (ivln_gemm_desc.residual_after_relu: the
+            // decoder's skip adds) - selects, no branch
+            const float r0 = __int_as_float(rres[r][0]), r1 = __int_as_float(rres[r][1]), r2 = __int_as_float(rres[r][2]), r3 = __int_as_float(rres[r][3]);
+            v.x += res_post ? 0.f : r0, v.y += res_post ? 0.f : r1, v.z += res_post ? 0.f : r2, v.w += res_post ? 0.f : r3;
             const float lo = relu_lo;  // 0 with ReLU, -inf without: fmaxf(x, -inf) == x
             v.x = fmaxf(v.x, lo), v.y = fmaxf(v.y, lo), v.z = fmaxf(v.z, lo), v.w = fmaxf(v.w, lo);
+            v.x += res_post ? r0 : 0.f, v.y += res_post ? r1 : 0.f, v.z += res_post ? r2 : 0.f, v.w += res_post ? r3 : 0.f;
             v4i o;
             o[0] = __float_as_int(v.x), o[1] = __float_as_int(v.y), o[2] = __float_as_int(v.z), o[3] = __float_as_int(v.w);
             __builtin_amdgcn_raw_buffer_store_b128(o, rD, cs < mrem ? (int)off0 : (int)OOB, cs * HW * 4, 0);
@@ -1114,7 +1118,8 @@ __global__ __launch_bounds__(WT ? 256 : 512, 2) void k_conv1x1_bf3_ks(const ivln
             if (p.scale) v.x = fmaf(v.x, sc, sh), v.y = fmaf(v.y, sc, sh), v.z = fmaf(v.z, sc, sh), v.w = fmaf(v.w, sc, sh);
             else if (p.shift) v.x += sh, v.y += sh, v.z += sh, v.w += sh;
             // (absent residual: the out-of-range loads returned zeros, but adding them would turn a -0 into +0: the branch stays)
-            if (p.residual)
+            const bool res_pre = p.residual && !p.residual_after_relu, res_post = p.residual && p.residual_after_relu;
+            if (res_pre)
                 v.x += __int_as_float(rres[it][0]), v.y += __int_as_float(rres[it][1]), v.z += __int_as_float(rres[it][2]),
                     v.w += __int_as_float(rres[it][3]);
             if (p.accumulate) {
@@ -1122,6 +1127,9 @@ __global__ __launch_bounds__(WT ? 256 : 512, 2) void k_conv1x1_bf3_ks(const ivln
                 v.x += ra.x, v.y += ra.y, v.z += ra.z, v.w += ra.w;
             }
             if (p.relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+            if (res_post)  // (ivln_gemm_desc.residual_after_relu: the decoder's skip adds)
+                v.x += __int_as_float(rres[it][0]), v.y += __int_as_float(rres[it][1]), v.z += __int_as_float(rres[it][2]),
+                    v.w += __int_as_float(rres[it][3]);
             *reinterpret_cast<float4*>(p.D + addr) = v;
         }
     }
@@ -1623,7 +1631,8 @@ int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
     // (tuning, tools/conv_cfg_sweep.py: tile_override 12 / 13 insist on the K-split / wave-tile form, 14 / 15 on 32- / 64-pixel tiles
     //  of the 3x3 K-split kernel, 20 + c on tile c of the tiled kernel)
     const int ov = d.tile_override;
-    const bool ins1 = ov == 11 || ov == 12 || ov == 13, ins3 = ov == 10 || ov == 14 || ov == 15;
+    const bool post = d.residual_after_relu != 0;  // (only the stride-1 1x1 kernels below know this epilogue form: they are insisted on)
+    const bool ins1 = ov == 11 || ov == 12 || ov == 13 || post, ins3 = ov == 10 || ov == 14 || ov == 15;
     if (KS == 1 && ov < 20 && (ks1_env != 0 || ins1) && d.splits <= 1 && !d.defer_epilogue && d.HoWo == d.Hout * d.Wout &&
         d.K == d.Cin && d.N % d.HoWo == 0 && d.Hout == d.Hin && d.Wout == d.Win) {
         const int rc = bf3_1x1_ks_launch(d, s, (ks1_env == 1 || ins1) ? 1 : 0, ov == 12 ? 0 : (ov == 13 ? 1 : -1));

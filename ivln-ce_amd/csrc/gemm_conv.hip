@@ -504,6 +504,14 @@ extern "C" int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream) {
         d.A_split = nullptr;
         if (d.tile_override == 0) d.tile_override = ivln_gemm_vec_eligible(d) ? 7 : 1;
     }
+    // residual behind the ReLU: only the stride-1 1x1 split-bf16 kernels have that epilogue form
+    if (d.residual_after_relu) {
+        if (!d.A_split || !d.residual || d.defer_epilogue || d.dmode != DMODE_NCHW || d.fuse_A_split || d.accumulate) return IVLN_E_UNSUPPORTED;
+        const int rc = ivln_conv_bf3_launch(d, s, true);
+        if (rc != IVLN_OK) return rc;
+        if (d.splits_used) *d.splits_used = 1;
+        return hipGetLastError() == hipSuccess ? IVLN_OK : IVLN_E_HIP;
+    }
     // a fused bottleneck tail (fuse_*): only conv_bf3.hip runs it; anything else would silently drop the 1x1 half
     if (d.fuse_A_split) {
         if (!d.A_split || d.defer_epilogue || d.dmode != DMODE_NCHW) return IVLN_E_UNSUPPORTED;

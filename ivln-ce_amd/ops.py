@@ -44,6 +44,7 @@ class GemmDesc(C.Structure):
         ("split_ok", i32),
         ("img_run_flags", vp),
         ("fuse_A_split", vp), ("fuse_a_grp_stride", i64), ("fuse_scale", vp), ("fuse_shift", vp), ("fuse_M", i32),
+        ("residual_after_relu", i32),
     ]
 
 
@@ -363,11 +364,14 @@ def conv_stat_ws(device, floats):
 
 
 def conv2d(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, relu=False, out=None, out_ctot=0,
-           in_img_stride=0, splitk=True, defer=False, ws_slot=0, weight_is_temp=False, stats=None, run_flags=None):
+           in_img_stride=0, splitk=True, defer=False, ws_slot=0, weight_is_temp=False, stats=None, run_flags=None,
+           residual_after_relu=False):
     """NCHW conv: x (N,Cin,H,W) [contiguous per image, image stride `in_img_stride`], w OIHW.
     out: optional destination (a channel slice of an (N,out_ctot,Ho,Wo) buffer).
     run_flags: optional int32 (N) on the device - output tiles all of whose images carry 0 are skipped and `out` (then a
-    persistent buffer of the caller) keeps what it held (ivln_gemm_desc.img_run_flags)."""
+    persistent buffer of the caller) keeps what it held (ivln_gemm_desc.img_run_flags).
+    residual_after_relu: out = relu(scale * conv + shift) + residual (RedNet's decoder skips); only the stride-1 1x1
+    split-bf16 kernels have that epilogue - returns None when the library declines (the caller issues conv + add)."""
     N, Cin, H, W = x.shape
     G = w.shape[0] if w.dim() == 5 else 0  # (G, Cout, Cin, k, k): weight set g for images [g*N/G, (g+1)*N/G)
     Cout, _, KH, KW = w.shape[-4:]
@@ -410,7 +414,7 @@ def conv2d(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, 
         want_1x1 = TILE_OVERRIDE >= 9 or SPLIT_BF16_1X1 == 1 or (SPLIT_BF16_1X1 != 0 and (big_1x1 or deep_1x1))
         if (want_1x1 and SPLIT_BF16 and stride in (1, 2) and (Cin >= 128 or deep_1x1) and (Cout >= 64 or deep_1x1 or TILE_OVERRIDE in (11, 12, 13)) and Wo % 4 == 0
                 and (Wo >= 8 or deep_1x1 or TILE_OVERRIDE in (11, 12, 13)) and w.is_contiguous()
-                and not defer and (N * Ho * Wo * Cout >= SPLIT_BF16_MIN_OUT or TILE_OVERRIDE >= 9)):
+                and not defer and (N * Ho * Wo * Cout >= SPLIT_BF16_MIN_OUT or TILE_OVERRIDE >= 9 or residual_after_relu)):
             sp = packed_conv_weights(w, cache=not weight_is_temp, split=True)
             if sp is not None:
                 d.A_split = dptr(sp)
@@ -452,6 +456,17 @@ def conv2d(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, 
         d.ws, d.ws_floats, d.splits = dptr(ws), ws.numel(), 0
     else:
         d.splits = 1
+    if residual_after_relu:
+        if residual is None or defer or stats is not None or run_flags is not None or TILE_OVERRIDE:
+            return None
+        d.residual_after_relu, d.splits = 1, 1
+        rc = _L().ivln_gemm_f32(C.byref(d), stream_ptr())
+        if rc == _lib.IVLN_E_UNSUPPORTED:
+            return None
+        check(rc, "ivln_gemm_f32 (residual behind the ReLU)")
+        if _REC is not None:
+            _rec(OP_GEMM, gemm=d)
+        return out
     if stats is not None:  # `stats` = a list: receives (partials, tiles) when the launch produced per-tile statistics
         tiles_max = (N * Ho * Wo + 31) // 32  # (pixel tiles hold 128 outputs; 4x headroom for ragged tilings)
         sp = conv_stat_ws(x.device, tiles_max * Cout * 3)
@@ -509,7 +524,7 @@ def conv3x3_then_1x1(x, w2, scale2, shift2, w3, scale3, shift3, residual):
         d.grp_imgs, d.a_grp_stride = N // G, Cmid * Cin * 9
     d.A_split, d.a_split_grp_stride = dptr(sp2), sp2.numel() // max(G, 1)
     d.fuse_A_split, d.fuse_a_grp_stride, d.fuse_M = dptr(sp3), sp3.numel() // max(G, 1), Cout
-    d.fuse_scale, d.fuse_shift = dptr(scale3), dptr(shift3)
+    d.fuse_scale, d.fuse_shift = _p(scale3), _p(shift3)
     _epilogue(d, scale2, shift2, residual, True)
     d.splits = 1
     rc = _L().ivln_gemm_f32(C.byref(d), stream_ptr())

@@ -75,6 +75,9 @@ def _convt(x, convt: nn.ConvTranspose2d, f: _Folded, **epi):
     return ops.conv_transpose2d(x, f.wt(convt), convt.stride[0], convt.padding[0], convt.output_padding[0], **epi)
 
 
+SKIP_ADD_FUSED = os.environ.get("IVLN_REDNET_SKIP_ADD", "1") != "0"  # A/B: 0 = the decoder's skip adds as launches of their own
+
+
 class Bottleneck(nn.Module):
     expansion = 4
 
@@ -268,6 +271,13 @@ class RedNet(nn.Module):
         s, b = self._folded.bn(layer[1])
         return ops.conv2d(x, layer[0].weight, scale=s, shift=b, relu=True)
 
+    def _skip_add(self, up, layer, fuse):
+        """up + agant(fuse) (rednet.py:244-263): the 1x1 skip conv with the decoder tensor added behind its ReLU in the same
+        launch where the library has that epilogue, else conv + add."""
+        s, b = self._folded.bn(layer[1])
+        out = ops.conv2d(fuse, layer[0].weight, scale=s, shift=b, residual=up, relu=True, residual_after_relu=True) if SKIP_ADD_FUSED else None
+        return out if out is not None else ops.add(up, self._agant(layer, fuse))
+
     def forward(self, rgb, depth):
         """rgb (B,3,H,W) normalised, depth (B,1,H,W) normalised -> scores (B,classes,H,W)
         (rednet.py:190-269, eval path)."""
@@ -310,10 +320,9 @@ class RedNet(nn.Module):
             x, d = self._seq(self.layer4, fuse3), self._seq(self.layer4_d, d)
             fuse4 = ops.add(x, d)
         x = self._agant(self.agant4, fuse4)
-        x = ops.add(self._seq(self.deconv1, x), self._agant(self.agant3, fuse3))
-        x = ops.add(self._seq(self.deconv2, x), self._agant(self.agant2, fuse2))
-        x = ops.add(self._seq(self.deconv3, x), self._agant(self.agant1, fuse1))
-        x = ops.add(self._seq(self.deconv4, x), self._agant(self.agant0, fuse0))
+        for seq, ag, fuse in ((self.deconv1, self.agant3, fuse3), (self.deconv2, self.agant2, fuse2),
+                              (self.deconv3, self.agant1, fuse1), (self.deconv4, self.agant0, fuse0)):
+            x = self._skip_add(self._seq(seq, x), ag, fuse)
         x = self._seq(self.final_conv, x)
         fd = self.final_deconv_custom
         return _convt(x, fd, f, shift=fd.bias)

@@ -213,6 +213,7 @@ int ivln_gemm_f32(const ivln_gemm_desc *desc, void *stream) {
     if (!desc || !desc->A || !desc->B || !desc->D || desc->M <= 0 || desc->N <= 0 || desc->K <= 0) return IVLN_E_INVALID;
     ivln_gemm_desc d = *desc;
     if (d.bmode == IVLN_B_IM2COL_T || d.bmode == IVLN_B_CONVT || d.defer_epilogue) return IVLN_E_UNSUPPORTED;
+    if (d.residual_after_relu) return IVLN_E_UNSUPPORTED; /* (the decoder-skip epilogue form: no twin, callers issue conv + add) */
     if (d.fuse_A_split) return IVLN_E_UNSUPPORTED; /* the fused bottleneck tail reads device-packed split weights: no twin (callers issue the two convs) */
     if (d.HoWo <= 0) d.HoWo = 1;
     if (d.dil <= 0) d.dil = 1;

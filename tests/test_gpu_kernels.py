@@ -395,6 +395,35 @@ def test_conv2d_split_bf16_kernel(N, Cin, H, W, Cout, k):
     assert float(wide_k[:, :4].abs().max()) == 0.0 and float(wide_k[:, 4 + Cout:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("N,Cin,Cout,H,W,form", [(2, 64, 64, 32, 32, 13), (2, 256, 64, 16, 16, 13), (2, 512, 128, 8, 16, 12), (1, 1024, 256, 8, 8, 12),
+                                                 (3, 80, 40, 4, 8, 13)])
+def test_conv1x1_split_bf16_residual_behind_the_relu(N, Cin, Cout, H, W, form):
+    """ivln_gemm_desc.residual_after_relu: relu(scale * conv + shift) + residual in the 1x1 kernel's epilogue - RedNet's decoder
+    skips (rednet.py:244-263: x = deconv(x) + agant(fuse)) without the add launch.  Both forms of k_conv1x1_bf3_ks: bit-identical
+    to the same form followed by the add kernel; within the split-bf16 bar of the float64 composition; a conv the 1x1 kernels do
+    not take (3x3) comes back as None."""
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(Cin + Cout + H)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    up = torch.randn(N, Cout, H, W, generator=g)
+    ref = F.relu(F.conv2d(x.double(), w.double()) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)) + up.double()
+    d = [v.to(DEV) for v in (x, w, sc, sh, up)]
+    got = ops.conv2d(d[0], d[1], scale=d[2], shift=d[3], residual=d[4], relu=True, residual_after_relu=True)
+    assert got is not None, "the library declined an eligible shape"
+    try:
+        ops.TILE_OVERRIDE = form  # the same form, then the add kernel
+        two = ops.add(d[4], ops.conv2d(d[0], d[1], scale=d[2], shift=d[3], relu=True))
+    finally:
+        ops.TILE_OVERRIDE = 0
+    _close(got, ref.float(), 3e-5)
+    assert torch.equal(got, two)
+    w3 = torch.randn(Cout, Cin, 3, 3, generator=g).to(DEV)
+    assert ops.conv2d(d[0], w3, pad=1, scale=d[2], shift=d[3], residual=d[4], relu=True, residual_after_relu=True) is None
+
+
 @pytest.mark.parametrize("N,Cin,Cmid,Cout,H,W,G", [(2, 64, 64, 256, 32, 32, 0), (2, 128, 128, 512, 8, 32, 0), (4, 64, 64, 256, 16, 64, 2),
                                                    (3, 48, 64, 96, 4, 32, 0), (2, 128, 128, 512, 32, 32, 2), (32, 128, 128, 256, 32, 32, 2)])
 def test_bottleneck_tail_as_one_launch(N, Cin, Cmid, Cout, H, W, G):

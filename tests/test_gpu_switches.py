@@ -32,6 +32,7 @@ CASES = [
     ("IVLN_BF3_1X1_FORM", "ks", ROLLOUT),                # ... K split over waves wherever a form is taken
     ("IVLN_BF3_1X1_FORM", "wt", ROLLOUT),                # ... wave tiles wherever a form is taken
     ("IVLN_BF3_FUSE", "0", ROLLOUT),                     # bottleneck tails as two launches
+    ("IVLN_REDNET_SKIP_ADD", "0", ROLLOUT),              # the decoder's skip adds as launches of their own
     ("IVLN_BF3_NOSPLIT4", "0", ROLLOUT + UPDATE),        # the 64 x 128 tile split over the channel chunks as in round 4
     ("IVLN_DEPTH_NET", "0", ROLLOUT),                    # depth encoder: launch chain
     ("IVLN_DEPTH_NET", "2", ROLLOUT),                    # ... persistent launch everywhere
