@@ -121,6 +121,15 @@ class GemmTimer:
                 return
             self.flops += 2 * desc.M * desc.N * desc.K
 
+        self.orig_soft = ops.gemm_soft
+
+        def timed_soft(desc):
+            """descriptors only some kernels take (a fused bottleneck tail: the 3x3 conv + the 1x1 conv behind it)"""
+            ok = self.orig_soft(desc)
+            if ok:
+                self.flops += 2 * desc.M * desc.N * desc.K + 2 * desc.fuse_M * desc.N * desc.M * (1 if desc.fuse_A_split else 0)
+            return ok
+
         self.orig_gn_conv = ops.gn_conv
 
         def timed_gn_conv(x, gn, **kw):
@@ -163,6 +172,7 @@ class GemmTimer:
 
         depth_net.DepthNetPlan.run = timed_dn_run
         ops.gemm = timed
+        ops.gemm_soft = timed_soft
         ops.gn_conv = timed_gn_conv
         ops.nconv = timed_nconv
         self._lib.ivln_conv_split_counters.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]
@@ -173,6 +183,7 @@ class GemmTimer:
 
     def __exit__(self, *a):
         self.ops.gemm = self.orig
+        self.ops.gemm_soft = self.orig_soft
         self.ops.gn_conv = self.orig_gn_conv
         self.ops.nconv = self.orig_nconv
         self.depth_net.DepthNetPlan.run = self.orig_dn_run

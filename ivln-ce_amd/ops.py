@@ -211,6 +211,18 @@ def gemm(desc: GemmDesc):
         _rec(OP_GEMM, gemm=desc)
 
 
+def gemm_soft(desc: GemmDesc) -> bool:
+    """ivln_gemm_f32 for descriptors that only some kernels take (fuse_*, residual_after_relu): False when the library
+    declines (IVLN_E_UNSUPPORTED: the caller takes its other route), True when the launch went out."""
+    rc = _L().ivln_gemm_f32(C.byref(desc), stream_ptr())
+    if rc == _lib.IVLN_E_UNSUPPORTED:
+        return False
+    check(rc, "ivln_gemm_f32")
+    if _REC is not None:
+        _rec(OP_GEMM, gemm=desc)
+    return True
+
+
 _WORK_STREAMS = {}
 EAGER_WORK_STREAM = os.environ.get("IVLN_EAGER_WORK_STREAM", "1") != "0"
 
@@ -460,13 +472,7 @@ def conv2d(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, 
         if residual is None or defer or stats is not None or run_flags is not None or TILE_OVERRIDE:
             return None
         d.residual_after_relu, d.splits = 1, 1
-        rc = _L().ivln_gemm_f32(C.byref(d), stream_ptr())
-        if rc == _lib.IVLN_E_UNSUPPORTED:
-            return None
-        check(rc, "ivln_gemm_f32 (residual behind the ReLU)")
-        if _REC is not None:
-            _rec(OP_GEMM, gemm=d)
-        return out
+        return out if gemm_soft(d) else None
     if stats is not None:  # `stats` = a list: receives (partials, tiles) when the launch produced per-tile statistics
         tiles_max = (N * Ho * Wo + 31) // 32  # (pixel tiles hold 128 outputs; 4x headroom for ragged tilings)
         sp = conv_stat_ws(x.device, tiles_max * Cout * 3)
@@ -527,13 +533,7 @@ def conv3x3_then_1x1(x, w2, scale2, shift2, w3, scale3, shift3, residual):
     d.fuse_scale, d.fuse_shift = _p(scale3), _p(shift3)
     _epilogue(d, scale2, shift2, residual, True)
     d.splits = 1
-    rc = _L().ivln_gemm_f32(C.byref(d), stream_ptr())
-    if rc == _lib.IVLN_E_UNSUPPORTED:
-        return None
-    check(rc, "ivln_gemm_f32 (fused bottleneck tail)")
-    if _REC is not None:
-        _rec(OP_GEMM, gemm=d)
-    return out
+    return out if gemm_soft(d) else None
 
 
 def bn_stats_from_partials(partials, tiles, bn, scale, shift, save_mean=None, save_rstd=None, update_running=True):
