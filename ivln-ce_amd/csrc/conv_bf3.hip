@@ -1162,6 +1162,10 @@ int bf3_1x1_ks_launch(ivln_gemm_desc& d, hipStream_t s, int mode, int form_pin =
     // form with short slices); IVLN_BF3_1X1_FORM = ks | wt pins one (tuning)
     static const char* form_env = getenv("IVLN_BF3_1X1_FORM");
     bool wt = nch <= 16;
+    // (32 chunks over MANY pixels - 256 x 16384 x 512, layer 3's first reduction at 8 + 8 images - would be four rounds of one
+    //  K-split workgroup per CU: the wave tiles take it, 43.6 against 51.5 us on the tiled 1x1 form and 52.1 K-split, tools/conv_cfg_sweep.py)
+    static const int maxwg0 = getenv("IVLN_BF3_1X1_MAXWG") ? atoi(getenv("IVLN_BF3_1X1_MAXWG")) : 2;
+    if (nch == 32 && (int64_t)((d.N + 127) / 128) * ((d.M + 31) / 32) > maxwg0 * (int64_t)ivln_cu_count()) wt = true;
     if (form_env) wt = form_env[0] == 'w';
     if (form_pin >= 0) wt = form_pin == 1;
     if (wt && nch > 64) wt = false;

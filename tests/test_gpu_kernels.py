@@ -113,6 +113,13 @@ def test_pools_and_map_features():
     g = torch.Generator().manual_seed(1)
     x = torch.randn(2, 5, 33, 40, generator=g)
     _close(ops.pool2d(x.to(DEV), 3, 2, 1, "max"), F.max_pool2d(x, 3, 2, 1), 0)
+    # MaxPool2d(3, 2, 1) on widths that are multiples of 8 (RedNet's stem): four outputs per thread from 16-byte loads - exact,
+    # odd heights, the pad value never leaks (a row / column of -inf), widths that take the generic kernel beside it
+    for shape in [(2, 5, 16, 16), (3, 4, 23, 8), (2, 64, 128, 128), (1, 3, 10, 40), (1, 2, 9, 12)]:
+        xw = torch.randn(*shape, generator=g)
+        xw[0, 0, 0, :] = float("-inf")
+        xw[0, 0, :, 0] = float("-inf")
+        assert torch.equal(ops.pool2d(xw.to(DEV), 3, 2, 1, "max").cpu(), F.max_pool2d(xw, 3, 2, 1)), shape
     x2 = torch.randn(2, 1, 64, 64, generator=g)
     _close(ops.pool2d(x2.to(DEV), 2, 2, 0, "avg"), F.avg_pool2d(x2, 2), 1e-6)
     occ = (torch.rand(3, 64, 64, generator=g) < 0.5).to(torch.uint8)
