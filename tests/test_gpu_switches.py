@@ -15,6 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 ROLLOUT = ["tests/test_gpu_policy.py::test_act_matches_reference_golden", "tests/test_gpu_rednet.py::test_rednet_matches_reference_golden",
            "tests/test_gpu_policy.py::test_act_matches_oracle_other_batches"]
+# (the split-bf16 kernel forms only engage at RedNet's real size: their switches also run the full-size comparison with the oracle)
+FULLSIZE = ROLLOUT + ["tests/test_gpu_rednet.py::test_rednet_fullsize_matches_oracle_and_pred_mapper_is_exact"]
 UPDATE = ["tests/test_gpu_train.py::test_reference_style_update_matches_golden",
           "tests/test_gpu_train.py::test_hip_update_agent_matches_reference_loss_and_moves_params"]
 
@@ -24,16 +26,18 @@ CASES = [
     ("IVLN_SPLIT_BF16_1X1", "1", ROLLOUT),               # the split-bf16 1x1 form wherever eligible
     ("IVLN_SPLIT_BF16_1X1", "0", ROLLOUT),
     ("IVLN_NO_SPLIT_BF16_WGRAD", "1", UPDATE),           # fp32 MFMA weight gradients
-    ("IVLN_BF3_KS", "0", ROLLOUT),                       # deep 3x3 convs on the tiled split-bf16 kernel + split-K slabs
-    ("IVLN_BF3_KS", "1", ROLLOUT),                       # ... on the K-split-over-waves kernel wherever eligible
-    ("IVLN_BF3_KS_TN", "1", ROLLOUT),                    # ... with 32-pixel tiles everywhere
-    ("IVLN_BF3_KS_TN", "2", ROLLOUT),                    # ... with 64-pixel tiles everywhere
-    ("IVLN_BF3_1X1_KS", "0", ROLLOUT),                   # stride-1 1x1 convs without the register-built forms
-    ("IVLN_BF3_1X1_FORM", "ks", ROLLOUT),                # ... K split over waves wherever a form is taken
-    ("IVLN_BF3_1X1_FORM", "wt", ROLLOUT),                # ... wave tiles wherever a form is taken
-    ("IVLN_BF3_FUSE", "0", ROLLOUT),                     # bottleneck tails as two launches
-    ("IVLN_REDNET_SKIP_ADD", "0", ROLLOUT),              # the decoder's skip adds as launches of their own
-    ("IVLN_BF3_NOSPLIT4", "0", ROLLOUT + UPDATE),        # the 64 x 128 tile split over the channel chunks as in round 4
+    ("IVLN_BF3_KS", "0", FULLSIZE),                       # deep 3x3 convs on the tiled split-bf16 kernel + split-K slabs
+    ("IVLN_BF3_KS", "1", FULLSIZE),                       # ... on the K-split-over-waves kernel wherever eligible
+    ("IVLN_BF3_KS_TN", "1", FULLSIZE),                    # ... with 32-pixel tiles everywhere
+    ("IVLN_BF3_KS_TN", "2", FULLSIZE),                    # ... with 64-pixel tiles everywhere
+    ("IVLN_BF3_1X1_KS", "0", FULLSIZE),                   # stride-1 1x1 convs without the register-built forms
+    ("IVLN_BF3_1X1_FORM", "ks", FULLSIZE),                # ... K split over waves wherever a form is taken
+    ("IVLN_BF3_1X1_FORM", "wt", FULLSIZE),                # ... wave tiles wherever a form is taken
+    ("IVLN_BF3_FUSE", "0", FULLSIZE),                     # bottleneck tails as two launches
+    ("IVLN_BF3_FUSE_PX", "128", FULLSIZE),                # ... fused, 128 mid channels on the 128 x 128-pixel tile
+    ("IVLN_BF3_FUSE_PX", "64", FULLSIZE),                 # ... on the 128 x 64-pixel tile
+    ("IVLN_REDNET_SKIP_ADD", "0", FULLSIZE),              # the decoder's skip adds as launches of their own
+    ("IVLN_BF3_NOSPLIT4", "0", FULLSIZE + UPDATE),        # the 64 x 128 tile split over the channel chunks as in round 4
     ("IVLN_DEPTH_NET", "0", ROLLOUT),                    # depth encoder: launch chain
     ("IVLN_DEPTH_NET", "2", ROLLOUT),                    # ... persistent launch everywhere
     ("IVLN_GN_CONV", "0", ROLLOUT),                      # ... conv + GroupNorm pairs (with IVLN_DEPTH_NET=0 below)
