@@ -1725,6 +1725,11 @@ int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
     if (d.tile_override >= 20 && d.tile_override < 20 + kBf3Cfgs) cfg = d.tile_override - 20;  // (tuning: tools/conv_cfg_sweep.py pins a tile)
     if ((cfg == 0 && !big_ok) || (KS == 1 && (cfg <= 1 || cfg == 6))) return IVLN_E_UNSUPPORTED;
     const int64_t nb = blocks_of(cfg);
+    // a pixel tile is rows x columns of ONE image (or whole small images): a Conv1d-shaped input (H = 1: the policy's k / v
+    // projections, 384 x 8192 x 192 in an update) would fill 1 row of 16 - 427 us for 1.2 GFLOP, found in round 5 after the
+    // 1x1 eligibility had been widened.  Tilings that use less than 15 % of their pixels go back to the fp32 GEMMs (at 21 % -
+    // 256 x 40960 x 256 as rows of 80 - this kernel still wins: 66.7 against 80.3 us).
+    if (!force && (double)d.N < 0.15 * (double)tiles_of(cfg) * kBf3BN[cfg]) return IVLN_E_UNSUPPORTED;
     if (cfg >= 4) {
         const int slots = cfg == 4 ? 3 : 2;
         const bool may_split = d.splits == 0 && d.ws && nch >= 2 && !d.stat_partials;

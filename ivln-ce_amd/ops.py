@@ -422,7 +422,8 @@ def conv2d(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, 
         # (round 5) stride-1 1x1 convs on k_conv1x1_bf3_ks, which builds its fragments in registers (no LDS in the K loop):
         # K split over the waves of a workgroup from 512 input channels, a 32 x 128 tile per wave up to 256 (the C side decides
         # by chunk count and grid size)
-        deep_1x1 = stride == 1 and Cin >= 64 and Cin % 16 == 0 and (Ho * Wo) % 4 == 0 and BF3_1X1_KS
+        # (maps only: Conv1d-shaped inputs - H = 1 - never fill a pixel tile, and their weights would be re-packed after every update)
+        deep_1x1 = stride == 1 and Cin >= 64 and Cin % 16 == 0 and (Ho * Wo) % 4 == 0 and (Ho >= 2 or TILE_OVERRIDE >= 9) and BF3_1X1_KS
         want_1x1 = TILE_OVERRIDE >= 9 or SPLIT_BF16_1X1 == 1 or (SPLIT_BF16_1X1 != 0 and (big_1x1 or deep_1x1))
         if (want_1x1 and SPLIT_BF16 and stride in (1, 2) and (Cin >= 128 or deep_1x1) and (Cout >= 64 or deep_1x1 or TILE_OVERRIDE in (11, 12, 13)) and Wo % 4 == 0
                 and (Wo >= 8 or deep_1x1 or TILE_OVERRIDE in (11, 12, 13)) and w.is_contiguous()
