@@ -16,7 +16,7 @@ The JSON line also carries
   roofline             MFMA family of the headline step: achieved = algorithmic FLOPs of one step / the step's WALL time;
                        peak = the rate of the step's FLOP mix with the fp32 MFMA pipe (157.3 TF) and the bf16 MFMA pipe
                        (2.5 PF, six executed FLOPs per algorithmic FLOP of a split-bf16 conv) at their dense peaks;
-                       frac = achieved / peak = bound time / wall time (never above 1).  Secondary: `fp32_peak_basis`
+                       frac = achieved / peak = bound time / wall time (not clamped; > 1 is flagged).  Secondary: `fp32_peak_basis`
                        (rounds 1-4's figure), `kernel_time` (instrumented single-stream pass), `mfma_busy` (committed PMC)
   cpu_baseline         the CPU oracle (torch-CPU RedNet port + C mapper + torch-CPU policy port) on this box's host cores
   gt_semantics_step    BASELINE configs[1] (gt semantics, 4 envs): its own value / roofline / mapper_roofline / cpu_baseline
@@ -46,11 +46,14 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f
 # algorithmic fp32 FLOP, so its share of a step is bounded by this / 6 = 416.7 "fp32-equivalent" TFLOP/s
 PEAK_BF16_MFMA_TFLOPS = 2500.0
 SPLIT_PRODUCTS = 6
-# the arithmetic type of the path: fp32 in / out / accumulate; the qualifier is part of the value since round 5
-DTYPE = "f32 (bf16x3 split on 3x3/7x7)"
+# the arithmetic type of the path: fp32 in / out / accumulate (how the fp32 products are formed is `dtype_note`'s business)
+DTYPE = "f32"
 PEAK_HBM_GBS = 8000.0  # same guide: HBM3E 8 TB/s spec (6.3 TB/s achievable)
-PROFILE_ROUNDS = ("r05", "r04", "r03", "r02", "r01")  # committed rocprofv3 summaries, newest first
-MFMA_FAMILY = "MFMA family (fp32: k_gemm / k_gemm_vec / k_conv_direct / k_depth_net / k_gn_conv / k_nconv; split-bf16: k_conv_bf3)"
+PROFILE_ROUNDS = ("r06", "r05", "r04", "r03", "r02", "r01")  # committed rocprofv3 summaries, newest first
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from kernel_family import FAMILY_KERNELS, base_name  # noqa: E402  (= ivln_family_kernel_names(): ONE definition of the family)
+
+MFMA_FAMILY = "MFMA family (" + " / ".join(FAMILY_KERNELS) + ")"
 
 
 def log(*a):
@@ -98,6 +101,7 @@ class GemmTimer:
     def __init__(self):
         self.flops = 0
         self.launches = 0
+        self.by_kernel = {}  # kernel name -> (launches, ms) of the pass, from the library's own sink
         self._ms = None
 
     def __enter__(self):
@@ -119,7 +123,8 @@ class GemmTimer:
                 # whose tokens changed are computed - count what ran (a read-back: this pass is outside the timed region)
                 self.flops += 2 * desc.M * desc.N * desc.K * float(flags.float().mean().item())
                 return
-            self.flops += 2 * desc.M * desc.N * desc.K
+            # (a stacked transposed conv multiplies its classes' zero padding too: ops.conv_transpose2d_s2 states the real taps)
+            self.flops += getattr(desc, "_algo_flops", 2 * desc.M * desc.N * desc.K)
 
         self.orig_soft = ops.gemm_soft
 
@@ -200,6 +205,12 @@ class GemmTimer:
             if dropped.value:
                 raise RuntimeError(f"GemmTimer: {dropped.value} launches beyond MAX_LAUNCHES went untimed")
             self._ms, self.launches = ms.value, n.value
+            self._lib.ivln_family_timing_report.argtypes = [C.c_char_p, C.c_int]
+            buf = C.create_string_buffer(4096)
+            self._check(self._lib.ivln_family_timing_report(buf, 4096), "ivln_family_timing_report")
+            for line in buf.value.decode().splitlines():
+                name, cnt, kms = line.split()
+                self.by_kernel[name] = (int(cnt), float(kms))
             f, k = C.c_double(0.0), C.c_longlong(0)
             self._lib.ivln_conv_split_counters(C.byref(f), C.byref(k), 0)
             self.split_flops, self.split_launches = f.value, k.value
@@ -217,7 +228,7 @@ def mixed_bound(flops, split_flops):
     """(bound in ms, peak in TFLOP/s) of a FLOP mix on the matrix cores: the part that ran on the fp32 MFMA kernels is
     priced on the fp32 MFMA peak, the part that ran on the split-bf16 kernels (csrc/conv_bf3.hip) on the bf16 peak at SIX
     executed bf16 FLOPs per algorithmic fp32 FLOP.  `peak` = flops / bound: the rate this mix would run at with both pipes
-    at their dense peaks - the denominator of every `roofline.frac` in the line, which therefore cannot pass 1."""
+    at their dense peaks - the denominator of every `roofline.frac` in the line (which a correct FLOP count cannot push past 1)."""
     rest = max(flops - split_flops, 0.0)
     bound_ms = (rest / (PEAK_F32_MFMA_TFLOPS * 1e12) + split_flops * SPLIT_PRODUCTS / (PEAK_BF16_MFMA_TFLOPS * 1e12)) * 1e3
     peak = (flops / (bound_ms * 1e-3)) / 1e12 if bound_ms > 0 else PEAK_F32_MFMA_TFLOPS
@@ -245,10 +256,12 @@ def split_bf16_part(flops, split_flops, split_launches, n_steps):
 
 
 def pmc_mfma_busy(name):
-    """MFMA-pipe busy fraction of the DOMINANT kernel of a committed PMC pass (profiles/rNN_<name>: one rocprofv3 run with
+    """MFMA-pipe busy fraction of EVERY family kernel of a committed PMC pass (profiles/rNN_<name>: one rocprofv3 run with
     `--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES`, summarised by tools/pmc_stats.py): busy cycles of the 1024 matrix
-    pipes / (1024 x SQ_BUSY_CYCLES / 32 shader engines).  Dominant = the family kernel with the most SQ-busy cycles in
-    the pass.  A counter pass cannot run inside the timed bench: the figure is the committed one, None without a file."""
+    pipes / (1024 x SQ_BUSY_CYCLES / 32 shader engines), per kernel name (its template instantiations summed; the family is
+    tools/kernel_family.py's list, not a prefix match - round 5 merged k_conv_bf3 with k_conv_bf3_ks and hid
+    k_conv1x1_bf3_ks).  `kernel` / `mfma_busy` = the member with the most SQ-busy cycles in the pass.  A counter pass
+    cannot run inside the timed bench: the figures are the committed ones, None without a file."""
     import csv
 
     for rnd in PROFILE_ROUNDS:
@@ -258,18 +271,22 @@ def pmc_mfma_busy(name):
         try:
             busy, sq = {}, {}
             for row in csv.DictReader(open(path)):
-                base = row["Name"].split("<")[0].split("(")[0]  # every instantiation of a kernel template counts as that kernel
+                base = base_name(row["Name"])
                 d = busy if row["Counter"] == "SQ_VALU_MFMA_BUSY_CYCLES" else sq
                 d[base] = d.get(base, 0.0) + float(row["Total"])
-            fam = [k for k in sq if busy.get(k, 0.0) > 0 and k.startswith(("k_conv", "k_gemm", "k_wgrad", "k_depth_net",
-                                                                           "k_gn_conv", "k_nconv"))]
+            fam = [k for k in FAMILY_KERNELS if sq.get(k, 0.0) > 0]
             if not fam:
                 return None
+            total = sum(sq[k] for k in fam)
+            table = {k: {"mfma_busy": round(busy.get(k, 0.0) / (1024.0 * sq[k] / 32.0), 4),
+                         "share_of_family_sq_busy_cycles": round(sq[k] / total, 4)} for k in fam}
             k = max(fam, key=lambda n: sq[n])
-            return {"kernel": k, "mfma_busy": round(busy[k] / (1024.0 * sq[k] / 32.0), 4),
+            return {"kernel": k, "mfma_busy": table[k]["mfma_busy"], "by_kernel": table,
+                    "family_weighted": round(sum(busy.get(k, 0.0) for k in fam) / (1024.0 * total / 32.0), 4),
                     "source": f"profiles/{rnd}_{name}",
-                    "formula": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 pipes x SQ_BUSY_CYCLES / 32 shader engines), summed over the "
-                               "kernel's template instantiations; dominant = most SQ-busy cycles in the pass"}
+                    "formula": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 pipes x SQ_BUSY_CYCLES / 32 shader engines) per kernel name; "
+                               "`kernel` = the member with the most SQ-busy cycles; `family_weighted` = the same ratio over "
+                               "the whole family"}
         except Exception:  # noqa: BLE001
             return None
     return None
@@ -281,7 +298,8 @@ def mfma_roofline(gt, ms, n_steps, traffic, what, wall_ms_per_step=None, busy=No
                 the step overlaps streams, so summed kernel durations are not a denominator), TFLOP/s
       peak      the rate THIS FLOP mix would run at with the fp32 MFMA pipe and the bf16 MFMA pipe at their dense peaks
                 (`mixed_bound`; the per-pipe peaks are in `peaks`)
-      frac      achieved / peak = bound time / wall time; never above 1
+      frac      achieved / peak = bound time / wall time (NOT clamped: a value above 1 is an accounting error and
+                `frac_exceeds_1` says so - tests/test_gpu_bench.py fails on it)
     Secondary figures: `fp32_peak_basis` (the same FLOPs priced on the fp32 MFMA peak alone - rounds 1-4's `frac`; a
     RATIO that can pass 1 where the split-bf16 kernels run faster than the fp32 pipe could), `kernel_time` (the family's
     summed kernel durations from the instrumented single-stream pass instead of wall time), `mfma_busy` (committed PMC
@@ -293,13 +311,15 @@ def mfma_roofline(gt, ms, n_steps, traffic, what, wall_ms_per_step=None, busy=No
     wall = wall_ms_per_step if wall_ms_per_step else k_ms
     ach = (flops_step / (wall * 1e-3)) / 1e12 if wall > 0 else 0.0
     k_ach = (flops_step / (k_ms * 1e-3)) / 1e12 if k_ms > 0 else 0.0
-    per_launch, per_step = traffic if isinstance(traffic, tuple) else (traffic, None)
+    per_launch, per_step, profile = (tuple(traffic) + (None,))[:3] if isinstance(traffic, tuple) else (traffic, None, None)
     return {
         "bound": "mfma", "achieved": round(ach, 3), "peak": round(peak, 2), "unit": "TFLOP/s",
-        "frac": round(min(bound_ms / wall, 1.0), 5) if wall > 0 else None, "traffic": per_launch,
+        "frac": round(bound_ms / wall, 5) if wall > 0 else None, "frac_exceeds_1": bool(wall > 0 and bound_ms / wall > 1.0),
+        "traffic": per_launch,
         "peaks": PEAKS, "bound_ms_per_" + per: round(bound_ms, 4),
         "traffic_unit": "HBM bytes per launch of the family (rocprofv3 PMC passes committed under profiles/)",
         "traffic_bytes_per_" + per: per_step,
+        "traffic_profile": profile,  # the committed PMC summary the two figures come from, with its per-kernel launches / bytes
         "kernel": MFMA_FAMILY + ": " + what,
         "flops_per_" + per: int(flops_step), "launches_per_" + per: round(gt.launches / n_steps, 1),
         "basis": ("algorithmic FLOPs of one " + per + " / WALL time of the timed " + per + " (median repetition; every other "
@@ -313,8 +333,10 @@ def mfma_roofline(gt, ms, n_steps, traffic, what, wall_ms_per_step=None, busy=No
                                     "as `frac`): a ratio, not a fraction of a bound - the split-bf16 convs run on a pipe "
                                     "with 16x the fp32 pipe's rate at 6x the work"},
         "kernel_time": {
-            "achieved": round(k_ach, 3), "frac": round(min(bound_ms / k_ms, 1.0), 5) if k_ms > 0 else None,
+            "achieved": round(k_ach, 3), "frac": round(bound_ms / k_ms, 5) if k_ms > 0 else None,
             "kernel_ms_per_" + per: round(k_ms, 4),
+            "by_kernel": {k: {"launches_per_" + per: round(c / n_steps, 3), "ms_per_" + per: round(t / n_steps, 4)}
+                          for k, (c, t) in sorted(getattr(gt, "by_kernel", {}).items(), key=lambda kv: -kv[1][1])},
             "time_basis": "sum of the family's kernel durations - a start / stop HIP event on every dispatch "
                           "(hipExtLaunchKernelGGL through ivln_family_timing_begin / _end), the per-kernel figure rocprofv3 "
                           "reports - in an instrumented EAGER single-stream pass outside the timed region",
@@ -406,10 +428,14 @@ def cpu_baseline(obs_cpu, B, budget_s=12.0, pred=False):
 
 
 def pmc_traffic_pair(name, family="mfma_family"):
-    """(bytes per launch, bytes per step) of a kernel family from a committed PMC summary, or None."""
+    """(bytes per launch, bytes per step, {source, by_kernel}) of a kernel family from a committed PMC summary, or None."""
     a = pmc_traffic(name, (family, "hbm_bytes_per_launch_corrected"))
     b = pmc_traffic(name, (family, "hbm_bytes_per_step_corrected"))
-    return None if a is None else (a, b)
+    if a is None:
+        return None
+    src = next((f"profiles/{r}_{name}" for r in PROFILE_ROUNDS if os.path.exists(os.path.join(ROOT, "profiles", f"{r}_{name}"))), None)
+    return (a, b, {"source": src, "by_kernel": pmc_traffic(name, (family, "by_kernel")),
+                   "family_launches_per_step": pmc_traffic(name, (family, "launches_per_step"))})
 
 
 def pmc_traffic(name, key):
@@ -926,6 +952,13 @@ def main():
             def do_step(i):
                 runner.step(obs_dev[i % n_pool])
         else:
+            # eager launches (--no-graph: the PMC passes) must be the kernels of the TIMED step: the capture runs the policy's
+            # depth encoder as conv + GroupNorm pairs beside RedNet and as the persistent launch otherwise (graphed.py);
+            # left at its eager default the pred-semantics pass priced k_depth_net, which the replayed step never launches
+            venc = getattr(getattr(policy.net, "depth_encoder", None), "visual_encoder", None)
+            if venc is not None:
+                venc.latency_bound = not pred
+
             def do_step(i):
                 rollout_step(tr, policy, obs_dev[i % n_pool], state)
         for i in range(W):
@@ -1072,10 +1105,11 @@ def main():
         "metric": METRIC, "value": head["value"], "unit": "env-steps/s", "n_gpus": world,
         "steps": K, "warmup": W, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
-        "dtype_note": "fp32 in, fp32 out, fp32 accumulation everywhere; the large 3x3 / 7x7 convs form their fp32 products from "
-                      "three bf16 pieces per operand on the bf16 MFMA pipe (six piece products, the dropped ones < 2^-23 of a "
-                      "product: error vs float64 at or below the fp32 MFMA kernels', tests/test_gpu_kernels.py; IVLN_SPLIT_BF16=0 "
-                      "keeps every conv on the fp32 MFMA kernels)",
+        "dtype_note": "fp32 in, fp32 out, fp32 accumulation everywhere.  The kernels named k_*_bf3* (3x3 / 7x7 convs, the deep and "
+                      "fused 1x1 convs, the stride-2 / transposed convs of RedNet, the map CNN's weight gradients) form their "
+                      "fp32 products from three bf16 pieces per operand on the bf16 MFMA pipe (six piece products, the dropped "
+                      "ones < 2^-23 of a product: error vs float64 at or below the fp32 MFMA kernels', tests/test_gpu_kernels.py); "
+                      "every other kernel multiplies in fp32.  IVLN_SPLIT_BF16=0 keeps every conv on the fp32 MFMA kernels",
         "repetitions": head["repetitions"],
         "config": dict(head["config"], parallelism=f"dp{world} (envs sharded, no data-path collective)",
                        headline=("configs[2], the largest single-GPU configuration of BASELINE.json (configs[0] is the CPU "
@@ -1095,11 +1129,32 @@ def main():
         out["dagger_collect_step"] = collect
     if iteration is not None:
         out["dagger_iteration"] = iteration
+    out.update(ranks_observed(world, dev))
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def ranks_observed(world, dev):
+    """What the collective itself saw, not what the environment said: `ranks_seen` = a sum all-reduce of
+    ones over the process group on the bench's device, `devices_seen` = distinct (host, device uuid) pairs gathered from
+    the ranks (1 under IVLN_BENCH_ONE_DEVICE, where every rank sits on cuda:0 over gloo), `backend` = the group's."""
+    import socket
+
+    props = torch.cuda.get_device_properties(dev)
+    ident = f"{socket.gethostname()}:{getattr(props, 'uuid', None) or getattr(props, 'pci_bus_id', dev.index)}"
+    if world <= 1:
+        return {"ranks_seen": 1, "devices_seen": 1, "collective_backend": None}
+    import torch.distributed as dist
+
+    ones = torch.ones(1, device=dev, dtype=torch.float32)
+    dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+    idents = [None] * world
+    dist.all_gather_object(idents, ident)
+    return {"ranks_seen": int(round(float(ones.item()))), "devices_seen": len(set(idents)),
+            "collective_backend": dist.get_backend()}
 
 
 def _watchdog(seconds, code, what):

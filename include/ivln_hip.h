@@ -248,6 +248,13 @@ int ivln_conv_split_kinds(long long* out4, int reset);
  * `roofline.achieved` live. */
 int ivln_family_timing_begin(int max_launches);
 int ivln_family_timing_end(double* total_ms, int* launches, int* dropped);
+/* The same pass broken down by kernel: after _end, one text line "<kernel> <launches> <ms>\n" per kernel name (the
+ * template's name without its arguments, e.g. k_conv1x1_bf3_ks) into buf (NUL-terminated; returns the bytes needed
+ * incl. the NUL when cap is too small - call again -, < 0 on error).  ivln_family_kernel_names() = the comma-separated
+ * list of every kernel that launches through the sink - THE definition of "the MFMA family" for bench.py's FLOP hooks,
+ * tools/pmc_traffic.py and the per-kernel MFMA-busy table (tools/kernel_family.py mirrors it; tests pin the mirror). */
+int ivln_family_timing_report(char* buf, int cap);
+const char* ivln_family_kernel_names(void);
 /* Pre-arrangement of OIHW conv weights (M, Cin, KS, KS), KS in {3, 7}, Cin % (KS == 7 ? 2 : 8) == 0, into the
  * LDS image of the direct convolution kernel; `out` holds ivln_conv_packed_floats(M, Cin, KS) floats (0 = shape
  * not eligible).  Re-run whenever the weights change. */

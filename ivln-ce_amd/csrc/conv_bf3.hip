@@ -93,12 +93,16 @@ __device__ unsigned long long g_bf3_stamp[8192 * 8];  // records of 8 words
 // the compiler pads for that only in the cases its hazard table lists, and on this part a VALU write right behind such a
 // store (scalar channel offset in soffset) was seen to land first in lanes 48-63 - one register of one store stale, once in
 // a few thousand workgroups, run-to-run different (tools/dbg_fuse.py: the fused bottleneck tail against the two launches).
+#ifdef BF3_NO_STORE_GUARD  // (tools/check_store_hazard.py's self-test: the checker has to find these sites unguarded)
+#define BF3_STORE_GUARD() do {} while (0)
+#else
 #define BF3_STORE_GUARD()                       \
     do {                                        \
         __builtin_amdgcn_sched_barrier(0);      \
         asm volatile("s_nop 3" ::: "memory");   \
         __builtin_amdgcn_sched_barrier(0);      \
     } while (0)
+#endif
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t bf3_rsrc(const void* p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
@@ -855,7 +859,7 @@ int launch_bf3_ks_tile(const ivln_gemm_desc& d, hipStream_t s, const unsigned ch
     }
     const int tiles_w = d.Wout / PTW, tiles_h = d.Hout / PTH;
     dim3 grid(tiles_w * tiles_h * nimg, (d.M + 31) / 32, 1);
-    IVLN_LAUNCH_FAMILY(kern, grid, dim3(512), lds, s, d, a_split, (long long)grp_bytes, tiles_w, tiles_h, nimg);
+    IVLN_LAUNCH_FAMILY_NAMED("k_conv_bf3_ks", kern, grid, dim3(512), lds, s, d, a_split, (long long)grp_bytes, tiles_w, tiles_h, nimg);
     return IVLN_OK;
 }
 
@@ -1237,7 +1241,7 @@ int launch_bf3(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a_sp
     const int tiles_w = (d.Wout + PTW - 1) / PTW, tiles_h = (d.Hout + PTH - 1) / PTH;
     const int groups = (nimg + IMGS - 1) / IMGS;
     dim3 grid(tiles_w * tiles_h * groups, (d.M + BM - 1) / BM, d.splits);
-    IVLN_LAUNCH_FAMILY(kern, grid, dim3(NTB), lds, s, d, a_split, (long long)grp_bytes, tiles_w, tiles_h, nimg, cps);
+    IVLN_LAUNCH_FAMILY_NAMED("k_conv_bf3", kern, grid, dim3(NTB), lds, s, d, a_split, (long long)grp_bytes, tiles_w, tiles_h, nimg, cps);
     return IVLN_OK;
 }
 
@@ -1257,7 +1261,7 @@ int launch_bf3_fused(const ivln_gemm_desc& d, hipStream_t s, const unsigned char
     const int tiles_w = d.Wout / PTW, tiles_h = d.Hout / PTH;
     dim3 grid(tiles_w * tiles_h * nimg, 1, 1);
     const int nch = d.Cin / CB;
-    IVLN_LAUNCH_FAMILY(kern, grid, dim3(NTB), lds, s, d, a_split, (long long)grp_bytes, tiles_w, tiles_h, nimg, nch);
+    IVLN_LAUNCH_FAMILY_NAMED("k_conv_bf3", kern, grid, dim3(NTB), lds, s, d, a_split, (long long)grp_bytes, tiles_w, tiles_h, nimg, nch);
     return IVLN_OK;
 }
 
@@ -1565,7 +1569,7 @@ int launch_wgrad_bf3(const ivln_gemm_desc& d, hipStream_t s, int nimg, int strip
         attr_done = true;
     }
     dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM, d.splits);
-    IVLN_LAUNCH_FAMILY(kern, grid, dim3(64 * WM * WN), lds, s, d, nimg, strips, sps);
+    IVLN_LAUNCH_FAMILY_NAMED("k_wgrad_bf3", kern, grid, dim3(64 * WM * WN), lds, s, d, nimg, strips, sps);
     return IVLN_OK;
 }
 

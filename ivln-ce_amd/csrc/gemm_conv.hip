@@ -19,6 +19,9 @@
 #include <stdlib.h>
 
 #include <vector>
+#include <string>
+#include <string.h>
+#include <stdio.h>
 
 #include "gemm_common.h"
 
@@ -433,12 +436,29 @@ int launch_tile(const ivln_gemm_desc& d, hipStream_t s) {
 
 // ---- duration sink of the family's launches (family_timing.h).  One user at a time (bench.py's instrumented pass). ----
 namespace {
+// every kernel that launches through IVLN_LAUNCH_FAMILY: the definition of "the MFMA family" (ivln_family_kernel_names)
+const char* const kFamilyKernels[] = {"k_gemm",     "k_gemm_vec",    "k_conv_direct",    "k_wgrad_direct", "k_conv1x1_stream", "k_conv_bf3",
+                                      "k_conv_bf3_ks", "k_conv1x1_bf3_ks", "k_wgrad_bf3", "k_gn_conv",      "k_nconv",          "k_depth_net"};
+constexpr int kFamilyCount = (int)(sizeof(kFamilyKernels) / sizeof(kFamilyKernels[0]));
 std::vector<hipEvent_t> g_timing_events;
-int g_timing_used = -1;  // -1: not armed
+std::vector<int> g_timing_kernel;  // per timed launch: index into kFamilyKernels, kFamilyCount = a name outside the list
+int g_timing_used = -1;            // -1: not armed
 int g_timing_dropped = 0;
+double g_report_ms[kFamilyCount + 1];
+int g_report_n[kFamilyCount + 1];
+bool g_report_valid = false;
+
+int family_index(const char* site) {  // "(k_conv_direct<3, 32, ...>)" / "k_depth_net" -> index of its template name
+    while (*site == '(' || *site == ' ') ++site;
+    size_t n = 0;
+    while (site[n] && site[n] != '<' && site[n] != ')' && site[n] != ' ') ++n;
+    for (int i = 0; i < kFamilyCount; ++i)
+        if (strlen(kFamilyKernels[i]) == n && !strncmp(kFamilyKernels[i], site, n)) return i;
+    return kFamilyCount;
+}
 }  // namespace
 
-bool ivln_family_timing_next(hipEvent_t* start, hipEvent_t* stop) {
+bool ivln_family_timing_next(hipEvent_t* start, hipEvent_t* stop, const char* kernel) {
     if (g_timing_used < 0) return false;
     if ((size_t)g_timing_used + 2 > g_timing_events.size()) {
         ++g_timing_dropped;
@@ -446,8 +466,16 @@ bool ivln_family_timing_next(hipEvent_t* start, hipEvent_t* stop) {
     }
     *start = g_timing_events[g_timing_used];
     *stop = g_timing_events[g_timing_used + 1];
+    g_timing_kernel[g_timing_used / 2] = family_index(kernel);
     g_timing_used += 2;
     return true;
+}
+
+extern "C" const char* ivln_family_kernel_names(void) {
+    static std::string names;
+    if (names.empty())
+        for (int i = 0; i < kFamilyCount; ++i) names += std::string(i ? "," : "") + kFamilyKernels[i];
+    return names.c_str();
 }
 
 extern "C" int ivln_family_timing_begin(int max_launches) {
@@ -457,8 +485,10 @@ extern "C" int ivln_family_timing_begin(int max_launches) {
         if (hipEventCreate(&e) != hipSuccess) return IVLN_E_HIP;
         g_timing_events.push_back(e);
     }
+    g_timing_kernel.assign(g_timing_events.size() / 2, kFamilyCount);
     g_timing_used = 0;
     g_timing_dropped = 0;
+    g_report_valid = false;
     return IVLN_OK;
 }
 
@@ -467,16 +497,35 @@ extern "C" int ivln_family_timing_end(double* total_ms, int* launches, int* drop
     const int used = g_timing_used;
     g_timing_used = -1;
     double sum = 0.0;
+    for (int k = 0; k <= kFamilyCount; ++k) g_report_ms[k] = 0.0, g_report_n[k] = 0;
     for (int i = 0; i < used; i += 2) {
         if (hipEventSynchronize(g_timing_events[i + 1]) != hipSuccess) return IVLN_E_HIP;
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, g_timing_events[i], g_timing_events[i + 1]) != hipSuccess) return IVLN_E_HIP;
         sum += ms;
+        g_report_ms[g_timing_kernel[i / 2]] += ms;
+        g_report_n[g_timing_kernel[i / 2]] += 1;
     }
+    g_report_valid = true;
     *total_ms = sum;
     *launches = used / 2;
     if (dropped) *dropped = g_timing_dropped;
     return IVLN_OK;
+}
+
+extern "C" int ivln_family_timing_report(char* buf, int cap) {
+    if (!g_report_valid) return IVLN_E_INVALID;
+    std::string out;
+    char line[128];
+    for (int k = 0; k <= kFamilyCount; ++k) {
+        if (!g_report_n[k]) continue;
+        snprintf(line, sizeof line, "%s %d %.6f\n", k < kFamilyCount ? kFamilyKernels[k] : "?", g_report_n[k], g_report_ms[k]);
+        out += line;
+    }
+    const int need = (int)out.size() + 1;
+    if (!buf || cap < need) return need;
+    memcpy(buf, out.c_str(), (size_t)need);
+    return 0;
 }
 
 extern "C" int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream) {

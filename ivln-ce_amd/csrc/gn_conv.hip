@@ -874,7 +874,7 @@ int ivln_gn_conv_f32(const ivln_gn_conv_desc* d, void* stream) {
     G.wl_floats = (int)wl;
     G.part_floats = (int)part;
     if (d->N > 65535) return IVLN_E_UNSUPPORTED;
-    IVLN_LAUNCH_FAMILY(fn, dim3(d->groups, d->N, S), dim3(GT), bytes, (hipStream_t)stream, *d, G);
+    IVLN_LAUNCH_FAMILY_NAMED("k_gn_conv", fn, dim3(d->groups, d->N, S), dim3(GT), bytes, (hipStream_t)stream, *d, G);
     return hipGetLastError() == hipSuccess ? IVLN_OK : IVLN_E_HIP;
 }
 
@@ -965,7 +965,7 @@ int ivln_nconv_f32(const ivln_nconv_desc* d, void* stream) {
             raised.insert((const void*)fn);
         }
     }
-    IVLN_LAUNCH_FAMILY(fn, dim3(G.strips, d->N, mz), dim3(GT), fl * sizeof(float), (hipStream_t)stream, *d, G);
+    IVLN_LAUNCH_FAMILY_NAMED("k_nconv", fn, dim3(G.strips, d->N, mz), dim3(GT), fl * sizeof(float), (hipStream_t)stream, *d, G);
     return hipGetLastError() == hipSuccess ? IVLN_OK : IVLN_E_HIP;
 }
 

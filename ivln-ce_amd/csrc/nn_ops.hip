@@ -488,6 +488,22 @@ __global__ __launch_bounds__(256) void k_pool2d(const float* __restrict__ x, flo
     y[idx] = acc;
 }
 
+// A 1 x 1 window at stride 2 (mode is irrelevant: one value per output) - the gather in front of a stride-2 1x1 conv
+// (ops.conv2d: RedNet's downsample branches, rednet.py:226-232): four consecutive outputs of a row per thread = every second value
+// of two 16-byte loads, one 16-byte store.  (The generic kernel reads one dword per output at an 8-byte stride.)
+__global__ __launch_bounds__(256) void k_subsample2_x4(const float* __restrict__ x, float* __restrict__ y, int64_t total4, int H, int W,
+                                                      int Ho, int Wo) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total4) return;
+    const int W4 = Wo >> 2;
+    const int j = (int)(idx % W4);
+    const int ho = (int)((idx / W4) % Ho);
+    const int64_t nc = idx / ((int64_t)W4 * Ho);
+    const float4* r = reinterpret_cast<const float4*>(x + (nc * H + 2 * ho) * W + 8 * j);
+    const float4 a = r[0], b = r[1];
+    *reinterpret_cast<float4*>(y + (nc * Ho + ho) * Wo + 4 * j) = make_float4(a.x, a.z, b.x, b.z);
+}
+
 // MaxPool2d(3, 2, 1) (RedNet's stem, rednet.py:195-197), four consecutive outputs of a row per thread: their windows cover input
 // columns 8 j - 1 .. 8 j + 7 of three rows - one 4-byte load + two 16-byte loads per row, every lane's loads contiguous with its
 // neighbours' - and leave as one 16-byte store.  (The generic kernel reads nine scattered dwords per output: 36 us for the
@@ -1559,6 +1575,10 @@ int ivln_pool2d_f32(const float* x, float* y, int NC, int H, int W, int k, int s
     int64_t total = (int64_t)NC * Ho * Wo;
     if (mode == 0 && k == 3 && s == 2 && p == 1 && (W & 7) == 0 && (Wo & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0) {
         hipLaunchKernelGGL(k_maxpool3s2p1_x4, dim3(nblk(total / 4)), dim3(256), 0, (hipStream_t)stream, x, y, total / 4, H, W, Ho, Wo);
+        return LAUNCH_OK();
+    }
+    if (k == 1 && s == 2 && p == 0 && (W & 7) == 0 && (H & 1) == 0 && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0) {
+        hipLaunchKernelGGL(k_subsample2_x4, dim3(nblk(total / 4)), dim3(256), 0, (hipStream_t)stream, x, y, total / 4, H, W, Ho, Wo);
         return LAUNCH_OK();
     }
     hipLaunchKernelGGL(k_pool2d, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, x, y, NC, H, W, Ho, Wo, k, s,

@@ -44,6 +44,45 @@ def _policy_masks(batch):
     return batch.get("episode_not_done_masks", batch["not_done_masks"])
 
 
+class _CutCapture:
+    """Stream capture of a SEQUENCE of hipGraphs that share one memory pool: `cut()` ends the graph being captured and begins
+    the next one on the same stream, so that a long dependent chain (RedNet -> mapper -> map CNN) can be replayed in pieces
+    with an event recorded between two of them - the point another stream's graph waits for.  Replaying the pieces back to
+    back on one stream is the uncut graph (same launches, same order, same buffers)."""
+
+    def __init__(self, stream, pool=None):
+        self.stream, self.pool, self.graphs = stream, pool, []
+
+    def _begin(self):
+        g = torch.cuda.CUDAGraph()
+        if self.pool is None:
+            g.capture_begin()
+        else:
+            g.capture_begin(pool=self.pool)
+        self.graphs.append(g)
+
+    def cut(self):
+        self.graphs[-1].capture_end()
+        self.pool = self.graphs[-1].pool()
+        self._begin()
+
+    def __enter__(self):
+        torch.cuda.synchronize()
+        self.stream.wait_stream(torch.cuda.current_stream())
+        self._ctx = torch.cuda.stream(self.stream)
+        self._ctx.__enter__()
+        self._begin()
+        return self
+
+    def __exit__(self, et, ev, tb):
+        try:
+            self.graphs[-1].capture_end()
+            self.pool = self.graphs[-1].pool()
+        finally:
+            self._ctx.__exit__(et, ev, tb)
+        return False
+
+
 class GraphedRollout:
     """mapper + `policy.act` of one env step as replayable hipGraphs (see the module docstring).  Side effect of the
     split capture: it fixes how the pieces that run beside each other are launched - the gt-semantics mapper narrow
@@ -52,9 +91,14 @@ class GraphedRollout:
     same kernels, so replay and eager stay bit-identical."""
 
     def __init__(self, policy, obs_transforms, example_obs: Dict, deterministic: bool = True, streams: bool = True,
-                 warmup: int = 2, extra_keys=()):
+                 warmup: int = 2, extra_keys=(), warmup_mapper: bool = True):
+        """warmup_mapper=False: the warm-up steps run everything EXCEPT the mapper's own kernels (MappingModule.dry_run) - for
+        a capture in the middle of a rollout whose launch path has changed since the last capture (a persistent encoder was
+        retired after a time-out: the launch chain has never run on the capture streams, and its per-stream workspaces must
+        exist before a capture can record launches that use them) while the world cloud must not be stepped."""
         self.policy = policy
         self.transforms = list(obs_transforms)
+        self._warmup_mapper = warmup_mapper
         self.deterministic = deterministic
         dev = next(policy.parameters()).device
         self.device = dev
@@ -83,6 +127,10 @@ class GraphedRollout:
                 self._capture(warmup)
         finally:
             ops.CMA_WS_OWNER = prev_owner
+        # the captured launches hold raw pointers into the instruction encoder's per-shape step caches; the encoder evicts the
+        # oldest shape once it has four - this runner keeps the ones that existed at its capture alive
+        ienc = getattr(policy.net, "instruction_encoder", None)
+        self._held_step_caches = list(getattr(ienc, "__dict__", {}).get("_step_caches", {}).values()) if ienc is not None else []
 
     def __del__(self):
         try:
@@ -144,7 +192,6 @@ class GraphedRollout:
     def _capture_split(self, warmup):
         dev = self.device
         net = self.policy.net
-        self.sA = _stream(dev, "depth", priority=int(os.environ.get("IVLN_DEPTH_STREAM_PRIORITY", "-1")))  # the critical chain wins dispatch when both queues are ready
         self.ev_in, self.ev_A = torch.cuda.Event(), torch.cuda.Event()
         main = torch.cuda.current_stream()
 
@@ -203,6 +250,12 @@ class GraphedRollout:
         # that will be captured has to exist before the capture.)
         venc = getattr(getattr(net, "depth_encoder", None), "visual_encoder", None)
         predicted = any(getattr(t, "predicted_semantics", False) for t in self.transforms)
+        # the depth encoder's stream: the critical chain of the gt-semantics step wins dispatch when both queues are ready
+        # (priority -1); beside RedNet it is NOT critical and takes a stream of its own role at IVLN_PRED_DEPTH_PRIORITY
+        if predicted:
+            self.sA = _stream(dev, "depth_beside_rednet", priority=int(os.environ.get("IVLN_PRED_DEPTH_PRIORITY", "-1")))
+        else:
+            self.sA = _stream(dev, "depth", priority=int(os.environ.get("IVLN_DEPTH_STREAM_PRIORITY", "-1")))
         if venc is not None:
             venc.latency_bound = not predicted
             venc.beside_other_work = True  # (its graph replays beside the mapper / map-CNN graph: ops.DEPTH_NET's policy)
@@ -229,12 +282,24 @@ class GraphedRollout:
             ienc.lstm_spare = spare
         s = _stream(dev, "warmup")
         s.wait_stream(main)
-        with torch.cuda.stream(s):  # warm-up: tables, workspaces (per stream), folded weights
-            for i in range(warmup):
+        cap_stream = _stream(dev, "capture")
+        with self._dry_mapper():
+            with torch.cuda.stream(s):  # warm-up: tables, workspaces (per stream), folded weights
+                for i in range(warmup):
+                    run_A()
+                    run_B2(i & 1, run_B1(i & 1))
+            if warmup:
+                # ... and once on the streams the graphs are captured on: per-stream state (split-K workspaces, GroupNorm /
+                # packed-weight scratch, the depth encoder's arena) must not be born inside a capture - a buffer from a
+                # graph's private pool would end up in a process-wide cache
+                s.synchronize()
+                cap_stream.wait_stream(s)
+                with torch.cuda.stream(cap_stream):
+                    run_A()
+                    run_B2(0, run_B1(0))
+                cap_stream.synchronize()
+            with torch.cuda.stream(self.sA):  # the side stream needs its own split-K workspace before capture
                 run_A()
-                run_B2(i & 1, run_B1(i & 1))
-        with torch.cuda.stream(self.sA):  # the side stream needs its own split-K workspace before capture
-            run_A()
         main.wait_stream(s)
         torch.cuda.synchronize()
         # A ground-truth-semantics mapper runs beside the depth-ResNet chain with time to spare (gB1 285 us, gA 580):
@@ -255,19 +320,35 @@ class GraphedRollout:
         self._dep = net._stash_dep  # (depth features, k/v) live in gA's pool
         self._txt = getattr(net, "_stash_txt", None)  # (predicted semantics: the instruction features too)
         # the previous action (read by the embedding in gB1) ping-pongs with the state: one gB1 per phase
+        # With predicted semantics gB1 is cut behind one of RedNet's stages (rednet.STAGE_HOOK) and gA is released by an event
+        # recorded at the cut: the depth encoder's ~110 small launches then run beside RedNet's pixel-starved deep stages,
+        # whose grids leave CUs idle, instead of taking CUs from the chip-filling first ones (round 5: gB1 alone 3242 us,
+        # 3562 us with gA started at t = 0).  IVLN_PRED_DEPTH_START: stage name, or "0" = no cut (gA starts with the step).
+        from . import rednet as _rednet
+
+        self._cut_stage = os.environ.get("IVLN_PRED_DEPTH_START", "layer2") if predicted else "0"
+        if self._cut_stage in ("0", "", "none"):
+            self._cut_stage = None
+        self.ev_mid = torch.cuda.Event()
         self.gB1, pool = [], None
         for src in (0, 1):
-            g1 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1, pool=pool):
-                net._stash_txt = self._txt
-                batch = run_B1(src)
-            pool = g1.pool()
+            with _CutCapture(cap_stream, pool) as cc:
+                def hook(name, cc=cc):
+                    if name == self._cut_stage and len(cc.graphs) == 1:
+                        cc.cut()
+                prev_hook, _rednet.STAGE_HOOK = _rednet.STAGE_HOOK, (hook if self._cut_stage else None)
+                try:
+                    net._stash_txt = self._txt
+                    batch = run_B1(src)
+                finally:
+                    _rednet.STAGE_HOOK = prev_hook
+            pool = cc.pool
             stash = net._stash
             g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2, pool=pool):
+            with torch.cuda.graph(g2, pool=pool, stream=cap_stream):
                 net._stash, net._stash_dep = stash, self._dep
                 run_B2(src, batch)
-            self.gB1.append(g1)
+            self.gB1.append(list(cc.graphs))
             self.graphs.append(g2)
         self._keep = (batch, stash)
         self.phase = 0
@@ -277,8 +358,14 @@ class GraphedRollout:
 
     def _replay_split(self):
         main = torch.cuda.current_stream()
-        self.ev_in.record(main)
-        self.sA.wait_event(self.ev_in)
+        pieces = self.gB1[self.phase]
+        if len(pieces) > 1:  # gB1 cut behind a RedNet stage: its head first, gA released at the cut
+            pieces[0].replay()
+            self.ev_mid.record(main)
+            self.sA.wait_event(self.ev_mid)
+        else:
+            self.ev_in.record(main)
+            self.sA.wait_event(self.ev_in)
         with torch.cuda.stream(self.sA):
             self.gA.replay()
             self.ev_A.record(self.sA)
@@ -291,14 +378,32 @@ class GraphedRollout:
         #  0.726 vs 0.714 ms per step, slower)
         # (... and the main graphs on a third stream with a priority of its own, whatever the priorities: 8.2 ms per pred-semantics
         #  step against 4.25, round 5 - the extra stream hop serialises the replay)
-        self.gB1[self.phase].replay()
+        pieces[-1].replay()
         main.wait_event(self.ev_A)
         self.graphs[self.phase].replay()
+
+    def _dry_mapper(self):
+        """Context: the transforms' mappers skip their own kernels (warmup_mapper=False), nothing otherwise."""
+        import contextlib
+
+        mms = [] if self._warmup_mapper else [mm for mm in (getattr(t, "mapping_module", None) for t in self.transforms) if mm is not None]
+
+        @contextlib.contextmanager
+        def ctx():
+            for mm in mms:
+                mm.dry_run = True
+            try:
+                yield
+            finally:
+                for mm in mms:
+                    mm.dry_run = False
+
+        return ctx()
 
     def _capture(self, warmup):
         s = _stream(self.device, "warmup")
         s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):  # warm-up off the default stream: creates tables, workspaces, handles
+        with self._dry_mapper(), torch.cuda.stream(s):  # warm-up off the default stream: creates tables, workspaces, handles
             for i in range(warmup):
                 self._body(i & 1)
         torch.cuda.current_stream().wait_stream(s)

@@ -198,6 +198,11 @@ class MappingModule:
                     raise Exception("Semantic Sensor not in use")  # mapper.py:660-661
                 labels = observations["semantic12"]
             labels = labels.reshape(B, H, W).to(torch.uint8).contiguous()
+            if getattr(self, "dry_run", False):
+                # a capture's warm-up after the first one (graphed.GraphedRollout(warmup_mapper=False)): everything in front of
+                # the mapper has run on this stream - RedNet's workspaces exist now - but the world cloud belongs to the
+                # rollout in progress and is not stepped; the maps are whatever the last real step left
+                return mem
             if posed:
                 check(
                     lib().ivln_mapper_step_posed(

@@ -360,6 +360,7 @@ SPLIT_BF16 = os.environ.get("IVLN_SPLIT_BF16", "1") != "0"
 SPLIT_BF16_WGRAD = os.environ.get("IVLN_SPLIT_BF16_WGRAD", "1") != "0"
 SPLIT_BF16_1X1 = int(os.environ.get("IVLN_SPLIT_BF16_1X1", "-1"))  # -1: by measured rule (ops.conv2d), 0 never, 1 always
 BF3_1X1_KS = os.environ.get("IVLN_BF3_1X1_KS", "1") != "0"  # A/B: 0 = deep-K 1x1 convs stay on the fp32 GEMM kernels
+S2_GATHER = os.environ.get("IVLN_S2_GATHER", "1") != "0"  # A/B: 0 = stride-2 1x1 convs read their input strided (tiled 1x1 form)
 SPLIT_BF16_MIN_OUT = int(os.environ.get("IVLN_SPLIT_BF16_MIN_OUT", str(1 << 18)))  # output elements below which nothing is packed
 _stat_ws = {}
 CONV_STATS = os.environ.get("IVLN_CONV_STATS", "1") != "0"  # A/B: BatchNorm statistics from the conv's epilogue
@@ -387,6 +388,16 @@ def conv2d(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, 
     N, Cin, H, W = x.shape
     G = w.shape[0] if w.dim() == 5 else 0  # (G, Cout, Cin, k, k): weight set g for images [g*N/G, (g+1)*N/G)
     Cout, _, KH, KW = w.shape[-4:]
+    if (S2_GATHER and stride == 2 and KH == 1 and KW == 1 and pad == 0 and SPLIT_BF16 and BF3_1X1_KS and not TILE_OVERRIDE
+            and Cin >= 64 and Cin % 16 == 0 and H % 2 == 0 and W % 8 == 0 and in_img_stride == 0 and not defer and x.is_contiguous()
+            and N * (H // 2) * (W // 2) * Cout >= SPLIT_BF16_MIN_OUT):
+        # a stride-2 1x1 conv (RedNet's downsample branches, rednet.py:226-232) reads every second pixel of every second row:
+        # gathered once into a dense quarter-size tensor (one pooling launch with a 1 x 1 window, a quarter of the input's
+        # bytes), it IS a stride-1 1x1 conv and takes the register-built split-bf16 kernels (k_conv1x1_bf3_ks) instead of the
+        # tiled 1x1 form - 47-52 us per launch at 8 + 8 images, the pipe a fifth busy (profiles/r05_predsem_B8_*)
+        xs = pool2d(x, 1, 2, 0, "max")
+        return conv2d(xs, w, 1, 0, dil, scale, shift, residual, relu, out, out_ctot, 0, splitk, defer, ws_slot, weight_is_temp,
+                      stats, run_flags, residual_after_relu)
     Ho = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
     Wo = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
     if defer:
@@ -652,6 +663,10 @@ def conv_transpose2d_s2(x, classes, scale=None, shift=None, residual=None, relu=
             d.koff, d.kpos = dptr(koff), dptr(kpos)
         _epilogue(d, scale, shift, residual, relu)
         d.ws, d.ws_floats, d.splits = dptr(ws), ws.numel(), 0
+        if w is stacked:
+            # the stacked form multiplies the zero padding of the classes' common window too (k = 3: 16 tap products per
+            # input pixel for 9 real ones): FLOP counters price the ALGORITHMIC taps, not the executed ones
+            d._algo_flops = 2 * Cout * d.N * Cin * sum(c.shape[2] * c.shape[3] for _, _, c in classes)
         gemm(d)
     return out
 

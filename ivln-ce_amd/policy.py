@@ -259,12 +259,21 @@ class MapCMANet(Net):
                 # yields Mq (H+1 channels) and TQb (h2 channels) for the fused head, no text_k tensor is made
                 wf, bf = self._cma_fold_weights()
                 cache = self.instruction_encoder.last_cache if sv is None else None
+                if cache is not None and getattr(cache, "fold_behind", False):
+                    # an earlier cached call re-encoded rows without folding them (the unfused head, or a capture that had
+                    # to drop the cache): `dirty` only names THIS call's rows, so every row is folded again
+                    if torch.cuda.is_current_stream_capturing():
+                        cache = None
+                    else:
+                        cache.dirty.fill_(1)
+                        cache.fold_behind = False
                 if cache is not None:
                     # per-episode cache (encoders.InstructionEncoder.step_cache): the folded operands live in the cache's
                     # persistent buffer and only the rows the encoder just re-encoded (cache.dirty) are recomputed
                     fkey = getattr(self, "_cma_fold_key", None)
                     if cache.fold is None or cache.fold_key != fkey:
                         if torch.cuda.is_current_stream_capturing():
+                            cache.fold_behind = True  # (the replays advance the cache's tokens without its fold)
                             cache = None  # (cannot be created / invalidated inside a capture: plain conv below)
                         else:
                             if cache.fold is None:
@@ -280,6 +289,8 @@ class MapCMANet(Net):
                 fold = ops.conv2d(t.view(r_, -1, 1, L_), wf.view(wf.shape[0], -1, 1, 1), shift=bf, splitk=False,
                                   run_flags=ops.all_rows_flags(r_, t.device))
                 return t, ln, fold.view(r_, -1, L_)
+            if sv is None and self.instruction_encoder.last_cache is not None:
+                self.instruction_encoder.last_cache.fold_behind = True  # (cached encoding, no fold made for its dirty rows)
             tk_ = ops.conv2d(t.view(r_, -1, 1, L_), self.text_k.weight.view(h2, -1, 1, 1), shift=self.text_k.bias,
                              splitk=False)
             return t, ln, tk_

@@ -75,6 +75,17 @@ def _convt(x, convt: nn.ConvTranspose2d, f: _Folded, **epi):
     return ops.conv_transpose2d(x, f.wt(convt), convt.stride[0], convt.padding[0], convt.output_padding[0], **epi)
 
 
+# Called with a stage name ("stem", "layer1" .. "layer4", "deconv1" .. "deconv4") when the launches of that stage are all
+# enqueued: graphed.GraphedRollout cuts its capture of the step there, so that the policy's depth encoder (another graph, on
+# the side stream) starts beside RedNet's pixel-starved stages instead of its chip-filling first ones.  None = no-op.
+STAGE_HOOK = None
+
+
+def _stage_done(name):
+    if STAGE_HOOK is not None:
+        STAGE_HOOK(name)
+
+
 SKIP_ADD_FUSED = os.environ.get("IVLN_REDNET_SKIP_ADD", "1") != "0"  # A/B: 0 = the decoder's skip adds as launches of their own
 
 
@@ -297,11 +308,13 @@ class RedNet(nn.Module):
             fuse0 = ops.add(S[:B], S[B:], out=S[:B])
             P = ops.pool2d(S, 3, 2, 1, "max")
             fuses = []
-            for la, lb in ((self.layer1, self.layer1_d), (self.layer2, self.layer2_d), (self.layer3, self.layer3_d),
-                           (self.layer4, self.layer4_d)):
+            _stage_done("stem")
+            for li, (la, lb) in enumerate(((self.layer1, self.layer1_d), (self.layer2, self.layer2_d),
+                                           (self.layer3, self.layer3_d), (self.layer4, self.layer4_d))):
                 for blk, blk_d in zip(la, lb):
                     P = _bottleneck_pair(blk, blk_d, P, f)
                 fuses.append(ops.add(P[:B], P[B:], out=P[:B]))
+                _stage_done(f"layer{li + 1}")
             fuse1, fuse2, fuse3, fuse4 = fuses
         else:
             s, b = f.bn(self.bn1)
@@ -320,9 +333,10 @@ class RedNet(nn.Module):
             x, d = self._seq(self.layer4, fuse3), self._seq(self.layer4_d, d)
             fuse4 = ops.add(x, d)
         x = self._agant(self.agant4, fuse4)
-        for seq, ag, fuse in ((self.deconv1, self.agant3, fuse3), (self.deconv2, self.agant2, fuse2),
-                              (self.deconv3, self.agant1, fuse1), (self.deconv4, self.agant0, fuse0)):
+        for di, (seq, ag, fuse) in enumerate(((self.deconv1, self.agant3, fuse3), (self.deconv2, self.agant2, fuse2),
+                                              (self.deconv3, self.agant1, fuse1), (self.deconv4, self.agant0, fuse0))):
             x = self._skip_add(self._seq(seq, x), ag, fuse)
+            _stage_done(f"deconv{di + 1}")
         x = self._seq(self.final_conv, x)
         fd = self.final_deconv_custom
         return _convt(x, fd, f, shift=fd.bias)

@@ -268,7 +268,9 @@ def _update_agent(policy, optimizer, observations, prev_actions, not_done_masks,
         # single rank: the Adam kernel skips the step ON THE DEVICE when this update's persistent GRU timed out (void
         # gradients); the host sees the sticky word after the loss read-back below and runs the update again on the
         # per-timestep launches.  (Several ranks: a rank-local skip would split the replicas - the error is raised.)
-        guard = ops.seq_guard_word(dev) if (dev.type == "cuda" and world == 1 and step_grad) else None
+        # (not with gradient accumulation: undoing the skipped step clears the whole bucket, earlier micro-batches included -
+        #  there the sticky word is an error like on several ranks: ADVICE r5)
+        guard = ops.seq_guard_word(dev) if (dev.type == "cuda" and world == 1 and step_grad and loss_accumulation_scalar == 1) else None
         if step_grad:
             optimizer.step(world, guard=guard)
         al = float(action_loss.item())
@@ -277,8 +279,20 @@ def _update_agent(policy, optimizer, observations, prev_actions, not_done_masks,
             if guard is not None and int(guard) != 0:  # (one 4-byte read on a stream the loss read-back has just drained)
                 ops.seq_recover()
                 optimizer.undo_skipped_step()
-                return _update_agent(policy, optimizer, observations, prev_actions, not_done_masks, corrected_actions, weights,
-                                     hidden_size, step_grad, loss_accumulation_scalar, world, tour_not_done_masks, rnn_states)
+                # the second forward must not count as a second batch: train-mode BatchNorm already folded THIS batch's
+                # statistics into its running buffers (they do not depend on the GRUs) - momentum 0 leaves them as they are
+                bns = [m for m in policy.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.training]
+                saved = [(m.momentum, None if m.num_batches_tracked is None else m.num_batches_tracked.clone()) for m in bns]
+                for m in bns:
+                    m.momentum = 0.0
+                try:
+                    return _update_agent(policy, optimizer, observations, prev_actions, not_done_masks, corrected_actions, weights,
+                                         hidden_size, step_grad, loss_accumulation_scalar, world, tour_not_done_masks, rnn_states)
+                finally:
+                    for m, (mom, nbt) in zip(bns, saved):
+                        m.momentum = mom
+                        if nbt is not None:
+                            m.num_batches_tracked.copy_(nbt)
             ops.check_seq_sync()  # the stream was just synchronised by .item(): a timed-out persistent GRU is an error
     if carry:
         return (al + ax) * scale, al, ax, rnn_out.detach()
@@ -336,45 +350,43 @@ class TrajectoryStore:
 
 
 def collate_fn(batch):
-    """dagger_trainer.py:42-117: pad every trajectory to the longest (obs with 1.0, actions/weights with
-    0), stack on dim 1 and flatten to time-major (T*N, ...); masks zero on the first step."""
+    """Trajectories -> one padded time-major batch: what dagger_trainer.py:42-117 returns (observations (T*N, ...) padded
+    with 1, previous / corrected actions and weights padded with 0, a not-done mask that is 0 on the first step only),
+    built the way the H2D copy wants it: every output is ONE (T, N, ...) slab allocated once - in pinned host memory when
+    a GPU is present, so PrefetchLoader's asynchronous copy reads it in place - pre-filled with its pad value, and each
+    trajectory is slice-copied into its column.  No per-trajectory pad tensors, no cat / stack intermediates, no second
+    pinning copy.  Pinned by tests/golden/collate_golden.json (values and dtypes)."""
+    n = len(batch)
+    lengths = [int(item[1].shape[0]) for item in batch]
+    T = max(lengths)
+    pinned = torch.cuda.is_available()
 
-    def _pad(t, max_len, fill_val=0):
-        pad_amount = max_len - t.size(0)
-        if pad_amount == 0:
-            return t
-        pad = torch.full_like(t[0:1], fill_val).expand(pad_amount, *t.size()[1:])
-        return torch.cat([t, pad], dim=0)
+    def slab(like, fill):
+        return torch.full((T, n) + tuple(like.shape[1:]), fill, dtype=like.dtype, pin_memory=pinned)
 
-    obs_b, prev_b, corr_b, w_b = [list(x) for x in zip(*batch)]
-    B = len(prev_b)
-    new_obs = defaultdict(list)
-    for sensor in obs_b[0]:
-        for bid in range(B):
-            new_obs[sensor].append(obs_b[bid][sensor])
-    max_len = max(e.size(0) for e in prev_b)
-    for bid in range(B):
-        for sensor in new_obs:
-            new_obs[sensor][bid] = _pad(new_obs[sensor][bid], max_len, fill_val=1.0)
-        prev_b[bid] = _pad(prev_b[bid], max_len)
-        corr_b[bid] = _pad(corr_b[bid], max_len)
-        w_b[bid] = _pad(w_b[bid], max_len)
-    out_obs = {}
-    for sensor in new_obs:
-        s = torch.stack(new_obs[sensor], dim=1)
-        out_obs[sensor] = s.view(-1, *s.size()[2:])
-    prev = torch.stack(prev_b, dim=1)
-    corr = torch.stack(corr_b, dim=1)
-    w = torch.stack(w_b, dim=1)
-    nd = torch.ones_like(corr, dtype=torch.uint8)
-    nd[0] = 0
-    return out_obs, prev.view(-1, 1), nd.view(-1, 1), corr, w
+    first_obs, first_prev, first_corr, first_w = batch[0]
+    obs = {k: slab(v, 1) for k, v in first_obs.items()}
+    prev, corr, weights = slab(first_prev, 0), slab(first_corr, 0), slab(first_w, 0)
+    for col, (o, p, c, w) in enumerate(batch):
+        L = lengths[col]
+        for k, dst in obs.items():
+            dst[:L, col] = o[k]
+        prev[:L, col], corr[:L, col], weights[:L, col] = p, c, w
+    not_done = torch.ones(corr.shape, dtype=torch.uint8, pin_memory=pinned)
+    not_done[0] = 0
+    flat = {k: v.view((T * n,) + tuple(v.shape[2:])) for k, v in obs.items()}
+    return flat, prev.view(-1, 1), not_done.view(-1, 1), corr, weights
 
 
 def _block_shuffle(lst, block_size):
-    blocks = [lst[i:i + block_size] for i in range(0, len(lst), block_size)]
-    random.shuffle(blocks)
-    return [e for b in blocks for e in b]
+    """Consecutive runs of `block_size` elements in a shuffled order (the runs stay intact; dagger_trainer.py:120-125's
+    contract incl. its draw sequence: ONE `random.shuffle` over as many items as there are runs)."""
+    starts = list(range(0, len(lst), block_size))
+    random.shuffle(starts)
+    out = []
+    for s0 in starts:
+        out.extend(lst[s0:s0 + block_size])
+    return out
 
 
 class IWTrajectoryDataset(torch.utils.data.IterableDataset):
@@ -535,6 +547,9 @@ class BaseVLNCETrainer:
         if self.device.type != "cuda" or not depth_net.any_failed():
             return None
         depth_net.recover_all()
+        # the launch path changed (the persistent form is retired): the next capture warms the new path up on its capture
+        # streams first - without stepping the mapper, whose world cloud belongs to the rollout in progress (_make_runner)
+        self._rewarm_next_capture = True
         if runner is not None:
             actions = runner.redo_last_step_eagerly()
             out = (actions, runner.rnn_states)
@@ -595,9 +610,12 @@ class BaseVLNCETrainer:
 
         # the three-graph split is MapCMANet's staging; other policies replay one graph on one stream
         split = type(self.policy).__name__ == "MapCMAPolicy"
-        keep = {k: v.clone() for k, v in self.policy.named_buffers()} if (first and self.policy.training) else None
+        rewarm = (not first) and getattr(self, "_rewarm_next_capture", False)
+        self._rewarm_next_capture = False
+        keep = {k: v.clone() for k, v in self.policy.named_buffers()} if ((first or rewarm) and self.policy.training) else None
         runner = GraphedRollout(self.policy, self.obs_transforms, batch, deterministic=deterministic,
-                                streams="split" if split else False, warmup=2 if first else 0, extra_keys=extra_keys)
+                                streams="split" if split else False, warmup=2 if first else (1 if rewarm else 0),
+                                extra_keys=extra_keys, warmup_mapper=not rewarm)
         if first:
             for t in self.obs_transforms:
                 if getattr(t, "mapping_module", None) is not None:
@@ -990,7 +1008,7 @@ class PrefetchLoader:
         def pin(x):
             if isinstance(x, dict):
                 return {k: pin(v) for k, v in x.items()}
-            return x.pin_memory() if (cuda and torch.is_tensor(x)) else x
+            return x.pin_memory() if (cuda and torch.is_tensor(x) and not x.is_pinned()) else x  # (collate_fn's slabs already are)
 
         def work():
             try:

@@ -36,3 +36,35 @@ def test_product_path_never_imports_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or "libmapper_ref" in txt:
                     bad.append(f)
     assert not bad, f"product files reference the oracle: {bad}"
+
+
+def test_mfma_family_has_one_definition():
+    """The family behind `roofline.traffic` / `mfma_busy` / the FLOP hooks: tools/kernel_family.py mirrors
+    ivln_family_kernel_names(), and every IVLN_LAUNCH_FAMILY site in csrc/ launches a kernel of that list."""
+    import sys
+
+    import __graft_entry__ as ge
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from kernel_family import FAMILY_KERNELS, base_name, is_family
+
+    L = ctypes.CDLL(ge.build())
+    L.ivln_family_kernel_names.restype = ctypes.c_char_p
+    assert tuple(L.ivln_family_kernel_names().decode().split(",")) == FAMILY_KERNELS
+    csrc = os.path.join(ROOT, "ivln-ce_amd", "csrc")
+    seen = set()
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith(".hip"):
+            continue
+        txt = open(os.path.join(csrc, f)).read()
+        for m in re.finditer(r"IVLN_LAUNCH_FAMILY\(\s*\(?\s*([A-Za-z_0-9]+)", txt):
+            assert m.group(1) in FAMILY_KERNELS, f"{f}: IVLN_LAUNCH_FAMILY({m.group(1)} ...) is not in the family list"
+            seen.add(m.group(1))
+        for m in re.finditer(r'IVLN_LAUNCH_FAMILY_NAMED\(\s*"([A-Za-z_0-9]+)"', txt):
+            assert m.group(1) in FAMILY_KERNELS, f"{f}: IVLN_LAUNCH_FAMILY_NAMED(\"{m.group(1)}\" ...) is not in the family list"
+            seen.add(m.group(1))
+    assert seen == set(FAMILY_KERNELS), (sorted(seen), FAMILY_KERNELS)
+    # rocprofv3's kernel names reduce to the same base names
+    assert base_name('void (anonymous namespace)::k_conv1x1_bf3_ks<2, 4, true>(ivln_gemm_desc, int)') == "k_conv1x1_bf3_ks"
+    assert base_name('"k_conv_bf3<3, 2, 1, 8, 16, 32, 1, 3, false>(ivln_gemm_desc, unsigned int const*, lo"') == "k_conv_bf3"
+    assert is_family("k_depth_net(DnArgs)") and not is_family("k_conv_bf3_pack<3>(float const*)") and not is_family("k_add(float*)")

@@ -720,6 +720,36 @@ def test_conv2d_split_bf16_1x1_form(N, Cin, H, Cout, stride):
         assert float((y.double().cpu() - ref).abs().max()) <= 3e-6 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("N,Cin,H,Cout,G", [(16, 256, 64, 512, 2), (16, 512, 32, 1024, 2), (16, 1024, 16, 2048, 2), (3, 64, 16, 96, 0)])
+def test_stride2_1x1_conv_through_the_gather_equals_the_strided_read(N, Cin, H, Cout, G):
+    """ops.conv2d gathers the input of a stride-2 1x1 conv (RedNet's downsample branches, rednet.py:226-232, image-grouped
+    over the stacked encoders) into a dense quarter-size tensor and runs the stride-1 register-built split-bf16 kernel on it;
+    IVLN_S2_GATHER=0 reads the input strided (the tiled 1x1 form / the fp32 GEMM).  Both against float64 (3e-6 of the largest
+    output); the gather itself is a copy (bit-equal to slicing)."""
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(N + Cin + Cout)
+    x = torch.randn(N, Cin, H, H, generator=g)
+    ws = [torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5 for _ in range(max(G, 1))]
+    sc, sh = torch.rand(max(G, 1) * Cout, generator=g) + 0.5, torch.randn(max(G, 1) * Cout, generator=g)
+    per = N // max(G, 1)
+    ref = torch.cat([F.conv2d(x[i * per:(i + 1) * per].double(), ws[i].double(), stride=2) * sc[i * Cout:(i + 1) * Cout].double().view(1, -1, 1, 1)
+                     + sh[i * Cout:(i + 1) * Cout].double().view(1, -1, 1, 1) for i in range(max(G, 1))])
+    w = (torch.stack(ws) if G else ws[0]).contiguous().to(DEV)
+    xd = x.to(DEV)
+    assert torch.equal(ops.pool2d(xd, 1, 2, 0, "max"), xd[:, :, ::2, ::2])
+    outs = {}
+    for gather in (True, False):
+        prev, ops.S2_GATHER = ops.S2_GATHER, gather
+        try:
+            outs[gather] = ops.conv2d(xd, w, stride=2, scale=sc.to(DEV), shift=sh.to(DEV))
+        finally:
+            ops.S2_GATHER = prev
+    for y in outs.values():
+        assert y.shape == ref.shape
+        assert float((y.double().cpu() - ref).abs().max()) <= 3e-6 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize(
     "N,Cin,H,Cout",
     [(6, 14, 64, 32),      # map CNN layer 1: 32 x 512 tile, two column tiles (686 columns: ragged), strips of two rows

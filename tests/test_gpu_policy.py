@@ -448,13 +448,21 @@ def test_replayed_step_whose_persistent_encoder_timed_out_is_redone_on_the_launc
     B, steps = 4, 7
     obs, _ = _episode_script(B, steps, seed=11)
 
-    def run(fail_at):
+    def run(fail_at, recapture=False, pol=pol):
         tr = GTSemanticsIterativeMapper.from_config(get_config())
         runner = GraphedRollout(pol, [tr], obs[0], deterministic=True, streams="split")
         tr.mapping_module.reset()
         runner.reset_state()
         out, rnn, prev = [], None, None
         for t, o in enumerate(obs):
+            if runner is None and recapture:
+                # what the loops do on their next step (trainers._make_runner with _rewarm_next_capture): a new capture whose
+                # warm-up runs the launch chain on the capture streams WITHOUT stepping the mapper, seeded with the carried state
+                n_before = tr.mapping_module.status()
+                runner = GraphedRollout(pol, [tr], o, deterministic=True, streams="split", warmup=1, warmup_mapper=False)
+                assert tr.mapping_module.status() == n_before, "the re-capture stepped the world cloud"
+                runner.rnn[runner.phase].copy_(rnn)
+                runner.prev[runner.phase].copy_(prev)
             if runner is not None:
                 if t == fail_at:
                     plan = depth_net.plan_for(pol.net.depth_encoder.visual_encoder, torch.device("cuda:0"))
@@ -483,3 +491,13 @@ def test_replayed_step_whose_persistent_encoder_timed_out_is_redone_on_the_launc
     for t in range(steps):
         assert torch.equal(hurt[t][0], healthy[t][0]), f"actions step {t}"
         assert float((hurt[t][1] - healthy[t][1]).abs().max()) < 2e-4, f"rnn step {t}"
+    # ... and with the rest of the rollout REPLAYED from a capture made after the recovery (the new graphs record
+    # the launch chain on streams that have to have run it eagerly first): the same steps as the eager continuation, bit for bit
+    pol2 = make_policy()  # (the same deterministic weights; a new encoder object = a plan that has not been retired)
+    for p in pol2.net.depth_encoder.visual_encoder.parameters():
+        p.requires_grad_(False)
+    again = run(3, recapture=True, pol=pol2)
+    assert not depth_net.any_failed()
+    for t in range(steps):
+        assert torch.equal(again[t][0], hurt[t][0]), f"actions step {t} (recaptured)"
+        assert torch.equal(again[t][1], hurt[t][1]), f"rnn step {t} (recaptured)"
