@@ -226,6 +226,10 @@ typedef struct ivln_gemm_desc {
      * Taken by the stride-1 1x1 split-bf16 kernels only (csrc/conv_bf3.hip: k_conv1x1_bf3_ks); any other route returns
      * IVLN_E_UNSUPPORTED and the caller issues conv + add. */
     int residual_after_relu;
+    /* IVLN_B_CONV_K2 -> IVLN_D_NCHW_UP2X4 only: how many of the 16 window taps of the four stacked parity classes are real
+     * (9 for a stride-2 3x3 transposed conv; 0 = all).  Arithmetic ignores it - the zero-padded taps multiply zeros - it only
+     * makes ivln_conv_split_counters tally ALGORITHMIC FLOPs instead of executed ones. */
+    int real_taps;
 } ivln_gemm_desc;
 
 int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream);

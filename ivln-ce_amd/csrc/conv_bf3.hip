@@ -39,7 +39,14 @@ typedef int v2i __attribute__((ext_vector_type(2)));
 constexpr int PIXB = 112;   // bytes per staged pixel: 3 pieces x 16 channels x 2 bytes + 16 of padding
 constexpr int CB = 16;      // input channels per chunk = K of one MFMA
 
-__host__ __device__ constexpr int bf3_taps_padded(int KS) { return KS == 7 ? 54 : (KS == 3 ? 9 : 1); }  // multiple of every prefetch depth used (3, 6 | 3, 9)
+__host__ __device__ constexpr int bf3_taps_padded(int KS) { return KS == 7 ? 54 : (KS == 3 ? 9 : (KS == 2 ? 4 : 1)); }  // multiple of every prefetch depth used (3, 6 | 3, 9 | 2, 4)
+// KS == 2: the 2 x 2 window of the stacked output-parity classes of a stride-2 3x3 transposed conv (IVLN_B_CONV_K2 ->
+// IVLN_D_NCHW_UP2X4, rednet.py:152-181: taps at input offsets 0..1, pad 0, the row / column past the edge reads as zero; rows
+// m = 4 * channel + class, a row's pixel (ho, wo) is output pixel (2 ho + a, 2 wo + b) of channel m / 4).
+// Patch geometry of a (PTH x PTW) tile: rows ho0 - pad .. + PTH + KS - 2; columns on a grid of aligned 16-byte groups that
+// starts bf3_gx0(KS) pixels left of the tile (odd kernels need the left halo's group, the 2 x 2 window does not).
+__host__ __device__ constexpr int bf3_gx0(int KS) { return KS == 2 ? 0 : 4; }
+__host__ __device__ constexpr int bf3_xoff(int KS) { return KS == 2 ? 0 : 4 - KS / 2; }  // patch column x = pixel x + XOFF of the group grid
 __host__ __device__ constexpr int bf3_stage_chunks(int KS) { return KS == 1 ? 4 : 1; }  // 16-channel chunks staged per barrier pair (1x1: one tap per chunk)
 
 // x -> the upper 16 bits of its three pieces (see the header): round-to-nearest-even at each step, remainders exact.
@@ -151,8 +158,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
     // first version's `if (c + 1 < c_end) load_patch` made it wait for the NEXT chunk's patch (an HBM round trip) at the
     // first tap of every chunk (s_waitcnt vmcnt(13) with 50 loads in flight).
     // 1x1 (CS chunks per stage, no halo): the flat (pixel, pair) enumeration with offsets re-derived per stage.
-    constexpr int XOFF = 4 - KS / 2;                 // patch column x is pixel x + XOFF of the aligned group grid
+    constexpr int XOFF = bf3_xoff(KS);               // patch column x is pixel x + XOFF of the aligned group grid
     constexpr int NG = (XOFF + PWR + 3) / 4;         // 16-byte groups per patch row
+    constexpr bool UP = KS == 2;                     // rows = 4 * channel + parity class, stores into the (2 H x 2 W) output
     constexpr int ITEMS3 = IMGS * PH * NG * (CB / 2);
     constexpr int NI3 = KS == 1 ? 1 : (ITEMS3 + NTB - 1) / NTB;
     constexpr unsigned OOB = 0x80000000u;            // (>= num_records of the descriptor: the load returns zeros)
@@ -165,7 +173,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
         for (int j = 0; j < NI3; ++j) {
             const int idx = t + j * NTB, rest = idx >> 3;
             const int g = rest % NG, yy = rest / NG, il = yy / PH, y = yy - il * PH;
-            const int hi = ho0 - p.pad + y, wi = wo0 - 4 + 4 * g, img = img0 + il;
+            const int hi = ho0 - p.pad + y, wi = wo0 - bf3_gx0(KS) + 4 * g, img = img0 + il;
             const bool ok = idx < ITEMS3 && img < nimg && (unsigned)hi < (unsigned)p.Hin && wi >= 0 && wi + 3 < p.Win;
             ivo[j] = ok ? (unsigned)(((int64_t)img * p.in_img_stride + (int64_t)(2 * qpair) * HW + hi * p.Win + wi) * 4) : OOB;
             idst[j] = ((il * PH + y) * PWR + 4 * g - XOFF) * PIXB + qpair * 4;  // pixel e of the group: + e * PIXB
@@ -550,6 +558,42 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
         }
         __syncthreads();
         const int mbase = m0 + slab * 32;
+        if constexpr (UP) {
+            // the slab's 32 rows = 8 channels x 4 parity classes; rows 4 c + 2 a (b = 0) and + 1 (b = 1) x two horizontally
+            // adjacent pixels of the tile = four consecutive floats of output row 2 ho + a: one 16-byte store per
+            // (channel, a, pixel pair), whole 64-byte segments of the (2 H x 2 W) tensor (gemm_common.h: up2x4_wide_store)
+            for (int idx = t; idx < 16 * (BN / 2); idx += NTB) {
+                const int r = idx / (BN / 2), j = idx - r * (BN / 2);  // r = 2 * (channel of the slab) + a
+                const int ml = 2 * r, nl = 2 * j;
+                const int il = nl / (PTH * PTW), ph = (nl / PTW) % PTH, pw = nl % PTW;
+                const int img = img0 + il, ho = ho0 + ph, wo = wo0 + pw;
+                if (mbase + ml >= p.M || img >= nimg || ho >= p.Hout || wo >= p.Wout) continue;  // (M % 4 == 0, Wout % 4 == 0: in or out whole)
+                const int co = (mbase + ml) >> 2, a = r & 1;
+                const int64_t addr = (((int64_t)img * p.Ctot + co) * (2 * p.Hout) + 2 * ho + a) * (2 * p.Wout) + 2 * wo;
+                const float2 t0 = *reinterpret_cast<const float2*>(T + ml * LDT + nl);
+                const float2 t1 = *reinterpret_cast<const float2*>(T + (ml + 1) * LDT + nl);
+                float4 v = make_float4(t0.x, t1.x, t0.y, t1.y);
+                if (p.scale) {
+                    const float sc = p.scale[co], sh = p.shift[co];
+                    v.x = fmaf(v.x, sc, sh), v.y = fmaf(v.y, sc, sh), v.z = fmaf(v.z, sc, sh), v.w = fmaf(v.w, sc, sh);
+                } else if (p.shift) {
+                    const float sh = p.shift[co];
+                    v.x += sh, v.y += sh, v.z += sh, v.w += sh;
+                }
+                if (p.residual) {
+                    const float4 rr = *reinterpret_cast<const float4*>(p.residual + addr);
+                    v.x += rr.x, v.y += rr.y, v.z += rr.z, v.w += rr.w;
+                }
+                if (p.accumulate) {
+                    const float4 rr = *reinterpret_cast<const float4*>(p.D + addr);
+                    v.x += rr.x, v.y += rr.y, v.z += rr.z, v.w += rr.w;
+                }
+                if (p.relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+                *reinterpret_cast<float4*>(p.D + addr) = v;
+            }
+            __syncthreads();
+            continue;
+        }
         for (int idx = t; idx < 32 * (BN / 4); idx += NTB) {
             const int ml = idx / (BN / 4), c4 = idx - ml * (BN / 4);
             const int m = mbase + ml;
@@ -632,7 +676,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
 //     launch, the same bits on every run.
 // L2 -> CU traffic is the price: every workgroup streams its 32 channels' weights for the whole K (885 KB at K = 4608).
 // ------------------------------------------------------------------------------------------------------------------
-template <int PTH, int PTW, int TN = 2>
+// KS = 2: the same kernel for the stacked parity classes of a stride-2 3x3 transposed conv over few pixels (the decoder's first
+// upsampling stages, rednet.py:152-181 at 8 x 8 and 16 x 16): rows = 4 * channel + class, a 2 x 2 window, and an epilogue that
+// stores 2 x 2 output blocks (IVLN_D_NCHW_UP2X4).
+template <int PTH, int PTW, int TN = 2, int KS = 3>
 __global__ __launch_bounds__(512, 2) void k_conv_bf3_ks(const ivln_gemm_desc p, const unsigned char* a_split, long long a_grp_bytes,
                                                         int tiles_w, int tiles_h, int nimg) {
     // DA: weight taps in flight.  A tap is only 12 MFMAs here (384 pipe cycles, 768 with the SIMD's other wave): three taps
@@ -640,10 +687,11 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf3_ks(const ivln_gemm_desc p, 
     // 512 x 512 x 4608 with 13 us of MFMA issue).  A whole chunk ahead (9 taps, 108 registers) covers it.
     // TN = 1 (32 pixels per workgroup): the launches that fill less than half the chip with 64-pixel tiles (512 x 512 x 4608:
     // 128 workgroups) - twice the workgroups, half the MFMAs per wave, 20 % more halo per output.
-    constexpr int NW = 8, KS = 3, KK = 9, DA = 9;
-    static_assert(PTH * PTW == 32 * TN, "32 TN pixels per workgroup");
-    constexpr int PH = PTH + 2, PWR = PTW + 2, NPIX = PH * PWR;
-    constexpr int XOFF = 3, NG = (XOFF + PWR + 3) / 4;
+    constexpr int NW = 8, KK = KS * KS, DA = KK;
+    constexpr bool UP = KS == 2;
+    static_assert(PTH * PTW == 32 * TN && (KS == 3 || KS == 2), "32 TN pixels per workgroup");
+    constexpr int PH = PTH + KS - 1, PWR = PTW + KS - 1, NPIX = PH * PWR;
+    constexpr int XOFF = bf3_xoff(KS), NG = (XOFF + PWR + 3) / 4;
     constexpr int ITEMS = PH * NG * (CB / 2), NI = (ITEMS + 63) / 64;
     constexpr int WREG = (NPIX * PIXB + 15) & ~15;  // bytes of a wave's patch region
     constexpr int LDT = 32 * TN + 4;
@@ -673,7 +721,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf3_ks(const ivln_gemm_desc p, 
     for (int j = 0; j < NI; ++j) {
         const int idx = lane + j * 64, rest = idx >> 3;
         const int g = rest % NG, y = rest / NG;
-        const int hi = ho0 - 1 + y, wi = wo0 - 4 + 4 * g;
+        const int hi = ho0 - (KS == 3 ? 1 : 0) + y, wi = wo0 - bf3_gx0(KS) + 4 * g;  // (pad 1 | the 2 x 2 window starts at the pixel itself)
         const bool ok = idx < ITEMS && img0 < nimg && (unsigned)hi < (unsigned)p.Hin && wi >= 0 && wi + 3 < p.Win;
         ivo[j] = ok ? (unsigned)(((int64_t)img0 * p.in_img_stride + (int64_t)(2 * qpair) * HW + hi * p.Win + wi) * 4) : OOB;
         idst[j] = (y * PWR + 4 * g - XOFF) * PIXB + qpair * 4;
@@ -782,7 +830,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf3_ks(const ivln_gemm_desc p, 
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) abuf[slot][pl] = load_a(s0 + r + DA, pl);
-                if (r == 1) load_patch(min(c + 1, c1 - 1));  // (next chunk's patch: 7 taps of MFMA work before the staging pass reads it)
+                if (r == (KK > 4 ? 1 : 0)) load_patch(min(c + 1, c1 - 1));  // (next chunk's patch: 7 | 3 taps of MFMA work before the staging pass reads it)
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -799,7 +847,44 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf3_ks(const ivln_gemm_desc p, 
         for (int r = 0; r < 16; ++r)
             red[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * LDT + tn * 32 + l31] = acc[tn][r];
     __syncthreads();
-    if (t < 32 * 8 * TN) {
+    if constexpr (UP) {
+        // 8 channels x 2 rows of the 2 x 2 blocks x 16 TN pixel pairs: GEMM rows 4 c + 2 a (b = 0) and + 1 (b = 1) at two
+        // horizontally adjacent pixels = four consecutive floats of output row 2 ho + a
+        if (t < 16 * 16 * TN) {
+            const int r = t / (16 * TN), j = t % (16 * TN);
+            const int ml = 2 * r, nl = 2 * j;
+            const int ph = nl / PTW, pw = nl % PTW;
+            const int ho = ho0 + ph, wo = wo0 + pw;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {  // fixed order
+                const float2 u0 = *reinterpret_cast<const float2*>(red + (w * 32 + ml) * LDT + nl);
+                const float2 u1 = *reinterpret_cast<const float2*>(red + (w * 32 + ml + 1) * LDT + nl);
+                v.x += u0.x, v.y += u1.x, v.z += u0.y, v.w += u1.y;
+            }
+            if (m0 + ml < p.M && img0 < nimg && ho < p.Hout && wo < p.Wout) {
+                const int co = (m0 + ml) >> 2, a = r & 1;
+                const int64_t addr = (((int64_t)img0 * p.Ctot + co) * (2 * p.Hout) + 2 * ho + a) * (2 * p.Wout) + 2 * wo;
+                if (p.scale) {
+                    const float sc = p.scale[co], sh = p.shift[co];
+                    v.x = fmaf(v.x, sc, sh), v.y = fmaf(v.y, sc, sh), v.z = fmaf(v.z, sc, sh), v.w = fmaf(v.w, sc, sh);
+                } else if (p.shift) {
+                    const float sh = p.shift[co];
+                    v.x += sh, v.y += sh, v.z += sh, v.w += sh;
+                }
+                if (p.residual) {
+                    const float4 rr = *reinterpret_cast<const float4*>(p.residual + addr);
+                    v.x += rr.x, v.y += rr.y, v.z += rr.z, v.w += rr.w;
+                }
+                if (p.accumulate) {
+                    const float4 rr = *reinterpret_cast<const float4*>(p.D + addr);
+                    v.x += rr.x, v.y += rr.y, v.z += rr.z, v.w += rr.w;
+                }
+                if (p.relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+                *reinterpret_cast<float4*>(p.D + addr) = v;
+            }
+        }
+    } else if (t < 32 * 8 * TN) {
         const int ml = t / (8 * TN), c4 = t % (8 * TN);  // 32 channels x 8 TN pixel quads
         const int m = m0 + ml, nl = 4 * c4;
         const int ph = nl / PTW, pw = nl % PTW;
@@ -846,12 +931,12 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf3_ks(const ivln_gemm_desc p, 
 #endif
 }
 
-template <int PTH, int PTW, int TN = 2>
+template <int PTH, int PTW, int TN = 2, int KS = 3>
 int launch_bf3_ks_tile(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a_split, int64_t grp_bytes, int nimg) {
-    constexpr int NPIX = (PTH + 2) * (PTW + 2), WREG = (NPIX * PIXB + 15) & ~15, RED = 8 * 32 * (32 * TN + 4) * 4;
+    constexpr int NPIX = (PTH + KS - 1) * (PTW + KS - 1), WREG = (NPIX * PIXB + 15) & ~15, RED = 8 * 32 * (32 * TN + 4) * 4;
     constexpr size_t lds = (size_t)(8 * WREG > RED ? 8 * WREG : RED);
     static_assert(lds <= 160 * 1024, "patch regions do not fit");
-    auto kern = k_conv_bf3_ks<PTH, PTW, TN>;
+    auto kern = k_conv_bf3_ks<PTH, PTW, TN, KS>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return IVLN_E_HIP;
@@ -866,6 +951,19 @@ int launch_bf3_ks_tile(const ivln_gemm_desc& d, hipStream_t s, const unsigned ch
 // Eligibility of the K-split-over-waves kernel: deep 3x3 convs over few pixels.  mode: 0 = heuristic, 1 = insist (tests, tuning)
 int bf3_ks_launch(ivln_gemm_desc& d, hipStream_t s, int nimg, int mode, int tn_pin = 0) {
     if (d.Cin % CB != 0 || d.Cin < 8 * CB || d.stat_partials || d.splits > 1) return IVLN_E_UNSUPPORTED;
+    if (d.bmode == BMODE_CONV_K2) {  // the stacked transposed-conv classes: 64-pixel tiles, no image groups
+        if (d.grp_imgs > 0 || (d.Wout != 8 && d.Wout != 16 && d.Wout != 32) || d.Hout % (64 / d.Wout) != 0 || (d.in_img_stride & 3) ||
+            (((uintptr_t)d.B) & 15) || (int64_t)nimg * d.in_img_stride * 4 >= (int64_t)1 << 31)
+            return IVLN_E_UNSUPPORTED;
+        const int64_t wgs2 = (int64_t)(d.N / 64) * ((d.M + 31) / 32);
+        if (mode == 0 && (wgs2 > 2 * (int64_t)ivln_cu_count() || wgs2 < ivln_cu_count() / 4)) return IVLN_E_UNSUPPORTED;
+        d.splits = 1;
+        const unsigned char* a2 = (const unsigned char*)d.A_split;
+        const int64_t gb2 = d.a_split_grp_stride * 4;
+        if (d.Wout == 8) return launch_bf3_ks_tile<8, 8, 2, 2>(d, s, a2, gb2, nimg);
+        if (d.Wout == 16) return launch_bf3_ks_tile<4, 16, 2, 2>(d, s, a2, gb2, nimg);
+        return launch_bf3_ks_tile<2, 32, 2, 2>(d, s, a2, gb2, nimg);
+    }
     if (d.Wout != 8 && d.Wout != 16 && d.Wout != 32) return IVLN_E_UNSUPPORTED;
     const int64_t wgs = (int64_t)(d.N / 64) * ((d.M + 31) / 32);
     // 32-pixel tiles where 64-pixel ones leave half of the CUs without a workgroup; IVLN_BF3_KS_TN = 1 | 2 pins one (tuning)
@@ -1303,7 +1401,16 @@ template <int KS>
 int launch_bf3_ks(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a, int64_t gb, int nimg, int cfg, int cps) {
     // weight taps in flight: a tap is 24 MFMAs = 768 pipe cycles per wave (12 = 384 with one channel tile per wave), an L2 /
     // MALL round trip ~2000
-    constexpr int DA2 = KS == 1 ? 2 : 3, DA1 = KS == 1 ? 4 : (KS == 7 ? 2 : 3);  // (6 / 9 taps ahead measured the same as 3 and cost 36-72 registers)
+    constexpr int DA2 = KS == 1 || KS == 2 ? 2 : 3, DA1 = KS == 1 || KS == 2 ? 4 : (KS == 7 ? 2 : 3);  // (6 / 9 taps ahead measured the same as 3 and cost 36-72 registers)
+    if constexpr (KS == 2) {  // (the transposed-conv classes: 4 M rows per output channel - only the tiles their shapes take)
+        switch (cfg) {
+            case 2: return launch_bf3_px<KS, 1, 2, 4, DA1>(d, s, a, gb, nimg, cps);   // 64 x 256
+            case 3: return launch_bf3_px<KS, 2, 2, 4, DA2>(d, s, a, gb, nimg, cps);   // 128 x 256
+            case 4: return launch_bf3_px<KS, 1, 2, 2, DA1>(d, s, a, gb, nimg, cps);   // 64 x 128
+            case 5: return launch_bf3_px<KS, 2, 2, 2, DA2>(d, s, a, gb, nimg, cps);   // 128 x 128
+            default: return IVLN_E_UNSUPPORTED;
+        }
+    }
     switch (cfg) {
         case 0: return launch_bf3_px<KS, 1, 1, 8, DA1>(d, s, a, gb, nimg, cps);   // 32 x 512, 8 waves
         case 1: return launch_bf3_px<KS, 2, 1, 8, DA2>(d, s, a, gb, nimg, cps);   // 64 x 512
@@ -1586,7 +1693,7 @@ int launch_wgrad_bf3_w(const ivln_gemm_desc& d, hipStream_t s, int nimg, int str
 }  // namespace
 
 extern "C" int64_t ivln_conv_split_words(int M, int Cin, int KS) {
-    if ((KS != 1 && KS != 3 && KS != 7) || M <= 0 || Cin <= 0) return 0;
+    if ((KS != 1 && KS != 2 && KS != 3 && KS != 7) || M <= 0 || Cin <= 0) return 0;
     return (int64_t)((M + 31) / 32) * ((Cin + CB - 1) / CB) * bf3_taps_padded(KS) * (3 * 1024 / 4);
 }
 
@@ -1632,7 +1739,42 @@ int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
     static const bool disabled = getenv("IVLN_NO_SPLIT_BF16") != nullptr;  // A/B switch
     if (!d.A_split || (disabled && !force)) return IVLN_E_UNSUPPORTED;
     const int KS = d.bmode == BMODE_CONV1X1 ? 1 : conv_ks(d.bmode);
-    if ((KS != 1 && KS != 3 && KS != 7) || d.amode != AMODE_MK || d.dmode != DMODE_NCHW || d.dil != 1) return IVLN_E_UNSUPPORTED;
+    if ((KS != 1 && KS != 2 && KS != 3 && KS != 7) || d.amode != AMODE_MK || d.dil != 1) return IVLN_E_UNSUPPORTED;
+    if (d.dmode != (KS == 2 ? DMODE_NCHW_UP2X4 : DMODE_NCHW)) return IVLN_E_UNSUPPORTED;  // (the 2 x 2 window only as the stacked transposed-conv classes)
+    // algorithmic FLOPs of a launch: the stacked classes multiply their common window's zero padding too (ivln_gemm_desc.real_taps)
+    const double flops_of = 2.0 * d.M * (double)d.N * d.K * (KS == 2 && d.real_taps > 0 ? d.real_taps / 16.0 : 1.0);
+    if (KS == 2) {
+        if (d.stride != 1 || d.pad != 0 || d.Hout != d.Hin || d.Wout != d.Win || (d.M & 3) || d.grp_imgs > 0 || d.stat_partials || d.defer_epilogue ||
+            d.splits > 1 || d.fuse_A_split || d.residual_after_relu || d.img_run_flags || d.K != d.Cin * 4 || d.HoWo != d.Hout * d.Wout ||
+            d.N % d.HoWo != 0 || (d.Wout & 3) || d.Wout < 8 || (((uintptr_t)d.D | (uintptr_t)d.residual) & 15) || d.Ctot * 4 != d.M)
+            return IVLN_E_UNSUPPORTED;
+        const int nimg2 = d.N / d.HoWo;
+        if ((int64_t)nimg2 * d.in_img_stride >= (int64_t)1 << 31) return IVLN_E_UNSUPPORTED;
+        static const bool convt_off = getenv("IVLN_BF3_CONVT") && getenv("IVLN_BF3_CONVT")[0] == '0';  // A/B switch
+        if (convt_off && !force) return IVLN_E_UNSUPPORTED;
+        const int ov2 = d.tile_override;
+        if (ov2 < 20) {  // few pixels: K split over the waves
+            const int rc = bf3_ks_launch(d, s, nimg2, (ov2 == 10 || ov2 == 15) ? 1 : 0);
+            if (rc != IVLN_E_UNSUPPORTED || ov2 == 10 || ov2 == 15) {
+                if (rc == IVLN_OK) g_bf3_flops += flops_of, ++g_bf3_launches, ++g_bf3_kind[1];
+                return rc;
+            }
+        }
+        const int CUS2 = ivln_cu_count();
+        auto blocks2 = [&](int cfg) {
+            const Bf3Px t = bf3_px(kBf3BN[cfg], d.Wout);
+            return (int64_t)((d.Wout + t.ptw - 1) / t.ptw) * ((d.Hout + t.pth - 1) / t.pth) * ((nimg2 + t.imgs - 1) / t.imgs) *
+                   ((d.M + kBf3BM[cfg] - 1) / kBf3BM[cfg]);
+        };
+        // the widest of the four tiles that gives every CU a workgroup (the classes cannot split K: no slabs in this store form)
+        int cfg2 = blocks2(3) >= CUS2 ? 3 : (blocks2(2) >= CUS2 ? 2 : (blocks2(5) >= CUS2 ? 5 : 4));
+        if (ov2 >= 20 && ov2 < 20 + kBf3Cfgs) cfg2 = ov2 - 20;
+        if (!force && blocks2(cfg2) < CUS2 / 2) return IVLN_E_UNSUPPORTED;
+        d.splits = 1;
+        const int rc = launch_bf3_ks<2>(d, s, (const unsigned char*)d.A_split, d.a_split_grp_stride * 4, nimg2, cfg2, (d.Cin + CB - 1) / CB);
+        if (rc == IVLN_OK) g_bf3_flops += flops_of, ++g_bf3_launches, ++g_bf3_kind[0];
+        return rc;
+    }
     // deep-K 1x1 convs: K split over the waves of a workgroup, fragments built in registers (k_conv1x1_bf3_ks);
     // IVLN_BF3_1X1_KS=0 | 1 = never | wherever eligible, tile_override 11 insists
     static const int ks1_env = getenv("IVLN_BF3_1X1_KS") ? atoi(getenv("IVLN_BF3_1X1_KS")) : -1;

@@ -67,19 +67,38 @@ class _CutCapture:
         self._begin()
 
     def __enter__(self):
+        import gc
+
+        # like torch.cuda.graph: garbage (an earlier runner's graphs, events, tensors) is collected BEFORE the capture - and
+        # the collector stays off until it ends: a CUDAGraph or an event destroyed by a collection that happens to trigger
+        # while this stream is capturing is a runtime call the capture does not allow
         torch.cuda.synchronize()
+        self._gc_was_on = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        torch.cuda.empty_cache()
         self.stream.wait_stream(torch.cuda.current_stream())
         self._ctx = torch.cuda.stream(self.stream)
         self._ctx.__enter__()
-        self._begin()
+        try:
+            self._begin()
+        except BaseException:
+            self._ctx.__exit__(None, None, None)
+            if self._gc_was_on:
+                gc.enable()
+            raise
         return self
 
     def __exit__(self, et, ev, tb):
+        import gc
+
         try:
             self.graphs[-1].capture_end()
             self.pool = self.graphs[-1].pool()
         finally:
             self._ctx.__exit__(et, ev, tb)
+            if self._gc_was_on:
+                gc.enable()
         return False
 
 
@@ -288,7 +307,7 @@ class GraphedRollout:
                 for i in range(warmup):
                     run_A()
                     run_B2(i & 1, run_B1(i & 1))
-            if warmup:
+            if warmup and os.environ.get("IVLN_CAPTURE_STREAM_WARMUP", "1") != "0":
                 # ... and once on the streams the graphs are captured on: per-stream state (split-K workspaces, GroupNorm /
                 # packed-weight scratch, the depth encoder's arena) must not be born inside a capture - a buffer from a
                 # graph's private pool would end up in a process-wide cache

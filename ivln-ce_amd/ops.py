@@ -45,6 +45,7 @@ class GemmDesc(C.Structure):
         ("img_run_flags", vp),
         ("fuse_A_split", vp), ("fuse_a_grp_stride", i64), ("fuse_scale", vp), ("fuse_shift", vp), ("fuse_M", i32),
         ("residual_after_relu", i32),
+        ("real_taps", i32),
     ]
 
 
@@ -360,6 +361,7 @@ SPLIT_BF16 = os.environ.get("IVLN_SPLIT_BF16", "1") != "0"
 SPLIT_BF16_WGRAD = os.environ.get("IVLN_SPLIT_BF16_WGRAD", "1") != "0"
 SPLIT_BF16_1X1 = int(os.environ.get("IVLN_SPLIT_BF16_1X1", "-1"))  # -1: by measured rule (ops.conv2d), 0 never, 1 always
 BF3_1X1_KS = os.environ.get("IVLN_BF3_1X1_KS", "1") != "0"  # A/B: 0 = deep-K 1x1 convs stay on the fp32 GEMM kernels
+BF3_CONVT = os.environ.get("IVLN_BF3_CONVT", "1") != "0"  # A/B: 0 = stride-2 3x3 transposed convs stay on the fp32 direct kernel
 S2_GATHER = os.environ.get("IVLN_S2_GATHER", "1") != "0"  # A/B: 0 = stride-2 1x1 convs read their input strided (tiled 1x1 form)
 SPLIT_BF16_MIN_OUT = int(os.environ.get("IVLN_SPLIT_BF16_MIN_OUT", str(1 << 18)))  # output elements below which nothing is packed
 _stat_ws = {}
@@ -657,6 +659,15 @@ def conv_transpose2d_s2(x, classes, scale=None, shift=None, residual=None, relu=
                 pk = packed_conv_weights(w)
                 if pk is not None:
                     d.A_packed = dptr(pk)
+            # the stacked classes on the split-bf16 kernels (csrc/conv_bf3.hip, KS = 2: K split over the waves for the
+            # pixel-starved first upsampling stages, the tiled kernel beyond); the C side decides and falls back to the above
+            if (w is stacked and SPLIT_BF16 and BF3_CONVT and Cin % 16 == 0 and W % 4 == 0 and W >= 8 and w.is_contiguous()
+                    and (N * H * W * w.shape[0] >= SPLIT_BF16_MIN_OUT or TILE_OVERRIDE >= 9)):
+                sp = packed_conv_weights(w, split=True)
+                if sp is not None:
+                    d.A_split = dptr(sp)
+                    d.a_split_grp_stride = sp.numel()
+                    d.real_taps = sum(c.shape[2] * c.shape[3] for _, _, c in classes)
         else:  # taps at input offsets (0..ta-1, 0..tb-1); rows/cols past the edge read as zero
             d.bmode = B_CONV
             koff, kpos = conv_tables(Cin, ta, tb, H, W, 1, x.device)

@@ -996,6 +996,66 @@ def test_vector_load_gemm_refuses_unaligned_shapes():
         ops.TILE_OVERRIDE = 0
 
 
+@pytest.mark.parametrize("N,Cin,H,Cout,form", [(8, 512, 8, 256, "ks"), (8, 256, 16, 128, "ks"), (8, 128, 32, 64, "tiled"), (8, 64, 64, 64, "tiled"),
+                                                (3, 128, 16, 24, "ks"), (2, 48, 32, 40, "tiled")])
+def test_conv_transpose2d_stride2_stacked_classes_on_the_split_bf16_kernels(N, Cin, H, Cout, form):
+    """RedNet's stride-2 3x3 transposed convs (rednet.py:152-181; the four decoder stages at 8 envs + two ragged shapes) as ONE
+    launch of the stacked parity classes on the split-bf16 kernels (csrc/conv_bf3.hip, KS = 2 -> IVLN_D_NCHW_UP2X4): K split
+    over the waves where pixels are few (tile_override 10), the tiled kernel beyond (tile_override 9 lets the library choose,
+    24 pins the 64 x 128 tile).  Against the float64 transposed conv with scale / shift / residual / ReLU: 3e-6 of the largest
+    output, at or below twice the fp32 direct kernel's error; reproducible; the default dispatch takes the same kernels."""
+    import ctypes as C
+
+    from ivln_ce_amd import ops
+    from ivln_ce_amd._lib import lib
+
+    g = torch.Generator().manual_seed(N + Cin + Cout)
+    x = torch.randn(N, Cin, H, H, generator=g)
+    w = torch.randn(Cin, Cout, 3, 3, generator=g) / (Cin * 9 / 4) ** 0.5
+    sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    ref = F.conv_transpose2d(x.double(), w.double(), None, stride=2, padding=1, output_padding=1)
+    res = torch.randn(ref.shape, generator=g)
+    ref = F.relu(ref * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1) + res.double())
+    cls = ops.convt_s2_classes(w.to(DEV), 1)
+    stacked = ops.convt_s2_stack(cls)
+    args = dict(scale=sc.to(DEV), shift=sh.to(DEV), residual=res.to(DEV), relu=True, stacked=stacked)
+    L = lib()
+    L.ivln_conv_split_counters.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]
+    L.ivln_conv_split_kinds.argtypes = [C.POINTER(C.c_longlong), C.c_int]
+
+    def run(override):
+        L.ivln_conv_split_counters(None, None, 1)
+        L.ivln_conv_split_kinds(None, 1)
+        ops.TILE_OVERRIDE = override
+        try:
+            y = ops.conv_transpose2d_s2(x.to(DEV), cls, **args)
+        finally:
+            ops.TILE_OVERRIDE = 0
+        f, n, kinds = C.c_double(0.0), C.c_longlong(0), (C.c_longlong * 4)()
+        L.ivln_conv_split_counters(C.byref(f), C.byref(n), 0)
+        L.ivln_conv_split_kinds(kinds, 0)
+        return y, f.value, n.value, list(kinds)
+
+    scale = float(ref.abs().max())
+    fp32, _, n0, _ = run(6)  # the fp32 direct kernel (2 x 2 window)
+    assert n0 == 0
+    e_fp32 = float((fp32.double().cpu() - ref).abs().max()) / scale
+    got, flops, n1, kinds = run(10 if form == "ks" else 9)
+    assert n1 == 1 and kinds[1 if form == "ks" else 0] == 1, (n1, kinds)
+    # the tally prices the nine real taps, not the sixteen executed ones (ivln_gemm_desc.real_taps)
+    assert abs(flops - 2.0 * Cout * Cin * 9 * N * H * H) < 1e-6 * flops
+    e = float((got.double().cpu() - ref).abs().max()) / scale
+    assert e <= 3e-6 and e <= 2.0 * e_fp32 + 1e-6, (e, e_fp32)
+    again, _, _, _ = run(10 if form == "ks" else 9)
+    assert torch.equal(got, again)
+    if form == "tiled":
+        pinned, _, n2, k2 = run(24)
+        assert n2 == 1 and k2[0] == 1 and float((pinned.double().cpu() - ref).abs().max()) / scale <= 3e-6
+    if N == 8:  # RedNet's own shapes: what the default dispatch launches
+        dflt, _, n3, k3 = run(0)
+        assert n3 == 1 and float((dflt.double().cpu() - ref).abs().max()) / scale <= 3e-6, (n3, k3)
+
+
 @pytest.mark.parametrize("N,Cin,H,W,Cout,k,p,op", [(2, 64, 8, 8, 32, 3, 1, 1), (3, 32, 16, 12, 13, 2, 0, 0),
                                                    (2, 16, 5, 7, 8, 3, 1, 1), (1, 128, 32, 32, 64, 3, 1, 1)])
 def test_conv_transpose2d_stride2_parity_classes(N, Cin, H, W, Cout, k, p, op):

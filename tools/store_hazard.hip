@@ -23,6 +23,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 
 constexpr int ITER = 16;     // store pairs per lane and launch (the fused tail stores 16 registers per tile)
 constexpr int THREADS = 256;
+constexpr unsigned PAD = 4096;  // bytes in front of slot 0
 
 #define CHECK(x)                                                                 \
     do {                                                                         \
@@ -50,7 +51,9 @@ __global__ __launch_bounds__(THREADS) void k_store_pairs(unsigned* __restrict__ 
     for (int it = 0; it < ITER; ++it) {
         const unsigned slot = (lane_id * ITER + it) * 2u;          // 16-byte slots 2i (first store) and 2i + 1 (second)
         const unsigned a = 0xA0000000u ^ (slot * 4u) ^ salt, b = 0xB0000000u ^ (slot * 4u) ^ salt;
-        const unsigned off1 = slot * 16u - (unsigned)soff, off2 = off1 + 16u;  // (the scalar offset is added back by the store)
+        // (the scalar offset is added back by the store; the buffer's range check sees the vector offset alone, which therefore
+        //  must not go negative: the slots start PAD bytes into the buffer)
+        const unsigned off1 = PAD + slot * 16u - (unsigned)soff, off2 = off1 + 16u;
 #define PAIR(PADTXT, SOFF)                                                                                                 \
     asm volatile(                                                                                                          \
         "v_mov_b32 v20, %[a]\n v_add_u32 v21, 1, %[a]\n v_add_u32 v22, 2, %[a]\n v_add_u32 v23, 3, %[a]\n"                  \
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(THREADS) void k_check(const unsigned* __restrict__ 
         const unsigned a = 0xA0000000u ^ (slot * 4u) ^ salt, b = 0xB0000000u ^ (slot * 4u) ^ salt;
         unsigned s_here = 0;
         for (int e = 0; e < 4; ++e) {
-            const unsigned v1 = buf[slot * 4u + e], v2 = buf[slot * 4u + 4u + e];
+            const unsigned v1 = buf[PAD / 4 + slot * 4u + e], v2 = buf[PAD / 4 + slot * 4u + 4u + e];
             if (v1 != a + e) {
                 if (v1 == b + e) ++stale, ++s_here;  // the first store wrote what the registers held AFTER the overwrite
                 else ++other;
@@ -117,7 +120,7 @@ void run(const char* name, int blocks, int launches, unsigned* buf, size_t bytes
 int main(int argc, char** argv) {
     const int launches = argc > 1 ? atoi(argv[1]) : 256;
     const int blocks = 4096;  // x 256 launches = 1.05 M workgroups per variant
-    const size_t bytes = (size_t)blocks * THREADS * ITER * 2 * 16;  // 512 MB
+    const size_t bytes = (size_t)blocks * THREADS * ITER * 2 * 16 + PAD;  // 512 MB
     unsigned* buf;
     unsigned long long* bad;
     CHECK(hipMalloc(&buf, bytes));
