@@ -542,14 +542,13 @@ class UpdateLeg:
         from ivln_ce_amd.aux_losses import AuxLosses
 
         overlap, _train.OVERLAP_INSTRUCTION = _train.OVERLAP_INSTRUCTION, False
-        overlap_w, _train.OVERLAP_WGRAD = _train.OVERLAP_WGRAD, False
         AuxLosses.activate()
         try:
             with GemmTimer() as gt:
                 self.once()
                 ms = gt.total_ms()
         finally:
-            _train.OVERLAP_INSTRUCTION, _train.OVERLAP_WGRAD = overlap, overlap_w
+            _train.OVERLAP_INSTRUCTION = overlap
             AuxLosses.deactivate()
         return mfma_roofline(gt, ms, 1, pmc_traffic_pair("update_pmc_traffic.json"),
                              "k_conv_bf3 / k_wgrad_bf3 (split-bf16: the map CNN's forward convs, input gradients and weight "
@@ -929,8 +928,9 @@ def main():
     if args.only_update:
         ul = UpdateLeg(policy, dev, world)
         ums = ul.timed(barrier, max_over_ranks, iters=max(5, min(K, 20)), reps=1)  # (a collective: every rank)
+        roof = ul.roofline(ums[0])  # (EVERY rank: the instrumented update contains the gradient all-reduce)
         if rank == 0:
-            print(json.dumps({"update_step": {"ms_per_update": round(ums[0], 3), "roofline": ul.roofline(ums[0]),
+            print(json.dumps({"update_step": {"ms_per_update": round(ums[0], 3), "roofline": roof,
                                               "allreduce": ul._allreduce}}), flush=True)
         return
     mode = False if args.no_graph else (True if args.streams else (False if args.single_stream else "split"))
@@ -1056,8 +1056,11 @@ def main():
                           "inflection-weighted CE + progress-monitor aux loss, HIP backward, "
                           + ("one flat RCCL all-reduce, " if world > 1 else "") + "Adam"}
         update["allreduce"] = ul._allreduce
+        # the instrumented pass is one more update_agent call, gradient all-reduce included: every rank runs it (rank 0 alone
+        # left its collective unmatched - found by the 8-rank one-device test of round 6; over RCCL that is a hang)
+        roof = ul.roofline(umed)
         if rank == 0:
-            update["roofline"] = ul.roofline(umed)
+            update["roofline"] = roof
             if world == 1 and not args.no_cpu_baseline:
                 log("cpu baseline (update) ...")
                 update["cpu_baseline"] = ul.cpu_baseline()

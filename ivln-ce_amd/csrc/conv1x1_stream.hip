@@ -136,14 +136,14 @@ inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 // IVLN_OK when launched, IVLN_E_UNSUPPORTED when the shape is not this kernel's (the caller goes on to k_gemm_vec).
 int ivln_conv1x1_stream_launch(const ivln_gemm_desc& d, hipStream_t s, bool force) {
-    static const bool disabled = getenv("IVLN_NO_CONV1X1_STREAM") != nullptr;  // A/B switch
-    static const int min_n = getenv("IVLN_CONV1X1_STREAM_MIN_N") ? atoi(getenv("IVLN_CONV1X1_STREAM_MIN_N")) : 4096;
+    constexpr bool disabled = false;  // A/B switch
+    constexpr int min_n = 4096;
     if ((disabled && !force) || d.amode != AMODE_MK || d.bmode != BMODE_CONV1X1 || d.dmode != DMODE_NCHW) return IVLN_E_UNSUPPORTED;
     // Measured on RedNet's shapes at 8 frames (profiles/r04_rednet_B8_gemm_shapes.txt; us, this kernel vs k_gemm_vec):
     // 1024 x 4096 x 256: 31.9 vs 34.0, 512 x 16384 x 128: 38.0 vs 38.8, 64 x 65536 x 256: 29.7 vs 31.2 - and 256 x 65536 x 64:
     // 54.6 vs 48.8 (that shape moves 151 MB with its residual: HBM-bound either way, and the tiled kernel overlaps its
     // stores better).  K = 64 therefore stays with the tiled kernel unless IVLN_CONV1X1_STREAM_K64 is set.
-    static const bool k64 = getenv("IVLN_CONV1X1_STREAM_K64") != nullptr;
+    constexpr bool k64 = false;
     if (d.K != 128 && d.K != 256 && !(d.K == 64 && (k64 || force))) return IVLN_E_UNSUPPORTED;
     if (d.stride != 1 || d.pad != 0 || d.Hin * d.Win != d.HoWo || d.defer_epilogue || d.splits > 1 || d.stat_partials) return IVLN_E_UNSUPPORTED;
     if ((d.HoWo & 127) || d.N % d.HoWo != 0 || (d.N < min_n && !force) || (d.lda & 3) || (d.in_img_stride & 3)) return IVLN_E_UNSUPPORTED;

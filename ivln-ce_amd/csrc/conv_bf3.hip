@@ -967,7 +967,7 @@ int bf3_ks_launch(ivln_gemm_desc& d, hipStream_t s, int nimg, int mode, int tn_p
     if (d.Wout != 8 && d.Wout != 16 && d.Wout != 32) return IVLN_E_UNSUPPORTED;
     const int64_t wgs = (int64_t)(d.N / 64) * ((d.M + 31) / 32);
     // 32-pixel tiles where 64-pixel ones leave half of the CUs without a workgroup; IVLN_BF3_KS_TN = 1 | 2 pins one (tuning)
-    static const int tn_env = getenv("IVLN_BF3_KS_TN") ? atoi(getenv("IVLN_BF3_KS_TN")) : 0;
+    constexpr int tn_env = 0;
     const bool small = tn_pin ? tn_pin == 1 : (tn_env ? tn_env == 1 : 2 * wgs <= ivln_cu_count());
     const int pth = (small ? 32 : 64) / d.Wout;
     if (d.Hout % pth != 0 || (d.in_img_stride & 3) || (((uintptr_t)d.B) & 15)) return IVLN_E_UNSUPPORTED;
@@ -1262,11 +1262,11 @@ int bf3_1x1_ks_launch(ivln_gemm_desc& d, hipStream_t s, int mode, int form_pin =
     const int nch = d.Cin / CB;
     // wave tiles (no K split) up to 16 chunks, K split over the 8 waves from 32 (in between - 272 ... 496 channels - the K-split
     // form with short slices); IVLN_BF3_1X1_FORM = ks | wt pins one (tuning)
-    static const char* form_env = getenv("IVLN_BF3_1X1_FORM");
+    constexpr const char* form_env = nullptr;
     bool wt = nch <= 16;
     // (32 chunks over MANY pixels - 256 x 16384 x 512, layer 3's first reduction at 8 + 8 images - would be four rounds of one
     //  K-split workgroup per CU: the wave tiles take it, 43.6 against 51.5 us on the tiled 1x1 form and 52.1 K-split, tools/conv_cfg_sweep.py)
-    static const int maxwg0 = getenv("IVLN_BF3_1X1_MAXWG") ? atoi(getenv("IVLN_BF3_1X1_MAXWG")) : 2;
+    constexpr int maxwg0 = 2;
     if (nch == 32 && (int64_t)((d.N + 127) / 128) * ((d.M + 31) / 32) > maxwg0 * (int64_t)ivln_cu_count()) wt = true;
     if (form_env) wt = form_env[0] == 'w';
     if (form_pin >= 0) wt = form_pin == 1;
@@ -1274,7 +1274,7 @@ int bf3_1x1_ks_launch(ivln_gemm_desc& d, hipStream_t s, int mode, int form_pin =
     if (wt && d.accumulate) return IVLN_E_UNSUPPORTED;  // (the wave-tile epilogue is straight-line code: no D += form)
     const int64_t mtiles = (d.M + 31) / 32;
     const int64_t wgs = wt ? (int64_t)((d.N + 511) / 512) * mtiles : (int64_t)((d.N + 127) / 128) * mtiles;
-    static const int maxwg_env = getenv("IVLN_BF3_1X1_MAXWG") ? atoi(getenv("IVLN_BF3_1X1_MAXWG")) : 2;  // tuning: rounds of one workgroup per CU
+    constexpr int maxwg_env = 2;  // tuning: rounds of one workgroup per CU
     if ((d.N + 127) / 128 > 65535) return IVLN_E_UNSUPPORTED;
     if (mode == 0) {
         // (measured inside RedNet: wins at 128 ... 512 workgroups - 256 x 4096 x 1024 35.7 -> 28 us, 256 x 2048 x 1024 28.4 -> 21.6 -,
@@ -1736,7 +1736,7 @@ extern "C" int ivln_conv_bf3_stamps(unsigned long long* host, int n) {
 #endif
 
 int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
-    static const bool disabled = getenv("IVLN_NO_SPLIT_BF16") != nullptr;  // A/B switch
+    constexpr bool disabled = false;  // A/B switch
     if (!d.A_split || (disabled && !force)) return IVLN_E_UNSUPPORTED;
     const int KS = d.bmode == BMODE_CONV1X1 ? 1 : conv_ks(d.bmode);
     if ((KS != 1 && KS != 2 && KS != 3 && KS != 7) || d.amode != AMODE_MK || d.dil != 1) return IVLN_E_UNSUPPORTED;
@@ -1815,7 +1815,7 @@ int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
         const int64_t gb = d.a_split_grp_stride * 4;
         // tiles: 64 or 128 channels x 128 pixels (4 x 32); 128 channels x 64 pixels (2 x 32, four waves of 32 channels) where the
         // 128-pixel grid would leave CUs without a workgroup (layer 2 at 8 + 8 images: 128 workgroups); IVLN_BF3_FUSE_PX pins (tuning)
-        static const int px_env = getenv("IVLN_BF3_FUSE_PX") ? atoi(getenv("IVLN_BF3_FUSE_PX")) : 0;
+        constexpr int px_env = 0;
         const int64_t wg128 = (int64_t)nimg * (d.Wout / 32) * (d.Hout / 4);
         const bool px64 = d.M == 128 && d.Hout % 2 == 0 && (px_env ? px_env == 64 : wg128 < ivln_cu_count());
         const int rc = d.M == 64 ? launch_bf3_fused<1, 2, 2, 3>(d, s, a, gb, nimg)
@@ -1846,8 +1846,8 @@ int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
         const int64_t round = (int64_t)CUS * slots, rounds = (nb + round - 1) / round;
         return nb * 4 >= rounds * round * 3;
     };
-    static const int cfg_env = getenv("IVLN_SPLIT_BF16_CFG") ? atoi(getenv("IVLN_SPLIT_BF16_CFG")) : -1;  // tuning
-    static const int split_env = getenv("IVLN_SPLIT_BF16_SPLITS") ? atoi(getenv("IVLN_SPLIT_BF16_SPLITS")) : 0;
+    constexpr int cfg_env = -1;  // tuning
+    constexpr int split_env = 0;
     // the widest tile that fills the chip on its own; else the 4-wave tiles (two or three workgroups per CU) with the channel
     // chunks split over blockIdx.z (raw slabs reduced by k_splitk_epilogue, like the fp32 kernels)
     int cfg = -1, splits = 1;
@@ -1855,8 +1855,8 @@ int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
     // (4-wave tiles, measured on RedNet's 3x3 shapes at 8 + 8 stacked images against the fp32 kernels: 128 x 128 wins from
     //  2 M outputs - 57 vs 64 us on 128 x 16384, 50 vs 67 on 256 x 4096 and 512 x 1024 -, 64 x 128 below - 41 vs 46 on
     //  128 x 8192, 37.5 vs 44 on 256 x 2048 and 512 x 512; 64-channel convs that need them lose - 42 vs 38 us on 64 x 32768)
-    static const bool nosplit4 = !(getenv("IVLN_BF3_NOSPLIT4") && getenv("IVLN_BF3_NOSPLIT4")[0] == '0');  // A/B: =0 restores the split 64 x 128 tiles
-    static const int cfg32_env = getenv("IVLN_SPLIT_BF16_CFG32") ? atoi(getenv("IVLN_SPLIT_BF16_CFG32")) : -1;  // tuning: 0 | 6
+    constexpr bool nosplit4 = true;  // A/B: =0 restores the split 64 x 128 tiles
+    constexpr int cfg32_env = -1;  // tuning: 0 | 6
     if (d.M <= 32) cfg = cfg32_env >= 0 ? cfg32_env : 6;
     else if (d.M <= 64)
         cfg = (big_ok && KS != 1 && fills(blocks_of(1), 1)) ? 1
@@ -1917,7 +1917,7 @@ int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
 
 // The 7x7 weight gradient on the split-bf16 arithmetic (k_wgrad_bf3).  IVLN_E_UNSUPPORTED -> the fp32 MFMA weight-gradient kernel.
 int ivln_wgrad_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
-    static const bool disabled = getenv("IVLN_NO_SPLIT_BF16") != nullptr || getenv("IVLN_NO_SPLIT_BF16_WGRAD") != nullptr;  // A/B switches
+    constexpr bool disabled = false;  // A/B switches
     if ((!d.split_ok && !force) || (disabled && !force)) return IVLN_E_UNSUPPORTED;
     if (d.amode != AMODE_NCHW_P || d.bmode != BMODE_IM2COL_T || d.dmode != DMODE_DENSE || d.stride != 1 || d.dil != 1 || d.Cin <= 0 ||
         d.N != d.Cin * 49 || d.defer_epilogue || d.pad != 3)
@@ -1932,7 +1932,7 @@ int ivln_wgrad_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
     // tile: 32 x 512, 64 x 512 or 128 x 256 (channels x columns); strips over blockIdx.z until a workgroup per CU
     // (32-channel outputs: 14 x 49 = 686 columns are two tiles of 384 - six waves - with 11 % of the columns idle; two tiles of
     //  512 left 33 % idle)
-    static const int l1_env = getenv("IVLN_WGRAD_BF3_WN32") ? atoi(getenv("IVLN_WGRAD_BF3_WN32")) : 0;  // tuning: 6 | 8
+    constexpr int l1_env = 0;  // tuning: 6 | 8
     const bool six = d.M <= 32 && (l1_env ? l1_env == 6 : (d.N + 383) / 384 * 384 < (d.N + 511) / 512 * 512);
     const int BM = d.M <= 32 ? 32 : (d.M <= 64 ? 64 : 128), BN = d.M <= 32 ? (six ? 384 : 512) : (d.M <= 64 ? 512 : 256);
     const int64_t blocks = (int64_t)((d.N + BN - 1) / BN) * ((d.M + BM - 1) / BM);
@@ -1940,7 +1940,7 @@ int ivln_wgrad_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
     int splits = 1;
     if (d.splits == 0) {
         if (d.ws) {
-            static const int want_env = getenv("IVLN_WGRAD_BF3_BLOCKS") ? atoi(getenv("IVLN_WGRAD_BF3_BLOCKS")) : 0;  // tuning
+            constexpr int want_env = 0;  // tuning
             // one workgroup per CU (LDS): as many splits as keep the grid inside whole rounds of 256 (13 column tiles x 20
             // splits = 260 workgroups ran a second round for four of them)
             const int64_t want = want_env > 0 ? want_env : ivln_cu_count();

@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256) void k_wgrad_direct(const ivln_gemm_desc p, in
 template <int KS, int PTW, int PTH, int IMGS>
 void launch_wgrad_wm(const ivln_gemm_desc& d, hipStream_t s, int nimg, int ntiles, int tps) {
     const int tiles_w = (d.Wout + PTW - 1) / PTW, tiles_h = (d.Hout + PTH - 1) / PTH;
-    static const bool novec = getenv("IVLN_WGRAD_SCALAR") != nullptr;  // A/B switch
+    constexpr bool novec = false;  // A/B switch
     const bool vec = !novec && PTW >= 4 && (d.Wout & 3) == 0 && ((uintptr_t)d.A & 15) == 0 && (d.HoWo & 3) == 0;
     if (d.M <= 32) {
         dim3 grid((d.N + 127) / 128, (d.M + 31) / 32, d.splits);
@@ -489,9 +489,9 @@ void launch_wgrad_ks(const ivln_gemm_desc& d, hipStream_t s, int nimg, int ntile
 }  // namespace
 
 int ivln_conv_direct_launch(ivln_gemm_desc& d, hipStream_t s) {
-    static const bool disabled = getenv("IVLN_NO_DIRECT_CONV") != nullptr;
+    constexpr bool disabled = false;
     const int KS = conv_ks(d.bmode);
-    static const bool no_s2 = getenv("IVLN_NO_DIRECT_CONV_S2") != nullptr;  // A/B switch
+    constexpr bool no_s2 = false;  // A/B switch
     if (disabled || KS == 0 || d.amode != AMODE_MK || d.dil != 1) return IVLN_E_UNSUPPORTED;
     if (d.stride != 1 && !(d.stride == 2 && KS != 2 && !no_s2)) return IVLN_E_UNSUPPORTED;
     const int CI = conv_direct_ci(KS);
@@ -516,9 +516,9 @@ int ivln_conv_direct_launch(ivln_gemm_desc& d, hipStream_t s) {
     if (d.defer_epilogue && (!d.ws || d.ws_floats < (int64_t)d.M * d.N)) return IVLN_E_INVALID;
     if (d.splits == 0) {
         // split the channel chunks over blockIdx.z until the grid covers the chip
-        static const int want_env = getenv("IVLN_DIRECT_SPLIT_WANT") ? atoi(getenv("IVLN_DIRECT_SPLIT_WANT")) : 0;  // tuning
-        static const int below_env = getenv("IVLN_DIRECT_SPLIT_BELOW") ? atoi(getenv("IVLN_DIRECT_SPLIT_BELOW")) : 0;
-        static const int defer_env = getenv("IVLN_DIRECT_DEFER_WANT") ? atoi(getenv("IVLN_DIRECT_DEFER_WANT")) : 0;  // tuning
+        constexpr int want_env = 0;  // tuning
+        constexpr int below_env = 0;
+        constexpr int defer_env = 0;  // tuning
         const int64_t want = (want_env > 0 && !d.defer_epilogue) ? want_env
                              : (d.defer_epilogue ? (defer_env > 0 ? defer_env : 256) : 512);
         if (d.ws && blocks < (below_env > 0 && !d.defer_epilogue ? below_env : 256) && nch >= 2) {
@@ -550,7 +550,7 @@ int ivln_conv_direct_launch(ivln_gemm_desc& d, hipStream_t s) {
 }
 
 int ivln_wgrad_direct_launch(ivln_gemm_desc& d, hipStream_t s) {
-    static const bool disabled = getenv("IVLN_NO_DIRECT_CONV") != nullptr;
+    constexpr bool disabled = false;
     if (disabled || d.amode != AMODE_NCHW_P || d.bmode != BMODE_IM2COL_T || d.stride != 1 || d.dil != 1 ||
         d.Cin <= 0 || d.N % d.Cin != 0 || d.defer_epilogue)
         return IVLN_E_UNSUPPORTED;
@@ -569,7 +569,7 @@ int ivln_wgrad_direct_launch(ivln_gemm_desc& d, hipStream_t s) {
     int splits = 1;
     if (d.splits == 0) {
         if (d.ws && ntiles >= 2) {
-            static const int want_env = getenv("IVLN_WGRAD_BLOCKS") ? atoi(getenv("IVLN_WGRAD_BLOCKS")) : 0;  // tuning
+            constexpr int want_env = 0;  // tuning
             // 8-16 blocks per CU: shorter blocks even out the tail of the one long wave of work (measured on the map
             // CNN's four layers at 512 images, 1024 / 2048 / 4096 wanted blocks: layer 1 - six column tiles - 1152 /
             // 1086 / 1009 us, layer 2 1165 / 1122 / 1135 us, layers 3-4 unchanged)

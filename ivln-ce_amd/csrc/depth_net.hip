@@ -759,7 +759,7 @@ int ivln_depth_net_f32(const ivln_depthnet_op* ops_dev, const ivln_depthnet_op* 
     const int resident = ivln_resident_blocks((const void*)k_depth_net, NT, lds);
     if (resident < 8 * CL) return IVLN_E_UNSUPPORTED;
     // (the clusters spin on each other's arrivals: all of them resident, or none)
-    static const int allow_plain = getenv("IVLN_DEPTH_NET_WRITE_THROUGH") ? 0 : 1;  // A/B switch: write-through stores only (519 -> 545 us)
+    constexpr int allow_plain = 1;  // A/B switch: write-through stores only (519 -> 545 us)
 #ifdef DEPTH_NET_TIMING
     hipLaunchKernelGGL(k_depth_net, dim3(8 * CL), dim3(NT), lds, (hipStream_t)stream, ops_dev, n_ops, weights, params, depth,
                        depth_img_stride, arena, arena_stride, out, out_img_stride, N, eps, (unsigned*)sync_ws, L, allow_plain);

@@ -630,7 +630,7 @@ extern "C" int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream) {
         if (nblocks(64, 128) >= 512) tile = 4;
     }
     if (d.tile_override > 0 && d.tile_override <= 5) tile = d.tile_override - 1;
-    static const int vec_tile_env = getenv("IVLN_VEC_TILE") ? atoi(getenv("IVLN_VEC_TILE")) : -1;  // tuning
+    constexpr int vec_tile_env = -1;  // tuning
     // contiguous operand modes (1x1 conv, linear): float4-staged kernel with 32-deep K tiles
     // (gemm_vec.hip); tile_override 7 insists on it, 1..5 pin the scalar-gather kernel
     const bool vec = (d.tile_override == 0 || d.tile_override == 7) && ivln_gemm_vec_eligible(d);
@@ -658,13 +658,13 @@ extern "C" int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream) {
     if (d.splits == 0) {
         // the consumer reduces for free when deferred
         const int min_tiles = d.defer_epilogue ? 2 : 4;
-        static const int want_env = getenv("IVLN_SPLIT_WANT") ? atoi(getenv("IVLN_SPLIT_WANT")) : 0;  // tuning
+        constexpr int want_env = 0;  // tuning
         // deferred: one block per CU measured as fast as four (3.50-3.54 K env-steps/s for 192..2048) at a
         // quarter of the slab bytes the consumer has to read back
-        static const int want_nd_env = getenv("IVLN_SPLIT_WANT_ND") ? atoi(getenv("IVLN_SPLIT_WANT_ND")) : 0;
+        constexpr int want_nd_env = 0;
         const int64_t want = want_env > 0 ? want_env
                              : (d.defer_epilogue ? 256 : (want_nd_env > 0 ? want_nd_env : 512));
-        static const int below_env = getenv("IVLN_SPLIT_BELOW") ? atoi(getenv("IVLN_SPLIT_BELOW")) : 0;  // tuning
+        constexpr int below_env = 0;  // tuning
         const int64_t below = (below_env > 0 && !d.defer_epilogue) ? below_env : 256;
         if (d.ws && blocks < below && nk >= 2 * min_tiles) {
             splits = (int)((want + blocks - 1) / blocks);
@@ -672,7 +672,7 @@ extern "C" int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream) {
             // weight gradients reduce over millions of pixels with a tiny M x N: allow deep splits there
             // (deep K with a small M x N - the LSTM / Conv1d weight gradients of the update, K = 40 960 rows: 16 splits left
             //  128 blocks on 256 CUs, 167 us for 2 GFLOP)
-            static const int deep_env = getenv("IVLN_SPLIT_DEEP") ? atoi(getenv("IVLN_SPLIT_DEEP")) : 64;  // tuning
+            constexpr int deep_env = 64;  // tuning
             const int max_splits = d.defer_epilogue ? (blocks <= 8 ? 64 : (blocks <= 32 ? 32 : 16))
                                                     : (nk >= 4096 ? 256 : (nk >= 512 ? deep_env : 16));
             if (splits > max_splits) splits = max_splits;

@@ -307,7 +307,7 @@ int ivln_gemm_vec_tile_k() { return BKV; }
 
 // Eligible: every float4 the kernel forms must be 16-byte aligned and must not straddle a row / image.
 bool ivln_gemm_vec_eligible(const ivln_gemm_desc& d) {
-    static const bool disabled = getenv("IVLN_NO_VEC_GEMM") != nullptr;
+    constexpr bool disabled = false;
     if (disabled || !al16(d.A) || !al16(d.B)) return false;
     if (d.amode == AMODE_MK) {
         if ((d.K & 3) || (d.lda & 3)) return false;
@@ -316,7 +316,7 @@ bool ivln_gemm_vec_eligible(const ivln_gemm_desc& d) {
     } else {
         return false;
     }
-    static const bool no_s2 = getenv("IVLN_NO_VEC_GEMM_S2") != nullptr;  // A/B switch
+    constexpr bool no_s2 = false;  // A/B switch
     if (d.bmode == BMODE_CONV1X1 && d.stride == 2) {
         // 16-byte loads at input column 2*wo (wo even): rows of 2*Wout columns, every row / plane / image 16-byte aligned
         if (no_s2 || d.amode != AMODE_MK || d.pad != 0 || d.Win != 2 * d.Wout || d.Hin < 2 * d.Hout - 1 || (d.Wout & 1) ||

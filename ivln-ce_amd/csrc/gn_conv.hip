@@ -800,7 +800,7 @@ int ivln_gn_conv_f32(const ivln_gn_conv_desc* d, void* stream) {
     int S = 1;
     const int blocks = d->N * d->groups;
     const int cmin = d->wa ? (d->wb && d->Cout_b < d->Cout_a ? d->Cout_b : d->Cout_a) : (d->wb ? d->Cout_b : 1);
-    static const int s_cap = getenv("IVLN_GN_CONV_S") ? atoi(getenv("IVLN_GN_CONV_S")) : 4;
+    constexpr int s_cap = 4;
     while (S < s_cap && blocks * S * 2 <= 256 && cmin / (S * 2) >= 16) S *= 2;
     // LDS: reduction scratch + tile (+ second operand) (+ residual) (+ pooled tile) + the staged weight slices.  When
     // both convs' slices fit they are loaded up front beside the tile (prestage); otherwise each conv streams its

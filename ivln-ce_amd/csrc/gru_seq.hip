@@ -389,15 +389,8 @@ k_gru_seq_bwd(const float* __restrict__ d_out, int64_t ld_dout, const float* __r
 
 }  // namespace
 
-// hidden units per workgroup: 8 (64 workgroups x 256 threads, one wave per SIMD) unless IVLN_SEQ_UPB=16 (A/B switch)
-static int units_per_wg() {
-    static int v = 0;
-    if (!v) {
-        const char* e = getenv("IVLN_SEQ_UPB");
-        v = (e && atoi(e) == 16) ? 16 : 8;
-    }
-    return v;
-}
+// hidden units per workgroup: 8 (64 workgroups x 256 threads, one wave per SIMD; 16 per workgroup measured slower, round 3)
+static int units_per_wg() { return 8; }
 
 
 // The persistent kernels spin on counters that every workgroup of the grid feeds: the whole grid has to be resident at

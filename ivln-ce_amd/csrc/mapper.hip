@@ -631,6 +631,9 @@ struct ivln_mapper {
     int n_blocks_local;
     int local_blocks, world_blocks;  // launch width of the local- / world-cloud kernels (0: full width)
     int64_t known_rank;
+    // a step begun by ivln_mapper_step_begin and not yet finished: what ivln_mapper_step_finish continues with
+    const float *step_T, *step_pose, *step_rot;
+    int step_B, step_lb;  // step_B == 0: no step is open
 };
 
 #define HIPCHK(x)                          \
@@ -757,16 +760,18 @@ int ivln_mapper_frames(const float* pose, const double* orientation, int B, floa
     return hipGetLastError() == hipSuccess ? IVLN_OK : IVLN_E_HIP;
 }
 
-static int mapper_step(ivln_mapper* m, const float* depth, const uint8_t* labels, const float* T, const float* pose,
-                       const float* rot, const double* orientation, float* T_out, float* rot_out,
-                       const uint8_t* not_done, int B, uint8_t* occ_out, uint8_t* sem_out, void* stream) {
+// The label-free half of a step: camera transforms (posed entry), local min / max, the keep-highest arg-max of the local
+// cloud (csrc header: kernels 1-2).  Reads depth and the sensor pose only - with predicted semantics it can run beside the
+// network that produces the labels (ivln_mapper_step_begin).
+static int mapper_begin(ivln_mapper* m, const float* depth, const float* T, const float* pose, const float* rot,
+                        const double* orientation, float* T_out, float* rot_out, const uint8_t* not_done, int B,
+                        uint8_t* occ_out, void* stream) {
     if (!m || B <= 0 || B > m->B_max) return IVLN_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
     const int64_t npix = (int64_t)B * m->H * m->W;
     int lb = (int)((npix + kThreads * kPPT - 1) / (kThreads * kPPT));  // local-cloud chunks: 4 pixels / thread
     if (m->local_blocks > 0 && m->local_blocks < lb) lb = m->local_blocks;  // narrow launch: a block walks several chunks
     const int map_cells = B * m->rows * m->cols;
-    const unsigned cap = (unsigned)m->capacity;
     if (orientation) {  // posed entry: transforms derived inside the first kernel
         const Cam c0{depth, nullptr, pose, m->xs, m->ys, B, m->H, m->W, m->half_res};
         hipLaunchKernelGGL(k_local_minmax<true>, dim3(lb), dim3(kThreads), 0, s, c0, occ_out, map_cells, m->bmmL,
@@ -780,6 +785,21 @@ static int mapper_step(ivln_mapper* m, const float* depth, const uint8_t* labels
                            (const double*)nullptr, (float*)nullptr, (float*)nullptr);
     hipLaunchKernelGGL(k_local_argmax, dim3(lb), dim3(kThreads), 0, s, cm, m->sc, m->tab64, m->table_cells, m->bmmL, lb,
                        m->bbox, m->B_max, not_done);
+    m->step_T = T, m->step_pose = pose, m->step_rot = rot, m->step_B = B, m->step_lb = lb;
+    return hipGetLastError() == hipSuccess ? IVLN_OK : IVLN_E_HIP;
+}
+
+// The rest of the step begun by mapper_begin: label the surviving local points, merge them into the world cloud, raster.
+static int mapper_finish(ivln_mapper* m, const float* depth, const uint8_t* labels, const uint8_t* not_done, int B,
+                         uint8_t* occ_out, uint8_t* sem_out, void* stream) {
+    if (!m || B <= 0 || B != m->step_B) return IVLN_E_INVALID;  // (no step open, or another batch than the one begun)
+    hipStream_t s = (hipStream_t)stream;
+    const float *T = m->step_T, *pose = m->step_pose, *rot = m->step_rot;
+    const int lb = m->step_lb;
+    m->step_B = 0;
+    const int map_cells = B * m->rows * m->cols;
+    const unsigned cap = (unsigned)m->capacity;
+    const Cam cm{depth, T, pose, m->xs, m->ys, B, m->H, m->W, m->half_res};
     hipLaunchKernelGGL(k_local_select, dim3(lb), dim3(kThreads), 0, s, cm, labels, m->sc, m->tab64, m->table_cells,
                        m->wbuf[0], m->wbuf[1], m->rbuf[0], m->rbuf[1], cap, m->bmmA);
     // world-cloud kernels: full width = up to 1024 workgroups, one point per thread; a narrow launch (set_launch_width) =
@@ -795,6 +815,25 @@ static int mapper_step(ivln_mapper* m, const float* depth, const uint8_t* labels
     hipLaunchKernelGGL(k_finalize, dim3(fin_blocks), dim3(kThreads), 0, s, m->cell, sem_out, map_cells, m->sc, 1, cap,
                        wb, B);
     return hipGetLastError() == hipSuccess ? IVLN_OK : IVLN_E_HIP;
+}
+
+static int mapper_step(ivln_mapper* m, const float* depth, const uint8_t* labels, const float* T, const float* pose,
+                       const float* rot, const double* orientation, float* T_out, float* rot_out,
+                       const uint8_t* not_done, int B, uint8_t* occ_out, uint8_t* sem_out, void* stream) {
+    const int rc = mapper_begin(m, depth, T, pose, rot, orientation, T_out, rot_out, not_done, B, occ_out, stream);
+    return rc != IVLN_OK ? rc : mapper_finish(m, depth, labels, not_done, B, occ_out, sem_out, stream);
+}
+
+int ivln_mapper_step_begin(ivln_mapper* m, const float* depth, const float* pose, const double* orientation,
+                           const uint8_t* not_done, int B, uint8_t* occ_out, float* T_out, float* rot_out, void* stream) {
+    if (!depth || !pose || !orientation || !T_out || !rot_out || !not_done || !occ_out) return IVLN_E_INVALID;
+    return mapper_begin(m, depth, nullptr, pose, nullptr, orientation, T_out, rot_out, not_done, B, occ_out, stream);
+}
+
+int ivln_mapper_step_finish(ivln_mapper* m, const float* depth, const uint8_t* labels, const uint8_t* not_done, int B,
+                            uint8_t* occ_out, uint8_t* sem_out, void* stream) {
+    if (!depth || !labels || !not_done || !occ_out || !sem_out) return IVLN_E_INVALID;
+    return mapper_finish(m, depth, labels, not_done, B, occ_out, sem_out, stream);
 }
 
 int ivln_mapper_step(ivln_mapper* m, const float* depth, const uint8_t* labels, const float* T, const float* pose,

@@ -1013,8 +1013,8 @@ int ivln_colsum_multi_f32(const float* const* xs, const int64_t* lds, const int*
 static int chan_splits(int N, int HW, int C, int K, int64_t ws_floats) {
     // >= 4 K elements per block, up to 256 blocks per channel (16 K / 64 left the BatchNorm backward statistics at 1.5-1.9
     // TB/s on the 268 MB layer: 32 x 64 blocks of 32 serial trips each; 90 -> 47 us per launch with 256)
-    static const int gran = getenv("IVLN_CHAN_GRAN") ? atoi(getenv("IVLN_CHAN_GRAN")) : 4096;  // tuning
-    static const int cap = getenv("IVLN_CHAN_CAP") ? atoi(getenv("IVLN_CHAN_CAP")) : 256;
+    constexpr int gran = 4096;  // tuning
+    constexpr int cap = 256;
     int S = (int)(((int64_t)N * HW + gran - 1) / gran);
     if (S > N) S = N;
     if (S > cap) S = cap;

@@ -14,6 +14,7 @@ from typing import Dict
 
 import torch
 
+from . import mapping as _mapping
 from . import ops
 
 _streams = {}
@@ -24,8 +25,6 @@ def _stream(device, role, **kw):
     by the stream, so a fresh stream per capture - the eval loop re-captures whenever envs pause - would pin a
     new set every time."""
     key = (str(device), role)
-    if os.environ.get("IVLN_FRESH_STREAMS"):  # experiment switch: a new stream per capture
-        return torch.cuda.Stream(device, **kw)
     if key not in _streams:
         _streams[key] = torch.cuda.Stream(device, **kw)
     return _streams[key]
@@ -134,6 +133,7 @@ class GraphedRollout:
         self.split = streams == "split"
         self.side = (_stream(dev, "fork_txt"), _stream(dev, "fork_map")) if (streams and not self.split) else None
         self.graphs = []
+        self._prefix, self.gA_parts = False, []
         self.phase = 0  # which buffer set holds the current state
         # the fused head's scratch is baked into the captured graphs: this runner owns one (ops.cma_step_ws)
         prev_owner, ops.CMA_WS_OWNER = ops.CMA_WS_OWNER, id(self)
@@ -223,11 +223,19 @@ class GraphedRollout:
                            device=dev),
         )
 
+        from . import rednet as _rednet
+
         def run_A():
             net._stage, net._persist = "dep", self._persist
             try:
                 with torch.no_grad():
                     batch = dict(self.static)
+                    if self._prefix:
+                        # the mapper's label-free half (transforms, min / max, keep-highest arg-max: depth and pose only)
+                        # rides at the head of the side graph, beside RedNet, instead of behind it on the critical path
+                        for t in self.transforms:
+                            t.begin_maps(batch)
+                        _rednet._stage_done("mapper_begin")
                     net.forward_hip(batch, self.rnn[0], self.prev[0], _policy_masks(batch))
             finally:
                 net._stage = net._persist = None
@@ -235,7 +243,7 @@ class GraphedRollout:
         def run_B1(src):
             batch = dict(self.static)
             for t in self.transforms:
-                batch = t(batch)
+                batch = t.finish_maps(batch) if self._prefix else t(batch)
             net._stage, net._persist = "pre", self._persist
             try:
                 with torch.no_grad():
@@ -269,12 +277,21 @@ class GraphedRollout:
         # that will be captured has to exist before the capture.)
         venc = getattr(getattr(net, "depth_encoder", None), "visual_encoder", None)
         predicted = any(getattr(t, "predicted_semantics", False) for t in self.transforms)
+        # With predicted semantics gB1 is cut behind one of RedNet's stages (rednet.STAGE_HOOK) and gA is released by an event
+        # recorded at the cut: the depth encoder's ~110 small launches then run beside RedNet's pixel-starved deep stages,
+        # whose grids leave CUs idle, instead of taking CUs from the chip-filling first ones (round 5: gB1 alone 3242 us,
+        # 3562 us with gA started at t = 0; round 6, profiles/r06_split_probe_start.txt: gB1 ends at 3477 / 3461 / 3432 us with
+        # the cut behind layer 2 / 3 / 4).  IVLN_PRED_DEPTH_START: stage name, or "0" = no cut (gA starts with the step).
+        self._cut_stage = os.environ.get("IVLN_PRED_DEPTH_START", "layer3") if predicted else "0"
+        if self._cut_stage in ("0", "", "none"):
+            self._cut_stage = None
+        # ... and the mapper's label-free half moves to the head of gA (MappingModule.begin / finish, ivln_mapper_step_begin /
+        # _finish): gB1 is cut a second time where the labels exist, and waits there for the event recorded behind the prefix
+        self._prefix = bool(self._cut_stage) and os.environ.get("IVLN_MAPPER_PREFIX", "1") != "0" and _mapping.STEP_POSED and all(
+            hasattr(t, "begin_maps") and type(t).__name__.endswith("IterativeMapper") for t in self.transforms)
         # the depth encoder's stream: the critical chain of the gt-semantics step wins dispatch when both queues are ready
-        # (priority -1); beside RedNet it is NOT critical and takes a stream of its own role at IVLN_PRED_DEPTH_PRIORITY
-        if predicted:
-            self.sA = _stream(dev, "depth_beside_rednet", priority=int(os.environ.get("IVLN_PRED_DEPTH_PRIORITY", "-1")))
-        else:
-            self.sA = _stream(dev, "depth", priority=int(os.environ.get("IVLN_DEPTH_STREAM_PRIORITY", "-1")))
+        # (priority -1; beside RedNet, where it is not critical, the priority made no difference: profiles/r06_split_probe_start.txt)
+        self.sA = _stream(dev, "depth", priority=-1)
         if venc is not None:
             venc.latency_bound = not predicted
             venc.beside_other_work = True  # (its graph replays beside the mapper / map-CNN graph: ops.DEPTH_NET's policy)
@@ -285,15 +302,13 @@ class GraphedRollout:
             if pd in ("chain", "net"):
                 venc.latency_bound = True
         net._txt_with_dep = predicted  # ... and the instruction encoder leaves RedNet's stream for the side graph
-        net._txt_last = os.environ.get("IVLN_TXT_LAST", "1") != "0"
+        net._txt_last = True
         # ... and with fewer than 8 images some XCDs stay free of it: the bi-LSTM's blocks that land there take all the work
         # (ops.lstm_bidir spare) instead of half of them waiting for the depth encoder to end
         ienc = net.instruction_encoder
         # (2B * spare blocks so that 2B of them land on the 8 - B free XCDs; measured at 4 and 5 images: 667 -> 620 us per
         #  step; at 6 and 7 - spare 4 and 8 - the recurrence still started only when the depth encoder ended: left alone)
         spare = int(os.environ.get("IVLN_LSTM_SPARE", str(2 if B <= 4 else 3 if B == 5 else 1)))
-        if not predicted and os.environ.get("IVLN_TXT_FIRST", "0") == "1":
-            net._txt_with_dep = "first"
         if net._txt_last and not predicted and spare > 1 and B < 8:
             # (the captured launches hold this word's ADDRESS: it lives as long as this object's graphs, whatever a later
             #  capture of the same policy hangs on the module)
@@ -307,7 +322,7 @@ class GraphedRollout:
                 for i in range(warmup):
                     run_A()
                     run_B2(i & 1, run_B1(i & 1))
-            if warmup and os.environ.get("IVLN_CAPTURE_STREAM_WARMUP", "1") != "0":
+            if warmup:
                 # ... and once on the streams the graphs are captured on: per-stream state (split-K workspaces, GroupNorm /
                 # packed-weight scratch, the depth encoder's arena) must not be born inside a capture - a buffer from a
                 # graph's private pool would end up in a process-wide cache
@@ -333,21 +348,21 @@ class GraphedRollout:
                 narrow = getattr(mm, "semantics_module", None) is None and lw != "0"
                 mm.set_launch_width(*([int(v) for v in lw.split(",")] if narrow else [0, 0]))
         ops.settle_packed_weights()
-        self.gA = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.gA, stream=self.sA):
-            run_A()
+        self.ev_pre = torch.cuda.Event()
+        with _CutCapture(self.sA) as ca:
+            def hook_a(name, ca=ca):
+                if name == "mapper_begin" and len(ca.graphs) == 1:
+                    ca.cut()
+            prev_hook, _rednet.STAGE_HOOK = _rednet.STAGE_HOOK, (hook_a if self._prefix else None)
+            try:
+                run_A()
+            finally:
+                _rednet.STAGE_HOOK = prev_hook
+        self.gA_parts = list(ca.graphs)  # [mapper prefix, depth encoder (+ instruction encoder)] or the one graph
+        self.gA = self.gA_parts[-1]
         self._dep = net._stash_dep  # (depth features, k/v) live in gA's pool
         self._txt = getattr(net, "_stash_txt", None)  # (predicted semantics: the instruction features too)
         # the previous action (read by the embedding in gB1) ping-pongs with the state: one gB1 per phase
-        # With predicted semantics gB1 is cut behind one of RedNet's stages (rednet.STAGE_HOOK) and gA is released by an event
-        # recorded at the cut: the depth encoder's ~110 small launches then run beside RedNet's pixel-starved deep stages,
-        # whose grids leave CUs idle, instead of taking CUs from the chip-filling first ones (round 5: gB1 alone 3242 us,
-        # 3562 us with gA started at t = 0).  IVLN_PRED_DEPTH_START: stage name, or "0" = no cut (gA starts with the step).
-        from . import rednet as _rednet
-
-        self._cut_stage = os.environ.get("IVLN_PRED_DEPTH_START", "layer2") if predicted else "0"
-        if self._cut_stage in ("0", "", "none"):
-            self._cut_stage = None
         self.ev_mid = torch.cuda.Event()
         self.gB1, pool = [], None
         for src in (0, 1):
@@ -355,6 +370,8 @@ class GraphedRollout:
                 def hook(name, cc=cc):
                     if name == self._cut_stage and len(cc.graphs) == 1:
                         cc.cut()
+                    elif name == "labels" and self._prefix and len(cc.graphs) == 2:
+                        cc.cut()  # (the mapper's second half starts here: the replay waits for the prefix's event in between)
                 prev_hook, _rednet.STAGE_HOOK = _rednet.STAGE_HOOK, (hook if self._cut_stage else None)
                 try:
                     net._stash_txt = self._txt
@@ -375,7 +392,9 @@ class GraphedRollout:
             venc.beside_other_work = False  # (the captured launches are what they are; eager calls decide for themselves)
         ienc.lstm_spare = 1  # (the ticket word stays with the module: the captured launches hold its address)
 
-    def _replay_split(self):
+    def _replay_split(self, mark=None):
+        """One step: the main graphs on the current stream, the side graph(s) on sA.  `mark(name, stream)` (tools/split_probe.py)
+        is called where gA starts / ends and where gB1 ends, to record timing events."""
         main = torch.cuda.current_stream()
         pieces = self.gB1[self.phase]
         if len(pieces) > 1:  # gB1 cut behind a RedNet stage: its head first, gA released at the cut
@@ -386,7 +405,14 @@ class GraphedRollout:
             self.ev_in.record(main)
             self.sA.wait_event(self.ev_in)
         with torch.cuda.stream(self.sA):
+            if mark:
+                mark("gA_start", self.sA)
+            if len(self.gA_parts) > 1:  # the mapper's label-free half, then the event gB1's last piece waits for
+                self.gA_parts[0].replay()
+                self.ev_pre.record(self.sA)
             self.gA.replay()
+            if mark:
+                mark("gA_end", self.sA)
             self.ev_A.record(self.sA)
         # (launching gB1 - RedNet with predicted semantics, the critical chain there - BEFORE gA was measured in round 3:
         #  5.485 vs 5.480 ms per step at 8 envs, no difference; the 0.8 ms hole in front of RedNet in a traced timeline is
@@ -397,7 +423,12 @@ class GraphedRollout:
         #  0.726 vs 0.714 ms per step, slower)
         # (... and the main graphs on a third stream with a priority of its own, whatever the priorities: 8.2 ms per pred-semantics
         #  step against 4.25, round 5 - the extra stream hop serialises the replay)
+        if len(pieces) == 3:  # ... RedNet's rest | the mapper's second half + map CNN, behind the prefix
+            pieces[1].replay()
+            main.wait_event(self.ev_pre)
         pieces[-1].replay()
+        if mark:
+            mark("gB1_end", main)
         main.wait_event(self.ev_A)
         self.graphs[self.phase].replay()
 

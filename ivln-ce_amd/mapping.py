@@ -236,6 +236,53 @@ class MappingModule:
 
     __call__ = forward
 
+    # -- the same step in two halves (ivln_mapper_step_begin / _finish): `begin` needs depth and pose only, so with predicted
+    #    semantics it can be enqueued on another stream beside the network whose labels `finish` waits for ------------------
+    def begin(self, observations: Dict[str, torch.Tensor]):
+        """Camera transforms, local min / max and the keep-highest arg-max of this step's depth frames (2 launches on the
+        current stream).  Iterative mode with the posed entry only; `finish` must follow, ordered behind it."""
+        if self.mode != "iterative" or not STEP_POSED:
+            raise _lib.IvlnError("MappingModule.begin / finish: iterative mode with the posed step entry only")
+        depth = observations["depth"]
+        B, H, W = depth.shape[0], depth.shape[1], depth.shape[2]
+        if B > self.b_max:
+            raise _lib.IvlnError(f"batch {B} > b_max {self.b_max}")
+        self._ensure_handle(H, W)
+        self.map_memory.batch_size = B
+        if getattr(self, "dry_run", False):
+            return
+        depth = depth.to(torch.float32).contiguous()
+        not_done = observations["not_done_masks"].reshape(-1).to(torch.uint8).contiguous()
+        pose = observations["world_robot_pose"].to(self.device, torch.float32).contiguous()
+        orientation = observations["world_robot_orientation"].to(self.device, torch.float64).contiguous()
+        # (finish reads pose / T / rot through the pointers begin was given: they stay alive on the module)
+        self._open = (depth, not_done, pose, orientation)
+        check(lib().ivln_mapper_step_begin(self._h, dptr(depth), dptr(pose), dptr(orientation), dptr(not_done), B,
+                                           dptr(self.map_memory._occ), dptr(self._T), dptr(self._rot), stream_ptr()),
+              "ivln_mapper_step_begin")
+
+    def finish(self, observations: Dict[str, torch.Tensor]) -> OccupancySemanticMapMemory:
+        """Labels (gt, or the semantics module's) -> world-cloud merge -> maps (4 launches behind the labels)."""
+        mem = self.map_memory
+        depth = observations["depth"]
+        B, H, W = depth.shape[0], depth.shape[1], depth.shape[2]
+        if self.semantics_module is not None:
+            labels = self.semantics_module(observations)
+        else:
+            if "semantic12" not in observations or observations["semantic12"] is None:
+                raise Exception("Semantic Sensor not in use")  # mapper.py:660-661
+            labels = observations["semantic12"]
+        labels = labels.reshape(B, H, W).to(torch.uint8).contiguous()
+        from . import rednet as _rednet
+
+        _rednet._stage_done("labels")  # (a capturing GraphedRollout cuts its graph here and waits for `begin`'s event)
+        if getattr(self, "dry_run", False):
+            return mem
+        depth_c, not_done, _, _ = self._open
+        check(lib().ivln_mapper_step_finish(self._h, dptr(depth_c), dptr(labels), dptr(not_done), B, dptr(mem._occ),
+                                            dptr(mem._sem), stream_ptr()), "ivln_mapper_step_finish")
+        return mem
+
     def _load_known(self, env_name):
         if env_name not in self._known_cache:
             with np.load(os.path.join(self.maps_location, f"{env_name}.npz")) as f:  # mapper.py:283-294

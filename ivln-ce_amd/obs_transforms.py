@@ -88,6 +88,19 @@ class Mapper(ObservationTransformer):
         observations["semantic_map"] = mem.semantic
         return observations
 
+    # the step in two halves (MappingModule.begin / finish): graphed.GraphedRollout enqueues `begin_maps` beside the network
+    # that predicts the labels and `finish_maps` behind it; together they are `forward`
+    def begin_maps(self, observations):
+        self.setup_mapping_module(observations)
+        self.mapping_module.begin(observations)
+
+    def finish_maps(self, observations):
+        mem = self.mapping_module.finish(observations)
+        observations["occupancy_map"] = mem.occupancy
+        observations["semantic_map"] = mem.semantic
+        observations = self.visualize_maps(observations)
+        return self.delete_extra_information(observations)
+
     def delete_extra_information(self, observations):
         for key in self.keys_to_delete:
             if key in observations:

@@ -194,9 +194,9 @@ def splitk_ws(device, floats=8 << 20, slot=0):
 
 
 TILE_OVERRIDE = 0  # tuning/tests: force a block tile (1..5), see ivln_gemm_desc.tile_override
-LINEAR_BWD_SPLIT = not bool(os.environ.get("IVLN_LINEAR_BWD_NO_SPLIT"))  # A/B: split-K in Linear dX / accumulating dW
+LINEAR_BWD_SPLIT = True  # split-K in Linear dX / accumulating dW
 NO_XCD_REMAP = False  # tests / A-B: identity workgroup -> tile mapping (ivln_gemm_desc.no_xcd_remap)
-NO_WIDE_EPILOGUE = bool(os.environ.get("IVLN_NO_WIDE_EPILOGUE"))  # A/B: 4-byte MFMA-layout stores for NCHW outputs
+NO_WIDE_EPILOGUE = False  # tests: 4-byte MFMA-layout stores for NCHW outputs
 PACK_WEIGHTS = True  # A/B switch: pre-arranged weights for the direct conv kernel
 
 
@@ -363,7 +363,7 @@ SPLIT_BF16_1X1 = int(os.environ.get("IVLN_SPLIT_BF16_1X1", "-1"))  # -1: by meas
 BF3_1X1_KS = os.environ.get("IVLN_BF3_1X1_KS", "1") != "0"  # A/B: 0 = deep-K 1x1 convs stay on the fp32 GEMM kernels
 BF3_CONVT = os.environ.get("IVLN_BF3_CONVT", "1") != "0"  # A/B: 0 = stride-2 3x3 transposed convs stay on the fp32 direct kernel
 S2_GATHER = os.environ.get("IVLN_S2_GATHER", "1") != "0"  # A/B: 0 = stride-2 1x1 convs read their input strided (tiled 1x1 form)
-SPLIT_BF16_MIN_OUT = int(os.environ.get("IVLN_SPLIT_BF16_MIN_OUT", str(1 << 18)))  # output elements below which nothing is packed
+SPLIT_BF16_MIN_OUT = 1 << 18  # output elements below which nothing is packed
 _stat_ws = {}
 CONV_STATS = os.environ.get("IVLN_CONV_STATS", "1") != "0"  # A/B: BatchNorm statistics from the conv's epilogue
 
@@ -814,21 +814,21 @@ CHAIN_GN_CONV = os.environ.get("IVLN_GN_CONV", "1") != "0"
 # The chain trades launches for slab bytes (16 partial slabs per conv), which pays while the step is latency-bound:
 # measured 4 envs 5.1 K vs 4.0 K env-steps/s, 8 envs 7.5 K vs 6.9 K, but 16 envs 9.5 K vs 10.1 K and 32 envs 11.1 K vs
 # 15.2 K - beyond 8 images per GPU the conv + GroupNorm pairs run.
-CHAIN_MAX_IMAGES = int(os.environ.get("IVLN_GN_CONV_MAX_IMAGES", "8"))
+CHAIN_MAX_IMAGES = 8
 # the bottlenecks before the chain (layer 1) as ivln_nconv_f32 launches: GroupNorm on load, statistics out, no slabs
-NCONV_FRONT = os.environ.get("IVLN_NCONV_FRONT", "1") != "0"
-NCONV_BLOCKS = int(os.environ.get("IVLN_NCONV_BLOCKS", "-1"))  # bottlenecks from the stem that run this way; -1: layer 1 (3) up to
+NCONV_FRONT = True
+NCONV_BLOCKS = -1  # bottlenecks from the stem that run this way; -1: layer 1 (3) up to
 # 5 images, layers 1-2 (7) beyond (measured at 8 envs: 1.017 -> 0.997 ms per step; at 4 envs the slab chain wins layer 2)
-NCONV_ROWS = int(os.environ.get("IVLN_NCONV_ROWS", "0"))  # output rows per workgroup (0: 64 pixels)
+NCONV_ROWS = 0  # output rows per workgroup (0: 64 pixels)
 # first bottleneck (0..16) that runs in the chain; earlier ones (large feature maps: 16 partial slabs of a 32x32 map
 # are more traffic than the launches they save) stay conv + GroupNorm pairs.  0 = the whole backbone incl. the stem;
 # 3 = from layer2 on (measured best at 4 envs: 0.790 ms/step vs 0.820 from the stem and 0.996 without the chain);
 # at 8 envs layer 2's slabs are twice as large and starting at layer 3 is better (1.046 vs 1.100 ms/step).
-CHAIN_FROM_BLOCK = int(os.environ.get("IVLN_GN_CONV_FROM", "-1"))  # -1: by batch size (3 up to 5 images, 7 = from layer 3 beyond)
+CHAIN_FROM_BLOCK = -1  # -1: by batch size (3 up to 5 images, 7 = from layer 3 beyond)
 # first bottleneck whose GN2 -> conv3 -> GN3 tail -> next conv1 run as ONE launch (the block re-normalises the whole
 # 16-64 KB conv2 output of its image): 2 launches per bottleneck instead of 3.  Measured SLOWER (0.835 vs 0.805 ms per
 # step from layer 3 on, profiles/r02_gn_conv_ab.txt: the merged launch takes 20 us against 8.5 + 9.8), so 16 = never.
-CHAIN_PAIR_FROM_BLOCK = int(os.environ.get("IVLN_GN_CONV_PAIR_FROM", "16"))
+CHAIN_PAIR_FROM_BLOCK = 16
 
 
 class GnConvDesc(C.Structure):
@@ -1658,7 +1658,7 @@ class ColsumQueue:
               "ivln_colsum_multi_f32")
 
 
-COLSUM_MULTI = os.environ.get("IVLN_COLSUM_MULTI", "1") != "0"  # A/B: one pair of launches for all bias gradients
+COLSUM_MULTI = True  # one pair of launches for all bias gradients
 
 
 def nchw_chansum(x):

@@ -16,7 +16,7 @@ from . import ops
 
 
 # RGB + depth encoders as one image-grouped pass (A/B switch: IVLN_REDNET_NO_GROUP=1 runs them as two chains)
-GROUP_ENCODERS = not bool(os.environ.get("IVLN_REDNET_NO_GROUP"))
+GROUP_ENCODERS = True  # (False: the two encoders as separate launch chains - what tests compare the stacked form with)
 
 
 def _conv3x3(cin, cout, stride=1):

@@ -19,13 +19,9 @@ from . import ops
 # The instruction bi-LSTM (forward 0.3 ms, BPTT 0.6 ms at T*N = 512 rows) is a latency-bound recurrence that
 # leaves the chip idle, and it is independent of the map CNN's convolutions (3.5 / 5.5 ms, MFMA-bound): in a
 # training pass it runs on a side stream next to them.  A/B switch for measurements and tests.
-OVERLAP_INSTRUCTION = not bool(os.environ.get("IVLN_NO_TRAIN_OVERLAP"))
-# The map CNN's four weight gradients (2.4 ms of 9.4 per update at T64 x N8) have no consumer before Adam: they CAN run on a
-# second side stream beside the chain that is sequential - input gradient of layer i -> BatchNorm / ReLU / pooling backward of
-# layer i-1 -> ...  Same kernels, same operands, same bits; the split-K workspace is per stream.  Measured (round 5, same
-# box, 10 updates each): 9.40 ms with the overlap, 9.36 without - both kernels fill the chip with 256-register workgroups,
-# none of the other's fit beside them, so there is nothing to overlap.  Opt-in: IVLN_WGRAD_OVERLAP=1.
-OVERLAP_WGRAD = bool(os.environ.get("IVLN_WGRAD_OVERLAP"))
+OVERLAP_INSTRUCTION = True
+# (The map CNN's four weight gradients on a second side stream beside the sequential dgrad chain: built and measured in
+#  round 5 - 9.40 ms with, 9.36 without: both kernels fill the chip with 256-register workgroups - and removed in round 6.)
 _side = {}
 
 
@@ -309,12 +305,9 @@ def _net_backward(net, S: Dict, d_feats: torch.Tensor) -> Dict:
     d_mp = ops.linear_bwd_input(d_pre_m, ml.weight)
     d_mp = _conv1d_backward(net.map_kv, d_mkv.view(rows, -1, 1, P), mp.view(rows, Cm, 1, P),
                             d_mp.view(rows, Cm, 1, P), G)
-    wg_side, G_wg = None, None
     if any(p.requires_grad for p in net.map_encoder.parameters()):
         d = d_mp.view(mp.shape)
         blocks = list(net.map_encoder.cnn)
-        if OVERLAP_WGRAD and not torch.cuda.is_current_stream_capturing():
-            wg_side, G_wg = side_stream(dev, "wgrad"), {}
         for i in range(len(blocks) - 1, -1, -1):
             conv, bn = blocks[i].conv[0], blocks[i].conv[1]
             s = S["map"][i]
@@ -324,13 +317,7 @@ def _net_backward(net, S: Dict, d_feats: torch.Tensor) -> Dict:
                 mean, rstd = bn.running_mean, torch.rsqrt(bn.running_var + bn.eps)
             dy, dgamma, dbeta = ops.cbra_bwd(d.contiguous(), s["y"], s["scale"], s["shift"], mean, rstd, s["train"])
             G[bn.weight], G[bn.bias] = dgamma, dbeta
-            if wg_side is not None:
-                wg_side.wait_stream(main)  # dy exists
-                share_with_stream((dy, s["x"]), wg_side)
-                with torch.cuda.stream(wg_side):
-                    G_wg[conv.weight] = ops.conv2d_bwd_weight(dy, s["x"], 7, 7, 1, 3)
-            else:
-                G[conv.weight] = ops.conv2d_bwd_weight(dy, s["x"], 7, 7, 1, 3)
+            G[conv.weight] = ops.conv2d_bwd_weight(dy, s["x"], 7, 7, 1, 3)
             if s["train"]:
                 # train-mode BatchNorm: sum_{n,h,w} dy = gamma*rstd*(S1 - S1 - S2*sum(xhat)/M) and sum(xhat) = 0,
                 # so the gradient of a conv bias feeding it is identically zero (autograd in the reference
@@ -341,10 +328,6 @@ def _net_backward(net, S: Dict, d_feats: torch.Tensor) -> Dict:
             if i > 0:
                 d = ops.conv2d(dy, ops.weight_flip_transpose(conv.weight), pad=3, weight_is_temp=True)
 
-    if wg_side is not None:
-        main.wait_stream(wg_side)
-        share_with_stream(G_wg, main)
-        G.update(G_wg)
     if G_txt is None:
         instruction_backward(net.instruction_encoder, S["txt"], d_txt, U, L, G)
     else:
@@ -423,7 +406,7 @@ class MapCMAForwardFn(torch.autograd.Function):
         return MapCMAForwardFn.apply((net, *args), *params)
 
 
-DIRECT_GRADS = os.environ.get("IVLN_DIRECT_GRADS", "1") != "0"  # A/B: parameters through Function.apply as before
+DIRECT_GRADS = True  # (False: parameters through Function.apply as before round 3)
 
 
 class MapCMAAnchoredFn(torch.autograd.Function):

@@ -20,48 +20,70 @@ FULLSIZE = ROLLOUT + ["tests/test_gpu_rednet.py::test_rednet_fullsize_matches_or
 UPDATE = ["tests/test_gpu_train.py::test_reference_style_update_matches_golden",
           "tests/test_gpu_train.py::test_hip_update_agent_matches_reference_loss_and_moves_params"]
 
-# (switch, value, which goldens)
+GRAPH = ["tests/test_gpu_policy.py::test_graphed_multistream_rollout_is_bit_identical_to_eager"]
+GRAPH_PRED = ["tests/test_gpu_predsem.py::test_predsem_graph_replay_is_bit_identical_to_eager_B8"]
+MAPPER = ["tests/test_gpu_mapper.py"]
+
+# (switch, value, which goldens) - every COMPUTE switch the package reads (round 6: 101 -> the list below + the run-time ones
+# test_every_switch_the_package_reads_is_listed names); a form that lost every committed A/B has no switch any more
 CASES = [
     ("IVLN_SPLIT_BF16", "0", ROLLOUT + UPDATE),          # every conv on the fp32 MFMA kernels
     ("IVLN_SPLIT_BF16_1X1", "1", ROLLOUT),               # the split-bf16 1x1 form wherever eligible
     ("IVLN_SPLIT_BF16_1X1", "0", ROLLOUT),
-    ("IVLN_NO_SPLIT_BF16_WGRAD", "1", UPDATE),           # fp32 MFMA weight gradients
+    ("IVLN_SPLIT_BF16_WGRAD", "0", UPDATE),              # fp32 MFMA weight gradients
     ("IVLN_BF3_KS", "0", FULLSIZE),                       # deep 3x3 convs on the tiled split-bf16 kernel + split-K slabs
     ("IVLN_BF3_KS", "1", FULLSIZE),                       # ... on the K-split-over-waves kernel wherever eligible
-    ("IVLN_BF3_KS_TN", "1", FULLSIZE),                    # ... with 32-pixel tiles everywhere
-    ("IVLN_BF3_KS_TN", "2", FULLSIZE),                    # ... with 64-pixel tiles everywhere
     ("IVLN_BF3_1X1_KS", "0", FULLSIZE),                   # stride-1 1x1 convs without the register-built forms
-    ("IVLN_BF3_1X1_FORM", "ks", FULLSIZE),                # ... K split over waves wherever a form is taken
-    ("IVLN_BF3_1X1_FORM", "wt", FULLSIZE),                # ... wave tiles wherever a form is taken
     ("IVLN_BF3_FUSE", "0", FULLSIZE),                     # bottleneck tails as two launches
-    ("IVLN_BF3_FUSE_PX", "128", FULLSIZE),                # ... fused, 128 mid channels on the 128 x 128-pixel tile
-    ("IVLN_BF3_FUSE_PX", "64", FULLSIZE),                 # ... on the 128 x 64-pixel tile
+    ("IVLN_BF3_CONVT", "0", FULLSIZE),                    # stride-2 3x3 transposed convs on the fp32 direct kernel
+    ("IVLN_S2_GATHER", "0", FULLSIZE),                    # stride-2 1x1 convs read their input strided
     ("IVLN_REDNET_SKIP_ADD", "0", FULLSIZE),              # the decoder's skip adds as launches of their own
-    ("IVLN_BF3_NOSPLIT4", "0", FULLSIZE + UPDATE),        # the 64 x 128 tile split over the channel chunks as in round 4
-    ("IVLN_DEPTH_NET", "0", ROLLOUT),                    # depth encoder: launch chain
-    ("IVLN_DEPTH_NET", "2", ROLLOUT),                    # ... persistent launch everywhere
-    ("IVLN_GN_CONV", "0", ROLLOUT),                      # ... conv + GroupNorm pairs (with IVLN_DEPTH_NET=0 below)
-    ("IVLN_NCONV_FRONT", "0", ROLLOUT),
-    ("IVLN_NO_VEC_GEMM", "1", ROLLOUT + UPDATE),         # scalar-gather implicit GEMM instead of the float4-staged one
-    ("IVLN_NO_DIRECT_CONV", "1", ROLLOUT + UPDATE),      # no LDS-patch direct conv
-    ("IVLN_NO_CONV1X1_STREAM", "1", ROLLOUT),
-    ("IVLN_NO_WIDE_EPILOGUE", "1", ROLLOUT),
+    ("IVLN_CONVT_STACK", "0", ROLLOUT),                   # transposed convs as four launches per parity class
+    ("IVLN_REDNET_PLAN", "0", ROLLOUT),                   # RedNet's launches walked from Python
+    ("IVLN_DEPTH_NET", "0", ROLLOUT),                     # depth encoder: launch chain
+    ("IVLN_DEPTH_NET", "2", ROLLOUT),                     # ... persistent launch everywhere
+    ("IVLN_DEPTH_NET_SPLIT_MIN", "9", GRAPH),             # ... never the persistent launch beside another graph
+    ("IVLN_GN_CONV", "0", ROLLOUT),                       # ... conv + GroupNorm pairs (with IVLN_DEPTH_NET=0 below)
     ("IVLN_NO_XCD_REMAP", "1", ROLLOUT),
-    ("IVLN_CONVT_STACK", "0", ROLLOUT),
-    ("IVLN_REDNET_NO_GROUP", "1", ROLLOUT),
-    ("IVLN_REDNET_PLAN", "0", ROLLOUT),
-    ("IVLN_CMA_STEP_MODE", "-1", ROLLOUT),               # unfused recurrent head
+    ("IVLN_CMA_STEP_MODE", "-1", ROLLOUT),                # unfused recurrent head
     ("IVLN_KV_LINEAR", "0", ROLLOUT),
     ("IVLN_FOLD_GATES", "0", ROLLOUT),
-    ("IVLN_CACHE_INSTRUCTION", "0", ROLLOUT),            # instruction re-encoded at every step
-    ("IVLN_SEQ_PERSISTENT", "0", UPDATE),                # per-timestep GRU launches
-    ("IVLN_NO_TRAIN_OVERLAP", "1", UPDATE),
-    ("IVLN_WGRAD_OVERLAP", "1", UPDATE),                 # weight gradients on a side stream
-    ("IVLN_LINEAR_BWD_NO_SPLIT", "1", UPDATE),
-    ("IVLN_DIRECT_GRADS", "0", UPDATE),
-    ("IVLN_COLSUM_MULTI", "0", UPDATE),
-    ("IVLN_CONV_STATS", "0", UPDATE),
+    ("IVLN_CACHE_INSTRUCTION", "0", ROLLOUT + GRAPH),     # instruction re-encoded at every step
+    ("IVLN_MAPPER_POSED", "0", MAPPER),                   # camera transforms from a launch of their own
+    ("IVLN_MAPPER_WIDTH", "0", GRAPH),                    # the gt-semantics mapper at full width beside the depth encoder
+    ("IVLN_LSTM_SPARE", "1", GRAPH),                      # the bi-LSTM without spare blocks
+    ("IVLN_PRED_DEPTH_START", "0", GRAPH_PRED),           # the depth graph starts with the step
+    ("IVLN_PRED_DEPTH_START", "layer1", GRAPH_PRED),      # ... behind RedNet's layer 1
+    ("IVLN_MAPPER_PREFIX", "0", GRAPH_PRED),              # the whole mapper behind RedNet (no label-free half beside it)
+    ("IVLN_PRED_DEPTH", "chain", GRAPH_PRED),             # the depth encoder beside RedNet as the launch-saving chain
+    ("IVLN_SEQ_PERSISTENT", "0", UPDATE),                 # per-timestep GRU launches
+    ("IVLN_CONV_STATS", "0", UPDATE),                     # BatchNorm statistics from a pass over the conv's output
+    ("IVLN_EAGER_WORK_STREAM", "0", UPDATE),              # eager updates on the current stream
+    ("IVLN_EARLY_LOSS", "1", UPDATE),                     # loss read-back in front of the backward pass
 ]
+# read by the package but not a compute path: library / backend / device selection, limits
+RUNTIME = {"IVLN_HIP_LIB", "IVLN_ENV_BACKEND", "IVLN_DIST_BACKEND", "IVLN_ONE_DEVICE", "IVLN_BENCH_ONE_DEVICE", "IVLN_BENCH_LIMIT_S",
+           "IVLN_HOST_THREADS"}
+
+
+def test_every_switch_the_package_reads_is_listed():
+    """CPU-side bookkeeping (runs with the GPU tests because the cases do): the IVLN_* names read anywhere in the package,
+    bench.py and run.py are exactly the compute switches of CASES plus RUNTIME, and there are at most 60 of them (VERDICT r5
+    item 6)."""
+    import re
+
+    names = set()
+    files = [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "run.py")]
+    for dp, _, fs in os.walk(os.path.join(ROOT, "ivln-ce_amd")):
+        files += [os.path.join(dp, f) for f in fs if f.endswith((".py", ".hip", ".h", ".cpp"))]
+    for f in files:
+        txt = open(f).read()
+        names |= set(re.findall(r'getenv\("(IVLN_[A-Z0-9_]+)"\)', txt))
+        names |= set(re.findall(r'environ\.get\(\s*"(IVLN_[A-Z0-9_]+)"', txt))
+        names |= set(re.findall(r'"(IVLN_[A-Z0-9_]+)" in os\.environ', txt))
+    listed = {c[0] for c in CASES} | RUNTIME
+    assert names == listed, (sorted(names - listed), sorted(listed - names))
+    assert len(names) <= 60
 
 
 @pytest.mark.parametrize("switch,value,tests", CASES, ids=[f"{s}={v}" for s, v, _ in CASES])

@@ -106,7 +106,7 @@ def test_ivln_groupnorm_f32_device_vs_twin():
     assert float(np.abs(yd.cpu().numpy() - yh).max()) < 2e-5
 
 
-@pytest.mark.parametrize("posed", [False, True], ids=["frames+step", "step_posed"])
+@pytest.mark.parametrize("posed", [False, True, "halves"], ids=["frames+step", "step_posed", "begin+finish"])
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "mapper_b*.npz"))), ids=lambda p: os.path.basename(p)[7:-4])
 def test_ivln_mapper_entry_points_device_vs_twin(path, posed):
     """create / frames / step (or step_posed: the same from the sensor pose, six launches) / status through the raw C
@@ -121,6 +121,9 @@ def test_ivln_mapper_entry_points_device_vs_twin(path, posed):
     T.check(Lt, Lt.ivln_mapper_create(B, H, W, vf, 6.4, 6.4, 0.1, 0, 0, C.byref(ht)), "twin create")
     T.check(Ld, Ld.ivln_mapper_create(B, H, W, vf, 6.4, 6.4, 0.1, 1 << 20, 1 << 22, C.byref(hd)), "device create")
     s = stream_ptr()
+    ht2 = C.c_void_p()  # ("halves": a second twin handle stepped through begin + finish beside the single-call one)
+    if posed == "halves":
+        T.check(Lt, Lt.ivln_mapper_create(B, H, W, vf, 6.4, 6.4, 0.1, 0, 0, C.byref(ht2)), "twin create 2")
     for t in range(int(g["steps"])):
         pose, orient = T.np32(g[f"pose_{t}"]), np.ascontiguousarray(g[f"orientation_{t}"], np.float64)
         depth = T.np32(g[f"depth_{t}"]).reshape(B, H, W)
@@ -135,7 +138,28 @@ def test_ivln_mapper_entry_points_device_vs_twin(path, posed):
         Td, rotd = torch.zeros((B, 4, 4), device=DEV), torch.zeros((B, 3, 3), device=DEV)
         occd = torch.zeros((B, 64, 64), dtype=torch.uint8, device=DEV)
         semd = torch.zeros((B, 64, 64), dtype=torch.uint8, device=DEV)
-        if posed:
+        if posed == "halves":
+            # the step in two calls (ivln_mapper_step_begin on a SIDE stream - what a pred-semantics step does beside RedNet -,
+            # _finish on the caller's behind an event), on both libraries; a finish for another batch size, or without a begin,
+            # is refused
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            assert Ld.ivln_mapper_step_finish(hd, _dp(dd), _dp(ld), _dp(ndd), B, _dp(occd), _dp(semd), s) != 0  # (no step open)
+            with torch.cuda.stream(side):
+                T.check(Ld, Ld.ivln_mapper_step_begin(hd, _dp(dd), _dp(pd), _dp(od), _dp(ndd), B, _dp(occd), _dp(Td), _dp(rotd),
+                                                      stream_ptr()), "device step_begin")
+            torch.cuda.current_stream().wait_stream(side)
+            assert Ld.ivln_mapper_step_finish(hd, _dp(dd), _dp(ld), _dp(ndd), B + 1, _dp(occd), _dp(semd), s) != 0
+            T.check(Ld, Ld.ivln_mapper_step_finish(hd, _dp(dd), _dp(ld), _dp(ndd), B, _dp(occd), _dp(semd), s), "device step_finish")
+            # ... and the twin's pair against its own single call (fresh handle state is the same: it was stepped above)
+            Th2, roth2 = np.zeros_like(Th), np.zeros_like(roth)
+            occ2, sem2 = np.zeros_like(occh), np.zeros_like(semh)
+            T.check(Lt, Lt.ivln_mapper_step_begin(ht2, T.hp(depth), T.hp(pose), T.hp(orient), T.hp(nd), B, T.hp(occ2), T.hp(Th2),
+                                                  T.hp(roth2), None), "twin step_begin")
+            T.check(Lt, Lt.ivln_mapper_step_finish(ht2, T.hp(depth), T.hp(labels), T.hp(nd), B, T.hp(occ2), T.hp(sem2), None),
+                    "twin step_finish")
+            assert np.array_equal(occ2, occh) and np.array_equal(sem2, semh) and np.array_equal(Th2, Th)
+        elif posed:
             T.check(Ld, Ld.ivln_mapper_step_posed(hd, _dp(dd), _dp(ld), _dp(pd), _dp(od), _dp(ndd), B, _dp(occd), _dp(semd),
                                                   _dp(Td), _dp(rotd), s), "device step_posed")
         else:
@@ -150,6 +174,8 @@ def test_ivln_mapper_entry_points_device_vs_twin(path, posed):
         assert nt.value == ndv.value == int(g[f"world_n_{t}"])
     Lt.ivln_mapper_destroy(ht)
     Ld.ivln_mapper_destroy(hd)
+    if posed == "halves":
+        Lt.ivln_mapper_destroy(ht2)
 
 
 # ---- round-2 entry points: device library vs CPU twin on the same bytes -----------------------------------------------

@@ -21,7 +21,7 @@ def test_twin_exports_the_header_symbols_it_claims():
     header = open(os.path.join(T.ROOT, "include", "ivln_hip.h")).read()
     for name in ["ivln_strerror", "ivln_version", "ivln_gemm_f32", "ivln_groupnorm_f32", "ivln_mapper_create",
                  "ivln_mapper_destroy", "ivln_mapper_reset", "ivln_mapper_frames", "ivln_mapper_step",
-                 "ivln_mapper_step_posed",
+                 "ivln_mapper_step_posed", "ivln_mapper_step_begin", "ivln_mapper_step_finish",
                  "ivln_mapper_known_begin", "ivln_mapper_load_known", "ivln_mapper_known_raster", "ivln_mapper_status",
                  "ivln_mapper_world_export", "ivln_gn_conv_f32", "ivln_nconv_f32", "ivln_kv_linear_f32",
                  "ivln_cma_step_fwd", "ivln_cma_step_ws_floats"]:

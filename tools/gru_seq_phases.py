@@ -24,7 +24,7 @@ vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
 L.ivln_gru_seq_fwd_persistent.argtypes = [vp, vp, i64, vp, vp, vp, vp, i64, vp, i64, i32, i32, vp, vp, vp, vp, vp, vp]
 L.ivln_gru_seq_stamps.argtypes = [vp, i32]
 DEV = "cuda:0"
-NWG = 32 if os.environ.get("IVLN_SEQ_UPB") == "16" else 64
+NWG = 32 if os.environ.get("(removed switch) IVLN_SEQ_UPB") == "16" else 64
 T = 64
 print(f"T = {T}; us per phase, median over {NWG} workgroups x {T - 2} steps (100 MHz stamps)")
 print(f"{'N':>3s} {'stage':>7s} {'matvec':>7s} {'element':>8s} {'drain':>7s} {'exchange':>9s} {'step':>7s}")

@@ -27,32 +27,14 @@ n = 100
 for i in range(n):
     r.load(obs[i % 40])
     main = torch.cuda.current_stream()
-    e0, eA, eB1, eEnd, eA0 = E(), E(), E(), E(), E()
-    e0.record(main)
-    pieces = r.gB1[r.phase]
-    if len(pieces) > 1:  # gB1 cut behind a RedNet stage (graphed.py): gA is released there
-        pieces[0].replay()
-        r.ev_mid.record(main)
-        r.sA.wait_event(r.ev_mid)
-    else:
-        r.ev_in.record(main)
-        r.sA.wait_event(r.ev_in)
-    with torch.cuda.stream(r.sA):
-        eA0.record(r.sA)
-        r.gA.replay()
-        eA.record(r.sA)
-        r.ev_A.record(r.sA)
-    pieces[-1].replay()
-    eB1.record(main)
-    main.wait_event(r.ev_A)
-    r.graphs[r.phase].replay()
-    eEnd.record(main)
+    ev = {k: E() for k in ("t0", "gA_start", "gA_end", "gB1_end", "end")}
+    ev["t0"].record(main)
+    r._replay_split(mark=lambda name, stream: ev[name].record(stream))  # (the runner's own replay order, with timing marks)
+    ev["end"].record(main)
     r.phase ^= 1
     torch.cuda.synchronize()
-    acc[0] += e0.elapsed_time(eA0)
-    acc[1] += e0.elapsed_time(eA)
-    acc[2] += e0.elapsed_time(eB1)
-    acc[3] += e0.elapsed_time(eEnd)
+    for j, k in enumerate(("gA_start", "gA_end", "gB1_end", "end")):
+        acc[j] += ev["t0"].elapsed_time(ev[k])
 print("per step (us), one step in flight at a time: gA start %.1f | gA end %.1f | gB1 end %.1f | step end %.1f"
       % tuple(1e3 * a / n for a in acc))
 
@@ -69,5 +51,5 @@ def alone(fn, stream, n=100):
     return 1e3 * a.elapsed_time(b) / n
 
 
-print("alone (us): gA %.1f | gB1 %.1f | gB2 %.1f" % (alone(r.gA.replay, r.sA), alone(lambda: [g.replay() for g in r.gB1[0]], torch.cuda.current_stream()),
+print("alone (us): gA %.1f | gB1 %.1f | gB2 %.1f" % (alone(lambda: [g.replay() for g in r.gA_parts], r.sA), alone(lambda: [g.replay() for g in r.gB1[0]], torch.cuda.current_stream()),
                                                    alone(r.graphs[0].replay, torch.cuda.current_stream())))

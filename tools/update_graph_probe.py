@@ -52,12 +52,12 @@ def timeit(f, n=10):
 for _ in range(3):
     leg.once()
 print(f"whole eager update (update_agent): {timeit(leg.once):.2f} ms")
-for name, a, b in (("side streams on", True, bool(_train.OVERLAP_WGRAD)), ("one stream", False, False)):
-    _train.OVERLAP_INSTRUCTION, _train.OVERLAP_WGRAD = a, b
+for name, a in (("side stream on", True), ("one stream", False)):
+    _train.OVERLAP_INSTRUCTION = a
     for _ in range(2):
         region(); leg.opt.zero_grad()
     print(f"eager forward + loss + backward, {name}: {timeit(lambda: (region(), leg.opt.zero_grad())):.2f} ms")
-_train.OVERLAP_INSTRUCTION, _train.OVERLAP_WGRAD = False, False
+_train.OVERLAP_INSTRUCTION = False
 s = torch.cuda.Stream()
 s.wait_stream(torch.cuda.current_stream())
 with torch.cuda.stream(s):
