@@ -75,13 +75,14 @@ int ivln_mapper_step_posed(ivln_mapper* m, const float* depth, const uint8_t* la
  * (mapper.py:398-474: unprojection, filters and the keep-highest selection read depth and pose only; the labels enter at
  * :513-617).  _begin = camera transforms + local min / max + the keep-highest arg-max (2 launches), _finish = label
  * selection, world-cloud merge, raster (4 launches): the same six kernels in the same order, the same bits.  _begin may be
- * enqueued on another stream than _finish as long as _finish is ordered behind it; pose, T_out and rot_out must stay valid
- * (and unchanged) until _finish, which takes the batch size of the step it closes (IVLN_E_INVALID otherwise, or when no
- * step is open).  One open step per handle. */
+ * enqueued on another stream than _finish as long as _finish is ordered behind it.  _finish takes the T / rot that _begin
+ * wrote (T_out, rot_out) and the same depth, pose, not_done and B; nothing on the host links the two calls (a captured step
+ * records each half once and replays them many times), so a _finish without its _begin is the caller's error: it would
+ * select from the previous step's arg-max table. */
 int ivln_mapper_step_begin(ivln_mapper* m, const float* depth, const float* pose, const double* orientation,
                            const uint8_t* not_done, int B, uint8_t* occ_out, float* T_out, float* rot_out, void* stream);
-int ivln_mapper_step_finish(ivln_mapper* m, const float* depth, const uint8_t* labels, const uint8_t* not_done, int B,
-                            uint8_t* occ_out, uint8_t* sem_out, void* stream);
+int ivln_mapper_step_finish(ivln_mapper* m, const float* depth, const uint8_t* labels, const float* T, const float* pose,
+                            const float* rot, const uint8_t* not_done, int B, uint8_t* occ_out, uint8_t* sem_out, void* stream);
 
 /* Known-map mode (mapper.py:851-881): begin = clear finished/paused envs; load = append the
  * pre-built cloud of env b (xyz f32 (n,3), sem u8 (n), device); raster = maps from the cloud. */

@@ -631,9 +631,6 @@ struct ivln_mapper {
     int n_blocks_local;
     int local_blocks, world_blocks;  // launch width of the local- / world-cloud kernels (0: full width)
     int64_t known_rank;
-    // a step begun by ivln_mapper_step_begin and not yet finished: what ivln_mapper_step_finish continues with
-    const float *step_T, *step_pose, *step_rot;
-    int step_B, step_lb;  // step_B == 0: no step is open
 };
 
 #define HIPCHK(x)                          \
@@ -785,18 +782,19 @@ static int mapper_begin(ivln_mapper* m, const float* depth, const float* T, cons
                            (const double*)nullptr, (float*)nullptr, (float*)nullptr);
     hipLaunchKernelGGL(k_local_argmax, dim3(lb), dim3(kThreads), 0, s, cm, m->sc, m->tab64, m->table_cells, m->bmmL, lb,
                        m->bbox, m->B_max, not_done);
-    m->step_T = T, m->step_pose = pose, m->step_rot = rot, m->step_B = B, m->step_lb = lb;
     return hipGetLastError() == hipSuccess ? IVLN_OK : IVLN_E_HIP;
 }
 
-// The rest of the step begun by mapper_begin: label the surviving local points, merge them into the world cloud, raster.
-static int mapper_finish(ivln_mapper* m, const float* depth, const uint8_t* labels, const uint8_t* not_done, int B,
-                         uint8_t* occ_out, uint8_t* sem_out, void* stream) {
-    if (!m || B <= 0 || B != m->step_B) return IVLN_E_INVALID;  // (no step open, or another batch than the one begun)
+// The rest of the step begun by mapper_begin (same batch, same T / pose / rot, same launch width): label the surviving local
+// points, merge them into the world cloud, raster.  No host-side state links the two halves - a captured step records each
+// half once and replays them many times -, the kernels' own state (arg-max table, block partials) does.
+static int mapper_finish(ivln_mapper* m, const float* depth, const uint8_t* labels, const float* T, const float* pose,
+                         const float* rot, const uint8_t* not_done, int B, uint8_t* occ_out, uint8_t* sem_out, void* stream) {
+    if (!m || B <= 0 || B > m->B_max) return IVLN_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    const float *T = m->step_T, *pose = m->step_pose, *rot = m->step_rot;
-    const int lb = m->step_lb;
-    m->step_B = 0;
+    const int64_t npix = (int64_t)B * m->H * m->W;
+    int lb = (int)((npix + kThreads * kPPT - 1) / (kThreads * kPPT));
+    if (m->local_blocks > 0 && m->local_blocks < lb) lb = m->local_blocks;  // (as in mapper_begin)
     const int map_cells = B * m->rows * m->cols;
     const unsigned cap = (unsigned)m->capacity;
     const Cam cm{depth, T, pose, m->xs, m->ys, B, m->H, m->W, m->half_res};
@@ -821,7 +819,8 @@ static int mapper_step(ivln_mapper* m, const float* depth, const uint8_t* labels
                        const float* rot, const double* orientation, float* T_out, float* rot_out,
                        const uint8_t* not_done, int B, uint8_t* occ_out, uint8_t* sem_out, void* stream) {
     const int rc = mapper_begin(m, depth, T, pose, rot, orientation, T_out, rot_out, not_done, B, occ_out, stream);
-    return rc != IVLN_OK ? rc : mapper_finish(m, depth, labels, not_done, B, occ_out, sem_out, stream);
+    if (rc != IVLN_OK) return rc;
+    return mapper_finish(m, depth, labels, orientation ? T_out : T, pose, orientation ? rot_out : rot, not_done, B, occ_out, sem_out, stream);
 }
 
 int ivln_mapper_step_begin(ivln_mapper* m, const float* depth, const float* pose, const double* orientation,
@@ -830,10 +829,10 @@ int ivln_mapper_step_begin(ivln_mapper* m, const float* depth, const float* pose
     return mapper_begin(m, depth, nullptr, pose, nullptr, orientation, T_out, rot_out, not_done, B, occ_out, stream);
 }
 
-int ivln_mapper_step_finish(ivln_mapper* m, const float* depth, const uint8_t* labels, const uint8_t* not_done, int B,
-                            uint8_t* occ_out, uint8_t* sem_out, void* stream) {
-    if (!depth || !labels || !not_done || !occ_out || !sem_out) return IVLN_E_INVALID;
-    return mapper_finish(m, depth, labels, not_done, B, occ_out, sem_out, stream);
+int ivln_mapper_step_finish(ivln_mapper* m, const float* depth, const uint8_t* labels, const float* T, const float* pose,
+                            const float* rot, const uint8_t* not_done, int B, uint8_t* occ_out, uint8_t* sem_out, void* stream) {
+    if (!depth || !labels || !T || !pose || !rot || !not_done || !occ_out || !sem_out) return IVLN_E_INVALID;
+    return mapper_finish(m, depth, labels, T, pose, rot, not_done, B, occ_out, sem_out, stream);
 }
 
 int ivln_mapper_step(ivln_mapper* m, const float* depth, const uint8_t* labels, const float* T, const float* pose,

@@ -278,9 +278,10 @@ class MappingModule:
         _rednet._stage_done("labels")  # (a capturing GraphedRollout cuts its graph here and waits for `begin`'s event)
         if getattr(self, "dry_run", False):
             return mem
-        depth_c, not_done, _, _ = self._open
-        check(lib().ivln_mapper_step_finish(self._h, dptr(depth_c), dptr(labels), dptr(not_done), B, dptr(mem._occ),
-                                            dptr(mem._sem), stream_ptr()), "ivln_mapper_step_finish")
+        depth_c, not_done, pose, _ = self._open
+        check(lib().ivln_mapper_step_finish(self._h, dptr(depth_c), dptr(labels), dptr(self._T), dptr(pose), dptr(self._rot),
+                                            dptr(not_done), B, dptr(mem._occ), dptr(mem._sem), stream_ptr()),
+              "ivln_mapper_step_finish")
         return mem
 
     def _load_known(self, env_name):

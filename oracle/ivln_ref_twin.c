@@ -44,10 +44,6 @@ void mapper_ref_world_get(const MapperRef *m, float *xyz, int32_t *b, uint8_t *s
 struct ivln_mapper {
     MapperRef *ref;
     int B_max;
-    /* a step opened by ivln_mapper_step_begin (the host twin has nothing to overlap: _begin derives the frames and
-     * remembers its arguments, _finish runs the whole step) */
-    const float *step_pose, *step_T, *step_rot;
-    int step_B;
 };
 
 const char *ivln_strerror(int code) {
@@ -118,20 +114,17 @@ int ivln_mapper_step_posed(ivln_mapper *m, const float *depth, const uint8_t *la
     return rc != IVLN_OK ? rc : ivln_mapper_step(m, depth, labels, T_out, pose, rot_out, not_done, B, occ_out, sem_out, stream);
 }
 
+/* (the host twin has nothing to overlap: _begin derives the frames, _finish runs the whole step from them) */
 int ivln_mapper_step_begin(ivln_mapper *m, const float *depth, const float *pose, const double *orientation,
                            const uint8_t *not_done, int B, uint8_t *occ_out, float *T_out, float *rot_out, void *stream) {
     if (!m || B <= 0 || B > m->B_max || !depth || !pose || !orientation || !T_out || !rot_out || !not_done || !occ_out) return IVLN_E_INVALID;
-    int rc = ivln_mapper_frames(pose, orientation, B, T_out, rot_out, stream);
-    if (rc != IVLN_OK) return rc;
-    m->step_pose = pose, m->step_T = T_out, m->step_rot = rot_out, m->step_B = B;
-    return IVLN_OK;
+    return ivln_mapper_frames(pose, orientation, B, T_out, rot_out, stream);
 }
 
-int ivln_mapper_step_finish(ivln_mapper *m, const float *depth, const uint8_t *labels, const uint8_t *not_done, int B,
-                            uint8_t *occ_out, uint8_t *sem_out, void *stream) {
-    if (!m || B <= 0 || B != m->step_B || !depth || !labels || !not_done || !occ_out || !sem_out) return IVLN_E_INVALID;
-    m->step_B = 0;
-    return ivln_mapper_step(m, depth, labels, m->step_T, m->step_pose, m->step_rot, not_done, B, occ_out, sem_out, stream);
+int ivln_mapper_step_finish(ivln_mapper *m, const float *depth, const uint8_t *labels, const float *T, const float *pose,
+                            const float *rot, const uint8_t *not_done, int B, uint8_t *occ_out, uint8_t *sem_out, void *stream) {
+    if (!depth || !labels || !T || !pose || !rot || !not_done || !occ_out || !sem_out) return IVLN_E_INVALID;
+    return ivln_mapper_step(m, depth, labels, T, pose, rot, not_done, B, occ_out, sem_out, stream);
 }
 
 int ivln_mapper_known_begin(ivln_mapper *m, const uint8_t *not_done, int B, void *stream) {

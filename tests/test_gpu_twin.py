@@ -140,24 +140,23 @@ def test_ivln_mapper_entry_points_device_vs_twin(path, posed):
         semd = torch.zeros((B, 64, 64), dtype=torch.uint8, device=DEV)
         if posed == "halves":
             # the step in two calls (ivln_mapper_step_begin on a SIDE stream - what a pred-semantics step does beside RedNet -,
-            # _finish on the caller's behind an event), on both libraries; a finish for another batch size, or without a begin,
-            # is refused
+            # _finish on the caller's behind an event), on both libraries; a finish for a batch beyond the handle's size is refused
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
-            assert Ld.ivln_mapper_step_finish(hd, _dp(dd), _dp(ld), _dp(ndd), B, _dp(occd), _dp(semd), s) != 0  # (no step open)
             with torch.cuda.stream(side):
                 T.check(Ld, Ld.ivln_mapper_step_begin(hd, _dp(dd), _dp(pd), _dp(od), _dp(ndd), B, _dp(occd), _dp(Td), _dp(rotd),
                                                       stream_ptr()), "device step_begin")
             torch.cuda.current_stream().wait_stream(side)
-            assert Ld.ivln_mapper_step_finish(hd, _dp(dd), _dp(ld), _dp(ndd), B + 1, _dp(occd), _dp(semd), s) != 0
-            T.check(Ld, Ld.ivln_mapper_step_finish(hd, _dp(dd), _dp(ld), _dp(ndd), B, _dp(occd), _dp(semd), s), "device step_finish")
+            assert Ld.ivln_mapper_step_finish(hd, _dp(dd), _dp(ld), _dp(Td), _dp(pd), _dp(rotd), _dp(ndd), 65, _dp(occd), _dp(semd), s) != 0  # (B > B_max)
+            T.check(Ld, Ld.ivln_mapper_step_finish(hd, _dp(dd), _dp(ld), _dp(Td), _dp(pd), _dp(rotd), _dp(ndd), B, _dp(occd), _dp(semd), s),
+                    "device step_finish")
             # ... and the twin's pair against its own single call (fresh handle state is the same: it was stepped above)
             Th2, roth2 = np.zeros_like(Th), np.zeros_like(roth)
             occ2, sem2 = np.zeros_like(occh), np.zeros_like(semh)
             T.check(Lt, Lt.ivln_mapper_step_begin(ht2, T.hp(depth), T.hp(pose), T.hp(orient), T.hp(nd), B, T.hp(occ2), T.hp(Th2),
                                                   T.hp(roth2), None), "twin step_begin")
-            T.check(Lt, Lt.ivln_mapper_step_finish(ht2, T.hp(depth), T.hp(labels), T.hp(nd), B, T.hp(occ2), T.hp(sem2), None),
-                    "twin step_finish")
+            T.check(Lt, Lt.ivln_mapper_step_finish(ht2, T.hp(depth), T.hp(labels), T.hp(Th2), T.hp(pose), T.hp(roth2), T.hp(nd), B,
+                                                   T.hp(occ2), T.hp(sem2), None), "twin step_finish")
             assert np.array_equal(occ2, occh) and np.array_equal(sem2, semh) and np.array_equal(Th2, Th)
         elif posed:
             T.check(Ld, Ld.ivln_mapper_step_posed(hd, _dp(dd), _dp(ld), _dp(pd), _dp(od), _dp(ndd), B, _dp(occd), _dp(semd),

@@ -29,7 +29,7 @@ def _sigs(L):
     L.ivln_mapper_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp]
     L.ivln_mapper_step_posed.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]
     L.ivln_mapper_step_begin.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]
-    L.ivln_mapper_step_finish.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp]
+    L.ivln_mapper_step_finish.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp]
     L.ivln_mapper_known_begin.argtypes = [vp, vp, i32, vp]
     L.ivln_mapper_load_known.argtypes = [vp, i32, vp, vp, i64, vp]
     L.ivln_mapper_known_raster.argtypes = [vp, vp, vp, i32, vp, vp, vp]
