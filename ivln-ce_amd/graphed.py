@@ -133,7 +133,7 @@ class GraphedRollout:
         self.split = streams == "split"
         self.side = (_stream(dev, "fork_txt"), _stream(dev, "fork_map")) if (streams and not self.split) else None
         self.graphs = []
-        self._prefix, self.gA_parts = False, []
+        self._prefix, self.gA_parts, self._a_tags, self._b_tags = False, [], [], []
         self.phase = 0  # which buffer set holds the current state
         # the fused head's scratch is baked into the captured graphs: this runner owns one (ops.cma_step_ws)
         prev_owner, ops.CMA_WS_OWNER = ops.CMA_WS_OWNER, id(self)
@@ -289,9 +289,11 @@ class GraphedRollout:
         # _finish): gB1 is cut a second time where the labels exist, and waits there for the event recorded behind the prefix
         self._prefix = bool(self._cut_stage) and os.environ.get("IVLN_MAPPER_PREFIX", "1") != "0" and _mapping.STEP_POSED and all(
             hasattr(t, "begin_maps") and type(t).__name__.endswith("IterativeMapper") for t in self.transforms)
-        # the depth encoder's stream: the critical chain of the gt-semantics step wins dispatch when both queues are ready
-        # (priority -1; beside RedNet, where it is not critical, the priority made no difference: profiles/r06_split_probe_start.txt)
-        self.sA = _stream(dev, "depth", priority=-1)
+        # (the side graph cut in two - its first part beside RedNet's early stages, the second beside its late ones, pausing
+        #  during the pixel-starved middle - was built and measured in round 6: gB1 ends at 3453-3462 us against 3408, whatever
+        #  the two cut points (profiles/r06_split_probe_twopart.txt): the loss follows the side launches, not the stage they run
+        #  beside.  Removed; the replay below still handles any number of tagged cuts.)
+        self._dd_cut, self._late_stage = None, None
         if venc is not None:
             venc.latency_bound = not predicted
             venc.beside_other_work = True  # (its graph replays beside the mapper / map-CNN graph: ops.DEPTH_NET's policy)
@@ -350,16 +352,21 @@ class GraphedRollout:
         ops.settle_packed_weights()
         self.ev_pre = torch.cuda.Event()
         with _CutCapture(self.sA) as ca:
+            a_tags = []
+
             def hook_a(name, ca=ca):
-                if name == "mapper_begin" and len(ca.graphs) == 1:
+                if (name == "mapper_begin" and self._prefix and not a_tags) or (name == self._dd_cut and "dd" not in a_tags):
+                    a_tags.append("pre" if name == "mapper_begin" else "dd")
                     ca.cut()
-            prev_hook, _rednet.STAGE_HOOK = _rednet.STAGE_HOOK, (hook_a if self._prefix else None)
+            prev_hook, _rednet.STAGE_HOOK = _rednet.STAGE_HOOK, (hook_a if (self._prefix or self._dd_cut) else None)
             try:
                 run_A()
             finally:
                 _rednet.STAGE_HOOK = prev_hook
-        self.gA_parts = list(ca.graphs)  # [mapper prefix, depth encoder (+ instruction encoder)] or the one graph
+        # [mapper prefix | depth encoder part 1 | part 2 (+ instruction encoder)]: a_tags names the boundary behind each piece but the last
+        self.gA_parts, self._a_tags = list(ca.graphs), a_tags
         self.gA = self.gA_parts[-1]
+        self.ev_late = torch.cuda.Event()
         self._dep = net._stash_dep  # (depth features, k/v) live in gA's pool
         self._txt = getattr(net, "_stash_txt", None)  # (predicted semantics: the instruction features too)
         # the previous action (read by the embedding in gB1) ping-pongs with the state: one gB1 per phase
@@ -367,10 +374,17 @@ class GraphedRollout:
         self.gB1, pool = [], None
         for src in (0, 1):
             with _CutCapture(cap_stream, pool) as cc:
-                def hook(name, cc=cc):
-                    if name == self._cut_stage and len(cc.graphs) == 1:
+                b_tags = []
+
+                def hook(name, cc=cc, b_tags=b_tags):
+                    if name == self._cut_stage and "mid" not in b_tags:
+                        b_tags.append("mid")
                         cc.cut()
-                    elif name == "labels" and self._prefix and len(cc.graphs) == 2:
+                    elif name == self._late_stage and "dd" in self._a_tags and "late" not in b_tags and "mid" in b_tags:
+                        b_tags.append("late")
+                        cc.cut()  # (the side graph's second part is released here)
+                    elif name == "labels" and self._prefix and "labels" not in b_tags and "mid" in b_tags:
+                        b_tags.append("labels")
                         cc.cut()  # (the mapper's second half starts here: the replay waits for the prefix's event in between)
                 prev_hook, _rednet.STAGE_HOOK = _rednet.STAGE_HOOK, (hook if self._cut_stage else None)
                 try:
@@ -385,6 +399,7 @@ class GraphedRollout:
                 net._stash, net._stash_dep = stash, self._dep
                 run_B2(src, batch)
             self.gB1.append(list(cc.graphs))
+            self._b_tags = b_tags  # (the same cuts in both phases)
             self.graphs.append(g2)
         self._keep = (batch, stash)
         self.phase = 0
@@ -394,39 +409,53 @@ class GraphedRollout:
 
     def _replay_split(self, mark=None):
         """One step: the main graphs on the current stream, the side graph(s) on sA.  `mark(name, stream)` (tools/split_probe.py)
-        is called where gA starts / ends and where gB1 ends, to record timing events."""
+        is called where gA starts / ends and where gB1 ends, to record timing events.
+        (Tried and left: gB1 BEFORE gA - no difference, round 3; gB1 on a third, CU-masked stream - 0.79-0.83 vs 0.708 ms per
+        gt step, round 3; gB2 behind gA on the side stream - slower; the main graphs on a third stream with a priority of its
+        own - 8.2 vs 4.25 ms, round 5: the extra stream hop serialises the replay.)"""
         main = torch.cuda.current_stream()
         pieces = self.gB1[self.phase]
-        if len(pieces) > 1:  # gB1 cut behind a RedNet stage: its head first, gA released at the cut
-            pieces[0].replay()
-            self.ev_mid.record(main)
-            self.sA.wait_event(self.ev_mid)
-        else:
+        b_tags = getattr(self, "_b_tags", []) if len(pieces) > 1 else []
+        a_parts, a_tags = self.gA_parts, self._a_tags
+        ai = 0  # next piece of the side graph
+
+        def side(upto_tag, wait_ev):
+            """replay the side pieces up to (and including) the one whose boundary is `upto_tag` (None: all the rest)"""
+            nonlocal ai
+            self.sA.wait_event(wait_ev)
+            with torch.cuda.stream(self.sA):
+                if mark and ai == 0:
+                    mark("gA_start", self.sA)
+                while ai < len(a_parts):
+                    a_parts[ai].replay()
+                    tag = a_tags[ai] if ai < len(a_tags) else None
+                    ai += 1
+                    if tag == "pre":
+                        self.ev_pre.record(self.sA)
+                    if tag is not None and tag == upto_tag:
+                        return
+                if mark:
+                    mark("gA_end", self.sA)
+                self.ev_A.record(self.sA)
+
+        if not b_tags:  # one main graph: the side graph starts with the step
             self.ev_in.record(main)
-            self.sA.wait_event(self.ev_in)
-        with torch.cuda.stream(self.sA):
-            if mark:
-                mark("gA_start", self.sA)
-            if len(self.gA_parts) > 1:  # the mapper's label-free half, then the event gB1's last piece waits for
-                self.gA_parts[0].replay()
-                self.ev_pre.record(self.sA)
-            self.gA.replay()
-            if mark:
-                mark("gA_end", self.sA)
-            self.ev_A.record(self.sA)
-        # (launching gB1 - RedNet with predicted semantics, the critical chain there - BEFORE gA was measured in round 3:
-        #  5.485 vs 5.480 ms per step at 8 envs, no difference; the 0.8 ms hole in front of RedNet in a traced timeline is
-        #  the tracer's slower graph launches)
-        # (gB1 on a third, CU-masked stream - hipExtStreamCreateWithCUMask, 32..192 CUs, contiguous or strided masks - so that
-        #  the map CNN's large grids stop crowding the chain: measured 0.79-0.83 ms per step against 0.708, round 3)
-        # (... and gB2 replayed BEHIND gA on the chain's stream, so that the critical edge gA -> gB2 stays inside one queue:
-        #  0.726 vs 0.714 ms per step, slower)
-        # (... and the main graphs on a third stream with a priority of its own, whatever the priorities: 8.2 ms per pred-semantics
-        #  step against 4.25, round 5 - the extra stream hop serialises the replay)
-        if len(pieces) == 3:  # ... RedNet's rest | the mapper's second half + map CNN, behind the prefix
-            pieces[1].replay()
-            main.wait_event(self.ev_pre)
-        pieces[-1].replay()
+            side(None, self.ev_in)
+            if "pre" in a_tags:  # (a mapper prefix in the side graph but no cut in the main one: it has to be over first)
+                main.wait_event(self.ev_pre)
+            pieces[-1].replay()
+        else:
+            for i, g in enumerate(pieces):
+                tag = b_tags[i - 1] if i > 0 else None  # the boundary in FRONT of this piece
+                if tag == "mid":      # ... released here: the side graph (its first part when it is cut in two)
+                    self.ev_mid.record(main)
+                    side("dd" if "late" in b_tags else None, self.ev_mid)
+                elif tag == "late":   # ... its second part
+                    self.ev_late.record(main)
+                    side(None, self.ev_late)
+                elif tag == "labels":  # the mapper's second half waits for its first (the side graph's head)
+                    main.wait_event(self.ev_pre)
+                g.replay()
         if mark:
             mark("gB1_end", main)
         main.wait_event(self.ev_A)
