@@ -294,6 +294,9 @@ class GraphedRollout:
         #  the two cut points (profiles/r06_split_probe_twopart.txt): the loss follows the side launches, not the stage they run
         #  beside.  Removed; the replay below still handles any number of tagged cuts.)
         self._dd_cut, self._late_stage = None, None
+        # the depth encoder's stream: the critical chain of the gt-semantics step wins dispatch when both queues are ready
+        # (priority -1; beside RedNet, where it is not critical, the priority made no difference: profiles/r06_split_probe_start.txt)
+        self.sA = _stream(dev, "depth", priority=-1)
         if venc is not None:
             venc.latency_bound = not predicted
             venc.beside_other_work = True  # (its graph replays beside the mapper / map-CNN graph: ops.DEPTH_NET's policy)

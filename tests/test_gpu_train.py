@@ -257,6 +257,40 @@ def test_eval_with_graph_replay_matches_eager_eval(tmp_path, same_depth_path):
     assert out[True]["episodes"] > 0
 
 
+def test_eval_with_predicted_semantics_graph_replay_matches_eager_eval(tmp_path, same_depth_path):
+    """BASELINE configs[2] through the trainer: `PredictedSemanticsIterativeMapper` (RedNet -> mapper) + `MapCMAPolicy.act`
+    replayed as captured graphs - the main graph in pieces, the depth encoder released behind RedNet's layer 3, the mapper's
+    label-free half at the head of the side graph (graphed.py, round 6) - including the captures WITHOUT a warm-up that follow
+    when envs run out of episodes and pause.  Per-episode stats and t-nDTW equal the eager loop's exactly (the eager loop runs
+    the depth encoder as conv + GroupNorm pairs too: the same kernels the capture chooses beside RedNet)."""
+    import ivln_ce_amd  # noqa: F401
+    from ivln_ce_amd import ops, trainers  # noqa: F401
+    from ivln_ce_amd.config import get_config
+    from ivln_ce_amd.registry import baseline_registry
+
+    same_depth_path(0)
+    chain, ops.CHAIN_GN_CONV = ops.CHAIN_GN_CONV, False
+    out = {}
+    try:
+        for mode in (True, False):
+            torch.manual_seed(0)
+            cfg = get_config(opts=[
+                "TRAINER_NAME", "dagger", "NUM_ENVIRONMENTS", 3, "MODEL.policy_name", "MapCMAPolicy",
+                "MODEL.INSTRUCTION_ENCODER.use_pretrained_embeddings", False, "MODEL.DEPTH_ENCODER.ddppo_checkpoint", "NONE",
+                "RL.POLICY.OBS_TRANSFORMS.ENABLED_TRANSFORMS", ["PredictedSemanticsIterativeMapper"],
+                "RESULTS_DIR", str(tmp_path / f"res{int(mode)}"), "EVAL_CKPT_PATH_DIR", str(tmp_path / "none.pth"),
+                "EVAL.USE_HIP_GRAPH", mode, "EVAL.SAVE_RESULTS", False,
+            ])
+            tr = baseline_registry.get_trainer("dagger")(cfg)
+            res = tr._eval_checkpoint(str(tmp_path / "none.pth"))
+            res.pop("eval_seconds")
+            out[mode] = res
+    finally:
+        ops.CHAIN_GN_CONV = chain
+    assert out[True] == out[False], f"graph {out[True]} vs eager {out[False]}"
+    assert out[True]["episodes"] > 0
+
+
 @pytest.mark.parametrize("policy", ["MapCMAPolicy", "LatentCMAPolicy"])
 def test_iterative_dagger_trainer_end_to_end(tmp_path, policy):
     """iterative_dagger: tour-by-tour collection (tour table stored as record 0) -> TourSampler batches -> HIP
