@@ -325,7 +325,6 @@ class _ResNet50GN(nn.Module):
         c, gn = self.conv1[0], self.conv1[1]
         y = ops.conv2d(x, c.weight, stride=2, pad=3, defer=True)
         first = ops.CHAIN_FROM_BLOCK if ops.CHAIN_FROM_BLOCK >= 0 else (3 if x.shape[0] <= 5 else 7)
-        first = getattr(self, "chain_from", first)  # (graphed.py, beside RedNet: 16 = no slab chain at all, only the front blocks' nconv launches)
         first = min(first, len(blocks))  # blocks before it run as conv + GroupNorm pairs
         if first == 0:
             r = ops.gn_conv(y, gn, relu=True, pool=True, **feeds(blocks[0]))

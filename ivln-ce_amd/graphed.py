@@ -303,17 +303,9 @@ class GraphedRollout:
             # measurement switch for the predicted-semantics step: how the policy's depth encoder runs beside RedNet -
             # "pairs" (default: conv + GroupNorm launches), "chain" (GroupNorm + next conv per launch), "net" (persistent launch)
             pd = os.environ.get("IVLN_PRED_DEPTH", "pairs") if predicted else None
-            venc.no_persistent = pd in ("chain", "front")
-            if pd in ("chain", "net", "front"):
+            venc.no_persistent = pd == "chain"
+            if pd in ("chain", "net"):
                 venc.latency_bound = True
-            # "front": layers 1-2 as GroupNorm-on-load convs (ivln_nconv_f32: 3 launches per bottleneck, no slabs), the rest
-            # as pairs - fewer side launches beside RedNet without the chain's slab traffic
-            bb = getattr(venc, "backbone", None)
-            if bb is not None:
-                if pd == "front":
-                    bb.chain_from = 16
-                elif hasattr(bb, "chain_from"):
-                    del bb.chain_from
         net._txt_with_dep = predicted  # ... and the instruction encoder leaves RedNet's stream for the side graph
         net._txt_last = True
         # ... and with fewer than 8 images some XCDs stay free of it: the bi-LSTM's blocks that land there take all the work
