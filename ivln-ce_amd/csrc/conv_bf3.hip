@@ -115,7 +115,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t bf3_rsrc(const void* p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
 }
 
-template <int KS, int TM, int WM, int WN, int PTH, int PTW, int IMGS, int DA, bool FUSE = false>
+// ST = 2 (round 6): the stride-2 3x3 convs of RedNet's layer 2-4 entry blocks (rednet.py:84-110, pad 1, Hin = 2 Hout).  Output
+// (ho, wo) reads input rows 2 ho - 1 .. 2 ho + 1: the patch is staged as FOUR PHASE PLANES - (row parity, column parity) of the
+// input pixel, each (PTH + 1) x (PTW + 1) pixels per image - so that tap (kh, kw) is plane (kh != 1, kw != 1) at offset
+// ((kh == 2), (kw == 2)): a compile-time LDS offset per tap, and a lane's base address depends on its output pixel only,
+// exactly as in the stride-1 kernel.  Odd input rows 2 i - 1 are plane row i (i = 0 .. PTH), even rows 2 i plane row i.
+template <int KS, int TM, int WM, int WN, int PTH, int PTW, int IMGS, int DA, bool FUSE = false, int ST = 1>
 __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_desc p, const unsigned char* a_split, long long a_grp_bytes,
                                                            int tiles_w, int tiles_h, int nimg, int chunks_per_split) {
 #ifdef BF3_TIMING
@@ -127,7 +132,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
     constexpr int KK = KS * KS, KKP = bf3_taps_padded(KS), CS = bf3_stage_chunks(KS);
     constexpr int RP = KKP * CS;  // taps (padded) between two barriers: a STAGE = CS chunks of 16 channels
     static_assert(RP % DA == 0 && KKP >= KK && (CS == 1 || KK == 1), "prefetch rotation closes over a stage");
-    constexpr int PH = PTH + KS - 1, PWR = PTW + KS - 1, NPIX = IMGS * PH * PWR;
+    static_assert(ST == 1 || (ST == 2 && KS == 3 && !FUSE), "stride 2: the 3x3 kernel only");
+    constexpr bool S2 = ST == 2;
+    // stride 1: PH x PWR patch pixels per image.  stride 2: four planes of PH x PWR = (PTH + 1) x (PTW + 1) each
+    constexpr int PH = S2 ? PTH + 1 : PTH + KS - 1, PWR = S2 ? PTW + 1 : PTW + KS - 1;
+    constexpr int PLANE = PH * PWR, NPIX = IMGS * (S2 ? 4 : 1) * PLANE;
     constexpr int ITEMS = NPIX * (CB / 2) * CS;
     constexpr int LDT = BN + 4;
     constexpr bool HAS_LITE = KS == 7 && TM == 1;  // (a second copy of the unrolled tap loop: only where one-hot inputs occur)
@@ -159,16 +168,19 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
     // first tap of every chunk (s_waitcnt vmcnt(13) with 50 loads in flight).
     // 1x1 (CS chunks per stage, no halo): the flat (pixel, pair) enumeration with offsets re-derived per stage.
     constexpr int XOFF = bf3_xoff(KS);               // patch column x is pixel x + XOFF of the aligned group grid
-    constexpr int NG = (XOFF + PWR + 3) / 4;         // 16-byte groups per patch row
+    // stride 2: input rows 2 ho0 - 1 .. 2 ho0 + 2 PTH - 1 (2 PTH + 1 of them), columns on the group grid that starts at 2 wo0 - 4
+    constexpr int PROWS = S2 ? 2 * PTH + 1 : PH;     // INPUT rows staged per image
+    constexpr int NG = S2 ? (2 * PTW + 3) / 4 + 1 : (XOFF + PWR + 3) / 4;  // 16-byte groups per input row
     constexpr bool UP = KS == 2;                     // rows = 4 * channel + parity class, stores into the (2 H x 2 W) output
-    constexpr int ITEMS3 = IMGS * PH * NG * (CB / 2);
+    constexpr int ITEMS3 = IMGS * PROWS * NG * (CB / 2);
     constexpr int NI3 = KS == 1 ? 1 : (ITEMS3 + NTB - 1) / NTB;
     constexpr unsigned OOB = 0x80000000u;            // (>= num_records of the descriptor: the load returns zeros)
     static_assert(NTB % 8 == 0, "a thread keeps its channel pair over its items");
     unsigned ivo[NI3];
     int idst[NI3], imask[NI3];
+    int idst1[S2 ? NI3 : 1];  // (stride 2: the odd-column plane's base; idst is the even-column plane's)
     const int qpair = t & 7;
-    if constexpr (KS != 1) {
+    if constexpr (KS != 1 && !S2) {
 #pragma unroll
         for (int j = 0; j < NI3; ++j) {
             const int idx = t + j * NTB, rest = idx >> 3;
@@ -180,6 +192,31 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
             int m = 0;
 #pragma unroll
             for (int e = 0; e < 4; ++e) m |= (idx < ITEMS3 && (unsigned)(4 * g + e - XOFF) < (unsigned)PWR) ? (1 << e) : 0;
+            imask[j] = m;
+        }
+    }
+    if constexpr (S2) {
+        // group g of input row y: pixels wi = 2 wo0 - 4 + 4 g + e.  e = 0, 2 are even columns 2 (wo0 + c): plane column
+        // c = 2 g - 2 + e / 2 (needed for c < PTW); e = 1, 3 are odd columns 2 (wo0 + c) - 1: c = 2 g - 1 + e / 2 (c <= PTW).
+        // Row y is input row 2 ho0 - 1 + y: y even = an odd row (plane row y / 2 <= PTH), y odd = an even row (plane row (y - 1) / 2).
+#pragma unroll
+        for (int j = 0; j < NI3; ++j) {
+            const int idx = t + j * NTB, rest = idx >> 3;
+            const int g = rest % NG, yy = rest / NG, il = yy / PROWS, y = yy - il * PROWS;
+            const int hi = 2 * ho0 - 1 + y, wi = 2 * wo0 - 4 + 4 * g, img = img0 + il;
+            const bool ok = idx < ITEMS3 && img < nimg && (unsigned)hi < (unsigned)p.Hin && wi >= 0 && wi + 3 < p.Win;
+            ivo[j] = ok ? (unsigned)(((int64_t)img * p.in_img_stride + (int64_t)(2 * qpair) * HW + hi * p.Win + wi) * 4) : OOB;
+            const int rp = (y & 1) ^ 1, prow = y >> 1;
+            const int pbase = (il * 4 + rp * 2) * PLANE + prow * PWR;
+            idst[j] = (pbase + 2 * g - 2) * PIXB + qpair * 4;           // even columns: e = 0 here, e = 2 one pixel on
+            idst1[j] = (pbase + PLANE + 2 * g - 1) * PIXB + qpair * 4;  // odd columns:  e = 1 here, e = 3 one pixel on
+            int m = 0;
+            if (idx < ITEMS3) {
+                m |= ((unsigned)(2 * g - 2) < (unsigned)PTW) ? 1 : 0;
+                m |= ((unsigned)(2 * g - 1) <= (unsigned)PTW) ? 2 : 0;
+                m |= ((unsigned)(2 * g - 1) < (unsigned)PTW) ? 4 : 0;
+                m |= ((unsigned)(2 * g) <= (unsigned)PTW) ? 8 : 0;
+            }
             imask[j] = m;
         }
     }
@@ -255,7 +292,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
                     split3_pair(__int_as_float(rv[j][0][e]), __int_as_float(rv[j][1][e]), H, M, L);
                     if ((imask[j] >> e) & 1) {  // (pixels of the group outside the patch - or items past the last - are not staged)
                         nz |= M | L;
-                        unsigned char* d = smem + idst[j] + e * PIXB;
+                        unsigned char* d = S2 ? smem + ((e & 1) ? idst1[j] : idst[j]) + (e >> 1) * PIXB : smem + idst[j] + e * PIXB;
                         *reinterpret_cast<uint32_t*>(d) = H;
                         *reinterpret_cast<uint32_t*>(d + 32) = M;
                         *reinterpret_cast<uint32_t*>(d + 64) = L;
@@ -271,7 +308,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
     for (int tn = 0; tn < TN; ++tn) {
         const int nl = (wn * TN + tn) * 32 + l31;
         const int il = nl / (PTH * PTW), ph = (nl / PTW) % PTH, pw = nl % PTW;
-        bbase[tn] = ((il * PH + ph) * PWR + pw) * PIXB + half * 16;
+        bbase[tn] = ((il * (S2 ? 4 : 1) * PH + ph) * PWR + pw) * PIXB + half * 16;  // (stride 2: plane (0, 0) of the image; the tap adds its plane)
     }
     // weights: [32-channel tile][chunk][tap (padded)][piece][lane] x 16 bytes
     __amdgpu_buffer_rsrc_t rA[TM];
@@ -331,7 +368,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_bf3(const ivln_gemm_de
             constexpr int NPL = LITE ? 1 : 3;
             auto read_b = [&](int r, bf16x8 (&b)[TN][3]) {  // the tap's B fragments: one ds_read_b128 per (pixel tile, piece)
                 const int kh = r / KS, kw = r - kh * KS;
-                const int toff = KS == 1 ? r * (NPIX * PIXB) : (kh * PWR + kw) * PIXB;  // (1x1: tap r = chunk r of the stage)
+                const int toff = KS == 1 ? r * (NPIX * PIXB)  // (1x1: tap r = chunk r of the stage)
+                                 : (S2 ? ((((kh != 1) * 2 + (kw != 1)) * PLANE + (kh == 2) * PWR + (kw == 2)) * PIXB) : (kh * PWR + kw) * PIXB);
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
@@ -1324,13 +1362,16 @@ __global__ __launch_bounds__(256) void k_conv_bf3_pack(const float* __restrict__
     out[idx] = (uint16_t)(pl == 0 ? h : (pl == 1 ? mm : l));
 }
 
-template <int KS, int TM, int WM, int WN, int PTH, int PTW, int IMGS, int DA>
+template <int KS, int TM, int WM, int WN, int PTH, int PTW, int IMGS, int DA, int ST = 1>
 int launch_bf3(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a_split, int64_t grp_bytes, int nimg, int cps) {
     constexpr int NTB = 64 * WM * WN, BM = 32 * TM * WM, BN = 64 * WN;
-    constexpr int PH = PTH + KS - 1, PWR = PTW + KS - 1, NPIX = IMGS * PH * PWR * bf3_stage_chunks(KS);
+    constexpr int PH = ST == 2 ? PTH + 1 : PTH + KS - 1, PWR = ST == 2 ? PTW + 1 : PTW + KS - 1;
+    constexpr int NPIX = IMGS * (ST == 2 ? 4 : 1) * PH * PWR * bf3_stage_chunks(KS);  // (stride 2: four phase planes)
     constexpr size_t lds = (size_t)(NPIX * PIXB > 32 * (BN + 4) * 4 ? NPIX * PIXB : 32 * (BN + 4) * 4);
-    static_assert(lds <= 160 * 1024, "patch does not fit");
-    auto kern = k_conv_bf3<KS, TM, WM, WN, PTH, PTW, IMGS, DA>;
+    if constexpr (lds > 160 * 1024) {
+        return IVLN_E_UNSUPPORTED;  // (a stride-2 tile whose planes do not fit: the dispatcher picks another)
+    } else {
+    auto kern = k_conv_bf3<KS, TM, WM, WN, PTH, PTW, IMGS, DA, false, ST>;
     static bool attr_done = false;  // (idempotent; a race only repeats the call)
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return IVLN_E_HIP;
@@ -1341,6 +1382,7 @@ int launch_bf3(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a_sp
     dim3 grid(tiles_w * tiles_h * groups, (d.M + BM - 1) / BM, d.splits);
     IVLN_LAUNCH_FAMILY_NAMED("k_conv_bf3", kern, grid, dim3(NTB), lds, s, d, a_split, (long long)grp_bytes, tiles_w, tiles_h, nimg, cps);
     return IVLN_OK;
+    }
 }
 
 // The fused bottleneck tail (ivln_gemm_desc.fuse_*): the 64 x 128 / 128 x 128 tiles of the 3x3 kernel with the 1x1 expansion behind.
@@ -1371,9 +1413,21 @@ inline Bf3Px bf3_px(int BN, int Wout) {
     return {pth, ptw, BN / (ptw * pth)};
 }
 
-template <int KS, int TM, int WM, int WN, int DA>
+template <int KS, int TM, int WM, int WN, int DA, int ST = 1>
 int launch_bf3_px(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a, int64_t gb, int nimg, int cps) {
     constexpr int BN = 64 * WN;
+    if constexpr (ST == 2) {  // stride-2 3x3: the 128- and 256-pixel tiles
+        static_assert(KS == 3 && (BN == 128 || BN == 256), "stride-2 tiles");
+        if constexpr (BN == 256) {
+            if (d.Wout > 16) return launch_bf3<KS, TM, WM, WN, 8, 32, 1, DA, 2>(d, s, a, gb, nimg, cps);
+            if (d.Wout > 8) return launch_bf3<KS, TM, WM, WN, 16, 16, 1, DA, 2>(d, s, a, gb, nimg, cps);
+            return launch_bf3<KS, TM, WM, WN, 8, 8, 4, DA, 2>(d, s, a, gb, nimg, cps);
+        } else {
+            if (d.Wout > 16) return launch_bf3<KS, TM, WM, WN, 4, 32, 1, DA, 2>(d, s, a, gb, nimg, cps);
+            if (d.Wout > 8) return launch_bf3<KS, TM, WM, WN, 8, 16, 1, DA, 2>(d, s, a, gb, nimg, cps);
+            return launch_bf3<KS, TM, WM, WN, 8, 8, 2, DA, 2>(d, s, a, gb, nimg, cps);
+        }
+    } else
     if constexpr (BN == 512 && KS == 1) {
         return IVLN_E_UNSUPPORTED;  // (four staged chunks of 512 pixels do not fit the LDS)
     } else if constexpr (BN == 512) {
@@ -1419,6 +1473,19 @@ int launch_bf3_ks(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a
         case 4: return launch_bf3_px<KS, 1, 2, 2, DA1>(d, s, a, gb, nimg, cps);   // 64 x 128, 4 waves: several workgroups per CU
         case 5: return launch_bf3_px<KS, 2, 2, 2, DA2>(d, s, a, gb, nimg, cps);   // 128 x 128, 4 waves
         default: return launch_bf3_px<KS, 1, 1, 4, DA1>(d, s, a, gb, nimg, cps);  // 32 x 256, 4 waves: two workgroups per CU
+    }
+}
+
+
+// stride-2 3x3 (k_conv_bf3<..., ST = 2>): the tiles whose four phase planes fit the LDS
+int launch_bf3_s2(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a, int64_t gb, int nimg, int cfg, int cps) {
+    switch (cfg) {
+        case 2: return launch_bf3_px<3, 1, 2, 4, 3, 2>(d, s, a, gb, nimg, cps);   // 64 x 256
+        case 3: return launch_bf3_px<3, 2, 2, 4, 3, 2>(d, s, a, gb, nimg, cps);   // 128 x 256
+        case 4: return launch_bf3_px<3, 1, 2, 2, 3, 2>(d, s, a, gb, nimg, cps);   // 64 x 128
+        case 5: return launch_bf3_px<3, 2, 2, 2, 3, 2>(d, s, a, gb, nimg, cps);   // 128 x 128
+        case 6: return launch_bf3_px<3, 1, 1, 4, 3, 2>(d, s, a, gb, nimg, cps);   // 32 x 256
+        default: return IVLN_E_UNSUPPORTED;
     }
 }
 
@@ -1796,9 +1863,15 @@ int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
     if (KS == 1) {  // 1x1, stride 1 or 2, no padding
         if ((d.stride != 1 && d.stride != 2) || d.pad != 0 || d.Hout != (d.Hin - 1) / d.stride + 1 || d.Wout != (d.Win - 1) / d.stride + 1 || d.M < 64)
             return IVLN_E_UNSUPPORTED;
+    } else if (KS == 3 && d.stride == 2) {  // stride-2 3x3 (pad 1, even input): the tiled kernel's phase-plane staging
+        static const bool s2_off = getenv("IVLN_BF3_S2") && getenv("IVLN_BF3_S2")[0] == '0';  // A/B switch
+        if ((s2_off && !force) || d.pad != 1 || d.Hin != 2 * d.Hout || d.Win != 2 * d.Wout || d.Cin % CB != 0 || d.fuse_A_split || d.stat_partials ||
+            d.img_run_flags)
+            return IVLN_E_UNSUPPORTED;
     } else if (d.stride != 1 || d.pad != KS / 2 || d.Hout != d.Hin || d.Wout != d.Win) {
         return IVLN_E_UNSUPPORTED;
     }
+    const bool s2 = KS == 3 && d.stride == 2;
     if (d.K != d.Cin * KS * KS || d.HoWo != d.Hout * d.Wout || d.N % d.HoWo != 0) return IVLN_E_UNSUPPORTED;
     if (d.defer_epilogue || d.splits > 1 || (d.Wout & 3) || d.Wout < 8 || (((uintptr_t)d.D | (uintptr_t)d.residual | (uintptr_t)d.ws) & 15))
         return IVLN_E_UNSUPPORTED;
@@ -1826,7 +1899,7 @@ int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
     }
     // pixel-starved deep 3x3 convs: K split over the waves of a workgroup, no slabs (k_conv_bf3_ks); IVLN_BF3_KS=0 | 1 = never | wherever eligible
     static const int ks_env = getenv("IVLN_BF3_KS") ? atoi(getenv("IVLN_BF3_KS")) : -1;
-    if (KS == 3 && ov < 20 && (ks_env != 0 || ins3) && d.splits <= 1) {
+    if (KS == 3 && !s2 && ov < 20 && (ks_env != 0 || ins3) && d.splits <= 1) {
         const int rc = bf3_ks_launch(d, s, nimg, (ks_env == 1 || ins3) ? 1 : 0, ov == 14 ? 1 : (ov == 15 ? 2 : 0));
         if (rc != IVLN_E_UNSUPPORTED || ins3) {
             if (rc == IVLN_OK) g_bf3_flops += 2.0 * d.M * (double)d.N * d.K, ++g_bf3_launches, ++g_bf3_kind[1];
@@ -1851,7 +1924,7 @@ int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
     // the widest tile that fills the chip on its own; else the 4-wave tiles (two or three workgroups per CU) with the channel
     // chunks split over blockIdx.z (raw slabs reduced by k_splitk_epilogue, like the fp32 kernels)
     int cfg = -1, splits = 1;
-    const bool big_ok = !(KS == 7 && d.Wout <= 8);  // (7x7 on 8x8 maps: eight images of 14 x 14 patch pixels do not fit)
+    const bool big_ok = !(KS == 7 && d.Wout <= 8) && !s2;  // (7x7 on 8x8 maps: eight images of 14 x 14 patch pixels do not fit; stride 2: 128- / 256-pixel tiles only)
     // (4-wave tiles, measured on RedNet's 3x3 shapes at 8 + 8 stacked images against the fp32 kernels: 128 x 128 wins from
     //  2 M outputs - 57 vs 64 us on 128 x 16384, 50 vs 67 on 256 x 4096 and 512 x 1024 -, 64 x 128 below - 41 vs 46 on
     //  128 x 8192, 37.5 vs 44 on 256 x 2048 and 512 x 512; 64-channel convs that need them lose - 42 vs 38 us on 64 x 32768)
@@ -1908,6 +1981,7 @@ int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
     const int BN = kBf3BN[cfg];
     const int64_t gb = d.a_split_grp_stride * 4;
     const int rc = KS == 7   ? launch_bf3_ks<7>(d, s, (const unsigned char*)d.A_split, gb, nimg, cfg, cps)
+                   : s2      ? launch_bf3_s2(d, s, (const unsigned char*)d.A_split, gb, nimg, cfg, cps)
                    : KS == 3 ? launch_bf3_ks<3>(d, s, (const unsigned char*)d.A_split, gb, nimg, cfg, cps)
                              : launch_bf3_ks<1>(d, s, (const unsigned char*)d.A_split, gb, nimg, cfg, cps);
     if (rc == IVLN_OK) g_bf3_flops += 2.0 * d.M * (double)d.N * d.K, ++g_bf3_launches, ++g_bf3_kind[0];

@@ -362,6 +362,7 @@ SPLIT_BF16_WGRAD = os.environ.get("IVLN_SPLIT_BF16_WGRAD", "1") != "0"
 SPLIT_BF16_1X1 = int(os.environ.get("IVLN_SPLIT_BF16_1X1", "-1"))  # -1: by measured rule (ops.conv2d), 0 never, 1 always
 BF3_1X1_KS = os.environ.get("IVLN_BF3_1X1_KS", "1") != "0"  # A/B: 0 = deep-K 1x1 convs stay on the fp32 GEMM kernels
 BF3_CONVT = os.environ.get("IVLN_BF3_CONVT", "1") != "0"  # A/B: 0 = stride-2 3x3 transposed convs stay on the fp32 direct kernel
+BF3_S2 = os.environ.get("IVLN_BF3_S2", "1") != "0"  # A/B: 0 = stride-2 3x3 convs stay on the fp32 direct kernel
 S2_GATHER = os.environ.get("IVLN_S2_GATHER", "1") != "0"  # A/B: 0 = stride-2 1x1 convs read their input strided (tiled 1x1 form)
 SPLIT_BF16_MIN_OUT = 1 << 18  # output elements below which nothing is packed
 _stat_ws = {}
@@ -454,7 +455,9 @@ def conv2d(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, 
                 d.a_packed_grp_stride = pk.numel() // max(G, 1)
         # same-size stride-1 convs over enough pixels: both operands as three bf16 pieces on the bf16 MFMA pipe
         # (csrc/conv_bf3.hip; the C side decides per shape and falls back to the fp32 MFMA kernels)
-        if (SPLIT_BF16 and stride == 1 and pad == KH // 2 and Wo % 4 == 0 and Wo >= 8 and w.is_contiguous() and not defer
+        # ... and (round 6) RedNet's stride-2 3x3 convs: the same kernel with its patch staged as four phase planes
+        s2_ok = stride == 2 and KH == 3 and BF3_S2 and H % 2 == 0 and W % 4 == 0 and Cin % 16 == 0
+        if (SPLIT_BF16 and (stride == 1 or s2_ok) and pad == KH // 2 and Wo % 4 == 0 and Wo >= 8 and w.is_contiguous() and not defer
                 and (N * Ho * Wo * Cout >= SPLIT_BF16_MIN_OUT or TILE_OVERRIDE >= 9)):
             sp = packed_conv_weights(w, cache=not weight_is_temp, split=True)
             if sp is not None:

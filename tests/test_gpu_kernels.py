@@ -402,6 +402,74 @@ def test_conv2d_split_bf16_kernel(N, Cin, H, W, Cout, k):
     assert float(wide_k[:, :4].abs().max()) == 0.0 and float(wide_k[:, 4 + Cout:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("N,Cin,H,W,Cout,G", [(16, 128, 64, 64, 128, 2), (16, 256, 32, 32, 256, 2), (16, 512, 16, 16, 512, 2), (3, 48, 24, 40, 40, 0),
+                                              (2, 32, 16, 16, 24, 0)])
+def test_conv2d_stride2_3x3_on_the_split_bf16_kernel(N, Cin, H, W, Cout, G):
+    """RedNet's stride-2 3x3 convs (the entry blocks of layers 2-4, rednet.py:84-110, image-grouped over the stacked encoders)
+    on the tiled split-bf16 kernel with its patch staged as four phase planes (k_conv_bf3<..., ST = 2>): against the float64
+    conv with the folded BatchNorm + ReLU epilogue, 3e-6 of the largest output and at or below twice the fp32 direct kernel's
+    error; every tile that fits (tile_override 22-26), with and without channel chunks split over blockIdx.z; reproducible;
+    output written into a channel slice of a wider tensor; and the default dispatch takes this kernel at RedNet's sizes."""
+    import ctypes as C
+
+    from ivln_ce_amd import ops
+    from ivln_ce_amd._lib import lib
+
+    g = torch.Generator().manual_seed(N + Cin + Cout)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    ws = [torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5 for _ in range(max(G, 1))]
+    sc, sh = torch.rand(max(G, 1) * Cout, generator=g) + 0.5, torch.randn(max(G, 1) * Cout, generator=g)
+    per = N // max(G, 1)
+    ref0 = torch.cat([F.conv2d(x[i * per:(i + 1) * per].double(), ws[i].double(), stride=2, padding=1) for i in range(max(G, 1))])
+    ref = torch.cat([F.relu(ref0[i * per:(i + 1) * per] * sc[i * Cout:(i + 1) * Cout].double().view(1, -1, 1, 1)
+                            + sh[i * Cout:(i + 1) * Cout].double().view(1, -1, 1, 1)) for i in range(max(G, 1))])
+    w = (torch.stack(ws) if G else ws[0]).contiguous().to(DEV)
+    xd, scd, shd = x.to(DEV), sc.to(DEV), sh.to(DEV)
+    L = lib()
+    L.ivln_conv_split_counters.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]
+
+    def run(override, **kw):
+        L.ivln_conv_split_counters(None, None, 1)
+        ops.TILE_OVERRIDE = override
+        try:
+            y = ops.conv2d(xd, w, stride=2, pad=1, **kw)
+        finally:
+            ops.TILE_OVERRIDE = 0
+        n = C.c_longlong(0)
+        L.ivln_conv_split_counters(None, C.byref(n), 0)
+        return y, n.value
+
+    scale0, scale = float(ref0.abs().max()), float(ref.abs().max())
+    fp32, n0 = run(6, splitk=False)
+    assert n0 == 0
+    e_fp32 = float((fp32.double().cpu() - ref0).abs().max()) / scale0
+    plain, n1 = run(9, splitk=False)
+    assert n1 == 1, "the split-bf16 kernel declined a shape it is built for"
+    e = float((plain.double().cpu() - ref0).abs().max()) / scale0
+    assert e <= 3e-6 and e <= 2.0 * e_fp32 + 1e-6, (e, e_fp32)
+    assert torch.equal(plain, run(9, splitk=False)[0])
+    full, _ = run(9, scale=scd, shift=shd, relu=True)  # (with a workspace on hand small grids split their channel chunks)
+    assert float((full.double().cpu() - ref).abs().max()) <= 3e-6 * scale
+    for ov in (22, 23, 24, 25, 26):
+        if (ov in (23, 25) and Cout < 128) or (G and N // G * (H // 2) * (W // 2) % (256 if ov in (22, 23, 26) else 128)):
+            continue
+        try:
+            y, n = run(ov, scale=scd, shift=shd, relu=True, splitk=False)
+        except Exception:  # noqa: BLE001 - a tile whose planes do not fit is declined (IVLN_E_UNSUPPORTED under an insisting override)
+            continue
+        assert n == 1 and float((y.double().cpu() - ref).abs().max()) <= 3e-6 * scale, ov
+    wide = torch.zeros(N, Cout + 8, H // 2, W // 2, device=DEV)
+    ops.TILE_OVERRIDE = 9
+    try:
+        ops.conv2d(xd, w, stride=2, pad=1, out=wide[:, 4:], out_ctot=Cout + 8, splitk=False)
+    finally:
+        ops.TILE_OVERRIDE = 0
+    assert torch.equal(wide[:, 4:4 + Cout], plain) and float(wide[:, :4].abs().max()) == 0.0 and float(wide[:, 4 + Cout:].abs().max()) == 0.0
+    if N == 16:  # RedNet's own shapes: what the default dispatch launches
+        dflt, n3 = run(0, scale=scd, shift=shd, relu=True)
+        assert n3 == 1 and float((dflt.double().cpu() - ref).abs().max()) <= 3e-6 * scale
+
+
 @pytest.mark.parametrize("N,Cin,Cout,H,W,form", [(2, 64, 64, 32, 32, 13), (2, 256, 64, 16, 16, 13), (2, 512, 128, 8, 16, 12), (1, 1024, 256, 8, 8, 12),
                                                  (3, 80, 40, 4, 8, 13)])
 def test_conv1x1_split_bf16_residual_behind_the_relu(N, Cin, Cout, H, W, form):

@@ -36,6 +36,7 @@ CASES = [
     ("IVLN_BF3_1X1_KS", "0", FULLSIZE),                   # stride-1 1x1 convs without the register-built forms
     ("IVLN_BF3_FUSE", "0", FULLSIZE),                     # bottleneck tails as two launches
     ("IVLN_BF3_CONVT", "0", FULLSIZE),                    # stride-2 3x3 transposed convs on the fp32 direct kernel
+    ("IVLN_BF3_S2", "0", FULLSIZE),                       # stride-2 3x3 convs on the fp32 direct kernel
     ("IVLN_S2_GATHER", "0", FULLSIZE),                    # stride-2 1x1 convs read their input strided
     ("IVLN_REDNET_SKIP_ADD", "0", FULLSIZE),              # the decoder's skip adds as launches of their own
     ("IVLN_CONVT_STACK", "0", ROLLOUT),                   # transposed convs as four launches per parity class
