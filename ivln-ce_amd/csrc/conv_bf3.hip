@@ -1174,6 +1174,41 @@ __global__ __launch_bounds__(WT ? 256 : 512, 2) void k_conv1x1_bf3_ks(const ivln
 #ifdef BF3_TIMING
     const unsigned long long ts2 = lane == 0 ? wall_clock64() : 0ull;
 #endif
+    // IVLN_D_NCHW_UP2X4 (the 2 x 2 stride-2 upsampling branches and the final deconv, rednet.py:239-245, 217-218: one tap per
+    // parity class): rows 4 c + 2 a (b = 0) and + 1 (b = 1) are registers r and r + 1 of one lane, its four pixels of a class-grid
+    // row are eight consecutive floats of output row 2 ho + a - two 16-byte stores per register pair, plain stores (no
+    // scalar-offset buffer stores here: nothing for the store guard to do).
+    const bool up = p.dmode == DMODE_NCHW_UP2X4;  // (uniform)
+    if (WT && up) {
+        const int n = n0 + 4 * l31;
+        if (n < p.N) {
+            const int img = n / HW, pp = n - img * HW;
+            const int ho = pp / p.Wout, wo = pp - ho * p.Wout;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const int m = m0 + 4 * half + (r & 3) + 8 * (r >> 2);  // row of b = 0; + 1 is b = 1 (M % 4 == 0: in or out together)
+                if (m >= p.M) continue;
+                const int co = m >> 2, a = (m >> 1) & 1;
+                const int64_t addr = (((int64_t)img * p.Ctot + co) * (2 * p.Hout) + 2 * ho + a) * (2 * p.Wout) + 2 * wo;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[2 * e] = acc[e][r], v[2 * e + 1] = acc[e][r + 1];
+                const float sc = p.scale ? p.scale[co] : 1.f, sh = p.shift ? p.shift[co] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = p.scale ? fmaf(v[e], sc, sh) : v[e] + sh;
+                if (p.residual) {
+                    const float4 r0 = *reinterpret_cast<const float4*>(p.residual + addr), r1 = *reinterpret_cast<const float4*>(p.residual + addr + 4);
+                    v[0] += r0.x, v[1] += r0.y, v[2] += r0.z, v[3] += r0.w, v[4] += r1.x, v[5] += r1.y, v[6] += r1.z, v[7] += r1.w;
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                *reinterpret_cast<float4*>(p.D + addr) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(p.D + addr + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+        }
+    } else
     if constexpr (WT) {
         const int n = n0 + 4 * l31;
         const int img = min(n, p.N - 1) / HW, pp = n - img * HW;
@@ -1214,6 +1249,48 @@ __global__ __launch_bounds__(WT ? 256 : 512, 2) void k_conv1x1_bf3_ks(const ivln
             o[0] = __float_as_int(v.x), o[1] = __float_as_int(v.y), o[2] = __float_as_int(v.z), o[3] = __float_as_int(v.w);
             __builtin_amdgcn_raw_buffer_store_b128(o, rD, cs < mrem ? (int)off0 : (int)OOB, cs * HW * 4, 0);
             BF3_STORE_GUARD();
+        }
+    } else if (up) {
+        // the eight waves' partial tiles meet in LDS as below; an item = (channel of the tile, a, pixel pair): rows 4 c + 2 a and + 1
+        // at two horizontally adjacent class-grid pixels = four consecutive floats of output row 2 ho + a
+        float* const red = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                red[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * LDT + tn * 32 + l31] = acc[tn][r];
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int item = t + it * 512, r = item >> 6, j = item & 63;  // 16 (channel, a) x 64 pixel pairs
+            const int ml = 2 * r, nl = 2 * j, n = n0 + nl;
+            const int e0 = nl & 3, q = nl >> 2;  // tile e, column q holds pixel 4 q + e
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {  // fixed order
+                const float* r0 = red + (w * 32 + ml) * LDT + q;
+                const float* r1 = r0 + LDT;
+                v.x += r0[e0 * 32], v.y += r1[e0 * 32], v.z += r0[(e0 + 1) * 32], v.w += r1[(e0 + 1) * 32];
+            }
+            if (m0 + ml < p.M && n < p.N) {
+                const int img = n / HW, pp = n - img * HW;
+                const int ho = pp / p.Wout, wo = pp - ho * p.Wout;
+                const int co = (m0 + ml) >> 2, a = r & 1;
+                const int64_t addr = (((int64_t)img * p.Ctot + co) * (2 * p.Hout) + 2 * ho + a) * (2 * p.Wout) + 2 * wo;
+                if (p.scale) {
+                    const float sc = p.scale[co], sh = p.shift[co];
+                    v.x = fmaf(v.x, sc, sh), v.y = fmaf(v.y, sc, sh), v.z = fmaf(v.z, sc, sh), v.w = fmaf(v.w, sc, sh);
+                } else if (p.shift) {
+                    const float sh = p.shift[co];
+                    v.x += sh, v.y += sh, v.z += sh, v.w += sh;
+                }
+                if (p.residual) {
+                    const float4 rr = *reinterpret_cast<const float4*>(p.residual + addr);
+                    v.x += rr.x, v.y += rr.y, v.z += rr.z, v.w += rr.w;
+                }
+                if (p.relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+                *reinterpret_cast<float4*>(p.D + addr) = v;
+            }
         }
     } else {
     constexpr int ITEMS = 2;  // 32 channels x 32 pixel quads = 1024 items over the workgroup's 512 threads
@@ -1807,7 +1884,20 @@ int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
     if (!d.A_split || (disabled && !force)) return IVLN_E_UNSUPPORTED;
     const int KS = d.bmode == BMODE_CONV1X1 ? 1 : conv_ks(d.bmode);
     if ((KS != 1 && KS != 2 && KS != 3 && KS != 7) || d.amode != AMODE_MK || d.dil != 1) return IVLN_E_UNSUPPORTED;
-    if (d.dmode != (KS == 2 ? DMODE_NCHW_UP2X4 : DMODE_NCHW)) return IVLN_E_UNSUPPORTED;  // (the 2 x 2 window only as the stacked transposed-conv classes)
+    // (the 2 x 2 window only as the stacked transposed-conv classes; a 1x1 conv may store them too: the 2 x 2 stride-2 upsampling convs)
+    const bool up1 = KS == 1 && d.dmode == DMODE_NCHW_UP2X4;
+    if (!up1 && d.dmode != (KS == 2 ? DMODE_NCHW_UP2X4 : DMODE_NCHW)) return IVLN_E_UNSUPPORTED;
+    if (up1) {  // stacked one-tap classes: the register-built stride-1 1x1 kernels with their 2 x 2-block epilogue, or nothing
+        static const bool convt_off1 = getenv("IVLN_BF3_CONVT") && getenv("IVLN_BF3_CONVT")[0] == '0';
+        if ((convt_off1 && !force) || (d.M & 3) || d.Ctot * 4 != d.M || d.grp_imgs > 0 || d.accumulate || d.residual_after_relu || d.defer_epilogue ||
+            d.splits > 1 || d.stat_partials || d.img_run_flags || d.fuse_A_split || (d.Wout & 3) || d.stride != 1 || d.pad != 0 || d.Hout != d.Hin ||
+            d.Wout != d.Win || d.K != d.Cin || d.HoWo != d.Hout * d.Wout || d.N % d.HoWo != 0)
+            return IVLN_E_UNSUPPORTED;
+        const int ovu = d.tile_override;
+        const int rc = bf3_1x1_ks_launch(d, s, (force || ovu == 11 || ovu == 12 || ovu == 13) ? 1 : 0, ovu == 12 ? 0 : (ovu == 13 ? 1 : -1));
+        if (rc == IVLN_OK) g_bf3_flops += 2.0 * d.M * (double)d.N * d.K, ++g_bf3_launches, ++g_bf3_kind[d.Cin / CB <= 16 ? 3 : 2];
+        return rc;
+    }
     // algorithmic FLOPs of a launch: the stacked classes multiply their common window's zero padding too (ivln_gemm_desc.real_taps)
     const double flops_of = 2.0 * d.M * (double)d.N * d.K * (KS == 2 && d.real_taps > 0 ? d.real_taps / 16.0 : 1.0);
     if (KS == 2) {

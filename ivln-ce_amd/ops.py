@@ -656,6 +656,14 @@ def conv_transpose2d_s2(x, classes, scale=None, shift=None, residual=None, relu=
         d.sDm, d.sDn = a, b
         if ta == 1 and tb == 1:
             d.bmode = B_CONV1X1
+            # the stacked one-tap classes of a 2 x 2 stride-2 transposed conv (RedNet's upsampling branches and final deconv) on the
+            # register-built split-bf16 1x1 kernels, which store the 2 x 2 output blocks themselves (csrc/conv_bf3.hip)
+            if (w is stacked and SPLIT_BF16 and BF3_CONVT and BF3_1X1_KS and Cin >= 64 and Cin % 16 == 0 and W % 4 == 0 and w.is_contiguous()
+                    and (N * H * W * w.shape[0] >= SPLIT_BF16_MIN_OUT or TILE_OVERRIDE >= 9)):
+                sp = packed_conv_weights(w, split=True)
+                if sp is not None:
+                    d.A_split = dptr(sp)
+                    d.a_split_grp_stride = sp.numel()
         elif ta == 2 and tb == 2:  # the 2x2 window: LDS-staged direct kernel, no tap tables (csrc/conv_direct.hip)
             d.bmode = B_CONV_K2
             if PACK_WEIGHTS and w.is_contiguous():

@@ -1124,6 +1124,54 @@ def test_conv_transpose2d_stride2_stacked_classes_on_the_split_bf16_kernels(N, C
         assert n3 == 1 and float((dflt.double().cpu() - ref).abs().max()) / scale <= 3e-6, (n3, k3)
 
 
+@pytest.mark.parametrize("N,Cin,H,Cout,form", [(8, 512, 8, 256, 12), (8, 256, 16, 128, 13), (8, 128, 32, 64, 13), (8, 64, 64, 64, 13), (8, 64, 128, 13, 13),
+                                                (3, 96, 8, 20, 13), (2, 512, 16, 24, 12)])
+def test_conv_transpose2d_2x2_stride2_on_the_split_bf16_1x1_kernels(N, Cin, H, Cout, form):
+    """RedNet's 2 x 2 stride-2 transposed convs (the four upsampling branches and the final 64 -> 13 deconv, rednet.py:239-245,
+    217-218) as the stacked one-tap classes on the register-built split-bf16 1x1 kernels, which store the 2 x 2 output blocks
+    themselves (k_conv1x1_bf3_ks: both forms, tile_override 12 = K split over the waves, 13 = wave tiles).  Against the
+    float64 transposed conv with scale / shift / residual / ReLU: 3e-6 of the largest output, at or below twice the fp32
+    kernel's error; reproducible."""
+    import ctypes as C
+
+    from ivln_ce_amd import ops
+    from ivln_ce_amd._lib import lib
+
+    g = torch.Generator().manual_seed(N + Cin + Cout + form)
+    x = torch.randn(N, Cin, H, H, generator=g)
+    w = torch.randn(Cin, Cout, 2, 2, generator=g) / Cin ** 0.5
+    sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    ref = F.conv_transpose2d(x.double(), w.double(), None, stride=2)
+    res = torch.randn(ref.shape, generator=g)
+    ref = F.relu(ref * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1) + res.double())
+    cls = ops.convt_s2_classes(w.to(DEV), 0)
+    stacked = ops.convt_s2_stack(cls)
+    args = dict(scale=sc.to(DEV), shift=sh.to(DEV), residual=res.to(DEV), relu=True, stacked=stacked)
+    L = lib()
+    L.ivln_conv_split_counters.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]
+
+    def run(override):
+        L.ivln_conv_split_counters(None, None, 1)
+        ops.TILE_OVERRIDE = override
+        try:
+            y = ops.conv_transpose2d_s2(x.to(DEV), cls, **args)
+        finally:
+            ops.TILE_OVERRIDE = 0
+        n = C.c_longlong(0)
+        L.ivln_conv_split_counters(None, C.byref(n), 0)
+        return y, n.value
+
+    scale = float(ref.abs().max())
+    fp32, n0 = run(7)  # the float4-staged fp32 GEMM
+    assert n0 == 0
+    e_fp32 = float((fp32.double().cpu() - ref).abs().max()) / scale
+    got, n1 = run(form)
+    assert n1 == 1
+    e = float((got.double().cpu() - ref).abs().max()) / scale
+    assert e <= 3e-6 and e <= 2.0 * e_fp32 + 1e-6, (e, e_fp32)
+    assert torch.equal(got, run(form)[0])
+
+
 @pytest.mark.parametrize("N,Cin,H,W,Cout,k,p,op", [(2, 64, 8, 8, 32, 3, 1, 1), (3, 32, 16, 12, 13, 2, 0, 0),
                                                    (2, 16, 5, 7, 8, 3, 1, 1), (1, 128, 32, 32, 64, 3, 1, 1)])
 def test_conv_transpose2d_stride2_parity_classes(N, Cin, H, W, Cout, k, p, op):
