@@ -859,7 +859,8 @@ def test_conv2d_split_bf16_refuses_what_it_is_not_built_for():
     from ivln_ce_amd._lib import IvlnError
 
     x = torch.randn(8, 32, 32, 32, device=DEV)
-    for w, kw in [(torch.randn(32, 32, 3, 3, device=DEV), dict(stride=2, pad=1)),       # strided
+    for w, kw in [(torch.randn(32, 32, 7, 7, device=DEV), dict(stride=2, pad=3)),       # strided 7x7 (stride 2 exists for 3x3 only: round 6)
+                  (torch.randn(32, 32, 3, 3, device=DEV), dict(stride=2, pad=0)),         # stride-2 3x3 without its padding
                   (torch.randn(32, 32, 3, 3, device=DEV), dict(pad=0)),                   # not same-size
                   (torch.randn(32, 32, 1, 1, device=DEV), dict(pad=0)),                   # 1x1 into 32 channels (below its 64-channel tiles)
                   (torch.randn(32, 32, 5, 5, device=DEV), dict(pad=2))]:                  # 5x5
