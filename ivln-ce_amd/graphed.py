@@ -292,8 +292,7 @@ class GraphedRollout:
         # (the side graph cut in two - its first part beside RedNet's early stages, the second beside its late ones, pausing
         #  during the pixel-starved middle - was built and measured in round 6: gB1 ends at 3453-3462 us against 3408, whatever
         #  the two cut points (profiles/r06_split_probe_twopart.txt): the loss follows the side launches, not the stage they run
-        #  beside.  Removed; the replay below still handles any number of tagged cuts.)
-        self._dd_cut, self._late_stage = None, None
+        #  beside.  Removed.)
         # the depth encoder's stream: the critical chain of the gt-semantics step wins dispatch when both queues are ready
         # (priority -1; beside RedNet, where it is not critical, the priority made no difference: profiles/r06_split_probe_start.txt)
         self.sA = _stream(dev, "depth", priority=-1)
@@ -358,18 +357,17 @@ class GraphedRollout:
             a_tags = []
 
             def hook_a(name, ca=ca):
-                if (name == "mapper_begin" and self._prefix and not a_tags) or (name == self._dd_cut and "dd" not in a_tags):
-                    a_tags.append("pre" if name == "mapper_begin" else "dd")
+                if name == "mapper_begin" and not a_tags:
+                    a_tags.append("pre")
                     ca.cut()
-            prev_hook, _rednet.STAGE_HOOK = _rednet.STAGE_HOOK, (hook_a if (self._prefix or self._dd_cut) else None)
+            prev_hook, _rednet.STAGE_HOOK = _rednet.STAGE_HOOK, (hook_a if self._prefix else None)
             try:
                 run_A()
             finally:
                 _rednet.STAGE_HOOK = prev_hook
-        # [mapper prefix | depth encoder part 1 | part 2 (+ instruction encoder)]: a_tags names the boundary behind each piece but the last
+        # [mapper prefix | depth encoder (+ instruction encoder)], or the one graph: a_tags names the boundary behind each piece but the last
         self.gA_parts, self._a_tags = list(ca.graphs), a_tags
         self.gA = self.gA_parts[-1]
-        self.ev_late = torch.cuda.Event()
         self._dep = net._stash_dep  # (depth features, k/v) live in gA's pool
         self._txt = getattr(net, "_stash_txt", None)  # (predicted semantics: the instruction features too)
         # the previous action (read by the embedding in gB1) ping-pongs with the state: one gB1 per phase
@@ -383,9 +381,6 @@ class GraphedRollout:
                     if name == self._cut_stage and "mid" not in b_tags:
                         b_tags.append("mid")
                         cc.cut()
-                    elif name == self._late_stage and "dd" in self._a_tags and "late" not in b_tags and "mid" in b_tags:
-                        b_tags.append("late")
-                        cc.cut()  # (the side graph's second part is released here)
                     elif name == "labels" and self._prefix and "labels" not in b_tags and "mid" in b_tags:
                         b_tags.append("labels")
                         cc.cut()  # (the mapper's second half starts here: the replay waits for the prefix's event in between)
@@ -420,42 +415,33 @@ class GraphedRollout:
         pieces = self.gB1[self.phase]
         b_tags = getattr(self, "_b_tags", []) if len(pieces) > 1 else []
         a_parts, a_tags = self.gA_parts, self._a_tags
-        ai = 0  # next piece of the side graph
 
-        def side(upto_tag, wait_ev):
-            """replay the side pieces up to (and including) the one whose boundary is `upto_tag` (None: all the rest)"""
-            nonlocal ai
+        def side(wait_ev):
+            """the side graph's pieces behind `wait_ev`; the event behind the mapper's prefix is recorded where it ends"""
             self.sA.wait_event(wait_ev)
             with torch.cuda.stream(self.sA):
-                if mark and ai == 0:
+                if mark:
                     mark("gA_start", self.sA)
-                while ai < len(a_parts):
-                    a_parts[ai].replay()
-                    tag = a_tags[ai] if ai < len(a_tags) else None
-                    ai += 1
-                    if tag == "pre":
+                for i, g in enumerate(a_parts):
+                    g.replay()
+                    if i < len(a_tags) and a_tags[i] == "pre":
                         self.ev_pre.record(self.sA)
-                    if tag is not None and tag == upto_tag:
-                        return
                 if mark:
                     mark("gA_end", self.sA)
                 self.ev_A.record(self.sA)
 
         if not b_tags:  # one main graph: the side graph starts with the step
             self.ev_in.record(main)
-            side(None, self.ev_in)
+            side(self.ev_in)
             if "pre" in a_tags:  # (a mapper prefix in the side graph but no cut in the main one: it has to be over first)
                 main.wait_event(self.ev_pre)
             pieces[-1].replay()
         else:
             for i, g in enumerate(pieces):
                 tag = b_tags[i - 1] if i > 0 else None  # the boundary in FRONT of this piece
-                if tag == "mid":      # ... released here: the side graph (its first part when it is cut in two)
+                if tag == "mid":      # ... released here: the side graph
                     self.ev_mid.record(main)
-                    side("dd" if "late" in b_tags else None, self.ev_mid)
-                elif tag == "late":   # ... its second part
-                    self.ev_late.record(main)
-                    side(None, self.ev_late)
+                    side(self.ev_mid)
                 elif tag == "labels":  # the mapper's second half waits for its first (the side graph's head)
                     main.wait_event(self.ev_pre)
                 g.replay()
