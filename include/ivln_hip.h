@@ -250,6 +250,14 @@ int ivln_gemm_f32(const ivln_gemm_desc* desc, void* stream);
  * ivln_conv_split_words(M, Cin, KS) 4-byte words (0: KS is not 1, 3 or 7). */
 int64_t ivln_conv_split_words(int M, int Cin, int KS);
 int ivln_conv_split_weights_f32(const float* W, int M, int Cin, int KS, void* out, void* stream);
+/* RedNet's stems (rednet.py:201-210: conv1 3 -> 64 and conv1_d 1 -> 64, 7x7, stride 2, pad 3; forward rednet.py:190-199):
+ * weights (M, Cin, 7, 7) fp32, Cin 1 or 3 -> the split-bf16 image with K laid out as kernel rows x 8 columns that
+ * ivln_gemm_desc.A_split must hold for a 7x7 stride-2 conv (ivln_conv_stem_split_words(M, Cin) 4-byte words; 0: not a stem).
+ * With it ivln_gemm_f32 runs such a conv - Hin = 2 Hout, Win = 2 Wout, Wout a multiple of 128, no image groups - on
+ * k_conv7s2_bf3 (csrc/conv_bf3.hip), residual in front of or behind the ReLU (residual_after_relu: the depth stem's output added
+ * to the RGB stem's); other shapes fall through to the fp32 kernels, which ignore A_split. */
+int64_t ivln_conv_stem_split_words(int M, int Cin);
+int ivln_conv_stem_split_weights_f32(const float* W, int M, int Cin, void* out, void* stream);
 /* Tally of the convs ivln_gemm_f32 sent to the split-bf16 kernel since the last reset: algorithmic FLOPs (2 M N K) and
  * launches (host side, at enqueue; measurement aid of bench.py - a captured graph's replays are not counted). */
 int ivln_conv_split_counters(double* flops, long long* launches, int reset);

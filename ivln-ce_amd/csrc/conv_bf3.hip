@@ -1057,6 +1057,8 @@ __global__ __launch_bounds__(WT ? 256 : 512, 2) void k_conv1x1_bf3_ks(const ivln
     // PIXELS.  A 1x1 conv's activation tile (128 pixels x Cin x 4 bytes: 512 KB at 1024 channels) outweighs a channel tile's
     // weights (196 KB), and with the pixel tile as the fast index every XCD fetched every activation: 8 x the input bytes
     // over the fabric, which is what bounded the first version (256 x 4096 x 1024: 134 MB in 23 us).
+    // (WT: the workgroup's four waves own four pixel tiles of ONE channel tile - they stream the same weights; four channel tiles of
+    //  one pixel tile, i.e. shared activations, measured 38 us per RedNet step slower: profiles/r06_predsem_ab_wtshare.txt)
     const int n0 = WT ? (bid.y * NW + wave) * BN : bid.y * BN, m0 = bid.x * 32;
     const int nch = p.Cin / CB;
     const int HW = p.HoWo;
@@ -1850,6 +1852,197 @@ extern "C" int ivln_conv_split_weights_f32(const float* W, int M, int Cin, int K
     return hipGetLastError() == hipSuccess ? IVLN_OK : IVLN_E_HIP;
 }
 
+namespace {
+// ------------------------------------------------------------------------------------------------------------------
+// RedNet's stems (rednet.py:201-210, 190-199: conv1 3 -> 64 and conv1_d 1 -> 64; 7x7, stride 2, pad 3) on the same arithmetic.
+// Three or one input channels leave the 16-channel chunks of the kernels above 81 / 94 % empty, so K is laid out the other
+// way round: a K step of 16 = TWO kernel rows (channel c, row kh) x 8 columns (kw = 0 .. 6 and a zero) - 11 steps for the 21
+// rows of the RGB stem, 4 for the 7 of the depth stem (one zero row each).  NO LDS and no barrier anywhere:
+//   * a wave owns 32 output channels x 128 consecutive pixels of ONE output row; as in the 1x1 kernels tile e holds pixel
+//     4 l31 + e in column l31, so register r of the four accumulators is a float4 of the output row;
+//   * lane (l31, half) needs, for its kernel row of the step, input columns 2 (4 l31 + e) - 3 + kw: the 14 consecutive floats
+//     8 l31 - 3 .. 8 l31 + 10 of input row 2 ho - 3 + kh, read as FOUR aligned 16-byte loads (8 l31 - 4 ..); rows and column
+//     groups outside the image are out-of-range buffer offsets, i.e. zeros - the padding costs nothing;
+//   * element pairs (2 t + 1, 2 t + 2), t = 0 .. 6, are split into the three bf16 pieces once (v_cvt_pk_bf16_f32 leaves the
+//     word the fragment wants); tile e's B fragment is pairs e .. e + 3 - every register index static;
+//   * weights: the image of ivln_conv_stem_split_weights_f32 - [32-channel tile][step][piece][lane] x 8 bf16, lane (l31, half)
+//     holding W[32 mt + l31][row 2 s + half][kw 0 .. 6], 0 - global -> registers two steps ahead;
+//   * epilogue: the 1x1 wave-tile kernel's (scale / shift, residual in front of or BEHIND the ReLU - the depth stem's output
+//     added to the RGB stem's, rednet.py:196 -, 16-byte stores).
+// ------------------------------------------------------------------------------------------------------------------
+template <int CIN>
+__global__ __launch_bounds__(256, 2) void k_conv7s2_bf3(const ivln_gemm_desc p, const unsigned char* a_split, int segs, int items) {
+    constexpr int Q = CIN * 7, S = (Q + 1) / 2, TN = 4;
+    constexpr unsigned OOB = 0x80000000u;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const BlockId bid = xcd_block_id(p.no_xcd_remap);
+    const int item = bid.x * 4 + wave;  // (channel tile, row segment, output row, image), channel tile fastest: a workgroup shares its input rows
+    if (item >= items) return;
+    const int mtiles = (p.M + 31) / 32;
+    const int mt = item % mtiles;
+    int rest = item / mtiles;
+    const int seg = rest % segs;
+    rest /= segs;
+    const int ho = rest % p.Hout, img = rest / p.Hout;
+    const int m0 = mt * 32;
+    const int H = p.Hin, W = p.Win, HW = p.HoWo;
+    const int b = 256 * seg + 8 * l31;  // input column of the lane's first pixel (2 * (128 seg + 4 l31))
+    const bool in0 = b >= 4, in3 = b + 8 < W;
+    const __amdgpu_buffer_rsrc_t rB = bf3_rsrc(p.B);
+    const __amdgpu_buffer_rsrc_t rA = bf3_rsrc(a_split + (int64_t)mt * S * 3072);
+    const int64_t img_off = (int64_t)img * p.in_img_stride + b - 4;
+    auto load_x = [&](int s, v4i (&xb)[4]) {
+        const int q = 2 * s + half;  // this half's kernel row (channel c, row kh) of step s
+        const int c = q / 7, kh = q - 7 * c;
+        const int hi = 2 * ho - 3 + kh;
+        const bool ok = q < Q && (unsigned)hi < (unsigned)H;
+        const unsigned off = (unsigned)((img_off + ((int64_t)c * H + hi) * W) * 4);
+        const unsigned o12 = ok ? off : OOB, o0 = ok && in0 ? off : OOB, o3 = ok && in3 ? off : OOB;
+        xb[0] = __builtin_amdgcn_raw_buffer_load_b128(rB, (int)o0, 0, 0);
+        xb[1] = __builtin_amdgcn_raw_buffer_load_b128(rB, (int)(o12 + 16u), 0, 0);
+        xb[2] = __builtin_amdgcn_raw_buffer_load_b128(rB, (int)(o12 + 32u), 0, 0);
+        xb[3] = __builtin_amdgcn_raw_buffer_load_b128(rB, (int)(o3 + 48u), 0, 0);
+    };
+    auto load_a = [&](int s, v4i (&ab)[3]) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) ab[pl] = __builtin_amdgcn_raw_buffer_load_b128(rA, (s * 3 + pl) * 1024 + lane * 16, 0, 0);
+    };
+    f32x16 acc[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[tn][i] = 0.f;
+    {
+        v4i xb[3][4], ab[3][3];
+        load_a(0, ab[0]);
+        load_x(0, xb[0]);
+        if (S > 1) load_a(1, ab[1]), load_x(1, xb[1]);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            if (s + 2 < S) load_a(s + 2, ab[(s + 2) % 3]), load_x(s + 2, xb[(s + 2) % 3]);  // two steps ahead
+            uint32_t Hh[7], Mm[7], Ll[7];
+#pragma unroll
+            for (int u = 0; u < 7; ++u) {
+                const int i0 = 2 * u + 1, i1 = 2 * u + 2;
+                split3_pair(__int_as_float(xb[s % 3][i0 >> 2][i0 & 3]), __int_as_float(xb[s % 3][i1 >> 2][i1 & 3]), Hh[u], Mm[u], Ll[u]);
+            }
+            v4i bq[TN][3];
+#pragma unroll
+            for (int e = 0; e < TN; ++e)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bq[e][0][i] = (int)Hh[e + i], bq[e][1][i] = (int)Mm[e + i], bq[e][2][i] = (int)Ll[e + i];
+            bf16x8 a[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) a[pl] = __builtin_bit_cast(bf16x8, ab[s % 3][pl]);
+#define IVLN_BF3_PROD(PA, PB)                            \
+    _Pragma("unroll") for (int tn = 0; tn < TN; ++tn)    \
+        acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA], __builtin_bit_cast(bf16x8, bq[tn][PB]), acc[tn], 0, 0, 0)
+            IVLN_BF3_PROD(0, 2);
+            IVLN_BF3_PROD(1, 1);
+            IVLN_BF3_PROD(2, 0);
+            IVLN_BF3_PROD(0, 1);
+            IVLN_BF3_PROD(1, 0);
+            IVLN_BF3_PROD(0, 0);
+#undef IVLN_BF3_PROD
+        }
+    }
+    // ---- epilogue (the wave-tile 1x1 kernel's): register r of the four tiles = channel (r & 3) + 8 (r >> 2) + 4 half at pixels
+    // 4 l31 .. + 3; operands requested first, straight-line code between the stores (BF3_STORE_GUARD) ----
+    const int pp = ho * p.Wout + 128 * seg + 4 * l31;
+    const int mrem = p.M - m0 - 4 * half;
+    const int me0 = m0 + 4 * half;
+    const unsigned off0 = (unsigned)(((img * p.Ctot + m0 + 4 * half) * HW + pp) * 4);
+    const __amdgpu_buffer_rsrc_t rR = bf3_rsrc(p.residual), rS = bf3_rsrc(p.scale), rH = bf3_rsrc(p.shift), rD = bf3_rsrc(p.D);
+    const bool has_res = p.residual != nullptr, has_sc = p.scale != nullptr, has_sh = p.shift != nullptr;
+    const float relu_lo = p.relu ? 0.f : -__builtin_huge_valf();
+    const bool res_post = p.residual_after_relu != 0;
+    v4i rres[16];
+    float esc[16], esh[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int cs = (r & 3) + 8 * (r >> 2);
+        const bool ok = cs < mrem;
+        esc[r] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rS, ok && has_sc ? me0 * 4 : (int)OOB, cs * 4, 0));
+        esh[r] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rH, ok && has_sh ? me0 * 4 : (int)OOB, cs * 4, 0));
+        rres[r] = __builtin_amdgcn_raw_buffer_load_b128(rR, ok && has_res ? (int)off0 : (int)OOB, cs * HW * 4, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int cs = (r & 3) + 8 * (r >> 2);
+        float4 v = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+        const float sc = has_sc ? esc[r] : 1.f, sh = esh[r];
+        v.x = fmaf(v.x, sc, sh), v.y = fmaf(v.y, sc, sh), v.z = fmaf(v.z, sc, sh), v.w = fmaf(v.w, sc, sh);
+        const float r0 = __int_as_float(rres[r][0]), r1 = __int_as_float(rres[r][1]), r2 = __int_as_float(rres[r][2]), r3 = __int_as_float(rres[r][3]);
+        v.x += res_post ? 0.f : r0, v.y += res_post ? 0.f : r1, v.z += res_post ? 0.f : r2, v.w += res_post ? 0.f : r3;
+        const float lo = relu_lo;
+        v.x = fmaxf(v.x, lo), v.y = fmaxf(v.y, lo), v.z = fmaxf(v.z, lo), v.w = fmaxf(v.w, lo);
+        v.x += res_post ? r0 : 0.f, v.y += res_post ? r1 : 0.f, v.z += res_post ? r2 : 0.f, v.w += res_post ? r3 : 0.f;
+        v4i o;
+        o[0] = __float_as_int(v.x), o[1] = __float_as_int(v.y), o[2] = __float_as_int(v.z), o[3] = __float_as_int(v.w);
+        __builtin_amdgcn_raw_buffer_store_b128(o, rD, cs < mrem ? (int)off0 : (int)OOB, cs * HW * 4, 0);
+        BF3_STORE_GUARD();
+    }
+}
+
+// [32-channel tile][step][piece][lane] x 8 bf16 of the stem kernel above: lane (l31, half), element j = W[32 mt + l31][c][kh][j] with
+// (c, kh) = kernel row 2 step + half, zero for j = 7 and rows past the last
+__global__ __launch_bounds__(256) void k_conv7s2_pack(const float* __restrict__ W, int M, int Cin, uint16_t* __restrict__ out, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int S = (Cin * 7 + 1) / 2;
+    const int j = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+    int64_t q = idx >> 9;
+    const int pl = (int)(q % 3);
+    q /= 3;
+    const int st = (int)(q % S);
+    const int mt = (int)(q / S);
+    const int m = mt * 32 + (lane & 31), row = 2 * st + (lane >> 5);
+    const float v = (m < M && row < Cin * 7 && j < 7) ? W[((int64_t)m * Cin * 7 + row) * 7 + j] : 0.f;
+    uint32_t h, mm, l;
+    split3(v, h, mm, l);
+    out[idx] = (uint16_t)(pl == 0 ? h : (pl == 1 ? mm : l));
+}
+
+}  // namespace
+
+extern "C" int64_t ivln_conv_stem_split_words(int M, int Cin) {
+    if (M <= 0 || (Cin != 1 && Cin != 3)) return 0;
+    return (int64_t)((M + 31) / 32) * ((Cin * 7 + 1) / 2) * (3 * 1024 / 4);
+}
+
+extern "C" int ivln_conv_stem_split_weights_f32(const float* W, int M, int Cin, void* out, void* stream) {
+    const int64_t words = ivln_conv_stem_split_words(M, Cin);
+    if (!W || !out || words <= 0) return IVLN_E_INVALID;
+    const int64_t total = words * 2;
+    hipLaunchKernelGGL(k_conv7s2_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, M, Cin, (uint16_t*)out, total);
+    return hipGetLastError() == hipSuccess ? IVLN_OK : IVLN_E_HIP;
+}
+
+namespace {
+// The stems' launcher: 7x7, stride 2, pad 3, one or three input channels, output rows of whole 128-pixel segments
+int bf3_stem_launch(ivln_gemm_desc& d, hipStream_t s) {
+    if ((d.Cin != 1 && d.Cin != 3) || d.pad != 3 || d.dil != 1 || d.Hin != 2 * d.Hout || d.Win != 2 * d.Wout || d.Wout % 128 != 0 ||
+        d.K != d.Cin * 49 || d.HoWo != d.Hout * d.Wout || d.N % d.HoWo != 0 || d.dmode != DMODE_NCHW || d.amode != AMODE_MK)
+        return IVLN_E_UNSUPPORTED;
+    if (d.grp_imgs > 0 || d.accumulate || d.defer_epilogue || d.splits > 1 || d.stat_partials || d.img_run_flags || d.fuse_A_split)
+        return IVLN_E_UNSUPPORTED;
+    if ((d.in_img_stride & 3) || ((((uintptr_t)d.B) | ((uintptr_t)d.D) | ((uintptr_t)d.residual)) & 15)) return IVLN_E_UNSUPPORTED;
+    const int64_t nimg = d.N / d.HoWo;
+    if (nimg * d.in_img_stride * 4 >= (int64_t)1 << 31 || nimg * d.Ctot * d.HoWo * 4 >= (int64_t)1 << 31) return IVLN_E_UNSUPPORTED;  // byte offsets of the buffer accesses
+    const int segs = d.Wout / 128;
+    const int64_t items = nimg * d.Hout * segs * ((d.M + 31) / 32);
+    if (items >= (int64_t)1 << 30) return IVLN_E_UNSUPPORTED;
+    d.splits = 1;
+    const dim3 grid((unsigned)((items + 3) / 4));
+    const unsigned char* a = (const unsigned char*)d.A_split;
+    if (d.Cin == 3) IVLN_LAUNCH_FAMILY(k_conv7s2_bf3<3>, grid, dim3(256), 0, s, d, a, segs, (int)items);
+    else IVLN_LAUNCH_FAMILY(k_conv7s2_bf3<1>, grid, dim3(256), 0, s, d, a, segs, (int)items);
+    return IVLN_OK;
+}
+}  // namespace
+
 // Eligibility + tile choice.  IVLN_E_UNSUPPORTED sends the caller to the fp32 MFMA kernels.
 // What went through this kernel since the last reset: algorithmic FLOPs (2 M N K of the convs it took) and launches -
 // bench.py prices them against the bf16 peak / 6 instead of the fp32 MFMA peak.  Host-side tally, not thread-safe.
@@ -1884,6 +2077,12 @@ int ivln_conv_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
     if (!d.A_split || (disabled && !force)) return IVLN_E_UNSUPPORTED;
     const int KS = d.bmode == BMODE_CONV1X1 ? 1 : conv_ks(d.bmode);
     if ((KS != 1 && KS != 2 && KS != 3 && KS != 7) || d.amode != AMODE_MK || d.dil != 1) return IVLN_E_UNSUPPORTED;
+    if (KS == 7 && d.stride == 2) {  // RedNet's stems: A_split is the image of ivln_conv_stem_split_weights_f32 (the caller's contract)
+        const int rc = bf3_stem_launch(d, s);
+        if (rc == IVLN_OK) g_bf3_flops += 2.0 * d.M * (double)d.N * d.K, ++g_bf3_launches, ++g_bf3_kind[0];
+        if (rc == IVLN_OK && d.stat_tiles) *d.stat_tiles = 0;
+        return rc;
+    }
     // (the 2 x 2 window only as the stacked transposed-conv classes; a 1x1 conv may store them too: the 2 x 2 stride-2 upsampling convs)
     const bool up1 = KS == 1 && d.dmode == DMODE_NCHW_UP2X4;
     if (!up1 && d.dmode != (KS == 2 ? DMODE_NCHW_UP2X4 : DMODE_NCHW)) return IVLN_E_UNSUPPORTED;

@@ -438,7 +438,8 @@ int launch_tile(const ivln_gemm_desc& d, hipStream_t s) {
 namespace {
 // every kernel that launches through IVLN_LAUNCH_FAMILY: the definition of "the MFMA family" (ivln_family_kernel_names)
 const char* const kFamilyKernels[] = {"k_gemm",     "k_gemm_vec",    "k_conv_direct",    "k_wgrad_direct", "k_conv1x1_stream", "k_conv_bf3",
-                                      "k_conv_bf3_ks", "k_conv1x1_bf3_ks", "k_wgrad_bf3", "k_gn_conv",      "k_nconv",          "k_depth_net"};
+                                      "k_conv_bf3_ks", "k_conv1x1_bf3_ks", "k_conv7s2_bf3", "k_wgrad_bf3",    "k_gn_conv",        "k_nconv",
+                                      "k_depth_net"};
 constexpr int kFamilyCount = (int)(sizeof(kFamilyKernels) / sizeof(kFamilyKernels[0]));
 std::vector<hipEvent_t> g_timing_events;
 std::vector<int> g_timing_kernel;  // per timed launch: index into kFamilyKernels, kFamilyCount = a name outside the list

@@ -283,7 +283,14 @@ def packed_conv_weights(w, cache=True, split=False):
     L.ivln_conv_split_words.restype = i64
     L.ivln_conv_split_words.argtypes = [i32, i32, i32]
     L.ivln_conv_split_weights_f32.argtypes = [vp, i32, i32, i32, vp, vp]
-    n1 = L.ivln_conv_split_words(Cout, Cin, KH) if split else L.ivln_conv_packed_floats(Cout, Cin, KH)
+    L.ivln_conv_stem_split_words.restype = i64
+    L.ivln_conv_stem_split_words.argtypes = [i32, i32]
+    L.ivln_conv_stem_split_weights_f32.argtypes = [vp, i32, i32, vp, vp]
+    stem = split == "stem"  # (7x7 stride-2 convs of 1 or 3 channels: K as kernel rows x 8 columns, k_conv7s2_bf3)
+    if stem:
+        n1 = L.ivln_conv_stem_split_words(Cout, Cin) if (G == 1 and KH == 7 and KW == 7) else 0
+    else:
+        n1 = L.ivln_conv_split_words(Cout, Cin, KH) if split else L.ivln_conv_packed_floats(Cout, Cin, KH)
     if n1 <= 0:
         return None
     n = n1 * G
@@ -292,6 +299,9 @@ def packed_conv_weights(w, cache=True, split=False):
                    else (L.ivln_conv_pack_weights_f32, "ivln_conv_pack_weights_f32"))
 
     def _pack(dst):
+        if stem:
+            check(L.ivln_conv_stem_split_weights_f32(w.data_ptr(), Cout, Cin, dst.data_ptr(), stream_ptr()), "ivln_conv_stem_split_weights_f32")
+            return
         for g in range(G):
             check(fn(w.data_ptr() + 4 * g * wsz, Cout, Cin, KH, dst.data_ptr() + 4 * g * n1, stream_ptr()), fn_name)
 
@@ -299,7 +309,7 @@ def packed_conv_weights(w, cache=True, split=False):
         out = torch.empty(n, dtype=torch.float32, device=w.device)
         _pack(out)
         return out
-    key = (w.data_ptr(), tuple(w.shape), bool(split))
+    key = (w.data_ptr(), tuple(w.shape), split)
     stamp = (w._version, WEIGHT_EPOCH)
     cur = torch.cuda.current_stream()
     hit = _packed.get(key)
@@ -363,6 +373,7 @@ SPLIT_BF16_1X1 = int(os.environ.get("IVLN_SPLIT_BF16_1X1", "-1"))  # -1: by meas
 BF3_1X1_KS = os.environ.get("IVLN_BF3_1X1_KS", "1") != "0"  # A/B: 0 = deep-K 1x1 convs stay on the fp32 GEMM kernels
 BF3_CONVT = os.environ.get("IVLN_BF3_CONVT", "1") != "0"  # A/B: 0 = stride-2 3x3 transposed convs stay on the fp32 direct kernel
 BF3_S2 = os.environ.get("IVLN_BF3_S2", "1") != "0"  # A/B: 0 = stride-2 3x3 convs stay on the fp32 direct kernel
+BF3_STEM = os.environ.get("IVLN_BF3_STEM", "1") != "0"  # A/B: 0 = RedNet's 7x7 stride-2 stems stay on the fp32 direct kernel (+ the fusion add as a launch)
 S2_GATHER = os.environ.get("IVLN_S2_GATHER", "1") != "0"  # A/B: 0 = stride-2 1x1 convs read their input strided (tiled 1x1 form)
 SPLIT_BF16_MIN_OUT = 1 << 18  # output elements below which nothing is packed
 _stat_ws = {}
@@ -457,7 +468,16 @@ def conv2d(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, 
         # (csrc/conv_bf3.hip; the C side decides per shape and falls back to the fp32 MFMA kernels)
         # ... and (round 6) RedNet's stride-2 3x3 convs: the same kernel with its patch staged as four phase planes
         s2_ok = stride == 2 and KH == 3 and BF3_S2 and H % 2 == 0 and W % 4 == 0 and Cin % 16 == 0
-        if (SPLIT_BF16 and (stride == 1 or s2_ok) and pad == KH // 2 and Wo % 4 == 0 and Wo >= 8 and w.is_contiguous() and not defer
+        # ... and RedNet's stems (7x7, stride 2, 3 | 1 channels, rednet.py:201-210): K as kernel rows x 8 columns, fragments built in
+        # registers from four 16-byte loads per lane and kernel row (k_conv7s2_bf3) - the only kernel that reads THIS weight image
+        stem_ok = (BF3_STEM and SPLIT_BF16 and stride == 2 and KH == 7 and pad == 3 and Cin in (1, 3) and not G and H == 2 * Ho
+                   and W == 2 * Wo and Wo % 128 == 0 and w.is_contiguous() and not defer and not TILE_OVERRIDE and stats is None
+                   and run_flags is None)
+        if stem_ok:
+            sp = packed_conv_weights(w, cache=not weight_is_temp, split="stem")
+            if sp is not None:
+                d.A_split = dptr(sp)
+        if (not stem_ok and SPLIT_BF16 and (stride == 1 or s2_ok) and pad == KH // 2 and Wo % 4 == 0 and Wo >= 8 and w.is_contiguous() and not defer
                 and (N * Ho * Wo * Cout >= SPLIT_BF16_MIN_OUT or TILE_OVERRIDE >= 9)):
             sp = packed_conv_weights(w, cache=not weight_is_temp, split=True)
             if sp is not None:

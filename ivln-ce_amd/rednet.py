@@ -302,10 +302,15 @@ class RedNet(nn.Module):
             B = rgb.shape[0]
             S = torch.empty((2 * B, 64, rgb.shape[2] // 2, rgb.shape[3] // 2), dtype=torch.float32, device=rgb.device)
             s, b = f.bn(self.bn1)
-            ops.conv2d(rgb, self.conv1.weight, stride=2, pad=3, scale=s, shift=b, relu=True, out=S[:B])
-            s, b = f.bn(self.bn1_d)
-            ops.conv2d(depth, self.conv1_d.weight, stride=2, pad=3, scale=s, shift=b, relu=True, out=S[B:])
-            fuse0 = ops.add(S[:B], S[B:], out=S[:B])
+            sd, bd = f.bn(self.bn1_d)
+            ops.conv2d(depth, self.conv1_d.weight, stride=2, pad=3, scale=sd, shift=bd, relu=True, out=S[B:])
+            # fuse0 = relu(bn1(conv1(rgb))) + the depth stem's output (rednet.py:196): added behind the RGB stem's ReLU in its own
+            # epilogue where the library has the stem kernel (256 x 256 inputs), else conv + add
+            fuse0 = ops.conv2d(rgb, self.conv1.weight, stride=2, pad=3, scale=s, shift=b, relu=True, out=S[:B], residual=S[B:],
+                               residual_after_relu=True) if ops.BF3_STEM else None
+            if fuse0 is None:
+                ops.conv2d(rgb, self.conv1.weight, stride=2, pad=3, scale=s, shift=b, relu=True, out=S[:B])
+                fuse0 = ops.add(S[:B], S[B:], out=S[:B])
             P = ops.pool2d(S, 3, 2, 1, "max")
             fuses = []
             _stage_done("stem")

@@ -402,6 +402,75 @@ def test_conv2d_split_bf16_kernel(N, Cin, H, W, Cout, k):
     assert float(wide_k[:, :4].abs().max()) == 0.0 and float(wide_k[:, 4 + Cout:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("N,Cin,H,W,Cout", [(8, 3, 256, 256, 64), (8, 1, 256, 256, 64), (2, 3, 12, 512, 48), (3, 1, 6, 256, 72), (1, 3, 2, 256, 32)])
+def test_conv2d_7x7_stride2_stems_on_the_split_bf16_kernel(N, Cin, H, W, Cout):
+    """RedNet's stems (rednet.py:201-210, 190-199: 7x7, stride 2, pad 3, 3 | 1 -> 64 channels on 256 x 256 inputs) on
+    k_conv7s2_bf3 (K as kernel rows x 8 columns, fragments built in registers): against the float64 conv, 3e-6 of the largest
+    output and at or below twice the fp32 direct kernel's error; the folded BatchNorm + ReLU epilogue with the residual in front
+    of and BEHIND the ReLU (the stems' fusion add); ragged channel counts, two row segments, maps of one output row; reproducible;
+    a channel slice of a wider tensor as the destination and a strided input batch; other widths go to the fp32 kernel."""
+    import ctypes as C
+
+    from ivln_ce_amd import ops
+    from ivln_ce_amd._lib import lib
+
+    g = torch.Generator().manual_seed(N + Cin + Cout + H)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 7, 7, generator=g) / (Cin * 49) ** 0.5
+    sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    res = torch.randn(N, Cout, H // 2, W // 2, generator=g)
+    ref0 = F.conv2d(x.double(), w.double(), stride=2, padding=3)
+    aff = ref0 * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
+    xd, wd, scd, shd, resd = x.to(DEV), w.to(DEV), sc.to(DEV), sh.to(DEV), res.to(DEV)
+    L = lib()
+    L.ivln_conv_split_counters.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]
+
+    def run(stem, xin=None, **kw):
+        L.ivln_conv_split_counters(None, None, 1)
+        old = ops.BF3_STEM
+        ops.BF3_STEM = stem
+        try:
+            y = ops.conv2d(xd if xin is None else xin, wd, stride=2, pad=3, **kw)
+        finally:
+            ops.BF3_STEM = old
+        n = C.c_longlong(0)
+        L.ivln_conv_split_counters(None, C.byref(n), 0)
+        return y, n.value
+
+    scale0 = float(ref0.abs().max())
+    fp32, n0 = run(False)
+    assert n0 == 0
+    e_fp32 = float((fp32.double().cpu() - ref0).abs().max()) / scale0
+    plain, n1 = run(True)
+    assert n1 == 1, "the stem kernel declined a shape it is built for"
+    e = float((plain.double().cpu() - ref0).abs().max()) / scale0
+    assert e <= 3e-6 and e <= 2.0 * e_fp32 + 1e-6, (e, e_fp32)
+    assert torch.equal(plain, run(True)[0])
+    for name, kw, want in (("bn+relu", dict(scale=scd, shift=shd, relu=True), F.relu(aff)),
+                           ("residual, relu", dict(scale=scd, shift=shd, relu=True, residual=resd), F.relu(aff + res.double())),
+                           ("relu, residual behind it", dict(scale=scd, shift=shd, relu=True, residual=resd, residual_after_relu=True),
+                            F.relu(aff) + res.double()),
+                           ("shift only", dict(shift=shd), ref0 + sh.double().view(1, -1, 1, 1))):
+        y, n = run(True, **kw)
+        assert y is not None and n == 1, name
+        assert float((y.double().cpu() - want).abs().max()) <= 3e-6 * float(want.abs().max()), name
+    # destination = a channel slice of a wider tensor, input = every second image of a longer batch (in_img_stride)
+    wide = torch.full((N, Cout + 8, H // 2, W // 2), 7.0, device=DEV)
+    y, n = run(True, scale=scd, shift=shd, relu=True, out=wide[:, 4:4 + Cout], out_ctot=Cout + 8)
+    assert n == 1 and float((wide[:, 4:4 + Cout].double().cpu() - F.relu(aff)).abs().max()) <= 3e-6 * float(aff.abs().max())
+    assert bool((wide[:, :4] == 7.0).all()) and bool((wide[:, 4 + Cout:] == 7.0).all())
+    x2 = torch.randn(2 * N, Cin, H, W, generator=g).to(DEV)
+    x2[::2] = xd
+    y, n = run(True, xin=x2[::2], in_img_stride=2 * Cin * H * W)
+    assert n == 1 and torch.equal(y, plain)
+    # a width the kernel is not built for: the fp32 direct kernel, same numbers as ever
+    xs = xd[..., : W - 32].contiguous()
+    ys, ns = run(True, xin=xs)
+    assert ns == 0
+    refs = F.conv2d(xs.double().cpu(), w.double(), stride=2, padding=3)
+    assert float((ys.double().cpu() - refs).abs().max()) <= 3e-6 * float(refs.abs().max())
+
+
 @pytest.mark.parametrize("N,Cin,H,W,Cout,G", [(16, 128, 64, 64, 128, 2), (16, 256, 32, 32, 256, 2), (16, 512, 16, 16, 512, 2), (3, 48, 24, 40, 40, 0),
                                               (2, 32, 16, 16, 24, 0)])
 def test_conv2d_stride2_3x3_on_the_split_bf16_kernel(N, Cin, H, W, Cout, G):

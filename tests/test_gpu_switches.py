@@ -38,6 +38,7 @@ CASES = [
     ("IVLN_BF3_CONVT", "0", FULLSIZE),                    # stride-2 3x3 transposed convs on the fp32 direct kernel
     ("IVLN_BF3_S2", "0", FULLSIZE),                       # stride-2 3x3 convs on the fp32 direct kernel
     ("IVLN_S2_GATHER", "0", FULLSIZE),                    # stride-2 1x1 convs read their input strided
+    ("IVLN_BF3_STEM", "0", FULLSIZE),                     # RedNet's 7x7 stems on the fp32 direct kernel, their fusion add a launch
     ("IVLN_REDNET_SKIP_ADD", "0", FULLSIZE),              # the decoder's skip adds as launches of their own
     ("IVLN_CONVT_STACK", "0", ROLLOUT),                   # transposed convs as four launches per parity class
     ("IVLN_REDNET_PLAN", "0", ROLLOUT),                   # RedNet's launches walked from Python

@@ -6,7 +6,7 @@ k_conv1x1_bf3_ks was missed by a prefix list)."""
 import re
 
 FAMILY_KERNELS = ("k_gemm", "k_gemm_vec", "k_conv_direct", "k_wgrad_direct", "k_conv1x1_stream", "k_conv_bf3",
-                  "k_conv_bf3_ks", "k_conv1x1_bf3_ks", "k_wgrad_bf3", "k_gn_conv", "k_nconv", "k_depth_net")
+                  "k_conv_bf3_ks", "k_conv1x1_bf3_ks", "k_conv7s2_bf3", "k_wgrad_bf3", "k_gn_conv", "k_nconv", "k_depth_net")
 MAPPER_KERNELS = ("k_local_minmax", "k_local_argmax", "k_local_select", "k_world_max", "k_world_select", "k_finalize",
                   "k_frames", "k_swap_counts")
 
