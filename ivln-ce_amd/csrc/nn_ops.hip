@@ -1395,6 +1395,28 @@ __global__ __launch_bounds__(256) void k_rgb_resize_normalize(const uint8_t* __r
     out[idx] = (v - mean[c]) / stdv[c];
 }
 
+// ... frames that already have the network's size (the 256 x 256 RGB-D of the rollout): the bilinear weights are exactly 1 and 0,
+// so a value is (u8 / 255 - mean) / std - the same operations in the same order, i.e. the general kernel's bits.  A thread
+// takes four pixels of a row: three 4-byte loads, one 16-byte store per channel plane.
+__global__ __launch_bounds__(256) void k_rgb_normalize_x4(const uint8_t* __restrict__ rgb, int64_t quads, int HW, float* __restrict__ out) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= quads) return;
+    const int64_t pix = q * 4, b = pix / HW, pp = pix - b * HW;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(rgb + pix * 3);
+    const uint32_t w0 = src[0], w1 = src[1], w2 = src[2];
+    const uint8_t by[12] = {(uint8_t)w0, (uint8_t)(w0 >> 8), (uint8_t)(w0 >> 16), (uint8_t)(w0 >> 24), (uint8_t)w1, (uint8_t)(w1 >> 8),
+                            (uint8_t)(w1 >> 16), (uint8_t)(w1 >> 24), (uint8_t)w2, (uint8_t)(w2 >> 8), (uint8_t)(w2 >> 16), (uint8_t)(w2 >> 24)};
+    const float mean[3] = {0.485f, 0.456f, 0.406f};
+    const float stdv[3] = {0.229f, 0.224f, 0.225f};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = ((float)by[3 * e + c] / 255.0f - mean[c]) / stdv[c];
+        *reinterpret_cast<float4*>(out + (b * 3 + c) * HW + pp) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_affine(const float* __restrict__ x, float* __restrict__ y, int64_t n,
                                                 float sub, float div) {
     int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1832,6 +1854,11 @@ int ivln_argmax_channels_u8(const float* x, int N, int C, int HW, uint8_t* out, 
 
 int ivln_rgb_resize_normalize_f32(const uint8_t* rgb, int B, int Hi, int Wi, int Ho, int Wo, float* out,
                                   void* stream) {
+    if (Hi == Ho && Wi == Wo && ((int64_t)Ho * Wo) % 4 == 0 && !((uintptr_t)rgb & 3) && !((uintptr_t)out & 15)) {
+        const int64_t quads = (int64_t)B * Ho * Wo / 4;
+        hipLaunchKernelGGL(k_rgb_normalize_x4, dim3(nblk(quads)), dim3(256), 0, (hipStream_t)stream, rgb, quads, Ho * Wo, out);
+        return LAUNCH_OK();
+    }
     hipLaunchKernelGGL(k_rgb_resize_normalize, dim3(nblk((int64_t)B * 3 * Ho * Wo)), dim3(256), 0,
                        (hipStream_t)stream, rgb, B, Hi, Wi, Ho, Wo, out);
     return LAUNCH_OK();

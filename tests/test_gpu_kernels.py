@@ -1681,3 +1681,30 @@ def test_batchnorm_statistics_from_the_conv_epilogue_match_the_pass_over_its_out
         _close(r[3], (1.0 / torch.sqrt(ref_var + 1e-5)).float(), 1e-4)
     for a, b in zip(res[0], res[1]):  # scale, shift, saved mean / rstd, running mean / var
         _close(a, b, 1e-5)
+
+
+@pytest.mark.parametrize("B,H,W", [(8, 256, 256), (2, 6, 10), (1, 2, 2)])
+def test_rgb_normalize_at_the_networks_size_is_the_resize_kernels_bits(B, H, W):
+    """RedNet's input prep (mapper.py:715-736, 788-793) on frames that already have the network's size: the bilinear weights
+    are exactly 1 and 0, so ivln_rgb_resize_normalize_f32 takes a four-pixels-per-thread kernel (k_rgb_normalize_x4) - against
+    the general kernel on the same frames (forced by a destination that is not 16-byte aligned) bit for bit, and against
+    (u8 / 255 - mean) / std in torch."""
+    import ctypes as C
+
+    from ivln_ce_amd import ops
+    from ivln_ce_amd._lib import lib
+
+    g = torch.Generator().manual_seed(B + H)
+    rgb = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8).to(DEV)
+    fast = ops.rgb_resize_normalize(rgb, H, W)
+    L = lib()
+    buf = torch.zeros(B * 3 * H * W + 4, dtype=torch.float32, device=DEV)
+    rc = L.ivln_rgb_resize_normalize_f32(C.c_void_p(rgb.data_ptr()), B, H, W, H, W, C.c_void_p(buf.data_ptr() + 4), C.c_void_p(ops.stream_ptr()))
+    assert rc == 0
+    torch.cuda.synchronize()
+    general = buf[1:1 + B * 3 * H * W].view(B, 3, H, W)
+    assert torch.equal(fast, general)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    want = (rgb.cpu().permute(0, 3, 1, 2).float() / 255.0 - mean) / std
+    assert float((fast.cpu() - want).abs().max()) <= 1e-6
