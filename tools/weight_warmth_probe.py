@@ -1,5 +1,5 @@
 """RedNet's deep pixel-starved conv launches with their weights L2-warm (one set, back to back), memory-side-cache-warm (8 sets in
-rotation) and HBM-cold (48 sets): what prefetching the next layer's weights could buy (profiles/r06_weight_warmth_probe.txt).
+rotation) and HBM-cold (48 sets): what prefetching the next layer's weights could buy (profiles/r06_weight_warmth_probe.txt)."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
