@@ -1583,9 +1583,14 @@ int launch_bf3_s2(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a
 //     family's k_splitk_epilogue like the fp32 weight-gradient kernel's;
 //   * the next strip's dy pairs and x triples fly under the MFMA phase in registers, are split and written after the barrier.
 // ------------------------------------------------------------------------------------------------------------------
-template <int TM, int WM, int WN, int W>
-__global__ __launch_bounds__(64 * WM * WN) void k_wgrad_bf3(const ivln_gemm_desc p, int nimg, int strips_total, int strips_per_split) {
+// XE (ivln_gemm_desc.split_ok == 2: the caller's promise that every x value is exact in bf16 - the first layer's one-hot map
+// features): x is staged as ONE piece (its upper 16 bits; a value with lower bits set poisons the result with NaNs), the three
+// products against its lower pieces do not exist, the x region is a third (47 KB of LDS with dy instead of 90: two workgroups per
+// CU hide each other's strip loads and barriers) and the kernel fits three waves per SIMD.
+template <int TM, int WM, int WN, int W, bool XE = false>
+__global__ __launch_bounds__(64 * WM * WN, XE ? 3 : 1) void k_wgrad_bf3(const ivln_gemm_desc p, int nimg, int strips_total, int strips_per_split) {
     constexpr int NTB = 64 * WM * WN, TN = 2, KS = 7, KK = 49;
+    constexpr int NPX = XE ? 1 : 3;                                // pieces of x in LDS
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int IMS = W == 8 ? 2 : 1, ROWS = 128 / (W * IMS);   // a strip: IMS images x ROWS rows x W columns = 128 pixels
     constexpr int PR = ROWS + KS - 1, PRT = IMS * PR, PWP = W + KS - 1;
@@ -1593,10 +1598,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_wgrad_bf3(const ivln_gemm_desc
     constexpr int XP = (XW | 1);                                   // row pitch in words (odd)
     constexpr int NCIB = (BN + KK - 1) / KK + 1;                   // input channels a column tile can touch
     constexpr int DP = 272;                                        // bytes per (channel, piece) row of dy: 128 bf16 + 16
-    constexpr int CHB = PRT * XP * 4, PLB = NCIB * CHB, CPYB = 3 * PLB;
+    constexpr int CHB = PRT * XP * 4, PLB = NCIB * CHB, CPYB = NPX * PLB;
     constexpr int DYB = 3 * BM * DP;                               // dy region in front of the x region
     constexpr int ND = BM * 64, NDI = (ND + NTB - 1) / NTB, NX = NCIB * PRT * XW, NXI = (NX + NTB - 1) / NTB;
-    constexpr bool HAS_LITE = TM == 1;  // (the 32-channel layer: the one whose x is the one-hot map features)
+    constexpr bool HAS_LITE = TM == 1 && !XE;  // (the 32-channel layer: the one whose x is the one-hot map features)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const xS = smem + DYB;
 
@@ -1687,6 +1692,19 @@ __global__ __launch_bounds__(64 * WM * WN) void k_wgrad_bf3(const ivln_gemm_desc
                 *reinterpret_cast<uint32_t*>(d + 2 * BM * DP) = L;
             }
         }
+        if constexpr (XE) {
+#pragma unroll
+            for (int i = 0; i < NXI; ++i) {  // exact values: the upper halves ARE the first pieces, the lower halves must be zero
+                const uint32_t u0 = __float_as_uint(xv[i][0]), u1 = __float_as_uint(xv[i][1]), u2 = __float_as_uint(xv[i][2]);
+                nzx |= (u0 | u1 | u2) & 0xFFFFu;
+                unsigned char* d = xS + xdst[i];
+                if (xdst[i] >= 0) {
+                    *reinterpret_cast<uint32_t*>(d) = (u0 >> 16) | (u1 & 0xFFFF0000u);         // pair (2j, 2j+1)
+                    *reinterpret_cast<uint32_t*>(d + CPYB) = (u1 >> 16) | (u2 & 0xFFFF0000u);  // pair (2j+1, 2j+2)
+                }
+            }
+            return nzx;
+        }
 #pragma unroll
         for (int i = 0; i < NXI; ++i) {
             uint32_t pa0, pa1, pa2, pb0, pb1, pb2;
@@ -1720,10 +1738,12 @@ __global__ __launch_bounds__(64 * WM * WN) void k_wgrad_bf3(const ivln_gemm_desc
 #ifdef BF3_TIMING
     const unsigned long long cyc0 = clock64();
 #endif
+    uint32_t inexact = 0;  // (XE: lower bits seen in x)
     if (s_beg < s_end) load_strip(s_beg);
     for (int st = s_beg; st < s_end; ++st) {
         const unsigned long long ta = BF3_T();
         const uint32_t nzx = stage_strip();
+        if constexpr (XE) inexact |= nzx;
         // (a strip whose x patch is bf16-exact - the first layer's one-hot map features - has zero lower pieces: the products
         //  against them are not issued and their fragments not read: a third of the 4-byte LDS reads that bound this kernel)
         const bool lite = HAS_LITE ? __syncthreads_or((int)(nzx != 0)) == 0 : (__syncthreads(), false);
@@ -1774,7 +1794,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_wgrad_bf3(const ivln_gemm_desc
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        if constexpr (HAS_LITE) {
+        if constexpr (XE) {
+            ksteps(std::true_type{});
+        } else if constexpr (HAS_LITE) {
             if (lite) ksteps(std::true_type{});
             else ksteps(std::false_type{});
         } else {
@@ -1783,6 +1805,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_wgrad_bf3(const ivln_gemm_desc
         __syncthreads();
         t_mma += BF3_T() - tb;
     }
+    // XE: a broken promise must not pass for a gradient - every output of a workgroup that saw an inexact x value becomes a NaN
+    const bool poison = XE ? __syncthreads_or((int)(inexact != 0)) != 0 : false;
 #ifdef BF3_TIMING
     if (threadIdx.x == 0) {
         const int b = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) & 8191;
@@ -1805,17 +1829,17 @@ __global__ __launch_bounds__(64 * WM * WN) void k_wgrad_bf3(const ivln_gemm_desc
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + (wn * TN + tn) * 32 + l31;
                 const int m = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m < p.M && n < p.N) slab[(int64_t)m * p.N + n] = acc[tm][tn][r];
+                if (m < p.M && n < p.N) slab[(int64_t)m * p.N + n] = poison ? __builtin_nanf("") : acc[tm][tn][r];
             }
 }
 
-template <int TM, int WM, int WN, int W>
+template <int TM, int WM, int WN, int W, bool XE = false>
 int launch_wgrad_bf3(const ivln_gemm_desc& d, hipStream_t s, int nimg, int strips, int sps) {
     constexpr int BM = 32 * TM * WM, BN = 64 * WN, IMS = W == 8 ? 2 : 1, ROWS = 128 / (W * IMS);
     constexpr int PRT = IMS * (ROWS + 6), XP = ((W + 6) / 2 + 1) | 1, NCIB = (BN + 48) / 49 + 1;
-    constexpr size_t lds = (size_t)3 * BM * 272 + (size_t)6 * NCIB * PRT * XP * 4;
+    constexpr size_t lds = (size_t)3 * BM * 272 + (size_t)(XE ? 2 : 6) * NCIB * PRT * XP * 4;
     static_assert(lds <= 160 * 1024, "strip does not fit");
-    auto kern = k_wgrad_bf3<TM, WM, WN, W>;
+    auto kern = k_wgrad_bf3<TM, WM, WN, W, XE>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return IVLN_E_HIP;
@@ -2300,13 +2324,15 @@ int ivln_wgrad_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
     const int BM = d.M <= 32 ? 32 : (d.M <= 64 ? 64 : 128), BN = d.M <= 32 ? (six ? 384 : 512) : (d.M <= 64 ? 512 : 256);
     const int64_t blocks = (int64_t)((d.N + BN - 1) / BN) * ((d.M + BM - 1) / BM);
     if (!d.ws || d.ws_floats < (int64_t)d.M * d.N) return IVLN_E_UNSUPPORTED;  // (the kernel always leaves raw slabs)
+    const bool xe = d.split_ok == 2 && d.M <= 32 && d.Wout == 64;  // x promised exact in bf16 (split_ok = 2): the one-piece form
     int splits = 1;
     if (d.splits == 0) {
         if (d.ws) {
             constexpr int want_env = 0;  // tuning
             // one workgroup per CU (LDS): as many splits as keep the grid inside whole rounds of 256 (13 column tiles x 20
             // splits = 260 workgroups ran a second round for four of them)
-            const int64_t want = want_env > 0 ? want_env : ivln_cu_count();
+            // (XE: 47 KB of LDS and three waves per SIMD - two workgroups per CU)
+            const int64_t want = want_env > 0 ? want_env : (xe ? 2 : 1) * (int64_t)ivln_cu_count();
             splits = (int)(want / blocks);
             if (splits < 1) splits = 1;
             if (splits > strips) splits = strips;
@@ -2323,8 +2349,8 @@ int ivln_wgrad_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
     splits = (strips + sps - 1) / sps;
     d.splits = splits;
     int rc;
-    if (d.M <= 32 && six) rc = launch_wgrad_bf3_w<1, 1, 6>(d, s, nimg, strips, sps);
-    else if (d.M <= 32) rc = launch_wgrad_bf3_w<1, 1, 8>(d, s, nimg, strips, sps);
+    if (d.M <= 32 && six) rc = xe ? launch_wgrad_bf3<1, 1, 6, 64, true>(d, s, nimg, strips, sps) : launch_wgrad_bf3_w<1, 1, 6>(d, s, nimg, strips, sps);
+    else if (d.M <= 32) rc = xe ? launch_wgrad_bf3<1, 1, 8, 64, true>(d, s, nimg, strips, sps) : launch_wgrad_bf3_w<1, 1, 8>(d, s, nimg, strips, sps);
     else if (d.M <= 64) rc = launch_wgrad_bf3_w<2, 1, 8>(d, s, nimg, strips, sps);
     else rc = launch_wgrad_bf3_w<2, 2, 4>(d, s, nimg, strips, sps);
     if (rc == IVLN_OK) g_bf3_flops += 2.0 * d.M * (double)d.N * d.K, ++g_bf3_launches;

@@ -1938,8 +1938,13 @@ def linear_bwd_weight(dy, x, out=None, accumulate=False):
     return out
 
 
-def conv2d_bwd_weight(dy, x, KH, KW, stride=1, pad=0):
-    """dW (Cout, Cin, KH, KW) = sum over pixels dy[co][p] * im2col(x)[(ci,kh,kw)][p]."""
+WGRAD_EXACT_X = os.environ.get("IVLN_WGRAD_EXACT_X", "1") != "0"  # A/B: 0 = the one-hot first layer's weight gradient stages x as three pieces too
+
+
+def conv2d_bwd_weight(dy, x, KH, KW, stride=1, pad=0, x_exact_bf16=False):
+    """dW (Cout, Cin, KH, KW) = sum over pixels dy[co][p] * im2col(x)[(ci,kh,kw)][p].
+    x_exact_bf16: the caller's promise that every value of x is exact in bf16 (one-hot map features): the split-bf16 kernel
+    stages x as one piece (ivln_gemm_desc.split_ok = 2; a broken promise gives NaNs, not a wrong gradient)."""
     N, Cout, Ho, Wo = dy.shape
     _, Cin, H, W = x.shape
     out = torch.empty((Cout, Cin, KH, KW), dtype=torch.float32, device=dy.device)
@@ -1956,6 +1961,6 @@ def conv2d_bwd_weight(dy, x, KH, KW, stride=1, pad=0):
     _epilogue(d, None, None, None, False)
     ws = splitk_ws(dy.device)
     d.ws, d.ws_floats, d.splits = dptr(ws), ws.numel(), 0
-    d.split_ok = int(SPLIT_BF16 and SPLIT_BF16_WGRAD)
+    d.split_ok = int(SPLIT_BF16 and SPLIT_BF16_WGRAD) * (2 if (x_exact_bf16 and WGRAD_EXACT_X) else 1)
     gemm(d)
     return out

@@ -317,7 +317,8 @@ def _net_backward(net, S: Dict, d_feats: torch.Tensor) -> Dict:
                 mean, rstd = bn.running_mean, torch.rsqrt(bn.running_var + bn.eps)
             dy, dgamma, dbeta = ops.cbra_bwd(d.contiguous(), s["y"], s["scale"], s["shift"], mean, rstd, s["train"])
             G[bn.weight], G[bn.bias] = dgamma, dbeta
-            G[conv.weight] = ops.conv2d_bwd_weight(dy, s["x"], 7, 7, 1, 3)
+            # (layer 0 reads ops.map_features' output: zeros and ones - encoders.SemanticMapEncoder.generate_map_features)
+            G[conv.weight] = ops.conv2d_bwd_weight(dy, s["x"], 7, 7, 1, 3, x_exact_bf16=(i == 0))
             if s["train"]:
                 # train-mode BatchNorm: sum_{n,h,w} dy = gamma*rstd*(S1 - S1 - S2*sum(xhat)/M) and sum(xhat) = 0,
                 # so the gradient of a conv bias feeding it is identically zero (autograd in the reference

@@ -923,6 +923,49 @@ def test_conv2d_weight_gradient_split_bf16_kernel(N, Cin, H, Cout):
     assert torch.equal(got, again)
 
 
+@pytest.mark.parametrize("N,Cin,Cout", [(6, 14, 32), (64, 14, 32), (5, 9, 20)])
+def test_conv2d_weight_gradient_with_bf16_exact_input_staged_as_one_piece(N, Cin, Cout):
+    """k_wgrad_bf3<..., XE> (ivln_gemm_desc.split_ok = 2): the map CNN's first layer reads one-hot map features
+    (map_encoder.py:60-75), whose values are exact in bf16 - x is staged as its upper 16 bits alone, the kernel needs half the
+    LDS and two thirds of the registers.  Against the float64 weight gradient as close as the three-piece form (both drop only
+    products with a zero factor) and as the fp32 kernel, deterministic, forced and by default dispatch; and a value that is NOT
+    exact - the promise broken - gives NaNs, not a wrong gradient."""
+    from ivln_ce_amd import ops
+
+    g = torch.Generator().manual_seed(N + Cin + Cout)
+    x = (torch.rand(N, Cin, 64, 64, generator=g) < 0.3).float()
+    dy = torch.randn(N, Cout, 64, 64, generator=g)
+    w = torch.zeros(Cout, Cin, 7, 7, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), w, padding=3).backward(dy.double())
+    ref = w.grad
+    xd, dyd = x.to(DEV), dy.to(DEV)
+    try:
+        ops.TILE_OVERRIDE = 9
+        one = ops.conv2d_bwd_weight(dyd, xd, 7, 7, pad=3, x_exact_bf16=True)
+        again = ops.conv2d_bwd_weight(dyd, xd, 7, 7, pad=3, x_exact_bf16=True)
+        three = ops.conv2d_bwd_weight(dyd, xd, 7, 7, pad=3)
+        ops.TILE_OVERRIDE = 6
+        fp32 = ops.conv2d_bwd_weight(dyd, xd, 7, 7, pad=3)
+        ops.TILE_OVERRIDE = 0
+        default = ops.conv2d_bwd_weight(dyd, xd, 7, 7, pad=3, x_exact_bf16=True)
+    finally:
+        ops.TILE_OVERRIDE = 0
+    scale = float(ref.abs().max())
+    e1, e3, e32 = (float((t.double().cpu() - ref).abs().max()) / scale for t in (one, three, fp32))
+    assert e1 <= 5e-6 and e1 <= 2.0 * e32 + 1e-6 and e1 <= 2.0 * e3 + 1e-6, (e1, e3, e32)
+    assert torch.equal(one, again)
+    assert float((default.double().cpu() - ref).abs().max()) <= 5e-6 * scale
+    bad = xd.clone()
+    bad[N // 2, Cin // 2, 17, 23] = 1.0 + 2.0 ** -12  # not a bf16 value
+    try:
+        ops.TILE_OVERRIDE = 9
+        broken = ops.conv2d_bwd_weight(dyd, bad, 7, 7, pad=3, x_exact_bf16=True)
+        honest = ops.conv2d_bwd_weight(dyd, bad, 7, 7, pad=3)
+    finally:
+        ops.TILE_OVERRIDE = 0
+    assert bool(torch.isnan(broken).any()) and not bool(torch.isnan(honest).any())
+
+
 def test_conv2d_split_bf16_refuses_what_it_is_not_built_for():
     from ivln_ce_amd import ops
     from ivln_ce_amd._lib import IvlnError

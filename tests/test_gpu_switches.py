@@ -58,6 +58,7 @@ CASES = [
     ("IVLN_PRED_DEPTH_START", "layer1", GRAPH_PRED),      # ... behind RedNet's layer 1
     ("IVLN_MAPPER_PREFIX", "0", GRAPH_PRED),              # the whole mapper behind RedNet (no label-free half beside it)
     ("IVLN_PRED_DEPTH", "chain", GRAPH_PRED),             # the depth encoder beside RedNet as the launch-saving chain
+    ("IVLN_WGRAD_EXACT_X", "0", UPDATE),                  # the one-hot first layer's weight gradient stages x as three pieces
     ("IVLN_SEQ_PERSISTENT", "0", UPDATE),                 # per-timestep GRU launches
     ("IVLN_CONV_STATS", "0", UPDATE),                     # BatchNorm statistics from a pass over the conv's output
     ("IVLN_EAGER_WORK_STREAM", "0", UPDATE),              # eager updates on the current stream
