@@ -215,7 +215,7 @@ typedef struct ivln_gemm_desc {
      * arithmetic (k_wgrad_bf3: both operands are activations, split while they are staged - nothing to pre-arrange);
      * tile_override 9 insists on it.  2: ... and the caller PROMISES that every value of B (the conv's input x) is exact in
      * bf16 - the map CNN's first layer reads one-hot map features (map_encoder.py:60-75) -: x is staged as one piece, half the
-     * LDS, two workgroups per CU (32-channel layers on 64-wide maps; elsewhere the promise is not used).  A value that is
+     * LDS, three workgroups per CU (32-channel layers on 64-wide maps; elsewhere the promise is not used).  A value that is
      * not exact turns the whole gradient into NaNs rather than into a wrong number. */
     int split_ok;
     /* optional (D_NCHW destinations, splits forced to 1): one int32 per image of the destination (N / HoWo of them); an

@@ -1585,8 +1585,8 @@ int launch_bf3_s2(const ivln_gemm_desc& d, hipStream_t s, const unsigned char* a
 // ------------------------------------------------------------------------------------------------------------------
 // XE (ivln_gemm_desc.split_ok == 2: the caller's promise that every x value is exact in bf16 - the first layer's one-hot map
 // features): x is staged as ONE piece (its upper 16 bits; a value with lower bits set poisons the result with NaNs), the three
-// products against its lower pieces do not exist, the x region is a third (47 KB of LDS with dy instead of 90: two workgroups per
-// CU hide each other's strip loads and barriers) and the kernel fits three waves per SIMD.
+// products against its lower pieces do not exist, the x region is a third (43 KB of LDS with dy for a 32 x 256 tile: three
+// workgroups per CU hide each other's strip loads and barriers) and the kernel fits three waves per SIMD.
 template <int TM, int WM, int WN, int W, bool XE = false>
 __global__ __launch_bounds__(64 * WM * WN, XE ? 3 : 1) void k_wgrad_bf3(const ivln_gemm_desc p, int nimg, int strips_total, int strips_per_split) {
     constexpr int NTB = 64 * WM * WN, TN = 2, KS = 7, KK = 49;
@@ -2321,18 +2321,19 @@ int ivln_wgrad_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
     //  512 left 33 % idle)
     constexpr int l1_env = 0;  // tuning: 6 | 8
     const bool six = d.M <= 32 && (l1_env ? l1_env == 6 : (d.N + 383) / 384 * 384 < (d.N + 511) / 512 * 512);
-    const int BM = d.M <= 32 ? 32 : (d.M <= 64 ? 64 : 128), BN = d.M <= 32 ? (six ? 384 : 512) : (d.M <= 64 ? 512 : 256);
+    // x promised exact in bf16 (split_ok = 2): the one-piece form, as 32 x 256 tiles of four waves - 43 KB of LDS, 3 workgroups per CU
+    // (9.09 against 9.02 ms per update with 32 x 384 tiles of six waves, two per CU; 9.44 with the three-piece form)
+    const bool xe = d.split_ok == 2 && d.M <= 32 && d.Wout == 64;
+    const int BM = d.M <= 32 ? 32 : (d.M <= 64 ? 64 : 128), BN = xe ? 256 : (d.M <= 32 ? (six ? 384 : 512) : (d.M <= 64 ? 512 : 256));
     const int64_t blocks = (int64_t)((d.N + BN - 1) / BN) * ((d.M + BM - 1) / BM);
     if (!d.ws || d.ws_floats < (int64_t)d.M * d.N) return IVLN_E_UNSUPPORTED;  // (the kernel always leaves raw slabs)
-    const bool xe = d.split_ok == 2 && d.M <= 32 && d.Wout == 64;  // x promised exact in bf16 (split_ok = 2): the one-piece form
     int splits = 1;
     if (d.splits == 0) {
         if (d.ws) {
             constexpr int want_env = 0;  // tuning
             // one workgroup per CU (LDS): as many splits as keep the grid inside whole rounds of 256 (13 column tiles x 20
             // splits = 260 workgroups ran a second round for four of them)
-            // (XE: 47 KB of LDS and three waves per SIMD - two workgroups per CU)
-            const int64_t want = want_env > 0 ? want_env : (xe ? 2 : 1) * (int64_t)ivln_cu_count();
+            const int64_t want = want_env > 0 ? want_env : (xe ? 3 : 1) * (int64_t)ivln_cu_count();
             splits = (int)(want / blocks);
             if (splits < 1) splits = 1;
             if (splits > strips) splits = strips;
@@ -2349,8 +2350,9 @@ int ivln_wgrad_bf3_launch(ivln_gemm_desc& d, hipStream_t s, bool force) {
     splits = (strips + sps - 1) / sps;
     d.splits = splits;
     int rc;
-    if (d.M <= 32 && six) rc = xe ? launch_wgrad_bf3<1, 1, 6, 64, true>(d, s, nimg, strips, sps) : launch_wgrad_bf3_w<1, 1, 6>(d, s, nimg, strips, sps);
-    else if (d.M <= 32) rc = xe ? launch_wgrad_bf3<1, 1, 8, 64, true>(d, s, nimg, strips, sps) : launch_wgrad_bf3_w<1, 1, 8>(d, s, nimg, strips, sps);
+    if (xe) rc = launch_wgrad_bf3<1, 1, 4, 64, true>(d, s, nimg, strips, sps);
+    else if (d.M <= 32 && six) rc = launch_wgrad_bf3_w<1, 1, 6>(d, s, nimg, strips, sps);
+    else if (d.M <= 32) rc = launch_wgrad_bf3_w<1, 1, 8>(d, s, nimg, strips, sps);
     else if (d.M <= 64) rc = launch_wgrad_bf3_w<2, 1, 8>(d, s, nimg, strips, sps);
     else rc = launch_wgrad_bf3_w<2, 2, 4>(d, s, nimg, strips, sps);
     if (rc == IVLN_OK) g_bf3_flops += 2.0 * d.M * (double)d.N * d.K, ++g_bf3_launches;
