@@ -54,3 +54,34 @@ def same_depth_path():
 
     yield pin
     ops.DEPTH_NET = old
+
+
+_RENDEZVOUS_NOISE = ("address already in use", "EADDRINUSE", "RendezvousConnectionError", "DistNetworkError", "Connection reset",
+                     "Connection refused", "Socket Timeout", "connect() timed out", "Broken pipe")
+
+
+def free_port():
+    """A TCP port that is free on 127.0.0.1 right now."""
+    import socket
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def run_torchrun(nproc, script, args=(), env=None, timeout=900):
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node nproc script args` on a port that is free NOW (a fixed port
+    collides with a socket another process on the box still holds - seen once in ~40 runs of the two-rank tests), started
+    once more, on another port, when the ranks died of the rendezvous itself; a failure of the test's own assertions is
+    returned as it is.  -> subprocess.CompletedProcess"""
+    import subprocess
+
+    r = None
+    for attempt in range(2):
+        port = free_port()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), script, *[str(a) for a in args]]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+        if r.returncode == 0 or not any(m in (r.stderr + r.stdout) for m in _RENDEZVOUS_NOISE):
+            break
+    return r

@@ -6,6 +6,7 @@ import sys
 
 import torch
 import torch.multiprocessing as mp
+from conftest import free_port
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -32,7 +33,8 @@ def _worker(rank, world, port, q):
 def test_gloo_world2_allreduce_and_sharding():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ps = [ctx.Process(target=_worker, args=(r, 2, 29731, q)) for r in range(2)]
+    port = free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in ps:
         p.start()
     out = sorted(q.get(timeout=120) for _ in range(2))
@@ -71,7 +73,8 @@ def _worker_min(rank, world, port, q):
 def test_collectives_refuse_to_run_ungrouped_and_min_reduce():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ps = [ctx.Process(target=_worker_min, args=(r, 2, 29741, q)) for r in range(2)]
+    port = free_port()
+    ps = [ctx.Process(target=_worker_min, args=(r, 2, port, q)) for r in range(2)]
     for p in ps:
         p.start()
     out = sorted(q.get(timeout=120) for _ in range(2))
@@ -173,7 +176,8 @@ def test_gloo_world8_sharding_min_batches_and_rank0_tour_ndtw():
     world = 8
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ps = [ctx.Process(target=_worker8, args=(r, world, 29751, q)) for r in range(world)]
+    port = free_port()
+    ps = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
     for p in ps:
         p.start()
     outs = sorted((q.get(timeout=300) for _ in range(world)), key=lambda o: o["rank"])

@@ -405,14 +405,11 @@ def test_update_with_host_trimmed_instruction_padding_is_the_same_update():
 def _run_two_ranks_one_gpu(tmp_path, port, *args):
     """Two ranks sharing cuda:0 over gloo (RCCL refuses two ranks per device): control flow of the multi-rank
     paths - env sharding, FlatAdam's all-reduce, rank-0 gather - on the 1-GPU box.  Never a measurement."""
-    import subprocess
-    import sys
+    from conftest import run_torchrun
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, IVLN_DIST_BACKEND="gloo", IVLN_ONE_DEVICE="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(root, "tools", "dist_smoke.py"), str(tmp_path), *args]
-    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    return run_torchrun(2, os.path.join(root, "tools", "dist_smoke.py"), (str(tmp_path), *args), env=env)  # (`port`: historical)
 
 
 @pytest.mark.gpu
@@ -939,11 +936,9 @@ def test_two_rank_update_equals_single_process_accumulation(tmp_path):
     all-reduced update == one process accumulating both shards' gradients and stepping with 1/2 folded into Adam."""
     env = dict(os.environ, IVLN_DIST_BACKEND="gloo", IVLN_ONE_DEVICE="1")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29571", os.path.join(root, "tools", "dp_equiv.py")]
-    import subprocess
+    from conftest import run_torchrun
 
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    r = run_torchrun(2, os.path.join(root, "tools", "dp_equiv.py"), env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "dist smoke ok: dp_equiv world 2" in r.stdout
     print(r.stdout[-600:])
